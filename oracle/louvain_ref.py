@@ -1,0 +1,187 @@
+"""TEST INFRASTRUCTURE -- pure-Python specification of the build's deterministic Louvain.
+
+Why this exists: the reference delegates community detection to third-party native code that is
+absent from /root/reference and from this image -- PhenoGraph's bundled Louvain executables
+(Blondel, Guillaume, Lambiotte, Lefebvre 2008; reached from dd.py:320-322) and Traag's
+``louvain`` / ``leidenalg`` C++ (reached through scanpy from dd.py:337-342).  No version is pinned
+(pyproject.toml:27-35,47-48 give lower bounds only), PhenoGraph seeds from time/pid, and the
+reference's tests pin no clustering output.  **Parity with upstream clustering is therefore
+unpinned.**  What *is* pinned is this specification: the product's host C++ implementation
+(``doubletdetection_amd/csrc/louvain.cpp``) must reproduce it bit-for-bit (same visiting order,
+same float64 operation order, no FMA contraction), which ``tests/test_louvain.py`` checks.
+
+Algorithm (the published multi-level modularity optimisation with a resolution parameter):
+
+* quality  Q = sum_c [ in_c / 2m  -  gamma * (tot_c / 2m)^2 ]   (RB-configuration form; gamma=1 is
+  Newman-Girvan modularity as in PhenoGraph, gamma=4 is what dd.py:417-420 passes to scanpy);
+* one level: visit nodes in a seeded random order (splitmix64 Fisher-Yates, one stream for all
+  levels); take the node out of its community; evaluate gain(c) = w(v,c) - gamma*tot_c*k_v/2m for
+  its own community first and then each neighbouring community in adjacency order; move to the
+  strictly best; repeat passes while nodes moved and the pass improved Q by more than 1e-6 (the
+  Blondel executable's default epsilon);
+* aggregate communities into super-nodes (self-loop = total internal weight, both directions),
+  repeat until a level moves nothing.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+_MASK = 0xFFFFFFFFFFFFFFFF
+MIN_GAIN = 1e-6
+
+
+class SplitMix64:
+    def __init__(self, seed: int):
+        self.state = int(seed) & _MASK
+
+    def next(self) -> int:
+        self.state = (self.state + 0x9E3779B97F4A7C15) & _MASK
+        z = self.state
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _MASK
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _MASK
+        return z ^ (z >> 31)
+
+
+def _shuffled(n: int, rng: SplitMix64):
+    order = list(range(n))
+    for i in range(n - 1, 0, -1):
+        j = rng.next() % (i + 1)
+        order[i], order[j] = order[j], order[i]
+    return order
+
+
+def _quality(in_, tot, m2, gamma):
+    q = 0.0
+    for c in range(len(tot)):
+        if tot[c] > 0.0:
+            b = tot[c] / m2
+            q += in_[c] / m2 - gamma * b * b
+    return q
+
+
+def _one_level(indptr, indices, weights, gamma, rng):
+    """Returns (comm list, moved_any)."""
+    n = len(indptr) - 1
+    deg = [0.0] * n
+    loops = [0.0] * n
+    for v in range(n):
+        s = 0.0
+        for e in range(indptr[v], indptr[v + 1]):
+            s += weights[e]
+            if indices[e] == v:
+                loops[v] += weights[e]
+        deg[v] = s
+    m2 = 0.0
+    for v in range(n):
+        m2 += deg[v]
+    comm = list(range(n))
+    if m2 == 0.0:
+        return comm, False
+    tot = deg[:]
+    in_ = loops[:]
+    order = _shuffled(n, rng)
+    neigh_w = [-1.0] * n
+    improved = False
+    new_q = _quality(in_, tot, m2, gamma)
+    while True:
+        cur_q = new_q
+        moves = 0
+        for v in order:
+            c_old = comm[v]
+            kv = deg[v]
+            seen = [c_old]
+            neigh_w[c_old] = 0.0
+            for e in range(indptr[v], indptr[v + 1]):
+                u = indices[e]
+                if u == v:
+                    continue
+                c = comm[u]
+                if neigh_w[c] == -1.0:
+                    neigh_w[c] = 0.0
+                    seen.append(c)
+                neigh_w[c] += weights[e]
+            # take v out of its community
+            tot[c_old] -= kv
+            in_[c_old] -= 2.0 * neigh_w[c_old] + loops[v]
+            best = c_old
+            best_gain = neigh_w[c_old] - gamma * tot[c_old] * kv / m2
+            for c in seen[1:]:
+                g = neigh_w[c] - gamma * tot[c] * kv / m2
+                if g > best_gain:
+                    best_gain = g
+                    best = c
+            tot[best] += kv
+            in_[best] += 2.0 * neigh_w[best] + loops[v]
+            comm[v] = best
+            if best != c_old:
+                moves += 1
+            for c in seen:
+                neigh_w[c] = -1.0
+        new_q = _quality(in_, tot, m2, gamma)
+        if moves > 0:
+            improved = True
+        if not (moves > 0 and new_q - cur_q > MIN_GAIN):
+            break
+    return comm, improved
+
+
+def _aggregate(indptr, indices, weights, comm):
+    """Super-node graph; communities renumbered by ascending id. Returns (indptr, indices, weights, renum)."""
+    n = len(indptr) - 1
+    used = sorted(set(comm))
+    renum = {c: i for i, c in enumerate(used)}
+    members = [[] for _ in used]
+    for v in range(n):
+        members[renum[comm[v]]].append(v)
+    new_indptr = [0]
+    new_indices = []
+    new_weights = []
+    for cn, mem in enumerate(members):
+        acc = {}
+        for v in mem:
+            for e in range(indptr[v], indptr[v + 1]):
+                t = renum[comm[indices[e]]]
+                if t in acc:
+                    acc[t] += weights[e]
+                else:
+                    acc[t] = weights[e]
+        for t in sorted(acc):
+            new_indices.append(t)
+            new_weights.append(acc[t])
+        new_indptr.append(len(new_indices))
+    return new_indptr, new_indices, new_weights, renum
+
+
+def louvain(indptr, indices, weights, gamma: float = 1.0, seed: int = 0) -> np.ndarray:
+    """Community label per node (0..K-1, numbered by ascending representative id)."""
+    indptr = [int(x) for x in np.asarray(indptr)]
+    indices = [int(x) for x in np.asarray(indices)]
+    weights = [float(x) for x in np.asarray(weights, dtype=np.float64)]
+    n = len(indptr) - 1
+    rng = SplitMix64(seed)
+    membership = list(range(n))
+    gamma = float(gamma)
+    while True:
+        comm, improved = _one_level(indptr, indices, weights, gamma, rng)
+        indptr, indices, weights, renum = _aggregate(indptr, indices, weights, comm)
+        membership = [renum[comm[c]] for c in membership]
+        if not improved:
+            break
+    return np.asarray(membership, dtype=np.int64)
+
+
+def modularity(indptr, indices, weights, labels, gamma: float = 1.0) -> float:
+    """Q of a labelling on a symmetric CSR graph (diagnostic)."""
+    indptr = np.asarray(indptr)
+    indices = np.asarray(indices)
+    weights = np.asarray(weights, dtype=np.float64)
+    labels = np.asarray(labels)
+    n = len(indptr) - 1
+    deg = np.add.reduceat(np.concatenate([weights, [0.0]]), indptr[:-1]) * (np.diff(indptr) > 0)
+    m2 = deg.sum()
+    rows = np.repeat(np.arange(n), np.diff(indptr))
+    same = labels[rows] == labels[indices]
+    k = labels.max() + 1
+    in_c = np.bincount(labels[rows][same], weights=weights[same], minlength=k)
+    tot_c = np.bincount(labels, weights=deg, minlength=k)
+    return float((in_c / m2 - gamma * (tot_c / m2) ** 2).sum())
