@@ -1,0 +1,352 @@
+"""ctypes binding of libddx.so (include/ddx.h).  No torch, no numpy C-API: plain pointers and sizes.
+
+The library is required: there is no CPU fallback.  ``load()`` raises if it is missing; creating a
+``Context`` raises if no gfx950 GPU is visible.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libddx.so")
+ABI_VERSION = 1
+
+_lib = None
+
+c_i64_p = C.POINTER(C.c_int64)
+c_i32_p = C.POINTER(C.c_int32)
+c_f32_p = C.POINTER(C.c_float)
+c_f64_p = C.POINTER(C.c_double)
+
+
+class DdxError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"libddx error {code}: {message}")
+        self.code = code
+
+
+_SIGNATURES = {
+    "ddx_abi_version": (C.c_int, []),
+    "ddx_last_error": (C.c_char_p, [C.c_void_p]),
+    "ddx_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "ddx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "ddx_destroy": (C.c_int, [C.c_void_p]),
+    "ddx_synchronize": (C.c_int, [C.c_void_p]),
+    "ddx_device_bytes": (C.c_int, [C.c_void_p, c_i64_p]),
+    "ddx_upload_raw": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, c_i64_p, c_i32_p, c_f32_p]),
+    "ddx_gene_variances": (C.c_int, [C.c_void_p, c_f32_p]),
+    "ddx_select_columns": (C.c_int, [C.c_void_p, c_i64_p, C.c_int32]),
+    "ddx_upload_counts": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, c_i64_p, c_i32_p, c_f32_p]),
+    "ddx_get_counts_nnz": (C.c_int, [C.c_void_p, c_i64_p]),
+    "ddx_get_counts": (C.c_int, [C.c_void_p, c_i64_p, c_i32_p, c_f32_p]),
+    "ddx_get_lib_size": (C.c_int, [C.c_void_p, c_f32_p]),
+    "ddx_get_normed": (C.c_int, [C.c_void_p, c_f32_p]),
+    "ddx_create_doublets": (C.c_int, [C.c_void_p, C.c_int64, c_i64_p]),
+    "ddx_get_synth_nnz": (C.c_int, [C.c_void_p, c_i64_p]),
+    "ddx_get_synth": (C.c_int, [C.c_void_p, c_i64_p, c_i32_p, c_f32_p]),
+    "ddx_lognormalise": (C.c_int, [C.c_void_p, C.c_float]),
+    "ddx_get_aug_lib": (C.c_int, [C.c_void_p, c_f32_p, c_f32_p]),
+    "ddx_get_aug_nnz": (C.c_int, [C.c_void_p, c_i64_p]),
+    "ddx_get_aug_values": (C.c_int, [C.c_void_p, c_f32_p, c_f32_p]),
+    "ddx_get_aug_dense_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, c_f32_p]),
+    "ddx_scale": (C.c_int, [C.c_void_p, C.c_float]),
+    "ddx_pca": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, c_f64_p, C.c_int64]),
+    "ddx_get_embedding": (C.c_int, [C.c_void_p, c_f32_p]),
+    "ddx_get_embedding_f64": (C.c_int, [C.c_void_p, c_f64_p, c_f64_p]),
+    "ddx_set_embedding": (C.c_int, [C.c_void_p, c_f32_p, C.c_int64, C.c_int32]),
+    "ddx_knn": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    "ddx_get_knn": (C.c_int, [C.c_void_p, c_i32_p, c_f64_p]),
+    "ddx_build_graph": (C.c_int, [C.c_void_p, C.c_int32]),
+    "ddx_get_graph_size": (C.c_int, [C.c_void_p, c_i64_p, c_i64_p]),
+    "ddx_get_graph": (C.c_int, [C.c_void_p, c_i64_p, c_i32_p, c_f64_p]),
+    "ddx_louvain": (C.c_int, [C.c_int64, c_i64_p, c_i32_p, c_f64_p, C.c_double, C.c_uint64, c_i32_p, c_f64_p]),
+    "ddx_relabel_by_size": (C.c_int, [C.c_int64, c_i32_p, C.c_int64, c_i64_p]),
+    "ddx_hypergeom_logsf": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int64, c_f64_p]),
+    "ddx_score_communities": (C.c_int, [c_i64_p, C.c_int64, C.c_int64, c_f64_p, c_f64_p]),
+    "ddx_timing_enable": (C.c_int, [C.c_void_p, C.c_int32]),
+    "ddx_timing_reset": (C.c_int, [C.c_void_p]),
+    "ddx_timing_count": (C.c_int, [C.c_void_p, c_i32_p]),
+    "ddx_timing_get": (C.c_int, [C.c_void_p, C.c_int32, C.c_char_p, c_i64_p, c_f64_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(sorted(_SIGNATURES))
+
+
+def load():
+    """dlopen libddx.so and declare every prototype of include/ddx.h.  Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m doubletdetection_amd._build` "
+            "(there is no CPU fallback for the HIP path)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.ddx_abi_version() != ABI_VERSION:
+        raise ImportError(f"libddx ABI {lib.ddx_abi_version()} != binding ABI {ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def _p(arr, ptype):
+    return arr.ctypes.data_as(ptype)
+
+
+def _check(rc, ctx=None):
+    if rc != 0:
+        msg = load().ddx_last_error(ctx)
+        raise DdxError(rc, msg.decode() if msg else "unknown")
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    rc = load().ddx_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+# ---- context-free host routines --------------------------------------------------------------
+def louvain(indptr, indices, weights, gamma: float, seed: int):
+    """Deterministic Louvain of libddx (host C++).  Returns (labels int32[n], quality)."""
+    lib = load()
+    indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+    indices = np.ascontiguousarray(indices, dtype=np.int32)
+    weights = np.ascontiguousarray(weights, dtype=np.float64)
+    n = indptr.shape[0] - 1
+    labels = np.empty(n, dtype=np.int32)
+    q = C.c_double(0.0)
+    _check(lib.ddx_louvain(n, _p(indptr, c_i64_p), _p(indices, c_i32_p), _p(weights, c_f64_p), float(gamma),
+                           int(seed) & 0xFFFFFFFFFFFFFFFF, _p(labels, c_i32_p), C.byref(q)))
+    return labels, q.value
+
+
+def relabel_by_size(labels, min_cluster_size=None):
+    lib = load()
+    labels = np.ascontiguousarray(labels, dtype=np.int32)
+    out = np.empty(labels.shape[0], dtype=np.int64)
+    mcs = -1 if min_cluster_size is None else int(min_cluster_size)
+    _check(lib.ddx_relabel_by_size(labels.shape[0], _p(labels, c_i32_p), mcs, _p(out, c_i64_p)))
+    return out
+
+
+def hypergeom_logsf(k, M, n, N) -> float:
+    out = C.c_double(0.0)
+    _check(load().ddx_hypergeom_logsf(int(k), int(M), int(n), int(N), C.byref(out)))
+    return out.value
+
+
+def score_communities(full, num_cells: int):
+    lib = load()
+    full = np.ascontiguousarray(full, dtype=np.int64)
+    scores = np.empty(num_cells, dtype=np.float64)
+    logp = np.empty(num_cells, dtype=np.float64)
+    _check(lib.ddx_score_communities(_p(full, c_i64_p), full.shape[0], int(num_cells), _p(scores, c_f64_p),
+                                     _p(logp, c_f64_p)))
+    return scores, logp
+
+
+# ---- device context ----------------------------------------------------------------------------
+class Context:
+    """One GPU, one stream, all device buffers of a fit (ddx_ctx)."""
+
+    def __init__(self, device: int = 0):
+        self._lib = load()
+        self._h = C.c_void_p(None)
+        _check(self._lib.ddx_create(int(device), C.byref(self._h)))
+        self.device = device
+        self.N = self.H = self.S = 0
+
+    def close(self):
+        if self._h:
+            self._lib.ddx_destroy(self._h)
+            self._h = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _c(self, rc):
+        _check(rc, self._h)
+
+    @property
+    def M(self):
+        return self.N + self.S
+
+    def synchronize(self):
+        self._c(self._lib.ddx_synchronize(self._h))
+
+    def device_bytes(self) -> int:
+        v = C.c_int64(0)
+        self._c(self._lib.ddx_device_bytes(self._h, C.byref(v)))
+        return v.value
+
+    # prologue
+    def upload_raw(self, csr):
+        ip = np.ascontiguousarray(csr.indptr, dtype=np.int64)
+        ix = np.ascontiguousarray(csr.indices, dtype=np.int32)
+        d = np.ascontiguousarray(csr.data, dtype=np.float32)
+        self._c(self._lib.ddx_upload_raw(self._h, csr.shape[0], csr.shape[1], _p(ip, c_i64_p), _p(ix, c_i32_p), _p(d, c_f32_p)))
+        self._rawG = csr.shape[1]
+        self._rawN = csr.shape[0]
+
+    def gene_variances(self):
+        out = np.empty(self._rawG, dtype=np.float32)
+        self._c(self._lib.ddx_gene_variances(self._h, _p(out, c_f32_p)))
+        return out
+
+    def select_columns(self, cols):
+        cols = np.ascontiguousarray(cols, dtype=np.int64)
+        self._c(self._lib.ddx_select_columns(self._h, _p(cols, c_i64_p), cols.shape[0]))
+        self.N, self.H, self.S = self._rawN, int(cols.shape[0]), 0
+
+    def upload_counts(self, csr):
+        ip = np.ascontiguousarray(csr.indptr, dtype=np.int64)
+        ix = np.ascontiguousarray(csr.indices, dtype=np.int32)
+        d = np.ascontiguousarray(csr.data, dtype=np.float32)
+        self._c(self._lib.ddx_upload_counts(self._h, csr.shape[0], csr.shape[1], _p(ip, c_i64_p), _p(ix, c_i32_p), _p(d, c_f32_p)))
+        self.N, self.H, self.S = int(csr.shape[0]), int(csr.shape[1]), 0
+
+    def get_counts(self):
+        import scipy.sparse as sp
+
+        nnz = C.c_int64(0)
+        self._c(self._lib.ddx_get_counts_nnz(self._h, C.byref(nnz)))
+        ip = np.empty(self.N + 1, dtype=np.int64)
+        ix = np.empty(nnz.value, dtype=np.int32)
+        d = np.empty(nnz.value, dtype=np.float32)
+        self._c(self._lib.ddx_get_counts(self._h, _p(ip, c_i64_p), _p(ix, c_i32_p), _p(d, c_f32_p)))
+        return sp.csr_matrix((d, ix, ip), shape=(self.N, self.H))
+
+    def lib_size(self):
+        out = np.empty(self.N, dtype=np.float32)
+        self._c(self._lib.ddx_get_lib_size(self._h, _p(out, c_f32_p)))
+        return out
+
+    def normed(self):
+        nnz = C.c_int64(0)
+        self._c(self._lib.ddx_get_counts_nnz(self._h, C.byref(nnz)))
+        out = np.empty(nnz.value, dtype=np.float32)
+        self._c(self._lib.ddx_get_normed(self._h, _p(out, c_f32_p)))
+        return out
+
+    # doublets
+    def create_doublets(self, parents):
+        parents = np.ascontiguousarray(parents, dtype=np.int64)
+        assert parents.ndim == 2 and parents.shape[1] == 2
+        self._c(self._lib.ddx_create_doublets(self._h, parents.shape[0], _p(parents, c_i64_p)))
+        self.S = int(parents.shape[0])
+
+    def get_synth(self):
+        import scipy.sparse as sp
+
+        nnz = C.c_int64(0)
+        self._c(self._lib.ddx_get_synth_nnz(self._h, C.byref(nnz)))
+        ip = np.empty(self.S + 1, dtype=np.int64)
+        ix = np.empty(nnz.value, dtype=np.int32)
+        d = np.empty(nnz.value, dtype=np.float32)
+        self._c(self._lib.ddx_get_synth(self._h, _p(ip, c_i64_p), _p(ix, c_i32_p), _p(d, c_f32_p)))
+        return sp.csr_matrix((d, ix, ip), shape=(self.S, self.H))
+
+    # normalisation
+    def lognormalise(self, pseudocount: float):
+        self._c(self._lib.ddx_lognormalise(self._h, float(pseudocount)))
+
+    def aug_lib(self):
+        out = np.empty(self.M, dtype=np.float32)
+        med = C.c_float(0.0)
+        self._c(self._lib.ddx_get_aug_lib(self._h, _p(out, c_f32_p), C.byref(med)))
+        return out, np.float32(med.value)
+
+    def aug_values(self):
+        nnz = C.c_int64(0)
+        self._c(self._lib.ddx_get_aug_nnz(self._h, C.byref(nnz)))
+        v = np.empty(nnz.value, dtype=np.float32)
+        z = np.empty(self.H, dtype=np.float32)
+        self._c(self._lib.ddx_get_aug_values(self._h, _p(v, c_f32_p), _p(z, c_f32_p)))
+        return v, z
+
+    def aug_dense_rows(self, row0: int, nrows: int):
+        out = np.empty((nrows, self.H), dtype=np.float32)
+        self._c(self._lib.ddx_get_aug_dense_rows(self._h, int(row0), int(nrows), _p(out, c_f32_p)))
+        return out
+
+    def scale(self, max_value: float):
+        self._c(self._lib.ddx_scale(self._h, float(max_value if max_value is not None else 0.0)))
+
+    # PCA
+    def pca(self, n_components: int, q0, n_oversamples: int = 10, n_iter: int = -1):
+        q0 = np.ascontiguousarray(q0, dtype=np.float64)
+        self._c(self._lib.ddx_pca(self._h, int(n_components), int(n_oversamples), int(n_iter), _p(q0, c_f64_p), q0.shape[0]))
+        self._C = int(n_components)
+        self._embM = self.M
+
+    def embedding(self):
+        out = np.empty((self._embM, self._C), dtype=np.float32)
+        self._c(self._lib.ddx_get_embedding(self._h, _p(out, c_f32_p)))
+        return out
+
+    def embedding_f64(self):
+        out = np.empty((self._embM, self._C), dtype=np.float64)
+        s = np.empty(self._C, dtype=np.float64)
+        self._c(self._lib.ddx_get_embedding_f64(self._h, _p(out, c_f64_p), _p(s, c_f64_p)))
+        return out, s
+
+    def set_embedding(self, emb):
+        emb = np.ascontiguousarray(emb, dtype=np.float32)
+        self._c(self._lib.ddx_set_embedding(self._h, _p(emb, c_f32_p), emb.shape[0], emb.shape[1]))
+        self._embM, self._C = int(emb.shape[0]), int(emb.shape[1])
+
+    # kNN / graph
+    def knn(self, k: int, include_self: bool):
+        self._c(self._lib.ddx_knn(self._h, int(k), 1 if include_self else 0))
+        self._K = int(k)
+
+    def get_knn(self, with_dist: bool = True):
+        idx = np.empty((self._embM, self._K), dtype=np.int32)
+        dist = np.empty((self._embM, self._K), dtype=np.float64) if with_dist else None
+        self._c(self._lib.ddx_get_knn(self._h, _p(idx, c_i32_p), _p(dist, c_f64_p) if with_dist else None))
+        return idx, dist
+
+    def build_graph(self, mode: int):
+        self._c(self._lib.ddx_build_graph(self._h, int(mode)))
+        n = C.c_int64(0)
+        e = C.c_int64(0)
+        self._c(self._lib.ddx_get_graph_size(self._h, C.byref(n), C.byref(e)))
+        ip = np.empty(n.value + 1, dtype=np.int64)
+        ix = np.empty(e.value, dtype=np.int32)
+        w = np.empty(e.value, dtype=np.float64)
+        self._c(self._lib.ddx_get_graph(self._h, _p(ip, c_i64_p), _p(ix, c_i32_p), _p(w, c_f64_p)))
+        return ip, ix, w
+
+    # timing
+    def timing_enable(self, on: bool = True):
+        self._c(self._lib.ddx_timing_enable(self._h, 1 if on else 0))
+
+    def timing_reset(self):
+        self._c(self._lib.ddx_timing_reset(self._h))
+
+    def timings(self):
+        n = C.c_int32(0)
+        self._c(self._lib.ddx_timing_count(self._h, C.byref(n)))
+        out = {}
+        buf = C.create_string_buffer(64)
+        for i in range(n.value):
+            launches = C.c_int64(0)
+            ms = C.c_double(0.0)
+            self._c(self._lib.ddx_timing_get(self._h, i, buf, C.byref(launches), C.byref(ms)))
+            out[buf.value.decode()] = (launches.value, ms.value)
+        return out

@@ -1,0 +1,400 @@
+"""BoostClassifier -- MI355X-native drop-in for DoubletDetection's classifier.
+
+Mirrors the public surface of the reference class (constructor signature and defaults
+``doubletdetection/doubletdetection.py:73-88``, ``fit`` ``:135``, ``predict`` ``:216``,
+``doublet_score`` ``:256``, fitted attributes ``:54-71``), so code written against the reference runs
+unchanged.  The boosting loop itself (``:192-198`` -> ``_one_fit`` ``:274-383`` ->
+``_createDoublets`` ``:385-402``) does not run through numpy / scipy / scanpy / phenograph: every
+iteration is executed by hand-written HIP kernels for gfx950 behind the C-ABI in ``include/ddx.h``.
+
+Division of labour (host keeps only what SURVEY.md section 3.5 assigns to it):
+
+* host (this file): argument validation, warnings, the numpy ``Generator`` parent draws and the
+  legacy ``RandomState`` PCA start matrix (so both random streams are the reference's, bit for bit),
+  the one-off HVG ``argsort``, orchestration, ``predict`` / ``doublet_score`` post-processing;
+* device (libddx.so): resident counts, synthetic doublets, log-normalisation, optional scaling,
+  randomized PCA, exact kNN, Jaccard / neighbour graphs;
+* host C++ inside libddx.so: deterministic Louvain and the hypergeometric scoring, run on worker
+  threads so they overlap with the next iteration's GPU work.
+
+Multi-GPU: one process per GPU (``torch.distributed``; RCCL when the backend is ``nccl``).  Boosting
+iterations are independent given the pre-drawn parent indices, so iteration ``i`` runs on rank
+``i % world_size`` and a single all-gather of the per-iteration result rows assembles the fitted
+attributes on every rank.
+"""
+from __future__ import annotations
+
+import os
+import warnings
+from collections.abc import Callable
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import scipy.sparse as sp_sparse
+from numpy.typing import NDArray
+
+from . import _lib
+
+__all__ = ["BoostClassifier"]
+
+_ALGORITHMS = ("louvain", "phenograph", "leiden")
+
+# keyword arguments of the upstream clustering entry points that are understood here; anything else
+# raises TypeError exactly like passing an unknown keyword to the upstream function would.
+_PHENOGRAPH_KW = {"k", "prune", "min_cluster_size", "resolution_parameter", "seed", "n_jobs", "q_tol",
+                  "louvain_time_limit", "nn_method", "primary_metric", "directed", "jaccard",
+                  "clustering_algo", "n_iterations", "use_weights", "partition_type"}
+_SCANPY_KW = {"resolution", "directed", "use_weights", "partition_type", "restrict_to", "adjacency",
+              "neighbors_key", "obsp", "copy", "flavor", "n_iterations"}
+
+
+def _dist_info():
+    """(rank, world_size, backend or None) of an initialised torch.distributed job, else (0, 1, None)."""
+    try:
+        import torch.distributed as dist
+    except Exception:  # pragma: no cover - torch always present in the target image
+        return 0, 1, None
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size(), dist.get_backend()
+    return 0, 1, None
+
+
+class _HipEngine:
+    """Device side of one fit on one GPU: thin sequencing of the libddx stages."""
+
+    def __init__(self, device: int):
+        self.ctx = _lib.Context(device)
+
+    def close(self):
+        self.ctx.close()
+
+    def upload(self, csr):
+        self.ctx.upload_counts(csr)
+
+    def run_iteration(self, parents, pseudocount, standard_scaling, n_components, q0, knn_k, include_self,
+                      graph_mode):
+        c = self.ctx
+        c.create_doublets(parents)
+        c.lognormalise(pseudocount)
+        if standard_scaling:
+            c.scale(15.0)
+        c.pca(n_components, q0)
+        c.knn(knn_k, include_self)
+        return c.build_graph(graph_mode)
+
+    def timings(self):
+        return self.ctx.timings()
+
+
+class BoostClassifier:
+    """Classifier for doublets in single-cell RNA-seq data (GPU implementation).
+
+    Parameters (identical meaning and defaults to the reference, ``doubletdetection.py:25-52``):
+        boost_rate: Proportion of cell population size to produce as synthetic doublets.
+        n_components: Number of principal components used for clustering.
+        n_top_var_genes: Number of highest variance genes to use; all genes when zero.
+        replace: If False, a cell is a synthetic doublet's parent at most once.
+        clustering_algorithm: "louvain", "leiden" or "phenograph".
+        clustering_kwargs: keyword arguments of the clustering algorithm (``prune`` defaults to True
+            for phenograph; ``directed=False``, ``resolution=4`` for louvain / leiden).
+        n_iters: Number of fit operations from which to collect p-values (default 10).
+        normalizer: unsupported on the GPU path (see ``fit``); must stay ``None``.
+        pseudocount: Pseudocount used in the default log-normalisation.
+        random_state: Seeds PCA and the parent draws.
+        verbose: Print progress messages.
+        standard_scaling: Standard-scale the normalised matrix before PCA.
+        n_jobs: host worker threads for community detection (-1: all cores).
+
+    Build-only keyword (after the reference's, so positional use is unaffected):
+        device: GPU ordinal; default ``LOCAL_RANK`` under torch.distributed, else 0.
+
+    Attributes after ``fit`` / ``predict``: ``all_log_p_values_``, ``all_scores_``, ``communities_``,
+    ``labels_``, ``parents_``, ``suggested_score_cutoff_``, ``synth_communities_``, ``top_var_genes_``,
+    ``voting_average_`` -- shapes and dtypes as in the reference (``doubletdetection.py:54-71``).
+    """
+
+    _engine_factory = _HipEngine  # tests replace this to exercise host logic without a GPU
+
+    def __init__(
+        self,
+        boost_rate: float = 0.25,
+        n_components: int = 30,
+        n_top_var_genes: int = 10000,
+        replace: bool = False,
+        clustering_algorithm: str = "phenograph",
+        clustering_kwargs: dict | None = None,
+        n_iters: int = 10,
+        normalizer: Callable | None = None,
+        pseudocount: float = 0.1,
+        random_state: int = 0,
+        verbose: bool = False,
+        standard_scaling: bool = False,
+        n_jobs: int = 1,
+        *,
+        device: int | None = None,
+    ) -> None:
+        if clustering_algorithm not in _ALGORITHMS:
+            raise ValueError("Clustering algorithm needs to be one of ['louvain', 'phenograph', 'leiden']")
+        self.clustering_algorithm = clustering_algorithm
+        self.boost_rate = boost_rate
+        self.replace = replace
+        self.n_iters = n_iters
+        self.normalizer = normalizer
+        self.pseudocount = pseudocount
+        self.random_state = random_state
+        self.verbose = verbose
+        self.standard_scaling = standard_scaling
+        self.n_jobs = n_jobs
+        self.device = device
+        # one Generator for the lifetime of the object: a second fit() continues the stream, as upstream
+        self.rng = np.random.default_rng(self.random_state)
+
+        if self.clustering_algorithm == "leiden":
+            warnings.warn("Leiden clustering is experimental and results have not been validated.")
+
+        # an untouched n_components is silently capped by n_top_var_genes; negative n_top_var_genes -> 0
+        untouched = n_components == 30 and n_top_var_genes > 0
+        self.n_components = min(n_components, n_top_var_genes) if untouched else n_components
+        self.n_top_var_genes = max(0, n_top_var_genes)
+
+        self.clustering_kwargs = clustering_kwargs if isinstance(clustering_kwargs, dict) else {}
+        self._set_clustering_kwargs()
+
+        if not self.replace and self.boost_rate > 0.5:
+            warnings.warn("boost_rate is trimmed to 0.5 when replace=False."
+                          " Set replace=True to use greater boost rates.")
+            self.boost_rate = 0.5
+
+        assert self.n_top_var_genes == 0 or self.n_components <= self.n_top_var_genes, (
+            "n_components={0} cannot be larger than n_top_var_genes={1}".format(n_components, n_top_var_genes))
+
+    # ------------------------------------------------------------------------------------------
+    def _set_clustering_kwargs(self) -> None:
+        kw = self.clustering_kwargs
+        if self.clustering_algorithm == "phenograph":
+            kw.setdefault("prune", True)
+            if self.n_iters == 1 and kw.get("prune") is True:
+                warnings.warn("Using phenograph parameter prune=False is strongly recommended when "
+                              "running only one iteration. Otherwise, expect many NaN labels.")
+            unknown = set(kw) - _PHENOGRAPH_KW
+        else:
+            kw.setdefault("directed", False)
+            kw.setdefault("resolution", 4)
+            if "key_added" in kw:
+                raise ValueError("'key_added' param cannot be overriden")
+            if "random_state" in kw:
+                raise ValueError("'random_state' param cannot be overriden. Please use classifier 'random_state'.")
+            unknown = set(kw) - _SCANPY_KW
+        if unknown:
+            raise TypeError(f"unsupported clustering_kwargs for {self.clustering_algorithm}: {sorted(unknown)}")
+
+    def _cluster_plan(self):
+        """(k, include_self, graph_mode, gamma, seed, min_cluster_size) for the chosen algorithm."""
+        kw = self.clustering_kwargs
+        if self.clustering_algorithm == "phenograph":
+            if kw.get("directed", False) or not kw.get("jaccard", True):
+                raise NotImplementedError("phenograph directed=True / jaccard=False graphs are not implemented")
+            if kw.get("primary_metric", "euclidean") != "euclidean":
+                raise NotImplementedError("only the euclidean metric is implemented")
+            seed = kw.get("seed")
+            seed = self.random_state if seed is None else seed
+            return (int(kw.get("k", 30)), False, 0 if kw.get("prune") else 1,
+                    float(kw.get("resolution_parameter", 1.0)), int(seed), int(kw.get("min_cluster_size", 10)))
+        if kw.get("directed", False):
+            raise NotImplementedError("directed=True neighbour graphs are not implemented")
+        return 10, True, 2, float(kw["resolution"]), int(self.random_state), None
+
+    @staticmethod
+    def _cluster_and_score(graph, gamma, seed, min_cluster_size, num_cells):
+        """Host C++: Louvain -> size-sorted labels -> per-community hypergeometric test."""
+        indptr, indices, weights = graph
+        labels, _ = _lib.louvain(indptr, indices, weights, gamma, seed)
+        full = _lib.relabel_by_size(labels, min_cluster_size)
+        scores, logp = _lib.score_communities(full, num_cells)
+        return full, scores, logp
+
+    # ------------------------------------------------------------------------------------------
+    def fit(self, raw_counts: NDArray | sp_sparse.csr_matrix) -> "BoostClassifier":
+        """Fits the classifier on raw_counts (cells x genes).
+
+        Sets ``all_scores_``, ``all_log_p_values_``, ``communities_``, ``top_var_genes_``,
+        ``parents_``, ``synth_communities_`` and returns ``self``.
+        """
+        from sklearn.utils import check_array
+
+        if self.normalizer is not None:
+            # upstream's custom-normalizer branch cannot complete either (it references variables that
+            # only the default branch defines, doubletdetection.py:301,372 -> UnboundLocalError)
+            raise NotImplementedError("a user `normalizer` callable cannot run on the GPU path; leave it None")
+        if self.pseudocount == 1:
+            raise NotImplementedError(
+                "pseudocount=1 selects upstream's sparse/ARPACK PCA (doubletdetection.py:296-297,308), "
+                "which the GPU path does not implement yet")
+
+        raw_counts = check_array(raw_counts, accept_sparse="csr", ensure_all_finite=True, ensure_2d=True,
+                                 dtype="float32")
+        if not sp_sparse.issparse(raw_counts):
+            if self.verbose:
+                print("Sparsifying matrix.")
+            raw_counts = sp_sparse.csr_matrix(raw_counts)
+
+        if 0 < self.n_top_var_genes < raw_counts.shape[1]:
+            # float32 population variance in scipy's evaluation order; ordering by numpy argsort so the
+            # tie order among equal variances is whatever upstream gets on the same host
+            second_moment = np.array(raw_counts.power(2).mean(axis=0))
+            first_moment = np.array(raw_counts.mean(axis=0))
+            gene_variances = (second_moment - first_moment ** 2)[0]
+            self.top_var_genes_ = np.argsort(gene_variances)[-self.n_top_var_genes:]
+            raw_counts = raw_counts.tocsc()[:, self.top_var_genes_].tocsr()
+        raw_counts.sort_indices()
+
+        self._num_cells, self._num_genes = raw_counts.shape
+        num_cells = self._num_cells
+        num_synths = int(self.boost_rate * num_cells)
+        n_iters = self.n_iters
+
+        rank, world, backend = _dist_info()
+        device = self.device
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0")) if world > 1 else 0
+
+        # the Generator stream must be consumed in iteration order whatever rank runs the iteration
+        all_parents = [self.rng.choice(num_cells, size=(num_synths, 2), replace=self.replace)
+                       for _ in range(n_iters)]
+
+        M = num_cells + num_synths
+        n_comp = self.n_components
+        self._check_pca_regime(M, self._num_genes, n_comp)
+        sketch = n_comp + 10
+        q0_rows = self._num_genes if M >= self._num_genes else M
+        # sklearn draws the start matrix from the legacy RandomState and casts it to the data dtype
+        q0 = np.random.RandomState(self.random_state).normal(size=(q0_rows, sketch))
+        q0 = q0.astype(np.float32).astype(np.float64)
+
+        knn_k, include_self, graph_mode, gamma, seed, min_cluster_size = self._cluster_plan()
+
+        mine = [i for i in range(n_iters) if i % world == rank]
+        workers = self.n_jobs if self.n_jobs and self.n_jobs > 0 else (os.cpu_count() or 1)
+        engine = self._engine_factory(device)
+        local = {}
+        try:
+            engine.upload(raw_counts)
+            with ThreadPoolExecutor(max_workers=max(1, min(workers, max(1, len(mine))))) as pool:
+                pending = {}
+                for i in mine:
+                    if self.verbose:
+                        print("Iteration {:3}/{}".format(i + 1, n_iters))
+                    graph = engine.run_iteration(all_parents[i], self.pseudocount, self.standard_scaling, n_comp,
+                                                 q0, knn_k, include_self, graph_mode)
+                    pending[i] = pool.submit(self._cluster_and_score, graph, gamma, seed, min_cluster_size,
+                                             num_cells)
+                for i, fut in pending.items():
+                    local[i] = fut.result()
+            self._device_timings = engine.timings() if hasattr(engine, "timings") else {}
+        finally:
+            engine.close()
+
+        self.all_scores_ = np.zeros((n_iters, num_cells))
+        self.all_log_p_values_ = np.zeros((n_iters, num_cells))
+        all_communities = np.zeros((n_iters, num_cells))
+        all_synth_communities = np.zeros((n_iters, num_synths))
+        rows = self._gather_rows(local, mine, n_iters, num_cells, num_synths, rank, world, backend, device)
+        for i in range(n_iters):
+            full, scores, logp = rows[i]
+            self.all_scores_[i] = scores
+            self.all_log_p_values_[i] = logp
+            all_communities[i] = full[:num_cells]
+            all_synth_communities[i] = full[num_cells:]
+            if self.verbose:
+                sizes = np.unique(full, return_counts=True)[1].tolist()
+                print("Found clusters [{0}, ... {2}], with sizes: {1}\n".format(full.min(), sizes, full.max()))
+        self.communities_ = all_communities
+        self.synth_communities_ = all_synth_communities
+        self.parents_ = [[list(p) for p in choices] for choices in all_parents]
+        return self
+
+    @staticmethod
+    def _check_pca_regime(M, H, n_comp):
+        """sklearn's svd_solver='auto' policy (sklearn/decomposition/_pca.py:524-536): the GPU path
+        implements the randomized branch, which every realistic data set selects."""
+        if not 1 <= n_comp <= min(M, H):
+            raise ValueError(f"n_components={n_comp} must be between 1 and min(n_samples, n_features)={min(M, H)}")
+        if H <= 1000 and M >= 10 * H:
+            regime = "covariance_eigh"
+        elif max(M, H) <= 500:
+            regime = "full"
+        elif n_comp < 0.8 * min(M, H):
+            regime = "randomized"
+        else:
+            regime = "full"
+        if regime != "randomized":
+            raise NotImplementedError(
+                f"for a {M}x{H} matrix with n_components={n_comp} scikit-learn selects its exact '{regime}' "
+                "PCA; only the randomized solver (max(shape) > 500, more than 1000 genes or fewer than 10 "
+                "cells per gene, n_components < 0.8*min(shape)) is implemented on the GPU")
+
+    def _gather_rows(self, local, mine, n_iters, num_cells, num_synths, rank, world, backend, device):
+        """Single collective: every rank contributes [full | scores | logp] rows of its iterations."""
+        if world == 1:
+            return {i: local[i] for i in range(n_iters)}
+        import torch
+        import torch.distributed as dist
+
+        M = num_cells + num_synths
+        width = M + 2 * num_cells
+        per_rank = (n_iters + world - 1) // world
+        buf = np.zeros((per_rank, width), dtype=np.float64)
+        for slot, i in enumerate(mine):
+            full, scores, logp = local[i]
+            buf[slot, :M] = full
+            buf[slot, M:M + num_cells] = scores
+            buf[slot, M + num_cells:] = logp
+        use_cuda = backend == "nccl"
+        t = torch.from_numpy(buf)
+        if use_cuda:
+            t = t.to(f"cuda:{device}")
+        out = torch.empty((world, per_rank, width), dtype=torch.float64, device=t.device)
+        dist.all_gather_into_tensor(out, t)
+        out = out.cpu().numpy()
+        rows = {}
+        for i in range(n_iters):
+            r, slot = i % world, i // world
+            row = out[r, slot]
+            rows[i] = (row[:M].astype(np.int64), row[M:M + num_cells], row[M + num_cells:])
+        return rows
+
+    # ------------------------------------------------------------------------------------------
+    def predict(self, p_thresh: float = 1e-7, voter_thresh: float = 0.9) -> NDArray:
+        """Doublet calls: 0 singlet, 1 doublet, NaN unscored.
+
+        n_iters > 1: a cell is called when the fraction of iterations with log p <= log(p_thresh)
+        reaches voter_thresh (non-finite log p-values are masked out of the vote); sets ``labels_`` and
+        ``voting_average_``.  n_iters == 1: scores are cut at the largest gap between consecutive
+        distinct scores; sets ``labels_`` (bool) and ``suggested_score_cutoff_``.
+        """
+        if self.n_iters > 1:
+            cut = np.log(p_thresh)
+            with np.errstate(invalid="ignore"):
+                valid_logp = np.ma.masked_invalid(self.all_log_p_values_)
+                vote = np.mean(valid_logp <= cut, axis=0)
+                called = (vote >= voter_thresh).astype(float)
+            self.labels_ = np.ma.filled(called, np.nan)
+            self.voting_average_ = np.ma.filled(vote, np.nan)
+            return self.labels_
+        scored = ~np.isnan(self.all_scores_)
+        candidates = np.unique(self.all_scores_[scored])
+        where = 0
+        if candidates.size > 1:
+            where = int(np.argmax(np.diff(candidates))) + 1
+        self.suggested_score_cutoff_ = candidates[where]
+        with np.errstate(invalid="ignore"):
+            self.labels_ = self.all_scores_[0, :] >= self.suggested_score_cutoff_
+        self.labels_[~scored[0, :]] = np.nan
+        return self.labels_
+
+    def doublet_score(self) -> NDArray:
+        """Average negative log p-value over iterations (higher = more doublet-like)."""
+        if self.n_iters > 1:
+            with np.errstate(invalid="ignore"):
+                return -np.mean(np.ma.masked_invalid(self.all_log_p_values_), axis=0)
+        return -self.all_log_p_values_[0]

@@ -1,0 +1,510 @@
+// libddx C-ABI: context life cycle, memory, timing and the thin extern "C" wrappers.
+#include <cstdarg>
+
+#include "ddx_internal.h"
+
+namespace ddx {
+
+static thread_local std::string g_tls_err;
+
+int set_err(ddx_ctx* ctx, int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf; else g_tls_err = buf;
+    return code;
+}
+
+int ensure(ddx_ctx* ctx, DevBuf& b, size_t bytes) {
+    if (bytes <= b.cap && b.p) return DDX_OK;
+    if (b.p) {
+        // contents are never needed across a growth: all callers refill after ensure()
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(b.p);
+        ctx->dev_bytes -= (int64_t)b.cap;
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    size_t want = bytes < 256 ? 256 : bytes;
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) {
+        b.p = nullptr;
+        return set_err(ctx, DDX_E_NOMEM, "hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
+    }
+    b.cap = want;
+    ctx->dev_bytes += (int64_t)want;
+    return DDX_OK;
+}
+
+void release(ddx_ctx* ctx, DevBuf& b) {
+    if (b.p) {
+        (void)hipFree(b.p);
+        ctx->dev_bytes -= (int64_t)b.cap;
+    }
+    b.p = nullptr;
+    b.cap = 0;
+}
+
+void timing_begin(ddx_ctx* ctx, const char* name) {
+    if (!ctx->timing) return;
+    auto it = ctx->t_index.find(name);
+    int id;
+    if (it == ctx->t_index.end()) {
+        id = (int)ctx->t_names.size();
+        ctx->t_names.emplace_back(name);
+        ctx->t_index[name] = id;
+        ctx->t_recs.emplace_back();
+    } else {
+        id = it->second;
+    }
+    PendingEvent ev;
+    ev.name_id = id;
+    if (hipEventCreate(&ev.start) != hipSuccess || hipEventCreate(&ev.stop) != hipSuccess) return;
+    (void)hipEventRecord(ev.start, ctx->stream);
+    ctx->t_pending.push_back(ev);
+}
+
+void timing_end(ddx_ctx* ctx) {
+    if (!ctx->timing || ctx->t_pending.empty()) return;
+    (void)hipEventRecord(ctx->t_pending.back().stop, ctx->stream);
+    if (ctx->t_pending.size() >= 2048) (void)timing_flush(ctx);
+}
+
+int timing_flush(ddx_ctx* ctx) {
+    if (ctx->t_pending.empty()) return DDX_OK;
+    DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto& ev : ctx->t_pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ev.start, ev.stop) == hipSuccess) {
+            ctx->t_recs[ev.name_id].launches += 1;
+            ctx->t_recs[ev.name_id].total_ms += ms;
+        }
+        (void)hipEventDestroy(ev.start);
+        (void)hipEventDestroy(ev.stop);
+    }
+    ctx->t_pending.clear();
+    return DDX_OK;
+}
+
+}  // namespace ddx
+
+using namespace ddx;
+
+#define REQUIRE_CTX(ctx) \
+    if (!(ctx)) return ddx::set_err(nullptr, DDX_E_ARG, "null context")
+#define USE_DEVICE(ctx) DDX_HIP((ctx), hipSetDevice((ctx)->device))
+
+extern "C" {
+
+int ddx_abi_version(void) { return DDX_ABI_VERSION; }
+
+const char* ddx_last_error(const ddx_ctx* ctx) { return ctx ? ctx->err.c_str() : g_tls_err.c_str(); }
+
+int ddx_device_count(int* count) {
+    if (!count) return set_err(nullptr, DDX_E_ARG, "null count");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return set_err(nullptr, DDX_E_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *count = n;
+    return DDX_OK;
+}
+
+int ddx_create(int device, ddx_ctx** out) {
+    if (!out) return set_err(nullptr, DDX_E_ARG, "null out");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return set_err(nullptr, DDX_E_HIP, "no HIP device available (%s)", hipGetErrorString(e));
+    if (device < 0 || device >= n) return set_err(nullptr, DDX_E_ARG, "device %d out of range [0,%d)", device, n);
+    e = hipSetDevice(device);
+    if (e != hipSuccess) return set_err(nullptr, DDX_E_HIP, "hipSetDevice: %s", hipGetErrorString(e));
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) return set_err(nullptr, DDX_E_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return set_err(nullptr, DDX_E_UNSUPPORTED, "libddx is built for gfx950 only; device %d is %s", device,
+                       prop.gcnArchName);
+    ddx_ctx* c = new (std::nothrow) ddx_ctx();
+    if (!c) return set_err(nullptr, DDX_E_NOMEM, "out of host memory");
+    c->device = device;
+    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete c;
+        return set_err(nullptr, DDX_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+    }
+    *out = c;
+    return DDX_OK;
+}
+
+int ddx_destroy(ddx_ctx* ctx) {
+    if (!ctx) return DDX_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)timing_flush(ctx);
+    DevBuf* bufs[] = {&ctx->raw_indptr, &ctx->raw_indices, &ctx->raw_data, &ctx->aug_indptr, &ctx->aug_indices,
+                      &ctx->aug_raw, &ctx->aug_x, &ctx->lib32, &ctx->lib64, &ctx->synth_counts, &ctx->parents,
+                      &ctx->csc_o_colptr, &ctx->csc_o_row, &ctx->csc_o_raw, &ctx->csc_o_x, &ctx->csc_s_colptr,
+                      &ctx->csc_s_row, &ctx->csc_s_raw, &ctx->csc_s_x, &ctx->sort_keys_in, &ctx->sort_keys_out,
+                      &ctx->sort_vals_in, &ctx->sort_vals_out, &ctx->sort_tmp, &ctx->median, &ctx->lib_sorted,
+                      &ctx->zcol, &ctx->colmean, &ctx->colstat, &ctx->pcaA, &ctx->pcaB, &ctx->pcaSmall,
+                      &ctx->pcaPartial, &ctx->pcaVec, &ctx->emb32, &ctx->emb64, &ctx->sing, &ctx->knn_idx,
+                      &ctx->knn_dist, &ctx->knn_sorted, &ctx->edge_w};
+    for (DevBuf* b : bufs) release(ctx, *b);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return DDX_OK;
+}
+
+int ddx_synchronize(ddx_ctx* ctx) {
+    REQUIRE_CTX(ctx);
+    USE_DEVICE(ctx);
+    DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return DDX_OK;
+}
+
+int ddx_device_bytes(const ddx_ctx* ctx, int64_t* bytes) {
+    REQUIRE_CTX(ctx);
+    if (!bytes) return DDX_E_ARG;
+    *bytes = ctx->dev_bytes;
+    return DDX_OK;
+}
+
+// ---- prologue -------------------------------------------------------------------------------
+static int check_csr(ddx_ctx* ctx, int64_t n, int32_t g, const int64_t* indptr, const int32_t* indices,
+                     const float* data) {
+    if (n <= 0 || g <= 0) return set_err(ctx, DDX_E_ARG, "empty matrix (%lld x %d)", (long long)n, g);
+    if (!indptr) return set_err(ctx, DDX_E_ARG, "null indptr");
+    if (indptr[0] != 0) return set_err(ctx, DDX_E_ARG, "indptr[0] must be 0");
+    for (int64_t i = 0; i < n; ++i)
+        if (indptr[i + 1] < indptr[i]) return set_err(ctx, DDX_E_ARG, "indptr not monotone at row %lld", (long long)i);
+    if (indptr[n] > 0 && (!indices || !data)) return set_err(ctx, DDX_E_ARG, "null indices/data");
+    return DDX_OK;
+}
+
+int ddx_upload_raw(ddx_ctx* ctx, int64_t n_cells, int32_t n_genes, const int64_t* indptr, const int32_t* indices,
+                   const float* data) {
+    REQUIRE_CTX(ctx);
+    USE_DEVICE(ctx);
+    DDX_TRY(check_csr(ctx, n_cells, n_genes, indptr, indices, data));
+    int64_t nnz = indptr[n_cells];
+    DDX_TRY(ensure(ctx, ctx->raw_indptr, sizeof(int64_t) * (n_cells + 1)));
+    DDX_TRY(ensure(ctx, ctx->raw_indices, sizeof(int32_t) * (size_t)(nnz + 1)));
+    DDX_TRY(ensure(ctx, ctx->raw_data, sizeof(float) * (size_t)(nnz + 1)));
+    DDX_HIP(ctx, hipMemcpyAsync(ctx->raw_indptr.p, indptr, sizeof(int64_t) * (n_cells + 1), hipMemcpyHostToDevice,
+                                ctx->stream));
+    if (nnz) {
+        DDX_HIP(ctx, hipMemcpyAsync(ctx->raw_indices.p, indices, sizeof(int32_t) * nnz, hipMemcpyHostToDevice,
+                                    ctx->stream));
+        DDX_HIP(ctx, hipMemcpyAsync(ctx->raw_data.p, data, sizeof(float) * nnz, hipMemcpyHostToDevice, ctx->stream));
+    }
+    DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->rawN = n_cells;
+    ctx->rawG = n_genes;
+    ctx->raw_nnz = nnz;
+    ctx->h_raw_indptr.assign(indptr, indptr + n_cells + 1);
+    return DDX_OK;
+}
+
+int ddx_gene_variances(ddx_ctx* ctx, float* var_out) {
+    REQUIRE_CTX(ctx);
+    USE_DEVICE(ctx);
+    if (!ctx->rawN) return set_err(ctx, DDX_E_ARG, "ddx_upload_raw has not been called");
+    if (!var_out) return set_err(ctx, DDX_E_ARG, "null output");
+    return stage_gene_variances(ctx, var_out);
+}
+
+int ddx_select_columns(ddx_ctx* ctx, const int64_t* cols, int32_t n_cols) {
+    REQUIRE_CTX(ctx);
+    USE_DEVICE(ctx);
+    if (!ctx->rawN) return set_err(ctx, DDX_E_ARG, "ddx_upload_raw has not been called");
+    if (!cols || n_cols <= 0) return set_err(ctx, DDX_E_ARG, "empty column selection");
+    return stage_select_columns(ctx, cols, n_cols);
+}
+
+int ddx_upload_counts(ddx_ctx* ctx, int64_t n_cells, int32_t n_genes, const int64_t* indptr, const int32_t* indices,
+                      const float* data) {
+    REQUIRE_CTX(ctx);
+    USE_DEVICE(ctx);
+    DDX_TRY(check_csr(ctx, n_cells, n_genes, indptr, indices, data));
+    return stage_upload_counts(ctx, n_cells, n_genes, indptr, indices, data, false);
+}
+
+#define NEED(cond, msg) \
+    if (!(cond)) return set_err(ctx, DDX_E_ARG, msg)
+
+static int d2h(ddx_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    if (!bytes) return DDX_OK;
+    DDX_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return DDX_OK;
+}
+
+int ddx_get_counts_nnz(ddx_ctx* ctx, int64_t* nnz) {
+    REQUIRE_CTX(ctx);
+    NEED(ctx->have_counts, "no counts uploaded");
+    *nnz = ctx->nnz;
+    return DDX_OK;
+}
+
+int ddx_get_counts(ddx_ctx* ctx, int64_t* indptr, int32_t* indices, float* data) {
+    REQUIRE_CTX(ctx);
+    USE_DEVICE(ctx);
+    NEED(ctx->have_counts, "no counts uploaded");
+    DDX_TRY(d2h(ctx, indptr, ctx->aug_indptr.p, sizeof(int64_t) * (ctx->N + 1)));
+    DDX_TRY(d2h(ctx, indices, ctx->aug_indices.p, sizeof(int32_t) * ctx->nnz));
+    DDX_TRY(d2h(ctx, data, ctx->aug_raw.p, sizeof(float) * ctx->nnz));
+    return DDX_OK;
+}
+
+int ddx_get_lib_size(ddx_ctx* ctx, float* lib_out) {
+    REQUIRE_CTX(ctx);
+    USE_DEVICE(ctx);
+    NEED(ctx->have_counts, "no counts uploaded");
+    return d2h(ctx, lib_out, ctx->lib32.p, sizeof(float) * ctx->N);
+}
+
+// normed values are recomputed on the fly inside the fused normalise kernel; this helper evaluates
+// the same expression (float)((double)v / rowsum) on the host from device data for the parity test.
+int ddx_get_normed(ddx_ctx* ctx, float* normed_out) {
+    REQUIRE_CTX(ctx);
+    USE_DEVICE(ctx);
+    NEED(ctx->have_counts, "no counts uploaded");
+    std::vector<float> v(ctx->nnz);
+    std::vector<double> l(ctx->N);
+    DDX_TRY(d2h(ctx, v.data(), ctx->aug_raw.p, sizeof(float) * ctx->nnz));
+    DDX_TRY(d2h(ctx, l.data(), ctx->lib64.p, sizeof(double) * ctx->N));
+    for (int64_t i = 0; i < ctx->N; ++i) {
+        double s = l[i];
+        for (int64_t e = ctx->h_indptr[i]; e < ctx->h_indptr[i + 1]; ++e)
+            normed_out[e] = (s == 0.0) ? v[e] : (float)((double)v[e] / s);
+    }
+    return DDX_OK;
+}
+
+// ---- doublets ---------------------------------------------------------------------------------
+int ddx_create_doublets(ddx_ctx* ctx, int64_t n_synth, const int64_t* parents) {
+    REQUIRE_CTX(ctx);
+    USE_DEVICE(ctx);
+    NEED(ctx->have_counts, "no counts uploaded");
+    NEED(n_synth >= 0, "negative n_synth");
+    NEED(n_synth == 0 || parents, "null parents");
+    for (int64_t i = 0; i < 2 * n_synth; ++i)
+        if (parents[i] < 0 || parents[i] >= ctx->N)
+            return set_err(ctx, DDX_E_ARG, "parent index %lld out of range at %lld", (long long)parents[i], (long long)i);
+    return stage_create_doublets(ctx, n_synth, parents);
+}
+
+int ddx_get_synth_nnz(ddx_ctx* ctx, int64_t* nnz) {
+    REQUIRE_CTX(ctx);
+    USE_DEVICE(ctx);
+    NEED(ctx->have_synth, "no synthetic doublets");
+    int64_t last = 0;
+    DDX_TRY(d2h(ctx, &last, ctx->aug_indptr.as<int64_t>() + ctx->M, sizeof(int64_t)));
+    *nnz = last - ctx->nnz;
+    return DDX_OK;
+}
+
+int ddx_get_synth(ddx_ctx* ctx, int64_t* indptr, int32_t* indices, float* data) {
+    REQUIRE_CTX(ctx);
+    USE_DEVICE(ctx);
+    NEED(ctx->have_synth, "no synthetic doublets");
+    DDX_TRY(d2h(ctx, indptr, ctx->aug_indptr.as<int64_t>() + ctx->N, sizeof(int64_t) * (ctx->S + 1)));
+    int64_t base = ctx->nnz;
+    int64_t n = indptr[ctx->S] - base;
+    for (int64_t i = 0; i <= ctx->S; ++i) indptr[i] -= base;
+    DDX_TRY(d2h(ctx, indices, ctx->aug_indices.as<int32_t>() + base, sizeof(int32_t) * n));
+    DDX_TRY(d2h(ctx, data, ctx->aug_raw.as<float>() + base, sizeof(float) * n));
+    return DDX_OK;
+}
+
+// ---- normalisation -----------------------------------------------------------------------------
+int ddx_lognormalise(ddx_ctx* ctx, float pseudocount) {
+    REQUIRE_CTX(ctx);
+    USE_DEVICE(ctx);
+    NEED(ctx->have_synth, "ddx_create_doublets must run first");
+    NEED(pseudocount > 0.f, "pseudocount must be positive");
+    return stage_lognormalise(ctx, pseudocount);
+}
+
+int ddx_get_aug_lib(ddx_ctx* ctx, float* lib_out, float* median_out) {
+    REQUIRE_CTX(ctx);
+    USE_DEVICE(ctx);
+    NEED(ctx->have_lognorm, "ddx_lognormalise must run first");
+    if (lib_out) DDX_TRY(d2h(ctx, lib_out, ctx->lib32.p, sizeof(float) * ctx->M));
+    if (median_out) DDX_TRY(d2h(ctx, median_out, ctx->median.p, sizeof(float)));
+    return DDX_OK;
+}
+
+int ddx_get_aug_nnz(ddx_ctx* ctx, int64_t* nnz) {
+    REQUIRE_CTX(ctx);
+    USE_DEVICE(ctx);
+    NEED(ctx->have_synth, "no synthetic doublets");
+    return d2h(ctx, nnz, ctx->aug_indptr.as<int64_t>() + ctx->M, sizeof(int64_t));
+}
+
+int ddx_get_aug_values(ddx_ctx* ctx, float* values_out, float* zero_value_out) {
+    REQUIRE_CTX(ctx);
+    USE_DEVICE(ctx);
+    NEED(ctx->have_lognorm, "ddx_lognormalise must run first");
+    int64_t n = 0;
+    DDX_TRY(d2h(ctx, &n, ctx->aug_indptr.as<int64_t>() + ctx->M, sizeof(int64_t)));
+    if (values_out) DDX_TRY(d2h(ctx, values_out, ctx->aug_x.p, sizeof(float) * n));
+    if (zero_value_out) DDX_TRY(d2h(ctx, zero_value_out, ctx->zcol.p, sizeof(float) * ctx->H));
+    return DDX_OK;
+}
+
+int ddx_get_aug_dense_rows(ddx_ctx* ctx, int64_t row0, int64_t nrows, float* out) {
+    REQUIRE_CTX(ctx);
+    USE_DEVICE(ctx);
+    NEED(ctx->have_lognorm, "ddx_lognormalise must run first");
+    NEED(row0 >= 0 && nrows >= 0 && row0 + nrows <= ctx->M, "row range out of bounds");
+    if (!nrows) return DDX_OK;
+    return stage_dense_rows(ctx, row0, nrows, out);
+}
+
+int ddx_scale(ddx_ctx* ctx, float max_value) {
+    REQUIRE_CTX(ctx);
+    USE_DEVICE(ctx);
+    NEED(ctx->have_lognorm, "ddx_lognormalise must run first");
+    NEED(!ctx->scaled, "matrix already scaled");
+    return stage_scale(ctx, max_value);
+}
+
+// ---- PCA ----------------------------------------------------------------------------------------
+int ddx_pca(ddx_ctx* ctx, int32_t n_components, int32_t n_oversamples, int32_t n_iter, const double* q0,
+            int64_t q0_rows) {
+    REQUIRE_CTX(ctx);
+    USE_DEVICE(ctx);
+    NEED(ctx->have_lognorm, "ddx_lognormalise must run first");
+    NEED(n_components >= 1 && n_oversamples >= 0, "bad sketch size");
+    NEED(q0, "null start matrix");
+    int64_t want = (ctx->M >= ctx->H) ? (int64_t)ctx->H : ctx->M;
+    if (q0_rows != want)
+        return set_err(ctx, DDX_E_ARG, "q0 must have %lld rows (M=%lld, H=%d), got %lld", (long long)want,
+                       (long long)ctx->M, ctx->H, (long long)q0_rows);
+    int64_t mn = ctx->M < ctx->H ? ctx->M : (int64_t)ctx->H;
+    if (n_components > mn) return set_err(ctx, DDX_E_ARG, "n_components=%d exceeds min(M,H)=%lld", n_components, (long long)mn);
+    return stage_pca(ctx, n_components, n_oversamples, n_iter, q0, q0_rows);
+}
+
+int ddx_get_embedding(ddx_ctx* ctx, float* emb_out) {
+    REQUIRE_CTX(ctx);
+    USE_DEVICE(ctx);
+    NEED(ctx->have_emb, "no embedding");
+    return d2h(ctx, emb_out, ctx->emb32.p, sizeof(float) * ctx->embM * ctx->C);
+}
+
+int ddx_get_embedding_f64(ddx_ctx* ctx, double* emb_out, double* singular_values) {
+    REQUIRE_CTX(ctx);
+    USE_DEVICE(ctx);
+    NEED(ctx->have_emb && ctx->emb64.p && ctx->sing.p, "no float64 embedding (set_embedding was used)");
+    if (emb_out) DDX_TRY(d2h(ctx, emb_out, ctx->emb64.p, sizeof(double) * ctx->embM * ctx->C));
+    if (singular_values) DDX_TRY(d2h(ctx, singular_values, ctx->sing.p, sizeof(double) * ctx->C));
+    return DDX_OK;
+}
+
+int ddx_set_embedding(ddx_ctx* ctx, const float* emb, int64_t n_rows, int32_t n_components) {
+    REQUIRE_CTX(ctx);
+    USE_DEVICE(ctx);
+    NEED(emb && n_rows > 0 && n_components > 0, "bad embedding");
+    DDX_TRY(ensure(ctx, ctx->emb32, sizeof(float) * n_rows * n_components));
+    DDX_HIP(ctx, hipMemcpyAsync(ctx->emb32.p, emb, sizeof(float) * n_rows * n_components, hipMemcpyHostToDevice,
+                                ctx->stream));
+    DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->embM = n_rows;
+    ctx->C = n_components;
+    ctx->have_emb = true;
+    ctx->have_knn = false;
+    return DDX_OK;
+}
+
+// ---- kNN / graph -------------------------------------------------------------------------------
+int ddx_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
+    REQUIRE_CTX(ctx);
+    USE_DEVICE(ctx);
+    NEED(ctx->have_emb, "no embedding");
+    NEED(k >= 1 && k <= 64, "k must be in [1,64]");
+    if ((int64_t)k + (include_self ? 0 : 1) > ctx->embM)
+        return set_err(ctx, DDX_E_ARG, "k=%d too large for %lld points", k, (long long)ctx->embM);
+    return stage_knn(ctx, k, include_self);
+}
+
+int ddx_get_knn(ddx_ctx* ctx, int32_t* idx_out, double* dist_out) {
+    REQUIRE_CTX(ctx);
+    USE_DEVICE(ctx);
+    NEED(ctx->have_knn, "no kNN result");
+    if (idx_out) DDX_TRY(d2h(ctx, idx_out, ctx->knn_idx.p, sizeof(int32_t) * ctx->embM * ctx->K));
+    if (dist_out) DDX_TRY(d2h(ctx, dist_out, ctx->knn_dist.p, sizeof(double) * ctx->embM * ctx->K));
+    return DDX_OK;
+}
+
+int ddx_build_graph(ddx_ctx* ctx, int32_t mode) {
+    REQUIRE_CTX(ctx);
+    USE_DEVICE(ctx);
+    NEED(ctx->have_knn, "no kNN result");
+    NEED(mode >= 0 && mode <= 2, "graph mode must be 0, 1 or 2");
+    if (mode == 2) { NEED(ctx->knn_self, "mode 2 expects a kNN table computed with include_self=1"); }
+    else { NEED(!ctx->knn_self, "Jaccard graphs expect a kNN table computed with include_self=0"); }
+    return stage_build_graph(ctx, mode);
+}
+
+int ddx_get_graph_size(ddx_ctx* ctx, int64_t* n_nodes, int64_t* n_entries) {
+    REQUIRE_CTX(ctx);
+    NEED(!ctx->g_indptr.empty(), "no graph");
+    *n_nodes = (int64_t)ctx->g_indptr.size() - 1;
+    *n_entries = ctx->g_indptr.back();
+    return DDX_OK;
+}
+
+int ddx_get_graph(ddx_ctx* ctx, int64_t* indptr, int32_t* indices, double* weights) {
+    REQUIRE_CTX(ctx);
+    NEED(!ctx->g_indptr.empty(), "no graph");
+    memcpy(indptr, ctx->g_indptr.data(), sizeof(int64_t) * ctx->g_indptr.size());
+    if (!ctx->g_indices.empty()) {
+        memcpy(indices, ctx->g_indices.data(), sizeof(int32_t) * ctx->g_indices.size());
+        memcpy(weights, ctx->g_weights.data(), sizeof(double) * ctx->g_weights.size());
+    }
+    return DDX_OK;
+}
+
+// ---- timing ------------------------------------------------------------------------------------
+int ddx_timing_enable(ddx_ctx* ctx, int32_t on) {
+    REQUIRE_CTX(ctx);
+    USE_DEVICE(ctx);
+    if (!on) DDX_TRY(timing_flush(ctx));
+    ctx->timing = on != 0;
+    return DDX_OK;
+}
+
+int ddx_timing_reset(ddx_ctx* ctx) {
+    REQUIRE_CTX(ctx);
+    USE_DEVICE(ctx);
+    DDX_TRY(timing_flush(ctx));
+    for (auto& r : ctx->t_recs) r = TimingRec();
+    return DDX_OK;
+}
+
+int ddx_timing_count(ddx_ctx* ctx, int32_t* n) {
+    REQUIRE_CTX(ctx);
+    USE_DEVICE(ctx);
+    DDX_TRY(timing_flush(ctx));
+    *n = (int32_t)ctx->t_names.size();
+    return DDX_OK;
+}
+
+int ddx_timing_get(ddx_ctx* ctx, int32_t i, char* name_out, int64_t* launches, double* total_ms) {
+    REQUIRE_CTX(ctx);
+    if (i < 0 || i >= (int32_t)ctx->t_names.size()) return set_err(ctx, DDX_E_ARG, "timing index out of range");
+    snprintf(name_out, 64, "%s", ctx->t_names[i].c_str());
+    *launches = ctx->t_recs[i].launches;
+    *total_ms = ctx->t_recs[i].total_ms;
+    return DDX_OK;
+}
+
+}  // extern "C"

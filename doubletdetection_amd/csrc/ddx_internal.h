@@ -1,0 +1,170 @@
+// Internal declarations shared by the libddx translation units (not part of the C-ABI).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/ddx.h"
+
+namespace ddx {
+
+constexpr int kWave = 64;  // gfx950 wavefront
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct TimingRec {
+    int64_t launches = 0;
+    double total_ms = 0.0;
+};
+
+struct PendingEvent {
+    int name_id;
+    hipEvent_t start, stop;
+};
+
+}  // namespace ddx
+
+struct ddx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    int64_t dev_bytes = 0;
+
+    // ---- raw (all genes) matrix, only used by the on-device prologue -------------------------
+    int64_t rawN = 0;
+    int32_t rawG = 0;
+    int64_t raw_nnz = 0;
+    ddx::DevBuf raw_indptr, raw_indices, raw_data;
+    std::vector<int64_t> h_raw_indptr;
+
+    // ---- HVG-restricted counts, resident for the whole fit -------------------------------------
+    int64_t N = 0;
+    int32_t H = 0;
+    int64_t nnz = 0;                 // stored entries of the N x H counts
+    std::vector<int64_t> h_indptr;   // host copy of the row pointer (capacity planning)
+    bool have_counts = false;
+
+    // augmented matrix (rows 0..N-1 = originals, N..M-1 = synthetic doublets), CSR
+    int64_t S = 0, M = 0;
+    int64_t cap_synth = 0;           // capacity (entries) reserved behind the originals
+    ddx::DevBuf aug_indptr;          // int64 [M+1]
+    ddx::DevBuf aug_indices;         // int32 [nnz + cap_synth]
+    ddx::DevBuf aug_raw;             // float [..] counts / summed counts
+    ddx::DevBuf aug_x;               // float [..] value handed to PCA (log-normalised, maybe scaled)
+    ddx::DevBuf lib32;               // float  [M] library sizes (float32 sequential sums)
+    ddx::DevBuf lib64;               // double [M] L1 norms (double sequential sums)
+    ddx::DevBuf synth_counts;        // int32 [S+1] scratch (row counts -> scan)
+    ddx::DevBuf parents;             // int64 [S*2]
+    bool have_synth = false;
+
+    // column-major mirror: originals (static structure) + synthetic part (rebuilt per iteration)
+    ddx::DevBuf csc_o_colptr;        // int64 [H+1]
+    ddx::DevBuf csc_o_row;           // int32 [nnz]
+    ddx::DevBuf csc_o_raw;           // float [nnz]
+    ddx::DevBuf csc_o_x;             // float [nnz]
+    ddx::DevBuf csc_s_colptr;        // int64 [H+1]
+    ddx::DevBuf csc_s_row;           // int32 [cap_synth]  (row ids already offset by N)
+    ddx::DevBuf csc_s_raw;           // float [cap_synth]
+    ddx::DevBuf csc_s_x;             // float [cap_synth]
+    ddx::DevBuf sort_keys_in, sort_keys_out, sort_vals_in, sort_vals_out, sort_tmp;
+
+    // normalisation state
+    float pseudocount = 0.1f;
+    bool have_lognorm = false;
+    bool scaled = false;
+    ddx::DevBuf median;              // float [1] (+ scratch)
+    ddx::DevBuf lib_sorted;          // float [M]
+    ddx::DevBuf zcol;                // float  [H] value of unstored entries per column
+    ddx::DevBuf colmean;             // double [H] mean over rows of (x - zcol) (0 for unstored)
+    ddx::DevBuf colstat;             // double [2H] scratch for scale
+
+    // PCA work space
+    int32_t C = 0;
+    ddx::DevBuf pcaA, pcaB, pcaSmall, pcaPartial, pcaVec;
+    ddx::DevBuf emb32;               // float  [M*C]
+    ddx::DevBuf emb64;               // double [M*C]
+    ddx::DevBuf sing;                // double [C]
+    int64_t embM = 0;
+    bool have_emb = false;
+
+    // kNN
+    int32_t K = 0;
+    bool knn_self = false;
+    ddx::DevBuf knn_idx;             // int32 [M*K]
+    ddx::DevBuf knn_dist;            // double [M*K]
+    ddx::DevBuf knn_sorted;          // int32 [M*K] neighbour lists sorted by index
+    ddx::DevBuf edge_w;              // double [M*K]
+    bool have_knn = false;
+
+    // graph (host)
+    std::vector<int64_t> g_indptr;
+    std::vector<int32_t> g_indices;
+    std::vector<double> g_weights;
+
+    // timing
+    bool timing = false;
+    std::vector<std::string> t_names;
+    std::map<std::string, int> t_index;
+    std::vector<ddx::TimingRec> t_recs;
+    std::vector<ddx::PendingEvent> t_pending;
+};
+
+namespace ddx {
+
+int set_err(ddx_ctx* ctx, int code, const char* fmt, ...);
+int ensure(ddx_ctx* ctx, DevBuf& b, size_t bytes);
+void release(ddx_ctx* ctx, DevBuf& b);
+void timing_begin(ddx_ctx* ctx, const char* name);
+void timing_end(ddx_ctx* ctx);
+int timing_flush(ddx_ctx* ctx);
+
+#define DDX_HIP(ctx, call)                                                                   \
+    do {                                                                                     \
+        hipError_t e__ = (call);                                                             \
+        if (e__ != hipSuccess)                                                               \
+            return ddx::set_err((ctx), DDX_E_HIP, "%s failed: %s (%s:%d)", #call,            \
+                                hipGetErrorString(e__), __FILE__, __LINE__);                 \
+    } while (0)
+
+#define DDX_TRY(expr)                 \
+    do {                              \
+        int rc__ = (expr);            \
+        if (rc__ != DDX_OK) return rc__; \
+    } while (0)
+
+// RAII-free scoped kernel timer: KTIME(ctx, "name") { launches... }
+struct ScopedTimer {
+    ddx_ctx* c;
+    ScopedTimer(ddx_ctx* ctx, const char* name) : c(ctx) { timing_begin(c, name); }
+    ~ScopedTimer() { timing_end(c); }
+};
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- stage entry points implemented in the .hip files ------------------------------------------
+int stage_upload_counts(ddx_ctx* ctx, int64_t N, int32_t H, const int64_t* indptr, const int32_t* indices,
+                        const float* data, bool from_device);
+int stage_create_doublets(ddx_ctx* ctx, int64_t S, const int64_t* parents);
+int stage_lognormalise(ddx_ctx* ctx, float pseudocount);
+int stage_scale(ddx_ctx* ctx, float max_value);
+int stage_dense_rows(ddx_ctx* ctx, int64_t row0, int64_t nrows, float* out_host);
+int stage_pca(ddx_ctx* ctx, int32_t C, int32_t oversample, int32_t n_iter, const double* q0, int64_t q0_rows);
+int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self);
+int stage_build_graph(ddx_ctx* ctx, int32_t mode);
+int stage_gene_variances(ddx_ctx* ctx, float* var_out);
+int stage_select_columns(ddx_ctx* ctx, const int64_t* cols, int32_t n_cols);
+
+// host-side numerics
+void jacobi_eigh(int n, double* a /* n*n row-major, destroyed */, double* evals, double* evecs);
+
+}  // namespace ddx

@@ -1,0 +1,557 @@
+// Truncated PCA of the augmented matrix = scikit-learn's seeded randomized SVD (what
+// sc.tl.pca(svd_solver="auto") runs for the reference, dd.py:305-314), evaluated in float64 on the
+// *implicit* matrix:  X = 1 z^T + L  with L stored sparse (CSR + column-major mirror), so that the
+// centred operator is  A = L - 1 m^T  (m = column means of L).  The dense M x H matrix of dd.py:295
+// is never formed: every product A Q / A^T Y is one pass over the stored entries (8 bytes each) with
+// gathers of L-wide float64 rows of the small operand from L2 / Infinity Cache.
+//
+// Steps (sklearn/utils/extmath.py:287-372,531-607; sklearn/decomposition/_pca.py:731-766):
+//   Q0 (host-drawn, seeded) -> n_iter x { Q <- orth(A Q) ; Q <- orth(A^T Q) } -> Q <- qr(A Q)
+//   B = Q^T A ; SVD(B) via eigh(B B^T) ; U = Q Uhat ; sign fix on the component rows ; return U S.
+// orth() is a Cholesky-QR instead of sklearn's LU: only the spanned subspace enters the next step, so
+// the float64 result is the same to ~1e-12 (oracle/dd_oracle.py:randomized_pca_f64 checks this).
+#include <algorithm>
+#include <cmath>
+
+#include "ddx_internal.h"
+
+namespace ddx {
+
+constexpr int kMaxL = 64;   // sketch width limit (n_components + n_oversamples)
+
+// ------------------------------------------------------------------------------------------------
+// SpMM over rows:  Y[i,:] = sum_j (x_ij - z_j) Q[j,:] - t[:]        (A Q, t = m^T Q)
+// One wave per matrix row.  The 64 lanes are split into `slots` groups of `lpn` lanes; a group
+// handles one stored entry at a time and each of its lanes two adjacent sketch columns (one 16-byte
+// load of Q), so a step consumes `slots` entries with fully coalesced L*8-byte row gathers.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_spmm_rows(const int64_t* __restrict__ indptr, const int32_t* __restrict__ cols,
+                                                   const float* __restrict__ x, const float* __restrict__ zcol,
+                                                   const double* __restrict__ Q, int L, int lpn, int slots,
+                                                   const double* __restrict__ tvec, int64_t M, double* __restrict__ Y) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int slot = lane / lpn, sub = lane - slot * lpn;
+    const bool active = slot < slots;
+    const int c0 = 2 * sub;
+    const bool has1 = (c0 + 1) < L;
+    const int64_t b = indptr[row], e = indptr[row + 1];
+    double acc0 = 0.0, acc1 = 0.0;
+    for (int64_t base = b; base < e; base += 64) {
+        const int64_t p = base + lane;
+        int32_t j = 0;
+        double d = 0.0;
+        if (p < e) {
+            j = cols[p];
+            d = (double)x[p] - (double)zcol[j];
+        }
+        const int cnt = (int)((e - base) < 64 ? (e - base) : 64);
+        for (int t0 = 0; t0 < cnt; t0 += slots) {
+            const int tt = t0 + slot;
+            const int src = tt < 64 ? tt : 63;
+            const int32_t jj = __shfl(j, src, 64);
+            double dd = __shfl(d, src, 64);
+            if (tt >= cnt) dd = 0.0;
+            if (active && c0 < L) {
+                const double* q = Q + (int64_t)jj * L + c0;
+                acc0 = fma(dd, q[0], acc0);
+                if (has1) acc1 = fma(dd, q[1], acc1);
+            }
+        }
+    }
+    // combine the slots in fixed order (slot 0 + slot 1 + ...)
+    double s0 = acc0, s1 = acc1;
+    for (int s = 1; s < slots; ++s) {
+        const double o0 = __shfl(acc0, lane + s * lpn, 64);
+        const double o1 = __shfl(acc1, lane + s * lpn, 64);
+        s0 += o0;
+        s1 += o1;
+    }
+    if (slot == 0 && c0 < L) {
+        Y[row * L + c0] = s0 - tvec[c0];
+        if (has1) Y[row * L + c0 + 1] = s1 - tvec[c0 + 1];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// SpMM over columns:  W[j,:] = sum_i (x_ij - z_j) Y[i,:] - m_j u[:]     (A^T Y, u = 1^T Y)
+// One 256-thread block per column; its 4 waves take interleaved 64-entry groups of the column's
+// two segments (original rows, synthetic rows); partial sums are combined in fixed order.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_spmm_cols(const int64_t* __restrict__ cp_o, const int32_t* __restrict__ row_o,
+                                                   const float* __restrict__ x_o, const int64_t* __restrict__ cp_s,
+                                                   const int32_t* __restrict__ row_s, const float* __restrict__ x_s,
+                                                   const float* __restrict__ zcol, const double* __restrict__ colmean,
+                                                   const double* __restrict__ Yin, int L, int lpn, int slots,
+                                                   const double* __restrict__ uvec, double* __restrict__ W) {
+    __shared__ double part[4][kMaxL];
+    const int j = blockIdx.x;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int slot = lane / lpn, sub = lane - slot * lpn;
+    const bool active = slot < slots;
+    const int c0 = 2 * sub;
+    const bool has1 = (c0 + 1) < L;
+    const double z = (double)zcol[j];
+    double acc0 = 0.0, acc1 = 0.0;
+    for (int seg = 0; seg < 2; ++seg) {
+        const int64_t* cp = seg ? cp_s : cp_o;
+        const int32_t* rows = seg ? row_s : row_o;
+        const float* x = seg ? x_s : x_o;
+        const int64_t lo = cp[j], hi = cp[j + 1];
+        for (int64_t base = lo + (int64_t)w * 64; base < hi; base += 256) {
+            const int64_t p = base + lane;
+            int32_t i = 0;
+            double d = 0.0;
+            if (p < hi) {
+                i = rows[p];
+                d = (double)x[p] - z;
+            }
+            const int cnt = (int)((hi - base) < 64 ? (hi - base) : 64);
+            for (int t0 = 0; t0 < cnt; t0 += slots) {
+                const int tt = t0 + slot;
+                const int src = tt < 64 ? tt : 63;
+                const int32_t ii = __shfl(i, src, 64);
+                double dd = __shfl(d, src, 64);
+                if (tt >= cnt) dd = 0.0;
+                if (active && c0 < L) {
+                    const double* y = Yin + (int64_t)ii * L + c0;
+                    acc0 = fma(dd, y[0], acc0);
+                    if (has1) acc1 = fma(dd, y[1], acc1);
+                }
+            }
+        }
+    }
+    double s0 = acc0, s1 = acc1;
+    for (int s = 1; s < slots; ++s) {
+        const double o0 = __shfl(acc0, lane + s * lpn, 64);
+        const double o1 = __shfl(acc1, lane + s * lpn, 64);
+        s0 += o0;
+        s1 += o1;
+    }
+    if (slot == 0 && c0 < L) {
+        part[w][c0] = s0;
+        if (has1) part[w][c0 + 1] = s1;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < L; c += 256) {
+        const double tot = ((part[0][c] + part[1][c]) + part[2][c]) + part[3][c];
+        W[(int64_t)j * L + c] = tot - colmean[j] * uvec[c];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// tall-skinny helpers on R x L row-major float64 matrices (all reductions in fixed order)
+// ------------------------------------------------------------------------------------------------
+// partial[b][c] = sum over the block's rows of w_r * X[r,c]   (w == nullptr: ones)
+__global__ void __launch_bounds__(256) k_wcolsum_partial(const double* __restrict__ X, int64_t R, int L,
+                                                         const double* __restrict__ wgt, int64_t rows_per_block,
+                                                         double* __restrict__ partial) {
+    __shared__ double red[256];
+    const int tid = threadIdx.x;
+    const int groups = 256 / L;            // row lanes per block (L <= 128 -> >= 2)
+    const int g = tid / L, c = tid - g * L;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = (r0 + rows_per_block < R) ? r0 + rows_per_block : R;
+    double acc = 0.0;
+    if (g < groups) {
+        for (int64_t r = r0 + g; r < r1; r += groups) {
+            const double v = X[r * L + c];
+            acc += wgt ? wgt[r] * v : v;
+        }
+    }
+    red[tid] = acc;
+    __syncthreads();
+    if (tid < L) {
+        double s = 0.0;
+        for (int gg = 0; gg < groups; ++gg) s += red[gg * L + tid];
+        partial[(int64_t)blockIdx.x * L + tid] = s;
+    }
+}
+
+__global__ void k_reduce_partials(const double* __restrict__ partial, int nblocks, int width, double* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= width) return;
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += partial[(int64_t)b * width + c];
+    out[c] = s;
+}
+
+// partial Gram: G_b = X_b^T X_b for a block of rows, staged through LDS in 32-row tiles
+__global__ void __launch_bounds__(256) k_gram_partial(const double* __restrict__ X, int64_t R, int L,
+                                                      int64_t rows_per_block, double* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) double tile[];  // [32][L]
+    const int tid = threadIdx.x;
+    const int npairs = L * L;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = (r0 + rows_per_block < R) ? r0 + rows_per_block : R;
+    constexpr int MAXP = (kMaxL * kMaxL + 255) / 256;  // pairs per thread upper bound
+    double acc[MAXP];
+#pragma unroll
+    for (int q = 0; q < MAXP; ++q) acc[q] = 0.0;
+    for (int64_t rb = r0; rb < r1; rb += 32) {
+        const int nr = (int)((r1 - rb) < 32 ? (r1 - rb) : 32);
+        __syncthreads();
+        for (int t = tid; t < nr * L; t += 256) tile[t] = X[rb * L + t];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < MAXP; ++q) {
+            const int pidx = tid + q * 256;
+            if (pidx < npairs) {
+                const int a = pidx / L, bcol = pidx - a * L;
+                double s = acc[q];
+                for (int r = 0; r < nr; ++r) s = fma(tile[r * L + a], tile[r * L + bcol], s);
+                acc[q] = s;
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < MAXP; ++q) {
+        const int pidx = tid + q * 256;
+        if (pidx < npairs) partial[(int64_t)blockIdx.x * npairs + pidx] = acc[q];
+    }
+}
+
+// single wave: G (L x L, symmetric positive definite) -> Rinv with G = R^T R, R upper triangular.
+// flag[0] |= 1 when a pivot had to be floored (rank-deficient sketch).
+__global__ void __launch_bounds__(64) k_chol_inv(const double* __restrict__ G, int L, double* __restrict__ Rinv,
+                                                 int* __restrict__ flag) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];  // a[L*L]
+    double* a = sm;
+    double* inv = Rinv;  // each lane only re-reads entries of the column it wrote itself
+    const int lane = threadIdx.x;
+    for (int t = lane; t < L * L; t += 64) { a[t] = G[t]; inv[t] = 0.0; }
+    __syncthreads();
+    double maxd = 0.0;
+    for (int k = 0; k < L; ++k) maxd = fmax(maxd, a[k * L + k]);
+    const double floor_v = maxd * 1e-26 + 1e-300;
+    for (int k = 0; k < L; ++k) {
+        if (lane == 0) {
+            double d = a[k * L + k];
+            if (!(d > floor_v)) { d = floor_v; atomicOr(flag, 1); }
+            a[k * L + k] = sqrt(d);
+        }
+        __syncthreads();
+        const double piv = a[k * L + k];
+        for (int jx = k + 1 + lane; jx < L; jx += 64) a[k * L + jx] /= piv;
+        __syncthreads();
+        const int rem = L - k - 1;
+        for (int t = lane; t < rem * rem; t += 64) {
+            const int i = k + 1 + t / rem, jx = k + 1 + t % rem;
+            if (jx >= i) a[i * L + jx] -= a[k * L + i] * a[k * L + jx];
+        }
+        __syncthreads();
+    }
+    // invert the upper-triangular factor, one column per lane
+    for (int jx = lane; jx < L; jx += 64) {
+        inv[jx * L + jx] = 1.0 / a[jx * L + jx];
+        for (int i = jx - 1; i >= 0; --i) {
+            double s = 0.0;
+            for (int p = i + 1; p <= jx; ++p) s += a[i * L + p] * inv[p * L + jx];
+            inv[i * L + jx] = -s / a[i * L + i];
+        }
+    }
+}
+
+// out[R x L2] = X[R x L] * T[L x L2]   (64 rows per block, X tile and T staged in LDS)
+__global__ void __launch_bounds__(256) k_right_mult(const double* __restrict__ X, int64_t R, int L,
+                                                    const double* __restrict__ T, int L2, double* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];  // T[L*L2] then xt[64*L]
+    double* t_s = sm;
+    double* x_s = sm + L * L2;
+    const int tid = threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.x * 64;
+    const int nr = (int)((R - r0) < 64 ? (R - r0) : 64);
+    for (int t = tid; t < L * L2; t += 256) t_s[t] = T[t];
+    for (int t = tid; t < nr * L; t += 256) x_s[t] = X[r0 * L + t];
+    __syncthreads();
+    for (int o = tid; o < nr * L2; o += 256) {
+        const int r = o / L2, c = o - r * L2;
+        double s = 0.0;
+        for (int p = 0; p < L; ++p) s = fma(x_s[r * L + p], t_s[p * L2 + c], s);
+        out[(r0 + r) * L2 + c] = s;
+    }
+}
+
+// per column c of X[R x C]: index of the largest |value| (first occurrence), then its sign
+__global__ void __launch_bounds__(256) k_col_sign(const double* __restrict__ X, int64_t R, int C, double* __restrict__ sign_out) {
+    __shared__ double bv[256];
+    __shared__ int64_t bi[256];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    double best = -1.0;
+    int64_t besti = 0;
+    for (int64_t r = tid; r < R; r += 256) {
+        const double v = fabs(X[r * C + c]);
+        if (v > best) { best = v; besti = r; }
+    }
+    bv[tid] = best;
+    bi[tid] = besti;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off) {
+            const double ov = bv[tid + off];
+            const int64_t oi = bi[tid + off];
+            if (ov > bv[tid] || (ov == bv[tid] && oi < bi[tid])) { bv[tid] = ov; bi[tid] = oi; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double v = X[bi[0] * C + c];
+        sign_out[c] = (v > 0.0) ? 1.0 : ((v < 0.0) ? -1.0 : 0.0);
+    }
+}
+
+__global__ void k_f64_to_f32(const double* __restrict__ in, int64_t n, float* __restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (float)in[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// host orchestration
+// ------------------------------------------------------------------------------------------------
+struct PcaWork {
+    ddx_ctx* ctx;
+    int L, lpn, slots;
+    int64_t M;
+    int32_t H;
+    double* partial;   // scratch for block partials
+    double* small;     // [4*L*L + 4*L]: G, Rinv, T, vecs
+    int* flag;
+};
+
+static int wcolsum(PcaWork& w, const double* X, int64_t R, const double* wgt, double* out) {
+    int nb = (int)std::min<int64_t>(512, ceil_div(R, 256));
+    int64_t rpb = ceil_div(R, nb);
+    nb = (int)ceil_div(R, rpb);
+    k_wcolsum_partial<<<nb, 256, 0, w.ctx->stream>>>(X, R, w.L, wgt, rpb, w.partial);
+    k_reduce_partials<<<1, 128, 0, w.ctx->stream>>>(w.partial, nb, w.L, out);
+    return DDX_OK;
+}
+
+static int gram(PcaWork& w, const double* X, int64_t R, double* G) {
+    int nb = (int)std::min<int64_t>(256, ceil_div(R, 128));
+    int64_t rpb = ceil_div(R, nb);
+    nb = (int)ceil_div(R, rpb);
+    const int LL = w.L * w.L;
+    k_gram_partial<<<nb, 256, sizeof(double) * 32 * w.L, w.ctx->stream>>>(X, R, w.L, rpb, w.partial);
+    k_reduce_partials<<<(unsigned)ceil_div(LL, 128), 128, 0, w.ctx->stream>>>(w.partial, nb, LL, G);
+    return DDX_OK;
+}
+
+// X <- X R^-1 with X^T X = R^T R  (one Cholesky-QR pass); result lands in `out`
+static int cholqr(PcaWork& w, const double* X, int64_t R, double* out) {
+    double* G = w.small;
+    double* Rinv = w.small + w.L * w.L;
+    ScopedTimer t(w.ctx, "pca_orth");
+    gram(w, X, R, G);
+    k_chol_inv<<<1, 64, sizeof(double) * w.L * w.L, w.ctx->stream>>>(G, w.L, Rinv, w.flag);
+    k_right_mult<<<(unsigned)ceil_div(R, 64), 256, sizeof(double) * (w.L * w.L + 64 * w.L), w.ctx->stream>>>(X, R, w.L, Rinv, w.L, out);
+    return DDX_OK;
+}
+
+static int apply_rows(PcaWork& w, const double* Qcol, double* Yrow) {  // A Q : [H x L] -> [M x L]
+    ddx_ctx* c = w.ctx;
+    double* tvec = w.small + 3 * w.L * w.L;
+    {
+        ScopedTimer t(c, "pca_colsum");
+        wcolsum(w, Qcol, w.H, c->colmean.as<double>(), tvec);
+    }
+    ScopedTimer t(c, "spmm_rows");
+    k_spmm_rows<<<(unsigned)ceil_div(w.M, 4), 256, 0, c->stream>>>(c->aug_indptr.as<int64_t>(), c->aug_indices.as<int32_t>(), c->aug_x.as<float>(),
+                                                                   c->zcol.as<float>(), Qcol, w.L, w.lpn, w.slots, tvec, w.M, Yrow);
+    return DDX_OK;
+}
+
+static int apply_cols(PcaWork& w, const double* Yrow, double* Wcol) {  // A^T Y : [M x L] -> [H x L]
+    ddx_ctx* c = w.ctx;
+    double* uvec = w.small + 3 * w.L * w.L + w.L;
+    {
+        ScopedTimer t(c, "pca_colsum");
+        wcolsum(w, Yrow, w.M, nullptr, uvec);
+    }
+    ScopedTimer t(c, "spmm_cols");
+    k_spmm_cols<<<(unsigned)w.H, 256, 0, c->stream>>>(c->csc_o_colptr.as<int64_t>(), c->csc_o_row.as<int32_t>(), c->csc_o_x.as<float>(),
+                                                      c->csc_s_colptr.as<int64_t>(), c->csc_s_row.as<int32_t>(), c->csc_s_x.as<float>(),
+                                                      c->zcol.as<float>(), c->colmean.as<double>(), Yrow, w.L, w.lpn, w.slots, uvec, Wcol);
+    return DDX_OK;
+}
+
+int stage_pca(ddx_ctx* ctx, int32_t C, int32_t oversample, int32_t n_iter, const double* q0, int64_t q0_rows) {
+    const int L = C + oversample;
+    if (L > kMaxL) return set_err(ctx, DDX_E_UNSUPPORTED, "sketch width %d exceeds %d", L, kMaxL);
+    const int64_t M = ctx->M;
+    const int32_t H = ctx->H;
+    const bool transposed = M < H;
+    const int64_t mn = transposed ? M : (int64_t)H;
+    if (n_iter < 0) n_iter = ((double)C < 0.1 * (double)mn) ? 7 : 4;
+
+    // row-side (M x L) and column-side (H x L) buffers, two of each (ping/pong)
+    DDX_TRY(ensure(ctx, ctx->pcaA, sizeof(double) * 2 * (size_t)M * L));
+    DDX_TRY(ensure(ctx, ctx->pcaB, sizeof(double) * 2 * (size_t)H * L));
+    DDX_TRY(ensure(ctx, ctx->pcaSmall, sizeof(double) * (4 * L * L + 4 * L) + 256));
+    DDX_TRY(ensure(ctx, ctx->pcaPartial, sizeof(double) * 512 * (size_t)std::max(L * L, 128)));
+    DDX_TRY(ensure(ctx, ctx->pcaVec, 256));
+    DDX_TRY(ensure(ctx, ctx->emb64, sizeof(double) * (size_t)M * C));
+    DDX_TRY(ensure(ctx, ctx->emb32, sizeof(float) * (size_t)M * C));
+    DDX_TRY(ensure(ctx, ctx->sing, sizeof(double) * L));
+    double* rowA = ctx->pcaA.as<double>();
+    double* rowB = rowA + (size_t)M * L;
+    double* colA = ctx->pcaB.as<double>();
+    double* colB = colA + (size_t)H * L;
+
+    PcaWork w;
+    w.ctx = ctx;
+    w.L = L;
+    w.lpn = (L + 1) / 2;
+    w.slots = 64 / w.lpn;
+    w.M = M;
+    w.H = H;
+    w.partial = ctx->pcaPartial.as<double>();
+    w.small = ctx->pcaSmall.as<double>();
+    w.flag = ctx->pcaVec.as<int>();
+    DDX_HIP(ctx, hipMemsetAsync(w.flag, 0, sizeof(int), ctx->stream));
+
+    double* Qfinal;    // orthonormal basis (M x L normal branch, H x L transposed branch)
+    double* Bt;        // projection on the other side (H x L normal, M x L transposed)
+    int64_t RQ, RB;
+    if (!transposed) {
+        DDX_HIP(ctx, hipMemcpyAsync(colA, q0, sizeof(double) * (size_t)H * L, hipMemcpyHostToDevice, ctx->stream));
+        for (int it = 0; it < n_iter; ++it) {
+            apply_rows(w, colA, rowA);
+            cholqr(w, rowA, M, rowB);
+            apply_cols(w, rowB, colB);
+            cholqr(w, colB, H, colA);
+        }
+        apply_rows(w, colA, rowA);
+        cholqr(w, rowA, M, rowB);
+        cholqr(w, rowB, M, rowA);       // second pass: orthonormal to working precision
+        apply_cols(w, rowA, colB);
+        Qfinal = rowA; RQ = M;
+        Bt = colB; RB = H;
+    } else {
+        DDX_HIP(ctx, hipMemcpyAsync(rowA, q0, sizeof(double) * (size_t)M * L, hipMemcpyHostToDevice, ctx->stream));
+        for (int it = 0; it < n_iter; ++it) {
+            apply_cols(w, rowA, colA);
+            cholqr(w, colA, H, colB);
+            apply_rows(w, colB, rowB);
+            cholqr(w, rowB, M, rowA);
+        }
+        apply_cols(w, rowA, colA);
+        cholqr(w, colA, H, colB);
+        cholqr(w, colB, H, colA);
+        apply_rows(w, colA, rowB);
+        Qfinal = colA; RQ = H;
+        Bt = rowB; RB = M;
+    }
+    // small eigenproblem: B B^T = Bt^T Bt = Uhat diag(s^2) Uhat^T
+    double* G = w.small;
+    gram(w, Bt, RB, G);
+    std::vector<double> hG((size_t)L * L), evals(L), evecs((size_t)L * L);
+    DDX_HIP(ctx, hipMemcpyAsync(hG.data(), G, sizeof(double) * L * L, hipMemcpyDeviceToHost, ctx->stream));
+    int hflag = 0;
+    DDX_HIP(ctx, hipMemcpyAsync(&hflag, w.flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (size_t t = 0; t < hG.size(); ++t)
+        if (!std::isfinite(hG[t])) return set_err(ctx, DDX_E_NUMERIC, "non-finite sketch (degenerate input matrix?)");
+    // symmetrise against rounding, then Jacobi
+    for (int a = 0; a < L; ++a)
+        for (int b = a + 1; b < L; ++b) hG[a * L + b] = hG[b * L + a] = 0.5 * (hG[a * L + b] + hG[b * L + a]);
+    jacobi_eigh(L, hG.data(), evals.data(), evecs.data());  // ascending eigenvalues, columns = vectors
+    // T1 = Uhat[:, :C] (descending singular values);  s = sqrt(eval)
+    std::vector<double> T1((size_t)L * C), svals(C), T2((size_t)L * C);
+    for (int c = 0; c < C; ++c) {
+        const int src = L - 1 - c;
+        svals[c] = std::sqrt(std::max(evals[src], 0.0));
+        for (int a = 0; a < L; ++a) T1[(size_t)a * C + c] = evecs[(size_t)a * L + src];
+    }
+    double* dT = w.small + 2 * L * L;  // L x C
+    double* dSign = w.small + 3 * L * L + 2 * L;
+    DDX_HIP(ctx, hipMemcpyAsync(dT, T1.data(), sizeof(double) * L * C, hipMemcpyHostToDevice, ctx->stream));
+    // sign decision on the component rows: components ~ (other side) * Uhat
+    double* signSrc = transposed ? Qfinal : Bt;
+    const int64_t signR = transposed ? RQ : RB;        // both are H
+    double* scratchHC = transposed ? colB : colA;      // H x C scratch (colA/colB are H x L >= H x C)
+    {
+        ScopedTimer t(ctx, "pca_finish");
+        k_right_mult<<<(unsigned)ceil_div(signR, 64), 256, sizeof(double) * (L * C + 64 * L), ctx->stream>>>(signSrc, signR, L, dT, C, scratchHC);
+        k_col_sign<<<C, 256, 0, ctx->stream>>>(scratchHC, signR, C, dSign);
+    }
+    std::vector<double> hsign(C);
+    DDX_HIP(ctx, hipMemcpyAsync(hsign.data(), dSign, sizeof(double) * C, hipMemcpyDeviceToHost, ctx->stream));
+    DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int c = 0; c < C; ++c) {
+        const double f = hsign[c] * (transposed ? 1.0 : svals[c]);
+        for (int a = 0; a < L; ++a) T2[(size_t)a * C + c] = T1[(size_t)a * C + c] * f;
+    }
+    DDX_HIP(ctx, hipMemcpyAsync(dT, T2.data(), sizeof(double) * L * C, hipMemcpyHostToDevice, ctx->stream));
+    DDX_HIP(ctx, hipMemcpyAsync(ctx->sing.p, svals.data(), sizeof(double) * C, hipMemcpyHostToDevice, ctx->stream));
+    {
+        ScopedTimer t(ctx, "pca_finish");
+        const double* scoreSrc = transposed ? Bt : Qfinal;  // both M x L
+        k_right_mult<<<(unsigned)ceil_div(M, 64), 256, sizeof(double) * (L * C + 64 * L), ctx->stream>>>(scoreSrc, M, L, dT, C, ctx->emb64.as<double>());
+        k_f64_to_f32<<<(unsigned)ceil_div(M * C, 256), 256, 0, ctx->stream>>>(ctx->emb64.as<double>(), M * C, ctx->emb32.as<float>());
+    }
+    DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));  // T2/svals are stack-backed host buffers
+    DDX_HIP(ctx, hipGetLastError());
+    ctx->C = C;
+    ctx->embM = M;
+    ctx->have_emb = true;
+    ctx->have_knn = false;
+    if (hflag) {
+        // not fatal: the sketch is wider than the numerical rank; the leading components are unaffected
+        ctx->err = "warning: rank-deficient sketch (pivot floored in Cholesky-QR)";
+    }
+    return DDX_OK;
+}
+
+// cyclic Jacobi eigen-decomposition of a small symmetric matrix (host, float64)
+void jacobi_eigh(int n, double* a, double* evals, double* evecs) {
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) evecs[i * n + j] = (i == j) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 64; ++sweep) {
+        double off = 0.0, diag = 0.0;
+        for (int i = 0; i < n; ++i) {
+            diag += a[i * n + i] * a[i * n + i];
+            for (int j = i + 1; j < n; ++j) off += a[i * n + j] * a[i * n + j];
+        }
+        if (off <= 1e-30 * diag || off == 0.0) break;
+        for (int p = 0; p < n - 1; ++p) {
+            for (int q = p + 1; q < n; ++q) {
+                const double apq = a[p * n + q];
+                if (apq == 0.0) continue;
+                const double app = a[p * n + p], aqq = a[q * n + q];
+                const double theta = (aqq - app) / (2.0 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < n; ++k) {
+                    const double akp = a[k * n + p], akq = a[k * n + q];
+                    a[k * n + p] = c * akp - s * akq;
+                    a[k * n + q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < n; ++k) {
+                    const double apk = a[p * n + k], aqk = a[q * n + k];
+                    a[p * n + k] = c * apk - s * aqk;
+                    a[q * n + k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < n; ++k) {
+                    const double vkp = evecs[k * n + p], vkq = evecs[k * n + q];
+                    evecs[k * n + p] = c * vkp - s * vkq;
+                    evecs[k * n + q] = s * vkp + c * vkq;
+                }
+            }
+        }
+    }
+    // sort ascending
+    std::vector<int> order(n);
+    for (int i = 0; i < n; ++i) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](int x, int y) { return a[x * n + x] < a[y * n + y]; });
+    std::vector<double> ev(n), vec((size_t)n * n);
+    for (int c = 0; c < n; ++c) {
+        ev[c] = a[order[c] * n + order[c]];
+        for (int k = 0; k < n; ++k) vec[(size_t)k * n + c] = evecs[(size_t)k * n + order[c]];
+    }
+    for (int c = 0; c < n; ++c) evals[c] = ev[c];
+    for (size_t t = 0; t < vec.size(); ++t) evecs[t] = vec[t];
+}
+
+}  // namespace ddx

@@ -1,0 +1,678 @@
+// Sparse-matrix stages of the boosting iteration on gfx950:
+//   - resident counts + memoised library sizes           (dd.py:178-184)
+//   - synthetic doublets: CSR two-row gather + sorted merge (dd.py:385-402)
+//   - log-normalisation of the augmented matrix, kept sparse (dd.py:286-298)
+//   - optional standard scaling                            (dd.py:302-303)
+// All kernels are HBM/L2-bound streaming or gather kernels: one wavefront (64 lanes) owns one matrix
+// row so that loads of a row are contiguous 256-byte segments; nothing here is GEMM-shaped.
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cmath>
+
+#include "ddx_internal.h"
+
+namespace ddx {
+
+// ------------------------------------------------------------------------------------------------
+// helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int lower_bound_i32(const int32_t* __restrict__ a, int n, int32_t key) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (a[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ int upper_bound_i32(const int32_t* __restrict__ a, int n, int32_t key) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (a[mid] <= key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// row id of CSR position `pos`: largest r with indptr[r] <= pos (rows may be empty)
+__device__ __forceinline__ int64_t row_of_pos(const int64_t* __restrict__ indptr, int64_t nrows, int64_t pos) {
+    int64_t lo = 0, hi = nrows;  // invariant: indptr[lo] <= pos < indptr[hi]
+    while (hi - lo > 1) {
+        int64_t mid = (lo + hi) >> 1;
+        if (indptr[mid] <= pos) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// Sequential (scipy csr_matvec order) float32 row sum and sklearn's double L1 norm.  One wave per
+// row: the wave loads 64 entries at a time (coalesced), then every lane replays the same left-to-right
+// additions through readlane broadcasts, so the result is the scalar loop's, bit for bit.
+__global__ void __launch_bounds__(256) k_row_sums(const int64_t* __restrict__ indptr, const float* __restrict__ val,
+                                                  int64_t row0, int64_t nrows, float* __restrict__ lib32,
+                                                  double* __restrict__ lib64) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= nrows) return;
+    const int64_t row = row0 + r;
+    const int64_t b = indptr[row], e = indptr[row + 1];
+    float s32 = 0.f;
+    double s64 = 0.0;
+    for (int64_t base = b; base < e; base += 64) {
+        const int64_t p = base + lane;
+        const float v = (p < e) ? val[p] : 0.f;
+        const int cnt = (int)((e - base) < 64 ? (e - base) : 64);
+        for (int t = 0; t < cnt; ++t) {
+            const float vt = __shfl(v, t, 64);
+            s32 = __fadd_rn(s32, vt);
+            s64 = __dadd_rn(s64, fabs((double)vt));
+        }
+    }
+    if (lane == 0) {
+        lib32[row] = s32;
+        lib64[row] = s64;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// doublets
+// ------------------------------------------------------------------------------------------------
+// Classification shared by the count and fill kernels.  A = row p0, B = row p1, both sorted.
+//   A element i : merged position i + #{b < a_i};   matched b adds its value;
+//   B element j : merged position j + #{a <= b_j};  dropped when matched (already emitted by A).
+// An entry is kept iff its float32 sum is != 0 (scipy csr_plus_csr drops exact zeros).
+
+__global__ void __launch_bounds__(256) k_doublet_count(const int64_t* __restrict__ indptr,
+                                                       const int32_t* __restrict__ indices,
+                                                       const float* __restrict__ val,
+                                                       const int64_t* __restrict__ parents, int64_t S,
+                                                       int32_t* __restrict__ counts) {
+    const int lane = threadIdx.x & 63;
+    const int64_t s = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (s >= S) return;
+    const int64_t p0 = parents[2 * s], p1 = parents[2 * s + 1];
+    const int64_t a0 = indptr[p0], b0 = indptr[p1];
+    const int la = (int)(indptr[p0 + 1] - a0), lb = (int)(indptr[p1 + 1] - b0);
+    const int32_t* A = indices + a0;
+    const int32_t* B = indices + b0;
+    int cnt = 0;
+    for (int i = lane; i < la; i += 64) {
+        const int32_t col = A[i];
+        const int r = lower_bound_i32(B, lb, col);
+        float v = val[a0 + i];
+        if (r < lb && B[r] == col) v = __fadd_rn(v, val[b0 + r]);
+        cnt += (v != 0.f);
+    }
+    for (int j = lane; j < lb; j += 64) {
+        const int32_t col = B[j];
+        const int r = lower_bound_i32(A, la, col);
+        const bool matched = (r < la && A[r] == col);
+        if (!matched) cnt += (val[b0 + j] != 0.f);
+    }
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
+    if (lane == 0) counts[s] = cnt;
+}
+
+// single-block exclusive scan of int32 counts into int64 row pointers: out[i] = base + sum_{t<i} in[t],
+// for i in [0, n]; n <= a few hundred thousand rows, one launch of 1024 threads.
+__global__ void __launch_bounds__(1024) k_scan_counts(const int32_t* __restrict__ in, int64_t n, int64_t base,
+                                                      int64_t* __restrict__ out) {
+    __shared__ int64_t wsum[16];
+    __shared__ int64_t carry;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0) carry = base;
+    __syncthreads();
+    for (int64_t start = 0; start < n; start += 1024) {
+        const int64_t i = start + tid;
+        int64_t v = (i < n) ? (int64_t)in[i] : 0;
+        int64_t x = v;  // inclusive scan inside the wave
+        for (int off = 1; off < 64; off <<= 1) {
+            int64_t y = __shfl_up(x, off, 64);
+            if (lane >= off) x += y;
+        }
+        if (lane == 63) wsum[w] = x;
+        __syncthreads();
+        int64_t woff = 0;
+        for (int t = 0; t < w; ++t) woff += wsum[t];
+        const int64_t c = carry;
+        if (i < n) out[i] = c + woff + x - v;
+        __syncthreads();
+        if (tid == 1023) carry = c + woff + x;
+        __syncthreads();
+    }
+    if (tid == 0) out[n] = carry;
+}
+
+constexpr int kMergeTile = 2048;
+
+__global__ void __launch_bounds__(256) k_doublet_fill(const int64_t* __restrict__ indptr,
+                                                      const int32_t* __restrict__ indices,
+                                                      const float* __restrict__ val,
+                                                      const int64_t* __restrict__ parents, int64_t N,
+                                                      const int64_t* __restrict__ out_indptr /* aug_indptr */,
+                                                      int32_t* __restrict__ out_indices, float* __restrict__ out_val) {
+    __shared__ int32_t t_col[kMergeTile];
+    __shared__ float t_val[kMergeTile];
+    __shared__ int32_t t_keep[kMergeTile];
+    __shared__ int32_t wsum[4];
+    __shared__ int32_t run_base;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int64_t s = blockIdx.x;
+    const int64_t p0 = parents[2 * s], p1 = parents[2 * s + 1];
+    const int64_t a0 = indptr[p0], b0 = indptr[p1];
+    const int la = (int)(indptr[p0 + 1] - a0), lb = (int)(indptr[p1 + 1] - b0);
+    const int32_t* A = indices + a0;
+    const int32_t* B = indices + b0;
+    const int L = la + lb;
+    const int64_t o0 = out_indptr[N + s];
+    if (tid == 0) run_base = 0;
+    for (int t0 = 0; t0 < L; t0 += kMergeTile) {
+        for (int i = tid; i < kMergeTile; i += 256) t_keep[i] = 0;
+        __syncthreads();
+        // A elements whose merged position falls in this tile.  Positions are increasing in i, so the
+        // candidates are i in [max(0, t0 - lb), min(la, t0 + tile)).
+        int ilo = t0 - lb; if (ilo < 0) ilo = 0;
+        int ihi = t0 + kMergeTile; if (ihi > la) ihi = la;
+        for (int i = ilo + tid; i < ihi; i += 256) {
+            const int32_t col = A[i];
+            const int r = lower_bound_i32(B, lb, col);
+            const int p = i + r - t0;
+            if (p >= 0 && p < kMergeTile) {
+                float v = val[a0 + i];
+                if (r < lb && B[r] == col) v = __fadd_rn(v, val[b0 + r]);
+                t_col[p] = col;
+                t_val[p] = v;
+                t_keep[p] = (v != 0.f);
+            }
+        }
+        int jlo = t0 - la; if (jlo < 0) jlo = 0;
+        int jhi = t0 + kMergeTile; if (jhi > lb) jhi = lb;
+        for (int j = jlo + tid; j < jhi; j += 256) {
+            const int32_t col = B[j];
+            const int r = upper_bound_i32(A, la, col);
+            const int p = j + r - t0;
+            if (p >= 0 && p < kMergeTile) {
+                const bool matched = (r > 0 && A[r - 1] == col);
+                const float v = val[b0 + j];
+                t_col[p] = col;
+                t_val[p] = v;
+                t_keep[p] = (!matched && v != 0.f);
+            }
+        }
+        __syncthreads();
+        // compaction: each thread owns 8 consecutive merged positions
+        constexpr int PER = kMergeTile / 256;
+        int local[PER];
+        int tot = 0;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            local[q] = tot;
+            tot += t_keep[tid * PER + q];
+        }
+        int x = tot;
+        for (int off = 1; off < 64; off <<= 1) {
+            int y = __shfl_up(x, off, 64);
+            if (lane >= off) x += y;
+        }
+        if (lane == 63) wsum[w] = x;
+        __syncthreads();
+        int woff = 0;
+        for (int t = 0; t < w; ++t) woff += wsum[t];
+        const int base = run_base + woff + x - tot;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int p = tid * PER + q;
+            if (t_keep[p]) {
+                out_indices[o0 + base + local[q]] = t_col[p];
+                out_val[o0 + base + local[q]] = t_val[p];
+            }
+        }
+        __syncthreads();
+        if (tid == 255) run_base = base + tot;
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// column-major mirror
+// ------------------------------------------------------------------------------------------------
+__global__ void k_iota_u32(uint32_t* out, int64_t n, uint32_t base) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = base + (uint32_t)i;
+}
+
+// colptr[j] = first sorted position whose key >= j, j in [0, H]
+__global__ void k_colptr_from_sorted(const int32_t* __restrict__ keys, int64_t n, int32_t H, int64_t* __restrict__ colptr) {
+    int32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j > H) return;
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if (keys[mid] < j) lo = mid + 1; else hi = mid;
+    }
+    colptr[j] = lo;
+}
+
+// gather row id and raw value of every column-sorted entry; pos = CSR position
+__global__ void k_csc_gather(const uint32_t* __restrict__ pos, int64_t n, const int64_t* __restrict__ indptr,
+                             int64_t row_lo, int64_t row_hi, const float* __restrict__ raw,
+                             int32_t* __restrict__ row_out, float* __restrict__ raw_out) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int64_t p = pos[t];
+    // rows [row_lo, row_hi): indptr[row_lo] <= p < indptr[row_hi]
+    int64_t lo = row_lo, hi = row_hi;
+    while (hi - lo > 1) {
+        int64_t mid = (lo + hi) >> 1;
+        if (indptr[mid] <= p) lo = mid; else hi = mid;
+    }
+    row_out[t] = (int32_t)lo;
+    raw_out[t] = raw[p];
+}
+
+// Build the column-major mirror of CSR entries [e0, e0+n) (rows [row_lo,row_hi)): stable radix sort
+// of (column, position) pairs -> entries of one column are in increasing row order.
+static int build_csc(ddx_ctx* ctx, int64_t e0, int64_t n, int64_t row_lo, int64_t row_hi, DevBuf& colptr,
+                     DevBuf& rows, DevBuf& raws) {
+    const int32_t H = ctx->H;
+    DDX_TRY(ensure(ctx, colptr, sizeof(int64_t) * (H + 1)));
+    if (n == 0) {
+        DDX_HIP(ctx, hipMemsetAsync(colptr.p, 0, sizeof(int64_t) * (H + 1), ctx->stream));
+        return DDX_OK;
+    }
+    DDX_TRY(ensure(ctx, ctx->sort_keys_out, sizeof(int32_t) * n));
+    DDX_TRY(ensure(ctx, ctx->sort_vals_in, sizeof(uint32_t) * n));
+    DDX_TRY(ensure(ctx, ctx->sort_vals_out, sizeof(uint32_t) * n));
+    k_iota_u32<<<(unsigned)ceil_div(n, 256), 256, 0, ctx->stream>>>(ctx->sort_vals_in.as<uint32_t>(), n, (uint32_t)e0);
+    int end_bit = 1;
+    while ((1 << end_bit) < H) ++end_bit;
+    const int32_t* keys_in = ctx->aug_indices.as<int32_t>() + e0;
+    size_t tmp_bytes = 0;
+    DDX_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys_in, ctx->sort_keys_out.as<int32_t>(),
+                                                    ctx->sort_vals_in.as<uint32_t>(), ctx->sort_vals_out.as<uint32_t>(),
+                                                    (int)n, 0, end_bit, ctx->stream));
+    DDX_TRY(ensure(ctx, ctx->sort_tmp, tmp_bytes));
+    {
+        ScopedTimer t(ctx, "csc_radix_sort");
+        DDX_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(ctx->sort_tmp.p, tmp_bytes, keys_in,
+                                                        ctx->sort_keys_out.as<int32_t>(), ctx->sort_vals_in.as<uint32_t>(),
+                                                        ctx->sort_vals_out.as<uint32_t>(), (int)n, 0, end_bit, ctx->stream));
+    }
+    {
+        ScopedTimer t(ctx, "csc_gather");
+        k_colptr_from_sorted<<<(unsigned)ceil_div(H + 1, 256), 256, 0, ctx->stream>>>(ctx->sort_keys_out.as<int32_t>(), n, H,
+                                                                                      colptr.as<int64_t>());
+        k_csc_gather<<<(unsigned)ceil_div(n, 256), 256, 0, ctx->stream>>>(ctx->sort_vals_out.as<uint32_t>(), n,
+                                                                          ctx->aug_indptr.as<int64_t>(), row_lo, row_hi,
+                                                                          ctx->aug_raw.as<float>(), rows.as<int32_t>(),
+                                                                          raws.as<float>());
+    }
+    DDX_HIP(ctx, hipGetLastError());
+    return DDX_OK;
+}
+
+// grow a buffer while keeping its first keep_bytes
+static int ensure_keep(ddx_ctx* ctx, DevBuf& b, size_t bytes, size_t keep_bytes) {
+    if (bytes <= b.cap && b.p) return DDX_OK;
+    DevBuf nb;
+    DDX_TRY(ensure(ctx, nb, bytes));
+    if (b.p && keep_bytes) {
+        hipError_t e = hipMemcpyAsync(nb.p, b.p, keep_bytes, hipMemcpyDeviceToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            release(ctx, nb);
+            return set_err(ctx, DDX_E_HIP, "device copy during growth failed: %s", hipGetErrorString(e));
+        }
+    }
+    release(ctx, b);
+    b = nb;
+    return DDX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage: upload counts
+// ------------------------------------------------------------------------------------------------
+int stage_upload_counts(ddx_ctx* ctx, int64_t N, int32_t H, const int64_t* indptr, const int32_t* indices,
+                        const float* data, bool from_device) {
+    const int64_t nnz = from_device ? ctx->nnz : indptr[N];
+    if (nnz >= (int64_t)1 << 31) return set_err(ctx, DDX_E_UNSUPPORTED, "more than 2^31-1 stored entries");
+    if (!from_device) {
+        // worst-case-ish room for the synthetic part (default boost_rate 0.25 needs ~0.5*nnz); grows on demand
+        const int64_t cap_s = nnz / 2 + nnz / 8 + 1024;
+        DDX_TRY(ensure(ctx, ctx->aug_indptr, sizeof(int64_t) * (N + N / 2 + 2)));
+        DDX_TRY(ensure(ctx, ctx->aug_indices, sizeof(int32_t) * (size_t)(nnz + cap_s)));
+        DDX_TRY(ensure(ctx, ctx->aug_raw, sizeof(float) * (size_t)(nnz + cap_s)));
+        DDX_TRY(ensure(ctx, ctx->aug_x, sizeof(float) * (size_t)(nnz + cap_s)));
+        ctx->cap_synth = cap_s;
+        DDX_HIP(ctx, hipMemcpyAsync(ctx->aug_indptr.p, indptr, sizeof(int64_t) * (N + 1), hipMemcpyHostToDevice, ctx->stream));
+        if (nnz) {
+            DDX_HIP(ctx, hipMemcpyAsync(ctx->aug_indices.p, indices, sizeof(int32_t) * nnz, hipMemcpyHostToDevice, ctx->stream));
+            DDX_HIP(ctx, hipMemcpyAsync(ctx->aug_raw.p, data, sizeof(float) * nnz, hipMemcpyHostToDevice, ctx->stream));
+        }
+        ctx->h_indptr.assign(indptr, indptr + N + 1);
+    }
+    ctx->N = N;
+    ctx->H = H;
+    ctx->nnz = nnz;
+    ctx->S = 0;
+    ctx->M = N;
+    ctx->have_synth = ctx->have_lognorm = ctx->scaled = ctx->have_emb = ctx->have_knn = false;
+    DDX_TRY(ensure(ctx, ctx->lib32, sizeof(float) * (N + N / 2 + 2)));
+    DDX_TRY(ensure(ctx, ctx->lib64, sizeof(double) * (N + N / 2 + 2)));
+    {
+        ScopedTimer t(ctx, "row_sums");
+        k_row_sums<<<(unsigned)ceil_div(N, 4), 256, 0, ctx->stream>>>(ctx->aug_indptr.as<int64_t>(), ctx->aug_raw.as<float>(), 0, N,
+                                                                      ctx->lib32.as<float>(), ctx->lib64.as<double>());
+    }
+    DDX_TRY(ensure(ctx, ctx->csc_o_row, sizeof(int32_t) * (size_t)(nnz + 1)));
+    DDX_TRY(ensure(ctx, ctx->csc_o_raw, sizeof(float) * (size_t)(nnz + 1)));
+    DDX_TRY(ensure(ctx, ctx->csc_o_x, sizeof(float) * (size_t)(nnz + 1)));
+    DDX_TRY(build_csc(ctx, 0, nnz, 0, N, ctx->csc_o_colptr, ctx->csc_o_row, ctx->csc_o_raw));
+    DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->have_counts = true;
+    return DDX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage: create doublets
+// ------------------------------------------------------------------------------------------------
+int stage_create_doublets(ddx_ctx* ctx, int64_t S, const int64_t* parents) {
+    const int64_t N = ctx->N;
+    // capacity from the host copy of the row pointer: |row p0| + |row p1| bounds each synthetic row
+    int64_t cap = 0;
+    for (int64_t s = 0; s < S; ++s) {
+        const int64_t a = parents[2 * s], b = parents[2 * s + 1];
+        cap += (ctx->h_indptr[a + 1] - ctx->h_indptr[a]) + (ctx->h_indptr[b + 1] - ctx->h_indptr[b]);
+    }
+    if (ctx->nnz + cap >= (int64_t)1 << 31) return set_err(ctx, DDX_E_UNSUPPORTED, "augmented matrix exceeds 2^31-1 entries");
+    if (cap > ctx->cap_synth || !ctx->aug_x.p) {
+        const size_t tot = (size_t)(ctx->nnz + cap + 1024);
+        DDX_TRY(ensure_keep(ctx, ctx->aug_indices, sizeof(int32_t) * tot, sizeof(int32_t) * ctx->nnz));
+        DDX_TRY(ensure_keep(ctx, ctx->aug_raw, sizeof(float) * tot, sizeof(float) * ctx->nnz));
+        DDX_TRY(ensure_keep(ctx, ctx->aug_x, sizeof(float) * tot, 0));
+        ctx->cap_synth = cap + 1024;
+    }
+    DDX_TRY(ensure_keep(ctx, ctx->aug_indptr, sizeof(int64_t) * (N + S + 2), sizeof(int64_t) * (N + 1)));
+    DDX_TRY(ensure_keep(ctx, ctx->lib32, sizeof(float) * (N + S + 2), sizeof(float) * N));
+    DDX_TRY(ensure_keep(ctx, ctx->lib64, sizeof(double) * (N + S + 2), sizeof(double) * N));
+    DDX_TRY(ensure(ctx, ctx->parents, sizeof(int64_t) * 2 * (S + 1)));
+    DDX_TRY(ensure(ctx, ctx->synth_counts, sizeof(int32_t) * (S + 1)));
+    DDX_TRY(ensure(ctx, ctx->csc_s_row, sizeof(int32_t) * (size_t)(ctx->cap_synth + 1)));
+    DDX_TRY(ensure(ctx, ctx->csc_s_raw, sizeof(float) * (size_t)(ctx->cap_synth + 1)));
+    DDX_TRY(ensure(ctx, ctx->csc_s_x, sizeof(float) * (size_t)(ctx->cap_synth + 1)));
+    ctx->S = S;
+    ctx->M = N + S;
+    ctx->have_lognorm = ctx->scaled = ctx->have_emb = ctx->have_knn = false;
+    if (S) {
+        DDX_HIP(ctx, hipMemcpyAsync(ctx->parents.p, parents, sizeof(int64_t) * 2 * S, hipMemcpyHostToDevice, ctx->stream));
+        {
+            ScopedTimer t(ctx, "doublet_count");
+            k_doublet_count<<<(unsigned)ceil_div(S, 4), 256, 0, ctx->stream>>>(ctx->aug_indptr.as<int64_t>(), ctx->aug_indices.as<int32_t>(),
+                                                                               ctx->aug_raw.as<float>(), ctx->parents.as<int64_t>(), S,
+                                                                               ctx->synth_counts.as<int32_t>());
+        }
+        k_scan_counts<<<1, 1024, 0, ctx->stream>>>(ctx->synth_counts.as<int32_t>(), S, ctx->nnz, ctx->aug_indptr.as<int64_t>() + N);
+        {
+            ScopedTimer t(ctx, "doublet_fill");
+            k_doublet_fill<<<(unsigned)S, 256, 0, ctx->stream>>>(ctx->aug_indptr.as<int64_t>(), ctx->aug_indices.as<int32_t>(),
+                                                                 ctx->aug_raw.as<float>(), ctx->parents.as<int64_t>(), N,
+                                                                 ctx->aug_indptr.as<int64_t>(), ctx->aug_indices.as<int32_t>(),
+                                                                 ctx->aug_raw.as<float>());
+        }
+        DDX_HIP(ctx, hipGetLastError());
+    }
+    ctx->have_synth = true;
+    return DDX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// normalisation
+// ------------------------------------------------------------------------------------------------
+// np.median of M float32 values from the ascending sort: middle element, or the float32 mean of the
+// two middle elements.
+__global__ void k_median_from_sorted(const float* __restrict__ sorted, int64_t M, float* __restrict__ med) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        if (M & 1) med[0] = sorted[M / 2];
+        else med[0] = __fdiv_rn(__fadd_rn(sorted[M / 2 - 1], sorted[M / 2]), 2.0f);
+    }
+}
+
+// the reference's element transform, evaluated in the reference's rounding order:
+//   normed = float32( v / (double)rowsum )      sklearn inplace_csr_row_normalize_l1 (rowsum==0: unchanged)
+//   scaled = normed * median                     float32 multiply                    (dd.py:293)
+//   x      = log(scaled + pc)  |  log1p(scaled)  float32 result                      (dd.py:295 / :297)
+// The log itself is evaluated in float64 and rounded once, i.e. the correctly rounded float32 value.
+__device__ __forceinline__ float lognorm_value(float v, double rowsum, float med, float pc, bool use_log1p) {
+    const float normed = (rowsum == 0.0) ? v : (float)((double)v / rowsum);
+    const float scaled = __fmul_rn(normed, med);
+    if (use_log1p) return (float)log1p((double)scaled);
+    return (float)log((double)__fadd_rn(scaled, pc));
+}
+
+__global__ void __launch_bounds__(256) k_lognorm_rows(const int64_t* __restrict__ indptr, const float* __restrict__ raw,
+                                                      const double* __restrict__ lib64, const float* __restrict__ med,
+                                                      float pc, int use_log1p, int64_t M, float* __restrict__ x) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int64_t b = indptr[row], e = indptr[row + 1];
+    const double s = lib64[row];
+    const float m = med[0];
+    for (int64_t p = b + lane; p < e; p += 64) x[p] = lognorm_value(raw[p], s, m, pc, use_log1p != 0);
+}
+
+__global__ void __launch_bounds__(256) k_lognorm_csc(const int32_t* __restrict__ rows, const float* __restrict__ raw,
+                                                     const int64_t* __restrict__ colptr, int32_t H,
+                                                     const double* __restrict__ lib64, const float* __restrict__ med,
+                                                     float pc, int use_log1p, float* __restrict__ x) {
+    const int64_t n = colptr[H];
+    const float m = med[0];
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x)
+        x[t] = lognorm_value(raw[t], lib64[rows[t]], m, pc, use_log1p != 0);
+}
+
+__global__ void k_fill_f32(float* out, int64_t n, float v) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = v;
+}
+
+// Per column j (one 256-thread block): deterministic float64 sums over the stored entries of both
+// column-major segments.  mode 0: colmean[j] = sum(x - z_j) / M.
+// mode 1 (scale statistics): stat[2j] = sum(x - z_j), stat[2j+1] = sum(float32(x*x)) , cnt via colptr.
+__global__ void __launch_bounds__(256) k_col_sums(const int64_t* __restrict__ cp_o, const float* __restrict__ x_o,
+                                                  const int64_t* __restrict__ cp_s, const float* __restrict__ x_s,
+                                                  const float* __restrict__ zcol, int64_t M, int mode,
+                                                  double* __restrict__ out) {
+    __shared__ double red[2][256];
+    const int j = blockIdx.x, tid = threadIdx.x;
+    const double z = (double)zcol[j];
+    double a = 0.0, b = 0.0;
+    for (int seg = 0; seg < 2; ++seg) {
+        const int64_t* cp = seg ? cp_s : cp_o;
+        const float* x = seg ? x_s : x_o;
+        const int64_t lo = cp[j], hi = cp[j + 1];
+        for (int64_t t = lo + tid; t < hi; t += 256) {
+            const float xv = x[t];
+            a += (double)xv - z;
+            if (mode) b += (double)__fmul_rn(xv, xv);
+        }
+    }
+    red[0][tid] = a;
+    red[1][tid] = b;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off) {
+            red[0][tid] += red[0][tid + off];
+            red[1][tid] += red[1][tid + off];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        if (mode == 0) out[j] = red[0][0] / (double)M;
+        else { out[2 * j] = red[0][0]; out[2 * j + 1] = red[1][0]; }
+    }
+}
+
+int stage_lognormalise(ddx_ctx* ctx, float pseudocount) {
+    const int64_t N = ctx->N, S = ctx->S, M = ctx->M;
+    const int32_t H = ctx->H;
+    // exact number of synthetic entries (one 8-byte read-back per iteration; sizes the radix sort)
+    int64_t nnz_aug = 0;
+    DDX_HIP(ctx, hipMemcpyAsync(&nnz_aug, ctx->aug_indptr.as<int64_t>() + M, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const int64_t nnz_s = nnz_aug - ctx->nnz;
+    if (S) {
+        ScopedTimer t(ctx, "row_sums");
+        k_row_sums<<<(unsigned)ceil_div(S, 4), 256, 0, ctx->stream>>>(ctx->aug_indptr.as<int64_t>(), ctx->aug_raw.as<float>(), N, S,
+                                                                      ctx->lib32.as<float>(), ctx->lib64.as<double>());
+    }
+    // median of the augmented library sizes
+    DDX_TRY(ensure(ctx, ctx->lib_sorted, sizeof(float) * M));
+    DDX_TRY(ensure(ctx, ctx->median, 256));
+    {
+        size_t tmp_bytes = 0;
+        DDX_HIP(ctx, hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, ctx->lib32.as<float>(), ctx->lib_sorted.as<float>(), (int)M, 0, 32, ctx->stream));
+        DDX_TRY(ensure(ctx, ctx->sort_tmp, tmp_bytes));
+        ScopedTimer t(ctx, "median");
+        DDX_HIP(ctx, hipcub::DeviceRadixSort::SortKeys(ctx->sort_tmp.p, tmp_bytes, ctx->lib32.as<float>(), ctx->lib_sorted.as<float>(), (int)M, 0, 32, ctx->stream));
+        k_median_from_sorted<<<1, 64, 0, ctx->stream>>>(ctx->lib_sorted.as<float>(), M, ctx->median.as<float>());
+    }
+    // column-major mirror of the synthetic rows
+    DDX_TRY(build_csc(ctx, ctx->nnz, nnz_s, N, M, ctx->csc_s_colptr, ctx->csc_s_row, ctx->csc_s_raw));
+    const int use_log1p = (pseudocount == 1.0f);
+    {
+        ScopedTimer t(ctx, "lognorm_rows");
+        k_lognorm_rows<<<(unsigned)ceil_div(M, 4), 256, 0, ctx->stream>>>(ctx->aug_indptr.as<int64_t>(), ctx->aug_raw.as<float>(),
+                                                                          ctx->lib64.as<double>(), ctx->median.as<float>(), pseudocount,
+                                                                          use_log1p, M, ctx->aug_x.as<float>());
+    }
+    {
+        ScopedTimer t(ctx, "lognorm_cols");
+        k_lognorm_csc<<<2048, 256, 0, ctx->stream>>>(ctx->csc_o_row.as<int32_t>(), ctx->csc_o_raw.as<float>(), ctx->csc_o_colptr.as<int64_t>(),
+                                                     H, ctx->lib64.as<double>(), ctx->median.as<float>(), pseudocount, use_log1p,
+                                                     ctx->csc_o_x.as<float>());
+        k_lognorm_csc<<<2048, 256, 0, ctx->stream>>>(ctx->csc_s_row.as<int32_t>(), ctx->csc_s_raw.as<float>(), ctx->csc_s_colptr.as<int64_t>(),
+                                                     H, ctx->lib64.as<double>(), ctx->median.as<float>(), pseudocount, use_log1p,
+                                                     ctx->csc_s_x.as<float>());
+    }
+    DDX_TRY(ensure(ctx, ctx->zcol, sizeof(float) * H));
+    DDX_TRY(ensure(ctx, ctx->colmean, sizeof(double) * H));
+    const float z = use_log1p ? 0.f : (float)std::log((double)pseudocount);
+    k_fill_f32<<<(unsigned)ceil_div(H, 256), 256, 0, ctx->stream>>>(ctx->zcol.as<float>(), H, z);
+    {
+        ScopedTimer t(ctx, "col_sums");
+        k_col_sums<<<(unsigned)H, 256, 0, ctx->stream>>>(ctx->csc_o_colptr.as<int64_t>(), ctx->csc_o_x.as<float>(), ctx->csc_s_colptr.as<int64_t>(),
+                                                         ctx->csc_s_x.as<float>(), ctx->zcol.as<float>(), M, 0, ctx->colmean.as<double>());
+    }
+    DDX_HIP(ctx, hipGetLastError());
+    ctx->pseudocount = pseudocount;
+    ctx->have_lognorm = true;
+    ctx->scaled = false;
+    ctx->have_emb = ctx->have_knn = false;
+    return DDX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// standard scaling (restated scanpy pp.scale; see oracle/dd_oracle.py:scale_like_scanpy)
+// ------------------------------------------------------------------------------------------------
+// per column: mean (f64), unbiased variance from the mean of float32-rounded squares, std==0 -> 1
+__global__ void k_scale_stats(const double* __restrict__ stat, const int64_t* __restrict__ cp_o,
+                              const int64_t* __restrict__ cp_s, const float* __restrict__ zcol, int64_t M, int32_t H,
+                              double* __restrict__ mean_out, double* __restrict__ std_out) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= H) return;
+    const double z = (double)zcol[j];
+    const double cnt = (double)((cp_o[j + 1] - cp_o[j]) + (cp_s[j + 1] - cp_s[j]));
+    const double zz = (double)__fmul_rn(zcol[j], zcol[j]);
+    const double mean = z + stat[2 * j] / (double)M;
+    const double mean_sq = (stat[2 * j + 1] + ((double)M - cnt) * zz) / (double)M;
+    double var = mean_sq - mean * mean;
+    if (M != 1) var *= (double)M / (double)(M - 1);
+    double sd = (var > 0.0) ? sqrt(var) : 0.0;  // (var < 0 only by rounding of a constant column)
+    if (sd == 0.0) sd = 1.0;
+    mean_out[j] = mean;
+    std_out[j] = sd;
+}
+
+__device__ __forceinline__ float scale_value(float x, double mean, double sd, float maxv) {
+    const float r1 = (float)((double)x - mean);
+    float r2 = (float)((double)r1 / sd);
+    if (maxv > 0.f) r2 = fminf(fmaxf(r2, -maxv), maxv);
+    return r2;
+}
+
+__global__ void k_scale_rows(const int32_t* __restrict__ cols, int64_t n_ptr_index, const int64_t* __restrict__ indptr,
+                             const double* __restrict__ mean, const double* __restrict__ sd, float maxv,
+                             float* __restrict__ x) {
+    const int64_t n = indptr[n_ptr_index];
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t j = cols[t];
+        x[t] = scale_value(x[t], mean[j], sd[j], maxv);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_scale_cols(const int64_t* __restrict__ cp, const double* __restrict__ mean,
+                                                    const double* __restrict__ sd, float maxv, float* __restrict__ x) {
+    const int j = blockIdx.x;
+    const double m = mean[j], s = sd[j];
+    for (int64_t t = cp[j] + threadIdx.x; t < cp[j + 1]; t += 256) x[t] = scale_value(x[t], m, s, maxv);
+}
+
+__global__ void k_scale_zcol(const double* __restrict__ mean, const double* __restrict__ sd, float maxv, int32_t H,
+                             float* __restrict__ zcol) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < H) zcol[j] = scale_value(zcol[j], mean[j], sd[j], maxv);
+}
+
+int stage_scale(ddx_ctx* ctx, float max_value) {
+    const int32_t H = ctx->H;
+    const int64_t M = ctx->M;
+    DDX_TRY(ensure(ctx, ctx->colstat, sizeof(double) * 4 * H));
+    double* stat = ctx->colstat.as<double>();
+    double* mean = stat + 2 * H;
+    double* sd = stat + 3 * H;
+    ScopedTimer t(ctx, "scale");
+    k_col_sums<<<(unsigned)H, 256, 0, ctx->stream>>>(ctx->csc_o_colptr.as<int64_t>(), ctx->csc_o_x.as<float>(), ctx->csc_s_colptr.as<int64_t>(),
+                                                     ctx->csc_s_x.as<float>(), ctx->zcol.as<float>(), M, 1, stat);
+    k_scale_stats<<<(unsigned)ceil_div(H, 256), 256, 0, ctx->stream>>>(stat, ctx->csc_o_colptr.as<int64_t>(), ctx->csc_s_colptr.as<int64_t>(),
+                                                                       ctx->zcol.as<float>(), M, H, mean, sd);
+    k_scale_rows<<<2048, 256, 0, ctx->stream>>>(ctx->aug_indices.as<int32_t>(), M, ctx->aug_indptr.as<int64_t>(), mean, sd, max_value,
+                                                ctx->aug_x.as<float>());
+    k_scale_cols<<<(unsigned)H, 256, 0, ctx->stream>>>(ctx->csc_o_colptr.as<int64_t>(), mean, sd, max_value, ctx->csc_o_x.as<float>());
+    k_scale_cols<<<(unsigned)H, 256, 0, ctx->stream>>>(ctx->csc_s_colptr.as<int64_t>(), mean, sd, max_value, ctx->csc_s_x.as<float>());
+    k_scale_zcol<<<(unsigned)ceil_div(H, 256), 256, 0, ctx->stream>>>(mean, sd, max_value, H, ctx->zcol.as<float>());
+    k_col_sums<<<(unsigned)H, 256, 0, ctx->stream>>>(ctx->csc_o_colptr.as<int64_t>(), ctx->csc_o_x.as<float>(), ctx->csc_s_colptr.as<int64_t>(),
+                                                     ctx->csc_s_x.as<float>(), ctx->zcol.as<float>(), M, 0, ctx->colmean.as<double>());
+    DDX_HIP(ctx, hipGetLastError());
+    ctx->scaled = true;
+    ctx->have_emb = ctx->have_knn = false;
+    return DDX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// test helper: densify rows of the matrix handed to PCA
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_dense_rows(const int64_t* __restrict__ indptr, const int32_t* __restrict__ cols,
+                                                    const float* __restrict__ x, const float* __restrict__ zcol, int32_t H,
+                                                    int64_t row0, float* __restrict__ out) {
+    const int64_t r = blockIdx.x;
+    float* o = out + r * (int64_t)H;
+    for (int j = threadIdx.x; j < H; j += 256) o[j] = zcol[j];
+    __syncthreads();
+    const int64_t b = indptr[row0 + r], e = indptr[row0 + r + 1];
+    for (int64_t p = b + threadIdx.x; p < e; p += 256) o[cols[p]] = x[p];
+}
+
+int stage_dense_rows(ddx_ctx* ctx, int64_t row0, int64_t nrows, float* out_host) {
+    DevBuf tmp;
+    DDX_TRY(ensure(ctx, tmp, sizeof(float) * nrows * ctx->H));
+    k_dense_rows<<<(unsigned)nrows, 256, 0, ctx->stream>>>(ctx->aug_indptr.as<int64_t>(), ctx->aug_indices.as<int32_t>(), ctx->aug_x.as<float>(),
+                                                           ctx->zcol.as<float>(), ctx->H, row0, tmp.as<float>());
+    hipError_t e = hipMemcpyAsync(out_host, tmp.p, sizeof(float) * nrows * ctx->H, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    release(ctx, tmp);
+    if (e != hipSuccess) return set_err(ctx, DDX_E_HIP, "dense rows copy failed: %s", hipGetErrorString(e));
+    return DDX_OK;
+}
+
+}  // namespace ddx

@@ -1,0 +1,228 @@
+// Host C++ community detection for libddx: deterministic multi-level modularity optimisation
+// (Blondel et al. 2008) with a resolution parameter.  It stands in for the native Louvain code the
+// reference reaches through phenograph.cluster (dd.py:320-322) and sc.tl.louvain (dd.py:337-342).
+// The specification -- visiting order, tie breaking, float64 operation order -- is the pure-Python
+// text in oracle/louvain_ref.py; this file must reproduce it bit for bit (tests/test_louvain.py).
+// Compiled with -ffp-contract=off so that no multiply-add is fused.
+#include <algorithm>
+#include <cstdint>
+#include <vector>
+
+#include "../../include/ddx.h"
+
+namespace {
+
+struct SplitMix64 {
+    uint64_t state;
+    explicit SplitMix64(uint64_t seed) : state(seed) {}
+    uint64_t next() {
+        state += 0x9E3779B97F4A7C15ULL;
+        uint64_t z = state;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+        return z ^ (z >> 31);
+    }
+};
+
+struct Graph {
+    std::vector<int64_t> indptr;
+    std::vector<int32_t> indices;
+    std::vector<double> weights;
+    int64_t n() const { return (int64_t)indptr.size() - 1; }
+};
+
+constexpr double kMinGain = 1e-6;
+
+double quality(const std::vector<double>& in_, const std::vector<double>& tot, double m2, double gamma) {
+    double q = 0.0;
+    for (size_t c = 0; c < tot.size(); ++c) {
+        if (tot[c] > 0.0) {
+            const double b = tot[c] / m2;
+            q += in_[c] / m2 - gamma * b * b;
+        }
+    }
+    return q;
+}
+
+// one level of local moving; returns true when any node moved
+bool one_level(const Graph& g, double gamma, SplitMix64& rng, std::vector<int32_t>& comm, double* q_out) {
+    const int64_t n = g.n();
+    std::vector<double> deg(n, 0.0), loops(n, 0.0);
+    for (int64_t v = 0; v < n; ++v) {
+        double s = 0.0;
+        for (int64_t e = g.indptr[v]; e < g.indptr[v + 1]; ++e) {
+            s += g.weights[e];
+            if (g.indices[e] == v) loops[v] += g.weights[e];
+        }
+        deg[v] = s;
+    }
+    double m2 = 0.0;
+    for (int64_t v = 0; v < n; ++v) m2 += deg[v];
+    comm.resize(n);
+    for (int64_t v = 0; v < n; ++v) comm[v] = (int32_t)v;
+    if (m2 == 0.0) {
+        if (q_out) *q_out = 0.0;
+        return false;
+    }
+    std::vector<double> tot(deg), in_(loops);
+    std::vector<int32_t> order(n);
+    for (int64_t i = 0; i < n; ++i) order[i] = (int32_t)i;
+    for (int64_t i = n - 1; i > 0; --i) {
+        const uint64_t j = rng.next() % (uint64_t)(i + 1);
+        std::swap(order[i], order[j]);
+    }
+    std::vector<double> neigh_w(n, -1.0);
+    std::vector<int32_t> seen;
+    seen.reserve(256);
+    bool improved = false;
+    double new_q = quality(in_, tot, m2, gamma);
+    while (true) {
+        const double cur_q = new_q;
+        int64_t moves = 0;
+        for (int64_t oi = 0; oi < n; ++oi) {
+            const int32_t v = order[oi];
+            const int32_t c_old = comm[v];
+            const double kv = deg[v];
+            seen.clear();
+            seen.push_back(c_old);
+            neigh_w[c_old] = 0.0;
+            for (int64_t e = g.indptr[v]; e < g.indptr[v + 1]; ++e) {
+                const int32_t u = g.indices[e];
+                if (u == v) continue;
+                const int32_t c = comm[u];
+                if (neigh_w[c] == -1.0) {
+                    neigh_w[c] = 0.0;
+                    seen.push_back(c);
+                }
+                neigh_w[c] += g.weights[e];
+            }
+            tot[c_old] -= kv;
+            in_[c_old] -= 2.0 * neigh_w[c_old] + loops[v];
+            int32_t best = c_old;
+            double best_gain = neigh_w[c_old] - gamma * tot[c_old] * kv / m2;
+            for (size_t t = 1; t < seen.size(); ++t) {
+                const int32_t c = seen[t];
+                const double gn = neigh_w[c] - gamma * tot[c] * kv / m2;
+                if (gn > best_gain) {
+                    best_gain = gn;
+                    best = c;
+                }
+            }
+            tot[best] += kv;
+            in_[best] += 2.0 * neigh_w[best] + loops[v];
+            comm[v] = best;
+            if (best != c_old) ++moves;
+            for (int32_t c : seen) neigh_w[c] = -1.0;
+        }
+        new_q = quality(in_, tot, m2, gamma);
+        if (moves > 0) improved = true;
+        if (!(moves > 0 && new_q - cur_q > kMinGain)) break;
+    }
+    if (q_out) *q_out = new_q;
+    return improved;
+}
+
+// super-node graph; communities renumbered by ascending id; renum[c_old] = new id or -1
+void aggregate(const Graph& g, const std::vector<int32_t>& comm, Graph& out, std::vector<int32_t>& renum) {
+    const int64_t n = g.n();
+    renum.assign(n, -1);
+    for (int64_t v = 0; v < n; ++v) renum[comm[v]] = 0;
+    int32_t k = 0;
+    for (int64_t c = 0; c < n; ++c)
+        if (renum[c] == 0) renum[c] = k++;
+    // members grouped by new id, ascending node order inside a group (counting sort)
+    std::vector<int64_t> start(k + 1, 0);
+    for (int64_t v = 0; v < n; ++v) start[renum[comm[v]] + 1]++;
+    for (int32_t c = 0; c < k; ++c) start[c + 1] += start[c];
+    std::vector<int32_t> members(n);
+    {
+        std::vector<int64_t> cur(start.begin(), start.end() - 1);
+        for (int64_t v = 0; v < n; ++v) members[cur[renum[comm[v]]]++] = (int32_t)v;
+    }
+    out.indptr.assign(1, 0);
+    out.indices.clear();
+    out.weights.clear();
+    std::vector<double> acc(k, 0.0);
+    std::vector<char> touched(k, 0);
+    std::vector<int32_t> tl;
+    for (int32_t cn = 0; cn < k; ++cn) {
+        tl.clear();
+        for (int64_t mi = start[cn]; mi < start[cn + 1]; ++mi) {
+            const int32_t v = members[mi];
+            for (int64_t e = g.indptr[v]; e < g.indptr[v + 1]; ++e) {
+                const int32_t t = renum[comm[g.indices[e]]];
+                if (!touched[t]) {
+                    touched[t] = 1;
+                    tl.push_back(t);
+                    acc[t] = g.weights[e];
+                } else {
+                    acc[t] += g.weights[e];
+                }
+            }
+        }
+        std::sort(tl.begin(), tl.end());
+        for (int32_t t : tl) {
+            out.indices.push_back(t);
+            out.weights.push_back(acc[t]);
+            touched[t] = 0;
+        }
+        out.indptr.push_back((int64_t)out.indices.size());
+    }
+}
+
+}  // namespace
+
+extern "C" int ddx_louvain(int64_t n_nodes, const int64_t* indptr, const int32_t* indices, const double* weights,
+                           double gamma, uint64_t seed, int32_t* labels_out, double* quality_out) {
+    if (n_nodes < 0 || !indptr || !labels_out) return DDX_E_ARG;
+    if (n_nodes == 0) return DDX_OK;
+    const int64_t nnz = indptr[n_nodes];
+    if (nnz > 0 && (!indices || !weights)) return DDX_E_ARG;
+    Graph g;
+    g.indptr.assign(indptr, indptr + n_nodes + 1);
+    g.indices.assign(indices, indices + nnz);
+    g.weights.assign(weights, weights + nnz);
+    for (int64_t e = 0; e < nnz; ++e)
+        if (g.indices[e] < 0 || g.indices[e] >= n_nodes) return DDX_E_ARG;
+    SplitMix64 rng(seed);
+    std::vector<int32_t> membership(n_nodes);
+    for (int64_t v = 0; v < n_nodes; ++v) membership[v] = (int32_t)v;
+    std::vector<int32_t> comm, renum;
+    double q = 0.0;
+    while (true) {
+        const bool improved = one_level(g, gamma, rng, comm, &q);
+        Graph next;
+        aggregate(g, comm, next, renum);
+        for (int64_t v = 0; v < n_nodes; ++v) membership[v] = renum[comm[membership[v]]];
+        g.indptr.swap(next.indptr);
+        g.indices.swap(next.indices);
+        g.weights.swap(next.weights);
+        if (!improved) break;
+    }
+    for (int64_t v = 0; v < n_nodes; ++v) labels_out[v] = membership[v];
+    if (quality_out) *quality_out = q;
+    return DDX_OK;
+}
+
+extern "C" int ddx_relabel_by_size(int64_t n, const int32_t* labels, int64_t min_cluster_size, int64_t* out) {
+    if (n < 0 || (n > 0 && (!labels || !out))) return DDX_E_ARG;
+    int32_t maxl = -1;
+    for (int64_t i = 0; i < n; ++i) {
+        if (labels[i] < 0) return DDX_E_ARG;
+        maxl = std::max(maxl, labels[i]);
+    }
+    std::vector<int64_t> count((size_t)maxl + 1, 0);
+    for (int64_t i = 0; i < n; ++i) count[labels[i]]++;
+    std::vector<int32_t> order;
+    for (int32_t c = 0; c <= maxl; ++c)
+        if (count[c] > 0) order.push_back(c);
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return count[a] > count[b]; });
+    std::vector<int64_t> map((size_t)maxl + 1, -1);
+    int64_t next = 0;
+    for (int32_t c : order) {
+        if (min_cluster_size >= 0 && count[c] <= min_cluster_size) map[c] = -1;
+        else map[c] = next++;
+    }
+    for (int64_t i = 0; i < n; ++i) out[i] = map[labels[i]];
+    return DDX_OK;
+}

@@ -1,0 +1,156 @@
+/* ddx.h -- C-ABI of libddx.so: the MI355X (gfx950) implementation of DoubletDetection's
+ * BoostClassifier.fit() boosting loop.
+ *
+ * The reference has no FFI of its own: its hot path is pure Python that calls numpy / scipy /
+ * scikit-learn / scanpy / phenograph.  The boundary a maintainer would bind is therefore the set of
+ * per-stage calls made from /root/reference/doubletdetection/doubletdetection.py (abbreviated dd.py);
+ * every entry point below cites the reference lines it replaces.  INTEGRATION.md shows the ctypes
+ * stub that goes into the reference in place of each cited block.
+ *
+ * Conventions
+ *   - plain C types only; caller-owned host buffers are passed as pointers + explicit sizes;
+ *   - every function returns 0 on success, a negative DDX_E_* code otherwise;
+ *     ddx_last_error(ctx) returns a human-readable message for the last failure on that context
+ *     (ctx == NULL: last failure of a context-less call on the calling thread);
+ *   - a ddx_ctx owns one GPU, one HIP stream and all device buffers; contexts are independent and
+ *     may be driven from different host threads (one process per GPU is the intended deployment);
+ *   - device results stay resident between stages; the ddx_get_* calls copy intermediates back for
+ *     stage-wise parity tests and are not needed in production;
+ *   - no C++ exceptions cross the boundary; no global mutable state besides the thread-local error.
+ *
+ * Shapes: N cells, H genes (after HVG restriction), S synthetic doublets, M = N + S, C components,
+ *         L = C + n_oversamples sketch width.
+ */
+#ifndef DDX_H
+#define DDX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DDX_ABI_VERSION 1
+
+#define DDX_OK 0
+#define DDX_E_ARG -1      /* invalid argument / stage called out of order */
+#define DDX_E_HIP -2      /* HIP runtime error */
+#define DDX_E_NOMEM -3    /* allocation failure */
+#define DDX_E_NUMERIC -4  /* numerical breakdown (e.g. rank-deficient sketch) */
+#define DDX_E_UNSUPPORTED -5
+
+typedef struct ddx_ctx ddx_ctx;
+
+/* ---- library / context -------------------------------------------------------------------- */
+int ddx_abi_version(void);
+const char* ddx_last_error(const ddx_ctx* ctx);
+int ddx_device_count(int* count);
+int ddx_create(int device, ddx_ctx** out);
+int ddx_destroy(ddx_ctx* ctx);
+int ddx_synchronize(ddx_ctx* ctx);
+/* bytes of device memory currently held by the context */
+int ddx_device_bytes(const ddx_ctx* ctx, int64_t* bytes);
+
+/* ---- fit() prologue: dd.py:165-184 ---------------------------------------------------------
+ * ddx_gene_variances replaces dd.py:167-170: float32 population variance per gene,
+ *   mean(x^2) - mean(x)^2, with scipy's evaluation order (values pre-multiplied by float32(1/N),
+ *   per-gene sequential float32 accumulation in row order) so that the ordering used by
+ *   argsort (dd.py:171) is bit-identical.  raw CSR is N x G (all genes), canonical (sorted indices).
+ * ddx_upload_counts replaces dd.py:178-184: takes the HVG-restricted float32 CSR (N x H, sorted
+ *   indices), keeps it resident, and memoises float32 library sizes (row sums accumulated
+ *   sequentially in float32, scipy csr_matvec order) and the float64 L1 row norms used by
+ *   sklearn's inplace_csr_row_normalize_l1.
+ * ddx_select_columns replaces dd.py:174-176 (tocsc()[:, top].tocsr()): restricts the CSR uploaded
+ *   by ddx_upload_raw to the given columns, renumbered to their position in `cols`, rows re-sorted. */
+int ddx_upload_raw(ddx_ctx* ctx, int64_t n_cells, int32_t n_genes, const int64_t* indptr,
+                   const int32_t* indices, const float* data);
+int ddx_gene_variances(ddx_ctx* ctx, float* var_out /* [G] */);
+int ddx_select_columns(ddx_ctx* ctx, const int64_t* cols, int32_t n_cols);
+int ddx_upload_counts(ddx_ctx* ctx, int64_t n_cells, int32_t n_genes, const int64_t* indptr,
+                      const int32_t* indices, const float* data);
+int ddx_get_counts_nnz(ddx_ctx* ctx, int64_t* nnz);
+int ddx_get_counts(ddx_ctx* ctx, int64_t* indptr /* [N+1] */, int32_t* indices, float* data);
+int ddx_get_lib_size(ddx_ctx* ctx, float* lib_out /* [N] */);
+int ddx_get_normed(ddx_ctx* ctx, float* normed_out /* [nnz] */);
+
+/* ---- _createDoublets(): dd.py:385-402 -------------------------------------------------------
+ * parents is the int64 [S,2] array drawn by rng.choice on the host (dd.py:394).  Builds the CSR
+ * raw[p0] + raw[p1] (sorted indices, exact zeros dropped -- scipy csr_plus_csr semantics). */
+int ddx_create_doublets(ddx_ctx* ctx, int64_t n_synth, const int64_t* parents);
+int ddx_get_synth_nnz(ddx_ctx* ctx, int64_t* nnz);
+int ddx_get_synth(ddx_ctx* ctx, int64_t* indptr /* [S+1] */, int32_t* indices, float* data);
+
+/* ---- default normalisation: dd.py:286-298 ---------------------------------------------------
+ * Computes synthetic library sizes, the float32 median of the augmented library sizes
+ * (np.median semantics), and for every stored entry of the augmented matrix
+ *   x = log( float32( float32(v / (double)rowsum) * median ) + float32(pseudocount) )   (pseudocount != 1)
+ *   x = log1p( float32( float32(v / (double)rowsum) * median ) )                        (pseudocount == 1)
+ * The dense matrix of dd.py:295 is never materialised: entries that are zero in the counts all
+ * equal log(pseudocount) and are carried as one scalar. */
+int ddx_lognormalise(ddx_ctx* ctx, float pseudocount);
+int ddx_get_aug_lib(ddx_ctx* ctx, float* lib_out /* [M] */, float* median_out);
+int ddx_get_aug_nnz(ddx_ctx* ctx, int64_t* nnz);
+int ddx_get_aug_values(ddx_ctx* ctx, float* values_out /* [nnz_aug], CSR order */,
+                       float* zero_value_out /* [H] value of unstored entries per column */);
+/* test helper: rows [row0, row0+nrows) of the matrix handed to PCA, densified, row-major float32 */
+int ddx_get_aug_dense_rows(ddx_ctx* ctx, int64_t row0, int64_t nrows, float* out /* [nrows*H] */);
+
+/* ---- sc.pp.scale(max_value): dd.py:302-303 --------------------------------------------------
+ * per-gene float64 mean / unbiased variance over all M rows (implicit zeros included), std==0 -> 1,
+ * (x-mean)/std with float32 rounding after each step, symmetric clip to [-max_value, max_value];
+ * max_value <= 0 means no clipping. */
+int ddx_scale(ddx_ctx* ctx, float max_value);
+
+/* ---- sc.tl.pca(svd_solver="auto") -> sklearn randomized PCA: dd.py:305-314 -------------------
+ * q0: the host-drawn start matrix RandomState(seed).normal(size=(q0_rows, L)) as float64 row-major;
+ *     q0_rows must be H when M >= H and M when M < H (sklearn's transpose rule).
+ * n_iter < 0 selects sklearn's "auto" (7 if C < 0.1*min(M,H) else 4).
+ * Produces the M x C float32 embedding (U*S, sign-fixed on the components) on the device. */
+int ddx_pca(ddx_ctx* ctx, int32_t n_components, int32_t n_oversamples, int32_t n_iter,
+            const double* q0, int64_t q0_rows);
+int ddx_get_embedding(ddx_ctx* ctx, float* emb_out /* [M*C] row-major */);
+int ddx_get_embedding_f64(ddx_ctx* ctx, double* emb_out /* [M*C] */, double* singular_values /* [C] */);
+/* stage isolation: feed an embedding computed elsewhere to the kNN stage */
+int ddx_set_embedding(ddx_ctx* ctx, const float* emb, int64_t n_rows, int32_t n_components);
+
+/* ---- kNN: phenograph.cluster / sc.pp.neighbors: dd.py:317-336 --------------------------------
+ * exact Euclidean k nearest neighbours over the embedding, float64 distances, ordering by
+ * (distance, index).  include_self = 1 reproduces scanpy's n_neighbors convention (the point itself
+ * is a candidate); include_self = 0 reproduces phenograph (self removed). */
+int ddx_knn(ddx_ctx* ctx, int32_t k, int32_t include_self);
+int ddx_get_knn(ddx_ctx* ctx, int32_t* idx_out /* [M*k] */, double* dist_out /* [M*k] or NULL */);
+
+/* ---- graph construction (device) ------------------------------------------------------------
+ * mode 0: PhenoGraph Jaccard graph, prune=True  (mutual kNN, weight J_ij*J_ji)
+ * mode 1: PhenoGraph Jaccard graph, prune=False ((J + J^T)/2)
+ * mode 2: scanpy neighbour topology, unit weights (union of kNN relations, self excluded)
+ * Result: symmetric CSR on the host, fetched with ddx_get_graph. */
+int ddx_build_graph(ddx_ctx* ctx, int32_t mode);
+int ddx_get_graph_size(ddx_ctx* ctx, int64_t* n_nodes, int64_t* n_entries);
+int ddx_get_graph(ddx_ctx* ctx, int64_t* indptr, int32_t* indices, double* weights);
+
+/* ---- community detection (host C++, context-free; see oracle/louvain_ref.py for the spec) ----
+ * replaces the Louvain stage inside phenograph.cluster / sc.tl.louvain (dd.py:320-322, 337-342). */
+int ddx_louvain(int64_t n_nodes, const int64_t* indptr, const int32_t* indices, const double* weights,
+                double gamma, uint64_t seed, int32_t* labels_out /* [n_nodes] */, double* quality_out);
+/* labels 0..K-1 by descending size (ties: smaller label first); communities with size <=
+ * min_cluster_size become -1 (pass a negative min_cluster_size to keep all). */
+int ddx_relabel_by_size(int64_t n, const int32_t* labels, int64_t min_cluster_size, int64_t* out);
+
+/* ---- scoring: dd.py:344-383 ------------------------------------------------------------------ */
+int ddx_hypergeom_logsf(int64_t k, int64_t M, int64_t n, int64_t N, double* out);
+int ddx_score_communities(const int64_t* full /* [M] */, int64_t n_aug, int64_t n_cells,
+                          double* scores /* [N] */, double* log_p /* [N] */);
+
+/* ---- per-stage device timing (HIP events on the context's stream) ----------------------------- */
+int ddx_timing_enable(ddx_ctx* ctx, int32_t on);
+int ddx_timing_reset(ddx_ctx* ctx);
+/* number of distinct kernels timed so far */
+int ddx_timing_count(ddx_ctx* ctx, int32_t* n);
+/* i-th record: name (NUL-terminated, at most 63 chars), launches, total milliseconds */
+int ddx_timing_get(ddx_ctx* ctx, int32_t i, char* name_out /* [64] */, int64_t* launches, double* total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DDX_H */

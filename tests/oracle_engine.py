@@ -1,0 +1,44 @@
+"""Test-only engine: the oracle's stages behind the product's engine interface, so that the host
+logic of BoostClassifier (validation, RNG stream order, sharding, gather, predict) can be exercised on
+machines without a GPU.  Never used by the product."""
+import numpy as np
+
+from oracle import dd_oracle as orc
+
+
+class OracleEngine:
+    def __init__(self, device):
+        self.device = device
+
+    def close(self):
+        pass
+
+    def upload(self, csr):
+        self.raw = csr.copy()
+        self.lib = orc.library_sizes(self.raw)
+        self.normed = orc.l1_normalise_rows(self.raw)
+
+    def run_iteration(self, parents, pseudocount, standard_scaling, n_components, q0, knn_k, include_self, graph_mode):
+        synth = orc.create_doublets(self.raw, parents)
+        aug, _, _ = orc.lognormalise(self.normed, self.lib, synth, pseudocount)
+        if standard_scaling:
+            aug = orc.scale_like_scanpy(aug, 15)
+        # the product passes the start matrix it drew; the oracle draws the same one from the seed
+        emb = orc.randomized_pca_f64(aug, n_components, self.seed)[0].astype(np.float32)
+        idx, _ = orc.knn_bruteforce_f64(emb, knn_k, include_self)
+        if graph_mode == 2:
+            G = orc.union_knn_graph(idx)
+        else:
+            G = orc.jaccard_graph(idx, prune=(graph_mode == 0))
+        return G.indptr.astype(np.int64), G.indices.astype(np.int32), G.data.astype(np.float64)
+
+    def timings(self):
+        return {}
+
+
+def make_engine_factory(seed):
+    def factory(device):
+        e = OracleEngine(device)
+        e.seed = seed
+        return e
+    return factory

@@ -1,0 +1,150 @@
+"""Host logic of the drop-in BoostClassifier (no GPU): API surface, validation, warnings, RNG stream,
+predict / doublet_score against the reference's golden outputs, end-to-end equality with the reference
+run when the device stages are supplied by the oracle engine."""
+import inspect
+import warnings
+
+import numpy as np
+import pytest
+
+from conftest import csr_from, load_golden
+from doubletdetection_amd import BoostClassifier
+from oracle_engine import make_engine_factory
+
+
+def test_constructor_signature_matches_reference():
+    # doubletdetection.py:73-88
+    sig = inspect.signature(BoostClassifier.__init__)
+    want = [("boost_rate", 0.25), ("n_components", 30), ("n_top_var_genes", 10000), ("replace", False),
+            ("clustering_algorithm", "phenograph"), ("clustering_kwargs", None), ("n_iters", 10),
+            ("normalizer", None), ("pseudocount", 0.1), ("random_state", 0), ("verbose", False),
+            ("standard_scaling", False), ("n_jobs", 1)]
+    params = list(sig.parameters.values())[1:]
+    positional = [p for p in params if p.kind == p.POSITIONAL_OR_KEYWORD]
+    assert [(p.name, p.default) for p in positional] == want
+    assert all(p.kind == p.KEYWORD_ONLY for p in params[len(want):])
+    assert list(inspect.signature(BoostClassifier.predict).parameters)[1:] == ["p_thresh", "voter_thresh"]
+    assert inspect.signature(BoostClassifier.predict).parameters["p_thresh"].default == 1e-7
+    assert inspect.signature(BoostClassifier.predict).parameters["voter_thresh"].default == 0.9
+
+
+def test_validation_and_warnings():
+    # tests/test_package.py:45-48
+    with pytest.raises(ValueError):
+        BoostClassifier(n_iters=2, clustering_algorithm="my_clusters", standard_scaling=True)
+    with pytest.raises(ValueError):
+        BoostClassifier(clustering_algorithm="louvain", clustering_kwargs={"key_added": "x"})
+    with pytest.raises(ValueError):
+        BoostClassifier(clustering_algorithm="leiden", clustering_kwargs={"random_state": 1})
+    with pytest.raises(AssertionError):
+        BoostClassifier(n_components=50, n_top_var_genes=40)
+    with pytest.warns(UserWarning, match="experimental"):
+        BoostClassifier(clustering_algorithm="leiden")
+    with pytest.warns(UserWarning, match="trimmed to 0.5"):
+        clf = BoostClassifier(boost_rate=0.7)
+    assert clf.boost_rate == 0.5
+    with pytest.warns(UserWarning, match="prune=False"):
+        BoostClassifier(n_iters=1)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        clf = BoostClassifier(boost_rate=0.7, replace=True)
+        assert clf.boost_rate == 0.7
+        assert BoostClassifier(n_top_var_genes=20).n_components == 20          # silent cap
+        assert BoostClassifier(n_top_var_genes=-5).n_top_var_genes == 0
+        kw = BoostClassifier(clustering_algorithm="louvain").clustering_kwargs
+        assert kw == {"directed": False, "resolution": 4}
+        assert BoostClassifier().clustering_kwargs == {"prune": True}
+    with pytest.raises(TypeError):
+        BoostClassifier(clustering_kwargs={"no_such_option": 1})
+
+
+def test_fit_rejects_bad_input():
+    clf = BoostClassifier(clustering_algorithm="louvain")
+    with pytest.raises(ValueError):
+        clf.fit(np.array([1.0, 2.0, 3.0]))                       # not 2-D
+    bad = np.ones((600, 120)); bad[3, 4] = np.nan
+    with pytest.raises(ValueError):
+        clf.fit(bad)
+    with pytest.raises(NotImplementedError):
+        BoostClassifier(normalizer=lambda x: x).fit(np.ones((600, 120)))
+
+
+def test_fit_fails_loudly_without_gpu():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from doubletdetection_amd._lib import DdxError
+
+    counts = np.random.default_rng(0).poisson(1.0, size=(600, 120))
+    with pytest.raises(DdxError):
+        BoostClassifier(n_iters=2, clustering_algorithm="louvain").fit(counts)
+
+
+def test_f9_predict_and_doublet_score_match_reference():
+    g = load_golden("f9_predict")
+    clf = BoostClassifier(n_iters=g["multi_logp"].shape[0], clustering_algorithm="louvain")
+    clf.all_log_p_values_ = g["multi_logp"].copy()
+    clf.all_scores_ = g["multi_scores"].copy()
+    for tag in ("default", "loose", "mid"):
+        pt, vt = g[f"multi_{tag}_params"]
+        lab = clf.predict(p_thresh=pt, voter_thresh=vt)
+        np.testing.assert_array_equal(lab, g[f"multi_{tag}_labels"])
+        np.testing.assert_array_equal(clf.voting_average_, g[f"multi_{tag}_voting"])
+    ds = clf.doublet_score()
+    assert isinstance(ds, np.ma.MaskedArray)
+    np.testing.assert_array_equal(np.ma.getmaskarray(ds), g["multi_dscore_mask"])
+    ok = ~g["multi_dscore_mask"]
+    np.testing.assert_array_equal(np.ma.getdata(ds)[ok], g["multi_dscore_data"][ok])
+    for tag in ("gap", "flat", "allnan_but_one"):
+        sc = g[f"single_{tag}_scores"][None, :]
+        with pytest.warns(UserWarning):
+            one = BoostClassifier(n_iters=1)
+        one.all_scores_ = sc.copy()
+        one.all_log_p_values_ = np.where(np.isnan(sc), np.nan, -sc * 20)
+        lab = one.predict()
+        assert lab.dtype == bool
+        np.testing.assert_array_equal(lab.astype(np.float64), g[f"single_{tag}_labels"])
+        np.testing.assert_array_equal(one.suggested_score_cutoff_, g[f"single_{tag}_cutoff"])
+        np.testing.assert_array_equal(one.doublet_score(), g[f"single_{tag}_dscore"])
+
+
+@pytest.mark.parametrize("case", ["case_a_hvg_pheno", "case_b_transposed_louvain", "case_c_reftest_scaled"])
+def test_end_to_end_equals_reference_run_with_oracle_engine(case, monkeypatch):
+    """Everything the host layer owns (coercion, HVG, parent stream, kwargs plan, native Louvain +
+    scoring, attribute assembly, predict) reproduces the reference's own run bit for bit."""
+    from conftest import golden_kwargs
+
+    g = load_golden(case)
+    kw = golden_kwargs(g)
+    monkeypatch.setattr(BoostClassifier, "_engine_factory", staticmethod(make_engine_factory(kw.get("random_state", 0))))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        clf = BoostClassifier(**kw)
+        clf.fit(csr_from(g, "counts"))
+    if "top_var_genes" in g.files:
+        np.testing.assert_array_equal(clf.top_var_genes_, g["top_var_genes"])
+    np.testing.assert_array_equal(np.asarray(clf.parents_, dtype=np.int64), g["parents"])
+    assert isinstance(clf.parents_, list) and isinstance(clf.parents_[0][0], list)
+    assert isinstance(clf.parents_[0][0][0], np.int64)
+    np.testing.assert_array_equal(clf.communities_, g["communities"])
+    np.testing.assert_array_equal(clf.synth_communities_, g["synth_communities"])
+    assert clf.communities_.dtype == np.float64 and clf.synth_communities_.dtype == np.float64
+    np.testing.assert_array_equal(clf.all_scores_, g["all_scores"])
+    np.testing.assert_allclose(clf.all_log_p_values_, g["all_log_p_values"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_array_equal(clf.predict(), g["labels_default"])
+    np.testing.assert_array_equal(clf.voting_average_, g["voting_average_default"])
+
+
+def test_second_fit_continues_the_rng_stream(monkeypatch):
+    g = load_golden("case_c_reftest_scaled")
+    monkeypatch.setattr(BoostClassifier, "_engine_factory", staticmethod(make_engine_factory(0)))
+    clf = BoostClassifier(n_iters=1, clustering_algorithm="louvain", standard_scaling=True)
+    counts = csr_from(g, "counts")
+    clf.fit(counts)
+    first = np.asarray(clf.parents_)
+    clf.fit(counts)
+    second = np.asarray(clf.parents_)
+    assert not np.array_equal(first, second)
+    np.testing.assert_array_equal(first[0], g["parents"][0])
+    np.testing.assert_array_equal(second[0], g["parents"][1])
