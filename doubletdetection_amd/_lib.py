@@ -319,7 +319,7 @@ class Context:
         idx = np.empty((self._embM, self._K), dtype=np.int32)
         dist = np.empty((self._embM, self._K), dtype=np.float64) if with_dist else None
         self._c(self._lib.ddx_get_knn(self._h, _p(idx, c_i32_p), _p(dist, c_f64_p) if with_dist else None))
-        return idx, dist
+        return idx, (np.sqrt(dist) if with_dist else None)   # the C-ABI returns squared distances
 
     def build_graph(self, mode: int):
         self._c(self._lib.ddx_build_graph(self._h, int(mode)))

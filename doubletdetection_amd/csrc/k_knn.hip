@@ -29,6 +29,7 @@ template <int CP>
 __global__ void __launch_bounds__(kKnnThreads) k_knn_brute(const double* __restrict__ E, int64_t M, int C, int K,
                                                            int include_self, int32_t* __restrict__ idx_out,
                                                            double* __restrict__ dist_out) {
+#pragma clang fp contract(off)  // (a-b)*(a-b) must round before the add: no fused multiply-add
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* ld = reinterpret_cast<double*>(smem);                       // [K][kKnnThreads]
     int32_t* li = reinterpret_cast<int32_t*>(smem + sizeof(double) * K * kKnnThreads);
@@ -45,8 +46,9 @@ __global__ void __launch_bounds__(kKnnThreads) k_knn_brute(const double* __restr
         double d2 = 0.0;
 #pragma unroll
         for (int t = 0; t < CP; ++t) {  // padded coordinates are 0: they add exactly +0.0
-            const double diff = __dsub_rn(qv[t], ec[t]);
-            d2 = __dadd_rn(d2, __dmul_rn(diff, diff));
+            const double diff = qv[t] - ec[t];
+            const double sq = diff * diff;      // rounded product (contract(off) above), then rounded add
+            d2 = d2 + sq;
         }
         if (valid && d2 < worst && (include_self || c != q)) {
             int pos = (count < K) ? count : K - 1;
@@ -64,7 +66,7 @@ __global__ void __launch_bounds__(kKnnThreads) k_knn_brute(const double* __restr
     if (valid) {
         for (int s = 0; s < K; ++s) {
             idx_out[q * K + s] = (s < count) ? li[s * kKnnThreads + tid] : -1;
-            dist_out[q * K + s] = (s < count) ? sqrt(ld[s * kKnnThreads + tid]) : __builtin_huge_val();
+            dist_out[q * K + s] = (s < count) ? ld[s * kKnnThreads + tid] : __builtin_huge_val();
         }
     }
 }

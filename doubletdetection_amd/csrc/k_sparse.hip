@@ -443,10 +443,12 @@ __global__ void k_median_from_sorted(const float* __restrict__ sorted, int64_t M
 //   x      = log(scaled + pc)  |  log1p(scaled)  float32 result                      (dd.py:295 / :297)
 // The log itself is evaluated in float64 and rounded once, i.e. the correctly rounded float32 value.
 __device__ __forceinline__ float lognorm_value(float v, double rowsum, float med, float pc, bool use_log1p) {
+#pragma clang fp contract(off)
     const float normed = (rowsum == 0.0) ? v : (float)((double)v / rowsum);
-    const float scaled = __fmul_rn(normed, med);
+    const float scaled = normed * med;          // plain operators: the pragma above forbids fusing
     if (use_log1p) return (float)log1p((double)scaled);
-    return (float)log((double)__fadd_rn(scaled, pc));
+    const float shifted = scaled + pc;
+    return (float)log((double)shifted);
 }
 
 __global__ void __launch_bounds__(256) k_lognorm_rows(const int64_t* __restrict__ indptr, const float* __restrict__ raw,
@@ -494,7 +496,7 @@ __global__ void __launch_bounds__(256) k_col_sums(const int64_t* __restrict__ cp
         for (int64_t t = lo + tid; t < hi; t += 256) {
             const float xv = x[t];
             a += (double)xv - z;
-            if (mode) b += (double)__fmul_rn(xv, xv);
+            if (mode) { const float sq = xv * xv; b += (double)sq; }
         }
     }
     red[0][tid] = a;
@@ -579,11 +581,13 @@ int stage_lognormalise(ddx_ctx* ctx, float pseudocount) {
 __global__ void k_scale_stats(const double* __restrict__ stat, const int64_t* __restrict__ cp_o,
                               const int64_t* __restrict__ cp_s, const float* __restrict__ zcol, int64_t M, int32_t H,
                               double* __restrict__ mean_out, double* __restrict__ std_out) {
+#pragma clang fp contract(off)
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= H) return;
     const double z = (double)zcol[j];
     const double cnt = (double)((cp_o[j + 1] - cp_o[j]) + (cp_s[j + 1] - cp_s[j]));
-    const double zz = (double)__fmul_rn(zcol[j], zcol[j]);
+    const float zsq = zcol[j] * zcol[j];
+    const double zz = (double)zsq;
     const double mean = z + stat[2 * j] / (double)M;
     const double mean_sq = (stat[2 * j + 1] + ((double)M - cnt) * zz) / (double)M;
     double var = mean_sq - mean * mean;
@@ -595,6 +599,7 @@ __global__ void k_scale_stats(const double* __restrict__ stat, const int64_t* __
 }
 
 __device__ __forceinline__ float scale_value(float x, double mean, double sd, float maxv) {
+#pragma clang fp contract(off)
     const float r1 = (float)((double)x - mean);
     float r2 = (float)((double)r1 / sd);
     if (maxv > 0.f) r2 = fminf(fmaxf(r2, -maxv), maxv);

@@ -114,11 +114,12 @@ int ddx_get_embedding_f64(ddx_ctx* ctx, double* emb_out /* [M*C] */, double* sin
 int ddx_set_embedding(ddx_ctx* ctx, const float* emb, int64_t n_rows, int32_t n_components);
 
 /* ---- kNN: phenograph.cluster / sc.pp.neighbors: dd.py:317-336 --------------------------------
- * exact Euclidean k nearest neighbours over the embedding, float64 distances, ordering by
- * (distance, index).  include_self = 1 reproduces scanpy's n_neighbors convention (the point itself
+ * exact Euclidean k nearest neighbours over the embedding, ordering by (distance, index).
+ * dist2_out receives the *squared* distances (float64, accumulated as sum((a-b)*(a-b)) over the
+ * components in order, no fused multiply-add), which is what the ordering is defined on.  include_self = 1 reproduces scanpy's n_neighbors convention (the point itself
  * is a candidate); include_self = 0 reproduces phenograph (self removed). */
 int ddx_knn(ddx_ctx* ctx, int32_t k, int32_t include_self);
-int ddx_get_knn(ddx_ctx* ctx, int32_t* idx_out /* [M*k] */, double* dist_out /* [M*k] or NULL */);
+int ddx_get_knn(ddx_ctx* ctx, int32_t* idx_out /* [M*k] */, double* dist2_out /* [M*k] or NULL */);
 
 /* ---- graph construction (device) ------------------------------------------------------------
  * mode 0: PhenoGraph Jaccard graph, prune=True  (mutual kNN, weight J_ij*J_ji)

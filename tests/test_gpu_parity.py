@@ -103,11 +103,17 @@ def test_lognormalised_matrix(ctx, case):
     dense = ctx.aug_dense_rows(0, ctx.M)
     # the reference's matrix rows stored in the golden file (numpy float32 log) vs correctly rounded log
     sel = g["pca_in0_rowsel"]
+    # numpy's SIMD float32 log is not correctly rounded (documented max error ~4 ulp, ISA dependent);
+    # the kernel returns the correctly rounded value, so agreement is "within numpy's own error"
     ulp = _ulp_diff(dense[sel], g["pca_in0_rows"])
-    assert ulp.max() <= 1, ulp.max()
-    assert (ulp == 0).mean() > 0.98
+    assert ulp.max() <= 4, ulp.max()
+    assert (ulp == 0).mean() > 0.85, (ulp == 0).mean()
     ulp_all = _ulp_diff(dense, aug)
-    assert ulp_all.max() <= 1
+    assert ulp_all.max() <= 4
+    # independent check of "correctly rounded": float64 log of the same float32 argument
+    scaled = (sp.vstack((orc.l1_normalise_rows(raw), orc.l1_normalise_rows(csr_from(g, "synth0")))) * med).toarray()
+    exact = np.log((scaled + np.float32(kw.get("pseudocount", 0.1))).astype(np.float64)).astype(np.float32)
+    np.testing.assert_array_equal(dense, exact)
     vals, z = ctx.aug_values()
     assert np.all(z == np.float32(np.log(np.float32(kw.get("pseudocount", 0.1)))))
     assert vals.shape[0] == raw.nnz + csr_from(g, "synth0").nnz
