@@ -1,0 +1,211 @@
+"""Benchmark of the BoostClassifier.fit() hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+One *step* is one complete ``BoostClassifier.fit()`` (HVG prologue + ``n_iters`` boosting iterations +
+result gather) on a synthetic count matrix that is already resident in HBM when the timed region
+starts (``clf.stage(X)`` uploads it beforehand).  Metric: cells/s = cells * steps / wall-clock, the
+maximum over ranks, whole job.  With N > 1 the boosting iterations are sharded over the ranks (one
+process per GPU, RCCL all-gather of the per-iteration result rows), so total work is fixed: "strong".
+
+Rank 0 prints ONE JSON line.  Besides the driver contract it carries
+  roofline      -- the dominant GPU kernel of the timed region: algorithmic bytes (or flops) per launch
+                   divided by its average launch duration measured with HIP events on the library's stream;
+  cpu_baseline  -- the CPU oracle (a port of the reference's numpy/scipy/sklearn path) timed on this host
+                   on a bounded sample of the same workload (N=1, rank 0 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+import warnings
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md)
+FP64_PEAK_TFLOPS = 78.6      # FP64 vector / FP64 MFMA peak, dense
+FP32_PEAK_TFLOPS = 157.3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--cells", type=int, default=100_000)
+    ap.add_argument("--genes", type=int, default=30_000)
+    ap.add_argument("--density", type=float, default=0.03)
+    ap.add_argument("--iters", type=int, default=10, help="n_iters (reference default 10)")
+    ap.add_argument("--algorithm", default="phenograph")
+    ap.add_argument("--scaling", action="store_true", help="standard_scaling=True")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-cells", type=int, default=6000)
+    return ap.parse_args()
+
+
+def kernel_models(N, G, H, S, nnz_aug, C, k, L=None):
+    """Algorithmic work per launch of every timed kernel (DESIGN.md section 'kernels')."""
+    M = N + S
+    L = L or (C + 10)
+    return {
+        # name: (bound, unit, work per launch, peak)
+        "spmm_rows": ("hbm", "GB/s", (8 * nnz_aug + 8 * M * L + 8 * H * L + 8 * (M + 1)) / 1e9, HBM_PEAK_GBS),
+        "spmm_cols": ("hbm", "GB/s", (8 * nnz_aug + 8 * H * L + 8 * M * L + 16 * (H + 1)) / 1e9, HBM_PEAK_GBS),
+        "knn_brute": ("mfma", "TFLOP/s", 3.0 * M * M * C / 1e12, FP64_PEAK_TFLOPS),
+        "doublet_fill": ("hbm", "GB/s", (8 * (nnz_aug * 2 * S / max(M + S, 1)) * 2) / 1e9, HBM_PEAK_GBS),
+        "lognorm_rows": ("hbm", "GB/s", (8 * nnz_aug + 8 * M) / 1e9, HBM_PEAK_GBS),
+        "lognorm_cols": ("hbm", "GB/s", (12 * nnz_aug) / 1e9, HBM_PEAK_GBS),
+        "csc_radix_sort": ("hbm", "GB/s", (16 * nnz_aug * S / max(M, 1)) / 1e9, HBM_PEAK_GBS),
+    }
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    assert world == args.gpus or world == 1, (world, args.gpus)
+    dev = f"cuda:{local_rank}"
+
+    from doubletdetection_amd import BoostClassifier
+    from doubletdetection_amd._synthetic import make_counts
+
+    os.environ["DDX_TIMING"] = "1"
+    t_gen = time.perf_counter()
+    X = make_counts(args.cells, args.genes, density=args.density, device=dev, seed=20250227)
+    t_gen = time.perf_counter() - t_gen
+    torch.cuda.empty_cache()
+    N, G = X.shape
+    kw = dict(n_iters=args.iters, clustering_algorithm=args.algorithm, standard_scaling=args.scaling,
+              random_state=0, n_jobs=-1)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def one_fit():
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            clf = BoostClassifier(**kw)
+            clf.stage(X)                    # counts resident in HBM before the clock starts
+        barrier()
+        t0 = time.perf_counter()
+        clf.fit(X)
+        barrier()
+        return clf, time.perf_counter() - t0
+
+    for _ in range(args.warmup):
+        one_fit()
+    elapsed = 0.0
+    timings = {}
+    clf = None
+    for _ in range(args.steps):
+        clf, dt = one_fit()
+        elapsed += dt
+        for name, (launches, ms) in clf._device_timings.items():
+            a = timings.setdefault(name, [0, 0.0])
+            a[0] += launches
+            a[1] += ms
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        H = clf._num_genes
+        S = int(clf.boost_rate * N)
+        nnz_aug = getattr(clf, "_last_nnz_aug", None) or int(X.nnz * 1.0)
+        C = clf.n_components
+        k = 30 if args.algorithm == "phenograph" else 10
+        models = kernel_models(N, G, H, S, nnz_aug, C, k)
+        gpu_ms = {n: v[1] for n, v in timings.items()}
+        dominant = max(gpu_ms, key=gpu_ms.get) if gpu_ms else None
+        roofline = None
+        if dominant in models:
+            bound, unit, work, peak = models[dominant]
+            avg_s = timings[dominant][1] / max(timings[dominant][0], 1) / 1e3
+            achieved = work / avg_s
+            roofline = {"bound": bound, "kernel": dominant, "achieved": round(achieved, 2), "peak": peak, "unit": unit,
+                        "frac": round(achieved / peak, 4), "traffic": None,
+                        "avg_launch_ms": round(avg_s * 1e3, 4), "launches": timings[dominant][0],
+                        "work_per_launch": work}
+        total_gpu_ms = sum(gpu_ms.values())
+        out = {
+            "metric": "cells/sec for full BoostClassifier.fit() (default n_iters)",
+            "value": round(N * args.steps / elapsed, 2),
+            "unit": "cells/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 2),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"synthetic {N}x{G} counts, {X.nnz / (N * G):.3%} nnz, n_iters={args.iters}, "
+                                   f"n_top_var_genes=10000, n_components=30, boost_rate=0.25, "
+                                   f"clustering_algorithm={args.algorithm}, standard_scaling={args.scaling}",
+                       "n_iters": args.iters, "sharding": f"iterations over {world} rank(s)",
+                       "host_threads": os.cpu_count()},
+            "roofline": roofline,
+            "gpu_kernel_ms_per_step": {n: round(v / args.steps, 3) for n, v in sorted(gpu_ms.items(), key=lambda kv: -kv[1])},
+            "gpu_busy_frac": round(total_gpu_ms / 1e3 / elapsed, 4),
+            "datagen_s": round(t_gen, 2),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(X, args, kw)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(X, args, kw):
+    """The CPU oracle ("port" of the reference's path: scipy sparse ops, dense log matrix, sklearn
+    randomized PCA, exact kNN, the same deterministic Louvain compiled for the host) on a bounded
+    row sample of the benchmark matrix, all host cores available to BLAS / sklearn."""
+    from doubletdetection_amd import _lib
+    from oracle import dd_oracle as orc
+
+    n = min(args.cpu_sample_cells, X.shape[0])
+    rows = np.sort(np.random.default_rng(0).choice(X.shape[0], size=n, replace=False))
+    sample = X[rows]
+    iters = 1
+
+    def native_louvain(indptr, indices, weights, gamma, seed):
+        return _lib.louvain(indptr, indices, weights, gamma, seed)[0].astype(np.int64)
+
+    okw = dict(n_iters=iters, clustering_algorithm=kw["clustering_algorithm"], standard_scaling=kw["standard_scaling"],
+               random_state=0, louvain_fn=native_louvain, knn_fn=orc._knn_sklearn_all_cores)
+    t0 = time.perf_counter()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        o = orc.OracleClassifier(**okw).fit(sample)
+    dt = time.perf_counter() - t0
+    per_iter = dt - o.timings["prologue"]
+    full_fit = o.timings["prologue"] + per_iter * args.iters     # iterations are identical work
+    return {"value": round(n / full_fit, 2), "unit": "cells/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"{n} of {X.shape[0]} cells x {X.shape[1]} genes, 1 iteration timed ({dt:.1f} s) and scaled to "
+                      f"n_iters={args.iters}; dense log matrix + sklearn randomized PCA + exact kNN + host Louvain",
+            "stage_seconds": {k2: round(v, 3) for k2, v in o.timings.items()}}
+
+
+if __name__ == "__main__":
+    main()

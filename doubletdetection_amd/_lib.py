@@ -271,6 +271,11 @@ class Context:
         self._c(self._lib.ddx_get_aug_lib(self._h, _p(out, c_f32_p), C.byref(med)))
         return out, np.float32(med.value)
 
+    def aug_nnz(self) -> int:
+        nnz = C.c_int64(0)
+        self._c(self._lib.ddx_get_aug_nnz(self._h, C.byref(nnz)))
+        return nnz.value
+
     def aug_values(self):
         nnz = C.c_int64(0)
         self._c(self._lib.ddx_get_aug_nnz(self._h, C.byref(nnz)))

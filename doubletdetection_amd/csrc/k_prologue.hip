@@ -1,16 +1,235 @@
-// fit() prologue on the device (dd.py:165-176): per-gene float32 variances and column restriction.
+// fit() prologue on the device (dd.py:165-176).
+//
+// gene variances (dd.py:167-170): scipy evaluates  X.power(2).mean(axis=0) - X.mean(axis=0)**2  for a
+// float32 CSR as   sum_i fl(fl(x_ig^2) * fl(1/N))  -  ( sum_i fl(x_ig * fl(1/N)) )^2   where both sums
+// are *sequential float32 accumulations in row order* (ones(1,N) @ X -> csc_matvec on the transpose).
+// The order decides which genes sit at the rank-H boundary of argsort, so it is reproduced exactly:
+// a stable radix sort by column brings each gene's values together in row order, then one wave per
+// gene replays the scalar loop (coalesced 64-entry loads, readlane-broadcast sequential adds).
+//
+// column restriction (dd.py:174-176, tocsc()[:, top].tocsr()): keep the selected genes, renumber them
+// to their position in `top` (ascending-variance order), sort every row by the new column id.
+#include <hipcub/hipcub.hpp>
+
 #include "ddx_internal.h"
 
 namespace ddx {
 
-int stage_gene_variances(ddx_ctx* ctx, float* var_out) {
-    (void)var_out;
-    return set_err(ctx, DDX_E_UNSUPPORTED, "device HVG prologue not built yet");
+__global__ void k_colptr_i32(const int32_t* __restrict__ keys, int64_t n, int32_t G, int64_t* __restrict__ colptr) {
+    int32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j > G) return;
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if (keys[mid] < j) lo = mid + 1; else hi = mid;
+    }
+    colptr[j] = lo;
 }
 
-int stage_select_columns(ddx_ctx* ctx, const int64_t* cols, int32_t n_cols) {
-    (void)cols; (void)n_cols;
-    return set_err(ctx, DDX_E_UNSUPPORTED, "device HVG prologue not built yet");
+__global__ void __launch_bounds__(256) k_gene_var(const int64_t* __restrict__ colptr, const float* __restrict__ vals,
+                                                  int32_t G, float rinv, float* __restrict__ var_out) {
+#pragma clang fp contract(off)
+    const int lane = threadIdx.x & 63;
+    const int32_t g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (g >= G) return;
+    const int64_t b = colptr[g], e = colptr[g + 1];
+    float s1 = 0.f, s2 = 0.f;
+    for (int64_t base = b; base < e; base += 64) {
+        const int64_t p = base + lane;
+        const float v = (p < e) ? vals[p] : 0.f;
+        const float sq = v * v;            // X.power(2): float32 square
+        const float a1 = v * rinv;         // (X * (1/N)) with the scalar rounded to float32
+        const float a2 = sq * rinv;
+        const int cnt = (int)((e - base) < 64 ? (e - base) : 64);
+        for (int t = 0; t < cnt; ++t) {
+            s1 = s1 + __shfl(a1, t, 64);
+            s2 = s2 + __shfl(a2, t, 64);
+        }
+    }
+    if (lane == 0) {
+        const float m2 = s1 * s1;
+        var_out[g] = s2 - m2;
+    }
+}
+
+int stage_gene_variances(ddx_ctx* ctx, float* var_out) {
+    const int64_t n = ctx->raw_nnz;
+    const int32_t G = ctx->rawG;
+    DevBuf keys_out, vals_out, colptr, var;
+    int rc = DDX_OK;
+    auto cleanup = [&]() { release(ctx, keys_out); release(ctx, vals_out); release(ctx, colptr); release(ctx, var); };
+    if ((rc = ensure(ctx, keys_out, sizeof(int32_t) * (n + 1))) || (rc = ensure(ctx, vals_out, sizeof(float) * (n + 1))) ||
+        (rc = ensure(ctx, colptr, sizeof(int64_t) * (G + 1))) || (rc = ensure(ctx, var, sizeof(float) * G))) {
+        cleanup();
+        return rc;
+    }
+    int end_bit = 1;
+    while ((1 << end_bit) < G) ++end_bit;
+    hipError_t e = hipSuccess;
+    if (n > 0) {
+        size_t tmp_bytes = 0;
+        e = hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, ctx->raw_indices.as<int32_t>(), keys_out.as<int32_t>(),
+                                               ctx->raw_data.as<float>(), vals_out.as<float>(), (int)n, 0, end_bit, ctx->stream);
+        if (e == hipSuccess && (rc = ensure(ctx, ctx->sort_tmp, tmp_bytes)) == DDX_OK) {
+            ScopedTimer t(ctx, "hvg_sort");
+            e = hipcub::DeviceRadixSort::SortPairs(ctx->sort_tmp.p, tmp_bytes, ctx->raw_indices.as<int32_t>(), keys_out.as<int32_t>(),
+                                                   ctx->raw_data.as<float>(), vals_out.as<float>(), (int)n, 0, end_bit, ctx->stream);
+        }
+    }
+    if (e == hipSuccess && rc == DDX_OK) {
+        ScopedTimer t(ctx, "hvg_variance");
+        k_colptr_i32<<<(unsigned)ceil_div(G + 1, 256), 256, 0, ctx->stream>>>(keys_out.as<int32_t>(), n, G, colptr.as<int64_t>());
+        const float rinv = (float)(1.0 / (double)ctx->rawN);
+        k_gene_var<<<(unsigned)ceil_div(G, 4), 256, 0, ctx->stream>>>(colptr.as<int64_t>(), vals_out.as<float>(), G, rinv, var.as<float>());
+    }
+    if (e == hipSuccess && rc == DDX_OK) e = hipMemcpyAsync(var_out, var.p, sizeof(float) * G, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && rc == DDX_OK) e = hipStreamSynchronize(ctx->stream);
+    cleanup();
+    if (rc != DDX_OK) return rc;
+    if (e != hipSuccess) return set_err(ctx, DDX_E_HIP, "gene variance stage failed: %s", hipGetErrorString(e));
+    return DDX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// column restriction
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_count_kept(const int64_t* __restrict__ indptr, const int32_t* __restrict__ cols,
+                                                    const int32_t* __restrict__ newid, int64_t N, int32_t* __restrict__ counts) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= N) return;
+    int c = 0;
+    for (int64_t p = indptr[row] + lane; p < indptr[row + 1]; p += 64) c += (newid[cols[p]] >= 0);
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+    if (lane == 0) counts[row] = c;
+}
+
+// order-preserving compaction of the kept entries of each row (one wave per row, ballot prefix)
+__global__ void __launch_bounds__(256) k_compact_kept(const int64_t* __restrict__ indptr, const int32_t* __restrict__ cols,
+                                                      const float* __restrict__ vals, const int32_t* __restrict__ newid,
+                                                      int64_t N, const int64_t* __restrict__ out_ptr,
+                                                      int32_t* __restrict__ out_cols, float* __restrict__ out_vals) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= N) return;
+    int64_t o = out_ptr[row];
+    const int64_t b = indptr[row], e = indptr[row + 1];
+    for (int64_t base = b; base < e; base += 64) {
+        const int64_t p = base + lane;
+        int32_t nid = -1;
+        float v = 0.f;
+        if (p < e) {
+            nid = newid[cols[p]];
+            v = vals[p];
+        }
+        const unsigned long long m = __ballot(nid >= 0);
+        if (nid >= 0) {
+            const int before = __popcll(m & ((1ull << lane) - 1ull));
+            out_cols[o + before] = nid;
+            out_vals[o + before] = v;
+        }
+        o += __popcll(m);
+    }
+}
+
+__global__ void k_fill_i32(int32_t* out, int64_t n, int32_t v) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = v;
+}
+
+__global__ void k_scatter_newid(const int64_t* __restrict__ sel, int32_t H, int32_t* __restrict__ newid) {
+    int32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < H) newid[sel[t]] = t;
+}
+
+// exclusive scan of per-row counts (same single-block scheme as the doublet stage)
+__global__ void __launch_bounds__(1024) k_scan_rows(const int32_t* __restrict__ in, int64_t n, int64_t* __restrict__ out) {
+    __shared__ int64_t wsum[16];
+    __shared__ int64_t carry;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int64_t start = 0; start < n; start += 1024) {
+        const int64_t i = start + tid;
+        const int64_t v = (i < n) ? (int64_t)in[i] : 0;
+        int64_t x = v;
+        for (int off = 1; off < 64; off <<= 1) {
+            int64_t y = __shfl_up(x, off, 64);
+            if (lane >= off) x += y;
+        }
+        if (lane == 63) wsum[w] = x;
+        __syncthreads();
+        int64_t woff = 0;
+        for (int t = 0; t < w; ++t) woff += wsum[t];
+        const int64_t c = carry;
+        if (i < n) out[i] = c + woff + x - v;
+        __syncthreads();
+        if (tid == 1023) carry = c + woff + x;
+        __syncthreads();
+    }
+    if (tid == 0) out[n] = carry;
+}
+
+int stage_select_columns(ddx_ctx* ctx, const int64_t* cols, int32_t H) {
+    const int64_t N = ctx->rawN;
+    const int32_t G = ctx->rawG;
+    for (int32_t t = 0; t < H; ++t)
+        if (cols[t] < 0 || cols[t] >= G) return set_err(ctx, DDX_E_ARG, "column %lld out of range", (long long)cols[t]);
+    DevBuf sel, newid, counts, tk, tv;
+    int rc = DDX_OK;
+    hipError_t e = hipSuccess;
+    auto cleanup = [&]() { release(ctx, sel); release(ctx, newid); release(ctx, counts); release(ctx, tk); release(ctx, tv); };
+#define PR_TRY(x) if ((rc = (x)) != DDX_OK) { cleanup(); return rc; }
+#define PR_HIP(x) if ((e = (x)) != hipSuccess) { cleanup(); return set_err(ctx, DDX_E_HIP, "%s: %s", #x, hipGetErrorString(e)); }
+    PR_TRY(ensure(ctx, sel, sizeof(int64_t) * H));
+    PR_TRY(ensure(ctx, newid, sizeof(int32_t) * G));
+    PR_TRY(ensure(ctx, counts, sizeof(int32_t) * (N + 1)));
+    PR_TRY(ensure(ctx, ctx->aug_indptr, sizeof(int64_t) * (N + N / 2 + 2)));
+    PR_HIP(hipMemcpyAsync(sel.p, cols, sizeof(int64_t) * H, hipMemcpyHostToDevice, ctx->stream));
+    int64_t kept = 0;
+    {
+        ScopedTimer t(ctx, "hvg_select");
+        k_fill_i32<<<(unsigned)ceil_div(G, 256), 256, 0, ctx->stream>>>(newid.as<int32_t>(), G, -1);
+        k_scatter_newid<<<(unsigned)ceil_div(H, 256), 256, 0, ctx->stream>>>(sel.as<int64_t>(), H, newid.as<int32_t>());
+        k_count_kept<<<(unsigned)ceil_div(N, 4), 256, 0, ctx->stream>>>(ctx->raw_indptr.as<int64_t>(), ctx->raw_indices.as<int32_t>(),
+                                                                        newid.as<int32_t>(), N, counts.as<int32_t>());
+        k_scan_rows<<<1, 1024, 0, ctx->stream>>>(counts.as<int32_t>(), N, ctx->aug_indptr.as<int64_t>());
+    }
+    ctx->h_indptr.resize(N + 1);
+    PR_HIP(hipMemcpyAsync(ctx->h_indptr.data(), ctx->aug_indptr.p, sizeof(int64_t) * (N + 1), hipMemcpyDeviceToHost, ctx->stream));
+    PR_HIP(hipStreamSynchronize(ctx->stream));
+    kept = ctx->h_indptr[N];
+    if (kept >= (int64_t)1 << 31) { cleanup(); return set_err(ctx, DDX_E_UNSUPPORTED, "more than 2^31-1 stored entries"); }
+    const int64_t cap_s = kept / 2 + kept / 8 + 1024;
+    PR_TRY(ensure(ctx, ctx->aug_indices, sizeof(int32_t) * (size_t)(kept + cap_s)));
+    PR_TRY(ensure(ctx, ctx->aug_raw, sizeof(float) * (size_t)(kept + cap_s)));
+    PR_TRY(ensure(ctx, ctx->aug_x, sizeof(float) * (size_t)(kept + cap_s)));
+    ctx->cap_synth = cap_s;
+    PR_TRY(ensure(ctx, tk, sizeof(int32_t) * (size_t)(kept + 1)));
+    PR_TRY(ensure(ctx, tv, sizeof(float) * (size_t)(kept + 1)));
+    if (kept > 0) {
+        int end_bit = 1;
+        while ((1 << end_bit) < H) ++end_bit;
+        size_t tmp_bytes = 0;
+        const int64_t* offs = ctx->aug_indptr.as<int64_t>();
+        PR_HIP(hipcub::DeviceSegmentedRadixSort::SortPairs(nullptr, tmp_bytes, tk.as<int32_t>(), ctx->aug_indices.as<int32_t>(),
+                                                           tv.as<float>(), ctx->aug_raw.as<float>(), (int)kept, (int)N, offs, offs + 1,
+                                                           0, end_bit, ctx->stream));
+        PR_TRY(ensure(ctx, ctx->sort_tmp, tmp_bytes));
+        ScopedTimer t(ctx, "hvg_select");
+        k_compact_kept<<<(unsigned)ceil_div(N, 4), 256, 0, ctx->stream>>>(ctx->raw_indptr.as<int64_t>(), ctx->raw_indices.as<int32_t>(),
+                                                                          ctx->raw_data.as<float>(), newid.as<int32_t>(), N,
+                                                                          ctx->aug_indptr.as<int64_t>(), tk.as<int32_t>(), tv.as<float>());
+        PR_HIP(hipcub::DeviceSegmentedRadixSort::SortPairs(ctx->sort_tmp.p, tmp_bytes, tk.as<int32_t>(), ctx->aug_indices.as<int32_t>(),
+                                                           tv.as<float>(), ctx->aug_raw.as<float>(), (int)kept, (int)N, offs, offs + 1,
+                                                           0, end_bit, ctx->stream));
+    }
+    PR_HIP(hipStreamSynchronize(ctx->stream));
+    cleanup();
+#undef PR_TRY
+#undef PR_HIP
+    ctx->nnz = kept;
+    return stage_upload_counts(ctx, N, H, nullptr, nullptr, nullptr, true);
 }
 
 }  // namespace ddx

@@ -359,8 +359,20 @@ def relabel_by_size(labels: np.ndarray, min_cluster_size: int | None = None) -> 
     return out
 
 
+def _knn_sklearn_all_cores(emb, k, include_self):
+    """sklearn exact search with every host core (used only when timing the CPU baseline)."""
+    from sklearn.neighbors import NearestNeighbors
+
+    kk = k if include_self else k + 1
+    nn = NearestNeighbors(n_neighbors=kk, algorithm="kd_tree" if not include_self else "brute", n_jobs=-1).fit(emb)
+    dist, idx = nn.kneighbors(emb)
+    if not include_self:
+        idx, dist = idx[:, 1:], dist[:, 1:]
+    return idx, dist
+
+
 def cluster_embedding(emb: np.ndarray, algorithm: str, clustering_kwargs: dict, random_state: int,
-                      louvain_fn=None) -> np.ndarray:
+                      louvain_fn=None, knn_fn=None) -> np.ndarray:
     """kNN -> graph -> deterministic community detection -> size-sorted labels.
 
     ``louvain_fn(indptr, indices, weights, gamma, seed) -> labels``: defaults to the pure-Python
@@ -368,17 +380,18 @@ def cluster_embedding(emb: np.ndarray, algorithm: str, clustering_kwargs: dict, 
     implementation of the same specification to keep the timing meaningful.
     """
     louvain_fn = louvain_fn or louvain_ref.louvain
+    knn_fn = knn_fn or knn_bruteforce_f64
     kw = dict(clustering_kwargs or {})
     if algorithm == "phenograph":
         k = int(kw.get("k", 30))
-        idx, _ = knn_bruteforce_f64(emb, k, include_self=False)
+        idx, _ = knn_fn(emb, k, include_self=False)
         G = jaccard_graph(idx, prune=bool(kw.get("prune", True)))
         gamma = float(kw.get("resolution_parameter", 1.0))
         seed = kw.get("seed", None)
         seed = random_state if seed is None else int(seed)
         lab = louvain_fn(G.indptr, G.indices, G.data, gamma, seed)
         return relabel_by_size(lab, int(kw.get("min_cluster_size", 10)))
-    idx, _ = knn_bruteforce_f64(emb, 10, include_self=True)
+    idx, _ = knn_fn(emb, 10, include_self=True)
     G = union_knn_graph(idx)
     gamma = float(kw.get("resolution", 4))
     lab = louvain_fn(G.indptr, G.indices, G.data, gamma, int(random_state))
@@ -457,7 +470,7 @@ class OracleClassifier:
     def __init__(self, boost_rate=0.25, n_components=30, n_top_var_genes=10000, replace=False,
                  clustering_algorithm="phenograph", clustering_kwargs=None, n_iters=10,
                  pseudocount=0.1, random_state=0, standard_scaling=False, pca="sklearn",
-                 louvain_fn=None):
+                 louvain_fn=None, knn_fn=None):
         if clustering_algorithm not in ("louvain", "phenograph", "leiden"):
             raise ValueError("Clustering algorithm needs to be one of ['louvain', 'phenograph', 'leiden']")
         self.boost_rate = 0.5 if (not replace and boost_rate > 0.5) else boost_rate
@@ -478,6 +491,7 @@ class OracleClassifier:
         self.standard_scaling = standard_scaling
         self.pca = pca
         self.louvain_fn = louvain_fn
+        self.knn_fn = knn_fn
         self.rng = np.random.default_rng(random_state)
         self.timings = collections.defaultdict(float)
 
@@ -515,7 +529,7 @@ class OracleClassifier:
                 emb = randomized_pca_f64(aug, self.n_components, self.random_state)[0].astype(np.float32)
             t3 = time.perf_counter()
             full = cluster_embedding(emb, self.clustering_algorithm, self.clustering_kwargs,
-                                     self.random_state, self.louvain_fn)
+                                     self.random_state, self.louvain_fn, self.knn_fn)
             t4 = time.perf_counter()
             sc_, lp_ = score_communities(full, N)
             t5 = time.perf_counter()

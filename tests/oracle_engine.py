@@ -13,6 +13,15 @@ class OracleEngine:
     def close(self):
         pass
 
+    def stage_raw(self, csr):
+        self.staged = csr.copy()
+
+    def gene_variances(self):
+        return orc.gene_variances(self.staged)
+
+    def select_columns(self, cols):
+        self.upload(self.staged.tocsc()[:, cols].tocsr())
+
     def upload(self, csr):
         self.raw = csr.copy()
         self.lib = orc.library_sizes(self.raw)

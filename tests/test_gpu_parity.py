@@ -46,6 +46,37 @@ def test_counts_resident_and_memoised(ctx, case):
     np.testing.assert_array_equal(ctx.normed(), g["normed_data"])
 
 
+# ---- a3: HVG prologue on the device (dd.py:165-176), bit exact ---------------------------------------
+@pytest.mark.parametrize("case", ["case_a_hvg_pheno", "case_b_transposed_louvain", "case_e_pc1_sparse"])
+def test_hvg_prologue(ctx, case):
+    g = load_golden(case)
+    kw = golden_kwargs(g)
+    raw = orc.coerce_counts(csr_from(g, "counts"))
+    ctx.upload_raw(raw)
+    var = ctx.gene_variances()
+    np.testing.assert_array_equal(var, orc.gene_variances(raw))       # float32, scipy's accumulation order
+    top = np.argsort(var)[-kw["n_top_var_genes"]:]
+    np.testing.assert_array_equal(top, g["top_var_genes"])
+    ctx.select_columns(top)
+    _same_csr(ctx.get_counts(), csr_from(g, "raw_hvg"))
+    np.testing.assert_array_equal(ctx.lib_size(), g["lib_size"])
+    np.testing.assert_array_equal(ctx.normed(), g["normed_data"])
+
+
+def test_hvg_prologue_non_integer_values_and_empty_genes(ctx):
+    # the accumulation order only shows with values whose partial sums round: use non-integers
+    rng = np.random.default_rng(3)
+    dense = (rng.random((700, 900)) < 0.2) * rng.gamma(2.0, 1.7, size=(700, 900))
+    dense[:, 17] = 0; dense[:, 400:420] = 0; dense[5] = 0
+    raw = sp.csr_matrix(dense.astype(np.float32))
+    ctx.upload_raw(raw)
+    var = ctx.gene_variances()
+    np.testing.assert_array_equal(var, orc.gene_variances(raw))
+    top = np.argsort(var)[-300:]
+    ctx.select_columns(top)
+    _same_csr(ctx.get_counts(), raw.tocsc()[:, top].tocsr())
+
+
 # ---- a6: synthetic doublets (dd.py:385-402), bit exact ---------------------------------------------
 @pytest.mark.parametrize("case", CASES)
 def test_doublets_match_reference(ctx, case):
