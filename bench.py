@@ -167,6 +167,7 @@ def main():
             "roofline": roofline,
             "gpu_kernel_ms_per_step": {n: round(v / args.steps, 3) for n, v in sorted(gpu_ms.items(), key=lambda kv: -kv[1])},
             "gpu_busy_frac": round(total_gpu_ms / 1e3 / elapsed, 4),
+            "host_seconds_last_step": {k2: round(v, 3) for k2, v in getattr(clf, "_host_timings", {}).items()},
             "datagen_s": round(t_gen, 2),
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -60,6 +60,8 @@ _SIGNATURES = {
     "ddx_knn": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "ddx_get_knn": (C.c_int, [C.c_void_p, c_i32_p, c_f64_p]),
     "ddx_build_graph": (C.c_int, [C.c_void_p, C.c_int32]),
+    "ddx_graph_relations": (C.c_int, [C.c_void_p, C.c_int32, c_i32_p, c_f64_p]),
+    "ddx_assemble_graph": (C.c_int, [C.c_int64, C.c_int32, c_i32_p, c_f64_p, c_i64_p, c_i32_p, c_f64_p]),
     "ddx_get_graph_size": (C.c_int, [C.c_void_p, c_i64_p, c_i64_p]),
     "ddx_get_graph": (C.c_int, [C.c_void_p, c_i64_p, c_i32_p, c_f64_p]),
     "ddx_louvain": (C.c_int, [C.c_int64, c_i64_p, c_i32_p, c_f64_p, C.c_double, C.c_uint64, c_i32_p, c_f64_p]),
@@ -133,6 +135,20 @@ def relabel_by_size(labels, min_cluster_size=None):
     mcs = -1 if min_cluster_size is None else int(min_cluster_size)
     _check(lib.ddx_relabel_by_size(labels.shape[0], _p(labels, c_i32_p), mcs, _p(out, c_i64_p)))
     return out
+
+
+def assemble_graph(idx, w):
+    """Symmetric CSR (indptr, indices, weights) from a relation table (host C++, thread-safe)."""
+    lib = load()
+    idx = np.ascontiguousarray(idx, dtype=np.int32)
+    w = np.ascontiguousarray(w, dtype=np.float64)
+    n, k = idx.shape
+    ip = np.empty(n + 1, dtype=np.int64)
+    ix = np.empty(2 * n * k, dtype=np.int32)
+    wt = np.empty(2 * n * k, dtype=np.float64)
+    _check(lib.ddx_assemble_graph(n, k, _p(idx, c_i32_p), _p(w, c_f64_p), _p(ip, c_i64_p), _p(ix, c_i32_p), _p(wt, c_f64_p)))
+    e = int(ip[-1])
+    return ip, ix[:e], wt[:e]
 
 
 def hypergeom_logsf(k, M, n, N) -> float:
@@ -336,6 +352,12 @@ class Context:
         w = np.empty(e.value, dtype=np.float64)
         self._c(self._lib.ddx_get_graph(self._h, _p(ip, c_i64_p), _p(ix, c_i32_p), _p(w, c_f64_p)))
         return ip, ix, w
+
+    def graph_relations(self, mode: int):
+        idx = np.empty((self._embM, self._K), dtype=np.int32)
+        w = np.empty((self._embM, self._K), dtype=np.float64)
+        self._c(self._lib.ddx_graph_relations(self._h, int(mode), _p(idx, c_i32_p), _p(w, c_f64_p)))
+        return idx, w
 
     # timing
     def timing_enable(self, on: bool = True):

@@ -91,7 +91,9 @@ class _HipEngine:
             c.scale(15.0)
         c.pca(n_components, q0)
         c.knn(knn_k, include_self)
-        return c.build_graph(graph_mode)
+        idx, w = c.graph_relations(graph_mode)
+        # the CSR assembly is host work: hand it to the worker thread together with the clustering
+        return lambda: _lib.assemble_graph(idx, w)
 
     def timings(self):
         return self.ctx.timings()
@@ -221,11 +223,17 @@ class BoostClassifier:
     @staticmethod
     def _cluster_and_score(graph, gamma, seed, min_cluster_size, num_cells):
         """Host C++: Louvain -> size-sorted labels -> per-community hypergeometric test."""
-        indptr, indices, weights = graph
+        import time
+
+        t0 = time.perf_counter()
+        indptr, indices, weights = graph() if callable(graph) else graph
+        t1 = time.perf_counter()
         labels, _ = _lib.louvain(indptr, indices, weights, gamma, seed)
+        t2 = time.perf_counter()
         full = _lib.relabel_by_size(labels, min_cluster_size)
         scores, logp = _lib.score_communities(full, num_cells)
-        return full, scores, logp
+        t3 = time.perf_counter()
+        return full, scores, logp, (t1 - t0, t2 - t1, t3 - t2)
 
     # ------------------------------------------------------------------------------------------
     def fit(self, raw_counts: NDArray | sp_sparse.csr_matrix) -> "BoostClassifier":
@@ -334,17 +342,29 @@ class BoostClassifier:
 
         mine = [i for i in range(n_iters) if i % world == rank]
         workers = self.n_jobs if self.n_jobs and self.n_jobs > 0 else (os.cpu_count() or 1)
+        import time
+
         local = {}
+        host = {"device_stages": 0.0, "wait_workers": 0.0, "graph_assembly": 0.0, "louvain": 0.0, "score": 0.0}
         with ThreadPoolExecutor(max_workers=max(1, min(workers, max(1, len(mine))))) as pool:
             pending = {}
             for i in mine:
                 if self.verbose:
                     print("Iteration {:3}/{}".format(i + 1, n_iters))
+                t0 = time.perf_counter()
                 graph = engine.run_iteration(all_parents[i], self.pseudocount, self.standard_scaling, n_comp,
                                              q0, knn_k, include_self, graph_mode)
+                host["device_stages"] += time.perf_counter() - t0
                 pending[i] = pool.submit(self._cluster_and_score, graph, gamma, seed, min_cluster_size, num_cells)
+            t0 = time.perf_counter()
             for i, fut in pending.items():
-                local[i] = fut.result()
+                full, scores, logp, (tg, tl, ts) = fut.result()
+                local[i] = (full, scores, logp)
+                host["graph_assembly"] += tg
+                host["louvain"] += tl
+                host["score"] += ts
+            host["wait_workers"] = time.perf_counter() - t0
+        self._host_timings = host
         self._device_timings = engine.timings() if hasattr(engine, "timings") else {}
         if mine and hasattr(engine, "aug_nnz"):
             self._last_nnz_aug = engine.aug_nnz()     # stored entries of the last augmented matrix

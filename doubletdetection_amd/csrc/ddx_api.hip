@@ -153,7 +153,7 @@ int ddx_destroy(ddx_ctx* ctx) {
                       &ctx->csc_s_row, &ctx->csc_s_raw, &ctx->csc_s_x, &ctx->sort_keys_in, &ctx->sort_keys_out,
                       &ctx->sort_vals_in, &ctx->sort_vals_out, &ctx->sort_tmp, &ctx->median, &ctx->lib_sorted,
                       &ctx->zcol, &ctx->colmean, &ctx->colstat, &ctx->pcaA, &ctx->pcaB, &ctx->pcaSmall,
-                      &ctx->pcaPartial, &ctx->pcaVec, &ctx->emb32, &ctx->emb64, &ctx->sing, &ctx->knn_idx,
+                      &ctx->pcaPartial, &ctx->pcaVec, &ctx->pcaPanel, &ctx->emb32, &ctx->emb64, &ctx->sing, &ctx->knn_idx,
                       &ctx->knn_dist, &ctx->knn_sorted, &ctx->edge_w};
     for (DevBuf* b : bufs) release(ctx, *b);
     (void)hipStreamDestroy(ctx->stream);
@@ -452,6 +452,35 @@ int ddx_build_graph(ddx_ctx* ctx, int32_t mode) {
     if (mode == 2) { NEED(ctx->knn_self, "mode 2 expects a kNN table computed with include_self=1"); }
     else { NEED(!ctx->knn_self, "Jaccard graphs expect a kNN table computed with include_self=0"); }
     return stage_build_graph(ctx, mode);
+}
+
+int ddx_graph_relations(ddx_ctx* ctx, int32_t mode, int32_t* idx_out, double* w_out) {
+    REQUIRE_CTX(ctx);
+    USE_DEVICE(ctx);
+    NEED(ctx->have_knn, "no kNN result");
+    NEED(mode >= 0 && mode <= 2, "graph mode must be 0, 1 or 2");
+    NEED(idx_out && w_out, "null output");
+    if (mode == 2) { NEED(ctx->knn_self, "mode 2 expects a kNN table computed with include_self=1"); }
+    else { NEED(!ctx->knn_self, "Jaccard graphs expect a kNN table computed with include_self=0"); }
+    return stage_graph_relations(ctx, mode, idx_out, w_out);
+}
+
+int ddx_assemble_graph(int64_t n_nodes, int32_t k, const int32_t* idx, const double* w, int64_t* indptr_out,
+                       int32_t* indices_out, double* weights_out) {
+    if (n_nodes < 0 || k <= 0 || !idx || !w || !indptr_out || !indices_out || !weights_out)
+        return set_err(nullptr, DDX_E_ARG, "bad arguments to ddx_assemble_graph");
+    for (int64_t t = 0; t < n_nodes * k; ++t)
+        if (w[t] != 0.0 && (idx[t] < 0 || idx[t] >= n_nodes)) return set_err(nullptr, DDX_E_ARG, "neighbour index out of range");
+    std::vector<int64_t> ip;
+    std::vector<int32_t> gi;
+    std::vector<double> gw;
+    assemble_graph(n_nodes, k, idx, w, ip, gi, gw);
+    memcpy(indptr_out, ip.data(), sizeof(int64_t) * ip.size());
+    if (!gi.empty()) {
+        memcpy(indices_out, gi.data(), sizeof(int32_t) * gi.size());
+        memcpy(weights_out, gw.data(), sizeof(double) * gw.size());
+    }
+    return DDX_OK;
 }
 
 int ddx_get_graph_size(ddx_ctx* ctx, int64_t* n_nodes, int64_t* n_entries) {

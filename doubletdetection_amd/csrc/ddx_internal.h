@@ -15,6 +15,7 @@
 namespace ddx {
 
 constexpr int kWave = 64;  // gfx950 wavefront
+constexpr int kPanelRows = 8192;  // rows per panel of the column-major mirror (8192 x 40 x 8 B = 2.6 MB of sketch rows)
 
 struct DevBuf {
     void* p = nullptr;
@@ -77,6 +78,11 @@ struct ddx_ctx {
     ddx::DevBuf csc_s_raw;           // float [cap_synth]
     ddx::DevBuf csc_s_x;             // float [cap_synth]
     ddx::DevBuf sort_keys_in, sort_keys_out, sort_vals_in, sort_vals_out, sort_tmp;
+    // the mirror is ordered by (row panel, column): entries of column j inside panel p form the segment
+    // colptr[p*H + j] .. colptr[p*H + j + 1].  A panel is kPanelRows consecutive rows of the augmented
+    // matrix, so the rows gathered while a panel is processed stay L2-resident.
+    int32_t P_o = 0;                 // panels covering the original rows [0, N)
+    int32_t p_s0 = 0, P_s = 0;       // first panel touched by synthetic rows, number of such panels
 
     // normalisation state
     float pseudocount = 0.1f;
@@ -90,7 +96,7 @@ struct ddx_ctx {
 
     // PCA work space
     int32_t C = 0;
-    ddx::DevBuf pcaA, pcaB, pcaSmall, pcaPartial, pcaVec;
+    ddx::DevBuf pcaA, pcaB, pcaSmall, pcaPartial, pcaVec, pcaPanel;
     ddx::DevBuf emb32;               // float  [M*C]
     ddx::DevBuf emb64;               // double [M*C]
     ddx::DevBuf sing;                // double [C]
@@ -161,6 +167,9 @@ int stage_dense_rows(ddx_ctx* ctx, int64_t row0, int64_t nrows, float* out_host)
 int stage_pca(ddx_ctx* ctx, int32_t C, int32_t oversample, int32_t n_iter, const double* q0, int64_t q0_rows);
 int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self);
 int stage_build_graph(ddx_ctx* ctx, int32_t mode);
+int stage_graph_relations(ddx_ctx* ctx, int32_t mode, int32_t* idx_host, double* w_host);
+void assemble_graph(int64_t M, int K, const int32_t* idx, const double* w, std::vector<int64_t>& ip,
+                    std::vector<int32_t>& gi, std::vector<double>& gw);
 int stage_gene_variances(ddx_ctx* ctx, float* var_out);
 int stage_select_columns(ddx_ctx* ctx, const int64_t* cols, int32_t n_cols);
 

@@ -76,18 +76,28 @@ __global__ void __launch_bounds__(256) k_spmm_rows(const int64_t* __restrict__ i
 
 // ------------------------------------------------------------------------------------------------
 // SpMM over columns:  W[j,:] = sum_i (x_ij - z_j) Y[i,:] - m_j u[:]     (A^T Y, u = 1^T Y)
-// One 256-thread block per column; its 4 waves take interleaved 64-entry groups of the column's
-// two segments (original rows, synthetic rows); partial sums are combined in fixed order.
+// The mirror is ordered by (row panel, column).  One wave owns one (panel, column) segment and
+// accumulates  Wp[panel][j][:] = sum_{i in panel} (x_ij - z_j) Y[i,:] ; a second tiny kernel adds the
+// panels in order.  Only the rows of one panel (kPanelRows x L x 8 B ~ 2.6 MB) are gathered while a
+// panel is processed, and all blocks of a panel are placed on the same XCD (block b runs on XCD b % 8),
+// so those gathers are served by that XCD's 4 MB L2 instead of the Infinity Cache.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_spmm_cols(const int64_t* __restrict__ cp_o, const int32_t* __restrict__ row_o,
-                                                   const float* __restrict__ x_o, const int64_t* __restrict__ cp_s,
-                                                   const int32_t* __restrict__ row_s, const float* __restrict__ x_s,
-                                                   const float* __restrict__ zcol, const double* __restrict__ colmean,
-                                                   const double* __restrict__ Yin, int L, int lpn, int slots,
-                                                   const double* __restrict__ uvec, double* __restrict__ W) {
-    __shared__ double part[4][kMaxL];
-    const int j = blockIdx.x;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+                                                   const float* __restrict__ x_o, int P_o,
+                                                   const int64_t* __restrict__ cp_s, const int32_t* __restrict__ row_s,
+                                                   const float* __restrict__ x_s, int p_s0, int P_s, int P, int32_t H,
+                                                   const float* __restrict__ zcol, const double* __restrict__ Yin,
+                                                   int L, int lpn, int slots, double* __restrict__ Wp) {
+    // XCD-aware decode: xcd = b % 8 handles panels xcd, xcd + 8, ... one after the other
+    const int groups = (H + 3) >> 2;                 // 4 columns (one per wave) per block
+    const int64_t b = blockIdx.x;
+    const int xcd = (int)(b & 7);
+    const int64_t t = b >> 3;
+    const int panel = xcd + 8 * (int)(t / groups);
+    if (panel >= P) return;
+    const int lane = threadIdx.x & 63;
+    const int j = (int)(t % groups) * 4 + (threadIdx.x >> 6);
+    if (j >= H) return;
     const int slot = lane / lpn, sub = lane - slot * lpn;
     const bool active = slot < slots;
     const int c0 = 2 * sub;
@@ -95,11 +105,20 @@ __global__ void __launch_bounds__(256) k_spmm_cols(const int64_t* __restrict__ c
     const double z = (double)zcol[j];
     double acc0 = 0.0, acc1 = 0.0;
     for (int seg = 0; seg < 2; ++seg) {
-        const int64_t* cp = seg ? cp_s : cp_o;
-        const int32_t* rows = seg ? row_s : row_o;
-        const float* x = seg ? x_s : x_o;
-        const int64_t lo = cp[j], hi = cp[j + 1];
-        for (int64_t base = lo + (int64_t)w * 64; base < hi; base += 256) {
+        int64_t lo, hi;
+        const int32_t* rows;
+        const float* x;
+        if (seg == 0) {
+            if (panel >= P_o) continue;
+            lo = cp_o[(int64_t)panel * H + j]; hi = cp_o[(int64_t)panel * H + j + 1];
+            rows = row_o; x = x_o;
+        } else {
+            const int ps = panel - p_s0;
+            if (ps < 0 || ps >= P_s) continue;
+            lo = cp_s[(int64_t)ps * H + j]; hi = cp_s[(int64_t)ps * H + j + 1];
+            rows = row_s; x = x_s;
+        }
+        for (int64_t base = lo; base < hi; base += 64) {
             const int64_t p = base + lane;
             int32_t i = 0;
             double d = 0.0;
@@ -130,14 +149,22 @@ __global__ void __launch_bounds__(256) k_spmm_cols(const int64_t* __restrict__ c
         s1 += o1;
     }
     if (slot == 0 && c0 < L) {
-        part[w][c0] = s0;
-        if (has1) part[w][c0 + 1] = s1;
+        double* w = Wp + ((int64_t)panel * H + j) * L + c0;
+        w[0] = s0;
+        if (has1) w[1] = s1;
     }
-    __syncthreads();
-    for (int c = threadIdx.x; c < L; c += 256) {
-        const double tot = ((part[0][c] + part[1][c]) + part[2][c]) + part[3][c];
-        W[(int64_t)j * L + c] = tot - colmean[j] * uvec[c];
-    }
+}
+
+// W[j,c] = sum_p Wp[p][j][c] - m_j u_c   (panels added in order)
+__global__ void k_sum_panels(const double* __restrict__ Wp, int P, int32_t H, int L, const double* __restrict__ colmean,
+                             const double* __restrict__ uvec, double* __restrict__ W) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)H * L) return;
+    const int64_t j = t / L;
+    const int c = (int)(t - j * L);
+    double s = 0.0;
+    for (int p = 0; p < P; ++p) s += Wp[(int64_t)p * H * L + t];
+    W[t] = s - colmean[j] * uvec[c];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -369,10 +396,15 @@ static int apply_cols(PcaWork& w, const double* Yrow, double* Wcol) {  // A^T Y 
         ScopedTimer t(c, "pca_colsum");
         wcolsum(w, Yrow, w.M, nullptr, uvec);
     }
+    const int P = (int)ceil_div(w.M, kPanelRows);
+    const int groups = (w.H + 3) / 4;
+    const int64_t grid = 8 * ceil_div(P, 8) * groups;
     ScopedTimer t(c, "spmm_cols");
-    k_spmm_cols<<<(unsigned)w.H, 256, 0, c->stream>>>(c->csc_o_colptr.as<int64_t>(), c->csc_o_row.as<int32_t>(), c->csc_o_x.as<float>(),
-                                                      c->csc_s_colptr.as<int64_t>(), c->csc_s_row.as<int32_t>(), c->csc_s_x.as<float>(),
-                                                      c->zcol.as<float>(), c->colmean.as<double>(), Yrow, w.L, w.lpn, w.slots, uvec, Wcol);
+    k_spmm_cols<<<(unsigned)grid, 256, 0, c->stream>>>(c->csc_o_colptr.as<int64_t>(), c->csc_o_row.as<int32_t>(), c->csc_o_x.as<float>(), c->P_o,
+                                                       c->csc_s_colptr.as<int64_t>(), c->csc_s_row.as<int32_t>(), c->csc_s_x.as<float>(), c->p_s0,
+                                                       c->P_s, P, w.H, c->zcol.as<float>(), Yrow, w.L, w.lpn, w.slots, c->pcaPanel.as<double>());
+    k_sum_panels<<<(unsigned)ceil_div((int64_t)w.H * w.L, 256), 256, 0, c->stream>>>(c->pcaPanel.as<double>(), P, w.H, w.L, c->colmean.as<double>(),
+                                                                                      uvec, Wcol);
     return DDX_OK;
 }
 
@@ -391,6 +423,7 @@ int stage_pca(ddx_ctx* ctx, int32_t C, int32_t oversample, int32_t n_iter, const
     DDX_TRY(ensure(ctx, ctx->pcaSmall, sizeof(double) * (4 * L * L + 4 * L) + 256));
     DDX_TRY(ensure(ctx, ctx->pcaPartial, sizeof(double) * 512 * (size_t)std::max(L * L, 128)));
     DDX_TRY(ensure(ctx, ctx->pcaVec, 256));
+    DDX_TRY(ensure(ctx, ctx->pcaPanel, sizeof(double) * (size_t)ceil_div(M, kPanelRows) * H * L));
     DDX_TRY(ensure(ctx, ctx->emb64, sizeof(double) * (size_t)M * C));
     DDX_TRY(ensure(ctx, ctx->emb32, sizeof(float) * (size_t)M * C));
     DDX_TRY(ensure(ctx, ctx->sing, sizeof(double) * L));

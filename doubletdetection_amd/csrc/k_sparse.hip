@@ -241,10 +241,22 @@ __global__ void k_iota_u32(uint32_t* out, int64_t n, uint32_t base) {
     if (i < n) out[i] = base + (uint32_t)i;
 }
 
-// colptr[j] = first sorted position whose key >= j, j in [0, H]
-__global__ void k_colptr_from_sorted(const int32_t* __restrict__ keys, int64_t n, int32_t H, int64_t* __restrict__ colptr) {
+// sort key of every stored entry of rows [row_lo, row_lo+nrows): (panel(row) - panel0) * H + column
+__global__ void __launch_bounds__(256) k_panel_keys(const int64_t* __restrict__ indptr, const int32_t* __restrict__ cols,
+                                                    int64_t row_lo, int64_t nrows, int32_t H, int32_t panel0, int64_t e0,
+                                                    int32_t* __restrict__ keys) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= nrows) return;
+    const int64_t row = row_lo + r;
+    const int32_t base = ((int32_t)(row / kPanelRows) - panel0) * H;
+    for (int64_t p = indptr[row] + lane; p < indptr[row + 1]; p += 64) keys[p - e0] = base + cols[p];
+}
+
+// colptr[j] = first sorted position whose key >= j, j in [0, nkeys]
+__global__ void k_colptr_from_sorted(const int32_t* __restrict__ keys, int64_t n, int32_t nkeys, int64_t* __restrict__ colptr) {
     int32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j > H) return;
+    if (j > nkeys) return;
     int64_t lo = 0, hi = n;
     while (lo < hi) {
         int64_t mid = (lo + hi) >> 1;
@@ -253,7 +265,7 @@ __global__ void k_colptr_from_sorted(const int32_t* __restrict__ keys, int64_t n
     colptr[j] = lo;
 }
 
-// gather row id and raw value of every column-sorted entry; pos = CSR position
+// gather row id and raw value of every mirror entry; pos = CSR position
 __global__ void k_csc_gather(const uint32_t* __restrict__ pos, int64_t n, const int64_t* __restrict__ indptr,
                              int64_t row_lo, int64_t row_hi, const float* __restrict__ raw,
                              int32_t* __restrict__ row_out, float* __restrict__ raw_out) {
@@ -270,38 +282,44 @@ __global__ void k_csc_gather(const uint32_t* __restrict__ pos, int64_t n, const 
     raw_out[t] = raw[p];
 }
 
-// Build the column-major mirror of CSR entries [e0, e0+n) (rows [row_lo,row_hi)): stable radix sort
-// of (column, position) pairs -> entries of one column are in increasing row order.
-static int build_csc(ddx_ctx* ctx, int64_t e0, int64_t n, int64_t row_lo, int64_t row_hi, DevBuf& colptr,
-                     DevBuf& rows, DevBuf& raws) {
+// Build the (panel, column)-ordered mirror of CSR entries [e0, e0+n) (rows [row_lo,row_hi)): stable radix
+// sort of (key, position) pairs -> inside a (panel, column) segment entries are in increasing row order.
+static int build_csc(ddx_ctx* ctx, int64_t e0, int64_t n, int64_t row_lo, int64_t row_hi, int32_t panel0,
+                     int32_t npanels, DevBuf& colptr, DevBuf& rows, DevBuf& raws) {
     const int32_t H = ctx->H;
-    DDX_TRY(ensure(ctx, colptr, sizeof(int64_t) * (H + 1)));
+    const int64_t nkeys64 = (int64_t)npanels * H;
+    if (nkeys64 >= ((int64_t)1 << 30)) return set_err(ctx, DDX_E_UNSUPPORTED, "panel x column key space too large");
+    const int32_t nkeys = (int32_t)nkeys64;
+    DDX_TRY(ensure(ctx, colptr, sizeof(int64_t) * (nkeys + 1)));
     if (n == 0) {
-        DDX_HIP(ctx, hipMemsetAsync(colptr.p, 0, sizeof(int64_t) * (H + 1), ctx->stream));
+        DDX_HIP(ctx, hipMemsetAsync(colptr.p, 0, sizeof(int64_t) * (nkeys + 1), ctx->stream));
         return DDX_OK;
     }
+    DDX_TRY(ensure(ctx, ctx->sort_keys_in, sizeof(int32_t) * n));
     DDX_TRY(ensure(ctx, ctx->sort_keys_out, sizeof(int32_t) * n));
     DDX_TRY(ensure(ctx, ctx->sort_vals_in, sizeof(uint32_t) * n));
     DDX_TRY(ensure(ctx, ctx->sort_vals_out, sizeof(uint32_t) * n));
     k_iota_u32<<<(unsigned)ceil_div(n, 256), 256, 0, ctx->stream>>>(ctx->sort_vals_in.as<uint32_t>(), n, (uint32_t)e0);
+    k_panel_keys<<<(unsigned)ceil_div(row_hi - row_lo, 4), 256, 0, ctx->stream>>>(ctx->aug_indptr.as<int64_t>(), ctx->aug_indices.as<int32_t>(),
+                                                                                 row_lo, row_hi - row_lo, H, panel0, e0,
+                                                                                 ctx->sort_keys_in.as<int32_t>());
     int end_bit = 1;
-    while ((1 << end_bit) < H) ++end_bit;
-    const int32_t* keys_in = ctx->aug_indices.as<int32_t>() + e0;
+    while (((int64_t)1 << end_bit) < nkeys64) ++end_bit;
     size_t tmp_bytes = 0;
-    DDX_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys_in, ctx->sort_keys_out.as<int32_t>(),
+    DDX_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, ctx->sort_keys_in.as<int32_t>(), ctx->sort_keys_out.as<int32_t>(),
                                                     ctx->sort_vals_in.as<uint32_t>(), ctx->sort_vals_out.as<uint32_t>(),
                                                     (int)n, 0, end_bit, ctx->stream));
     DDX_TRY(ensure(ctx, ctx->sort_tmp, tmp_bytes));
     {
         ScopedTimer t(ctx, "csc_radix_sort");
-        DDX_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(ctx->sort_tmp.p, tmp_bytes, keys_in,
+        DDX_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(ctx->sort_tmp.p, tmp_bytes, ctx->sort_keys_in.as<int32_t>(),
                                                         ctx->sort_keys_out.as<int32_t>(), ctx->sort_vals_in.as<uint32_t>(),
                                                         ctx->sort_vals_out.as<uint32_t>(), (int)n, 0, end_bit, ctx->stream));
     }
     {
         ScopedTimer t(ctx, "csc_gather");
-        k_colptr_from_sorted<<<(unsigned)ceil_div(H + 1, 256), 256, 0, ctx->stream>>>(ctx->sort_keys_out.as<int32_t>(), n, H,
-                                                                                      colptr.as<int64_t>());
+        k_colptr_from_sorted<<<(unsigned)ceil_div(nkeys + 1, 256), 256, 0, ctx->stream>>>(ctx->sort_keys_out.as<int32_t>(), n, nkeys,
+                                                                                          colptr.as<int64_t>());
         k_csc_gather<<<(unsigned)ceil_div(n, 256), 256, 0, ctx->stream>>>(ctx->sort_vals_out.as<uint32_t>(), n,
                                                                           ctx->aug_indptr.as<int64_t>(), row_lo, row_hi,
                                                                           ctx->aug_raw.as<float>(), rows.as<int32_t>(),
@@ -367,7 +385,8 @@ int stage_upload_counts(ddx_ctx* ctx, int64_t N, int32_t H, const int64_t* indpt
     DDX_TRY(ensure(ctx, ctx->csc_o_row, sizeof(int32_t) * (size_t)(nnz + 1)));
     DDX_TRY(ensure(ctx, ctx->csc_o_raw, sizeof(float) * (size_t)(nnz + 1)));
     DDX_TRY(ensure(ctx, ctx->csc_o_x, sizeof(float) * (size_t)(nnz + 1)));
-    DDX_TRY(build_csc(ctx, 0, nnz, 0, N, ctx->csc_o_colptr, ctx->csc_o_row, ctx->csc_o_raw));
+    ctx->P_o = (int32_t)ceil_div(N, kPanelRows);
+    DDX_TRY(build_csc(ctx, 0, nnz, 0, N, 0, ctx->P_o, ctx->csc_o_colptr, ctx->csc_o_row, ctx->csc_o_raw));
     DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->have_counts = true;
     return DDX_OK;
@@ -464,10 +483,10 @@ __global__ void __launch_bounds__(256) k_lognorm_rows(const int64_t* __restrict_
 }
 
 __global__ void __launch_bounds__(256) k_lognorm_csc(const int32_t* __restrict__ rows, const float* __restrict__ raw,
-                                                     const int64_t* __restrict__ colptr, int32_t H,
+                                                     const int64_t* __restrict__ colptr, int32_t nkeys,
                                                      const double* __restrict__ lib64, const float* __restrict__ med,
                                                      float pc, int use_log1p, float* __restrict__ x) {
-    const int64_t n = colptr[H];
+    const int64_t n = colptr[nkeys];
     const float m = med[0];
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x)
         x[t] = lognorm_value(raw[t], lib64[rows[t]], m, pc, use_log1p != 0);
@@ -481,9 +500,9 @@ __global__ void k_fill_f32(float* out, int64_t n, float v) {
 // Per column j (one 256-thread block): deterministic float64 sums over the stored entries of both
 // column-major segments.  mode 0: colmean[j] = sum(x - z_j) / M.
 // mode 1 (scale statistics): stat[2j] = sum(x - z_j), stat[2j+1] = sum(float32(x*x)) , cnt via colptr.
-__global__ void __launch_bounds__(256) k_col_sums(const int64_t* __restrict__ cp_o, const float* __restrict__ x_o,
-                                                  const int64_t* __restrict__ cp_s, const float* __restrict__ x_s,
-                                                  const float* __restrict__ zcol, int64_t M, int mode,
+__global__ void __launch_bounds__(256) k_col_sums(const int64_t* __restrict__ cp_o, const float* __restrict__ x_o, int P_o,
+                                                  const int64_t* __restrict__ cp_s, const float* __restrict__ x_s, int P_s,
+                                                  const float* __restrict__ zcol, int32_t H, int64_t M, int mode,
                                                   double* __restrict__ out) {
     __shared__ double red[2][256];
     const int j = blockIdx.x, tid = threadIdx.x;
@@ -492,11 +511,14 @@ __global__ void __launch_bounds__(256) k_col_sums(const int64_t* __restrict__ cp
     for (int seg = 0; seg < 2; ++seg) {
         const int64_t* cp = seg ? cp_s : cp_o;
         const float* x = seg ? x_s : x_o;
-        const int64_t lo = cp[j], hi = cp[j + 1];
-        for (int64_t t = lo + tid; t < hi; t += 256) {
-            const float xv = x[t];
-            a += (double)xv - z;
-            if (mode) { const float sq = xv * xv; b += (double)sq; }
+        const int P = seg ? P_s : P_o;
+        for (int p = 0; p < P; ++p) {
+            const int64_t lo = cp[(int64_t)p * H + j], hi = cp[(int64_t)p * H + j + 1];
+            for (int64_t t = lo + tid; t < hi; t += 256) {
+                const float xv = x[t];
+                a += (double)xv - z;
+                if (mode) { const float sq = xv * xv; b += (double)sq; }
+            }
         }
     }
     red[0][tid] = a;
@@ -540,7 +562,9 @@ int stage_lognormalise(ddx_ctx* ctx, float pseudocount) {
         k_median_from_sorted<<<1, 64, 0, ctx->stream>>>(ctx->lib_sorted.as<float>(), M, ctx->median.as<float>());
     }
     // column-major mirror of the synthetic rows
-    DDX_TRY(build_csc(ctx, ctx->nnz, nnz_s, N, M, ctx->csc_s_colptr, ctx->csc_s_row, ctx->csc_s_raw));
+    ctx->p_s0 = (int32_t)(N / kPanelRows);
+    ctx->P_s = S ? (int32_t)((M - 1) / kPanelRows) - ctx->p_s0 + 1 : 0;
+    DDX_TRY(build_csc(ctx, ctx->nnz, nnz_s, N, M, ctx->p_s0, ctx->P_s > 0 ? ctx->P_s : 1, ctx->csc_s_colptr, ctx->csc_s_row, ctx->csc_s_raw));
     const int use_log1p = (pseudocount == 1.0f);
     {
         ScopedTimer t(ctx, "lognorm_rows");
@@ -551,10 +575,10 @@ int stage_lognormalise(ddx_ctx* ctx, float pseudocount) {
     {
         ScopedTimer t(ctx, "lognorm_cols");
         k_lognorm_csc<<<2048, 256, 0, ctx->stream>>>(ctx->csc_o_row.as<int32_t>(), ctx->csc_o_raw.as<float>(), ctx->csc_o_colptr.as<int64_t>(),
-                                                     H, ctx->lib64.as<double>(), ctx->median.as<float>(), pseudocount, use_log1p,
+                                                     ctx->P_o * H, ctx->lib64.as<double>(), ctx->median.as<float>(), pseudocount, use_log1p,
                                                      ctx->csc_o_x.as<float>());
         k_lognorm_csc<<<2048, 256, 0, ctx->stream>>>(ctx->csc_s_row.as<int32_t>(), ctx->csc_s_raw.as<float>(), ctx->csc_s_colptr.as<int64_t>(),
-                                                     H, ctx->lib64.as<double>(), ctx->median.as<float>(), pseudocount, use_log1p,
+                                                     (ctx->P_s > 0 ? ctx->P_s : 1) * H, ctx->lib64.as<double>(), ctx->median.as<float>(), pseudocount, use_log1p,
                                                      ctx->csc_s_x.as<float>());
     }
     DDX_TRY(ensure(ctx, ctx->zcol, sizeof(float) * H));
@@ -563,8 +587,8 @@ int stage_lognormalise(ddx_ctx* ctx, float pseudocount) {
     k_fill_f32<<<(unsigned)ceil_div(H, 256), 256, 0, ctx->stream>>>(ctx->zcol.as<float>(), H, z);
     {
         ScopedTimer t(ctx, "col_sums");
-        k_col_sums<<<(unsigned)H, 256, 0, ctx->stream>>>(ctx->csc_o_colptr.as<int64_t>(), ctx->csc_o_x.as<float>(), ctx->csc_s_colptr.as<int64_t>(),
-                                                         ctx->csc_s_x.as<float>(), ctx->zcol.as<float>(), M, 0, ctx->colmean.as<double>());
+        k_col_sums<<<(unsigned)H, 256, 0, ctx->stream>>>(ctx->csc_o_colptr.as<int64_t>(), ctx->csc_o_x.as<float>(), ctx->P_o, ctx->csc_s_colptr.as<int64_t>(),
+                                                         ctx->csc_s_x.as<float>(), ctx->P_s, ctx->zcol.as<float>(), H, M, 0, ctx->colmean.as<double>());
     }
     DDX_HIP(ctx, hipGetLastError());
     ctx->pseudocount = pseudocount;
@@ -578,14 +602,17 @@ int stage_lognormalise(ddx_ctx* ctx, float pseudocount) {
 // standard scaling (restated scanpy pp.scale; see oracle/dd_oracle.py:scale_like_scanpy)
 // ------------------------------------------------------------------------------------------------
 // per column: mean (f64), unbiased variance from the mean of float32-rounded squares, std==0 -> 1
-__global__ void k_scale_stats(const double* __restrict__ stat, const int64_t* __restrict__ cp_o,
-                              const int64_t* __restrict__ cp_s, const float* __restrict__ zcol, int64_t M, int32_t H,
+__global__ void k_scale_stats(const double* __restrict__ stat, const int64_t* __restrict__ cp_o, int P_o,
+                              const int64_t* __restrict__ cp_s, int P_s, const float* __restrict__ zcol, int64_t M, int32_t H,
                               double* __restrict__ mean_out, double* __restrict__ std_out) {
 #pragma clang fp contract(off)
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= H) return;
     const double z = (double)zcol[j];
-    const double cnt = (double)((cp_o[j + 1] - cp_o[j]) + (cp_s[j + 1] - cp_s[j]));
+    int64_t stored = 0;
+    for (int p = 0; p < P_o; ++p) stored += cp_o[(int64_t)p * H + j + 1] - cp_o[(int64_t)p * H + j];
+    for (int p = 0; p < P_s; ++p) stored += cp_s[(int64_t)p * H + j + 1] - cp_s[(int64_t)p * H + j];
+    const double cnt = (double)stored;
     const float zsq = zcol[j] * zcol[j];
     const double zz = (double)zsq;
     const double mean = z + stat[2 * j] / (double)M;
@@ -616,11 +643,14 @@ __global__ void k_scale_rows(const int32_t* __restrict__ cols, int64_t n_ptr_ind
     }
 }
 
-__global__ void __launch_bounds__(256) k_scale_cols(const int64_t* __restrict__ cp, const double* __restrict__ mean,
-                                                    const double* __restrict__ sd, float maxv, float* __restrict__ x) {
+__global__ void __launch_bounds__(256) k_scale_cols(const int64_t* __restrict__ cp, int P, int32_t H,
+                                                    const double* __restrict__ mean, const double* __restrict__ sd,
+                                                    float maxv, float* __restrict__ x) {
     const int j = blockIdx.x;
     const double m = mean[j], s = sd[j];
-    for (int64_t t = cp[j] + threadIdx.x; t < cp[j + 1]; t += 256) x[t] = scale_value(x[t], m, s, maxv);
+    for (int p = 0; p < P; ++p)
+        for (int64_t t = cp[(int64_t)p * H + j] + threadIdx.x; t < cp[(int64_t)p * H + j + 1]; t += 256)
+            x[t] = scale_value(x[t], m, s, maxv);
 }
 
 __global__ void k_scale_zcol(const double* __restrict__ mean, const double* __restrict__ sd, float maxv, int32_t H,
@@ -637,17 +667,17 @@ int stage_scale(ddx_ctx* ctx, float max_value) {
     double* mean = stat + 2 * H;
     double* sd = stat + 3 * H;
     ScopedTimer t(ctx, "scale");
-    k_col_sums<<<(unsigned)H, 256, 0, ctx->stream>>>(ctx->csc_o_colptr.as<int64_t>(), ctx->csc_o_x.as<float>(), ctx->csc_s_colptr.as<int64_t>(),
-                                                     ctx->csc_s_x.as<float>(), ctx->zcol.as<float>(), M, 1, stat);
-    k_scale_stats<<<(unsigned)ceil_div(H, 256), 256, 0, ctx->stream>>>(stat, ctx->csc_o_colptr.as<int64_t>(), ctx->csc_s_colptr.as<int64_t>(),
-                                                                       ctx->zcol.as<float>(), M, H, mean, sd);
+    k_col_sums<<<(unsigned)H, 256, 0, ctx->stream>>>(ctx->csc_o_colptr.as<int64_t>(), ctx->csc_o_x.as<float>(), ctx->P_o, ctx->csc_s_colptr.as<int64_t>(),
+                                                     ctx->csc_s_x.as<float>(), ctx->P_s, ctx->zcol.as<float>(), H, M, 1, stat);
+    k_scale_stats<<<(unsigned)ceil_div(H, 256), 256, 0, ctx->stream>>>(stat, ctx->csc_o_colptr.as<int64_t>(), ctx->P_o, ctx->csc_s_colptr.as<int64_t>(),
+                                                                       ctx->P_s, ctx->zcol.as<float>(), M, H, mean, sd);
     k_scale_rows<<<2048, 256, 0, ctx->stream>>>(ctx->aug_indices.as<int32_t>(), M, ctx->aug_indptr.as<int64_t>(), mean, sd, max_value,
                                                 ctx->aug_x.as<float>());
-    k_scale_cols<<<(unsigned)H, 256, 0, ctx->stream>>>(ctx->csc_o_colptr.as<int64_t>(), mean, sd, max_value, ctx->csc_o_x.as<float>());
-    k_scale_cols<<<(unsigned)H, 256, 0, ctx->stream>>>(ctx->csc_s_colptr.as<int64_t>(), mean, sd, max_value, ctx->csc_s_x.as<float>());
+    k_scale_cols<<<(unsigned)H, 256, 0, ctx->stream>>>(ctx->csc_o_colptr.as<int64_t>(), ctx->P_o, H, mean, sd, max_value, ctx->csc_o_x.as<float>());
+    k_scale_cols<<<(unsigned)H, 256, 0, ctx->stream>>>(ctx->csc_s_colptr.as<int64_t>(), ctx->P_s, H, mean, sd, max_value, ctx->csc_s_x.as<float>());
     k_scale_zcol<<<(unsigned)ceil_div(H, 256), 256, 0, ctx->stream>>>(mean, sd, max_value, H, ctx->zcol.as<float>());
-    k_col_sums<<<(unsigned)H, 256, 0, ctx->stream>>>(ctx->csc_o_colptr.as<int64_t>(), ctx->csc_o_x.as<float>(), ctx->csc_s_colptr.as<int64_t>(),
-                                                     ctx->csc_s_x.as<float>(), ctx->zcol.as<float>(), M, 0, ctx->colmean.as<double>());
+    k_col_sums<<<(unsigned)H, 256, 0, ctx->stream>>>(ctx->csc_o_colptr.as<int64_t>(), ctx->csc_o_x.as<float>(), ctx->P_o, ctx->csc_s_colptr.as<int64_t>(),
+                                                     ctx->csc_s_x.as<float>(), ctx->P_s, ctx->zcol.as<float>(), H, M, 0, ctx->colmean.as<double>());
     DDX_HIP(ctx, hipGetLastError());
     ctx->scaled = true;
     ctx->have_emb = ctx->have_knn = false;

@@ -127,6 +127,14 @@ int ddx_get_knn(ddx_ctx* ctx, int32_t* idx_out /* [M*k] */, double* dist2_out /*
  * mode 2: scanpy neighbour topology, unit weights (union of kNN relations, self excluded)
  * Result: symmetric CSR on the host, fetched with ddx_get_graph. */
 int ddx_build_graph(ddx_ctx* ctx, int32_t mode);
+/* The same in two halves, so that the host half can run on a worker thread while the GPU moves on:
+ * ddx_graph_relations runs the device kernels and copies back the [M,k] relation table: idx (kNN
+ * indices) and w (relation weight; 0 = no edge; negative = one-directional relation whose reverse
+ * entry must be added).  ddx_assemble_graph (context-free, thread-safe) turns that table into the
+ * symmetric CSR; indices_out / weights_out need room for 2*M*k entries. */
+int ddx_graph_relations(ddx_ctx* ctx, int32_t mode, int32_t* idx_out /* [M*k] */, double* w_out /* [M*k] */);
+int ddx_assemble_graph(int64_t n_nodes, int32_t k, const int32_t* idx, const double* w,
+                       int64_t* indptr_out /* [M+1] */, int32_t* indices_out, double* weights_out);
 int ddx_get_graph_size(ddx_ctx* ctx, int64_t* n_nodes, int64_t* n_entries);
 int ddx_get_graph(ddx_ctx* ctx, int64_t* indptr, int32_t* indices, double* weights);
 
