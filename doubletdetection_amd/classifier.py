@@ -428,9 +428,9 @@ class BoostClassifier:
         t = torch.from_numpy(buf)
         if use_cuda:
             t = t.to(f"cuda:{device}")
-        out = torch.empty((world, per_rank, width), dtype=torch.float64, device=t.device)
-        dist.all_gather_into_tensor(out, t)
-        out = out.cpu().numpy()
+        out = torch.empty((world * per_rank, width), dtype=torch.float64, device=t.device)
+        dist.all_gather_into_tensor(out, t)          # the one collective of the path (RCCL under nccl)
+        out = out.cpu().numpy().reshape(world, per_rank, width)
         rows = {}
         for i in range(n_iters):
             r, slot = i % world, i // world

@@ -5,7 +5,10 @@
 // text in oracle/louvain_ref.py; this file must reproduce it bit for bit (tests/test_louvain.py).
 // Compiled with -ffp-contract=off so that no multiply-add is fused.
 #include <algorithm>
+#include <chrono>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "../../include/ddx.h"
@@ -189,10 +192,20 @@ extern "C" int ddx_louvain(int64_t n_nodes, const int64_t* indptr, const int32_t
     for (int64_t v = 0; v < n_nodes; ++v) membership[v] = (int32_t)v;
     std::vector<int32_t> comm, renum;
     double q = 0.0;
+    const bool dbg = std::getenv("DDX_LOUVAIN_DEBUG") != nullptr;
     while (true) {
+        auto t0 = std::chrono::steady_clock::now();
         const bool improved = one_level(g, gamma, rng, comm, &q);
+        auto t1 = std::chrono::steady_clock::now();
         Graph next;
         aggregate(g, comm, next, renum);
+        if (dbg) {
+            auto t2 = std::chrono::steady_clock::now();
+            std::fprintf(stderr, "[louvain] level n=%lld nnz=%lld -> %lld nodes; move %.1f ms, aggregate %.1f ms, Q=%.6f\n",
+                         (long long)g.n(), (long long)g.indices.size(), (long long)next.n(),
+                         std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                         std::chrono::duration<double, std::milli>(t2 - t1).count(), q);
+        }
         for (int64_t v = 0; v < n_nodes; ++v) membership[v] = renum[comm[membership[v]]];
         g.indptr.swap(next.indptr);
         g.indices.swap(next.indices);

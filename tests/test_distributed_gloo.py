@@ -1,0 +1,82 @@
+"""N>1 path on CPU: two processes, gloo backend, boosting iterations sharded i % world == rank and
+assembled by the single all-gather.  Device stages come from the test-only oracle engine, clustering
+and scoring from libddx's host C++ -- i.e. everything except the HIP kernels is the product path."""
+import os
+import socket
+import sys
+import warnings
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, csr_from, golden_kwargs, load_golden
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, case, n_iters, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+
+    from doubletdetection_amd import BoostClassifier
+    from oracle_engine import make_engine_factory
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = load_golden(case)
+        kw = golden_kwargs(g)
+        kw["n_iters"] = n_iters
+        BoostClassifier._engine_factory = staticmethod(make_engine_factory(kw.get("random_state", 0)))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            clf = BoostClassifier(**kw).fit(csr_from(g, "counts"))
+            labels = clf.predict()
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), scores=clf.all_scores_, logp=clf.all_log_p_values_,
+                 comm=clf.communities_, synth=clf.synth_communities_, parents=np.asarray(clf.parents_),
+                 labels=labels, voting=clf.voting_average_)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case,n_iters", [("case_c_reftest_scaled", 3), ("case_a_hvg_pheno", 2)])
+def test_two_rank_fit_equals_single_process(tmp_path, case, n_iters):
+    import torch.multiprocessing as mp
+
+    from doubletdetection_amd import BoostClassifier
+    from oracle_engine import make_engine_factory
+
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, case, n_iters, str(tmp_path)), nprocs=2, join=True)
+    g = load_golden(case)
+    kw = golden_kwargs(g)
+    kw["n_iters"] = n_iters
+    old = BoostClassifier._engine_factory
+    BoostClassifier._engine_factory = staticmethod(make_engine_factory(kw.get("random_state", 0)))
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            single = BoostClassifier(**kw).fit(csr_from(g, "counts"))
+            single_labels = single.predict()
+    finally:
+        BoostClassifier._engine_factory = old
+    for rank in (0, 1):                                  # every rank holds the complete result
+        r = np.load(tmp_path / f"rank{rank}.npz")
+        np.testing.assert_array_equal(r["parents"], np.asarray(single.parents_))
+        np.testing.assert_array_equal(r["comm"], single.communities_)
+        np.testing.assert_array_equal(r["synth"], single.synth_communities_)
+        np.testing.assert_array_equal(r["scores"], single.all_scores_)
+        np.testing.assert_array_equal(r["logp"], single.all_log_p_values_)
+        np.testing.assert_array_equal(r["labels"], single_labels)
+        np.testing.assert_array_equal(r["voting"], single.voting_average_)
+    # iterations the golden run also did must reproduce the reference's own output
+    k = min(n_iters, g["communities"].shape[0])
+    np.testing.assert_array_equal(single.communities_[:k], g["communities"][:k])

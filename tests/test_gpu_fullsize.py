@@ -1,0 +1,130 @@
+"""Size-independent properties of the HIP path at BASELINE.json sizes (configs[1]: 50k x 20k, ~5 % nnz),
+where the CPU oracle would take minutes per stage.  GPU only."""
+import warnings
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+
+N, G, DENS = 50_000, 20_000, 0.05
+
+
+@pytest.fixture(scope="module")
+def data():
+    from doubletdetection_amd._synthetic import make_counts
+
+    return make_counts(N, G, density=DENS, device="cuda:0", seed=11)
+
+
+@pytest.fixture(scope="module")
+def staged(data):
+    from doubletdetection_amd import _lib
+
+    ctx = _lib.Context(0)
+    ctx.upload_raw(data)
+    var = ctx.gene_variances()
+    top = np.argsort(var)[-10000:]
+    ctx.select_columns(top)
+    rng = np.random.default_rng(0)
+    S = N // 4
+    parents = rng.choice(N, size=(S, 2), replace=False)
+    ctx.create_doublets(parents)
+    yield ctx, var, top, parents
+    ctx.close()
+
+
+def test_prologue_properties(data, staged):
+    ctx, var, top, _ = staged
+    # variance vector: float64 recomputation agrees to float32 accumulation error; selection is the top-H set
+    d64 = data.astype(np.float64)
+    m1 = np.asarray(d64.mean(axis=0)).ravel()
+    m2 = np.asarray(d64.multiply(d64).mean(axis=0)).ravel()
+    ref = m2 - m1 ** 2
+    np.testing.assert_allclose(var, ref, rtol=2e-3, atol=1e-6)
+    assert var[top].min() >= np.sort(var)[-10000]
+    sub = ctx.get_counts()
+    assert sub.shape == (N, 10000) and sub.has_sorted_indices
+    assert np.all(np.diff(sub.indptr) >= 0)
+    # column j of the restricted matrix is gene top[j]: column sums agree exactly (integer counts)
+    np.testing.assert_array_equal(np.asarray(sub.sum(axis=0)).ravel(), np.asarray(data[:, top].sum(axis=0)).ravel())
+    np.testing.assert_array_equal(ctx.lib_size(), np.asarray(sub.sum(axis=1)).ravel())
+
+
+def test_doublet_linearity_and_canonical_form(staged):
+    ctx, _, _, parents = staged
+    sub = ctx.get_counts()
+    synth = ctx.get_synth()
+    assert synth.shape == (parents.shape[0], 10000)
+    assert synth.has_canonical_format and np.all(synth.data != 0)
+    lib = np.asarray(sub.sum(axis=1)).ravel()
+    # linearity: row sums and column sums of parent0 + parent1
+    np.testing.assert_array_equal(np.asarray(synth.sum(axis=1)).ravel(), lib[parents[:, 0]] + lib[parents[:, 1]])
+    rows = np.random.default_rng(1).choice(parents.shape[0], size=300, replace=False)
+    want = sub[parents[rows, 0]] + sub[parents[rows, 1]]
+    got = synth[rows]
+    assert (got != want).nnz == 0
+    # entries of a doublet = union of its parents' supports
+    nnz_par = np.diff(sub.indptr)
+    assert np.all(np.diff(synth.indptr) <= nnz_par[parents[:, 0]] + nnz_par[parents[:, 1]])
+    assert np.all(np.diff(synth.indptr) >= np.maximum(nnz_par[parents[:, 0]], nnz_par[parents[:, 1]]))
+
+
+def test_pca_and_knn_properties(staged):
+    ctx, _, _, parents = staged
+    ctx.lognormalise(0.1)
+    lib, med = ctx.aug_lib()
+    assert med == np.median(lib)
+    M, H, C = ctx.M, ctx.H, 30
+    q0 = np.random.RandomState(0).normal(size=(H, C + 10)).astype(np.float32).astype(np.float64)
+    ctx.pca(C, q0)
+    emb, sing = ctx.embedding_f64()
+    assert emb.shape == (M, C) and np.all(np.isfinite(emb))
+    # U*S: columns are centred, mutually orthogonal, with norms equal to the singular values, sorted
+    np.testing.assert_allclose(emb.mean(axis=0), 0.0, atol=1e-9 * sing[0])
+    gram = emb.T @ emb
+    np.testing.assert_allclose(gram, np.diag(sing ** 2), rtol=1e-9, atol=1e-9 * sing[0] ** 2)
+    assert np.all(np.diff(sing) <= 0)
+    # kNN: ordering, self exclusion, and exactness against a float64 brute force for sampled queries
+    ctx.knn(30, False)
+    idx, dist = ctx.get_knn()
+    assert idx.min() >= 0 and idx.max() < M
+    assert np.all(idx != np.arange(M)[:, None])
+    assert np.all(np.diff(dist, axis=1) >= 0)
+    e32 = ctx.embedding()
+    e = e32.astype(np.float64)
+    for qi in np.random.default_rng(3).choice(M, size=40, replace=False):
+        d2 = np.zeros(M)
+        for c in range(C):
+            diff = e[qi, c] - e[:, c]
+            d2 += diff * diff
+        d2[qi] = np.inf
+        order = np.lexsort((np.arange(M), d2))[:30]
+        np.testing.assert_array_equal(idx[qi], order)
+        np.testing.assert_array_equal(dist[qi], np.sqrt(d2[order]))
+    # graph: symmetric, no self loops, weights in (0, 1]
+    ip, ix, w = ctx.build_graph(0)
+    Gm = sp.csr_matrix((w, ix, ip), shape=(M, M))
+    assert abs(Gm - Gm.T).nnz == 0 and Gm.diagonal().sum() == 0
+    assert w.min() > 0 and w.max() <= 1.0
+
+
+def test_fit_is_deterministic_and_finds_doublets(data):
+    from doubletdetection_amd import BoostClassifier
+
+    res = []
+    for _ in range(2):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            clf = BoostClassifier(n_iters=3, clustering_algorithm="louvain", random_state=7, n_jobs=-1).fit(data)
+        res.append((clf.all_log_p_values_.copy(), clf.communities_.copy(), clf.doublet_score()))
+    np.testing.assert_array_equal(res[0][0], res[1][0])          # tests/test_package.py:25-38 at full size
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+    np.testing.assert_equal(np.ma.getdata(res[0][2]), np.ma.getdata(res[1][2]))
+    assert clf.all_log_p_values_.shape == (3, N) and clf.synth_communities_.shape == (3, N // 4)
+    # the generator plants 5 % true doublets (sums of two cells): their scores must rank above singlets'
+    score = np.ma.filled(clf.doublet_score(), 0.0)
+    lib = np.asarray(data.sum(axis=1)).ravel()
+    top = np.argsort(score)[-N // 50:]
+    assert lib[top].mean() > 1.3 * lib.mean()
