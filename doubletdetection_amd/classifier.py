@@ -259,6 +259,9 @@ class BoostClassifier:
             self._drop_stage()
             raw_counts, engine, device, restrict = self._stage(raw_counts, rank, world)
         self._staged = None
+        import time
+
+        t_fit0 = time.perf_counter()
         try:
             if restrict:
                 # dd.py:165-176 -- float32 variances on the device in scipy's evaluation order; the
@@ -270,9 +273,15 @@ class BoostClassifier:
             else:
                 engine.upload(raw_counts)
                 num_genes = raw_counts.shape[1]
-            return self._fit_resident(engine, raw_counts.shape[0], num_genes, rank, world, backend, device)
+            t_prologue = time.perf_counter() - t_fit0
+            self._fit_resident(engine, raw_counts.shape[0], num_genes, rank, world, backend, device)
+            self._host_timings["prologue"] = t_prologue
         finally:
+            t0 = time.perf_counter()
             engine.close()
+        self._host_timings["close"] = time.perf_counter() - t0
+        self._host_timings["fit_total"] = time.perf_counter() - t_fit0
+        return self
 
     def _coerce(self, raw_counts):
         """dd.py:149-160: float32 CSR from an ndarray or any sparse matrix (finite, 2-D)."""
@@ -325,6 +334,9 @@ class BoostClassifier:
         num_synths = int(self.boost_rate * num_cells)
         n_iters = self.n_iters
 
+        import time
+
+        t_setup0 = time.perf_counter()
         # the Generator stream must be consumed in iteration order whatever rank runs the iteration
         all_parents = [self.rng.choice(num_cells, size=(num_synths, 2), replace=self.replace)
                        for _ in range(n_iters)]
@@ -342,10 +354,8 @@ class BoostClassifier:
 
         mine = [i for i in range(n_iters) if i % world == rank]
         workers = self.n_jobs if self.n_jobs and self.n_jobs > 0 else (os.cpu_count() or 1)
-        import time
-
         local = {}
-        host = {"device_stages": 0.0, "wait_workers": 0.0, "graph_assembly": 0.0, "louvain": 0.0, "score": 0.0}
+        host = {"draws": time.perf_counter() - t_setup0, "device_stages": 0.0, "wait_workers": 0.0, "graph_assembly": 0.0, "louvain": 0.0, "score": 0.0}
         with ThreadPoolExecutor(max_workers=max(1, min(workers, max(1, len(mine))))) as pool:
             pending = {}
             for i in mine:
@@ -369,6 +379,7 @@ class BoostClassifier:
         if mine and hasattr(engine, "aug_nnz"):
             self._last_nnz_aug = engine.aug_nnz()     # stored entries of the last augmented matrix
 
+        t_asm0 = time.perf_counter()
         self.all_scores_ = np.zeros((n_iters, num_cells))
         self.all_log_p_values_ = np.zeros((n_iters, num_cells))
         all_communities = np.zeros((n_iters, num_cells))
@@ -385,8 +396,25 @@ class BoostClassifier:
                 print("Found clusters [{0}, ... {2}], with sizes: {1}\n".format(full.min(), sizes, full.max()))
         self.communities_ = all_communities
         self.synth_communities_ = all_synth_communities
-        self.parents_ = [[list(p) for p in choices] for choices in all_parents]
+        self._parent_arrays = all_parents
+        self._parents_lists = None
+        self._host_timings["assemble"] = time.perf_counter() - t_asm0
         return self
+
+    @property
+    def parents_(self):
+        """Parent cells' indexes for each synthetic doublet, one entry per iteration, in the reference's
+        format (list of lists of ``[np.int64, np.int64]``, dd.py:395).  The nested lists are built on
+        first access (the int64 [S,2] arrays are what ``fit`` keeps)."""
+        if getattr(self, "_parents_lists", None) is None:
+            if getattr(self, "_parent_arrays", None) is None:
+                raise AttributeError("parents_ is set by fit()")
+            self._parents_lists = [[list(p) for p in choices] for choices in self._parent_arrays]
+        return self._parents_lists
+
+    @parents_.setter
+    def parents_(self, value):
+        self._parents_lists = value
 
     @staticmethod
     def _check_pca_regime(M, H, n_comp):

@@ -9,6 +9,7 @@
 // thread lives in LDS, slot-major ([slot][thread]) so lanes hit distinct banks; insertions are rare
 // after the first few hundred candidates (expected k*ln(M/k) per query).
 #include <algorithm>
+#include <cstdlib>
 
 #include "ddx_internal.h"
 
@@ -78,7 +79,7 @@ template <int CP>
 __global__ void __launch_bounds__(256) k_knn_mfma(const float* __restrict__ E, const float* __restrict__ Et,
                                                   const float* __restrict__ nrm, int64_t M, int64_t Mp, int K,
                                                   int include_self, int32_t* __restrict__ idx_out,
-                                                  double* __restrict__ dist_out) {
+                                                  double* __restrict__ dist_out, int debug_mode) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* ld = reinterpret_cast<double*>(smem);                                   // [K][kQPerBlock]
     int32_t* li = reinterpret_cast<int32_t*>(ld + (size_t)K * kQPerBlock);          // [K][kQPerBlock]
@@ -144,6 +145,7 @@ __global__ void __launch_bounds__(256) k_knn_mfma(const float* __restrict__ E, c
             if (s0 < th[0][r] && (include_self || cand != qid[0][r])) hits |= 1u << r;
             if (s1 < th[1][r] && (include_self || cand != qid[1][r])) hits |= 16u << r;
         }
+        if (debug_mode == 1) hits = 0;   // profiling aid: screen only
         if (__ballot(hits != 0)) {
             // confirm: each lane walks its own surviving pairs; lanes work in parallel
             while (__ballot(hits != 0)) {
@@ -240,14 +242,16 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
     {
         ScopedTimer t(ctx, "knn_brute");
         const unsigned grid = (unsigned)ceil_div(Mp, kQPerBlock);
+        const char* dbg_env = getenv("DDX_KNN_DEBUG");
+        const int dbg = dbg_env ? atoi(dbg_env) : 0;
         if (lds > 48 * 1024) {
             DDX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_knn_mfma<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             DDX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_knn_mfma<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         }
         if (CP == 32)
-            k_knn_mfma<32><<<grid, 256, lds, ctx->stream>>>(E, Et, nrm, M, Mp, k, include_self, ctx->knn_idx.as<int32_t>(), ctx->knn_dist.as<double>());
+            k_knn_mfma<32><<<grid, 256, lds, ctx->stream>>>(E, Et, nrm, M, Mp, k, include_self, ctx->knn_idx.as<int32_t>(), ctx->knn_dist.as<double>(), dbg);
         else
-            k_knn_mfma<64><<<grid, 256, lds, ctx->stream>>>(E, Et, nrm, M, Mp, k, include_self, ctx->knn_idx.as<int32_t>(), ctx->knn_dist.as<double>());
+            k_knn_mfma<64><<<grid, 256, lds, ctx->stream>>>(E, Et, nrm, M, Mp, k, include_self, ctx->knn_idx.as<int32_t>(), ctx->knn_dist.as<double>(), dbg);
     }
     DDX_HIP(ctx, hipGetLastError());
     ctx->K = k;

@@ -79,11 +79,14 @@ bool one_level(const Graph& g, double gamma, SplitMix64& rng, std::vector<int32_
     seen.reserve(256);
     bool improved = false;
     double new_q = quality(in_, tot, m2, gamma);
+    std::vector<char> active(n, 1), next_active(n, 0);
     while (true) {
         const double cur_q = new_q;
         int64_t moves = 0;
+        std::fill(next_active.begin(), next_active.end(), 0);
         for (int64_t oi = 0; oi < n; ++oi) {
             const int32_t v = order[oi];
+            if (!active[v]) continue;
             const int32_t c_old = comm[v];
             const double kv = deg[v];
             seen.clear();
@@ -114,12 +117,20 @@ bool one_level(const Graph& g, double gamma, SplitMix64& rng, std::vector<int32_
             tot[best] += kv;
             in_[best] += 2.0 * neigh_w[best] + loops[v];
             comm[v] = best;
-            if (best != c_old) ++moves;
+            if (best != c_old) {
+                ++moves;
+                for (int64_t e = g.indptr[v]; e < g.indptr[v + 1]; ++e) {
+                    const int32_t u = g.indices[e];
+                    if (u != v && comm[u] != best) next_active[u] = 1;
+                }
+            }
             for (int32_t c : seen) neigh_w[c] = -1.0;
         }
         new_q = quality(in_, tot, m2, gamma);
+        if (std::getenv("DDX_LOUVAIN_DEBUG")) std::fprintf(stderr, "[louvain]   pass: n=%lld moves=%lld dQ=%.3e\n", (long long)n, (long long)moves, new_q - cur_q);
         if (moves > 0) improved = true;
         if (!(moves > 0 && new_q - cur_q > kMinGain)) break;
+        active.swap(next_active);
     }
     if (q_out) *q_out = new_q;
     return improved;

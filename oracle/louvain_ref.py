@@ -18,7 +18,9 @@ Algorithm (the published multi-level modularity optimisation with a resolution p
   levels); take the node out of its community; evaluate gain(c) = w(v,c) - gamma*tot_c*k_v/2m for
   its own community first and then each neighbouring community in adjacency order; move to the
   strictly best; repeat passes while nodes moved and the pass improved Q by more than 1e-6 (the
-  Blondel executable's default epsilon);
+  Blondel executable's default epsilon).  After the first pass of a level only *active* nodes are
+  revisited: a move of v activates, for the next pass, every neighbour of v that is not in v's new
+  community (the pruning of Ozaki et al. 2016 / Traag's fast local move);
 * aggregate communities into super-nodes (self-loop = total internal weight, both directions),
   repeat until a level moves nothing.
 """
@@ -83,10 +85,14 @@ def _one_level(indptr, indices, weights, gamma, rng):
     neigh_w = [-1.0] * n
     improved = False
     new_q = _quality(in_, tot, m2, gamma)
+    active = [True] * n
     while True:
         cur_q = new_q
         moves = 0
+        next_active = [False] * n
         for v in order:
+            if not active[v]:
+                continue
             c_old = comm[v]
             kv = deg[v]
             seen = [c_old]
@@ -115,6 +121,10 @@ def _one_level(indptr, indices, weights, gamma, rng):
             comm[v] = best
             if best != c_old:
                 moves += 1
+                for e in range(indptr[v], indptr[v + 1]):
+                    u = indices[e]
+                    if u != v and comm[u] != best:
+                        next_active[u] = True
             for c in seen:
                 neigh_w[c] = -1.0
         new_q = _quality(in_, tot, m2, gamma)
@@ -122,6 +132,7 @@ def _one_level(indptr, indices, weights, gamma, rng):
             improved = True
         if not (moves > 0 and new_q - cur_q > MIN_GAIN):
             break
+        active = next_active
     return comm, improved
 
 
