@@ -42,16 +42,252 @@ __global__ void k_knn_prepare(const float* __restrict__ in, int64_t M, int64_t M
     nrm[r] = (r < M) ? n : __builtin_huge_valf();
 }
 
+// Screen slack: |fl32(|q|^2 + |c|^2 - 2 q.c) - d2| <= (CP + 8) * 2^-24 * (|q|^2 + |c|^2) for the float32
+// MFMA dot product (a k-ordered fmaf chain) and float32 norms (4.3e-6 at CP = 64).  The screen is evaluated
+// in the rearranged form  q.c > 0.5*(1-slack)*|c|^2 + 0.5*((1-slack)*|q|^2 - thr), whose extra float32
+// roundings (<= 2e-7 relative to the norms) are covered by the margin in 8e-6.
+constexpr float kScreenSlack = 8.0e-6f;
+constexpr int kBoundKeep = 6;      // smallest sample distances kept per lane and row in the bound pass
+constexpr int kCandCap = 768;      // candidate slots per query between the emit and select passes
+
+// ================================================================================================
+// exact kNN in three passes (all 16x16 query x candidate tiles run on v_mfma_f32_16x16x4_f32):
+//   1. bound : over a strided sample of candidate tiles, every lane keeps the kBoundKeep smallest
+//              *upper bounds* of the squared distance per screened row; the k-th smallest of the
+//              16*kBoundKeep kept values of a row is an upper bound T_q of the query's true k-th
+//              neighbour distance (k-th smallest of a subset >= k-th smallest of the whole set).
+//   2. emit  : over all candidate tiles, a pair survives when a *lower bound* of its squared distance
+//              is below T_q (so no true neighbour can be lost); survivors (a few hundred per query,
+//              0.2-0.4 % of the pairs) are appended to the query's candidate list.  Pure streaming:
+//              16 MFMA + 16 VALU per tile, no LDS, no data-dependent state.
+//   3. select: one wave per query evaluates its candidates exactly (float64, the reference's
+//              arithmetic, one candidate per lane) and sorts them by (distance, index) in LDS; the
+//              first k are the result.  A query whose list overflowed is re-scanned over all points
+//              by the same pass, so the result is exact in every case and independent of the
+//              (non-deterministic) order in which survivors were appended.
+// ================================================================================================
+
+// ---- candidate tiles are staged through LDS once per block (4 waves share them) ---------------------
+// tiles per staged chunk: 16 KB of coordinates per buffer whatever the padded dimension
+__host__ __device__ constexpr int chunk_tiles(int CP) { return CP <= 32 ? 8 : 4; }
+
+template <int CP>
+struct TileStage {
+    static constexpr int kChunkTiles = chunk_tiles(CP);
+    static constexpr int kFloats = kChunkTiles * 16 * CP;          // coordinates of one chunk
+    static constexpr int kPerThread = kFloats / 256;               // floats per thread (256 threads)
+    static_assert(kPerThread % 4 == 0, "chunk must split into float4 per thread");
+    f4 regs[kPerThread / 4];
+    float nreg;                                                    // threads 0..127 carry one norm each
+    // global -> registers (issue early), registers -> LDS (after the barrier that retires the old buffer)
+    __device__ __forceinline__ void fetch(const float* __restrict__ Et, const float* __restrict__ nrm, int64_t chunk,
+                                          int64_t n_chunk_tiles_total, int64_t tile_stride, int tid) {
+#pragma unroll
+        for (int u = 0; u < kPerThread / 4; ++u) {
+            const int f = (u * 256 + tid) * 4;                     // float offset inside the chunk
+            const int t = f / (16 * CP);                           // tile slot
+            int64_t tile = (chunk * kChunkTiles + t);
+            if (tile >= n_chunk_tiles_total) tile = n_chunk_tiles_total - 1;
+            regs[u] = *reinterpret_cast<const f4*>(Et + tile * tile_stride * 16 * CP + (f - t * 16 * CP));
+        }
+        if (tid < kChunkTiles * 16) {
+            int64_t tile = chunk * kChunkTiles + (tid >> 4);
+            if (tile >= n_chunk_tiles_total) tile = n_chunk_tiles_total - 1;
+            nreg = nrm[tile * tile_stride * 16 + (tid & 15)];
+        }
+    }
+    __device__ __forceinline__ void commit(float* lds_coords, float* lds_norms, int tid) const {
+#pragma unroll
+        for (int u = 0; u < kPerThread / 4; ++u) *reinterpret_cast<f4*>(lds_coords + (u * 256 + tid) * 4) = regs[u];
+        if (tid < kChunkTiles * 16) lds_norms[tid] = nreg;
+    }
+};
+
+template <int CP, int RT>
+struct QueryTiles {
+    static constexpr int KS = CP / 4;
+    float a[RT][KS];
+    __device__ __forceinline__ void load(const float* __restrict__ Et, int64_t q0, int lane) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int s = 0; s < KS; ++s) a[rt][s] = Et[((q0 >> 4) + rt) * 16 * CP + s * 64 + lane];
+    }
+    __device__ __forceinline__ void dots(const float* b, f4 (&acc)[RT]) const {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[rt] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][s], b[s], acc[rt], 0, 0, 0);
+    }
+};
+
+constexpr int kBoundRT = 2;   // query tiles per wave in the bound pass (register budget: 16 rows x kBoundKeep)
+constexpr int kEmitRT = 2;    // query tiles per wave in the emit pass (more waves beats more reuse: tiles come from LDS)
+
+template <int CP>
+__global__ void __launch_bounds__(256) k_knn_bound(const float* __restrict__ Et, const float* __restrict__ nrm,
+                                                   int64_t Mp, int K, int include_self, int64_t nsamp_tiles,
+                                                   int64_t tile_stride, float* __restrict__ thr_out) {
+    constexpr int KS = CP / 4;
+    constexpr int RT = kBoundRT, NV = 4 * RT;
+    constexpr int kChunkTiles = chunk_tiles(CP);
+    __shared__ __attribute__((aligned(16))) float lds_c[2][kChunkTiles * 16 * CP];
+    __shared__ float lds_n[2][kChunkTiles * 16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t q0 = ((int64_t)blockIdx.x * 4 + wave) * (16 * RT);     // Mp is a multiple of 256: no partial blocks
+    QueryTiles<CP, RT> qt;
+    qt.load(Et, q0, lane);
+    const int rbase = 4 * (lane >> 4), jcol = lane & 15;
+    float nq[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) nq[v] = nrm[q0 + (v >> 2) * 16 + rbase + (v & 3)];
+    float best[NV][kBoundKeep];   // ascending
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int t = 0; t < kBoundKeep; ++t) best[v][t] = __builtin_huge_valf();
+    const int64_t own_tile = q0 >> 4;
+    const int64_t nchunks = (nsamp_tiles + kChunkTiles - 1) / kChunkTiles;
+    TileStage<CP> st;
+    st.fetch(Et, nrm, 0, nsamp_tiles, tile_stride, tid);
+    st.commit(lds_c[0], lds_n[0], tid);
+    __syncthreads();
+    for (int64_t ch = 0; ch < nchunks; ++ch) {
+        const int buf = (int)(ch & 1);
+        if (ch + 1 < nchunks) st.fetch(Et, nrm, ch + 1, nsamp_tiles, tile_stride, tid);
+        const int ntile = (int)((nsamp_tiles - ch * kChunkTiles) < kChunkTiles ? (nsamp_tiles - ch * kChunkTiles) : kChunkTiles);
+        for (int t = 0; t < ntile; ++t) {
+            const int64_t tile = (ch * kChunkTiles + t) * tile_stride;
+            float b[KS];
+#pragma unroll
+            for (int s = 0; s < KS; ++s) b[s] = lds_c[buf][t * 16 * CP + s * 64 + lane];
+            const float nc = lds_n[buf][t * 16 + jcol];
+            f4 acc[RT];
+            qt.dots(b, acc);
+            const bool own = !include_self && (tile >= own_tile && tile < own_tile + RT);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const float dot = acc[v >> 2][v & 3];
+                const float n = nq[v] + nc;
+                float ub = fmaf(-2.f, dot, n) + kScreenSlack * n;        // upper bound of the exact squared distance
+                if (own && (tile * 16 + jcol) == (q0 + (v >> 2) * 16 + rbase + (v & 3))) ub = __builtin_huge_valf();
+                if (!(ub < best[v][kBoundKeep - 1])) continue;           // also rejects NaN (padding rows/candidates)
+                best[v][kBoundKeep - 1] = ub;
+#pragma unroll
+                for (int u = kBoundKeep - 1; u > 0; --u) {
+                    const float lo = fminf(best[v][u - 1], best[v][u]), hi = fmaxf(best[v][u - 1], best[v][u]);
+                    best[v][u - 1] = lo;
+                    best[v][u] = hi;
+                }
+            }
+        }
+        if (ch + 1 < nchunks) st.commit(lds_c[buf ^ 1], lds_n[buf ^ 1], tid);
+        __syncthreads();
+    }
+    // k-th smallest of the 16*kBoundKeep values of each row (held by the 16 lanes that share lane>>4)
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        float kth = __builtin_huge_valf();
+        int rank[kBoundKeep];
+#pragma unroll
+        for (int t = 0; t < kBoundKeep; ++t) rank[t] = 0;
+        for (int o = 0; o < 16; ++o) {
+            const int src = (lane & 48) | ((jcol + o) & 15);
+#pragma unroll
+            for (int u = 0; u < kBoundKeep; ++u) {
+                const float other = __shfl(best[v][u], src, 64);
+                const int okey = ((jcol + o) & 15) * kBoundKeep + u;      // tie-break key of the other value
+#pragma unroll
+                for (int t = 0; t < kBoundKeep; ++t) {
+                    const int mkey = jcol * kBoundKeep + t;
+                    rank[t] += (other < best[v][t] || (other == best[v][t] && okey < mkey)) ? 1 : 0;
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < kBoundKeep; ++t)
+            if (rank[t] == K - 1) kth = best[v][t];
+        // exactly one lane of the 16 holds the value of rank K-1: share it
+        for (int o = 1; o < 16; o <<= 1) kth = fminf(kth, __shfl_xor(kth, o, 64));
+        if (jcol == 0) thr_out[q0 + (v >> 2) * 16 + rbase + (v & 3)] = kth;   // +inf when fewer than K sample points
+    }
+}
+
+template <int CP>
+__global__ void __launch_bounds__(256) k_knn_emit(const float* __restrict__ Et, const float* __restrict__ nrm,
+                                                  const float* __restrict__ thr, int64_t Mp, int include_self,
+                                                  int32_t* __restrict__ ccount, int32_t* __restrict__ cbuf) {
+    constexpr int KS = CP / 4;
+    constexpr int RT = kEmitRT, NV = 4 * RT;
+    constexpr int kChunkTiles = chunk_tiles(CP);
+    __shared__ __attribute__((aligned(16))) float lds_c[2][kChunkTiles * 16 * CP];
+    __shared__ float lds_n[2][kChunkTiles * 16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t q0 = ((int64_t)blockIdx.x * 4 + wave) * (16 * RT);     // Mp is a multiple of 256: no partial blocks
+    QueryTiles<CP, RT> qt;
+    qt.load(Et, q0, lane);
+    const int rbase = 4 * (lane >> 4), jcol = lane & 15;
+    float hr[NV];   // 0.5*((1-slack)*|q|^2 - T_q): q.c must exceed 0.5*(1-slack)*|c|^2 + hr
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int64_t q = q0 + (v >> 2) * 16 + rbase + (v & 3);
+        const float n = nrm[q], t = thr[q];
+        hr[v] = 0.5f * ((1.0f - kScreenSlack) * n - t);
+        if (!(n < __builtin_huge_valf())) hr[v] = __builtin_huge_valf();       // padding query: nothing passes
+        else if (!(t < __builtin_huge_valf())) hr[v] = -__builtin_huge_valf(); // no bound: everything passes
+    }
+    const int64_t ntiles = Mp >> 4;
+    const int64_t own_tile = q0 >> 4;
+    const int64_t nchunks = (ntiles + kChunkTiles - 1) / kChunkTiles;
+    TileStage<CP> st;
+    st.fetch(Et, nrm, 0, ntiles, 1, tid);
+    st.commit(lds_c[0], lds_n[0], tid);
+    __syncthreads();
+    for (int64_t ch = 0; ch < nchunks; ++ch) {
+        const int buf = (int)(ch & 1);
+        if (ch + 1 < nchunks) st.fetch(Et, nrm, ch + 1, ntiles, 1, tid);
+        const int ntile = (int)((ntiles - ch * kChunkTiles) < kChunkTiles ? (ntiles - ch * kChunkTiles) : kChunkTiles);
+        for (int t = 0; t < ntile; ++t) {
+            const int64_t tile = ch * kChunkTiles + t;
+            float b[KS];
+#pragma unroll
+            for (int s = 0; s < KS; ++s) b[s] = lds_c[buf][t * 16 * CP + s * 64 + lane];
+            const float hc = 0.5f * (1.0f - kScreenSlack) * lds_n[buf][t * 16 + jcol];   // +inf for padding candidates
+            f4 acc[RT];
+            qt.dots(b, acc);
+            unsigned hits = 0;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) hits |= (acc[v >> 2][v & 3] > hc + hr[v]) ? (1u << v) : 0u;
+            if (__ballot(hits != 0)) {
+                const int32_t cand = (int32_t)(tile * 16 + jcol);
+                const bool own = !include_self && (tile >= own_tile && tile < own_tile + RT);
+                while (hits) {
+                    const int v = __ffs(hits) - 1;
+                    hits &= hits - 1;
+                    const int64_t q = q0 + (v >> 2) * 16 + rbase + (v & 3);
+                    if (own && q == cand) continue;
+                    const int slot = atomicAdd(&ccount[q], 1);
+                    if (slot < kCandCap) cbuf[q * kCandCap + slot] = cand;
+                }
+            }
+        }
+        if (ch + 1 < nchunks) st.commit(lds_c[buf ^ 1], lds_n[buf ^ 1], tid);
+        __syncthreads();
+    }
+}
+
 // Exact squared distance in the reference's arithmetic: float64, (a-b)*(a-b) rounded, then added,
 // components in order -- bit-identical to the float64 brute-force definition (oracle knn_bruteforce_f64).
 template <int CP>
-__device__ __forceinline__ double exact_d2(const float* __restrict__ a, const float* __restrict__ b) {
+__device__ __forceinline__ double exact_d2(const float* q /* LDS, CP floats */, const float* __restrict__ c) {
 #pragma clang fp contract(off)
     double d2 = 0.0;
 #pragma unroll
     for (int t = 0; t < CP; t += 4) {
-        const f4 x = *reinterpret_cast<const f4*>(a + t);
-        const f4 y = *reinterpret_cast<const f4*>(b + t);
+        const f4 y = *reinterpret_cast<const f4*>(c + t);
+        const f4 x = *reinterpret_cast<const f4*>(q + t);
         const double d0 = (double)x.x - (double)y.x; const double s0 = d0 * d0; d2 = d2 + s0;
         const double d1 = (double)x.y - (double)y.y; const double s1 = d1 * d1; d2 = d2 + s1;
         const double d2_ = (double)x.z - (double)y.z; const double s2 = d2_ * d2_; d2 = d2 + s2;
@@ -60,167 +296,108 @@ __device__ __forceinline__ double exact_d2(const float* __restrict__ a, const fl
     return d2;
 }
 
-// Screen slack: |fl32(|q|^2 + |c|^2 - 2 q.c) - d2| <= (CP + 8) * 2^-24 * (|q|^2 + |c|^2) for the float32
-// MFMA dot product (a k-ordered fmaf chain) and float32 norms; 7e-6 covers CP <= 64 with margin.
-constexpr float kScreenSlack = 7.0e-6f;
+constexpr int kSelMax = 1024;   // sort window of the select pass (power of two, >= kCandCap + 64)
 
-constexpr int kQPerWave = 32;                 // two 16-row MFMA tiles of queries per wave
-constexpr int kQPerBlock = 4 * kQPerWave;     // 4 waves, no cross-wave sharing
-
-// kNN = float32 MFMA screen + exact float64 confirmation.
-//  screen : for a 16x16 (query x candidate) tile the squared distances are |q|^2 + |c|^2 - 2 q.c with
-//           q.c from CP/4 v_mfma_f32_16x16x4_f32; a pair survives when the value minus a rigorous
-//           rounding bound is below the query's current k-th best distance (kept as a float32 upper
-//           bound).  After the first few hundred candidates almost nothing survives.
-//  confirm: every surviving lane re-evaluates its pair exactly in float64 (all survivors of a tile in
-//           parallel) and inserts it into the query's sorted top-k list in LDS, ordered by
-//           (distance, index) so the result does not depend on the visiting order.
-template <int CP>
-__global__ void __launch_bounds__(256) k_knn_mfma(const float* __restrict__ E, const float* __restrict__ Et,
-                                                  const float* __restrict__ nrm, int64_t M, int64_t Mp, int K,
-                                                  int include_self, int32_t* __restrict__ idx_out,
-                                                  double* __restrict__ dist_out, int debug_mode) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double* ld = reinterpret_cast<double*>(smem);                                   // [K][kQPerBlock]
-    int32_t* li = reinterpret_cast<int32_t*>(ld + (size_t)K * kQPerBlock);          // [K][kQPerBlock]
-    int32_t* cnt = li + (size_t)K * kQPerBlock;                                     // [kQPerBlock]
-    float* thr = reinterpret_cast<float*>(cnt + kQPerBlock);                        // [kQPerBlock] float32 upper bound of the k-th best
-    int32_t* owner = reinterpret_cast<int32_t*>(thr + kQPerBlock);                  // [kQPerBlock]
-    constexpr int KS = CP / 4;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t q0 = ((int64_t)blockIdx.x * 4 + wave) * kQPerWave;                // first query of this wave
-    if (q0 >= Mp) return;                                                           // (whole wave; no block barriers are used)
-    const int lq0 = wave * kQPerWave;                                               // first local query slot
-    for (int t = lane; t < kQPerWave; t += 64) { cnt[lq0 + t] = 0; thr[lq0 + t] = __builtin_huge_valf(); owner[lq0 + t] = -1; }
-
-    // A operands: 2 query tiles x KS k-steps
-    float a[2][KS];
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-        for (int s = 0; s < KS; ++s) a[rt][s] = Et[((q0 >> 4) + rt) * 16 * CP + s * 64 + lane];
-    // rows held by this lane in the MFMA result: row(reg) = 4*(lane>>4) + reg, column = lane & 15
-    const int rbase = 4 * (lane >> 4);
-    float nq[2][4];
-    int64_t qid[2][4];
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            qid[rt][r] = q0 + rt * 16 + rbase + r;
-            nq[rt][r] = nrm[qid[rt][r]];      // +inf for padding queries: they never pass the screen
-        }
-    float th[2][4];
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) th[rt][r] = __builtin_huge_valf();
-
-    const int64_t ntiles = Mp >> 4;
-    float b[KS];
-#pragma unroll
-    for (int s = 0; s < KS; ++s) b[s] = Et[s * 64 + lane];
-    float ncand = nrm[lane & 15];
-    for (int64_t tile = 0; tile < ntiles; ++tile) {
-        // prefetch the next candidate tile while this one is in the matrix pipe
-        float bn[KS];
-        const int64_t tn = (tile + 1 < ntiles) ? tile + 1 : tile;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) bn[s] = Et[tn * 16 * CP + s * 64 + lane];
-        const float ncand_n = nrm[tn * 16 + (lane & 15)];
-
-        f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0][s], b[s], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1][s], b[s], acc1, 0, 0, 0);
-        }
-        const int64_t cand = tile * 16 + (lane & 15);
-        unsigned hits = 0;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float n0 = nq[0][r] + ncand, n1 = nq[1][r] + ncand;
-            const float s0 = fmaf(-2.f, acc0[r], n0) - kScreenSlack * n0;
-            const float s1 = fmaf(-2.f, acc1[r], n1) - kScreenSlack * n1;
-            if (s0 < th[0][r] && (include_self || cand != qid[0][r])) hits |= 1u << r;
-            if (s1 < th[1][r] && (include_self || cand != qid[1][r])) hits |= 16u << r;
-        }
-        if (debug_mode == 1) hits = 0;   // profiling aid: screen only
-        if (__ballot(hits != 0)) {
-            // confirm: each lane walks its own surviving pairs; lanes work in parallel
-            while (__ballot(hits != 0)) {
-                int lq = -1;
-                double d2 = 0.0;
-                if (hits) {
-                    const int bit = __ffs(hits) - 1;
-                    hits &= hits - 1;
-                    lq = lq0 + (bit >> 2) * 16 + rbase + (bit & 3);
-                    const int64_t qg = q0 + (bit >> 2) * 16 + rbase + (bit & 3);
-                    d2 = exact_d2<CP>(E + qg * CP, E + cand * CP);
-                    // cheap exact pre-check against the list's current k-th entry
-                    const int c0 = cnt[lq];
-                    if (c0 == K) {
-                        const double wd = ld[(K - 1) * kQPerBlock + lq];
-                        const int32_t wi = li[(K - 1) * kQPerBlock + lq];
-                        if (!(d2 < wd || (d2 == wd && (int32_t)cand < wi))) lq = -1;
-                    }
-                }
-                // one inserter per query at a time (lanes of this wave only ever touch this wave's queries)
-                bool pending = lq >= 0;
-                while (__ballot(pending)) {
-                    if (pending) owner[lq] = lane;
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    if (pending && owner[lq] == lane) {
-                        const int c0 = cnt[lq];
-                        bool take = true;
-                        if (c0 == K) {
-                            const double wd = ld[(K - 1) * kQPerBlock + lq];
-                            const int32_t wi = li[(K - 1) * kQPerBlock + lq];
-                            take = d2 < wd || (d2 == wd && (int32_t)cand < wi);
-                        }
-                        if (take) {
-                            int pos = (c0 < K) ? c0 : K - 1;
-                            while (pos > 0) {
-                                const double pd = ld[(pos - 1) * kQPerBlock + lq];
-                                const int32_t pi = li[(pos - 1) * kQPerBlock + lq];
-                                if (!(pd > d2 || (pd == d2 && pi > (int32_t)cand))) break;
-                                ld[pos * kQPerBlock + lq] = pd;
-                                li[pos * kQPerBlock + lq] = pi;
-                                --pos;
-                            }
-                            ld[pos * kQPerBlock + lq] = d2;
-                            li[pos * kQPerBlock + lq] = (int32_t)cand;
-                            const int c1 = (c0 < K) ? c0 + 1 : K;
-                            cnt[lq] = c1;
-                            if (c1 == K) thr[lq] = __double2float_ru(ld[(K - 1) * kQPerBlock + lq]);
-                        }
-                        pending = false;
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                }
+// bitonic sort of d[0..P), ix[0..P) by (distance, index), ascending; one wave, P a power of two >= 64
+__device__ __forceinline__ void wave_sort(double* d, int32_t* ix, int P, int lane) {
+    for (int size = 2; size <= P; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = lane; t < (P >> 1); t += 64) {
+                const int lo = ((t / stride) * stride * 2) + (t % stride);
+                const int hi = lo + stride;
+                const bool up = ((lo & size) == 0);
+                const double dl = d[lo], dh = d[hi];
+                const int32_t il = ix[lo], ih = ix[hi];
+                const bool gt = dl > dh || (dl == dh && il > ih);
+                if (gt == up) { d[lo] = dh; d[hi] = dl; ix[lo] = ih; ix[hi] = il; }
             }
-            // refresh the float32 thresholds of the rows this lane screens
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) th[rt][r] = thr[lq0 + rt * 16 + rbase + r];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
-#pragma unroll
-        for (int s = 0; s < KS; ++s) b[s] = bn[s];
-        ncand = ncand_n;
     }
-    // write back: lane t < 32 owns local query t
-    for (int t = lane; t < kQPerWave; t += 64) {
-        const int64_t qg = q0 + t;
-        if (qg < M) {
-            const int c = cnt[lq0 + t];
-            for (int s = 0; s < K; ++s) {
-                idx_out[qg * K + s] = (s < c) ? li[s * kQPerBlock + lq0 + t] : -1;
-                dist_out[qg * K + s] = (s < c) ? ld[s * kQPerBlock + lq0 + t] : __builtin_huge_val();
-            }
+}
+
+// one wave per query (4 per block, no block-level synchronisation)
+template <int CP>
+__global__ void __launch_bounds__(256) k_knn_select(const float* __restrict__ E, int64_t M, int K, int include_self,
+                                                    const int32_t* __restrict__ ccount, const int32_t* __restrict__ cbuf,
+                                                    int32_t* __restrict__ idx_out, double* __restrict__ dist_out,
+                                                    int32_t* __restrict__ n_overflow) {
+    __shared__ __attribute__((aligned(16))) double sd[4][kSelMax];
+    __shared__ int32_t si[4][kSelMax];
+    __shared__ __attribute__((aligned(16))) float sq[4][CP];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t q = (int64_t)blockIdx.x * 4 + wave;
+    if (q >= M) return;
+    double* d = sd[wave];
+    int32_t* ix = si[wave];
+    float* qrow = sq[wave];
+    for (int t = lane; t < CP; t += 64) qrow[t] = E[q * CP + t];
+    const int cnt_all = ccount[q];
+    const bool overflow = cnt_all > kCandCap;
+    const int cnt = overflow ? kCandCap : cnt_all;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // exact distances of the listed candidates, one per lane and step, then sort
+    int P = 64;
+    while (P < cnt) P <<= 1;
+    for (int t = lane; t < P; t += 64) {
+        double dv = __builtin_huge_val();
+        int32_t iv = 0x7fffffff;
+        if (t < cnt) {
+            const int64_t c = cbuf[q * kCandCap + t];
+            dv = exact_d2<CP>(qrow, E + c * CP);
+            iv = (int32_t)c;
         }
+        d[t] = dv;
+        ix[t] = iv;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    wave_sort(d, ix, P, lane);
+    int kept = cnt < K ? cnt : K;
+    if (overflow) {
+        // The list was cut at kCandCap entries.  Its k-th exact distance is still an upper bound of the true
+        // k-th distance: rescan every point exactly, keep those not beyond it, and sort again.
+        if (lane == 0) atomicAdd(n_overflow, 1);
+        const double bound = d[K - 1];
+        int fill = 0;                               // entries appended behind nothing: the window restarts empty
+        for (int64_t c0 = 0; c0 < M; c0 += 64) {
+            const int64_t c = c0 + lane;
+            double dv = __builtin_huge_val();
+            bool keep = false;
+            if (c < M && (include_self || c != q)) {
+                dv = exact_d2<CP>(qrow, E + c * CP);
+                keep = dv <= bound;
+            }
+            const unsigned long long m = __ballot(keep);
+            const int n_new = __popcll(m);
+            if (fill + n_new > kSelMax) {           // pathological ties: compact to the best K and go on
+                for (int t = fill + lane; t < kSelMax; t += 64) { d[t] = __builtin_huge_val(); ix[t] = 0x7fffffff; }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                wave_sort(d, ix, kSelMax, lane);
+                fill = K;
+            }
+            if (keep) {
+                const int pos = fill + __popcll(m & ((1ull << lane) - 1ull));
+                d[pos] = dv;
+                ix[pos] = (int32_t)c;
+            }
+            fill += n_new;
+        }
+        P = 64;
+        while (P < fill) P <<= 1;
+        for (int t = fill + lane; t < P; t += 64) { d[t] = __builtin_huge_val(); ix[t] = 0x7fffffff; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        wave_sort(d, ix, P, lane);
+        kept = fill < K ? fill : K;
+    }
+    for (int s = lane; s < K; s += 64) {
+        const bool ok = s < kept && ix[s] != 0x7fffffff;
+        idx_out[q * K + s] = ok ? ix[s] : -1;
+        dist_out[q * K + s] = ok ? d[s] : __builtin_huge_val();
     }
 }
 
@@ -228,32 +405,58 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
     const int64_t M = ctx->embM;
     const int C = ctx->C;
     if (C > kMaxDim) return set_err(ctx, DDX_E_UNSUPPORTED, "embedding dimension %d exceeds %d", C, kMaxDim);
+    if (k > 16 * (kBoundKeep - 1)) return set_err(ctx, DDX_E_UNSUPPORTED, "k=%d exceeds %d", k, 16 * (kBoundKeep - 1));
     const int CP = (C <= 32) ? 32 : 64;
-    const int64_t Mp = ceil_div(M, kQPerWave) * kQPerWave;     // whole query tiles per wave
-    // workspace (reuses the PCA row buffer): E [Mp*CP] | Et [Mp*CP] | nrm [Mp]
-    DDX_TRY(ensure(ctx, ctx->pcaA, sizeof(float) * ((size_t)Mp * CP * 2 + Mp + 64)));
+    const int64_t Mp = ceil_div(M, 256) * 256;                 // whole blocks of queries in both MFMA passes
+    // workspace (reuses the PCA row buffer): E [Mp*CP] | Et [Mp*CP] | nrm [Mp] | thr [Mp] | ccount [Mp+1] | cbuf [Mp*cap]
+    const size_t f_words = (size_t)Mp * CP * 2 + 2 * (size_t)Mp;
+    const size_t i_words = (size_t)Mp + 64 + (size_t)Mp * kCandCap;
+    DDX_TRY(ensure(ctx, ctx->pcaA, sizeof(float) * f_words + sizeof(int32_t) * i_words + 256));
     DDX_TRY(ensure(ctx, ctx->knn_idx, sizeof(int32_t) * (size_t)M * k));
     DDX_TRY(ensure(ctx, ctx->knn_dist, sizeof(double) * (size_t)M * k));
     float* E = ctx->pcaA.as<float>();
     float* Et = E + (size_t)Mp * CP;
     float* nrm = Et + (size_t)Mp * CP;
+    float* thr = nrm + Mp;
+    int32_t* ccount = reinterpret_cast<int32_t*>(thr + Mp);   // [Mp] + overflow counter at [Mp]
+    int32_t* cbuf = ccount + Mp + 64;
     k_knn_prepare<<<(unsigned)ceil_div(Mp, 256), 256, 0, ctx->stream>>>(ctx->emb32.as<float>(), M, Mp, C, CP, E, Et, nrm);
-    const size_t lds = (sizeof(double) + sizeof(int32_t)) * (size_t)k * kQPerBlock + 3 * sizeof(int32_t) * kQPerBlock;
+    DDX_HIP(ctx, hipMemsetAsync(ccount, 0, sizeof(int32_t) * (Mp + 64), ctx->stream));
+    // sample so that about 144 candidates per query survive: the k-th of a sample of S corresponds to rank k*M/S
+    const int64_t ntiles = Mp >> 4;
+    int64_t nsamp = ceil_div((int64_t)k * M, (int64_t)144 * 16);
+    if (nsamp < 128) nsamp = 128;
+    if (nsamp > ntiles) nsamp = ntiles;
+    int64_t stride = ntiles / nsamp;
+    if (stride < 1) stride = 1;
     {
-        ScopedTimer t(ctx, "knn_brute");
-        const unsigned grid = (unsigned)ceil_div(Mp, kQPerBlock);
-        const char* dbg_env = getenv("DDX_KNN_DEBUG");
-        const int dbg = dbg_env ? atoi(dbg_env) : 0;
-        if (lds > 48 * 1024) {
-            DDX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_knn_mfma<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            DDX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_knn_mfma<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        }
-        if (CP == 32)
-            k_knn_mfma<32><<<grid, 256, lds, ctx->stream>>>(E, Et, nrm, M, Mp, k, include_self, ctx->knn_idx.as<int32_t>(), ctx->knn_dist.as<double>(), dbg);
-        else
-            k_knn_mfma<64><<<grid, 256, lds, ctx->stream>>>(E, Et, nrm, M, Mp, k, include_self, ctx->knn_idx.as<int32_t>(), ctx->knn_dist.as<double>(), dbg);
+        ScopedTimer t(ctx, "knn_bound");
+        const unsigned grid = (unsigned)(Mp / (4 * 16 * kBoundRT));
+        if (CP == 32) k_knn_bound<32><<<grid, 256, 0, ctx->stream>>>(Et, nrm, Mp, k, include_self, nsamp, stride, thr);
+        else k_knn_bound<64><<<grid, 256, 0, ctx->stream>>>(Et, nrm, Mp, k, include_self, nsamp, stride, thr);
+    }
+    {
+        ScopedTimer t(ctx, "knn_emit");
+        const unsigned grid = (unsigned)(Mp / (4 * 16 * kEmitRT));
+        if (CP == 32) k_knn_emit<32><<<grid, 256, 0, ctx->stream>>>(Et, nrm, thr, Mp, include_self, ccount, cbuf);
+        else k_knn_emit<64><<<grid, 256, 0, ctx->stream>>>(Et, nrm, thr, Mp, include_self, ccount, cbuf);
+    }
+    {
+        ScopedTimer t(ctx, "knn_select");
+        const unsigned g2 = (unsigned)ceil_div(M, 4);
+        if (CP == 32) k_knn_select<32><<<g2, 256, 0, ctx->stream>>>(E, M, k, include_self, ccount, cbuf, ctx->knn_idx.as<int32_t>(), ctx->knn_dist.as<double>(), ccount + Mp);
+        else k_knn_select<64><<<g2, 256, 0, ctx->stream>>>(E, M, k, include_self, ccount, cbuf, ctx->knn_idx.as<int32_t>(), ctx->knn_dist.as<double>(), ccount + Mp);
     }
     DDX_HIP(ctx, hipGetLastError());
+    if (getenv("DDX_KNN_DEBUG")) {
+        std::vector<int32_t> h(Mp + 1);
+        DDX_HIP(ctx, hipMemcpyAsync(h.data(), ccount, sizeof(int32_t) * (Mp + 1), hipMemcpyDeviceToHost, ctx->stream));
+        DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        double sum = 0; int mx = 0; int64_t over = 0;
+        for (int64_t i = 0; i < M; ++i) { sum += h[i]; if (h[i] > mx) mx = h[i]; over += h[i] > kCandCap; }
+        fprintf(stderr, "[knn] k=%d sample tiles=%lld stride=%lld: candidates/query mean %.1f max %d, overflowed %lld (counter %d)\n",
+                k, (long long)nsamp, (long long)stride, sum / M, mx, (long long)over, h[Mp]);
+    }
     ctx->K = k;
     ctx->knn_self = include_self != 0;
     ctx->have_knn = true;
