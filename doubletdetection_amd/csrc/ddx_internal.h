@@ -96,7 +96,7 @@ struct ddx_ctx {
 
     // PCA work space
     int32_t C = 0;
-    ddx::DevBuf pcaA, pcaB, pcaSmall, pcaPartial, pcaVec, pcaPanel;
+    ddx::DevBuf pcaA, pcaB, pcaSmall, pcaPartial, pcaVec, pcaPanel, pcaOp;
     ddx::DevBuf emb32;               // float  [M*C]
     ddx::DevBuf emb64;               // double [M*C]
     ddx::DevBuf sing;                // double [C]

@@ -12,6 +12,7 @@
 // the float64 result is the same to ~1e-12 (oracle/dd_oracle.py:randomized_pca_f64 checks this).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #include "ddx_internal.h"
 
@@ -19,25 +20,52 @@ namespace ddx {
 
 constexpr int kMaxL = 64;   // sketch width limit (n_components + n_oversamples)
 
+typedef double d2v __attribute__((ext_vector_type(2)));
+typedef float f4v __attribute__((ext_vector_type(4)));
+
+// One gathered operand row is read as 16-byte pieces: 2 float64 or 4 float32 sketch columns per lane.
+// The float32 variant reads a rounded copy of the operand (products and sums stay float64); it halves
+// the gathered bytes, which is what bounds these kernels.  VW = sketch columns per lane.
+template <typename T> struct Gather;
+template <> struct Gather<double> {
+    static constexpr int VW = 2;
+    __device__ static __forceinline__ void load(const double* p, double (&v)[2]) {
+        const d2v t = *reinterpret_cast<const d2v*>(p);
+        v[0] = t.x; v[1] = t.y;
+    }
+};
+template <> struct Gather<float> {
+    static constexpr int VW = 4;
+    __device__ static __forceinline__ void load(const float* p, double (&v)[4]) {
+        const f4v t = *reinterpret_cast<const f4v*>(p);
+        v[0] = (double)t.x; v[1] = (double)t.y; v[2] = (double)t.z; v[3] = (double)t.w;
+    }
+};
+
 // ------------------------------------------------------------------------------------------------
 // SpMM over rows:  Y[i,:] = sum_j (x_ij - z_j) Q[j,:] - t[:]        (A Q, t = m^T Q)
-// One wave per matrix row.  The 64 lanes are split into `slots` groups of `lpn` lanes; a group
-// handles one stored entry at a time and each of its lanes two adjacent sketch columns (one 16-byte
-// load of Q), so a step consumes `slots` entries with fully coalesced L*8-byte row gathers.
+// One wave per matrix row.  The 64 lanes are split into `slots` groups of `lpn` lanes; a group handles
+// one stored entry at a time and each of its lanes VW adjacent sketch columns (one 16-byte load of Q),
+// so a step consumes `slots` entries with fully coalesced row gathers.  Four steps are in flight per
+// trip: all gathers are issued before the first multiply-add; the accumulation order (entry by entry)
+// is fixed, so results are reproducible bit for bit.   Requires L % VW == 0.
 // ------------------------------------------------------------------------------------------------
+template <typename T>
 __global__ void __launch_bounds__(256) k_spmm_rows(const int64_t* __restrict__ indptr, const int32_t* __restrict__ cols,
                                                    const float* __restrict__ x, const float* __restrict__ zcol,
-                                                   const double* __restrict__ Q, int L, int lpn, int slots,
+                                                   const T* __restrict__ Q, int ld, int L, int lpn, int slots,
                                                    const double* __restrict__ tvec, int64_t M, double* __restrict__ Y) {
+    constexpr int VW = Gather<T>::VW;
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= M) return;
     const int slot = lane / lpn, sub = lane - slot * lpn;
     const bool active = slot < slots;
-    const int c0 = 2 * sub;
-    const bool has1 = (c0 + 1) < L;
+    const int c0 = VW * sub;
     const int64_t b = indptr[row], e = indptr[row + 1];
-    double acc0 = 0.0, acc1 = 0.0;
+    double acc[VW];
+#pragma unroll
+    for (int c = 0; c < VW; ++c) acc[c] = 0.0;
     for (int64_t base = b; base < e; base += 64) {
         const int64_t p = base + lane;
         int32_t j = 0;
@@ -47,30 +75,34 @@ __global__ void __launch_bounds__(256) k_spmm_rows(const int64_t* __restrict__ i
             d = (double)x[p] - (double)zcol[j];
         }
         const int cnt = (int)((e - base) < 64 ? (e - base) : 64);
-        for (int t0 = 0; t0 < cnt; t0 += slots) {
-            const int tt = t0 + slot;
-            const int src = tt < 64 ? tt : 63;
-            const int32_t jj = __shfl(j, src, 64);
-            double dd = __shfl(d, src, 64);
-            if (tt >= cnt) dd = 0.0;
-            if (active && c0 < L) {
-                const double* q = Q + (int64_t)jj * L + c0;
-                acc0 = fma(dd, q[0], acc0);
-                if (has1) acc1 = fma(dd, q[1], acc1);
+        for (int t0 = 0; t0 < cnt; t0 += 4 * slots) {
+            int32_t jj[4];
+            double dd[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int tt = t0 + u * slots + slot;
+                const int src = tt < 64 ? tt : 63;
+                jj[u] = __shfl(j, src, 64);
+                dd[u] = __shfl(d, src, 64);
+                if (tt >= cnt) { dd[u] = 0.0; jj[u] = 0; }
+            }
+            if (active) {
+                double qv[4][VW];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) Gather<T>::load(Q + (int64_t)jj[u] * ld + c0, qv[u]);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int c = 0; c < VW; ++c) acc[c] = fma(dd[u], qv[u][c], acc[c]);
             }
         }
     }
     // combine the slots in fixed order (slot 0 + slot 1 + ...)
-    double s0 = acc0, s1 = acc1;
-    for (int s = 1; s < slots; ++s) {
-        const double o0 = __shfl(acc0, lane + s * lpn, 64);
-        const double o1 = __shfl(acc1, lane + s * lpn, 64);
-        s0 += o0;
-        s1 += o1;
-    }
-    if (slot == 0 && c0 < L) {
-        Y[row * L + c0] = s0 - tvec[c0];
-        if (has1) Y[row * L + c0 + 1] = s1 - tvec[c0 + 1];
+#pragma unroll
+    for (int c = 0; c < VW; ++c) {
+        double sum = acc[c];
+        for (int s = 1; s < slots; ++s) sum += __shfl(acc[c], lane + s * lpn, 64);
+        if (slot == 0 && c0 + c < L) Y[row * L + c0 + c] = sum - tvec[c0 + c];
     }
 }
 
@@ -82,12 +114,14 @@ __global__ void __launch_bounds__(256) k_spmm_rows(const int64_t* __restrict__ i
 // panel is processed, and all blocks of a panel are placed on the same XCD (block b runs on XCD b % 8),
 // so those gathers are served by that XCD's 4 MB L2 instead of the Infinity Cache.
 // ------------------------------------------------------------------------------------------------
+template <typename T>
 __global__ void __launch_bounds__(256) k_spmm_cols(const int64_t* __restrict__ cp_o, const int32_t* __restrict__ row_o,
                                                    const float* __restrict__ x_o, int P_o,
                                                    const int64_t* __restrict__ cp_s, const int32_t* __restrict__ row_s,
                                                    const float* __restrict__ x_s, int p_s0, int P_s, int P, int32_t H,
-                                                   const float* __restrict__ zcol, const double* __restrict__ Yin,
+                                                   const float* __restrict__ zcol, const T* __restrict__ Yin, int ld,
                                                    int L, int lpn, int slots, double* __restrict__ Wp) {
+    constexpr int VW = Gather<T>::VW;
     // XCD-aware decode: xcd = b % 8 handles panels xcd, xcd + 8, ... one after the other
     const int groups = (H + 3) >> 2;                 // 4 columns (one per wave) per block
     const int64_t b = blockIdx.x;
@@ -100,10 +134,11 @@ __global__ void __launch_bounds__(256) k_spmm_cols(const int64_t* __restrict__ c
     if (j >= H) return;
     const int slot = lane / lpn, sub = lane - slot * lpn;
     const bool active = slot < slots;
-    const int c0 = 2 * sub;
-    const bool has1 = (c0 + 1) < L;
+    const int c0 = VW * sub;
     const double z = (double)zcol[j];
-    double acc0 = 0.0, acc1 = 0.0;
+    double acc[VW];
+#pragma unroll
+    for (int c = 0; c < VW; ++c) acc[c] = 0.0;
     for (int seg = 0; seg < 2; ++seg) {
         int64_t lo, hi;
         const int32_t* rows;
@@ -127,32 +162,45 @@ __global__ void __launch_bounds__(256) k_spmm_cols(const int64_t* __restrict__ c
                 d = (double)x[p] - z;
             }
             const int cnt = (int)((hi - base) < 64 ? (hi - base) : 64);
-            for (int t0 = 0; t0 < cnt; t0 += slots) {
-                const int tt = t0 + slot;
-                const int src = tt < 64 ? tt : 63;
-                const int32_t ii = __shfl(i, src, 64);
-                double dd = __shfl(d, src, 64);
-                if (tt >= cnt) dd = 0.0;
-                if (active && c0 < L) {
-                    const double* y = Yin + (int64_t)ii * L + c0;
-                    acc0 = fma(dd, y[0], acc0);
-                    if (has1) acc1 = fma(dd, y[1], acc1);
+            for (int t0 = 0; t0 < cnt; t0 += 4 * slots) {
+                int32_t ii[4];
+                double dd[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int tt = t0 + u * slots + slot;
+                    const int src = tt < 64 ? tt : 63;
+                    ii[u] = __shfl(i, src, 64);
+                    dd[u] = __shfl(d, src, 64);
+                    if (tt >= cnt) { dd[u] = 0.0; ii[u] = 0; }
+                }
+                if (active) {
+                    double yv[4][VW];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) Gather<T>::load(Yin + (int64_t)ii[u] * ld + c0, yv[u]);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int c = 0; c < VW; ++c) acc[c] = fma(dd[u], yv[u][c], acc[c]);
                 }
             }
         }
     }
-    double s0 = acc0, s1 = acc1;
-    for (int s = 1; s < slots; ++s) {
-        const double o0 = __shfl(acc0, lane + s * lpn, 64);
-        const double o1 = __shfl(acc1, lane + s * lpn, 64);
-        s0 += o0;
-        s1 += o1;
+#pragma unroll
+    for (int c = 0; c < VW; ++c) {
+        double sum = acc[c];
+        for (int s = 1; s < slots; ++s) sum += __shfl(acc[c], lane + s * lpn, 64);
+        if (slot == 0 && c0 + c < L) Wp[((int64_t)panel * H + j) * L + c0 + c] = sum;
     }
-    if (slot == 0 && c0 < L) {
-        double* w = Wp + ((int64_t)panel * H + j) * L + c0;
-        w[0] = s0;
-        if (has1) w[1] = s1;
-    }
+}
+
+// padded (and possibly float32-rounded) copy of an R x L operand: out[r*ld + c], zero in the padding columns
+template <typename T>
+__global__ void k_operand_copy(const double* __restrict__ in, int64_t R, int L, int ld, T* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= R * ld) return;
+    const int64_t r = t / ld;
+    const int c = (int)(t - r * ld);
+    out[t] = (c < L) ? (T)in[r * L + c] : (T)0;
 }
 
 // W[j,c] = sum_p Wp[p][j][c] - m_j u_c   (panels added in order)
@@ -339,6 +387,8 @@ __global__ void k_f64_to_f32(const double* __restrict__ in, int64_t n, float* __
 struct PcaWork {
     ddx_ctx* ctx;
     int L, lpn, slots;
+    bool gather32;     // gather a float32 copy of the small operand (needs L % 4 == 0)
+    float* op32;       // scratch for that copy: max(M, H) x L floats
     int64_t M;
     int32_t H;
     double* partial;   // scratch for block partials
@@ -376,6 +426,14 @@ static int cholqr(PcaWork& w, const double* X, int64_t R, double* out) {
     return DDX_OK;
 }
 
+// operand preparation: returns the pointer/leading dimension the gather kernels should use
+template <typename T>
+static const T* prepared_operand(PcaWork& w, const double* X, int64_t R, int ld) {
+    T* out = reinterpret_cast<T*>(w.op32);
+    k_operand_copy<T><<<(unsigned)ceil_div(R * ld, 256), 256, 0, w.ctx->stream>>>(X, R, w.L, ld, out);
+    return out;
+}
+
 static int apply_rows(PcaWork& w, const double* Qcol, double* Yrow) {  // A Q : [H x L] -> [M x L]
     ddx_ctx* c = w.ctx;
     double* tvec = w.small + 3 * w.L * w.L;
@@ -384,8 +442,18 @@ static int apply_rows(PcaWork& w, const double* Qcol, double* Yrow) {  // A Q : 
         wcolsum(w, Qcol, w.H, c->colmean.as<double>(), tvec);
     }
     ScopedTimer t(c, "spmm_rows");
-    k_spmm_rows<<<(unsigned)ceil_div(w.M, 4), 256, 0, c->stream>>>(c->aug_indptr.as<int64_t>(), c->aug_indices.as<int32_t>(), c->aug_x.as<float>(),
-                                                                   c->zcol.as<float>(), Qcol, w.L, w.lpn, w.slots, tvec, w.M, Yrow);
+    const unsigned grid = (unsigned)ceil_div(w.M, 4);
+    if (w.gather32) {
+        const int ld = (w.L + 3) & ~3, lpn = ld / 4;
+        const float* op = prepared_operand<float>(w, Qcol, w.H, ld);
+        k_spmm_rows<float><<<grid, 256, 0, c->stream>>>(c->aug_indptr.as<int64_t>(), c->aug_indices.as<int32_t>(), c->aug_x.as<float>(),
+                                                        c->zcol.as<float>(), op, ld, w.L, lpn, 64 / lpn, tvec, w.M, Yrow);
+    } else {
+        const int ld = (w.L + 1) & ~1, lpn = ld / 2;
+        const double* op = (ld == w.L) ? Qcol : prepared_operand<double>(w, Qcol, w.H, ld);
+        k_spmm_rows<double><<<grid, 256, 0, c->stream>>>(c->aug_indptr.as<int64_t>(), c->aug_indices.as<int32_t>(), c->aug_x.as<float>(),
+                                                         c->zcol.as<float>(), op, ld, w.L, lpn, 64 / lpn, tvec, w.M, Yrow);
+    }
     return DDX_OK;
 }
 
@@ -400,9 +468,19 @@ static int apply_cols(PcaWork& w, const double* Yrow, double* Wcol) {  // A^T Y 
     const int groups = (w.H + 3) / 4;
     const int64_t grid = 8 * ceil_div(P, 8) * groups;
     ScopedTimer t(c, "spmm_cols");
-    k_spmm_cols<<<(unsigned)grid, 256, 0, c->stream>>>(c->csc_o_colptr.as<int64_t>(), c->csc_o_row.as<int32_t>(), c->csc_o_x.as<float>(), c->P_o,
-                                                       c->csc_s_colptr.as<int64_t>(), c->csc_s_row.as<int32_t>(), c->csc_s_x.as<float>(), c->p_s0,
-                                                       c->P_s, P, w.H, c->zcol.as<float>(), Yrow, w.L, w.lpn, w.slots, c->pcaPanel.as<double>());
+    if (w.gather32) {
+        const int ld = (w.L + 3) & ~3, lpn = ld / 4;
+        const float* op = prepared_operand<float>(w, Yrow, w.M, ld);
+        k_spmm_cols<float><<<(unsigned)grid, 256, 0, c->stream>>>(c->csc_o_colptr.as<int64_t>(), c->csc_o_row.as<int32_t>(), c->csc_o_x.as<float>(), c->P_o,
+                                                              c->csc_s_colptr.as<int64_t>(), c->csc_s_row.as<int32_t>(), c->csc_s_x.as<float>(), c->p_s0,
+                                                              c->P_s, P, w.H, c->zcol.as<float>(), op, ld, w.L, lpn, 64 / lpn, c->pcaPanel.as<double>());
+    } else {
+        const int ld = (w.L + 1) & ~1, lpn = ld / 2;
+        const double* op = (ld == w.L) ? Yrow : prepared_operand<double>(w, Yrow, w.M, ld);
+        k_spmm_cols<double><<<(unsigned)grid, 256, 0, c->stream>>>(c->csc_o_colptr.as<int64_t>(), c->csc_o_row.as<int32_t>(), c->csc_o_x.as<float>(), c->P_o,
+                                                               c->csc_s_colptr.as<int64_t>(), c->csc_s_row.as<int32_t>(), c->csc_s_x.as<float>(), c->p_s0,
+                                                               c->P_s, P, w.H, c->zcol.as<float>(), op, ld, w.L, lpn, 64 / lpn, c->pcaPanel.as<double>());
+    }
     k_sum_panels<<<(unsigned)ceil_div((int64_t)w.H * w.L, 256), 256, 0, c->stream>>>(c->pcaPanel.as<double>(), P, w.H, w.L, c->colmean.as<double>(),
                                                                                       uvec, Wcol);
     return DDX_OK;
@@ -437,6 +515,15 @@ int stage_pca(ddx_ctx* ctx, int32_t C, int32_t oversample, int32_t n_iter, const
     w.L = L;
     w.lpn = (L + 1) / 2;
     w.slots = 64 / w.lpn;
+    {
+        // DDX_PCA_GATHER=f64 gathers the float64 iterates themselves; the default gathers a float32-rounded
+        // copy (float64 products and sums), which moves half the bytes through L2
+        const char* g = getenv("DDX_PCA_GATHER");
+        w.gather32 = !(g && (g[0] == 'f' || g[0] == 'F') && g[1] == '6');
+    }
+    const int64_t maxR = M > H ? M : (int64_t)H;
+    DDX_TRY(ensure(ctx, ctx->pcaOp, sizeof(double) * (size_t)maxR * (L + 4)));
+    w.op32 = ctx->pcaOp.as<float>();
     w.M = M;
     w.H = H;
     w.partial = ctx->pcaPartial.as<double>();
