@@ -30,6 +30,10 @@ if ROOT not in sys.path:
 
 import numpy as np  # noqa: E402
 
+# HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide
+# coalesced reads, + WRITE_SIZE), headline workload, see profiles/r01_pmc_traffic.md; None = not collected
+PMC_TRAFFIC_GB = {"spmm_rows": 1.46, "spmm_cols": 1.67, "knn_emit": None}
+
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md)
 FP64_PEAK_TFLOPS = 78.6      # FP64 vector / FP64 MFMA peak, dense
 FP32_PEAK_TFLOPS = 157.3
@@ -52,14 +56,22 @@ def parse():
 
 
 def kernel_models(N, G, H, S, nnz_aug, C, k, L=None):
-    """Algorithmic work per launch of every timed kernel (DESIGN.md section 'kernels')."""
+    """Algorithmic work per launch of the kernels that can dominate.
+
+    HBM-bound kernels: bytes that must cross HBM once (matrix entries 8 B each + dense operands in and out).
+    MFMA-bound kernels: useful flops of the distance screen (2 flop per component and pair, padded C)."""
     M = N + S
     L = L or (C + 10)
+    CP = 32 if C <= 32 else 64
+    Mp = -(-M // 256) * 256
+    nsamp_tiles = min(max(-(-k * M // (144 * 16)), 128), Mp // 16)
     return {
         # name: (bound, unit, work per launch, peak)
         "spmm_rows": ("hbm", "GB/s", (8 * nnz_aug + 8 * M * L + 8 * H * L + 8 * (M + 1)) / 1e9, HBM_PEAK_GBS),
         "spmm_cols": ("hbm", "GB/s", (8 * nnz_aug + 8 * H * L + 8 * M * L + 16 * (H + 1)) / 1e9, HBM_PEAK_GBS),
-        "knn_brute": ("mfma", "TFLOP/s", 3.0 * M * M * C / 1e12, FP64_PEAK_TFLOPS),
+        "knn_emit": ("mfma", "TFLOP/s", 2.0 * Mp * Mp * CP / 1e12, FP32_PEAK_TFLOPS),
+        "knn_bound": ("mfma", "TFLOP/s", 2.0 * Mp * nsamp_tiles * 16 * CP / 1e12, FP32_PEAK_TFLOPS),
+        "pca_orth": ("hbm", "GB/s", (24 * M * L) / 1e9, HBM_PEAK_GBS),
         "doublet_fill": ("hbm", "GB/s", (8 * (nnz_aug * 2 * S / max(M + S, 1)) * 2) / 1e9, HBM_PEAK_GBS),
         "lognorm_rows": ("hbm", "GB/s", (8 * nnz_aug + 8 * M) / 1e9, HBM_PEAK_GBS),
         "lognorm_cols": ("hbm", "GB/s", (12 * nnz_aug) / 1e9, HBM_PEAK_GBS),
@@ -136,15 +148,16 @@ def main():
         models = kernel_models(N, G, H, S, nnz_aug, C, k)
         gpu_ms = {n: v[1] for n, v in timings.items()}
         dominant = max(gpu_ms, key=gpu_ms.get) if gpu_ms else None
-        roofline = None
-        if dominant in models:
-            bound, unit, work, peak = models[dominant]
-            avg_s = timings[dominant][1] / max(timings[dominant][0], 1) / 1e3
+        def roof(name):
+            bound, unit, work, peak = models[name]
+            avg_s = timings[name][1] / max(timings[name][0], 1) / 1e3
             achieved = work / avg_s
-            roofline = {"bound": bound, "kernel": dominant, "achieved": round(achieved, 2), "peak": peak, "unit": unit,
-                        "frac": round(achieved / peak, 4), "traffic": None,
-                        "avg_launch_ms": round(avg_s * 1e3, 4), "launches": timings[dominant][0],
-                        "work_per_launch": work}
+            return {"bound": bound, "kernel": name, "achieved": round(achieved, 2), "peak": peak, "unit": unit,
+                    "frac": round(achieved / peak, 4), "traffic": PMC_TRAFFIC_GB.get(name),
+                    "avg_launch_ms": round(avg_s * 1e3, 4), "launches": timings[name][0], "work_per_launch": round(work, 4)}
+
+        roofline = roof(dominant) if dominant in models else None
+        roofline_all = [roof(n) for n in sorted(gpu_ms, key=gpu_ms.get, reverse=True) if n in models][:6]
         total_gpu_ms = sum(gpu_ms.values())
         out = {
             "metric": "cells/sec for full BoostClassifier.fit() (default n_iters)",
@@ -165,6 +178,7 @@ def main():
                        "n_iters": args.iters, "sharding": f"iterations over {world} rank(s)",
                        "host_threads": os.cpu_count()},
             "roofline": roofline,
+            "roofline_top_kernels": roofline_all,
             "gpu_kernel_ms_per_step": {n: round(v / args.steps, 3) for n, v in sorted(gpu_ms.items(), key=lambda kv: -kv[1])},
             "gpu_busy_frac": round(total_gpu_ms / 1e3 / elapsed, 4),
             "host_seconds_last_step": {k2: round(v, 3) for k2, v in getattr(clf, "_host_timings", {}).items()},

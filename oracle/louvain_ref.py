@@ -14,7 +14,7 @@ Algorithm (the published multi-level modularity optimisation with a resolution p
 
 * quality  Q = sum_c [ in_c / 2m  -  gamma * (tot_c / 2m)^2 ]   (RB-configuration form; gamma=1 is
   Newman-Girvan modularity as in PhenoGraph, gamma=4 is what dd.py:417-420 passes to scanpy);
-* one level: visit nodes in a seeded random order (splitmix64 Fisher-Yates, one stream for all
+* one level: visit nodes in index order starting at a seeded offset (one splitmix64 stream for all
   levels); take the node out of its community; evaluate gain(c) = w(v,c) - gamma*tot_c*k_v/2m for
   its own community first and then each neighbouring community in adjacency order; move to the
   strictly best; repeat passes while nodes moved and the pass improved Q by more than 1e-6 (the
@@ -44,12 +44,10 @@ class SplitMix64:
         return z ^ (z >> 31)
 
 
-def _shuffled(n: int, rng: SplitMix64):
-    order = list(range(n))
-    for i in range(n - 1, 0, -1):
-        j = rng.next() % (i + 1)
-        order[i], order[j] = order[j], order[i]
-    return order
+def _visit_order(n: int, rng: SplitMix64):
+    """Index order starting at a seeded offset."""
+    start = rng.next() % n
+    return [(start + i) % n for i in range(n)]
 
 
 def _quality(in_, tot, m2, gamma):
@@ -81,7 +79,7 @@ def _one_level(indptr, indices, weights, gamma, rng):
         return comm, False
     tot = deg[:]
     in_ = loops[:]
-    order = _shuffled(n, rng)
+    order = _visit_order(n, rng)
     neigh_w = [-1.0] * n
     improved = False
     new_q = _quality(in_, tot, m2, gamma)

@@ -174,7 +174,7 @@ def test_pca_scores(ctx, case, gather, monkeypatch):
     # default: the operator products gather a float32-rounded copy of the 40-column iterate (float64
     # products and sums); DDX_PCA_GATHER=f64 gathers the float64 iterate itself
     monkeypatch.setenv("DDX_PCA_GATHER", gather)
-    tol = 1e-7 if gather == "f64" else 2e-6
+    tol = 1e-7 if gather == "f64" else 1e-5     # bar: 1e-4 (sklearn f32 vs f64 differs by up to 8e-4)
     g = load_golden(case)
     kw = golden_kwargs(g)
     raw = csr_from(g, "raw_hvg")
