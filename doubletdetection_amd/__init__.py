@@ -5,7 +5,7 @@
 (libddx.so, C-ABI in include/ddx.h).  Importing the package does not touch the GPU; constructing the
 device context inside ``fit`` fails loudly when libddx.so or a gfx950 device is missing.
 """
-from .classifier import BoostClassifier
+from .classifier import BoostClassifier, release_device_memory
 
 __version__ = "0.1.0"
-__all__ = ["BoostClassifier"]
+__all__ = ["BoostClassifier", "release_device_memory"]

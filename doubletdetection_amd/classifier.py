@@ -59,16 +59,41 @@ def _dist_info():
     return 0, 1, None
 
 
+# Device contexts (and the HBM buffers they own) are kept per GPU between fits, like a caching allocator:
+# re-allocating ~3 GB of device memory for every fit() costs more than the prologue itself.
+_CONTEXT_POOL: dict = {}
+
+
+def release_device_memory() -> None:
+    """Destroy the pooled device contexts and free their HBM buffers."""
+    while _CONTEXT_POOL:
+        _, ctx = _CONTEXT_POOL.popitem()
+        ctx.close()
+
+
+import atexit  # noqa: E402
+
+atexit.register(release_device_memory)
+
+
 class _HipEngine:
     """Device side of one fit on one GPU: thin sequencing of the libddx stages."""
 
     def __init__(self, device: int):
-        self.ctx = _lib.Context(device)
-        if os.environ.get("DDX_TIMING") == "1":      # per-kernel HIP-event timing (bench.py / profiling)
-            self.ctx.timing_enable(True)
+        self.device = device
+        self.ctx = _CONTEXT_POOL.pop(device, None) or _lib.Context(device)
+        timing = os.environ.get("DDX_TIMING") == "1"     # per-kernel HIP-event timing (bench.py / profiling)
+        self.ctx.timing_enable(timing)
+        if timing:
+            self.ctx.timing_reset()
 
     def close(self):
-        self.ctx.close()
+        if self.ctx is not None:
+            if self.device in _CONTEXT_POOL:             # another engine already parked one: drop this one
+                self.ctx.close()
+            else:
+                _CONTEXT_POOL[self.device] = self.ctx
+            self.ctx = None
 
     def upload(self, csr):
         self.ctx.upload_counts(csr)
@@ -91,9 +116,7 @@ class _HipEngine:
             c.scale(15.0)
         c.pca(n_components, q0)
         c.knn(knn_k, include_self)
-        idx, w = c.graph_relations(graph_mode)
-        # the CSR assembly is host work: hand it to the worker thread together with the clustering
-        return lambda: _lib.assemble_graph(idx, w)
+        return c.build_graph(graph_mode)      # symmetric CSR assembled on the device
 
     def timings(self):
         return self.ctx.timings()

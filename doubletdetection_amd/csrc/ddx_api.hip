@@ -485,20 +485,22 @@ int ddx_assemble_graph(int64_t n_nodes, int32_t k, const int32_t* idx, const dou
 
 int ddx_get_graph_size(ddx_ctx* ctx, int64_t* n_nodes, int64_t* n_entries) {
     REQUIRE_CTX(ctx);
-    NEED(!ctx->g_indptr.empty(), "no graph");
-    *n_nodes = (int64_t)ctx->g_indptr.size() - 1;
-    *n_entries = ctx->g_indptr.back();
+    NEED(ctx->g_nodes >= 0, "no graph");
+    *n_nodes = ctx->g_nodes;
+    *n_entries = ctx->g_entries;
     return DDX_OK;
 }
 
 int ddx_get_graph(ddx_ctx* ctx, int64_t* indptr, int32_t* indices, double* weights) {
     REQUIRE_CTX(ctx);
-    NEED(!ctx->g_indptr.empty(), "no graph");
-    memcpy(indptr, ctx->g_indptr.data(), sizeof(int64_t) * ctx->g_indptr.size());
-    if (!ctx->g_indices.empty()) {
-        memcpy(indices, ctx->g_indices.data(), sizeof(int32_t) * ctx->g_indices.size());
-        memcpy(weights, ctx->g_weights.data(), sizeof(double) * ctx->g_weights.size());
+    USE_DEVICE(ctx);
+    NEED(ctx->g_nodes >= 0, "no graph");
+    DDX_HIP(ctx, hipMemcpyAsync(indptr, ctx->g_d_indptr, sizeof(int64_t) * (ctx->g_nodes + 1), hipMemcpyDeviceToHost, ctx->stream));
+    if (ctx->g_entries > 0) {
+        DDX_HIP(ctx, hipMemcpyAsync(indices, ctx->g_d_cols, sizeof(int32_t) * ctx->g_entries, hipMemcpyDeviceToHost, ctx->stream));
+        DDX_HIP(ctx, hipMemcpyAsync(weights, ctx->g_d_vals, sizeof(double) * ctx->g_entries, hipMemcpyDeviceToHost, ctx->stream));
     }
+    DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return DDX_OK;
 }
 

@@ -112,10 +112,11 @@ struct ddx_ctx {
     ddx::DevBuf edge_w;              // double [M*K]
     bool have_knn = false;
 
-    // graph (host)
-    std::vector<int64_t> g_indptr;
-    std::vector<int32_t> g_indices;
-    std::vector<double> g_weights;
+    // graph: symmetric CSR left on the device by ddx_build_graph (views into pcaPanel)
+    int64_t g_nodes = -1, g_entries = 0;
+    const int64_t* g_d_indptr = nullptr;
+    const int32_t* g_d_cols = nullptr;
+    const double* g_d_vals = nullptr;
 
     // timing
     bool timing = false;

@@ -8,6 +8,8 @@
 // by (distance, index) is bit-identical to an IEEE float64 brute force.  The running top-k of each
 // thread lives in LDS, slot-major ([slot][thread]) so lanes hit distinct banks; insertions are rare
 // after the first few hundred candidates (expected k*ln(M/k) per query).
+#include <hipcub/hipcub.hpp>
+
 #include <algorithm>
 #include <cstdlib>
 
@@ -528,18 +530,58 @@ __global__ void __launch_bounds__(256) k_edge_weights(const int32_t* __restrict_
     w_out[t] = mutual ? w : -w;
 }
 
+// ---- symmetric CSR on the device ----------------------------------------------------------------------
+// every relation with a non-zero weight contributes the pair (i,j); a one-directional relation (negative
+// flag) also contributes (j,i).  Pairs are keyed (row << 32 | column) and radix-sorted, which yields rows
+// in order and columns ascending inside a row (the adjacency order the community-detection spec visits).
+__global__ void __launch_bounds__(256) k_pair_count(const double* __restrict__ w, int64_t n, int32_t* __restrict__ cnt) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const double v = w[t];
+    cnt[t] = (v == 0.0) ? 0 : (v < 0.0 ? 2 : 1);
+}
+
+__global__ void __launch_bounds__(256) k_pair_emit(const int32_t* __restrict__ idx, const double* __restrict__ w, int64_t n,
+                                                   int K, const int64_t* __restrict__ offs, uint64_t* __restrict__ keys,
+                                                   double* __restrict__ vals) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const double v = w[t];
+    if (v == 0.0) return;
+    const uint64_t i = (uint64_t)(t / K), j = (uint64_t)idx[t];
+    const double av = v < 0.0 ? -v : v;
+    int64_t o = offs[t];
+    keys[o] = (i << 32) | j;
+    vals[o] = av;
+    if (v < 0.0) {
+        keys[o + 1] = (j << 32) | i;
+        vals[o + 1] = av;
+    }
+}
+
+__global__ void k_rowptr_from_keys(const uint64_t* __restrict__ keys, int64_t n, int64_t M, int64_t* __restrict__ indptr) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > M) return;
+    int64_t lo = 0, hi = n;   // first key with row >= r
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if ((int64_t)(keys[mid] >> 32) < r) lo = mid + 1; else hi = mid;
+    }
+    indptr[r] = lo;
+}
+
+__global__ void k_cols_from_keys(const uint64_t* __restrict__ keys, int64_t n, int32_t* __restrict__ cols) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) cols[t] = (int32_t)(keys[t] & 0xffffffffull);
+}
+
 // device part: relation weights for the kNN table currently held by the context
+static int graph_weights_device(ddx_ctx* ctx, int32_t mode);
+
 int stage_graph_relations(ddx_ctx* ctx, int32_t mode, int32_t* idx_host, double* w_host) {
     const int64_t M = ctx->embM;
     const int K = ctx->K;
-    DDX_TRY(ensure(ctx, ctx->knn_sorted, sizeof(int32_t) * (size_t)M * K));
-    DDX_TRY(ensure(ctx, ctx->edge_w, sizeof(double) * (size_t)M * K));
-    {
-        ScopedTimer t(ctx, "graph_weights");
-        k_sort_neighbours<<<(unsigned)ceil_div(M, 64), 64, sizeof(int32_t) * K * 64, ctx->stream>>>(ctx->knn_idx.as<int32_t>(), M, K, ctx->knn_sorted.as<int32_t>());
-        k_edge_weights<<<(unsigned)ceil_div(M * K, 256), 256, 0, ctx->stream>>>(ctx->knn_idx.as<int32_t>(), ctx->knn_sorted.as<int32_t>(), M, K, mode,
-                                                                                ctx->edge_w.as<double>());
-    }
+    DDX_TRY(graph_weights_device(ctx, mode));
     DDX_HIP(ctx, hipMemcpyAsync(idx_host, ctx->knn_idx.p, sizeof(int32_t) * (size_t)M * K, hipMemcpyDeviceToHost, ctx->stream));
     DDX_HIP(ctx, hipMemcpyAsync(w_host, ctx->edge_w.p, sizeof(double) * (size_t)M * K, hipMemcpyDeviceToHost, ctx->stream));
     DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -590,13 +632,68 @@ void assemble_graph(int64_t M, int K, const int32_t* idx, const double* w, std::
     }
 }
 
+// relation weights on the device (no copies)
+static int graph_weights_device(ddx_ctx* ctx, int32_t mode) {
+    const int64_t M = ctx->embM;
+    const int K = ctx->K;
+    DDX_TRY(ensure(ctx, ctx->knn_sorted, sizeof(int32_t) * (size_t)M * K));
+    DDX_TRY(ensure(ctx, ctx->edge_w, sizeof(double) * (size_t)M * K));
+    ScopedTimer t(ctx, "graph_weights");
+    k_sort_neighbours<<<(unsigned)ceil_div(M, 64), 64, sizeof(int32_t) * K * 64, ctx->stream>>>(ctx->knn_idx.as<int32_t>(), M, K, ctx->knn_sorted.as<int32_t>());
+    k_edge_weights<<<(unsigned)ceil_div(M * K, 256), 256, 0, ctx->stream>>>(ctx->knn_idx.as<int32_t>(), ctx->knn_sorted.as<int32_t>(), M, K, mode,
+                                                                            ctx->edge_w.as<double>());
+    return DDX_OK;
+}
+
+// whole graph stage on the device; the symmetric CSR lands in the context's host vectors
 int stage_build_graph(ddx_ctx* ctx, int32_t mode) {
     const int64_t M = ctx->embM;
     const int K = ctx->K;
-    std::vector<int32_t> idx((size_t)M * K);
-    std::vector<double> w((size_t)M * K);
-    DDX_TRY(stage_graph_relations(ctx, mode, idx.data(), w.data()));
-    assemble_graph(M, K, idx.data(), w.data(), ctx->g_indptr, ctx->g_indices, ctx->g_weights);
+    const int64_t n = M * K;
+    DDX_TRY(graph_weights_device(ctx, mode));
+    // workspace carved from the PCA panel buffer: cnt i32[n] | offs i64[n+1] | keys u64[2n] x2 | vals f64[2n] x2 | indptr i64[M+1] | cols i32[2n]
+    const size_t bytes = sizeof(int32_t) * n + sizeof(int64_t) * (n + 1) + 2 * sizeof(uint64_t) * 2 * n + 2 * sizeof(double) * 2 * n +
+                         sizeof(int64_t) * (M + 1) + sizeof(int32_t) * 2 * n + 1024;
+    DDX_TRY(ensure(ctx, ctx->pcaPanel, bytes));
+    unsigned char* base = ctx->pcaPanel.as<unsigned char>();
+    auto carve = [&](size_t sz) { unsigned char* p = base; base += (sz + 255) & ~(size_t)255; return p; };
+    int64_t* offs = reinterpret_cast<int64_t*>(carve(sizeof(int64_t) * (n + 1)));
+    uint64_t* keys_a = reinterpret_cast<uint64_t*>(carve(sizeof(uint64_t) * 2 * n));
+    uint64_t* keys_b = reinterpret_cast<uint64_t*>(carve(sizeof(uint64_t) * 2 * n));
+    double* vals_a = reinterpret_cast<double*>(carve(sizeof(double) * 2 * n));
+    double* vals_b = reinterpret_cast<double*>(carve(sizeof(double) * 2 * n));
+    int64_t* d_indptr = reinterpret_cast<int64_t*>(carve(sizeof(int64_t) * (M + 1)));
+    int32_t* d_cols = reinterpret_cast<int32_t*>(carve(sizeof(int32_t) * 2 * n));
+    int32_t* cnt = reinterpret_cast<int32_t*>(carve(sizeof(int32_t) * (n + 1)));
+    int64_t E = 0;
+    {
+        ScopedTimer t(ctx, "graph_assemble");
+        k_pair_count<<<(unsigned)ceil_div(n, 256), 256, 0, ctx->stream>>>(ctx->edge_w.as<double>(), n, cnt);
+        size_t tmp_bytes = 0;
+        DDX_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, cnt, offs, (int)n + 1, ctx->stream));
+        size_t tmp2 = 0;
+        int end_bit = 33;
+        while (((int64_t)1 << (end_bit - 32)) < M) ++end_bit;
+        DDX_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp2, keys_a, keys_b, vals_a, vals_b, (int)(2 * n), 0, end_bit, ctx->stream));
+        DDX_TRY(ensure(ctx, ctx->sort_tmp, std::max(tmp_bytes, tmp2)));
+        // (cnt has n entries; the scan reads one more element: it lives in the padding of the carve and is ignored)
+        DDX_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(ctx->sort_tmp.p, tmp_bytes, cnt, offs, (int)n + 1, ctx->stream));
+        DDX_HIP(ctx, hipMemcpyAsync(&E, offs + n, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+        k_pair_emit<<<(unsigned)ceil_div(n, 256), 256, 0, ctx->stream>>>(ctx->knn_idx.as<int32_t>(), ctx->edge_w.as<double>(), n, K, offs, keys_a, vals_a);
+        DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (E > 0) {
+            DDX_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(ctx->sort_tmp.p, tmp2, keys_a, keys_b, vals_a, vals_b, (int)E, 0, end_bit, ctx->stream));
+            k_cols_from_keys<<<(unsigned)ceil_div(E, 256), 256, 0, ctx->stream>>>(keys_b, E, d_cols);
+        }
+        k_rowptr_from_keys<<<(unsigned)ceil_div(M + 1, 256), 256, 0, ctx->stream>>>(keys_b, E, M, d_indptr);
+    }
+    DDX_HIP(ctx, hipGetLastError());
+    // the CSR stays on the device until ddx_get_graph copies it straight into the caller's buffers
+    ctx->g_nodes = M;
+    ctx->g_entries = E;
+    ctx->g_d_indptr = d_indptr;
+    ctx->g_d_cols = d_cols;
+    ctx->g_d_vals = vals_b;
     return DDX_OK;
 }
 

@@ -487,6 +487,7 @@ static int apply_cols(PcaWork& w, const double* Yrow, double* Wcol) {  // A^T Y 
 }
 
 int stage_pca(ddx_ctx* ctx, int32_t C, int32_t oversample, int32_t n_iter, const double* q0, int64_t q0_rows) {
+    ctx->g_nodes = -1;   // a graph left on the device lives in the panel buffer this stage overwrites
     const int L = C + oversample;
     if (L > kMaxL) return set_err(ctx, DDX_E_UNSUPPORTED, "sketch width %d exceeds %d", L, kMaxL);
     const int64_t M = ctx->M;
