@@ -5,6 +5,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -15,7 +16,12 @@
 namespace ddx {
 
 constexpr int kWave = 64;  // gfx950 wavefront
-constexpr int kPanelRows = 8192;  // rows per panel of the column-major mirror (8192 x 40 x 8 B = 2.6 MB of sketch rows)
+// rows per panel of the column-major mirror: the sketch rows of one panel (rows x 40 x 4 or 8 B) should fit
+// one XCD's 4 MB L2 -> 16384 rows when the operand copy is float32, 8192 when float64 iterates are gathered
+inline bool pca_gather_f32() {
+    const char* g = getenv("DDX_PCA_GATHER");
+    return !(g && (g[0] == 'f' || g[0] == 'F') && g[1] == '6');
+}
 
 struct DevBuf {
     void* p = nullptr;
@@ -81,6 +87,7 @@ struct ddx_ctx {
     // the mirror is ordered by (row panel, column): entries of column j inside panel p form the segment
     // colptr[p*H + j] .. colptr[p*H + j + 1].  A panel is kPanelRows consecutive rows of the augmented
     // matrix, so the rows gathered while a panel is processed stay L2-resident.
+    int32_t panel_rows = 8192;       // fixed when the counts are uploaded
     int32_t P_o = 0;                 // panels covering the original rows [0, N)
     int32_t p_s0 = 0, P_s = 0;       // first panel touched by synthetic rows, number of such panels
 

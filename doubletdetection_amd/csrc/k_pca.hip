@@ -20,6 +20,8 @@ namespace ddx {
 
 constexpr int kMaxL = 64;   // sketch width limit (n_components + n_oversamples)
 
+constexpr int kGatherDepth = 4;   // gathers in flight per lane and trip
+
 typedef double d2v __attribute__((ext_vector_type(2)));
 typedef float f4v __attribute__((ext_vector_type(4)));
 
@@ -75,11 +77,11 @@ __global__ void __launch_bounds__(256) k_spmm_rows(const int64_t* __restrict__ i
             d = (double)x[p] - (double)zcol[j];
         }
         const int cnt = (int)((e - base) < 64 ? (e - base) : 64);
-        for (int t0 = 0; t0 < cnt; t0 += 4 * slots) {
-            int32_t jj[4];
-            double dd[4];
+        for (int t0 = 0; t0 < cnt; t0 += kGatherDepth * slots) {
+            int32_t jj[kGatherDepth];
+            double dd[kGatherDepth];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < kGatherDepth; ++u) {
                 const int tt = t0 + u * slots + slot;
                 const int src = tt < 64 ? tt : 63;
                 jj[u] = __shfl(j, src, 64);
@@ -87,11 +89,11 @@ __global__ void __launch_bounds__(256) k_spmm_rows(const int64_t* __restrict__ i
                 if (tt >= cnt) { dd[u] = 0.0; jj[u] = 0; }
             }
             if (active) {
-                double qv[4][VW];
+                double qv[kGatherDepth][VW];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) Gather<T>::load(Q + (int64_t)jj[u] * ld + c0, qv[u]);
+                for (int u = 0; u < kGatherDepth; ++u) Gather<T>::load(Q + (int64_t)jj[u] * ld + c0, qv[u]);
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
+                for (int u = 0; u < kGatherDepth; ++u)
 #pragma unroll
                     for (int c = 0; c < VW; ++c) acc[c] = fma(dd[u], qv[u][c], acc[c]);
             }
@@ -110,7 +112,7 @@ __global__ void __launch_bounds__(256) k_spmm_rows(const int64_t* __restrict__ i
 // SpMM over columns:  W[j,:] = sum_i (x_ij - z_j) Y[i,:] - m_j u[:]     (A^T Y, u = 1^T Y)
 // The mirror is ordered by (row panel, column).  One wave owns one (panel, column) segment and
 // accumulates  Wp[panel][j][:] = sum_{i in panel} (x_ij - z_j) Y[i,:] ; a second tiny kernel adds the
-// panels in order.  Only the rows of one panel (kPanelRows x L x 8 B ~ 2.6 MB) are gathered while a
+// panels in order.  Only the rows of one panel (panel_rows x L x 4 or 8 B ~ 2.6 MB) are gathered while a
 // panel is processed, and all blocks of a panel are placed on the same XCD (block b runs on XCD b % 8),
 // so those gathers are served by that XCD's 4 MB L2 instead of the Infinity Cache.
 // ------------------------------------------------------------------------------------------------
@@ -162,11 +164,11 @@ __global__ void __launch_bounds__(256) k_spmm_cols(const int64_t* __restrict__ c
                 d = (double)x[p] - z;
             }
             const int cnt = (int)((hi - base) < 64 ? (hi - base) : 64);
-            for (int t0 = 0; t0 < cnt; t0 += 4 * slots) {
-                int32_t ii[4];
-                double dd[4];
+            for (int t0 = 0; t0 < cnt; t0 += kGatherDepth * slots) {
+                int32_t ii[kGatherDepth];
+                double dd[kGatherDepth];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < kGatherDepth; ++u) {
                     const int tt = t0 + u * slots + slot;
                     const int src = tt < 64 ? tt : 63;
                     ii[u] = __shfl(i, src, 64);
@@ -174,11 +176,11 @@ __global__ void __launch_bounds__(256) k_spmm_cols(const int64_t* __restrict__ c
                     if (tt >= cnt) { dd[u] = 0.0; ii[u] = 0; }
                 }
                 if (active) {
-                    double yv[4][VW];
+                    double yv[kGatherDepth][VW];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) Gather<T>::load(Yin + (int64_t)ii[u] * ld + c0, yv[u]);
+                    for (int u = 0; u < kGatherDepth; ++u) Gather<T>::load(Yin + (int64_t)ii[u] * ld + c0, yv[u]);
 #pragma unroll
-                    for (int u = 0; u < 4; ++u)
+                    for (int u = 0; u < kGatherDepth; ++u)
 #pragma unroll
                         for (int c = 0; c < VW; ++c) acc[c] = fma(dd[u], yv[u][c], acc[c]);
                 }
@@ -464,7 +466,7 @@ static int apply_cols(PcaWork& w, const double* Yrow, double* Wcol) {  // A^T Y 
         ScopedTimer t(c, "pca_colsum");
         wcolsum(w, Yrow, w.M, nullptr, uvec);
     }
-    const int P = (int)ceil_div(w.M, kPanelRows);
+    const int P = (int)ceil_div(w.M, c->panel_rows);
     const int groups = (w.H + 3) / 4;
     const int64_t grid = 8 * ceil_div(P, 8) * groups;
     ScopedTimer t(c, "spmm_cols");
@@ -502,7 +504,7 @@ int stage_pca(ddx_ctx* ctx, int32_t C, int32_t oversample, int32_t n_iter, const
     DDX_TRY(ensure(ctx, ctx->pcaSmall, sizeof(double) * (4 * L * L + 4 * L) + 256));
     DDX_TRY(ensure(ctx, ctx->pcaPartial, sizeof(double) * 512 * (size_t)std::max(L * L, 128)));
     DDX_TRY(ensure(ctx, ctx->pcaVec, 256));
-    DDX_TRY(ensure(ctx, ctx->pcaPanel, sizeof(double) * (size_t)ceil_div(M, kPanelRows) * H * L));
+    DDX_TRY(ensure(ctx, ctx->pcaPanel, sizeof(double) * (size_t)ceil_div(M, ctx->panel_rows) * H * L));
     DDX_TRY(ensure(ctx, ctx->emb64, sizeof(double) * (size_t)M * C));
     DDX_TRY(ensure(ctx, ctx->emb32, sizeof(float) * (size_t)M * C));
     DDX_TRY(ensure(ctx, ctx->sing, sizeof(double) * L));
@@ -519,8 +521,7 @@ int stage_pca(ddx_ctx* ctx, int32_t C, int32_t oversample, int32_t n_iter, const
     {
         // DDX_PCA_GATHER=f64 gathers the float64 iterates themselves; the default gathers a float32-rounded
         // copy (float64 products and sums), which moves half the bytes through L2
-        const char* g = getenv("DDX_PCA_GATHER");
-        w.gather32 = !(g && (g[0] == 'f' || g[0] == 'F') && g[1] == '6');
+        w.gather32 = pca_gather_f32();
     }
     const int64_t maxR = M > H ? M : (int64_t)H;
     DDX_TRY(ensure(ctx, ctx->pcaOp, sizeof(double) * (size_t)maxR * (L + 4)));

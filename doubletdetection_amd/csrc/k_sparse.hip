@@ -243,13 +243,13 @@ __global__ void k_iota_u32(uint32_t* out, int64_t n, uint32_t base) {
 
 // sort key of every stored entry of rows [row_lo, row_lo+nrows): (panel(row) - panel0) * H + column
 __global__ void __launch_bounds__(256) k_panel_keys(const int64_t* __restrict__ indptr, const int32_t* __restrict__ cols,
-                                                    int64_t row_lo, int64_t nrows, int32_t H, int32_t panel0, int64_t e0,
-                                                    int32_t* __restrict__ keys) {
+                                                    int64_t row_lo, int64_t nrows, int32_t H, int32_t panel0, int32_t panel_rows,
+                                                    int64_t e0, int32_t* __restrict__ keys) {
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (r >= nrows) return;
     const int64_t row = row_lo + r;
-    const int32_t base = ((int32_t)(row / kPanelRows) - panel0) * H;
+    const int32_t base = ((int32_t)(row / panel_rows) - panel0) * H;
     for (int64_t p = indptr[row] + lane; p < indptr[row + 1]; p += 64) keys[p - e0] = base + cols[p];
 }
 
@@ -301,7 +301,7 @@ static int build_csc(ddx_ctx* ctx, int64_t e0, int64_t n, int64_t row_lo, int64_
     DDX_TRY(ensure(ctx, ctx->sort_vals_out, sizeof(uint32_t) * n));
     k_iota_u32<<<(unsigned)ceil_div(n, 256), 256, 0, ctx->stream>>>(ctx->sort_vals_in.as<uint32_t>(), n, (uint32_t)e0);
     k_panel_keys<<<(unsigned)ceil_div(row_hi - row_lo, 4), 256, 0, ctx->stream>>>(ctx->aug_indptr.as<int64_t>(), ctx->aug_indices.as<int32_t>(),
-                                                                                 row_lo, row_hi - row_lo, H, panel0, e0,
+                                                                                 row_lo, row_hi - row_lo, H, panel0, ctx->panel_rows, e0,
                                                                                  ctx->sort_keys_in.as<int32_t>());
     int end_bit = 1;
     while (((int64_t)1 << end_bit) < nkeys64) ++end_bit;
@@ -385,7 +385,8 @@ int stage_upload_counts(ddx_ctx* ctx, int64_t N, int32_t H, const int64_t* indpt
     DDX_TRY(ensure(ctx, ctx->csc_o_row, sizeof(int32_t) * (size_t)(nnz + 1)));
     DDX_TRY(ensure(ctx, ctx->csc_o_raw, sizeof(float) * (size_t)(nnz + 1)));
     DDX_TRY(ensure(ctx, ctx->csc_o_x, sizeof(float) * (size_t)(nnz + 1)));
-    ctx->P_o = (int32_t)ceil_div(N, kPanelRows);
+    ctx->panel_rows = 4096;   // measured optimum on MI355X (8192: +19 %, 2048: +5 % on the A^T Y pass)
+    ctx->P_o = (int32_t)ceil_div(N, ctx->panel_rows);
     DDX_TRY(build_csc(ctx, 0, nnz, 0, N, 0, ctx->P_o, ctx->csc_o_colptr, ctx->csc_o_row, ctx->csc_o_raw));
     DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->have_counts = true;
@@ -562,8 +563,8 @@ int stage_lognormalise(ddx_ctx* ctx, float pseudocount) {
         k_median_from_sorted<<<1, 64, 0, ctx->stream>>>(ctx->lib_sorted.as<float>(), M, ctx->median.as<float>());
     }
     // column-major mirror of the synthetic rows
-    ctx->p_s0 = (int32_t)(N / kPanelRows);
-    ctx->P_s = S ? (int32_t)((M - 1) / kPanelRows) - ctx->p_s0 + 1 : 0;
+    ctx->p_s0 = (int32_t)(N / ctx->panel_rows);
+    ctx->P_s = S ? (int32_t)((M - 1) / ctx->panel_rows) - ctx->p_s0 + 1 : 0;
     DDX_TRY(build_csc(ctx, ctx->nnz, nnz_s, N, M, ctx->p_s0, ctx->P_s > 0 ? ctx->P_s : 1, ctx->csc_s_colptr, ctx->csc_s_row, ctx->csc_s_raw));
     const int use_log1p = (pseudocount == 1.0f);
     {
