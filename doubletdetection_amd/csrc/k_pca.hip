@@ -246,12 +246,15 @@ __global__ void __launch_bounds__(256) k_wcolsum_partial(const double* __restric
     }
 }
 
-__global__ void k_reduce_partials(const double* __restrict__ partial, int nblocks, int width, double* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+// out[c] = sum_b partial[b][c]: one wave per output; lanes take interleaved blocks, then a fixed butterfly
+__global__ void __launch_bounds__(256) k_reduce_partials(const double* __restrict__ partial, int nblocks, int width, double* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (c >= width) return;
     double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += partial[(int64_t)b * width + c];
-    out[c] = s;
+    for (int b = lane; b < nblocks; b += 64) s += partial[(int64_t)b * width + c];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (lane == 0) out[c] = s;
 }
 
 // partial Gram: G_b = X_b^T X_b for a block of rows, staged through LDS in 32-row tiles
@@ -290,6 +293,8 @@ __global__ void __launch_bounds__(256) k_gram_partial(const double* __restrict__
 }
 
 // single wave: G (L x L, symmetric positive definite) -> Rinv with G = R^T R, R upper triangular.
+// Lane j owns column j of the upper triangle (L <= 64); row k is normalised, then every lane updates its
+// own column below row k -- no cross-lane writes, one wave barrier per step.
 // flag[0] |= 1 when a pivot had to be floored (rank-deficient sketch).
 __global__ void __launch_bounds__(64) k_chol_inv(const double* __restrict__ G, int L, double* __restrict__ Rinv,
                                                  int* __restrict__ flag) {
@@ -303,19 +308,22 @@ __global__ void __launch_bounds__(64) k_chol_inv(const double* __restrict__ G, i
     for (int k = 0; k < L; ++k) maxd = fmax(maxd, a[k * L + k]);
     const double floor_v = maxd * 1e-26 + 1e-300;
     for (int k = 0; k < L; ++k) {
-        if (lane == 0) {
-            double d = a[k * L + k];
-            if (!(d > floor_v)) { d = floor_v; atomicOr(flag, 1); }
-            a[k * L + k] = sqrt(d);
+        double d = a[k * L + k];
+        if (!(d > floor_v)) {
+            d = floor_v;
+            if (lane == 0) atomicOr(flag, 1);
+        }
+        const double piv = sqrt(d);
+        __syncthreads();                       // everyone has read a[k][k] before it is overwritten
+        if (lane == k) a[k * L + k] = piv;
+        if (lane > k && lane < L) {
+            const double r = a[k * L + lane] / piv;      // R[k][lane]
+            a[k * L + lane] = r;
         }
         __syncthreads();
-        const double piv = a[k * L + k];
-        for (int jx = k + 1 + lane; jx < L; jx += 64) a[k * L + jx] /= piv;
-        __syncthreads();
-        const int rem = L - k - 1;
-        for (int t = lane; t < rem * rem; t += 64) {
-            const int i = k + 1 + t / rem, jx = k + 1 + t % rem;
-            if (jx >= i) a[i * L + jx] -= a[k * L + i] * a[k * L + jx];
+        if (lane > k && lane < L) {
+            const double r = a[k * L + lane];
+            for (int i = k + 1; i <= lane; ++i) a[i * L + lane] -= a[k * L + i] * r;
         }
         __syncthreads();
     }
@@ -403,7 +411,7 @@ static int wcolsum(PcaWork& w, const double* X, int64_t R, const double* wgt, do
     int64_t rpb = ceil_div(R, nb);
     nb = (int)ceil_div(R, rpb);
     k_wcolsum_partial<<<nb, 256, 0, w.ctx->stream>>>(X, R, w.L, wgt, rpb, w.partial);
-    k_reduce_partials<<<1, 128, 0, w.ctx->stream>>>(w.partial, nb, w.L, out);
+    k_reduce_partials<<<(unsigned)ceil_div(w.L, 4), 256, 0, w.ctx->stream>>>(w.partial, nb, w.L, out);
     return DDX_OK;
 }
 
@@ -413,7 +421,7 @@ static int gram(PcaWork& w, const double* X, int64_t R, double* G) {
     nb = (int)ceil_div(R, rpb);
     const int LL = w.L * w.L;
     k_gram_partial<<<nb, 256, sizeof(double) * 32 * w.L, w.ctx->stream>>>(X, R, w.L, rpb, w.partial);
-    k_reduce_partials<<<(unsigned)ceil_div(LL, 128), 128, 0, w.ctx->stream>>>(w.partial, nb, LL, G);
+    k_reduce_partials<<<(unsigned)ceil_div(LL, 4), 256, 0, w.ctx->stream>>>(w.partial, nb, LL, G);
     return DDX_OK;
 }
 

@@ -313,3 +313,50 @@ def test_reference_test_suite_scenario():
     np.testing.assert_equal(s[0], s[1])
     assert clf.all_log_p_values_.shape == (2, 500) and clf.communities_.shape == (2, 500)
     assert clf.synth_communities_.shape == (2, 125)
+
+
+# ---- API corners on the GPU path ---------------------------------------------------------------------------
+def test_api_corners_on_gpu(capsys):
+    from doubletdetection_amd import BoostClassifier
+
+    rng = np.random.default_rng(5)
+    dense = rng.poisson(0.8, size=(700, 150)).astype(np.int64)        # dense ndarray input is sparsified (dd.py:157-160)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        # single iteration: score-gap predict, bool labels, suggested cutoff (dd.py:243-252)
+        one = BoostClassifier(n_iters=1, clustering_kwargs={"prune": False}, verbose=True).fit(dense)
+        lab = one.predict()
+        assert lab.dtype == bool and hasattr(one, "suggested_score_cutoff_")
+        assert one.doublet_score().shape == (700,)
+        out = capsys.readouterr().out
+        assert "Sparsifying matrix." in out and "Iteration   1/1" in out and "Found clusters" in out
+        # replace=True with boost_rate > 0.5, odd sketch width (n_components=25 -> 35 columns), louvain + scaling
+        many = BoostClassifier(n_iters=2, replace=True, boost_rate=0.8, n_components=25, clustering_algorithm="louvain",
+                               standard_scaling=True, random_state=3).fit(sp.csr_matrix(dense))
+        ref = orc.OracleClassifier(n_iters=2, replace=True, boost_rate=0.8, n_components=25, clustering_algorithm="louvain",
+                                   standard_scaling=True, random_state=3, pca="f64").fit(sp.csr_matrix(dense))
+    assert many.synth_communities_.shape == (2, 560)
+    np.testing.assert_array_equal(np.asarray(many.parents_), np.asarray(ref.parents_))
+    np.testing.assert_array_equal(many.communities_, ref.communities_)
+    np.testing.assert_array_equal(many.all_scores_, ref.all_scores_)
+    # sparse input in another format / dtype is coerced like check_array does
+    again = None
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        again = BoostClassifier(n_iters=2, replace=True, boost_rate=0.8, n_components=25, clustering_algorithm="louvain",
+                                standard_scaling=True, random_state=3).fit(sp.csc_matrix(dense.astype(np.float64)))
+    np.testing.assert_array_equal(again.all_log_p_values_, many.all_log_p_values_)
+
+
+def test_unsupported_regimes_raise_clearly():
+    from doubletdetection_amd import BoostClassifier
+
+    rng = np.random.default_rng(6)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        with pytest.raises(NotImplementedError, match="covariance_eigh"):
+            BoostClassifier(n_iters=2, clustering_algorithm="louvain").fit(rng.poisson(1.0, size=(5000, 60)))
+        with pytest.raises(NotImplementedError, match="full"):
+            BoostClassifier(n_iters=2, clustering_algorithm="louvain").fit(rng.poisson(1.0, size=(300, 100)))
+        with pytest.raises(NotImplementedError, match="pseudocount=1"):
+            BoostClassifier(n_iters=2, pseudocount=1).fit(rng.poisson(1.0, size=(600, 100)))
