@@ -54,6 +54,7 @@ _SIGNATURES = {
     "ddx_get_aug_dense_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, c_f32_p]),
     "ddx_scale": (C.c_int, [C.c_void_p, C.c_float]),
     "ddx_pca": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, c_f64_p, C.c_int64]),
+    "ddx_operator_apply": (C.c_int, [C.c_void_p, C.c_int32, c_f64_p, C.c_int32, c_f64_p]),
     "ddx_get_embedding": (C.c_int, [C.c_void_p, c_f32_p]),
     "ddx_get_embedding_f64": (C.c_int, [C.c_void_p, c_f64_p, c_f64_p]),
     "ddx_set_embedding": (C.c_int, [C.c_void_p, c_f32_p, C.c_int64, C.c_int32]),
@@ -314,6 +315,16 @@ class Context:
         self._c(self._lib.ddx_pca(self._h, int(n_components), int(n_oversamples), int(n_iter), _p(q0, c_f64_p), q0.shape[0]))
         self._C = int(n_components)
         self._embM = self.M
+
+    def operator_apply(self, X, mode: int):
+        """Products with the centred matrix A held by the context (include/ddx.h: ddx_operator_apply):
+        mode 0: A @ X, 1: A.T @ X, 2: A.T @ (A @ X), 3: A @ (A.T @ X)."""
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        n = X.shape[1]
+        rows_out = self.M if mode in (0, 3) else self.H
+        out = np.empty((rows_out, n), dtype=np.float64)
+        self._c(self._lib.ddx_operator_apply(self._h, int(mode), _p(X, c_f64_p), n, _p(out, c_f64_p)))
+        return out
 
     def embedding(self):
         out = np.empty((self._embM, self._C), dtype=np.float32)

@@ -114,9 +114,44 @@ class _HipEngine:
         c.lognormalise(pseudocount)
         if standard_scaling:
             c.scale(15.0)
-        c.pca(n_components, q0)
+        if q0 is None:
+            self._pca_exact(n_components)
+        else:
+            c.pca(n_components, q0)
         c.knn(knn_k, include_self)
         return c.build_graph(graph_mode)      # symmetric CSR assembled on the device
+
+    def _pca_exact(self, n_components, block=40):
+        """sklearn's exact regimes ("full" / "covariance_eigh"): eigen-decomposition of the smaller Gram
+        matrix of the centred operator, built block-wise on the device; scores = A V (= U S), sign fixed on
+        the component rows as svd_flip(u_based_decision=False) does."""
+        c = self.ctx
+        M, H = c.M, c.H
+        small, mode = (H, 2) if H <= M else (M, 3)
+        gram = np.empty((small, small))
+        for j0 in range(0, small, block):
+            n = min(block, small - j0)
+            unit = np.zeros((small, n))
+            unit[j0 + np.arange(n), np.arange(n)] = 1.0
+            gram[:, j0:j0 + n] = c.operator_apply(unit, mode)
+        gram = 0.5 * (gram + gram.T)
+        evals, evecs = np.linalg.eigh(gram)
+        top = np.argsort(evals)[::-1][:n_components]
+        sing = np.sqrt(np.maximum(evals[top], 0.0))
+        if H <= M:
+            comps = evecs[:, top]                                   # H x C: right singular vectors
+            scores = None
+        else:
+            left = evecs[:, top]                                    # M x C: left singular vectors
+            comps = c.operator_apply(left, 1) / np.where(sing > 0, sing, 1.0)
+            scores = left * sing
+        pick = np.argmax(np.abs(comps), axis=0)
+        signs = np.sign(comps[pick, np.arange(comps.shape[1])])
+        if scores is None:
+            scores = c.operator_apply(comps * signs, 0)
+        else:
+            scores = scores * signs
+        c.set_embedding(scores.astype(np.float32))
 
     def timings(self):
         return self.ctx.timings()
@@ -366,12 +401,15 @@ class BoostClassifier:
 
         M = num_cells + num_synths
         n_comp = self.n_components
-        self._check_pca_regime(M, self._num_genes, n_comp)
-        sketch = n_comp + 10
-        q0_rows = self._num_genes if M >= self._num_genes else M
-        # sklearn draws the start matrix from the legacy RandomState and casts it to the data dtype
-        q0 = np.random.RandomState(self.random_state).normal(size=(q0_rows, sketch))
-        q0 = q0.astype(np.float32).astype(np.float64)
+        regime = self._pca_regime(M, self._num_genes, n_comp)
+        if regime == "randomized":
+            sketch = n_comp + 10
+            q0_rows = self._num_genes if M >= self._num_genes else M
+            # sklearn draws the start matrix from the legacy RandomState and casts it to the data dtype
+            q0 = np.random.RandomState(self.random_state).normal(size=(q0_rows, sketch))
+            q0 = q0.astype(np.float32).astype(np.float64)
+        else:
+            q0 = None      # exact regime: no random start (engine builds and diagonalises the Gram matrix)
 
         knn_k, include_self, graph_mode, gamma, seed, min_cluster_size = self._cluster_plan()
 
@@ -440,9 +478,8 @@ class BoostClassifier:
         self._parents_lists = value
 
     @staticmethod
-    def _check_pca_regime(M, H, n_comp):
-        """sklearn's svd_solver='auto' policy (sklearn/decomposition/_pca.py:524-536): the GPU path
-        implements the randomized branch, which every realistic data set selects."""
+    def _pca_regime(M, H, n_comp):
+        """sklearn's svd_solver='auto' policy for a dense M x H array (sklearn/decomposition/_pca.py:524-536)."""
         if not 1 <= n_comp <= min(M, H):
             raise ValueError(f"n_components={n_comp} must be between 1 and min(n_samples, n_features)={min(M, H)}")
         if H <= 1000 and M >= 10 * H:
@@ -453,11 +490,11 @@ class BoostClassifier:
             regime = "randomized"
         else:
             regime = "full"
-        if regime != "randomized":
+        if regime != "randomized" and min(M, H) > 4096:
             raise NotImplementedError(
-                f"for a {M}x{H} matrix with n_components={n_comp} scikit-learn selects its exact '{regime}' "
-                "PCA; only the randomized solver (max(shape) > 500, more than 1000 genes or fewer than 10 "
-                "cells per gene, n_components < 0.8*min(shape)) is implemented on the GPU")
+                f"scikit-learn selects its exact '{regime}' PCA for a {M}x{H} matrix with n_components={n_comp}; "
+                "the GPU path diagonalises the smaller Gram matrix on the host and supports min(shape) <= 4096 there")
+        return regime
 
     def _gather_rows(self, local, mine, n_iters, num_cells, num_synths, rank, world, backend, device):
         """Single collective: every rank contributes [full | scores | logp] rows of its iterations."""

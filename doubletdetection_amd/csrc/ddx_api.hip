@@ -393,6 +393,15 @@ int ddx_pca(ddx_ctx* ctx, int32_t n_components, int32_t n_oversamples, int32_t n
     return stage_pca(ctx, n_components, n_oversamples, n_iter, q0, q0_rows);
 }
 
+int ddx_operator_apply(ddx_ctx* ctx, int32_t transpose, const double* X, int32_t n, double* out) {
+    REQUIRE_CTX(ctx);
+    USE_DEVICE(ctx);
+    NEED(ctx->have_lognorm, "ddx_lognormalise must run first");
+    NEED(X && out, "null buffer");
+    NEED(n >= 1 && n <= 64, "n must be in [1,64]");
+    return stage_operator_apply(ctx, transpose, X, n, out);
+}
+
 int ddx_get_embedding(ddx_ctx* ctx, float* emb_out) {
     REQUIRE_CTX(ctx);
     USE_DEVICE(ctx);

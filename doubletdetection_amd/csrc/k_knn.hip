@@ -118,10 +118,12 @@ struct QueryTiles {
     __device__ __forceinline__ void dots(const float* b, f4 (&acc)[RT]) const {
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) acc[rt] = f4{0.f, 0.f, 0.f, 0.f};
+        __builtin_amdgcn_s_setprio(1);     // keep the matrix pipe fed while co-resident waves do their compares
 #pragma unroll
         for (int s = 0; s < KS; ++s)
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][s], b[s], acc[rt], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
     }
 };
 

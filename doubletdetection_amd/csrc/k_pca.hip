@@ -496,6 +496,64 @@ static int apply_cols(PcaWork& w, const double* Yrow, double* Wcol) {  // A^T Y 
     return DDX_OK;
 }
 
+static int pca_work_init(ddx_ctx* ctx, int L, PcaWork& w) {
+    const int64_t M = ctx->M;
+    const int32_t H = ctx->H;
+    DDX_TRY(ensure(ctx, ctx->pcaSmall, sizeof(double) * (4 * L * L + 4 * L) + 256));
+    DDX_TRY(ensure(ctx, ctx->pcaPartial, sizeof(double) * 512 * (size_t)std::max(L * L, 128)));
+    DDX_TRY(ensure(ctx, ctx->pcaVec, 256));
+    DDX_TRY(ensure(ctx, ctx->pcaPanel, sizeof(double) * (size_t)ceil_div(M, ctx->panel_rows) * H * L));
+    w.ctx = ctx;
+    w.L = L;
+    w.lpn = (L + 1) / 2;
+    w.slots = 64 / w.lpn;
+    w.M = M;
+    w.H = H;
+    w.partial = ctx->pcaPartial.as<double>();
+    w.small = ctx->pcaSmall.as<double>();
+    w.flag = ctx->pcaVec.as<int>();
+    w.gather32 = pca_gather_f32();
+    const int64_t maxR = M > H ? M : (int64_t)H;
+    DDX_TRY(ensure(ctx, ctx->pcaOp, sizeof(double) * (size_t)maxR * (L + 4)));
+    w.op32 = ctx->pcaOp.as<float>();
+    return DDX_OK;
+}
+
+// mode 0: out[M x n] = A X        (X: H x n)        mode 2: out[H x n] = A^T (A X)   (X: H x n)
+// mode 1: out[H x n] = A^T X      (X: M x n)        mode 3: out[M x n] = A (A^T X)   (X: M x n)
+// for a caller-supplied block of n <= 64 vectors.  Always gathers float64: this entry point serves the
+// exact-PCA regimes, where the Gram matrix is formed column block by column block.
+int stage_operator_apply(ddx_ctx* ctx, int32_t mode, const double* X, int32_t n, double* out) {
+    ctx->g_nodes = -1;
+    const int64_t M = ctx->M;
+    const int32_t H = ctx->H;
+    PcaWork w;
+    DDX_TRY(pca_work_init(ctx, n, w));
+    w.gather32 = false;
+    DDX_TRY(ensure(ctx, ctx->pcaA, sizeof(double) * 2 * (size_t)M * n));
+    DDX_TRY(ensure(ctx, ctx->pcaB, sizeof(double) * 2 * (size_t)H * n));
+    double* rowA = ctx->pcaA.as<double>();
+    double* rowB = rowA + (size_t)M * n;
+    double* colA = ctx->pcaB.as<double>();
+    double* colB = colA + (size_t)H * n;
+    const bool in_rows = (mode == 1 || mode == 3);        // input lives on the row side (M x n)
+    const bool out_rows = (mode == 0 || mode == 3);
+    double* in_d = in_rows ? rowA : colA;
+    DDX_HIP(ctx, hipMemcpyAsync(in_d, X, sizeof(double) * (size_t)(in_rows ? M : (int64_t)H) * n, hipMemcpyHostToDevice, ctx->stream));
+    double* res = nullptr;
+    switch (mode) {
+        case 0: apply_rows(w, colA, rowA); res = rowA; break;
+        case 1: apply_cols(w, rowA, colA); res = colA; break;
+        case 2: apply_rows(w, colA, rowA); apply_cols(w, rowA, colB); res = colB; break;
+        case 3: apply_cols(w, rowA, colA); apply_rows(w, colA, rowB); res = rowB; break;
+        default: return set_err(ctx, DDX_E_ARG, "operator mode must be 0..3");
+    }
+    DDX_HIP(ctx, hipMemcpyAsync(out, res, sizeof(double) * (size_t)(out_rows ? M : (int64_t)H) * n, hipMemcpyDeviceToHost, ctx->stream));
+    DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    DDX_HIP(ctx, hipGetLastError());
+    return DDX_OK;
+}
+
 int stage_pca(ddx_ctx* ctx, int32_t C, int32_t oversample, int32_t n_iter, const double* q0, int64_t q0_rows) {
     ctx->g_nodes = -1;   // a graph left on the device lives in the panel buffer this stage overwrites
     const int L = C + oversample;

@@ -108,6 +108,14 @@ int ddx_scale(ddx_ctx* ctx, float max_value);
  * Produces the M x C float32 embedding (U*S, sign-fixed on the components) on the device. */
 int ddx_pca(ddx_ctx* ctx, int32_t n_components, int32_t n_oversamples, int32_t n_iter,
             const double* q0, int64_t q0_rows);
+/* The centred operator itself, for sklearn's exact regimes (svd_solver "full" / "covariance_eigh", chosen by
+ * PCA(svd_solver="auto") for small inputs, sklearn/decomposition/_pca.py:524-536): the host builds the
+ * small Gram matrix from products with unit vectors, takes its eigen-decomposition and projects.
+ *   mode 0: out[M x n] = A X          (X is H x n, row-major float64)
+ *   mode 1: out[H x n] = A^T X        (X is M x n)
+ *   mode 2: out[H x n] = A^T (A X)    (X is H x n)   -- a column block of the H x H Gram matrix
+ *   mode 3: out[M x n] = A (A^T X)    (X is M x n)   -- a column block of the M x M Gram matrix     1 <= n <= 64 */
+int ddx_operator_apply(ddx_ctx* ctx, int32_t mode, const double* X, int32_t n, double* out);
 int ddx_get_embedding(ddx_ctx* ctx, float* emb_out /* [M*C] row-major */);
 int ddx_get_embedding_f64(ddx_ctx* ctx, double* emb_out /* [M*C] */, double* singular_values /* [C] */);
 /* stage isolation: feed an embedding computed elsewhere to the kNN stage */

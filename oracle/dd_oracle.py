@@ -245,6 +245,26 @@ def randomized_pca_f64(X: np.ndarray, n_comps: int, seed: int, round_q0_f32: boo
     return U * s[None, :], s, Vt
 
 
+def exact_pca_f64(X: np.ndarray, n_comps: int):
+    """sklearn's exact regimes ("full": LAPACK SVD of the centred matrix; "covariance_eigh": eigh of the
+    covariance) in float64: scores = U S with the v-based sign flip (sklearn/decomposition/_pca.py:
+    _fit_full + svd_flip(u_based_decision=False))."""
+    A = np.asarray(X, dtype=np.float64)
+    A = A - A.mean(axis=0)
+    U, s, Vt = np.linalg.svd(A, full_matrices=False)
+    U, s, Vt = U[:, :n_comps], s[:n_comps], Vt[:n_comps]
+    idx = np.argmax(np.abs(Vt), axis=1)
+    signs = np.sign(Vt[np.arange(Vt.shape[0]), idx])
+    return U * signs[None, :] * s[None, :], s, Vt * signs[:, None]
+
+
+def pca_f64(X: np.ndarray, n_comps: int, seed: int):
+    """Float64 evaluation of whatever PCA(svd_solver="auto") selects for X."""
+    if sklearn_solver_policy(X.shape[0], X.shape[1], n_comps) == "randomized":
+        return randomized_pca_f64(X, n_comps, seed)
+    return exact_pca_f64(X, n_comps)
+
+
 def per_component_rel_dev(a: np.ndarray, b: np.ndarray) -> np.ndarray:
     """||a[:, c] - b[:, c]|| / ||b[:, c]|| per PCA component (the H3 acceptance metric)."""
     a = np.asarray(a, dtype=np.float64)
@@ -526,7 +546,7 @@ class OracleClassifier:
             if self.pca == "sklearn":
                 emb = pca_sklearn(aug, self.n_components, self.random_state).astype(np.float32)
             else:
-                emb = randomized_pca_f64(aug, self.n_components, self.random_state)[0].astype(np.float32)
+                emb = pca_f64(aug, self.n_components, self.random_state)[0].astype(np.float32)
             t3 = time.perf_counter()
             full = cluster_embedding(emb, self.clustering_algorithm, self.clustering_kwargs,
                                      self.random_state, self.louvain_fn, self.knn_fn)

@@ -33,7 +33,7 @@ class OracleEngine:
         if standard_scaling:
             aug = orc.scale_like_scanpy(aug, 15)
         # the product passes the start matrix it drew; the oracle draws the same one from the seed
-        emb = orc.randomized_pca_f64(aug, n_components, self.seed)[0].astype(np.float32)
+        emb = orc.pca_f64(aug, n_components, self.seed)[0].astype(np.float32)
         idx, _ = orc.knn_bruteforce_f64(emb, knn_k, include_self)
         if graph_mode == 2:
             G = orc.union_knn_graph(idx)

@@ -348,15 +348,36 @@ def test_api_corners_on_gpu(capsys):
     np.testing.assert_array_equal(again.all_log_p_values_, many.all_log_p_values_)
 
 
+@pytest.mark.parametrize("shape,regime", [((5000, 60), "covariance_eigh"), ((300, 100), "full"), ((120, 400), "full")])
+def test_exact_pca_regimes(shape, regime):
+    """Small inputs for which PCA(svd_solver="auto") takes an exact solver: scores vs sklearn in float64,
+    and the whole fit vs the oracle."""
+    from doubletdetection_amd import BoostClassifier
+
+    counts = np.random.default_rng(9).poisson(1.0, size=shape)
+    n_comp = 30 if min(shape) > 40 else 20
+    kw = dict(n_iters=2, clustering_algorithm="louvain", n_components=n_comp, random_state=4)
+    S = int(0.25 * shape[0])
+    assert orc.sklearn_solver_policy(shape[0] + S, shape[1], n_comp) == regime
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        clf = BoostClassifier(**kw).fit(counts)
+        ref = orc.OracleClassifier(pca="f64", **kw).fit(counts)
+        skl = orc.OracleClassifier(pca="sklearn", **kw).fit(counts)     # what the reference would run (float32)
+    np.testing.assert_array_equal(clf.communities_, ref.communities_)
+    np.testing.assert_array_equal(clf.all_scores_, ref.all_scores_)
+    # the oracle's float64 exact PCA against sklearn's own float32 run: singular values (= column norms of
+    # U S); individual components of pure-noise data are near-degenerate and not comparable one by one
+    sv_ref = np.linalg.norm(ref.embeddings_[0].astype(np.float64), axis=0)
+    sv_skl = np.linalg.norm(skl.embeddings_[0].astype(np.float64), axis=0)
+    np.testing.assert_allclose(sv_ref, sv_skl, rtol=1e-4)
+
+
 def test_unsupported_regimes_raise_clearly():
     from doubletdetection_amd import BoostClassifier
 
     rng = np.random.default_rng(6)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        with pytest.raises(NotImplementedError, match="covariance_eigh"):
-            BoostClassifier(n_iters=2, clustering_algorithm="louvain").fit(rng.poisson(1.0, size=(5000, 60)))
-        with pytest.raises(NotImplementedError, match="full"):
-            BoostClassifier(n_iters=2, clustering_algorithm="louvain").fit(rng.poisson(1.0, size=(300, 100)))
         with pytest.raises(NotImplementedError, match="pseudocount=1"):
             BoostClassifier(n_iters=2, pseudocount=1).fit(rng.poisson(1.0, size=(600, 100)))
