@@ -114,12 +114,34 @@ class _HipEngine:
         c.lognormalise(pseudocount)
         if standard_scaling:
             c.scale(15.0)
-        if q0 is None:
+        if isinstance(q0, str) and q0 == "arpack":
+            self._pca_arpack(n_components, self._arpack_seed)
+        elif q0 is None:
             self._pca_exact(n_components)
         else:
             c.pca(n_components, q0)
         c.knn(knn_k, include_self)
         return c.build_graph(graph_mode)      # symmetric CSR assembled on the device
+
+    def _pca_arpack(self, n_components, seed):
+        """pseudocount == 1 without scaling keeps the matrix sparse upstream and switches sc.tl.pca to
+        svd_solver="arpack" (dd.py:296-297,308): an implicitly-centred truncated SVD converged to machine
+        precision.  ARPACK's Lanczos recurrences run on the host (scipy, the very routine upstream uses);
+        every matrix-vector product is one SpMV on the device.  Start vector and sign convention as in
+        sklearn's PCA arpack branch (_init_arpack_v0, svd_flip(u_based_decision=False))."""
+        from scipy.sparse.linalg import LinearOperator, svds
+
+        c = self.ctx
+        M, H = c.M, c.H
+        op = LinearOperator((M, H), dtype=np.float64,
+                            matvec=lambda x: c.operator_apply(np.asarray(x, dtype=np.float64).reshape(H, 1), 0).ravel(),
+                            rmatvec=lambda y: c.operator_apply(np.asarray(y, dtype=np.float64).reshape(M, 1), 1).ravel())
+        v0 = np.random.RandomState(seed).uniform(-1, 1, size=min(M, H))
+        u, sv, vt = svds(op, k=n_components, tol=0.0, v0=v0, solver="arpack")
+        u, sv, vt = u[:, ::-1], sv[::-1], vt[::-1]
+        pick = np.argmax(np.abs(vt), axis=1)
+        signs = np.sign(vt[np.arange(vt.shape[0]), pick])
+        c.set_embedding((u * signs[None, :] * sv[None, :]).astype(np.float32))
 
     def _pca_exact(self, n_components, block=40):
         """sklearn's exact regimes ("full" / "covariance_eigh"): eigen-decomposition of the smaller Gram
@@ -304,11 +326,6 @@ class BoostClassifier:
             # upstream's custom-normalizer branch cannot complete either (it references variables that
             # only the default branch defines, doubletdetection.py:301,372 -> UnboundLocalError)
             raise NotImplementedError("a user `normalizer` callable cannot run on the GPU path; leave it None")
-        if self.pseudocount == 1:
-            raise NotImplementedError(
-                "pseudocount=1 selects upstream's sparse/ARPACK PCA (doubletdetection.py:296-297,308), "
-                "which the GPU path does not implement yet")
-
         rank, world, backend = _dist_info()
         staged = getattr(self, "_staged", None)
         if staged is not None and staged[0] is raw_counts:
@@ -401,8 +418,15 @@ class BoostClassifier:
 
         M = num_cells + num_synths
         n_comp = self.n_components
-        regime = self._pca_regime(M, self._num_genes, n_comp)
-        if regime == "randomized":
+        sparse_branch = self.pseudocount == 1 and not self.standard_scaling      # dd.py:296-297,308
+        regime = "arpack" if sparse_branch else self._pca_regime(M, self._num_genes, n_comp)
+        if regime == "arpack":
+            if not 1 <= n_comp < min(M, self._num_genes):
+                raise ValueError(f"n_components={n_comp} must be strictly less than min(n_samples, n_features)="
+                                 f"{min(M, self._num_genes)} with svd_solver='arpack'")
+            q0 = "arpack"
+            engine._arpack_seed = self.random_state
+        elif regime == "randomized":
             sketch = n_comp + 10
             q0_rows = self._num_genes if M >= self._num_genes else M
             # sklearn draws the start matrix from the legacy RandomState and casts it to the data dtype

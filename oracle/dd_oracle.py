@@ -538,12 +538,16 @@ class OracleClassifier:
             synth = create_doublets(raw, parents)
             t1 = time.perf_counter()
             aug, _, _ = lognormalise(normed, lib, synth, self.pseudocount)
-            if sp.issparse(aug):
-                raise NotImplementedError("pseudocount == 1 (sparse/ARPACK path) is not restated yet")
             if self.standard_scaling:
+                if sp.issparse(aug):
+                    aug = aug.toarray()             # scanpy densifies to zero-centre; PCA then sees a dense array
                 aug = scale_like_scanpy(aug, max_value=15)
             t2 = time.perf_counter()
-            if self.pca == "sklearn":
+            if sp.issparse(aug):
+                # dd.py:308: svd_solver="arpack" on the CSR matrix (sklearn centres implicitly)
+                emb = pca_sklearn(aug.astype(np.float32 if self.pca == "sklearn" else np.float64), self.n_components,
+                                  self.random_state, svd_solver="arpack").astype(np.float32)
+            elif self.pca == "sklearn":
                 emb = pca_sklearn(aug, self.n_components, self.random_state).astype(np.float32)
             else:
                 emb = pca_f64(aug, self.n_components, self.random_state)[0].astype(np.float32)

@@ -30,10 +30,17 @@ class OracleEngine:
     def run_iteration(self, parents, pseudocount, standard_scaling, n_components, q0, knn_k, include_self, graph_mode):
         synth = orc.create_doublets(self.raw, parents)
         aug, _, _ = orc.lognormalise(self.normed, self.lib, synth, pseudocount)
+        import scipy.sparse as sp
+
         if standard_scaling:
-            aug = orc.scale_like_scanpy(aug, 15)
+            aug = orc.scale_like_scanpy(aug.toarray() if sp.issparse(aug) else aug, 15)
+        if sp.issparse(aug):
+            emb = orc.pca_sklearn(aug.astype(np.float64), n_components, self.seed, svd_solver="arpack").astype(np.float32)
+        else:
+            emb = None
         # the product passes the start matrix it drew; the oracle draws the same one from the seed
-        emb = orc.pca_f64(aug, n_components, self.seed)[0].astype(np.float32)
+        if emb is None:
+            emb = orc.pca_f64(aug, n_components, self.seed)[0].astype(np.float32)
         idx, _ = orc.knn_bruteforce_f64(emb, knn_k, include_self)
         if graph_mode == 2:
             G = orc.union_knn_graph(idx)

@@ -373,11 +373,37 @@ def test_exact_pca_regimes(shape, regime):
     np.testing.assert_allclose(sv_ref, sv_skl, rtol=1e-4)
 
 
+def test_sparse_arpack_path_pseudocount_one(ctx):
+    """pseudocount=1 keeps the matrix sparse upstream and PCA runs ARPACK (dd.py:296-297,308): golden case E."""
+    from doubletdetection_amd import BoostClassifier
+
+    g = load_golden("case_e_pc1_sparse")
+    kw = golden_kwargs(g)
+    raw = csr_from(g, "raw_hvg")
+    ctx.upload_counts(raw)
+    ctx.create_doublets(g["parents"][0])
+    ctx.lognormalise(1.0)
+    vals, z = ctx.aug_values()
+    want = csr_from(g, "pca_in0")                      # the reference's own log1p(CSR) matrix
+    assert np.all(z == 0)
+    assert _ulp_diff(vals, want.data).max() <= 4       # numpy log1p vs correctly rounded
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        clf = BoostClassifier(**kw).fit(csr_from(g, "counts"))
+        ref = orc.OracleClassifier(pca="f64", **kw).fit(csr_from(g, "counts"))
+    # ARPACK converges to the exact truncated SVD whatever drives it: embeddings agree to solver tolerance
+    np.testing.assert_array_equal(np.asarray(clf.parents_), g["parents"])
+    agree = np.mean(clf.communities_ == ref.communities_)
+    assert agree > 0.98, agree
+    agree_ref = np.mean(clf.communities_ == g["communities"])
+    assert agree_ref > 0.95, agree_ref
+
+
 def test_unsupported_regimes_raise_clearly():
     from doubletdetection_amd import BoostClassifier
 
     rng = np.random.default_rng(6)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        with pytest.raises(NotImplementedError, match="pseudocount=1"):
-            BoostClassifier(n_iters=2, pseudocount=1).fit(rng.poisson(1.0, size=(600, 100)))
+        with pytest.raises(NotImplementedError, match="normalizer"):
+            BoostClassifier(n_iters=2, normalizer=lambda x: x).fit(rng.poisson(1.0, size=(600, 100)))
