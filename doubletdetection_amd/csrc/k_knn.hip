@@ -28,17 +28,28 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 //       Et[tile*16*CP + s*64 + l] -- one fully coalesced 256-byte load per MFMA k-step, and the same
 //       formula serves the A operand (queries) and the B operand (candidates).
 // nrm : float32 squared norms; padding points carry +inf so they can never pass the screen.
+// Eb  : bfloat16 split operands for v_mfma_f32_16x16x32_bf16: every coordinate a is stored as
+//       hi = bf16(a) and lo = bf16(a - hi); for tile t, 32-component block kb and part p (0 = hi, 1 = lo)
+//       lane l = ((d % 32) / 8) * 16 + j holds components d = 32*kb + 8*(l>>4) + 0..7 of point 16*t + j as
+//       8 consecutive bf16 at Eb[(((t*KB + kb)*2 + p)*64 + l)*8], i.e. one coalesced 1 KB load per operand.
 __global__ void k_knn_prepare(const float* __restrict__ in, int64_t M, int64_t Mp, int C, int CP,
-                              float* __restrict__ E, float* __restrict__ Et, float* __restrict__ nrm) {
+                              float* __restrict__ E, float* __restrict__ Et, __bf16* __restrict__ Eb,
+                              float* __restrict__ nrm) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= Mp) return;
     float n = 0.f;
     const int64_t tile = r >> 4;
     const int j = (int)(r & 15);
+    const int KB = CP / 32;
     for (int d = 0; d < CP; ++d) {
         const float v = (r < M && d < C) ? in[r * C + d] : 0.f;
         E[r * CP + d] = v;
         Et[tile * 16 * CP + (d >> 2) * 64 + (d & 3) * 16 + j] = v;
+        const __bf16 hi = (__bf16)v;
+        const __bf16 lo = (__bf16)(v - (float)hi);
+        const int kb = d >> 5, lane = (((d & 31) >> 3) << 4) | j, e = d & 7;
+        Eb[(((tile * KB + kb) * 2 + 0) * 64 + lane) * 8 + e] = hi;
+        Eb[(((tile * KB + kb) * 2 + 1) * 64 + lane) * 8 + e] = lo;
         n = fmaf(v, v, n);
     }
     nrm[r] = (r < M) ? n : __builtin_huge_valf();
@@ -228,7 +239,9 @@ __global__ void __launch_bounds__(256) k_knn_emit(const float* __restrict__ Et, 
     constexpr int kChunkTiles = chunk_tiles(CP);
     __shared__ __attribute__((aligned(16))) float lds_c[2][kChunkTiles * 16 * CP];
     __shared__ float lds_n[2][kChunkTiles * 16];
+    __shared__ int32_t lcnt[4][16 * kEmitRT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (lane < 16 * kEmitRT) lcnt[wave][lane] = 0;
     const int64_t q0 = ((int64_t)blockIdx.x * 4 + wave) * (16 * RT);     // Mp is a multiple of 256: no partial blocks
     QueryTiles<CP, RT> qt;
     qt.load(Et, q0, lane);
@@ -270,9 +283,11 @@ __global__ void __launch_bounds__(256) k_knn_emit(const float* __restrict__ Et, 
                 while (hits) {
                     const int v = __ffs(hits) - 1;
                     hits &= hits - 1;
-                    const int64_t q = q0 + (v >> 2) * 16 + rbase + (v & 3);
+                    const int lq = (v >> 2) * 16 + rbase + (v & 3);
+                    const int64_t q = q0 + lq;
                     if (own && q == cand) continue;
-                    const int slot = atomicAdd(&ccount[q], 1);
+                    // this wave is the only writer of its queries' lists: the slot counter lives in LDS
+                    const int slot = atomicAdd(&lcnt[wave][lq], 1);
                     if (slot < kCandCap) cbuf[q * kCandCap + slot] = cand;
                 }
             }
@@ -280,6 +295,233 @@ __global__ void __launch_bounds__(256) k_knn_emit(const float* __restrict__ Et, 
         if (ch + 1 < nchunks) st.commit(lds_c[buf ^ 1], lds_n[buf ^ 1], tid);
         __syncthreads();
     }
+    if (lane < 16 * kEmitRT) ccount[q0 + lane] = lcnt[wave][lane];
+}
+
+// ---- bfloat16-split variant of the two MFMA passes ---------------------------------------------------------
+// q.c ~= qh.ch + qh.cl + ql.ch with three v_mfma_f32_16x16x32_bf16 (16x the f32 MFMA rate each).  Dropped
+// terms (ql.cl and the residuals of the two-term split) are <= 3*2^-18 |q_i||c_i| per component, the float32
+// accumulation of 3*32 exact products adds <= ~6e-6 sum|q_i c_i|: |error(q.c)| <= 1.8e-5 |q||c| <= 0.9e-5 (|q|^2+|c|^2);
+// doubled in the distance and with the float32 norms that is 2.5e-5 (|q|^2+|c|^2).  The slack below leaves 1.6x margin.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr float kScreenSlackBf = 4.0e-5f;
+
+template <int CP>
+struct TileStageBf {           // one chunk = chunk_tiles(CP) tiles x (hi|lo) x KB kilobytes = 16 KB, as for float32
+    static constexpr int kChunkTiles = chunk_tiles(CP);
+    static constexpr int kBytes = kChunkTiles * 16 * CP * 4;       // 2 parts x 2 bytes = 4 bytes per coordinate
+    static constexpr int kVec = kBytes / 16 / 256;                 // 16-byte vectors per thread
+    f4 regs[kVec];
+    float nreg;
+    __device__ __forceinline__ void fetch(const __bf16* __restrict__ Eb, const float* __restrict__ nrm, int64_t chunk,
+                                          int64_t ntiles_total, int64_t tile_stride, int tid) {
+        constexpr int tile_vecs = 16 * CP * 4 / 16;                // 16-byte vectors per tile
+#pragma unroll
+        for (int u = 0; u < kVec; ++u) {
+            const int vix = u * 256 + tid;
+            const int t = vix / tile_vecs;
+            int64_t tile = chunk * kChunkTiles + t;
+            if (tile >= ntiles_total) tile = ntiles_total - 1;
+            regs[u] = reinterpret_cast<const f4*>(Eb)[tile * tile_stride * tile_vecs + (vix - t * tile_vecs)];
+        }
+        if (tid < kChunkTiles * 16) {
+            int64_t tile = chunk * kChunkTiles + (tid >> 4);
+            if (tile >= ntiles_total) tile = ntiles_total - 1;
+            nreg = nrm[tile * tile_stride * 16 + (tid & 15)];
+        }
+    }
+    __device__ __forceinline__ void commit(f4* lds_c, float* lds_n, int tid) const {
+#pragma unroll
+        for (int u = 0; u < kVec; ++u) lds_c[u * 256 + tid] = regs[u];
+        if (tid < kChunkTiles * 16) lds_n[tid] = nreg;
+    }
+};
+
+template <int CP, int RT>
+struct QueryTilesBf {
+    static constexpr int KB = CP / 32;
+    bf16x8 ah[RT][KB], al[RT][KB];
+    __device__ __forceinline__ void load(const __bf16* __restrict__ Eb, int64_t q0, int lane) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                const bf16x8* p = reinterpret_cast<const bf16x8*>(Eb) + ((((q0 >> 4) + rt) * KB + kb) * 2) * 64 + lane;
+                ah[rt][kb] = p[0];
+                al[rt][kb] = p[64];
+            }
+    }
+    // tile image in LDS: [kb][part][lane] vectors of 16 bytes
+    __device__ __forceinline__ void dots(const f4* tile, int lane, f4 (&acc)[RT]) const {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[rt] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            const f4 rh = tile[(kb * 2 + 0) * 64 + lane];
+            const f4 rl = tile[(kb * 2 + 1) * 64 + lane];
+            const bf16x8 bh = __builtin_bit_cast(bf16x8, rh);
+            const bf16x8 bl = __builtin_bit_cast(bf16x8, rl);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[rt][kb], bh, acc[rt], 0, 0, 0);   // small terms first
+                acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt][kb], bl, acc[rt], 0, 0, 0);
+                acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt][kb], bh, acc[rt], 0, 0, 0);
+            }
+        }
+    }
+};
+
+template <int CP>
+__global__ void __launch_bounds__(256) k_knn_bound_bf(const __bf16* __restrict__ Eb, const float* __restrict__ nrm,
+                                                      int64_t Mp, int K, int include_self, int64_t nsamp_tiles,
+                                                      int64_t tile_stride, float* __restrict__ thr_out) {
+    constexpr int RT = kBoundRT, NV = 4 * RT;
+    constexpr int kChunkTiles = chunk_tiles(CP);
+    constexpr int tile_vecs = 16 * CP * 4 / 16;
+    __shared__ f4 lds_c[2][kChunkTiles * tile_vecs];
+    __shared__ float lds_n[2][kChunkTiles * 16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t q0 = ((int64_t)blockIdx.x * 4 + wave) * (16 * RT);
+    QueryTilesBf<CP, RT> qt;
+    qt.load(Eb, q0, lane);
+    const int rbase = 4 * (lane >> 4), jcol = lane & 15;
+    float nq[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) nq[v] = nrm[q0 + (v >> 2) * 16 + rbase + (v & 3)];
+    float best[NV][kBoundKeep];
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int t = 0; t < kBoundKeep; ++t) best[v][t] = __builtin_huge_valf();
+    const int64_t own_tile = q0 >> 4;
+    const int64_t nchunks = (nsamp_tiles + kChunkTiles - 1) / kChunkTiles;
+    TileStageBf<CP> st;
+    st.fetch(Eb, nrm, 0, nsamp_tiles, tile_stride, tid);
+    st.commit(lds_c[0], lds_n[0], tid);
+    __syncthreads();
+    for (int64_t ch = 0; ch < nchunks; ++ch) {
+        const int buf = (int)(ch & 1);
+        if (ch + 1 < nchunks) st.fetch(Eb, nrm, ch + 1, nsamp_tiles, tile_stride, tid);
+        const int ntile = (int)((nsamp_tiles - ch * kChunkTiles) < kChunkTiles ? (nsamp_tiles - ch * kChunkTiles) : kChunkTiles);
+        for (int t = 0; t < ntile; ++t) {
+            const int64_t tile = (ch * kChunkTiles + t) * tile_stride;
+            const float nc = lds_n[buf][t * 16 + jcol];
+            f4 acc[RT];
+            qt.dots(lds_c[buf] + t * tile_vecs, lane, acc);
+            const bool own = !include_self && (tile >= own_tile && tile < own_tile + RT);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const float dot = acc[v >> 2][v & 3];
+                const float n = nq[v] + nc;
+                float ub = fmaf(-2.f, dot, n) + kScreenSlackBf * n;      // upper bound of the exact squared distance
+                if (own && (tile * 16 + jcol) == (q0 + (v >> 2) * 16 + rbase + (v & 3))) ub = __builtin_huge_valf();
+                if (!(ub < best[v][kBoundKeep - 1])) continue;
+                best[v][kBoundKeep - 1] = ub;
+#pragma unroll
+                for (int u = kBoundKeep - 1; u > 0; --u) {
+                    const float lo = fminf(best[v][u - 1], best[v][u]), hi = fmaxf(best[v][u - 1], best[v][u]);
+                    best[v][u - 1] = lo;
+                    best[v][u] = hi;
+                }
+            }
+        }
+        if (ch + 1 < nchunks) st.commit(lds_c[buf ^ 1], lds_n[buf ^ 1], tid);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        float kth = __builtin_huge_valf();
+        int rank[kBoundKeep];
+#pragma unroll
+        for (int t = 0; t < kBoundKeep; ++t) rank[t] = 0;
+        for (int o = 0; o < 16; ++o) {
+            const int src = (lane & 48) | ((jcol + o) & 15);
+#pragma unroll
+            for (int u = 0; u < kBoundKeep; ++u) {
+                const float other = __shfl(best[v][u], src, 64);
+                const int okey = ((jcol + o) & 15) * kBoundKeep + u;
+#pragma unroll
+                for (int t = 0; t < kBoundKeep; ++t) {
+                    const int mkey = jcol * kBoundKeep + t;
+                    rank[t] += (other < best[v][t] || (other == best[v][t] && okey < mkey)) ? 1 : 0;
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < kBoundKeep; ++t)
+            if (rank[t] == K - 1) kth = best[v][t];
+        for (int o = 1; o < 16; o <<= 1) kth = fminf(kth, __shfl_xor(kth, o, 64));
+        if (jcol == 0) thr_out[q0 + (v >> 2) * 16 + rbase + (v & 3)] = kth;
+    }
+}
+
+template <int CP>
+__global__ void __launch_bounds__(256) k_knn_emit_bf(const __bf16* __restrict__ Eb, const float* __restrict__ nrm,
+                                                     const float* __restrict__ thr, int64_t Mp, int include_self,
+                                                     int32_t* __restrict__ ccount, int32_t* __restrict__ cbuf) {
+    constexpr int RT = kEmitRT, NV = 4 * RT;
+    constexpr int kChunkTiles = chunk_tiles(CP);
+    constexpr int tile_vecs = 16 * CP * 4 / 16;
+    __shared__ f4 lds_c[2][kChunkTiles * tile_vecs];
+    __shared__ float lds_n[2][kChunkTiles * 16];
+    __shared__ int32_t lcnt[4][16 * kEmitRT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (lane < 16 * kEmitRT) lcnt[wave][lane] = 0;
+    const int64_t q0 = ((int64_t)blockIdx.x * 4 + wave) * (16 * RT);
+    QueryTilesBf<CP, RT> qt;
+    qt.load(Eb, q0, lane);
+    const int rbase = 4 * (lane >> 4), jcol = lane & 15;
+    float hr[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int64_t q = q0 + (v >> 2) * 16 + rbase + (v & 3);
+        const float n = nrm[q], t = thr[q];
+        hr[v] = 0.5f * ((1.0f - kScreenSlackBf) * n - t);
+        if (!(n < __builtin_huge_valf())) hr[v] = __builtin_huge_valf();
+        else if (!(t < __builtin_huge_valf())) hr[v] = -__builtin_huge_valf();
+    }
+    const int64_t ntiles = Mp >> 4;
+    const int64_t own_tile = q0 >> 4;
+    const int64_t nchunks = (ntiles + kChunkTiles - 1) / kChunkTiles;
+    TileStageBf<CP> st;
+    st.fetch(Eb, nrm, 0, ntiles, 1, tid);
+    st.commit(lds_c[0], lds_n[0], tid);
+    __syncthreads();
+    for (int64_t ch = 0; ch < nchunks; ++ch) {
+        const int buf = (int)(ch & 1);
+        if (ch + 1 < nchunks) st.fetch(Eb, nrm, ch + 1, ntiles, 1, tid);
+        const int ntile = (int)((ntiles - ch * kChunkTiles) < kChunkTiles ? (ntiles - ch * kChunkTiles) : kChunkTiles);
+        for (int t = 0; t < ntile; ++t) {
+            const int64_t tile = ch * kChunkTiles + t;
+            const float hc = 0.5f * (1.0f - kScreenSlackBf) * lds_n[buf][t * 16 + jcol];
+            f4 acc[RT];
+            qt.dots(lds_c[buf] + t * tile_vecs, lane, acc);
+            // one compare per pair; the wave-wide masks live in scalar registers
+            unsigned long long any = 0, hm[NV];
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                hm[v] = __ballot(acc[v >> 2][v & 3] > hc + hr[v]);
+                any |= hm[v];
+            }
+            if (any) {
+                const int32_t cand = (int32_t)(tile * 16 + jcol);
+                const bool own = !include_self && (tile >= own_tile && tile < own_tile + RT);
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    if (!((hm[v] >> lane) & 1ull)) continue;
+                    const int lq = (v >> 2) * 16 + rbase + (v & 3);
+                    const int64_t q = q0 + lq;
+                    if (own && q == cand) continue;
+                    // this wave is the only writer of its queries' lists: the slot counter lives in LDS
+                    const int slot = atomicAdd(&lcnt[wave][lq], 1);
+                    if (slot < kCandCap) cbuf[q * kCandCap + slot] = cand;
+                }
+            }
+        }
+        if (ch + 1 < nchunks) st.commit(lds_c[buf ^ 1], lds_n[buf ^ 1], tid);
+        __syncthreads();
+    }
+    if (lane < 16 * kEmitRT) ccount[q0 + lane] = lcnt[wave][lane];
 }
 
 // Exact squared distance in the reference's arithmetic: float64, (a-b)*(a-b) rounded, then added,
@@ -412,19 +654,22 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
     if (k > 16 * (kBoundKeep - 1)) return set_err(ctx, DDX_E_UNSUPPORTED, "k=%d exceeds %d", k, 16 * (kBoundKeep - 1));
     const int CP = (C <= 32) ? 32 : 64;
     const int64_t Mp = ceil_div(M, 256) * 256;                 // whole blocks of queries in both MFMA passes
-    // workspace (reuses the PCA row buffer): E [Mp*CP] | Et [Mp*CP] | nrm [Mp] | thr [Mp] | ccount [Mp+1] | cbuf [Mp*cap]
-    const size_t f_words = (size_t)Mp * CP * 2 + 2 * (size_t)Mp;
+    // workspace (reuses the PCA row buffer): E [Mp*CP] | Et [Mp*CP] | Eb [Mp*CP as bf16 hi+lo] | nrm [Mp] | thr [Mp] | ccount [Mp+1] | cbuf [Mp*cap]
+    const size_t f_words = (size_t)Mp * CP * 3 + 2 * (size_t)Mp;
     const size_t i_words = (size_t)Mp + 64 + (size_t)Mp * kCandCap;
     DDX_TRY(ensure(ctx, ctx->pcaA, sizeof(float) * f_words + sizeof(int32_t) * i_words + 256));
     DDX_TRY(ensure(ctx, ctx->knn_idx, sizeof(int32_t) * (size_t)M * k));
     DDX_TRY(ensure(ctx, ctx->knn_dist, sizeof(double) * (size_t)M * k));
     float* E = ctx->pcaA.as<float>();
     float* Et = E + (size_t)Mp * CP;
-    float* nrm = Et + (size_t)Mp * CP;
+    __bf16* Eb = reinterpret_cast<__bf16*>(Et + (size_t)Mp * CP);      // 2 parts x 2 bytes = CP floats per point
+    float* nrm = Et + 2 * (size_t)Mp * CP;
     float* thr = nrm + Mp;
+    const char* scr = getenv("DDX_KNN_SCREEN");
+    const bool bf = !(scr && scr[0] == 'f' && scr[1] == '3');          // DDX_KNN_SCREEN=f32 selects the float32 MFMA screen
     int32_t* ccount = reinterpret_cast<int32_t*>(thr + Mp);   // [Mp] + overflow counter at [Mp]
     int32_t* cbuf = ccount + Mp + 64;
-    k_knn_prepare<<<(unsigned)ceil_div(Mp, 256), 256, 0, ctx->stream>>>(ctx->emb32.as<float>(), M, Mp, C, CP, E, Et, nrm);
+    k_knn_prepare<<<(unsigned)ceil_div(Mp, 256), 256, 0, ctx->stream>>>(ctx->emb32.as<float>(), M, Mp, C, CP, E, Et, Eb, nrm);
     DDX_HIP(ctx, hipMemsetAsync(ccount, 0, sizeof(int32_t) * (Mp + 64), ctx->stream));
     // sample so that about 144 candidates per query survive: the k-th of a sample of S corresponds to rank k*M/S
     const int64_t ntiles = Mp >> 4;
@@ -436,13 +681,17 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
     {
         ScopedTimer t(ctx, "knn_bound");
         const unsigned grid = (unsigned)(Mp / (4 * 16 * kBoundRT));
-        if (CP == 32) k_knn_bound<32><<<grid, 256, 0, ctx->stream>>>(Et, nrm, Mp, k, include_self, nsamp, stride, thr);
+        if (bf && CP == 32) k_knn_bound_bf<32><<<grid, 256, 0, ctx->stream>>>(Eb, nrm, Mp, k, include_self, nsamp, stride, thr);
+        else if (bf) k_knn_bound_bf<64><<<grid, 256, 0, ctx->stream>>>(Eb, nrm, Mp, k, include_self, nsamp, stride, thr);
+        else if (CP == 32) k_knn_bound<32><<<grid, 256, 0, ctx->stream>>>(Et, nrm, Mp, k, include_self, nsamp, stride, thr);
         else k_knn_bound<64><<<grid, 256, 0, ctx->stream>>>(Et, nrm, Mp, k, include_self, nsamp, stride, thr);
     }
     {
         ScopedTimer t(ctx, "knn_emit");
         const unsigned grid = (unsigned)(Mp / (4 * 16 * kEmitRT));
-        if (CP == 32) k_knn_emit<32><<<grid, 256, 0, ctx->stream>>>(Et, nrm, thr, Mp, include_self, ccount, cbuf);
+        if (bf && CP == 32) k_knn_emit_bf<32><<<grid, 256, 0, ctx->stream>>>(Eb, nrm, thr, Mp, include_self, ccount, cbuf);
+        else if (bf) k_knn_emit_bf<64><<<grid, 256, 0, ctx->stream>>>(Eb, nrm, thr, Mp, include_self, ccount, cbuf);
+        else if (CP == 32) k_knn_emit<32><<<grid, 256, 0, ctx->stream>>>(Et, nrm, thr, Mp, include_self, ccount, cbuf);
         else k_knn_emit<64><<<grid, 256, 0, ctx->stream>>>(Et, nrm, thr, Mp, include_self, ccount, cbuf);
     }
     {
