@@ -31,8 +31,8 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 
 # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide
-# coalesced reads, + WRITE_SIZE), headline workload, see profiles/r01_pmc_traffic.md; None = not collected
-PMC_TRAFFIC_GB = {"spmm_rows": 1.46, "spmm_cols": 1.67, "knn_emit": None}
+# coalesced reads, + WRITE_SIZE), headline workload, profiles/r01c_pmc_counters.txt; None = not collected
+PMC_TRAFFIC_GB = {"spmm_rows": 1.03, "spmm_cols": 1.07, "knn_emit": 0.87, "knn_bound": 0.05, "knn_select": 1.31}
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md)
 FP64_PEAK_TFLOPS = 78.6      # FP64 vector / FP64 MFMA peak, dense
@@ -51,7 +51,7 @@ def parse():
     ap.add_argument("--algorithm", default="phenograph")
     ap.add_argument("--scaling", action="store_true", help="standard_scaling=True")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-cells", type=int, default=6000)
+    ap.add_argument("--cpu-sample-cells", type=int, default=20000)
     return ap.parse_args()
 
 
