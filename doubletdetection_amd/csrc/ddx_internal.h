@@ -18,6 +18,16 @@ namespace ddx {
 constexpr int kWave = 64;  // gfx950 wavefront
 // rows per panel of the column-major mirror: the sketch rows of one panel (rows x 40 x 4 or 8 B) should fit
 // one XCD's 4 MB L2 -> 16384 rows when the operand copy is float32, 8192 when float64 iterates are gathered
+// LDS-staged operator products (default): a slice of the float32 operand lives in LDS while the stored entries
+// stream by.  kLdsPanelRows = rows of the row-major sketch per slice of the A^T Y pass = rows per panel of the
+// column-major mirror (784 x 40 floats = 123 KB of the 160 KB LDS, the rest stages stored entries).  DDX_SPMM=gather selects the L2-gather kernels.
+constexpr int kLdsPanelRows = 784;
+constexpr int kGatherPanelRows = 4096;   // measured optimum for the gather kernels (8192: +19 %, 2048: +5 %)
+inline bool spmm_lds() {
+    const char* g = getenv("DDX_SPMM");
+    return !(g && (g[0] == 'g' || g[0] == 'G'));
+}
+
 inline bool pca_gather_f32() {
     const char* g = getenv("DDX_PCA_GATHER");
     return !(g && (g[0] == 'f' || g[0] == 'F') && g[1] == '6');
@@ -88,6 +98,7 @@ struct ddx_ctx {
     // colptr[p*H + j] .. colptr[p*H + j + 1].  A panel is kPanelRows consecutive rows of the augmented
     // matrix, so the rows gathered while a panel is processed stay L2-resident.
     int32_t panel_rows = 8192;       // fixed when the counts are uploaded
+    ddx::DevBuf rowseg;              // int32 [M x (slices+1)]: offset in row i of the first entry whose column is >= slice*SR
     int32_t P_o = 0;                 // panels covering the original rows [0, N)
     int32_t p_s0 = 0, P_s = 0;       // first panel touched by synthetic rows, number of such panels
 

@@ -195,6 +195,283 @@ __global__ void __launch_bounds__(256) k_spmm_cols(const int64_t* __restrict__ c
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// LDS-staged operator products (the default).  The gather kernels above fetch one 160-byte operand row per
+// stored entry through L1/L2 (19.5 GB per launch at the headline workload, 12 TB/s out of L2) -- that, not
+// HBM, bounds them.  Here a *slice* of the float32 operand (SR consecutive rows) is staged in LDS by one
+// 1024-thread workgroup per CU and every per-entry fetch is an LDS read.
+//
+//   ROWS (A Q):   operand = Q (H rows), outputs = rows of the augmented matrix.  A workgroup owns a set of rows
+//                 and walks all slices of Q; the entries of row i whose column falls in slice s are the
+//                 contiguous sub-range rowseg[i][s..s+1] of the CSR row.
+//   COLS (A^T Y): operand = Y (M rows), outputs = columns.  The column-major mirror is ordered by
+//                 (row panel of SR rows, column), so the entries of column j inside slice s are contiguous.  A
+//                 workgroup owns a set of columns and a strided subset of the slices (slice group g takes slices
+//                 g, g + groups, ...), and writes one partial H x L block per group; k_sum_panels adds the groups.
+//
+// Ownership.  The 64 lanes of a wave form SLOTS groups of `lpn` lanes, a lane holding two adjacent sketch
+// columns.  Each *group* owns kLdsOwnG outputs and keeps their float64 accumulators in registers across all
+// slices (no replication across groups, no final reduction), so a wave advances SLOTS segments -- one per group
+// -- in lock step, one stored entry per group and step.  Outputs are strided across workgroups
+// (output = owner + owners * local), so every workgroup holds the same mix of original and (twice as long)
+// synthetic rows.
+//
+// Pipeline.  The stored entries of the SLOTS current segments are fetched 64 per segment and round, one round
+// ahead (global-load latency hides behind the previous round's arithmetic), converted once to
+// (LDS byte address of the operand row, float64 value x - z) in the wave's staging area -- padded with zeros to
+// a full round so the step loop needs no bounds logic -- and then consumed four steps at a time with the
+// LDS reads of the next four steps issued before the multiply-adds of the current ones.  All orders are fixed.
+// ------------------------------------------------------------------------------------------------
+constexpr int kLdsOwnG = 6;        // outputs owned by one lane group
+constexpr int kLdsWaves = 16;      // waves per workgroup
+constexpr int kLdsChunk = 64;      // stored entries per segment and round
+constexpr int kLdsBudget = 160 * 1024;
+// staging per wave and lane group: 64 float64 values + 64 LDS offsets, the group strides padded by 16 bytes so
+// that the groups' broadcast reads of entry t fall into different banks
+constexpr int kLdsDStride = kLdsChunk + 2;    // doubles
+constexpr int kLdsOStride = kLdsChunk + 4;    // uint32
+constexpr int lds_stage_bytes(int slots) { return kLdsWaves * slots * (kLdsDStride * 8 + kLdsOStride * 4); }
+
+struct LdsSpmmArgs {
+    const float* op;     // operand, row-major [opRows x ld] float32
+    int ld, L, lpn;
+    int64_t opRows;
+    int SR, nslices, groups;      // slice height, number of slices, slice groups (1 for ROWS)
+    int64_t nOut;                 // outputs (M for ROWS, H for COLS)
+    int owners;                   // workgroups along the outputs = output stride
+    // ROWS
+    const int64_t* indptr; const int32_t* cols; const float* x; const float* zcol; const int32_t* rowseg; const double* tvec;
+    // COLS
+    const int64_t* cp_o; const int32_t* row_o; const float* x_o; int P_o;
+    const int64_t* cp_s; const int32_t* row_s; const float* x_s; int p_s0, P_s;
+    double* out;                  // ROWS: Y [M x L];  COLS: partials [groups x H x L]
+};
+
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ int64_t read_lane64(int64_t v, int j) {
+    return ((int64_t)__builtin_amdgcn_readlane((int)(v >> 32), j) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)v, j);
+}
+
+template <int SLOTS> struct LdsFetch {
+    int32_t i[SLOTS];
+    float x[SLOTS];
+};
+
+// entries [l[g] + r*64, ...) of the SLOTS current segments, one per lane and segment.  Lanes past the end of a
+// segment re-read its first entry (always a readable address), so the loads are unconditional and nothing
+// consumes them before the staging step of the *next* round -- that is what keeps them in flight.
+template <int SLOTS>
+__device__ __forceinline__ LdsFetch<SLOTS> lds_fetch(const int32_t* __restrict__ idx, const float* __restrict__ x,
+                                                     const int64_t (&l)[SLOTS], const int64_t (&h)[SLOTS], int r, int lane) {
+    LdsFetch<SLOTS> f;
+#pragma unroll
+    for (int g = 0; g < SLOTS; ++g) {
+        int64_t p = l[g] + (int64_t)r * kLdsChunk + lane;
+        p = p < h[g] ? p : l[g];
+        f.i[g] = idx[p];
+        f.x[g] = x[p];
+    }
+    return f;
+}
+
+// one round: stage the fetched entries, then `nsteps` lock-step steps (rounded up to a multiple of 4 <= 64)
+template <bool ROWS, int SLOTS>
+__device__ __forceinline__ void lds_round(const LdsFetch<SLOTS>& f, const int (&nvalid)[SLOTS], int nsteps, int32_t base, const double (&zc)[SLOTS],
+                                          const unsigned char* opB, const float* zS, int ld, double* dS, uint32_t* offS, int lane,
+                                          const double* myd, const uint32_t* myoff, double (&acc)[2]) {
+#pragma unroll
+    for (int g = 0; g < SLOTS; ++g) {
+        const bool ok = lane < nvalid[g];
+        const int i = ok ? f.i[g] - base : 0;
+        const double z = ROWS ? (double)zS[i] : zc[g];
+        dS[g * kLdsDStride + lane] = ok ? (double)f.x[g] - z : 0.0;
+        offS[g * kLdsOStride + lane] = (uint32_t)(i * ld) * 4u;
+    }
+    wave_lds_sync();
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    for (int t0 = 0; t0 < nsteps; t0 += 8) {          // the staged round is zero-padded to 64 entries
+        d2 dv[4];
+        u4 ov[2];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) dv[u] = *reinterpret_cast<const d2*>(myd + t0 + 2 * u);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) ov[u] = *reinterpret_cast<const u4*>(myoff + t0 + 4 * u);
+        float2 q[8];
+        q[0] = *reinterpret_cast<const float2*>(opB + ov[0].x); q[1] = *reinterpret_cast<const float2*>(opB + ov[0].y);
+        q[2] = *reinterpret_cast<const float2*>(opB + ov[0].z); q[3] = *reinterpret_cast<const float2*>(opB + ov[0].w);
+        q[4] = *reinterpret_cast<const float2*>(opB + ov[1].x); q[5] = *reinterpret_cast<const float2*>(opB + ov[1].y);
+        q[6] = *reinterpret_cast<const float2*>(opB + ov[1].z); q[7] = *reinterpret_cast<const float2*>(opB + ov[1].w);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            acc[0] = fma(dv[u].x, (double)q[2 * u].x, acc[0]);     acc[1] = fma(dv[u].x, (double)q[2 * u].y, acc[1]);
+            acc[0] = fma(dv[u].y, (double)q[2 * u + 1].x, acc[0]); acc[1] = fma(dv[u].y, (double)q[2 * u + 1].y, acc[1]);
+        }
+    }
+    wave_lds_sync();
+}
+
+template <bool ROWS, int SLOTS>
+__global__ void __launch_bounds__(1024) k_spmm_lds(const LdsSpmmArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    float* opS = reinterpret_cast<float*>(smem);
+    float* zS = opS + (size_t)a.SR * a.ld;
+    unsigned char* stg = reinterpret_cast<unsigned char*>(zS + (ROWS ? ((a.SR + 3) & ~3) : 0));   // 16-byte aligned
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double* dS = reinterpret_cast<double*>(stg + wave * (SLOTS * (kLdsDStride * 8 + kLdsOStride * 4)));
+    uint32_t* offS = reinterpret_cast<uint32_t*>(dS + SLOTS * kLdsDStride);
+    int slot = lane / a.lpn;
+    int sub = lane - slot * a.lpn;
+    const bool active = slot < SLOTS && 2 * sub < a.ld;
+    if (slot >= SLOTS) slot = SLOTS - 1;            // idle lanes shadow the last group (reads only)
+    if (2 * sub >= a.ld) sub = 0;
+    const double* myd = dS + slot * kLdsDStride;
+    const uint32_t* myoff = offS + slot * kLdsOStride;
+    const unsigned char* opB = smem + 8 * sub;       // this lane's two sketch columns of operand row 0
+    const int owner = (int)(blockIdx.x % a.owners);
+    const int group = (int)(blockIdx.x / a.owners);
+    constexpr int PERW = SLOTS * kLdsOwnG;          // outputs per wave; local output m = k*SLOTS + g
+
+    // local output m of this wave -> global output.  COLS: strided over the workgroups (columns of one slice are
+    // contiguous in the mirror anyway).  ROWS: a wave owns PERW *consecutive* rows (one contiguous piece of the
+    // CSR arrays per wave), the runs of a workgroup are spread over the matrix.
+    auto out_index = [&](int m) -> int64_t {
+        return ROWS ? ((int64_t)wave * a.owners + owner) * PERW + m : (int64_t)owner + (int64_t)a.owners * (wave * PERW + m);
+    };
+    // lane m < PERW looks after the segment bounds of local output m
+    const int64_t myout = out_index(lane);
+    const bool mine = lane < PERW && myout < a.nOut;
+    int64_t rowbase = 0;
+    if (ROWS && mine) rowbase = a.indptr[myout];
+    float zmine = 0.0f;                              // COLS: z of the owned column, handed out by readlane
+    if (!ROWS && mine) zmine = a.zcol[myout];
+    double acc[kLdsOwnG][2];
+#pragma unroll
+    for (int k = 0; k < kLdsOwnG; ++k) { acc[k][0] = 0.0; acc[k][1] = 0.0; }
+
+    for (int s = group; s < a.nslices; s += a.groups) {
+        __syncthreads();
+        const int64_t r0 = (int64_t)s * a.SR;
+        const int nr = (int)((a.opRows - r0) < a.SR ? (a.opRows - r0) : a.SR);
+        {
+            const int nvec = (nr * a.ld + 3) >> 2;
+            const f4v* src = reinterpret_cast<const f4v*>(a.op + r0 * a.ld);
+            f4v* dst = reinterpret_cast<f4v*>(opS);
+            for (int i = threadIdx.x; i < nvec; i += 1024) dst[i] = src[i];
+            if (ROWS)
+                for (int i = threadIdx.x; i < nr; i += 1024) zS[i] = a.zcol[r0 + i];
+        }
+        __syncthreads();
+        // COLS: the entries of a slice come from the mirror of the original rows, of the synthetic rows, or (the
+        // one slice that straddles row N) from both, one after the other
+        for (int st = 0; st < (ROWS ? 1 : 2); ++st) {
+            const int32_t* sidx = a.cols;
+            const float* sx = a.x;
+            int64_t lo = 0, hi = 0;
+            if (ROWS) {
+                if (mine) {
+                    const int32_t* rs = a.rowseg + myout * (a.nslices + 1) + s;
+                    lo = rowbase + rs[0];
+                    hi = rowbase + rs[1];
+                }
+            } else if (st == 0) {
+                if (s >= a.P_o) continue;
+                sidx = a.row_o; sx = a.x_o;
+                if (mine) { lo = a.cp_o[(int64_t)s * a.nOut + myout]; hi = a.cp_o[(int64_t)s * a.nOut + myout + 1]; }
+            } else {
+                const int ps = s - a.p_s0;
+                if (ps < 0 || ps >= a.P_s) continue;
+                sidx = a.row_s; sx = a.x_s;
+                if (mine) { lo = a.cp_s[(int64_t)ps * a.nOut + myout]; hi = a.cp_s[(int64_t)ps * a.nOut + myout + 1]; }
+            }
+
+            // unit k covers the SLOTS segments of local outputs k*SLOTS + g
+            auto unit_bounds = [&](int k, int64_t (&l)[SLOTS], int64_t (&h)[SLOTS], int& maxlen) {
+                maxlen = 0;
+#pragma unroll
+                for (int g = 0; g < SLOTS; ++g) {
+                    l[g] = read_lane64(lo, k * SLOTS + g);
+                    h[g] = read_lane64(hi, k * SLOTS + g);
+                    const int len = (int)(h[g] - l[g]);
+                    maxlen = len > maxlen ? len : maxlen;
+                }
+            };
+            int64_t l[SLOTS], h[SLOTS];
+            int maxlen;
+            unit_bounds(0, l, h, maxlen);
+            LdsFetch<SLOTS> cur = lds_fetch<SLOTS>(sidx, sx, l, h, 0, lane);
+#pragma unroll
+            for (int k = 0; k < kLdsOwnG; ++k) {
+                int64_t l2[SLOTS], h2[SLOTS];
+                int maxlen2 = 0;
+                if (k + 1 < kLdsOwnG) unit_bounds(k + 1, l2, h2, maxlen2);
+                double zc[SLOTS];
+#pragma unroll
+                for (int g = 0; g < SLOTS; ++g)
+                    zc[g] = ROWS ? 0.0 : (double)__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, zmine), k * SLOTS + g));
+                for (int r = 0;; ++r) {
+                    const bool more = (r + 1) * kLdsChunk < maxlen;
+                    LdsFetch<SLOTS> nxt = cur;
+                    if (more) nxt = lds_fetch<SLOTS>(sidx, sx, l, h, r + 1, lane);
+                    else if (k + 1 < kLdsOwnG) nxt = lds_fetch<SLOTS>(sidx, sx, l2, h2, 0, lane);
+                    const int left = maxlen - r * kLdsChunk;
+                    if (left > 0) {
+                        const int nsteps = left < kLdsChunk ? left : kLdsChunk;
+                        int nvalid[SLOTS];
+#pragma unroll
+                        for (int g = 0; g < SLOTS; ++g) nvalid[g] = (int)(h[g] - l[g]) - r * kLdsChunk;
+                        lds_round<ROWS, SLOTS>(cur, nvalid, nsteps, (int32_t)r0, zc, opB, zS, a.ld, dS, offS, lane, myd, myoff, acc[k]);
+                    }
+                    cur = nxt;
+                    if (!more) break;
+                }
+                if (k + 1 < kLdsOwnG) {
+#pragma unroll
+                    for (int g = 0; g < SLOTS; ++g) { l[g] = l2[g]; h[g] = h2[g]; }
+                    maxlen = maxlen2;
+                }
+            }
+        }
+    }
+    // every lane group writes its own outputs
+#pragma unroll
+    for (int k = 0; k < kLdsOwnG; ++k) {
+        const int64_t o = out_index(k * SLOTS + slot);
+        if (active && o < a.nOut) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int col = 2 * sub + c;
+                if (col < a.L) {
+                    if (ROWS) a.out[o * a.L + col] = acc[k][c] - a.tvec[col];
+                    else a.out[((int64_t)group * a.nOut + o) * a.L + col] = acc[k][c];
+                }
+            }
+        }
+    }
+}
+
+// rowseg[row*(ns+1) + p] = offset inside row `row` of its first stored entry whose column is >= p*SR (p = ns: row length)
+__global__ void k_row_segments(const int64_t* __restrict__ indptr, const int32_t* __restrict__ cols, int64_t nrows, int ns,
+                               int SR, int32_t* __restrict__ rowseg) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nrows * (ns + 1)) return;
+    const int64_t row = t / (ns + 1);
+    const int p = (int)(t - row * (ns + 1));
+    const int64_t b = indptr[row], e = indptr[row + 1];
+    const int64_t key = (int64_t)p * SR;
+    int64_t lo = b, hi = e;
+    if (p == ns) lo = e;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (cols[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    rowseg[t] = (int32_t)(lo - b);
+}
+
 // padded (and possibly float32-rounded) copy of an R x L operand: out[r*ld + c], zero in the padding columns
 template <typename T>
 __global__ void k_operand_copy(const double* __restrict__ in, int64_t R, int L, int ld, T* __restrict__ out) {
@@ -401,6 +678,8 @@ struct PcaWork {
     float* op32;       // scratch for that copy: max(M, H) x L floats
     int64_t M;
     int32_t H;
+    bool lds;          // LDS-staged products (needs gather32 and a slice that fits the LDS)
+    int rows_SR = 0, rows_ns = 0;   // A Q: slice height / slice count of the H-row operand
     double* partial;   // scratch for block partials
     double* small;     // [4*L*L + 4*L]: G, Rinv, T, vecs
     int* flag;
@@ -444,6 +723,30 @@ static const T* prepared_operand(PcaWork& w, const double* X, int64_t R, int ld)
     return out;
 }
 
+// lane-group geometry of the LDS kernels for a padded sketch width ld (0 slots: not applicable)
+static int lds_slots(int ld) { return ld <= 32 ? 4 : (ld <= 42 ? 3 : 0); }
+static int lds_lpn(int ld) { return ld <= 32 ? 16 : ld / 2; }
+static int lds_owners(int64_t nOut, int slots) {
+    const int64_t need = ceil_div(nOut, (int64_t)kLdsWaves * slots * kLdsOwnG);
+    return (int)(need <= 256 ? need : 256 * ceil_div(need, 256));     // whole rounds of one workgroup per CU
+}
+
+template <bool ROWS, int SLOTS>
+static int launch_lds_t(ddx_ctx* c, const LdsSpmmArgs& a, unsigned grid, size_t lds_bytes) {
+    static bool configured = false;
+    if (!configured) {
+        DDX_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmm_lds<ROWS, SLOTS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+        configured = true;
+    }
+    k_spmm_lds<ROWS, SLOTS><<<grid, 1024, lds_bytes, c->stream>>>(a);
+    return DDX_OK;
+}
+
+template <bool ROWS>
+static int launch_lds(ddx_ctx* c, const LdsSpmmArgs& a, int slots, unsigned grid, size_t lds_bytes) {
+    return slots == 4 ? launch_lds_t<ROWS, 4>(c, a, grid, lds_bytes) : launch_lds_t<ROWS, 3>(c, a, grid, lds_bytes);
+}
+
 static int apply_rows(PcaWork& w, const double* Qcol, double* Yrow) {  // A Q : [H x L] -> [M x L]
     ddx_ctx* c = w.ctx;
     double* tvec = w.small + 3 * w.L * w.L;
@@ -453,6 +756,18 @@ static int apply_rows(PcaWork& w, const double* Qcol, double* Yrow) {  // A Q : 
     }
     ScopedTimer t(c, "spmm_rows");
     const unsigned grid = (unsigned)ceil_div(w.M, 4);
+    if (w.lds) {
+        LdsSpmmArgs a{};
+        a.ld = (w.L + 3) & ~3; a.L = w.L; a.lpn = lds_lpn(a.ld);
+        const int slots = lds_slots(a.ld);
+        a.op = prepared_operand<float>(w, Qcol, w.H, a.ld);
+        a.opRows = w.H; a.SR = w.rows_SR; a.nslices = w.rows_ns; a.groups = 1;
+        a.nOut = w.M; a.owners = lds_owners(w.M, slots);
+        a.indptr = c->aug_indptr.as<int64_t>(); a.cols = c->aug_indices.as<int32_t>(); a.x = c->aug_x.as<float>();
+        a.zcol = c->zcol.as<float>(); a.rowseg = c->rowseg.as<int32_t>(); a.tvec = tvec; a.out = Yrow;
+        const size_t lds_bytes = (size_t)a.SR * a.ld * 4 + (size_t)((a.SR + 3) & ~3) * 4 + lds_stage_bytes(slots);
+        return launch_lds<true>(c, a, slots, (unsigned)a.owners, lds_bytes);
+    }
     if (w.gather32) {
         const int ld = (w.L + 3) & ~3, lpn = ld / 4;
         const float* op = prepared_operand<float>(w, Qcol, w.H, ld);
@@ -478,6 +793,25 @@ static int apply_cols(PcaWork& w, const double* Yrow, double* Wcol) {  // A^T Y 
     const int groups = (w.H + 3) / 4;
     const int64_t grid = 8 * ceil_div(P, 8) * groups;
     ScopedTimer t(c, "spmm_cols");
+    if (w.lds) {
+        LdsSpmmArgs a{};
+        a.ld = (w.L + 3) & ~3; a.L = w.L; a.lpn = lds_lpn(a.ld);
+        const int slots = lds_slots(a.ld);
+        a.op = prepared_operand<float>(w, Yrow, w.M, a.ld);
+        a.opRows = w.M; a.SR = c->panel_rows; a.nslices = P;
+        a.nOut = w.H; a.owners = lds_owners(w.H, slots);
+        a.groups = std::max(1, std::min(P, 512 / a.owners));
+        a.zcol = c->zcol.as<float>();
+        a.cp_o = c->csc_o_colptr.as<int64_t>(); a.row_o = c->csc_o_row.as<int32_t>(); a.x_o = c->csc_o_x.as<float>(); a.P_o = c->P_o;
+        a.cp_s = c->csc_s_colptr.as<int64_t>(); a.row_s = c->csc_s_row.as<int32_t>(); a.x_s = c->csc_s_x.as<float>();
+        a.p_s0 = c->p_s0; a.P_s = c->P_s;
+        a.out = c->pcaPanel.as<double>();
+        const size_t lds_bytes = (size_t)a.SR * a.ld * 4 + lds_stage_bytes(slots);
+        DDX_TRY(launch_lds<false>(c, a, slots, (unsigned)(a.owners * a.groups), lds_bytes));
+        k_sum_panels<<<(unsigned)ceil_div((int64_t)w.H * w.L, 256), 256, 0, c->stream>>>(c->pcaPanel.as<double>(), a.groups, w.H, w.L, c->colmean.as<double>(),
+                                                                                          uvec, Wcol);
+        return DDX_OK;
+    }
     if (w.gather32) {
         const int ld = (w.L + 3) & ~3, lpn = ld / 4;
         const float* op = prepared_operand<float>(w, Yrow, w.M, ld);
@@ -493,6 +827,28 @@ static int apply_cols(PcaWork& w, const double* Yrow, double* Wcol) {  // A^T Y 
     }
     k_sum_panels<<<(unsigned)ceil_div((int64_t)w.H * w.L, 256), 256, 0, c->stream>>>(c->pcaPanel.as<double>(), P, w.H, w.L, c->colmean.as<double>(),
                                                                                       uvec, Wcol);
+    return DDX_OK;
+}
+
+// decide whether the LDS-staged products apply and build the row-segment table of the A Q pass
+static int lds_setup(ddx_ctx* ctx, int L, PcaWork& w) {
+    w.lds = false;
+    if (!(w.gather32 && spmm_lds())) return DDX_OK;
+    const int64_t M = ctx->M;
+    const int32_t H = ctx->H;
+    const int ld = (L + 3) & ~3;
+    const int slots = lds_slots(ld);
+    if (!slots) return DDX_OK;
+    const bool cols_fit = (size_t)ctx->panel_rows * ld * 4 + lds_stage_bytes(slots) <= (size_t)kLdsBudget;
+    const int srmax = ((kLdsBudget - lds_stage_bytes(slots)) / (ld * 4 + 4)) & ~3;
+    if (!cols_fit || srmax < 64) return DDX_OK;
+    w.lds = true;
+    w.rows_ns = (int)ceil_div(H, srmax);
+    w.rows_SR = (int)((ceil_div(H, w.rows_ns) + 3) & ~3);
+    DDX_TRY(ensure(ctx, ctx->rowseg, sizeof(int32_t) * (size_t)M * (w.rows_ns + 1)));
+    ScopedTimer t(ctx, "row_segments");
+    k_row_segments<<<(unsigned)ceil_div(M * (w.rows_ns + 1), 256), 256, 0, ctx->stream>>>(ctx->aug_indptr.as<int64_t>(), ctx->aug_indices.as<int32_t>(), M, w.rows_ns,
+                                                                                       w.rows_SR, ctx->rowseg.as<int32_t>());
     return DDX_OK;
 }
 
@@ -513,6 +869,7 @@ static int pca_work_init(ddx_ctx* ctx, int L, PcaWork& w) {
     w.small = ctx->pcaSmall.as<double>();
     w.flag = ctx->pcaVec.as<int>();
     w.gather32 = pca_gather_f32();
+    w.lds = false;
     const int64_t maxR = M > H ? M : (int64_t)H;
     DDX_TRY(ensure(ctx, ctx->pcaOp, sizeof(double) * (size_t)maxR * (L + 4)));
     w.op32 = ctx->pcaOp.as<float>();
@@ -589,6 +946,9 @@ int stage_pca(ddx_ctx* ctx, int32_t C, int32_t oversample, int32_t n_iter, const
         // copy (float64 products and sums), which moves half the bytes through L2
         w.gather32 = pca_gather_f32();
     }
+    w.M = M;
+    w.H = H;
+    DDX_TRY(lds_setup(ctx, L, w));
     const int64_t maxR = M > H ? M : (int64_t)H;
     DDX_TRY(ensure(ctx, ctx->pcaOp, sizeof(double) * (size_t)maxR * (L + 4)));
     w.op32 = ctx->pcaOp.as<float>();

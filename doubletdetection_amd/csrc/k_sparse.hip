@@ -385,7 +385,7 @@ int stage_upload_counts(ddx_ctx* ctx, int64_t N, int32_t H, const int64_t* indpt
     DDX_TRY(ensure(ctx, ctx->csc_o_row, sizeof(int32_t) * (size_t)(nnz + 1)));
     DDX_TRY(ensure(ctx, ctx->csc_o_raw, sizeof(float) * (size_t)(nnz + 1)));
     DDX_TRY(ensure(ctx, ctx->csc_o_x, sizeof(float) * (size_t)(nnz + 1)));
-    ctx->panel_rows = 4096;   // measured optimum on MI355X (8192: +19 %, 2048: +5 % on the A^T Y pass)
+    ctx->panel_rows = (spmm_lds() && pca_gather_f32()) ? kLdsPanelRows : kGatherPanelRows;
     ctx->P_o = (int32_t)ceil_div(N, ctx->panel_rows);
     DDX_TRY(build_csc(ctx, 0, nnz, 0, N, 0, ctx->P_o, ctx->csc_o_colptr, ctx->csc_o_row, ctx->csc_o_raw));
     DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
