@@ -99,6 +99,9 @@ struct ddx_ctx {
     // matrix, so the rows gathered while a panel is processed stay L2-resident.
     int32_t panel_rows = 8192;       // fixed when the counts are uploaded
     ddx::DevBuf rowseg;              // int32 [M x (slices+1)]: offset in row i of the first entry whose column is >= slice*SR
+    ddx::DevBuf rank_buf;            // sort scratch + results of stage_rankings
+    const int32_t* rank_rows = nullptr;   // rows by stored entries, descending (views into rank_buf)
+    const int32_t* rank_cols = nullptr;   // columns likewise
     int32_t P_o = 0;                 // panels covering the original rows [0, N)
     int32_t p_s0 = 0, P_s = 0;       // first panel touched by synthetic rows, number of such panels
 
@@ -190,6 +193,7 @@ int stage_build_graph(ddx_ctx* ctx, int32_t mode);
 int stage_graph_relations(ddx_ctx* ctx, int32_t mode, int32_t* idx_host, double* w_host);
 void assemble_graph(int64_t M, int K, const int32_t* idx, const double* w, std::vector<int64_t>& ip,
                     std::vector<int32_t>& gi, std::vector<double>& gw);
+int stage_rankings(ddx_ctx* ctx);
 int stage_gene_variances(ddx_ctx* ctx, float* var_out);
 int stage_select_columns(ddx_ctx* ctx, const int64_t* cols, int32_t n_cols);
 

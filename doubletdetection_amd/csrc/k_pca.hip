@@ -238,7 +238,8 @@ struct LdsSpmmArgs {
     int64_t opRows;
     int SR, nslices, groups;      // slice height, number of slices, slice groups (1 for ROWS)
     int64_t nOut;                 // outputs (M for ROWS, H for COLS)
-    int owners;                   // workgroups along the outputs = output stride
+    int owners;                   // workgroups along the outputs
+    const int32_t* perm;          // outputs sorted by stored entries (descending): rank -> output
     // ROWS
     const int64_t* indptr; const int32_t* cols; const float* x; const float* zcol; const int32_t* rowseg; const double* tvec;
     // COLS
@@ -336,15 +337,18 @@ __global__ void __launch_bounds__(1024) k_spmm_lds(const LdsSpmmArgs a) {
     const int group = (int)(blockIdx.x / a.owners);
     constexpr int PERW = SLOTS * kLdsOwnG;          // outputs per wave; local output m = k*SLOTS + g
 
-    // local output m of this wave -> global output.  COLS: strided over the workgroups (columns of one slice are
-    // contiguous in the mirror anyway).  ROWS: a wave owns PERW *consecutive* rows (one contiguous piece of the
-    // CSR arrays per wave), the runs of a workgroup are spread over the matrix.
+    // Local output (k, g) of this wave -> rank in the outputs sorted by their number of stored entries -> output.
+    // The SLOTS outputs of a unit are consecutive ranks (near-equal segment lengths, so the lock step wastes
+    // little); the units of a wave, the waves of a workgroup and the workgroups are interleaved over the whole
+    // ranking, so they all carry the same load.
     auto out_index = [&](int m) -> int64_t {
-        return ROWS ? ((int64_t)wave * a.owners + owner) * PERW + m : (int64_t)owner + (int64_t)a.owners * (wave * PERW + m);
+        const int k = m / SLOTS, g = m - k * SLOTS;
+        const int64_t rank = (((int64_t)k * kLdsWaves + wave) * a.owners + owner) * SLOTS + g;
+        return rank < a.nOut ? (int64_t)a.perm[rank] : a.nOut;
     };
     // lane m < PERW looks after the segment bounds of local output m
-    const int64_t myout = out_index(lane);
-    const bool mine = lane < PERW && myout < a.nOut;
+    const int64_t myout = lane < PERW ? out_index(lane) : a.nOut;
+    const bool mine = myout < a.nOut;
     int64_t rowbase = 0;
     if (ROWS && mine) rowbase = a.indptr[myout];
     float zmine = 0.0f;                              // COLS: z of the owned column, handed out by readlane
@@ -440,7 +444,7 @@ __global__ void __launch_bounds__(1024) k_spmm_lds(const LdsSpmmArgs a) {
     // every lane group writes its own outputs
 #pragma unroll
     for (int k = 0; k < kLdsOwnG; ++k) {
-        const int64_t o = out_index(k * SLOTS + slot);
+        const int64_t o = __shfl(myout, k * SLOTS + slot, 64);     // the bounds lane of this group's k-th output knows it
         if (active && o < a.nOut) {
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
@@ -765,6 +769,7 @@ static int apply_rows(PcaWork& w, const double* Qcol, double* Yrow) {  // A Q : 
         a.nOut = w.M; a.owners = lds_owners(w.M, slots);
         a.indptr = c->aug_indptr.as<int64_t>(); a.cols = c->aug_indices.as<int32_t>(); a.x = c->aug_x.as<float>();
         a.zcol = c->zcol.as<float>(); a.rowseg = c->rowseg.as<int32_t>(); a.tvec = tvec; a.out = Yrow;
+        a.perm = c->rank_rows;
         const size_t lds_bytes = (size_t)a.SR * a.ld * 4 + (size_t)((a.SR + 3) & ~3) * 4 + lds_stage_bytes(slots);
         return launch_lds<true>(c, a, slots, (unsigned)a.owners, lds_bytes);
     }
@@ -806,6 +811,7 @@ static int apply_cols(PcaWork& w, const double* Yrow, double* Wcol) {  // A^T Y 
         a.cp_s = c->csc_s_colptr.as<int64_t>(); a.row_s = c->csc_s_row.as<int32_t>(); a.x_s = c->csc_s_x.as<float>();
         a.p_s0 = c->p_s0; a.P_s = c->P_s;
         a.out = c->pcaPanel.as<double>();
+        a.perm = c->rank_cols;
         const size_t lds_bytes = (size_t)a.SR * a.ld * 4 + lds_stage_bytes(slots);
         DDX_TRY(launch_lds<false>(c, a, slots, (unsigned)(a.owners * a.groups), lds_bytes));
         k_sum_panels<<<(unsigned)ceil_div((int64_t)w.H * w.L, 256), 256, 0, c->stream>>>(c->pcaPanel.as<double>(), a.groups, w.H, w.L, c->colmean.as<double>(),
@@ -847,6 +853,7 @@ static int lds_setup(ddx_ctx* ctx, int L, PcaWork& w) {
     w.rows_SR = (int)((ceil_div(H, w.rows_ns) + 3) & ~3);
     DDX_TRY(ensure(ctx, ctx->rowseg, sizeof(int32_t) * (size_t)M * (w.rows_ns + 1)));
     ScopedTimer t(ctx, "row_segments");
+    DDX_TRY(stage_rankings(ctx));
     k_row_segments<<<(unsigned)ceil_div(M * (w.rows_ns + 1), 256), 256, 0, ctx->stream>>>(ctx->aug_indptr.as<int64_t>(), ctx->aug_indices.as<int32_t>(), M, w.rows_ns,
                                                                                        w.rows_SR, ctx->rowseg.as<int32_t>());
     return DDX_OK;

@@ -233,6 +233,49 @@ __global__ void __launch_bounds__(256) k_doublet_fill(const int64_t* __restrict_
     }
 }
 
+// sort keys for the output rankings: stored entries per row / per column (over all panels of both mirrors)
+__global__ void k_row_lengths(const int64_t* __restrict__ indptr, int64_t M, uint32_t* __restrict__ keys, int32_t* __restrict__ ids) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    keys[i] = (uint32_t)(indptr[i + 1] - indptr[i]);
+    ids[i] = (int32_t)i;
+}
+__global__ void k_col_lengths(const int64_t* __restrict__ cp_o, int P_o, const int64_t* __restrict__ cp_s, int P_s, int32_t H,
+                              uint32_t* __restrict__ keys, int32_t* __restrict__ ids) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= H) return;
+    int64_t n = 0;
+    for (int p = 0; p < P_o; ++p) n += cp_o[(int64_t)p * H + j + 1] - cp_o[(int64_t)p * H + j];
+    for (int p = 0; p < P_s; ++p) n += cp_s[(int64_t)p * H + j + 1] - cp_s[(int64_t)p * H + j];
+    keys[j] = (uint32_t)n;
+    ids[j] = j;
+}
+
+// Rankings used by the LDS-staged operator products: rows and columns sorted by their number of stored entries
+// (descending, ties by index -- the radix sort is stable).  Rebuilt per iteration: the synthetic rows change.
+int stage_rankings(ddx_ctx* ctx) {
+    const int64_t M = ctx->M;
+    const int32_t H = ctx->H;
+    const int64_t n = M + H;
+    DDX_TRY(ensure(ctx, ctx->rank_buf, (sizeof(uint32_t) * 2 + sizeof(int32_t) * 2) * (size_t)n));
+    uint32_t* keys_in = ctx->rank_buf.as<uint32_t>();
+    uint32_t* keys_out = keys_in + n;
+    int32_t* ids_in = reinterpret_cast<int32_t*>(keys_out + n);
+    int32_t* ids_out = ids_in + n;
+    k_row_lengths<<<(unsigned)ceil_div(M, 256), 256, 0, ctx->stream>>>(ctx->aug_indptr.as<int64_t>(), M, keys_in, ids_in);
+    k_col_lengths<<<(unsigned)ceil_div(H, 256), 256, 0, ctx->stream>>>(ctx->csc_o_colptr.as<int64_t>(), ctx->P_o, ctx->csc_s_colptr.as<int64_t>(), ctx->P_s, H,
+                                                                       keys_in + M, ids_in + M);
+    size_t tmp_r = 0, tmp_c = 0;
+    DDX_HIP(ctx, hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tmp_r, keys_in, keys_out, ids_in, ids_out, (int)M, 0, 32, ctx->stream));
+    DDX_HIP(ctx, hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tmp_c, keys_in + M, keys_out + M, ids_in + M, ids_out + M, (int)H, 0, 32, ctx->stream));
+    DDX_TRY(ensure(ctx, ctx->sort_tmp, std::max(tmp_r, tmp_c)));
+    DDX_HIP(ctx, hipcub::DeviceRadixSort::SortPairsDescending(ctx->sort_tmp.p, tmp_r, keys_in, keys_out, ids_in, ids_out, (int)M, 0, 32, ctx->stream));
+    DDX_HIP(ctx, hipcub::DeviceRadixSort::SortPairsDescending(ctx->sort_tmp.p, tmp_c, keys_in + M, keys_out + M, ids_in + M, ids_out + M, (int)H, 0, 32, ctx->stream));
+    ctx->rank_rows = ids_out;
+    ctx->rank_cols = ids_out + M;
+    return DDX_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // column-major mirror
 // ------------------------------------------------------------------------------------------------
