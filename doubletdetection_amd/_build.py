@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libddx.so")
 
-HIP_SOURCES = ["ddx_api.hip", "k_sparse.hip", "k_pca.hip", "k_knn.hip", "k_prologue.hip"]
+HIP_SOURCES = ["ddx_api.hip", "k_sparse.hip", "k_pca.hip", "k_knn.hip", "k_prologue.hip", "k_louvain.hip"]
 CXX_SOURCES = ["louvain.cpp", "hostmath.cpp"]
 HEADERS = ["ddx_internal.h", os.path.join("..", "..", "include", "ddx.h")]
 

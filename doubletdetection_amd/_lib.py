@@ -22,6 +22,9 @@ c_f32_p = C.POINTER(C.c_float)
 c_f64_p = C.POINTER(C.c_double)
 
 
+E_UNSUPPORTED = -5   # DDX_E_UNSUPPORTED of include/ddx.h
+
+
 class DdxError(RuntimeError):
     def __init__(self, code, message):
         super().__init__(f"libddx error {code}: {message}")
@@ -66,6 +69,11 @@ _SIGNATURES = {
     "ddx_get_graph_size": (C.c_int, [C.c_void_p, c_i64_p, c_i64_p]),
     "ddx_get_graph": (C.c_int, [C.c_void_p, c_i64_p, c_i32_p, c_f64_p]),
     "ddx_louvain": (C.c_int, [C.c_int64, c_i64_p, c_i32_p, c_f64_p, C.c_double, C.c_uint64, c_i32_p, c_f64_p]),
+    "ddx_louvain_sequential": (C.c_int, [C.c_int64, c_i64_p, c_i32_p, c_f64_p, C.c_double, C.c_uint64, c_i32_p, c_f64_p]),
+    "ddx_presweep": (C.c_int, [C.c_int64, c_i64_p, c_i32_p, c_f64_p, C.c_double, C.c_int32, c_i32_p, c_i64_p, c_i64_p, c_i32_p, c_f64_p]),
+    "ddx_coarsen_graph": (C.c_int, [C.c_void_p, C.c_double, C.c_int32]),
+    "ddx_get_coarse_size": (C.c_int, [C.c_void_p, c_i64_p, c_i64_p]),
+    "ddx_get_coarse_graph": (C.c_int, [C.c_void_p, c_i32_p, c_i64_p, c_i32_p, c_f64_p]),
     "ddx_relabel_by_size": (C.c_int, [C.c_int64, c_i32_p, C.c_int64, c_i64_p]),
     "ddx_hypergeom_logsf": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int64, c_f64_p]),
     "ddx_score_communities": (C.c_int, [c_i64_p, C.c_int64, C.c_int64, c_f64_p, c_f64_p]),
@@ -127,6 +135,43 @@ def louvain(indptr, indices, weights, gamma: float, seed: int):
     _check(lib.ddx_louvain(n, _p(indptr, c_i64_p), _p(indices, c_i32_p), _p(weights, c_f64_p), float(gamma),
                            int(seed) & 0xFFFFFFFFFFFFFFFF, _p(labels, c_i32_p), C.byref(q)))
     return labels, q.value
+
+
+PRESWEEPS = 6   # DDX_PRESWEEPS of include/ddx.h
+
+
+def louvain_sequential(indptr, indices, weights, gamma: float, seed: int):
+    """Part B of the specification only (sequential multi-level optimisation).  Returns (labels, quality)."""
+    lib = load()
+    indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+    indices = np.ascontiguousarray(indices, dtype=np.int32)
+    weights = np.ascontiguousarray(weights, dtype=np.float64)
+    n = indptr.shape[0] - 1
+    labels = np.empty(n, dtype=np.int32)
+    q = C.c_double(0.0)
+    _check(lib.ddx_louvain_sequential(n, _p(indptr, c_i64_p), _p(indices, c_i32_p), _p(weights, c_f64_p), float(gamma),
+                                      int(seed) & 0xFFFFFFFFFFFFFFFF, _p(labels, c_i32_p), C.byref(q)))
+    return labels, q.value
+
+
+def presweep(indptr, indices, weights, gamma: float, sweeps: int = PRESWEEPS):
+    """Part A on the host.  Returns (member int32[n], c_indptr, c_indices, c_weights)."""
+    lib = load()
+    indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+    indices = np.ascontiguousarray(indices, dtype=np.int32)
+    weights = np.ascontiguousarray(weights, dtype=np.float64)
+    n = indptr.shape[0] - 1
+    nnz = int(indptr[-1]) if n > 0 else 0
+    member = np.empty(n, dtype=np.int32)
+    c_indptr = np.zeros(n + 1, dtype=np.int64)
+    c_indices = np.empty(max(nnz, 1), dtype=np.int32)
+    c_weights = np.empty(max(nnz, 1), dtype=np.float64)
+    nc = C.c_int64(0)
+    _check(lib.ddx_presweep(n, _p(indptr, c_i64_p), _p(indices, c_i32_p), _p(weights, c_f64_p), float(gamma), int(sweeps),
+                            _p(member, c_i32_p), C.byref(nc), _p(c_indptr, c_i64_p), _p(c_indices, c_i32_p), _p(c_weights, c_f64_p)))
+    k = nc.value
+    e = int(c_indptr[k])
+    return member, c_indptr[:k + 1].copy(), c_indices[:e].copy(), c_weights[:e].copy()
 
 
 def relabel_by_size(labels, min_cluster_size=None):
@@ -353,8 +398,10 @@ class Context:
         self._c(self._lib.ddx_get_knn(self._h, _p(idx, c_i32_p), _p(dist, c_f64_p) if with_dist else None))
         return idx, (np.sqrt(dist) if with_dist else None)   # the C-ABI returns squared distances
 
-    def build_graph(self, mode: int):
+    def build_graph(self, mode: int, fetch: bool = True):
         self._c(self._lib.ddx_build_graph(self._h, int(mode)))
+        if not fetch:
+            return None
         n = C.c_int64(0)
         e = C.c_int64(0)
         self._c(self._lib.ddx_get_graph_size(self._h, C.byref(n), C.byref(e)))
@@ -363,6 +410,30 @@ class Context:
         w = np.empty(e.value, dtype=np.float64)
         self._c(self._lib.ddx_get_graph(self._h, _p(ip, c_i64_p), _p(ix, c_i32_p), _p(w, c_f64_p)))
         return ip, ix, w
+
+    def fetch_graph(self):
+        """The symmetric CSR left on the device by build_graph."""
+        n = C.c_int64(0)
+        e = C.c_int64(0)
+        self._c(self._lib.ddx_get_graph_size(self._h, C.byref(n), C.byref(e)))
+        ip = np.empty(n.value + 1, dtype=np.int64)
+        ix = np.empty(e.value, dtype=np.int32)
+        w = np.empty(e.value, dtype=np.float64)
+        self._c(self._lib.ddx_get_graph(self._h, _p(ip, c_i64_p), _p(ix, c_i32_p), _p(w, c_f64_p)))
+        return ip, ix, w
+
+    def coarsen_graph(self, gamma: float, sweeps: int = PRESWEEPS):
+        """Part A of the community detection on the device graph.  Returns (member, indptr, indices, weights)."""
+        self._c(self._lib.ddx_coarsen_graph(self._h, float(gamma), int(sweeps)))
+        n = C.c_int64(0)
+        e = C.c_int64(0)
+        self._c(self._lib.ddx_get_coarse_size(self._h, C.byref(n), C.byref(e)))
+        member = np.empty(self._embM, dtype=np.int32)
+        ip = np.empty(n.value + 1, dtype=np.int64)
+        ix = np.empty(e.value, dtype=np.int32)
+        w = np.empty(e.value, dtype=np.float64)
+        self._c(self._lib.ddx_get_coarse_graph(self._h, _p(member, c_i32_p), _p(ip, c_i64_p), _p(ix, c_i32_p), _p(w, c_f64_p)))
+        return member, ip, ix, w
 
     def graph_relations(self, mode: int):
         idx = np.empty((self._embM, self._K), dtype=np.int32)

@@ -108,7 +108,10 @@ class _HipEngine:
         self.ctx.select_columns(cols)
 
     def run_iteration(self, parents, pseudocount, standard_scaling, n_components, q0, knn_k, include_self,
-                      graph_mode):
+                      graph_mode, gamma=None):
+        """One boosting iteration on the device.  Returns the symmetric graph (indptr, indices, weights), or --
+        when ``gamma`` is given -- the result of the synchronous pre-sweeps run on the device:
+        (member, coarse indptr, coarse indices, coarse weights)."""
         c = self.ctx
         c.create_doublets(parents)
         c.lognormalise(pseudocount)
@@ -121,7 +124,15 @@ class _HipEngine:
         else:
             c.pca(n_components, q0)
         c.knn(knn_k, include_self)
-        return c.build_graph(graph_mode)      # symmetric CSR assembled on the device
+        if gamma is None:
+            return c.build_graph(graph_mode)  # symmetric CSR assembled on the device
+        c.build_graph(graph_mode, fetch=False)
+        try:
+            return c.coarsen_graph(gamma)
+        except _lib.DdxError as err:          # a hub with more neighbours than the device sweep handles
+            if err.code != _lib.E_UNSUPPORTED:
+                raise
+            return c.fetch_graph()
 
     def _pca_arpack(self, n_components, seed):
         """pseudocount == 1 without scaling keeps the matrix sparse upstream and switches sc.tl.pca to
@@ -306,9 +317,13 @@ class BoostClassifier:
         import time
 
         t0 = time.perf_counter()
-        indptr, indices, weights = graph() if callable(graph) else graph
+        graph = graph() if callable(graph) else graph
         t1 = time.perf_counter()
-        labels, _ = _lib.louvain(indptr, indices, weights, gamma, seed)
+        if len(graph) == 4:                   # pre-sweeps already done on the device: finish on the coarse graph
+            member, indptr, indices, weights = graph
+            labels = _lib.louvain_sequential(indptr, indices, weights, gamma, seed)[0][member]
+        else:
+            labels, _ = _lib.louvain(*graph, gamma, seed)
         t2 = time.perf_counter()
         full = _lib.relabel_by_size(labels, min_cluster_size)
         scores, logp = _lib.score_communities(full, num_cells)
@@ -448,7 +463,7 @@ class BoostClassifier:
                     print("Iteration {:3}/{}".format(i + 1, n_iters))
                 t0 = time.perf_counter()
                 graph = engine.run_iteration(all_parents[i], self.pseudocount, self.standard_scaling, n_comp,
-                                             q0, knn_k, include_self, graph_mode)
+                                             q0, knn_k, include_self, graph_mode, gamma)
                 host["device_stages"] += time.perf_counter() - t0
                 pending[i] = pool.submit(self._cluster_and_score, graph, gamma, seed, min_cluster_size, num_cells)
             t0 = time.perf_counter()

@@ -153,7 +153,7 @@ int ddx_destroy(ddx_ctx* ctx) {
                       &ctx->csc_s_row, &ctx->csc_s_raw, &ctx->csc_s_x, &ctx->sort_keys_in, &ctx->sort_keys_out,
                       &ctx->sort_vals_in, &ctx->sort_vals_out, &ctx->sort_tmp, &ctx->median, &ctx->lib_sorted,
                       &ctx->zcol, &ctx->colmean, &ctx->colstat, &ctx->pcaA, &ctx->pcaB, &ctx->pcaSmall,
-                      &ctx->pcaPartial, &ctx->pcaVec, &ctx->pcaPanel, &ctx->pcaOp, &ctx->rowseg, &ctx->rank_buf, &ctx->emb32, &ctx->emb64, &ctx->sing, &ctx->knn_idx,
+                      &ctx->pcaPartial, &ctx->pcaVec, &ctx->pcaPanel, &ctx->pcaOp, &ctx->rowseg, &ctx->rank_buf, &ctx->lv_buf, &ctx->emb32, &ctx->emb64, &ctx->sing, &ctx->knn_idx,
                       &ctx->knn_dist, &ctx->knn_sorted, &ctx->edge_w};
     for (DevBuf* b : bufs) release(ctx, *b);
     (void)hipStreamDestroy(ctx->stream);
@@ -508,6 +508,37 @@ int ddx_get_graph(ddx_ctx* ctx, int64_t* indptr, int32_t* indices, double* weigh
     if (ctx->g_entries > 0) {
         DDX_HIP(ctx, hipMemcpyAsync(indices, ctx->g_d_cols, sizeof(int32_t) * ctx->g_entries, hipMemcpyDeviceToHost, ctx->stream));
         DDX_HIP(ctx, hipMemcpyAsync(weights, ctx->g_d_vals, sizeof(double) * ctx->g_entries, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return DDX_OK;
+}
+
+int ddx_coarsen_graph(ddx_ctx* ctx, double gamma, int32_t sweeps) {
+    REQUIRE_CTX(ctx);
+    USE_DEVICE(ctx);
+    NEED(ctx->g_nodes >= 0, "no graph: call ddx_build_graph first");
+    NEED(sweeps >= 0, "sweeps must be >= 0");
+    return stage_coarsen_graph(ctx, gamma, sweeps);
+}
+
+int ddx_get_coarse_size(ddx_ctx* ctx, int64_t* n_coarse, int64_t* n_entries) {
+    REQUIRE_CTX(ctx);
+    NEED(ctx->c_nodes >= 0, "no coarse graph");
+    NEED(n_coarse && n_entries, "null output");
+    *n_coarse = ctx->c_nodes;
+    *n_entries = ctx->c_entries;
+    return DDX_OK;
+}
+
+int ddx_get_coarse_graph(ddx_ctx* ctx, int32_t* member, int64_t* indptr, int32_t* indices, double* weights) {
+    REQUIRE_CTX(ctx);
+    USE_DEVICE(ctx);
+    NEED(ctx->c_nodes >= 0 && ctx->g_nodes >= 0, "no coarse graph");
+    DDX_HIP(ctx, hipMemcpyAsync(member, ctx->c_d_member, sizeof(int32_t) * ctx->g_nodes, hipMemcpyDeviceToHost, ctx->stream));
+    DDX_HIP(ctx, hipMemcpyAsync(indptr, ctx->c_d_indptr, sizeof(int64_t) * (ctx->c_nodes + 1), hipMemcpyDeviceToHost, ctx->stream));
+    if (ctx->c_entries > 0) {
+        DDX_HIP(ctx, hipMemcpyAsync(indices, ctx->c_d_cols, sizeof(int32_t) * ctx->c_entries, hipMemcpyDeviceToHost, ctx->stream));
+        DDX_HIP(ctx, hipMemcpyAsync(weights, ctx->c_d_vals, sizeof(double) * ctx->c_entries, hipMemcpyDeviceToHost, ctx->stream));
     }
     DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return DDX_OK;

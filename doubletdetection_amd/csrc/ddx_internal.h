@@ -139,6 +139,14 @@ struct ddx_ctx {
     const int32_t* g_d_cols = nullptr;
     const double* g_d_vals = nullptr;
 
+    // coarse graph left on the device by ddx_coarsen_graph (views into lv_buf)
+    ddx::DevBuf lv_buf;
+    int64_t c_nodes = -1, c_entries = 0;
+    const int32_t* c_d_member = nullptr;
+    const int64_t* c_d_indptr = nullptr;
+    const int32_t* c_d_cols = nullptr;
+    const double* c_d_vals = nullptr;
+
     // timing
     bool timing = false;
     std::vector<std::string> t_names;
@@ -194,6 +202,7 @@ int stage_graph_relations(ddx_ctx* ctx, int32_t mode, int32_t* idx_host, double*
 void assemble_graph(int64_t M, int K, const int32_t* idx, const double* w, std::vector<int64_t>& ip,
                     std::vector<int32_t>& gi, std::vector<double>& gw);
 int stage_rankings(ddx_ctx* ctx);
+int stage_coarsen_graph(ddx_ctx* ctx, double gamma, int32_t sweeps);
 int stage_gene_variances(ddx_ctx* ctx, float* var_out);
 int stage_select_columns(ddx_ctx* ctx, const int64_t* cols, int32_t n_cols);
 

@@ -1,0 +1,275 @@
+// Part A of the community-detection specification (oracle/louvain_ref.py:presweep) on the GPU: synchronous
+// sweeps of the local-moving step on integer-quantised weights, then an exact aggregation of the communities.
+// It is applied to the symmetric CSR that ddx_build_graph left on the device; the host only sees the aggregated
+// graph (a few thousand super-nodes) and finishes with the sequential multi-level optimisation
+// (ddx_louvain_sequential).  This replaces the Louvain stage inside phenograph.cluster / sc.tl.louvain
+// (dd.py:320-322, 337-342) together with louvain.cpp.
+//
+// Why it is exact and order-free: edge weights are rounded once to multiples of 2^-20 and every sum (node strength,
+// community total, node-to-community weight, aggregated edge weight) is an int64 sum -- atomics and sorts may
+// reorder them freely.  The only floating-point work is the score
+//     score(v,c) = (double)W(v,c) * (double)2m  -  (gamma * (double)tot'_c) * (double)k_v
+// three multiplications and a subtraction, evaluated without FMA contraction exactly as the host and the Python
+// specification do; ties go to the smaller community id, so the lane order inside a wave does not matter either.
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+
+#include "ddx_internal.h"
+
+namespace ddx {
+
+#pragma clang fp contract(off)
+
+constexpr double kWeightScale = 1048576.0;   // 2^20, as in louvain.cpp / louvain_ref.py
+constexpr int kLvCap = 1024;                 // neighbours of one node handled by the LDS path
+
+__global__ void k_lv_quantise(const double* __restrict__ w, int64_t E, int64_t* __restrict__ wq) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < E) wq[e] = (int64_t)rint(w[e] * kWeightScale);
+}
+
+// strength of every node (self loops included), identity communities, 2m, largest degree
+__global__ void k_lv_strength(const int64_t* __restrict__ indptr, const int64_t* __restrict__ wq, int64_t n, int64_t* __restrict__ K,
+                              int32_t* __restrict__ comm, unsigned long long* __restrict__ m2, int32_t* __restrict__ maxdeg) {
+    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    int64_t s = 0;
+    const int64_t b = indptr[v], e = indptr[v + 1];
+    for (int64_t p = b; p < e; ++p) s += wq[p];
+    K[v] = s;
+    comm[v] = (int32_t)v;
+    atomicAdd(m2, (unsigned long long)s);
+    atomicMax(maxdeg, (int32_t)(e - b));
+}
+
+__global__ void k_lv_totals(const int32_t* __restrict__ comm, const int64_t* __restrict__ K, int64_t n,
+                            unsigned long long* __restrict__ tot, int32_t* __restrict__ size) {
+    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    atomicAdd(tot + comm[v], (unsigned long long)K[v]);
+    atomicAdd(size + comm[v], 1);
+}
+
+__device__ __forceinline__ int64_t shfl64(int64_t v, int src) {
+    const int lo = __shfl((int)v, src, 64), hi = __shfl((int)(v >> 32), src, 64);
+    return ((int64_t)hi << 32) | (uint32_t)lo;
+}
+
+// wave-wide argmax of (score, smaller community wins ties); c < 0 marks "no candidate"
+__device__ __forceinline__ void wave_best(double& s, int32_t& c) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double s2 = __shfl_xor(s, off, 64);
+        const int32_t c2 = __shfl_xor(c, off, 64);
+        const bool take = c2 >= 0 && (c < 0 || s2 > s || (s2 == s && c2 < c));
+        if (take) { s = s2; c = c2; }
+    }
+}
+
+// One synchronous sweep: one wave per node decides from (comm, tot, size) and writes next[v].
+__global__ void __launch_bounds__(256) k_lv_sweep(const int64_t* __restrict__ indptr, const int32_t* __restrict__ cols,
+                                                  const int64_t* __restrict__ wq, const int64_t* __restrict__ K,
+                                                  const int32_t* __restrict__ comm, const unsigned long long* __restrict__ tot,
+                                                  const int32_t* __restrict__ size, int64_t n, double gamma, double m2d,
+                                                  int32_t* __restrict__ next) {
+    __shared__ int32_t cS[4][kLvCap];
+    __shared__ int64_t wS[4][kLvCap];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t v = (int64_t)blockIdx.x * 4 + wave;
+    if (v >= n) return;
+    const int64_t b = indptr[v];
+    const int deg = (int)(indptr[v + 1] - b);
+    const int32_t own = comm[v];
+    const int64_t kvi = K[v];
+    const double kv = (double)kvi;
+    double best_s = 0.0;
+    int32_t best_c = -1;
+    int64_t w_own = 0;
+    if (deg <= 64) {
+        int32_t c = -1;
+        int64_t w = 0;
+        if (lane < deg) {
+            const int32_t u = cols[b + lane];
+            w = wq[b + lane];
+            c = (u == (int32_t)v) ? -1 : comm[u];
+        }
+        int64_t W = 0;
+        bool leader = c >= 0;
+        for (int j = 0; j < deg; ++j) {
+            const int32_t cj = __shfl(c, j, 64);
+            const int64_t wj = shfl64(w, j);
+            if (cj == c) {
+                W += wj;
+                if (j < lane) leader = false;
+            }
+            if (cj == own) w_own += wj;
+        }
+        if (leader && c != own) {
+            best_s = (double)W * m2d - (gamma * (double)(int64_t)tot[c]) * kv;
+            best_c = c;
+        }
+    } else {
+        const int d = deg < kLvCap ? deg : kLvCap;       // deg > kLvCap is rejected on the host before the launch
+        for (int i = lane; i < d; i += 64) {
+            const int32_t u = cols[b + i];
+            cS[wave][i] = (u == (int32_t)v) ? -1 : comm[u];
+            wS[wave][i] = wq[b + i];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int i = lane; i < d; i += 64) {
+            const int32_t c = cS[wave][i];
+            if (c < 0) continue;
+            int64_t W = 0;
+            bool leader = true;
+            for (int j = 0; j < d; ++j) {
+                if (cS[wave][j] == c) {
+                    W += wS[wave][j];
+                    if (j < i) leader = false;
+                }
+            }
+            if (c == own) {
+                if (leader) w_own = W;
+            } else if (leader) {
+                const double s = (double)W * m2d - (gamma * (double)(int64_t)tot[c]) * kv;
+                if (best_c < 0 || s > best_s || (s == best_s && c < best_c)) { best_s = s; best_c = c; }
+            }
+        }
+        // the lane that led the own community holds w_own; everybody else 0
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) w_own += shfl64(w_own, lane ^ off);
+    }
+    wave_best(best_s, best_c);
+    if (lane == 0) {
+        const double own_score = (double)w_own * m2d - (gamma * (double)((int64_t)tot[own] - kvi)) * kv;
+        int32_t target = own;
+        if (best_c >= 0 && best_s > own_score && !(size[own] == 1 && size[best_c] == 1 && best_c > own)) target = best_c;
+        next[v] = target;
+    }
+}
+
+__global__ void k_lv_used(const int32_t* __restrict__ comm, int64_t n, int32_t* __restrict__ used) {
+    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < n) used[comm[v]] = 1;
+}
+
+__global__ void k_lv_member(const int32_t* __restrict__ comm, const int32_t* __restrict__ renum, int64_t n, int32_t* __restrict__ member) {
+    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < n) member[v] = renum[comm[v]];
+}
+
+__global__ void __launch_bounds__(256) k_lv_edge_keys(const int64_t* __restrict__ indptr, const int32_t* __restrict__ cols,
+                                                      const int32_t* __restrict__ member, int64_t n, uint64_t* __restrict__ keys) {
+    const int lane = threadIdx.x & 63;
+    const int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (v >= n) return;
+    const uint64_t hi = (uint64_t)member[v] << 32;
+    for (int64_t p = indptr[v] + lane; p < indptr[v + 1]; p += 64) keys[p] = hi | (uint32_t)member[cols[p]];
+}
+
+__global__ void k_lv_rowptr(const uint64_t* __restrict__ keys, int64_t n, int64_t rows, int64_t* __restrict__ indptr) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > rows) return;
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if ((int64_t)(keys[mid] >> 32) < r) lo = mid + 1; else hi = mid;
+    }
+    indptr[r] = lo;
+}
+
+__global__ void k_lv_unpack(const uint64_t* __restrict__ keys, const int64_t* __restrict__ sums, int64_t n, int32_t* __restrict__ cols,
+                            double* __restrict__ w) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    cols[t] = (int32_t)(keys[t] & 0xffffffffull);
+    w[t] = (double)sums[t] / kWeightScale;
+}
+
+int stage_coarsen_graph(ddx_ctx* ctx, double gamma, int32_t sweeps) {
+    const int64_t n = ctx->g_nodes;
+    const int64_t E = ctx->g_entries;
+    ctx->c_nodes = -1;
+    // workspace: wq i64[E] | keys u64[E] x2 | vals i64[E] | sums i64[E] | K i64[n] | tot u64[n] | indptr i64[n+1] | comm,next,size,used,renum,member i32[n]
+    //            | cols i32[E] | w f64[E] | scalars
+    const size_t bytes = sizeof(int64_t) * (size_t)E * 5 + sizeof(int64_t) * (size_t)(3 * n + 8) + sizeof(int32_t) * (size_t)(6 * n + 8) +
+                         (sizeof(int32_t) + sizeof(double)) * (size_t)E + 64 * 256;
+    DDX_TRY(ensure(ctx, ctx->lv_buf, bytes));
+    unsigned char* base = ctx->lv_buf.as<unsigned char>();
+    auto carve = [&](size_t sz) { unsigned char* p = base; base += (sz + 255) & ~(size_t)255; return p; };
+    int64_t* wq = reinterpret_cast<int64_t*>(carve(sizeof(int64_t) * E));
+    uint64_t* keys_a = reinterpret_cast<uint64_t*>(carve(sizeof(uint64_t) * E));
+    uint64_t* keys_b = reinterpret_cast<uint64_t*>(carve(sizeof(uint64_t) * E));
+    int64_t* vals_b = reinterpret_cast<int64_t*>(carve(sizeof(int64_t) * E));
+    int64_t* sums = reinterpret_cast<int64_t*>(carve(sizeof(int64_t) * E));
+    int64_t* K = reinterpret_cast<int64_t*>(carve(sizeof(int64_t) * n));
+    unsigned long long* tot = reinterpret_cast<unsigned long long*>(carve(sizeof(int64_t) * n));
+    int64_t* c_indptr = reinterpret_cast<int64_t*>(carve(sizeof(int64_t) * (n + 1)));
+    int32_t* comm = reinterpret_cast<int32_t*>(carve(sizeof(int32_t) * n));
+    int32_t* next = reinterpret_cast<int32_t*>(carve(sizeof(int32_t) * n));
+    int32_t* size = reinterpret_cast<int32_t*>(carve(sizeof(int32_t) * n));
+    int32_t* used = reinterpret_cast<int32_t*>(carve(sizeof(int32_t) * (n + 1)));
+    int32_t* renum = reinterpret_cast<int32_t*>(carve(sizeof(int32_t) * (n + 1)));
+    int32_t* member = reinterpret_cast<int32_t*>(carve(sizeof(int32_t) * n));
+    int32_t* c_cols = reinterpret_cast<int32_t*>(carve(sizeof(int32_t) * E));
+    double* c_w = reinterpret_cast<double*>(carve(sizeof(double) * E));
+    unsigned long long* scal = reinterpret_cast<unsigned long long*>(carve(256));   // [0] = 2m, [1] = max degree, [2] = runs
+    hipStream_t st = ctx->stream;
+    ScopedTimer t(ctx, "graph_coarsen");
+    DDX_HIP(ctx, hipMemsetAsync(scal, 0, 256, st));
+    if (E > 0) k_lv_quantise<<<(unsigned)ceil_div(E, 256), 256, 0, st>>>(ctx->g_d_vals, E, wq);
+    k_lv_strength<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(ctx->g_d_indptr, wq, n, K, comm, scal, reinterpret_cast<int32_t*>(scal + 1));
+    unsigned long long h_scal[2] = {0, 0};
+    DDX_HIP(ctx, hipMemcpyAsync(h_scal, scal, sizeof(h_scal), hipMemcpyDeviceToHost, st));
+    DDX_HIP(ctx, hipStreamSynchronize(st));
+    const int64_t m2 = (int64_t)h_scal[0];
+    const int32_t maxdeg = (int32_t)(h_scal[1] & 0xffffffffull);
+    if (maxdeg > kLvCap) return set_err(ctx, DDX_E_UNSUPPORTED, "a node with %d neighbours exceeds the device sweep's capacity (%d)", maxdeg, kLvCap);
+    int32_t* cur = comm;
+    int32_t* nxt = next;
+    for (int s = 0; s < sweeps && m2 > 0; ++s) {
+        DDX_HIP(ctx, hipMemsetAsync(tot, 0, sizeof(int64_t) * n, st));
+        DDX_HIP(ctx, hipMemsetAsync(size, 0, sizeof(int32_t) * n, st));
+        k_lv_totals<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(cur, K, n, tot, size);
+        k_lv_sweep<<<(unsigned)ceil_div(n, 4), 256, 0, st>>>(ctx->g_d_indptr, ctx->g_d_cols, wq, K, cur, tot, size, n, gamma, (double)m2, nxt);
+        std::swap(cur, nxt);      // a sweep that moves nothing reproduces its input, so running all of them equals stopping early
+    }
+    // renumber the surviving communities by ascending id
+    DDX_HIP(ctx, hipMemsetAsync(used, 0, sizeof(int32_t) * (n + 1), st));
+    k_lv_used<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(cur, n, used);
+    size_t tmp_scan = 0, tmp_sort = 0, tmp_red = 0;
+    DDX_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_scan, used, renum, (int)n + 1, st));
+    int end_bit = 33;
+    while (((int64_t)1 << (end_bit - 32)) < n) ++end_bit;
+    if (E > 0) {
+        DDX_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_sort, keys_a, keys_b, wq, vals_b, (int)E, 0, end_bit, st));
+        DDX_HIP(ctx, hipcub::DeviceReduce::ReduceByKey(nullptr, tmp_red, keys_b, keys_a, vals_b, sums, reinterpret_cast<int64_t*>(scal + 2), hipcub::Sum(), (int)E, st));
+    }
+    DDX_TRY(ensure(ctx, ctx->sort_tmp, std::max(tmp_scan, std::max(tmp_sort, tmp_red))));
+    DDX_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(ctx->sort_tmp.p, tmp_scan, used, renum, (int)n + 1, st));
+    k_lv_member<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(cur, renum, n, member);
+    int64_t runs = 0;
+    if (E > 0) {
+        k_lv_edge_keys<<<(unsigned)ceil_div(n, 4), 256, 0, st>>>(ctx->g_d_indptr, ctx->g_d_cols, member, n, keys_a);
+        DDX_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(ctx->sort_tmp.p, tmp_sort, keys_a, keys_b, wq, vals_b, (int)E, 0, end_bit, st));
+        DDX_HIP(ctx, hipcub::DeviceReduce::ReduceByKey(ctx->sort_tmp.p, tmp_red, keys_b, keys_a, vals_b, sums, reinterpret_cast<int64_t*>(scal + 2), hipcub::Sum(), (int)E, st));
+    }
+    int32_t nc = 0;
+    DDX_HIP(ctx, hipMemcpyAsync(&nc, renum + n, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    DDX_HIP(ctx, hipMemcpyAsync(&runs, scal + 2, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    DDX_HIP(ctx, hipStreamSynchronize(st));
+    if (E == 0) runs = 0;
+    if (runs > 0) k_lv_unpack<<<(unsigned)ceil_div(runs, 256), 256, 0, st>>>(keys_a, sums, runs, c_cols, c_w);
+    k_lv_rowptr<<<(unsigned)ceil_div((int64_t)nc + 1, 256), 256, 0, st>>>(keys_a, runs, nc, c_indptr);
+    DDX_HIP(ctx, hipGetLastError());
+    ctx->c_nodes = nc;
+    ctx->c_entries = runs;
+    ctx->c_d_member = member;
+    ctx->c_d_indptr = c_indptr;
+    ctx->c_d_cols = c_cols;
+    ctx->c_d_vals = c_w;
+    return DDX_OK;
+}
+
+}  // namespace ddx

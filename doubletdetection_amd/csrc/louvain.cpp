@@ -6,6 +6,7 @@
 // Compiled with -ffp-contract=off so that no multiply-add is fused.
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -217,22 +218,126 @@ void aggregate(const Graph& g, const std::vector<int32_t>& comm, Graph& out, std
     }
 }
 
-}  // namespace
+// ------------------------------------------------------------------------------------------------
+// Part A of the specification (oracle/louvain_ref.py:presweep): synchronous sweeps on integer-quantised
+// weights, then exact aggregation.  This is the host statement of what k_louvain.hip runs on the GPU.
+// ------------------------------------------------------------------------------------------------
+constexpr double kWeightScale = 1048576.0;   // 2^20
 
-extern "C" int ddx_louvain(int64_t n_nodes, const int64_t* indptr, const int32_t* indices, const double* weights,
-                           double gamma, uint64_t seed, int32_t* labels_out, double* quality_out) {
-    if (n_nodes < 0 || !indptr || !labels_out) return DDX_E_ARG;
-    if (n_nodes == 0) return DDX_OK;
-    const int64_t nnz = indptr[n_nodes];
-    if (nnz > 0 && (!indices || !weights)) return DDX_E_ARG;
-    Graph g;
-    g.indptr.assign(indptr, indptr + n_nodes + 1);
-    g.indices.assign(indices, indices + nnz);
-    g.weights.assign(weights, weights + nnz);
-    for (int64_t e = 0; e < nnz; ++e)
-        if (g.indices[e] < 0 || g.indices[e] >= n_nodes) return DDX_E_ARG;
+void presweep(const Graph& g, double gamma, int sweeps, std::vector<int32_t>& member, Graph& coarse) {
+    const int64_t n = g.n();
+    const int64_t nnz = (int64_t)g.indices.size();
+    std::vector<int64_t> wq(nnz);
+    for (int64_t e = 0; e < nnz; ++e) wq[e] = (int64_t)std::nearbyint(g.weights[e] * kWeightScale);
+    std::vector<int64_t> K(n, 0);
+    int64_t m2 = 0;
+    for (int64_t v = 0; v < n; ++v) {
+        int64_t s = 0;
+        for (int64_t e = g.indptr[v]; e < g.indptr[v + 1]; ++e) s += wq[e];
+        K[v] = s;
+        m2 += s;
+    }
+    std::vector<int32_t> comm(n), next(n);
+    for (int64_t v = 0; v < n; ++v) comm[v] = (int32_t)v;
+    std::vector<int64_t> tot(n), acc(n, -1);
+    std::vector<int32_t> size(n), seen;
+    for (int sweep = 0; sweep < sweeps && m2 > 0; ++sweep) {
+        std::fill(tot.begin(), tot.end(), 0);
+        std::fill(size.begin(), size.end(), 0);
+        for (int64_t v = 0; v < n; ++v) {
+            tot[comm[v]] += K[v];
+            size[comm[v]]++;
+        }
+        int64_t moves = 0;
+        const double m2d = (double)m2;
+        for (int64_t v = 0; v < n; ++v) {
+            const int32_t own = comm[v];
+            seen.clear();
+            for (int64_t e = g.indptr[v]; e < g.indptr[v + 1]; ++e) {
+                const int32_t u = g.indices[e];
+                if (u == v) continue;
+                const int32_t c = comm[u];
+                if (acc[c] < 0) {
+                    acc[c] = 0;
+                    seen.push_back(c);
+                }
+                acc[c] += wq[e];
+            }
+            const double kv = (double)K[v];
+            const int64_t w_own = acc[own] < 0 ? 0 : acc[own];
+            const double own_score = (double)w_own * m2d - (gamma * (double)(tot[own] - K[v])) * kv;
+            int32_t best = -1;
+            double best_score = 0.0;
+            for (int32_t c : seen) {
+                if (c == own) continue;
+                const double sc = (double)acc[c] * m2d - (gamma * (double)tot[c]) * kv;
+                if (best < 0 || sc > best_score || (sc == best_score && c < best)) {
+                    best = c;
+                    best_score = sc;
+                }
+            }
+            for (int32_t c : seen) acc[c] = -1;
+            int32_t target = own;
+            if (best >= 0 && best_score > own_score && !(size[own] == 1 && size[best] == 1 && best > own)) {
+                target = best;
+                ++moves;
+            }
+            next[v] = target;
+        }
+        if (moves == 0) break;
+        comm.swap(next);
+    }
+    // exact aggregation; coarse nodes numbered by ascending community id
+    std::vector<int32_t> renum(n, -1);
+    for (int64_t v = 0; v < n; ++v) renum[comm[v]] = 0;
+    int32_t k = 0;
+    for (int64_t c = 0; c < n; ++c)
+        if (renum[c] == 0) renum[c] = k++;
+    member.resize(n);
+    for (int64_t v = 0; v < n; ++v) member[v] = renum[comm[v]];
+    std::vector<int64_t> start(k + 1, 0);
+    for (int64_t v = 0; v < n; ++v) start[member[v] + 1]++;
+    for (int32_t c = 0; c < k; ++c) start[c + 1] += start[c];
+    std::vector<int32_t> members(n);
+    {
+        std::vector<int64_t> cur(start.begin(), start.end() - 1);
+        for (int64_t v = 0; v < n; ++v) members[cur[member[v]]++] = (int32_t)v;
+    }
+    coarse.indptr.assign(1, 0);
+    coarse.indices.clear();
+    coarse.weights.clear();
+    std::vector<int64_t> sum(k, 0);
+    std::vector<char> touched(k, 0);
+    std::vector<int32_t> tl;
+    for (int32_t cn = 0; cn < k; ++cn) {
+        tl.clear();
+        for (int64_t mi = start[cn]; mi < start[cn + 1]; ++mi) {
+            const int32_t v = members[mi];
+            for (int64_t e = g.indptr[v]; e < g.indptr[v + 1]; ++e) {
+                const int32_t t = member[g.indices[e]];
+                if (!touched[t]) {
+                    touched[t] = 1;
+                    tl.push_back(t);
+                    sum[t] = 0;
+                }
+                sum[t] += wq[e];
+            }
+        }
+        std::sort(tl.begin(), tl.end());
+        for (int32_t t : tl) {
+            coarse.indices.push_back(t);
+            coarse.weights.push_back((double)sum[t] / kWeightScale);
+            touched[t] = 0;
+        }
+        coarse.indptr.push_back((int64_t)coarse.indices.size());
+    }
+}
+
+// Part B: multi-level sequential optimisation; labels numbered by ascending representative id
+void sequential_levels(Graph& g, double gamma, uint64_t seed, std::vector<int32_t>& membership, double* q_out) {
+    const int64_t n_nodes = g.n();
     SplitMix64 rng(seed);
-    std::vector<int32_t> membership(n_nodes);
+    membership.resize(n_nodes);
     for (int64_t v = 0; v < n_nodes; ++v) membership[v] = (int32_t)v;
     std::vector<int32_t> comm, renum;
     double q = 0.0;
@@ -256,8 +361,71 @@ extern "C" int ddx_louvain(int64_t n_nodes, const int64_t* indptr, const int32_t
         g.weights.swap(next.weights);
         if (!improved) break;
     }
+    if (q_out) *q_out = q;
+}
+
+int load_graph(int64_t n_nodes, const int64_t* indptr, const int32_t* indices, const double* weights, Graph& g) {
+    if (n_nodes < 0 || !indptr) return DDX_E_ARG;
+    const int64_t nnz = n_nodes ? indptr[n_nodes] : 0;
+    if (nnz > 0 && (!indices || !weights)) return DDX_E_ARG;
+    g.indptr.assign(indptr, indptr + n_nodes + 1);
+    g.indices.assign(indices, indices + nnz);
+    g.weights.assign(weights, weights + nnz);
+    for (int64_t e = 0; e < nnz; ++e)
+        if (g.indices[e] < 0 || g.indices[e] >= n_nodes) return DDX_E_ARG;
+    return DDX_OK;
+}
+
+}  // namespace
+
+extern "C" int ddx_louvain_sequential(int64_t n_nodes, const int64_t* indptr, const int32_t* indices, const double* weights,
+                                      double gamma, uint64_t seed, int32_t* labels_out, double* quality_out) {
+    if (!labels_out) return DDX_E_ARG;
+    if (n_nodes == 0) return DDX_OK;
+    Graph g;
+    const int rc = load_graph(n_nodes, indptr, indices, weights, g);
+    if (rc != DDX_OK) return rc;
+    std::vector<int32_t> membership;
+    sequential_levels(g, gamma, seed, membership, quality_out);
     for (int64_t v = 0; v < n_nodes; ++v) labels_out[v] = membership[v];
-    if (quality_out) *quality_out = q;
+    return DDX_OK;
+}
+
+extern "C" int ddx_presweep(int64_t n_nodes, const int64_t* indptr, const int32_t* indices, const double* weights, double gamma,
+                            int32_t sweeps, int32_t* member_out, int64_t* n_coarse_out, int64_t* c_indptr_out,
+                            int32_t* c_indices_out, double* c_weights_out) {
+    if (!member_out || !n_coarse_out || !c_indptr_out) return DDX_E_ARG;
+    *n_coarse_out = 0;
+    if (n_nodes == 0) { c_indptr_out[0] = 0; return DDX_OK; }
+    Graph g, coarse;
+    const int rc = load_graph(n_nodes, indptr, indices, weights, g);
+    if (rc != DDX_OK) return rc;
+    std::vector<int32_t> member;
+    presweep(g, gamma, sweeps, member, coarse);
+    const int64_t nc = coarse.n();
+    *n_coarse_out = nc;
+    for (int64_t v = 0; v < n_nodes; ++v) member_out[v] = member[v];
+    for (int64_t c = 0; c <= nc; ++c) c_indptr_out[c] = coarse.indptr[c];
+    const int64_t cnnz = (int64_t)coarse.indices.size();
+    if (cnnz > 0 && (!c_indices_out || !c_weights_out)) return DDX_E_ARG;
+    for (int64_t e = 0; e < cnnz; ++e) {
+        c_indices_out[e] = coarse.indices[e];
+        c_weights_out[e] = coarse.weights[e];
+    }
+    return DDX_OK;
+}
+
+extern "C" int ddx_louvain(int64_t n_nodes, const int64_t* indptr, const int32_t* indices, const double* weights,
+                           double gamma, uint64_t seed, int32_t* labels_out, double* quality_out) {
+    if (!labels_out) return DDX_E_ARG;
+    if (n_nodes == 0) return DDX_OK;
+    Graph g, coarse;
+    const int rc = load_graph(n_nodes, indptr, indices, weights, g);
+    if (rc != DDX_OK) return rc;
+    std::vector<int32_t> member, membership;
+    presweep(g, gamma, DDX_PRESWEEPS, member, coarse);
+    sequential_levels(coarse, gamma, seed, membership, quality_out);
+    for (int64_t v = 0; v < n_nodes; ++v) labels_out[v] = membership[member[v]];
     return DDX_OK;
 }
 

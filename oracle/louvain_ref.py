@@ -10,7 +10,19 @@ unpinned.**  What *is* pinned is this specification: the product's host C++ impl
 (``doubletdetection_amd/csrc/louvain.cpp``) must reproduce it bit-for-bit (same visiting order,
 same float64 operation order, no FMA contraction), which ``tests/test_louvain.py`` checks.
 
-Algorithm (the published multi-level modularity optimisation with a resolution parameter):
+Algorithm (the published multi-level modularity optimisation with a resolution parameter), in two parts.
+
+**Part A -- synchronous pre-sweeps** (``presweep``; what the GPU runs, cf. the parallel Louvain variants of
+Lu, Halappanavar, Kalyanaraman 2015 and Naim et al. 2017).  Weights are quantised to integers
+``wq = rint(w * 2**20)`` so that every sum below is exact and independent of summation order.  For
+``PRESWEEPS`` sweeps (stopping early when nothing moves) *all* nodes decide at once from the same state:
+``score(v, c) = W(v,c) * 2m  -  gamma * (tot_c - [c == own] k_v) * k_v`` (float64, this operation order), the
+best community among the neighbours' communities (ties: smaller id) is taken if its score is strictly larger than
+staying, except that a node that is alone in its community does not move to another lone node with a larger id
+(the minimum-label rule that prevents two singletons from swapping for ever).  The communities are then
+aggregated exactly (integer sums, renumbered by ascending id).
+
+**Part B -- sequential multi-level optimisation** of the aggregated graph:
 
 * quality  Q = sum_c [ in_c / 2m  -  gamma * (tot_c / 2m)^2 ]   (RB-configuration form; gamma=1 is
   Newman-Girvan modularity as in PhenoGraph, gamma=4 is what dd.py:417-420 passes to scanpy);
@@ -30,6 +42,73 @@ import numpy as np
 
 _MASK = 0xFFFFFFFFFFFFFFFF
 MIN_GAIN = 1e-6
+PRESWEEPS = 6
+WEIGHT_SCALE = float(1 << 20)
+
+
+def presweep(indptr, indices, weights, gamma: float = 1.0, sweeps: int = PRESWEEPS):
+    """Part A.  Returns (member, c_indptr, c_indices, c_weights): member[v] = coarse node of v (numbered by
+    ascending community id) and the aggregated graph with float64 weights (integer sums / 2**20)."""
+    indptr = np.asarray(indptr, dtype=np.int64)
+    indices = np.asarray(indices, dtype=np.int64)
+    n = len(indptr) - 1
+    wq = np.rint(np.asarray(weights, dtype=np.float64) * WEIGHT_SCALE).astype(np.int64)
+    rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(indptr))
+    K = np.zeros(n, dtype=np.int64)
+    np.add.at(K, rows, wq)
+    m2 = int(K.sum())
+    comm = np.arange(n, dtype=np.int64)
+    noself = rows != indices
+    r_ns, u_ns, w_ns = rows[noself], indices[noself], wq[noself]
+    gamma = float(gamma)
+    for _ in range(int(sweeps) if m2 > 0 else 0):
+        tot = np.zeros(n, dtype=np.int64)
+        np.add.at(tot, comm, K)
+        size = np.bincount(comm, minlength=n)
+        if len(r_ns) == 0:
+            break
+        key = r_ns * n + comm[u_ns]                       # (node, neighbour community)
+        order = np.argsort(key, kind="stable")
+        ks, ws = key[order], w_ns[order]
+        first = np.concatenate([[True], ks[1:] != ks[:-1]])
+        W = np.add.reduceat(ws, np.flatnonzero(first))    # exact integer sums
+        kv, kc = ks[first] // n, ks[first] % n
+        own = kc == comm[kv]
+        own_w = np.zeros(n, dtype=np.int64)
+        own_w[kv[own]] = W[own]
+        kvf = K.astype(np.float64)
+        own_score = own_w.astype(np.float64) * float(m2) - (gamma * (tot[comm] - K).astype(np.float64)) * kvf
+        cand = ~own
+        cv, cc, cw = kv[cand], kc[cand], W[cand]
+        score = cw.astype(np.float64) * float(m2) - (gamma * tot[cc].astype(np.float64)) * kvf[cv]
+        o2 = np.lexsort((cc, -score, cv))                 # per node: best score first, ties by smaller community
+        cv2 = cv[o2]
+        f2 = np.concatenate([[True], cv2[1:] != cv2[:-1]]) if len(cv2) else np.zeros(0, dtype=bool)
+        bv, bc, bs = cv2[f2], cc[o2][f2], score[o2][f2]
+        move = bs > own_score[bv]
+        lone = (size[comm[bv]] == 1) & (size[bc] == 1) & (bc > comm[bv])
+        move &= ~lone
+        if not move.any():
+            break
+        new_comm = comm.copy()
+        new_comm[bv[move]] = bc[move]
+        comm = new_comm
+    used, member = np.unique(comm, return_inverse=True)
+    nc = len(used)
+    ckey = member[rows] * nc + member[indices]
+    order = np.argsort(ckey, kind="stable")
+    ks, ws = ckey[order], wq[order]
+    if len(ks):
+        first = np.concatenate([[True], ks[1:] != ks[:-1]])
+        W = np.add.reduceat(ws, np.flatnonzero(first))
+        cr, ccol = ks[first] // nc, ks[first] % nc
+    else:
+        W = np.zeros(0, dtype=np.int64)
+        cr = ccol = np.zeros(0, dtype=np.int64)
+    c_indptr = np.zeros(nc + 1, dtype=np.int64)
+    np.add.at(c_indptr, cr + 1, 1)
+    c_indptr = np.cumsum(c_indptr)
+    return member.astype(np.int64), c_indptr, ccol.astype(np.int64), W.astype(np.float64) / WEIGHT_SCALE
 
 
 class SplitMix64:
@@ -161,8 +240,17 @@ def _aggregate(indptr, indices, weights, comm):
     return new_indptr, new_indices, new_weights, renum
 
 
-def louvain(indptr, indices, weights, gamma: float = 1.0, seed: int = 0) -> np.ndarray:
+def louvain(indptr, indices, weights, gamma: float = 1.0, seed: int = 0, presweeps: int = PRESWEEPS) -> np.ndarray:
     """Community label per node (0..K-1, numbered by ascending representative id)."""
+    member = None
+    if presweeps > 0:
+        member, indptr, indices, weights = presweep(indptr, indices, weights, gamma, presweeps)
+    lab = _louvain_sequential(indptr, indices, weights, gamma, seed)
+    return lab if member is None else lab[member]
+
+
+def _louvain_sequential(indptr, indices, weights, gamma: float = 1.0, seed: int = 0) -> np.ndarray:
+    """Part B."""
     indptr = [int(x) for x in np.asarray(indptr)]
     indices = [int(x) for x in np.asarray(indices)]
     weights = [float(x) for x in np.asarray(weights, dtype=np.float64)]

@@ -8,6 +8,7 @@ import scipy.sparse as sp
 
 from conftest import CASES, csr_from, golden_kwargs, load_golden
 from oracle import dd_oracle as orc
+from oracle import louvain_ref
 
 pytestmark = pytest.mark.gpu
 
@@ -263,6 +264,52 @@ def test_graphs(ctx, case):
     np.testing.assert_array_equal(ip, G.indptr)
     np.testing.assert_array_equal(ix, G.indices)
     np.testing.assert_array_equal(w, G.data)
+
+
+@pytest.mark.parametrize("case", ["case_a_hvg_pheno", "case_b_transposed_louvain"])
+def test_device_presweeps_match_host(ctx, case):
+    """Part A of the community detection on the device (ddx_coarsen_graph) against the host statement and the
+    Python specification: member table and aggregated graph bit for bit, for every graph type and both gammas."""
+    from doubletdetection_amd import _lib
+
+    g = load_golden(case)
+    ctx.set_embedding(g["pca_f32"][0])
+    for k, self_, mode, gamma in ((30, False, 0, 1.0), (30, False, 1, 1.0), (10, True, 2, 4.0), (10, True, 2, 1.0)):
+        ctx.knn(k, self_)
+        ip, ix, w = ctx.build_graph(mode)
+        for sweeps in (1, _lib.PRESWEEPS):
+            m_dev, ip_dev, ix_dev, w_dev = ctx.coarsen_graph(gamma, sweeps)
+            m_host, ip_host, ix_host, w_host = _lib.presweep(ip, ix, w, gamma, sweeps)
+            np.testing.assert_array_equal(m_dev, m_host)
+            np.testing.assert_array_equal(ip_dev, ip_host)
+            np.testing.assert_array_equal(ix_dev, ix_host)
+            np.testing.assert_array_equal(w_dev, w_host)
+        m_ref, ip_ref, ix_ref, w_ref = louvain_ref.presweep(ip, ix, w, gamma)
+        np.testing.assert_array_equal(m_dev, m_ref)
+        np.testing.assert_array_equal(w_dev, w_ref)
+        # device A + host B = host A + B
+        lab = _lib.louvain_sequential(ip_dev, ix_dev, w_dev, gamma, 3)[0][m_dev]
+        np.testing.assert_array_equal(lab, _lib.louvain(ip, ix, w, gamma, 3)[0])
+
+
+def test_device_presweeps_high_degree_nodes(ctx):
+    """Nodes with more than 64 neighbours take the LDS path of the sweep kernel; a star-heavy graph exercises it."""
+    from doubletdetection_amd import _lib
+
+    rng = np.random.default_rng(11)
+    n = 3000
+    emb = rng.normal(size=(n, 8)).astype(np.float32)
+    emb[:40] *= 0.02                                          # a tight core that ends up in everybody's neighbour list
+    ctx.set_embedding(emb)
+    ctx.knn(30, False)
+    ip, ix, w = ctx.build_graph(1)
+    assert np.diff(ip).max() > 64
+    m_dev, ip_dev, ix_dev, w_dev = ctx.coarsen_graph(1.0)
+    m_host, ip_host, ix_host, w_host = _lib.presweep(ip, ix, w, 1.0)
+    np.testing.assert_array_equal(m_dev, m_host)
+    np.testing.assert_array_equal(ip_dev, ip_host)
+    np.testing.assert_array_equal(ix_dev, ix_host)
+    np.testing.assert_array_equal(w_dev, w_host)
 
 
 # ---- whole fit -------------------------------------------------------------------------------------------

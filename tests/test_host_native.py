@@ -63,9 +63,36 @@ def test_louvain_matches_python_specification_bit_for_bit(n, k, seed, weighted, 
     ref = louvain_ref.louvain(A.indptr, A.indices, A.data, gamma, seed)
     got, q = _lib.louvain(A.indptr, A.indices, A.data, gamma, seed)
     np.testing.assert_array_equal(got.astype(np.int64), ref)
-    assert abs(q - louvain_ref.modularity(A.indptr, A.indices, A.data, ref, gamma)) < 1e-9
+    # q is evaluated on the aggregated graph, whose weights are multiples of 2^-20
+    assert abs(q - louvain_ref.modularity(A.indptr, A.indices, A.data, ref, gamma)) < 1e-5
     # sanity: it finds structure
     assert len(np.unique(got)) < n
+
+
+@pytest.mark.parametrize("n,k,seed,weighted,gamma", [(300, 6, 2, True, 1.0), (800, 5, 123, False, 4.0), (2000, 10, 9, True, 1.0)])
+def test_presweep_and_sequential_parts_match_specification(n, k, seed, weighted, gamma):
+    """Part A (synchronous sweeps + exact aggregation) and part B (sequential levels) separately, and A o B = whole."""
+    A = _random_graph(n, k, seed, weighted)
+    m_ref, ip_ref, ix_ref, w_ref = louvain_ref.presweep(A.indptr, A.indices, A.data, gamma)
+    m, ip, ix, w = _lib.presweep(A.indptr, A.indices, A.data, gamma)
+    np.testing.assert_array_equal(m, m_ref)
+    np.testing.assert_array_equal(ip, ip_ref)
+    np.testing.assert_array_equal(ix, ix_ref)
+    np.testing.assert_array_equal(w, w_ref)
+    assert len(ip) - 1 < n                                   # it does coarsen
+    for sweeps in (0, 1, 3):
+        ms, ips, ixs, ws = _lib.presweep(A.indptr, A.indices, A.data, gamma, sweeps)
+        mr, ipr, ixr, wr = louvain_ref.presweep(A.indptr, A.indices, A.data, gamma, sweeps)
+        np.testing.assert_array_equal(ms, mr)
+        np.testing.assert_array_equal(ws, wr)
+    seq, _ = _lib.louvain_sequential(ip, ix, w, gamma, seed)
+    np.testing.assert_array_equal(seq.astype(np.int64), louvain_ref._louvain_sequential(ip_ref, ix_ref, w_ref, gamma, seed))
+    whole, _ = _lib.louvain(A.indptr, A.indices, A.data, gamma, seed)
+    np.testing.assert_array_equal(whole, seq[m])
+    # the pre-sweeps cost no modularity worth mentioning against the purely sequential optimisation
+    q_whole = louvain_ref.modularity(A.indptr, A.indices, A.data, whole, gamma)
+    q_seq = louvain_ref.modularity(A.indptr, A.indices, A.data, _lib.louvain_sequential(A.indptr, A.indices, A.data, gamma, seed)[0], gamma)
+    assert q_whole > q_seq - 0.02
 
 
 def test_louvain_edge_cases():
