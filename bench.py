@@ -37,6 +37,7 @@ PMC_TRAFFIC_GB = {"spmm_rows": 1.03, "spmm_cols": 1.07, "knn_emit": 0.87, "knn_b
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md)
 FP64_PEAK_TFLOPS = 78.6      # FP64 vector / FP64 MFMA peak, dense
 FP32_PEAK_TFLOPS = 157.3
+BF16_PEAK_TFLOPS = 2500.0     # dense bf16 MFMA peak (MI355X_MICROARCH.md; not the 2:1-sparsity figure)
 
 
 def parse():
@@ -69,8 +70,9 @@ def kernel_models(N, G, H, S, nnz_aug, C, k, L=None):
         # name: (bound, unit, work per launch, peak)
         "spmm_rows": ("hbm", "GB/s", (8 * nnz_aug + 8 * M * L + 8 * H * L + 8 * (M + 1)) / 1e9, HBM_PEAK_GBS),
         "spmm_cols": ("hbm", "GB/s", (8 * nnz_aug + 8 * H * L + 8 * M * L + 16 * (H + 1)) / 1e9, HBM_PEAK_GBS),
-        "knn_emit": ("mfma", "TFLOP/s", 2.0 * Mp * Mp * CP / 1e12, FP32_PEAK_TFLOPS),
-        "knn_bound": ("mfma", "TFLOP/s", 2.0 * Mp * nsamp_tiles * 16 * CP / 1e12, FP32_PEAK_TFLOPS),
+        # distance screen on the bfloat16 MFMA: three products (hi*hi, hi*lo, lo*hi) per pair and component
+        "knn_emit": ("mfma", "TFLOP/s", 3 * 2.0 * Mp * Mp * CP / 1e12, BF16_PEAK_TFLOPS),
+        "knn_bound": ("mfma", "TFLOP/s", 3 * 2.0 * Mp * nsamp_tiles * 16 * CP / 1e12, BF16_PEAK_TFLOPS),
         "pca_orth": ("hbm", "GB/s", (24 * M * L) / 1e9, HBM_PEAK_GBS),
         "doublet_fill": ("hbm", "GB/s", (8 * (nnz_aug * 2 * S / max(M + S, 1)) * 2) / 1e9, HBM_PEAK_GBS),
         "lognorm_rows": ("hbm", "GB/s", (8 * nnz_aug + 8 * M) / 1e9, HBM_PEAK_GBS),

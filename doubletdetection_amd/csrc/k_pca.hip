@@ -365,9 +365,16 @@ __global__ void __launch_bounds__(1024) k_spmm_lds(const LdsSpmmArgs a) {
             const int nvec = (nr * a.ld + 3) >> 2;
             const f4v* src = reinterpret_cast<const f4v*>(a.op + r0 * a.ld);
             f4v* dst = reinterpret_cast<f4v*>(opS);
-            for (int i = threadIdx.x; i < nvec; i += 1024) dst[i] = src[i];
+            // asynchronous global -> LDS copy (16 bytes per lane, LDS destination = wave-uniform base + lane*16):
+            // all of a wave's pieces are in flight together and no register is tied up
+            for (int base = wave * 64; base < nvec; base += 1024) {
+                if (base + lane < nvec)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + base + lane),
+                                                     (__attribute__((address_space(3))) void*)(dst + base), 16, 0, 0);
+            }
             if (ROWS)
                 for (int i = threadIdx.x; i < nr; i += 1024) zS[i] = a.zcol[r0 + i];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();
         // COLS: the entries of a slice come from the mirror of the original rows, of the synthetic rows, or (the
