@@ -32,17 +32,21 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 //       hi = bf16(a) and lo = bf16(a - hi); for tile t, 32-component block kb and part p (0 = hi, 1 = lo)
 //       lane l = ((d % 32) / 8) * 16 + j holds components d = 32*kb + 8*(l>>4) + 0..7 of point 16*t + j as
 //       8 consecutive bf16 at Eb[(((t*KB + kb)*2 + p)*64 + l)*8], i.e. one coalesced 1 KB load per operand.
-__global__ void k_knn_prepare(const float* __restrict__ in, int64_t M, int64_t Mp, int C, int CP,
+// Points are laid out in the order `perm` (ascending first principal component, see stage_knn): row r of every
+// layout is embedding row perm[r];  p1[r] = its first component (+inf for padding rows).
+__global__ void k_knn_prepare(const float* __restrict__ in, const int32_t* __restrict__ perm, int64_t M, int64_t Mp, int C, int CP,
                               float* __restrict__ E, float* __restrict__ Et, __bf16* __restrict__ Eb,
-                              float* __restrict__ nrm) {
+                              float* __restrict__ nrm, float* __restrict__ p1) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= Mp) return;
+    const int64_t src = r < M ? perm[r] : 0;
+    p1[r] = r < M ? in[src * C] : __builtin_huge_valf();
     float n = 0.f;
     const int64_t tile = r >> 4;
     const int j = (int)(r & 15);
     const int KB = CP / 32;
     for (int d = 0; d < CP; ++d) {
-        const float v = (r < M && d < C) ? in[r * C + d] : 0.f;
+        const float v = (r < M && d < C) ? in[src * C + d] : 0.f;
         E[r * CP + d] = v;
         Et[tile * 16 * CP + (d >> 2) * 64 + (d & 3) * 16 + j] = v;
         const __bf16 hi = (__bf16)v;
@@ -165,16 +169,22 @@ __global__ void __launch_bounds__(256) k_knn_bound(const float* __restrict__ Et,
         for (int t = 0; t < kBoundKeep; ++t) best[v][t] = __builtin_huge_valf();
     const int64_t own_tile = q0 >> 4;
     const int64_t nchunks = (nsamp_tiles + kChunkTiles - 1) / kChunkTiles;
-    TileStage<CP> st;
-    st.fetch(Et, nrm, 0, nsamp_tiles, tile_stride, tid);
+        // sample = the nsamp_tiles tiles around this block in first-component order (contiguous, see stage_knn)
+    int64_t tile0 = (((int64_t)blockIdx.x * 4) * RT) + 2 * RT - nsamp_tiles / 2;
+    if (tile0 > (Mp >> 4) - nsamp_tiles) tile0 = (Mp >> 4) - nsamp_tiles;
+    if (tile0 < 0) tile0 = 0;
+    const float* Etw = Et + tile0 * 16 * CP;
+    const float* nrmw = nrm + tile0 * 16;
+TileStage<CP> st;
+    st.fetch(Etw, nrmw, 0, nsamp_tiles, tile_stride, tid);
     st.commit(lds_c[0], lds_n[0], tid);
     __syncthreads();
     for (int64_t ch = 0; ch < nchunks; ++ch) {
         const int buf = (int)(ch & 1);
-        if (ch + 1 < nchunks) st.fetch(Et, nrm, ch + 1, nsamp_tiles, tile_stride, tid);
+        if (ch + 1 < nchunks) st.fetch(Etw, nrmw, ch + 1, nsamp_tiles, tile_stride, tid);
         const int ntile = (int)((nsamp_tiles - ch * kChunkTiles) < kChunkTiles ? (nsamp_tiles - ch * kChunkTiles) : kChunkTiles);
         for (int t = 0; t < ntile; ++t) {
-            const int64_t tile = (ch * kChunkTiles + t) * tile_stride;
+            const int64_t tile = tile0 + (ch * kChunkTiles + t) * tile_stride;
             float b[KS];
 #pragma unroll
             for (int s = 0; s < KS; ++s) b[s] = lds_c[buf][t * 16 * CP + s * 64 + lane];
@@ -233,7 +243,7 @@ __global__ void __launch_bounds__(256) k_knn_bound(const float* __restrict__ Et,
 template <int CP>
 __global__ void __launch_bounds__(256) k_knn_emit(const float* __restrict__ Et, const float* __restrict__ nrm,
                                                   const float* __restrict__ thr, int64_t Mp, int include_self,
-                                                  int32_t* __restrict__ ccount, int32_t* __restrict__ cbuf) {
+                                                  int32_t* __restrict__ ccount, int32_t* __restrict__ cbuf, const int32_t* __restrict__ win) {
     constexpr int KS = CP / 4;
     constexpr int RT = kEmitRT, NV = 4 * RT;
     constexpr int kChunkTiles = chunk_tiles(CP);
@@ -255,19 +265,24 @@ __global__ void __launch_bounds__(256) k_knn_emit(const float* __restrict__ Et, 
         if (!(n < __builtin_huge_valf())) hr[v] = __builtin_huge_valf();       // padding query: nothing passes
         else if (!(t < __builtin_huge_valf())) hr[v] = -__builtin_huge_valf(); // no bound: everything passes
     }
-    const int64_t ntiles = Mp >> 4;
+    // candidate tiles whose first component can be within reach of any query of this block (k_knn_window)
+    const int64_t t_lo = win[2 * blockIdx.x], ntiles = win[2 * blockIdx.x + 1] - t_lo;
+    if (ntiles <= 0) {                          // block-uniform: nothing can be within reach
+        if (lane < 16 * kEmitRT) ccount[q0 + lane] = 0;
+        return;
+    }
     const int64_t own_tile = q0 >> 4;
     const int64_t nchunks = (ntiles + kChunkTiles - 1) / kChunkTiles;
     TileStage<CP> st;
-    st.fetch(Et, nrm, 0, ntiles, 1, tid);
+    st.fetch(Et + t_lo * 16 * CP, nrm + t_lo * 16, 0, ntiles, 1, tid);
     st.commit(lds_c[0], lds_n[0], tid);
     __syncthreads();
     for (int64_t ch = 0; ch < nchunks; ++ch) {
         const int buf = (int)(ch & 1);
-        if (ch + 1 < nchunks) st.fetch(Et, nrm, ch + 1, ntiles, 1, tid);
+        if (ch + 1 < nchunks) st.fetch(Et + t_lo * 16 * CP, nrm + t_lo * 16, ch + 1, ntiles, 1, tid);
         const int ntile = (int)((ntiles - ch * kChunkTiles) < kChunkTiles ? (ntiles - ch * kChunkTiles) : kChunkTiles);
         for (int t = 0; t < ntile; ++t) {
-            const int64_t tile = ch * kChunkTiles + t;
+            const int64_t tile = t_lo + ch * kChunkTiles + t;
             float b[KS];
 #pragma unroll
             for (int s = 0; s < KS; ++s) b[s] = lds_c[buf][t * 16 * CP + s * 64 + lane];
@@ -395,16 +410,22 @@ __global__ void __launch_bounds__(256) k_knn_bound_bf(const __bf16* __restrict__
         for (int t = 0; t < kBoundKeep; ++t) best[v][t] = __builtin_huge_valf();
     const int64_t own_tile = q0 >> 4;
     const int64_t nchunks = (nsamp_tiles + kChunkTiles - 1) / kChunkTiles;
-    TileStageBf<CP> st;
-    st.fetch(Eb, nrm, 0, nsamp_tiles, tile_stride, tid);
+        // sample = the nsamp_tiles tiles around this block in first-component order (contiguous, see stage_knn)
+    int64_t tile0 = (((int64_t)blockIdx.x * 4) * RT) + 2 * RT - nsamp_tiles / 2;
+    if (tile0 > (Mp >> 4) - nsamp_tiles) tile0 = (Mp >> 4) - nsamp_tiles;
+    if (tile0 < 0) tile0 = 0;
+    const __bf16* Ebw = Eb + tile0 * 16 * CP * 2;
+    const float* nrmw = nrm + tile0 * 16;
+TileStageBf<CP> st;
+    st.fetch(Ebw, nrmw, 0, nsamp_tiles, tile_stride, tid);
     st.commit(lds_c[0], lds_n[0], tid);
     __syncthreads();
     for (int64_t ch = 0; ch < nchunks; ++ch) {
         const int buf = (int)(ch & 1);
-        if (ch + 1 < nchunks) st.fetch(Eb, nrm, ch + 1, nsamp_tiles, tile_stride, tid);
+        if (ch + 1 < nchunks) st.fetch(Ebw, nrmw, ch + 1, nsamp_tiles, tile_stride, tid);
         const int ntile = (int)((nsamp_tiles - ch * kChunkTiles) < kChunkTiles ? (nsamp_tiles - ch * kChunkTiles) : kChunkTiles);
         for (int t = 0; t < ntile; ++t) {
-            const int64_t tile = (ch * kChunkTiles + t) * tile_stride;
+            const int64_t tile = tile0 + (ch * kChunkTiles + t) * tile_stride;
             const float nc = lds_n[buf][t * 16 + jcol];
             f4 acc[RT];
             qt.dots(lds_c[buf] + t * tile_vecs, lane, acc);
@@ -458,7 +479,7 @@ __global__ void __launch_bounds__(256) k_knn_bound_bf(const __bf16* __restrict__
 template <int CP>
 __global__ void __launch_bounds__(256) k_knn_emit_bf(const __bf16* __restrict__ Eb, const float* __restrict__ nrm,
                                                      const float* __restrict__ thr, int64_t Mp, int include_self,
-                                                     int32_t* __restrict__ ccount, int32_t* __restrict__ cbuf) {
+                                                     int32_t* __restrict__ ccount, int32_t* __restrict__ cbuf, const int32_t* __restrict__ win) {
     constexpr int RT = kEmitRT, NV = 4 * RT;
     constexpr int kChunkTiles = chunk_tiles(CP);
     constexpr int tile_vecs = 16 * CP * 4 / 16;
@@ -480,19 +501,24 @@ __global__ void __launch_bounds__(256) k_knn_emit_bf(const __bf16* __restrict__ 
         if (!(n < __builtin_huge_valf())) hr[v] = __builtin_huge_valf();
         else if (!(t < __builtin_huge_valf())) hr[v] = -__builtin_huge_valf();
     }
-    const int64_t ntiles = Mp >> 4;
+    // candidate tiles whose first component can be within reach of any query of this block (k_knn_window)
+    const int64_t t_lo = win[2 * blockIdx.x], ntiles = win[2 * blockIdx.x + 1] - t_lo;
+    if (ntiles <= 0) {                          // block-uniform: nothing can be within reach
+        if (lane < 16 * kEmitRT) ccount[q0 + lane] = 0;
+        return;
+    }
     const int64_t own_tile = q0 >> 4;
     const int64_t nchunks = (ntiles + kChunkTiles - 1) / kChunkTiles;
     TileStageBf<CP> st;
-    st.fetch(Eb, nrm, 0, ntiles, 1, tid);
+    st.fetch(Eb + t_lo * 16 * CP * 2, nrm + t_lo * 16, 0, ntiles, 1, tid);
     st.commit(lds_c[0], lds_n[0], tid);
     __syncthreads();
     for (int64_t ch = 0; ch < nchunks; ++ch) {
         const int buf = (int)(ch & 1);
-        if (ch + 1 < nchunks) st.fetch(Eb, nrm, ch + 1, ntiles, 1, tid);
+        if (ch + 1 < nchunks) st.fetch(Eb + t_lo * 16 * CP * 2, nrm + t_lo * 16, ch + 1, ntiles, 1, tid);
         const int ntile = (int)((ntiles - ch * kChunkTiles) < kChunkTiles ? (ntiles - ch * kChunkTiles) : kChunkTiles);
         for (int t = 0; t < ntile; ++t) {
-            const int64_t tile = ch * kChunkTiles + t;
+            const int64_t tile = t_lo + ch * kChunkTiles + t;
             const float hc = 0.5f * (1.0f - kScreenSlackBf) * lds_n[buf][t * 16 + jcol];
             f4 acc[RT];
             qt.dots(lds_c[buf] + t * tile_vecs, lane, acc);
@@ -565,8 +591,8 @@ __device__ __forceinline__ void wave_sort(double* d, int32_t* ix, int P, int lan
 
 // one wave per query (4 per block, no block-level synchronisation)
 template <int CP>
-__global__ void __launch_bounds__(256) k_knn_select(const float* __restrict__ E, int64_t M, int K, int include_self,
-                                                    const int32_t* __restrict__ ccount, const int32_t* __restrict__ cbuf,
+__global__ void __launch_bounds__(256) k_knn_select(const float* __restrict__ E, const int32_t* __restrict__ perm, int64_t M, int K,
+                                                    int include_self, const int32_t* __restrict__ ccount, const int32_t* __restrict__ cbuf,
                                                     int32_t* __restrict__ idx_out, double* __restrict__ dist_out,
                                                     int32_t* __restrict__ n_overflow) {
     __shared__ __attribute__((aligned(16))) double sd[4][kSelMax];
@@ -593,7 +619,7 @@ __global__ void __launch_bounds__(256) k_knn_select(const float* __restrict__ E,
         if (t < cnt) {
             const int64_t c = cbuf[q * kCandCap + t];
             dv = exact_d2<CP>(qrow, E + c * CP);
-            iv = (int32_t)c;
+            iv = perm[c];                            // ties are broken by the caller's point ids
         }
         d[t] = dv;
         ix[t] = iv;
@@ -628,7 +654,7 @@ __global__ void __launch_bounds__(256) k_knn_select(const float* __restrict__ E,
             if (keep) {
                 const int pos = fill + __popcll(m & ((1ull << lane) - 1ull));
                 d[pos] = dv;
-                ix[pos] = (int32_t)c;
+                ix[pos] = perm[c];
             }
             fill += n_new;
         }
@@ -640,11 +666,57 @@ __global__ void __launch_bounds__(256) k_knn_select(const float* __restrict__ E,
         wave_sort(d, ix, P, lane);
         kept = fill < K ? fill : K;
     }
+    const int64_t qo = perm[q];                     // row of the caller's table
     for (int s = lane; s < K; s += 64) {
         const bool ok = s < kept && ix[s] != 0x7fffffff;
-        idx_out[q * K + s] = ok ? ix[s] : -1;
-        dist_out[q * K + s] = ok ? d[s] : __builtin_huge_val();
+        idx_out[qo * K + s] = ok ? ix[s] : -1;
+        dist_out[qo * K + s] = ok ? d[s] : __builtin_huge_val();
     }
+}
+
+// sort key of the point order: the first principal component
+__global__ void k_knn_keys(const float* __restrict__ emb, int64_t M, int C, float* __restrict__ keys, int32_t* __restrict__ ids) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= M) return;
+    keys[r] = emb[r * C];
+    ids[r] = (int32_t)r;
+}
+
+// Candidate window of one emit block (its 4*16*kEmitRT consecutive queries in first-component order): a candidate c
+// can only matter for query q if d2(q,c) <= T_q, and d2(q,c) >= (q_1 - c_1)^2, so c_1 must lie within sqrt(T_q) of
+// q_1.  Points are sorted by that component, hence the admissible candidates of the whole block form one contiguous
+// range of tiles [win[2b], win[2b+1]).  The radius carries a 1e-5 relative margin for the float32 square root.
+__global__ void __launch_bounds__(64) k_knn_window(const float* __restrict__ p1, const float* __restrict__ thr, const float* __restrict__ nrm,
+                                                   int64_t Mp, int32_t* __restrict__ win) {
+    constexpr int QB = 4 * 16 * kEmitRT;
+    const int lane = threadIdx.x;
+    const int64_t qb = (int64_t)blockIdx.x * QB;
+    float lo = __builtin_huge_valf(), hi = -__builtin_huge_valf();
+    for (int t = lane; t < QB; t += 64) {
+        const int64_t q = qb + t;
+        if (!(nrm[q] < __builtin_huge_valf())) continue;          // padding query
+        const float T = thr[q];
+        const float x = p1[q];
+        const float r = T < __builtin_huge_valf() ? sqrtf(fmaxf(T, 0.f)) * 1.00001f + fabsf(x) * 2.4e-7f + 1e-30f : __builtin_huge_valf();
+        lo = fminf(lo, x - r);
+        hi = fmaxf(hi, x + r);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = fminf(lo, __shfl_xor(lo, o, 64));
+        hi = fmaxf(hi, __shfl_xor(hi, o, 64));
+    }
+    if (lane != 0) return;
+    int64_t first = 0, last = 0;
+    if (lo <= hi) {
+        int64_t a = 0, b = Mp;                       // first position with p1 >= lo
+        while (a < b) { const int64_t m = (a + b) >> 1; if (p1[m] < lo) a = m + 1; else b = m; }
+        first = a;
+        a = first; b = Mp;                           // first position with p1 > hi
+        while (a < b) { const int64_t m = (a + b) >> 1; if (p1[m] <= hi) a = m + 1; else b = m; }
+        last = a;
+    }
+    win[2 * blockIdx.x] = (int32_t)(first >> 4);
+    win[2 * blockIdx.x + 1] = (int32_t)((last + 15) >> 4);
 }
 
 int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
@@ -654,9 +726,11 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
     if (k > 16 * (kBoundKeep - 1)) return set_err(ctx, DDX_E_UNSUPPORTED, "k=%d exceeds %d", k, 16 * (kBoundKeep - 1));
     const int CP = (C <= 32) ? 32 : 64;
     const int64_t Mp = ceil_div(M, 256) * 256;                 // whole blocks of queries in both MFMA passes
-    // workspace (reuses the PCA row buffer): E [Mp*CP] | Et [Mp*CP] | Eb [Mp*CP as bf16 hi+lo] | nrm [Mp] | thr [Mp] | ccount [Mp+1] | cbuf [Mp*cap]
-    const size_t f_words = (size_t)Mp * CP * 3 + 2 * (size_t)Mp;
-    const size_t i_words = (size_t)Mp + 64 + (size_t)Mp * kCandCap;
+    // workspace (reuses the PCA row buffer): E [Mp*CP] | Et [Mp*CP] | Eb [Mp*CP as bf16 hi+lo] | nrm [Mp] | thr [Mp] | p1 [Mp] | keys [2*Mp]
+    //            | ccount [Mp+64] | ids [2*Mp] | win [2*blocks] | cbuf [Mp*cap]
+    const size_t f_words = (size_t)Mp * CP * 3 + 5 * (size_t)Mp;
+    const int64_t emit_blocks = Mp / (4 * 16 * kEmitRT);
+    const size_t i_words = (size_t)Mp + 64 + 2 * (size_t)Mp + 2 * (size_t)emit_blocks + 64 + (size_t)Mp * kCandCap;
     DDX_TRY(ensure(ctx, ctx->pcaA, sizeof(float) * f_words + sizeof(int32_t) * i_words + 256));
     DDX_TRY(ensure(ctx, ctx->knn_idx, sizeof(int32_t) * (size_t)M * k));
     DDX_TRY(ensure(ctx, ctx->knn_dist, sizeof(double) * (size_t)M * k));
@@ -665,19 +739,36 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
     __bf16* Eb = reinterpret_cast<__bf16*>(Et + (size_t)Mp * CP);      // 2 parts x 2 bytes = CP floats per point
     float* nrm = Et + 2 * (size_t)Mp * CP;
     float* thr = nrm + Mp;
+    float* p1 = thr + Mp;
+    float* keys_in = p1 + Mp;
+    float* keys_out = keys_in + Mp;
     const char* scr = getenv("DDX_KNN_SCREEN");
     const bool bf = !(scr && scr[0] == 'f' && scr[1] == '3');          // DDX_KNN_SCREEN=f32 selects the float32 MFMA screen
-    int32_t* ccount = reinterpret_cast<int32_t*>(thr + Mp);   // [Mp] + overflow counter at [Mp]
-    int32_t* cbuf = ccount + Mp + 64;
-    k_knn_prepare<<<(unsigned)ceil_div(Mp, 256), 256, 0, ctx->stream>>>(ctx->emb32.as<float>(), M, Mp, C, CP, E, Et, Eb, nrm);
+    int32_t* ccount = reinterpret_cast<int32_t*>(keys_out + Mp);   // [Mp] + overflow counter at [Mp]
+    int32_t* ids_in = ccount + Mp + 64;
+    int32_t* perm = ids_in + Mp;
+    int32_t* win = perm + Mp;
+    int32_t* cbuf = win + 2 * emit_blocks + 64;
+    // Order the points by their first principal component (stable radix sort: ties by id).  Every pass below works
+    // in that order: a query's neighbours are then confined to a window of positions around it (k_knn_window).
+    {
+        ScopedTimer t(ctx, "knn_prepare");
+        k_knn_keys<<<(unsigned)ceil_div(M, 256), 256, 0, ctx->stream>>>(ctx->emb32.as<float>(), M, C, keys_in, ids_in);
+        size_t tmp_bytes = 0;
+        DDX_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys_in, keys_out, ids_in, perm, (int)M, 0, 32, ctx->stream));
+        DDX_TRY(ensure(ctx, ctx->sort_tmp, tmp_bytes));
+        DDX_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(ctx->sort_tmp.p, tmp_bytes, keys_in, keys_out, ids_in, perm, (int)M, 0, 32, ctx->stream));
+        k_knn_prepare<<<(unsigned)ceil_div(Mp, 256), 256, 0, ctx->stream>>>(ctx->emb32.as<float>(), perm, M, Mp, C, CP, E, Et, Eb, nrm, p1);
+    }
     DDX_HIP(ctx, hipMemsetAsync(ccount, 0, sizeof(int32_t) * (Mp + 64), ctx->stream));
-    // sample so that about 144 candidates per query survive: the k-th of a sample of S corresponds to rank k*M/S
+    // Bound pass: the K-th smallest distance inside the nsamp tiles nearest to the query in first-component order is
+    // an upper bound of its true K-th distance (any subset gives one; this subset holds most of the true neighbours).
     const int64_t ntiles = Mp >> 4;
-    int64_t nsamp = ceil_div((int64_t)k * M, (int64_t)144 * 16);
-    if (nsamp < 128) nsamp = 128;
+    int64_t nsamp = 512;
+    if (const char* e = getenv("DDX_KNN_SAMPLE_TILES")) nsamp = atoll(e);
+    if (nsamp < 2 * (int64_t)ceil_div(k, 16) + 8) nsamp = 2 * (int64_t)ceil_div(k, 16) + 8;
     if (nsamp > ntiles) nsamp = ntiles;
-    int64_t stride = ntiles / nsamp;
-    if (stride < 1) stride = 1;
+    const int64_t stride = 1;
     {
         ScopedTimer t(ctx, "knn_bound");
         const unsigned grid = (unsigned)(Mp / (4 * 16 * kBoundRT));
@@ -688,17 +779,18 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
     }
     {
         ScopedTimer t(ctx, "knn_emit");
-        const unsigned grid = (unsigned)(Mp / (4 * 16 * kEmitRT));
-        if (bf && CP == 32) k_knn_emit_bf<32><<<grid, 256, 0, ctx->stream>>>(Eb, nrm, thr, Mp, include_self, ccount, cbuf);
-        else if (bf) k_knn_emit_bf<64><<<grid, 256, 0, ctx->stream>>>(Eb, nrm, thr, Mp, include_self, ccount, cbuf);
-        else if (CP == 32) k_knn_emit<32><<<grid, 256, 0, ctx->stream>>>(Et, nrm, thr, Mp, include_self, ccount, cbuf);
-        else k_knn_emit<64><<<grid, 256, 0, ctx->stream>>>(Et, nrm, thr, Mp, include_self, ccount, cbuf);
+        const unsigned grid = (unsigned)emit_blocks;
+        k_knn_window<<<grid, 64, 0, ctx->stream>>>(p1, thr, nrm, Mp, win);
+        if (bf && CP == 32) k_knn_emit_bf<32><<<grid, 256, 0, ctx->stream>>>(Eb, nrm, thr, Mp, include_self, ccount, cbuf, win);
+        else if (bf) k_knn_emit_bf<64><<<grid, 256, 0, ctx->stream>>>(Eb, nrm, thr, Mp, include_self, ccount, cbuf, win);
+        else if (CP == 32) k_knn_emit<32><<<grid, 256, 0, ctx->stream>>>(Et, nrm, thr, Mp, include_self, ccount, cbuf, win);
+        else k_knn_emit<64><<<grid, 256, 0, ctx->stream>>>(Et, nrm, thr, Mp, include_self, ccount, cbuf, win);
     }
     {
         ScopedTimer t(ctx, "knn_select");
         const unsigned g2 = (unsigned)ceil_div(M, 4);
-        if (CP == 32) k_knn_select<32><<<g2, 256, 0, ctx->stream>>>(E, M, k, include_self, ccount, cbuf, ctx->knn_idx.as<int32_t>(), ctx->knn_dist.as<double>(), ccount + Mp);
-        else k_knn_select<64><<<g2, 256, 0, ctx->stream>>>(E, M, k, include_self, ccount, cbuf, ctx->knn_idx.as<int32_t>(), ctx->knn_dist.as<double>(), ccount + Mp);
+        if (CP == 32) k_knn_select<32><<<g2, 256, 0, ctx->stream>>>(E, perm, M, k, include_self, ccount, cbuf, ctx->knn_idx.as<int32_t>(), ctx->knn_dist.as<double>(), ccount + Mp);
+        else k_knn_select<64><<<g2, 256, 0, ctx->stream>>>(E, perm, M, k, include_self, ccount, cbuf, ctx->knn_idx.as<int32_t>(), ctx->knn_dist.as<double>(), ccount + Mp);
     }
     DDX_HIP(ctx, hipGetLastError());
     if (getenv("DDX_KNN_DEBUG")) {
@@ -707,8 +799,12 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
         DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
         double sum = 0; int mx = 0; int64_t over = 0;
         for (int64_t i = 0; i < M; ++i) { sum += h[i]; if (h[i] > mx) mx = h[i]; over += h[i] > kCandCap; }
-        fprintf(stderr, "[knn] k=%d sample tiles=%lld stride=%lld: candidates/query mean %.1f max %d, overflowed %lld (counter %d)\n",
-                k, (long long)nsamp, (long long)stride, sum / M, mx, (long long)over, h[Mp]);
+        std::vector<int32_t> hw(2 * emit_blocks);
+        DDX_HIP(ctx, hipMemcpy(hw.data(), win, sizeof(int32_t) * 2 * emit_blocks, hipMemcpyDeviceToHost));
+        double wsum = 0;
+        for (int64_t b = 0; b < emit_blocks; ++b) wsum += hw[2 * b + 1] - hw[2 * b];
+        fprintf(stderr, "[knn] k=%d sample tiles=%lld: candidates/query mean %.1f max %d, overflowed %lld (counter %d); emit window %.1f%% of the tiles\n",
+                k, (long long)nsamp, sum / M, mx, (long long)over, h[Mp], 100.0 * wsum / ((double)emit_blocks * (double)ntiles));
     }
     ctx->K = k;
     ctx->knn_self = include_self != 0;
