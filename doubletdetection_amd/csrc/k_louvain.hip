@@ -31,7 +31,8 @@ __global__ void k_lv_quantise(const double* __restrict__ w, int64_t E, int64_t* 
 
 // strength of every node (self loops included), identity communities, 2m, largest degree
 __global__ void k_lv_strength(const int64_t* __restrict__ indptr, const int64_t* __restrict__ wq, int64_t n, int64_t* __restrict__ K,
-                              int32_t* __restrict__ comm, unsigned long long* __restrict__ m2, int32_t* __restrict__ maxdeg) {
+                              int32_t* __restrict__ comm, unsigned long long* __restrict__ m2, int32_t* __restrict__ maxdeg,
+                              int32_t* __restrict__ nbig, int32_t* __restrict__ big_list) {
     const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= n) return;
     int64_t s = 0;
@@ -41,6 +42,7 @@ __global__ void k_lv_strength(const int64_t* __restrict__ indptr, const int64_t*
     comm[v] = (int32_t)v;
     atomicAdd(m2, (unsigned long long)s);
     atomicMax(maxdeg, (int32_t)(e - b));
+    if (e - b > 64) big_list[atomicAdd(nbig, 1)] = (int32_t)v;     // handled by the LDS variant of the sweep (any order)
 }
 
 __global__ void k_lv_totals(const int32_t* __restrict__ comm, const int64_t* __restrict__ K, int64_t n,
@@ -67,26 +69,31 @@ __device__ __forceinline__ void wave_best(double& s, int32_t& c) {
     }
 }
 
-// One synchronous sweep: one wave per node decides from (comm, tot, size) and writes next[v].
+// One synchronous sweep: one wave per node decides from (comm, tot, size) and writes next[v].  Nodes with at most 64
+// neighbours (nearly all) are handled in registers by the BIG = false instance, which needs no LDS and so keeps the
+// CU full of waves (the work is a chain of dependent loads); the few others are listed in big_list and go through LDS.
+template <bool BIG>
 __global__ void __launch_bounds__(256) k_lv_sweep(const int64_t* __restrict__ indptr, const int32_t* __restrict__ cols,
                                                   const int64_t* __restrict__ wq, const int64_t* __restrict__ K,
                                                   const int32_t* __restrict__ comm, const unsigned long long* __restrict__ tot,
                                                   const int32_t* __restrict__ size, int64_t n, double gamma, double m2d,
-                                                  int32_t* __restrict__ next) {
-    __shared__ int32_t cS[4][kLvCap];
-    __shared__ int64_t wS[4][kLvCap];
+                                                  const int32_t* __restrict__ big_list, int32_t* __restrict__ next) {
+    __shared__ int32_t cS[BIG ? 4 : 1][BIG ? kLvCap : 1];
+    __shared__ int64_t wS[BIG ? 4 : 1][BIG ? kLvCap : 1];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t v = (int64_t)blockIdx.x * 4 + wave;
+    int64_t v = (int64_t)blockIdx.x * 4 + wave;
     if (v >= n) return;
+    if (BIG) v = big_list[v];
     const int64_t b = indptr[v];
     const int deg = (int)(indptr[v + 1] - b);
+    if (!BIG && deg > 64) return;
     const int32_t own = comm[v];
     const int64_t kvi = K[v];
     const double kv = (double)kvi;
     double best_s = 0.0;
     int32_t best_c = -1;
     int64_t w_own = 0;
-    if (deg <= 64) {
+    if (!BIG) {
         int32_t c = -1;
         int64_t w = 0;
         if (lane < deg) {
@@ -110,22 +117,23 @@ __global__ void __launch_bounds__(256) k_lv_sweep(const int64_t* __restrict__ in
             best_c = c;
         }
     } else {
+        const int wv = BIG ? wave : 0;
         const int d = deg < kLvCap ? deg : kLvCap;       // deg > kLvCap is rejected on the host before the launch
         for (int i = lane; i < d; i += 64) {
             const int32_t u = cols[b + i];
-            cS[wave][i] = (u == (int32_t)v) ? -1 : comm[u];
-            wS[wave][i] = wq[b + i];
+            cS[wv][i] = (u == (int32_t)v) ? -1 : comm[u];
+            wS[wv][i] = wq[b + i];
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         for (int i = lane; i < d; i += 64) {
-            const int32_t c = cS[wave][i];
+            const int32_t c = cS[wv][i];
             if (c < 0) continue;
             int64_t W = 0;
             bool leader = true;
             for (int j = 0; j < d; ++j) {
-                if (cS[wave][j] == c) {
-                    W += wS[wave][j];
+                if (cS[wv][j] == c) {
+                    W += wS[wv][j];
                     if (j < i) leader = false;
                 }
             }
@@ -193,7 +201,7 @@ int stage_coarsen_graph(ddx_ctx* ctx, double gamma, int32_t sweeps) {
     ctx->c_nodes = -1;
     // workspace: wq i64[E] | keys u64[E] x2 | vals i64[E] | sums i64[E] | K i64[n] | tot u64[n] | indptr i64[n+1] | comm,next,size,used,renum,member i32[n]
     //            | cols i32[E] | w f64[E] | scalars
-    const size_t bytes = sizeof(int64_t) * (size_t)E * 5 + sizeof(int64_t) * (size_t)(3 * n + 8) + sizeof(int32_t) * (size_t)(6 * n + 8) +
+    const size_t bytes = sizeof(int64_t) * (size_t)E * 5 + sizeof(int64_t) * (size_t)(3 * n + 8) + sizeof(int32_t) * (size_t)(7 * n + 8) +
                          (sizeof(int32_t) + sizeof(double)) * (size_t)E + 64 * 256;
     DDX_TRY(ensure(ctx, ctx->lv_buf, bytes));
     unsigned char* base = ctx->lv_buf.as<unsigned char>();
@@ -212,19 +220,22 @@ int stage_coarsen_graph(ddx_ctx* ctx, double gamma, int32_t sweeps) {
     int32_t* used = reinterpret_cast<int32_t*>(carve(sizeof(int32_t) * (n + 1)));
     int32_t* renum = reinterpret_cast<int32_t*>(carve(sizeof(int32_t) * (n + 1)));
     int32_t* member = reinterpret_cast<int32_t*>(carve(sizeof(int32_t) * n));
+    int32_t* big_list = reinterpret_cast<int32_t*>(carve(sizeof(int32_t) * n));
     int32_t* c_cols = reinterpret_cast<int32_t*>(carve(sizeof(int32_t) * E));
     double* c_w = reinterpret_cast<double*>(carve(sizeof(double) * E));
-    unsigned long long* scal = reinterpret_cast<unsigned long long*>(carve(256));   // [0] = 2m, [1] = max degree, [2] = runs
+    unsigned long long* scal = reinterpret_cast<unsigned long long*>(carve(256));   // [0] = 2m, [1] = max degree | #big nodes, [2] = runs
     hipStream_t st = ctx->stream;
     ScopedTimer t(ctx, "graph_coarsen");
     DDX_HIP(ctx, hipMemsetAsync(scal, 0, 256, st));
     if (E > 0) k_lv_quantise<<<(unsigned)ceil_div(E, 256), 256, 0, st>>>(ctx->g_d_vals, E, wq);
-    k_lv_strength<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(ctx->g_d_indptr, wq, n, K, comm, scal, reinterpret_cast<int32_t*>(scal + 1));
+    k_lv_strength<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(ctx->g_d_indptr, wq, n, K, comm, scal, reinterpret_cast<int32_t*>(scal + 1),
+                                                              reinterpret_cast<int32_t*>(scal + 1) + 1, big_list);
     unsigned long long h_scal[2] = {0, 0};
     DDX_HIP(ctx, hipMemcpyAsync(h_scal, scal, sizeof(h_scal), hipMemcpyDeviceToHost, st));
     DDX_HIP(ctx, hipStreamSynchronize(st));
     const int64_t m2 = (int64_t)h_scal[0];
     const int32_t maxdeg = (int32_t)(h_scal[1] & 0xffffffffull);
+    const int32_t nbig = (int32_t)(h_scal[1] >> 32);
     if (maxdeg > kLvCap) return set_err(ctx, DDX_E_UNSUPPORTED, "a node with %d neighbours exceeds the device sweep's capacity (%d)", maxdeg, kLvCap);
     int32_t* cur = comm;
     int32_t* nxt = next;
@@ -232,7 +243,9 @@ int stage_coarsen_graph(ddx_ctx* ctx, double gamma, int32_t sweeps) {
         DDX_HIP(ctx, hipMemsetAsync(tot, 0, sizeof(int64_t) * n, st));
         DDX_HIP(ctx, hipMemsetAsync(size, 0, sizeof(int32_t) * n, st));
         k_lv_totals<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(cur, K, n, tot, size);
-        k_lv_sweep<<<(unsigned)ceil_div(n, 4), 256, 0, st>>>(ctx->g_d_indptr, ctx->g_d_cols, wq, K, cur, tot, size, n, gamma, (double)m2, nxt);
+        k_lv_sweep<false><<<(unsigned)ceil_div(n, 4), 256, 0, st>>>(ctx->g_d_indptr, ctx->g_d_cols, wq, K, cur, tot, size, n, gamma, (double)m2, big_list, nxt);
+        if (nbig > 0)
+            k_lv_sweep<true><<<(unsigned)ceil_div(nbig, 4), 256, 0, st>>>(ctx->g_d_indptr, ctx->g_d_cols, wq, K, cur, tot, size, nbig, gamma, (double)m2, big_list, nxt);
         std::swap(cur, nxt);      // a sweep that moves nothing reproduces its input, so running all of them equals stopping early
     }
     // renumber the surviving communities by ascending id

@@ -586,9 +586,9 @@ __global__ void __launch_bounds__(256) k_gram_partial(const double* __restrict__
 // flag[0] |= 1 when a pivot had to be floored (rank-deficient sketch).
 __global__ void __launch_bounds__(64) k_chol_inv(const double* __restrict__ G, int L, double* __restrict__ Rinv,
                                                  int* __restrict__ flag) {
-    extern __shared__ __attribute__((aligned(16))) double sm[];  // a[L*L]
+    extern __shared__ __attribute__((aligned(16))) double sm[];  // a[L*L] | inv[L*L]
     double* a = sm;
-    double* inv = Rinv;  // each lane only re-reads entries of the column it wrote itself
+    double* inv = sm + L * L;   // built in LDS (a lane re-reads what it wrote: through global memory that costs a round trip per entry)
     const int lane = threadIdx.x;
     for (int t = lane; t < L * L; t += 64) { a[t] = G[t]; inv[t] = 0.0; }
     __syncthreads();
@@ -624,6 +624,8 @@ __global__ void __launch_bounds__(64) k_chol_inv(const double* __restrict__ G, i
             inv[i * L + jx] = -s / a[i * L + i];
         }
     }
+    __syncthreads();
+    for (int t = lane; t < L * L; t += 64) Rinv[t] = inv[t];
 }
 
 // out[R x L2] = X[R x L] * T[L x L2]   (64 rows per block, X tile and T staged in LDS)
@@ -721,7 +723,7 @@ static int cholqr(PcaWork& w, const double* X, int64_t R, double* out) {
     double* Rinv = w.small + w.L * w.L;
     ScopedTimer t(w.ctx, "pca_orth");
     gram(w, X, R, G);
-    k_chol_inv<<<1, 64, sizeof(double) * w.L * w.L, w.ctx->stream>>>(G, w.L, Rinv, w.flag);
+    k_chol_inv<<<1, 64, 2 * sizeof(double) * w.L * w.L, w.ctx->stream>>>(G, w.L, Rinv, w.flag);
     k_right_mult<<<(unsigned)ceil_div(R, 64), 256, sizeof(double) * (w.L * w.L + 64 * w.L), w.ctx->stream>>>(X, R, w.L, Rinv, w.L, out);
     return DDX_OK;
 }
