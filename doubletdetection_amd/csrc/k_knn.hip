@@ -764,7 +764,9 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
     // Bound pass: the K-th smallest distance inside the nsamp tiles nearest to the query in first-component order is
     // an upper bound of its true K-th distance (any subset gives one; this subset holds most of the true neighbours).
     const int64_t ntiles = Mp >> 4;
-    int64_t nsamp = 512;
+    // The subset grows with the point count (1/16 of the tiles, at least 512): a fixed-size subset would hold an ever
+    // smaller share of the true neighbours, T_q would loosen and the candidate lists overflow.
+    int64_t nsamp = std::max<int64_t>(512, ntiles / 16);
     if (const char* e = getenv("DDX_KNN_SAMPLE_TILES")) nsamp = atoll(e);
     if (nsamp < 2 * (int64_t)ceil_div(k, 16) + 8) nsamp = 2 * (int64_t)ceil_div(k, 16) + 8;
     if (nsamp > ntiles) nsamp = ntiles;
