@@ -71,7 +71,7 @@ _SIGNATURES = {
     "ddx_louvain": (C.c_int, [C.c_int64, c_i64_p, c_i32_p, c_f64_p, C.c_double, C.c_uint64, c_i32_p, c_f64_p]),
     "ddx_louvain_sequential": (C.c_int, [C.c_int64, c_i64_p, c_i32_p, c_f64_p, C.c_double, C.c_uint64, c_i32_p, c_f64_p]),
     "ddx_presweep": (C.c_int, [C.c_int64, c_i64_p, c_i32_p, c_f64_p, C.c_double, C.c_int32, c_i32_p, c_i64_p, c_i64_p, c_i32_p, c_f64_p]),
-    "ddx_coarsen_graph": (C.c_int, [C.c_void_p, C.c_double, C.c_int32]),
+    "ddx_coarsen_graph": (C.c_int, [C.c_void_p, C.c_double, C.c_int32, C.c_int32]),
     "ddx_get_coarse_size": (C.c_int, [C.c_void_p, c_i64_p, c_i64_p]),
     "ddx_get_coarse_graph": (C.c_int, [C.c_void_p, c_i32_p, c_i64_p, c_i32_p, c_f64_p]),
     "ddx_relabel_by_size": (C.c_int, [C.c_int64, c_i32_p, C.c_int64, c_i64_p]),
@@ -137,7 +137,8 @@ def louvain(indptr, indices, weights, gamma: float, seed: int):
     return labels, q.value
 
 
-PRESWEEPS = 6   # DDX_PRESWEEPS of include/ddx.h
+PRESWEEPS = 6         # DDX_PRESWEEPS of include/ddx.h
+PRESWEEP_LEVELS = 2   # DDX_PRESWEEP_LEVELS
 
 
 def louvain_sequential(indptr, indices, weights, gamma: float, seed: int):
@@ -422,9 +423,9 @@ class Context:
         self._c(self._lib.ddx_get_graph(self._h, _p(ip, c_i64_p), _p(ix, c_i32_p), _p(w, c_f64_p)))
         return ip, ix, w
 
-    def coarsen_graph(self, gamma: float, sweeps: int = PRESWEEPS):
+    def coarsen_graph(self, gamma: float, sweeps: int = PRESWEEPS, levels: int = PRESWEEP_LEVELS):
         """Part A of the community detection on the device graph.  Returns (member, indptr, indices, weights)."""
-        self._c(self._lib.ddx_coarsen_graph(self._h, float(gamma), int(sweeps)))
+        self._c(self._lib.ddx_coarsen_graph(self._h, float(gamma), int(sweeps), int(levels)))
         n = C.c_int64(0)
         e = C.c_int64(0)
         self._c(self._lib.ddx_get_coarse_size(self._h, C.byref(n), C.byref(e)))

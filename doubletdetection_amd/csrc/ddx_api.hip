@@ -513,12 +513,12 @@ int ddx_get_graph(ddx_ctx* ctx, int64_t* indptr, int32_t* indices, double* weigh
     return DDX_OK;
 }
 
-int ddx_coarsen_graph(ddx_ctx* ctx, double gamma, int32_t sweeps) {
+int ddx_coarsen_graph(ddx_ctx* ctx, double gamma, int32_t sweeps, int32_t levels) {
     REQUIRE_CTX(ctx);
     USE_DEVICE(ctx);
     NEED(ctx->g_nodes >= 0, "no graph: call ddx_build_graph first");
-    NEED(sweeps >= 0, "sweeps must be >= 0");
-    return stage_coarsen_graph(ctx, gamma, sweeps);
+    NEED(sweeps >= 0 && levels >= 1, "sweeps must be >= 0 and levels >= 1");
+    return stage_coarsen_graph(ctx, gamma, sweeps, levels);
 }
 
 int ddx_get_coarse_size(ddx_ctx* ctx, int64_t* n_coarse, int64_t* n_entries) {

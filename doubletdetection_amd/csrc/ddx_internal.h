@@ -202,7 +202,7 @@ int stage_graph_relations(ddx_ctx* ctx, int32_t mode, int32_t* idx_host, double*
 void assemble_graph(int64_t M, int K, const int32_t* idx, const double* w, std::vector<int64_t>& ip,
                     std::vector<int32_t>& gi, std::vector<double>& gw);
 int stage_rankings(ddx_ctx* ctx);
-int stage_coarsen_graph(ddx_ctx* ctx, double gamma, int32_t sweeps);
+int stage_coarsen_graph(ddx_ctx* ctx, double gamma, int32_t sweeps, int32_t levels);
 int stage_gene_variances(ddx_ctx* ctx, float* var_out);
 int stage_select_columns(ddx_ctx* ctx, const int64_t* cols, int32_t n_cols);
 

@@ -195,93 +195,152 @@ __global__ void k_lv_unpack(const uint64_t* __restrict__ keys, const int64_t* __
     w[t] = (double)sums[t] / kWeightScale;
 }
 
-int stage_coarsen_graph(ddx_ctx* ctx, double gamma, int32_t sweeps) {
-    const int64_t n = ctx->g_nodes;
-    const int64_t E = ctx->g_entries;
-    ctx->c_nodes = -1;
-    // workspace: wq i64[E] | keys u64[E] x2 | vals i64[E] | sums i64[E] | K i64[n] | tot u64[n] | indptr i64[n+1] | comm,next,size,used,renum,member i32[n]
-    //            | cols i32[E] | w f64[E] | scalars
-    const size_t bytes = sizeof(int64_t) * (size_t)E * 5 + sizeof(int64_t) * (size_t)(3 * n + 8) + sizeof(int32_t) * (size_t)(7 * n + 8) +
-                         (sizeof(int32_t) + sizeof(double)) * (size_t)E + 64 * 256;
-    DDX_TRY(ensure(ctx, ctx->lv_buf, bytes));
-    unsigned char* base = ctx->lv_buf.as<unsigned char>();
-    auto carve = [&](size_t sz) { unsigned char* p = base; base += (sz + 255) & ~(size_t)255; return p; };
-    int64_t* wq = reinterpret_cast<int64_t*>(carve(sizeof(int64_t) * E));
-    uint64_t* keys_a = reinterpret_cast<uint64_t*>(carve(sizeof(uint64_t) * E));
-    uint64_t* keys_b = reinterpret_cast<uint64_t*>(carve(sizeof(uint64_t) * E));
-    int64_t* vals_b = reinterpret_cast<int64_t*>(carve(sizeof(int64_t) * E));
-    int64_t* sums = reinterpret_cast<int64_t*>(carve(sizeof(int64_t) * E));
-    int64_t* K = reinterpret_cast<int64_t*>(carve(sizeof(int64_t) * n));
-    unsigned long long* tot = reinterpret_cast<unsigned long long*>(carve(sizeof(int64_t) * n));
-    int64_t* c_indptr = reinterpret_cast<int64_t*>(carve(sizeof(int64_t) * (n + 1)));
-    int32_t* comm = reinterpret_cast<int32_t*>(carve(sizeof(int32_t) * n));
-    int32_t* next = reinterpret_cast<int32_t*>(carve(sizeof(int32_t) * n));
-    int32_t* size = reinterpret_cast<int32_t*>(carve(sizeof(int32_t) * n));
-    int32_t* used = reinterpret_cast<int32_t*>(carve(sizeof(int32_t) * (n + 1)));
-    int32_t* renum = reinterpret_cast<int32_t*>(carve(sizeof(int32_t) * (n + 1)));
-    int32_t* member = reinterpret_cast<int32_t*>(carve(sizeof(int32_t) * n));
-    int32_t* big_list = reinterpret_cast<int32_t*>(carve(sizeof(int32_t) * n));
-    int32_t* c_cols = reinterpret_cast<int32_t*>(carve(sizeof(int32_t) * E));
-    double* c_w = reinterpret_cast<double*>(carve(sizeof(double) * E));
-    unsigned long long* scal = reinterpret_cast<unsigned long long*>(carve(256));   // [0] = 2m, [1] = max degree | #big nodes, [2] = runs
+__global__ void k_lv_compose(const int32_t* __restrict__ first, const int32_t* __restrict__ second, int64_t n, int32_t* __restrict__ out) {
+    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < n) out[v] = second[first[v]];
+}
+
+struct LvGraph {            // a CSR on the device
+    int64_t n = 0, E = 0;
+    const int64_t* indptr = nullptr;
+    const int32_t* cols = nullptr;
+    const double* w = nullptr;
+};
+
+struct LvScratch {          // sized for the finest level, reused by the coarser ones
+    int64_t *wq, *vals_b, *sums, *K;
+    uint64_t *keys_a, *keys_b;
+    unsigned long long *tot, *scal;
+    int32_t *comm, *next, *size, *used, *renum, *big_list;
+};
+
+// one level: `sweeps` synchronous sweeps on `in`, exact aggregation into (member, out)
+static int coarsen_level(ddx_ctx* ctx, const LvGraph& in, double gamma, int32_t sweeps, const LvScratch& sc, int32_t* member,
+                         int64_t* c_indptr, int32_t* c_cols, double* c_w, LvGraph& out) {
+    const int64_t n = in.n, E = in.E;
     hipStream_t st = ctx->stream;
-    ScopedTimer t(ctx, "graph_coarsen");
-    DDX_HIP(ctx, hipMemsetAsync(scal, 0, 256, st));
-    if (E > 0) k_lv_quantise<<<(unsigned)ceil_div(E, 256), 256, 0, st>>>(ctx->g_d_vals, E, wq);
-    k_lv_strength<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(ctx->g_d_indptr, wq, n, K, comm, scal, reinterpret_cast<int32_t*>(scal + 1),
-                                                              reinterpret_cast<int32_t*>(scal + 1) + 1, big_list);
+    DDX_HIP(ctx, hipMemsetAsync(sc.scal, 0, 256, st));
+    if (E > 0) k_lv_quantise<<<(unsigned)ceil_div(E, 256), 256, 0, st>>>(in.w, E, sc.wq);
+    k_lv_strength<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(in.indptr, sc.wq, n, sc.K, sc.comm, sc.scal, reinterpret_cast<int32_t*>(sc.scal + 1),
+                                                              reinterpret_cast<int32_t*>(sc.scal + 1) + 1, sc.big_list);
     unsigned long long h_scal[2] = {0, 0};
-    DDX_HIP(ctx, hipMemcpyAsync(h_scal, scal, sizeof(h_scal), hipMemcpyDeviceToHost, st));
+    DDX_HIP(ctx, hipMemcpyAsync(h_scal, sc.scal, sizeof(h_scal), hipMemcpyDeviceToHost, st));
     DDX_HIP(ctx, hipStreamSynchronize(st));
     const int64_t m2 = (int64_t)h_scal[0];
     const int32_t maxdeg = (int32_t)(h_scal[1] & 0xffffffffull);
     const int32_t nbig = (int32_t)(h_scal[1] >> 32);
     if (maxdeg > kLvCap) return set_err(ctx, DDX_E_UNSUPPORTED, "a node with %d neighbours exceeds the device sweep's capacity (%d)", maxdeg, kLvCap);
-    int32_t* cur = comm;
-    int32_t* nxt = next;
+    int32_t* cur = sc.comm;
+    int32_t* nxt = sc.next;
     for (int s = 0; s < sweeps && m2 > 0; ++s) {
-        DDX_HIP(ctx, hipMemsetAsync(tot, 0, sizeof(int64_t) * n, st));
-        DDX_HIP(ctx, hipMemsetAsync(size, 0, sizeof(int32_t) * n, st));
-        k_lv_totals<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(cur, K, n, tot, size);
-        k_lv_sweep<false><<<(unsigned)ceil_div(n, 4), 256, 0, st>>>(ctx->g_d_indptr, ctx->g_d_cols, wq, K, cur, tot, size, n, gamma, (double)m2, big_list, nxt);
+        DDX_HIP(ctx, hipMemsetAsync(sc.tot, 0, sizeof(int64_t) * n, st));
+        DDX_HIP(ctx, hipMemsetAsync(sc.size, 0, sizeof(int32_t) * n, st));
+        k_lv_totals<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(cur, sc.K, n, sc.tot, sc.size);
+        k_lv_sweep<false><<<(unsigned)ceil_div(n, 4), 256, 0, st>>>(in.indptr, in.cols, sc.wq, sc.K, cur, sc.tot, sc.size, n, gamma, (double)m2, sc.big_list, nxt);
         if (nbig > 0)
-            k_lv_sweep<true><<<(unsigned)ceil_div(nbig, 4), 256, 0, st>>>(ctx->g_d_indptr, ctx->g_d_cols, wq, K, cur, tot, size, nbig, gamma, (double)m2, big_list, nxt);
+            k_lv_sweep<true><<<(unsigned)ceil_div(nbig, 4), 256, 0, st>>>(in.indptr, in.cols, sc.wq, sc.K, cur, sc.tot, sc.size, nbig, gamma, (double)m2, sc.big_list, nxt);
         std::swap(cur, nxt);      // a sweep that moves nothing reproduces its input, so running all of them equals stopping early
     }
     // renumber the surviving communities by ascending id
-    DDX_HIP(ctx, hipMemsetAsync(used, 0, sizeof(int32_t) * (n + 1), st));
-    k_lv_used<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(cur, n, used);
+    DDX_HIP(ctx, hipMemsetAsync(sc.used, 0, sizeof(int32_t) * (n + 1), st));
+    k_lv_used<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(cur, n, sc.used);
     size_t tmp_scan = 0, tmp_sort = 0, tmp_red = 0;
-    DDX_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_scan, used, renum, (int)n + 1, st));
+    DDX_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_scan, sc.used, sc.renum, (int)n + 1, st));
     int end_bit = 33;
     while (((int64_t)1 << (end_bit - 32)) < n) ++end_bit;
+    int64_t* runs_d = reinterpret_cast<int64_t*>(sc.scal + 2);
     if (E > 0) {
-        DDX_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_sort, keys_a, keys_b, wq, vals_b, (int)E, 0, end_bit, st));
-        DDX_HIP(ctx, hipcub::DeviceReduce::ReduceByKey(nullptr, tmp_red, keys_b, keys_a, vals_b, sums, reinterpret_cast<int64_t*>(scal + 2), hipcub::Sum(), (int)E, st));
+        DDX_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_sort, sc.keys_a, sc.keys_b, sc.wq, sc.vals_b, (int)E, 0, end_bit, st));
+        DDX_HIP(ctx, hipcub::DeviceReduce::ReduceByKey(nullptr, tmp_red, sc.keys_b, sc.keys_a, sc.vals_b, sc.sums, runs_d, hipcub::Sum(), (int)E, st));
     }
     DDX_TRY(ensure(ctx, ctx->sort_tmp, std::max(tmp_scan, std::max(tmp_sort, tmp_red))));
-    DDX_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(ctx->sort_tmp.p, tmp_scan, used, renum, (int)n + 1, st));
-    k_lv_member<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(cur, renum, n, member);
+    DDX_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(ctx->sort_tmp.p, tmp_scan, sc.used, sc.renum, (int)n + 1, st));
+    k_lv_member<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(cur, sc.renum, n, member);
     int64_t runs = 0;
     if (E > 0) {
-        k_lv_edge_keys<<<(unsigned)ceil_div(n, 4), 256, 0, st>>>(ctx->g_d_indptr, ctx->g_d_cols, member, n, keys_a);
-        DDX_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(ctx->sort_tmp.p, tmp_sort, keys_a, keys_b, wq, vals_b, (int)E, 0, end_bit, st));
-        DDX_HIP(ctx, hipcub::DeviceReduce::ReduceByKey(ctx->sort_tmp.p, tmp_red, keys_b, keys_a, vals_b, sums, reinterpret_cast<int64_t*>(scal + 2), hipcub::Sum(), (int)E, st));
+        k_lv_edge_keys<<<(unsigned)ceil_div(n, 4), 256, 0, st>>>(in.indptr, in.cols, member, n, sc.keys_a);
+        DDX_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(ctx->sort_tmp.p, tmp_sort, sc.keys_a, sc.keys_b, sc.wq, sc.vals_b, (int)E, 0, end_bit, st));
+        DDX_HIP(ctx, hipcub::DeviceReduce::ReduceByKey(ctx->sort_tmp.p, tmp_red, sc.keys_b, sc.keys_a, sc.vals_b, sc.sums, runs_d, hipcub::Sum(), (int)E, st));
     }
     int32_t nc = 0;
-    DDX_HIP(ctx, hipMemcpyAsync(&nc, renum + n, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    DDX_HIP(ctx, hipMemcpyAsync(&runs, scal + 2, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    DDX_HIP(ctx, hipMemcpyAsync(&nc, sc.renum + n, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    DDX_HIP(ctx, hipMemcpyAsync(&runs, runs_d, sizeof(int64_t), hipMemcpyDeviceToHost, st));
     DDX_HIP(ctx, hipStreamSynchronize(st));
     if (E == 0) runs = 0;
-    if (runs > 0) k_lv_unpack<<<(unsigned)ceil_div(runs, 256), 256, 0, st>>>(keys_a, sums, runs, c_cols, c_w);
-    k_lv_rowptr<<<(unsigned)ceil_div((int64_t)nc + 1, 256), 256, 0, st>>>(keys_a, runs, nc, c_indptr);
+    if (runs > 0) k_lv_unpack<<<(unsigned)ceil_div(runs, 256), 256, 0, st>>>(sc.keys_a, sc.sums, runs, c_cols, c_w);
+    k_lv_rowptr<<<(unsigned)ceil_div((int64_t)nc + 1, 256), 256, 0, st>>>(sc.keys_a, runs, nc, c_indptr);
     DDX_HIP(ctx, hipGetLastError());
-    ctx->c_nodes = nc;
-    ctx->c_entries = runs;
-    ctx->c_d_member = member;
-    ctx->c_d_indptr = c_indptr;
-    ctx->c_d_cols = c_cols;
-    ctx->c_d_vals = c_w;
+    out.n = nc;
+    out.E = runs;
+    out.indptr = c_indptr;
+    out.cols = c_cols;
+    out.w = c_w;
+    return DDX_OK;
+}
+
+int stage_coarsen_graph(ddx_ctx* ctx, double gamma, int32_t sweeps, int32_t levels) {
+    const int64_t n = ctx->g_nodes;
+    const int64_t E = ctx->g_entries;
+    ctx->c_nodes = -1;
+    // scratch (wq, keys x2, vals, sums: E each; K, tot: n; comm, next, size, used, renum, big_list: n) + two output sets
+    // (member i32[n], indptr i64[n+1], cols i32[E], w f64[E]) that the levels write alternately + the composed member table
+    const size_t out_set = sizeof(int32_t) * (size_t)n + sizeof(int64_t) * (size_t)(n + 1) + (sizeof(int32_t) + sizeof(double)) * (size_t)E + 4 * 256;
+    const size_t bytes = sizeof(int64_t) * (size_t)E * 5 + sizeof(int64_t) * (size_t)(2 * n + 8) + sizeof(int32_t) * (size_t)(7 * n + 8) + 2 * out_set + 32 * 256;
+    DDX_TRY(ensure(ctx, ctx->lv_buf, bytes));
+    unsigned char* base = ctx->lv_buf.as<unsigned char>();
+    auto carve = [&](size_t sz) { unsigned char* p = base; base += (sz + 255) & ~(size_t)255; return p; };
+    LvScratch sc;
+    sc.wq = reinterpret_cast<int64_t*>(carve(sizeof(int64_t) * E));
+    sc.keys_a = reinterpret_cast<uint64_t*>(carve(sizeof(uint64_t) * E));
+    sc.keys_b = reinterpret_cast<uint64_t*>(carve(sizeof(uint64_t) * E));
+    sc.vals_b = reinterpret_cast<int64_t*>(carve(sizeof(int64_t) * E));
+    sc.sums = reinterpret_cast<int64_t*>(carve(sizeof(int64_t) * E));
+    sc.K = reinterpret_cast<int64_t*>(carve(sizeof(int64_t) * n));
+    sc.tot = reinterpret_cast<unsigned long long*>(carve(sizeof(int64_t) * n));
+    sc.comm = reinterpret_cast<int32_t*>(carve(sizeof(int32_t) * n));
+    sc.next = reinterpret_cast<int32_t*>(carve(sizeof(int32_t) * n));
+    sc.size = reinterpret_cast<int32_t*>(carve(sizeof(int32_t) * n));
+    sc.used = reinterpret_cast<int32_t*>(carve(sizeof(int32_t) * (n + 1)));
+    sc.renum = reinterpret_cast<int32_t*>(carve(sizeof(int32_t) * (n + 1)));
+    sc.big_list = reinterpret_cast<int32_t*>(carve(sizeof(int32_t) * n));
+    sc.scal = reinterpret_cast<unsigned long long*>(carve(256));   // [0] = 2m, [1] = max degree | #big nodes, [2] = runs
+    int32_t* member_set[2];
+    int64_t* indptr_set[2];
+    int32_t* cols_set[2];
+    double* w_set[2];
+    for (int i = 0; i < 2; ++i) {
+        member_set[i] = reinterpret_cast<int32_t*>(carve(sizeof(int32_t) * n));
+        indptr_set[i] = reinterpret_cast<int64_t*>(carve(sizeof(int64_t) * (n + 1)));
+        cols_set[i] = reinterpret_cast<int32_t*>(carve(sizeof(int32_t) * E));
+        w_set[i] = reinterpret_cast<double*>(carve(sizeof(double) * E));
+    }
+    int32_t* total_a = reinterpret_cast<int32_t*>(carve(sizeof(int32_t) * n));
+    int32_t* total_b = reinterpret_cast<int32_t*>(carve(sizeof(int32_t) * n));
+    ScopedTimer t(ctx, "graph_coarsen");
+    LvGraph cur;
+    cur.n = n; cur.E = E; cur.indptr = ctx->g_d_indptr; cur.cols = ctx->g_d_cols; cur.w = ctx->g_d_vals;
+    const int32_t* total = nullptr;          // member of every original node in the current coarse graph
+    for (int lvl = 0; lvl < levels; ++lvl) {
+        const int o = lvl & 1;
+        LvGraph nextg;
+        DDX_TRY(coarsen_level(ctx, cur, gamma, sweeps, sc, member_set[o], indptr_set[o], cols_set[o], w_set[o], nextg));
+        if (!total) {
+            total = member_set[o];
+        } else {
+            int32_t* dst = (total == total_a) ? total_b : total_a;
+            k_lv_compose<<<(unsigned)ceil_div(n, 256), 256, 0, ctx->stream>>>(total, member_set[o], n, dst);
+            total = dst;
+        }
+        cur = nextg;
+    }
+    DDX_HIP(ctx, hipGetLastError());
+    if (!total) return set_err(ctx, DDX_E_ARG, "levels must be >= 1");
+    ctx->c_nodes = cur.n;
+    ctx->c_entries = cur.E;
+    ctx->c_d_member = total;
+    ctx->c_d_indptr = cur.indptr;
+    ctx->c_d_cols = cur.cols;
+    ctx->c_d_vals = cur.w;
     return DDX_OK;
 }
 

@@ -422,10 +422,17 @@ extern "C" int ddx_louvain(int64_t n_nodes, const int64_t* indptr, const int32_t
     Graph g, coarse;
     const int rc = load_graph(n_nodes, indptr, indices, weights, g);
     if (rc != DDX_OK) return rc;
-    std::vector<int32_t> member, membership;
-    presweep(g, gamma, DDX_PRESWEEPS, member, coarse);
-    sequential_levels(coarse, gamma, seed, membership, quality_out);
-    for (int64_t v = 0; v < n_nodes; ++v) labels_out[v] = membership[member[v]];
+    std::vector<int32_t> total(n_nodes), member, membership;
+    for (int64_t v = 0; v < n_nodes; ++v) total[v] = (int32_t)v;
+    for (int lvl = 0; lvl < DDX_PRESWEEP_LEVELS; ++lvl) {
+        presweep(g, gamma, DDX_PRESWEEPS, member, coarse);
+        for (int64_t v = 0; v < n_nodes; ++v) total[v] = member[total[v]];
+        g.indptr.swap(coarse.indptr);
+        g.indices.swap(coarse.indices);
+        g.weights.swap(coarse.weights);
+    }
+    sequential_levels(g, gamma, seed, membership, quality_out);
+    for (int64_t v = 0; v < n_nodes; ++v) labels_out[v] = membership[total[v]];
     return DDX_OK;
 }
 

@@ -148,14 +148,16 @@ int ddx_get_graph(ddx_ctx* ctx, int64_t* indptr, int32_t* indices, double* weigh
 
 /* ---- community detection (see oracle/louvain_ref.py for the spec) --------------------------------
  * replaces the Louvain stage inside phenograph.cluster / sc.tl.louvain (dd.py:320-322, 337-342).
- * The specification has two parts: (A) DDX_PRESWEEPS synchronous sweeps on integer-quantised weights followed
- * by an exact aggregation, (B) sequential multi-level optimisation of the aggregated graph.
+ * The specification has two parts: (A) DDX_PRESWEEP_LEVELS times { DDX_PRESWEEPS synchronous sweeps on
+ * integer-quantised weights followed by an exact aggregation }, (B) sequential multi-level optimisation of the
+ * aggregated graph.
  *   ddx_louvain            = A + B on the host (context-free, thread-safe);
- *   ddx_presweep           = A on the host;       ddx_louvain_sequential = B on the host;
- *   ddx_coarsen_graph      = A on the GPU, applied to the graph ddx_build_graph left on the device; the
+ *   ddx_presweep           = one level of A on the host;   ddx_louvain_sequential = B on the host;
+ *   ddx_coarsen_graph      = `levels` levels of A on the GPU, applied to the graph ddx_build_graph left on the device; the
  *                            result (member of every node + aggregated CSR) is read with ddx_get_coarse_*.
  * A on the GPU followed by ddx_louvain_sequential equals ddx_louvain bit for bit. */
 #define DDX_PRESWEEPS 6
+#define DDX_PRESWEEP_LEVELS 2
 int ddx_louvain(int64_t n_nodes, const int64_t* indptr, const int32_t* indices, const double* weights,
                 double gamma, uint64_t seed, int32_t* labels_out /* [n_nodes] */, double* quality_out);
 int ddx_louvain_sequential(int64_t n_nodes, const int64_t* indptr, const int32_t* indices, const double* weights,
@@ -163,7 +165,7 @@ int ddx_louvain_sequential(int64_t n_nodes, const int64_t* indptr, const int32_t
 int ddx_presweep(int64_t n_nodes, const int64_t* indptr, const int32_t* indices, const double* weights, double gamma,
                  int32_t sweeps, int32_t* member_out /* [n_nodes] */, int64_t* n_coarse_out,
                  int64_t* c_indptr_out /* [n_nodes+1] */, int32_t* c_indices_out /* [nnz] */, double* c_weights_out /* [nnz] */);
-int ddx_coarsen_graph(ddx_ctx* ctx, double gamma, int32_t sweeps);
+int ddx_coarsen_graph(ddx_ctx* ctx, double gamma, int32_t sweeps, int32_t levels);
 int ddx_get_coarse_size(ddx_ctx* ctx, int64_t* n_coarse, int64_t* n_entries);
 int ddx_get_coarse_graph(ddx_ctx* ctx, int32_t* member /* [n_nodes] */, int64_t* indptr /* [n_coarse+1] */,
                          int32_t* indices, double* weights);

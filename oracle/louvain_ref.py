@@ -12,7 +12,8 @@ same float64 operation order, no FMA contraction), which ``tests/test_louvain.py
 
 Algorithm (the published multi-level modularity optimisation with a resolution parameter), in two parts.
 
-**Part A -- synchronous pre-sweeps** (``presweep``; what the GPU runs, cf. the parallel Louvain variants of
+**Part A -- synchronous pre-sweeps** (``presweep``, applied ``PRESWEEP_LEVELS`` times, each time to the graph the
+previous application aggregated; what the GPU runs, cf. the parallel Louvain variants of
 Lu, Halappanavar, Kalyanaraman 2015 and Naim et al. 2017).  Weights are quantised to integers
 ``wq = rint(w * 2**20)`` so that every sum below is exact and independent of summation order.  For
 ``PRESWEEPS`` sweeps (stopping early when nothing moves) *all* nodes decide at once from the same state:
@@ -43,6 +44,7 @@ import numpy as np
 _MASK = 0xFFFFFFFFFFFFFFFF
 MIN_GAIN = 1e-6
 PRESWEEPS = 6
+PRESWEEP_LEVELS = 2
 WEIGHT_SCALE = float(1 << 20)
 
 
@@ -240,11 +242,13 @@ def _aggregate(indptr, indices, weights, comm):
     return new_indptr, new_indices, new_weights, renum
 
 
-def louvain(indptr, indices, weights, gamma: float = 1.0, seed: int = 0, presweeps: int = PRESWEEPS) -> np.ndarray:
+def louvain(indptr, indices, weights, gamma: float = 1.0, seed: int = 0, presweeps: int = PRESWEEPS,
+            levels: int = PRESWEEP_LEVELS) -> np.ndarray:
     """Community label per node (0..K-1, numbered by ascending representative id)."""
     member = None
-    if presweeps > 0:
-        member, indptr, indices, weights = presweep(indptr, indices, weights, gamma, presweeps)
+    for _ in range(levels if presweeps > 0 else 0):
+        m, indptr, indices, weights = presweep(indptr, indices, weights, gamma, presweeps)
+        member = m if member is None else m[member]
     lab = _louvain_sequential(indptr, indices, weights, gamma, seed)
     return lab if member is None else lab[member]
 

@@ -278,7 +278,7 @@ def test_device_presweeps_match_host(ctx, case):
         ctx.knn(k, self_)
         ip, ix, w = ctx.build_graph(mode)
         for sweeps in (1, _lib.PRESWEEPS):
-            m_dev, ip_dev, ix_dev, w_dev = ctx.coarsen_graph(gamma, sweeps)
+            m_dev, ip_dev, ix_dev, w_dev = ctx.coarsen_graph(gamma, sweeps, levels=1)
             m_host, ip_host, ix_host, w_host = _lib.presweep(ip, ix, w, gamma, sweeps)
             np.testing.assert_array_equal(m_dev, m_host)
             np.testing.assert_array_equal(ip_dev, ip_host)
@@ -287,7 +287,19 @@ def test_device_presweeps_match_host(ctx, case):
         m_ref, ip_ref, ix_ref, w_ref = louvain_ref.presweep(ip, ix, w, gamma)
         np.testing.assert_array_equal(m_dev, m_ref)
         np.testing.assert_array_equal(w_dev, w_ref)
+        # several levels on the device = the host statement applied repeatedly
+        for levels in (2, 3):
+            m_dev, ip_dev, ix_dev, w_dev = ctx.coarsen_graph(gamma, levels=levels)
+            total, gr = None, (ip, ix, w)
+            for _ in range(levels):
+                mm, *gr = _lib.presweep(*gr, gamma)
+                total = mm if total is None else mm[total]
+            np.testing.assert_array_equal(m_dev, total)
+            np.testing.assert_array_equal(ip_dev, gr[0])
+            np.testing.assert_array_equal(ix_dev, gr[1])
+            np.testing.assert_array_equal(w_dev, gr[2])
         # device A + host B = host A + B
+        m_dev, ip_dev, ix_dev, w_dev = ctx.coarsen_graph(gamma)
         lab = _lib.louvain_sequential(ip_dev, ix_dev, w_dev, gamma, 3)[0][m_dev]
         np.testing.assert_array_equal(lab, _lib.louvain(ip, ix, w, gamma, 3)[0])
 
@@ -304,7 +316,7 @@ def test_device_presweeps_high_degree_nodes(ctx):
     ctx.knn(30, False)
     ip, ix, w = ctx.build_graph(1)
     assert np.diff(ip).max() > 64
-    m_dev, ip_dev, ix_dev, w_dev = ctx.coarsen_graph(1.0)
+    m_dev, ip_dev, ix_dev, w_dev = ctx.coarsen_graph(1.0, levels=1)
     m_host, ip_host, ix_host, w_host = _lib.presweep(ip, ix, w, 1.0)
     np.testing.assert_array_equal(m_dev, m_host)
     np.testing.assert_array_equal(ip_dev, ip_host)

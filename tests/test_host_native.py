@@ -87,8 +87,13 @@ def test_presweep_and_sequential_parts_match_specification(n, k, seed, weighted,
         np.testing.assert_array_equal(ws, wr)
     seq, _ = _lib.louvain_sequential(ip, ix, w, gamma, seed)
     np.testing.assert_array_equal(seq.astype(np.int64), louvain_ref._louvain_sequential(ip_ref, ix_ref, w_ref, gamma, seed))
+    # the whole = PRESWEEP_LEVELS applications of part A, then part B
+    total, g = None, (A.indptr, A.indices, A.data)
+    for _ in range(_lib.PRESWEEP_LEVELS):
+        mm, *g = _lib.presweep(*g, gamma)
+        total = mm if total is None else mm[total]
     whole, _ = _lib.louvain(A.indptr, A.indices, A.data, gamma, seed)
-    np.testing.assert_array_equal(whole, seq[m])
+    np.testing.assert_array_equal(whole, _lib.louvain_sequential(*g, gamma, seed)[0][total])
     # the pre-sweeps cost no modularity worth mentioning against the purely sequential optimisation
     q_whole = louvain_ref.modularity(A.indptr, A.indices, A.data, whole, gamma)
     q_seq = louvain_ref.modularity(A.indptr, A.indices, A.data, _lib.louvain_sequential(A.indptr, A.indices, A.data, gamma, seed)[0], gamma)
