@@ -879,6 +879,62 @@ __global__ void __launch_bounds__(256) k_edge_weights(const int32_t* __restrict_
     w_out[t] = mutual ? w : -w;
 }
 
+// The same weights, one wave per node (K <= 64): N(i) sits sorted in LDS, lane l holds the l-th relation of i and,
+// relation by relation, the wave loads N(j) (one coalesced row), every lane looks its element up in N(i) by
+// binary search and a ballot counts the shared neighbours.  Four rows are in flight at a time.
+__global__ void __launch_bounds__(256) k_edge_weights_wave(const int32_t* __restrict__ idx, const int32_t* __restrict__ sorted,
+                                                           int64_t M, int K, int mode, double* __restrict__ w_out) {
+    __shared__ int32_t nS[4][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + wave;
+    if (i >= M) return;
+    int32_t* Ni = nS[wave];
+    Ni[lane] = lane < K ? sorted[i * K + lane] : 0x7fffffff;
+    const int32_t myj = lane < K ? idx[i * K + lane] : -1;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    double myw = 0.0;
+    for (int t0 = 0; t0 < K; t0 += 4) {
+        int32_t j[4], y[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            j[u] = (t0 + u < K) ? __shfl(myj, t0 + u, 64) : -1;
+            const bool ok = j[u] >= 0 && j[u] != (int32_t)i;
+            y[u] = (ok && lane < K) ? sorted[(int64_t)j[u] * K + lane] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (t0 + u >= K) break;
+            const bool ok = j[u] >= 0 && j[u] != (int32_t)i;
+            const bool valid = ok && lane < K;
+            bool found = false;
+            if (valid) {
+                int lo = 0, hi = K;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (Ni[mid] < y[u]) lo = mid + 1; else hi = mid;
+                }
+                found = lo < K && Ni[lo] == y[u];
+            }
+            const int shared = __popcll(__ballot(found));
+            const bool mutual = __ballot(valid && y[u] == (int32_t)i) != 0ull;
+            double w = 0.0;
+            if (ok) {
+                if (mode == 2) {
+                    w = 1.0;
+                } else {
+                    const double J = (double)shared / (2.0 * (double)K - (double)shared);
+                    if (mode == 0) w = mutual ? J * J : 0.0;
+                    else w = mutual ? (J + J) / 2.0 : J / 2.0;
+                }
+                w = mutual ? w : -w;
+            }
+            if (lane == t0 + u) myw = w;
+        }
+    }
+    if (lane < K) w_out[i * K + lane] = myw;
+}
+
 // ---- symmetric CSR on the device ----------------------------------------------------------------------
 // every relation with a non-zero weight contributes the pair (i,j); a one-directional relation (negative
 // flag) also contributes (j,i).  Pairs are keyed (row << 32 | column) and radix-sorted, which yields rows
@@ -989,8 +1045,12 @@ static int graph_weights_device(ddx_ctx* ctx, int32_t mode) {
     DDX_TRY(ensure(ctx, ctx->edge_w, sizeof(double) * (size_t)M * K));
     ScopedTimer t(ctx, "graph_weights");
     k_sort_neighbours<<<(unsigned)ceil_div(M, 64), 64, sizeof(int32_t) * K * 64, ctx->stream>>>(ctx->knn_idx.as<int32_t>(), M, K, ctx->knn_sorted.as<int32_t>());
-    k_edge_weights<<<(unsigned)ceil_div(M * K, 256), 256, 0, ctx->stream>>>(ctx->knn_idx.as<int32_t>(), ctx->knn_sorted.as<int32_t>(), M, K, mode,
-                                                                            ctx->edge_w.as<double>());
+    if (K <= 64)
+        k_edge_weights_wave<<<(unsigned)ceil_div(M, 4), 256, 0, ctx->stream>>>(ctx->knn_idx.as<int32_t>(), ctx->knn_sorted.as<int32_t>(), M, K, mode,
+                                                                               ctx->edge_w.as<double>());
+    else
+        k_edge_weights<<<(unsigned)ceil_div(M * K, 256), 256, 0, ctx->stream>>>(ctx->knn_idx.as<int32_t>(), ctx->knn_sorted.as<int32_t>(), M, K, mode,
+                                                                                ctx->edge_w.as<double>());
     return DDX_OK;
 }
 
