@@ -15,6 +15,8 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libddx.so")
 
+# per-file flags: the kNN screen compares MFMA results right away -- keep the accumulators in VGPRs (no v_accvgpr_read)
+EXTRA_FLAGS = {"k_knn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 HIP_SOURCES = ["ddx_api.hip", "k_sparse.hip", "k_pca.hip", "k_knn.hip", "k_prologue.hip", "k_louvain.hip"]
 CXX_SOURCES = ["louvain.cpp", "hostmath.cpp"]
 HEADERS = ["ddx_internal.h", os.path.join("..", "..", "include", "ddx.h")]
@@ -45,8 +47,9 @@ def build(force: bool = False, verbose: bool = True) -> str:
         o = os.path.join(OBJ, src + ".o")
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result",
-                   "-c", s, "-o", o]
+            cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result"]
+            cmd += EXTRA_FLAGS.get(src, [])
+            cmd += ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((cmd, subprocess.Popen(cmd)))

@@ -36,7 +36,7 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 // layout is embedding row perm[r];  p1[r] = its first component (+inf for padding rows).
 __global__ void k_knn_prepare(const float* __restrict__ in, const int32_t* __restrict__ perm, int64_t M, int64_t Mp, int C, int CP,
                               float* __restrict__ E, float* __restrict__ Et, __bf16* __restrict__ Eb,
-                              float* __restrict__ nrm, float* __restrict__ p1) {
+                              float* __restrict__ nrm, float* __restrict__ p1, f4* __restrict__ start4) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= Mp) return;
     const int64_t src = r < M ? perm[r] : 0;
@@ -57,6 +57,9 @@ __global__ void k_knn_prepare(const float* __restrict__ in, const int32_t* __res
         n = fmaf(v, v, n);
     }
     nrm[r] = (r < M) ? n : __builtin_huge_valf();
+    // accumulator start value of the bfloat16 emit pass, as one MFMA C quad: -0.5*(1-slack)*|c|^2 (-inf for padding)
+    const float h = (r < M) ? -0.5f * (1.0f - 4.0e-5f) * n : -__builtin_huge_valf();
+    start4[r] = f4{h, h, h, h};
 }
 
 // Screen slack: |fl32(|q|^2 + |c|^2 - 2 q.c) - d2| <= (CP + 8) * 2^-24 * (|q|^2 + |c|^2) for the float32
@@ -350,6 +353,15 @@ struct TileStageBf {           // one chunk = chunk_tiles(CP) tiles x (hi|lo) x 
         for (int u = 0; u < kVec; ++u) lds_c[u * 256 + tid] = regs[u];
         if (tid < kChunkTiles * 16) lds_n[tid] = nreg;
     }
+    // emit pass: instead of |c|^2 store the accumulator start value -0.5*(1-slack)*|c|^2, four times (one MFMA C quad)
+    __device__ __forceinline__ void commit_start(f4* lds_c, f4* lds_h, int tid) const {
+#pragma unroll
+        for (int u = 0; u < kVec; ++u) lds_c[u * 256 + tid] = regs[u];
+        if (tid < kChunkTiles * 16) {
+            const float h = -0.5f * (1.0f - kScreenSlackBf) * nreg;
+            lds_h[tid] = f4{h, h, h, h};
+        }
+    }
 };
 
 template <int CP, int RT>
@@ -367,9 +379,21 @@ struct QueryTilesBf {
             }
     }
     // tile image in LDS: [kb][part][lane] vectors of 16 bytes
-    __device__ __forceinline__ void dots(const f4* tile, int lane, f4 (&acc)[RT]) const {
+    __device__ __forceinline__ void dots(const f4* tile, int lane, f4 (&acc)[RT]) const { dots_from(tile, lane, f4{0.f, 0.f, 0.f, 0.f}, acc); }
+    // one 32-component block whose candidate operands are already in registers (CP = 32)
+    __device__ __forceinline__ void dots_regs(const f4 rh, const f4 rl, const f4 start, f4 (&acc)[RT]) const {
+        const bf16x8 bh = __builtin_bit_cast(bf16x8, rh);
+        const bf16x8 bl = __builtin_bit_cast(bf16x8, rl);
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) acc[rt] = f4{0.f, 0.f, 0.f, 0.f};
+        for (int rt = 0; rt < RT; ++rt) {
+            acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[rt][0], bh, start, 0, 0, 0);   // small terms first
+            acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt][0], bl, acc[rt], 0, 0, 0);
+            acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt][0], bh, acc[rt], 0, 0, 0);
+        }
+    }
+    __device__ __forceinline__ void dots_from(const f4* tile, int lane, const f4 start, f4 (&acc)[RT]) const {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[rt] = start;
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) {
             const f4 rh = tile[(kb * 2 + 0) * 64 + lane];
@@ -477,29 +501,33 @@ TileStageBf<CP> st;
 }
 
 template <int CP>
-__global__ void __launch_bounds__(256) k_knn_emit_bf(const __bf16* __restrict__ Eb, const float* __restrict__ nrm,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) k_knn_emit_bf(const __bf16* __restrict__ Eb, const float* __restrict__ nrm, const f4* __restrict__ start4,
                                                      const float* __restrict__ thr, int64_t Mp, int include_self,
-                                                     int32_t* __restrict__ ccount, int32_t* __restrict__ cbuf, const int32_t* __restrict__ win) {
+                                                     int32_t* __restrict__ ccount, int32_t* __restrict__ cbuf, const int32_t* __restrict__ win, int dbg) {
     constexpr int RT = kEmitRT, NV = 4 * RT;
     constexpr int kChunkTiles = chunk_tiles(CP);
     constexpr int tile_vecs = 16 * CP * 4 / 16;
     __shared__ f4 lds_c[2][kChunkTiles * tile_vecs];
-    __shared__ float lds_n[2][kChunkTiles * 16];
-    __shared__ int32_t lcnt[4][16 * kEmitRT];
+    __shared__ f4 lds_h[2][kChunkTiles * 16];     // accumulator start values -0.5*(1-slack)*|c|^2 (see commit_start)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (lane < 16 * kEmitRT) lcnt[wave][lane] = 0;
     const int64_t q0 = ((int64_t)blockIdx.x * 4 + wave) * (16 * RT);
     QueryTilesBf<CP, RT> qt;
     qt.load(Eb, q0, lane);
     const int rbase = 4 * (lane >> 4), jcol = lane & 15;
+    // A wave is the only writer of its 16*RT queries' candidate lists, and the 16 lanes of a lane group see the same
+    // NV queries: every lane keeps the NV slot counters of its group in registers (identical in the 16 lanes, updated
+    // by all of them from the ballot masks), so appending needs no atomics and no cross-lane traffic.
+    int cnt[NV];
     float hr[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
+        cnt[v] = 0;
         const int64_t q = q0 + (v >> 2) * 16 + rbase + (v & 3);
         const float n = nrm[q], t = thr[q];
         hr[v] = 0.5f * ((1.0f - kScreenSlackBf) * n - t);
         if (!(n < __builtin_huge_valf())) hr[v] = __builtin_huge_valf();
         else if (!(t < __builtin_huge_valf())) hr[v] = -__builtin_huge_valf();
+        if (dbg & 1) hr[v] = __builtin_huge_valf();          // experiment: nothing passes the screen
     }
     // candidate tiles whose first component can be within reach of any query of this block (k_knn_window)
     const int64_t t_lo = win[2 * blockIdx.x], ntiles = win[2 * blockIdx.x + 1] - t_lo;
@@ -509,24 +537,55 @@ __global__ void __launch_bounds__(256) k_knn_emit_bf(const __bf16* __restrict__ 
     }
     const int64_t own_tile = q0 >> 4;
     const int64_t nchunks = (ntiles + kChunkTiles - 1) / kChunkTiles;
-    TileStageBf<CP> st;
-    st.fetch(Eb + t_lo * 16 * CP * 2, nrm + t_lo * 16, 0, ntiles, 1, tid);
-    st.commit(lds_c[0], lds_n[0], tid);
+    // Chunk staging by asynchronous global -> LDS copies (16 bytes per lane, LDS destination = wave-uniform base +
+    // lane*16, no registers held): a chunk of kChunkTiles tiles is contiguous in Eb, as are its start quads.
+    const f4* srcE = reinterpret_cast<const f4*>(Eb) + t_lo * tile_vecs;
+    const f4* srcH = start4 + t_lo * 16;
+    const int64_t last_vec = ntiles * tile_vecs - 1, last_h = ntiles * 16 - 1;
+    auto stage = [&](int64_t ch, int buf) {
+#pragma unroll
+        for (int u = 0; u < kChunkTiles * tile_vecs / 256; ++u) {
+            int64_t g = ch * (kChunkTiles * tile_vecs) + u * 256 + tid;
+            if (g > last_vec) g = last_vec;                       // the ragged last chunk re-reads the last tile
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcE + g),
+                                             (__attribute__((address_space(3))) void*)(lds_c[buf] + u * 256 + wave * 64), 16, 0, 0);
+        }
+        if (tid < kChunkTiles * 16) {                             // whole waves (kChunkTiles*16 is a multiple of 64)
+            int64_t g = ch * (kChunkTiles * 16) + tid;
+            if (g > last_h) g = last_h;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcH + g),
+                                             (__attribute__((address_space(3))) void*)(lds_h[buf] + wave * 64), 16, 0, 0);
+        }
+    };
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int64_t ch = 0; ch < nchunks; ++ch) {
         const int buf = (int)(ch & 1);
-        if (ch + 1 < nchunks) st.fetch(Eb + t_lo * 16 * CP * 2, nrm + t_lo * 16, ch + 1, ntiles, 1, tid);
+        if (ch + 1 < nchunks) stage(ch + 1, buf ^ 1);
         const int ntile = (int)((ntiles - ch * kChunkTiles) < kChunkTiles ? (ntiles - ch * kChunkTiles) : kChunkTiles);
+        // operands of tile t+1 are read from LDS while tile t is on the matrix pipe
+        const f4* tb = lds_c[buf];
+        f4 rh = tb[lane], rl = tb[64 + lane], rs = lds_h[buf][jcol];
+        static_assert(CP == 32 || CP == 64, "");
         for (int t = 0; t < ntile; ++t) {
             const int64_t tile = t_lo + ch * kChunkTiles + t;
-            const float hc = 0.5f * (1.0f - kScreenSlackBf) * lds_n[buf][t * 16 + jcol];
+            const int tn = t + 1 < ntile ? t + 1 : t;
             f4 acc[RT];
-            qt.dots(lds_c[buf] + t * tile_vecs, lane, acc);
+            if (CP == 32) {
+                const f4 ch_ = rh, cl_ = rl, cs_ = rs;
+                rh = tb[tn * tile_vecs + lane];
+                rl = tb[tn * tile_vecs + 64 + lane];
+                rs = lds_h[buf][tn * 16 + jcol];
+                qt.dots_regs(ch_, cl_, cs_, acc);
+            } else {
+                qt.dots_from(tb + t * tile_vecs, lane, lds_h[buf][t * 16 + jcol], acc);
+            }
             // one compare per pair; the wave-wide masks live in scalar registers
             unsigned long long any = 0, hm[NV];
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
-                hm[v] = __ballot(acc[v >> 2][v & 3] > hc + hr[v]);
+                hm[v] = __ballot(acc[v >> 2][v & 3] > hr[v]);
                 any |= hm[v];
             }
             if (any) {
@@ -534,20 +593,28 @@ __global__ void __launch_bounds__(256) k_knn_emit_bf(const __bf16* __restrict__ 
                 const bool own = !include_self && (tile >= own_tile && tile < own_tile + RT);
 #pragma unroll
                 for (int v = 0; v < NV; ++v) {
-                    if (!((hm[v] >> lane) & 1ull)) continue;
-                    const int lq = (v >> 2) * 16 + rbase + (v & 3);
-                    const int64_t q = q0 + lq;
-                    if (own && q == cand) continue;
-                    // this wave is the only writer of its queries' lists: the slot counter lives in LDS
-                    const int slot = atomicAdd(&lcnt[wave][lq], 1);
-                    if (slot < kCandCap) cbuf[q * kCandCap + slot] = cand;
+                    unsigned long long m = hm[v];
+                    if (m == 0ull) continue;                     // wave-uniform: usually at most one of the masks is set
+                    const int64_t q = q0 + (v >> 2) * 16 + rbase + (v & 3);
+                    if (own) m &= ~__ballot(q == cand);          // a point is not its own neighbour
+                    const unsigned m16 = (unsigned)(m >> (lane & 48)) & 0xffffu;     // the 16 candidates of this lane group's query
+                    if (m16) {
+                        if ((m16 >> jcol) & 1u) {
+                            const int slot = cnt[v] + __popc(m16 & ((1u << jcol) - 1u));
+                            if (slot < kCandCap) cbuf[q * kCandCap + slot] = cand;
+                        }
+                        cnt[v] += __popc(m16);
+                    }
                 }
             }
         }
-        if (ch + 1 < nchunks) st.commit(lds_c[buf ^ 1], lds_n[buf ^ 1], tid);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the next chunk has landed before anyone crosses the barrier
         __syncthreads();
     }
-    if (lane < 16 * kEmitRT) ccount[q0 + lane] = lcnt[wave][lane];
+    if (jcol == 0) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) ccount[q0 + (v >> 2) * 16 + rbase + (v & 3)] = cnt[v];
+    }
 }
 
 // Exact squared distance in the reference's arithmetic: float64, (a-b)*(a-b) rounded, then added,
@@ -728,7 +795,7 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
     const int64_t Mp = ceil_div(M, 256) * 256;                 // whole blocks of queries in both MFMA passes
     // workspace (reuses the PCA row buffer): E [Mp*CP] | Et [Mp*CP] | Eb [Mp*CP as bf16 hi+lo] | nrm [Mp] | thr [Mp] | p1 [Mp] | keys [2*Mp]
     //            | ccount [Mp+64] | ids [2*Mp] | win [2*blocks] | cbuf [Mp*cap]
-    const size_t f_words = (size_t)Mp * CP * 3 + 5 * (size_t)Mp;
+    const size_t f_words = (size_t)Mp * CP * 3 + 9 * (size_t)Mp + 16;
     const int64_t emit_blocks = Mp / (4 * 16 * kEmitRT);
     const size_t i_words = (size_t)Mp + 64 + 2 * (size_t)Mp + 2 * (size_t)emit_blocks + 64 + (size_t)Mp * kCandCap;
     DDX_TRY(ensure(ctx, ctx->pcaA, sizeof(float) * f_words + sizeof(int32_t) * i_words + 256));
@@ -742,9 +809,10 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
     float* p1 = thr + Mp;
     float* keys_in = p1 + Mp;
     float* keys_out = keys_in + Mp;
+    f4* start4 = reinterpret_cast<f4*>(keys_out + Mp + ((4 - ((3 * (size_t)Mp * CP + 5 * (size_t)Mp) & 3)) & 3));   // 16-byte aligned
     const char* scr = getenv("DDX_KNN_SCREEN");
     const bool bf = !(scr && scr[0] == 'f' && scr[1] == '3');          // DDX_KNN_SCREEN=f32 selects the float32 MFMA screen
-    int32_t* ccount = reinterpret_cast<int32_t*>(keys_out + Mp);   // [Mp] + overflow counter at [Mp]
+    int32_t* ccount = reinterpret_cast<int32_t*>(reinterpret_cast<float*>(start4) + 4 * (size_t)Mp);   // [Mp] + overflow counter at [Mp]
     int32_t* ids_in = ccount + Mp + 64;
     int32_t* perm = ids_in + Mp;
     int32_t* win = perm + Mp;
@@ -758,7 +826,7 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
         DDX_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys_in, keys_out, ids_in, perm, (int)M, 0, 32, ctx->stream));
         DDX_TRY(ensure(ctx, ctx->sort_tmp, tmp_bytes));
         DDX_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(ctx->sort_tmp.p, tmp_bytes, keys_in, keys_out, ids_in, perm, (int)M, 0, 32, ctx->stream));
-        k_knn_prepare<<<(unsigned)ceil_div(Mp, 256), 256, 0, ctx->stream>>>(ctx->emb32.as<float>(), perm, M, Mp, C, CP, E, Et, Eb, nrm, p1);
+        k_knn_prepare<<<(unsigned)ceil_div(Mp, 256), 256, 0, ctx->stream>>>(ctx->emb32.as<float>(), perm, M, Mp, C, CP, E, Et, Eb, nrm, p1, start4);
     }
     DDX_HIP(ctx, hipMemsetAsync(ccount, 0, sizeof(int32_t) * (Mp + 64), ctx->stream));
     // Bound pass: the K-th smallest distance inside the nsamp tiles nearest to the query in first-component order is
@@ -782,9 +850,10 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
     {
         ScopedTimer t(ctx, "knn_emit");
         const unsigned grid = (unsigned)emit_blocks;
+        const int dbg_mode = getenv("DDX_KNN_EXPERIMENT") ? atoi(getenv("DDX_KNN_EXPERIMENT")) : 0;   // timing experiments only (wrong results)
         k_knn_window<<<grid, 64, 0, ctx->stream>>>(p1, thr, nrm, Mp, win);
-        if (bf && CP == 32) k_knn_emit_bf<32><<<grid, 256, 0, ctx->stream>>>(Eb, nrm, thr, Mp, include_self, ccount, cbuf, win);
-        else if (bf) k_knn_emit_bf<64><<<grid, 256, 0, ctx->stream>>>(Eb, nrm, thr, Mp, include_self, ccount, cbuf, win);
+        if (bf && CP == 32) k_knn_emit_bf<32><<<grid, 256, 0, ctx->stream>>>(Eb, nrm, start4, thr, Mp, include_self, ccount, cbuf, win, dbg_mode);
+        else if (bf) k_knn_emit_bf<64><<<grid, 256, 0, ctx->stream>>>(Eb, nrm, start4, thr, Mp, include_self, ccount, cbuf, win, dbg_mode);
         else if (CP == 32) k_knn_emit<32><<<grid, 256, 0, ctx->stream>>>(Et, nrm, thr, Mp, include_self, ccount, cbuf, win);
         else k_knn_emit<64><<<grid, 256, 0, ctx->stream>>>(Et, nrm, thr, Mp, include_self, ccount, cbuf, win);
     }
