@@ -70,6 +70,7 @@ struct ddx_ctx {
     int64_t nnz = 0;                 // stored entries of the N x H counts
     std::vector<int64_t> h_indptr;   // host copy of the row pointer (capacity planning)
     bool have_counts = false;
+    bool counts_exact = false;       // counts are small non-negative integers: row sums are exact in any order
 
     // augmented matrix (rows 0..N-1 = originals, N..M-1 = synthetic doublets), CSR
     int64_t S = 0, M = 0;
@@ -93,7 +94,7 @@ struct ddx_ctx {
     ddx::DevBuf csc_s_row;           // int32 [cap_synth]  (row ids already offset by N)
     ddx::DevBuf csc_s_raw;           // float [cap_synth]
     ddx::DevBuf csc_s_x;             // float [cap_synth]
-    ddx::DevBuf sort_keys_in, sort_keys_out, sort_vals_in, sort_vals_out, sort_tmp;
+    ddx::DevBuf sort_keys_in, sort_keys_out, sort_vals_in, sort_vals_out, sort_tmp, sort_rowid;
     // the mirror is ordered by (row panel, column): entries of column j inside panel p form the segment
     // colptr[p*H + j] .. colptr[p*H + j + 1].  A panel is kPanelRows consecutive rows of the augmented
     // matrix, so the rows gathered while a panel is processed stay L2-resident.
@@ -114,6 +115,7 @@ struct ddx_ctx {
     ddx::DevBuf zcol;                // float  [H] value of unstored entries per column
     ddx::DevBuf colmean;             // double [H] mean over rows of (x - zcol) (0 for unstored)
     ddx::DevBuf colstat;             // double [2H] scratch for scale
+    ddx::DevBuf col_part;            // double [2 x (panels x H)] per-(panel, column) partial sums
 
     // PCA work space
     int32_t C = 0;

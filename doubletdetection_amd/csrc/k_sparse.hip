@@ -74,6 +74,34 @@ __global__ void __launch_bounds__(256) k_row_sums(const int64_t* __restrict__ in
     }
 }
 
+// Counts are normally non-negative integers with library sizes far below 2^23: then every partial sum of a row -- of an
+// original cell or of a doublet (the sum of two of them) -- is an integer below 2^24, exact in float32 whatever the
+// order, and the sequential replay above can be replaced by a lane-strided sum.  flag[0] stays 1 iff that holds.
+__global__ void k_counts_exact(const float* __restrict__ val, int64_t nnz, const float* __restrict__ lib32, int64_t nrows, int* __restrict__ flag) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool ok = true;
+    if (t < nnz) { const float v = val[t]; ok = v >= 0.f && v == truncf(v); }
+    if (t < nrows) ok = ok && lib32[t] < 8388608.f;
+    if (!ok) flag[0] = 0;
+}
+
+__global__ void __launch_bounds__(256) k_row_sums_exact(const int64_t* __restrict__ indptr, const float* __restrict__ val,
+                                                        int64_t row0, int64_t nrows, float* __restrict__ lib32,
+                                                        double* __restrict__ lib64) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= nrows) return;
+    const int64_t row = row0 + r;
+    float s = 0.f;
+    for (int64_t p = indptr[row] + lane; p < indptr[row + 1]; p += 64) s += val[p];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) {
+        lib32[row] = s;
+        lib64[row] = (double)s;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // doublets
 // ------------------------------------------------------------------------------------------------
@@ -287,13 +315,16 @@ __global__ void k_iota_u32(uint32_t* out, int64_t n, uint32_t base) {
 // sort key of every stored entry of rows [row_lo, row_lo+nrows): (panel(row) - panel0) * H + column
 __global__ void __launch_bounds__(256) k_panel_keys(const int64_t* __restrict__ indptr, const int32_t* __restrict__ cols,
                                                     int64_t row_lo, int64_t nrows, int32_t H, int32_t panel0, int32_t panel_rows,
-                                                    int64_t e0, int32_t* __restrict__ keys) {
+                                                    int64_t e0, int32_t* __restrict__ keys, int32_t* __restrict__ rowid) {
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (r >= nrows) return;
     const int64_t row = row_lo + r;
     const int32_t base = ((int32_t)(row / panel_rows) - panel0) * H;
-    for (int64_t p = indptr[row] + lane; p < indptr[row + 1]; p += 64) keys[p - e0] = base + cols[p];
+    for (int64_t p = indptr[row] + lane; p < indptr[row + 1]; p += 64) {
+        keys[p - e0] = base + cols[p];
+        rowid[p - e0] = (int32_t)row;                // looked up again after the sort (cheaper than a search in indptr)
+    }
 }
 
 // colptr[j] = first sorted position whose key >= j, j in [0, nkeys]
@@ -308,20 +339,13 @@ __global__ void k_colptr_from_sorted(const int32_t* __restrict__ keys, int64_t n
     colptr[j] = lo;
 }
 
-// gather row id and raw value of every mirror entry; pos = CSR position
-__global__ void k_csc_gather(const uint32_t* __restrict__ pos, int64_t n, const int64_t* __restrict__ indptr,
-                             int64_t row_lo, int64_t row_hi, const float* __restrict__ raw,
-                             int32_t* __restrict__ row_out, float* __restrict__ raw_out) {
+// gather row id and raw value of every mirror entry; pos = CSR position, rowid indexed by pos - e0
+__global__ void k_csc_gather(const uint32_t* __restrict__ pos, int64_t n, int64_t e0, const int32_t* __restrict__ rowid,
+                             const float* __restrict__ raw, int32_t* __restrict__ row_out, float* __restrict__ raw_out) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     const int64_t p = pos[t];
-    // rows [row_lo, row_hi): indptr[row_lo] <= p < indptr[row_hi]
-    int64_t lo = row_lo, hi = row_hi;
-    while (hi - lo > 1) {
-        int64_t mid = (lo + hi) >> 1;
-        if (indptr[mid] <= p) lo = mid; else hi = mid;
-    }
-    row_out[t] = (int32_t)lo;
+    row_out[t] = rowid[p - e0];
     raw_out[t] = raw[p];
 }
 
@@ -342,10 +366,11 @@ static int build_csc(ddx_ctx* ctx, int64_t e0, int64_t n, int64_t row_lo, int64_
     DDX_TRY(ensure(ctx, ctx->sort_keys_out, sizeof(int32_t) * n));
     DDX_TRY(ensure(ctx, ctx->sort_vals_in, sizeof(uint32_t) * n));
     DDX_TRY(ensure(ctx, ctx->sort_vals_out, sizeof(uint32_t) * n));
+    DDX_TRY(ensure(ctx, ctx->sort_rowid, sizeof(int32_t) * n));
     k_iota_u32<<<(unsigned)ceil_div(n, 256), 256, 0, ctx->stream>>>(ctx->sort_vals_in.as<uint32_t>(), n, (uint32_t)e0);
     k_panel_keys<<<(unsigned)ceil_div(row_hi - row_lo, 4), 256, 0, ctx->stream>>>(ctx->aug_indptr.as<int64_t>(), ctx->aug_indices.as<int32_t>(),
                                                                                  row_lo, row_hi - row_lo, H, panel0, ctx->panel_rows, e0,
-                                                                                 ctx->sort_keys_in.as<int32_t>());
+                                                                                 ctx->sort_keys_in.as<int32_t>(), ctx->sort_rowid.as<int32_t>());
     int end_bit = 1;
     while (((int64_t)1 << end_bit) < nkeys64) ++end_bit;
     size_t tmp_bytes = 0;
@@ -363,10 +388,8 @@ static int build_csc(ddx_ctx* ctx, int64_t e0, int64_t n, int64_t row_lo, int64_
         ScopedTimer t(ctx, "csc_gather");
         k_colptr_from_sorted<<<(unsigned)ceil_div(nkeys + 1, 256), 256, 0, ctx->stream>>>(ctx->sort_keys_out.as<int32_t>(), n, nkeys,
                                                                                           colptr.as<int64_t>());
-        k_csc_gather<<<(unsigned)ceil_div(n, 256), 256, 0, ctx->stream>>>(ctx->sort_vals_out.as<uint32_t>(), n,
-                                                                          ctx->aug_indptr.as<int64_t>(), row_lo, row_hi,
-                                                                          ctx->aug_raw.as<float>(), rows.as<int32_t>(),
-                                                                          raws.as<float>());
+        k_csc_gather<<<(unsigned)ceil_div(n, 256), 256, 0, ctx->stream>>>(ctx->sort_vals_out.as<uint32_t>(), n, e0, ctx->sort_rowid.as<int32_t>(),
+                                                                          ctx->aug_raw.as<float>(), rows.as<int32_t>(), raws.as<float>());
     }
     DDX_HIP(ctx, hipGetLastError());
     return DDX_OK;
@@ -431,6 +454,17 @@ int stage_upload_counts(ddx_ctx* ctx, int64_t N, int32_t H, const int64_t* indpt
     ctx->panel_rows = (spmm_lds() && pca_gather_f32()) ? kLdsPanelRows : kGatherPanelRows;
     ctx->P_o = (int32_t)ceil_div(N, ctx->panel_rows);
     DDX_TRY(build_csc(ctx, 0, nnz, 0, N, 0, ctx->P_o, ctx->csc_o_colptr, ctx->csc_o_row, ctx->csc_o_raw));
+    {
+        DDX_TRY(ensure(ctx, ctx->median, 256));
+        int one = 1, exact = 0;
+        int* flag = ctx->median.as<int>() + 8;
+        DDX_HIP(ctx, hipMemcpyAsync(flag, &one, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        const int64_t span = nnz > N ? nnz : N;
+        k_counts_exact<<<(unsigned)ceil_div(span, 256), 256, 0, ctx->stream>>>(ctx->aug_raw.as<float>(), nnz, ctx->lib32.as<float>(), N, flag);
+        DDX_HIP(ctx, hipMemcpyAsync(&exact, flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->counts_exact = exact != 0 && !getenv("DDX_ROW_SUMS_SEQUENTIAL");
+    }
     DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->have_counts = true;
     return DDX_OK;
@@ -541,44 +575,67 @@ __global__ void k_fill_f32(float* out, int64_t n, float v) {
     if (i < n) out[i] = v;
 }
 
-// Per column j (one 256-thread block): deterministic float64 sums over the stored entries of both
-// column-major segments.  mode 0: colmean[j] = sum(x - z_j) / M.
-// mode 1 (scale statistics): stat[2j] = sum(x - z_j), stat[2j+1] = sum(float32(x*x)) , cnt via colptr.
-__global__ void __launch_bounds__(256) k_col_sums(const int64_t* __restrict__ cp_o, const float* __restrict__ x_o, int P_o,
-                                                  const int64_t* __restrict__ cp_s, const float* __restrict__ x_s, int P_s,
-                                                  const float* __restrict__ zcol, int32_t H, int64_t M, int mode,
-                                                  double* __restrict__ out) {
-    __shared__ double red[2][256];
-    const int j = blockIdx.x, tid = threadIdx.x;
-    const double z = (double)zcol[j];
+// Column sums over the stored entries of both column-major mirrors, in two deterministic stages.  A (panel, column)
+// segment is contiguous, and so are the segments of consecutive columns of one panel: stage 1 gives every segment to
+// 16 lanes (lane-strided float64 partial sums, fixed butterfly), stage 2 adds the panels of a column in order.
+// mode 0: colmean[j] = sum(x - z_j) / M.
+// mode 1 (scale statistics): stat[2j] = sum(x - z_j), stat[2j+1] = sum(float32(x*x)).
+__global__ void __launch_bounds__(256) k_col_partials(const int64_t* __restrict__ cp, const float* __restrict__ x, int64_t nseg, int32_t H,
+                                                      const float* __restrict__ zcol, int mode, double* __restrict__ part) {
+    // 16 lanes per segment (a segment holds a few dozen entries): 16 segments per workgroup
+    const int sub = threadIdx.x & 15;
+    const int64_t seg = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool live = seg < nseg;
     double a = 0.0, b = 0.0;
-    for (int seg = 0; seg < 2; ++seg) {
-        const int64_t* cp = seg ? cp_s : cp_o;
-        const float* x = seg ? x_s : x_o;
-        const int P = seg ? P_s : P_o;
-        for (int p = 0; p < P; ++p) {
-            const int64_t lo = cp[(int64_t)p * H + j], hi = cp[(int64_t)p * H + j + 1];
-            for (int64_t t = lo + tid; t < hi; t += 256) {
-                const float xv = x[t];
-                a += (double)xv - z;
-                if (mode) { const float sq = xv * xv; b += (double)sq; }
-            }
+    if (live) {
+        const double z = (double)zcol[(int)(seg % H)];
+        const int64_t lo = cp[seg], hi = cp[seg + 1];
+        for (int64_t t = lo + sub; t < hi; t += 16) {
+            const float xv = x[t];
+            a += (double)xv - z;
+            if (mode) { const float sq = xv * xv; b += (double)sq; }
         }
     }
-    red[0][tid] = a;
-    red[1][tid] = b;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if (tid < off) {
-            red[0][tid] += red[0][tid + off];
-            red[1][tid] += red[1][tid + off];
-        }
-        __syncthreads();
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+        a += __shfl_xor(a, o, 64);
+        if (mode) b += __shfl_xor(b, o, 64);
     }
-    if (tid == 0) {
-        if (mode == 0) out[j] = red[0][0] / (double)M;
-        else { out[2 * j] = red[0][0]; out[2 * j + 1] = red[1][0]; }
+    if (live && sub == 0) {
+        part[seg] = a;
+        if (mode) part[nseg + seg] = b;
     }
+}
+
+__global__ void k_col_reduce(const double* __restrict__ part_o, int P_o, int64_t nseg_o, const double* __restrict__ part_s, int P_s,
+                             int64_t nseg_s, int32_t H, int64_t M, int mode, double* __restrict__ out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= H) return;
+    double a = 0.0, b = 0.0;
+    for (int p = 0; p < P_o; ++p) {
+        a += part_o[(int64_t)p * H + j];
+        if (mode) b += part_o[nseg_o + (int64_t)p * H + j];
+    }
+    for (int p = 0; p < P_s; ++p) {
+        a += part_s[(int64_t)p * H + j];
+        if (mode) b += part_s[nseg_s + (int64_t)p * H + j];
+    }
+    if (mode == 0) out[j] = a / (double)M;
+    else { out[2 * j] = a; out[2 * j + 1] = b; }
+}
+
+static int col_sums(ddx_ctx* ctx, int mode, double* out) {
+    const int32_t H = ctx->H;
+    const int64_t nseg_o = (int64_t)ctx->P_o * H, nseg_s = (int64_t)ctx->P_s * H;
+    DDX_TRY(ensure(ctx, ctx->col_part, sizeof(double) * 2 * (size_t)(nseg_o + nseg_s + 2)));
+    double* part_o = ctx->col_part.as<double>();
+    double* part_s = part_o + 2 * nseg_o;
+    if (nseg_o) k_col_partials<<<(unsigned)ceil_div(nseg_o, 16), 256, 0, ctx->stream>>>(ctx->csc_o_colptr.as<int64_t>(), ctx->csc_o_x.as<float>(), nseg_o, H,
+                                                                                     ctx->zcol.as<float>(), mode, part_o);
+    if (nseg_s) k_col_partials<<<(unsigned)ceil_div(nseg_s, 16), 256, 0, ctx->stream>>>(ctx->csc_s_colptr.as<int64_t>(), ctx->csc_s_x.as<float>(), nseg_s, H,
+                                                                                     ctx->zcol.as<float>(), mode, part_s);
+    k_col_reduce<<<(unsigned)ceil_div(H, 256), 256, 0, ctx->stream>>>(part_o, ctx->P_o, nseg_o, part_s, ctx->P_s, nseg_s, H, ctx->M, mode, out);
+    return DDX_OK;
 }
 
 int stage_lognormalise(ddx_ctx* ctx, float pseudocount) {
@@ -591,7 +648,11 @@ int stage_lognormalise(ddx_ctx* ctx, float pseudocount) {
     const int64_t nnz_s = nnz_aug - ctx->nnz;
     if (S) {
         ScopedTimer t(ctx, "row_sums");
-        k_row_sums<<<(unsigned)ceil_div(S, 4), 256, 0, ctx->stream>>>(ctx->aug_indptr.as<int64_t>(), ctx->aug_raw.as<float>(), N, S,
+if (ctx->counts_exact)
+            k_row_sums_exact<<<(unsigned)ceil_div(S, 4), 256, 0, ctx->stream>>>(ctx->aug_indptr.as<int64_t>(), ctx->aug_raw.as<float>(), N, S,
+                                                                      ctx->lib32.as<float>(), ctx->lib64.as<double>());
+        else
+            k_row_sums<<<(unsigned)ceil_div(S, 4), 256, 0, ctx->stream>>>(ctx->aug_indptr.as<int64_t>(), ctx->aug_raw.as<float>(), N, S,
                                                                       ctx->lib32.as<float>(), ctx->lib64.as<double>());
     }
     // median of the augmented library sizes
@@ -631,8 +692,7 @@ int stage_lognormalise(ddx_ctx* ctx, float pseudocount) {
     k_fill_f32<<<(unsigned)ceil_div(H, 256), 256, 0, ctx->stream>>>(ctx->zcol.as<float>(), H, z);
     {
         ScopedTimer t(ctx, "col_sums");
-        k_col_sums<<<(unsigned)H, 256, 0, ctx->stream>>>(ctx->csc_o_colptr.as<int64_t>(), ctx->csc_o_x.as<float>(), ctx->P_o, ctx->csc_s_colptr.as<int64_t>(),
-                                                         ctx->csc_s_x.as<float>(), ctx->P_s, ctx->zcol.as<float>(), H, M, 0, ctx->colmean.as<double>());
+        DDX_TRY(col_sums(ctx, 0, ctx->colmean.as<double>()));
     }
     DDX_HIP(ctx, hipGetLastError());
     ctx->pseudocount = pseudocount;
@@ -711,8 +771,7 @@ int stage_scale(ddx_ctx* ctx, float max_value) {
     double* mean = stat + 2 * H;
     double* sd = stat + 3 * H;
     ScopedTimer t(ctx, "scale");
-    k_col_sums<<<(unsigned)H, 256, 0, ctx->stream>>>(ctx->csc_o_colptr.as<int64_t>(), ctx->csc_o_x.as<float>(), ctx->P_o, ctx->csc_s_colptr.as<int64_t>(),
-                                                     ctx->csc_s_x.as<float>(), ctx->P_s, ctx->zcol.as<float>(), H, M, 1, stat);
+    DDX_TRY(col_sums(ctx, 1, stat));
     k_scale_stats<<<(unsigned)ceil_div(H, 256), 256, 0, ctx->stream>>>(stat, ctx->csc_o_colptr.as<int64_t>(), ctx->P_o, ctx->csc_s_colptr.as<int64_t>(),
                                                                        ctx->P_s, ctx->zcol.as<float>(), M, H, mean, sd);
     k_scale_rows<<<2048, 256, 0, ctx->stream>>>(ctx->aug_indices.as<int32_t>(), M, ctx->aug_indptr.as<int64_t>(), mean, sd, max_value,
@@ -720,8 +779,7 @@ int stage_scale(ddx_ctx* ctx, float max_value) {
     k_scale_cols<<<(unsigned)H, 256, 0, ctx->stream>>>(ctx->csc_o_colptr.as<int64_t>(), ctx->P_o, H, mean, sd, max_value, ctx->csc_o_x.as<float>());
     k_scale_cols<<<(unsigned)H, 256, 0, ctx->stream>>>(ctx->csc_s_colptr.as<int64_t>(), ctx->P_s, H, mean, sd, max_value, ctx->csc_s_x.as<float>());
     k_scale_zcol<<<(unsigned)ceil_div(H, 256), 256, 0, ctx->stream>>>(mean, sd, max_value, H, ctx->zcol.as<float>());
-    k_col_sums<<<(unsigned)H, 256, 0, ctx->stream>>>(ctx->csc_o_colptr.as<int64_t>(), ctx->csc_o_x.as<float>(), ctx->P_o, ctx->csc_s_colptr.as<int64_t>(),
-                                                     ctx->csc_s_x.as<float>(), ctx->P_s, ctx->zcol.as<float>(), H, M, 0, ctx->colmean.as<double>());
+    DDX_TRY(col_sums(ctx, 0, ctx->colmean.as<double>()));
     DDX_HIP(ctx, hipGetLastError());
     ctx->scaled = true;
     ctx->have_emb = ctx->have_knn = false;
