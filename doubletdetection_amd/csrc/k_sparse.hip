@@ -45,7 +45,8 @@ __device__ __forceinline__ int64_t row_of_pos(const int64_t* __restrict__ indptr
     return lo;
 }
 
-// Sequential (scipy csr_matvec order) float32 row sum and sklearn's double L1 norm.  One wave per
+// Sequential (scipy csr_matvec order; exact and hence order-free for count data -- a scipy that reduces pairwise
+// can differ by an ulp or two on fractional input) float32 row sum and sklearn's double L1 norm.  One wave per
 // row: the wave loads 64 entries at a time (coalesced), then every lane replays the same left-to-right
 // additions through readlane broadcasts, so the result is the scalar loop's, bit for bit.
 __global__ void __launch_bounds__(256) k_row_sums(const int64_t* __restrict__ indptr, const float* __restrict__ val,

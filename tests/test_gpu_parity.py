@@ -118,6 +118,36 @@ def test_doublets_edge_cases(ctx):
     assert ctx.get_synth().shape == (0, raw.shape[1])
 
 
+def test_library_sizes_integer_and_fractional_counts(ctx):
+    """Small integer counts take an order-free row sum (exact in float32, so bit-identical to the reference whatever
+    order its scipy sums in); fractional input falls back to a left-to-right float32 accumulation (csr_matvec order),
+    which can differ from a scipy that reduces pairwise by an ulp or two."""
+    rng = np.random.default_rng(5)
+    dense = (rng.random((300, 900)) < 0.3) * rng.gamma(2.0, 37.123, size=(300, 900))
+    raw = sp.csr_matrix(dense.astype(np.float32))
+    raw.sort_indices()
+    ctx.upload_counts(raw)
+    parents = rng.integers(0, 300, size=(80, 2)).astype(np.int64)
+    ctx.create_doublets(parents)
+    ctx.lognormalise(0.1)
+    synth = orc.create_doublets(raw, parents)
+    want = np.concatenate([orc.library_sizes(raw), orc.library_sizes(synth)])
+    lib, _ = ctx.aug_lib()
+    np.testing.assert_allclose(lib, want, rtol=2e-6)
+    seq = np.array([np.add.accumulate(r.data, dtype=np.float32)[-1] if r.nnz else np.float32(0) for r in sp.vstack((raw, synth)).tocsr()],
+                   dtype=np.float32)
+    np.testing.assert_array_equal(lib, seq)                   # the documented order, bit for bit
+    # and the integer case through the fast path: same answer as any order
+    ints = sp.csr_matrix(np.floor(dense / 20.0).astype(np.float32))
+    ints.eliminate_zeros()
+    ints.sort_indices()
+    ctx.upload_counts(ints)
+    ctx.create_doublets(parents)
+    ctx.lognormalise(0.1)
+    want = np.concatenate([orc.library_sizes(ints), orc.library_sizes(orc.create_doublets(ints, parents))])
+    np.testing.assert_array_equal(ctx.aug_lib()[0], want)
+
+
 # ---- a7: log-normalisation (dd.py:286-298) -----------------------------------------------------------
 @pytest.mark.parametrize("case", ["case_a_hvg_pheno", "case_b_transposed_louvain", "case_d_replace_single"])
 def test_lognormalised_matrix(ctx, case):
