@@ -23,7 +23,7 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 t0 = int(rows[0]["Start_Timestamp"])
-for r in rows[-700:]:          # the last boosting iterations of the timed fit
+for r in rows[-1300:]:          # the last boosting iterations of the timed fit
     print(f'{(int(r["Start_Timestamp"]) - t0) / 1e6:10.3f} ms  {(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3:9.1f} us  {r["Kernel_Name"][:100]}')
 PY
 
