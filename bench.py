@@ -31,8 +31,8 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 
 # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide
-# coalesced reads, + WRITE_SIZE), headline workload, profiles/r01d_pmc_counters.txt; None = not collected
-PMC_TRAFFIC_GB = {"spmm_rows": 1.58, "spmm_cols": 1.59, "knn_emit": 4.56, "knn_bound": 0.81, "knn_select": 0.42}
+# coalesced reads, + WRITE_SIZE), headline workload, profiles/r01e_pmc_counters.txt; None = not collected
+PMC_TRAFFIC_GB = {"spmm_rows": 1.58, "spmm_cols": 1.59, "knn_emit": 4.69, "knn_bound": 0.81, "knn_select": 0.42}
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md)
 FP64_PEAK_TFLOPS = 78.6      # FP64 vector / FP64 MFMA peak, dense
@@ -56,7 +56,7 @@ def parse():
     return ap.parse_args()
 
 
-def kernel_models(N, G, H, S, nnz_aug, C, k, L=None):
+def kernel_models(N, G, H, S, nnz_aug, C, k, L=None, knn_window=1.0):
     """Algorithmic work per launch of the kernels that can dominate.
 
     HBM-bound kernels: bytes that must cross HBM once (matrix entries 8 B each + dense operands in and out).
@@ -65,13 +65,14 @@ def kernel_models(N, G, H, S, nnz_aug, C, k, L=None):
     L = L or (C + 10)
     CP = 32 if C <= 32 else 64
     Mp = -(-M // 256) * 256
-    nsamp_tiles = min(max(-(-k * M // (144 * 16)), 128), Mp // 16)
+    nsamp_tiles = min(max(512, (Mp // 16) // 16), Mp // 16)      # tiles of the bound pass's subset (stage_knn)
     return {
         # name: (bound, unit, work per launch, peak)
         "spmm_rows": ("hbm", "GB/s", (8 * nnz_aug + 8 * M * L + 8 * H * L + 8 * (M + 1)) / 1e9, HBM_PEAK_GBS),
         "spmm_cols": ("hbm", "GB/s", (8 * nnz_aug + 8 * H * L + 8 * M * L + 16 * (H + 1)) / 1e9, HBM_PEAK_GBS),
         # distance screen on the bfloat16 MFMA: three products (hi*hi, hi*lo, lo*hi) per pair and component
-        "knn_emit": ("mfma", "TFLOP/s", 3 * 2.0 * Mp * Mp * CP / 1e12, BF16_PEAK_TFLOPS),
+        # (the emit pass only screens the tile pairs its first-component window admits: measured fraction)
+        "knn_emit": ("mfma", "TFLOP/s", knn_window * 3 * 2.0 * Mp * Mp * CP / 1e12, BF16_PEAK_TFLOPS),
         "knn_bound": ("mfma", "TFLOP/s", 3 * 2.0 * Mp * nsamp_tiles * 16 * CP / 1e12, BF16_PEAK_TFLOPS),
         "pca_orth": ("hbm", "GB/s", (24 * M * L) / 1e9, HBM_PEAK_GBS),
         "doublet_fill": ("hbm", "GB/s", (8 * (nnz_aug * 2 * S / max(M + S, 1)) * 2) / 1e9, HBM_PEAK_GBS),
@@ -147,7 +148,7 @@ def main():
         nnz_aug = getattr(clf, "_last_nnz_aug", None) or int(X.nnz * 1.0)
         C = clf.n_components
         k = 30 if args.algorithm == "phenograph" else 10
-        models = kernel_models(N, G, H, S, nnz_aug, C, k)
+        models = kernel_models(N, G, H, S, nnz_aug, C, k, knn_window=getattr(clf, "_last_knn_window", 1.0))
         gpu_ms = {n: v[1] for n, v in timings.items()}
         dominant = max(gpu_ms, key=gpu_ms.get) if gpu_ms else None
         def roof(name):

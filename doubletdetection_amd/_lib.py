@@ -63,6 +63,7 @@ _SIGNATURES = {
     "ddx_set_embedding": (C.c_int, [C.c_void_p, c_f32_p, C.c_int64, C.c_int32]),
     "ddx_knn": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "ddx_get_knn": (C.c_int, [C.c_void_p, c_i32_p, c_f64_p]),
+    "ddx_get_knn_window_fraction": (C.c_int, [C.c_void_p, c_f64_p]),
     "ddx_build_graph": (C.c_int, [C.c_void_p, C.c_int32]),
     "ddx_graph_relations": (C.c_int, [C.c_void_p, C.c_int32, c_i32_p, c_f64_p]),
     "ddx_assemble_graph": (C.c_int, [C.c_int64, C.c_int32, c_i32_p, c_f64_p, c_i64_p, c_i32_p, c_f64_p]),
@@ -398,6 +399,11 @@ class Context:
         dist = np.empty((self._embM, self._K), dtype=np.float64) if with_dist else None
         self._c(self._lib.ddx_get_knn(self._h, _p(idx, c_i32_p), _p(dist, c_f64_p) if with_dist else None))
         return idx, (np.sqrt(dist) if with_dist else None)   # the C-ABI returns squared distances
+
+    def knn_window_fraction(self) -> float:
+        f = C.c_double(0.0)
+        self._c(self._lib.ddx_get_knn_window_fraction(self._h, C.byref(f)))
+        return f.value
 
     def build_graph(self, mode: int, fetch: bool = True):
         self._c(self._lib.ddx_build_graph(self._h, int(mode)))

@@ -192,6 +192,9 @@ class _HipEngine:
     def aug_nnz(self):
         return self.ctx.aug_nnz()
 
+    def knn_window_fraction(self):
+        return self.ctx.knn_window_fraction()
+
 
 class BoostClassifier:
     """Classifier for doublets in single-cell RNA-seq data (GPU implementation).
@@ -309,7 +312,9 @@ class BoostClassifier:
                     float(kw.get("resolution_parameter", 1.0)), int(seed), int(kw.get("min_cluster_size", 10)))
         if kw.get("directed", False):
             raise NotImplementedError("directed=True neighbour graphs are not implemented")
-        return 10, True, 2, float(kw["resolution"]), int(self.random_state), None
+        # sc.tl.louvain ignores the edge weights (use_weights=False); sc.tl.leiden runs on the umap connectivities
+        mode = 3 if self.clustering_algorithm == "leiden" else 2
+        return 10, True, mode, float(kw["resolution"]), int(self.random_state), None
 
     @staticmethod
     def _cluster_and_score(graph, gamma, seed, min_cluster_size, num_cells):
@@ -478,6 +483,8 @@ class BoostClassifier:
         self._device_timings = engine.timings() if hasattr(engine, "timings") else {}
         if mine and hasattr(engine, "aug_nnz"):
             self._last_nnz_aug = engine.aug_nnz()     # stored entries of the last augmented matrix
+        if mine and hasattr(engine, "knn_window_fraction"):
+            self._last_knn_window = engine.knn_window_fraction()   # share of the tile pairs the last kNN screened
 
         t_asm0 = time.perf_counter()
         self.all_scores_ = np.zeros((n_iters, num_cells))

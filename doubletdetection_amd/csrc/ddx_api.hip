@@ -453,12 +453,22 @@ int ddx_get_knn(ddx_ctx* ctx, int32_t* idx_out, double* dist_out) {
     return DDX_OK;
 }
 
+int ddx_get_knn_window_fraction(ddx_ctx* ctx, double* fraction) {
+    REQUIRE_CTX(ctx);
+    USE_DEVICE(ctx);
+    NEED(ctx->have_knn && ctx->knn_window_total && fraction, "no kNN result");
+    unsigned long long total = 0;
+    DDX_TRY(d2h(ctx, &total, ctx->knn_window_total, sizeof(total)));
+    *fraction = ctx->knn_window_pairs > 0.0 ? (double)total / ctx->knn_window_pairs : 0.0;
+    return DDX_OK;
+}
+
 int ddx_build_graph(ddx_ctx* ctx, int32_t mode) {
     REQUIRE_CTX(ctx);
     USE_DEVICE(ctx);
     NEED(ctx->have_knn, "no kNN result");
-    NEED(mode >= 0 && mode <= 2, "graph mode must be 0, 1 or 2");
-    if (mode == 2) { NEED(ctx->knn_self, "mode 2 expects a kNN table computed with include_self=1"); }
+    NEED(mode >= 0 && mode <= 3, "graph mode must be 0, 1, 2 or 3");
+    if (mode >= 2) { NEED(ctx->knn_self, "modes 2 and 3 expect a kNN table computed with include_self=1"); }
     else { NEED(!ctx->knn_self, "Jaccard graphs expect a kNN table computed with include_self=0"); }
     return stage_build_graph(ctx, mode);
 }
@@ -467,9 +477,9 @@ int ddx_graph_relations(ddx_ctx* ctx, int32_t mode, int32_t* idx_out, double* w_
     REQUIRE_CTX(ctx);
     USE_DEVICE(ctx);
     NEED(ctx->have_knn, "no kNN result");
-    NEED(mode >= 0 && mode <= 2, "graph mode must be 0, 1 or 2");
+    NEED(mode >= 0 && mode <= 3, "graph mode must be 0, 1, 2 or 3");
     NEED(idx_out && w_out, "null output");
-    if (mode == 2) { NEED(ctx->knn_self, "mode 2 expects a kNN table computed with include_self=1"); }
+    if (mode >= 2) { NEED(ctx->knn_self, "modes 2 and 3 expect a kNN table computed with include_self=1"); }
     else { NEED(!ctx->knn_self, "Jaccard graphs expect a kNN table computed with include_self=0"); }
     return stage_graph_relations(ctx, mode, idx_out, w_out);
 }

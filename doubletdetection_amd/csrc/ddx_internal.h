@@ -134,6 +134,8 @@ struct ddx_ctx {
     ddx::DevBuf knn_sorted;          // int32 [M*K] neighbour lists sorted by index
     ddx::DevBuf edge_w;              // double [M*K]
     bool have_knn = false;
+    const unsigned long long* knn_window_total = nullptr;   // device counter: (query block, candidate tile) pairs screened by the emit pass
+    double knn_window_pairs = 0.0;                          // the same count without pruning
 
     // graph: symmetric CSR left on the device by ddx_build_graph (views into pcaPanel)
     int64_t g_nodes = -1, g_entries = 0;

@@ -754,7 +754,7 @@ __global__ void k_knn_keys(const float* __restrict__ emb, int64_t M, int C, floa
 // q_1.  Points are sorted by that component, hence the admissible candidates of the whole block form one contiguous
 // range of tiles [win[2b], win[2b+1]).  The radius carries a 1e-5 relative margin for the float32 square root.
 __global__ void __launch_bounds__(64) k_knn_window(const float* __restrict__ p1, const float* __restrict__ thr, const float* __restrict__ nrm,
-                                                   int64_t Mp, int32_t* __restrict__ win) {
+                                                   int64_t Mp, int32_t* __restrict__ win, unsigned long long* __restrict__ total_tiles) {
     constexpr int QB = 4 * 16 * kEmitRT;
     const int lane = threadIdx.x;
     const int64_t qb = (int64_t)blockIdx.x * QB;
@@ -784,6 +784,7 @@ __global__ void __launch_bounds__(64) k_knn_window(const float* __restrict__ p1,
     }
     win[2 * blockIdx.x] = (int32_t)(first >> 4);
     win[2 * blockIdx.x + 1] = (int32_t)((last + 15) >> 4);
+    atomicAdd(total_tiles, (unsigned long long)(((last + 15) >> 4) - (first >> 4)));     // statistics only (bench.py's flop count)
 }
 
 int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
@@ -851,7 +852,7 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
         ScopedTimer t(ctx, "knn_emit");
         const unsigned grid = (unsigned)emit_blocks;
         const int dbg_mode = getenv("DDX_KNN_EXPERIMENT") ? atoi(getenv("DDX_KNN_EXPERIMENT")) : 0;   // timing experiments only (wrong results)
-        k_knn_window<<<grid, 64, 0, ctx->stream>>>(p1, thr, nrm, Mp, win);
+        k_knn_window<<<grid, 64, 0, ctx->stream>>>(p1, thr, nrm, Mp, win, reinterpret_cast<unsigned long long*>(ccount + Mp + 2));
         if (bf && CP == 32) k_knn_emit_bf<32><<<grid, 256, 0, ctx->stream>>>(Eb, nrm, start4, thr, Mp, include_self, ccount, cbuf, win, dbg_mode);
         else if (bf) k_knn_emit_bf<64><<<grid, 256, 0, ctx->stream>>>(Eb, nrm, start4, thr, Mp, include_self, ccount, cbuf, win, dbg_mode);
         else if (CP == 32) k_knn_emit<32><<<grid, 256, 0, ctx->stream>>>(Et, nrm, thr, Mp, include_self, ccount, cbuf, win);
@@ -877,6 +878,8 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
         fprintf(stderr, "[knn] k=%d sample tiles=%lld: candidates/query mean %.1f max %d, overflowed %lld (counter %d); emit window %.1f%% of the tiles\n",
                 k, (long long)nsamp, sum / M, mx, (long long)over, h[Mp], 100.0 * wsum / ((double)emit_blocks * (double)ntiles));
     }
+    ctx->knn_window_total = reinterpret_cast<const unsigned long long*>(ccount + Mp + 2);
+    ctx->knn_window_pairs = (double)emit_blocks * (double)ntiles;
     ctx->K = k;
     ctx->knn_self = include_self != 0;
     ctx->have_knn = true;
@@ -1004,6 +1007,73 @@ __global__ void __launch_bounds__(256) k_edge_weights_wave(const int32_t* __rest
     if (lane < K) w_out[i * K + lane] = myw;
 }
 
+// ---- umap connectivities (mode 3: what sc.tl.leiden clusters on) --------------------------------------------
+// oracle/dd_oracle.py:umap_connectivities states the computation (umap-learn's fuzzy_simplicial_set with
+// local_connectivity = 1, set_op_mix_ratio = 1): distances rounded to float32, everything else float64.
+// One thread per point: rho = smallest positive distance, sigma from 64 bisection steps, then the directed weights.
+__global__ void __launch_bounds__(256) k_umap_directed(const int32_t* __restrict__ idx, const double* __restrict__ d2, int64_t M, int K,
+                                                       double target, double* __restrict__ val) {
+#pragma clang fp contract(off)
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    const double* row = d2 + i * K;
+    double rho = __builtin_huge_val(), mean = 0.0;
+    for (int j = 0; j < K; ++j) {
+        const double d = (double)(float)sqrt(row[j]);
+        if (d > 0.0 && d < rho) rho = d;
+        mean = mean + d;
+    }
+    if (!(rho < __builtin_huge_val())) rho = 0.0;
+    mean = mean / (double)K;
+    double lo = 0.0, hi = __builtin_huge_val(), mid = 1.0;
+    for (int it = 0; it < 64; ++it) {
+        double psum = 0.0;
+        for (int j = 1; j < K; ++j) {
+            const double g = (double)(float)sqrt(row[j]) - rho;
+            psum = psum + (g > 0.0 ? exp(-(g / mid)) : 1.0);
+        }
+        if (psum > target) {
+            hi = mid;
+            mid = (lo + hi) / 2.0;
+        } else {
+            lo = mid;
+            mid = (hi < __builtin_huge_val()) ? (lo + hi) / 2.0 : mid * 2.0;
+        }
+    }
+    const double floor_v = 1e-3 * mean;
+    const double sigma = mid > floor_v ? mid : floor_v;
+    for (int j = 0; j < K; ++j) {
+        const int32_t c = idx[i * K + j];
+        const double g = (double)(float)sqrt(row[j]) - rho;
+        double v = (g <= 0.0 || sigma == 0.0) ? 1.0 : exp(-(g / sigma));
+        if (c == (int32_t)i || c < 0) v = 0.0;
+        val[i * K + j] = v;
+    }
+}
+
+// fuzzy union a + b - a*b with the reverse relation (b = 0 when j does not list i); a one-directional relation is
+// flagged by a negative weight, as for the other graph types (the assembly adds its reverse entry)
+__global__ void __launch_bounds__(256) k_umap_union(const int32_t* __restrict__ idx, const double* __restrict__ val, int64_t M, int K,
+                                                    double* __restrict__ w_out) {
+#pragma clang fp contract(off)
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= M * K) return;
+    const int64_t i = t / K;
+    const int32_t j = idx[t];
+    const double a = val[t];
+    if (j < 0 || j == (int32_t)i || a == 0.0) { w_out[t] = 0.0; return; }
+    double b = 0.0;
+    bool mutual = false;
+    for (int c = 0; c < K; ++c) {
+        if (idx[(int64_t)j * K + c] == (int32_t)i) {
+            const double bv = val[(int64_t)j * K + c];
+            if (bv != 0.0) { b = bv; mutual = true; }
+            break;
+        }
+    }
+    w_out[t] = mutual ? (a + b) - a * b : -a;
+}
+
 // ---- symmetric CSR on the device ----------------------------------------------------------------------
 // every relation with a non-zero weight contributes the pair (i,j); a one-directional relation (negative
 // flag) also contributes (j,i).  Pairs are keyed (row << 32 | column) and radix-sorted, which yields rows
@@ -1113,6 +1183,14 @@ static int graph_weights_device(ddx_ctx* ctx, int32_t mode) {
     DDX_TRY(ensure(ctx, ctx->knn_sorted, sizeof(int32_t) * (size_t)M * K));
     DDX_TRY(ensure(ctx, ctx->edge_w, sizeof(double) * (size_t)M * K));
     ScopedTimer t(ctx, "graph_weights");
+    if (mode == 3) {
+        // directed weights go to knn_sorted's neighbour (reused as float64 scratch: M*K doubles live in pcaOp)
+        DDX_TRY(ensure(ctx, ctx->pcaOp, sizeof(double) * (size_t)M * K));
+        double* val = ctx->pcaOp.as<double>();
+        k_umap_directed<<<(unsigned)ceil_div(M, 256), 256, 0, ctx->stream>>>(ctx->knn_idx.as<int32_t>(), ctx->knn_dist.as<double>(), M, K, std::log2((double)K), val);
+        k_umap_union<<<(unsigned)ceil_div(M * K, 256), 256, 0, ctx->stream>>>(ctx->knn_idx.as<int32_t>(), val, M, K, ctx->edge_w.as<double>());
+        return DDX_OK;
+    }
     k_sort_neighbours<<<(unsigned)ceil_div(M, 64), 64, sizeof(int32_t) * K * 64, ctx->stream>>>(ctx->knn_idx.as<int32_t>(), M, K, ctx->knn_sorted.as<int32_t>());
     if (K <= 64)
         k_edge_weights_wave<<<(unsigned)ceil_div(M, 4), 256, 0, ctx->stream>>>(ctx->knn_idx.as<int32_t>(), ctx->knn_sorted.as<int32_t>(), M, K, mode,

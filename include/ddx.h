@@ -128,11 +128,16 @@ int ddx_set_embedding(ddx_ctx* ctx, const float* emb, int64_t n_rows, int32_t n_
  * is a candidate); include_self = 0 reproduces phenograph (self removed). */
 int ddx_knn(ddx_ctx* ctx, int32_t k, int32_t include_self);
 int ddx_get_knn(ddx_ctx* ctx, int32_t* idx_out /* [M*k] */, double* dist2_out /* [M*k] or NULL */);
+/* statistics: share of the (query block, candidate tile) pairs the last ddx_knn had to screen after pruning on the
+ * first component (1 = all pairs).  bench.py scales the distance-screen flop count with it. */
+int ddx_get_knn_window_fraction(ddx_ctx* ctx, double* fraction);
 
 /* ---- graph construction (device) ------------------------------------------------------------
  * mode 0: PhenoGraph Jaccard graph, prune=True  (mutual kNN, weight J_ij*J_ji)
  * mode 1: PhenoGraph Jaccard graph, prune=False ((J + J^T)/2)
- * mode 2: scanpy neighbour topology, unit weights (union of kNN relations, self excluded)
+ * mode 2: scanpy neighbour topology, unit weights (union of kNN relations, self excluded): what sc.tl.louvain uses
+ * mode 3: the same topology with umap's fuzzy-simplicial-set weights (sc.pp.neighbors(method="umap") connectivities):
+ *         what sc.tl.leiden uses
  * Result: symmetric CSR on the host, fetched with ddx_get_graph. */
 int ddx_build_graph(ddx_ctx* ctx, int32_t mode);
 /* The same in two halves, so that the host half can run on a worker thread while the GPU moves on:

@@ -360,6 +360,59 @@ def union_knn_graph(idx_with_self: np.ndarray) -> sp.csr_matrix:
     return A
 
 
+def umap_connectivities(idx_with_self: np.ndarray, dist: np.ndarray) -> sp.csr_matrix:
+    """Weights of scanpy's ``sc.pp.neighbors(method="umap")`` graph, which ``sc.tl.leiden`` uses (use_weights=True):
+    umap-learn's ``fuzzy_simplicial_set`` (McInnes et al. 2018; ``smooth_knn_dist`` + ``compute_membership_strengths``
+    + fuzzy union, local_connectivity = 1, set_op_mix_ratio = 1).  PARITY UNPINNED (umap-learn absent).  Restated:
+
+    * distances enter as float32 (what scanpy hands over), everything else is float64;
+    * rho_i = smallest positive distance of row i (0 if none);
+    * sigma_i from 64 bisection steps on  sum_{j>=1} exp(-max(d_ij - rho_i, 0) / sigma) = log2(k)   (lo = 0,
+      hi = inf, start 1, doubling while hi is infinite) -- upstream stops early once within 1e-5, the restatement
+      always runs the 64 steps; then the floor sigma_i >= 1e-3 * mean(d_i.) (upstream uses the mean of *all* distances
+      for a row without a positive distance; such a row has mean 0 here and keeps its sigma);
+    * w_ij = 0 for j = i, 1 if d_ij <= rho_i or sigma_i = 0, else exp(-(d_ij - rho_i) / sigma_i);
+    * symmetric weight  a + b - a*b  with a = w_ij, b = w_ji (0 when absent)."""
+    idx = np.asarray(idx_with_self, dtype=np.int64)
+    d = np.asarray(dist, dtype=np.float64).astype(np.float32).astype(np.float64)
+    m, k = idx.shape
+    target = float(np.log2(k))
+    pos = np.where(d > 0.0, d, np.inf)
+    rho = pos.min(axis=1)
+    rho[~np.isfinite(rho)] = 0.0
+    lo = np.zeros(m)
+    hi = np.full(m, np.inf)
+    mid = np.ones(m)
+    gap = np.maximum(d[:, 1:] - rho[:, None], 0.0)
+    for _ in range(64):
+        psum = np.zeros(m)
+        for j in range(k - 1):                       # left-to-right, as the device does
+            psum = psum + np.where(gap[:, j] > 0.0, np.exp(-(gap[:, j] / mid)), 1.0)
+        over = psum > target
+        hi = np.where(over, mid, hi)
+        lo = np.where(over, lo, mid)
+        mid = np.where(over, (lo + hi) / 2.0, np.where(np.isinf(hi), mid * 2.0, (lo + hi) / 2.0))
+    rowmean = np.zeros(m)
+    for j in range(k):
+        rowmean = rowmean + d[:, j]
+    rowmean = rowmean / k
+    sigma = np.maximum(mid, 1e-3 * rowmean)
+    rows = np.repeat(np.arange(m), k)
+    cols = idx.ravel()
+    dd = d.ravel() - rho[rows]
+    val = np.where((dd <= 0.0) | (sigma[rows] == 0.0), 1.0, np.exp(-(dd / sigma[rows])))
+    val = np.where(cols == rows, 0.0, val)
+    keep = (cols >= 0) & (val != 0.0)
+    A = sp.coo_matrix((val[keep], (rows[keep], cols[keep])), shape=(m, m)).tocsr()
+    A.sum_duplicates()
+    T = A.T.tocsr()
+    S = A + T - A.multiply(T)
+    S = sp.csr_matrix(S)
+    S.eliminate_zeros()
+    S.sort_indices()
+    return S
+
+
 def relabel_by_size(labels: np.ndarray, min_cluster_size: int | None = None) -> np.ndarray:
     """Labels 0..K-1 by descending community size (ties: smaller original label first).
 
@@ -411,8 +464,9 @@ def cluster_embedding(emb: np.ndarray, algorithm: str, clustering_kwargs: dict, 
         seed = random_state if seed is None else int(seed)
         lab = louvain_fn(G.indptr, G.indices, G.data, gamma, seed)
         return relabel_by_size(lab, int(kw.get("min_cluster_size", 10)))
-    idx, _ = knn_fn(emb, 10, include_self=True)
-    G = union_knn_graph(idx)
+    idx, dist = knn_fn(emb, 10, include_self=True)
+    # sc.tl.louvain ignores the weights (use_weights=False), sc.tl.leiden uses the umap connectivities
+    G = umap_connectivities(idx, dist) if algorithm == "leiden" else union_knn_graph(idx)
     gamma = float(kw.get("resolution", 4))
     lab = louvain_fn(G.indptr, G.indices, G.data, gamma, int(random_state))
     return relabel_by_size(lab, None)

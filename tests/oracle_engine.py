@@ -41,8 +41,10 @@ class OracleEngine:
         # the product passes the start matrix it drew; the oracle draws the same one from the seed
         if emb is None:
             emb = orc.pca_f64(aug, n_components, self.seed)[0].astype(np.float32)
-        idx, _ = orc.knn_bruteforce_f64(emb, knn_k, include_self)
-        if graph_mode == 2:
+        idx, dist = orc.knn_bruteforce_f64(emb, knn_k, include_self)
+        if graph_mode == 3:
+            G = orc.umap_connectivities(idx, dist)
+        elif graph_mode == 2:
             G = orc.union_knn_graph(idx)
         else:
             G = orc.jaccard_graph(idx, prune=(graph_mode == 0))

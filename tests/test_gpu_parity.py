@@ -294,6 +294,14 @@ def test_graphs(ctx, case):
     np.testing.assert_array_equal(ip, G.indptr)
     np.testing.assert_array_equal(ix, G.indices)
     np.testing.assert_array_equal(w, G.data)
+    # umap connectivities (what leiden clusters on): same topology, weights to the last bits of exp()
+    idx, dist = ctx.get_knn()
+    ip3, ix3, w3 = ctx.build_graph(3)
+    U = orc.umap_connectivities(idx.astype(np.int64), dist)
+    np.testing.assert_array_equal(ip3, U.indptr)
+    np.testing.assert_array_equal(ix3, U.indices)
+    np.testing.assert_allclose(w3, U.data, rtol=1e-12, atol=0)
+    np.testing.assert_array_equal(ip3, ip)
 
 
 @pytest.mark.parametrize("case", ["case_a_hvg_pheno", "case_b_transposed_louvain"])
