@@ -49,6 +49,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         if force or _stale(o, [s] + hdrs):
             cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result"]
             cmd += EXTRA_FLAGS.get(src, [])
+            cmd += os.environ.get("DDX_EXTRA_HIPCC_FLAGS", "").split()     # experiments (e.g. -DDDX_LDS_PANEL_ROWS=592)
             cmd += ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)

@@ -21,7 +21,10 @@ constexpr int kWave = 64;  // gfx950 wavefront
 // LDS-staged operator products (default): a slice of the float32 operand lives in LDS while the stored entries
 // stream by.  kLdsPanelRows = rows of the row-major sketch per slice of the A^T Y pass = rows per panel of the
 // column-major mirror (784 x 40 floats = 123 KB of the 160 KB LDS, the rest stages stored entries).  DDX_SPMM=gather selects the L2-gather kernels.
-constexpr int kLdsPanelRows = 784;
+#ifndef DDX_LDS_PANEL_ROWS
+#define DDX_LDS_PANEL_ROWS 784
+#endif
+constexpr int kLdsPanelRows = DDX_LDS_PANEL_ROWS;
 constexpr int kGatherPanelRows = 4096;   // measured optimum for the gather kernels (8192: +19 %, 2048: +5 %)
 inline bool spmm_lds() {
     const char* g = getenv("DDX_SPMM");

@@ -855,7 +855,8 @@ static int lds_setup(ddx_ctx* ctx, int L, PcaWork& w) {
     const int slots = lds_slots(ld);
     if (!slots) return DDX_OK;
     const bool cols_fit = (size_t)ctx->panel_rows * ld * 4 + lds_stage_bytes(slots) <= (size_t)kLdsBudget;
-    const int srmax = ((kLdsBudget - lds_stage_bytes(slots)) / (ld * 4 + 4)) & ~3;
+    int srmax = ((kLdsBudget - lds_stage_bytes(slots)) / (ld * 4 + 4)) & ~3;
+    if (srmax > kLdsPanelRows) srmax = kLdsPanelRows & ~3;      // same slice height in both passes
     if (!cols_fit || srmax < 64) return DDX_OK;
     w.lds = true;
     w.rows_ns = (int)ceil_div(H, srmax);

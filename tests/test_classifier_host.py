@@ -148,3 +148,38 @@ def test_second_fit_continues_the_rng_stream(monkeypatch):
     assert not np.array_equal(first, second)
     np.testing.assert_array_equal(first[0], g["parents"][0])
     np.testing.assert_array_equal(second[0], g["parents"][1])
+
+
+def test_reference_plot_functions_accept_the_classifier(monkeypatch):
+    """doubletdetection.plot.convergence / threshold only read ``n_iters`` and
+    ``all_log_p_values_`` (plot.py:65-66,123); run the reference's own plotting code on a fitted drop-in and
+    compare the curves it draws with the same numbers computed from predict().  Needs the reference tree
+    (this container) and matplotlib; skipped elsewhere."""
+    import importlib.util
+    import os
+
+    plot_py = "/root/reference/doubletdetection/plot.py"
+    if not os.path.exists(plot_py):
+        pytest.skip("reference tree not mounted")
+    mpl = pytest.importorskip("matplotlib")
+    mpl.use("Agg")
+    spec = importlib.util.spec_from_file_location("_ref_plot", plot_py)
+    plot = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(plot)
+
+    g = load_golden("case_a_hvg_pheno")
+    from conftest import golden_kwargs
+    kw = golden_kwargs(g)
+    monkeypatch.setattr(BoostClassifier, "_engine_factory", staticmethod(make_engine_factory(kw.get("random_state", 0))))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        clf = BoostClassifier(**kw).fit(csr_from(g, "counts"))
+        fig = plot.convergence(clf, show=False, p_thresh=1e-3, voter_thresh=0.5)
+        drawn = fig.axes[0].lines[0].get_ydata()
+        assert len(drawn) == clf.n_iters
+        # the last point of the convergence curve is the number of doublets predict() calls with the same thresholds
+        assert drawn[-1] == np.nansum(clf.predict(p_thresh=1e-3, voter_thresh=0.5))
+        fig2 = plot.threshold(clf, show=False, p_step=20)
+        assert fig2.axes, "threshold() drew nothing"
+    import matplotlib.pyplot as plt
+    plt.close("all")
