@@ -413,6 +413,24 @@ def test_reference_test_suite_scenario():
 
 
 # ---- API corners on the GPU path ---------------------------------------------------------------------------
+@pytest.mark.parametrize("n_components,algo", [(45, "louvain"), (12, "leiden"), (54, "phenograph")])
+def test_other_sketch_widths_and_leiden(n_components, algo):
+    """Sketch widths other than the default 40: > 42 columns leave the LDS-staged products (gather kernels on the
+    784-row panels), <= 32 take the 4-group geometry; and the leiden name end to end (umap connectivities)."""
+    from doubletdetection_amd import BoostClassifier
+    from doubletdetection_amd._synthetic import make_counts
+
+    counts = make_counts(900, 700, density=0.15, n_types=5, seed=21)
+    kw = dict(n_iters=2, n_top_var_genes=600, n_components=n_components, clustering_algorithm=algo, random_state=2)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        clf = BoostClassifier(**kw).fit(counts)
+        ref = orc.OracleClassifier(pca="f64", **kw).fit(counts)
+    np.testing.assert_array_equal(clf.communities_, ref.communities_)
+    np.testing.assert_array_equal(clf.all_scores_, ref.all_scores_)
+    np.testing.assert_allclose(clf.all_log_p_values_, ref.all_log_p_values_, rtol=1e-9, atol=1e-9)
+
+
 def test_api_corners_on_gpu(capsys):
     from doubletdetection_amd import BoostClassifier
 
