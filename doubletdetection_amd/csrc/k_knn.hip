@@ -146,7 +146,11 @@ struct QueryTiles {
 };
 
 constexpr int kBoundRT = 2;   // query tiles per wave in the bound pass (register budget: 16 rows x kBoundKeep)
-constexpr int kEmitRT = 2;    // query tiles per wave in the emit pass (more waves beats more reuse: tiles come from LDS)
+#ifndef DDX_EMIT_RT
+#define DDX_EMIT_RT 2
+#endif
+constexpr int kEmitRT = DDX_EMIT_RT;    // query tiles per wave in the emit pass
+#define DDX_EMIT_WAVES (DDX_EMIT_RT <= 2 ? 4 : 3)
 
 template <int CP>
 __global__ void __launch_bounds__(256) k_knn_bound(const float* __restrict__ Et, const float* __restrict__ nrm,
@@ -501,7 +505,7 @@ TileStageBf<CP> st;
 }
 
 template <int CP>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) k_knn_emit_bf(const __bf16* __restrict__ Eb, const float* __restrict__ nrm, const f4* __restrict__ start4,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DDX_EMIT_WAVES, DDX_EMIT_WAVES))) k_knn_emit_bf(const __bf16* __restrict__ Eb, const float* __restrict__ nrm, const f4* __restrict__ start4,
                                                      const float* __restrict__ thr, int64_t Mp, int include_self,
                                                      int32_t* __restrict__ ccount, int32_t* __restrict__ cbuf, const int32_t* __restrict__ win, int dbg) {
     constexpr int RT = kEmitRT, NV = 4 * RT;
