@@ -22,7 +22,7 @@ namespace ddx {
 #pragma clang fp contract(off)
 
 constexpr double kWeightScale = 1048576.0;   // 2^20, as in louvain.cpp / louvain_ref.py
-constexpr int kLvCap = 1024;                 // neighbours of one node handled by the LDS path
+constexpr int kLvCap = 4096;                 // neighbours of one node handled by the LDS path (one wave per workgroup there)
 
 __global__ void k_lv_quantise(const double* __restrict__ w, int64_t E, int64_t* __restrict__ wq) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -78,10 +78,10 @@ __global__ void __launch_bounds__(256) k_lv_sweep(const int64_t* __restrict__ in
                                                   const int32_t* __restrict__ comm, const unsigned long long* __restrict__ tot,
                                                   const int32_t* __restrict__ size, int64_t n, double gamma, double m2d,
                                                   const int32_t* __restrict__ big_list, int32_t* __restrict__ next) {
-    __shared__ int32_t cS[BIG ? 4 : 1][BIG ? kLvCap : 1];
-    __shared__ int64_t wS[BIG ? 4 : 1][BIG ? kLvCap : 1];
+    __shared__ int32_t cS[1][BIG ? kLvCap : 1];
+    __shared__ int64_t wS[1][BIG ? kLvCap : 1];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    int64_t v = (int64_t)blockIdx.x * 4 + wave;
+    int64_t v = BIG ? (int64_t)blockIdx.x : (int64_t)blockIdx.x * 4 + wave;        // BIG: 64-thread workgroups
     if (v >= n) return;
     if (BIG) v = big_list[v];
     const int64_t b = indptr[v];
@@ -117,7 +117,7 @@ __global__ void __launch_bounds__(256) k_lv_sweep(const int64_t* __restrict__ in
             best_c = c;
         }
     } else {
-        const int wv = BIG ? wave : 0;
+        const int wv = 0;
         const int d = deg < kLvCap ? deg : kLvCap;       // deg > kLvCap is rejected on the host before the launch
         for (int i = lane; i < d; i += 64) {
             const int32_t u = cols[b + i];
@@ -238,7 +238,7 @@ static int coarsen_level(ddx_ctx* ctx, const LvGraph& in, double gamma, int32_t 
         k_lv_totals<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(cur, sc.K, n, sc.tot, sc.size);
         k_lv_sweep<false><<<(unsigned)ceil_div(n, 4), 256, 0, st>>>(in.indptr, in.cols, sc.wq, sc.K, cur, sc.tot, sc.size, n, gamma, (double)m2, sc.big_list, nxt);
         if (nbig > 0)
-            k_lv_sweep<true><<<(unsigned)ceil_div(nbig, 4), 256, 0, st>>>(in.indptr, in.cols, sc.wq, sc.K, cur, sc.tot, sc.size, nbig, gamma, (double)m2, sc.big_list, nxt);
+            k_lv_sweep<true><<<(unsigned)nbig, 64, 0, st>>>(in.indptr, in.cols, sc.wq, sc.K, cur, sc.tot, sc.size, nbig, gamma, (double)m2, sc.big_list, nxt);
         std::swap(cur, nxt);      // a sweep that moves nothing reproduces its input, so running all of them equals stopping early
     }
     // renumber the surviving communities by ascending id

@@ -362,6 +362,38 @@ def test_device_presweeps_high_degree_nodes(ctx):
     np.testing.assert_array_equal(w_dev, w_host)
 
 
+def test_device_presweeps_refuse_hubs_beyond_capacity_and_fit_falls_back(ctx):
+    """A node with more neighbours than the sweep kernel's LDS table (4096) makes ddx_coarsen_graph return
+    DDX_E_UNSUPPORTED; BoostClassifier then fetches the graph and runs the whole specification on the host."""
+    from doubletdetection_amd import BoostClassifier, _lib
+
+    rng = np.random.default_rng(12)
+    n = 8000
+    emb = rng.normal(size=(n, 32))
+    emb = (10.0 * emb / np.linalg.norm(emb, axis=1, keepdims=True)).astype(np.float32)   # a sphere: neighbours far apart
+    emb[:35] = (0.01 * rng.normal(size=(35, 32))).astype(np.float32)                     # ... except the core at its centre
+    ctx.set_embedding(emb)
+    ctx.knn(30, False)
+    ip, ix, w = ctx.build_graph(1)
+    assert np.diff(ip).max() > 4096
+    with pytest.raises(_lib.DdxError) as err:
+        ctx.coarsen_graph(1.0)
+    assert err.value.code == _lib.E_UNSUPPORTED
+    # the classifier's fallback: same labels as the host specification on the fetched graph
+    from doubletdetection_amd.classifier import _HipEngine
+    eng = _HipEngine.__new__(_HipEngine)
+    eng.ctx = ctx
+    graph = None
+    ctx.build_graph(1, fetch=False)
+    try:
+        graph = ctx.coarsen_graph(1.0)
+    except _lib.DdxError:
+        graph = ctx.fetch_graph()
+    full, _, _, _ = BoostClassifier._cluster_and_score(graph, 1.0, 0, 10, n - 100)
+    lab = _lib.louvain(ip, ix, w, 1.0, 0)[0]
+    np.testing.assert_array_equal(full, _lib.relabel_by_size(lab, 10))
+
+
 # ---- whole fit -------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("case", ["case_a_hvg_pheno", "case_b_transposed_louvain", "case_c_reftest_scaled",
                                   "case_d_replace_single"])
