@@ -611,7 +611,16 @@ __global__ void __launch_bounds__(64) k_chol_inv(const double* __restrict__ G, i
         __syncthreads();
         if (lane > k && lane < L) {
             const double r = a[k * L + lane];
-            for (int i = k + 1; i <= lane; ++i) a[i * L + lane] -= a[k * L + i] * r;
+            int i = k + 1;
+            for (; i + 3 <= lane; i += 4) {          // four independent updates in flight (LDS latency, not work, bounds this)
+                const double r0 = a[k * L + i], r1 = a[k * L + i + 1], r2 = a[k * L + i + 2], r3 = a[k * L + i + 3];
+                const double v0 = a[i * L + lane], v1 = a[(i + 1) * L + lane], v2 = a[(i + 2) * L + lane], v3 = a[(i + 3) * L + lane];
+                a[i * L + lane] = v0 - r0 * r;
+                a[(i + 1) * L + lane] = v1 - r1 * r;
+                a[(i + 2) * L + lane] = v2 - r2 * r;
+                a[(i + 3) * L + lane] = v3 - r3 * r;
+            }
+            for (; i <= lane; ++i) a[i * L + lane] -= a[k * L + i] * r;
         }
         __syncthreads();
     }
@@ -619,8 +628,16 @@ __global__ void __launch_bounds__(64) k_chol_inv(const double* __restrict__ G, i
     for (int jx = lane; jx < L; jx += 64) {
         inv[jx * L + jx] = 1.0 / a[jx * L + jx];
         for (int i = jx - 1; i >= 0; --i) {
-            double s = 0.0;
-            for (int p = i + 1; p <= jx; ++p) s += a[i * L + p] * inv[p * L + jx];
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            int p = i + 1;
+            for (; p + 3 <= jx; p += 4) {
+                s0 += a[i * L + p] * inv[p * L + jx];
+                s1 += a[i * L + p + 1] * inv[(p + 1) * L + jx];
+                s2 += a[i * L + p + 2] * inv[(p + 2) * L + jx];
+                s3 += a[i * L + p + 3] * inv[(p + 3) * L + jx];
+            }
+            for (; p <= jx; ++p) s0 += a[i * L + p] * inv[p * L + jx];
+            const double s = (s0 + s1) + (s2 + s3);
             inv[i * L + jx] = -s / a[i * L + i];
         }
     }
