@@ -545,18 +545,26 @@ __global__ void __launch_bounds__(256) k_reduce_partials(const double* __restric
     if (lane == 0) out[c] = s;
 }
 
-// partial Gram: G_b = X_b^T X_b for a block of rows, staged through LDS in 32-row tiles
+// partial Gram: G_b = X_b^T X_b for a block of rows, staged through LDS in 32-row tiles.  Only the pairs a <= b
+// are accumulated (each thread owns a few of the L(L+1)/2), both triangles are written.
 __global__ void __launch_bounds__(256) k_gram_partial(const double* __restrict__ X, int64_t R, int L,
                                                       int64_t rows_per_block, double* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) double tile[];  // [32][L]
     const int tid = threadIdx.x;
-    const int npairs = L * L;
+    const int npairs = L * (L + 1) / 2;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     const int64_t r1 = (r0 + rows_per_block < R) ? r0 + rows_per_block : R;
-    constexpr int MAXP = (kMaxL * kMaxL + 255) / 256;  // pairs per thread upper bound
+    constexpr int MAXP = (kMaxL * (kMaxL + 1) / 2 + 255) / 256;  // pairs per thread upper bound
     double acc[MAXP];
+    int pa[MAXP], pb[MAXP];
 #pragma unroll
-    for (int q = 0; q < MAXP; ++q) acc[q] = 0.0;
+    for (int q = 0; q < MAXP; ++q) {
+        acc[q] = 0.0;
+        int rest = tid + q * 256, a = 0;          // pair number -> (a, b) with a <= b, rows of the upper triangle in order
+        while (a < L && rest >= L - a) { rest -= L - a; ++a; }
+        pa[q] = a;
+        pb[q] = a + rest;
+    }
     for (int64_t rb = r0; rb < r1; rb += 32) {
         const int nr = (int)((r1 - rb) < 32 ? (r1 - rb) : 32);
         __syncthreads();
@@ -564,9 +572,8 @@ __global__ void __launch_bounds__(256) k_gram_partial(const double* __restrict__
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < MAXP; ++q) {
-            const int pidx = tid + q * 256;
-            if (pidx < npairs) {
-                const int a = pidx / L, bcol = pidx - a * L;
+            if (tid + q * 256 < npairs) {
+                const int a = pa[q], bcol = pb[q];
                 double s = acc[q];
                 for (int r = 0; r < nr; ++r) s = fma(tile[r * L + a], tile[r * L + bcol], s);
                 acc[q] = s;
@@ -575,8 +582,11 @@ __global__ void __launch_bounds__(256) k_gram_partial(const double* __restrict__
     }
 #pragma unroll
     for (int q = 0; q < MAXP; ++q) {
-        const int pidx = tid + q * 256;
-        if (pidx < npairs) partial[(int64_t)blockIdx.x * npairs + pidx] = acc[q];
+        if (tid + q * 256 < npairs) {
+            double* out = partial + (int64_t)blockIdx.x * L * L;
+            out[pa[q] * L + pb[q]] = acc[q];
+            out[pb[q] * L + pa[q]] = acc[q];
+        }
     }
 }
 
