@@ -267,11 +267,11 @@ template <int SLOTS> struct LdsFetch {
 // consumes them before the staging step of the *next* round -- that is what keeps them in flight.
 template <int SLOTS>
 __device__ __forceinline__ LdsFetch<SLOTS> lds_fetch(const int32_t* __restrict__ idx, const float* __restrict__ x,
-                                                     const int64_t (&l)[SLOTS], const int64_t (&h)[SLOTS], int r, int lane) {
+                                                     const int32_t (&l)[SLOTS], const int32_t (&h)[SLOTS], int r, int lane) {
     LdsFetch<SLOTS> f;
 #pragma unroll
     for (int g = 0; g < SLOTS; ++g) {
-        int64_t p = l[g] + (int64_t)r * kLdsChunk + lane;
+        int32_t p = l[g] + r * kLdsChunk + lane;         // positions fit 31 bits (stage_create_doublets enforces it)
         p = p < h[g] ? p : l[g];
         f.i[g] = idx[p];
         f.x[g] = x[p];
@@ -382,42 +382,42 @@ __global__ void __launch_bounds__(1024) k_spmm_lds(const LdsSpmmArgs a) {
         for (int st = 0; st < (ROWS ? 1 : 2); ++st) {
             const int32_t* sidx = a.cols;
             const float* sx = a.x;
-            int64_t lo = 0, hi = 0;
+            int32_t lo = 0, hi = 0;
             if (ROWS) {
                 if (mine) {
                     const int32_t* rs = a.rowseg + myout * (a.nslices + 1) + s;
-                    lo = rowbase + rs[0];
-                    hi = rowbase + rs[1];
+                    lo = (int32_t)(rowbase + rs[0]);
+                    hi = (int32_t)(rowbase + rs[1]);
                 }
             } else if (st == 0) {
                 if (s >= a.P_o) continue;
                 sidx = a.row_o; sx = a.x_o;
-                if (mine) { lo = a.cp_o[(int64_t)s * a.nOut + myout]; hi = a.cp_o[(int64_t)s * a.nOut + myout + 1]; }
+                if (mine) { lo = (int32_t)a.cp_o[(int64_t)s * a.nOut + myout]; hi = (int32_t)a.cp_o[(int64_t)s * a.nOut + myout + 1]; }
             } else {
                 const int ps = s - a.p_s0;
                 if (ps < 0 || ps >= a.P_s) continue;
                 sidx = a.row_s; sx = a.x_s;
-                if (mine) { lo = a.cp_s[(int64_t)ps * a.nOut + myout]; hi = a.cp_s[(int64_t)ps * a.nOut + myout + 1]; }
+                if (mine) { lo = (int32_t)a.cp_s[(int64_t)ps * a.nOut + myout]; hi = (int32_t)a.cp_s[(int64_t)ps * a.nOut + myout + 1]; }
             }
 
             // unit k covers the SLOTS segments of local outputs k*SLOTS + g
-            auto unit_bounds = [&](int k, int64_t (&l)[SLOTS], int64_t (&h)[SLOTS], int& maxlen) {
+            auto unit_bounds = [&](int k, int32_t (&l)[SLOTS], int32_t (&h)[SLOTS], int& maxlen) {
                 maxlen = 0;
 #pragma unroll
                 for (int g = 0; g < SLOTS; ++g) {
-                    l[g] = read_lane64(lo, k * SLOTS + g);
-                    h[g] = read_lane64(hi, k * SLOTS + g);
-                    const int len = (int)(h[g] - l[g]);
+                    l[g] = __builtin_amdgcn_readlane(lo, k * SLOTS + g);
+                    h[g] = __builtin_amdgcn_readlane(hi, k * SLOTS + g);
+                    const int len = h[g] - l[g];
                     maxlen = len > maxlen ? len : maxlen;
                 }
             };
-            int64_t l[SLOTS], h[SLOTS];
+            int32_t l[SLOTS], h[SLOTS];
             int maxlen;
             unit_bounds(0, l, h, maxlen);
             LdsFetch<SLOTS> cur = lds_fetch<SLOTS>(sidx, sx, l, h, 0, lane);
 #pragma unroll
             for (int k = 0; k < kLdsOwnG; ++k) {
-                int64_t l2[SLOTS], h2[SLOTS];
+                int32_t l2[SLOTS], h2[SLOTS];
                 int maxlen2 = 0;
                 if (k + 1 < kLdsOwnG) unit_bounds(k + 1, l2, h2, maxlen2);
                 double zc[SLOTS];
@@ -434,7 +434,7 @@ __global__ void __launch_bounds__(1024) k_spmm_lds(const LdsSpmmArgs a) {
                         const int nsteps = left < kLdsChunk ? left : kLdsChunk;
                         int nvalid[SLOTS];
 #pragma unroll
-                        for (int g = 0; g < SLOTS; ++g) nvalid[g] = (int)(h[g] - l[g]) - r * kLdsChunk;
+                        for (int g = 0; g < SLOTS; ++g) nvalid[g] = (h[g] - l[g]) - r * kLdsChunk;
                         lds_round<ROWS, SLOTS>(cur, nvalid, nsteps, (int32_t)r0, zc, opB, zS, a.ld, dS, offS, lane, myd, myoff, acc[k]);
                     }
                     cur = nxt;
