@@ -1,13 +1,12 @@
 // Exact brute-force kNN over the low-dimensional embedding and the graphs handed to community
 // detection (phenograph.cluster / sc.pp.neighbors call sites, dd.py:317-336).
 //
-// kNN: one thread owns one query (its coordinates live in VGPRs as float64); every thread of the
-// wave walks the same candidate, whose coordinates are wave-uniform and therefore come through the
-// scalar cache (no LDS staging, no per-lane loads).  Squared distances are accumulated exactly as
-// the float64 reference does (subtract, multiply, add -- no fused multiply-add) so that the ordering
-// by (distance, index) is bit-identical to an IEEE float64 brute force.  The running top-k of each
-// thread lives in LDS, slot-major ([slot][thread]) so lanes hit distinct banks; insertions are rare
-// after the first few hundred candidates (expected k*ln(M/k) per query).
+// kNN: exact, defined in float64 (subtract, multiply, add component by component, no fused multiply-add; ties by
+// index), computed in three passes over the points sorted by their first principal component -- an MFMA screen
+// that bounds every query's k-th distance from the tiles around it, an MFMA screen of the pruned tile range that
+// lists every pair that could be among the k nearest, and an exact float64 evaluation + sort of those few
+// candidates (stage_knn below).  The screens only have to be conservative; the result is
+// bit-identical to an IEEE float64 brute force.
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
@@ -71,20 +70,20 @@ constexpr int kBoundKeep = 6;      // smallest sample distances kept per lane an
 constexpr int kCandCap = 768;      // candidate slots per query between the emit and select passes
 
 // ================================================================================================
-// exact kNN in three passes (all 16x16 query x candidate tiles run on v_mfma_f32_16x16x4_f32):
-//   1. bound : over a strided sample of candidate tiles, every lane keeps the kBoundKeep smallest
+// exact kNN in three passes (16x16 query x candidate tiles on v_mfma_f32_16x16x32_bf16 with a bfloat16 hi/lo split,
+// or on v_mfma_f32_16x16x4_f32 with DDX_KNN_SCREEN=f32); points are in first-principal-component order:
+//   1. bound : over the tiles nearest to the query in that order, every lane keeps the kBoundKeep smallest
 //              *upper bounds* of the squared distance per screened row; the k-th smallest of the
 //              16*kBoundKeep kept values of a row is an upper bound T_q of the query's true k-th
 //              neighbour distance (k-th smallest of a subset >= k-th smallest of the whole set).
-//   2. emit  : over all candidate tiles, a pair survives when a *lower bound* of its squared distance
-//              is below T_q (so no true neighbour can be lost); survivors (a few hundred per query,
-//              0.2-0.4 % of the pairs) are appended to the query's candidate list.  Pure streaming:
-//              16 MFMA + 16 VALU per tile, no LDS, no data-dependent state.
+//   2. emit  : over the contiguous tile range with |c_1 - q_1| <= sqrt(T_q) (k_knn_window), a pair survives when a
+//              *lower bound* of its squared distance is below T_q (so no true neighbour can be lost); survivors
+//              (about a hundred per query) are appended to the query's candidate list.
 //   3. select: one wave per query evaluates its candidates exactly (float64, the reference's
 //              arithmetic, one candidate per lane) and sorts them by (distance, index) in LDS; the
 //              first k are the result.  A query whose list overflowed is re-scanned over all points
 //              by the same pass, so the result is exact in every case and independent of the
-//              (non-deterministic) order in which survivors were appended.
+//              order in which survivors were appended.
 // ================================================================================================
 
 // ---- candidate tiles are staged through LDS once per block (4 waves share them) ---------------------

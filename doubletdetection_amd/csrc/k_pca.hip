@@ -2,14 +2,17 @@
 // sc.tl.pca(svd_solver="auto") runs for the reference, dd.py:305-314), evaluated in float64 on the
 // *implicit* matrix:  X = 1 z^T + L  with L stored sparse (CSR + column-major mirror), so that the
 // centred operator is  A = L - 1 m^T  (m = column means of L).  The dense M x H matrix of dd.py:295
-// is never formed: every product A Q / A^T Y is one pass over the stored entries (8 bytes each) with
-// gathers of L-wide float64 rows of the small operand from L2 / Infinity Cache.
+// is never formed: every product A Q / A^T Y is one pass over the stored entries (8 bytes each); the L-wide rows
+// of the small operand are fetched from a float32 copy of it staged slice by slice in LDS (k_spmm_lds, the
+// default), or gathered from L2 by the first-generation kernels (k_spmm_rows / k_spmm_cols: float64 mode,
+// ddx_operator_apply, sketch widths > 42, DDX_SPMM=gather).  Products and sums are float64 throughout.
 //
 // Steps (sklearn/utils/extmath.py:287-372,531-607; sklearn/decomposition/_pca.py:731-766):
 //   Q0 (host-drawn, seeded) -> n_iter x { Q <- orth(A Q) ; Q <- orth(A^T Q) } -> Q <- qr(A Q)
 //   B = Q^T A ; SVD(B) via eigh(B B^T) ; U = Q Uhat ; sign fix on the component rows ; return U S.
-// orth() is a Cholesky-QR instead of sklearn's LU: only the spanned subspace enters the next step, so
-// the float64 result is the same to ~1e-12 (oracle/dd_oracle.py:randomized_pca_f64 checks this).
+// orth() is a Cholesky-QR instead of sklearn's LU, applied once per power iteration (A^T A Q) instead of after each
+// half step: only the spanned subspace enters the next step, so the float64 result is the same to ~1e-12
+// (oracle/dd_oracle.py:randomized_pca_f64 checks this); the final basis gets two passes (CholQR2).
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
