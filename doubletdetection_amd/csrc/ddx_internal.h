@@ -16,11 +16,11 @@
 namespace ddx {
 
 constexpr int kWave = 64;  // gfx950 wavefront
-// rows per panel of the column-major mirror: the sketch rows of one panel (rows x 40 x 4 or 8 B) should fit
-// one XCD's 4 MB L2 -> 16384 rows when the operand copy is float32, 8192 when float64 iterates are gathered
+// Rows per panel of the column-major mirror.
 // LDS-staged operator products (default): a slice of the float32 operand lives in LDS while the stored entries
 // stream by.  kLdsPanelRows = rows of the row-major sketch per slice of the A^T Y pass = rows per panel of the
-// column-major mirror (784 x 40 floats = 123 KB of the 160 KB LDS, the rest stages stored entries).  DDX_SPMM=gather selects the L2-gather kernels.
+// column-major mirror (784 x 40 floats = 123 KB of the 160 KB LDS, the rest stages stored entries).
+// DDX_SPMM=gather selects the L2-gather kernels, whose panels (kGatherPanelRows) are sized for one XCD's 4 MB L2.
 #ifndef DDX_LDS_PANEL_ROWS
 #define DDX_LDS_PANEL_ROWS 784
 #endif
@@ -101,7 +101,7 @@ struct ddx_ctx {
     // the mirror is ordered by (row panel, column): entries of column j inside panel p form the segment
     // colptr[p*H + j] .. colptr[p*H + j + 1].  A panel is kPanelRows consecutive rows of the augmented
     // matrix, so the rows gathered while a panel is processed stay L2-resident.
-    int32_t panel_rows = 8192;       // fixed when the counts are uploaded
+    int32_t panel_rows = 784;        // fixed when the counts are uploaded (kLdsPanelRows or kGatherPanelRows)
     ddx::DevBuf rowseg;              // int32 [M x (slices+1)]: offset in row i of the first entry whose column is >= slice*SR
     ddx::DevBuf rank_buf;            // sort scratch + results of stage_rankings
     const int32_t* rank_rows = nullptr;   // rows by stored entries, descending (views into rank_buf)
