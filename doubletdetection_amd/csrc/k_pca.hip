@@ -1100,54 +1100,153 @@ int stage_pca(ddx_ctx* ctx, int32_t C, int32_t oversample, int32_t n_iter, const
     return DDX_OK;
 }
 
-// cyclic Jacobi eigen-decomposition of a small symmetric matrix (host, float64)
-void jacobi_eigh(int n, double* a, double* evals, double* evecs) {
-    for (int i = 0; i < n; ++i)
-        for (int j = 0; j < n; ++j) evecs[i * n + j] = (i == j) ? 1.0 : 0.0;
-    for (int sweep = 0; sweep < 64; ++sweep) {
-        double off = 0.0, diag = 0.0;
-        for (int i = 0; i < n; ++i) {
-            diag += a[i * n + i] * a[i * n + i];
-            for (int j = i + 1; j < n; ++j) off += a[i * n + j] * a[i * n + j];
-        }
-        if (off <= 1e-30 * diag || off == 0.0) break;
-        for (int p = 0; p < n - 1; ++p) {
-            for (int q = p + 1; q < n; ++q) {
-                const double apq = a[p * n + q];
-                if (apq == 0.0) continue;
-                const double app = a[p * n + p], aqq = a[q * n + q];
-                const double theta = (aqq - app) / (2.0 * apq);
-                const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
-                const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
-                for (int k = 0; k < n; ++k) {
-                    const double akp = a[k * n + p], akq = a[k * n + q];
-                    a[k * n + p] = c * akp - s * akq;
-                    a[k * n + q] = s * akp + c * akq;
+// Symmetric eigen-decomposition: Householder reduction to tridiagonal form followed by the implicit QL iteration
+// (the classical tred2 / tql2 pair of Bowdler, Martin, Reinsch and Wilkinson).  v: n x n row-major, on entry the
+// symmetric matrix, on exit the eigenvectors in its columns; d: eigenvalues, ascending.
+static void sym_eigh_ql(int n, double* v, double* d) {
+    std::vector<double> e(n, 0.0);
+    for (int j = 0; j < n; ++j) d[j] = v[(n - 1) * n + j];
+    // Householder reduction
+    for (int i = n - 1; i > 0; --i) {
+        double scale = 0.0, h = 0.0;
+        for (int k = 0; k < i; ++k) scale += std::fabs(d[k]);
+        if (scale == 0.0) {
+            e[i] = d[i - 1];
+            for (int j = 0; j < i; ++j) {
+                d[j] = v[(i - 1) * n + j];
+                v[i * n + j] = 0.0;
+                v[j * n + i] = 0.0;
+            }
+        } else {
+            for (int k = 0; k < i; ++k) { d[k] /= scale; h += d[k] * d[k]; }
+            double f = d[i - 1];
+            double g = std::sqrt(h);
+            if (f > 0) g = -g;
+            e[i] = scale * g;
+            h -= f * g;
+            d[i - 1] = f - g;
+            for (int j = 0; j < i; ++j) e[j] = 0.0;
+            for (int j = 0; j < i; ++j) {
+                f = d[j];
+                v[j * n + i] = f;
+                g = e[j] + v[j * n + j] * f;
+                for (int k = j + 1; k <= i - 1; ++k) {
+                    g += v[k * n + j] * d[k];
+                    e[k] += v[k * n + j] * f;
                 }
-                for (int k = 0; k < n; ++k) {
-                    const double apk = a[p * n + k], aqk = a[q * n + k];
-                    a[p * n + k] = c * apk - s * aqk;
-                    a[q * n + k] = s * apk + c * aqk;
-                }
-                for (int k = 0; k < n; ++k) {
-                    const double vkp = evecs[k * n + p], vkq = evecs[k * n + q];
-                    evecs[k * n + p] = c * vkp - s * vkq;
-                    evecs[k * n + q] = s * vkp + c * vkq;
-                }
+                e[j] = g;
+            }
+            f = 0.0;
+            for (int j = 0; j < i; ++j) { e[j] /= h; f += e[j] * d[j]; }
+            const double hh = f / (h + h);
+            for (int j = 0; j < i; ++j) e[j] -= hh * d[j];
+            for (int j = 0; j < i; ++j) {
+                f = d[j];
+                g = e[j];
+                for (int k = j; k <= i - 1; ++k) v[k * n + j] -= (f * e[k] + g * d[k]);
+                d[j] = v[(i - 1) * n + j];
+                v[i * n + j] = 0.0;
             }
         }
+        d[i] = h;
     }
-    // sort ascending
-    std::vector<int> order(n);
-    for (int i = 0; i < n; ++i) order[i] = i;
-    std::sort(order.begin(), order.end(), [&](int x, int y) { return a[x * n + x] < a[y * n + y]; });
-    std::vector<double> ev(n), vec((size_t)n * n);
-    for (int c = 0; c < n; ++c) {
-        ev[c] = a[order[c] * n + order[c]];
-        for (int k = 0; k < n; ++k) vec[(size_t)k * n + c] = evecs[(size_t)k * n + order[c]];
+    // accumulate the transformations
+    for (int i = 0; i < n - 1; ++i) {
+        v[(n - 1) * n + i] = v[i * n + i];
+        v[i * n + i] = 1.0;
+        const double h = d[i + 1];
+        if (h != 0.0) {
+            for (int k = 0; k <= i; ++k) d[k] = v[k * n + i + 1] / h;
+            for (int j = 0; j <= i; ++j) {
+                double g = 0.0;
+                for (int k = 0; k <= i; ++k) g += v[k * n + i + 1] * v[k * n + j];
+                for (int k = 0; k <= i; ++k) v[k * n + j] -= g * d[k];
+            }
+        }
+        for (int k = 0; k <= i; ++k) v[k * n + i + 1] = 0.0;
     }
-    for (int c = 0; c < n; ++c) evals[c] = ev[c];
-    for (size_t t = 0; t < vec.size(); ++t) evecs[t] = vec[t];
+    for (int j = 0; j < n; ++j) {
+        d[j] = v[(n - 1) * n + j];
+        v[(n - 1) * n + j] = 0.0;
+    }
+    v[(n - 1) * n + n - 1] = 1.0;
+    e[0] = 0.0;
+    // implicit QL
+    for (int i = 1; i < n; ++i) e[i - 1] = e[i];
+    e[n - 1] = 0.0;
+    double f = 0.0, tst1 = 0.0;
+    const double eps = std::pow(2.0, -52.0);
+    for (int l = 0; l < n; ++l) {
+        tst1 = std::max(tst1, std::fabs(d[l]) + std::fabs(e[l]));
+        int m = l;
+        while (m < n) {
+            if (std::fabs(e[m]) <= eps * tst1) break;
+            ++m;
+        }
+        if (m > l) {
+            int iter = 0;
+            do {
+                ++iter;
+                double g = d[l];
+                double p = (d[l + 1] - g) / (2.0 * e[l]);
+                double r = std::hypot(p, 1.0);
+                if (p < 0) r = -r;
+                d[l] = e[l] / (p + r);
+                d[l + 1] = e[l] * (p + r);
+                const double dl1 = d[l + 1];
+                double h = g - d[l];
+                for (int i = l + 2; i < n; ++i) d[i] -= h;
+                f += h;
+                p = d[m];
+                double c = 1.0, c2 = c, c3 = c;
+                const double el1 = e[l + 1];
+                double s = 0.0, s2 = 0.0;
+                for (int i = m - 1; i >= l; --i) {
+                    c3 = c2;
+                    c2 = c;
+                    s2 = s;
+                    g = c * e[i];
+                    h = c * p;
+                    r = std::hypot(p, e[i]);
+                    e[i + 1] = s * r;
+                    s = e[i] / r;
+                    c = p / r;
+                    p = c * d[i] - s * g;
+                    d[i + 1] = h + s * (c * g + s * d[i]);
+                    for (int k = 0; k < n; ++k) {
+                        h = v[k * n + i + 1];
+                        v[k * n + i + 1] = s * v[k * n + i] + c * h;
+                        v[k * n + i] = c * v[k * n + i] - s * h;
+                    }
+                }
+                p = -s * s2 * c3 * el1 * e[l] / dl1;
+                e[l] = s * p;
+                d[l] = c * p;
+            } while (std::fabs(e[l]) > eps * tst1 && iter < 200);
+        }
+        d[l] += f;
+        e[l] = 0.0;
+    }
+    // ascending order
+    for (int i = 0; i < n - 1; ++i) {
+        int k = i;
+        double p = d[i];
+        for (int j = i + 1; j < n; ++j)
+            if (d[j] < p) { k = j; p = d[j]; }
+        if (k != i) {
+            d[k] = d[i];
+            d[i] = p;
+            for (int j = 0; j < n; ++j) std::swap(v[j * n + i], v[j * n + k]);
+        }
+    }
+}
+
+
+// eigen-decomposition of the small symmetric matrix B B^T on the host (float64): ascending eigenvalues, eigenvectors
+// in the columns of evecs.  (A cyclic Jacobi iteration did this first: 0.53 ms for 40 x 40 against 0.16 ms.)
+void jacobi_eigh(int n, double* a, double* evals, double* evecs) {
+    for (int t = 0; t < n * n; ++t) evecs[t] = a[t];
+    sym_eigh_ql(n, evecs, evals);
 }
 
 }  // namespace ddx
