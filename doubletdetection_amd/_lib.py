@@ -357,9 +357,13 @@ class Context:
         self._c(self._lib.ddx_scale(self._h, float(max_value if max_value is not None else 0.0)))
 
     # PCA
-    def pca(self, n_components: int, q0, n_oversamples: int = 10, n_iter: int = -1):
-        q0 = np.ascontiguousarray(q0, dtype=np.float64)
-        self._c(self._lib.ddx_pca(self._h, int(n_components), int(n_oversamples), int(n_iter), _p(q0, c_f64_p), q0.shape[0]))
+    def pca(self, n_components: int, q0, n_oversamples: int = 10, n_iter: int = -1, q0_rows: int = 0):
+        """q0 = None reuses the start matrix the previous call left on the device (pass q0_rows then)."""
+        if q0 is None:
+            self._c(self._lib.ddx_pca(self._h, int(n_components), int(n_oversamples), int(n_iter), None, int(q0_rows)))
+        else:
+            q0 = np.ascontiguousarray(q0, dtype=np.float64)
+            self._c(self._lib.ddx_pca(self._h, int(n_components), int(n_oversamples), int(n_iter), _p(q0, c_f64_p), q0.shape[0]))
         self._C = int(n_components)
         self._embM = self.M
 

@@ -122,7 +122,12 @@ class _HipEngine:
         elif q0 is None:
             self._pca_exact(n_components)
         else:
-            c.pca(n_components, q0)
+            # every iteration of a fit starts from the same seeded matrix: upload it once per array object
+            if getattr(self, "_q0_resident", None) is q0:
+                c.pca(n_components, None, q0_rows=q0.shape[0])
+            else:
+                c.pca(n_components, q0)
+                self._q0_resident = q0
         c.knn(knn_k, include_self)
         if gamma is None:
             return c.build_graph(graph_mode)  # symmetric CSR assembled on the device

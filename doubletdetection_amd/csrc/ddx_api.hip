@@ -153,9 +153,10 @@ int ddx_destroy(ddx_ctx* ctx) {
                       &ctx->csc_s_row, &ctx->csc_s_raw, &ctx->csc_s_x, &ctx->sort_keys_in, &ctx->sort_keys_out,
                       &ctx->sort_vals_in, &ctx->sort_vals_out, &ctx->sort_tmp, &ctx->sort_rowid, &ctx->median, &ctx->lib_sorted,
                       &ctx->zcol, &ctx->colmean, &ctx->colstat, &ctx->col_part, &ctx->pcaA, &ctx->pcaB, &ctx->pcaSmall,
-                      &ctx->pcaPartial, &ctx->pcaVec, &ctx->pcaPanel, &ctx->pcaOp, &ctx->rowseg, &ctx->rank_buf, &ctx->lv_buf, &ctx->emb32, &ctx->emb64, &ctx->sing, &ctx->knn_idx,
+                      &ctx->pcaPartial, &ctx->pcaVec, &ctx->pcaPanel, &ctx->pcaOp, &ctx->pcaQ0, &ctx->rowseg, &ctx->rank_buf, &ctx->lv_buf, &ctx->lv_pack, &ctx->emb32, &ctx->emb64, &ctx->sing, &ctx->knn_idx,
                       &ctx->knn_dist, &ctx->knn_sorted, &ctx->edge_w};
     for (DevBuf* b : bufs) release(ctx, *b);
+    if (ctx->lv_host) (void)hipHostFree(ctx->lv_host);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return DDX_OK;
@@ -383,8 +384,10 @@ int ddx_pca(ddx_ctx* ctx, int32_t n_components, int32_t n_oversamples, int32_t n
     USE_DEVICE(ctx);
     NEED(ctx->have_lognorm, "ddx_lognormalise must run first");
     NEED(n_components >= 1 && n_oversamples >= 0, "bad sketch size");
-    NEED(q0, "null start matrix");
     int64_t want = (ctx->M >= ctx->H) ? (int64_t)ctx->H : ctx->M;
+    if (!q0) {   // reuse the start matrix of the previous call (boosting iterations share their seeded start)
+        NEED(ctx->q0_rows == want && ctx->q0_cols == n_components + n_oversamples, "no start matrix of this shape is resident");
+    }
     if (q0_rows != want)
         return set_err(ctx, DDX_E_ARG, "q0 must have %lld rows (M=%lld, H=%d), got %lld", (long long)want,
                        (long long)ctx->M, ctx->H, (long long)q0_rows);
@@ -543,14 +546,19 @@ int ddx_get_coarse_size(ddx_ctx* ctx, int64_t* n_coarse, int64_t* n_entries) {
 int ddx_get_coarse_graph(ddx_ctx* ctx, int32_t* member, int64_t* indptr, int32_t* indices, double* weights) {
     REQUIRE_CTX(ctx);
     USE_DEVICE(ctx);
-    NEED(ctx->c_nodes >= 0 && ctx->g_nodes >= 0, "no coarse graph");
-    DDX_HIP(ctx, hipMemcpyAsync(member, ctx->c_d_member, sizeof(int32_t) * ctx->g_nodes, hipMemcpyDeviceToHost, ctx->stream));
-    DDX_HIP(ctx, hipMemcpyAsync(indptr, ctx->c_d_indptr, sizeof(int64_t) * (ctx->c_nodes + 1), hipMemcpyDeviceToHost, ctx->stream));
-    if (ctx->c_entries > 0) {
-        DDX_HIP(ctx, hipMemcpyAsync(indices, ctx->c_d_cols, sizeof(int32_t) * ctx->c_entries, hipMemcpyDeviceToHost, ctx->stream));
-        DDX_HIP(ctx, hipMemcpyAsync(weights, ctx->c_d_vals, sizeof(double) * ctx->c_entries, hipMemcpyDeviceToHost, ctx->stream));
+    NEED(ctx->c_nodes >= 0 && ctx->g_nodes >= 0 && ctx->lv_host_valid, "no coarse graph");
+    DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));        // the packed copy issued by ddx_coarsen_graph has landed
+    const int64_t E = ctx->c_entries, nc = ctx->c_nodes, n = ctx->g_nodes;
+    const double* hw = static_cast<const double*>(ctx->lv_host);
+    const int64_t* hi = reinterpret_cast<const int64_t*>(hw + E);
+    const int32_t* hm = reinterpret_cast<const int32_t*>(hi + nc + 1);
+    const int32_t* hc = hm + n;
+    std::memcpy(member, hm, sizeof(int32_t) * (size_t)n);
+    std::memcpy(indptr, hi, sizeof(int64_t) * (size_t)(nc + 1));
+    if (E > 0) {
+        std::memcpy(indices, hc, sizeof(int32_t) * (size_t)E);
+        std::memcpy(weights, hw, sizeof(double) * (size_t)E);
     }
-    DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return DDX_OK;
 }
 

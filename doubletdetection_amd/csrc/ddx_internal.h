@@ -122,7 +122,9 @@ struct ddx_ctx {
 
     // PCA work space
     int32_t C = 0;
-    ddx::DevBuf pcaA, pcaB, pcaSmall, pcaPartial, pcaVec, pcaPanel, pcaOp;
+    ddx::DevBuf pcaA, pcaB, pcaSmall, pcaPartial, pcaVec, pcaPanel, pcaOp, pcaQ0;
+    int64_t q0_rows = 0;             // shape of the start matrix kept in pcaQ0
+    int32_t q0_cols = 0;
     ddx::DevBuf emb32;               // float  [M*C]
     ddx::DevBuf emb64;               // double [M*C]
     ddx::DevBuf sing;                // double [C]
@@ -147,7 +149,10 @@ struct ddx_ctx {
     const double* g_d_vals = nullptr;
 
     // coarse graph left on the device by ddx_coarsen_graph (views into lv_buf)
-    ddx::DevBuf lv_buf;
+    ddx::DevBuf lv_buf, lv_pack;
+    void* lv_host = nullptr;         // pinned host copy of the packed coarse graph (w | indptr | member | cols)
+    size_t lv_host_cap = 0;
+    bool lv_host_valid = false;
     int64_t c_nodes = -1, c_entries = 0;
     const int32_t* c_d_member = nullptr;
     const int64_t* c_d_indptr = nullptr;

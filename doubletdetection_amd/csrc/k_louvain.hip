@@ -278,10 +278,24 @@ static int coarsen_level(ddx_ctx* ctx, const LvGraph& in, double gamma, int32_t 
     return DDX_OK;
 }
 
+// result of the last level packed for one device-to-host copy: w f64[E] | indptr i64[nc+1] | member i32[n] | cols i32[E]
+__global__ void k_lv_pack(const double* __restrict__ w, const int64_t* __restrict__ indptr, const int32_t* __restrict__ member,
+                          const int32_t* __restrict__ cols, int64_t E, int64_t nc, int64_t n, unsigned char* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double* ow = reinterpret_cast<double*>(out);
+    int64_t* oi = reinterpret_cast<int64_t*>(ow + E);
+    int32_t* om = reinterpret_cast<int32_t*>(oi + nc + 1);
+    int32_t* oc = om + n;
+    if (t < E) { ow[t] = w[t]; oc[t] = cols[t]; }
+    if (t <= nc) oi[t] = indptr[t];
+    if (t < n) om[t] = member[t];
+}
+
 int stage_coarsen_graph(ddx_ctx* ctx, double gamma, int32_t sweeps, int32_t levels) {
     const int64_t n = ctx->g_nodes;
     const int64_t E = ctx->g_entries;
     ctx->c_nodes = -1;
+    ctx->lv_host_valid = false;
     // scratch (wq, keys x2, vals, sums: E each; K, tot: n; comm, next, size, used, renum, big_list: n) + two output sets
     // (member i32[n], indptr i64[n+1], cols i32[E], w f64[E]) that the levels write alternately + the composed member table
     const size_t out_set = sizeof(int32_t) * (size_t)n + sizeof(int64_t) * (size_t)(n + 1) + (sizeof(int32_t) + sizeof(double)) * (size_t)E + 4 * 256;
@@ -341,6 +355,21 @@ int stage_coarsen_graph(ddx_ctx* ctx, double gamma, int32_t sweeps, int32_t leve
     ctx->c_d_indptr = cur.indptr;
     ctx->c_d_cols = cur.cols;
     ctx->c_d_vals = cur.w;
+    // one packed copy to pinned host memory instead of four small ones (each costs a round trip)
+    const size_t packed = 8 * (size_t)cur.E + 8 * (size_t)(cur.n + 1) + 4 * (size_t)n + 4 * (size_t)cur.E;
+    DDX_TRY(ensure(ctx, ctx->lv_pack, packed + 64));
+    if (packed > ctx->lv_host_cap) {
+        if (ctx->lv_host) (void)hipHostFree(ctx->lv_host);
+        ctx->lv_host = nullptr;
+        ctx->lv_host_cap = 0;
+        DDX_HIP(ctx, hipHostMalloc(&ctx->lv_host, packed * 2 + 4096, hipHostMallocDefault));
+        ctx->lv_host_cap = packed * 2 + 4096;
+    }
+    const int64_t span = std::max<int64_t>(std::max<int64_t>(cur.E, cur.n + 1), n);
+    k_lv_pack<<<(unsigned)ceil_div(span, 256), 256, 0, ctx->stream>>>(cur.w, cur.indptr, total, cur.cols, cur.E, cur.n, n, ctx->lv_pack.as<unsigned char>());
+    DDX_HIP(ctx, hipMemcpyAsync(ctx->lv_host, ctx->lv_pack.p, packed, hipMemcpyDeviceToHost, ctx->stream));
+    DDX_HIP(ctx, hipGetLastError());
+    ctx->lv_host_valid = true;
     return DDX_OK;
 }
 

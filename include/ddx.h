@@ -103,7 +103,8 @@ int ddx_scale(ddx_ctx* ctx, float max_value);
 
 /* ---- sc.tl.pca(svd_solver="auto") -> sklearn randomized PCA: dd.py:305-314 -------------------
  * q0: the host-drawn start matrix RandomState(seed).normal(size=(q0_rows, L)) as float64 row-major;
- *     q0_rows must be H when M >= H and M when M < H (sklearn's transpose rule).
+ *     q0_rows must be H when M >= H and M when M < H (sklearn's transpose rule).  q0 == NULL reuses the start
+ *     matrix of the previous call (it stays on the device; all boosting iterations draw the same seeded start).
  * n_iter < 0 selects sklearn's "auto" (7 if C < 0.1*min(M,H) else 4).
  * Produces the M x C float32 embedding (U*S, sign-fixed on the components) on the device. */
 int ddx_pca(ddx_ctx* ctx, int32_t n_components, int32_t n_oversamples, int32_t n_iter,
