@@ -110,6 +110,51 @@ def test_pca_and_knn_properties(staged):
     assert w.min() > 0 and w.max() <= 1.0
 
 
+def test_operator_product_variants_agree_at_full_size(data, staged, monkeypatch):
+    """The same randomized PCA through the three implementations of the operator products: LDS-staged float32
+    operand (default), L2-gather float32 operand (DDX_SPMM=gather), L2-gather float64 operand (DDX_PCA_GATHER=f64).
+    The first two compute identical products in different summation orders (agreement to amplified rounding noise); the
+    float64 mode differs by the float32 rounding of the operand copies (< 1e-5 per component, as in the small
+    oracle test)."""
+    import os
+
+    from doubletdetection_amd import _lib
+
+    ctx, _, top, parents = staged
+    ctx.lognormalise(0.1)
+    M, H, C = ctx.M, ctx.H, 30
+    q0 = np.random.RandomState(0).normal(size=(H, C + 10)).astype(np.float32).astype(np.float64)
+    ctx.pca(C, q0)
+    emb_lds, sing_lds = ctx.embedding_f64()
+
+    def other(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        c2 = _lib.Context(0)                        # the panel height of the mirror is fixed at upload
+        try:
+            c2.upload_raw(data)
+            c2.gene_variances()
+            c2.select_columns(top)
+            c2.create_doublets(parents)
+            c2.lognormalise(0.1)
+            c2.pca(C, q0)
+            return c2.embedding_f64()
+        finally:
+            c2.close()
+            for k in env:
+                monkeypatch.delenv(k, raising=False)
+
+    emb_g, sing_g = other({"DDX_SPMM": "gather"})
+    # (rounding noise of the two summation orders, amplified through seven power iterations of unconverged
+    # trailing components: 4e-10 observed on the singular values)
+    np.testing.assert_allclose(sing_g, sing_lds, rtol=1e-8)
+    rel_g = np.linalg.norm(emb_g - emb_lds, axis=0) / np.linalg.norm(emb_lds, axis=0)
+    assert rel_g.max() < 1e-6, rel_g.max()
+    emb_f, sing_f = other({"DDX_SPMM": "gather", "DDX_PCA_GATHER": "f64"})
+    rel = np.linalg.norm(emb_f - emb_lds, axis=0) / np.linalg.norm(emb_f, axis=0)
+    assert rel.max() < 1e-5, rel.max()
+
+
 def test_fit_is_deterministic_and_finds_doublets(data):
     from doubletdetection_amd import BoostClassifier
 
