@@ -108,6 +108,18 @@ def test_pca_and_knn_properties(staged):
     Gm = sp.csr_matrix((w, ix, ip), shape=(M, M))
     assert abs(Gm - Gm.T).nnz == 0 and Gm.diagonal().sum() == 0
     assert w.min() > 0 and w.max() <= 1.0
+    # community detection part A at this size: device == host statement, bit for bit
+    from doubletdetection_amd import _lib
+    m_dev, ip_dev, ix_dev, w_dev = ctx.coarsen_graph(1.0)
+    total, gr = None, (ip, ix, w)
+    for _ in range(_lib.PRESWEEP_LEVELS):
+        mm, *gr = _lib.presweep(*gr, 1.0)
+        total = mm if total is None else mm[total]
+    np.testing.assert_array_equal(m_dev, total)
+    np.testing.assert_array_equal(ip_dev, gr[0])
+    np.testing.assert_array_equal(ix_dev, gr[1])
+    np.testing.assert_array_equal(w_dev, gr[2])
+    assert len(ip_dev) - 1 < M // 20                          # it coarsens by more than an order of magnitude
 
 
 def test_operator_product_variants_agree_at_full_size(data, staged, monkeypatch):
