@@ -148,7 +148,7 @@ int ddx_destroy(ddx_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     (void)timing_flush(ctx);
     DevBuf* bufs[] = {&ctx->raw_indptr, &ctx->raw_indices, &ctx->raw_data, &ctx->aug_indptr, &ctx->aug_indices,
-                      &ctx->aug_raw, &ctx->aug_x, &ctx->lib32, &ctx->lib64, &ctx->synth_counts, &ctx->parents,
+                      &ctx->aug_raw, &ctx->aug_x, &ctx->lib32, &ctx->lib64, &ctx->synth_counts, &ctx->parents, &ctx->pad_off,
                       &ctx->csc_o_colptr, &ctx->csc_o_row, &ctx->csc_o_raw, &ctx->csc_o_x, &ctx->csc_s_colptr,
                       &ctx->csc_s_row, &ctx->csc_s_raw, &ctx->csc_s_x, &ctx->sort_keys_in, &ctx->sort_keys_out,
                       &ctx->sort_vals_in, &ctx->sort_vals_out, &ctx->sort_tmp, &ctx->sort_rowid, &ctx->median, &ctx->lib_sorted,

@@ -86,6 +86,8 @@ struct ddx_ctx {
     ddx::DevBuf lib64;               // double [M] L1 norms (double sequential sums)
     ddx::DevBuf synth_counts;        // int32 [S+1] scratch (row counts -> scan)
     ddx::DevBuf parents;             // int64 [S*2]
+    ddx::DevBuf pad_off;             // int64 [S+1] padded row offsets of the doublet fill
+    std::vector<int64_t> h_pad_off;
     bool have_synth = false;
 
     // column-major mirror: originals (static structure) + synthetic part (rebuilt per iteration)

@@ -106,41 +106,10 @@ __global__ void __launch_bounds__(256) k_row_sums_exact(const int64_t* __restric
 // ------------------------------------------------------------------------------------------------
 // doublets
 // ------------------------------------------------------------------------------------------------
-// Classification shared by the count and fill kernels.  A = row p0, B = row p1, both sorted.
+// Classification used by the fill kernel.  A = row p0, B = row p1, both sorted.
 //   A element i : merged position i + #{b < a_i};   matched b adds its value;
 //   B element j : merged position j + #{a <= b_j};  dropped when matched (already emitted by A).
 // An entry is kept iff its float32 sum is != 0 (scipy csr_plus_csr drops exact zeros).
-
-__global__ void __launch_bounds__(256) k_doublet_count(const int64_t* __restrict__ indptr,
-                                                       const int32_t* __restrict__ indices,
-                                                       const float* __restrict__ val,
-                                                       const int64_t* __restrict__ parents, int64_t S,
-                                                       int32_t* __restrict__ counts) {
-    const int lane = threadIdx.x & 63;
-    const int64_t s = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (s >= S) return;
-    const int64_t p0 = parents[2 * s], p1 = parents[2 * s + 1];
-    const int64_t a0 = indptr[p0], b0 = indptr[p1];
-    const int la = (int)(indptr[p0 + 1] - a0), lb = (int)(indptr[p1 + 1] - b0);
-    const int32_t* A = indices + a0;
-    const int32_t* B = indices + b0;
-    int cnt = 0;
-    for (int i = lane; i < la; i += 64) {
-        const int32_t col = A[i];
-        const int r = lower_bound_i32(B, lb, col);
-        float v = val[a0 + i];
-        if (r < lb && B[r] == col) v = __fadd_rn(v, val[b0 + r]);
-        cnt += (v != 0.f);
-    }
-    for (int j = lane; j < lb; j += 64) {
-        const int32_t col = B[j];
-        const int r = lower_bound_i32(A, la, col);
-        const bool matched = (r < la && A[r] == col);
-        if (!matched) cnt += (val[b0 + j] != 0.f);
-    }
-    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
-    if (lane == 0) counts[s] = cnt;
-}
 
 // single-block exclusive scan of int32 counts into int64 row pointers: out[i] = base + sum_{t<i} in[t],
 // for i in [0, n]; n <= a few hundred thousand rows, one launch of 1024 threads.
@@ -177,9 +146,10 @@ constexpr int kMergeTile = 2048;
 __global__ void __launch_bounds__(256) k_doublet_fill(const int64_t* __restrict__ indptr,
                                                       const int32_t* __restrict__ indices,
                                                       const float* __restrict__ val,
-                                                      const int64_t* __restrict__ parents, int64_t N,
-                                                      const int64_t* __restrict__ out_indptr /* aug_indptr */,
-                                                      int32_t* __restrict__ out_indices, float* __restrict__ out_val) {
+                                                      const int64_t* __restrict__ parents,
+                                                      const int64_t* __restrict__ out_off /* [S]: start of row s in the outputs */,
+                                                      int32_t* __restrict__ out_indices, float* __restrict__ out_val,
+                                                      int32_t* __restrict__ counts /* [S]: entries written, or null */) {
     __shared__ int32_t t_col[kMergeTile];
     __shared__ float t_val[kMergeTile];
     __shared__ int32_t t_keep[kMergeTile];
@@ -193,7 +163,7 @@ __global__ void __launch_bounds__(256) k_doublet_fill(const int64_t* __restrict_
     const int32_t* A = indices + a0;
     const int32_t* B = indices + b0;
     const int L = la + lb;
-    const int64_t o0 = out_indptr[N + s];
+    const int64_t o0 = out_off[s];
     if (tid == 0) run_base = 0;
     for (int t0 = 0; t0 < L; t0 += kMergeTile) {
         for (int i = tid; i < kMergeTile; i += 256) t_keep[i] = 0;
@@ -259,6 +229,22 @@ __global__ void __launch_bounds__(256) k_doublet_fill(const int64_t* __restrict_
         __syncthreads();
         if (tid == 255) run_base = base + tot;
         __syncthreads();
+    }
+    if (counts && tid == 0) counts[s] = run_base;
+}
+
+// rows written at padded offsets (|parent 0| + |parent 1| slots each) moved to their final CSR positions
+__global__ void __launch_bounds__(256) k_doublet_compact(const int64_t* __restrict__ pad_off, const int32_t* __restrict__ pad_idx,
+                                                         const float* __restrict__ pad_val, const int64_t* __restrict__ indptr_s /* aug_indptr + N */,
+                                                         int64_t S, int32_t* __restrict__ out_indices, float* __restrict__ out_val) {
+    const int lane = threadIdx.x & 63;
+    const int64_t s = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= S) return;
+    const int64_t src = pad_off[s], dst = indptr_s[s];
+    const int n = (int)(indptr_s[s + 1] - dst);
+    for (int i = lane; i < n; i += 64) {
+        out_indices[dst + i] = pad_idx[src + i];
+        out_val[dst + i] = pad_val[src + i];
     }
 }
 
@@ -476,12 +462,16 @@ int stage_upload_counts(ddx_ctx* ctx, int64_t N, int32_t H, const int64_t* indpt
 // ------------------------------------------------------------------------------------------------
 int stage_create_doublets(ddx_ctx* ctx, int64_t S, const int64_t* parents) {
     const int64_t N = ctx->N;
-    // capacity from the host copy of the row pointer: |row p0| + |row p1| bounds each synthetic row
+    // capacity from the host copy of the row pointer: |row p0| + |row p1| bounds each synthetic row; the running sum
+    // is where the fill kernel writes row s before the rows are compacted to their true lengths
     int64_t cap = 0;
+    ctx->h_pad_off.resize((size_t)S + 1);
     for (int64_t s = 0; s < S; ++s) {
         const int64_t a = parents[2 * s], b = parents[2 * s + 1];
+        ctx->h_pad_off[s] = cap;
         cap += (ctx->h_indptr[a + 1] - ctx->h_indptr[a]) + (ctx->h_indptr[b + 1] - ctx->h_indptr[b]);
     }
+    ctx->h_pad_off[S] = cap;
     if (ctx->nnz + cap >= (int64_t)1 << 31) return set_err(ctx, DDX_E_UNSUPPORTED, "augmented matrix exceeds 2^31-1 entries");
     if (cap > ctx->cap_synth || !ctx->aug_x.p) {
         const size_t tot = (size_t)(ctx->nnz + cap + 1024);
@@ -503,19 +493,22 @@ int stage_create_doublets(ddx_ctx* ctx, int64_t S, const int64_t* parents) {
     ctx->have_lognorm = ctx->scaled = ctx->have_emb = ctx->have_knn = false;
     if (S) {
         DDX_HIP(ctx, hipMemcpyAsync(ctx->parents.p, parents, sizeof(int64_t) * 2 * S, hipMemcpyHostToDevice, ctx->stream));
-        {
-            ScopedTimer t(ctx, "doublet_count");
-            k_doublet_count<<<(unsigned)ceil_div(S, 4), 256, 0, ctx->stream>>>(ctx->aug_indptr.as<int64_t>(), ctx->aug_indices.as<int32_t>(),
-                                                                               ctx->aug_raw.as<float>(), ctx->parents.as<int64_t>(), S,
-                                                                               ctx->synth_counts.as<int32_t>());
-        }
-        k_scan_counts<<<1, 1024, 0, ctx->stream>>>(ctx->synth_counts.as<int32_t>(), S, ctx->nnz, ctx->aug_indptr.as<int64_t>() + N);
+        // one merge per doublet: rows are written at padded offsets into the (not yet rebuilt) mirror buffers, counted
+        // on the way, scanned into the row pointer and moved to their final positions
+        DDX_TRY(ensure(ctx, ctx->pad_off, sizeof(int64_t) * (S + 1)));
+        DDX_HIP(ctx, hipMemcpyAsync(ctx->pad_off.p, ctx->h_pad_off.data(), sizeof(int64_t) * (S + 1), hipMemcpyHostToDevice, ctx->stream));
         {
             ScopedTimer t(ctx, "doublet_fill");
             k_doublet_fill<<<(unsigned)S, 256, 0, ctx->stream>>>(ctx->aug_indptr.as<int64_t>(), ctx->aug_indices.as<int32_t>(),
-                                                                 ctx->aug_raw.as<float>(), ctx->parents.as<int64_t>(), N,
-                                                                 ctx->aug_indptr.as<int64_t>(), ctx->aug_indices.as<int32_t>(),
-                                                                 ctx->aug_raw.as<float>());
+                                                                 ctx->aug_raw.as<float>(), ctx->parents.as<int64_t>(), ctx->pad_off.as<int64_t>(),
+                                                                 ctx->csc_s_row.as<int32_t>(), ctx->csc_s_raw.as<float>(), ctx->synth_counts.as<int32_t>());
+        }
+        k_scan_counts<<<1, 1024, 0, ctx->stream>>>(ctx->synth_counts.as<int32_t>(), S, ctx->nnz, ctx->aug_indptr.as<int64_t>() + N);
+        {
+            ScopedTimer t(ctx, "doublet_compact");
+            k_doublet_compact<<<(unsigned)ceil_div(S, 4), 256, 0, ctx->stream>>>(ctx->pad_off.as<int64_t>(), ctx->csc_s_row.as<int32_t>(), ctx->csc_s_raw.as<float>(),
+                                                                                 ctx->aug_indptr.as<int64_t>() + N, S, ctx->aug_indices.as<int32_t>(),
+                                                                                 ctx->aug_raw.as<float>());
         }
         DDX_HIP(ctx, hipGetLastError());
     }
