@@ -96,6 +96,18 @@ def load():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -m doubletdetection_amd._build` "
             "(there is no CPU fallback for the HIP path)")
+    # PyTorch-ROCm bundles its own copy of the HIP runtime.  The two coexist in one process when torch's initialises
+    # first; if torch is already imported, make sure it has done so before libddx touches the device.  (A process that
+    # imports torch only *after* its first ddx context should call torch.cuda.init() before creating that context.)
+    import sys
+
+    torch = sys.modules.get("torch")
+    if torch is not None:
+        try:
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except Exception:
+            pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)

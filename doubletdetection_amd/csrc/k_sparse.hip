@@ -142,6 +142,7 @@ __global__ void __launch_bounds__(1024) k_scan_counts(const int32_t* __restrict_
 }
 
 constexpr int kMergeTile = 2048;
+constexpr int kMergeStage = 6144;     // column entries of both parents staged in LDS (24 KB)
 
 __global__ void __launch_bounds__(256) k_doublet_fill(const int64_t* __restrict__ indptr,
                                                       const int32_t* __restrict__ indices,
@@ -155,6 +156,7 @@ __global__ void __launch_bounds__(256) k_doublet_fill(const int64_t* __restrict_
     __shared__ int32_t t_keep[kMergeTile];
     __shared__ int32_t wsum[4];
     __shared__ int32_t run_base;
+    __shared__ int32_t s_idx[kMergeStage];          // both parents' column lists when they fit: the searches then run in LDS
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int64_t s = blockIdx.x;
     const int64_t p0 = parents[2 * s], p1 = parents[2 * s + 1];
@@ -163,6 +165,13 @@ __global__ void __launch_bounds__(256) k_doublet_fill(const int64_t* __restrict_
     const int32_t* A = indices + a0;
     const int32_t* B = indices + b0;
     const int L = la + lb;
+    if (L <= kMergeStage) {                         // block-uniform
+        for (int i = tid; i < la; i += 256) s_idx[i] = A[i];
+        for (int j = tid; j < lb; j += 256) s_idx[la + j] = B[j];
+        A = s_idx;
+        B = s_idx + la;
+        __syncthreads();
+    }
     const int64_t o0 = out_off[s];
     if (tid == 0) run_base = 0;
     for (int t0 = 0; t0 < L; t0 += kMergeTile) {

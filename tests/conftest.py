@@ -16,6 +16,22 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` through gpurun)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _torch_runtime_first():
+    """PyTorch ships its own copy of the HIP runtime; libddx.so links the system one.  Both work in one process when
+    torch initialises its runtime first (bench.py's order) -- the other way round torch later reports "no
+    ROCm-capable device".  Some GPU tests use torch for data generation, so initialise it before any test touches
+    libddx, whatever order the tests were selected in.  No-op on a machine without a GPU."""
+    try:
+        import torch
+
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:      # torch absent or unusable: the tests that need it will say so
+        pass
+    yield
+
+
 def load_golden(name):
     return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
 
