@@ -117,29 +117,50 @@ __global__ void __launch_bounds__(256) k_lv_sweep(const int64_t* __restrict__ in
             best_c = c;
         }
     } else {
-        const int wv = 0;
+        // LDS path: sort the (community, weight) pairs of the node by community (wave-wide bitonic sort), then every
+        // run of equal communities is summed by the lane that finds its first element.  O(d log^2 d / 64) per lane.
         const int d = deg < kLvCap ? deg : kLvCap;       // deg > kLvCap is rejected on the host before the launch
-        for (int i = lane; i < d; i += 64) {
-            const int32_t u = cols[b + i];
-            cS[wv][i] = (u == (int32_t)v) ? -1 : comm[u];
-            wS[wv][i] = wq[b + i];
+        int P = 64;
+        while (P < d) P <<= 1;
+        for (int i = lane; i < P; i += 64) {
+            int32_t c = 0x7fffffff;                      // padding sorts last
+            int64_t wv = 0;
+            if (i < d) {
+                const int32_t u = cols[b + i];
+                c = (u == (int32_t)v) ? 0x7ffffffe : comm[u];     // self loops: a class of their own, ignored below
+                wv = wq[b + i];
+            }
+            cS[0][i] = c;
+            wS[0][i] = wv;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        for (int i = lane; i < d; i += 64) {
-            const int32_t c = cS[wv][i];
-            if (c < 0) continue;
-            int64_t W = 0;
-            bool leader = true;
-            for (int j = 0; j < d; ++j) {
-                if (cS[wv][j] == c) {
-                    W += wS[wv][j];
-                    if (j < i) leader = false;
+        for (int size = 2; size <= P; size <<= 1) {
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                for (int t = lane; t < (P >> 1); t += 64) {
+                    const int lo = ((t / stride) * stride * 2) + (t % stride);
+                    const int hi = lo + stride;
+                    const bool up = ((lo & size) == 0);
+                    const int32_t cl = cS[0][lo], ch = cS[0][hi];
+                    if ((cl > ch) == up) {
+                        const int64_t wl = wS[0][lo], wh = wS[0][hi];
+                        cS[0][lo] = ch; cS[0][hi] = cl;
+                        wS[0][lo] = wh; wS[0][hi] = wl;
+                    }
                 }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
             }
+        }
+        for (int i = lane; i < d; i += 64) {
+            const int32_t c = cS[0][i];
+            if (c >= 0x7ffffffe) continue;               // self loops / padding
+            if (i > 0 && cS[0][i - 1] == c) continue;    // not the first element of its run
+            int64_t W = 0;
+            for (int j = i; j < d && cS[0][j] == c; ++j) W += wS[0][j];
             if (c == own) {
-                if (leader) w_own = W;
-            } else if (leader) {
+                w_own = W;
+            } else {
                 const double s = (double)W * m2d - (gamma * (double)(int64_t)tot[c]) * kv;
                 if (best_c < 0 || s > best_s || (s == best_s && c < best_c)) { best_s = s; best_c = c; }
             }
