@@ -1079,7 +1079,7 @@ __global__ void __launch_bounds__(256) k_umap_union(const int32_t* __restrict__ 
 
 // ---- symmetric CSR on the device ----------------------------------------------------------------------
 // every relation with a non-zero weight contributes the pair (i,j); a one-directional relation (negative
-// flag) also contributes (j,i).  Pairs are keyed (row << 32 | column) and radix-sorted, which yields rows
+// flag) also contributes (j,i).  Pairs are keyed (row << bits(M) | column) and radix-sorted, which yields rows
 // in order and columns ascending inside a row (the adjacency order the community-detection spec visits).
 __global__ void __launch_bounds__(256) k_pair_count(const double* __restrict__ w, int64_t n, int32_t* __restrict__ cnt) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1089,7 +1089,7 @@ __global__ void __launch_bounds__(256) k_pair_count(const double* __restrict__ w
 }
 
 __global__ void __launch_bounds__(256) k_pair_emit(const int32_t* __restrict__ idx, const double* __restrict__ w, int64_t n,
-                                                   int K, const int64_t* __restrict__ offs, uint64_t* __restrict__ keys,
+                                                   int K, int shift, const int64_t* __restrict__ offs, uint64_t* __restrict__ keys,
                                                    double* __restrict__ vals) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
@@ -1098,28 +1098,28 @@ __global__ void __launch_bounds__(256) k_pair_emit(const int32_t* __restrict__ i
     const uint64_t i = (uint64_t)(t / K), j = (uint64_t)idx[t];
     const double av = v < 0.0 ? -v : v;
     int64_t o = offs[t];
-    keys[o] = (i << 32) | j;
+    keys[o] = (i << shift) | j;            // shift = bits of the node count: the sort only passes over 2*shift bits
     vals[o] = av;
     if (v < 0.0) {
-        keys[o + 1] = (j << 32) | i;
+        keys[o + 1] = (j << shift) | i;
         vals[o + 1] = av;
     }
 }
 
-__global__ void k_rowptr_from_keys(const uint64_t* __restrict__ keys, int64_t n, int64_t M, int64_t* __restrict__ indptr) {
+__global__ void k_rowptr_from_keys(const uint64_t* __restrict__ keys, int64_t n, int64_t M, int shift, int64_t* __restrict__ indptr) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r > M) return;
     int64_t lo = 0, hi = n;   // first key with row >= r
     while (lo < hi) {
         const int64_t mid = (lo + hi) >> 1;
-        if ((int64_t)(keys[mid] >> 32) < r) lo = mid + 1; else hi = mid;
+        if ((int64_t)(keys[mid] >> shift) < r) lo = mid + 1; else hi = mid;
     }
     indptr[r] = lo;
 }
 
-__global__ void k_cols_from_keys(const uint64_t* __restrict__ keys, int64_t n, int32_t* __restrict__ cols) {
+__global__ void k_cols_from_keys(const uint64_t* __restrict__ keys, int64_t n, int shift, int32_t* __restrict__ cols) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n) cols[t] = (int32_t)(keys[t] & 0xffffffffull);
+    if (t < n) cols[t] = (int32_t)(keys[t] & ((1ull << shift) - 1ull));
 }
 
 // device part: relation weights for the kNN table currently held by the context
@@ -1231,20 +1231,21 @@ int stage_build_graph(ddx_ctx* ctx, int32_t mode) {
         size_t tmp_bytes = 0;
         DDX_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, cnt, offs, (int)n + 1, ctx->stream));
         size_t tmp2 = 0;
-        int end_bit = 33;
-        while (((int64_t)1 << (end_bit - 32)) < M) ++end_bit;
+        int shift = 1;                               // pairs are keyed row << shift | column with shift = bits(M)
+        while (((int64_t)1 << shift) < M) ++shift;
+        const int end_bit = 2 * shift;
         DDX_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp2, keys_a, keys_b, vals_a, vals_b, (int)(2 * n), 0, end_bit, ctx->stream));
         DDX_TRY(ensure(ctx, ctx->sort_tmp, std::max(tmp_bytes, tmp2)));
         // (cnt has n entries; the scan reads one more element: it lives in the padding of the carve and is ignored)
         DDX_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(ctx->sort_tmp.p, tmp_bytes, cnt, offs, (int)n + 1, ctx->stream));
         DDX_HIP(ctx, hipMemcpyAsync(&E, offs + n, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
-        k_pair_emit<<<(unsigned)ceil_div(n, 256), 256, 0, ctx->stream>>>(ctx->knn_idx.as<int32_t>(), ctx->edge_w.as<double>(), n, K, offs, keys_a, vals_a);
+        k_pair_emit<<<(unsigned)ceil_div(n, 256), 256, 0, ctx->stream>>>(ctx->knn_idx.as<int32_t>(), ctx->edge_w.as<double>(), n, K, shift, offs, keys_a, vals_a);
         DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (E > 0) {
             DDX_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(ctx->sort_tmp.p, tmp2, keys_a, keys_b, vals_a, vals_b, (int)E, 0, end_bit, ctx->stream));
-            k_cols_from_keys<<<(unsigned)ceil_div(E, 256), 256, 0, ctx->stream>>>(keys_b, E, d_cols);
+            k_cols_from_keys<<<(unsigned)ceil_div(E, 256), 256, 0, ctx->stream>>>(keys_b, E, shift, d_cols);
         }
-        k_rowptr_from_keys<<<(unsigned)ceil_div(M + 1, 256), 256, 0, ctx->stream>>>(keys_b, E, M, d_indptr);
+        k_rowptr_from_keys<<<(unsigned)ceil_div(M + 1, 256), 256, 0, ctx->stream>>>(keys_b, E, M, shift, d_indptr);
     }
     DDX_HIP(ctx, hipGetLastError());
     // the CSR stays on the device until ddx_get_graph copies it straight into the caller's buffers

@@ -189,30 +189,30 @@ __global__ void k_lv_member(const int32_t* __restrict__ comm, const int32_t* __r
 }
 
 __global__ void __launch_bounds__(256) k_lv_edge_keys(const int64_t* __restrict__ indptr, const int32_t* __restrict__ cols,
-                                                      const int32_t* __restrict__ member, int64_t n, uint64_t* __restrict__ keys) {
+                                                      const int32_t* __restrict__ member, int64_t n, int shift, uint64_t* __restrict__ keys) {
     const int lane = threadIdx.x & 63;
     const int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (v >= n) return;
-    const uint64_t hi = (uint64_t)member[v] << 32;
+    const uint64_t hi = (uint64_t)member[v] << shift;
     for (int64_t p = indptr[v] + lane; p < indptr[v + 1]; p += 64) keys[p] = hi | (uint32_t)member[cols[p]];
 }
 
-__global__ void k_lv_rowptr(const uint64_t* __restrict__ keys, int64_t n, int64_t rows, int64_t* __restrict__ indptr) {
+__global__ void k_lv_rowptr(const uint64_t* __restrict__ keys, int64_t n, int64_t rows, int shift, int64_t* __restrict__ indptr) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r > rows) return;
     int64_t lo = 0, hi = n;
     while (lo < hi) {
         const int64_t mid = (lo + hi) >> 1;
-        if ((int64_t)(keys[mid] >> 32) < r) lo = mid + 1; else hi = mid;
+        if ((int64_t)(keys[mid] >> shift) < r) lo = mid + 1; else hi = mid;
     }
     indptr[r] = lo;
 }
 
-__global__ void k_lv_unpack(const uint64_t* __restrict__ keys, const int64_t* __restrict__ sums, int64_t n, int32_t* __restrict__ cols,
-                            double* __restrict__ w) {
+__global__ void k_lv_unpack(const uint64_t* __restrict__ keys, const int64_t* __restrict__ sums, int64_t n, int shift,
+                            int32_t* __restrict__ cols, double* __restrict__ w) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
-    cols[t] = (int32_t)(keys[t] & 0xffffffffull);
+    cols[t] = (int32_t)(keys[t] & ((1ull << shift) - 1ull));
     w[t] = (double)sums[t] / kWeightScale;
 }
 
@@ -267,8 +267,9 @@ static int coarsen_level(ddx_ctx* ctx, const LvGraph& in, double gamma, int32_t 
     k_lv_used<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(cur, n, sc.used);
     size_t tmp_scan = 0, tmp_sort = 0, tmp_red = 0;
     DDX_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_scan, sc.used, sc.renum, (int)n + 1, st));
-    int end_bit = 33;
-    while (((int64_t)1 << (end_bit - 32)) < n) ++end_bit;
+    int shift = 1;                                   // keys: coarse row << shift | coarse column, shift = bits(n)
+    while (((int64_t)1 << shift) < n) ++shift;
+    const int end_bit = 2 * shift;
     int64_t* runs_d = reinterpret_cast<int64_t*>(sc.scal + 2);
     if (E > 0) {
         DDX_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_sort, sc.keys_a, sc.keys_b, sc.wq, sc.vals_b, (int)E, 0, end_bit, st));
@@ -279,7 +280,7 @@ static int coarsen_level(ddx_ctx* ctx, const LvGraph& in, double gamma, int32_t 
     k_lv_member<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(cur, sc.renum, n, member);
     int64_t runs = 0;
     if (E > 0) {
-        k_lv_edge_keys<<<(unsigned)ceil_div(n, 4), 256, 0, st>>>(in.indptr, in.cols, member, n, sc.keys_a);
+        k_lv_edge_keys<<<(unsigned)ceil_div(n, 4), 256, 0, st>>>(in.indptr, in.cols, member, n, shift, sc.keys_a);
         DDX_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(ctx->sort_tmp.p, tmp_sort, sc.keys_a, sc.keys_b, sc.wq, sc.vals_b, (int)E, 0, end_bit, st));
         DDX_HIP(ctx, hipcub::DeviceReduce::ReduceByKey(ctx->sort_tmp.p, tmp_red, sc.keys_b, sc.keys_a, sc.vals_b, sc.sums, runs_d, hipcub::Sum(), (int)E, st));
     }
@@ -288,8 +289,8 @@ static int coarsen_level(ddx_ctx* ctx, const LvGraph& in, double gamma, int32_t 
     DDX_HIP(ctx, hipMemcpyAsync(&runs, runs_d, sizeof(int64_t), hipMemcpyDeviceToHost, st));
     DDX_HIP(ctx, hipStreamSynchronize(st));
     if (E == 0) runs = 0;
-    if (runs > 0) k_lv_unpack<<<(unsigned)ceil_div(runs, 256), 256, 0, st>>>(sc.keys_a, sc.sums, runs, c_cols, c_w);
-    k_lv_rowptr<<<(unsigned)ceil_div((int64_t)nc + 1, 256), 256, 0, st>>>(sc.keys_a, runs, nc, c_indptr);
+    if (runs > 0) k_lv_unpack<<<(unsigned)ceil_div(runs, 256), 256, 0, st>>>(sc.keys_a, sc.sums, runs, shift, c_cols, c_w);
+    k_lv_rowptr<<<(unsigned)ceil_div((int64_t)nc + 1, 256), 256, 0, st>>>(sc.keys_a, runs, nc, shift, c_indptr);
     DDX_HIP(ctx, hipGetLastError());
     out.n = nc;
     out.E = runs;
