@@ -290,11 +290,14 @@ int stage_rankings(ddx_ctx* ctx) {
     k_col_lengths<<<(unsigned)ceil_div(H, 256), 256, 0, ctx->stream>>>(ctx->csc_o_colptr.as<int64_t>(), ctx->P_o, ctx->csc_s_colptr.as<int64_t>(), ctx->P_s, H,
                                                                        keys_in + M, ids_in + M);
     size_t tmp_r = 0, tmp_c = 0;
-    DDX_HIP(ctx, hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tmp_r, keys_in, keys_out, ids_in, ids_out, (int)M, 0, 32, ctx->stream));
-    DDX_HIP(ctx, hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tmp_c, keys_in + M, keys_out + M, ids_in + M, ids_out + M, (int)H, 0, 32, ctx->stream));
+    int bits_r = 1, bits_c = 1;                 // a row holds at most H entries, a column at most M: sort only those bits
+    while (((int64_t)1 << bits_r) <= H) ++bits_r;
+    while (((int64_t)1 << bits_c) <= M) ++bits_c;
+    DDX_HIP(ctx, hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tmp_r, keys_in, keys_out, ids_in, ids_out, (int)M, 0, bits_r, ctx->stream));
+    DDX_HIP(ctx, hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tmp_c, keys_in + M, keys_out + M, ids_in + M, ids_out + M, (int)H, 0, bits_c, ctx->stream));
     DDX_TRY(ensure(ctx, ctx->sort_tmp, std::max(tmp_r, tmp_c)));
-    DDX_HIP(ctx, hipcub::DeviceRadixSort::SortPairsDescending(ctx->sort_tmp.p, tmp_r, keys_in, keys_out, ids_in, ids_out, (int)M, 0, 32, ctx->stream));
-    DDX_HIP(ctx, hipcub::DeviceRadixSort::SortPairsDescending(ctx->sort_tmp.p, tmp_c, keys_in + M, keys_out + M, ids_in + M, ids_out + M, (int)H, 0, 32, ctx->stream));
+    DDX_HIP(ctx, hipcub::DeviceRadixSort::SortPairsDescending(ctx->sort_tmp.p, tmp_r, keys_in, keys_out, ids_in, ids_out, (int)M, 0, bits_r, ctx->stream));
+    DDX_HIP(ctx, hipcub::DeviceRadixSort::SortPairsDescending(ctx->sort_tmp.p, tmp_c, keys_in + M, keys_out + M, ids_in + M, ids_out + M, (int)H, 0, bits_c, ctx->stream));
     ctx->rank_rows = ids_out;
     ctx->rank_cols = ids_out + M;
     return DDX_OK;
