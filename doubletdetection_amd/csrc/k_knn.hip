@@ -639,6 +639,7 @@ __device__ __forceinline__ double exact_d2(const float* q /* LDS, CP floats */, 
 }
 
 constexpr int kSelMax = 1024;   // sort window of the select pass (power of two, >= kCandCap + 64)
+constexpr int kSelSmall = 256;  // queries with at most this many candidates (nearly all) sort in a small window: 4x the waves per CU
 
 // bitonic sort of d[0..P), ix[0..P) by (distance, index), ascending; one wave, P a power of two >= 64
 __device__ __forceinline__ void wave_sort(double* d, int32_t* ix, int P, int lane) {
@@ -659,14 +660,15 @@ __device__ __forceinline__ void wave_sort(double* d, int32_t* ix, int P, int lan
     }
 }
 
-// one wave per query (4 per block, no block-level synchronisation)
-template <int CP>
+// one wave per query (4 per block, no block-level synchronisation).  Two instances share the work: SELMAX = kSelSmall
+// takes the queries whose list fits that window, SELMAX = kSelMax the few longer (or overflowed) ones.
+template <int CP, int SELMAX>
 __global__ void __launch_bounds__(256) k_knn_select(const float* __restrict__ E, const int32_t* __restrict__ perm, int64_t M, int K,
                                                     int include_self, const int32_t* __restrict__ ccount, const int32_t* __restrict__ cbuf,
                                                     int32_t* __restrict__ idx_out, double* __restrict__ dist_out,
                                                     int32_t* __restrict__ n_overflow) {
-    __shared__ __attribute__((aligned(16))) double sd[4][kSelMax];
-    __shared__ int32_t si[4][kSelMax];
+    __shared__ __attribute__((aligned(16))) double sd[4][SELMAX];
+    __shared__ int32_t si[4][SELMAX];
     __shared__ __attribute__((aligned(16))) float sq[4][CP];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t q = (int64_t)blockIdx.x * 4 + wave;
@@ -676,6 +678,7 @@ __global__ void __launch_bounds__(256) k_knn_select(const float* __restrict__ E,
     float* qrow = sq[wave];
     for (int t = lane; t < CP; t += 64) qrow[t] = E[q * CP + t];
     const int cnt_all = ccount[q];
+    if ((SELMAX == kSelSmall) != (cnt_all <= kSelSmall)) return;      // the other instance's query
     const bool overflow = cnt_all > kCandCap;
     const int cnt = overflow ? kCandCap : cnt_all;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -714,11 +717,11 @@ __global__ void __launch_bounds__(256) k_knn_select(const float* __restrict__ E,
             }
             const unsigned long long m = __ballot(keep);
             const int n_new = __popcll(m);
-            if (fill + n_new > kSelMax) {           // pathological ties: compact to the best K and go on
-                for (int t = fill + lane; t < kSelMax; t += 64) { d[t] = __builtin_huge_val(); ix[t] = 0x7fffffff; }
+            if (fill + n_new > SELMAX) {           // pathological ties: compact to the best K and go on
+                for (int t = fill + lane; t < SELMAX; t += 64) { d[t] = __builtin_huge_val(); ix[t] = 0x7fffffff; }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                wave_sort(d, ix, kSelMax, lane);
+                wave_sort(d, ix, SELMAX, lane);
                 fill = K;
             }
             if (keep) {
@@ -864,8 +867,13 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
     {
         ScopedTimer t(ctx, "knn_select");
         const unsigned g2 = (unsigned)ceil_div(M, 4);
-        if (CP == 32) k_knn_select<32><<<g2, 256, 0, ctx->stream>>>(E, perm, M, k, include_self, ccount, cbuf, ctx->knn_idx.as<int32_t>(), ctx->knn_dist.as<double>(), ccount + Mp);
-        else k_knn_select<64><<<g2, 256, 0, ctx->stream>>>(E, perm, M, k, include_self, ccount, cbuf, ctx->knn_idx.as<int32_t>(), ctx->knn_dist.as<double>(), ccount + Mp);
+        if (CP == 32) {
+            k_knn_select<32, kSelSmall><<<g2, 256, 0, ctx->stream>>>(E, perm, M, k, include_self, ccount, cbuf, ctx->knn_idx.as<int32_t>(), ctx->knn_dist.as<double>(), ccount + Mp);
+            k_knn_select<32, kSelMax><<<g2, 256, 0, ctx->stream>>>(E, perm, M, k, include_self, ccount, cbuf, ctx->knn_idx.as<int32_t>(), ctx->knn_dist.as<double>(), ccount + Mp);
+        } else {
+            k_knn_select<64, kSelSmall><<<g2, 256, 0, ctx->stream>>>(E, perm, M, k, include_self, ccount, cbuf, ctx->knn_idx.as<int32_t>(), ctx->knn_dist.as<double>(), ccount + Mp);
+            k_knn_select<64, kSelMax><<<g2, 256, 0, ctx->stream>>>(E, perm, M, k, include_self, ccount, cbuf, ctx->knn_idx.as<int32_t>(), ctx->knn_dist.as<double>(), ccount + Mp);
+        }
     }
     DDX_HIP(ctx, hipGetLastError());
     if (getenv("DDX_KNN_DEBUG")) {
