@@ -66,7 +66,11 @@ __global__ void k_knn_prepare(const float* __restrict__ in, const int32_t* __res
 // in the rearranged form  q.c > 0.5*(1-slack)*|c|^2 + 0.5*((1-slack)*|q|^2 - thr), whose extra float32
 // roundings (<= 2e-7 relative to the norms) are covered by the margin in 8e-6.
 constexpr float kScreenSlack = 8.0e-6f;
-constexpr int kBoundKeep = 6;      // smallest sample distances kept per lane and row in the bound pass
+// Smallest sample distances kept per lane and row in the bound pass.  Whatever the lanes keep, the k-th smallest of the
+// kept values is the k-th smallest of a subset, i.e. a valid upper bound; keeping 4 (instead of 6) loosens it for the
+// queries where one lane meets more than 4 of the k nearest sample points, and lets four waves share a SIMD.
+constexpr int kBoundKeepSmall = 4;   // k <= 48
+constexpr int kBoundKeepLarge = 6;   // k <= 80
 constexpr int kCandCap = 768;      // candidate slots per query between the emit and select passes
 
 // ================================================================================================
@@ -151,7 +155,7 @@ constexpr int kBoundRT = 2;   // query tiles per wave in the bound pass (registe
 constexpr int kEmitRT = DDX_EMIT_RT;    // query tiles per wave in the emit pass
 #define DDX_EMIT_WAVES (DDX_EMIT_RT <= 2 ? 4 : 3)
 
-template <int CP>
+template <int CP, int kBoundKeep>
 __global__ void __launch_bounds__(256) k_knn_bound(const float* __restrict__ Et, const float* __restrict__ nrm,
                                                    int64_t Mp, int K, int include_self, int64_t nsamp_tiles,
                                                    int64_t tile_stride, float* __restrict__ thr_out) {
@@ -413,7 +417,7 @@ struct QueryTilesBf {
     }
 };
 
-template <int CP>
+template <int CP, int kBoundKeep>
 __global__ void __launch_bounds__(256) k_knn_bound_bf(const __bf16* __restrict__ Eb, const float* __restrict__ nrm,
                                                       int64_t Mp, int K, int include_self, int64_t nsamp_tiles,
                                                       int64_t tile_stride, float* __restrict__ thr_out) {
@@ -797,7 +801,8 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
     const int64_t M = ctx->embM;
     const int C = ctx->C;
     if (C > kMaxDim) return set_err(ctx, DDX_E_UNSUPPORTED, "embedding dimension %d exceeds %d", C, kMaxDim);
-    if (k > 16 * (kBoundKeep - 1)) return set_err(ctx, DDX_E_UNSUPPORTED, "k=%d exceeds %d", k, 16 * (kBoundKeep - 1));
+    if (k > 16 * (kBoundKeepLarge - 1)) return set_err(ctx, DDX_E_UNSUPPORTED, "k=%d exceeds %d", k, 16 * (kBoundKeepLarge - 1));
+    const bool keep_small = k <= 16 * (kBoundKeepSmall - 1);
     const int CP = (C <= 32) ? 32 : 64;
     const int64_t Mp = ceil_div(M, 256) * 256;                 // whole blocks of queries in both MFMA passes
     // workspace (reuses the PCA row buffer): E [Mp*CP] | Et [Mp*CP] | Eb [Mp*CP as bf16 hi+lo] | nrm [Mp] | thr [Mp] | p1 [Mp] | keys [2*Mp]
@@ -849,10 +854,16 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
     {
         ScopedTimer t(ctx, "knn_bound");
         const unsigned grid = (unsigned)(Mp / (4 * 16 * kBoundRT));
-        if (bf && CP == 32) k_knn_bound_bf<32><<<grid, 256, 0, ctx->stream>>>(Eb, nrm, Mp, k, include_self, nsamp, stride, thr);
-        else if (bf) k_knn_bound_bf<64><<<grid, 256, 0, ctx->stream>>>(Eb, nrm, Mp, k, include_self, nsamp, stride, thr);
-        else if (CP == 32) k_knn_bound<32><<<grid, 256, 0, ctx->stream>>>(Et, nrm, Mp, k, include_self, nsamp, stride, thr);
-        else k_knn_bound<64><<<grid, 256, 0, ctx->stream>>>(Et, nrm, Mp, k, include_self, nsamp, stride, thr);
+#define DDX_BOUND_LAUNCH(KERNEL, OPERAND)                                                                                        \
+    do {                                                                                                                       \
+        if (CP == 32 && keep_small) KERNEL<32, kBoundKeepSmall><<<grid, 256, 0, ctx->stream>>>(OPERAND, nrm, Mp, k, include_self, nsamp, stride, thr); \
+        else if (CP == 32) KERNEL<32, kBoundKeepLarge><<<grid, 256, 0, ctx->stream>>>(OPERAND, nrm, Mp, k, include_self, nsamp, stride, thr);      \
+        else if (keep_small) KERNEL<64, kBoundKeepSmall><<<grid, 256, 0, ctx->stream>>>(OPERAND, nrm, Mp, k, include_self, nsamp, stride, thr);    \
+        else KERNEL<64, kBoundKeepLarge><<<grid, 256, 0, ctx->stream>>>(OPERAND, nrm, Mp, k, include_self, nsamp, stride, thr);                    \
+    } while (0)
+        if (bf) DDX_BOUND_LAUNCH(k_knn_bound_bf, Eb);
+        else DDX_BOUND_LAUNCH(k_knn_bound, Et);
+#undef DDX_BOUND_LAUNCH
     }
     {
         ScopedTimer t(ctx, "knn_emit");
