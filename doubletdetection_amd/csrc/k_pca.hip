@@ -550,6 +550,7 @@ __global__ void __launch_bounds__(256) k_reduce_partials(const double* __restric
 
 // partial Gram: G_b = X_b^T X_b for a block of rows, staged through LDS in 32-row tiles.  Only the pairs a <= b
 // are accumulated (each thread owns a few of the L(L+1)/2), both triangles are written.
+template <int MAXP>   // pairs per thread: ceil(L(L+1)/2 / 256)
 __global__ void __launch_bounds__(256) k_gram_partial(const double* __restrict__ X, int64_t R, int L,
                                                       int64_t rows_per_block, double* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) double tile[];  // [32][L]
@@ -557,7 +558,6 @@ __global__ void __launch_bounds__(256) k_gram_partial(const double* __restrict__
     const int npairs = L * (L + 1) / 2;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     const int64_t r1 = (r0 + rows_per_block < R) ? r0 + rows_per_block : R;
-    constexpr int MAXP = (kMaxL * (kMaxL + 1) / 2 + 255) / 256;  // pairs per thread upper bound
     double acc[MAXP];
     int pa[MAXP], pb[MAXP];
 #pragma unroll
@@ -738,11 +738,12 @@ static int wcolsum(PcaWork& w, const double* X, int64_t R, const double* wgt, do
 }
 
 static int gram(PcaWork& w, const double* X, int64_t R, double* G) {
-    int nb = (int)std::min<int64_t>(256, ceil_div(R, 128));
+    int nb = (int)std::min<int64_t>(512, ceil_div(R, 128));      // pcaPartial holds 512 partial Gram matrices
     int64_t rpb = ceil_div(R, nb);
     nb = (int)ceil_div(R, rpb);
     const int LL = w.L * w.L;
-    k_gram_partial<<<nb, 256, sizeof(double) * 32 * w.L, w.ctx->stream>>>(X, R, w.L, rpb, w.partial);
+    if (w.L * (w.L + 1) / 2 <= 4 * 256) k_gram_partial<4><<<nb, 256, sizeof(double) * 32 * w.L, w.ctx->stream>>>(X, R, w.L, rpb, w.partial);
+    else k_gram_partial<(kMaxL * (kMaxL + 1) / 2 + 255) / 256><<<nb, 256, sizeof(double) * 32 * w.L, w.ctx->stream>>>(X, R, w.L, rpb, w.partial);
     k_reduce_partials<<<(unsigned)ceil_div(LL, 4), 256, 0, w.ctx->stream>>>(w.partial, nb, LL, G);
     return DDX_OK;
 }

@@ -142,9 +142,9 @@ __global__ void __launch_bounds__(1024) k_scan_counts(const int32_t* __restrict_
 }
 
 constexpr int kMergeTile = 2048;
-constexpr int kMergeStage = 6144;     // column entries of both parents staged in LDS (24 KB)
+constexpr int kMergeStage = 3840;     // column entries of both parents staged in LDS (15 KB: four workgroups per CU)
 
-__global__ void __launch_bounds__(256) k_doublet_fill(const int64_t* __restrict__ indptr,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) k_doublet_fill(const int64_t* __restrict__ indptr,
                                                       const int32_t* __restrict__ indices,
                                                       const float* __restrict__ val,
                                                       const int64_t* __restrict__ parents,
