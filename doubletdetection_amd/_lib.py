@@ -71,6 +71,8 @@ _SIGNATURES = {
     "ddx_get_graph": (C.c_int, [C.c_void_p, c_i64_p, c_i32_p, c_f64_p]),
     "ddx_louvain": (C.c_int, [C.c_int64, c_i64_p, c_i32_p, c_f64_p, C.c_double, C.c_uint64, c_i32_p, c_f64_p]),
     "ddx_louvain_sequential": (C.c_int, [C.c_int64, c_i64_p, c_i32_p, c_f64_p, C.c_double, C.c_uint64, c_i32_p, c_f64_p]),
+    "ddx_leiden": (C.c_int, [C.c_int64, c_i64_p, c_i32_p, c_f64_p, C.c_double, C.c_uint64, c_i32_p]),
+    "ddx_leiden_sequential": (C.c_int, [C.c_int64, c_i64_p, c_i32_p, c_f64_p, C.c_double, C.c_uint64, c_i32_p]),
     "ddx_presweep": (C.c_int, [C.c_int64, c_i64_p, c_i32_p, c_f64_p, C.c_double, C.c_int32, c_i32_p, c_i64_p, c_i64_p, c_i32_p, c_f64_p]),
     "ddx_coarsen_graph": (C.c_int, [C.c_void_p, C.c_double, C.c_int32, C.c_int32]),
     "ddx_get_coarse_size": (C.c_int, [C.c_void_p, c_i64_p, c_i64_p]),
@@ -166,6 +168,28 @@ def louvain_sequential(indptr, indices, weights, gamma: float, seed: int):
     _check(lib.ddx_louvain_sequential(n, _p(indptr, c_i64_p), _p(indices, c_i32_p), _p(weights, c_f64_p), float(gamma),
                                       int(seed) & 0xFFFFFFFFFFFFFFFF, _p(labels, c_i32_p), C.byref(q)))
     return labels, q.value
+
+
+def _leiden_call(name, indptr, indices, weights, gamma, seed):
+    lib = load()
+    indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+    indices = np.ascontiguousarray(indices, dtype=np.int32)
+    weights = np.ascontiguousarray(weights, dtype=np.float64)
+    n = indptr.shape[0] - 1
+    labels = np.empty(n, dtype=np.int32)
+    _check(getattr(lib, name)(n, _p(indptr, c_i64_p), _p(indices, c_i32_p), _p(weights, c_f64_p), float(gamma),
+                              int(seed) & 0xFFFFFFFFFFFFFFFF, _p(labels, c_i32_p)))
+    return labels
+
+
+def leiden(indptr, indices, weights, gamma: float, seed: int):
+    """Pre-sweeps (part A) followed by sequential Leiden (part B') on the host.  Returns labels int32[n]."""
+    return _leiden_call("ddx_leiden", indptr, indices, weights, gamma, seed)
+
+
+def leiden_sequential(indptr, indices, weights, gamma: float, seed: int):
+    """Part B' of the specification only (Leiden on the given graph).  Returns labels int32[n]."""
+    return _leiden_call("ddx_leiden_sequential", indptr, indices, weights, gamma, seed)
 
 
 def presweep(indptr, indices, weights, gamma: float, sweeps: int = PRESWEEPS):

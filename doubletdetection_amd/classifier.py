@@ -304,7 +304,7 @@ class BoostClassifier:
             raise TypeError(f"unsupported clustering_kwargs for {self.clustering_algorithm}: {sorted(unknown)}")
 
     def _cluster_plan(self):
-        """(k, include_self, graph_mode, gamma, seed, min_cluster_size) for the chosen algorithm."""
+        """(k, include_self, graph_mode, gamma, seed, min_cluster_size, leiden) for the chosen algorithm."""
         kw = self.clustering_kwargs
         if self.clustering_algorithm == "phenograph":
             if kw.get("directed", False) or not kw.get("jaccard", True):
@@ -314,16 +314,16 @@ class BoostClassifier:
             seed = kw.get("seed")
             seed = self.random_state if seed is None else seed
             return (int(kw.get("k", 30)), False, 0 if kw.get("prune") else 1,
-                    float(kw.get("resolution_parameter", 1.0)), int(seed), int(kw.get("min_cluster_size", 10)))
+                    float(kw.get("resolution_parameter", 1.0)), int(seed), int(kw.get("min_cluster_size", 10)), False)
         if kw.get("directed", False):
             raise NotImplementedError("directed=True neighbour graphs are not implemented")
         # sc.tl.louvain ignores the edge weights (use_weights=False); sc.tl.leiden runs on the umap connectivities
         mode = 3 if self.clustering_algorithm == "leiden" else 2
-        return 10, True, mode, float(kw["resolution"]), int(self.random_state), None
+        return 10, True, mode, float(kw["resolution"]), int(self.random_state), None, self.clustering_algorithm == "leiden"
 
     @staticmethod
-    def _cluster_and_score(graph, gamma, seed, min_cluster_size, num_cells):
-        """Host C++: Louvain -> size-sorted labels -> per-community hypergeometric test."""
+    def _cluster_and_score(graph, gamma, seed, min_cluster_size, num_cells, leiden=False):
+        """Host C++: Louvain (or Leiden) -> size-sorted labels -> per-community hypergeometric test."""
         import time
 
         t0 = time.perf_counter()
@@ -331,7 +331,12 @@ class BoostClassifier:
         t1 = time.perf_counter()
         if len(graph) == 4:                   # pre-sweeps already done on the device: finish on the coarse graph
             member, indptr, indices, weights = graph
-            labels = _lib.louvain_sequential(indptr, indices, weights, gamma, seed)[0][member]
+            if leiden:
+                labels = _lib.leiden_sequential(indptr, indices, weights, gamma, seed)[member]
+            else:
+                labels = _lib.louvain_sequential(indptr, indices, weights, gamma, seed)[0][member]
+        elif leiden:
+            labels = _lib.leiden(*graph, gamma, seed)
         else:
             labels, _ = _lib.louvain(*graph, gamma, seed)
         t2 = time.perf_counter()
@@ -460,7 +465,7 @@ class BoostClassifier:
         else:
             q0 = None      # exact regime: no random start (engine builds and diagonalises the Gram matrix)
 
-        knn_k, include_self, graph_mode, gamma, seed, min_cluster_size = self._cluster_plan()
+        knn_k, include_self, graph_mode, gamma, seed, min_cluster_size, leiden = self._cluster_plan()
 
         mine = [i for i in range(n_iters) if i % world == rank]
         workers = self.n_jobs if self.n_jobs and self.n_jobs > 0 else (os.cpu_count() or 1)
@@ -475,7 +480,7 @@ class BoostClassifier:
                 graph = engine.run_iteration(all_parents[i], self.pseudocount, self.standard_scaling, n_comp,
                                              q0, knn_k, include_self, graph_mode, gamma)
                 host["device_stages"] += time.perf_counter() - t0
-                pending[i] = pool.submit(self._cluster_and_score, graph, gamma, seed, min_cluster_size, num_cells)
+                pending[i] = pool.submit(self._cluster_and_score, graph, gamma, seed, min_cluster_size, num_cells, leiden)
             t0 = time.perf_counter()
             for i, fut in pending.items():
                 full, scores, logp, (tg, tl, ts) = fut.result()

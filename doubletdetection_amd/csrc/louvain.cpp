@@ -364,6 +364,239 @@ void sequential_levels(Graph& g, double gamma, uint64_t seed, std::vector<int32_
     if (q_out) *q_out = q;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Part B' of the specification (oracle/louvain_ref.py:_leiden_sequential): Leiden (Traag, Waltman, van Eck 2019)
+// with the refinement's randomised merge taken at theta -> 0.  Stands in for leidenalg, which the reference reaches
+// through sc.tl.leiden (dd.py:329,337-342).
+// ------------------------------------------------------------------------------------------------
+constexpr int kLeidenMaxIterations = 16;
+
+void degrees(const Graph& g, std::vector<double>& deg, std::vector<double>& loops, double& m2) {
+    const int64_t n = g.n();
+    deg.assign(n, 0.0);
+    loops.assign(n, 0.0);
+    for (int64_t v = 0; v < n; ++v) {
+        double s = 0.0;
+        for (int64_t e = g.indptr[v]; e < g.indptr[v + 1]; ++e) {
+            s += g.weights[e];
+            if (g.indices[e] == v) loops[v] += g.weights[e];
+        }
+        deg[v] = s;
+    }
+    m2 = 0.0;
+    for (int64_t v = 0; v < n; ++v) m2 += deg[v];
+}
+
+// local moving from the partition in comm (ids < n), with the option of leaving for an empty community
+bool leiden_move(const Graph& g, double gamma, SplitMix64& rng, std::vector<int32_t>& comm) {
+    const int64_t n = g.n();
+    std::vector<double> deg, loops;
+    double m2;
+    degrees(g, deg, loops, m2);
+    if (m2 == 0.0) return false;
+    std::vector<double> tot(n, 0.0), in_(n, 0.0);
+    std::vector<int32_t> size(n, 0);
+    for (int64_t v = 0; v < n; ++v) {
+        tot[comm[v]] += deg[v];
+        size[comm[v]]++;
+    }
+    for (int64_t v = 0; v < n; ++v)
+        for (int64_t e = g.indptr[v]; e < g.indptr[v + 1]; ++e)
+            if (comm[g.indices[e]] == comm[v]) in_[comm[v]] += g.weights[e];
+    std::vector<int32_t> empty;
+    for (int64_t c = n - 1; c >= 0; --c)
+        if (size[c] == 0) empty.push_back((int32_t)c);
+    const int64_t start = (int64_t)(rng.next() % (uint64_t)n);
+    std::vector<double> neigh_w(n, -1.0);
+    std::vector<int32_t> seen;
+    seen.reserve(256);
+    auto quality = [&]() {
+        double q = 0.0;
+        for (int64_t c = 0; c < n; ++c)
+            if (tot[c] > 0.0) {
+                const double b = tot[c] / m2;
+                q += in_[c] / m2 - gamma * b * b;
+            }
+        return q;
+    };
+    bool improved = false;
+    double new_q = quality();
+    std::vector<char> active(n, 1), next_active(n, 0);
+    while (true) {
+        const double cur_q = new_q;
+        int64_t moves = 0;
+        std::fill(next_active.begin(), next_active.end(), 0);
+        for (int64_t oi = 0; oi < n; ++oi) {
+            const int32_t v = (int32_t)((start + oi) % n);
+            if (!active[v]) continue;
+            const int32_t c_old = comm[v];
+            const double kv = deg[v];
+            seen.clear();
+            seen.push_back(c_old);
+            neigh_w[c_old] = 0.0;
+            for (int64_t e = g.indptr[v]; e < g.indptr[v + 1]; ++e) {
+                const int32_t u = g.indices[e];
+                if (u == v) continue;
+                const int32_t c = comm[u];
+                if (neigh_w[c] == -1.0) {
+                    neigh_w[c] = 0.0;
+                    seen.push_back(c);
+                }
+                neigh_w[c] += g.weights[e];
+            }
+            tot[c_old] -= kv;
+            in_[c_old] -= 2.0 * neigh_w[c_old] + loops[v];
+            size[c_old]--;
+            int32_t best = c_old;
+            double best_gain = neigh_w[c_old] - gamma * tot[c_old] * kv / m2;
+            for (size_t t = 1; t < seen.size(); ++t) {
+                const int32_t c = seen[t];
+                const double gn = neigh_w[c] - gamma * tot[c] * kv / m2;
+                if (gn > best_gain) {
+                    best_gain = gn;
+                    best = c;
+                }
+            }
+            double w_best = neigh_w[best];
+            if (best_gain < 0.0 && size[c_old] > 0) {
+                best = empty.back();
+                empty.pop_back();
+                w_best = 0.0;
+            }
+            tot[best] += kv;
+            in_[best] += 2.0 * w_best + loops[v];
+            size[best]++;
+            comm[v] = best;
+            if (best != c_old) {
+                ++moves;
+                if (size[c_old] == 0) empty.push_back(c_old);
+                for (int64_t e = g.indptr[v]; e < g.indptr[v + 1]; ++e) {
+                    const int32_t u = g.indices[e];
+                    if (u != v && comm[u] != best) next_active[u] = 1;
+                }
+            }
+            for (int32_t c : seen) neigh_w[c] = -1.0;
+        }
+        new_q = quality();
+        if (moves > 0) improved = true;
+        if (!(moves > 0 && new_q - cur_q > kMinGain)) break;
+        active.swap(next_active);
+    }
+    return improved;
+}
+
+// refinement: merges of single nodes into well-connected groups inside their community
+void leiden_refine(const Graph& g, double gamma, SplitMix64& rng, const std::vector<int32_t>& comm,
+                   std::vector<int32_t>& ref) {
+    const int64_t n = g.n();
+    std::vector<double> deg, loops;
+    double m2;
+    degrees(g, deg, loops, m2);
+    ref.resize(n);
+    for (int64_t v = 0; v < n; ++v) ref[v] = (int32_t)v;
+    if (m2 == 0.0) return;
+    std::vector<double> ktot(n, 0.0), ext(n, 0.0);
+    for (int64_t v = 0; v < n; ++v) ktot[comm[v]] += deg[v];
+    for (int64_t v = 0; v < n; ++v) {
+        double s = 0.0;
+        for (int64_t e = g.indptr[v]; e < g.indptr[v + 1]; ++e) {
+            const int32_t u = g.indices[e];
+            if (u != v && comm[u] == comm[v]) s += g.weights[e];
+        }
+        ext[v] = s;
+    }
+    std::vector<double> rtot(deg), neigh_w(n, -1.0);
+    std::vector<int32_t> rsize(n, 1), seen;
+    const int64_t start = (int64_t)(rng.next() % (uint64_t)n);
+    for (int64_t oi = 0; oi < n; ++oi) {
+        const int32_t v = (int32_t)((start + oi) % n);
+        if (rsize[ref[v]] != 1) continue;
+        const double kc = ktot[comm[v]];
+        const double kv = deg[v];
+        if (!(ext[v] >= gamma * kv * (kc - kv) / m2)) continue;
+        seen.clear();
+        for (int64_t e = g.indptr[v]; e < g.indptr[v + 1]; ++e) {
+            const int32_t u = g.indices[e];
+            if (u == v || comm[u] != comm[v]) continue;
+            const int32_t r = ref[u];
+            if (neigh_w[r] == -1.0) {
+                neigh_w[r] = 0.0;
+                seen.push_back(r);
+            }
+            neigh_w[r] += g.weights[e];
+        }
+        int32_t best = -1;
+        double best_gain = 0.0;
+        for (int32_t r : seen) {
+            if (!(ext[r] >= gamma * rtot[r] * (kc - rtot[r]) / m2)) continue;
+            const double gn = neigh_w[r] - gamma * rtot[r] * kv / m2;
+            if (gn > best_gain) {
+                best_gain = gn;
+                best = r;
+            }
+        }
+        if (best >= 0) {
+            ext[best] = ext[best] + ext[v] - 2.0 * neigh_w[best];
+            rtot[best] += kv;
+            rsize[best]++;
+            rsize[v] = 0;
+            ref[v] = best;
+        }
+        for (int32_t r : seen) neigh_w[r] = -1.0;
+    }
+}
+
+// number of distinct ids in comm (ids < n); renum[c] = rank of c among the used ids, -1 when unused
+int32_t rank_ids(const std::vector<int32_t>& comm, int64_t n, std::vector<int32_t>& renum) {
+    renum.assign(n, -1);
+    for (size_t v = 0; v < comm.size(); ++v) renum[comm[v]] = 0;
+    int32_t k = 0;
+    for (int64_t c = 0; c < n; ++c)
+        if (renum[c] == 0) renum[c] = k++;
+    return k;
+}
+
+void leiden_levels(const Graph& g0, double gamma, uint64_t seed, std::vector<int32_t>& partition) {
+    const int64_t n = g0.n();
+    SplitMix64 rng(seed);
+    partition.resize(n);
+    for (int64_t v = 0; v < n; ++v) partition[v] = (int32_t)v;
+    std::vector<int32_t> node_of(n), comm, ref, renum, cren, init;
+    for (int it = 0; it < kLeidenMaxIterations; ++it) {
+        Graph g = g0;
+        for (int64_t v = 0; v < n; ++v) node_of[v] = (int32_t)v;
+        init = partition;
+        bool any_move = false;
+        while (true) {
+            comm = init;
+            const bool moved = leiden_move(g, gamma, rng, comm);
+            any_move = any_move || moved;
+            const int64_t ng = g.n();
+            if (rank_ids(comm, ng, cren) == ng) {
+                for (int64_t v = 0; v < n; ++v) partition[v] = comm[node_of[v]];
+                break;
+            }
+            leiden_refine(g, gamma, rng, comm, ref);
+            Graph next;
+            aggregate(g, ref, next, renum);
+            const int64_t nn = next.n();
+            init.assign(nn, 0);
+            for (int64_t v = 0; v < ng; ++v) init[renum[ref[v]]] = cren[comm[v]];
+            for (int64_t v = 0; v < n; ++v) node_of[v] = renum[ref[node_of[v]]];
+            g.indptr.swap(next.indptr);
+            g.indices.swap(next.indices);
+            g.weights.swap(next.weights);
+            if (nn == ng) {
+                for (int64_t v = 0; v < n; ++v) partition[v] = init[node_of[v]];
+                break;
+            }
+        }
+        rank_ids(partition, n, renum);
+        for (int64_t v = 0; v < n; ++v) partition[v] = renum[partition[v]];
+        if (!any_move) break;
+    }
+}
+
 int load_graph(int64_t n_nodes, const int64_t* indptr, const int32_t* indices, const double* weights, Graph& g) {
     if (n_nodes < 0 || !indptr) return DDX_E_ARG;
     const int64_t nnz = n_nodes ? indptr[n_nodes] : 0;
@@ -388,6 +621,40 @@ extern "C" int ddx_louvain_sequential(int64_t n_nodes, const int64_t* indptr, co
     std::vector<int32_t> membership;
     sequential_levels(g, gamma, seed, membership, quality_out);
     for (int64_t v = 0; v < n_nodes; ++v) labels_out[v] = membership[v];
+    return DDX_OK;
+}
+
+extern "C" int ddx_leiden_sequential(int64_t n_nodes, const int64_t* indptr, const int32_t* indices, const double* weights,
+                                     double gamma, uint64_t seed, int32_t* labels_out) {
+    if (!labels_out) return DDX_E_ARG;
+    if (n_nodes == 0) return DDX_OK;
+    Graph g;
+    const int rc = load_graph(n_nodes, indptr, indices, weights, g);
+    if (rc != DDX_OK) return rc;
+    std::vector<int32_t> partition;
+    leiden_levels(g, gamma, seed, partition);
+    for (int64_t v = 0; v < n_nodes; ++v) labels_out[v] = partition[v];
+    return DDX_OK;
+}
+
+extern "C" int ddx_leiden(int64_t n_nodes, const int64_t* indptr, const int32_t* indices, const double* weights, double gamma,
+                          uint64_t seed, int32_t* labels_out) {
+    if (!labels_out) return DDX_E_ARG;
+    if (n_nodes == 0) return DDX_OK;
+    Graph g, coarse;
+    const int rc = load_graph(n_nodes, indptr, indices, weights, g);
+    if (rc != DDX_OK) return rc;
+    std::vector<int32_t> total(n_nodes), member, partition;
+    for (int64_t v = 0; v < n_nodes; ++v) total[v] = (int32_t)v;
+    for (int lvl = 0; lvl < DDX_PRESWEEP_LEVELS; ++lvl) {
+        presweep(g, gamma, DDX_PRESWEEPS, member, coarse);
+        for (int64_t v = 0; v < n_nodes; ++v) total[v] = member[total[v]];
+        g.indptr.swap(coarse.indptr);
+        g.indices.swap(coarse.indices);
+        g.weights.swap(coarse.weights);
+    }
+    leiden_levels(g, gamma, seed, partition);
+    for (int64_t v = 0; v < n_nodes; ++v) labels_out[v] = partition[total[v]];
     return DDX_OK;
 }
 

@@ -161,13 +161,20 @@ int ddx_get_graph(ddx_ctx* ctx, int64_t* indptr, int32_t* indices, double* weigh
  *   ddx_presweep           = one level of A on the host;   ddx_louvain_sequential = B on the host;
  *   ddx_coarsen_graph      = `levels` levels of A on the GPU, applied to the graph ddx_build_graph left on the device; the
  *                            result (member of every node + aggregated CSR) is read with ddx_get_coarse_*.
- * A on the GPU followed by ddx_louvain_sequential equals ddx_louvain bit for bit. */
+ * A on the GPU followed by ddx_louvain_sequential equals ddx_louvain bit for bit.
+ *   ddx_leiden_sequential  = part B' (Leiden: local moving, refinement, aggregation on the refined groups, iterated
+ *                            until stable) in place of B -- replaces leidenalg behind sc.tl.leiden (dd.py:329,337-342);
+ *   ddx_leiden             = A + B' on the host. */
 #define DDX_PRESWEEPS 6
 #define DDX_PRESWEEP_LEVELS 2
 int ddx_louvain(int64_t n_nodes, const int64_t* indptr, const int32_t* indices, const double* weights,
                 double gamma, uint64_t seed, int32_t* labels_out /* [n_nodes] */, double* quality_out);
 int ddx_louvain_sequential(int64_t n_nodes, const int64_t* indptr, const int32_t* indices, const double* weights,
                            double gamma, uint64_t seed, int32_t* labels_out /* [n_nodes] */, double* quality_out);
+int ddx_leiden(int64_t n_nodes, const int64_t* indptr, const int32_t* indices, const double* weights, double gamma,
+               uint64_t seed, int32_t* labels_out /* [n_nodes] */);
+int ddx_leiden_sequential(int64_t n_nodes, const int64_t* indptr, const int32_t* indices, const double* weights,
+                          double gamma, uint64_t seed, int32_t* labels_out /* [n_nodes] */);
 int ddx_presweep(int64_t n_nodes, const int64_t* indptr, const int32_t* indices, const double* weights, double gamma,
                  int32_t sweeps, int32_t* member_out /* [n_nodes] */, int64_t* n_coarse_out,
                  int64_t* c_indptr_out /* [n_nodes+1] */, int32_t* c_indices_out /* [nnz] */, double* c_weights_out /* [nnz] */);

@@ -465,10 +465,15 @@ def cluster_embedding(emb: np.ndarray, algorithm: str, clustering_kwargs: dict, 
         lab = louvain_fn(G.indptr, G.indices, G.data, gamma, seed)
         return relabel_by_size(lab, int(kw.get("min_cluster_size", 10)))
     idx, dist = knn_fn(emb, 10, include_self=True)
-    # sc.tl.louvain ignores the weights (use_weights=False), sc.tl.leiden uses the umap connectivities
-    G = umap_connectivities(idx, dist) if algorithm == "leiden" else union_knn_graph(idx)
     gamma = float(kw.get("resolution", 4))
-    lab = louvain_fn(G.indptr, G.indices, G.data, gamma, int(random_state))
+    if algorithm == "leiden":
+        # sc.tl.leiden runs on the umap connectivities (use_weights=True); Leiden specification (part B')
+        G = umap_connectivities(idx, dist)
+        lab = louvain_ref.leiden(G.indptr, G.indices, G.data, gamma, int(random_state))
+    else:
+        # sc.tl.louvain ignores the weights (use_weights=False)
+        G = union_knn_graph(idx)
+        lab = louvain_fn(G.indptr, G.indices, G.data, gamma, int(random_state))
     return relabel_by_size(lab, None)
 
 

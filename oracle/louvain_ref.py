@@ -36,6 +36,23 @@ aggregated exactly (integer sums, renumbered by ascending id).
   community (the pruning of Ozaki et al. 2016 / Traag's fast local move);
 * aggregate communities into super-nodes (self-loop = total internal weight, both directions),
   repeat until a level moves nothing.
+
+**Part B' -- sequential Leiden** (``leiden``; Traag, Waltman, van Eck 2019, "From Louvain to Leiden", Algorithm 1,
+with the randomised merge of its refinement phase taken in the limit theta -> 0, i.e. the best admissible merge,
+which makes the result a function of the seed only).  Used instead of part B for ``clustering_algorithm="leiden"``
+(dd.py:329,337-342 -> sc.tl.leiden -> leidenalg, absent here):
+
+* local moving as in part B, but started from a given partition (singletons on the first level, the unrefined
+  communities afterwards) and with the extra option of leaving for an empty community when every gain is negative
+  (which happens for gamma > 1);
+* refinement inside every community C: every node starts alone; nodes are visited in index order from a seeded
+  offset; a node that is still alone and well connected, E(v, C-v) >= gamma k_v (K_C - k_v) / 2m, joins the
+  well-connected (E(R, C-R) >= gamma K_R (K_C - K_R) / 2m) refined group R of C with the strictly largest positive
+  gain w(v,R) - gamma K_R k_v / 2m (ties: first in adjacency order);
+* aggregate on the *refined* groups, the unrefined communities become the starting partition of the next level;
+  stop when every community is a single node or the refinement merged nothing;
+* repeat the whole procedure from the resulting partition until an iteration moves no node (leidenalg's
+  ``n_iterations=-1``, scanpy's default), at most ``LEIDEN_MAX_ITERATIONS`` times.
 """
 from __future__ import annotations
 
@@ -46,6 +63,7 @@ MIN_GAIN = 1e-6
 PRESWEEPS = 6
 PRESWEEP_LEVELS = 2
 WEIGHT_SCALE = float(1 << 20)
+LEIDEN_MAX_ITERATIONS = 16
 
 
 def presweep(indptr, indices, weights, gamma: float = 1.0, sweeps: int = PRESWEEPS):
@@ -269,6 +287,215 @@ def _louvain_sequential(indptr, indices, weights, gamma: float = 1.0, seed: int 
         if not improved:
             break
     return np.asarray(membership, dtype=np.int64)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Part B': Leiden
+# ----------------------------------------------------------------------------------------------------------------------
+def _degrees(indptr, indices, weights):
+    n = len(indptr) - 1
+    deg = [0.0] * n
+    loops = [0.0] * n
+    for v in range(n):
+        s = 0.0
+        for e in range(indptr[v], indptr[v + 1]):
+            s += weights[e]
+            if indices[e] == v:
+                loops[v] += weights[e]
+        deg[v] = s
+    m2 = 0.0
+    for v in range(n):
+        m2 += deg[v]
+    return deg, loops, m2
+
+
+def _leiden_move(indptr, indices, weights, gamma, rng, init):
+    """Local moving from the partition ``init`` (ids < n).  Returns (comm list, moved_any)."""
+    n = len(indptr) - 1
+    deg, loops, m2 = _degrees(indptr, indices, weights)
+    comm = list(init)
+    if m2 == 0.0:
+        return comm, False
+    tot = [0.0] * n
+    in_ = [0.0] * n
+    size = [0] * n
+    for v in range(n):
+        tot[comm[v]] += deg[v]
+        size[comm[v]] += 1
+    for v in range(n):
+        for e in range(indptr[v], indptr[v + 1]):
+            if comm[indices[e]] == comm[v]:
+                in_[comm[v]] += weights[e]
+    empty = [c for c in range(n - 1, -1, -1) if size[c] == 0]      # pop() gives the smallest empty id first
+    order = _visit_order(n, rng)
+    neigh_w = [-1.0] * n
+    improved = False
+    new_q = _quality(in_, tot, m2, gamma)
+    active = [True] * n
+    while True:
+        cur_q = new_q
+        moves = 0
+        next_active = [False] * n
+        for v in order:
+            if not active[v]:
+                continue
+            c_old = comm[v]
+            kv = deg[v]
+            seen = [c_old]
+            neigh_w[c_old] = 0.0
+            for e in range(indptr[v], indptr[v + 1]):
+                u = indices[e]
+                if u == v:
+                    continue
+                c = comm[u]
+                if neigh_w[c] == -1.0:
+                    neigh_w[c] = 0.0
+                    seen.append(c)
+                neigh_w[c] += weights[e]
+            tot[c_old] -= kv
+            in_[c_old] -= 2.0 * neigh_w[c_old] + loops[v]
+            size[c_old] -= 1
+            best = c_old
+            best_gain = neigh_w[c_old] - gamma * tot[c_old] * kv / m2
+            for c in seen[1:]:
+                g = neigh_w[c] - gamma * tot[c] * kv / m2
+                if g > best_gain:
+                    best_gain = g
+                    best = c
+            w_best = neigh_w[best]
+            if best_gain < 0.0 and size[c_old] > 0:
+                best = empty.pop()                                 # alone is better than any neighbour
+                w_best = 0.0
+            tot[best] += kv
+            in_[best] += 2.0 * w_best + loops[v]
+            size[best] += 1
+            comm[v] = best
+            if best != c_old:
+                moves += 1
+                if size[c_old] == 0:
+                    empty.append(c_old)
+                for e in range(indptr[v], indptr[v + 1]):
+                    u = indices[e]
+                    if u != v and comm[u] != best:
+                        next_active[u] = True
+            for c in seen:
+                neigh_w[c] = -1.0
+        new_q = _quality(in_, tot, m2, gamma)
+        if moves > 0:
+            improved = True
+        if not (moves > 0 and new_q - cur_q > MIN_GAIN):
+            break
+        active = next_active
+    return comm, improved
+
+
+def _leiden_refine(indptr, indices, weights, gamma, rng, comm):
+    """Refined partition (list, ids = a member's index) of the partition ``comm``."""
+    n = len(indptr) - 1
+    deg, _, m2 = _degrees(indptr, indices, weights)
+    ref = list(range(n))
+    if m2 == 0.0:
+        return ref
+    ktot = [0.0] * n                     # K_C of the unrefined communities
+    for v in range(n):
+        ktot[comm[v]] += deg[v]
+    ext = [0.0] * n                      # E(R, C - R) per refined group (initially per node)
+    for v in range(n):
+        s = 0.0
+        for e in range(indptr[v], indptr[v + 1]):
+            u = indices[e]
+            if u != v and comm[u] == comm[v]:
+                s += weights[e]
+        ext[v] = s
+    rtot = deg[:]
+    rsize = [1] * n
+    neigh_w = [-1.0] * n
+    for v in _visit_order(n, rng):
+        if rsize[ref[v]] != 1:
+            continue
+        kc = ktot[comm[v]]
+        kv = deg[v]
+        if not (ext[v] >= gamma * kv * (kc - kv) / m2):
+            continue
+        seen = []
+        for e in range(indptr[v], indptr[v + 1]):
+            u = indices[e]
+            if u == v or comm[u] != comm[v]:
+                continue
+            r = ref[u]
+            if neigh_w[r] == -1.0:
+                neigh_w[r] = 0.0
+                seen.append(r)
+            neigh_w[r] += weights[e]
+        best = -1
+        best_gain = 0.0
+        for r in seen:
+            if not (ext[r] >= gamma * rtot[r] * (kc - rtot[r]) / m2):
+                continue
+            g = neigh_w[r] - gamma * rtot[r] * kv / m2
+            if g > best_gain:
+                best_gain = g
+                best = r
+        if best >= 0:
+            ext[best] = ext[best] + ext[v] - 2.0 * neigh_w[best]
+            rtot[best] += kv
+            rsize[best] += 1
+            rsize[v] = 0
+            ref[v] = best
+        for r in seen:
+            neigh_w[r] = -1.0
+    return ref
+
+
+def _leiden_sequential(indptr, indices, weights, gamma: float = 1.0, seed: int = 0) -> np.ndarray:
+    """Part B'."""
+    indptr0 = [int(x) for x in np.asarray(indptr)]
+    indices0 = [int(x) for x in np.asarray(indices)]
+    weights0 = [float(x) for x in np.asarray(weights, dtype=np.float64)]
+    n = len(indptr0) - 1
+    rng = SplitMix64(seed)
+    gamma = float(gamma)
+    partition = list(range(n))                     # community of every original node
+    for _ in range(LEIDEN_MAX_ITERATIONS):
+        g_indptr, g_indices, g_weights = indptr0, indices0, weights0
+        node_of = list(range(n))                   # aggregate node of every original node
+        init = partition[:]
+        any_move = False
+        while True:
+            comm, moved = _leiden_move(g_indptr, g_indices, g_weights, gamma, rng, init)
+            any_move = any_move or moved
+            ng = len(g_indptr) - 1
+            if len(set(comm)) == ng:
+                partition = [comm[node_of[v]] for v in range(n)]
+                break
+            ref = _leiden_refine(g_indptr, g_indices, g_weights, gamma, rng, comm)
+            g_indptr, g_indices, g_weights, renum = _aggregate(g_indptr, g_indices, g_weights, ref)
+            # unrefined communities, renumbered by ascending id, become the next level's starting partition
+            cren = {c: i for i, c in enumerate(sorted(set(comm)))}
+            init = [0] * len(renum)
+            for v in range(ng):
+                init[renum[ref[v]]] = cren[comm[v]]
+            node_of = [renum[ref[node_of[v]]] for v in range(n)]
+            if len(renum) == ng:                   # refinement merged nothing: the partition is final
+                partition = [init[node_of[v]] for v in range(n)]
+                break
+        # ids < n for the next iteration: renumber by ascending id
+        pren = {c: i for i, c in enumerate(sorted(set(partition)))}
+        partition = [pren[c] for c in partition]
+        if not any_move:
+            break
+    return np.asarray(partition, dtype=np.int64)
+
+
+def leiden(indptr, indices, weights, gamma: float = 1.0, seed: int = 0, presweeps: int = PRESWEEPS,
+           levels: int = PRESWEEP_LEVELS) -> np.ndarray:
+    """Part A, then part B' on the aggregated graph."""
+    member = None
+    for _ in range(levels if presweeps > 0 else 0):
+        m, indptr, indices, weights = presweep(indptr, indices, weights, gamma, presweeps)
+        member = m if member is None else m[member]
+    lab = _leiden_sequential(indptr, indices, weights, gamma, seed)
+    return lab if member is None else lab[member]
 
 
 def modularity(indptr, indices, weights, labels, gamma: float = 1.0) -> float:

@@ -69,6 +69,56 @@ def test_louvain_matches_python_specification_bit_for_bit(n, k, seed, weighted, 
     assert len(np.unique(got)) < n
 
 
+@pytest.mark.parametrize("n,k,seed,weighted,gamma", [
+    (60, 4, 1, False, 1.0), (300, 6, 2, True, 1.0), (300, 6, 3, False, 4.0), (800, 8, 4, True, 4.0),
+    (800, 5, 123, False, 4.0), (50, 3, 5, True, 0.5), (1500, 10, 8, True, 2.0)])
+def test_leiden_matches_python_specification_bit_for_bit(n, k, seed, weighted, gamma):
+    """Part B' (Leiden: local moving with the empty-community option, refinement, aggregation on the refined groups,
+    iterated until stable) on its own and behind the pre-sweeps; and the property Leiden exists for: every community
+    is connected (on the graph part B' ran on)."""
+    from scipy.sparse.csgraph import connected_components
+
+    A = _random_graph(n, k, seed, weighted)
+    ref = louvain_ref._leiden_sequential(A.indptr, A.indices, A.data, gamma, seed)
+    got = _lib.leiden_sequential(A.indptr, A.indices, A.data, gamma, seed)
+    np.testing.assert_array_equal(got.astype(np.int64), ref)
+    assert 1 < len(np.unique(got)) < n
+    for c in np.unique(got):
+        idx = np.flatnonzero(got == c)
+        assert connected_components(A[idx][:, idx], directed=False)[0] == 1
+    # not worse than the Louvain levels on the same graph (refinement only adds ways out of a local optimum)
+    q_leiden = louvain_ref.modularity(A.indptr, A.indices, A.data, got, gamma)
+    q_louvain = louvain_ref.modularity(A.indptr, A.indices, A.data,
+                                       _lib.louvain_sequential(A.indptr, A.indices, A.data, gamma, seed)[0], gamma)
+    assert q_leiden > q_louvain - 0.01
+    # whole = pre-sweeps, then part B' on the aggregated graph
+    whole = _lib.leiden(A.indptr, A.indices, A.data, gamma, seed)
+    np.testing.assert_array_equal(whole.astype(np.int64), louvain_ref.leiden(A.indptr, A.indices, A.data, gamma, seed))
+    total, g = None, (A.indptr, A.indices, A.data)
+    for _ in range(_lib.PRESWEEP_LEVELS):
+        mm, *g = _lib.presweep(*g, gamma)
+        total = mm if total is None else mm[total]
+    np.testing.assert_array_equal(whole, _lib.leiden_sequential(*g, gamma, seed)[total])
+
+
+def test_leiden_degenerate_graphs():
+    """No edges, a single node, isolated nodes beside a clique."""
+    lab = _lib.leiden_sequential(np.zeros(6, dtype=np.int64), np.zeros(0, dtype=np.int32), np.zeros(0), 1.0, 0)
+    np.testing.assert_array_equal(lab, np.arange(5))
+    lab = _lib.leiden(np.zeros(2, dtype=np.int64), np.zeros(0, dtype=np.int32), np.zeros(0), 1.0, 0)
+    np.testing.assert_array_equal(lab, [0])
+    A = sp.lil_matrix((7, 7))
+    for i in range(4):
+        for j in range(4):
+            if i != j:
+                A[i + 2, j + 2] = 1.0
+    A = A.tocsr()
+    for fn, rf in ((_lib.leiden_sequential, louvain_ref._leiden_sequential), (_lib.leiden, louvain_ref.leiden)):
+        lab = fn(A.indptr, A.indices, A.data, 1.0, 3)
+        np.testing.assert_array_equal(lab.astype(np.int64), rf(A.indptr, A.indices, A.data, 1.0, 3))
+        assert len(set(lab[2:6])) == 1 and len(set(lab)) == 4
+
+
 @pytest.mark.parametrize("n,k,seed,weighted,gamma", [(300, 6, 2, True, 1.0), (800, 5, 123, False, 4.0), (2000, 10, 9, True, 1.0)])
 def test_presweep_and_sequential_parts_match_specification(n, k, seed, weighted, gamma):
     """Part A (synchronous sweeps + exact aggregation) and part B (sequential levels) separately, and A o B = whole."""
