@@ -173,7 +173,7 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f64",
+            "dtype": "f32 products, f64 sums",
             "data": "synthetic",
             "config": {"workload": f"synthetic {N}x{G} counts, {X.nnz / (N * G):.3%} nnz, n_iters={args.iters}, "
                                    f"n_top_var_genes=10000, n_components=30, boost_rate=0.25, "

@@ -5,7 +5,8 @@
 // is never formed: every product A Q / A^T Y is one pass over the stored entries (8 bytes each); the L-wide rows
 // of the small operand are fetched from a float32 copy of it staged slice by slice in LDS (k_spmm_lds, the
 // default), or gathered from L2 by the first-generation kernels (k_spmm_rows / k_spmm_cols: float64 mode,
-// ddx_operator_apply, sketch widths > 42, DDX_SPMM=gather).  Products and sums are float64 throughout.
+// ddx_operator_apply, sketch widths > 42, DDX_SPMM=gather).  Sums are float64 throughout; products are float64 in the
+// gather kernels and, in the LDS kernels, float32 within a trip of eight entries (DDX_SPMM_TRIP=f64: float64).
 //
 // Steps (sklearn/utils/extmath.py:287-372,531-607; sklearn/decomposition/_pca.py:731-766):
 //   Q0 (host-drawn, seeded) -> n_iter x { Q <- orth(A Q) ; Q <- orth(A^T Q) } -> Q <- qr(A Q)
@@ -221,9 +222,11 @@ __global__ void __launch_bounds__(256) k_spmm_cols(const int64_t* __restrict__ c
 //
 // Pipeline.  The stored entries of the SLOTS current segments are fetched 64 per segment and round, one round
 // ahead (global-load latency hides behind the previous round's arithmetic), converted once to
-// (LDS byte address of the operand row, float64 value x - z) in the wave's staging area -- padded with zeros to
-// a full round so the step loop needs no bounds logic -- and then consumed four steps at a time with the
-// LDS reads of the next four steps issued before the multiply-adds of the current ones.  All orders are fixed.
+// (LDS byte address of the operand row, value x - z) in the wave's staging area -- padded with zeros to
+// a full round so the step loop needs no bounds logic -- and then consumed a trip of eight steps at a time: the
+// eight operand reads are issued together, the eight products of a lane's two columns are formed and summed in
+// float32 with v_pk_fma_f32 (two chains of four), and the trip's sum is added to the float64 accumulator.
+// All orders are fixed.
 // ------------------------------------------------------------------------------------------------
 constexpr int kLdsOwnG = 6;        // outputs owned by one lane group
 constexpr int kLdsWaves = 16;      // waves per workgroup
@@ -283,21 +286,55 @@ __device__ __forceinline__ LdsFetch<SLOTS> lds_fetch(const int32_t* __restrict__
 }
 
 // one round: stage the fetched entries, then `nsteps` lock-step steps (rounded up to a multiple of 4 <= 64)
-template <bool ROWS, int SLOTS>
+// PK: the eight products of a trip are formed and added in float32, two sketch columns per instruction
+// (v_pk_fma_f32, two chains of four), and the trip's sum is added to the float64 accumulator.
+template <bool ROWS, int SLOTS, bool PK>
 __device__ __forceinline__ void lds_round(const LdsFetch<SLOTS>& f, const int (&nvalid)[SLOTS], int nsteps, int32_t base, const double (&zc)[SLOTS],
                                           const unsigned char* opB, const float* zS, int ld, double* dS, uint32_t* offS, int lane,
                                           const double* myd, const uint32_t* myoff, double (&acc)[2]) {
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
 #pragma unroll
     for (int g = 0; g < SLOTS; ++g) {
         const bool ok = lane < nvalid[g];
         const int i = ok ? f.i[g] - base : 0;
         const double z = ROWS ? (double)zS[i] : zc[g];
-        dS[g * kLdsDStride + lane] = ok ? (double)f.x[g] - z : 0.0;
+        const double d = ok ? (double)f.x[g] - z : 0.0;
+        if (PK) reinterpret_cast<float*>(dS + g * kLdsDStride)[lane] = (float)d;
+        else dS[g * kLdsDStride + lane] = d;
         offS[g * kLdsOStride + lane] = (uint32_t)(i * ld) * 4u;
     }
     wave_lds_sync();
+    if (PK) {
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const float* myf = reinterpret_cast<const float*>(myd);
+        for (int t0 = 0; t0 < nsteps; t0 += 8) {
+            f4v fv[2];
+            u4 ov[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) fv[u] = *reinterpret_cast<const f4v*>(myf + t0 + 4 * u);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) ov[u] = *reinterpret_cast<const u4*>(myoff + t0 + 4 * u);
+            f2 q[8];
+            q[0] = *reinterpret_cast<const f2*>(opB + ov[0].x); q[1] = *reinterpret_cast<const f2*>(opB + ov[0].y);
+            q[2] = *reinterpret_cast<const f2*>(opB + ov[0].z); q[3] = *reinterpret_cast<const f2*>(opB + ov[0].w);
+            q[4] = *reinterpret_cast<const f2*>(opB + ov[1].x); q[5] = *reinterpret_cast<const f2*>(opB + ov[1].y);
+            q[6] = *reinterpret_cast<const f2*>(opB + ov[1].z); q[7] = *reinterpret_cast<const f2*>(opB + ov[1].w);
+            f2 p0 = q[0] * (f2){fv[0].x, fv[0].x};
+            f2 p1 = q[1] * (f2){fv[0].y, fv[0].y};
+            p0 = __builtin_elementwise_fma(q[2], (f2){fv[0].z, fv[0].z}, p0);
+            p1 = __builtin_elementwise_fma(q[3], (f2){fv[0].w, fv[0].w}, p1);
+            p0 = __builtin_elementwise_fma(q[4], (f2){fv[1].x, fv[1].x}, p0);
+            p1 = __builtin_elementwise_fma(q[5], (f2){fv[1].y, fv[1].y}, p1);
+            p0 = __builtin_elementwise_fma(q[6], (f2){fv[1].z, fv[1].z}, p0);
+            p1 = __builtin_elementwise_fma(q[7], (f2){fv[1].w, fv[1].w}, p1);
+            p0 = p0 + p1;
+            acc[0] += (double)p0.x;
+            acc[1] += (double)p0.y;
+        }
+        wave_lds_sync();
+        return;
+    }
     typedef double d2 __attribute__((ext_vector_type(2)));
-    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
     for (int t0 = 0; t0 < nsteps; t0 += 8) {          // the staged round is zero-padded to 64 entries
         d2 dv[4];
         u4 ov[2];
@@ -319,7 +356,7 @@ __device__ __forceinline__ void lds_round(const LdsFetch<SLOTS>& f, const int (&
     wave_lds_sync();
 }
 
-template <bool ROWS, int SLOTS>
+template <bool ROWS, int SLOTS, bool PK>
 __global__ void __launch_bounds__(1024) k_spmm_lds(const LdsSpmmArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     float* opS = reinterpret_cast<float*>(smem);
@@ -438,7 +475,7 @@ __global__ void __launch_bounds__(1024) k_spmm_lds(const LdsSpmmArgs a) {
                         int nvalid[SLOTS];
 #pragma unroll
                         for (int g = 0; g < SLOTS; ++g) nvalid[g] = (h[g] - l[g]) - r * kLdsChunk;
-                        lds_round<ROWS, SLOTS>(cur, nvalid, nsteps, (int32_t)r0, zc, opB, zS, a.ld, dS, offS, lane, myd, myoff, acc[k]);
+                        lds_round<ROWS, SLOTS, PK>(cur, nvalid, nsteps, (int32_t)r0, zc, opB, zS, a.ld, dS, offS, lane, myd, myoff, acc[k]);
                     }
                     cur = nxt;
                     if (!more) break;
@@ -775,20 +812,30 @@ static int lds_owners(int64_t nOut, int slots) {
     return (int)(need <= 256 ? need : 256 * ceil_div(need, 256));     // whole rounds of one workgroup per CU
 }
 
-template <bool ROWS, int SLOTS>
+template <bool ROWS, int SLOTS, bool PK>
 static int launch_lds_t(ddx_ctx* c, const LdsSpmmArgs& a, unsigned grid, size_t lds_bytes) {
     static bool configured = false;
     if (!configured) {
-        DDX_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmm_lds<ROWS, SLOTS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+        DDX_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmm_lds<ROWS, SLOTS, PK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
         configured = true;
     }
-    k_spmm_lds<ROWS, SLOTS><<<grid, 1024, lds_bytes, c->stream>>>(a);
+    k_spmm_lds<ROWS, SLOTS, PK><<<grid, 1024, lds_bytes, c->stream>>>(a);
     return DDX_OK;
+}
+
+// Default: the eight products of a trip in packed float32, trip sums added in float64 (profiles/tools/spmm_precision.py:
+// 7e-7 per component against the all-float64 run at 50k x 20k, 4e-7 with float64 products; 0.69 instead of 0.84 ms).
+// DDX_SPMM_TRIP=f64 selects float64 products.
+static bool lds_packed() {
+    static const bool v = [] { const char* e = std::getenv("DDX_SPMM_TRIP"); return !(e && std::strcmp(e, "f64") == 0); }();
+    return v;
 }
 
 template <bool ROWS>
 static int launch_lds(ddx_ctx* c, const LdsSpmmArgs& a, int slots, unsigned grid, size_t lds_bytes) {
-    return slots == 4 ? launch_lds_t<ROWS, 4>(c, a, grid, lds_bytes) : launch_lds_t<ROWS, 3>(c, a, grid, lds_bytes);
+    if (lds_packed())
+        return slots == 4 ? launch_lds_t<ROWS, 4, true>(c, a, grid, lds_bytes) : launch_lds_t<ROWS, 3, true>(c, a, grid, lds_bytes);
+    return slots == 4 ? launch_lds_t<ROWS, 4, false>(c, a, grid, lds_bytes) : launch_lds_t<ROWS, 3, false>(c, a, grid, lds_bytes);
 }
 
 static int apply_rows(PcaWork& w, const double* Qcol, double* Yrow) {  // A Q : [H x L] -> [M x L]
