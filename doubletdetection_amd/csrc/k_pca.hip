@@ -695,6 +695,59 @@ __global__ void __launch_bounds__(64) k_chol_inv(const double* __restrict__ G, i
     for (int t = lane; t < L * L; t += 64) Rinv[t] = inv[t];
 }
 
+// The same factorisation and inverse with the matrix in registers (sketch width LT known at compile time, one
+// column per lane, everything unrolled): entries of other columns arrive through v_readlane instead of LDS round
+// trips, which bound the kernel above (68 us at L = 40 against ~25 us here).
+__device__ __forceinline__ double lane_value(double v, int j) {
+    const int64_t b = __builtin_bit_cast(int64_t, v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)b, j);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(b >> 32), j);
+    return __builtin_bit_cast(double, ((int64_t)hi << 32) | (int64_t)lo);
+}
+
+template <int LT>
+__global__ void __launch_bounds__(64) k_chol_inv_reg(const double* __restrict__ G, double* __restrict__ Rinv, int* __restrict__ flag) {
+    const int lane = threadIdx.x;
+    const int col = lane < LT ? lane : LT - 1;          // idle lanes shadow the last column
+    double a[LT];
+#pragma unroll
+    for (int i = 0; i < LT; ++i) a[i] = G[i * LT + col];
+    double maxd = 0.0;
+#pragma unroll
+    for (int k = 0; k < LT; ++k) maxd = fmax(maxd, lane_value(a[k], k));
+    const double floor_v = maxd * 1e-26 + 1e-300;
+#pragma unroll
+    for (int k = 0; k < LT; ++k) {
+        double d = lane_value(a[k], k);
+        if (!(d > floor_v)) {
+            d = floor_v;
+            if (lane == 0) atomicOr(flag, 1);
+        }
+        const double piv = sqrt(d);
+        const double r = a[k] / piv;                     // R[k][lane] for lane > k
+        a[k] = lane == k ? piv : r;
+#pragma unroll
+        for (int i = k + 1; i < LT; ++i) a[i] -= lane_value(r, i) * r;     // meaningful for lane >= i
+    }
+    // column `lane` of the inverse of the upper-triangular factor, bottom up
+    double x[LT];
+#pragma unroll
+    for (int i = LT - 1; i >= 0; --i) {
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int p = i + 1; p < LT; ++p) {
+            const double rip = lane_value(a[i], p);      // R[i][p]
+            if ((p - i) & 1) s0 += rip * x[p]; else s1 += rip * x[p];      // x[p] = 0 beyond the diagonal
+        }
+        const double rii = lane_value(a[i], i);
+        x[i] = i == lane ? 1.0 / rii : (i < lane ? -(s0 + s1) / rii : 0.0);
+    }
+    if (lane < LT) {
+#pragma unroll
+        for (int i = 0; i < LT; ++i) Rinv[i * LT + lane] = x[i];
+    }
+}
+
 // out[R x L2] = X[R x L] * T[L x L2]   (64 rows per block, X tile and T staged in LDS)
 __global__ void __launch_bounds__(256) k_right_mult(const double* __restrict__ X, int64_t R, int L,
                                                     const double* __restrict__ T, int L2, double* __restrict__ out) {
@@ -791,7 +844,8 @@ static int cholqr(PcaWork& w, const double* X, int64_t R, double* out) {
     double* Rinv = w.small + w.L * w.L;
     ScopedTimer t(w.ctx, "pca_orth");
     gram(w, X, R, G);
-    k_chol_inv<<<1, 64, 2 * sizeof(double) * w.L * w.L, w.ctx->stream>>>(G, w.L, Rinv, w.flag);
+    if (w.L == 40) k_chol_inv_reg<40><<<1, 64, 0, w.ctx->stream>>>(G, Rinv, w.flag);      // the default sketch width (30 + 10)
+    else k_chol_inv<<<1, 64, 2 * sizeof(double) * w.L * w.L, w.ctx->stream>>>(G, w.L, Rinv, w.flag);
     k_right_mult<<<(unsigned)ceil_div(R, 64), 256, sizeof(double) * (w.L * w.L + 64 * w.L), w.ctx->stream>>>(X, R, w.L, Rinv, w.L, out);
     return DDX_OK;
 }
