@@ -236,7 +236,9 @@ constexpr int kLdsBudget = 160 * 1024;
 // that the groups' broadcast reads of entry t fall into different banks
 constexpr int kLdsDStride = kLdsChunk + 2;    // doubles
 constexpr int kLdsOStride = kLdsChunk + 4;    // uint32
-constexpr int lds_stage_bytes(int slots) { return kLdsWaves * slots * (kLdsDStride * 8 + kLdsOStride * 4); }
+// (float32 values of the packed trips take kLdsOStride * 4 bytes per group instead of kLdsDStride * 8)
+constexpr int lds_value_bytes(bool pk) { return pk ? kLdsOStride * 4 : kLdsDStride * 8; }
+constexpr int lds_stage_bytes(int slots, bool pk) { return kLdsWaves * slots * (lds_value_bytes(pk) + kLdsOStride * 4); }
 
 struct LdsSpmmArgs {
     const float* op;     // operand, row-major [opRows x ld] float32
@@ -288,94 +290,109 @@ __device__ __forceinline__ LdsFetch<SLOTS> lds_fetch(const int32_t* __restrict__
 // one round: stage the fetched entries, then `nsteps` lock-step steps (rounded up to a multiple of 4 <= 64)
 // PK: the eight products of a trip are formed and added in float32, two sketch columns per instruction
 // (v_pk_fma_f32, two chains of four), and the trip's sum is added to the float64 accumulator.
-template <bool ROWS, int SLOTS, bool PK>
+// CPL: sketch columns per lane (2: ds_read_b64 per entry, 4: ds_read_b128).
+template <bool ROWS, int SLOTS, bool PK, int CPL>
 __device__ __forceinline__ void lds_round(const LdsFetch<SLOTS>& f, const int (&nvalid)[SLOTS], int nsteps, int32_t base, const double (&zc)[SLOTS],
                                           const unsigned char* opB, const float* zS, int ld, double* dS, uint32_t* offS, int lane,
-                                          const double* myd, const uint32_t* myoff, double (&acc)[2]) {
+                                          const double* myd, const uint32_t* myoff, double (&acc)[CPL]) {
     typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    typedef float fq __attribute__((ext_vector_type(CPL)));
 #pragma unroll
     for (int g = 0; g < SLOTS; ++g) {
         const bool ok = lane < nvalid[g];
         const int i = ok ? f.i[g] - base : 0;
         const double z = ROWS ? (double)zS[i] : zc[g];
         const double d = ok ? (double)f.x[g] - z : 0.0;
-        if (PK) reinterpret_cast<float*>(dS + g * kLdsDStride)[lane] = (float)d;
+        if (PK) reinterpret_cast<float*>(dS)[g * kLdsOStride + lane] = (float)d;
         else dS[g * kLdsDStride + lane] = d;
         offS[g * kLdsOStride + lane] = (uint32_t)(i * ld) * 4u;
     }
     wave_lds_sync();
     if (PK) {
-        typedef float f2 __attribute__((ext_vector_type(2)));
         const float* myf = reinterpret_cast<const float*>(myd);
-        for (int t0 = 0; t0 < nsteps; t0 += 8) {
+        for (int t0 = 0; t0 < nsteps; t0 += 8) {          // the staged round is zero-padded to 64 entries
             f4v fv[2];
             u4 ov[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) fv[u] = *reinterpret_cast<const f4v*>(myf + t0 + 4 * u);
 #pragma unroll
             for (int u = 0; u < 2; ++u) ov[u] = *reinterpret_cast<const u4*>(myoff + t0 + 4 * u);
-            f2 q[8];
-            q[0] = *reinterpret_cast<const f2*>(opB + ov[0].x); q[1] = *reinterpret_cast<const f2*>(opB + ov[0].y);
-            q[2] = *reinterpret_cast<const f2*>(opB + ov[0].z); q[3] = *reinterpret_cast<const f2*>(opB + ov[0].w);
-            q[4] = *reinterpret_cast<const f2*>(opB + ov[1].x); q[5] = *reinterpret_cast<const f2*>(opB + ov[1].y);
-            q[6] = *reinterpret_cast<const f2*>(opB + ov[1].z); q[7] = *reinterpret_cast<const f2*>(opB + ov[1].w);
-            f2 p0 = q[0] * (f2){fv[0].x, fv[0].x};
-            f2 p1 = q[1] * (f2){fv[0].y, fv[0].y};
-            p0 = __builtin_elementwise_fma(q[2], (f2){fv[0].z, fv[0].z}, p0);
-            p1 = __builtin_elementwise_fma(q[3], (f2){fv[0].w, fv[0].w}, p1);
-            p0 = __builtin_elementwise_fma(q[4], (f2){fv[1].x, fv[1].x}, p0);
-            p1 = __builtin_elementwise_fma(q[5], (f2){fv[1].y, fv[1].y}, p1);
-            p0 = __builtin_elementwise_fma(q[6], (f2){fv[1].z, fv[1].z}, p0);
-            p1 = __builtin_elementwise_fma(q[7], (f2){fv[1].w, fv[1].w}, p1);
+            fq q[8];
+            q[0] = *reinterpret_cast<const fq*>(opB + ov[0].x); q[1] = *reinterpret_cast<const fq*>(opB + ov[0].y);
+            q[2] = *reinterpret_cast<const fq*>(opB + ov[0].z); q[3] = *reinterpret_cast<const fq*>(opB + ov[0].w);
+            q[4] = *reinterpret_cast<const fq*>(opB + ov[1].x); q[5] = *reinterpret_cast<const fq*>(opB + ov[1].y);
+            q[6] = *reinterpret_cast<const fq*>(opB + ov[1].z); q[7] = *reinterpret_cast<const fq*>(opB + ov[1].w);
+            fq p0 = q[0] * fv[0].x;
+            fq p1 = q[1] * fv[0].y;
+            p0 = __builtin_elementwise_fma(q[2], (fq)(fv[0].z), p0);
+            p1 = __builtin_elementwise_fma(q[3], (fq)(fv[0].w), p1);
+            p0 = __builtin_elementwise_fma(q[4], (fq)(fv[1].x), p0);
+            p1 = __builtin_elementwise_fma(q[5], (fq)(fv[1].y), p1);
+            p0 = __builtin_elementwise_fma(q[6], (fq)(fv[1].z), p0);
+            p1 = __builtin_elementwise_fma(q[7], (fq)(fv[1].w), p1);
             p0 = p0 + p1;
-            acc[0] += (double)p0.x;
-            acc[1] += (double)p0.y;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) acc[c] += (double)p0[c];
         }
         wave_lds_sync();
         return;
     }
     typedef double d2 __attribute__((ext_vector_type(2)));
-    for (int t0 = 0; t0 < nsteps; t0 += 8) {          // the staged round is zero-padded to 64 entries
+    for (int t0 = 0; t0 < nsteps; t0 += 8) {
         d2 dv[4];
         u4 ov[2];
 #pragma unroll
         for (int u = 0; u < 4; ++u) dv[u] = *reinterpret_cast<const d2*>(myd + t0 + 2 * u);
 #pragma unroll
         for (int u = 0; u < 2; ++u) ov[u] = *reinterpret_cast<const u4*>(myoff + t0 + 4 * u);
-        float2 q[8];
-        q[0] = *reinterpret_cast<const float2*>(opB + ov[0].x); q[1] = *reinterpret_cast<const float2*>(opB + ov[0].y);
-        q[2] = *reinterpret_cast<const float2*>(opB + ov[0].z); q[3] = *reinterpret_cast<const float2*>(opB + ov[0].w);
-        q[4] = *reinterpret_cast<const float2*>(opB + ov[1].x); q[5] = *reinterpret_cast<const float2*>(opB + ov[1].y);
-        q[6] = *reinterpret_cast<const float2*>(opB + ov[1].z); q[7] = *reinterpret_cast<const float2*>(opB + ov[1].w);
+        fq q[8];
+        q[0] = *reinterpret_cast<const fq*>(opB + ov[0].x); q[1] = *reinterpret_cast<const fq*>(opB + ov[0].y);
+        q[2] = *reinterpret_cast<const fq*>(opB + ov[0].z); q[3] = *reinterpret_cast<const fq*>(opB + ov[0].w);
+        q[4] = *reinterpret_cast<const fq*>(opB + ov[1].x); q[5] = *reinterpret_cast<const fq*>(opB + ov[1].y);
+        q[6] = *reinterpret_cast<const fq*>(opB + ov[1].z); q[7] = *reinterpret_cast<const fq*>(opB + ov[1].w);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            acc[0] = fma(dv[u].x, (double)q[2 * u].x, acc[0]);     acc[1] = fma(dv[u].x, (double)q[2 * u].y, acc[1]);
-            acc[0] = fma(dv[u].y, (double)q[2 * u + 1].x, acc[0]); acc[1] = fma(dv[u].y, (double)q[2 * u + 1].y, acc[1]);
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) acc[c] = fma(dv[u].x, (double)q[2 * u][c], acc[c]);
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) acc[c] = fma(dv[u].y, (double)q[2 * u + 1][c], acc[c]);
         }
     }
     wave_lds_sync();
 }
 
-template <bool ROWS, int SLOTS, bool PK>
+// CPL = 4 ("quad" geometry): four groups of 16 lanes that coincide with the four lane groups in which the LDS
+// services a ds_read_b128 -- {0-3,12-15,20-27}, {4-11,16-19,28-31} and the same + 32 -- so the lanes served in one
+// LDS cycle all read the same operand row (no bank conflicts) or the same staged entry (broadcast).  A lane holds
+// four adjacent sketch columns; with ld = 40 ten of the 16 lanes of a group work.
+template <bool ROWS, int SLOTS, bool PK, int CPL, int OWN>
 __global__ void __launch_bounds__(1024) k_spmm_lds(const LdsSpmmArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     float* opS = reinterpret_cast<float*>(smem);
     float* zS = opS + (size_t)a.SR * a.ld;
     unsigned char* stg = reinterpret_cast<unsigned char*>(zS + (ROWS ? ((a.SR + 3) & ~3) : 0));   // 16-byte aligned
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    double* dS = reinterpret_cast<double*>(stg + wave * (SLOTS * (kLdsDStride * 8 + kLdsOStride * 4)));
-    uint32_t* offS = reinterpret_cast<uint32_t*>(dS + SLOTS * kLdsDStride);
-    int slot = lane / a.lpn;
-    int sub = lane - slot * a.lpn;
-    const bool active = slot < SLOTS && 2 * sub < a.ld;
+    double* dS = reinterpret_cast<double*>(stg + wave * (SLOTS * (lds_value_bytes(PK) + kLdsOStride * 4)));
+    uint32_t* offS = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(dS) + SLOTS * lds_value_bytes(PK));
+    int slot, sub;
+    if (CPL == 4) {
+        const int h = lane & 31;
+        const bool odd = (h >= 4 && h < 12) || (h >= 16 && h < 20) || h >= 28;
+        slot = (lane >> 5) * 2 + (odd ? 1 : 0);
+        sub = odd ? (h < 12 ? h - 4 : (h < 20 ? h - 8 : h - 16)) : (h < 4 ? h : (h < 16 ? h - 8 : h - 12));
+    } else {
+        slot = lane / a.lpn;
+        sub = lane - slot * a.lpn;
+    }
+    const bool active = slot < SLOTS && CPL * sub < a.ld;
     if (slot >= SLOTS) slot = SLOTS - 1;            // idle lanes shadow the last group (reads only)
-    if (2 * sub >= a.ld) sub = 0;
-    const double* myd = dS + slot * kLdsDStride;
+    if (CPL * sub >= a.ld) sub = 0;
+    const double* myd = reinterpret_cast<const double*>(reinterpret_cast<const unsigned char*>(dS) + slot * lds_value_bytes(PK));
     const uint32_t* myoff = offS + slot * kLdsOStride;
-    const unsigned char* opB = smem + 8 * sub;       // this lane's two sketch columns of operand row 0
+    const unsigned char* opB = smem + 4 * CPL * sub;  // this lane's sketch columns of operand row 0
     const int owner = (int)(blockIdx.x % a.owners);
     const int group = (int)(blockIdx.x / a.owners);
-    constexpr int PERW = SLOTS * kLdsOwnG;          // outputs per wave; local output m = k*SLOTS + g
+    constexpr int PERW = SLOTS * OWN;               // outputs per wave; local output m = k*SLOTS + g
 
     // Local output (k, g) of this wave -> rank in the outputs sorted by their number of stored entries -> output.
     // The SLOTS outputs of a unit are consecutive ranks (near-equal segment lengths, so the lock step wastes
@@ -393,9 +410,11 @@ __global__ void __launch_bounds__(1024) k_spmm_lds(const LdsSpmmArgs a) {
     if (ROWS && mine) rowbase = a.indptr[myout];
     float zmine = 0.0f;                              // COLS: z of the owned column, handed out by readlane
     if (!ROWS && mine) zmine = a.zcol[myout];
-    double acc[kLdsOwnG][2];
+    double acc[OWN][CPL];
 #pragma unroll
-    for (int k = 0; k < kLdsOwnG; ++k) { acc[k][0] = 0.0; acc[k][1] = 0.0; }
+    for (int k = 0; k < OWN; ++k)
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) acc[k][c] = 0.0;
 
     for (int s = group; s < a.nslices; s += a.groups) {
         __syncthreads();
@@ -456,10 +475,10 @@ __global__ void __launch_bounds__(1024) k_spmm_lds(const LdsSpmmArgs a) {
             unit_bounds(0, l, h, maxlen);
             LdsFetch<SLOTS> cur = lds_fetch<SLOTS>(sidx, sx, l, h, 0, lane);
 #pragma unroll
-            for (int k = 0; k < kLdsOwnG; ++k) {
+            for (int k = 0; k < OWN; ++k) {
                 int32_t l2[SLOTS], h2[SLOTS];
                 int maxlen2 = 0;
-                if (k + 1 < kLdsOwnG) unit_bounds(k + 1, l2, h2, maxlen2);
+                if (k + 1 < OWN) unit_bounds(k + 1, l2, h2, maxlen2);
                 double zc[SLOTS];
 #pragma unroll
                 for (int g = 0; g < SLOTS; ++g)
@@ -468,19 +487,19 @@ __global__ void __launch_bounds__(1024) k_spmm_lds(const LdsSpmmArgs a) {
                     const bool more = (r + 1) * kLdsChunk < maxlen;
                     LdsFetch<SLOTS> nxt = cur;
                     if (more) nxt = lds_fetch<SLOTS>(sidx, sx, l, h, r + 1, lane);
-                    else if (k + 1 < kLdsOwnG) nxt = lds_fetch<SLOTS>(sidx, sx, l2, h2, 0, lane);
+                    else if (k + 1 < OWN) nxt = lds_fetch<SLOTS>(sidx, sx, l2, h2, 0, lane);
                     const int left = maxlen - r * kLdsChunk;
                     if (left > 0) {
                         const int nsteps = left < kLdsChunk ? left : kLdsChunk;
                         int nvalid[SLOTS];
 #pragma unroll
                         for (int g = 0; g < SLOTS; ++g) nvalid[g] = (h[g] - l[g]) - r * kLdsChunk;
-                        lds_round<ROWS, SLOTS, PK>(cur, nvalid, nsteps, (int32_t)r0, zc, opB, zS, a.ld, dS, offS, lane, myd, myoff, acc[k]);
+                        lds_round<ROWS, SLOTS, PK, CPL>(cur, nvalid, nsteps, (int32_t)r0, zc, opB, zS, a.ld, dS, offS, lane, myd, myoff, acc[k]);
                     }
                     cur = nxt;
                     if (!more) break;
                 }
-                if (k + 1 < kLdsOwnG) {
+                if (k + 1 < OWN) {
 #pragma unroll
                     for (int g = 0; g < SLOTS; ++g) { l[g] = l2[g]; h[g] = h2[g]; }
                     maxlen = maxlen2;
@@ -490,12 +509,12 @@ __global__ void __launch_bounds__(1024) k_spmm_lds(const LdsSpmmArgs a) {
     }
     // every lane group writes its own outputs
 #pragma unroll
-    for (int k = 0; k < kLdsOwnG; ++k) {
+    for (int k = 0; k < OWN; ++k) {
         const int64_t o = __shfl(myout, k * SLOTS + slot, 64);     // the bounds lane of this group's k-th output knows it
         if (active && o < a.nOut) {
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const int col = 2 * sub + c;
+            for (int c = 0; c < CPL; ++c) {
+                const int col = CPL * sub + c;
                 if (col < a.L) {
                     if (ROWS) a.out[o * a.L + col] = acc[k][c] - a.tvec[col];
                     else a.out[((int64_t)group * a.nOut + o) * a.L + col] = acc[k][c];
@@ -858,22 +877,34 @@ static const T* prepared_operand(PcaWork& w, const double* X, int64_t R, int ld)
     return out;
 }
 
-// lane-group geometry of the LDS kernels for a padded sketch width ld (0 slots: not applicable)
-static int lds_slots(int ld) { return ld <= 32 ? 4 : (ld <= 42 ? 3 : 0); }
-static int lds_lpn(int ld) { return ld <= 32 ? 16 : ld / 2; }
-static int lds_owners(int64_t nOut, int slots) {
-    const int64_t need = ceil_div(nOut, (int64_t)kLdsWaves * slots * kLdsOwnG);
+// lane-group geometry of the LDS kernels for a padded sketch width ld (0 slots: not applicable).
+// "pair": two columns per lane, groups of ld/2 lanes (ld <= 42) or 16 lanes (ld <= 32); "quad": four columns per lane,
+// four groups of 16 lanes, any ld <= 64.  At ld = 40 the two run at the same speed (0.67-0.71 ms; the quad geometry has
+// no bank conflicts and half the staged-entry reads per entry, but neither the LDS nor the VALU is what bounds the
+// kernel), so pair stays the default where it applies and quad serves the wider sketches.  DDX_SPMM_GEOM=pair|quad
+// forces one of them.
+static bool lds_packed();
+static bool lds_quad(int ld) {
+    static const int mode = [] { const char* e = std::getenv("DDX_SPMM_GEOM"); return !e ? 0 : (std::strcmp(e, "pair") == 0 ? 1 : (std::strcmp(e, "quad") == 0 ? 2 : 0)); }();
+    if (!lds_packed() || mode == 1) return false;       // (the float64-product trips keep the pair geometry: twice the staging)
+    return mode == 2 || ld > 42;
+}
+constexpr int kLdsOwnQuad = 4;     // outputs owned by one lane group in the quad geometry (4 x 4 float64 accumulators)
+static int lds_slots(int ld) { return lds_quad(ld) ? (ld <= 64 ? 4 : 0) : (ld <= 32 ? 4 : (ld <= 42 ? 3 : 0)); }
+static int lds_lpn(int ld) { return (lds_quad(ld) || ld <= 32) ? 16 : ld / 2; }
+static int lds_owners(int64_t nOut, int slots, int ld) {
+    const int64_t need = ceil_div(nOut, (int64_t)kLdsWaves * slots * (lds_quad(ld) ? kLdsOwnQuad : kLdsOwnG));
     return (int)(need <= 256 ? need : 256 * ceil_div(need, 256));     // whole rounds of one workgroup per CU
 }
 
-template <bool ROWS, int SLOTS, bool PK>
+template <bool ROWS, int SLOTS, bool PK, int CPL, int OWN>
 static int launch_lds_t(ddx_ctx* c, const LdsSpmmArgs& a, unsigned grid, size_t lds_bytes) {
     static bool configured = false;
     if (!configured) {
-        DDX_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmm_lds<ROWS, SLOTS, PK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+        DDX_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmm_lds<ROWS, SLOTS, PK, CPL, OWN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
         configured = true;
     }
-    k_spmm_lds<ROWS, SLOTS, PK><<<grid, 1024, lds_bytes, c->stream>>>(a);
+    k_spmm_lds<ROWS, SLOTS, PK, CPL, OWN><<<grid, 1024, lds_bytes, c->stream>>>(a);
     return DDX_OK;
 }
 
@@ -887,9 +918,10 @@ static bool lds_packed() {
 
 template <bool ROWS>
 static int launch_lds(ddx_ctx* c, const LdsSpmmArgs& a, int slots, unsigned grid, size_t lds_bytes) {
+    if (lds_quad(a.ld)) return launch_lds_t<ROWS, 4, true, 4, kLdsOwnQuad>(c, a, grid, lds_bytes);
     if (lds_packed())
-        return slots == 4 ? launch_lds_t<ROWS, 4, true>(c, a, grid, lds_bytes) : launch_lds_t<ROWS, 3, true>(c, a, grid, lds_bytes);
-    return slots == 4 ? launch_lds_t<ROWS, 4, false>(c, a, grid, lds_bytes) : launch_lds_t<ROWS, 3, false>(c, a, grid, lds_bytes);
+        return slots == 4 ? launch_lds_t<ROWS, 4, true, 2, kLdsOwnG>(c, a, grid, lds_bytes) : launch_lds_t<ROWS, 3, true, 2, kLdsOwnG>(c, a, grid, lds_bytes);
+    return slots == 4 ? launch_lds_t<ROWS, 4, false, 2, kLdsOwnG>(c, a, grid, lds_bytes) : launch_lds_t<ROWS, 3, false, 2, kLdsOwnG>(c, a, grid, lds_bytes);
 }
 
 static int apply_rows(PcaWork& w, const double* Qcol, double* Yrow) {  // A Q : [H x L] -> [M x L]
@@ -907,11 +939,11 @@ static int apply_rows(PcaWork& w, const double* Qcol, double* Yrow) {  // A Q : 
         const int slots = lds_slots(a.ld);
         a.op = prepared_operand<float>(w, Qcol, w.H, a.ld);
         a.opRows = w.H; a.SR = w.rows_SR; a.nslices = w.rows_ns; a.groups = 1;
-        a.nOut = w.M; a.owners = lds_owners(w.M, slots);
+        a.nOut = w.M; a.owners = lds_owners(w.M, slots, a.ld);
         a.indptr = c->aug_indptr.as<int64_t>(); a.cols = c->aug_indices.as<int32_t>(); a.x = c->aug_x.as<float>();
         a.zcol = c->zcol.as<float>(); a.rowseg = c->rowseg.as<int32_t>(); a.tvec = tvec; a.out = Yrow;
         a.perm = c->rank_rows;
-        const size_t lds_bytes = (size_t)a.SR * a.ld * 4 + (size_t)((a.SR + 3) & ~3) * 4 + lds_stage_bytes(slots);
+        const size_t lds_bytes = (size_t)a.SR * a.ld * 4 + (size_t)((a.SR + 3) & ~3) * 4 + lds_stage_bytes(slots, lds_packed());
         return launch_lds<true>(c, a, slots, (unsigned)a.owners, lds_bytes);
     }
     if (w.gather32) {
@@ -945,7 +977,7 @@ static int apply_cols(PcaWork& w, const double* Yrow, double* Wcol) {  // A^T Y 
         const int slots = lds_slots(a.ld);
         a.op = prepared_operand<float>(w, Yrow, w.M, a.ld);
         a.opRows = w.M; a.SR = c->panel_rows; a.nslices = P;
-        a.nOut = w.H; a.owners = lds_owners(w.H, slots);
+        a.nOut = w.H; a.owners = lds_owners(w.H, slots, a.ld);
         a.groups = std::max(1, std::min(P, 512 / a.owners));
         a.zcol = c->zcol.as<float>();
         a.cp_o = c->csc_o_colptr.as<int64_t>(); a.row_o = c->csc_o_row.as<int32_t>(); a.x_o = c->csc_o_x.as<float>(); a.P_o = c->P_o;
@@ -953,7 +985,7 @@ static int apply_cols(PcaWork& w, const double* Yrow, double* Wcol) {  // A^T Y 
         a.p_s0 = c->p_s0; a.P_s = c->P_s;
         a.out = c->pcaPanel.as<double>();
         a.perm = c->rank_cols;
-        const size_t lds_bytes = (size_t)a.SR * a.ld * 4 + lds_stage_bytes(slots);
+        const size_t lds_bytes = (size_t)a.SR * a.ld * 4 + lds_stage_bytes(slots, lds_packed());
         DDX_TRY(launch_lds<false>(c, a, slots, (unsigned)(a.owners * a.groups), lds_bytes));
         k_sum_panels<<<(unsigned)ceil_div((int64_t)w.H * w.L, 256), 256, 0, c->stream>>>(c->pcaPanel.as<double>(), a.groups, w.H, w.L, c->colmean.as<double>(),
                                                                                           uvec, Wcol);
@@ -986,8 +1018,8 @@ static int lds_setup(ddx_ctx* ctx, int L, PcaWork& w) {
     const int ld = (L + 3) & ~3;
     const int slots = lds_slots(ld);
     if (!slots) return DDX_OK;
-    const bool cols_fit = (size_t)ctx->panel_rows * ld * 4 + lds_stage_bytes(slots) <= (size_t)kLdsBudget;
-    int srmax = ((kLdsBudget - lds_stage_bytes(slots)) / (ld * 4 + 4)) & ~3;
+    const bool cols_fit = (size_t)ctx->panel_rows * ld * 4 + lds_stage_bytes(slots, lds_packed()) <= (size_t)kLdsBudget;
+    int srmax = ((kLdsBudget - lds_stage_bytes(slots, lds_packed())) / (ld * 4 + 4)) & ~3;
     if (srmax > kLdsPanelRows) srmax = kLdsPanelRows & ~3;      // same slice height in both passes
     if (!cols_fit || srmax < 64) return DDX_OK;
     w.lds = true;
