@@ -445,10 +445,10 @@ def test_reference_test_suite_scenario():
 
 
 # ---- API corners on the GPU path ---------------------------------------------------------------------------
-@pytest.mark.parametrize("n_components,algo", [(45, "louvain"), (12, "leiden"), (54, "phenograph")])
+@pytest.mark.parametrize("n_components,algo", [(45, "louvain"), (12, "leiden"), (54, "phenograph"), (50, "louvain")])
 def test_other_sketch_widths_and_leiden(n_components, algo):
     """Sketch widths other than the default 40: > 42 columns take the quad geometry of the LDS-staged products (four
-    columns per lane, up to 64; beyond that the gather kernels), <= 32 the 4-group pair geometry; and the leiden name
+    columns per lane, up to the limit of 64), <= 32 the 4-group pair geometry; and the leiden name
     end to end (umap connectivities, Leiden refinement)."""
     from doubletdetection_amd import BoostClassifier
     from doubletdetection_amd._synthetic import make_counts
