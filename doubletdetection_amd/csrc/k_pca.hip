@@ -228,10 +228,18 @@ __global__ void __launch_bounds__(256) k_spmm_cols(const int64_t* __restrict__ c
 // float32 with v_pk_fma_f32 (two chains of four), and the trip's sum is added to the float64 accumulator.
 // All orders are fixed.
 // ------------------------------------------------------------------------------------------------
+#ifndef DDX_SPMM_DBG
+#define DDX_SPMM_DBG 0      // ablation builds only (profiles/tools/spmm_ablation.sh): 1 no operand reads, 2 no entry fetches, 4 no staged reads, 8 no slice staging, 16 no trips, 32 no entry staging
+#endif
 constexpr int kLdsOwnG = 6;        // outputs owned by one lane group
-constexpr int kLdsWaves = 16;      // waves per workgroup
+#ifndef DDX_LDS_WAVES
+#define DDX_LDS_WAVES 16
+#endif
+constexpr int kLdsWaves = DDX_LDS_WAVES;      // waves per workgroup (16: one workgroup per CU; 8: two, each with half the LDS)
+constexpr int kLdsWgPerCu = 16 / kLdsWaves;
+constexpr int kLdsThreads = kLdsWaves * 64;
 constexpr int kLdsChunk = 64;      // stored entries per segment and round
-constexpr int kLdsBudget = 160 * 1024;
+constexpr int kLdsBudget = 160 * 1024 / kLdsWgPerCu;
 // staging per wave and lane group: 64 float64 values + 64 LDS offsets, the group strides padded by 16 bytes so
 // that the groups' broadcast reads of entry t fall into different banks
 constexpr int kLdsDStride = kLdsChunk + 2;    // doubles
@@ -281,6 +289,7 @@ __device__ __forceinline__ LdsFetch<SLOTS> lds_fetch(const int32_t* __restrict__
     for (int g = 0; g < SLOTS; ++g) {
         int32_t p = l[g] + r * kLdsChunk + lane;         // positions fit 31 bits (stage_create_doublets enforces it)
         p = p < h[g] ? p : l[g];
+        if (DDX_SPMM_DBG & 2) p = l[g];
         f.i[g] = idx[p];
         f.x[g] = x[p];
     }
@@ -301,27 +310,41 @@ __device__ __forceinline__ void lds_round(const LdsFetch<SLOTS>& f, const int (&
     for (int g = 0; g < SLOTS; ++g) {
         const bool ok = lane < nvalid[g];
         const int i = ok ? f.i[g] - base : 0;
-        const double z = ROWS ? (double)zS[i] : zc[g];
-        const double d = ok ? (double)f.x[g] - z : 0.0;
-        if (PK) reinterpret_cast<float*>(dS)[g * kLdsOStride + lane] = (float)d;
-        else dS[g * kLdsDStride + lane] = d;
-        offS[g * kLdsOStride + lane] = (uint32_t)(i * ld) * 4u;
+        if (DDX_SPMM_DBG & 32) continue;
+        if (PK) {
+            // x - z in float32 is the correctly rounded difference, i.e. what the float64 difference rounds to
+            const float zf = ROWS ? zS[i] : (float)zc[g];
+            reinterpret_cast<float*>(dS)[g * kLdsOStride + lane] = ok ? f.x[g] - zf : 0.0f;
+        } else {
+            const double z = ROWS ? (double)zS[i] : zc[g];
+            dS[g * kLdsDStride + lane] = ok ? (double)f.x[g] - z : 0.0;
+        }
+        offS[g * kLdsOStride + lane] = __umul24((uint32_t)i, (uint32_t)(ld * 4));      // i < 2^24, ld * 4 < 2^24
     }
     wave_lds_sync();
     if (PK) {
         const float* myf = reinterpret_cast<const float*>(myd);
-        for (int t0 = 0; t0 < nsteps; t0 += 8) {          // the staged round is zero-padded to 64 entries
+        for (int t0 = 0; t0 < ((DDX_SPMM_DBG & 16) ? 0 : nsteps); t0 += 8) {          // the staged round is zero-padded to 64 entries
             f4v fv[2];
             u4 ov[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) fv[u] = *reinterpret_cast<const f4v*>(myf + t0 + 4 * u);
 #pragma unroll
             for (int u = 0; u < 2; ++u) ov[u] = *reinterpret_cast<const u4*>(myoff + t0 + 4 * u);
+            if (DDX_SPMM_DBG & 4) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) { fv[u] = (f4v)((float)t0); ov[u] = (u4)((uint32_t)(t0 * 160 + u * 640)) + (u4){0u, 160u, 320u, 480u}; }
+            }
             fq q[8];
+            if (DDX_SPMM_DBG & 1) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) q[u] = (fq)(__builtin_bit_cast(float, ov[u >> 2][u & 3]));
+            } else {
             q[0] = *reinterpret_cast<const fq*>(opB + ov[0].x); q[1] = *reinterpret_cast<const fq*>(opB + ov[0].y);
             q[2] = *reinterpret_cast<const fq*>(opB + ov[0].z); q[3] = *reinterpret_cast<const fq*>(opB + ov[0].w);
             q[4] = *reinterpret_cast<const fq*>(opB + ov[1].x); q[5] = *reinterpret_cast<const fq*>(opB + ov[1].y);
             q[6] = *reinterpret_cast<const fq*>(opB + ov[1].z); q[7] = *reinterpret_cast<const fq*>(opB + ov[1].w);
+            }
             fq p0 = q[0] * fv[0].x;
             fq p1 = q[1] * fv[0].y;
             p0 = __builtin_elementwise_fma(q[2], (fq)(fv[0].z), p0);
@@ -366,7 +389,7 @@ __device__ __forceinline__ void lds_round(const LdsFetch<SLOTS>& f, const int (&
 // LDS cycle all read the same operand row (no bank conflicts) or the same staged entry (broadcast).  A lane holds
 // four adjacent sketch columns; with ld = 40 ten of the 16 lanes of a group work.
 template <bool ROWS, int SLOTS, bool PK, int CPL, int OWN>
-__global__ void __launch_bounds__(1024) k_spmm_lds(const LdsSpmmArgs a) {
+__global__ void __launch_bounds__(kLdsThreads) k_spmm_lds(const LdsSpmmArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     float* opS = reinterpret_cast<float*>(smem);
     float* zS = opS + (size_t)a.SR * a.ld;
@@ -426,13 +449,14 @@ __global__ void __launch_bounds__(1024) k_spmm_lds(const LdsSpmmArgs a) {
             f4v* dst = reinterpret_cast<f4v*>(opS);
             // asynchronous global -> LDS copy (16 bytes per lane, LDS destination = wave-uniform base + lane*16):
             // all of a wave's pieces are in flight together and no register is tied up
-            for (int base = wave * 64; base < nvec; base += 1024) {
+            for (int base = wave * 64; base < nvec; base += kLdsThreads) {
+                if (DDX_SPMM_DBG & 8) break;
                 if (base + lane < nvec)
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + base + lane),
                                                      (__attribute__((address_space(3))) void*)(dst + base), 16, 0, 0);
             }
             if (ROWS)
-                for (int i = threadIdx.x; i < nr; i += 1024) zS[i] = a.zcol[r0 + i];
+                for (int i = threadIdx.x; i < nr; i += kLdsThreads) zS[i] = a.zcol[r0 + i];
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();
@@ -894,7 +918,8 @@ static int lds_slots(int ld) { return lds_quad(ld) ? (ld <= 64 ? 4 : 0) : (ld <=
 static int lds_lpn(int ld) { return (lds_quad(ld) || ld <= 32) ? 16 : ld / 2; }
 static int lds_owners(int64_t nOut, int slots, int ld) {
     const int64_t need = ceil_div(nOut, (int64_t)kLdsWaves * slots * (lds_quad(ld) ? kLdsOwnQuad : kLdsOwnG));
-    return (int)(need <= 256 ? need : 256 * ceil_div(need, 256));     // whole rounds of one workgroup per CU
+    constexpr int64_t per_round = 256 * kLdsWgPerCu;
+    return (int)(need <= per_round ? need : per_round * ceil_div(need, per_round));     // whole rounds of resident workgroups
 }
 
 template <bool ROWS, int SLOTS, bool PK, int CPL, int OWN>
@@ -904,7 +929,7 @@ static int launch_lds_t(ddx_ctx* c, const LdsSpmmArgs& a, unsigned grid, size_t 
         DDX_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmm_lds<ROWS, SLOTS, PK, CPL, OWN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
         configured = true;
     }
-    k_spmm_lds<ROWS, SLOTS, PK, CPL, OWN><<<grid, 1024, lds_bytes, c->stream>>>(a);
+    k_spmm_lds<ROWS, SLOTS, PK, CPL, OWN><<<grid, kLdsThreads, lds_bytes, c->stream>>>(a);
     return DDX_OK;
 }
 
@@ -978,7 +1003,7 @@ static int apply_cols(PcaWork& w, const double* Yrow, double* Wcol) {  // A^T Y 
         a.op = prepared_operand<float>(w, Yrow, w.M, a.ld);
         a.opRows = w.M; a.SR = c->panel_rows; a.nslices = P;
         a.nOut = w.H; a.owners = lds_owners(w.H, slots, a.ld);
-        a.groups = std::max(1, std::min(P, 512 / a.owners));
+        a.groups = std::max(1, std::min(P, 512 * kLdsWgPerCu / a.owners));
         a.zcol = c->zcol.as<float>();
         a.cp_o = c->csc_o_colptr.as<int64_t>(); a.row_o = c->csc_o_row.as<int32_t>(); a.x_o = c->csc_o_x.as<float>(); a.P_o = c->P_o;
         a.cp_s = c->csc_s_colptr.as<int64_t>(); a.row_s = c->csc_s_row.as<int32_t>(); a.x_s = c->csc_s_x.as<float>();
