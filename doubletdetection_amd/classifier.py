@@ -367,6 +367,9 @@ class BoostClassifier:
         import time
 
         t_fit0 = time.perf_counter()
+        num_genes = self.n_top_var_genes if restrict else raw_counts.shape[1]
+        drawer = ThreadPoolExecutor(max_workers=1)
+        draws = drawer.submit(self._draw, raw_counts.shape[0], num_genes)     # overlaps the device prologue
         try:
             if restrict:
                 # dd.py:165-176 -- float32 variances on the device in scipy's evaluation order; the
@@ -379,10 +382,15 @@ class BoostClassifier:
                 engine.upload(raw_counts)
                 num_genes = raw_counts.shape[1]
             t_prologue = time.perf_counter() - t_fit0
-            self._fit_resident(engine, raw_counts.shape[0], num_genes, rank, world, backend, device)
+            self._fit_resident(engine, raw_counts.shape[0], num_genes, rank, world, backend, device, draws)
             self._host_timings["prologue"] = t_prologue
         finally:
             t0 = time.perf_counter()
+            try:
+                draws.result()             # never leave the Generator in use by a worker
+            except Exception:
+                pass
+            drawer.shutdown(wait=True)
             engine.close()
         self._host_timings["close"] = time.perf_counter() - t0
         self._host_timings["fit_total"] = time.perf_counter() - t_fit0
@@ -434,7 +442,25 @@ class BoostClassifier:
         self._staged = (raw_counts, csr, engine, device, restrict)
         return self
 
-    def _fit_resident(self, engine, num_cells, num_genes, rank, world, backend, device):
+    def _draw(self, num_cells, num_genes):
+        """Host-side random draws of one fit: the parents of every iteration (dd.py:394; the Generator stream must be
+        consumed in iteration order whatever rank runs the iteration) and, for the randomized PCA regime, sklearn's
+        start matrix.  fit() runs this on a worker thread while the device executes the prologue."""
+        num_synths = int(self.boost_rate * num_cells)
+        all_parents = [self.rng.choice(num_cells, size=(num_synths, 2), replace=self.replace)
+                       for _ in range(self.n_iters)]
+        M = num_cells + num_synths
+        q0 = None
+        sparse_branch = self.pseudocount == 1 and not self.standard_scaling
+        if not sparse_branch and self._pca_regime(M, num_genes, self.n_components) == "randomized":
+            sketch = self.n_components + 10
+            q0_rows = num_genes if M >= num_genes else M
+            # sklearn draws the start matrix from the legacy RandomState and casts it to the data dtype
+            q0 = np.random.RandomState(self.random_state).normal(size=(q0_rows, sketch))
+            q0 = q0.astype(np.float32).astype(np.float64)
+        return all_parents, q0
+
+    def _fit_resident(self, engine, num_cells, num_genes, rank, world, backend, device, draws=None):
         self._num_cells, self._num_genes = num_cells, num_genes
         num_synths = int(self.boost_rate * num_cells)
         n_iters = self.n_iters
@@ -442,9 +468,7 @@ class BoostClassifier:
         import time
 
         t_setup0 = time.perf_counter()
-        # the Generator stream must be consumed in iteration order whatever rank runs the iteration
-        all_parents = [self.rng.choice(num_cells, size=(num_synths, 2), replace=self.replace)
-                       for _ in range(n_iters)]
+        all_parents, q0_drawn = draws.result() if draws is not None else self._draw(num_cells, num_genes)
 
         M = num_cells + num_synths
         n_comp = self.n_components
@@ -457,11 +481,7 @@ class BoostClassifier:
             q0 = "arpack"
             engine._arpack_seed = self.random_state
         elif regime == "randomized":
-            sketch = n_comp + 10
-            q0_rows = self._num_genes if M >= self._num_genes else M
-            # sklearn draws the start matrix from the legacy RandomState and casts it to the data dtype
-            q0 = np.random.RandomState(self.random_state).normal(size=(q0_rows, sketch))
-            q0 = q0.astype(np.float32).astype(np.float64)
+            q0 = q0_drawn
         else:
             q0 = None      # exact regime: no random start (engine builds and diagonalises the Gram matrix)
 
