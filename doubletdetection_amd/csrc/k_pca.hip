@@ -909,7 +909,8 @@ static const T* prepared_operand(PcaWork& w, const double* X, int64_t R, int ld)
 // forces one of them.
 static bool lds_packed();
 static bool lds_quad(int ld) {
-    static const int mode = [] { const char* e = std::getenv("DDX_SPMM_GEOM"); return !e ? 0 : (std::strcmp(e, "pair") == 0 ? 1 : (std::strcmp(e, "quad") == 0 ? 2 : 0)); }();
+    const char* e = std::getenv("DDX_SPMM_GEOM");       // read per call: tests switch it between contexts
+    const int mode = !e ? 0 : (std::strcmp(e, "pair") == 0 ? 1 : (std::strcmp(e, "quad") == 0 ? 2 : 0));
     if (!lds_packed() || mode == 1) return false;       // (the float64-product trips keep the pair geometry: twice the staging)
     return mode == 2 || ld > 42;
 }
@@ -937,8 +938,8 @@ static int launch_lds_t(ddx_ctx* c, const LdsSpmmArgs& a, unsigned grid, size_t 
 // 7e-7 per component against the all-float64 run at 50k x 20k, 4e-7 with float64 products; 0.69 instead of 0.84 ms).
 // DDX_SPMM_TRIP=f64 selects float64 products.
 static bool lds_packed() {
-    static const bool v = [] { const char* e = std::getenv("DDX_SPMM_TRIP"); return !(e && std::strcmp(e, "f64") == 0); }();
-    return v;
+    const char* e = std::getenv("DDX_SPMM_TRIP");
+    return !(e && std::strcmp(e, "f64") == 0);
 }
 
 template <bool ROWS>

@@ -123,9 +123,10 @@ def test_pca_and_knn_properties(staged):
 
 
 def test_operator_product_variants_agree_at_full_size(data, staged, monkeypatch):
-    """The same randomized PCA through the three implementations of the operator products: LDS-staged float32
-    operand (default), L2-gather float32 operand (DDX_SPMM=gather), L2-gather float64 operand (DDX_PCA_GATHER=f64).
-    The first two compute identical products in different summation orders (agreement to amplified rounding noise); the
+    """The same randomized PCA through the implementations of the operator products: LDS-staged float32
+    operand with float32 products inside a trip (default), L2-gather float32 operand (DDX_SPMM=gather), L2-gather
+    float64 operand (DDX_PCA_GATHER=f64), LDS with float64 products, LDS in the quad geometry.
+    The first two compute the same products up to the float32 trip sums and the summation order; the
     float64 mode differs by the float32 rounding of the operand copies (< 1e-5 per component, as in the small
     oracle test)."""
     import os
@@ -165,6 +166,12 @@ def test_operator_product_variants_agree_at_full_size(data, staged, monkeypatch)
     emb_f, sing_f = other({"DDX_SPMM": "gather", "DDX_PCA_GATHER": "f64"})
     rel = np.linalg.norm(emb_f - emb_lds, axis=0) / np.linalg.norm(emb_f, axis=0)
     assert rel.max() < 1e-5, rel.max()
+    # the other two LDS variants: float64 products inside a trip, and the quad geometry at width 40
+    for env in ({"DDX_SPMM_TRIP": "f64"}, {"DDX_SPMM_GEOM": "quad"}):
+        emb_v, sing_v = other(env)
+        np.testing.assert_allclose(sing_v, sing_lds, rtol=1e-8)
+        rel_v = np.linalg.norm(emb_v - emb_lds, axis=0) / np.linalg.norm(emb_lds, axis=0)
+        assert rel_v.max() < 2e-6, (env, rel_v.max())
 
 
 def test_fit_is_deterministic_and_finds_doublets(data):
