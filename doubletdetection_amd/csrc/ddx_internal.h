@@ -117,6 +117,7 @@ struct ddx_ctx {
     bool scaled = false;
     ddx::DevBuf median;              // float [1] (+ scratch)
     ddx::DevBuf lib_sorted;          // float [M]
+    ddx::DevBuf lognorm_tab;         // float [M x 16] log-normalised value of the counts 1..16 in every row (row-major pass)
     ddx::DevBuf zcol;                // float  [H] value of unstored entries per column
     ddx::DevBuf colmean;             // double [H] mean over rows of (x - zcol) (0 for unstored)
     ddx::DevBuf colstat;             // double [2H] scratch for scale
