@@ -31,7 +31,7 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 
 # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide
-# coalesced reads, + WRITE_SIZE), headline workload, profiles/r01m_pmc_counters.txt; None = not collected
+# coalesced reads, + WRITE_SIZE), headline workload, profiles/r01n_pmc_counters.txt; None = not collected
 PMC_TRAFFIC_GB = {"spmm_rows": 1.55, "spmm_cols": 1.58, "knn_emit": 4.76, "knn_bound": 0.89, "knn_select": 0.44}
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md)
