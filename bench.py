@@ -205,7 +205,7 @@ def cpu_baseline(X, args, kw):
     n = min(args.cpu_sample_cells, X.shape[0])
     rows = np.sort(np.random.default_rng(0).choice(X.shape[0], size=n, replace=False))
     sample = X[rows]
-    iters = 1
+    iters = 2        # ~10 s of CPU work on the GPU box's host
 
     def native_louvain(indptr, indices, weights, gamma, seed):
         return _lib.louvain(indptr, indices, weights, gamma, seed)[0].astype(np.int64)
@@ -217,10 +217,10 @@ def cpu_baseline(X, args, kw):
         warnings.simplefilter("ignore")
         o = orc.OracleClassifier(**okw).fit(sample)
     dt = time.perf_counter() - t0
-    per_iter = dt - o.timings["prologue"]
+    per_iter = (dt - o.timings["prologue"]) / iters
     full_fit = o.timings["prologue"] + per_iter * args.iters     # iterations are identical work
     return {"value": round(n / full_fit, 2), "unit": "cells/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": f"{n} of {X.shape[0]} cells x {X.shape[1]} genes, 1 iteration timed ({dt:.1f} s) and scaled to "
+            "sample": f"{n} of {X.shape[0]} cells x {X.shape[1]} genes, {iters} iterations timed ({dt:.1f} s) and scaled to "
                       f"n_iters={args.iters}; dense log matrix + sklearn randomized PCA + exact kNN + host Louvain",
             "stage_seconds": {k2: round(v, 3) for k2, v in o.timings.items()}}
 
