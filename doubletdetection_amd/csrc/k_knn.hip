@@ -92,7 +92,10 @@ constexpr int kCandCap = 768;      // candidate slots per query between the emit
 
 // ---- candidate tiles are staged through LDS once per block (4 waves share them) ---------------------
 // tiles per staged chunk: 16 KB of coordinates per buffer whatever the padded dimension
-__host__ __device__ constexpr int chunk_tiles(int CP) { return CP <= 32 ? 8 : 4; }
+#ifndef DDX_CHUNK_TILES32
+#define DDX_CHUNK_TILES32 8
+#endif
+__host__ __device__ constexpr int chunk_tiles(int CP) { return CP <= 32 ? DDX_CHUNK_TILES32 : DDX_CHUNK_TILES32 / 2; }
 
 template <int CP>
 struct TileStage {

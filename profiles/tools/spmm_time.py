@@ -27,5 +27,13 @@ for rep in range(2):
     except Exception as e:  # noqa: BLE001
         print("pca:", str(e)[:80])
 t = ctx.timings()
-print(sys.argv[1] if len(sys.argv) > 1 else "", {k: round(v[1] / max(v[0], 1), 4) for k, v in t.items() if k.startswith("spmm")})
+out = {k: round(v[1] / max(v[0], 1), 4) for k, v in t.items() if k.startswith("spmm")}
+try:
+    ctx.timing_reset()
+    ctx.knn(30, False)
+    ctx.synchronize()
+    out.update({k: round(v[1] / max(v[0], 1), 4) for k, v in ctx.timings().items() if k.startswith("knn")})
+except Exception as e:  # noqa: BLE001
+    print("knn:", str(e)[:80])
+print(sys.argv[1] if len(sys.argv) > 1 else "", out)
 ctx.close()
