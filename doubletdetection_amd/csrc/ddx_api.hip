@@ -47,21 +47,36 @@ void release(ddx_ctx* ctx, DevBuf& b) {
     b.cap = 0;
 }
 
+static bool timing_event(ddx_ctx* ctx, hipEvent_t* ev) {
+    if (!ctx->t_free.empty()) {
+        *ev = ctx->t_free.back();
+        ctx->t_free.pop_back();
+        return true;
+    }
+    return hipEventCreate(ev) == hipSuccess;
+}
+
 void timing_begin(ddx_ctx* ctx, const char* name) {
     if (!ctx->timing) return;
-    auto it = ctx->t_index.find(name);
     int id;
-    if (it == ctx->t_index.end()) {
-        id = (int)ctx->t_names.size();
-        ctx->t_names.emplace_back(name);
-        ctx->t_index[name] = id;
-        ctx->t_recs.emplace_back();
+    auto pit = ctx->t_by_ptr.find(name);
+    if (pit != ctx->t_by_ptr.end()) {
+        id = pit->second;
     } else {
-        id = it->second;
+        auto it = ctx->t_index.find(name);
+        if (it == ctx->t_index.end()) {
+            id = (int)ctx->t_names.size();
+            ctx->t_names.emplace_back(name);
+            ctx->t_index[name] = id;
+            ctx->t_recs.emplace_back();
+        } else {
+            id = it->second;
+        }
+        ctx->t_by_ptr[name] = id;
     }
     PendingEvent ev;
     ev.name_id = id;
-    if (hipEventCreate(&ev.start) != hipSuccess || hipEventCreate(&ev.stop) != hipSuccess) return;
+    if (!timing_event(ctx, &ev.start) || !timing_event(ctx, &ev.stop)) return;
     (void)hipEventRecord(ev.start, ctx->stream);
     ctx->t_pending.push_back(ev);
 }
@@ -81,8 +96,8 @@ int timing_flush(ddx_ctx* ctx) {
             ctx->t_recs[ev.name_id].launches += 1;
             ctx->t_recs[ev.name_id].total_ms += ms;
         }
-        (void)hipEventDestroy(ev.start);
-        (void)hipEventDestroy(ev.stop);
+        ctx->t_free.push_back(ev.start);
+        ctx->t_free.push_back(ev.stop);
     }
     ctx->t_pending.clear();
     return DDX_OK;
@@ -147,6 +162,8 @@ int ddx_destroy(ddx_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     (void)timing_flush(ctx);
+    for (hipEvent_t e : ctx->t_free) (void)hipEventDestroy(e);
+    ctx->t_free.clear();
     DevBuf* bufs[] = {&ctx->raw_indptr, &ctx->raw_indices, &ctx->raw_data, &ctx->aug_indptr, &ctx->aug_indices,
                       &ctx->aug_raw, &ctx->aug_x, &ctx->lib32, &ctx->lib64, &ctx->synth_counts, &ctx->parents, &ctx->pad_off,
                       &ctx->csc_o_colptr, &ctx->csc_o_row, &ctx->csc_o_raw, &ctx->csc_o_x, &ctx->csc_s_colptr,

@@ -168,6 +168,8 @@ struct ddx_ctx {
     std::map<std::string, int> t_index;
     std::vector<ddx::TimingRec> t_recs;
     std::vector<ddx::PendingEvent> t_pending;
+    std::vector<hipEvent_t> t_free;          // recycled events (creating a pair per scope cost more than recording it)
+    std::map<const void*, int> t_by_ptr;     // scope names are string literals: their address identifies them
 };
 
 namespace ddx {
