@@ -262,6 +262,7 @@ struct LdsSpmmArgs {
     const int64_t* cp_o; const int32_t* row_o; const float* x_o; int P_o;
     const int64_t* cp_s; const int32_t* row_s; const float* x_s; int p_s0, P_s;
     double* out;                  // ROWS: Y [M x L];  COLS: partials [groups x H x L]
+    float* out32;                 // ROWS: padded float32 copy of Y [M x ld] for the A^T Y pass that follows (or null)
 };
 
 __device__ __forceinline__ void wave_lds_sync() {
@@ -540,8 +541,13 @@ __global__ void __launch_bounds__(kLdsThreads) k_spmm_lds(const LdsSpmmArgs a) {
             for (int c = 0; c < CPL; ++c) {
                 const int col = CPL * sub + c;
                 if (col < a.L) {
-                    if (ROWS) a.out[o * a.L + col] = acc[k][c] - a.tvec[col];
-                    else a.out[((int64_t)group * a.nOut + o) * a.L + col] = acc[k][c];
+                    if (ROWS) {
+                        const double y = acc[k][c] - a.tvec[col];
+                        a.out[o * a.L + col] = y;
+                        if (a.out32) a.out32[o * a.ld + col] = (float)y;
+                    } else {
+                        a.out[((int64_t)group * a.nOut + o) * a.L + col] = acc[k][c];
+                    }
                 }
             }
         }
@@ -792,8 +798,10 @@ __global__ void __launch_bounds__(64) k_chol_inv_reg(const double* __restrict__ 
 }
 
 // out[R x L2] = X[R x L] * T[L x L2]   (64 rows per block, X tile and T staged in LDS)
+// out32 != nullptr: also the padded float32 copy of the result that the next operator product stages (ld32 columns)
 __global__ void __launch_bounds__(256) k_right_mult(const double* __restrict__ X, int64_t R, int L,
-                                                    const double* __restrict__ T, int L2, double* __restrict__ out) {
+                                                    const double* __restrict__ T, int L2, double* __restrict__ out,
+                                                    float* __restrict__ out32 = nullptr, int ld32 = 0) {
     extern __shared__ __attribute__((aligned(16))) double sm[];  // T[L*L2] then xt[64*L]
     double* t_s = sm;
     double* x_s = sm + L * L2;
@@ -808,6 +816,7 @@ __global__ void __launch_bounds__(256) k_right_mult(const double* __restrict__ X
         double s = 0.0;
         for (int p = 0; p < L; ++p) s = fma(x_s[r * L + p], t_s[p * L2 + c], s);
         out[(r0 + r) * L2 + c] = s;
+        if (out32) out32[(r0 + r) * ld32 + c] = (float)s;
     }
 }
 
@@ -852,6 +861,12 @@ struct PcaWork {
     int L, lpn, slots;
     bool gather32;     // gather a float32 copy of the small operand (needs L % 4 == 0)
     float* op32;       // scratch for that copy: max(M, H) x L floats
+    // LDS mode: two float32 operand copies live side by side (op32 = copy of an M-row sketch, opQ = copy of an H-row
+    // one), each written by the kernel that produces the float64 matrix it mirrors (`*_of`); k_operand_copy only runs
+    // when a product is asked for a matrix nobody mirrored.
+    float* opQ = nullptr;
+    const double* opY_of = nullptr;
+    const double* opQ_of = nullptr;
     int64_t M;
     int32_t H;
     bool lds;          // LDS-staged products (needs gather32 and a slice that fits the LDS)
@@ -889,7 +904,15 @@ static int cholqr(PcaWork& w, const double* X, int64_t R, double* out) {
     gram(w, X, R, G);
     if (w.L == 40) k_chol_inv_reg<40><<<1, 64, 0, w.ctx->stream>>>(G, Rinv, w.flag);      // the default sketch width (30 + 10)
     else k_chol_inv<<<1, 64, 2 * sizeof(double) * w.L * w.L, w.ctx->stream>>>(G, w.L, Rinv, w.flag);
-    k_right_mult<<<(unsigned)ceil_div(R, 64), 256, sizeof(double) * (w.L * w.L + 64 * w.L), w.ctx->stream>>>(X, R, w.L, Rinv, w.L, out);
+    float* out32 = nullptr;
+    const int ld = (w.L + 3) & ~3;
+    if (w.lds && w.opQ) {
+        if (w.opY_of == out) w.opY_of = nullptr;
+        if (w.opQ_of == out) w.opQ_of = nullptr;
+        if (R == w.H) { out32 = w.opQ; w.opQ_of = out; }
+        else if (R == w.M) { out32 = w.op32; w.opY_of = out; }
+    }
+    k_right_mult<<<(unsigned)ceil_div(R, 64), 256, sizeof(double) * (w.L * w.L + 64 * w.L), w.ctx->stream>>>(X, R, w.L, Rinv, w.L, out, out32, ld);
     return DDX_OK;
 }
 
@@ -963,7 +986,20 @@ static int apply_rows(PcaWork& w, const double* Qcol, double* Yrow) {  // A Q : 
         LdsSpmmArgs a{};
         a.ld = (w.L + 3) & ~3; a.L = w.L; a.lpn = lds_lpn(a.ld);
         const int slots = lds_slots(a.ld);
-        a.op = prepared_operand<float>(w, Qcol, w.H, a.ld);
+        if (w.opQ && w.opQ_of == Qcol) {
+            a.op = w.opQ;                                   // mirrored by the kernel that produced Qcol
+        } else if (w.opQ) {
+            k_operand_copy<float><<<(unsigned)ceil_div((int64_t)w.H * a.ld, 256), 256, 0, c->stream>>>(Qcol, w.H, w.L, a.ld, w.opQ);
+            w.opQ_of = Qcol;
+            a.op = w.opQ;
+        } else {
+            a.op = prepared_operand<float>(w, Qcol, w.H, a.ld);
+        }
+        if (w.opQ) {                                        // this product mirrors its own result for the A^T Y pass
+            if (w.opQ_of == Yrow) w.opQ_of = nullptr;
+            a.out32 = w.op32;
+            w.opY_of = Yrow;
+        }
         a.opRows = w.H; a.SR = w.rows_SR; a.nslices = w.rows_ns; a.groups = 1;
         a.nOut = w.M; a.owners = lds_owners(w.M, slots, a.ld);
         a.indptr = c->aug_indptr.as<int64_t>(); a.cols = c->aug_indices.as<int32_t>(); a.x = c->aug_x.as<float>();
@@ -1001,7 +1037,14 @@ static int apply_cols(PcaWork& w, const double* Yrow, double* Wcol) {  // A^T Y 
         LdsSpmmArgs a{};
         a.ld = (w.L + 3) & ~3; a.L = w.L; a.lpn = lds_lpn(a.ld);
         const int slots = lds_slots(a.ld);
-        a.op = prepared_operand<float>(w, Yrow, w.M, a.ld);
+        if (w.opQ && w.opY_of == Yrow) {
+            a.op = w.op32;                                  // mirrored by the kernel that produced Yrow
+        } else {
+            a.op = prepared_operand<float>(w, Yrow, w.M, a.ld);
+            if (w.opQ) w.opY_of = Yrow;
+        }
+        if (w.opQ && w.opQ_of == Wcol) w.opQ_of = nullptr;   // the result overwrites a mirrored matrix
+        if (w.opQ && w.opY_of == Wcol) w.opY_of = nullptr;
         a.opRows = w.M; a.SR = c->panel_rows; a.nslices = P;
         a.nOut = w.H; a.owners = lds_owners(w.H, slots, a.ld);
         a.groups = std::max(1, std::min(P, 512 * kLdsWgPerCu / a.owners));
@@ -1159,6 +1202,13 @@ int stage_pca(ddx_ctx* ctx, int32_t C, int32_t oversample, int32_t n_iter, const
     const int64_t maxR = M > H ? M : (int64_t)H;
     DDX_TRY(ensure(ctx, ctx->pcaOp, sizeof(double) * (size_t)maxR * (L + 4)));
     w.op32 = ctx->pcaOp.as<float>();
+    if (w.lds) {
+        // second operand copy behind the first (pcaOp holds max(M, H) x (L + 4) doubles = twice that many floats)
+        w.opQ = w.op32 + (size_t)maxR * (L + 4);
+        w.opQ_of = w.opY_of = nullptr;
+        if (((L + 3) & ~3) != L)             // padding columns of the mirrored copies stay zero
+            DDX_HIP(ctx, hipMemsetAsync(w.op32, 0, sizeof(double) * (size_t)maxR * (L + 4), ctx->stream));
+    }
     w.M = M;
     w.H = H;
     w.partial = ctx->pcaPartial.as<double>();
