@@ -174,14 +174,15 @@ def test_operator_product_variants_agree_at_full_size(data, staged, monkeypatch)
         assert rel_v.max() < 2e-6, (env, rel_v.max())
 
 
-def test_fit_is_deterministic_and_finds_doublets(data):
+@pytest.mark.parametrize("algorithm", ["louvain", "leiden"])
+def test_fit_is_deterministic_and_finds_doublets(data, algorithm):
     from doubletdetection_amd import BoostClassifier
 
     res = []
     for _ in range(2):
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            clf = BoostClassifier(n_iters=3, clustering_algorithm="louvain", random_state=7, n_jobs=-1).fit(data)
+            clf = BoostClassifier(n_iters=3, clustering_algorithm=algorithm, random_state=7, n_jobs=-1).fit(data)
         res.append((clf.all_log_p_values_.copy(), clf.communities_.copy(), clf.doublet_score()))
     np.testing.assert_array_equal(res[0][0], res[1][0])          # tests/test_package.py:25-38 at full size
     np.testing.assert_array_equal(res[0][1], res[1][1])
