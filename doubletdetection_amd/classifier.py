@@ -588,7 +588,7 @@ class BoostClassifier:
             buf[slot, :M] = full
             buf[slot, M:M + num_cells] = scores
             buf[slot, M + num_cells:] = logp
-        use_cuda = backend == "nccl"
+        use_cuda = "nccl" in str(backend)        # RCCL needs device tensors ("nccl", or "cpu:gloo,cuda:nccl")
         t = torch.from_numpy(buf)
         if use_cuda:
             t = t.to(f"cuda:{device}")
