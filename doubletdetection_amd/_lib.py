@@ -126,9 +126,16 @@ def _p(arr, ptype):
 
 
 def _check(rc, ctx=None):
-    if rc != 0:
-        msg = load().ddx_last_error(ctx)
-        raise DdxError(rc, msg.decode() if msg else "unknown")
+    if rc == 0:
+        return
+    msg = load().ddx_last_error(ctx)
+    msg = msg.decode() if msg else "unknown"
+    if rc > 0:                      # DDX_W_*: the call succeeded, the library has something to say
+        import warnings
+
+        warnings.warn(f"libddx: {msg}", RuntimeWarning, stacklevel=3)
+        return
+    raise DdxError(rc, msg)
 
 
 def device_count() -> int:

@@ -59,13 +59,19 @@ def _dist_info():
     return 0, 1, None
 
 
-# Device contexts (and the HBM buffers they own) are kept per GPU between fits, like a caching allocator:
-# re-allocating ~3 GB of device memory for every fit() costs more than the prologue itself.
+# The reference releases everything it allocated when fit() returns (dd.py:200-205); so does this class: the device
+# context of a fit (stream + every HBM buffer) is destroyed when the fit ends.  DDX_KEEP_CONTEXT=1 (read when a fit
+# ends) parks the context per GPU instead, like a caching allocator, so that back-to-back fits skip the allocations;
+# release_device_memory() frees what is parked.
 _CONTEXT_POOL: dict = {}
 
 
+def _keep_contexts() -> bool:
+    return os.environ.get("DDX_KEEP_CONTEXT", "0") not in ("", "0")
+
+
 def release_device_memory() -> None:
-    """Destroy the pooled device contexts and free their HBM buffers."""
+    """Destroy the parked device contexts (DDX_KEEP_CONTEXT=1) and free their HBM buffers."""
     while _CONTEXT_POOL:
         _, ctx = _CONTEXT_POOL.popitem()
         ctx.close()
@@ -89,10 +95,10 @@ class _HipEngine:
 
     def close(self):
         if self.ctx is not None:
-            if self.device in _CONTEXT_POOL:             # another engine already parked one: drop this one
-                self.ctx.close()
-            else:
+            if _keep_contexts() and self.device not in _CONTEXT_POOL:
                 _CONTEXT_POOL[self.device] = self.ctx
+            else:
+                self.ctx.close()                         # frees every HBM buffer of the fit
             self.ctx = None
 
     def upload(self, csr):
@@ -303,23 +309,98 @@ class BoostClassifier:
         if unknown:
             raise TypeError(f"unsupported clustering_kwargs for {self.clustering_algorithm}: {sorted(unknown)}")
 
+    # Device limits of the hand-written kernels: the randomized sketch holds at most 64 columns
+    # (n_components + 10 oversamples), the kNN kernels at most 64 embedding dimensions and 64 neighbours.
+    _MAX_SKETCH = 64
+    _MAX_EMBED = 64
+    _MAX_K = 64
+
     def _cluster_plan(self):
-        """(k, include_self, graph_mode, gamma, seed, min_cluster_size, leiden) for the chosen algorithm."""
+        """(k, include_self, graph_mode, gamma, seed, min_cluster_size, leiden) for the chosen algorithm.
+
+        Every accepted keyword either changes the plan the way it changes the upstream call, is a documented no-op
+        (worker counts, time limits, exact nearest-neighbour back-ends), or raises ``NotImplementedError`` -- a
+        keyword is never swallowed while the result silently differs from the reference's."""
         kw = self.clustering_kwargs
+
+        def unsupported(name, value, why):
+            raise NotImplementedError(f"clustering_kwargs[{name!r}]={value!r} is not implemented on the GPU path: {why}")
+
         if self.clustering_algorithm == "phenograph":
-            if kw.get("directed", False) or not kw.get("jaccard", True):
-                raise NotImplementedError("phenograph directed=True / jaccard=False graphs are not implemented")
+            # phenograph.cluster(data, clustering_algo="louvain", k=30, directed=False, prune=False,
+            #   min_cluster_size=10, jaccard=True, primary_metric="euclidean", n_jobs=-1, q_tol=1e-3,
+            #   louvain_time_limit=2000, nn_method="kdtree", partition_type=None, resolution_parameter=1,
+            #   n_iterations=-1, use_weights=True, seed=None)                        [dd.py:320-322]
+            if kw.get("directed", False):
+                unsupported("directed", True, "only the undirected Jaccard graphs are built")
+            if not kw.get("jaccard", True):
+                unsupported("jaccard", False, "only the Jaccard graphs are built")
             if kw.get("primary_metric", "euclidean") != "euclidean":
-                raise NotImplementedError("only the euclidean metric is implemented")
-            seed = kw.get("seed")
-            seed = self.random_state if seed is None else seed
-            return (int(kw.get("k", 30)), False, 0 if kw.get("prune") else 1,
-                    float(kw.get("resolution_parameter", 1.0)), int(seed), int(kw.get("min_cluster_size", 10)), False)
+                unsupported("primary_metric", kw["primary_metric"], "only the euclidean metric is implemented")
+            if kw.get("nn_method", "kdtree") not in ("kdtree", "brute"):
+                unsupported("nn_method", kw["nn_method"], "the device search is exact ('kdtree' and 'brute' give it)")
+            algo = kw.get("clustering_algo", "louvain")
+            if algo not in ("louvain", "leiden"):
+                raise ValueError("clustering_algo needs to be one of ['louvain', 'leiden']")
+            if kw.get("partition_type") is not None:
+                unsupported("partition_type", kw["partition_type"], "only RBConfigurationVertexPartition (the default)")
+            k = int(kw.get("k", 30))
+            mode = 0 if kw.get("prune") else 1
+            mcs = int(kw.get("min_cluster_size", 10))
+            if algo == "leiden":
+                # upstream: leidenalg on the Jaccard graph with resolution_parameter / seed / use_weights / n_iterations
+                if kw.get("n_iterations", -1) != -1:
+                    unsupported("n_iterations", kw["n_iterations"], "Leiden is iterated until stable (-1)")
+                if not kw.get("use_weights", True):
+                    unsupported("use_weights", False, "Leiden runs on the Jaccard weights")
+                seed = kw.get("seed")
+                seed = self.random_state if seed is None else seed
+                return k, False, mode, float(kw.get("resolution_parameter", 1.0)), int(seed), mcs, True
+            # clustering_algo="louvain": upstream's Louvain binaries take no resolution, no seed and always use the
+            # weights -- resolution_parameter / seed / use_weights / n_iterations only reach leidenalg.  The
+            # deterministic Louvain here is seeded from the classifier's random_state.
+            return k, False, mode, 1.0, int(self.random_state), mcs, False
+
+        # sc.tl.louvain(adata, resolution, random_state, restrict_to=None, key_added, adjacency=None,
+        #   flavor="vtraag", directed=True, use_weights=False, partition_type=None, neighbors_key=None, obsp=None, copy)
+        # sc.tl.leiden(adata, resolution, restrict_to=None, random_state, key_added, adjacency=None, directed,
+        #   use_weights=True, n_iterations=-1, partition_type=None, neighbors_key=None, obsp=None, copy, flavor)
         if kw.get("directed", False):
-            raise NotImplementedError("directed=True neighbour graphs are not implemented")
-        # sc.tl.louvain ignores the edge weights (use_weights=False); sc.tl.leiden runs on the umap connectivities
-        mode = 3 if self.clustering_algorithm == "leiden" else 2
-        return 10, True, mode, float(kw["resolution"]), int(self.random_state), None, self.clustering_algorithm == "leiden"
+            unsupported("directed", True, "only undirected neighbour graphs are built")
+        for name in ("restrict_to", "adjacency", "neighbors_key", "obsp", "partition_type"):
+            if kw.get(name) is not None:
+                unsupported(name, kw[name], "the graph is the one sc.pp.neighbors builds on the PCA embedding")
+        leiden = self.clustering_algorithm == "leiden"
+        flavor = kw.get("flavor", "leidenalg" if leiden else "vtraag")
+        if flavor != ("leidenalg" if leiden else "vtraag"):
+            unsupported("flavor", flavor, "only the default flavor is restated")
+        if leiden and kw.get("n_iterations", -1) != -1:
+            unsupported("n_iterations", kw["n_iterations"], "Leiden is iterated until stable (-1)")
+        if not leiden and "n_iterations" in kw:
+            raise TypeError("louvain() got an unexpected keyword argument 'n_iterations'")
+        # sc.tl.louvain ignores the edge weights unless use_weights=True; sc.tl.leiden uses the umap connectivities
+        # unless use_weights=False
+        weighted = bool(kw.get("use_weights", leiden))
+        return 10, True, 3 if weighted else 2, float(kw["resolution"]), int(self.random_state), None, leiden
+
+    def _check_device_limits(self, num_cells, num_genes):
+        """Fail before anything is uploaded when a request exceeds what the device kernels hold (DESIGN.md section 7);
+        the reference has no such limits, so say so instead of failing in the middle of a fit."""
+        num_synths = int(self.boost_rate * num_cells)
+        M = num_cells + num_synths
+        n_comp = self.n_components
+        k = self._cluster_plan()[0]
+        if k > self._MAX_K:
+            raise NotImplementedError(f"k={k} nearest neighbours requested; the device kNN holds at most {self._MAX_K}")
+        if n_comp > self._MAX_EMBED:
+            raise NotImplementedError(f"n_components={n_comp}: the device kNN works on at most {self._MAX_EMBED} "
+                                      "embedding dimensions")
+        sparse_branch = self.pseudocount == 1 and not self.standard_scaling
+        if not sparse_branch and 1 <= n_comp <= min(M, num_genes) and \
+                self._pca_regime(M, num_genes, n_comp) == "randomized" and n_comp + 10 > self._MAX_SKETCH:
+            raise NotImplementedError(f"n_components={n_comp}: the randomized PCA sketch (n_components + 10 columns) is "
+                                      f"limited to {self._MAX_SKETCH} columns on the device, i.e. n_components <= "
+                                      f"{self._MAX_SKETCH - 10}")
 
     @staticmethod
     def _cluster_and_score(graph, gamma, seed, min_cluster_size, num_cells, leiden=False):
@@ -406,18 +487,21 @@ class BoostClassifier:
             if self.verbose:
                 print("Sparsifying matrix.")
             raw_counts = sp_sparse.csr_matrix(raw_counts)
-        if not raw_counts.has_sorted_indices:
+        if not raw_counts.has_canonical_format:
+            # the device merges assume sorted, duplicate-free rows; scipy's own row indexing / addition
+            # (dd.py:174-176,397-399) canonicalises on the way, so doing it here changes nothing downstream
             raw_counts = raw_counts.copy()
-            raw_counts.sort_indices()
+            raw_counts.sum_duplicates()
         return raw_counts
 
     def _stage(self, raw_counts, rank, world):
         csr = self._coerce(raw_counts)
+        restrict = 0 < self.n_top_var_genes < csr.shape[1]
+        self._check_device_limits(csr.shape[0], self.n_top_var_genes if restrict else csr.shape[1])
         device = self.device
         if device is None:
             device = int(os.environ.get("LOCAL_RANK", "0")) if world > 1 else 0
         engine = self._engine_factory(device)
-        restrict = 0 < self.n_top_var_genes < csr.shape[1]
         try:
             if restrict:
                 engine.stage_raw(csr)

@@ -47,6 +47,27 @@ void release(ddx_ctx* ctx, DevBuf& b) {
     b.cap = 0;
 }
 
+void Options::read_environment() {
+    auto is = [](const char* v, const char* want) { return v && std::strcmp(v, want) == 0; };
+    const char* g = getenv("DDX_SPMM");
+    spmm_lds = !(g && (g[0] == 'g' || g[0] == 'G'));
+    g = getenv("DDX_PCA_GATHER");
+    gather_f32 = !(g && (g[0] == 'f' || g[0] == 'F') && g[1] == '6');
+    g = getenv("DDX_SPMM_GEOM");
+    spmm_geom = is(g, "pair") ? 1 : (is(g, "quad") ? 2 : 0);
+    trip_packed = !is(getenv("DDX_SPMM_TRIP"), "f64");
+    g = getenv("DDX_KNN_SCREEN");
+    knn_bf16 = !(g && g[0] == 'f' && g[1] == '3');
+    g = getenv("DDX_KNN_SAMPLE_TILES");
+    knn_sample_tiles = g ? atoll(g) : 0;
+    row_sums_sequential = getenv("DDX_ROW_SUMS_SEQUENTIAL") != nullptr;
+    knn_debug = getenv("DDX_KNN_DEBUG") != nullptr;
+#ifdef DDX_ABLATION
+    g = getenv("DDX_KNN_EXPERIMENT");
+    knn_ablation = g ? atoi(g) : 0;
+#endif
+}
+
 static bool timing_event(ddx_ctx* ctx, hipEvent_t* ev) {
     if (!ctx->t_free.empty()) {
         *ev = ctx->t_free.back();
@@ -148,6 +169,7 @@ int ddx_create(int device, ddx_ctx** out) {
     ddx_ctx* c = new (std::nothrow) ddx_ctx();
     if (!c) return set_err(nullptr, DDX_E_NOMEM, "out of host memory");
     c->device = device;
+    c->opt.read_environment();
     e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         delete c;
@@ -211,6 +233,7 @@ int ddx_upload_raw(ddx_ctx* ctx, int64_t n_cells, int32_t n_genes, const int64_t
     USE_DEVICE(ctx);
     DDX_TRY(check_csr(ctx, n_cells, n_genes, indptr, indices, data));
     int64_t nnz = indptr[n_cells];
+    if (nnz >= (int64_t)1 << 31) return set_err(ctx, DDX_E_UNSUPPORTED, "more than 2^31-1 stored entries");
     DDX_TRY(ensure(ctx, ctx->raw_indptr, sizeof(int64_t) * (n_cells + 1)));
     DDX_TRY(ensure(ctx, ctx->raw_indices, sizeof(int32_t) * (size_t)(nnz + 1)));
     DDX_TRY(ensure(ctx, ctx->raw_data, sizeof(float) * (size_t)(nnz + 1)));
@@ -221,7 +244,8 @@ int ddx_upload_raw(ddx_ctx* ctx, int64_t n_cells, int32_t n_genes, const int64_t
                                     ctx->stream));
         DDX_HIP(ctx, hipMemcpyAsync(ctx->raw_data.p, data, sizeof(float) * nnz, hipMemcpyHostToDevice, ctx->stream));
     }
-    DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->rawN = 0;
+    DDX_TRY(validate_csr(ctx, ctx->raw_indptr.as<int64_t>(), ctx->raw_indices.as<int32_t>(), ctx->raw_data.as<float>(), n_cells, n_genes));
     ctx->rawN = n_cells;
     ctx->rawG = n_genes;
     ctx->raw_nnz = nnz;

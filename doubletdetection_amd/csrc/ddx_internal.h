@@ -26,15 +26,28 @@ constexpr int kWave = 64;  // gfx950 wavefront
 #endif
 constexpr int kLdsPanelRows = DDX_LDS_PANEL_ROWS;
 constexpr int kGatherPanelRows = 4096;   // measured optimum for the gather kernels (8192: +19 %, 2048: +5 %)
-inline bool spmm_lds() {
-    const char* g = getenv("DDX_SPMM");
-    return !(g && (g[0] == 'g' || g[0] == 'G'));
-}
-
-inline bool pca_gather_f32() {
-    const char* g = getenv("DDX_PCA_GATHER");
-    return !(g && (g[0] == 'f' || g[0] == 'F') && g[1] == '6');
-}
+// Tuning / diagnostic switches.  The environment is read ONCE, when the context is created (ddx_create); a context
+// never looks at the environment again, so a variable changed in the middle of a fit cannot change its results.
+//   DDX_SPMM=gather        L2-gather operator products instead of the LDS-staged ones
+//   DDX_PCA_GATHER=f64     float64 operand gathers (gather kernels only)
+//   DDX_SPMM_GEOM=pair|quad, DDX_SPMM_TRIP=f64   variants of the LDS-staged products
+//   DDX_KNN_SCREEN=f32     float32 MFMA distance screen instead of the bfloat16 split
+//   DDX_KNN_SAMPLE_TILES=n size of the bound pass's subset
+//   DDX_ROW_SUMS_SEQUENTIAL=1  always replay the sequential row sums (skip the exact-integer shortcut)
+//   DDX_KNN_DEBUG=1        print candidate-list statistics
+// Switches that produce wrong results (timing ablations) exist only in builds with -DDDX_ABLATION.
+struct Options {
+    bool spmm_lds = true;
+    bool gather_f32 = true;
+    int spmm_geom = 0;               // 0 auto, 1 pair, 2 quad
+    bool trip_packed = true;
+    bool knn_bf16 = true;
+    int64_t knn_sample_tiles = 0;    // 0 = default rule
+    bool row_sums_sequential = false;
+    bool knn_debug = false;
+    int knn_ablation = 0;            // only honoured under DDX_ABLATION
+    void read_environment();
+};
 
 struct DevBuf {
     void* p = nullptr;
@@ -57,6 +70,7 @@ struct PendingEvent {
 struct ddx_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    ddx::Options opt;
     std::string err;
     int64_t dev_bytes = 0;
 
@@ -218,6 +232,7 @@ int stage_build_graph(ddx_ctx* ctx, int32_t mode);
 int stage_graph_relations(ddx_ctx* ctx, int32_t mode, int32_t* idx_host, double* w_host);
 void assemble_graph(int64_t M, int K, const int32_t* idx, const double* w, std::vector<int64_t>& ip,
                     std::vector<int32_t>& gi, std::vector<double>& gw);
+int validate_csr(ddx_ctx* ctx, const int64_t* indptr, const int32_t* cols, const float* vals, int64_t N, int32_t G);
 int stage_rankings(ddx_ctx* ctx);
 int stage_coarsen_graph(ddx_ctx* ctx, double gamma, int32_t sweeps, int32_t levels);
 int stage_gene_variances(ddx_ctx* ctx, float* var_out);

@@ -825,8 +825,7 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
     float* keys_in = p1 + Mp;
     float* keys_out = keys_in + Mp;
     f4* start4 = reinterpret_cast<f4*>(keys_out + Mp + ((4 - ((3 * (size_t)Mp * CP + 5 * (size_t)Mp) & 3)) & 3));   // 16-byte aligned
-    const char* scr = getenv("DDX_KNN_SCREEN");
-    const bool bf = !(scr && scr[0] == 'f' && scr[1] == '3');          // DDX_KNN_SCREEN=f32 selects the float32 MFMA screen
+    const bool bf = ctx->opt.knn_bf16;                                  // DDX_KNN_SCREEN=f32 selects the float32 MFMA screen
     int32_t* ccount = reinterpret_cast<int32_t*>(reinterpret_cast<float*>(start4) + 4 * (size_t)Mp);   // [Mp] + overflow counter at [Mp]
     int32_t* ids_in = ccount + Mp + 64;
     int32_t* perm = ids_in + Mp;
@@ -850,7 +849,7 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
     // The subset grows with the point count (1/16 of the tiles, at least 512): a fixed-size subset would hold an ever
     // smaller share of the true neighbours, T_q would loosen and the candidate lists overflow.
     int64_t nsamp = std::max<int64_t>(512, ntiles / 16);
-    if (const char* e = getenv("DDX_KNN_SAMPLE_TILES")) nsamp = atoll(e);
+    if (ctx->opt.knn_sample_tiles > 0) nsamp = ctx->opt.knn_sample_tiles;
     if (nsamp < 2 * (int64_t)ceil_div(k, 16) + 8) nsamp = 2 * (int64_t)ceil_div(k, 16) + 8;
     if (nsamp > ntiles) nsamp = ntiles;
     const int64_t stride = 1;
@@ -871,7 +870,7 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
     {
         ScopedTimer t(ctx, "knn_emit");
         const unsigned grid = (unsigned)emit_blocks;
-        const int dbg_mode = getenv("DDX_KNN_EXPERIMENT") ? atoi(getenv("DDX_KNN_EXPERIMENT")) : 0;   // timing experiments only (wrong results)
+        const int dbg_mode = ctx->opt.knn_ablation;     // timing ablations (wrong results): non-zero only in -DDDX_ABLATION builds
         k_knn_window<<<grid, 64, 0, ctx->stream>>>(p1, thr, nrm, Mp, win, reinterpret_cast<unsigned long long*>(ccount + Mp + 2));
         if (bf && CP == 32) k_knn_emit_bf<32><<<grid, 256, 0, ctx->stream>>>(Eb, nrm, start4, thr, Mp, include_self, ccount, cbuf, win, dbg_mode);
         else if (bf) k_knn_emit_bf<64><<<grid, 256, 0, ctx->stream>>>(Eb, nrm, start4, thr, Mp, include_self, ccount, cbuf, win, dbg_mode);
@@ -890,7 +889,7 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
         }
     }
     DDX_HIP(ctx, hipGetLastError());
-    if (getenv("DDX_KNN_DEBUG")) {
+    if (ctx->opt.knn_debug) {
         std::vector<int32_t> h(Mp + 1);
         DDX_HIP(ctx, hipMemcpyAsync(h.data(), ccount, sizeof(int32_t) * (Mp + 1), hipMemcpyDeviceToHost, ctx->stream));
         DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -930,10 +930,11 @@ static const T* prepared_operand(PcaWork& w, const double* X, int64_t R, int ld)
 // no bank conflicts and half the staged-entry reads per entry, but neither the LDS nor the VALU is what bounds the
 // kernel), so pair stays the default where it applies and quad serves the wider sketches.  DDX_SPMM_GEOM=pair|quad
 // forces one of them.
+// switches of the context whose stage is running on this thread (read from the environment once, at ddx_create)
+static thread_local const Options* t_opt = nullptr;
 static bool lds_packed();
 static bool lds_quad(int ld) {
-    const char* e = std::getenv("DDX_SPMM_GEOM");       // read per call: tests switch it between contexts
-    const int mode = !e ? 0 : (std::strcmp(e, "pair") == 0 ? 1 : (std::strcmp(e, "quad") == 0 ? 2 : 0));
+    const int mode = t_opt->spmm_geom;
     if (!lds_packed() || mode == 1) return false;       // (the float64-product trips keep the pair geometry: twice the staging)
     return mode == 2 || ld > 42;
 }
@@ -960,10 +961,7 @@ static int launch_lds_t(ddx_ctx* c, const LdsSpmmArgs& a, unsigned grid, size_t 
 // Default: the eight products of a trip in packed float32, trip sums added in float64 (profiles/tools/spmm_precision.py:
 // 7e-7 per component against the all-float64 run at 50k x 20k, 4e-7 with float64 products; 0.69 instead of 0.84 ms).
 // DDX_SPMM_TRIP=f64 selects float64 products.
-static bool lds_packed() {
-    const char* e = std::getenv("DDX_SPMM_TRIP");
-    return !(e && std::strcmp(e, "f64") == 0);
-}
+static bool lds_packed() { return t_opt->trip_packed; }
 
 template <bool ROWS>
 static int launch_lds(ddx_ctx* c, const LdsSpmmArgs& a, int slots, unsigned grid, size_t lds_bytes) {
@@ -1081,7 +1079,7 @@ static int apply_cols(PcaWork& w, const double* Yrow, double* Wcol) {  // A^T Y 
 // decide whether the LDS-staged products apply and build the row-segment table of the A Q pass
 static int lds_setup(ddx_ctx* ctx, int L, PcaWork& w) {
     w.lds = false;
-    if (!(w.gather32 && spmm_lds())) return DDX_OK;
+    if (!(w.gather32 && ctx->opt.spmm_lds)) return DDX_OK;
     const int64_t M = ctx->M;
     const int32_t H = ctx->H;
     const int ld = (L + 3) & ~3;
@@ -1118,7 +1116,7 @@ static int pca_work_init(ddx_ctx* ctx, int L, PcaWork& w) {
     w.partial = ctx->pcaPartial.as<double>();
     w.small = ctx->pcaSmall.as<double>();
     w.flag = ctx->pcaVec.as<int>();
-    w.gather32 = pca_gather_f32();
+    w.gather32 = ctx->opt.gather_f32;
     w.lds = false;
     const int64_t maxR = M > H ? M : (int64_t)H;
     DDX_TRY(ensure(ctx, ctx->pcaOp, sizeof(double) * (size_t)maxR * (L + 4)));
@@ -1131,6 +1129,7 @@ static int pca_work_init(ddx_ctx* ctx, int L, PcaWork& w) {
 // for a caller-supplied block of n <= 64 vectors.  Always gathers float64: this entry point serves the
 // exact-PCA regimes, where the Gram matrix is formed column block by column block.
 int stage_operator_apply(ddx_ctx* ctx, int32_t mode, const double* X, int32_t n, double* out) {
+    t_opt = &ctx->opt;
     ctx->g_nodes = -1;
     const int64_t M = ctx->M;
     const int32_t H = ctx->H;
@@ -1162,6 +1161,7 @@ int stage_operator_apply(ddx_ctx* ctx, int32_t mode, const double* X, int32_t n,
 }
 
 int stage_pca(ddx_ctx* ctx, int32_t C, int32_t oversample, int32_t n_iter, const double* q0, int64_t q0_rows) {
+    t_opt = &ctx->opt;
     ctx->g_nodes = -1;   // a graph left on the device lives in the panel buffer this stage overwrites
     const int L = C + oversample;
     if (L > kMaxL) return set_err(ctx, DDX_E_UNSUPPORTED, "sketch width %d exceeds %d", L, kMaxL);
@@ -1194,7 +1194,7 @@ int stage_pca(ddx_ctx* ctx, int32_t C, int32_t oversample, int32_t n_iter, const
     {
         // DDX_PCA_GATHER=f64 gathers the float64 iterates themselves; the default gathers a float32-rounded
         // copy (float64 products and sums), which moves half the bytes through L2
-        w.gather32 = pca_gather_f32();
+        w.gather32 = ctx->opt.gather_f32;
     }
     w.M = M;
     w.H = H;
@@ -1312,7 +1312,9 @@ int stage_pca(ddx_ctx* ctx, int32_t C, int32_t oversample, int32_t n_iter, const
     ctx->have_knn = false;
     if (hflag) {
         // not fatal: the sketch is wider than the numerical rank; the leading components are unaffected
-        ctx->err = "warning: rank-deficient sketch (pivot floored in Cholesky-QR)";
+        ctx->err = "rank-deficient sketch (a pivot was floored in the Cholesky-QR of the randomized PCA): the matrix has "
+                   "fewer independent directions than n_components + n_oversamples; trailing components are arbitrary";
+        return DDX_W_RANK;
     }
     return DDX_OK;
 }

@@ -15,6 +15,40 @@
 
 namespace ddx {
 
+// Canonical-form check of an uploaded CSR (one wave per row): column ids inside [0, G), strictly increasing inside a
+// row (sorted, no duplicates -- the doublet merge and its binary searches rely on it), finite values.
+// flags: bit 0 non-finite value, bit 1 column out of range, bit 2 unsorted or duplicate column.
+__global__ void __launch_bounds__(256) k_validate_csr(const int64_t* __restrict__ indptr, const int32_t* __restrict__ cols,
+                                                      const float* __restrict__ vals, int64_t N, int32_t G, int* __restrict__ flags) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= N) return;
+    const int64_t b = indptr[row], e = indptr[row + 1];
+    int bad = 0;
+    for (int64_t p = b + lane; p < e; p += 64) {
+        const int32_t c = cols[p];
+        const float v = vals[p];
+        if (!(fabsf(v) <= 3.4028234663852886e38f)) bad |= 1;      // NaN or infinity
+        if (c < 0 || c >= G) bad |= 2;
+        if (p > b && cols[p - 1] >= c) bad |= 4;
+    }
+    if (bad) atomicOr(flags, bad);
+}
+
+int validate_csr(ddx_ctx* ctx, const int64_t* indptr, const int32_t* cols, const float* vals, int64_t N, int32_t G) {
+    DDX_TRY(ensure(ctx, ctx->median, 256));
+    int* flag = ctx->median.as<int>() + 12;
+    int h = 0;
+    DDX_HIP(ctx, hipMemsetAsync(flag, 0, sizeof(int), ctx->stream));
+    k_validate_csr<<<(unsigned)ceil_div(N, 4), 256, 0, ctx->stream>>>(indptr, cols, vals, N, G, flag);
+    DDX_HIP(ctx, hipMemcpyAsync(&h, flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (h & 1) return set_err(ctx, DDX_E_ARG, "counts contain a non-finite value (NaN or infinity)");
+    if (h & 2) return set_err(ctx, DDX_E_ARG, "CSR column index outside [0, %d)", G);
+    if (h & 4) return set_err(ctx, DDX_E_ARG, "CSR rows must hold strictly increasing column indices (sorted, no duplicates)");
+    return DDX_OK;
+}
+
 __global__ void k_colptr_i32(const int32_t* __restrict__ keys, int64_t n, int32_t G, int64_t* __restrict__ colptr) {
     int32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j > G) return;

@@ -433,6 +433,8 @@ int stage_upload_counts(ddx_ctx* ctx, int64_t N, int32_t H, const int64_t* indpt
             DDX_HIP(ctx, hipMemcpyAsync(ctx->aug_raw.p, data, sizeof(float) * nnz, hipMemcpyHostToDevice, ctx->stream));
         }
         ctx->h_indptr.assign(indptr, indptr + N + 1);
+        ctx->have_counts = false;
+        DDX_TRY(validate_csr(ctx, ctx->aug_indptr.as<int64_t>(), ctx->aug_indices.as<int32_t>(), ctx->aug_raw.as<float>(), N, H));
     }
     ctx->N = N;
     ctx->H = H;
@@ -450,7 +452,7 @@ int stage_upload_counts(ddx_ctx* ctx, int64_t N, int32_t H, const int64_t* indpt
     DDX_TRY(ensure(ctx, ctx->csc_o_row, sizeof(int32_t) * (size_t)(nnz + 1)));
     DDX_TRY(ensure(ctx, ctx->csc_o_raw, sizeof(float) * (size_t)(nnz + 1)));
     DDX_TRY(ensure(ctx, ctx->csc_o_x, sizeof(float) * (size_t)(nnz + 1)));
-    ctx->panel_rows = (spmm_lds() && pca_gather_f32()) ? kLdsPanelRows : kGatherPanelRows;
+    ctx->panel_rows = (ctx->opt.spmm_lds && ctx->opt.gather_f32) ? kLdsPanelRows : kGatherPanelRows;
     ctx->P_o = (int32_t)ceil_div(N, ctx->panel_rows);
     DDX_TRY(build_csc(ctx, 0, nnz, 0, N, 0, ctx->P_o, ctx->csc_o_colptr, ctx->csc_o_row, ctx->csc_o_raw));
     {
@@ -462,7 +464,7 @@ int stage_upload_counts(ddx_ctx* ctx, int64_t N, int32_t H, const int64_t* indpt
         k_counts_exact<<<(unsigned)ceil_div(span, 256), 256, 0, ctx->stream>>>(ctx->aug_raw.as<float>(), nnz, ctx->lib32.as<float>(), N, flag);
         DDX_HIP(ctx, hipMemcpyAsync(&exact, flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        ctx->counts_exact = exact != 0 && !getenv("DDX_ROW_SUMS_SEQUENTIAL");
+        ctx->counts_exact = exact != 0 && !ctx->opt.row_sums_sequential;
     }
     DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->have_counts = true;

@@ -9,7 +9,8 @@
  *
  * Conventions
  *   - plain C types only; caller-owned host buffers are passed as pointers + explicit sizes;
- *   - every function returns 0 on success, a negative DDX_E_* code otherwise;
+ *   - every function returns 0 on success, a negative DDX_E_* code on failure, a positive DDX_W_* code on success
+ *     with a warning;
  *     ddx_last_error(ctx) returns a human-readable message for the last failure on that context
  *     (ctx == NULL: last failure of a context-less call on the calling thread);
  *   - a ddx_ctx owns one GPU, one HIP stream and all device buffers; contexts are independent and
@@ -38,6 +39,8 @@ extern "C" {
 #define DDX_E_NOMEM -3    /* allocation failure */
 #define DDX_E_NUMERIC -4  /* numerical breakdown (e.g. rank-deficient sketch) */
 #define DDX_E_UNSUPPORTED -5
+/* positive codes: the call succeeded and its results are valid; ddx_last_error(ctx) holds a warning text */
+#define DDX_W_RANK 1      /* ddx_pca: the sketch is wider than the numerical rank of the matrix */
 
 typedef struct ddx_ctx ddx_ctx;
 

@@ -329,11 +329,14 @@ def jaccard_graph(idx: np.ndarray, prune: bool) -> sp.csr_matrix:
     weight J_ij * J_ji; prune=False averages (J + J^T)/2.  Returned symmetric, no explicit zeros.
     """
     m, k = idx.shape
-    sets = [set(row.tolist()) for row in idx]
     rows = np.repeat(np.arange(m), k)
-    cols = idx.ravel()
-    shared = np.fromiter((len(sets[i] & sets[j]) for i, j in zip(rows, cols)), dtype=np.float64,
-                         count=m * k)
+    cols = np.asarray(idx).ravel()
+    # |N(i) & N(j)| for every pair: (B B^T)_ij with B the m x m kNN indicator; only the kNN positions are kept
+    B = sp.csr_matrix((np.ones(m * k, dtype=np.float32), (rows, cols)), shape=(m, m))
+    B.sum_duplicates()
+    B.data[:] = 1.0
+    shared_all = (B @ B.T).tocsr()
+    shared = np.asarray(shared_all[rows, cols]).ravel().astype(np.float64)
     w = shared / (2.0 * k - shared)
     J = sp.coo_matrix((w, (rows, cols)), shape=(m, m)).tocsr()
     if prune:
@@ -459,20 +462,24 @@ def cluster_embedding(emb: np.ndarray, algorithm: str, clustering_kwargs: dict, 
         k = int(kw.get("k", 30))
         idx, _ = knn_fn(emb, k, include_self=False)
         G = jaccard_graph(idx, prune=bool(kw.get("prune", True)))
-        gamma = float(kw.get("resolution_parameter", 1.0))
-        seed = kw.get("seed", None)
-        seed = random_state if seed is None else int(seed)
-        lab = louvain_fn(G.indptr, G.indices, G.data, gamma, seed)
+        if kw.get("clustering_algo", "louvain") == "leiden":
+            # phenograph hands resolution_parameter / seed to leidenalg only
+            seed = kw.get("seed", None)
+            seed = random_state if seed is None else int(seed)
+            lab = louvain_ref.leiden(G.indptr, G.indices, G.data, float(kw.get("resolution_parameter", 1.0)), seed)
+        else:
+            # the Louvain binaries take neither a resolution nor a seed: gamma = 1, deterministic seed = random_state
+            lab = louvain_fn(G.indptr, G.indices, G.data, 1.0, int(random_state))
         return relabel_by_size(lab, int(kw.get("min_cluster_size", 10)))
     idx, dist = knn_fn(emb, 10, include_self=True)
     gamma = float(kw.get("resolution", 4))
-    if algorithm == "leiden":
-        # sc.tl.leiden runs on the umap connectivities (use_weights=True); Leiden specification (part B')
-        G = umap_connectivities(idx, dist)
+    leiden = algorithm == "leiden"
+    # sc.tl.leiden runs on the umap connectivities (use_weights=True); sc.tl.louvain ignores the weights
+    # (use_weights=False) unless told otherwise
+    G = umap_connectivities(idx, dist) if kw.get("use_weights", leiden) else union_knn_graph(idx)
+    if leiden:
         lab = louvain_ref.leiden(G.indptr, G.indices, G.data, gamma, int(random_state))
     else:
-        # sc.tl.louvain ignores the weights (use_weights=False)
-        G = union_knn_graph(idx)
         lab = louvain_fn(G.indptr, G.indices, G.data, gamma, int(random_state))
     return relabel_by_size(lab, None)
 

@@ -183,3 +183,89 @@ def test_reference_plot_functions_accept_the_classifier(monkeypatch):
         assert fig2.axes, "threshold() drew nothing"
     import matplotlib.pyplot as plt
     plt.close("all")
+
+
+def test_clustering_kwargs_never_silently_ignored():
+    """Every accepted clustering keyword either shapes the plan the way it shapes the upstream call, is a no-op
+    upstream too, or raises -- never a silent difference from the reference (dd.py:116-119,320-322,337-342)."""
+    def plan(algo, **kw):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            return BoostClassifier(clustering_algorithm=algo, clustering_kwargs=kw, random_state=3)._cluster_plan()
+
+    # phenograph defaults: k=30, no self, pruned Jaccard graph, Louvain binaries take no resolution and no seed
+    assert plan("phenograph") == (30, False, 0, 1.0, 3, 10, False)
+    assert plan("phenograph", resolution_parameter=2.5, seed=9) == (30, False, 0, 1.0, 3, 10, False)
+    assert plan("phenograph", clustering_algo="leiden", resolution_parameter=2.5, seed=9, prune=False, k=15,
+                min_cluster_size=4) == (15, False, 1, 2.5, 9, 4, True)
+    assert plan("phenograph", nn_method="brute", n_jobs=4, q_tol=1e-4, louvain_time_limit=10)[:3] == (30, False, 0)
+    for bad in ({"directed": True}, {"jaccard": False}, {"primary_metric": "cosine"}, {"nn_method": "faiss"},
+                {"partition_type": object()}, {"clustering_algo": "leiden", "n_iterations": 3},
+                {"clustering_algo": "leiden", "use_weights": False}):
+        with pytest.raises(NotImplementedError):
+            plan("phenograph", **bad)
+    with pytest.raises(ValueError):
+        plan("phenograph", clustering_algo="spectral")
+    # scanpy: louvain ignores weights unless asked, leiden uses them unless asked not to
+    assert plan("louvain") == (10, True, 2, 4.0, 3, None, False)
+    assert plan("louvain", use_weights=True, resolution=1.5) == (10, True, 3, 1.5, 3, None, False)
+    assert plan("leiden") == (10, True, 3, 4.0, 3, None, True)
+    assert plan("leiden", use_weights=False) == (10, True, 2, 4.0, 3, None, True)
+    for algo, bad in (("louvain", {"directed": True}), ("louvain", {"restrict_to": ("a", ["1"])}),
+                      ("leiden", {"adjacency": 1}), ("louvain", {"obsp": "x"}), ("leiden", {"neighbors_key": "n"}),
+                      ("louvain", {"partition_type": object()}), ("louvain", {"flavor": "igraph"}),
+                      ("leiden", {"flavor": "igraph"}), ("leiden", {"n_iterations": 2})):
+        with pytest.raises(NotImplementedError):
+            plan(algo, **bad)
+    with pytest.raises(TypeError):
+        plan("louvain", n_iterations=2)            # sc.tl.louvain has no such keyword
+
+
+def test_device_limits_raise_before_any_upload():
+    """n_components / k beyond what the device kernels hold fail up front with a clear message (not mid-fit)."""
+    class Untouchable:
+        def __init__(self, device):
+            raise AssertionError("an engine was created before the limits were checked")
+
+    counts = np.random.default_rng(0).poisson(1.0, size=(900, 700))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for kw in (dict(n_components=55, n_top_var_genes=0), dict(n_components=70, n_top_var_genes=0),
+                   dict(clustering_kwargs={"k": 65})):
+            clf = BoostClassifier(n_iters=2, **kw)
+            clf._engine_factory = Untouchable
+            with pytest.raises(NotImplementedError, match="device"):
+                clf.fit(counts)
+
+
+def test_non_canonical_csr_is_canonicalised(monkeypatch):
+    """Duplicate / unsorted column entries are summed and sorted on the way in, as scipy's own indexing and
+    addition (dd.py:174-176,397-399) would do; the caller's matrix is left untouched."""
+    import scipy.sparse as sp
+
+    seen = {}
+
+    class Recorder:
+        def __init__(self, device):
+            pass
+
+        def close(self):
+            pass
+
+        def upload(self, csr):
+            seen["csr"] = csr
+            raise RuntimeError("stop here")
+
+    indptr = np.array([0, 3, 5], dtype=np.int32)
+    indices = np.array([2, 0, 2, 1, 1], dtype=np.int32)
+    data = np.array([1, 2, 3, 4, 5], dtype=np.float32)
+    x = sp.csr_matrix((data, indices, indptr), shape=(2, 3))
+    assert not x.has_canonical_format
+    clf = BoostClassifier(n_iters=2, n_top_var_genes=0, clustering_algorithm="louvain")
+    clf._engine_factory = Recorder
+    with pytest.raises(RuntimeError, match="stop here"):
+        clf.fit(x)
+    got = seen["csr"]
+    assert got.has_canonical_format and got.dtype == np.float32
+    np.testing.assert_array_equal(got.toarray(), [[2, 0, 4], [0, 9, 0]])
+    np.testing.assert_array_equal(x.indices, indices)           # caller's arrays untouched
