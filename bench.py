@@ -210,7 +210,9 @@ def main():
             "config": {"workload": f"synthetic {N}x{G} counts, {X.nnz / (N * G):.3%} nnz, n_iters={args.iters}, "
                                    f"n_top_var_genes=10000, n_components=30, boost_rate=0.25, "
                                    f"clustering_algorithm={args.algorithm}, standard_scaling={args.scaling}",
-                       "n_iters": args.iters, "sharding": f"iterations over {world} rank(s)",
+                       "n_iters": args.iters,
+                       "sharding": f"iterations over {world} rank(s) x {getattr(clf, '_lanes_used', 1)} device context(s) "
+                                   "(streams) per GPU",
                        "host_threads": os.cpu_count()},
             "roofline": roofline,
             "roofline_top_kernels": roofline_all,

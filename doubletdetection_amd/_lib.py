@@ -43,6 +43,7 @@ _SIGNATURES = {
     "ddx_gene_variances": (C.c_int, [C.c_void_p, c_f32_p]),
     "ddx_select_columns": (C.c_int, [C.c_void_p, c_i64_p, C.c_int32]),
     "ddx_upload_counts": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, c_i64_p, c_i32_p, c_f32_p]),
+    "ddx_clone_counts": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ddx_get_counts_nnz": (C.c_int, [C.c_void_p, c_i64_p]),
     "ddx_get_counts": (C.c_int, [C.c_void_p, c_i64_p, c_i32_p, c_f32_p]),
     "ddx_get_lib_size": (C.c_int, [C.c_void_p, c_f32_p]),
@@ -326,6 +327,11 @@ class Context:
         d = np.ascontiguousarray(csr.data, dtype=np.float32)
         self._c(self._lib.ddx_upload_counts(self._h, csr.shape[0], csr.shape[1], _p(ip, c_i64_p), _p(ix, c_i32_p), _p(d, c_f32_p)))
         self.N, self.H, self.S = int(csr.shape[0]), int(csr.shape[1]), 0
+
+    def clone_counts_from(self, src: "Context"):
+        """Device-to-device copy of the resident counts of another context on the same GPU (ddx_clone_counts)."""
+        self._c(self._lib.ddx_clone_counts(self._h, src._h))
+        self.N, self.H, self.S = src.N, src.H, 0
 
     def get_counts(self):
         import scipy.sparse as sp

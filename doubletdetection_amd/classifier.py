@@ -113,27 +113,32 @@ class _HipEngine:
     def select_columns(self, cols):
         self.ctx.select_columns(cols)
 
+    def clone_from(self, other):
+        """Take over the resident counts of another engine on the same GPU (device-to-device, ddx_clone_counts)."""
+        self.ctx.clone_counts_from(other.ctx)
+
     def run_iteration(self, parents, pseudocount, standard_scaling, n_components, q0, knn_k, include_self,
-                      graph_mode, gamma=None):
+                      graph_mode, gamma=None, pca_lock=None):
         """One boosting iteration on the device.  Returns the symmetric graph (indptr, indices, weights), or --
         when ``gamma`` is given -- the result of the synchronous pre-sweeps run on the device:
-        (member, coarse indptr, coarse indices, coarse weights)."""
+        (member, coarse indptr, coarse indices, coarse weights).
+
+        ``pca_lock``: the contexts (streams) of one GPU take turns in the PCA stage.  Its operator products fill every
+        CU by themselves, so two of them side by side gain nothing; what the second stream buys is that its
+        latency-bound stages (graph construction, community pre-sweeps, sorts, the small factorisations) run in the
+        shadow of the other stream's products."""
         c = self.ctx
         c.create_doublets(parents)
         c.lognormalise(pseudocount)
         if standard_scaling:
             c.scale(15.0)
-        if isinstance(q0, str) and q0 == "arpack":
-            self._pca_arpack(n_components, self._arpack_seed)
-        elif q0 is None:
-            self._pca_exact(n_components)
-        else:
-            # every iteration of a fit starts from the same seeded matrix: upload it once per array object
-            if getattr(self, "_q0_resident", None) is q0:
-                c.pca(n_components, None, q0_rows=q0.shape[0])
-            else:
-                c.pca(n_components, q0)
-                self._q0_resident = q0
+        if pca_lock is not None:
+            pca_lock.acquire()
+        try:
+            self._pca(n_components, q0)
+        finally:
+            if pca_lock is not None:
+                pca_lock.release()
         c.knn(knn_k, include_self)
         if gamma is None:
             return c.build_graph(graph_mode)  # symmetric CSR assembled on the device
@@ -144,6 +149,19 @@ class _HipEngine:
             if err.code != _lib.E_UNSUPPORTED:
                 raise
             return c.fetch_graph()
+
+    def _pca(self, n_components, q0):
+        c = self.ctx
+        if isinstance(q0, str) and q0 == "arpack":
+            self._pca_arpack(n_components, self._arpack_seed)
+        elif q0 is None:
+            self._pca_exact(n_components)
+        elif getattr(self, "_q0_resident", None) is q0:
+            # every iteration of a fit starts from the same seeded matrix: it is uploaded once per array object
+            c.pca(n_components, None, q0_rows=q0.shape[0])
+        else:
+            c.pca(n_components, q0)
+            self._q0_resident = q0
 
     def _pca_arpack(self, n_components, seed):
         """pseudocount == 1 without scaling keeps the matrix sparse upstream and switches sc.tl.pca to
@@ -226,8 +244,12 @@ class BoostClassifier:
         standard_scaling: Standard-scale the normalised matrix before PCA.
         n_jobs: host worker threads for community detection (-1: all cores).
 
-    Build-only keyword (after the reference's, so positional use is unaffected):
+    Build-only keywords (after the reference's, so positional use is unaffected):
         device: GPU ordinal; default ``LOCAL_RANK`` under torch.distributed, else 0.
+        devices: list of GPU ordinals driven by THIS process (one host thread and at least one device context per GPU;
+            boosting iterations are dealt out over them).  Default: ``[device]``.
+        streams_per_device: device contexts (HIP streams) per GPU, each running its own boosting iterations; the
+            once-per-fit prologue is shared by device-to-device copies.  Default 2 (``DDX_STREAMS`` overrides).
 
     Attributes after ``fit`` / ``predict``: ``all_log_p_values_``, ``all_scores_``, ``communities_``,
     ``labels_``, ``parents_``, ``suggested_score_cutoff_``, ``synth_communities_``, ``top_var_genes_``,
@@ -253,6 +275,8 @@ class BoostClassifier:
         n_jobs: int = 1,
         *,
         device: int | None = None,
+        devices: list | None = None,
+        streams_per_device: int | None = None,
     ) -> None:
         if clustering_algorithm not in _ALGORITHMS:
             raise ValueError("Clustering algorithm needs to be one of ['louvain', 'phenograph', 'leiden']")
@@ -267,6 +291,8 @@ class BoostClassifier:
         self.standard_scaling = standard_scaling
         self.n_jobs = n_jobs
         self.device = device
+        self.devices = None if devices is None else [int(d) for d in devices]
+        self.streams_per_device = streams_per_device
         # one Generator for the lifetime of the object: a second fit() continues the stream, as upstream
         self.rng = np.random.default_rng(self.random_state)
 
@@ -437,34 +463,38 @@ class BoostClassifier:
             # upstream's custom-normalizer branch cannot complete either (it references variables that
             # only the default branch defines, doubletdetection.py:301,372 -> UnboundLocalError)
             raise NotImplementedError("a user `normalizer` callable cannot run on the GPU path; leave it None")
-        rank, world, backend = _dist_info()
-        staged = getattr(self, "_staged", None)
-        if staged is not None and staged[0] is raw_counts:
-            _, raw_counts, engine, device, restrict = staged          # counts already resident in HBM
-        else:
-            self._drop_stage()
-            raw_counts, engine, device, restrict = self._stage(raw_counts, rank, world)
-        self._staged = None
         import time
 
         t_fit0 = time.perf_counter()
-        num_genes = self.n_top_var_genes if restrict else raw_counts.shape[1]
+        rank, world, backend = _dist_info()
+        staged = getattr(self, "_staged", None)
+        if staged is not None and staged[0] is raw_counts:
+            _, csr, leaders, restrict = staged                        # counts already resident in HBM
+            t_fit0 = time.perf_counter()
+        else:
+            self._drop_stage()
+            csr, leaders, restrict = self._stage(raw_counts, rank, world)
+        self._staged = None
+        t_staged = time.perf_counter()
+        num_cells = csr.shape[0]
+        num_genes = self.n_top_var_genes if restrict else csr.shape[1]
         drawer = ThreadPoolExecutor(max_workers=1)
-        draws = drawer.submit(self._draw, raw_counts.shape[0], num_genes)     # overlaps the device prologue
+        draws = drawer.submit(self._draw, num_cells, num_genes)     # overlaps the device prologue
+        lanes = []
         try:
+            devs = list(leaders)
             if restrict:
-                # dd.py:165-176 -- float32 variances on the device in scipy's evaluation order; the
-                # ordering itself stays numpy's argsort so ties fall exactly as they do upstream
-                gene_variances = engine.gene_variances()
+                # dd.py:165-176 -- float32 variances on the device in scipy's evaluation order (identical on every GPU, so
+                # one computes them); the ordering itself stays numpy's argsort so ties fall exactly as they do upstream
+                gene_variances = leaders[devs[0]].gene_variances()
                 self.top_var_genes_ = np.argsort(gene_variances)[-self.n_top_var_genes:]
-                engine.select_columns(self.top_var_genes_)
-                num_genes = self.n_top_var_genes
-            else:
-                engine.upload(raw_counts)
-                num_genes = raw_counts.shape[1]
-            t_prologue = time.perf_counter() - t_fit0
-            self._fit_resident(engine, raw_counts.shape[0], num_genes, rank, world, backend, device, draws)
+                self._on_each(leaders.values(), lambda e: e.select_columns(self.top_var_genes_))
+            n_mine = len([i for i in range(self.n_iters) if i % world == rank])
+            lanes = self._open_lanes(leaders, n_mine)
+            t_prologue = time.perf_counter() - t_staged
+            self._fit_resident(lanes, num_cells, num_genes, rank, world, backend, draws)
             self._host_timings["prologue"] = t_prologue
+            self._host_timings["stage"] = t_staged - t_fit0
         finally:
             t0 = time.perf_counter()
             try:
@@ -472,7 +502,8 @@ class BoostClassifier:
             except Exception:
                 pass
             drawer.shutdown(wait=True)
-            engine.close()
+            for e in {id(e): e for e in list(leaders.values()) + [ln[1] for ln in lanes]}.values():
+                e.close()
         self._host_timings["close"] = time.perf_counter() - t0
         self._host_timings["fit_total"] = time.perf_counter() - t_fit0
         return self
@@ -494,26 +525,80 @@ class BoostClassifier:
             raw_counts.sum_duplicates()
         return raw_counts
 
+    # ---- devices, streams, lanes ---------------------------------------------------------------------------------
+    def _device_list(self, world):
+        if self.devices is not None:
+            if not self.devices:
+                raise ValueError("devices must name at least one GPU")
+            return list(dict.fromkeys(self.devices))
+        if self.device is not None:
+            return [int(self.device)]
+        return [int(os.environ.get("LOCAL_RANK", "0")) if world > 1 else 0]
+
+    def _stream_count(self):
+        n = self.streams_per_device
+        if n is None:
+            n = int(os.environ.get("DDX_STREAMS", "2"))
+        if n < 1:
+            raise ValueError("streams_per_device must be at least 1")
+        return int(n)
+
+    @staticmethod
+    def _on_each(items, fn):
+        """fn(item) for every item, on one host thread per item when there are several (ctypes calls drop the GIL, so
+        the GPUs of a node upload / compute side by side); the first exception is re-raised."""
+        items = list(items)
+        if len(items) <= 1:
+            return [fn(it) for it in items]
+        with ThreadPoolExecutor(max_workers=len(items)) as pool:
+            return [f.result() for f in [pool.submit(fn, it) for it in items]]
+
     def _stage(self, raw_counts, rank, world):
+        """Validate the input and make it resident on every GPU of this process: one leader context per GPU."""
         csr = self._coerce(raw_counts)
         restrict = 0 < self.n_top_var_genes < csr.shape[1]
         self._check_device_limits(csr.shape[0], self.n_top_var_genes if restrict else csr.shape[1])
-        device = self.device
-        if device is None:
-            device = int(os.environ.get("LOCAL_RANK", "0")) if world > 1 else 0
-        engine = self._engine_factory(device)
+        leaders = {}
         try:
-            if restrict:
-                engine.stage_raw(csr)
+            for dev in self._device_list(world):
+                leaders[dev] = self._engine_factory(dev)
+            self._on_each(leaders.values(), (lambda e: e.stage_raw(csr)) if restrict else (lambda e: e.upload(csr)))
         except Exception:
-            engine.close()
+            for e in leaders.values():
+                e.close()
             raise
-        return csr, engine, device, restrict
+        return csr, leaders, restrict
+
+    def _open_lanes(self, leaders, n_mine):
+        """[(device, engine)]: the leader context of every GPU plus streams_per_device - 1 followers that copy its resident
+        counts device-to-device.  Lanes are ordered stream-major so that a short job reaches every GPU first."""
+        streams = self._stream_count()
+        needed = max(1, n_mine)                  # a lane without an iteration to run is not opened
+        lanes = [(dev, eng) for dev, eng in leaders.items()]
+        followers = []
+        for k in range(1, streams):
+            for dev, eng in leaders.items():
+                if len(lanes) + len(followers) >= needed:
+                    break
+                followers.append((dev, eng))
+        made = []
+        try:
+            for dev, leader in followers:
+                f = self._engine_factory(dev)
+                made.append((dev, f))
+            # a leader must be idle while it is copied: the followers of different GPUs copy side by side
+            self._on_each(list(zip(made, followers)), lambda p: p[0][1].clone_from(p[1][1]))
+        except Exception:
+            for _, f in made:
+                f.close()
+            raise
+        return lanes + made
 
     def _drop_stage(self):
         staged = getattr(self, "_staged", None)
         if staged is not None:
-            staged[2].close()
+            for e in staged[2].values():
+                e.close()
         self._staged = None
 
     def stage(self, raw_counts) -> "BoostClassifier":
@@ -522,8 +607,8 @@ class BoostClassifier:
         region.  ``fit`` on any other object simply stages that object itself."""
         rank, world, _ = _dist_info()
         self._drop_stage()
-        csr, engine, device, restrict = self._stage(raw_counts, rank, world)
-        self._staged = (raw_counts, csr, engine, device, restrict)
+        csr, leaders, restrict = self._stage(raw_counts, rank, world)
+        self._staged = (raw_counts, csr, leaders, restrict)
         return self
 
     def _draw(self, num_cells, num_genes):
@@ -544,12 +629,13 @@ class BoostClassifier:
             q0 = q0.astype(np.float32).astype(np.float64)
         return all_parents, q0
 
-    def _fit_resident(self, engine, num_cells, num_genes, rank, world, backend, device, draws=None):
+    def _fit_resident(self, lanes, num_cells, num_genes, rank, world, backend, draws=None):
+        import threading
+        import time
+
         self._num_cells, self._num_genes = num_cells, num_genes
         num_synths = int(self.boost_rate * num_cells)
         n_iters = self.n_iters
-
-        import time
 
         t_setup0 = time.perf_counter()
         all_parents, q0_drawn = draws.result() if draws is not None else self._draw(num_cells, num_genes)
@@ -563,7 +649,8 @@ class BoostClassifier:
                 raise ValueError(f"n_components={n_comp} must be strictly less than min(n_samples, n_features)="
                                  f"{min(M, self._num_genes)} with svd_solver='arpack'")
             q0 = "arpack"
-            engine._arpack_seed = self.random_state
+            for _, eng in lanes:
+                eng._arpack_seed = self.random_state
         elif regime == "randomized":
             q0 = q0_drawn
         else:
@@ -571,41 +658,57 @@ class BoostClassifier:
 
         knn_k, include_self, graph_mode, gamma, seed, min_cluster_size, leiden = self._cluster_plan()
 
+        # iteration i belongs to rank i % world (one process per GPU under torch.distributed); inside this process the
+        # rank's iterations are dealt out over the lanes (GPUs x streams)
         mine = [i for i in range(n_iters) if i % world == rank]
+        lanes = lanes[:max(1, len(mine))]
+        share = [mine[k::len(lanes)] for k in range(len(lanes))]
+        pca_locks = {dev: (threading.Lock() if sum(1 for d, _ in lanes if d == dev) > 1 else None) for dev, _ in lanes}
         workers = self.n_jobs if self.n_jobs and self.n_jobs > 0 else (os.cpu_count() or 1)
         local = {}
         host = {"draws": time.perf_counter() - t_setup0, "device_stages": 0.0, "wait_workers": 0.0, "graph_assembly": 0.0, "louvain": 0.0, "score": 0.0}
+        t_dev0 = time.perf_counter()
         with ThreadPoolExecutor(max_workers=max(1, min(workers, max(1, len(mine))))) as pool:
             pending = {}
-            for i in mine:
-                if self.verbose:
-                    print("Iteration {:3}/{}".format(i + 1, n_iters))
-                t0 = time.perf_counter()
-                graph = engine.run_iteration(all_parents[i], self.pseudocount, self.standard_scaling, n_comp,
-                                             q0, knn_k, include_self, graph_mode, gamma)
-                host["device_stages"] += time.perf_counter() - t0
-                pending[i] = pool.submit(self._cluster_and_score, graph, gamma, seed, min_cluster_size, num_cells, leiden)
+
+            def drive(k):
+                dev, engine = lanes[k]
+                for i in share[k]:
+                    if self.verbose:
+                        print("Iteration {:3}/{}".format(i + 1, n_iters))
+                    graph = engine.run_iteration(all_parents[i], self.pseudocount, self.standard_scaling, n_comp,
+                                                 q0, knn_k, include_self, graph_mode, gamma, pca_locks[dev])
+                    pending[i] = pool.submit(self._cluster_and_score, graph, gamma, seed, min_cluster_size, num_cells, leiden)
+
+            self._on_each(range(len(lanes)), drive)
+            host["device_stages"] = time.perf_counter() - t_dev0
             t0 = time.perf_counter()
-            for i, fut in pending.items():
-                full, scores, logp, (tg, tl, ts) = fut.result()
+            for i in mine:
+                full, scores, logp, (tg, tl, ts) = pending[i].result()
                 local[i] = (full, scores, logp)
                 host["graph_assembly"] += tg
                 host["louvain"] += tl
                 host["score"] += ts
             host["wait_workers"] = time.perf_counter() - t0
         self._host_timings = host
-        self._device_timings = engine.timings() if hasattr(engine, "timings") else {}
-        if mine and hasattr(engine, "aug_nnz"):
-            self._last_nnz_aug = engine.aug_nnz()     # stored entries of the last augmented matrix
-        if mine and hasattr(engine, "knn_window_fraction"):
-            self._last_knn_window = engine.knn_window_fraction()   # share of the tile pairs the last kNN screened
+        self._lanes_used = len(lanes)
+        self._device_timings = {}
+        for _, engine in lanes:
+            for name, (launches, ms) in (engine.timings() if hasattr(engine, "timings") else {}).items():
+                a = self._device_timings.get(name, (0, 0.0))
+                self._device_timings[name] = (a[0] + launches, a[1] + ms)
+        lead = lanes[0][1]
+        if mine and hasattr(lead, "aug_nnz"):
+            self._last_nnz_aug = lead.aug_nnz()     # stored entries of the last augmented matrix
+        if mine and hasattr(lead, "knn_window_fraction"):
+            self._last_knn_window = lead.knn_window_fraction()   # share of the tile pairs the last kNN screened
 
         t_asm0 = time.perf_counter()
         self.all_scores_ = np.zeros((n_iters, num_cells))
         self.all_log_p_values_ = np.zeros((n_iters, num_cells))
         all_communities = np.zeros((n_iters, num_cells))
         all_synth_communities = np.zeros((n_iters, num_synths))
-        rows = self._gather_rows(local, mine, n_iters, num_cells, num_synths, rank, world, backend, device)
+        rows = self._gather_rows(local, mine, n_iters, num_cells, num_synths, rank, world, backend, lanes[0][0])
         for i in range(n_iters):
             full, scores, logp = rows[i]
             self.all_scores_[i] = scores
@@ -657,8 +760,9 @@ class BoostClassifier:
         return regime
 
     def _gather_rows(self, local, mine, n_iters, num_cells, num_synths, rank, world, backend, device):
-        """Single collective: every rank contributes [full | scores | logp] rows of its iterations."""
-        if world == 1:
+        """Single collective: every rank contributes [full | scores | logp] rows of its iterations.  It runs whenever
+        a torch.distributed process group is up (also a one-rank group: same code path), never otherwise."""
+        if backend is None:
             return {i: local[i] for i in range(n_iters)}
         import torch
         import torch.distributed as dist

@@ -280,6 +280,17 @@ int ddx_upload_counts(ddx_ctx* ctx, int64_t n_cells, int32_t n_genes, const int6
 #define NEED(cond, msg) \
     if (!(cond)) return set_err(ctx, DDX_E_ARG, msg)
 
+int ddx_clone_counts(ddx_ctx* ctx, ddx_ctx* src) {
+    REQUIRE_CTX(ctx);
+    NEED(src && src != ctx, "source context must be another context");
+    NEED(src->have_counts, "source context holds no counts");
+    if (src->device != ctx->device)
+        return set_err(ctx, DDX_E_UNSUPPORTED, "ddx_clone_counts: contexts live on different GPUs (%d, %d)", ctx->device, src->device);
+    USE_DEVICE(ctx);
+    DDX_HIP(ctx, hipStreamSynchronize(src->stream));
+    return stage_clone_counts(ctx, src);
+}
+
 static int d2h(ddx_ctx* ctx, void* dst, const void* src, size_t bytes) {
     if (!bytes) return DDX_OK;
     DDX_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));

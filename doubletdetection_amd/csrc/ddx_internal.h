@@ -221,6 +221,7 @@ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // ---- stage entry points implemented in the .hip files ------------------------------------------
 int stage_upload_counts(ddx_ctx* ctx, int64_t N, int32_t H, const int64_t* indptr, const int32_t* indices,
                         const float* data, bool from_device);
+int stage_clone_counts(ddx_ctx* ctx, const ddx_ctx* src);
 int stage_create_doublets(ddx_ctx* ctx, int64_t S, const int64_t* parents);
 int stage_lognormalise(ddx_ctx* ctx, float pseudocount);
 int stage_scale(ddx_ctx* ctx, float max_value);

@@ -472,6 +472,53 @@ int stage_upload_counts(ddx_ctx* ctx, int64_t N, int32_t H, const int64_t* indpt
 }
 
 // ------------------------------------------------------------------------------------------------
+// stage: clone the resident counts of another context on the same GPU (device-to-device)
+// ------------------------------------------------------------------------------------------------
+int stage_clone_counts(ddx_ctx* ctx, const ddx_ctx* src) {
+    const int64_t N = src->N, nnz = src->nnz;
+    const int32_t H = src->H;
+    const int64_t cap_s = nnz / 2 + nnz / 8 + 1024;
+    ctx->have_counts = false;
+    DDX_TRY(ensure(ctx, ctx->aug_indptr, sizeof(int64_t) * (N + N / 2 + 2)));
+    DDX_TRY(ensure(ctx, ctx->aug_indices, sizeof(int32_t) * (size_t)(nnz + cap_s)));
+    DDX_TRY(ensure(ctx, ctx->aug_raw, sizeof(float) * (size_t)(nnz + cap_s)));
+    DDX_TRY(ensure(ctx, ctx->aug_x, sizeof(float) * (size_t)(nnz + cap_s)));
+    DDX_TRY(ensure(ctx, ctx->lib32, sizeof(float) * (N + N / 2 + 2)));
+    DDX_TRY(ensure(ctx, ctx->lib64, sizeof(double) * (N + N / 2 + 2)));
+    DDX_TRY(ensure(ctx, ctx->csc_o_row, sizeof(int32_t) * (size_t)(nnz + 1)));
+    DDX_TRY(ensure(ctx, ctx->csc_o_raw, sizeof(float) * (size_t)(nnz + 1)));
+    DDX_TRY(ensure(ctx, ctx->csc_o_x, sizeof(float) * (size_t)(nnz + 1)));
+    const size_t cp_bytes = sizeof(int64_t) * ((size_t)src->P_o * H + 1);
+    DDX_TRY(ensure(ctx, ctx->csc_o_colptr, cp_bytes));
+    DDX_TRY(ensure(ctx, ctx->median, 256));
+    auto copy = [&](DevBuf& d, const DevBuf& s, size_t bytes) -> hipError_t {
+        return bytes ? hipMemcpyAsync(d.p, s.p, bytes, hipMemcpyDeviceToDevice, ctx->stream) : hipSuccess;
+    };
+    DDX_HIP(ctx, copy(ctx->aug_indptr, src->aug_indptr, sizeof(int64_t) * (N + 1)));
+    DDX_HIP(ctx, copy(ctx->aug_indices, src->aug_indices, sizeof(int32_t) * nnz));
+    DDX_HIP(ctx, copy(ctx->aug_raw, src->aug_raw, sizeof(float) * nnz));
+    DDX_HIP(ctx, copy(ctx->lib32, src->lib32, sizeof(float) * N));
+    DDX_HIP(ctx, copy(ctx->lib64, src->lib64, sizeof(double) * N));
+    DDX_HIP(ctx, copy(ctx->csc_o_colptr, src->csc_o_colptr, cp_bytes));
+    DDX_HIP(ctx, copy(ctx->csc_o_row, src->csc_o_row, sizeof(int32_t) * nnz));
+    DDX_HIP(ctx, copy(ctx->csc_o_raw, src->csc_o_raw, sizeof(float) * nnz));
+    ctx->cap_synth = cap_s;
+    ctx->h_indptr = src->h_indptr;
+    ctx->N = N;
+    ctx->H = H;
+    ctx->nnz = nnz;
+    ctx->S = 0;
+    ctx->M = N;
+    ctx->panel_rows = src->panel_rows;
+    ctx->P_o = src->P_o;
+    ctx->counts_exact = src->counts_exact;
+    ctx->have_synth = ctx->have_lognorm = ctx->scaled = ctx->have_emb = ctx->have_knn = false;
+    DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->have_counts = true;
+    return DDX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // stage: create doublets
 // ------------------------------------------------------------------------------------------------
 int stage_create_doublets(ddx_ctx* ctx, int64_t S, const int64_t* parents) {

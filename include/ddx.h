@@ -71,6 +71,12 @@ int ddx_gene_variances(ddx_ctx* ctx, float* var_out /* [G] */);
 int ddx_select_columns(ddx_ctx* ctx, const int64_t* cols, int32_t n_cols);
 int ddx_upload_counts(ddx_ctx* ctx, int64_t n_cells, int32_t n_genes, const int64_t* indptr,
                       const int32_t* indices, const float* data);
+/* ddx_clone_counts: make `dst` hold the same resident counts as `src` (everything ddx_upload_counts / ddx_select_columns
+ *   left there: restricted CSR, library sizes, column-major mirror) by device-to-device copies -- no PCIe traffic, no
+ *   recomputation.  Both contexts must live on the same GPU; `src` must be idle during the call.  This is how several
+ *   contexts (streams) of one GPU share the once-per-fit prologue (dd.py:165-184) and then run different boosting
+ *   iterations (dd.py:192-198) concurrently. */
+int ddx_clone_counts(ddx_ctx* dst, ddx_ctx* src);
 int ddx_get_counts_nnz(ddx_ctx* ctx, int64_t* nnz);
 int ddx_get_counts(ddx_ctx* ctx, int64_t* indptr /* [N+1] */, int32_t* indices, float* data);
 int ddx_get_lib_size(ddx_ctx* ctx, float* lib_out /* [N] */);

@@ -27,7 +27,11 @@ class OracleEngine:
         self.lib = orc.library_sizes(self.raw)
         self.normed = orc.l1_normalise_rows(self.raw)
 
-    def run_iteration(self, parents, pseudocount, standard_scaling, n_components, q0, knn_k, include_self, graph_mode, gamma=None):
+    def clone_from(self, other):
+        self.raw, self.lib, self.normed = other.raw, other.lib, other.normed
+
+    def run_iteration(self, parents, pseudocount, standard_scaling, n_components, q0, knn_k, include_self, graph_mode, gamma=None,
+                      pca_lock=None):
         synth = orc.create_doublets(self.raw, parents)
         aug, _, _ = orc.lognormalise(self.normed, self.lib, synth, pseudocount)
         import scipy.sparse as sp

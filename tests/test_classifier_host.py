@@ -269,3 +269,48 @@ def test_non_canonical_csr_is_canonicalised(monkeypatch):
     assert got.has_canonical_format and got.dtype == np.float32
     np.testing.assert_array_equal(got.toarray(), [[2, 0, 4], [0, 9, 0]])
     np.testing.assert_array_equal(x.indices, indices)           # caller's arrays untouched
+
+
+@pytest.mark.parametrize("devices,streams", [([0], 1), ([0], 3), ([0, 1], 1), ([2, 0, 1], 2)])
+def test_lanes_do_not_change_results(monkeypatch, devices, streams):
+    """Boosting iterations dealt out over GPUs x streams of one process (dd.py:192-198 are independent given the
+    pre-drawn parents): every layout gives the arrays of the single-lane run, and followers clone their leader."""
+    from oracle_engine import OracleEngine
+
+    g = load_golden("case_c_reftest_scaled")
+    counts = csr_from(g, "counts")
+    made = []
+
+    def factory(device):
+        e = OracleEngine(device)
+        e.seed = 0
+        e.cloned_from = None
+        made.append(e)
+        return e
+
+    plain_clone = OracleEngine.clone_from
+
+    def clone_from(self, other):
+        plain_clone(self, other)
+        self.cloned_from = other
+
+    monkeypatch.setattr(OracleEngine, "clone_from", clone_from, raising=False)
+    kw = dict(n_iters=5, clustering_algorithm="louvain", standard_scaling=True, random_state=0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        base = BoostClassifier(streams_per_device=1, **kw)
+        base._engine_factory = make_engine_factory(0)
+        base.fit(counts)
+        clf = BoostClassifier(devices=devices, streams_per_device=streams, **kw)
+        clf._engine_factory = factory
+        clf.fit(counts)
+    for name in ("all_log_p_values_", "all_scores_", "communities_", "synth_communities_"):
+        np.testing.assert_array_equal(getattr(clf, name), getattr(base, name))
+    np.testing.assert_array_equal(np.asarray(clf.parents_), np.asarray(base.parents_))
+    want_lanes = min(5, len(devices) * streams)
+    assert clf._lanes_used == want_lanes and len(made) == want_lanes
+    leaders = [e for e in made if e.cloned_from is None]
+    assert sorted(e.device for e in leaders) == sorted(devices)
+    for e in made:
+        if e.cloned_from is not None:
+            assert e.cloned_from.device == e.device and e.cloned_from.cloned_from is None

@@ -1,7 +1,12 @@
-"""N>1 path with the real HIP engine: two processes (gloo rendezvous, both on GPU 0 -- the test box has one GPU,
-and RCCL refuses two ranks on one device) shard the boosting iterations and all-gather the result rows; every rank
-must end up with exactly what a single process computes.  The nccl/RCCL flavour of the same code runs in
-``bench.py --gpus N`` (one process per GPU)."""
+"""N>1 path with the real HIP engine.
+
+* two processes (gloo rendezvous, both on GPU 0 -- the test box has one GPU, and RCCL refuses two ranks on one device)
+  shard the boosting iterations and all-gather the result rows; every rank must end up with exactly what a single
+  process computes;
+* the RCCL flavour of the very same code (backend "nccl": device tensors, ``all_gather_into_tensor`` over RCCL) with
+  as many ranks as the box has GPUs -- one rank on a one-GPU box, which still drives libddx's HIP runtime, torch's
+  HIP runtime and RCCL in one process -- and with >= 2 ranks whenever >= 2 GPUs are visible;
+* one process driving several GPUs / several streams per GPU (``devices=``, ``streams_per_device=``)."""
 import os
 import socket
 import sys
@@ -32,19 +37,26 @@ def _counts():
 _KW = dict(n_iters=5, n_top_var_genes=700, random_state=3, device=0)
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, backend="gloo"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0")
     sys.path.insert(0, ROOT)
+    import torch
     import torch.distributed as dist
 
     from doubletdetection_amd import BoostClassifier
 
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    kw = dict(_KW)
+    if backend == "nccl":
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{rank}"))
+        kw["device"] = rank
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            clf = BoostClassifier(**_KW).fit(_counts())
+            clf = BoostClassifier(**kw).fit(_counts())
             labels = clf.predict()
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), scores=clf.all_scores_, logp=clf.all_log_p_values_,
                  comm=clf.communities_, synth=clf.synth_communities_, parents=np.asarray(clf.parents_), labels=labels)
@@ -71,3 +83,53 @@ def test_two_ranks_on_the_hip_engine_equal_one_process(tmp_path):
         np.testing.assert_array_equal(r["scores"], single.all_scores_)
         np.testing.assert_array_equal(r["logp"], single.all_log_p_values_)
         np.testing.assert_array_equal(r["labels"], single_labels)
+
+
+def _compare_with_single(tmp_path, ranks):
+    from doubletdetection_amd import BoostClassifier
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        single = BoostClassifier(**_KW).fit(_counts())
+        single_labels = single.predict()
+    for rank in ranks:
+        r = np.load(tmp_path / f"rank{rank}.npz")
+        np.testing.assert_array_equal(r["parents"], np.asarray(single.parents_))
+        np.testing.assert_array_equal(r["comm"], single.communities_)
+        np.testing.assert_array_equal(r["synth"], single.synth_communities_)
+        np.testing.assert_array_equal(r["scores"], single.all_scores_)
+        np.testing.assert_array_equal(r["logp"], single.all_log_p_values_)
+        np.testing.assert_array_equal(r["labels"], single_labels)
+
+
+def test_rccl_backend_one_rank_per_visible_gpu(tmp_path):
+    """backend="nccl" (= RCCL): the result rows travel as device tensors through all_gather_into_tensor.  World size =
+    number of visible GPUs (capped at 4), so a one-GPU box still runs the RCCL code path end to end."""
+    import torch
+    import torch.multiprocessing as mp
+
+    world = max(1, min(4, torch.cuda.device_count()))
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), "nccl"), nprocs=world, join=True)
+    _compare_with_single(tmp_path, range(world))
+
+
+def test_streams_and_devices_of_one_process_equal_single_lane():
+    """devices= / streams_per_device=: iterations dealt out over device contexts driven by host threads of ONE process;
+    followers take the prologue's result by device-to-device copy.  Results are those of the single-lane run."""
+    import torch
+
+    from doubletdetection_amd import BoostClassifier
+
+    counts = _counts()
+    kw = {k: v for k, v in _KW.items() if k != "device"}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        base = BoostClassifier(device=0, streams_per_device=1, **kw).fit(counts)
+        layouts = [dict(device=0, streams_per_device=2), dict(device=0, streams_per_device=4)]
+        if torch.cuda.device_count() >= 2:
+            layouts.append(dict(devices=list(range(min(4, torch.cuda.device_count()))), streams_per_device=2))
+        for layout in layouts:
+            clf = BoostClassifier(**layout, **kw).fit(counts)
+            assert clf._lanes_used == min(kw["n_iters"], len(layout.get("devices", [0])) * layout["streams_per_device"])
+            for name in ("all_log_p_values_", "all_scores_", "communities_", "synth_communities_"):
+                np.testing.assert_array_equal(getattr(clf, name), getattr(base, name))

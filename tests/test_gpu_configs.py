@@ -285,43 +285,59 @@ def data_c5():
     return make_counts(11_769, 33_538, density=0.06, device="cuda:0", seed=55)
 
 
-def test_c5_scaled_matrix_matches_float64_recomputation(data_c5):
-    """dd.py:302-303 at real width: per-gene mean / unbiased std over all M rows, (x - mean) / std, clip to +-15."""
+def _prepared_c5(data_c5):
     from doubletdetection_amd import _lib
 
     N = data_c5.shape[0]
     parents = np.random.default_rng(0).choice(N, size=(N // 4, 2), replace=False)
     ctx = _lib.Context(0)
+    ctx.upload_raw(data_c5)
+    var = ctx.gene_variances()
+    ctx.select_columns(np.argsort(var)[-10_000:])
+    ctx.create_doublets(parents)
+    ctx.lognormalise(0.1)
+    return ctx
+
+
+def _dense_columns(ctx, cols, chunk=2048):
+    M = ctx.M
+    return np.vstack([ctx.aug_dense_rows(r, min(chunk, M - r))[:, cols] for r in range(0, M, chunk)])
+
+
+@pytest.mark.parametrize("max_value", [15.0, 2.5])
+def test_c5_scaled_matrix_matches_float64_recomputation(data_c5, max_value):
+    """dd.py:302-303 at real width: per-gene mean / unbiased std over all M rows, (x - mean) / std, clip.
+    With the 10 000 most variable of 33 538 genes at 6 % density no gene is rare enough to reach +-15 (that takes a
+    gene stored in fewer than M/225 rows), so the clip itself is also exercised at this width with max_value=2.5."""
+    ctx = _prepared_c5(data_c5)
     try:
-        ctx.upload_raw(data_c5)
-        var = ctx.gene_variances()
-        ctx.select_columns(np.argsort(var)[-10_000:])
-        ctx.create_doublets(parents)
-        ctx.lognormalise(0.1)
         M, H = ctx.M, ctx.H
-        # 128 random genes + the 128 sparsest ones (a gene stored in < M/225 rows scales beyond the clip)
+        # 128 random genes + the 128 sparsest ones (the largest scaled values)
         col_nnz = np.bincount(ctx.get_counts().indices, minlength=H)
         cols = np.unique(np.concatenate([np.random.default_rng(4).choice(H, size=128, replace=False),
                                          np.argsort(col_nnz, kind="stable")[:128]]))
-        chunk = 2048
-        before = np.vstack([ctx.aug_dense_rows(r, min(chunk, M - r))[:, cols] for r in range(0, M, chunk)])
-        ctx.scale(15.0)
-        after = np.vstack([ctx.aug_dense_rows(r, min(chunk, M - r))[:, cols] for r in range(0, M, chunk)])
-        want = orc.scale_like_scanpy(before, max_value=15)            # float64 statistics, float32 steps
-        assert after.max() == 15.0                                    # the clip is reached at this size
-        assert (after == 15.0).sum() >= 1 and after.min() >= -15.0
+        before = _dense_columns(ctx, cols)
+        ctx.scale(max_value)
+        after = _dense_columns(ctx, cols)
+        want = orc.scale_like_scanpy(before, max_value=max_value)     # float64 statistics, float32 steps
         np.testing.assert_allclose(after, want, rtol=2e-6, atol=2e-6)
+        assert after.max() <= max_value and after.min() >= -max_value
+        if max_value < 15.0:
+            assert (after == max_value).sum() > 1000                   # the clip is reached, widely
+            assert np.array_equal(after == max_value, want == max_value)
         # column statistics of the scaled matrix in float64: mean 0 / unbiased variance 1 wherever nothing was clipped
-        unclipped = np.flatnonzero((np.abs(after) < 15.0).all(axis=0))
-        a64 = after[:, unclipped].astype(np.float64)
-        np.testing.assert_allclose(a64.mean(axis=0), 0.0, atol=5e-6)
-        np.testing.assert_allclose(a64.var(axis=0, ddof=1), 1.0, rtol=2e-5)
-        # PCA runs on the scaled matrix: centred, orthogonal scores
+        unclipped = np.flatnonzero((np.abs(after) < max_value).all(axis=0))
+        assert unclipped.size > (100 if max_value == 15.0 else 0)
+        if unclipped.size:
+            a64 = after[:, unclipped].astype(np.float64)
+            np.testing.assert_allclose(a64.mean(axis=0), 0.0, atol=5e-6)
+            np.testing.assert_allclose(a64.var(axis=0, ddof=1), 1.0, rtol=2e-5)
+        # PCA runs on the scaled (and clipped) matrix: orthogonal scores that match the float64 oracle on the same matrix
         q0 = np.random.RandomState(0).normal(size=(H, 40)).astype(np.float32).astype(np.float64)
         ctx.pca(30, q0)
         emb, sing = ctx.embedding_f64()
         np.testing.assert_allclose(emb.T @ emb, np.diag(sing ** 2), rtol=1e-9, atol=1e-9 * sing[0] ** 2)
-        dense = np.vstack([ctx.aug_dense_rows(r, min(chunk, M - r)) for r in range(0, M, chunk)])
+        dense = np.vstack([ctx.aug_dense_rows(r, min(2048, M - r)) for r in range(0, M, 2048)])
         want_emb, s_want, _ = orc.randomized_pca_f64(dense, 30, 0)
         np.testing.assert_allclose(sing, s_want, rtol=1e-6)
         assert orc.per_component_rel_dev(emb, want_emb).max() <= 1e-5
