@@ -17,34 +17,67 @@ int set_err(ddx_ctx* ctx, int code, const char* fmt, ...) {
     return code;
 }
 
-int ensure(ddx_ctx* ctx, DevBuf& b, size_t bytes) {
-    if (bytes <= b.cap && b.p) return DDX_OK;
-    if (b.p) {
-        // contents are never needed across a growth: all callers refill after ensure()
-        (void)hipStreamSynchronize(ctx->stream);
-        (void)hipFree(b.p);
-        ctx->dev_bytes -= (int64_t)b.cap;
-        b.p = nullptr;
-        b.cap = 0;
-    }
-    size_t want = bytes < 256 ? 256 : bytes;
-    hipError_t e = hipMalloc(&b.p, want);
-    if (e != hipSuccess) {
-        b.p = nullptr;
-        return set_err(ctx, DDX_E_NOMEM, "hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
-    }
-    b.cap = want;
-    ctx->dev_bytes += (int64_t)want;
-    return DDX_OK;
-}
-
 void release(ddx_ctx* ctx, DevBuf& b) {
-    if (b.p) {
-        (void)hipFree(b.p);
-        ctx->dev_bytes -= (int64_t)b.cap;
+    Arena& A = ctx->arena;
+    if (b.p && b.blk >= 0 && b.blk < (int)A.blocks.size()) {
+        A.blocks[b.blk].free = true;
+        // fall back over free blocks at the top (a block is at the top of its chunk iff it ends at the chunk's bump pointer)
+        while (!A.blocks.empty()) {
+            Arena::Block& t = A.blocks.back();
+            Arena::Chunk& c = A.chunks[t.chunk];
+            if (!t.free || t.off + t.size != c.off) break;
+            c.off = t.off;
+            A.blocks.pop_back();
+        }
     }
     b.p = nullptr;
     b.cap = 0;
+    b.blk = -1;
+}
+
+void arena_hint(ddx_ctx* ctx, size_t bytes) {
+    if (bytes > ctx->arena.next_chunk) ctx->arena.next_chunk = bytes;
+}
+
+void arena_destroy(ddx_ctx* ctx) {
+    for (auto& c : ctx->arena.chunks) (void)hipFree(c.p);
+    ctx->arena.chunks.clear();
+    ctx->arena.blocks.clear();
+    ctx->dev_bytes = 0;
+}
+
+int ensure(ddx_ctx* ctx, DevBuf& b, size_t bytes) {
+    if (bytes <= b.cap && b.p) return DDX_OK;
+    // contents are never needed across a growth: all callers refill after ensure()
+    if (b.p) release(ctx, b);
+    Arena& A = ctx->arena;
+    const size_t want = ((bytes < 256 ? 256 : bytes) + 255) & ~(size_t)255;
+    int ci = -1;
+    for (int i = (int)A.chunks.size() - 1; i >= 0; --i)
+        if (A.chunks[i].off + want <= A.chunks[i].cap) { ci = i; break; }
+    if (ci < 0) {
+        size_t cap = A.next_chunk > want ? A.next_chunk : want;
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, cap);
+        if (e != hipSuccess && cap > want) {      // the guess was too greedy for what is left: take what is needed
+            cap = want;
+            e = hipMalloc(&p, cap);
+        }
+        if (e != hipSuccess)
+            return set_err(ctx, DDX_E_NOMEM, "hipMalloc(%zu bytes) failed: %s", cap, hipGetErrorString(e));
+        A.chunks.push_back({p, cap, 0});
+        ctx->dev_bytes += (int64_t)cap;
+        A.next_chunk = std::max<size_t>((size_t)256 << 20, cap / 4);   // later chunks: a quarter of the first guess
+        ci = (int)A.chunks.size() - 1;
+    }
+    Arena::Chunk& c = A.chunks[ci];
+    // a block can only fall back when it is the last one recorded: keep blocks in allocation order per top chunk
+    b.p = static_cast<char*>(c.p) + c.off;
+    b.cap = want;
+    b.blk = (int)A.blocks.size();
+    A.blocks.push_back({ci, c.off, want, false});
+    c.off += want;
+    return DDX_OK;
 }
 
 void Options::read_environment() {
@@ -195,6 +228,7 @@ int ddx_destroy(ddx_ctx* ctx) {
                       &ctx->pcaPartial, &ctx->pcaVec, &ctx->pcaPanel, &ctx->pcaOp, &ctx->pcaQ0, &ctx->rowseg, &ctx->rank_buf, &ctx->lv_buf, &ctx->lv_pack, &ctx->emb32, &ctx->emb64, &ctx->sing, &ctx->knn_idx,
                       &ctx->knn_dist, &ctx->knn_sorted, &ctx->edge_w};
     for (DevBuf* b : bufs) release(ctx, *b);
+    arena_destroy(ctx);
     if (ctx->lv_host) (void)hipHostFree(ctx->lv_host);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -234,6 +268,9 @@ int ddx_upload_raw(ddx_ctx* ctx, int64_t n_cells, int32_t n_genes, const int64_t
     DDX_TRY(check_csr(ctx, n_cells, n_genes, indptr, indices, data));
     int64_t nnz = indptr[n_cells];
     if (nnz >= (int64_t)1 << 31) return set_err(ctx, DDX_E_UNSUPPORTED, "more than 2^31-1 stored entries");
+    // everything a fit allocates on this context, in one chunk: raw CSR + HVG temporaries + restricted matrix, its
+    // mirror, sort space, PCA / kNN / graph work space (about 95 bytes per stored raw entry at the benchmark shapes)
+    arena_hint(ctx, (size_t)nnz * 100 + (size_t)n_cells * 6000 + ((size_t)1 << 30));
     DDX_TRY(ensure(ctx, ctx->raw_indptr, sizeof(int64_t) * (n_cells + 1)));
     DDX_TRY(ensure(ctx, ctx->raw_indices, sizeof(int32_t) * (size_t)(nnz + 1)));
     DDX_TRY(ensure(ctx, ctx->raw_data, sizeof(float) * (size_t)(nnz + 1)));

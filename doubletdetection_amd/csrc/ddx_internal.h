@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -52,7 +53,21 @@ struct Options {
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
+    int blk = -1;                    // block of the context's arena that backs the buffer
     template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+// Device memory of a context comes from a few large chunks (one hipMalloc each) that are carved up by a bump pointer:
+// a fit allocates ~50 buffers and hipFree costs ~0.2 ms apiece and synchronises the whole device, which would stall the
+// other contexts (streams) of the GPU in the middle of their iterations.  Blocks are returned in any order; the bump
+// pointer falls back over whatever is free at the top of its chunk (the stages' temporaries are LIFO in practice), the
+// rest is reclaimed when the context is destroyed -- hipFree is called only there.
+struct Arena {
+    struct Chunk { void* p; size_t cap, off; };
+    struct Block { int chunk; size_t off, size; bool free; };
+    std::vector<Chunk> chunks;
+    std::vector<Block> blocks;
+    size_t next_chunk = (size_t)256 << 20;     // size of the next chunk to request (ddx reserves a better guess at upload)
 };
 
 struct TimingRec {
@@ -71,6 +86,7 @@ struct ddx_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     ddx::Options opt;
+    ddx::Arena arena;
     std::string err;
     int64_t dev_bytes = 0;
 
@@ -191,6 +207,8 @@ namespace ddx {
 int set_err(ddx_ctx* ctx, int code, const char* fmt, ...);
 int ensure(ddx_ctx* ctx, DevBuf& b, size_t bytes);
 void release(ddx_ctx* ctx, DevBuf& b);
+void arena_hint(ddx_ctx* ctx, size_t bytes);      // expected total need: sizes the next chunk
+void arena_destroy(ddx_ctx* ctx);
 void timing_begin(ddx_ctx* ctx, const char* name);
 void timing_end(ddx_ctx* ctx);
 int timing_flush(ddx_ctx* ctx);

@@ -420,6 +420,7 @@ int stage_upload_counts(ddx_ctx* ctx, int64_t N, int32_t H, const int64_t* indpt
     const int64_t nnz = from_device ? ctx->nnz : indptr[N];
     if (nnz >= (int64_t)1 << 31) return set_err(ctx, DDX_E_UNSUPPORTED, "more than 2^31-1 stored entries");
     if (!from_device) {
+        arena_hint(ctx, (size_t)nnz * 80 + (size_t)N * 6000 + ((size_t)1 << 30));
         // worst-case-ish room for the synthetic part (default boost_rate 0.25 needs ~0.5*nnz); grows on demand
         const int64_t cap_s = nnz / 2 + nnz / 8 + 1024;
         DDX_TRY(ensure(ctx, ctx->aug_indptr, sizeof(int64_t) * (N + N / 2 + 2)));
@@ -479,6 +480,7 @@ int stage_clone_counts(ddx_ctx* ctx, const ddx_ctx* src) {
     const int32_t H = src->H;
     const int64_t cap_s = nnz / 2 + nnz / 8 + 1024;
     ctx->have_counts = false;
+    arena_hint(ctx, (size_t)nnz * 80 + (size_t)N * 6000 + ((size_t)1 << 30));
     DDX_TRY(ensure(ctx, ctx->aug_indptr, sizeof(int64_t) * (N + N / 2 + 2)));
     DDX_TRY(ensure(ctx, ctx->aug_indices, sizeof(int32_t) * (size_t)(nnz + cap_s)));
     DDX_TRY(ensure(ctx, ctx->aug_raw, sizeof(float) * (size_t)(nnz + cap_s)));

@@ -201,10 +201,18 @@ def test_scaled_matrix(ctx):
 @pytest.mark.parametrize("gather", ["f32", "f64"])
 @pytest.mark.parametrize("case", ["case_a_hvg_pheno", "case_b_transposed_louvain", "case_c_reftest_scaled",
                                   "case_d_replace_single"])
-def test_pca_scores(ctx, case, gather, monkeypatch):
+def test_pca_scores(case, gather, monkeypatch):
     # default: the operator products gather a float32-rounded copy of the 40-column iterate (float64
-    # products and sums); DDX_PCA_GATHER=f64 gathers the float64 iterate itself
+    # products and sums); DDX_PCA_GATHER=f64 gathers the float64 iterate itself.  A context reads the environment once,
+    # when it is created: make one for this setting.
+    from doubletdetection_amd import _lib
+
     monkeypatch.setenv("DDX_PCA_GATHER", gather)
+    with _lib.Context(0) as ctx:
+        _pca_scores_body(ctx, case, gather)
+
+
+def _pca_scores_body(ctx, case, gather):
     tol = 1e-7 if gather == "f64" else 1e-5     # bar: 1e-4 (sklearn f32 vs f64 differs by up to 8e-4)
     g = load_golden(case)
     kw = golden_kwargs(g)
