@@ -59,22 +59,25 @@ def _dist_info():
     return 0, 1, None
 
 
-# The reference releases everything it allocated when fit() returns (dd.py:200-205); so does this class: the device
-# context of a fit (stream + every HBM buffer) is destroyed when the fit ends.  DDX_KEEP_CONTEXT=1 (read when a fit
-# ends) parks the context per GPU instead, like a caching allocator, so that back-to-back fits skip the allocations;
-# release_device_memory() frees what is parked.
-_CONTEXT_POOL: dict = {}
+# Device contexts (stream + the memory chunks their buffers are carved from) are parked per GPU when a fit ends and
+# taken up again by the next fit of this process, like a caching allocator.  Measured on MI355X (profiles/r02_alloc_notes.txt):
+# a fit that has to obtain its ~10 GB chunks from the driver anew stalls for 0.8-1.5 s every other fit once two contexts
+# per GPU are in play, against 0.25 s for the whole fit.  The reference frees its (host) intermediates when fit() returns
+# (dd.py:200-205); to get that behaviour set DDX_KEEP_CONTEXT=0 (read when a fit ends), or call
+# release_device_memory() at any time -- it is also registered with atexit.
+_CONTEXT_POOL: dict = {}          # device -> [parked _lib.Context, ...]
 
 
 def _keep_contexts() -> bool:
-    return os.environ.get("DDX_KEEP_CONTEXT", "0") not in ("", "0")
+    return os.environ.get("DDX_KEEP_CONTEXT", "1") not in ("", "0")
 
 
 def release_device_memory() -> None:
-    """Destroy the parked device contexts (DDX_KEEP_CONTEXT=1) and free their HBM buffers."""
+    """Destroy the parked device contexts and free their HBM."""
     while _CONTEXT_POOL:
-        _, ctx = _CONTEXT_POOL.popitem()
-        ctx.close()
+        _, parked = _CONTEXT_POOL.popitem()
+        for ctx in parked:
+            ctx.close()
 
 
 import atexit  # noqa: E402
@@ -87,7 +90,8 @@ class _HipEngine:
 
     def __init__(self, device: int):
         self.device = device
-        self.ctx = _CONTEXT_POOL.pop(device, None) or _lib.Context(device)
+        parked = _CONTEXT_POOL.get(device)
+        self.ctx = parked.pop() if parked else _lib.Context(device)
         timing = os.environ.get("DDX_TIMING") == "1"     # per-kernel HIP-event timing (bench.py / profiling)
         self.ctx.timing_enable(timing)
         if timing:
@@ -95,8 +99,8 @@ class _HipEngine:
 
     def close(self):
         if self.ctx is not None:
-            if _keep_contexts() and self.device not in _CONTEXT_POOL:
-                _CONTEXT_POOL[self.device] = self.ctx
+            if _keep_contexts():
+                _CONTEXT_POOL.setdefault(self.device, []).append(self.ctx)
             else:
                 self.ctx.close()                         # frees every HBM buffer of the fit
             self.ctx = None

@@ -39,6 +39,32 @@ void arena_hint(ddx_ctx* ctx, size_t bytes) {
     if (bytes > ctx->arena.next_chunk) ctx->arena.next_chunk = bytes;
 }
 
+// A context starts a new fit: forget every buffer and result of the previous one, keep the chunks (their memory is
+// handed out again from the start).  Called by the entry points that make counts resident.
+void context_reset(ddx_ctx* ctx) {
+    (void)hipStreamSynchronize(ctx->stream);
+    DevBuf* bufs[] = {&ctx->raw_indptr, &ctx->raw_indices, &ctx->raw_data, &ctx->aug_indptr, &ctx->aug_indices,
+                      &ctx->aug_raw, &ctx->aug_x, &ctx->lib32, &ctx->lib64, &ctx->synth_counts, &ctx->parents, &ctx->pad_off,
+                      &ctx->csc_o_colptr, &ctx->csc_o_row, &ctx->csc_o_raw, &ctx->csc_o_x, &ctx->csc_s_colptr,
+                      &ctx->csc_s_row, &ctx->csc_s_raw, &ctx->csc_s_x, &ctx->sort_keys_in, &ctx->sort_keys_out,
+                      &ctx->sort_vals_in, &ctx->sort_vals_out, &ctx->sort_tmp, &ctx->sort_rowid, &ctx->median, &ctx->lib_sorted, &ctx->lognorm_tab,
+                      &ctx->zcol, &ctx->colmean, &ctx->colstat, &ctx->col_part, &ctx->pcaA, &ctx->pcaB, &ctx->pcaSmall,
+                      &ctx->pcaPartial, &ctx->pcaVec, &ctx->pcaPanel, &ctx->pcaOp, &ctx->pcaQ0, &ctx->rowseg, &ctx->rank_buf, &ctx->lv_buf, &ctx->lv_pack, &ctx->emb32, &ctx->emb64, &ctx->sing, &ctx->knn_idx,
+                      &ctx->knn_dist, &ctx->knn_sorted, &ctx->edge_w};
+    for (DevBuf* b : bufs) { b->p = nullptr; b->cap = 0; b->blk = -1; }
+    ctx->arena.blocks.clear();
+    for (auto& c : ctx->arena.chunks) c.off = 0;
+    ctx->rawN = 0; ctx->rawG = 0; ctx->raw_nnz = 0;
+    ctx->N = 0; ctx->H = 0; ctx->nnz = 0; ctx->S = 0; ctx->M = 0; ctx->cap_synth = 0;
+    ctx->have_counts = ctx->have_synth = ctx->have_lognorm = ctx->scaled = ctx->have_emb = ctx->have_knn = false;
+    ctx->q0_rows = 0; ctx->q0_cols = 0;
+    ctx->rank_rows = ctx->rank_cols = nullptr;
+    ctx->knn_window_total = nullptr;
+    ctx->g_nodes = -1; ctx->g_entries = 0; ctx->g_d_indptr = nullptr; ctx->g_d_cols = nullptr; ctx->g_d_vals = nullptr;
+    ctx->c_nodes = -1; ctx->c_entries = 0; ctx->c_d_member = nullptr; ctx->c_d_indptr = nullptr; ctx->c_d_cols = nullptr; ctx->c_d_vals = nullptr;
+    ctx->lv_host_valid = false;
+}
+
 void arena_destroy(ddx_ctx* ctx) {
     for (auto& c : ctx->arena.chunks) (void)hipFree(c.p);
     ctx->arena.chunks.clear();
@@ -219,15 +245,7 @@ int ddx_destroy(ddx_ctx* ctx) {
     (void)timing_flush(ctx);
     for (hipEvent_t e : ctx->t_free) (void)hipEventDestroy(e);
     ctx->t_free.clear();
-    DevBuf* bufs[] = {&ctx->raw_indptr, &ctx->raw_indices, &ctx->raw_data, &ctx->aug_indptr, &ctx->aug_indices,
-                      &ctx->aug_raw, &ctx->aug_x, &ctx->lib32, &ctx->lib64, &ctx->synth_counts, &ctx->parents, &ctx->pad_off,
-                      &ctx->csc_o_colptr, &ctx->csc_o_row, &ctx->csc_o_raw, &ctx->csc_o_x, &ctx->csc_s_colptr,
-                      &ctx->csc_s_row, &ctx->csc_s_raw, &ctx->csc_s_x, &ctx->sort_keys_in, &ctx->sort_keys_out,
-                      &ctx->sort_vals_in, &ctx->sort_vals_out, &ctx->sort_tmp, &ctx->sort_rowid, &ctx->median, &ctx->lib_sorted, &ctx->lognorm_tab,
-                      &ctx->zcol, &ctx->colmean, &ctx->colstat, &ctx->col_part, &ctx->pcaA, &ctx->pcaB, &ctx->pcaSmall,
-                      &ctx->pcaPartial, &ctx->pcaVec, &ctx->pcaPanel, &ctx->pcaOp, &ctx->pcaQ0, &ctx->rowseg, &ctx->rank_buf, &ctx->lv_buf, &ctx->lv_pack, &ctx->emb32, &ctx->emb64, &ctx->sing, &ctx->knn_idx,
-                      &ctx->knn_dist, &ctx->knn_sorted, &ctx->edge_w};
-    for (DevBuf* b : bufs) release(ctx, *b);
+    context_reset(ctx);
     arena_destroy(ctx);
     if (ctx->lv_host) (void)hipHostFree(ctx->lv_host);
     (void)hipStreamDestroy(ctx->stream);
@@ -268,6 +286,7 @@ int ddx_upload_raw(ddx_ctx* ctx, int64_t n_cells, int32_t n_genes, const int64_t
     DDX_TRY(check_csr(ctx, n_cells, n_genes, indptr, indices, data));
     int64_t nnz = indptr[n_cells];
     if (nnz >= (int64_t)1 << 31) return set_err(ctx, DDX_E_UNSUPPORTED, "more than 2^31-1 stored entries");
+    context_reset(ctx);
     // everything a fit allocates on this context, in one chunk: raw CSR + HVG temporaries + restricted matrix, its
     // mirror, sort space, PCA / kNN / graph work space (about 95 bytes per stored raw entry at the benchmark shapes)
     arena_hint(ctx, (size_t)nnz * 100 + (size_t)n_cells * 6000 + ((size_t)1 << 30));
@@ -311,6 +330,7 @@ int ddx_upload_counts(ddx_ctx* ctx, int64_t n_cells, int32_t n_genes, const int6
     REQUIRE_CTX(ctx);
     USE_DEVICE(ctx);
     DDX_TRY(check_csr(ctx, n_cells, n_genes, indptr, indices, data));
+    context_reset(ctx);
     return stage_upload_counts(ctx, n_cells, n_genes, indptr, indices, data, false);
 }
 
@@ -325,6 +345,7 @@ int ddx_clone_counts(ddx_ctx* ctx, ddx_ctx* src) {
         return set_err(ctx, DDX_E_UNSUPPORTED, "ddx_clone_counts: contexts live on different GPUs (%d, %d)", ctx->device, src->device);
     USE_DEVICE(ctx);
     DDX_HIP(ctx, hipStreamSynchronize(src->stream));
+    context_reset(ctx);
     return stage_clone_counts(ctx, src);
 }
 

@@ -209,6 +209,7 @@ int ensure(ddx_ctx* ctx, DevBuf& b, size_t bytes);
 void release(ddx_ctx* ctx, DevBuf& b);
 void arena_hint(ddx_ctx* ctx, size_t bytes);      // expected total need: sizes the next chunk
 void arena_destroy(ddx_ctx* ctx);
+void context_reset(ddx_ctx* ctx);
 void timing_begin(ddx_ctx* ctx, const char* name);
 void timing_end(ddx_ctx* ctx);
 int timing_flush(ddx_ctx* ctx);

@@ -1263,7 +1263,12 @@ int stage_build_graph(ddx_ctx* ctx, int32_t mode) {
         k_pair_emit<<<(unsigned)ceil_div(n, 256), 256, 0, ctx->stream>>>(ctx->knn_idx.as<int32_t>(), ctx->edge_w.as<double>(), n, K, shift, offs, keys_a, vals_a);
         DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (E > 0) {
-            DDX_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(ctx->sort_tmp.p, tmp2, keys_a, keys_b, vals_a, vals_b, (int)E, 0, end_bit, ctx->stream));
+            // the sort picks its algorithm (single block / merge / onesweep) by the element count, and each has its own
+            // temporary-storage need: ask again for the actual count
+            size_t tmp3 = 0;
+            DDX_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp3, keys_a, keys_b, vals_a, vals_b, (int)E, 0, end_bit, ctx->stream));
+            DDX_TRY(ensure(ctx, ctx->sort_tmp, tmp3));
+            DDX_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(ctx->sort_tmp.p, tmp3, keys_a, keys_b, vals_a, vals_b, (int)E, 0, end_bit, ctx->stream));
             k_cols_from_keys<<<(unsigned)ceil_div(E, 256), 256, 0, ctx->stream>>>(keys_b, E, shift, d_cols);
         }
         k_rowptr_from_keys<<<(unsigned)ceil_div(M + 1, 256), 256, 0, ctx->stream>>>(keys_b, E, M, shift, d_indptr);
