@@ -39,6 +39,7 @@ _SIGNATURES = {
     "ddx_destroy": (C.c_int, [C.c_void_p]),
     "ddx_synchronize": (C.c_int, [C.c_void_p]),
     "ddx_device_bytes": (C.c_int, [C.c_void_p, c_i64_p]),
+    "ddx_check_memory": (C.c_int, [C.c_void_p]),
     "ddx_upload_raw": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, c_i64_p, c_i32_p, c_f32_p]),
     "ddx_gene_variances": (C.c_int, [C.c_void_p, c_f32_p]),
     "ddx_select_columns": (C.c_int, [C.c_void_p, c_i64_p, C.c_int32]),
@@ -272,8 +273,14 @@ class Context:
 
     def close(self):
         if self._h:
-            self._lib.ddx_destroy(self._h)
-            self._h = C.c_void_p(None)
+            try:
+                if os.environ.get("DDX_ARENA_GUARD", "0") not in ("", "0"):
+                    rc = self._lib.ddx_check_memory(self._h)
+                    if rc == -4:                        # DDX_E_NUMERIC: a buffer was overrun
+                        _check(rc, self._h)
+            finally:
+                self._lib.ddx_destroy(self._h)
+                self._h = C.c_void_p(None)
 
     def __del__(self):
         try:
@@ -296,6 +303,10 @@ class Context:
 
     def synchronize(self):
         self._c(self._lib.ddx_synchronize(self._h))
+
+    def check_memory(self):
+        """Raises if a kernel wrote past the end of a device buffer (needs DDX_ARENA_GUARD=1 when the context is made)."""
+        self._c(self._lib.ddx_check_memory(self._h))
 
     def device_bytes(self) -> int:
         v = C.c_int64(0)

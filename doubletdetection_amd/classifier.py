@@ -99,6 +99,8 @@ class _HipEngine:
 
     def close(self):
         if self.ctx is not None:
+            if os.environ.get("DDX_ARENA_GUARD", "0") not in ("", "0"):
+                self.ctx.check_memory()                  # overflow detector (tests): raises, naming the buffer
             if _keep_contexts():
                 _CONTEXT_POOL.setdefault(self.device, []).append(self.ctx)
             else:

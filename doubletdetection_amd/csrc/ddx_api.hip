@@ -77,7 +77,7 @@ int ensure(ddx_ctx* ctx, DevBuf& b, size_t bytes) {
     // contents are never needed across a growth: all callers refill after ensure()
     if (b.p) release(ctx, b);
     Arena& A = ctx->arena;
-    const size_t want = ((bytes < 256 ? 256 : bytes) + 255) & ~(size_t)255;
+    const size_t want = (((bytes < 256 ? 256 : bytes) + 255) & ~(size_t)255) + kArenaPad;
     int ci = -1;
     for (int i = (int)A.chunks.size() - 1; i >= 0; --i)
         if (A.chunks[i].off + want <= A.chunks[i].cap) { ci = i; break; }
@@ -99,10 +99,12 @@ int ensure(ddx_ctx* ctx, DevBuf& b, size_t bytes) {
     Arena::Chunk& c = A.chunks[ci];
     // a block can only fall back when it is the last one recorded: keep blocks in allocation order per top chunk
     b.p = static_cast<char*>(c.p) + c.off;
-    b.cap = want;
+    b.cap = want - kArenaPad;
     b.blk = (int)A.blocks.size();
     A.blocks.push_back({ci, c.off, want, false});
     c.off += want;
+    if (ctx->opt.arena_guard)
+        (void)hipMemsetAsync(static_cast<char*>(b.p) + b.cap, 0xA5, kArenaPad, ctx->stream);
     return DDX_OK;
 }
 
@@ -121,6 +123,8 @@ void Options::read_environment() {
     knn_sample_tiles = g ? atoll(g) : 0;
     row_sums_sequential = getenv("DDX_ROW_SUMS_SEQUENTIAL") != nullptr;
     knn_debug = getenv("DDX_KNN_DEBUG") != nullptr;
+    g = getenv("DDX_ARENA_GUARD");
+    arena_guard = g && g[0] != '0' && g[0] != 0;
 #ifdef DDX_ABLATION
     g = getenv("DDX_KNN_EXPERIMENT");
     knn_ablation = g ? atoi(g) : 0;
@@ -257,6 +261,26 @@ int ddx_synchronize(ddx_ctx* ctx) {
     REQUIRE_CTX(ctx);
     USE_DEVICE(ctx);
     DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return DDX_OK;
+}
+
+int ddx_check_memory(ddx_ctx* ctx) {
+    REQUIRE_CTX(ctx);
+    USE_DEVICE(ctx);
+    if (!ctx->opt.arena_guard) return set_err(ctx, DDX_E_ARG, "the context was created without DDX_ARENA_GUARD=1");
+    DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<unsigned char> h(kArenaPad);
+    int n = 0;
+    for (const auto& blk : ctx->arena.blocks) {
+        if (blk.free) { ++n; continue; }
+        const char* pad = static_cast<const char*>(ctx->arena.chunks[blk.chunk].p) + blk.off + blk.size - kArenaPad;
+        DDX_HIP(ctx, hipMemcpy(h.data(), pad, kArenaPad, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < kArenaPad; ++i)
+            if (h[i] != 0xA5)
+                return set_err(ctx, DDX_E_NUMERIC, "buffer overflow: block %d (%zu bytes at chunk %d + %zu) was written %zu bytes past its end",
+                               n, blk.size - kArenaPad, blk.chunk, blk.off, i + 1);
+        ++n;
+    }
     return DDX_OK;
 }
 

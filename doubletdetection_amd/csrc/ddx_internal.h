@@ -36,6 +36,7 @@ constexpr int kGatherPanelRows = 4096;   // measured optimum for the gather kern
 //   DDX_KNN_SAMPLE_TILES=n size of the bound pass's subset
 //   DDX_ROW_SUMS_SEQUENTIAL=1  always replay the sequential row sums (skip the exact-integer shortcut)
 //   DDX_KNN_DEBUG=1        print candidate-list statistics
+//   DDX_ARENA_GUARD=1      overflow detector: see ddx_check_memory
 // Switches that produce wrong results (timing ablations) exist only in builds with -DDDX_ABLATION.
 struct Options {
     bool spmm_lds = true;
@@ -46,6 +47,7 @@ struct Options {
     int64_t knn_sample_tiles = 0;    // 0 = default rule
     bool row_sums_sequential = false;
     bool knn_debug = false;
+    bool arena_guard = false;        // DDX_ARENA_GUARD=1: pattern-fill the pad behind every block, ddx_check_memory verifies it
     int knn_ablation = 0;            // only honoured under DDX_ABLATION
     void read_environment();
 };
@@ -210,6 +212,7 @@ void release(ddx_ctx* ctx, DevBuf& b);
 void arena_hint(ddx_ctx* ctx, size_t bytes);      // expected total need: sizes the next chunk
 void arena_destroy(ddx_ctx* ctx);
 void context_reset(ddx_ctx* ctx);
+constexpr size_t kArenaPad = 4096;     // slack behind every block (tolerates the padded tail reads of the kernels)
 void timing_begin(ddx_ctx* ctx, const char* name);
 void timing_end(ddx_ctx* ctx);
 int timing_flush(ddx_ctx* ctx);

@@ -1231,20 +1231,23 @@ int stage_build_graph(ddx_ctx* ctx, int32_t mode) {
     const int K = ctx->K;
     const int64_t n = M * K;
     DDX_TRY(graph_weights_device(ctx, mode));
-    // workspace carved from the PCA panel buffer: cnt i32[n] | offs i64[n+1] | keys u64[2n] x2 | vals f64[2n] x2 | indptr i64[M+1] | cols i32[2n]
-    const size_t bytes = sizeof(int32_t) * n + sizeof(int64_t) * (n + 1) + 2 * sizeof(uint64_t) * 2 * n + 2 * sizeof(double) * 2 * n +
-                         sizeof(int64_t) * (M + 1) + sizeof(int32_t) * 2 * n + 1024;
+    // workspace carved from the PCA panel buffer: offs i64[n+1] | keys u64[2n] x2 | vals f64[2n] x2 | indptr i64[M+1] | cols i32[2n] | cnt i32[n+1]
+    // (sized by the same arithmetic that carves it: every piece is rounded up to 256 bytes)
+    size_t bytes = 0;
+    auto piece = [&](size_t sz) { const size_t o = bytes; bytes += (sz + 255) & ~(size_t)255; return o; };
+    const size_t o_offs = piece(sizeof(int64_t) * (n + 1)), o_ka = piece(sizeof(uint64_t) * 2 * n), o_kb = piece(sizeof(uint64_t) * 2 * n);
+    const size_t o_va = piece(sizeof(double) * 2 * n), o_vb = piece(sizeof(double) * 2 * n), o_ip = piece(sizeof(int64_t) * (M + 1));
+    const size_t o_cols = piece(sizeof(int32_t) * 2 * n), o_cnt = piece(sizeof(int32_t) * (n + 1));
     DDX_TRY(ensure(ctx, ctx->pcaPanel, bytes));
     unsigned char* base = ctx->pcaPanel.as<unsigned char>();
-    auto carve = [&](size_t sz) { unsigned char* p = base; base += (sz + 255) & ~(size_t)255; return p; };
-    int64_t* offs = reinterpret_cast<int64_t*>(carve(sizeof(int64_t) * (n + 1)));
-    uint64_t* keys_a = reinterpret_cast<uint64_t*>(carve(sizeof(uint64_t) * 2 * n));
-    uint64_t* keys_b = reinterpret_cast<uint64_t*>(carve(sizeof(uint64_t) * 2 * n));
-    double* vals_a = reinterpret_cast<double*>(carve(sizeof(double) * 2 * n));
-    double* vals_b = reinterpret_cast<double*>(carve(sizeof(double) * 2 * n));
-    int64_t* d_indptr = reinterpret_cast<int64_t*>(carve(sizeof(int64_t) * (M + 1)));
-    int32_t* d_cols = reinterpret_cast<int32_t*>(carve(sizeof(int32_t) * 2 * n));
-    int32_t* cnt = reinterpret_cast<int32_t*>(carve(sizeof(int32_t) * (n + 1)));
+    int64_t* offs = reinterpret_cast<int64_t*>(base + o_offs);
+    uint64_t* keys_a = reinterpret_cast<uint64_t*>(base + o_ka);
+    uint64_t* keys_b = reinterpret_cast<uint64_t*>(base + o_kb);
+    double* vals_a = reinterpret_cast<double*>(base + o_va);
+    double* vals_b = reinterpret_cast<double*>(base + o_vb);
+    int64_t* d_indptr = reinterpret_cast<int64_t*>(base + o_ip);
+    int32_t* d_cols = reinterpret_cast<int32_t*>(base + o_cols);
+    int32_t* cnt = reinterpret_cast<int32_t*>(base + o_cnt);
     int64_t E = 0;
     {
         ScopedTimer t(ctx, "graph_assemble");
@@ -1257,7 +1260,7 @@ int stage_build_graph(ddx_ctx* ctx, int32_t mode) {
         const int end_bit = 2 * shift;
         DDX_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp2, keys_a, keys_b, vals_a, vals_b, (int)(2 * n), 0, end_bit, ctx->stream));
         DDX_TRY(ensure(ctx, ctx->sort_tmp, std::max(tmp_bytes, tmp2)));
-        // (cnt has n entries; the scan reads one more element: it lives in the padding of the carve and is ignored)
+        // (k_pair_count fills cnt[0..n); the exclusive scan over n + 1 elements never adds cnt[n] to an output)
         DDX_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(ctx->sort_tmp.p, tmp_bytes, cnt, offs, (int)n + 1, ctx->stream));
         DDX_HIP(ctx, hipMemcpyAsync(&E, offs + n, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
         k_pair_emit<<<(unsigned)ceil_div(n, 256), 256, 0, ctx->stream>>>(ctx->knn_idx.as<int32_t>(), ctx->edge_w.as<double>(), n, K, shift, offs, keys_a, vals_a);

@@ -319,39 +319,53 @@ int stage_coarsen_graph(ddx_ctx* ctx, double gamma, int32_t sweeps, int32_t leve
     ctx->c_nodes = -1;
     ctx->lv_host_valid = false;
     // scratch (wq, keys x2, vals, sums: E each; K, tot: n; comm, next, size, used, renum, big_list: n) + two output sets
-    // (member i32[n], indptr i64[n+1], cols i32[E], w f64[E]) that the levels write alternately + the composed member table
-    const size_t out_set = sizeof(int32_t) * (size_t)n + sizeof(int64_t) * (size_t)(n + 1) + (sizeof(int32_t) + sizeof(double)) * (size_t)E + 4 * 256;
-    const size_t bytes = sizeof(int64_t) * (size_t)E * 5 + sizeof(int64_t) * (size_t)(2 * n + 8) + sizeof(int32_t) * (size_t)(7 * n + 8) + 2 * out_set + 32 * 256;
+    // (member i32[n], indptr i64[n+1], cols i32[E], w f64[E]) that the levels write alternately + the composed member tables.
+    // The layout is computed first (every piece rounded up to 256 bytes) and the buffer sized from it.
+    size_t bytes = 0;
+    auto piece = [&](size_t sz) { const size_t o = bytes; bytes += (sz + 255) & ~(size_t)255; return o; };
+    const size_t o_wq = piece(sizeof(int64_t) * E), o_ka = piece(sizeof(uint64_t) * E), o_kb = piece(sizeof(uint64_t) * E);
+    const size_t o_vb = piece(sizeof(int64_t) * E), o_sums = piece(sizeof(int64_t) * E);
+    const size_t o_K = piece(sizeof(int64_t) * n), o_tot = piece(sizeof(int64_t) * n);
+    const size_t o_comm = piece(sizeof(int32_t) * n), o_next = piece(sizeof(int32_t) * n), o_size = piece(sizeof(int32_t) * n);
+    const size_t o_used = piece(sizeof(int32_t) * (n + 1)), o_renum = piece(sizeof(int32_t) * (n + 1)), o_big = piece(sizeof(int32_t) * n);
+    const size_t o_scal = piece(256);
+    size_t o_member[2], o_indptr[2], o_cols[2], o_w[2];
+    for (int i = 0; i < 2; ++i) {
+        o_member[i] = piece(sizeof(int32_t) * n);
+        o_indptr[i] = piece(sizeof(int64_t) * (n + 1));
+        o_cols[i] = piece(sizeof(int32_t) * E);
+        o_w[i] = piece(sizeof(double) * E);
+    }
+    const size_t o_ta = piece(sizeof(int32_t) * n), o_tb = piece(sizeof(int32_t) * n);
     DDX_TRY(ensure(ctx, ctx->lv_buf, bytes));
     unsigned char* base = ctx->lv_buf.as<unsigned char>();
-    auto carve = [&](size_t sz) { unsigned char* p = base; base += (sz + 255) & ~(size_t)255; return p; };
     LvScratch sc;
-    sc.wq = reinterpret_cast<int64_t*>(carve(sizeof(int64_t) * E));
-    sc.keys_a = reinterpret_cast<uint64_t*>(carve(sizeof(uint64_t) * E));
-    sc.keys_b = reinterpret_cast<uint64_t*>(carve(sizeof(uint64_t) * E));
-    sc.vals_b = reinterpret_cast<int64_t*>(carve(sizeof(int64_t) * E));
-    sc.sums = reinterpret_cast<int64_t*>(carve(sizeof(int64_t) * E));
-    sc.K = reinterpret_cast<int64_t*>(carve(sizeof(int64_t) * n));
-    sc.tot = reinterpret_cast<unsigned long long*>(carve(sizeof(int64_t) * n));
-    sc.comm = reinterpret_cast<int32_t*>(carve(sizeof(int32_t) * n));
-    sc.next = reinterpret_cast<int32_t*>(carve(sizeof(int32_t) * n));
-    sc.size = reinterpret_cast<int32_t*>(carve(sizeof(int32_t) * n));
-    sc.used = reinterpret_cast<int32_t*>(carve(sizeof(int32_t) * (n + 1)));
-    sc.renum = reinterpret_cast<int32_t*>(carve(sizeof(int32_t) * (n + 1)));
-    sc.big_list = reinterpret_cast<int32_t*>(carve(sizeof(int32_t) * n));
-    sc.scal = reinterpret_cast<unsigned long long*>(carve(256));   // [0] = 2m, [1] = max degree | #big nodes, [2] = runs
+    sc.wq = reinterpret_cast<int64_t*>(base + o_wq);
+    sc.keys_a = reinterpret_cast<uint64_t*>(base + o_ka);
+    sc.keys_b = reinterpret_cast<uint64_t*>(base + o_kb);
+    sc.vals_b = reinterpret_cast<int64_t*>(base + o_vb);
+    sc.sums = reinterpret_cast<int64_t*>(base + o_sums);
+    sc.K = reinterpret_cast<int64_t*>(base + o_K);
+    sc.tot = reinterpret_cast<unsigned long long*>(base + o_tot);
+    sc.comm = reinterpret_cast<int32_t*>(base + o_comm);
+    sc.next = reinterpret_cast<int32_t*>(base + o_next);
+    sc.size = reinterpret_cast<int32_t*>(base + o_size);
+    sc.used = reinterpret_cast<int32_t*>(base + o_used);
+    sc.renum = reinterpret_cast<int32_t*>(base + o_renum);
+    sc.big_list = reinterpret_cast<int32_t*>(base + o_big);
+    sc.scal = reinterpret_cast<unsigned long long*>(base + o_scal);   // [0] = 2m, [1] = max degree | #big nodes, [2] = runs
     int32_t* member_set[2];
     int64_t* indptr_set[2];
     int32_t* cols_set[2];
     double* w_set[2];
     for (int i = 0; i < 2; ++i) {
-        member_set[i] = reinterpret_cast<int32_t*>(carve(sizeof(int32_t) * n));
-        indptr_set[i] = reinterpret_cast<int64_t*>(carve(sizeof(int64_t) * (n + 1)));
-        cols_set[i] = reinterpret_cast<int32_t*>(carve(sizeof(int32_t) * E));
-        w_set[i] = reinterpret_cast<double*>(carve(sizeof(double) * E));
+        member_set[i] = reinterpret_cast<int32_t*>(base + o_member[i]);
+        indptr_set[i] = reinterpret_cast<int64_t*>(base + o_indptr[i]);
+        cols_set[i] = reinterpret_cast<int32_t*>(base + o_cols[i]);
+        w_set[i] = reinterpret_cast<double*>(base + o_w[i]);
     }
-    int32_t* total_a = reinterpret_cast<int32_t*>(carve(sizeof(int32_t) * n));
-    int32_t* total_b = reinterpret_cast<int32_t*>(carve(sizeof(int32_t) * n));
+    int32_t* total_a = reinterpret_cast<int32_t*>(base + o_ta);
+    int32_t* total_b = reinterpret_cast<int32_t*>(base + o_tb);
     ScopedTimer t(ctx, "graph_coarsen");
     LvGraph cur;
     cur.n = n; cur.E = E; cur.indptr = ctx->g_d_indptr; cur.cols = ctx->g_d_cols; cur.w = ctx->g_d_vals;

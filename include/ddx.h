@@ -51,6 +51,9 @@ int ddx_device_count(int* count);
 int ddx_create(int device, ddx_ctx** out);
 int ddx_destroy(ddx_ctx* ctx);
 int ddx_synchronize(ddx_ctx* ctx);
+/* overflow detector (contexts created with DDX_ARENA_GUARD=1 in the environment): every device buffer is followed by a
+ * pattern-filled pad; returns DDX_E_NUMERIC and names the buffer if a kernel wrote past the end of one */
+int ddx_check_memory(ddx_ctx* ctx);
 /* bytes of device memory currently held by the context */
 int ddx_device_bytes(const ddx_ctx* ctx, int64_t* bytes);
 

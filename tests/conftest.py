@@ -11,6 +11,10 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# every device context made by the tests carries pattern-filled pads behind its buffers; BoostClassifier checks them when
+# a fit ends, the module-level contexts of the stage tests when they are closed (tests/test_gpu_*.py)
+os.environ.setdefault("DDX_ARENA_GUARD", "1")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` through gpurun)")
