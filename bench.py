@@ -57,6 +57,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-cells", type=int, default=20000)
     ap.add_argument("--resident-steps", type=int, default=2, help="extra fits on staged counts for value_resident (N=1)")
+    ap.add_argument("--no-exclusive", action="store_true", help="skip the extra single-context fits behind roofline_exclusive")
     return ap.parse_args()
 
 
@@ -138,10 +139,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def one_fit(resident=False):
+    def one_fit(resident=False, **extra):
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            clf = BoostClassifier(**kw)
+            clf = BoostClassifier(**kw, **extra)
             if resident:
                 clf.stage(X)                # validation + upload ahead of the clock (value_resident only)
             barrier()
@@ -167,8 +168,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     resident_elapsed = None
+    exclusive = None
     if world == 1 and args.resident_steps > 0:
         resident_elapsed = sum(one_fit(resident=True)[1] for _ in range(args.resident_steps))
+    if world == 1 and getattr(clf, "_lanes_used", 1) > 1 and not args.no_exclusive:
+        # one more fit on a single device context: every kernel has the GPU to itself, so its HIP-event duration is the
+        # kernel's own (in the timed region two contexts share the GPU and a launch is stretched by its neighbours)
+        one_fit(streams_per_device=1)
+        exclusive = one_fit(streams_per_device=1)[0]._device_timings
 
     if rank == 0:
         H = clf._num_genes
@@ -179,7 +186,7 @@ def main():
         models = kernel_models(N, G, H, S, nnz_aug, C, k, knn_window=getattr(clf, "_last_knn_window", 1.0))
         gpu_ms = {n: v[1] for n, v in timings.items()}
         dominant = max(gpu_ms, key=gpu_ms.get) if gpu_ms else None
-        def roof(name):
+        def roof(name, timings=timings):
             bound, unit, work, peak = models[name]
             avg_s = timings[name][1] / max(timings[name][0], 1) / 1e3
             achieved = work / avg_s
@@ -190,6 +197,10 @@ def main():
 
         roofline = roof(dominant) if dominant in models else None
         roofline_all = [roof(n) for n in sorted(gpu_ms, key=gpu_ms.get, reverse=True) if n in models][:6]
+        roofline_excl = None
+        if exclusive:
+            ex = {n: [v[0], v[1]] for n, v in exclusive.items()}
+            roofline_excl = [roof(n, ex) for n in sorted(ex, key=lambda n: -ex[n][1]) if n in models][:6]
         total_gpu_ms = sum(gpu_ms.values())
         out = {
             "metric": "cells/sec for full BoostClassifier.fit() (default n_iters)",
@@ -216,11 +227,15 @@ def main():
                        "host_threads": os.cpu_count()},
             "roofline": roofline,
             "roofline_top_kernels": roofline_all,
+            "roofline_exclusive": roofline_excl,
             "gpu_kernel_ms_per_step": {n: round(v / args.steps, 3) for n, v in sorted(gpu_ms.items(), key=lambda kv: -kv[1])},
             "gpu_busy_frac": round(total_gpu_ms / 1e3 / elapsed, 4),
             "host_seconds_last_step": {k2: round(v, 3) for k2, v in getattr(clf, "_host_timings", {}).items()},
             "datagen_s": round(t_gen, 2),
-            "notes": "PCA = sklearn's randomized SVD as 16 sparse operator products per iteration (no dense H x H Gram is "
+            "notes": "roofline / roofline_top_kernels: HIP events over the timed region, where two device contexts (streams) "
+                     "share the GPU, so a launch's duration includes the time it cedes to the other stream's kernels; "
+                     "roofline_exclusive: the same kernels in one extra fit on a single context (each kernel alone on the GPU).  "
+                     "PCA = sklearn's randomized SVD as 16 sparse operator products per iteration (no dense H x H Gram is "
                      "formed, DESIGN.md section 3), so there is no MFMA Gram step to report; the MFMA units run the kNN "
                      "distance screen (knn_emit / knn_bound rows of roofline_top_kernels)",
         }

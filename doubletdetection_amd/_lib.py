@@ -22,7 +22,8 @@ c_f32_p = C.POINTER(C.c_float)
 c_f64_p = C.POINTER(C.c_double)
 
 
-E_UNSUPPORTED = -5   # DDX_E_UNSUPPORTED of include/ddx.h
+E_ARG = -1           # DDX_E_ARG of include/ddx.h
+E_UNSUPPORTED = -5   # DDX_E_UNSUPPORTED
 
 
 class DdxError(RuntimeError):

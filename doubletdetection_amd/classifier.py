@@ -514,8 +514,24 @@ class BoostClassifier:
         self._host_timings["fit_total"] = time.perf_counter() - t_fit0
         return self
 
+    @staticmethod
+    def _is_plain_csr(x):
+        """A scipy CSR matrix that check_array(accept_sparse="csr", dtype="float32") would hand back untouched."""
+        return (sp_sparse.issparse(x) and x.format == "csr" and x.dtype == np.float32 and x.ndim == 2
+                and x.indices.dtype == np.int32 and x.shape[0] >= 1 and x.shape[1] >= 1)
+
     def _coerce(self, raw_counts):
-        """dd.py:149-160: float32 CSR from an ndarray or any sparse matrix (finite, 2-D)."""
+        """dd.py:149-160: float32 CSR from an ndarray or any sparse matrix (finite, 2-D).
+
+        Returns (csr, validated).  A float32 CSR is what check_array would return unchanged after reading every value
+        once on the host (finite check); that pass and the canonical-form check run on the device instead, on the
+        uploaded arrays (ddx_upload_raw / ddx_upload_counts validate what they receive) -- ``validated`` is False then
+        and ``_stage`` falls back to this host path if the device objects."""
+        if self._is_plain_csr(raw_counts):
+            return raw_counts, False
+        return self._coerce_on_host(raw_counts), True
+
+    def _coerce_on_host(self, raw_counts):
         from sklearn.utils import check_array
 
         raw_counts = check_array(raw_counts, accept_sparse="csr", ensure_all_finite=True, ensure_2d=True,
@@ -561,14 +577,24 @@ class BoostClassifier:
 
     def _stage(self, raw_counts, rank, world):
         """Validate the input and make it resident on every GPU of this process: one leader context per GPU."""
-        csr = self._coerce(raw_counts)
+        csr, validated = self._coerce(raw_counts)
         restrict = 0 < self.n_top_var_genes < csr.shape[1]
         self._check_device_limits(csr.shape[0], self.n_top_var_genes if restrict else csr.shape[1])
         leaders = {}
         try:
             for dev in self._device_list(world):
                 leaders[dev] = self._engine_factory(dev)
-            self._on_each(leaders.values(), (lambda e: e.stage_raw(csr)) if restrict else (lambda e: e.upload(csr)))
+            put = (lambda e: e.stage_raw(csr)) if restrict else (lambda e: e.upload(csr))
+            try:
+                self._on_each(leaders.values(), put)
+            except _lib.DdxError as err:
+                if validated or err.code != _lib.E_ARG:
+                    raise
+                # the device found a non-finite value or a non-canonical row in a matrix the host had not read: let
+                # check_array raise its ValueError (dd.py:149-155), or canonicalise and upload again
+                csr = self._coerce_on_host(raw_counts)
+                put = (lambda e: e.stage_raw(csr)) if restrict else (lambda e: e.upload(csr))
+                self._on_each(leaders.values(), put)
         except Exception:
             for e in leaders.values():
                 e.close()

@@ -72,12 +72,22 @@ __global__ void __launch_bounds__(256) k_gene_var(const int64_t* __restrict__ co
         const int64_t p = base + lane;
         const float v = (p < e) ? vals[p] : 0.f;
         const float sq = v * v;            // X.power(2): float32 square
-        const float a1 = v * rinv;         // (X * (1/N)) with the scalar rounded to float32
-        const float a2 = sq * rinv;
+        const int a1 = __builtin_bit_cast(int, v * rinv);     // (X * (1/N)) with the scalar rounded to float32
+        const int a2 = __builtin_bit_cast(int, sq * rinv);
         const int cnt = (int)((e - base) < 64 ? (e - base) : 64);
-        for (int t = 0; t < cnt; ++t) {
-            s1 = s1 + __shfl(a1, t, 64);
-            s2 = s2 + __shfl(a2, t, 64);
+        if (cnt == 64) {
+            // full chunk: the 64 sequential additions with compile-time lane numbers (v_readlane_b32 into an SGPR, one
+            // dependent v_add per sum) -- the two chains are independent and interleave
+#pragma unroll
+            for (int t = 0; t < 64; ++t) {
+                s1 = s1 + __builtin_bit_cast(float, __builtin_amdgcn_readlane(a1, t));
+                s2 = s2 + __builtin_bit_cast(float, __builtin_amdgcn_readlane(a2, t));
+            }
+        } else {
+            for (int t = 0; t < cnt; ++t) {
+                s1 = s1 + __builtin_bit_cast(float, __builtin_amdgcn_readlane(a1, t));
+                s2 = s2 + __builtin_bit_cast(float, __builtin_amdgcn_readlane(a2, t));
+            }
         }
     }
     if (lane == 0) {

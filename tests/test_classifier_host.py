@@ -253,6 +253,11 @@ def test_non_canonical_csr_is_canonicalised(monkeypatch):
             pass
 
         def upload(self, csr):
+            # what libddx does with the arrays it receives (ddx_upload_counts validates them on the device)
+            from doubletdetection_amd import _lib
+
+            if not csr.has_canonical_format:
+                raise _lib.DdxError(_lib.E_ARG, "CSR rows must hold strictly increasing column indices (sorted, no duplicates)")
             seen["csr"] = csr
             raise RuntimeError("stop here")
 

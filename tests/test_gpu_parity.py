@@ -555,6 +555,38 @@ def test_sparse_arpack_path_pseudocount_one(ctx):
     assert agree_ref > 0.95, agree_ref
 
 
+def test_device_side_input_validation():
+    """A float32 CSR is not read by the host at all (check_array would only run its finite check over it): the device
+    validates what it receives.  NaN / inf still raise check_array's ValueError (dd.py:149-155); rows with unsorted or
+    duplicate columns are canonicalised as scipy's indexing would (dd.py:174-176) and give the canonical matrix's result."""
+    from doubletdetection_amd import BoostClassifier
+    from doubletdetection_amd._synthetic import make_counts
+
+    counts = make_counts(800, 500, density=0.15, n_types=4, seed=3)
+    kw = dict(n_iters=2, n_top_var_genes=400, clustering_algorithm="louvain", random_state=1)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        base = BoostClassifier(**kw).fit(counts)
+        for bad_value in (np.nan, np.inf):
+            bad = counts.copy()
+            bad.data[1234] = bad_value
+            with pytest.raises(ValueError, match="NaN|infinity"):
+                BoostClassifier(**kw).fit(bad)
+        # reverse the column order inside every row and split one entry into two duplicates
+        ip = counts.indptr
+        idx = np.concatenate([counts.indices[ip[i]:ip[i + 1]][::-1] for i in range(counts.shape[0])]).astype(np.int32)
+        dat = np.concatenate([counts.data[ip[i]:ip[i + 1]][::-1] for i in range(counts.shape[0])]).astype(np.float32)
+        messy = sp.csr_matrix((dat, idx, ip.copy()), shape=counts.shape)
+        assert not messy.has_sorted_indices
+        got = BoostClassifier(**kw).fit(messy)
+        np.testing.assert_array_equal(got.all_log_p_values_, base.all_log_p_values_)
+        np.testing.assert_array_equal(messy.indices, idx)                  # the caller's matrix is left alone
+        off = counts.copy()
+        off.indices[off.indptr[7] - 1] = 9999                               # last entry of a row: beyond the 500 genes
+        with pytest.raises((ValueError, RuntimeError)):
+            BoostClassifier(**kw).fit(off)
+
+
 def test_unsupported_regimes_raise_clearly():
     from doubletdetection_amd import BoostClassifier
 
