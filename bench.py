@@ -262,8 +262,11 @@ def cpu_baseline(X, args, kw):
     def native_louvain(indptr, indices, weights, gamma, seed):
         return _lib.louvain(indptr, indices, weights, gamma, seed)[0].astype(np.int64)
 
+    def native_best_of(indptr, indices, weights, gamma, seed, q_tol):
+        return _lib.louvain_best_of(indptr, indices, weights, gamma, seed, q_tol, threads=min(20, os.cpu_count() or 1))[0].astype(np.int64)
+
     okw = dict(n_iters=iters, clustering_algorithm=kw["clustering_algorithm"], standard_scaling=kw["standard_scaling"],
-               random_state=0, louvain_fn=native_louvain, knn_fn=orc._knn_sklearn_all_cores)
+               random_state=0, louvain_fn=native_louvain, best_of_fn=native_best_of, knn_fn=orc._knn_sklearn_all_cores)
     t0 = time.perf_counter()
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")

@@ -19,7 +19,7 @@ LIB = os.path.join(HERE, "libddx.so")
 EXTRA_FLAGS = {"k_knn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 HIP_SOURCES = ["ddx_api.hip", "k_sparse.hip", "k_pca.hip", "k_knn.hip", "k_prologue.hip", "k_louvain.hip"]
 CXX_SOURCES = ["louvain.cpp", "hostmath.cpp"]
-HEADERS = ["ddx_internal.h", os.path.join("..", "..", "include", "ddx.h")]
+HEADERS = ["ddx_internal.h", "ddx_prims.h", os.path.join("..", "..", "include", "ddx.h")]
 
 
 def _hipcc():
@@ -59,7 +59,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         o = os.path.join(OBJ, src + ".o")
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-c", s, "-o", o]
+            cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-pthread", "-Wall", "-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((cmd, subprocess.Popen(cmd)))
@@ -67,7 +67,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         if p.wait() != 0:
             raise RuntimeError("compile failed: " + " ".join(cmd))
     if force or procs or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-o", LIB] + objs
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-pthread", "-o", LIB] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

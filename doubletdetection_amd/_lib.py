@@ -74,6 +74,8 @@ _SIGNATURES = {
     "ddx_get_graph": (C.c_int, [C.c_void_p, c_i64_p, c_i32_p, c_f64_p]),
     "ddx_louvain": (C.c_int, [C.c_int64, c_i64_p, c_i32_p, c_f64_p, C.c_double, C.c_uint64, c_i32_p, c_f64_p]),
     "ddx_louvain_sequential": (C.c_int, [C.c_int64, c_i64_p, c_i32_p, c_f64_p, C.c_double, C.c_uint64, c_i32_p, c_f64_p]),
+    "ddx_louvain_best_of": (C.c_int, [C.c_int64, c_i64_p, c_i32_p, c_f64_p, C.c_double, C.c_uint64, C.c_double, C.c_int32, C.c_int32,
+                                      C.c_int32, C.c_int32, c_i32_p, c_f64_p, c_i32_p]),
     "ddx_leiden": (C.c_int, [C.c_int64, c_i64_p, c_i32_p, c_f64_p, C.c_double, C.c_uint64, c_i32_p]),
     "ddx_leiden_sequential": (C.c_int, [C.c_int64, c_i64_p, c_i32_p, c_f64_p, C.c_double, C.c_uint64, c_i32_p]),
     "ddx_presweep": (C.c_int, [C.c_int64, c_i64_p, c_i32_p, c_f64_p, C.c_double, C.c_int32, c_i32_p, c_i64_p, c_i64_p, c_i32_p, c_f64_p]),
@@ -178,6 +180,23 @@ def louvain_sequential(indptr, indices, weights, gamma: float, seed: int):
     _check(lib.ddx_louvain_sequential(n, _p(indptr, c_i64_p), _p(indices, c_i32_p), _p(weights, c_f64_p), float(gamma),
                                       int(seed) & 0xFFFFFFFFFFFFFFFF, _p(labels, c_i32_p), C.byref(q)))
     return labels, q.value
+
+
+def louvain_best_of(indptr, indices, weights, gamma: float, seed: int, q_tol: float = 1e-3, stall: int = 20, max_runs: int = 1000,
+                    threads: int = 1, presweeps: bool = True):
+    """PhenoGraph's restart rule around the deterministic Louvain (ddx_louvain_best_of).  Returns (labels, quality, runs)."""
+    lib = load()
+    indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+    indices = np.ascontiguousarray(indices, dtype=np.int32)
+    weights = np.ascontiguousarray(weights, dtype=np.float64)
+    n = indptr.shape[0] - 1
+    labels = np.empty(n, dtype=np.int32)
+    q = C.c_double(0.0)
+    runs = C.c_int32(0)
+    _check(lib.ddx_louvain_best_of(n, _p(indptr, c_i64_p), _p(indices, c_i32_p), _p(weights, c_f64_p), float(gamma),
+                                   int(seed) & 0xFFFFFFFFFFFFFFFF, float(q_tol), int(stall), int(max_runs), int(threads),
+                                   1 if presweeps else 0, _p(labels, c_i32_p), C.byref(q), C.byref(runs)))
+    return labels, q.value, runs.value
 
 
 def _leiden_call(name, indptr, indices, weights, gamma, seed):

@@ -248,7 +248,8 @@ class BoostClassifier:
         random_state: Seeds PCA and the parent draws.
         verbose: Print progress messages.
         standard_scaling: Standard-scale the normalised matrix before PCA.
-        n_jobs: host worker threads for community detection (-1: all cores).
+        n_jobs: host worker threads for community detection and scoring (-1: all cores; 1, the default, lets the library
+            choose: min(32, cores)).
 
     Build-only keywords (after the reference's, so positional use is unaffected):
         device: GPU ordinal; default ``LOCAL_RANK`` under torch.distributed, else 0.
@@ -348,7 +349,8 @@ class BoostClassifier:
     _MAX_K = 64
 
     def _cluster_plan(self):
-        """(k, include_self, graph_mode, gamma, seed, min_cluster_size, leiden) for the chosen algorithm.
+        """(k, include_self, graph_mode, gamma, seed, min_cluster_size, leiden, q_tol) for the chosen algorithm
+        (q_tol: tolerance of PhenoGraph's best-of-restarts rule; None = one run).
 
         Every accepted keyword either changes the plan the way it changes the upstream call, is a documented no-op
         (worker counts, time limits, exact nearest-neighbour back-ends), or raises ``NotImplementedError`` -- a
@@ -387,11 +389,12 @@ class BoostClassifier:
                     unsupported("use_weights", False, "Leiden runs on the Jaccard weights")
                 seed = kw.get("seed")
                 seed = self.random_state if seed is None else seed
-                return k, False, mode, float(kw.get("resolution_parameter", 1.0)), int(seed), mcs, True
+                return k, False, mode, float(kw.get("resolution_parameter", 1.0)), int(seed), mcs, True, None
             # clustering_algo="louvain": upstream's Louvain binaries take no resolution, no seed and always use the
             # weights -- resolution_parameter / seed / use_weights / n_iterations only reach leidenalg.  The
-            # deterministic Louvain here is seeded from the classifier's random_state.
-            return k, False, mode, 1.0, int(self.random_state), mcs, False
+            # deterministic Louvain here is seeded from the classifier's random_state and, like upstream's runlouvain, re-run
+            # from other node orders until 20 runs in a row fail to raise the modularity by more than q_tol.
+            return k, False, mode, 1.0, int(self.random_state), mcs, False, float(kw.get("q_tol", 1e-3))
 
         # sc.tl.louvain(adata, resolution, random_state, restrict_to=None, key_added, adjacency=None,
         #   flavor="vtraag", directed=True, use_weights=False, partition_type=None, neighbors_key=None, obsp=None, copy)
@@ -413,7 +416,7 @@ class BoostClassifier:
         # sc.tl.louvain ignores the edge weights unless use_weights=True; sc.tl.leiden uses the umap connectivities
         # unless use_weights=False
         weighted = bool(kw.get("use_weights", leiden))
-        return 10, True, 3 if weighted else 2, float(kw["resolution"]), int(self.random_state), None, leiden
+        return 10, True, 3 if weighted else 2, float(kw["resolution"]), int(self.random_state), None, leiden, None
 
     def _check_device_limits(self, num_cells, num_genes):
         """Fail before anything is uploaded when a request exceeds what the device kernels hold (DESIGN.md section 7);
@@ -435,7 +438,7 @@ class BoostClassifier:
                                       f"{self._MAX_SKETCH - 10}")
 
     @staticmethod
-    def _cluster_and_score(graph, gamma, seed, min_cluster_size, num_cells, leiden=False):
+    def _cluster_and_score(graph, gamma, seed, min_cluster_size, num_cells, leiden=False, q_tol=None, threads=1):
         """Host C++: Louvain (or Leiden) -> size-sorted labels -> per-community hypergeometric test."""
         import time
 
@@ -446,10 +449,14 @@ class BoostClassifier:
             member, indptr, indices, weights = graph
             if leiden:
                 labels = _lib.leiden_sequential(indptr, indices, weights, gamma, seed)[member]
+            elif q_tol is not None:
+                labels = _lib.louvain_best_of(indptr, indices, weights, gamma, seed, q_tol, threads=threads, presweeps=False)[0][member]
             else:
                 labels = _lib.louvain_sequential(indptr, indices, weights, gamma, seed)[0][member]
         elif leiden:
             labels = _lib.leiden(*graph, gamma, seed)
+        elif q_tol is not None:
+            labels = _lib.louvain_best_of(*graph, gamma, seed, q_tol, threads=threads)[0]
         else:
             labels, _ = _lib.louvain(*graph, gamma, seed)
         t2 = time.perf_counter()
@@ -556,6 +563,20 @@ class BoostClassifier:
         if self.device is not None:
             return [int(self.device)]
         return [int(os.environ.get("LOCAL_RANK", "0")) if world > 1 else 0]
+
+    def _host_threads(self):
+        """Host threads for community detection + scoring (they run while the GPU works on the next iteration).
+        n_jobs > 1: that many; n_jobs <= 0: every core; n_jobs == 1 (the reference's default, where it only sizes
+        PhenoGraph's process pool) leaves the choice to the library: min(32, cores).  DDX_HOST_THREADS overrides."""
+        env = os.environ.get("DDX_HOST_THREADS")
+        if env:
+            return max(1, int(env))
+        cores = os.cpu_count() or 1
+        if self.n_jobs is None or self.n_jobs <= 0:
+            return cores
+        if self.n_jobs == 1:
+            return min(32, cores)
+        return int(self.n_jobs)
 
     def _stream_count(self):
         n = self.streams_per_device
@@ -688,7 +709,7 @@ class BoostClassifier:
         else:
             q0 = None      # exact regime: no random start (engine builds and diagonalises the Gram matrix)
 
-        knn_k, include_self, graph_mode, gamma, seed, min_cluster_size, leiden = self._cluster_plan()
+        knn_k, include_self, graph_mode, gamma, seed, min_cluster_size, leiden, q_tol = self._cluster_plan()
 
         # iteration i belongs to rank i % world (one process per GPU under torch.distributed); inside this process the
         # rank's iterations are dealt out over the lanes (GPUs x streams)
@@ -696,7 +717,9 @@ class BoostClassifier:
         lanes = lanes[:max(1, len(mine))]
         share = [mine[k::len(lanes)] for k in range(len(lanes))]
         pca_locks = {dev: (threading.Lock() if sum(1 for d, _ in lanes if d == dev) > 1 else None) for dev, _ in lanes}
-        workers = self.n_jobs if self.n_jobs and self.n_jobs > 0 else (os.cpu_count() or 1)
+        workers = self._host_threads()
+        # host threads one clustering job may use for its batch of restarts (the jobs of different iterations overlap)
+        restart_threads = max(1, min(20, workers // max(1, min(workers, len(mine)))))
         local = {}
         host = {"draws": time.perf_counter() - t_setup0, "device_stages": 0.0, "wait_workers": 0.0, "graph_assembly": 0.0, "louvain": 0.0, "score": 0.0}
         t_dev0 = time.perf_counter()
@@ -710,7 +733,8 @@ class BoostClassifier:
                         print("Iteration {:3}/{}".format(i + 1, n_iters))
                     graph = engine.run_iteration(all_parents[i], self.pseudocount, self.standard_scaling, n_comp,
                                                  q0, knn_k, include_self, graph_mode, gamma, pca_locks[dev])
-                    pending[i] = pool.submit(self._cluster_and_score, graph, gamma, seed, min_cluster_size, num_cells, leiden)
+                    pending[i] = pool.submit(self._cluster_and_score, graph, gamma, seed, min_cluster_size, num_cells, leiden,
+                                             q_tol, restart_threads)
 
             self._on_each(range(len(lanes)), drive)
             host["device_stages"] = time.perf_counter() - t_dev0

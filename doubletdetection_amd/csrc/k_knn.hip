@@ -7,7 +7,7 @@
 // lists every pair that could be among the k nearest, and an exact float64 evaluation + sort of those few
 // candidates (stage_knn below).  The screens only have to be conservative; the result is
 // bit-identical to an IEEE float64 brute force.
-#include <hipcub/hipcub.hpp>
+#include "ddx_prims.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -837,9 +837,9 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
         ScopedTimer t(ctx, "knn_prepare");
         k_knn_keys<<<(unsigned)ceil_div(M, 256), 256, 0, ctx->stream>>>(ctx->emb32.as<float>(), M, C, keys_in, ids_in);
         size_t tmp_bytes = 0;
-        DDX_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys_in, keys_out, ids_in, perm, (int)M, 0, 32, ctx->stream));
+        DDX_HIP(ctx, prim::sort_pairs(nullptr, tmp_bytes, keys_in, keys_out, ids_in, perm, (int)M, 0, 32, ctx->stream));
         DDX_TRY(ensure(ctx, ctx->sort_tmp, tmp_bytes));
-        DDX_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(ctx->sort_tmp.p, tmp_bytes, keys_in, keys_out, ids_in, perm, (int)M, 0, 32, ctx->stream));
+        DDX_HIP(ctx, prim::sort_pairs(ctx->sort_tmp.p, tmp_bytes, keys_in, keys_out, ids_in, perm, (int)M, 0, 32, ctx->stream));
         k_knn_prepare<<<(unsigned)ceil_div(Mp, 256), 256, 0, ctx->stream>>>(ctx->emb32.as<float>(), perm, M, Mp, C, CP, E, Et, Eb, nrm, p1, start4);
     }
     DDX_HIP(ctx, hipMemsetAsync(ccount, 0, sizeof(int32_t) * (Mp + 64), ctx->stream));
@@ -1253,15 +1253,15 @@ int stage_build_graph(ddx_ctx* ctx, int32_t mode) {
         ScopedTimer t(ctx, "graph_assemble");
         k_pair_count<<<(unsigned)ceil_div(n, 256), 256, 0, ctx->stream>>>(ctx->edge_w.as<double>(), n, cnt);
         size_t tmp_bytes = 0;
-        DDX_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, cnt, offs, (int)n + 1, ctx->stream));
+        DDX_HIP(ctx, prim::exclusive_sum(nullptr, tmp_bytes, cnt, offs, (int)n + 1, ctx->stream));
         size_t tmp2 = 0;
         int shift = 1;                               // pairs are keyed row << shift | column with shift = bits(M)
         while (((int64_t)1 << shift) < M) ++shift;
         const int end_bit = 2 * shift;
-        DDX_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp2, keys_a, keys_b, vals_a, vals_b, (int)(2 * n), 0, end_bit, ctx->stream));
+        DDX_HIP(ctx, prim::sort_pairs(nullptr, tmp2, keys_a, keys_b, vals_a, vals_b, (int)(2 * n), 0, end_bit, ctx->stream));
         DDX_TRY(ensure(ctx, ctx->sort_tmp, std::max(tmp_bytes, tmp2)));
         // (k_pair_count fills cnt[0..n); the exclusive scan over n + 1 elements never adds cnt[n] to an output)
-        DDX_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(ctx->sort_tmp.p, tmp_bytes, cnt, offs, (int)n + 1, ctx->stream));
+        DDX_HIP(ctx, prim::exclusive_sum(ctx->sort_tmp.p, tmp_bytes, cnt, offs, (int)n + 1, ctx->stream));
         DDX_HIP(ctx, hipMemcpyAsync(&E, offs + n, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
         k_pair_emit<<<(unsigned)ceil_div(n, 256), 256, 0, ctx->stream>>>(ctx->knn_idx.as<int32_t>(), ctx->edge_w.as<double>(), n, K, shift, offs, keys_a, vals_a);
         DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1269,9 +1269,9 @@ int stage_build_graph(ddx_ctx* ctx, int32_t mode) {
             // the sort picks its algorithm (single block / merge / onesweep) by the element count, and each has its own
             // temporary-storage need: ask again for the actual count
             size_t tmp3 = 0;
-            DDX_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp3, keys_a, keys_b, vals_a, vals_b, (int)E, 0, end_bit, ctx->stream));
+            DDX_HIP(ctx, prim::sort_pairs(nullptr, tmp3, keys_a, keys_b, vals_a, vals_b, (int)E, 0, end_bit, ctx->stream));
             DDX_TRY(ensure(ctx, ctx->sort_tmp, tmp3));
-            DDX_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(ctx->sort_tmp.p, tmp3, keys_a, keys_b, vals_a, vals_b, (int)E, 0, end_bit, ctx->stream));
+            DDX_HIP(ctx, prim::sort_pairs(ctx->sort_tmp.p, tmp3, keys_a, keys_b, vals_a, vals_b, (int)E, 0, end_bit, ctx->stream));
             k_cols_from_keys<<<(unsigned)ceil_div(E, 256), 256, 0, ctx->stream>>>(keys_b, E, shift, d_cols);
         }
         k_rowptr_from_keys<<<(unsigned)ceil_div(M + 1, 256), 256, 0, ctx->stream>>>(keys_b, E, M, shift, d_indptr);

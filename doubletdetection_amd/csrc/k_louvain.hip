@@ -11,7 +11,7 @@
 //     score(v,c) = (double)W(v,c) * (double)2m  -  (gamma * (double)tot'_c) * (double)k_v
 // three multiplications and a subtraction, evaluated without FMA contraction exactly as the host and the Python
 // specification do; ties go to the smaller community id, so the lane order inside a wave does not matter either.
-#include <hipcub/hipcub.hpp>
+#include "ddx_prims.h"
 
 #include <algorithm>
 
@@ -266,23 +266,23 @@ static int coarsen_level(ddx_ctx* ctx, const LvGraph& in, double gamma, int32_t 
     DDX_HIP(ctx, hipMemsetAsync(sc.used, 0, sizeof(int32_t) * (n + 1), st));
     k_lv_used<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(cur, n, sc.used);
     size_t tmp_scan = 0, tmp_sort = 0, tmp_red = 0;
-    DDX_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_scan, sc.used, sc.renum, (int)n + 1, st));
+    DDX_HIP(ctx, prim::exclusive_sum(nullptr, tmp_scan, sc.used, sc.renum, (int)n + 1, st));
     int shift = 1;                                   // keys: coarse row << shift | coarse column, shift = bits(n)
     while (((int64_t)1 << shift) < n) ++shift;
     const int end_bit = 2 * shift;
     int64_t* runs_d = reinterpret_cast<int64_t*>(sc.scal + 2);
     if (E > 0) {
-        DDX_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_sort, sc.keys_a, sc.keys_b, sc.wq, sc.vals_b, (int)E, 0, end_bit, st));
-        DDX_HIP(ctx, hipcub::DeviceReduce::ReduceByKey(nullptr, tmp_red, sc.keys_b, sc.keys_a, sc.vals_b, sc.sums, runs_d, hipcub::Sum(), (int)E, st));
+        DDX_HIP(ctx, prim::sort_pairs(nullptr, tmp_sort, sc.keys_a, sc.keys_b, sc.wq, sc.vals_b, (int)E, 0, end_bit, st));
+        DDX_HIP(ctx, prim::reduce_by_key_sum(nullptr, tmp_red, sc.keys_b, sc.keys_a, sc.vals_b, sc.sums, runs_d, (size_t)E, st));
     }
     DDX_TRY(ensure(ctx, ctx->sort_tmp, std::max(tmp_scan, std::max(tmp_sort, tmp_red))));
-    DDX_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(ctx->sort_tmp.p, tmp_scan, sc.used, sc.renum, (int)n + 1, st));
+    DDX_HIP(ctx, prim::exclusive_sum(ctx->sort_tmp.p, tmp_scan, sc.used, sc.renum, (int)n + 1, st));
     k_lv_member<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(cur, sc.renum, n, member);
     int64_t runs = 0;
     if (E > 0) {
         k_lv_edge_keys<<<(unsigned)ceil_div(n, 4), 256, 0, st>>>(in.indptr, in.cols, member, n, shift, sc.keys_a);
-        DDX_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(ctx->sort_tmp.p, tmp_sort, sc.keys_a, sc.keys_b, sc.wq, sc.vals_b, (int)E, 0, end_bit, st));
-        DDX_HIP(ctx, hipcub::DeviceReduce::ReduceByKey(ctx->sort_tmp.p, tmp_red, sc.keys_b, sc.keys_a, sc.vals_b, sc.sums, runs_d, hipcub::Sum(), (int)E, st));
+        DDX_HIP(ctx, prim::sort_pairs(ctx->sort_tmp.p, tmp_sort, sc.keys_a, sc.keys_b, sc.wq, sc.vals_b, (int)E, 0, end_bit, st));
+        DDX_HIP(ctx, prim::reduce_by_key_sum(ctx->sort_tmp.p, tmp_red, sc.keys_b, sc.keys_a, sc.vals_b, sc.sums, runs_d, (size_t)E, st));
     }
     int32_t nc = 0;
     DDX_HIP(ctx, hipMemcpyAsync(&nc, sc.renum + n, sizeof(int32_t), hipMemcpyDeviceToHost, st));

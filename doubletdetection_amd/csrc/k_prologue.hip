@@ -9,7 +9,7 @@
 //
 // column restriction (dd.py:174-176, tocsc()[:, top].tocsr()): keep the selected genes, renumber them
 // to their position in `top` (ascending-variance order), sort every row by the new column id.
-#include <hipcub/hipcub.hpp>
+#include "ddx_prims.h"
 
 #include "ddx_internal.h"
 
@@ -112,11 +112,11 @@ int stage_gene_variances(ddx_ctx* ctx, float* var_out) {
     hipError_t e = hipSuccess;
     if (n > 0) {
         size_t tmp_bytes = 0;
-        e = hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, ctx->raw_indices.as<int32_t>(), keys_out.as<int32_t>(),
+        e = prim::sort_pairs(nullptr, tmp_bytes, ctx->raw_indices.as<int32_t>(), keys_out.as<int32_t>(),
                                                ctx->raw_data.as<float>(), vals_out.as<float>(), (int)n, 0, end_bit, ctx->stream);
         if (e == hipSuccess && (rc = ensure(ctx, ctx->sort_tmp, tmp_bytes)) == DDX_OK) {
             ScopedTimer t(ctx, "hvg_sort");
-            e = hipcub::DeviceRadixSort::SortPairs(ctx->sort_tmp.p, tmp_bytes, ctx->raw_indices.as<int32_t>(), keys_out.as<int32_t>(),
+            e = prim::sort_pairs(ctx->sort_tmp.p, tmp_bytes, ctx->raw_indices.as<int32_t>(), keys_out.as<int32_t>(),
                                                    ctx->raw_data.as<float>(), vals_out.as<float>(), (int)n, 0, end_bit, ctx->stream);
         }
     }
@@ -256,7 +256,7 @@ int stage_select_columns(ddx_ctx* ctx, const int64_t* cols, int32_t H) {
         while ((1 << end_bit) < H) ++end_bit;
         size_t tmp_bytes = 0;
         const int64_t* offs = ctx->aug_indptr.as<int64_t>();
-        PR_HIP(hipcub::DeviceSegmentedRadixSort::SortPairs(nullptr, tmp_bytes, tk.as<int32_t>(), ctx->aug_indices.as<int32_t>(),
+        PR_HIP(prim::segmented_sort_pairs(nullptr, tmp_bytes, tk.as<int32_t>(), ctx->aug_indices.as<int32_t>(),
                                                            tv.as<float>(), ctx->aug_raw.as<float>(), (int)kept, (int)N, offs, offs + 1,
                                                            0, end_bit, ctx->stream));
         PR_TRY(ensure(ctx, ctx->sort_tmp, tmp_bytes));
@@ -264,7 +264,7 @@ int stage_select_columns(ddx_ctx* ctx, const int64_t* cols, int32_t H) {
         k_compact_kept<<<(unsigned)ceil_div(N, 4), 256, 0, ctx->stream>>>(ctx->raw_indptr.as<int64_t>(), ctx->raw_indices.as<int32_t>(),
                                                                           ctx->raw_data.as<float>(), newid.as<int32_t>(), N,
                                                                           ctx->aug_indptr.as<int64_t>(), tk.as<int32_t>(), tv.as<float>());
-        PR_HIP(hipcub::DeviceSegmentedRadixSort::SortPairs(ctx->sort_tmp.p, tmp_bytes, tk.as<int32_t>(), ctx->aug_indices.as<int32_t>(),
+        PR_HIP(prim::segmented_sort_pairs(ctx->sort_tmp.p, tmp_bytes, tk.as<int32_t>(), ctx->aug_indices.as<int32_t>(),
                                                            tv.as<float>(), ctx->aug_raw.as<float>(), (int)kept, (int)N, offs, offs + 1,
                                                            0, end_bit, ctx->stream));
     }

@@ -5,7 +5,7 @@
 //   - optional standard scaling                            (dd.py:302-303)
 // All kernels are HBM/L2-bound streaming or gather kernels: one wavefront (64 lanes) owns one matrix
 // row so that loads of a row are contiguous 256-byte segments; nothing here is GEMM-shaped.
-#include <hipcub/hipcub.hpp>
+#include "ddx_prims.h"
 
 #include <algorithm>
 #include <cmath>
@@ -293,11 +293,11 @@ int stage_rankings(ddx_ctx* ctx) {
     int bits_r = 1, bits_c = 1;                 // a row holds at most H entries, a column at most M: sort only those bits
     while (((int64_t)1 << bits_r) <= H) ++bits_r;
     while (((int64_t)1 << bits_c) <= M) ++bits_c;
-    DDX_HIP(ctx, hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tmp_r, keys_in, keys_out, ids_in, ids_out, (int)M, 0, bits_r, ctx->stream));
-    DDX_HIP(ctx, hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tmp_c, keys_in + M, keys_out + M, ids_in + M, ids_out + M, (int)H, 0, bits_c, ctx->stream));
+    DDX_HIP(ctx, prim::sort_pairs_desc(nullptr, tmp_r, keys_in, keys_out, ids_in, ids_out, (int)M, 0, bits_r, ctx->stream));
+    DDX_HIP(ctx, prim::sort_pairs_desc(nullptr, tmp_c, keys_in + M, keys_out + M, ids_in + M, ids_out + M, (int)H, 0, bits_c, ctx->stream));
     DDX_TRY(ensure(ctx, ctx->sort_tmp, std::max(tmp_r, tmp_c)));
-    DDX_HIP(ctx, hipcub::DeviceRadixSort::SortPairsDescending(ctx->sort_tmp.p, tmp_r, keys_in, keys_out, ids_in, ids_out, (int)M, 0, bits_r, ctx->stream));
-    DDX_HIP(ctx, hipcub::DeviceRadixSort::SortPairsDescending(ctx->sort_tmp.p, tmp_c, keys_in + M, keys_out + M, ids_in + M, ids_out + M, (int)H, 0, bits_c, ctx->stream));
+    DDX_HIP(ctx, prim::sort_pairs_desc(ctx->sort_tmp.p, tmp_r, keys_in, keys_out, ids_in, ids_out, (int)M, 0, bits_r, ctx->stream));
+    DDX_HIP(ctx, prim::sort_pairs_desc(ctx->sort_tmp.p, tmp_c, keys_in + M, keys_out + M, ids_in + M, ids_out + M, (int)H, 0, bits_c, ctx->stream));
     ctx->rank_rows = ids_out;
     ctx->rank_cols = ids_out + M;
     return DDX_OK;
@@ -373,13 +373,13 @@ static int build_csc(ddx_ctx* ctx, int64_t e0, int64_t n, int64_t row_lo, int64_
     int end_bit = 1;
     while (((int64_t)1 << end_bit) < nkeys64) ++end_bit;
     size_t tmp_bytes = 0;
-    DDX_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, ctx->sort_keys_in.as<int32_t>(), ctx->sort_keys_out.as<int32_t>(),
+    DDX_HIP(ctx, prim::sort_pairs(nullptr, tmp_bytes, ctx->sort_keys_in.as<int32_t>(), ctx->sort_keys_out.as<int32_t>(),
                                                     ctx->sort_vals_in.as<uint32_t>(), ctx->sort_vals_out.as<uint32_t>(),
                                                     (int)n, 0, end_bit, ctx->stream));
     DDX_TRY(ensure(ctx, ctx->sort_tmp, tmp_bytes));
     {
         ScopedTimer t(ctx, "csc_radix_sort");
-        DDX_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(ctx->sort_tmp.p, tmp_bytes, ctx->sort_keys_in.as<int32_t>(),
+        DDX_HIP(ctx, prim::sort_pairs(ctx->sort_tmp.p, tmp_bytes, ctx->sort_keys_in.as<int32_t>(),
                                                         ctx->sort_keys_out.as<int32_t>(), ctx->sort_vals_in.as<uint32_t>(),
                                                         ctx->sort_vals_out.as<uint32_t>(), (int)n, 0, end_bit, ctx->stream));
     }
@@ -792,10 +792,10 @@ if (ctx->counts_exact)
     DDX_TRY(ensure(ctx, ctx->median, 256));
     {
         size_t tmp_bytes = 0;
-        DDX_HIP(ctx, hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, ctx->lib32.as<float>(), ctx->lib_sorted.as<float>(), (int)M, 0, 32, ctx->stream));
+        DDX_HIP(ctx, prim::sort_keys(nullptr, tmp_bytes, ctx->lib32.as<float>(), ctx->lib_sorted.as<float>(), (int)M, 0, 32, ctx->stream));
         DDX_TRY(ensure(ctx, ctx->sort_tmp, tmp_bytes));
         ScopedTimer t(ctx, "median");
-        DDX_HIP(ctx, hipcub::DeviceRadixSort::SortKeys(ctx->sort_tmp.p, tmp_bytes, ctx->lib32.as<float>(), ctx->lib_sorted.as<float>(), (int)M, 0, 32, ctx->stream));
+        DDX_HIP(ctx, prim::sort_keys(ctx->sort_tmp.p, tmp_bytes, ctx->lib32.as<float>(), ctx->lib_sorted.as<float>(), (int)M, 0, 32, ctx->stream));
         k_median_from_sorted<<<1, 64, 0, ctx->stream>>>(ctx->lib_sorted.as<float>(), M, ctx->median.as<float>());
     }
     // column-major mirror of the synthetic rows

@@ -10,6 +10,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <thread>
 #include <vector>
 
 #include "../../include/ddx.h"
@@ -700,6 +701,71 @@ extern "C" int ddx_louvain(int64_t n_nodes, const int64_t* indptr, const int32_t
     }
     sequential_levels(g, gamma, seed, membership, quality_out);
     for (int64_t v = 0; v < n_nodes; ++v) labels_out[v] = membership[total[v]];
+    return DDX_OK;
+}
+
+// PhenoGraph's restart rule on top of part B (upstream phenograph.core.runlouvain, reached from dd.py:320-322: the
+// Louvain executable is run again and again, each time from another random node order; a run replaces the best result
+// when its modularity exceeds the best by more than q_tol; the loop ends after `stall` consecutive runs without such a
+// gain).  Run r uses seed + r, so the outcome is a function of (graph, gamma, seed, q_tol, stall) only.  Runs are
+// independent of each other: a batch of `stall` of them is evaluated on host threads at once and the rule is then
+// applied in run order; runs of the batch behind the stopping point are discarded, exactly as if never started.
+extern "C" int ddx_louvain_best_of(int64_t n_nodes, const int64_t* indptr, const int32_t* indices, const double* weights,
+                                   double gamma, uint64_t seed, double q_tol, int32_t stall, int32_t max_runs, int32_t threads,
+                                   int32_t presweeps, int32_t* labels_out, double* quality_out, int32_t* runs_out) {
+    if (!labels_out || stall < 1 || max_runs < 1) return DDX_E_ARG;
+    if (runs_out) *runs_out = 0;
+    if (quality_out) *quality_out = 0.0;
+    if (n_nodes == 0) return DDX_OK;
+    Graph g, coarse;
+    const int rc = load_graph(n_nodes, indptr, indices, weights, g);
+    if (rc != DDX_OK) return rc;
+    std::vector<int32_t> total(n_nodes), member;
+    for (int64_t v = 0; v < n_nodes; ++v) total[v] = (int32_t)v;
+    if (presweeps) {
+        for (int lvl = 0; lvl < DDX_PRESWEEP_LEVELS; ++lvl) {
+            presweep(g, gamma, DDX_PRESWEEPS, member, coarse);
+            for (int64_t v = 0; v < n_nodes; ++v) total[v] = member[total[v]];
+            g.indptr.swap(coarse.indptr);
+            g.indices.swap(coarse.indices);
+            g.weights.swap(coarse.weights);
+        }
+    }
+    std::vector<int32_t> best;
+    double best_q = 0.0;
+    int32_t run = 0, updated = 0;
+    bool have = false;
+    const int nthreads = threads < 1 ? 1 : threads;
+    while (run - updated < stall && run < max_runs) {
+        const int batch = std::min<int32_t>(stall, max_runs - run);
+        std::vector<std::vector<int32_t>> memb(batch);
+        std::vector<double> q(batch, 0.0);
+        const int nt = std::min(nthreads, batch);
+        auto work = [&](int t) {
+            for (int b = t; b < batch; b += nt) {
+                Graph copy = g;                      // sequential_levels consumes its graph
+                sequential_levels(copy, gamma, seed + (uint64_t)(run + b), memb[b], &q[b]);
+            }
+        };
+        if (nt <= 1) {
+            work(0);
+        } else {
+            std::vector<std::thread> pool;
+            for (int t = 0; t < nt; ++t) pool.emplace_back(work, t);
+            for (auto& th : pool) th.join();
+        }
+        for (int b = 0; b < batch && run - updated < stall; ++b, ++run) {
+            if (!have || q[b] - best_q > q_tol) {
+                best.swap(memb[b]);
+                best_q = q[b];
+                updated = run;
+                have = true;
+            }
+        }
+    }
+    for (int64_t v = 0; v < n_nodes; ++v) labels_out[v] = best[total[v]];
+    if (quality_out) *quality_out = best_q;
+    if (runs_out) *runs_out = run;
     return DDX_OK;
 }
 

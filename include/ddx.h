@@ -187,6 +187,14 @@ int ddx_leiden(int64_t n_nodes, const int64_t* indptr, const int32_t* indices, c
                uint64_t seed, int32_t* labels_out /* [n_nodes] */);
 int ddx_leiden_sequential(int64_t n_nodes, const int64_t* indptr, const int32_t* indices, const double* weights,
                           double gamma, uint64_t seed, int32_t* labels_out /* [n_nodes] */);
+/* ddx_louvain_best_of: PhenoGraph's restart rule (upstream phenograph.core.runlouvain behind dd.py:320-322): part B is
+ * run from seeds seed, seed+1, ...; a run replaces the best when its modularity is larger by more than q_tol; stop after
+ * `stall` consecutive runs without such a gain (upstream: q_tol = 1e-3, 20 runs) or after max_runs.  presweeps != 0 runs
+ * part A first (the host statement of ddx_coarsen_graph), presweeps == 0 takes the graph as it is (already coarsened on
+ * the device).  `threads` host threads evaluate a batch of runs at once; the result does not depend on it. */
+int ddx_louvain_best_of(int64_t n_nodes, const int64_t* indptr, const int32_t* indices, const double* weights, double gamma,
+                        uint64_t seed, double q_tol, int32_t stall, int32_t max_runs, int32_t threads, int32_t presweeps,
+                        int32_t* labels_out /* [n_nodes] */, double* quality_out, int32_t* runs_out);
 int ddx_presweep(int64_t n_nodes, const int64_t* indptr, const int32_t* indices, const double* weights, double gamma,
                  int32_t sweeps, int32_t* member_out /* [n_nodes] */, int64_t* n_coarse_out,
                  int64_t* c_indptr_out /* [n_nodes+1] */, int32_t* c_indices_out /* [nnz] */, double* c_weights_out /* [nnz] */);

@@ -448,14 +448,17 @@ def _knn_sklearn_all_cores(emb, k, include_self):
 
 
 def cluster_embedding(emb: np.ndarray, algorithm: str, clustering_kwargs: dict, random_state: int,
-                      louvain_fn=None, knn_fn=None) -> np.ndarray:
+                      louvain_fn=None, knn_fn=None, best_of_fn=None) -> np.ndarray:
     """kNN -> graph -> deterministic community detection -> size-sorted labels.
 
     ``louvain_fn(indptr, indices, weights, gamma, seed) -> labels``: defaults to the pure-Python
     specification in ``oracle/louvain_ref.py``; bench's cpu_baseline leg passes a compiled
     implementation of the same specification to keep the timing meaningful.
+    ``best_of_fn(indptr, indices, weights, gamma, seed, q_tol) -> labels``: PhenoGraph's restart rule
+    (``louvain_ref.louvain_best_of`` by default).
     """
     louvain_fn = louvain_fn or louvain_ref.louvain
+    best_of_fn = best_of_fn or (lambda ip, ix, w, gamma, seed, q_tol: louvain_ref.louvain_best_of(ip, ix, w, gamma, seed, q_tol)[0])
     knn_fn = knn_fn or knn_bruteforce_f64
     kw = dict(clustering_kwargs or {})
     if algorithm == "phenograph":
@@ -468,8 +471,9 @@ def cluster_embedding(emb: np.ndarray, algorithm: str, clustering_kwargs: dict, 
             seed = random_state if seed is None else int(seed)
             lab = louvain_ref.leiden(G.indptr, G.indices, G.data, float(kw.get("resolution_parameter", 1.0)), seed)
         else:
-            # the Louvain binaries take neither a resolution nor a seed: gamma = 1, deterministic seed = random_state
-            lab = louvain_fn(G.indptr, G.indices, G.data, 1.0, int(random_state))
+            # the Louvain binaries take neither a resolution nor a seed (gamma = 1, deterministic seed = random_state) and
+            # are re-run until 20 runs in a row gain less than q_tol (phenograph.core.runlouvain)
+            lab = best_of_fn(G.indptr, G.indices, G.data, 1.0, int(random_state), float(kw.get("q_tol", 1e-3)))
         return relabel_by_size(lab, int(kw.get("min_cluster_size", 10)))
     idx, dist = knn_fn(emb, 10, include_self=True)
     gamma = float(kw.get("resolution", 4))
@@ -556,7 +560,7 @@ class OracleClassifier:
     def __init__(self, boost_rate=0.25, n_components=30, n_top_var_genes=10000, replace=False,
                  clustering_algorithm="phenograph", clustering_kwargs=None, n_iters=10,
                  pseudocount=0.1, random_state=0, standard_scaling=False, pca="sklearn",
-                 louvain_fn=None, knn_fn=None):
+                 louvain_fn=None, knn_fn=None, best_of_fn=None):
         if clustering_algorithm not in ("louvain", "phenograph", "leiden"):
             raise ValueError("Clustering algorithm needs to be one of ['louvain', 'phenograph', 'leiden']")
         self.boost_rate = 0.5 if (not replace and boost_rate > 0.5) else boost_rate
@@ -578,6 +582,7 @@ class OracleClassifier:
         self.pca = pca
         self.louvain_fn = louvain_fn
         self.knn_fn = knn_fn
+        self.best_of_fn = best_of_fn
         self.rng = np.random.default_rng(random_state)
         self.timings = collections.defaultdict(float)
 
@@ -619,7 +624,7 @@ class OracleClassifier:
                 emb = pca_f64(aug, self.n_components, self.random_state)[0].astype(np.float32)
             t3 = time.perf_counter()
             full = cluster_embedding(emb, self.clustering_algorithm, self.clustering_kwargs,
-                                     self.random_state, self.louvain_fn, self.knn_fn)
+                                     self.random_state, self.louvain_fn, self.knn_fn, self.best_of_fn)
             t4 = time.perf_counter()
             sc_, lp_ = score_communities(full, N)
             t5 = time.perf_counter()

@@ -175,7 +175,7 @@ def _one_level(indptr, indices, weights, gamma, rng):
         m2 += deg[v]
     comm = list(range(n))
     if m2 == 0.0:
-        return comm, False
+        return comm, False, 0.0
     tot = deg[:]
     in_ = loops[:]
     order = _visit_order(n, rng)
@@ -230,7 +230,7 @@ def _one_level(indptr, indices, weights, gamma, rng):
         if not (moves > 0 and new_q - cur_q > MIN_GAIN):
             break
         active = next_active
-    return comm, improved
+    return comm, improved, new_q
 
 
 def _aggregate(indptr, indices, weights, comm):
@@ -271,8 +271,8 @@ def louvain(indptr, indices, weights, gamma: float = 1.0, seed: int = 0, preswee
     return lab if member is None else lab[member]
 
 
-def _louvain_sequential(indptr, indices, weights, gamma: float = 1.0, seed: int = 0) -> np.ndarray:
-    """Part B."""
+def _louvain_sequential(indptr, indices, weights, gamma: float = 1.0, seed: int = 0, with_quality: bool = False):
+    """Part B.  ``with_quality``: also return Q of the final partition (the quality the last level evaluates)."""
     indptr = [int(x) for x in np.asarray(indptr)]
     indices = [int(x) for x in np.asarray(indices)]
     weights = [float(x) for x in np.asarray(weights, dtype=np.float64)]
@@ -280,13 +280,36 @@ def _louvain_sequential(indptr, indices, weights, gamma: float = 1.0, seed: int 
     rng = SplitMix64(seed)
     membership = list(range(n))
     gamma = float(gamma)
+    q = 0.0
     while True:
-        comm, improved = _one_level(indptr, indices, weights, gamma, rng)
+        comm, improved, q = _one_level(indptr, indices, weights, gamma, rng)
         indptr, indices, weights, renum = _aggregate(indptr, indices, weights, comm)
         membership = [renum[comm[c]] for c in membership]
         if not improved:
             break
-    return np.asarray(membership, dtype=np.int64)
+    membership = np.asarray(membership, dtype=np.int64)
+    return (membership, q) if with_quality else membership
+
+
+def louvain_best_of(indptr, indices, weights, gamma: float = 1.0, seed: int = 0, q_tol: float = 1e-3, stall: int = 20,
+                    max_runs: int = 1000, presweeps: int = PRESWEEPS, presweep_levels: int = PRESWEEP_LEVELS):
+    """PhenoGraph's restart rule around part B (upstream ``phenograph.core.runlouvain``, reached from dd.py:320-322 --
+    restated, the package is absent): the Louvain executable is run again and again from another random node order; a
+    run replaces the best result when its modularity exceeds the best by more than ``q_tol`` (1e-3 upstream); the loop
+    ends after ``stall`` (20) consecutive runs without such a gain.  Upstream seeds every run from time / pid; here run r
+    uses ``seed + r``, so the outcome is a function of (graph, gamma, seed, q_tol, stall).  Part A (the pre-sweeps) is
+    deterministic and runs once.  Returns (labels, quality of the kept run, number of runs)."""
+    member = None
+    for _ in range(presweep_levels if presweeps > 0 else 0):
+        m, indptr, indices, weights = presweep(indptr, indices, weights, gamma, presweeps)
+        member = m if member is None else m[member]
+    best, best_q, run, updated = None, 0.0, 0, 0
+    while run - updated < stall and run < max_runs:
+        lab, q = _louvain_sequential(indptr, indices, weights, gamma, (seed + run) & 0xFFFFFFFFFFFFFFFF, with_quality=True)
+        if best is None or q - best_q > q_tol:
+            best, best_q, updated = lab, q, run
+        run += 1
+    return (best if member is None else best[member]), best_q, run
 
 
 # ----------------------------------------------------------------------------------------------------------------------

@@ -194,11 +194,11 @@ def test_clustering_kwargs_never_silently_ignored():
             return BoostClassifier(clustering_algorithm=algo, clustering_kwargs=kw, random_state=3)._cluster_plan()
 
     # phenograph defaults: k=30, no self, pruned Jaccard graph, Louvain binaries take no resolution and no seed
-    assert plan("phenograph") == (30, False, 0, 1.0, 3, 10, False)
-    assert plan("phenograph", resolution_parameter=2.5, seed=9) == (30, False, 0, 1.0, 3, 10, False)
+    assert plan("phenograph") == (30, False, 0, 1.0, 3, 10, False, 1e-3)
+    assert plan("phenograph", resolution_parameter=2.5, seed=9) == (30, False, 0, 1.0, 3, 10, False, 1e-3)
     assert plan("phenograph", clustering_algo="leiden", resolution_parameter=2.5, seed=9, prune=False, k=15,
-                min_cluster_size=4) == (15, False, 1, 2.5, 9, 4, True)
-    assert plan("phenograph", nn_method="brute", n_jobs=4, q_tol=1e-4, louvain_time_limit=10)[:3] == (30, False, 0)
+                min_cluster_size=4) == (15, False, 1, 2.5, 9, 4, True, None)
+    assert plan("phenograph", nn_method="brute", n_jobs=4, q_tol=1e-4, louvain_time_limit=10) == (30, False, 0, 1.0, 3, 10, False, 1e-4)
     for bad in ({"directed": True}, {"jaccard": False}, {"primary_metric": "cosine"}, {"nn_method": "faiss"},
                 {"partition_type": object()}, {"clustering_algo": "leiden", "n_iterations": 3},
                 {"clustering_algo": "leiden", "use_weights": False}):
@@ -207,10 +207,10 @@ def test_clustering_kwargs_never_silently_ignored():
     with pytest.raises(ValueError):
         plan("phenograph", clustering_algo="spectral")
     # scanpy: louvain ignores weights unless asked, leiden uses them unless asked not to
-    assert plan("louvain") == (10, True, 2, 4.0, 3, None, False)
-    assert plan("louvain", use_weights=True, resolution=1.5) == (10, True, 3, 1.5, 3, None, False)
-    assert plan("leiden") == (10, True, 3, 4.0, 3, None, True)
-    assert plan("leiden", use_weights=False) == (10, True, 2, 4.0, 3, None, True)
+    assert plan("louvain") == (10, True, 2, 4.0, 3, None, False, None)
+    assert plan("louvain", use_weights=True, resolution=1.5) == (10, True, 3, 1.5, 3, None, False, None)
+    assert plan("leiden") == (10, True, 3, 4.0, 3, None, True, None)
+    assert plan("leiden", use_weights=False) == (10, True, 2, 4.0, 3, None, True, None)
     for algo, bad in (("louvain", {"directed": True}), ("louvain", {"restrict_to": ("a", ["1"])}),
                       ("leiden", {"adjacency": 1}), ("louvain", {"obsp": "x"}), ("leiden", {"neighbors_key": "n"}),
                       ("louvain", {"partition_type": object()}), ("louvain", {"flavor": "igraph"}),

@@ -25,6 +25,12 @@ def _native_louvain(indptr, indices, weights, gamma, seed):
     return _lib.louvain(indptr, indices, weights, gamma, seed)[0].astype(np.int64)
 
 
+def _native_best_of(indptr, indices, weights, gamma, seed, q_tol):
+    from doubletdetection_amd import _lib
+
+    return _lib.louvain_best_of(indptr, indices, weights, gamma, seed, q_tol, threads=8)[0].astype(np.int64)
+
+
 def _ari(a, b):
     from sklearn.metrics import adjusted_rand_score
 
@@ -263,7 +269,7 @@ def test_c1_whole_fit_matches_oracle(data_c1):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         clf = BoostClassifier(n_jobs=-1, **kw).fit(data_c1)
-        ref = orc.OracleClassifier(pca="f64", louvain_fn=_native_louvain, **kw).fit(data_c1)
+        ref = orc.OracleClassifier(pca="f64", louvain_fn=_native_louvain, best_of_fn=_native_best_of, **kw).fit(data_c1)
         np.testing.assert_array_equal(clf.top_var_genes_, ref.top_var_genes_)
         np.testing.assert_array_equal(np.asarray(clf.parents_), np.asarray(ref.parents_))
         agree = float(np.mean(clf.communities_ == ref.communities_))

@@ -150,6 +150,31 @@ def test_presweep_and_sequential_parts_match_specification(n, k, seed, weighted,
     assert q_whole > q_seq - 0.02
 
 
+@pytest.mark.parametrize("n,k,seed,weighted,gamma,q_tol", [(400, 6, 1, True, 1.0, 1e-3), (900, 5, 77, False, 4.0, 1e-3),
+                                                           (1500, 8, 5, True, 1.0, 1e-5), (300, 4, 2, True, 1.0, 0.5)])
+def test_best_of_restarts_matches_python_specification(n, k, seed, weighted, gamma, q_tol):
+    """PhenoGraph's restart rule (oracle/louvain_ref.py:louvain_best_of): labels, kept modularity and the number of runs
+    are those of the Python statement, whatever number of host threads evaluates the batches."""
+    A = _random_graph(n, k, seed, weighted)
+    lab, q, runs = louvain_ref.louvain_best_of(A.indptr, A.indices, A.data, gamma, seed, q_tol)
+    assert runs >= 20                                              # never fewer than `stall` runs
+    for threads in (1, 7):
+        got, gq, gruns = _lib.louvain_best_of(A.indptr, A.indices, A.data, gamma, seed, q_tol, threads=threads)
+        np.testing.assert_array_equal(got, lab)
+        assert gq == q and gruns == runs
+    # the kept run is at least as good as the single deterministic run, and its Q is the modularity of its labels
+    single, q_single = _lib.louvain(A.indptr, A.indices, A.data, gamma, seed)
+    assert q >= q_single
+    mq = louvain_ref.modularity(A.indptr, A.indices, A.data, lab, gamma)
+    # (part A quantises the weights to multiples of 2**-20 before part B sees them)
+    assert abs(mq - q) < 1e-4
+    # without part A the rule applies to the graph as given (how the classifier finishes a graph coarsened on the GPU)
+    lab2, q2, runs2 = louvain_ref.louvain_best_of(A.indptr, A.indices, A.data, gamma, seed, q_tol, presweeps=0)
+    got2, gq2, gruns2 = _lib.louvain_best_of(A.indptr, A.indices, A.data, gamma, seed, q_tol, threads=3, presweeps=False)
+    np.testing.assert_array_equal(got2, lab2)
+    assert gq2 == q2 and gruns2 == runs2
+
+
 def test_louvain_edge_cases():
     # no edges at all
     ip = np.zeros(6, dtype=np.int64)
