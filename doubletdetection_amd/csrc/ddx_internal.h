@@ -36,6 +36,7 @@ constexpr int kGatherPanelRows = 4096;   // measured optimum for the gather kern
 //   DDX_KNN_SAMPLE_TILES=n size of the bound pass's subset
 //   DDX_ROW_SUMS_SEQUENTIAL=1  always replay the sequential row sums (skip the exact-integer shortcut)
 //   DDX_KNN_DEBUG=1        print candidate-list statistics
+//   DDX_MIRROR=sort        column-major mirror by radix sort (the counting sort's reference)
 //   DDX_ARENA_GUARD=1      overflow detector: see ddx_check_memory
 // Switches that produce wrong results (timing ablations) exist only in builds with -DDDX_ABLATION.
 struct Options {
@@ -47,6 +48,7 @@ struct Options {
     int64_t knn_sample_tiles = 0;    // 0 = default rule
     bool row_sums_sequential = false;
     bool knn_debug = false;
+    bool mirror_counting = true;     // DDX_MIRROR=sort: build the column-major mirror by radix sort instead of counting sort
     bool arena_guard = false;        // DDX_ARENA_GUARD=1: pattern-fill the pad behind every block, ddx_check_memory verifies it
     int knn_ablation = 0;            // only honoured under DDX_ABLATION
     void read_environment();
