@@ -147,6 +147,7 @@ struct ddx_ctx {
 
     // normalisation state
     float pseudocount = 0.1f;
+    float zvalue = 0.f;              // value of the unstored entries before scaling: log(pseudocount), or 0 for log1p
     bool have_lognorm = false;
     bool scaled = false;
     ddx::DevBuf median;              // float [1] (+ scratch)

@@ -261,6 +261,8 @@ struct LdsSpmmArgs {
     // COLS
     const int64_t* cp_o; const int32_t* row_o; const float* x_o; int P_o;
     const int64_t* cp_s; const int32_t* row_s; const float* x_s; int p_s0, P_s;
+    int z_uniform;                // ROWS: every column has the same value for unstored entries (no scaling): zval, no table
+    float zval;
     double* out;                  // ROWS: Y [M x L];  COLS: partials [groups x H x L]
     float* out32;                 // ROWS: padded float32 copy of Y [M x ld] for the A^T Y pass that follows (or null)
 };
@@ -303,21 +305,34 @@ __device__ __forceinline__ LdsFetch<SLOTS> lds_fetch(const int32_t* __restrict__
 // CPL: sketch columns per lane (2: ds_read_b64 per entry, 4: ds_read_b128).
 template <bool ROWS, int SLOTS, bool PK, int CPL>
 __device__ __forceinline__ void lds_round(const LdsFetch<SLOTS>& f, const int (&nvalid)[SLOTS], int nsteps, int32_t base, const double (&zc)[SLOTS],
-                                          const unsigned char* opB, const float* zS, int ld, double* dS, uint32_t* offS, int lane,
+                                          const unsigned char* opB, const float* zS, bool zuni, float zval, int ld, double* dS, uint32_t* offS, int lane,
                                           const double* myd, const uint32_t* myoff, double (&acc)[CPL]) {
     typedef uint32_t u4 __attribute__((ext_vector_type(4)));
     typedef float fq __attribute__((ext_vector_type(CPL)));
+    // value of the unstored entries of each entry's column.  ROWS: one constant when the matrix is not scaled (no
+    // lookup at all); otherwise the SLOTS table reads are issued together, ahead of the first use (one LDS round trip
+    // for the round instead of one per lane group)
+    int idx[SLOTS];
+    float zf[SLOTS];
+#pragma unroll
+    for (int g = 0; g < SLOTS; ++g) idx[g] = lane < nvalid[g] ? f.i[g] - base : 0;
+    if (ROWS && !zuni) {
+#pragma unroll
+        for (int g = 0; g < SLOTS; ++g) zf[g] = zS[idx[g]];
+    } else {
+#pragma unroll
+        for (int g = 0; g < SLOTS; ++g) zf[g] = ROWS ? zval : (float)zc[g];
+    }
 #pragma unroll
     for (int g = 0; g < SLOTS; ++g) {
         const bool ok = lane < nvalid[g];
-        const int i = ok ? f.i[g] - base : 0;
+        const int i = idx[g];
         if (DDX_SPMM_DBG & 32) continue;
         if (PK) {
             // x - z in float32 is the correctly rounded difference, i.e. what the float64 difference rounds to
-            const float zf = ROWS ? zS[i] : (float)zc[g];
-            reinterpret_cast<float*>(dS)[g * kLdsOStride + lane] = ok ? f.x[g] - zf : 0.0f;
+            reinterpret_cast<float*>(dS)[g * kLdsOStride + lane] = ok ? f.x[g] - zf[g] : 0.0f;
         } else {
-            const double z = ROWS ? (double)zS[i] : zc[g];
+            const double z = ROWS ? (double)zf[g] : zc[g];
             dS[g * kLdsDStride + lane] = ok ? (double)f.x[g] - z : 0.0;
         }
         offS[g * kLdsOStride + lane] = __umul24((uint32_t)i, (uint32_t)(ld * 4));      // i < 2^24, ld * 4 < 2^24
@@ -416,6 +431,7 @@ __global__ void __launch_bounds__(kLdsThreads) k_spmm_lds(const LdsSpmmArgs a) {
     const unsigned char* opB = smem + 4 * CPL * sub;  // this lane's sketch columns of operand row 0
     const int owner = (int)(blockIdx.x % a.owners);
     const int group = (int)(blockIdx.x / a.owners);
+    const bool zuni = ROWS && a.z_uniform != 0;
     constexpr int PERW = SLOTS * OWN;               // outputs per wave; local output m = k*SLOTS + g
 
     // Local output (k, g) of this wave -> rank in the outputs sorted by their number of stored entries -> output.
@@ -456,7 +472,7 @@ __global__ void __launch_bounds__(kLdsThreads) k_spmm_lds(const LdsSpmmArgs a) {
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + base + lane),
                                                      (__attribute__((address_space(3))) void*)(dst + base), 16, 0, 0);
             }
-            if (ROWS)
+            if (ROWS && !zuni)
                 for (int i = threadIdx.x; i < nr; i += kLdsThreads) zS[i] = a.zcol[r0 + i];
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -519,7 +535,7 @@ __global__ void __launch_bounds__(kLdsThreads) k_spmm_lds(const LdsSpmmArgs a) {
                         int nvalid[SLOTS];
 #pragma unroll
                         for (int g = 0; g < SLOTS; ++g) nvalid[g] = (h[g] - l[g]) - r * kLdsChunk;
-                        lds_round<ROWS, SLOTS, PK, CPL>(cur, nvalid, nsteps, (int32_t)r0, zc, opB, zS, a.ld, dS, offS, lane, myd, myoff, acc[k]);
+                        lds_round<ROWS, SLOTS, PK, CPL>(cur, nvalid, nsteps, (int32_t)r0, zc, opB, zS, zuni, a.zval, a.ld, dS, offS, lane, myd, myoff, acc[k]);
                     }
                     cur = nxt;
                     if (!more) break;
@@ -1002,6 +1018,8 @@ static int apply_rows(PcaWork& w, const double* Qcol, double* Yrow) {  // A Q : 
         a.nOut = w.M; a.owners = lds_owners(w.M, slots, a.ld);
         a.indptr = c->aug_indptr.as<int64_t>(); a.cols = c->aug_indices.as<int32_t>(); a.x = c->aug_x.as<float>();
         a.zcol = c->zcol.as<float>(); a.rowseg = c->rowseg.as<int32_t>(); a.tvec = tvec; a.out = Yrow;
+        a.z_uniform = c->scaled ? 0 : 1;              // unscaled: every column's unstored value is log(pseudocount)
+        a.zval = c->zvalue;
         a.perm = c->rank_rows;
         const size_t lds_bytes = (size_t)a.SR * a.ld * 4 + (size_t)((a.SR + 3) & ~3) * 4 + lds_stage_bytes(slots, lds_packed());
         return launch_lds<true>(c, a, slots, (unsigned)a.owners, lds_bytes);

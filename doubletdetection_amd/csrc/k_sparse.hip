@@ -965,6 +965,7 @@ if (ctx->counts_exact)
     DDX_TRY(ensure(ctx, ctx->colmean, sizeof(double) * H));
     const float z = use_log1p ? 0.f : (float)std::log((double)pseudocount);
     k_fill_f32<<<(unsigned)ceil_div(H, 256), 256, 0, ctx->stream>>>(ctx->zcol.as<float>(), H, z);
+    ctx->zvalue = z;
     {
         ScopedTimer t(ctx, "col_sums");
         DDX_TRY(col_sums(ctx, 0, ctx->colmean.as<double>()));
