@@ -716,7 +716,8 @@ class BoostClassifier:
         mine = [i for i in range(n_iters) if i % world == rank]
         lanes = lanes[:max(1, len(mine))]
         share = [mine[k::len(lanes)] for k in range(len(lanes))]
-        pca_locks = {dev: (threading.Lock() if sum(1 for d, _ in lanes if d == dev) > 1 else None) for dev, _ in lanes}
+        use_lock = os.environ.get("DDX_PCA_LOCK", "1") not in ("", "0")       # A/B switch: PCA stages of one GPU take turns
+        pca_locks = {dev: (threading.Lock() if use_lock and sum(1 for d, _ in lanes if d == dev) > 1 else None) for dev, _ in lanes}
         workers = self._host_threads()
         # host threads one clustering job may use for its batch of restarts (the jobs of different iterations overlap)
         restart_threads = max(1, min(20, workers // max(1, min(workers, len(mine)))))

@@ -555,6 +555,35 @@ def test_sparse_arpack_path_pseudocount_one(ctx):
     assert agree_ref > 0.95, agree_ref
 
 
+def test_fit_with_empty_cells_and_empty_genes():
+    """Ragged input: cells without any count (library size 0: sklearn's row normalisation leaves them untouched, their
+    log-normalised row is the constant log(pseudocount)), genes nobody expresses, a cell with a single count.  The
+    whole fit equals the float64 oracle; doublets of an empty parent equal the other parent."""
+    from doubletdetection_amd import BoostClassifier
+    from doubletdetection_amd._synthetic import make_counts
+
+    counts = make_counts(700, 500, density=0.15, n_types=4, seed=13).tolil()
+    for r in (0, 17, 350, 699):
+        counts[r, :] = 0
+    counts[5, :] = 0
+    counts[5, 123] = 2
+    counts[:, [3, 250, 499]] = 0
+    counts = sp.csr_matrix(counts.tocsr(), dtype=np.float32)
+    counts.eliminate_zeros()
+    for kw in (dict(n_top_var_genes=400, clustering_algorithm="louvain"), dict(n_top_var_genes=0, standard_scaling=True)):
+        kw = dict(n_iters=2, random_state=4, **kw)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            clf = BoostClassifier(**kw).fit(counts)
+            ref = orc.OracleClassifier(pca="f64", **kw).fit(counts)
+        np.testing.assert_array_equal(np.asarray(clf.parents_), np.asarray(ref.parents_))
+        np.testing.assert_array_equal(clf.communities_, ref.communities_)
+        np.testing.assert_array_equal(clf.synth_communities_, ref.synth_communities_)
+        np.testing.assert_array_equal(clf.all_scores_, ref.all_scores_)
+        np.testing.assert_allclose(clf.all_log_p_values_, ref.all_log_p_values_, rtol=1e-9, atol=1e-9)
+        assert np.all(np.isfinite(clf.all_scores_[~np.isnan(clf.all_scores_)]))
+
+
 def test_device_side_input_validation():
     """A float32 CSR is not read by the host at all (check_array would only run its finite check over it): the device
     validates what it receives.  NaN / inf still raise check_array's ValueError (dd.py:149-155); rows with unsorted or
