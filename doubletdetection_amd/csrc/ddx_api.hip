@@ -35,6 +35,13 @@ void release(ddx_ctx* ctx, DevBuf& b) {
     b.blk = -1;
 }
 
+int allow_dynamic_lds(ddx_ctx* ctx, const void* kernel, int bytes) {
+    if (ctx->lds_configured.count(kernel)) return DDX_OK;
+    DDX_HIP(ctx, hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    ctx->lds_configured[kernel] = true;
+    return DDX_OK;
+}
+
 void arena_hint(ddx_ctx* ctx, size_t bytes) {
     if (bytes > ctx->arena.next_chunk) ctx->arena.next_chunk = bytes;
 }

@@ -91,6 +91,7 @@ struct ddx_ctx {
     hipStream_t stream = nullptr;
     ddx::Options opt;
     ddx::Arena arena;
+    std::map<const void*, bool> lds_configured;   // kernels whose dynamic-LDS limit was raised on this context's device
     std::string err;
     int64_t dev_bytes = 0;
 
@@ -215,6 +216,9 @@ void release(ddx_ctx* ctx, DevBuf& b);
 void arena_hint(ddx_ctx* ctx, size_t bytes);      // expected total need: sizes the next chunk
 void arena_destroy(ddx_ctx* ctx);
 void context_reset(ddx_ctx* ctx);
+// raise a kernel's dynamic shared-memory limit once per context (the attribute is per device: a process-wide flag would
+// leave the second GPU of a multi-GPU process with the 64 KB default)
+int allow_dynamic_lds(ddx_ctx* ctx, const void* kernel, int bytes);
 constexpr size_t kArenaPad = 4096;     // slack behind every block (tolerates the padded tail reads of the kernels)
 void timing_begin(ddx_ctx* ctx, const char* name);
 void timing_end(ddx_ctx* ctx);

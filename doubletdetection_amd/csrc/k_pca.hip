@@ -965,11 +965,7 @@ static int lds_owners(int64_t nOut, int slots, int ld) {
 
 template <bool ROWS, int SLOTS, bool PK, int CPL, int OWN>
 static int launch_lds_t(ddx_ctx* c, const LdsSpmmArgs& a, unsigned grid, size_t lds_bytes) {
-    static bool configured = false;
-    if (!configured) {
-        DDX_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmm_lds<ROWS, SLOTS, PK, CPL, OWN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
-        configured = true;
-    }
+    DDX_TRY(allow_dynamic_lds(c, reinterpret_cast<const void*>(&k_spmm_lds<ROWS, SLOTS, PK, CPL, OWN>), (int)kLdsBudget));
     k_spmm_lds<ROWS, SLOTS, PK, CPL, OWN><<<grid, kLdsThreads, lds_bytes, c->stream>>>(a);
     return DDX_OK;
 }

@@ -461,12 +461,8 @@ static int build_csc(ddx_ctx* ctx, int64_t e0, int64_t n, int64_t row_lo, int64_
     uint16_t* cnt = reinterpret_cast<uint16_t*>(base + o_cnt);
     uint32_t* tot = reinterpret_cast<uint32_t*>(base + o_tot);
     int64_t* scan = reinterpret_cast<int64_t*>(base + o_scan);
-    static bool configured = false;
-    if (!configured) {
-        DDX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mirror_count), hipFuncAttributeMaxDynamicSharedMemorySize, kMirrorMaxH * 4));
-        DDX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mirror_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, kMirrorMaxH * 4));
-        configured = true;
-    }
+    DDX_TRY(allow_dynamic_lds(ctx, reinterpret_cast<const void*>(&k_mirror_count), kMirrorMaxH * 4));
+    DDX_TRY(allow_dynamic_lds(ctx, reinterpret_cast<const void*>(&k_mirror_scatter), kMirrorMaxH * 4));
     const size_t lds = sizeof(uint32_t) * (size_t)H;
     ScopedTimer t(ctx, "mirror_build");
     k_mirror_count<<<(unsigned)n_sb, kMirrorThreads, lds, ctx->stream>>>(ctx->aug_indptr.as<int64_t>(), ctx->aug_indices.as<int32_t>(), row_lo, row_hi,
