@@ -17,6 +17,11 @@ rm -rf /tmp/prof_stats
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- $bench > "$out/${tag}_stats_bench.log" 2>&1
 f=$(find /tmp/prof_stats -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && cp "$f" "$out/${tag}_kernel_stats.csv"
+# the same command on a single device context: every kernel alone on the GPU (what bench.py's `roofline` reports)
+rm -rf /tmp/prof_stats1
+DDX_STREAMS=1 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats1 -- $bench > "$out/${tag}_stats_bench_1stream.log" 2>&1
+f1=$(find /tmp/prof_stats1 -name "*kernel_stats.csv" | head -1)
+[ -n "$f1" ] && cp "$f1" "$out/${tag}_kernel_stats_1stream.csv"
 t=$(find /tmp/prof_stats -name "*kernel_trace.csv" | head -1)
 [ -n "$t" ] && python - "$t" > "$out/${tag}_launch_sequence.txt" <<'PY'
 import csv, sys
