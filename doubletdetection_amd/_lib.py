@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libddx.so")
+LIB_PATH = os.environ.get("DDX_LIB") or os.path.join(_HERE, "libddx.so")      # DDX_LIB: an experimental build (profiles/tools)
 ABI_VERSION = 1
 
 _lib = None
