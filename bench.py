@@ -99,7 +99,8 @@ def kernel_models(N, G, H, S, nnz_aug, C, k, L=None, knn_window=1.0):
         "doublet_fill": ("hbm", "GB/s", (8 * (nnz_aug * 2 * S / max(M + S, 1)) * 2) / 1e9, HBM_PEAK_GBS),
         "lognorm_rows": ("hbm", "GB/s", (8 * nnz_aug + 8 * M) / 1e9, HBM_PEAK_GBS),
         "lognorm_cols": ("hbm", "GB/s", (12 * nnz_aug) / 1e9, HBM_PEAK_GBS),
-        "csc_radix_sort": ("hbm", "GB/s", (16 * nnz_aug * S / max(M, 1)) / 1e9, HBM_PEAK_GBS),
+        # counting-sort mirror of the synthetic rows: columns read twice (4 B), raw values once (4 B), (row, raw) written once (8 B)
+        "mirror_build": ("hbm", "GB/s", (20 * nnz_aug * 2 * S / max(M + S, 1)) / 1e9, HBM_PEAK_GBS),
     }
 
 

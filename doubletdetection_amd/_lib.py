@@ -12,7 +12,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DDX_LIB") or os.path.join(_HERE, "libddx.so")      # DDX_LIB: an experimental build (profiles/tools)
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _lib = None
 

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DDX_ABI_VERSION 1
+#define DDX_ABI_VERSION 2
 
 #define DDX_OK 0
 #define DDX_E_ARG -1      /* invalid argument / stage called out of order */
