@@ -73,18 +73,6 @@ constexpr int kBoundKeepSmall = 4;   // k <= 48
 constexpr int kBoundKeepLarge = 6;   // k <= 80
 constexpr int kCandCap = 768;      // candidate slots per query between the emit and select passes
 
-
-// Workgroup b runs on XCD b % 8 (observed placement, MI355X_MICROARCH.md; used for L2 locality only, never for
-// correctness).  The MFMA passes walk, per block of queries, a window of candidate tiles around the block's position in
-// first-component order: neighbouring query blocks share most of their window.  Handing each XCD a contiguous range of
-// logical blocks makes the blocks that are resident on an XCD at the same time read the same tiles, so the tiles are
-// fetched into that XCD's L2 once instead of once per XCD.  Launch 8 * ceil(nblocks / 8) workgroups.
-__device__ __forceinline__ int64_t xcd_block(int64_t nblocks) {
-    const int64_t per = (nblocks + 7) >> 3;
-    return (int64_t)(blockIdx.x & 7) * per + (int64_t)(blockIdx.x >> 3);
-}
-static inline unsigned xcd_grid(int64_t nblocks) { return (unsigned)(8 * ((nblocks + 7) >> 3)); }
-
 // ================================================================================================
 // exact kNN in three passes (16x16 query x candidate tiles on v_mfma_f32_16x16x32_bf16 with a bfloat16 hi/lo split,
 // or on v_mfma_f32_16x16x4_f32 with DDX_KNN_SCREEN=f32); points are in first-principal-component order:
@@ -180,9 +168,7 @@ __global__ void __launch_bounds__(256) k_knn_bound(const float* __restrict__ Et,
     __shared__ __attribute__((aligned(16))) float lds_c[2][kChunkTiles * 16 * CP];
     __shared__ float lds_n[2][kChunkTiles * 16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t blk = xcd_block(Mp / (64 * RT));
-    if (blk >= Mp / (64 * RT)) return;
-    const int64_t q0 = ((int64_t)blk * 4 + wave) * (16 * RT);     // Mp is a multiple of 256: no partial blocks
+    const int64_t q0 = ((int64_t)blockIdx.x * 4 + wave) * (16 * RT);     // Mp is a multiple of 256: no partial blocks
     QueryTiles<CP, RT> qt;
     qt.load(Et, q0, lane);
     const int rbase = 4 * (lane >> 4), jcol = lane & 15;
@@ -197,7 +183,7 @@ __global__ void __launch_bounds__(256) k_knn_bound(const float* __restrict__ Et,
     const int64_t own_tile = q0 >> 4;
     const int64_t nchunks = (nsamp_tiles + kChunkTiles - 1) / kChunkTiles;
         // sample = the nsamp_tiles tiles around this block in first-component order (contiguous, see stage_knn)
-    int64_t tile0 = (((int64_t)blk * 4) * RT) + 2 * RT - nsamp_tiles / 2;
+    int64_t tile0 = (((int64_t)blockIdx.x * 4) * RT) + 2 * RT - nsamp_tiles / 2;
     if (tile0 > (Mp >> 4) - nsamp_tiles) tile0 = (Mp >> 4) - nsamp_tiles;
     if (tile0 < 0) tile0 = 0;
     const float* Etw = Et + tile0 * 16 * CP;
@@ -279,9 +265,7 @@ __global__ void __launch_bounds__(256) k_knn_emit(const float* __restrict__ Et, 
     __shared__ int32_t lcnt[4][16 * kEmitRT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (lane < 16 * kEmitRT) lcnt[wave][lane] = 0;
-    const int64_t blk = xcd_block(Mp / (64 * RT));
-    if (blk >= Mp / (64 * RT)) return;
-    const int64_t q0 = ((int64_t)blk * 4 + wave) * (16 * RT);     // Mp is a multiple of 256: no partial blocks
+    const int64_t q0 = ((int64_t)blockIdx.x * 4 + wave) * (16 * RT);     // Mp is a multiple of 256: no partial blocks
     QueryTiles<CP, RT> qt;
     qt.load(Et, q0, lane);
     const int rbase = 4 * (lane >> 4), jcol = lane & 15;
@@ -295,7 +279,7 @@ __global__ void __launch_bounds__(256) k_knn_emit(const float* __restrict__ Et, 
         else if (!(t < __builtin_huge_valf())) hr[v] = -__builtin_huge_valf(); // no bound: everything passes
     }
     // candidate tiles whose first component can be within reach of any query of this block (k_knn_window)
-    const int64_t t_lo = win[2 * blk], ntiles = win[2 * blk + 1] - t_lo;
+    const int64_t t_lo = win[2 * blockIdx.x], ntiles = win[2 * blockIdx.x + 1] - t_lo;
     if (ntiles <= 0) {                          // block-uniform: nothing can be within reach
         if (lane < 16 * kEmitRT) ccount[q0 + lane] = 0;
         return;
@@ -446,9 +430,7 @@ __global__ void __launch_bounds__(256) k_knn_bound_bf(const __bf16* __restrict__
     __shared__ f4 lds_c[2][kChunkTiles * tile_vecs];
     __shared__ float lds_n[2][kChunkTiles * 16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t blk = xcd_block(Mp / (64 * RT));
-    if (blk >= Mp / (64 * RT)) return;
-    const int64_t q0 = ((int64_t)blk * 4 + wave) * (16 * RT);
+    const int64_t q0 = ((int64_t)blockIdx.x * 4 + wave) * (16 * RT);
     QueryTilesBf<CP, RT> qt;
     qt.load(Eb, q0, lane);
     const int rbase = 4 * (lane >> 4), jcol = lane & 15;
@@ -463,7 +445,7 @@ __global__ void __launch_bounds__(256) k_knn_bound_bf(const __bf16* __restrict__
     const int64_t own_tile = q0 >> 4;
     const int64_t nchunks = (nsamp_tiles + kChunkTiles - 1) / kChunkTiles;
         // sample = the nsamp_tiles tiles around this block in first-component order (contiguous, see stage_knn)
-    int64_t tile0 = (((int64_t)blk * 4) * RT) + 2 * RT - nsamp_tiles / 2;
+    int64_t tile0 = (((int64_t)blockIdx.x * 4) * RT) + 2 * RT - nsamp_tiles / 2;
     if (tile0 > (Mp >> 4) - nsamp_tiles) tile0 = (Mp >> 4) - nsamp_tiles;
     if (tile0 < 0) tile0 = 0;
     const __bf16* Ebw = Eb + tile0 * 16 * CP * 2;
@@ -538,9 +520,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DDX_EM
     __shared__ f4 lds_c[2][kChunkTiles * tile_vecs];
     __shared__ f4 lds_h[2][kChunkTiles * 16];     // accumulator start values -0.5*(1-slack)*|c|^2 (see commit_start)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t blk = xcd_block(Mp / (64 * RT));
-    if (blk >= Mp / (64 * RT)) return;
-    const int64_t q0 = ((int64_t)blk * 4 + wave) * (16 * RT);
+    const int64_t q0 = ((int64_t)blockIdx.x * 4 + wave) * (16 * RT);
     QueryTilesBf<CP, RT> qt;
     qt.load(Eb, q0, lane);
     const int rbase = 4 * (lane >> 4), jcol = lane & 15;
@@ -560,7 +540,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DDX_EM
         if (dbg & 1) hr[v] = __builtin_huge_valf();          // experiment: nothing passes the screen
     }
     // candidate tiles whose first component can be within reach of any query of this block (k_knn_window)
-    const int64_t t_lo = win[2 * blk], ntiles = win[2 * blk + 1] - t_lo;
+    const int64_t t_lo = win[2 * blockIdx.x], ntiles = win[2 * blockIdx.x + 1] - t_lo;
     if (ntiles <= 0) {                          // block-uniform: nothing can be within reach
         if (lane < 16 * kEmitRT) ccount[q0 + lane] = 0;
         return;
@@ -875,7 +855,7 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
     const int64_t stride = 1;
     {
         ScopedTimer t(ctx, "knn_bound");
-        const unsigned grid = xcd_grid(Mp / (4 * 16 * kBoundRT));
+        const unsigned grid = (unsigned)(Mp / (4 * 16 * kBoundRT));
 #define DDX_BOUND_LAUNCH(KERNEL, OPERAND)                                                                                        \
     do {                                                                                                                       \
         if (CP == 32 && keep_small) KERNEL<32, kBoundKeepSmall><<<grid, 256, 0, ctx->stream>>>(OPERAND, nrm, Mp, k, include_self, nsamp, stride, thr); \
@@ -889,14 +869,13 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
     }
     {
         ScopedTimer t(ctx, "knn_emit");
-        const unsigned grid = (unsigned)emit_blocks;          // k_knn_window: one workgroup per logical block
-        const unsigned egrid = xcd_grid(emit_blocks);         // emit: XCD-aware placement of the logical blocks
+        const unsigned grid = (unsigned)emit_blocks;
         const int dbg_mode = ctx->opt.knn_ablation;     // timing ablations (wrong results): non-zero only in -DDDX_ABLATION builds
         k_knn_window<<<grid, 64, 0, ctx->stream>>>(p1, thr, nrm, Mp, win, reinterpret_cast<unsigned long long*>(ccount + Mp + 2));
-        if (bf && CP == 32) k_knn_emit_bf<32><<<egrid, 256, 0, ctx->stream>>>(Eb, nrm, start4, thr, Mp, include_self, ccount, cbuf, win, dbg_mode);
-        else if (bf) k_knn_emit_bf<64><<<egrid, 256, 0, ctx->stream>>>(Eb, nrm, start4, thr, Mp, include_self, ccount, cbuf, win, dbg_mode);
-        else if (CP == 32) k_knn_emit<32><<<egrid, 256, 0, ctx->stream>>>(Et, nrm, thr, Mp, include_self, ccount, cbuf, win);
-        else k_knn_emit<64><<<egrid, 256, 0, ctx->stream>>>(Et, nrm, thr, Mp, include_self, ccount, cbuf, win);
+        if (bf && CP == 32) k_knn_emit_bf<32><<<grid, 256, 0, ctx->stream>>>(Eb, nrm, start4, thr, Mp, include_self, ccount, cbuf, win, dbg_mode);
+        else if (bf) k_knn_emit_bf<64><<<grid, 256, 0, ctx->stream>>>(Eb, nrm, start4, thr, Mp, include_self, ccount, cbuf, win, dbg_mode);
+        else if (CP == 32) k_knn_emit<32><<<grid, 256, 0, ctx->stream>>>(Et, nrm, thr, Mp, include_self, ccount, cbuf, win);
+        else k_knn_emit<64><<<grid, 256, 0, ctx->stream>>>(Et, nrm, thr, Mp, include_self, ccount, cbuf, win);
     }
     {
         ScopedTimer t(ctx, "knn_select");
