@@ -545,7 +545,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DDX_EM
         if (lane < 16 * kEmitRT) ccount[q0 + lane] = 0;
         return;
     }
-    const int64_t own_tile = q0 >> 4;
+    const int32_t own_tile = (int32_t)(q0 >> 4);
     const int64_t nchunks = (ntiles + kChunkTiles - 1) / kChunkTiles;
     // Chunk staging by asynchronous global -> LDS copies (16 bytes per lane, LDS destination = wave-uniform base +
     // lane*16, no registers held): a chunk of kChunkTiles tiles is contiguous in Eb, as are its start quads.
@@ -574,24 +574,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DDX_EM
         const int buf = (int)(ch & 1);
         if (ch + 1 < nchunks) stage(ch + 1, buf ^ 1);
         const int ntile = (int)((ntiles - ch * kChunkTiles) < kChunkTiles ? (ntiles - ch * kChunkTiles) : kChunkTiles);
-        // operands of tile t+1 are read from LDS while tile t is on the matrix pipe
         const f4* tb = lds_c[buf];
-        f4 rh = tb[lane], rl = tb[64 + lane], rs = lds_h[buf][jcol];
         static_assert(CP == 32 || CP == 64, "");
-        for (int t = 0; t < ntile; ++t) {
-            const int64_t tile = t_lo + ch * kChunkTiles + t;
-            const int tn = t + 1 < ntile ? t + 1 : t;
-            f4 acc[RT];
-            if (CP == 32) {
-                const f4 ch_ = rh, cl_ = rl, cs_ = rs;
-                rh = tb[tn * tile_vecs + lane];
-                rl = tb[tn * tile_vecs + 64 + lane];
-                rs = lds_h[buf][tn * 16 + jcol];
-                qt.dots_regs(ch_, cl_, cs_, acc);
-            } else {
-                qt.dots_from(tb + t * tile_vecs, lane, lds_h[buf][t * 16 + jcol], acc);
-            }
-            // one compare per pair; the wave-wide masks live in scalar registers
+        // one compare per pair; the wave-wide masks live in scalar registers
+        auto judge = [&](const f4 (&acc)[RT], const int32_t tile) {
             unsigned long long any = 0, hm[NV];
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
@@ -599,7 +585,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DDX_EM
                 any |= hm[v];
             }
             if (any) {
-                const int32_t cand = (int32_t)(tile * 16 + jcol);
+                const int32_t cand = tile * 16 + jcol;
                 const bool own = !include_self && (tile >= own_tile && tile < own_tile + RT);
 #pragma unroll
                 for (int v = 0; v < NV; ++v) {
@@ -616,6 +602,37 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DDX_EM
                         cnt[v] += __popc(m16);
                     }
                 }
+            }
+        };
+        const int32_t tile0 = (int32_t)t_lo + (int32_t)ch * kChunkTiles;
+        if (CP == 32) {
+            // operands of the next tile are read from LDS while the current one is on the matrix pipe; two register
+            // sets (A, B) alternate, two tiles per trip, so that nothing is copied between them
+            f4 ah_ = tb[lane], al_ = tb[64 + lane], as_ = lds_h[buf][jcol];
+            int t = 0;
+            for (; t + 1 < ntile; t += 2) {
+                const f4 bh_ = tb[(t + 1) * tile_vecs + lane], bl_ = tb[(t + 1) * tile_vecs + 64 + lane], bs_ = lds_h[buf][(t + 1) * 16 + jcol];
+                f4 acc[RT];
+                qt.dots_regs(ah_, al_, as_, acc);
+                judge(acc, tile0 + t);
+                const int t2 = t + 2 < ntile ? t + 2 : t + 1;
+                ah_ = tb[t2 * tile_vecs + lane];
+                al_ = tb[t2 * tile_vecs + 64 + lane];
+                as_ = lds_h[buf][t2 * 16 + jcol];
+                f4 acc2[RT];
+                qt.dots_regs(bh_, bl_, bs_, acc2);
+                judge(acc2, tile0 + t + 1);
+            }
+            if (t < ntile) {
+                f4 acc[RT];
+                qt.dots_regs(ah_, al_, as_, acc);
+                judge(acc, tile0 + t);
+            }
+        } else {
+            for (int t = 0; t < ntile; ++t) {
+                f4 acc[RT];
+                qt.dots_from(tb + t * tile_vecs, lane, lds_h[buf][t * 16 + jcol], acc);
+                judge(acc, tile0 + t);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the next chunk has landed before anyone crosses the barrier
