@@ -34,8 +34,8 @@ import numpy as np  # noqa: E402
 
 # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide
 # coalesced reads, + WRITE_SIZE), headline workload, profiles/r01n_pmc_counters.txt; None = not collected
-PMC_TRAFFIC_GB = {"spmm_rows": 1.57, "spmm_cols": 1.58, "knn_emit": 4.76, "knn_bound": 0.89, "knn_select": 0.42}
-PMC_TRAFFIC_SOURCE = ("profiles/r02e_pmc_counters.txt (separate rocprofv3 --pmc passes of this command, round 2; a constant of this "
+PMC_TRAFFIC_GB = {"spmm_rows": 1.57, "spmm_cols": 1.58, "knn_emit": 4.96, "knn_bound": 0.89, "knn_select": 0.42}
+PMC_TRAFFIC_SOURCE = ("profiles/r02i_pmc_counters.txt (separate rocprofv3 --pmc passes of this command, round 2; a constant of this "
                       "file, not re-measured by the run that prints it)")
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md)
@@ -171,8 +171,13 @@ def main():
         elapsed = float(t.item())
     resident_elapsed = None
     exclusive = None
+    plain_elapsed = None
     if world == 1 and args.resident_steps > 0:
         resident_elapsed = sum(one_fit(resident=True)[1] for _ in range(args.resident_steps))
+        # the same fits without the per-kernel HIP events (two events per timed scope, ~1 300 scopes per fit)
+        os.environ["DDX_TIMING"] = "0"
+        plain_elapsed = sum(one_fit()[1] for _ in range(args.resident_steps))
+        os.environ["DDX_TIMING"] = "1"
     if world == 1 and getattr(clf, "_lanes_used", 1) > 1 and not args.no_exclusive:
         # one more fit on a single device context: every kernel has the GPU to itself, so its HIP-event duration is the
         # kernel's own (in the timed region two contexts share the GPU and a launch is stretched by its neighbours)
@@ -222,6 +227,7 @@ def main():
             "timed_region": "BoostClassifier(**kw).fit(host scipy CSR): check_array-equivalent validation + PCIe upload + "
                             "HVG prologue + n_iters iterations + gather (dd.py:135-214)",
             "value_resident": (round(N * args.resident_steps / resident_elapsed, 2) if resident_elapsed else None),
+            "value_uninstrumented": (round(N * args.resident_steps / plain_elapsed, 2) if plain_elapsed else None),
             "unit": "cells/s",
             "n_gpus": world,
             "steps": args.steps,
