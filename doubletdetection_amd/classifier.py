@@ -97,8 +97,14 @@ class _HipEngine:
         if timing:
             self.ctx.timing_reset()
 
-    def close(self):
+    def close(self, discard: bool = False):
+        """Park the context for the next fit, or destroy it (``discard``: a fit that failed does not hand its context,
+        possibly in an error state, to the next one)."""
         if self.ctx is not None:
+            if discard:
+                ctx, self.ctx = self.ctx, None
+                ctx.close()
+                return
             if os.environ.get("DDX_ARENA_GUARD", "0") not in ("", "0"):
                 self.ctx.check_memory()                  # overflow detector (tests): raises, naming the buffer
             if _keep_contexts():
@@ -508,6 +514,9 @@ class BoostClassifier:
             self._host_timings["prologue"] = t_prologue
             self._host_timings["stage"] = t_staged - t_fit0
         finally:
+            import sys
+
+            failed = sys.exc_info()[0] is not None
             t0 = time.perf_counter()
             try:
                 draws.result()             # never leave the Generator in use by a worker
@@ -515,7 +524,10 @@ class BoostClassifier:
                 pass
             drawer.shutdown(wait=True)
             for e in {id(e): e for e in list(leaders.values()) + [ln[1] for ln in lanes]}.values():
-                e.close()
+                if failed and hasattr(e, "ctx"):
+                    e.close(discard=True)
+                else:
+                    e.close()
         self._host_timings["close"] = time.perf_counter() - t0
         self._host_timings["fit_total"] = time.perf_counter() - t_fit0
         return self
