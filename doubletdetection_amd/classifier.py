@@ -524,8 +524,8 @@ class BoostClassifier:
                 pass
             drawer.shutdown(wait=True)
             for e in {id(e): e for e in list(leaders.values()) + [ln[1] for ln in lanes]}.values():
-                if failed and hasattr(e, "ctx"):
-                    e.close(discard=True)
+                if failed:
+                    self._discard(e)
                 else:
                     e.close()
         self._host_timings["close"] = time.perf_counter() - t0
@@ -629,7 +629,7 @@ class BoostClassifier:
                 self._on_each(leaders.values(), put)
         except Exception:
             for e in leaders.values():
-                e.close()
+                self._discard(e)
             raise
         return csr, leaders, restrict
 
@@ -654,9 +654,17 @@ class BoostClassifier:
             self._on_each(list(zip(made, followers)), lambda p: p[0][1].clone_from(p[1][1]))
         except Exception:
             for _, f in made:
-                f.close()
+                self._discard(f)
             raise
         return lanes + made
+
+    @staticmethod
+    def _discard(engine):
+        """Close an engine after a failure: the HIP engine destroys its context instead of parking it."""
+        try:
+            engine.close(discard=True)
+        except TypeError:                 # test engines without the keyword
+            engine.close()
 
     def _drop_stage(self):
         staged = getattr(self, "_staged", None)
