@@ -47,15 +47,18 @@ def _worker(rank, world, port, case, n_iters, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case,n_iters", [("case_c_reftest_scaled", 3), ("case_a_hvg_pheno", 2)])
-def test_two_rank_fit_equals_single_process(tmp_path, case, n_iters):
+@pytest.mark.parametrize("case,n_iters,world", [("case_c_reftest_scaled", 3, 2), ("case_a_hvg_pheno", 2, 2),
+                                                ("case_c_reftest_scaled", 5, 3), ("case_b_transposed_louvain", 2, 3)])
+def test_multi_rank_fit_equals_single_process(tmp_path, case, n_iters, world):
+    """world ranks (uneven shares: 5 iterations over 3 ranks; a rank without any iteration: 2 over 3), each dealing its
+    iterations out over two device contexts; the byte-packed all-gather leaves the complete result on every rank."""
     import torch.multiprocessing as mp
 
     from doubletdetection_amd import BoostClassifier
     from oracle_engine import make_engine_factory
 
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, case, n_iters, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, port, case, n_iters, str(tmp_path)), nprocs=world, join=True)
     g = load_golden(case)
     kw = golden_kwargs(g)
     kw["n_iters"] = n_iters
@@ -68,7 +71,7 @@ def test_two_rank_fit_equals_single_process(tmp_path, case, n_iters):
             single_labels = single.predict()
     finally:
         BoostClassifier._engine_factory = old
-    for rank in (0, 1):                                  # every rank holds the complete result
+    for rank in range(world):                            # every rank holds the complete result
         r = np.load(tmp_path / f"rank{rank}.npz")
         np.testing.assert_array_equal(r["parents"], np.asarray(single.parents_))
         np.testing.assert_array_equal(r["comm"], single.communities_)
