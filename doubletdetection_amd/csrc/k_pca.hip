@@ -229,7 +229,7 @@ __global__ void __launch_bounds__(256) k_spmm_cols(const int64_t* __restrict__ c
 // All orders are fixed.
 // ------------------------------------------------------------------------------------------------
 #ifndef DDX_SPMM_DBG
-#define DDX_SPMM_DBG 0      // ablation builds only (profiles/tools/spmm_ablation.sh): 1 no operand reads, 2 no entry fetches, 4 no staged reads, 8 no slice staging, 16 no trips, 32 no entry staging
+#define DDX_SPMM_DBG 0      // ablation builds only (profiles/tools/spmm_ablation.sh): 1 no operand reads, 2 no entry fetches, 4 no staged reads, 8 no slice staging, 16 no trips, 32 no entry staging, 64 conflict-free operand rows
 #endif
 constexpr int kLdsOwnG = 6;        // outputs owned by one lane group
 #ifndef DDX_LDS_WAVES
@@ -350,6 +350,15 @@ __device__ __forceinline__ void lds_round(const LdsFetch<SLOTS>& f, const int (&
             if (DDX_SPMM_DBG & 4) {
 #pragma unroll
                 for (int u = 0; u < 2; ++u) { fv[u] = (f4v)((float)t0); ov[u] = (u4)((uint32_t)(t0 * 160 + u * 640)) + (u4){0u, 160u, 320u, 480u}; }
+            }
+            if (DDX_SPMM_DBG & 64) {
+                // ablation: operand rows whose bank ranges never collide inside a half-wave (row classes 0, 1, 7 mod 8 for the
+                // three lane groups): what conflict-free operand reads would be worth
+                const uint32_t cls = (uint32_t)((myoff - offS) / kLdsOStride) == 0u ? 0u : ((uint32_t)((myoff - offS) / kLdsOStride) == 1u ? 1u : 7u);
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ov[u][e] = ((((uint32_t)t0 + 4u * u + e) & 63u) * 8u + cls) * (uint32_t)(ld * 4);
             }
             fq q[8];
             if (DDX_SPMM_DBG & 1) {
