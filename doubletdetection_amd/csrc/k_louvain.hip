@@ -77,12 +77,16 @@ __global__ void __launch_bounds__(256) k_lv_sweep(const int64_t* __restrict__ in
                                                   const int64_t* __restrict__ wq, const int64_t* __restrict__ K,
                                                   const int32_t* __restrict__ comm, const unsigned long long* __restrict__ tot,
                                                   const int32_t* __restrict__ size, int64_t n, double gamma, double m2d,
-                                                  const int32_t* __restrict__ big_list, int32_t* __restrict__ next) {
+                                                  const int32_t* __restrict__ big_list, int32_t* __restrict__ next,
+                                                  unsigned long long* __restrict__ tot_clear, int32_t* __restrict__ size_clear) {
     __shared__ int32_t cS[1][BIG ? kLvCap : 1];
     __shared__ int64_t wS[1][BIG ? kLvCap : 1];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int64_t v = BIG ? (int64_t)blockIdx.x : (int64_t)blockIdx.x * 4 + wave;        // BIG: 64-thread workgroups
     if (v >= n) return;
+    // the totals of the NEXT sweep are accumulated into the other pair of arrays: clear entry v of it here (this
+    // instance visits every node id once), which replaces two memset launches per sweep
+    if (!BIG && lane == 0 && tot_clear) { tot_clear[v] = 0ull; size_clear[v] = 0; }
     if (BIG) v = big_list[v];
     const int64_t b = indptr[v];
     const int deg = (int)(indptr[v + 1] - b);
@@ -231,8 +235,8 @@ struct LvGraph {            // a CSR on the device
 struct LvScratch {          // sized for the finest level, reused by the coarser ones
     int64_t *wq, *vals_b, *sums, *K;
     uint64_t *keys_a, *keys_b;
-    unsigned long long *tot, *scal;
-    int32_t *comm, *next, *size, *used, *renum, *big_list;
+    unsigned long long *tot, *tot2, *scal;
+    int32_t *comm, *next, *size, *size2, *used, *renum, *big_list;
 };
 
 // one level: `sweeps` synchronous sweeps on `in`, exact aggregation into (member, out)
@@ -253,13 +257,23 @@ static int coarsen_level(ddx_ctx* ctx, const LvGraph& in, double gamma, int32_t 
     if (maxdeg > kLvCap) return set_err(ctx, DDX_E_UNSUPPORTED, "a node with %d neighbours exceeds the device sweep's capacity (%d)", maxdeg, kLvCap);
     int32_t* cur = sc.comm;
     int32_t* nxt = sc.next;
+    // community totals ping-pong between two pairs of arrays: sweep s reads pair s & 1 and clears the other one for sweep s + 1
+    // (tot | tot2 and size | size2 are adjacent pieces of the scratch buffer: one memset each clears both before the first sweep)
+    if (sweeps > 0 && m2 > 0) {
+        DDX_HIP(ctx, hipMemsetAsync(sc.tot, 0, (size_t)(reinterpret_cast<unsigned char*>(sc.tot2) - reinterpret_cast<unsigned char*>(sc.tot)) + sizeof(int64_t) * n, st));
+        DDX_HIP(ctx, hipMemsetAsync(sc.size, 0, (size_t)(reinterpret_cast<unsigned char*>(sc.size2) - reinterpret_cast<unsigned char*>(sc.size)) + sizeof(int32_t) * n, st));
+    }
     for (int s = 0; s < sweeps && m2 > 0; ++s) {
-        DDX_HIP(ctx, hipMemsetAsync(sc.tot, 0, sizeof(int64_t) * n, st));
-        DDX_HIP(ctx, hipMemsetAsync(sc.size, 0, sizeof(int32_t) * n, st));
-        k_lv_totals<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(cur, sc.K, n, sc.tot, sc.size);
-        k_lv_sweep<false><<<(unsigned)ceil_div(n, 4), 256, 0, st>>>(in.indptr, in.cols, sc.wq, sc.K, cur, sc.tot, sc.size, n, gamma, (double)m2, sc.big_list, nxt);
+        unsigned long long* tot = (s & 1) ? sc.tot2 : sc.tot;
+        unsigned long long* tot_other = (s & 1) ? sc.tot : sc.tot2;
+        int32_t* size = (s & 1) ? sc.size2 : sc.size;
+        int32_t* size_other = (s & 1) ? sc.size : sc.size2;
+        k_lv_totals<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(cur, sc.K, n, tot, size);
+        k_lv_sweep<false><<<(unsigned)ceil_div(n, 4), 256, 0, st>>>(in.indptr, in.cols, sc.wq, sc.K, cur, tot, size, n, gamma, (double)m2, sc.big_list, nxt,
+                                                                    tot_other, size_other);
         if (nbig > 0)
-            k_lv_sweep<true><<<(unsigned)nbig, 64, 0, st>>>(in.indptr, in.cols, sc.wq, sc.K, cur, sc.tot, sc.size, nbig, gamma, (double)m2, sc.big_list, nxt);
+            k_lv_sweep<true><<<(unsigned)nbig, 64, 0, st>>>(in.indptr, in.cols, sc.wq, sc.K, cur, tot, size, nbig, gamma, (double)m2, sc.big_list, nxt,
+                                                            nullptr, nullptr);
         std::swap(cur, nxt);      // a sweep that moves nothing reproduces its input, so running all of them equals stopping early
     }
     // renumber the surviving communities by ascending id
@@ -325,8 +339,8 @@ int stage_coarsen_graph(ddx_ctx* ctx, double gamma, int32_t sweeps, int32_t leve
     auto piece = [&](size_t sz) { const size_t o = bytes; bytes += (sz + 255) & ~(size_t)255; return o; };
     const size_t o_wq = piece(sizeof(int64_t) * E), o_ka = piece(sizeof(uint64_t) * E), o_kb = piece(sizeof(uint64_t) * E);
     const size_t o_vb = piece(sizeof(int64_t) * E), o_sums = piece(sizeof(int64_t) * E);
-    const size_t o_K = piece(sizeof(int64_t) * n), o_tot = piece(sizeof(int64_t) * n);
-    const size_t o_comm = piece(sizeof(int32_t) * n), o_next = piece(sizeof(int32_t) * n), o_size = piece(sizeof(int32_t) * n);
+    const size_t o_K = piece(sizeof(int64_t) * n), o_tot = piece(sizeof(int64_t) * n), o_tot2 = piece(sizeof(int64_t) * n);
+    const size_t o_comm = piece(sizeof(int32_t) * n), o_next = piece(sizeof(int32_t) * n), o_size = piece(sizeof(int32_t) * n), o_size2 = piece(sizeof(int32_t) * n);
     const size_t o_used = piece(sizeof(int32_t) * (n + 1)), o_renum = piece(sizeof(int32_t) * (n + 1)), o_big = piece(sizeof(int32_t) * n);
     const size_t o_scal = piece(256);
     size_t o_member[2], o_indptr[2], o_cols[2], o_w[2];
@@ -347,9 +361,11 @@ int stage_coarsen_graph(ddx_ctx* ctx, double gamma, int32_t sweeps, int32_t leve
     sc.sums = reinterpret_cast<int64_t*>(base + o_sums);
     sc.K = reinterpret_cast<int64_t*>(base + o_K);
     sc.tot = reinterpret_cast<unsigned long long*>(base + o_tot);
+    sc.tot2 = reinterpret_cast<unsigned long long*>(base + o_tot2);
     sc.comm = reinterpret_cast<int32_t*>(base + o_comm);
     sc.next = reinterpret_cast<int32_t*>(base + o_next);
     sc.size = reinterpret_cast<int32_t*>(base + o_size);
+    sc.size2 = reinterpret_cast<int32_t*>(base + o_size2);
     sc.used = reinterpret_cast<int32_t*>(base + o_used);
     sc.renum = reinterpret_cast<int32_t*>(base + o_renum);
     sc.big_list = reinterpret_cast<int32_t*>(base + o_big);
