@@ -4,6 +4,8 @@
 #include <cmath>
 #include <cstdint>
 #include <limits>
+#include <memory>
+#include <mutex>
 #include <unordered_map>
 #include <vector>
 
@@ -11,7 +13,38 @@
 
 namespace {
 
-inline double betaln(double a, double b) { return std::lgamma(a) + std::lgamma(b) - std::lgamma(a + b); }
+// lgamma of the integer arguments the hypergeometric terms use, memoised: one scoring call evaluates it ~10^6 times
+// (18 per term, ~50 terms per community, ~2 000 communities), always at integers <= M + 2.  The table holds
+// std::lgamma(i) itself, so results are bit-identical to calling it; it only grows, under a mutex, and readers keep a
+// reference to the version they started with.
+std::mutex g_lg_mutex;
+std::shared_ptr<const std::vector<double>> g_lg_table;
+
+std::shared_ptr<const std::vector<double>> lgamma_table(int64_t upto) {
+    std::lock_guard<std::mutex> lock(g_lg_mutex);
+    if (!g_lg_table || (int64_t)g_lg_table->size() <= upto) {
+        auto t = std::make_shared<std::vector<double>>();
+        const size_t old = g_lg_table ? g_lg_table->size() : 0;
+        t->resize((size_t)upto + 1025);
+        for (size_t i = 0; i < old; ++i) (*t)[i] = (*g_lg_table)[i];
+        for (size_t i = old; i < t->size(); ++i) (*t)[i] = std::lgamma((double)i);
+        g_lg_table = t;
+    }
+    return g_lg_table;
+}
+
+thread_local const std::vector<double>* t_lg = nullptr;
+
+inline double lg(double x) {
+    // every argument on this path is a non-negative integer; fall back to the library for anything else
+    if (t_lg && x >= 0.0 && x < (double)t_lg->size()) {
+        const size_t i = (size_t)x;
+        if ((double)i == x) return (*t_lg)[i];
+    }
+    return std::lgamma(x);
+}
+
+inline double betaln(double a, double b) { return lg(a) + lg(b) - lg(a + b); }
 
 // scipy hypergeom._logpmf(k, M=tot, n=good, N=draw)
 double logpmf(double k, double tot, double good, double draw) {
@@ -61,10 +94,37 @@ extern "C" int ddx_score_communities(const int64_t* full, int64_t n_aug, int64_t
                                      double* log_p) {
     if (!full || !scores || !log_p || n_cells < 0 || n_aug < n_cells) return DDX_E_ARG;
     const int64_t S = n_aug - n_cells;
-    std::unordered_map<int64_t, int64_t> n_orig, n_synth;
-    int64_t min_id = std::numeric_limits<int64_t>::max();
+    const double nan = std::numeric_limits<double>::quiet_NaN();
+    int64_t min_id = std::numeric_limits<int64_t>::max(), max_id = std::numeric_limits<int64_t>::min();
     for (int64_t i = 0; i < n_aug; ++i) {
         if (full[i] < min_id) min_id = full[i];
+        if (full[i] > max_id) max_id = full[i];
+    }
+    const auto table_ref = lgamma_table(n_aug + 2);       // memoised lgamma for this call (this thread)
+    struct Scope { Scope(const std::vector<double>* p) { t_lg = p; } ~Scope() { t_lg = nullptr; } } scope(table_ref.get());
+    if (n_aug > 0 && min_id >= -1 && max_id < n_aug) {
+        // the usual case (labels -1 .. K-1 from ddx_relabel_by_size): direct tables instead of hash maps
+        const size_t K = (size_t)(max_id + 2);                   // slot 0 holds label -1
+        std::vector<int64_t> n_orig(K, 0), n_synth(K, 0);
+        for (int64_t i = 0; i < n_cells; ++i) n_orig[(size_t)(full[i] + 1)]++;
+        for (int64_t i = n_cells; i < n_aug; ++i) n_synth[(size_t)(full[i] + 1)]++;
+        std::vector<double> score(K, 0.0), logp(K, 0.0);
+        for (size_t c = 0; c < K; ++c) {
+            if (n_orig[c] == 0) continue;
+            const int64_t oc = n_orig[c], sc = n_synth[c];
+            score[c] = (double)sc / (double)(sc + oc);
+            logp[c] = hypergeom_logsf(sc, n_aug, S, sc + oc);
+        }
+        for (int64_t i = 0; i < n_cells; ++i) {
+            const size_t c = (size_t)(full[i] + 1);
+            scores[i] = score[c];
+            log_p[i] = logp[c];
+            if (full[i] == -1) scores[i] = log_p[i] = nan;
+        }
+        return DDX_OK;
+    }
+    std::unordered_map<int64_t, int64_t> n_orig, n_synth;
+    for (int64_t i = 0; i < n_aug; ++i) {
         if (i < n_cells) n_orig[full[i]]++; else n_synth[full[i]]++;
     }
     std::unordered_map<int64_t, std::pair<double, double>> table;
@@ -75,7 +135,6 @@ extern "C" int ddx_score_communities(const int64_t* full, int64_t n_aug, int64_t
         const double score = (double)sc / (double)(sc + oc);
         table[kv.first] = {score, hypergeom_logsf(sc, n_aug, S, sc + oc)};
     }
-    const double nan = std::numeric_limits<double>::quiet_NaN();
     for (int64_t i = 0; i < n_cells; ++i) {
         const auto& pr = table[full[i]];
         scores[i] = pr.first;
