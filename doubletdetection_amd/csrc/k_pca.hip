@@ -228,6 +228,9 @@ __global__ void __launch_bounds__(256) k_spmm_cols(const int64_t* __restrict__ c
 // float32 with v_pk_fma_f32 (two chains of four), and the trip's sum is added to the float64 accumulator.
 // All orders are fixed.
 // ------------------------------------------------------------------------------------------------
+#ifndef DDX_SPMM_OFF16
+#define DDX_SPMM_OFF16 1    // packed-float32 trips stage 16-bit operand row indices (0: 32-bit byte offsets, the first version)
+#endif
 #ifndef DDX_SPMM_DBG
 #define DDX_SPMM_DBG 0      // ablation builds only (profiles/tools/spmm_ablation.sh): 1 no operand reads, 2 no entry fetches, 4 no staged reads, 8 no slice staging, 16 no trips, 32 no entry staging, 64 conflict-free operand rows
 #endif
@@ -335,7 +338,10 @@ __device__ __forceinline__ void lds_round(const LdsFetch<SLOTS>& f, const int (&
             const double z = ROWS ? (double)zf[g] : zc[g];
             dS[g * kLdsDStride + lane] = ok ? (double)f.x[g] - z : 0.0;
         }
-        offS[g * kLdsOStride + lane] = __umul24((uint32_t)i, (uint32_t)(ld * 4));      // i < 2^24, ld * 4 < 2^24
+        if (PK && DDX_SPMM_OFF16 && !(DDX_SPMM_DBG & (1 | 4 | 64)))       // operand row index inside the slice (< 2^16); the trip multiplies it out (v_mad_u32_u16)
+            reinterpret_cast<uint16_t*>(offS + g * kLdsOStride)[lane] = (uint16_t)i;
+        else
+            offS[g * kLdsOStride + lane] = __umul24((uint32_t)i, (uint32_t)(ld * 4));      // i < 2^24, ld * 4 < 2^24
     }
     wave_lds_sync();
     if (PK) {
@@ -345,6 +351,23 @@ __device__ __forceinline__ void lds_round(const LdsFetch<SLOTS>& f, const int (&
             u4 ov[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) fv[u] = *reinterpret_cast<const f4v*>(myf + t0 + 4 * u);
+            fq q[8];
+            if (DDX_SPMM_OFF16 && !(DDX_SPMM_DBG & (1 | 4 | 64))) {
+                // eight 16-bit row indices in one 16-byte read (half the staged-offset traffic); address = index * row
+                // bytes + this lane's column base in one v_mad_u32_u16 each (op_sel picks the high half of a pair)
+                typedef __attribute__((address_space(3))) const fq lds_fq;
+                const u4 pk16 = *reinterpret_cast<const u4*>(reinterpret_cast<const uint16_t*>(myoff) + t0);
+                const uint32_t rowb = (uint32_t)(ld * 4);
+                const uint32_t base3 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)opB;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    uint32_t alo, ahi;
+                    asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(alo) : "v"(pk16[w]), "s"(rowb), "v"(base3));
+                    asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(ahi) : "v"(pk16[w]), "s"(rowb), "v"(base3));
+                    q[2 * w] = *reinterpret_cast<lds_fq*>((uintptr_t)alo);
+                    q[2 * w + 1] = *reinterpret_cast<lds_fq*>((uintptr_t)ahi);
+                }
+            } else {
 #pragma unroll
             for (int u = 0; u < 2; ++u) ov[u] = *reinterpret_cast<const u4*>(myoff + t0 + 4 * u);
             if (DDX_SPMM_DBG & 4) {
@@ -360,7 +383,6 @@ __device__ __forceinline__ void lds_round(const LdsFetch<SLOTS>& f, const int (&
 #pragma unroll
                     for (int e = 0; e < 4; ++e) ov[u][e] = ((((uint32_t)t0 + 4u * u + e) & 63u) * 8u + cls) * (uint32_t)(ld * 4);
             }
-            fq q[8];
             if (DDX_SPMM_DBG & 1) {
 #pragma unroll
                 for (int u = 0; u < 8; ++u) q[u] = (fq)(__builtin_bit_cast(float, ov[u >> 2][u & 3]));
@@ -369,6 +391,7 @@ __device__ __forceinline__ void lds_round(const LdsFetch<SLOTS>& f, const int (&
             q[2] = *reinterpret_cast<const fq*>(opB + ov[0].z); q[3] = *reinterpret_cast<const fq*>(opB + ov[0].w);
             q[4] = *reinterpret_cast<const fq*>(opB + ov[1].x); q[5] = *reinterpret_cast<const fq*>(opB + ov[1].y);
             q[6] = *reinterpret_cast<const fq*>(opB + ov[1].z); q[7] = *reinterpret_cast<const fq*>(opB + ov[1].w);
+            }
             }
             fq p0 = q[0] * fv[0].x;
             fq p1 = q[1] * fv[0].y;
