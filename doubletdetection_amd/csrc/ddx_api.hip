@@ -130,7 +130,7 @@ void Options::read_environment() {
     knn_sample_tiles = g ? atoll(g) : 0;
     row_sums_sequential = getenv("DDX_ROW_SUMS_SEQUENTIAL") != nullptr;
     knn_debug = getenv("DDX_KNN_DEBUG") != nullptr;
-    mirror_counting = !is(getenv("DDX_MIRROR"), "sort");
+    mirror_mode = is(getenv("DDX_MIRROR"), "sort") ? 0 : (is(getenv("DDX_MIRROR"), "scatter") ? 1 : 2);
     g = getenv("DDX_ARENA_GUARD");
     arena_guard = g && g[0] != '0' && g[0] != 0;
 #ifdef DDX_ABLATION

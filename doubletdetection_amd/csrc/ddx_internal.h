@@ -48,7 +48,7 @@ struct Options {
     int64_t knn_sample_tiles = 0;    // 0 = default rule
     bool row_sums_sequential = false;
     bool knn_debug = false;
-    bool mirror_counting = true;     // DDX_MIRROR=sort: build the column-major mirror by radix sort instead of counting sort
+    int mirror_mode = 2;             // column-major mirror: 2 counting sort placed by LDS tiles, 1 (DDX_MIRROR=scatter) counting sort with scattered stores, 0 (DDX_MIRROR=sort) radix sort
     bool arena_guard = false;        // DDX_ARENA_GUARD=1: pattern-fill the pad behind every block, ddx_check_memory verifies it
     int knn_ablation = 0;            // only honoured under DDX_ABLATION
     void read_environment();

@@ -368,7 +368,7 @@ constexpr int kMirrorMaxH = 36 * 1024;  // LDS histogram of 32-bit counters: 144
 
 __global__ void __launch_bounds__(kMirrorThreads) k_mirror_count(const int64_t* __restrict__ indptr, const int32_t* __restrict__ cols,
                                                                  int64_t row_lo, int64_t row_hi, int32_t sub_rows, int64_t sb0, int32_t H,
-                                                                 uint16_t* __restrict__ cnt) {
+                                                                 uint16_t* __restrict__ cnt, int32_t W, int32_t wpp, uint32_t* __restrict__ bnd) {
     extern __shared__ uint32_t hist[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     for (int j = tid; j < H; j += kMirrorThreads) hist[j] = 0;
@@ -377,8 +377,32 @@ __global__ void __launch_bounds__(kMirrorThreads) k_mirror_count(const int64_t* 
     int64_t r0 = sb * sub_rows, r1 = r0 + sub_rows;
     if (r0 < row_lo) r0 = row_lo;
     if (r1 > row_hi) r1 = row_hi;
-    for (int64_t r = r0 + wave; r < r1; r += kMirrorThreads / 64)
-        for (int64_t p = indptr[r] + lane; p < indptr[r + 1]; p += 64) atomicAdd(&hist[cols[p]], 1u);
+    for (int64_t r = r0 + wave; r < r1; r += kMirrorThreads / 64) {
+        const int64_t b = indptr[r], e = indptr[r + 1];
+        if (!bnd) {
+            for (int64_t p = b + lane; p < e; p += 64) atomicAdd(&hist[cols[p]], 1u);
+            continue;
+        }
+        // with the tile placement: bnd[row][w] = position of the row's first entry whose column is >= w * W (w = 0 .. wpp)
+        uint32_t* mine = bnd + (size_t)(r - row_lo) * (size_t)(wpp + 1);
+        int carry = -1;                                  // window of the previous entry
+        for (int64_t p0 = b; p0 < e; p0 += 64) {         // (positions fit 31 bits: checked at upload)
+            const int64_t p = p0 + lane;
+            int wnd = wpp;                               // lanes behind the row end close the remaining windows
+            if (p < e) {
+                const int32_t c = cols[p];
+                atomicAdd(&hist[c], 1u);
+                wnd = c / W;
+            }
+            int prev = __shfl_up(wnd, 1, 64);
+            if (lane == 0) prev = carry;
+            if (p <= e)                                  // (p == e: the first lane behind the row)
+                for (int w = prev + 1; w <= wnd; ++w) mine[w] = (uint32_t)p;
+            carry = __shfl(wnd, 63, 64);
+        }
+        if (carry < wpp && lane == 0)                    // empty row, or a row that ends with a full chunk
+            for (int w = carry + 1; w <= wpp; ++w) mine[w] = (uint32_t)e;
+    }
     __syncthreads();
     uint16_t* out = cnt + (size_t)blockIdx.x * H;
     for (int j = tid; j < H; j += kMirrorThreads) out[j] = (uint16_t)hist[j];
@@ -438,6 +462,174 @@ __global__ void k_colptr_from_totals(const int64_t* __restrict__ scan, int64_t n
     else if (t == nkeys) colptr[t] = total;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Placement by tiles (the default for the LDS panels).  k_mirror_scatter above writes every entry with two scattered
+// 4-byte stores; the 16 sub-blocks of a panel each own ~6 entries of a (panel, column) segment, so practically every
+// store ends up as a partial-line write in HBM -- 2 x 3e7 of them per build of the synthetic rows, 1.15 ms, which no
+// amount of latency hiding improves (measured: one of the two stores removed = half the time).  Here a workgroup owns
+// a tile = (panel of 784 rows) x (window of W ~ 45 consecutive columns), whose entries form ONE contiguous range of
+// the mirror (~5 000 entries): it assembles that range in LDS and writes it out with full, coalesced lines.
+//   * k_mirror_count (which reads every column index anyway) also records, per row and window, where the row's entries
+//     of that window start: bnd[row][w] = position of the row's first entry with column >= w * W.  (A search per tile
+//     and row -- 16-ary, two dependent rounds of probes -- was tried first: 32 scattered line requests per row and tile
+//     kept each CU's L1 busy for 25 of the tile's 50 us.)
+//   * 8 lanes look after a row: the row's entries inside the window are [bnd[row][w], bnd[row][w + 1]), fetched with
+//     one 8-wide load (rows with more take further turns); the loads of all rows of a wave are in flight together.
+//   * position inside the (panel, column) segment = number of earlier rows of the panel that hold the column: every
+//     entry sets bit (column, row) of a column-major bitmap in LDS; after a prefix over the 25 words of each column
+//     the rank of an entry is a table value plus one popcount.  Exact in any order: the mirror is bit-identical to
+//     the stable sort and to the counting scatter.
+//   * a 128-byte line of the CSR holds the entries of ~5 neighbouring windows: the tiles are numbered so that the
+//     workgroups running on one XCD at a time (block b runs on XCD b % 8) work on consecutive windows of one panel,
+//     and the line is fetched from HBM once and then found in that XCD's L2 (L2 hit rate 35 % -> 95 %, fetched bytes
+//     3.2 GB -> 0.74 GB per build: profiles/r02n_mirror_notes.txt).
+// Tiles larger than the LDS range (rare: windows are sized for 70 % of it) spill their tail entries directly.
+// ------------------------------------------------------------------------------------------------
+#ifndef DDX_TILE_CAP
+#define DDX_TILE_CAP 7168
+#define DDX_TILE_MAXW 96
+#endif
+constexpr int kTileRows = kLdsPanelRows;                  // rows of a panel
+constexpr int kTileWpc = (kTileRows + 31) / 32;           // bitmap words per column
+constexpr int kTileRpw = (kTileRows + 15) / 16;           // rows per wave
+#ifndef DDX_TILE_LPR
+#define DDX_TILE_LPR 8
+#endif
+#ifndef DDX_TILE_FILL
+#define DDX_TILE_FILL 0.7
+#endif
+constexpr int kTileLpr = DDX_TILE_LPR;                    // lanes per row
+constexpr int kTileRps = 64 / kTileLpr;                   // rows per wave and step
+constexpr int kTileSteps = (kTileRpw + kTileRps - 1) / kTileRps;
+constexpr int kTileCap = DDX_TILE_CAP;                    // entries assembled in LDS
+constexpr int kTileMaxW = DDX_TILE_MAXW;                  // widest window
+constexpr size_t kTileLds = (size_t)kTileCap * 8 + (size_t)kTileMaxW * kTileWpc * 6 + ((size_t)kTileMaxW + 4) * 4 + 64;
+static_assert(kTileLds <= 80 * 1024, "two tile workgroups per CU");
+static_assert(kTileRows <= 65535, "segment ranks are kept in 16 bits");
+
+#ifdef DDX_TILE_PROF
+__device__ unsigned long long g_tile_prof[8];
+#define TILE_STAMP(i) do { if (threadIdx.x == 0) { const unsigned long long now_ = wall_clock64(); if (i) atomicAdd(&g_tile_prof[i], now_ - stamp_); stamp_ = now_; } } while (0)
+#else
+#define TILE_STAMP(i) do { } while (0)
+#endif
+__global__ void __launch_bounds__(1024, 8) k_mirror_tiles(const int32_t* __restrict__ cols,
+                                                          const float* __restrict__ raw, int64_t row_lo, int64_t row_hi, int32_t panel0,
+                                                          int32_t H, int32_t W, int32_t wpp, int32_t ntiles, const uint32_t* __restrict__ bnd, const int64_t* __restrict__ colptr,
+                                                          int32_t* __restrict__ row_out, float* __restrict__ raw_out) {
+#ifdef DDX_TILE_PROF
+    unsigned long long stamp_ = 0;
+#endif
+    extern __shared__ __align__(16) unsigned char tile_smem[];
+    int32_t* stR = reinterpret_cast<int32_t*>(tile_smem);
+    float* stV = reinterpret_cast<float*>(stR + kTileCap);
+    uint32_t* bm = reinterpret_cast<uint32_t*>(stV + kTileCap);
+    uint32_t* baseS = bm + kTileMaxW * kTileWpc;              // [w + 1] offsets of the window's columns inside the tile
+    uint16_t* pre = reinterpret_cast<uint16_t*>(baseS + kTileMaxW + 4);   // [w x words] entries of the column in earlier words
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, quad = lane / kTileLpr, l16 = lane % kTileLpr;
+    TILE_STAMP(0);
+    // tile number: the blocks of one XCD (b % 8) walk a contiguous eighth of the tiles
+    const int32_t per = (ntiles + 7) >> 3;
+    const int32_t t = (int32_t)(blockIdx.x & 7) * per + (int32_t)(blockIdx.x >> 3);
+    if (t >= ntiles) return;
+    const int32_t p = t / wpp;
+    const int32_t j0 = (t - p * wpp) * W;
+    const int32_t j1 = j0 + W < H ? j0 + W : H;
+    const int32_t w = j1 - j0;
+    const int64_t prow0 = ((int64_t)panel0 + p) * kTileRows;
+    const int64_t* cp = colptr + (int64_t)p * H;
+    const int64_t gbase = cp[j0];
+
+    for (int i = tid; i < w * kTileWpc; i += 1024) bm[i] = 0u;
+    for (int i = tid; i <= w; i += 1024) baseS[i] = (uint32_t)(cp[j0 + i] - gbase);
+
+    // 1. per row: its entries inside the window are [lo, hi) of the boundary table; the first 16 stay in registers
+    const int rb = wave * kTileRpw + quad;
+    const int32_t wnd = t - p * wpp;
+    uint32_t lo[kTileSteps], hi[kTileSteps];
+#pragma unroll
+    for (int s = 0; s < kTileSteps; ++s) {
+        const int rl = rb + kTileRps * s;
+        const int64_t row = prow0 + rl;
+        lo[s] = hi[s] = 0;
+        if (kTileRps * s + quad < kTileRpw && rl < kTileRows && row >= row_lo && row < row_hi) {
+            const uint32_t* bp = bnd + (size_t)(row - row_lo) * (size_t)(wpp + 1) + wnd;
+            lo[s] = bp[0];
+            hi[s] = bp[1];
+        }
+    }
+    int32_t c1[kTileSteps];
+    float v1[kTileSteps];
+#pragma unroll
+    for (int s = 0; s < kTileSteps; ++s) {
+        const uint32_t q = lo[s] + l16;
+        c1[s] = -1;
+        v1[s] = 0.f;
+        if (q < hi[s]) { c1[s] = cols[q]; v1[s] = raw[q]; }
+    }
+    __syncthreads();
+    TILE_STAMP(1);
+    TILE_STAMP(2);
+    uint32_t more = 0;
+#pragma unroll
+    for (int s = 0; s < kTileSteps; ++s) {
+        const int rl = rb + kTileRps * s;
+        if (c1[s] >= 0) atomicOr(&bm[(c1[s] - j0) * kTileWpc + (rl >> 5)], 1u << (rl & 31));
+        if (hi[s] - lo[s] > (uint32_t)kTileLpr) more |= 1u << s;
+    }
+    if (more) {                                        // (rare) rows with more than 16 entries inside the window
+#pragma unroll 1
+        for (int s = 0; s < kTileSteps; ++s) {
+            if (!((more >> s) & 1u)) continue;
+            const int rl = rb + kTileRps * s;
+            const uint32_t* bp = bnd + (size_t)(prow0 + rl - row_lo) * (size_t)(wpp + 1) + wnd;
+            for (uint32_t q = bp[0] + kTileLpr + l16; q < bp[1]; q += kTileLpr)
+                atomicOr(&bm[(cols[q] - j0) * kTileWpc + (rl >> 5)], 1u << (rl & 31));
+        }
+    }
+    __syncthreads();
+    TILE_STAMP(3);
+    // 2. per column: entries in the earlier words of the bitmap
+    if (tid < w) {
+        uint32_t run = 0;
+        for (int k = 0; k < kTileWpc; ++k) {
+            pre[tid * kTileWpc + k] = (uint16_t)run;
+            run += __popc(bm[tid * kTileWpc + k]);
+        }
+    }
+    __syncthreads();
+    TILE_STAMP(4);
+    // 3. place
+    auto place = [&](int32_t c, float v, int rl) {
+        const int jl = c - j0;
+        const uint32_t word = bm[jl * kTileWpc + (rl >> 5)];
+        const uint32_t pos = baseS[jl] + pre[jl * kTileWpc + (rl >> 5)] + __popc(word & ((1u << (rl & 31)) - 1u));
+        if (pos < (uint32_t)kTileCap) { stR[pos] = (int32_t)(prow0 + rl); stV[pos] = v; }
+        else { row_out[gbase + pos] = (int32_t)(prow0 + rl); raw_out[gbase + pos] = v; }
+    };
+#pragma unroll
+    for (int s = 0; s < kTileSteps; ++s)
+        if (c1[s] >= 0) place(c1[s], v1[s], rb + kTileRps * s);
+    if (more) {
+#pragma unroll 1
+        for (int s = 0; s < kTileSteps; ++s) {
+            if (!((more >> s) & 1u)) continue;
+            const int rl = rb + kTileRps * s;
+            const uint32_t* bp = bnd + (size_t)(prow0 + rl - row_lo) * (size_t)(wpp + 1) + wnd;
+            for (uint32_t q = bp[0] + kTileLpr + l16; q < bp[1]; q += kTileLpr) place(cols[q], raw[q], rl);
+        }
+    }
+    __syncthreads();
+    TILE_STAMP(5);
+    // 4. the tile's range of the mirror, full lines
+    const uint32_t ntile = baseS[w] < (uint32_t)kTileCap ? baseS[w] : (uint32_t)kTileCap;
+    for (uint32_t i = tid; i < ntile; i += 1024) {
+        row_out[gbase + i] = stR[i];
+        raw_out[gbase + i] = stV[i];
+    }
+    TILE_STAMP(6);
+}
+
 static int build_csc_sorted(ddx_ctx* ctx, int64_t e0, int64_t n, int64_t row_lo, int64_t row_hi, int32_t panel0,
                             int32_t npanels, DevBuf& colptr, DevBuf& rows, DevBuf& raws);
 
@@ -445,7 +637,7 @@ static int build_csc_sorted(ddx_ctx* ctx, int64_t e0, int64_t n, int64_t row_lo,
 static int build_csc(ddx_ctx* ctx, int64_t e0, int64_t n, int64_t row_lo, int64_t row_hi, int32_t panel0,
                      int32_t npanels, DevBuf& colptr, DevBuf& rows, DevBuf& raws) {
     const int32_t H = ctx->H;
-    if (H > kMirrorMaxH || ctx->panel_rows % kMirrorSub != 0 || ctx->panel_rows / kMirrorSub >= 65536 || !ctx->opt.mirror_counting || n == 0)
+    if (H > kMirrorMaxH || ctx->panel_rows % kMirrorSub != 0 || ctx->panel_rows / kMirrorSub >= 65536 || ctx->opt.mirror_mode == 0 || n == 0)
         return build_csc_sorted(ctx, e0, n, row_lo, row_hi, panel0, npanels, colptr, rows, raws);
     const int64_t nkeys = (int64_t)npanels * H;
     if (nkeys >= ((int64_t)1 << 30)) return set_err(ctx, DDX_E_UNSUPPORTED, "panel x column key space too large");
@@ -464,18 +656,50 @@ static int build_csc(ddx_ctx* ctx, int64_t e0, int64_t n, int64_t row_lo, int64_
     DDX_TRY(allow_dynamic_lds(ctx, reinterpret_cast<const void*>(&k_mirror_count), kMirrorMaxH * 4));
     DDX_TRY(allow_dynamic_lds(ctx, reinterpret_cast<const void*>(&k_mirror_scatter), kMirrorMaxH * 4));
     const size_t lds = sizeof(uint32_t) * (size_t)H;
+    // tile placement: window width = 70 % of the LDS range at the average segment length
+    const bool tiles = ctx->opt.mirror_mode == 2 && ctx->panel_rows == kTileRows;
+    int32_t W = 0, wpp = 0;
+    uint32_t* bnd = nullptr;
+    if (tiles) {
+        const double avg = (double)n / (double)nkeys;
+        W = (int32_t)(DDX_TILE_FILL * kTileCap / (avg > 1.0 ? avg : 1.0));
+        W = W < 8 ? 8 : (W > kTileMaxW ? kTileMaxW : W);
+        wpp = (int32_t)ceil_div((int64_t)H, (int64_t)W);                     // windows per panel
+        if ((int64_t)wpp * npanels >= ((int64_t)1 << 30)) return set_err(ctx, DDX_E_UNSUPPORTED, "too many mirror tiles");
+        DDX_TRY(ensure(ctx, ctx->sort_keys_out, sizeof(uint32_t) * (size_t)(row_hi - row_lo) * (size_t)(wpp + 1)));
+        bnd = ctx->sort_keys_out.as<uint32_t>();
+    }
     ScopedTimer t(ctx, "mirror_build");
     k_mirror_count<<<(unsigned)n_sb, kMirrorThreads, lds, ctx->stream>>>(ctx->aug_indptr.as<int64_t>(), ctx->aug_indices.as<int32_t>(), row_lo, row_hi,
-                                                                         sub_rows, sb0, H, cnt);
+                                                                         sub_rows, sb0, H, cnt, W, wpp, bnd);
     k_mirror_prefix<<<(unsigned)ceil_div(nkeys, 256), 256, 0, ctx->stream>>>(cnt, sb0, n_sb, panel0, npanels, H, tot);
     size_t tmp_bytes = 0;
     DDX_HIP(ctx, prim::exclusive_sum(nullptr, tmp_bytes, tot, scan, (size_t)nkeys, ctx->stream));
     DDX_TRY(ensure(ctx, ctx->sort_tmp, tmp_bytes));
     DDX_HIP(ctx, prim::exclusive_sum(ctx->sort_tmp.p, tmp_bytes, tot, scan, (size_t)nkeys, ctx->stream));
     k_colptr_from_totals<<<(unsigned)ceil_div(nkeys + 1, 256), 256, 0, ctx->stream>>>(scan, nkeys, n, colptr.as<int64_t>());
-    k_mirror_scatter<<<(unsigned)n_sb, kMirrorThreads, lds, ctx->stream>>>(ctx->aug_indptr.as<int64_t>(), ctx->aug_indices.as<int32_t>(),
-                                                                           ctx->aug_raw.as<float>(), row_lo, row_hi, sub_rows, sb0, panel0, H, cnt,
-                                                                           colptr.as<int64_t>(), rows.as<int32_t>(), raws.as<float>());
+    if (tiles) {
+        const int64_t ntiles = (int64_t)wpp * npanels;
+        DDX_TRY(allow_dynamic_lds(ctx, reinterpret_cast<const void*>(&k_mirror_tiles), (int)kTileLds));
+        k_mirror_tiles<<<(unsigned)(ceil_div(ntiles, (int64_t)8) * 8), 1024, kTileLds, ctx->stream>>>(
+            ctx->aug_indices.as<int32_t>(), ctx->aug_raw.as<float>(), row_lo, row_hi, panel0, H, W, wpp, (int32_t)ntiles, bnd, colptr.as<int64_t>(), rows.as<int32_t>(), raws.as<float>());
+#ifdef DDX_TILE_PROF
+        {
+            unsigned long long h[8];
+            hipStreamSynchronize(ctx->stream);
+            hipMemcpyFromSymbol(h, HIP_SYMBOL(g_tile_prof), sizeof(h));
+            fprintf(stderr, "tile phases (100 MHz ticks per tile, %lld tiles):", (long long)ntiles);
+            for (int i = 1; i < 7; ++i) fprintf(stderr, " %.1f", (double)h[i] / (double)ntiles);
+            fprintf(stderr, "\n");
+            unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            hipMemcpyToSymbol(HIP_SYMBOL(g_tile_prof), z, sizeof(z));
+        }
+#endif
+    } else {
+        k_mirror_scatter<<<(unsigned)n_sb, kMirrorThreads, lds, ctx->stream>>>(ctx->aug_indptr.as<int64_t>(), ctx->aug_indices.as<int32_t>(),
+                                                                               ctx->aug_raw.as<float>(), row_lo, row_hi, sub_rows, sb0, panel0, H, cnt,
+                                                                               colptr.as<int64_t>(), rows.as<int32_t>(), raws.as<float>());
+    }
     DDX_HIP(ctx, hipGetLastError());
     (void)e0;
     return DDX_OK;

@@ -159,9 +159,11 @@ def test_operator_product_variants_agree_at_full_size(data, staged, monkeypatch)
 
     # the column-major mirror built by counting sort (default) and by the stable radix sort it replaces hold the same
     # entries in the same order: bit-identical scores
-    emb_m, sing_m = other({"DDX_MIRROR": "sort"})
-    np.testing.assert_array_equal(emb_m, emb_lds)
-    np.testing.assert_array_equal(sing_m, sing_lds)
+    # (default: counting sort placed by LDS tiles; "scatter": counting sort with scattered stores; "sort": radix sort)
+    for mode in ("sort", "scatter"):
+        emb_m, sing_m = other({"DDX_MIRROR": mode})
+        np.testing.assert_array_equal(emb_m, emb_lds)
+        np.testing.assert_array_equal(sing_m, sing_lds)
     emb_g, sing_g = other({"DDX_SPMM": "gather"})
     # (rounding noise of the two summation orders, amplified through seven power iterations of unconverged
     # trailing components: 4e-10 observed on the singular values)

@@ -148,6 +148,50 @@ def test_library_sizes_integer_and_fractional_counts(ctx):
     np.testing.assert_array_equal(ctx.aug_lib()[0], want)
 
 
+def test_column_mirror_placement_modes(monkeypatch):
+    """The column-major mirror (dd.py has no counterpart: it serves A^T Y of the PCA) built three ways -- LDS tiles
+    (default), scattered stores, radix sort -- on a matrix that leaves the comfortable regime: rows holding every
+    column (more than 16 entries of a row inside a tile window), a block of columns held by every row (tiles larger
+    than the LDS range: spill path), empty rows and empty columns, a panel straddling original and synthetic rows."""
+    from doubletdetection_amd import _lib
+
+    rng = np.random.default_rng(11)
+    N, H = 1700, 1300
+    dense = (rng.random((N, H)) < 0.02) * rng.integers(1, 9, size=(N, H))
+    dense[:, 40:150] = rng.integers(1, 5, size=(N, 110))          # columns stored in every row
+    dense[100:130, :] = rng.integers(1, 4, size=(30, H))           # rows that hold every column
+    dense[300:340, :] = 0                                          # empty rows
+    dense[:, 700:760] = 0                                          # empty columns
+    dense[5, 0] = 7
+    counts = sp.csr_matrix(dense.astype(np.float32))
+    parents = rng.choice(N, size=(N // 4, 2), replace=False)
+    Y = rng.normal(size=(N + N // 4, 5))
+
+    def products(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        c = _lib.Context(0)
+        try:
+            c.upload_counts(counts)
+            c.create_doublets(parents)
+            c.lognormalise(0.1)
+            X = c.aug_dense_rows(0, c.M).astype(np.float64)
+            return X, c.operator_apply(Y, 1)
+        finally:
+            c.close()
+            for k in env:
+                monkeypatch.delenv(k, raising=False)
+
+    X, tiles = products({})
+    _, scatter = products({"DDX_MIRROR": "scatter"})
+    _, sort = products({"DDX_MIRROR": "sort"})
+    np.testing.assert_array_equal(tiles, sort)
+    np.testing.assert_array_equal(scatter, sort)
+    # against the row-major copy: A^T Y = (X - 1 mu^T)^T Y
+    ref = (X - X.mean(axis=0)).T @ Y
+    np.testing.assert_allclose(tiles, ref, rtol=0, atol=1e-9 * np.abs(ref).max())
+
+
 # ---- a7: log-normalisation (dd.py:286-298) -----------------------------------------------------------
 @pytest.mark.parametrize("case", ["case_a_hvg_pheno", "case_b_transposed_louvain", "case_d_replace_single"])
 def test_lognormalised_matrix(ctx, case):
