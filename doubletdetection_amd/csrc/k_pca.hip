@@ -231,9 +231,6 @@ __global__ void __launch_bounds__(256) k_spmm_cols(const int64_t* __restrict__ c
 #ifndef DDX_SPMM_OFF16
 #define DDX_SPMM_OFF16 1    // packed-float32 trips stage 16-bit operand row indices (0: 32-bit byte offsets, the first version)
 #endif
-#ifndef DDX_SPMM_PIPE
-#define DDX_SPMM_PIPE 1    // software-pipelined trips (0: one trip after the other)
-#endif
 #ifndef DDX_SPMM_DBG
 #define DDX_SPMM_DBG 0      // ablation builds only (profiles/tools/spmm_ablation.sh): 1 no operand reads, 2 no entry fetches, 4 no staged reads, 8 no slice staging, 16 no trips, 32 no entry staging, 64 conflict-free operand rows
 #endif
@@ -347,81 +344,6 @@ __device__ __forceinline__ void lds_round(const LdsFetch<SLOTS>& f, const int (&
             offS[g * kLdsOStride + lane] = __umul24((uint32_t)i, (uint32_t)(ld * 4));      // i < 2^24, ld * 4 < 2^24
     }
     wave_lds_sync();
-    if (PK && DDX_SPMM_PIPE && DDX_SPMM_OFF16 && DDX_SPMM_DBG == 0) {
-        // Software-pipelined trips.  A trip is a chain staged reads -> address arithmetic -> operand reads -> multiply-adds;
-        // run one after the other, the LDS sits idle while a wave multiplies and the VALU while it waits for reads (with
-        // 4 waves per SIMD the other waves fill only part of that).  Here the operand reads of trip t + 1 and the staged
-        // reads of trips t + 1 / t + 2 are issued before the multiply-adds of trip t, in two alternating register sets.
-        // Products, sums and their order are those of the plain loop below: same bits.
-        typedef __attribute__((address_space(3))) const fq lds_fq;
-        const float* myf = reinterpret_cast<const float*>(myd);
-        const uint16_t* my16 = reinterpret_cast<const uint16_t*>(myoff);
-        const uint32_t rowb = (uint32_t)(ld * 4);
-        const uint32_t base3 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)opB;
-        const int ntrips = (nsteps + 7) >> 3;
-        auto issue = [&](const u4& pk16, fq (&q)[8]) {
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                uint32_t alo, ahi;
-                asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(alo) : "v"(pk16[w]), "s"(rowb), "v"(base3));
-                asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(ahi) : "v"(pk16[w]), "s"(rowb), "v"(base3));
-                q[2 * w] = *reinterpret_cast<lds_fq*>((uintptr_t)alo);
-                q[2 * w + 1] = *reinterpret_cast<lds_fq*>((uintptr_t)ahi);
-            }
-        };
-        auto fmas = [&](const fq (&q)[8], const f4v (&fv)[2]) {
-            fq p0 = q[0] * fv[0].x;
-            fq p1 = q[1] * fv[0].y;
-            p0 = __builtin_elementwise_fma(q[2], (fq)(fv[0].z), p0);
-            p1 = __builtin_elementwise_fma(q[3], (fq)(fv[0].w), p1);
-            p0 = __builtin_elementwise_fma(q[4], (fq)(fv[1].x), p0);
-            p1 = __builtin_elementwise_fma(q[5], (fq)(fv[1].y), p1);
-            p0 = __builtin_elementwise_fma(q[6], (fq)(fv[1].z), p0);
-            p1 = __builtin_elementwise_fma(q[7], (fq)(fv[1].w), p1);
-            p0 = p0 + p1;
-#pragma unroll
-            for (int c = 0; c < CPL; ++c) acc[c] += (double)p0[c];
-        };
-        fq qA[8], qB[8];
-        f4v fvA[2], fvB[2];
-        // (staged reads one or two trips past the end stay inside the wave's staging area and are never used)
-        auto values = [&](int t, f4v (&fv)[2]) {
-            fv[0] = *reinterpret_cast<const f4v*>(myf + 8 * t);
-            fv[1] = *reinterpret_cast<const f4v*>(myf + 8 * t + 4);
-        };
-        // (the index read of the trip after next goes first in its group, so that waiting for it later does not wait
-        // for the operand reads issued behind it)
-        u4 pkA = *reinterpret_cast<const u4*>(my16), pkB;
-        values(0, fvA);
-        pkB = *reinterpret_cast<const u4*>(my16 + 8);
-        issue(pkA, qA);
-        int t = 0;
-        for (; t + 2 < ntrips; t += 2) {               // no branches inside: the wait counts are exact
-            pkA = *reinterpret_cast<const u4*>(my16 + 8 * (t + 2));
-            issue(pkB, qB);
-            values(t + 1, fvB);
-            __builtin_amdgcn_sched_barrier(0);
-            fmas(qA, fvA);
-            __builtin_amdgcn_sched_barrier(0);
-            pkB = *reinterpret_cast<const u4*>(my16 + 8 * (t + 3));
-            issue(pkA, qA);
-            values(t + 2, fvA);
-            __builtin_amdgcn_sched_barrier(0);
-            fmas(qB, fvB);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (t + 1 < ntrips) {
-            issue(pkB, qB);
-            values(t + 1, fvB);
-            __builtin_amdgcn_sched_barrier(0);
-            fmas(qA, fvA);
-            fmas(qB, fvB);
-        } else {
-            fmas(qA, fvA);
-        }
-        wave_lds_sync();
-        return;
-    }
     if (PK) {
         const float* myf = reinterpret_cast<const float*>(myd);
         for (int t0 = 0; t0 < ((DDX_SPMM_DBG & 16) ? 0 : nsteps); t0 += 8) {          // the staged round is zero-padded to 64 entries
