@@ -1,5 +1,6 @@
 // EXPERIMENT, not part of libddx (see profiles/r02o_mfma_products.txt for what was measured; this file is the last state
-// tried -- variant v6 for A Q, v5 for A^T Y -- and builds with profiles/experiments/mfma_products_integration.patch applied).
+// tried -- A Q: k_tile_rows (v7) and the K-split k_tile_rows_part (v8, the one wired in), A^T Y: v5 -- and builds with
+// profiles/experiments/mfma_products_integration.patch applied).
 // libddx -- operator products of the randomized PCA on the matrix cores (DDX_SPMM=mfma; experimental).
 //
 // The LDS-staged products (k_pca.hip) read one 160-byte operand row per stored entry and are bound by the LDS pipe at
@@ -28,11 +29,8 @@ typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 constexpr int kTRows = 64;            // matrix rows of a tile (four MFMA row tiles), one row per lane while it is filled
 constexpr int kTK = 32;               // columns of a tile = contraction depth of one MFMA
 constexpr int kTNt = 3;               // MFMA column tiles: sketch widths up to 48
+constexpr int kTStrideT = 144;         // bytes between the rows of the transposed tile of A^T Y (128 + 16)
 constexpr int kTStride = 80;          // bytes between tile rows in LDS (64 + 16: the 16 rows of a fragment read hit distinct banks)
-#ifndef DDX_TILE_WPE
-#define DDX_TILE_WPE 4
-#endif
-constexpr int kTFlushG = 32;          // (experiment) slabs between additions into the float64 result in memory
 constexpr int kTFlush = 4;            // float32 accumulators are added into float64 every kTFlush tiles (128 columns)
 constexpr float kTScaleA = 1024.0f;   // 2^10: |x - z| < 64 (log-normalised values, or scaled values clipped at 15)
 constexpr int kTWaves = 4;            // waves per workgroup
@@ -166,7 +164,7 @@ __global__ void __launch_bounds__(256) k_tile_pack(const int64_t* __restrict__ i
             const int sl = (c - c0) >> 5;
             const uint32_t slot = start[sl] + atomicAdd(&cnt[sl], 1u);
             uint2 rec;
-            rec.x = ((uint32_t)rr << 5) | (uint32_t)(c & 31);
+            rec.x = ((uint32_t)rr * kTStride + (uint32_t)(c & 31) * 2u) | (((uint32_t)(c & 31) * kTStrideT + (uint32_t)rr * 2u) << 16);
             rec.y = (uint32_t)__builtin_bit_cast(uint16_t, h) | ((uint32_t)__builtin_bit_cast(uint16_t, l) << 16);
             if (slot < (uint32_t)kPackCap) stage[slot] = rec; else recs[gbase + slot] = rec;
         }
@@ -185,73 +183,190 @@ __device__ __forceinline__ void tile_clear(unsigned char* t, int bytes, int lane
 // The wave streams the tiles of its row block.  Two pairs of LDS tiles alternate: while the matrix cores work on tile s
 // (A fragments read from one pair, operand fragments of slab s straight from global memory -- 6 KB per slab, shared by
 // all waves through L1 / L2), the records of tile s + 1 are written into the other pair and those of tile s + 2 are on
-// their way from memory; a pair is cleared as soon as its fragments have been read.
+// their way from memory; a pair is cleared as soon as its fragments have been read.  The slab loop is unrolled twice so
+// that the two register sets (records, operand fragments) alternate without copies.
 constexpr int kTileBytes = 2 * kTRows * kTStride;      // hi + lo tile of a wave (10 KB)
 template <int NT>
-__global__ void __launch_bounds__(64 * kTWaves) __attribute__((amdgpu_waves_per_eu(DDX_TILE_WPE, DDX_TILE_WPE))) k_tile_rows(const int32_t* __restrict__ blk, const uint2* __restrict__ recs, int64_t M, int nslabs, int L,
+struct RowsState {
+    uint2 rec[kTPre];
+    h8 bh[NT], bl[NT];
+};
+template <int NT>
+__global__ void __launch_bounds__(64 * kTWaves) __attribute__((amdgpu_waves_per_eu(2, 2))) k_tile_rows(const int32_t* __restrict__ blk, const uint2* __restrict__ recs, int64_t M, int nslabs, int L,
                                                             const h8* __restrict__ frag, const double* __restrict__ inv,
                                                             const double* __restrict__ tvec, double* __restrict__ out) {
     extern __shared__ __align__(16) unsigned char tile_lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    unsigned char* t0 = tile_lds + (size_t)wave * kTileBytes;
+    unsigned char* t0 = tile_lds + (size_t)wave * (2 * kTileBytes);
     const int64_t b = (int64_t)blockIdx.x * kTWaves + wave;
     if (b * kTRows >= M) return;
-    tile_clear(t0, kTileBytes, lane);
+    tile_clear(t0, 2 * kTileBytes, lane);
+    double acc[4][NT][4];
     f4t d[4][NT];
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
             d[t][n] = f4t{0, 0, 0, 0};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[t][n][i] = 0.0;
         }
     const int frag_row = (lane & 15) * kTStride + 16 * (lane >> 4);
     const int32_t* myblk = blk + b * (nslabs + 1);
-    auto put = [&](unsigned char* tile, const uint2 r) {
-        const uint32_t off = (r.x >> 5) * kTStride + (r.x & 31u) * 2u;
-        *reinterpret_cast<uint16_t*>(tile + off) = (uint16_t)(r.y & 0xffffu);
-        *reinterpret_cast<uint16_t*>(tile + kTRows * kTStride + off) = (uint16_t)(r.y >> 16);
-    };
+    const uint2* myrec = recs + lane;
+    const h8* myfrag = frag + lane;
     // (record reads run a little past a short tile: inside the records of the row block or the pad behind the buffer)
-    auto fill = [&](unsigned char* tile, const uint2 (&rec)[kTPre], int32_t p0, int32_t p1) {
+    auto fetch = [&](RowsState<NT>& st, int32_t p, int slab) {
 #pragma unroll
-        for (int u = 0; u < kTPre; ++u)
-            if (p0 + u * 64 + lane < p1) put(tile, rec[u]);
-        for (int32_t e = p0 + kTPre * 64; e < p1; e += 64)       // (dense tiles)
-            if (e + lane < p1) put(tile, recs[e + lane]);
-    };
-    uint2 rec[kTPre];
-    int32_t pa = myblk[0], pb = myblk[1];            // tile being filled next: [pa, pb)
-#pragma unroll
-    for (int u = 0; u < kTPre; ++u) rec[u] = recs[pa + u * 64 + lane];
-    h8 nh[NT], nl[NT];
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        nh[n] = frag[((int64_t)n * 2 + 0) * 64 + lane];
-        nl[n] = frag[((int64_t)n * 2 + 1) * 64 + lane];
-    }
-    for (int s = 0; s < nslabs; ++s) {
-        unsigned char* cur = t0;
-        h8 bh[NT], bl[NT];
-#pragma unroll
-        for (int n = 0; n < NT; ++n) { bh[n] = nh[n]; bl[n] = nl[n]; }
-        fill(cur, rec, pa, pb);
-        const int s1 = s + 1 < nslabs ? s + 1 : s;
-        pa = pb;
-        pb = myblk[s1 + 1];
-#pragma unroll
-        for (int u = 0; u < kTPre; ++u) rec[u] = recs[pa + u * 64 + lane];
+        for (int u = 0; u < kTPre; ++u) st.rec[u] = myrec[p + u * 64];
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
-            nh[n] = frag[(((int64_t)s1 * kTNt + n) * 2 + 0) * 64 + lane];
-            nl[n] = frag[(((int64_t)s1 * kTNt + n) * 2 + 1) * 64 + lane];
+            st.bh[n] = myfrag[((slab * kTNt + n) * 2 + 0) * 64];
+            st.bl[n] = myfrag[((slab * kTNt + n) * 2 + 1) * 64];
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        // four row tiles x NT column tiles x (hi hi + hi lo + lo hi) from the pair filled one turn earlier
+    };
+    auto fill = [&](unsigned char* tile, const RowsState<NT>& st, int32_t p0, int32_t p1) {
+        const int32_t n = p1 - p0 - lane;            // this lane's record u exists if u * 64 < n
+#pragma unroll
+        for (int u = 0; u < kTPre; ++u)
+            if (u * 64 < n) {
+                const uint32_t off = st.rec[u].x & 0xffffu;
+                *reinterpret_cast<uint16_t*>(tile + off) = (uint16_t)(st.rec[u].y & 0xffffu);
+                *reinterpret_cast<uint16_t*>(tile + kTRows * kTStride + off) = (uint16_t)(st.rec[u].y >> 16);
+            }
+        for (int32_t e = p0 + kTPre * 64 + lane; e < p1; e += 64) {      // (dense tiles)
+            const uint2 r = recs[e];
+            const uint32_t off = r.x & 0xffffu;
+            *reinterpret_cast<uint16_t*>(tile + off) = (uint16_t)(r.y & 0xffffu);
+            *reinterpret_cast<uint16_t*>(tile + kTRows * kTStride + off) = (uint16_t)(r.y >> 16);
+        }
+    };
+    auto multiply = [&](const unsigned char* tile, const RowsState<NT>& st) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const h8 ah = *reinterpret_cast<const h8*>(cur + t * 16 * kTStride + frag_row);
-            const h8 al = *reinterpret_cast<const h8*>(cur + kTRows * kTStride + t * 16 * kTStride + frag_row);
+            const h8 ah = *reinterpret_cast<const h8*>(tile + t * 16 * kTStride + frag_row);
+            const h8 al = *reinterpret_cast<const h8*>(tile + kTRows * kTStride + t * 16 * kTStride + frag_row);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) d[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, st.bh[n], d[t][n], 0, 0, 0);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) d[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, st.bl[n], d[t][n], 0, 0, 0);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) d[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, st.bh[n], d[t][n], 0, 0, 0);
+        }
+    };
+    auto flush = [&]() {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[t][n][i] += (double)d[t][n][i];
+                d[t][n] = f4t{0, 0, 0, 0};
+            }
+    };
+    // one turn: tile s is in `cur` with its state in A; B holds the records / fragments of tile s + 1 (already fetched)
+    auto turn = [&](int s, unsigned char* cur, unsigned char* nxt, RowsState<NT>& A, RowsState<NT>& B, int32_t& pa, int32_t& pb) {
+        // tile s + 1 into the other pair, then its successor's records and fragments requested into A's record set...
+        if (s + 1 < nslabs) fill(nxt, B, pa, pb);
+        multiply(cur, A);                            // (A's fragments; A's records are dead since tile s was filled)
+        const int s2 = s + 2 < nslabs ? s + 2 : nslabs - 1;
+        pa = pb;
+        pb = myblk[s2 + 1];
+        fetch(A, pa, s2);                            // ...after the MFMAs have been issued with A's fragments
+        tile_clear(cur, kTileBytes, lane);           // (LDS operations of a wave execute in order: the reads above come first)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if ((s % kTFlush) == kTFlush - 1 || s == nslabs - 1) flush();
+    };
+    RowsState<NT> A, B;
+    int32_t pa = myblk[0], pb = myblk[1];
+    fetch(A, pa, 0);
+    fill(t0, A, pa, pb);                             // tile 0
+    pa = pb;
+    pb = myblk[nslabs > 1 ? 2 : 1];
+    fetch(B, pa, nslabs > 1 ? 1 : 0);                // tile 1
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int s = 0; s < nslabs; s += 2) {
+        turn(s, t0, t0 + kTileBytes, A, B, pa, pb);
+        if (s + 1 < nslabs) turn(s + 1, t0 + kTileBytes, t0, B, A, pa, pb);
+    }
+    // D layout: lane l holds rows 4*(l >> 4) + 0..3 and column l & 15 of every 16 x 16 tile
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int col = 16 * n + (lane & 15);
+            if (col >= L) continue;
+            const double sc = inv[col], tv = tvec[col];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int64_t r = b * kTRows + 16 * t + 4 * (lane >> 4) + i;
+                if (r < M) out[r * L + col] = acc[t][n][i] * sc - tv;
+            }
+        }
+}
+
+// ---- A Q, many short waves: one wave per (64 rows, range of slabs); float32 partial sums, added in float64 afterwards ----
+constexpr int kTSlabsPerPart = 40;     // 1 280 columns per partial sum
+template <int NT>
+#ifndef DDX_TT_DBG
+#define DDX_TT_DBG 0
+#endif
+__global__ void __launch_bounds__(64 * kTWaves) __attribute__((amdgpu_waves_per_eu(4, 4))) k_tile_rows_part(const int32_t* __restrict__ blk, const uint2* __restrict__ recs, int64_t M, int nslabs,
+                                                            const h8* __restrict__ frag, float* __restrict__ partial /* [parts][Mpad][16 * NT] */, int64_t Mpad) {
+    extern __shared__ __align__(16) unsigned char tile_lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned char* tile = tile_lds + (size_t)wave * kTileBytes;
+    const int64_t b = (int64_t)blockIdx.x * kTWaves + wave;
+    const int part = blockIdx.y;
+    if (b * kTRows >= M) return;
+    tile_clear(tile, kTileBytes, lane);
+    f4t d[4][NT];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) d[t][n] = f4t{0, 0, 0, 0};
+    const int frag_row = (lane & 15) * kTStride + 16 * (lane >> 4);
+    const int32_t* myblk = blk + b * (nslabs + 1);
+    const uint2* myrec = recs + lane;
+    const h8* myfrag = frag + lane;
+    const int s0 = part * kTSlabsPerPart;
+    const int s1 = s0 + kTSlabsPerPart < nslabs ? s0 + kTSlabsPerPart : nslabs;
+    int32_t p0 = myblk[s0];
+    for (int s = s0; s < s1; ++s) {
+        const int32_t p1 = myblk[s + 1];
+        h8 bh[NT], bl[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            bh[n] = myfrag[(((DDX_TT_DBG & 16) ? 0 : s * kTNt + n) * 2 + 0) * 64];
+            bl[n] = myfrag[(((DDX_TT_DBG & 16) ? 0 : s * kTNt + n) * 2 + 1) * 64];
+        }
+        uint2 rec[kTPre];
+#pragma unroll
+        for (int u = 0; u < kTPre; ++u) rec[u] = myrec[p0 + u * 64];
+        const int32_t n_mine = p1 - p0 - lane;
+#pragma unroll
+        for (int u = 0; u < kTPre; ++u)
+            if (u * 64 < n_mine && !(DDX_TT_DBG & 2)) {
+                const uint32_t off = rec[u].x & 0xffffu;
+                *reinterpret_cast<uint16_t*>(tile + off) = (uint16_t)(rec[u].y & 0xffffu);
+                *reinterpret_cast<uint16_t*>(tile + kTRows * kTStride + off) = (uint16_t)(rec[u].y >> 16);
+            }
+        for (int32_t e = p0 + kTPre * 64 + lane; e < p1; e += 64) {
+            const uint2 r = recs[e];
+            const uint32_t off = r.x & 0xffffu;
+            *reinterpret_cast<uint16_t*>(tile + off) = (uint16_t)(r.y & 0xffffu);
+            *reinterpret_cast<uint16_t*>(tile + kTRows * kTStride + off) = (uint16_t)(r.y >> 16);
+        }
+        p0 = p1;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const h8 ah = (DDX_TT_DBG & 8) ? bh[0] : *reinterpret_cast<const h8*>(tile + t * 16 * kTStride + frag_row);
+            const h8 al = (DDX_TT_DBG & 8) ? bl[0] : *reinterpret_cast<const h8*>(tile + kTRows * kTStride + t * 16 * kTStride + frag_row);
+            if (DDX_TT_DBG & 4) { d[t][0][0] += (float)ah[0] + (float)al[0] + (float)bh[0][0] + (float)bl[1][0] + (float)bh[NT - 1][0] + (float)bl[NT - 1][0]; continue; }
 #pragma unroll
             for (int n = 0; n < NT; ++n) d[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[n], d[t][n], 0, 0, 0);
 #pragma unroll
@@ -259,38 +374,35 @@ __global__ void __launch_bounds__(64 * kTWaves) __attribute__((amdgpu_waves_per_
 #pragma unroll
             for (int n = 0; n < NT; ++n) d[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[n], d[t][n], 0, 0, 0);
         }
-        tile_clear(cur, kTileBytes, lane);           // (LDS operations of a wave execute in order: the reads above come first)
+        if (!(DDX_TT_DBG & 1)) tile_clear(tile, kTileBytes, lane);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if ((s % kTFlushG) == kTFlushG - 1 || s == nslabs - 1) {
-            // float32 sums of kTFlushG slabs added into the float64 result (first turn: result = sum * scale - t)
-            const bool first = s < kTFlushG;
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int n = 0; n < NT; ++n) {
-                    const int col = 16 * n + (lane & 15);
-                    if (col < L) {
-                        const double sc = inv[col], tv = tvec[col];
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const int64_t r = b * kTRows + 16 * t + 4 * (lane >> 4) + i;
-                            if (r < M) {
-                                double* o = out + r * L + col;
-                                *o = (first ? -tv : *o) + (double)d[t][n][i] * sc;
-                            }
-                        }
-                    }
-                    d[t][n] = f4t{0, 0, 0, 0};
-                }
-        }
     }
+    float* my = partial + ((int64_t)part * Mpad + b * kTRows) * (16 * NT);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) my[(16 * t + 4 * (lane >> 4) + i) * (16 * NT) + 16 * n + (lane & 15)] = d[t][n][i];
+}
+
+// out[r][c] = (sum over parts, in order, of partial[part][r][c]) * inv[c] - tvec[c]
+__global__ void __launch_bounds__(256) k_tile_rows_sum(const float* __restrict__ partial, int parts, int64_t M, int64_t Mpad, int L, int ldp,
+                                                       const double* __restrict__ inv, const double* __restrict__ tvec, double* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= M * ldp) return;
+    const int64_t r = t / ldp;
+    const int c = (int)(t - r * ldp);
+    if (c >= L) return;
+    double a = 0.0;
+    for (int p = 0; p < parts; ++p) a += (double)partial[((int64_t)p * Mpad + r) * ldp + c];
+    out[r * L + c] = a * inv[c] - tvec[c];
 }
 
 // ---- A^T Y: one wave per column slab (32 columns = 2 MFMA row tiles of A^T) and range of row blocks ------------------
 // The same records, written transposed: tile row = column inside the slab, contraction index = row inside the block
 // (64 = two MFMA steps).  Partial results per range of row blocks; k_sum_panels adds them in order.
-constexpr int kTStrideT = 144;        // bytes between the rows of the transposed tile (128 + 16)
 constexpr int kTileBytesT = 2 * kTK * kTStrideT;       // hi + lo transposed tile of a wave (9 KB)
 template <int NT>
 __global__ void __launch_bounds__(64 * kTWaves) __attribute__((amdgpu_waves_per_eu(2, 2))) k_tile_cols(const int32_t* __restrict__ blk, const uint2* __restrict__ recs, int64_t nblocks, int nslabs,
@@ -318,7 +430,7 @@ __global__ void __launch_bounds__(64 * kTWaves) __attribute__((amdgpu_waves_per_
     const int64_t b1 = b0 + blocks_per_part < nblocks ? b0 + blocks_per_part : nblocks;
     if (b0 >= b1) return;
     auto put = [&](unsigned char* tile, const uint2 r) {
-        const uint32_t off = (r.x & 31u) * kTStrideT + (r.x >> 5) * 2u;
+        const uint32_t off = r.x >> 16;
         *reinterpret_cast<uint16_t*>(tile + off) = (uint16_t)(r.y & 0xffffu);
         *reinterpret_cast<uint16_t*>(tile + kTK * kTStrideT + off) = (uint16_t)(r.y >> 16);
     };
@@ -477,18 +589,22 @@ int tiles_pack(ddx_ctx* ctx) {
 }
 
 int tiles_apply_rows(ddx_ctx* ctx, int L, const double* tvec, double* Yrow) {
-    const size_t lds = (size_t)kTWaves * kTileBytes;
     const int nslabs = (int)ceil_div((int64_t)ctx->H, (int64_t)kTK);
-    const unsigned grid = (unsigned)ceil_div(ceil_div(ctx->M, (int64_t)kTRows), (int64_t)kTWaves);
+    const int64_t nblocks = ceil_div(ctx->M, (int64_t)kTRows);
     const double* inv = reinterpret_cast<const double*>(ctx->tile_scale.as<unsigned char>() + 512);
-    DDX_TRY(allow_dynamic_lds(ctx, reinterpret_cast<const void*>(&k_tile_rows<2>), (int)lds));
-    DDX_TRY(allow_dynamic_lds(ctx, reinterpret_cast<const void*>(&k_tile_rows<3>), (int)lds));
-    if (L <= 32)
-        k_tile_rows<2><<<grid, 64 * kTWaves, lds, ctx->stream>>>(ctx->tile_blk.as<int32_t>(), ctx->tile_recs.as<uint2>(), ctx->M, nslabs, L,
-                                                                 ctx->tile_frag.as<h8>(), inv, tvec, Yrow);
+    const int parts = (int)ceil_div((int64_t)nslabs, (int64_t)kTSlabsPerPart);
+    const int nt = L <= 32 ? 2 : 3;
+    const int64_t Mpad = nblocks * kTRows;
+    DDX_TRY(ensure(ctx, ctx->tile_part, sizeof(float) * (size_t)parts * Mpad * 16 * nt));
+    const size_t lds = (size_t)kTWaves * kTileBytes;
+    const dim3 grid((unsigned)ceil_div(nblocks, (int64_t)kTWaves), (unsigned)parts);
+    if (nt == 2)
+        k_tile_rows_part<2><<<grid, 64 * kTWaves, lds, ctx->stream>>>(ctx->tile_blk.as<int32_t>(), ctx->tile_recs.as<uint2>(), ctx->M, nslabs,
+                                                                      ctx->tile_frag.as<h8>(), ctx->tile_part.as<float>(), Mpad);
     else
-        k_tile_rows<3><<<grid, 64 * kTWaves, lds, ctx->stream>>>(ctx->tile_blk.as<int32_t>(), ctx->tile_recs.as<uint2>(), ctx->M, nslabs, L,
-                                                                 ctx->tile_frag.as<h8>(), inv, tvec, Yrow);
+        k_tile_rows_part<3><<<grid, 64 * kTWaves, lds, ctx->stream>>>(ctx->tile_blk.as<int32_t>(), ctx->tile_recs.as<uint2>(), ctx->M, nslabs,
+                                                                      ctx->tile_frag.as<h8>(), ctx->tile_part.as<float>(), Mpad);
+    k_tile_rows_sum<<<(unsigned)ceil_div(ctx->M * 16 * nt, (int64_t)256), 256, 0, ctx->stream>>>(ctx->tile_part.as<float>(), parts, ctx->M, Mpad, L, 16 * nt, inv, tvec, Yrow);
     return DDX_OK;
 }
 
