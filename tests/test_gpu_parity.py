@@ -152,7 +152,8 @@ def test_column_mirror_placement_modes(monkeypatch):
     """The column-major mirror (dd.py has no counterpart: it serves A^T Y of the PCA) built three ways -- LDS tiles
     (default), scattered stores, radix sort -- on a matrix that leaves the comfortable regime: rows holding every
     column (more than 16 entries of a row inside a tile window), a block of columns held by every row (tiles larger
-    than the LDS range: spill path), empty rows and empty columns, a panel straddling original and synthetic rows."""
+    than the LDS range: spill path), empty rows and empty columns, a panel straddling original and synthetic rows;
+    and counts outside the log-normalisation table (both passes: the row-major copy and the mirror must agree)."""
     from doubletdetection_amd import _lib
 
     rng = np.random.default_rng(11)
@@ -163,6 +164,12 @@ def test_column_mirror_placement_modes(monkeypatch):
     dense[300:340, :] = 0                                          # empty rows
     dense[:, 700:760] = 0                                          # empty columns
     dense[5, 0] = 7
+    dense = dense.astype(np.float64)
+    # counts outside the (row, count) table of the log-normalisation: large and fractional values (evaluated in place)
+    big = rng.random((N, H)) < 0.002
+    dense[big] = rng.choice([17.0, 37.0, 250.0, 2.5, 0.25], size=int(big.sum()))
+    dense[300:340, :] = 0
+    dense[:, 700:760] = 0
     counts = sp.csr_matrix(dense.astype(np.float32))
     parents = rng.choice(N, size=(N // 4, 2), replace=False)
     Y = rng.normal(size=(N + N // 4, 5))
