@@ -1127,10 +1127,17 @@ __global__ void __launch_bounds__(256) k_col_partials(const int64_t* __restrict_
     if (live) {
         const double z = (double)zcol[(int)(seg % H)];
         const int64_t lo = cp[seg], hi = cp[seg + 1];
-        for (int64_t t = lo + sub; t < hi; t += 16) {
-            const float xv = x[t];
-            a += (double)xv - z;
-            if (mode) { const float sq = xv * xv; b += (double)sq; }
+        // four loads in flight per lane; the additions stay in the order of the plain loop
+        for (int64_t t = lo + sub; t < hi; t += 64) {
+            float xv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) xv[u] = t + 16 * u < hi ? x[t + 16 * u] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (t + 16 * u < hi) {
+                    a += (double)xv[u] - z;
+                    if (mode) { const float sq = xv[u] * xv[u]; b += (double)sq; }
+                }
         }
     }
 #pragma unroll
