@@ -1035,14 +1035,20 @@ __global__ void __launch_bounds__(256) k_lognorm_rows(const int64_t* __restrict_
     for (int64_t row = r0; row < r0 + rows_per_wave && row < M; ++row) {
         const int64_t b = indptr[row], e = indptr[row + 1];
         const float tv = tab[row * kLognormTab + (lane & (kLognormTab - 1))];     // lane c-1 holds the value of count c
-        for (int64_t base = b; base < e; base += 64) {       // all lanes stay in the loop: they are shuffle sources
-            const int64_t p = base + lane;
-            const bool valid = p < e;
-            const float v = valid ? raw[p] : 1.0f;
-            const int c = small_count(v, kLognormTab);
-            const float r = __shfl(tv, c ? c - 1 : 0, 64);
-            if (valid && c) x[p] = r;
-            lognorm_enqueue(q, qn, valid && !c, p, v, (int32_t)row, lane, lib64, m, pc, use_log1p != 0, x);
+        for (int64_t base = b; base < e; base += 256) {      // all lanes stay in the loop: they are shuffle sources
+            float v4[4];                                      // four loads in flight per lane
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v4[u] = base + 64 * u + lane < e ? raw[base + 64 * u + lane] : 1.0f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t p = base + 64 * u + lane;
+                const bool valid = p < e;
+                const float v = v4[u];
+                const int c = small_count(v, kLognormTab);
+                const float r = __shfl(tv, c ? c - 1 : 0, 64);
+                if (valid && c) x[p] = r;
+                lognorm_enqueue(q, qn, valid && !c, p, v, (int32_t)row, lane, lib64, m, pc, use_log1p != 0, x);
+            }
         }
     }
     lognorm_flush(q, qn, lane, lib64, m, pc, use_log1p != 0, x);
