@@ -166,8 +166,20 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
     const int32_t* B = indices + b0;
     const int L = la + lb;
     if (L <= kMergeStage) {                         // block-uniform
-        for (int i = tid; i < la; i += 256) s_idx[i] = A[i];
-        for (int j = tid; j < lb; j += 256) s_idx[la + j] = B[j];
+        // (all loads of a thread in flight before the first LDS store: parents hold ~900 entries, 4 per thread)
+        for (int i0 = 0; i0 < L; i0 += 4 * 256) {
+            int32_t v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * 256 + tid;
+                v[u] = i < la ? A[i] : (i < L ? B[i - la] : 0);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * 256 + tid;
+                if (i < L) s_idx[i] = v[u];
+            }
+        }
         A = s_idx;
         B = s_idx + la;
         __syncthreads();
@@ -183,10 +195,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
         int ihi = t0 + kMergeTile; if (ihi > la) ihi = la;
         for (int i = ilo + tid; i < ihi; i += 256) {
             const int32_t col = A[i];
+            const float va = val[a0 + i];                  // (requested before the search, used after it)
             const int r = lower_bound_i32(B, lb, col);
             const int p = i + r - t0;
             if (p >= 0 && p < kMergeTile) {
-                float v = val[a0 + i];
+                float v = va;
                 if (r < lb && B[r] == col) v = __fadd_rn(v, val[b0 + r]);
                 t_col[p] = col;
                 t_val[p] = v;
@@ -197,11 +210,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
         int jhi = t0 + kMergeTile; if (jhi > lb) jhi = lb;
         for (int j = jlo + tid; j < jhi; j += 256) {
             const int32_t col = B[j];
+            const float v = val[b0 + j];                   // (requested before the search, used after it)
             const int r = upper_bound_i32(A, la, col);
             const int p = j + r - t0;
             if (p >= 0 && p < kMergeTile) {
                 const bool matched = (r > 0 && A[r - 1] == col);
-                const float v = val[b0 + j];
                 t_col[p] = col;
                 t_val[p] = v;
                 t_keep[p] = (!matched && v != 0.f);
@@ -251,9 +264,20 @@ __global__ void __launch_bounds__(256) k_doublet_compact(const int64_t* __restri
     if (s >= S) return;
     const int64_t src = pad_off[s], dst = indptr_s[s];
     const int n = (int)(indptr_s[s + 1] - dst);
-    for (int i = lane; i < n; i += 64) {
-        out_indices[dst + i] = pad_idx[src + i];
-        out_val[dst + i] = pad_val[src + i];
+    for (int i0 = lane; i0 < n; i0 += 256) {              // four elements of both arrays in flight per lane
+        int32_t ci[4];
+        float cv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + 64 * u;
+            ci[u] = i < n ? pad_idx[src + i] : 0;
+            cv[u] = i < n ? pad_val[src + i] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + 64 * u;
+            if (i < n) { out_indices[dst + i] = ci[u]; out_val[dst + i] = cv[u]; }
+        }
     }
 }
 
