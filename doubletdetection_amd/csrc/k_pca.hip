@@ -657,9 +657,17 @@ __global__ void __launch_bounds__(256) k_wcolsum_partial(const double* __restric
     const int64_t r1 = (r0 + rows_per_block < R) ? r0 + rows_per_block : R;
     double acc = 0.0;
     if (g < groups) {
-        for (int64_t r = r0 + g; r < r1; r += groups) {
-            const double v = X[r * L + c];
-            acc += wgt ? wgt[r] * v : v;
+        for (int64_t r = r0 + g; r < r1; r += 4 * groups) {      // four rows in flight; additions in the order of the plain loop
+            double v[4], wv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t ru = r + (int64_t)u * groups;
+                v[u] = ru < r1 ? X[ru * L + c] : 0.0;
+                wv[u] = (wgt && ru < r1) ? wgt[ru] : 1.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (r + (int64_t)u * groups < r1) acc += wgt ? wv[u] * v[u] : v[u];
         }
     }
     red[tid] = acc;
@@ -705,7 +713,14 @@ __global__ void __launch_bounds__(256) k_gram_partial(const double* __restrict__
     for (int64_t rb = r0; rb < r1; rb += 32) {
         const int nr = (int)((r1 - rb) < 32 ? (r1 - rb) : 32);
         __syncthreads();
-        for (int t = tid; t < nr * L; t += 256) tile[t] = X[rb * L + t];
+        for (int t0 = tid; t0 < nr * L; t0 += 4 * 256) {          // (all loads of a thread in flight before the LDS stores)
+            double v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = t0 + u * 256 < nr * L ? X[rb * L + t0 + u * 256] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (t0 + u * 256 < nr * L) tile[t0 + u * 256] = v[u];
+        }
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < MAXP; ++q) {
@@ -857,7 +872,14 @@ __global__ void __launch_bounds__(256) k_right_mult(const double* __restrict__ X
     const int64_t r0 = (int64_t)blockIdx.x * 64;
     const int nr = (int)((R - r0) < 64 ? (R - r0) : 64);
     for (int t = tid; t < L * L2; t += 256) t_s[t] = T[t];
-    for (int t = tid; t < nr * L; t += 256) x_s[t] = X[r0 * L + t];
+    for (int t0 = tid; t0 < nr * L; t0 += 4 * 256) {              // (all loads of a thread in flight before the LDS stores)
+        double v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = t0 + u * 256 < nr * L ? X[r0 * L + t0 + u * 256] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (t0 + u * 256 < nr * L) x_s[t0 + u * 256] = v[u];
+    }
     __syncthreads();
     for (int o = tid; o < nr * L2; o += 256) {
         const int r = o / L2, c = o - r * L2;
