@@ -485,6 +485,9 @@ class BoostClassifier:
 
         t_fit0 = time.perf_counter()
         rank, world, backend = _dist_info()
+        if world > 1 and "DDX_UPLOAD_THREADS" not in os.environ:
+            # every rank packs its own copy of the matrix for the upload: share the host cores (one node assumed)
+            os.environ["DDX_UPLOAD_THREADS"] = str(max(4, min(48, (os.cpu_count() or 8) // (2 * world))))
         staged = getattr(self, "_staged", None)
         if staged is not None and staged[0] is raw_counts:
             _, csr, leaders, restrict = staged                        # counts already resident in HBM

@@ -675,3 +675,42 @@ def test_unsupported_regimes_raise_clearly():
         warnings.simplefilter("ignore")
         with pytest.raises(NotImplementedError, match="normalizer"):
             BoostClassifier(n_iters=2, normalizer=lambda x: x).fit(rng.poisson(1.0, size=(600, 100)))
+
+
+def test_packed_upload_equals_plain_upload(monkeypatch):
+    """dd.py:149-160 (the matrix handed to fit()).  The raw matrix travels packed (column | count << 16, 4 bytes per entry,
+    host threads + pinned chunks) when every count is an integer below 65 536 and there are at most 65 536 genes, plain
+    otherwise; both leave the same device matrix."""
+    from doubletdetection_amd import _lib
+    from doubletdetection_amd._synthetic import make_counts
+
+    counts = make_counts(60_000, 3000, density=0.02, seed=4)            # > 2^20 stored entries: the packed path applies
+    counts.data[::1001] = 40_000.0                                        # large but representable counts
+    assert counts.nnz > (1 << 20)
+
+    def restricted(env, mat):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        c = _lib.Context(0)
+        try:
+            c.upload_raw(mat)
+            var = c.gene_variances()
+            c.select_columns(np.sort(np.argsort(var)[-500:]))
+            return var, c.get_counts()
+        finally:
+            c.close()
+            for k in env:
+                monkeypatch.delenv(k, raising=False)
+
+    var_p, sub_p = restricted({}, counts)
+    var_q, sub_q = restricted({"DDX_UPLOAD": "plain"}, counts)
+    np.testing.assert_array_equal(var_p, var_q)
+    _same_csr(sub_p, sub_q)
+    # entries the packed form cannot hold (fractional, >= 65 536): the call falls back to the plain copies
+    odd = counts.copy()
+    odd.data[5] = 2.5
+    odd.data[77] = 70_000.0
+    var_f, sub_f = restricted({}, odd)
+    var_g, sub_g = restricted({"DDX_UPLOAD": "plain"}, odd)
+    np.testing.assert_array_equal(var_f, var_g)
+    _same_csr(sub_f, sub_g)
