@@ -138,6 +138,7 @@ void Options::read_environment() {
     row_sums_sequential = getenv("DDX_ROW_SUMS_SEQUENTIAL") != nullptr;
     knn_debug = getenv("DDX_KNN_DEBUG") != nullptr;
     upload_packed = !is(getenv("DDX_UPLOAD"), "plain");
+    upload_wait = is(getenv("DDX_UPLOAD"), "packed");
     mirror_mode = is(getenv("DDX_MIRROR"), "sort") ? 0 : (is(getenv("DDX_MIRROR"), "scatter") ? 1 : 2);
     g = getenv("DDX_ARENA_GUARD");
     arena_guard = g && g[0] != '0' && g[0] != 0;
@@ -268,7 +269,6 @@ int ddx_destroy(ddx_ctx* ctx) {
     context_reset(ctx);
     arena_destroy(ctx);
     if (ctx->lv_host) (void)hipHostFree(ctx->lv_host);
-    if (ctx->pin_buf) (void)hipHostFree(ctx->pin_buf);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -393,6 +393,19 @@ class WorkerPool {
     bool stop_ = false;
 };
 std::mutex g_pool_mutex;                     // one packed upload at a time per process (they share the host cores anyway)
+// pinned staging of the packed upload, one per process.  Pinning 0.37 GB takes ~70 ms, five uploads' worth: the first
+// call that needs a (larger) buffer starts the allocation on a helper thread and sends its matrix plain; later calls
+// find the buffer ready.  Never freed (a few hundred MB of host memory for the life of the process).
+std::atomic<int> g_pin_state{0};             // 0 none / too small, 1 being allocated, 2 ready
+void* g_pin_buf = nullptr;
+size_t g_pin_bytes = 0;
+void pin_allocate(size_t need, int device) {
+    (void)hipSetDevice(device);
+    if (g_pin_buf) { (void)hipHostFree(g_pin_buf); g_pin_buf = nullptr; g_pin_bytes = 0; }
+    void* p = nullptr;
+    if (hipHostMalloc(&p, need, hipHostMallocPortable) == hipSuccess) { g_pin_buf = p; g_pin_bytes = need; g_pin_state.store(2, std::memory_order_release); }
+    else { (void)hipGetLastError(); g_pin_state.store(0, std::memory_order_release); }
+}
 WorkerPool* g_pool = nullptr;
 pid_t g_pool_pid = 0;
 // (called with g_pool_mutex held.  Threads do not survive fork(): a child process builds its own pool; the parent's
@@ -416,19 +429,26 @@ static int upload_packed(ddx_ctx* ctx, int64_t nnz, int32_t n_genes, const int32
     const int64_t chunk = std::max<int64_t>((nnz + 15) / 16, (int64_t)1 << 18);
     const int64_t nchunks = (nnz + chunk - 1) / chunk;
     const size_t need = sizeof(uint32_t) * (size_t)nnz;
-    if (ctx->pin_bytes < need) {
-        if (ctx->pin_buf) (void)hipHostFree(ctx->pin_buf);
-        ctx->pin_buf = nullptr; ctx->pin_bytes = 0;
-        if (hipHostMalloc(&ctx->pin_buf, need, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); ctx->pin_buf = nullptr; return 1; }
-        ctx->pin_bytes = need;
-    }
-    if (!ctx->copy_stream && hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); ctx->copy_stream = nullptr; return 1; }
-    DDX_TRY(ensure(ctx, ctx->raw_packed, need));
-    uint32_t* pin = static_cast<uint32_t*>(ctx->pin_buf);
     // one packed upload at a time: a second context staging at the same moment (several GPUs driven by one process)
     // sends its copy plain, in parallel, instead of queueing behind this one
     std::unique_lock<std::mutex> pool_lock(g_pool_mutex, std::try_to_lock);
     if (!pool_lock.owns_lock()) return 1;
+    {
+        static pid_t pin_pid = 0;
+        if (pin_pid != getpid()) { pin_pid = getpid(); g_pin_state.store(0); g_pin_buf = nullptr; g_pin_bytes = 0; }   // (a forked child starts over)
+        const int st = g_pin_state.load(std::memory_order_acquire);
+        if (st == 1) return 1;                                   // still being pinned
+        if (st == 0 || g_pin_bytes < need) {
+            g_pin_state.store(1);
+            const size_t want = need + need / 8;                 // (some room for the next, slightly larger matrix)
+            if (ctx->opt.upload_wait) pin_allocate(want, ctx->device);
+            else { std::thread(pin_allocate, want, ctx->device).detach(); return 1; }
+            if (g_pin_state.load() != 2) return 1;
+        }
+    }
+    if (!ctx->copy_stream && hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); ctx->copy_stream = nullptr; return 1; }
+    DDX_TRY(ensure(ctx, ctx->raw_packed, need));
+    uint32_t* pin = static_cast<uint32_t*>(g_pin_buf);
     WorkerPool* pool = upload_pool();
     const int T = pool->size();
     std::vector<std::atomic<int>> done(nchunks);

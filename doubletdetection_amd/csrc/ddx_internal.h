@@ -50,6 +50,7 @@ struct Options {
     bool knn_debug = false;
     int mirror_mode = 2;             // column-major mirror: 2 counting sort placed by LDS tiles, 1 (DDX_MIRROR=scatter) counting sort with scattered stores, 0 (DDX_MIRROR=sort) radix sort
     bool upload_packed = true;       // DDX_UPLOAD=plain: send the raw matrix as it is (8 bytes per entry) instead of packed (4)
+    bool upload_wait = false;        // DDX_UPLOAD=packed: wait for the pinned staging buffer instead of sending the first matrix plain (tests)
     bool arena_guard = false;        // DDX_ARENA_GUARD=1: pattern-fill the pad behind every block, ddx_check_memory verifies it
     int knn_ablation = 0;            // only honoured under DDX_ABLATION
     void read_environment();
@@ -102,8 +103,6 @@ struct ddx_ctx {
     int64_t raw_nnz = 0;
     ddx::DevBuf raw_indptr, raw_indices, raw_data;
     std::vector<int64_t> h_raw_indptr;
-    void* pin_buf = nullptr;         // pinned staging of the packed upload (kept between fits)
-    size_t pin_bytes = 0;
     hipStream_t copy_stream = nullptr;   // the packed chunks travel on their own stream
     ddx::DevBuf raw_packed;          // the packed matrix on the device (expanded chunk by chunk)
 

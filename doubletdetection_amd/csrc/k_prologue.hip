@@ -25,12 +25,23 @@ __global__ void __launch_bounds__(256) k_validate_csr(const int64_t* __restrict_
     if (row >= N) return;
     const int64_t b = indptr[row], e = indptr[row + 1];
     int bad = 0;
-    for (int64_t p = b + lane; p < e; p += 64) {
-        const int32_t c = cols[p];
-        const float v = vals[p];
-        if (!(fabsf(v) <= 3.4028234663852886e38f)) bad |= 1;      // NaN or infinity
-        if (c < 0 || c >= G) bad |= 2;
-        if (p > b && cols[p - 1] >= c) bad |= 4;
+    for (int64_t p0 = b + lane; p0 < e; p0 += 256) {                  // four steps of 64 entries requested together
+        int32_t c[4], cp[4];
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t p = p0 + 64 * u;
+            c[u] = p < e ? cols[p] : 0;
+            cp[u] = (p < e && p > b) ? cols[p - 1] : -1;
+            v[u] = p < e ? vals[p] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (p0 + 64 * u >= e) break;
+            if (!(fabsf(v[u]) <= 3.4028234663852886e38f)) bad |= 1;   // NaN or infinity
+            if (c[u] < 0 || c[u] >= G) bad |= 2;
+            if (cp[u] >= c[u]) bad |= 4;
+        }
     }
     if (bad) atomicOr(flags, bad);
 }
@@ -143,7 +154,14 @@ __global__ void __launch_bounds__(256) k_count_kept(const int64_t* __restrict__ 
     const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= N) return;
     int c = 0;
-    for (int64_t p = indptr[row] + lane; p < indptr[row + 1]; p += 64) c += (newid[cols[p]] >= 0);
+    const int64_t e = indptr[row + 1];
+    for (int64_t p = indptr[row] + lane; p < e; p += 256) {          // four dependent load pairs in flight per lane
+        int32_t j[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) j[u] = p + 64 * u < e ? cols[p + 64 * u] : -1;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) c += (j[u] >= 0 && newid[j[u]] >= 0);
+    }
     for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
     if (lane == 0) counts[row] = c;
 }
@@ -158,21 +176,28 @@ __global__ void __launch_bounds__(256) k_compact_kept(const int64_t* __restrict_
     if (row >= N) return;
     int64_t o = out_ptr[row];
     const int64_t b = indptr[row], e = indptr[row + 1];
-    for (int64_t base = b; base < e; base += 64) {
-        const int64_t p = base + lane;
-        int32_t nid = -1;
-        float v = 0.f;
-        if (p < e) {
-            nid = newid[cols[p]];
-            v = vals[p];
+    for (int64_t base = b; base < e; base += 256) {                  // four 64-entry steps requested together, written in order
+        int32_t nid[4];
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t p = base + 64 * u + lane;
+            const int32_t j = p < e ? cols[p] : -1;
+            v[u] = p < e ? vals[p] : 0.f;
+            nid[u] = j;
         }
-        const unsigned long long m = __ballot(nid >= 0);
-        if (nid >= 0) {
-            const int before = __popcll(m & ((1ull << lane) - 1ull));
-            out_cols[o + before] = nid;
-            out_vals[o + before] = v;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) nid[u] = nid[u] >= 0 ? newid[nid[u]] : -1;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned long long m = __ballot(nid[u] >= 0);
+            if (nid[u] >= 0) {
+                const int before = __popcll(m & ((1ull << lane) - 1ull));
+                out_cols[o + before] = nid[u];
+                out_vals[o + before] = v[u];
+            }
+            o += __popcll(m);
         }
-        o += __popcll(m);
     }
 }
 

@@ -702,7 +702,9 @@ def test_packed_upload_equals_plain_upload(monkeypatch):
             for k in env:
                 monkeypatch.delenv(k, raising=False)
 
-    var_p, sub_p = restricted({}, counts)
+    # (DDX_UPLOAD=packed waits for the pinned staging buffer; by default the first matrix of a process travels plain
+    # while the buffer is being pinned in the background)
+    var_p, sub_p = restricted({"DDX_UPLOAD": "packed"}, counts)
     var_q, sub_q = restricted({"DDX_UPLOAD": "plain"}, counts)
     np.testing.assert_array_equal(var_p, var_q)
     _same_csr(sub_p, sub_q)
@@ -710,7 +712,7 @@ def test_packed_upload_equals_plain_upload(monkeypatch):
     odd = counts.copy()
     odd.data[5] = 2.5
     odd.data[77] = 70_000.0
-    var_f, sub_f = restricted({}, odd)
+    var_f, sub_f = restricted({"DDX_UPLOAD": "packed"}, odd)
     var_g, sub_g = restricted({"DDX_UPLOAD": "plain"}, odd)
     np.testing.assert_array_equal(var_f, var_g)
     _same_csr(sub_f, sub_g)
