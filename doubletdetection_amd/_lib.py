@@ -12,7 +12,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DDX_LIB") or os.path.join(_HERE, "libddx.so")      # DDX_LIB: an experimental build (profiles/tools)
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _lib = None
 
@@ -41,6 +41,9 @@ _SIGNATURES = {
     "ddx_synchronize": (C.c_int, [C.c_void_p]),
     "ddx_device_bytes": (C.c_int, [C.c_void_p, c_i64_p]),
     "ddx_check_memory": (C.c_int, [C.c_void_p]),
+    "ddx_reserve_hint": (C.c_int, [C.c_void_p, C.c_int64]),
+    "ddx_trim": (C.c_int, [C.c_void_p, C.c_int64]),
+    "ddx_set_upload_threads": (C.c_int, [C.c_int32]),
     "ddx_upload_raw": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, c_i64_p, c_i32_p, c_f32_p]),
     "ddx_gene_variances": (C.c_int, [C.c_void_p, c_f32_p]),
     "ddx_select_columns": (C.c_int, [C.c_void_p, c_i64_p, C.c_int32]),
@@ -147,6 +150,11 @@ def device_count() -> int:
     n = C.c_int(0)
     rc = load().ddx_device_count(C.byref(n))
     return n.value if rc == 0 else 0
+
+
+def set_upload_threads(n: int) -> None:
+    """Host threads that pack the raw matrix for the upload (process-wide; 0 = the library's default)."""
+    _check(load().ddx_set_upload_threads(int(n)))
 
 
 # ---- context-free host routines --------------------------------------------------------------
@@ -332,6 +340,14 @@ class Context:
         v = C.c_int64(0)
         self._c(self._lib.ddx_device_bytes(self._h, C.byref(v)))
         return v.value
+
+    def reserve_hint(self, nbytes: int):
+        """Size of the next memory chunk the context requests from the driver (0: the library's own guess)."""
+        self._c(self._lib.ddx_reserve_hint(self._h, int(nbytes)))
+
+    def trim(self, keep_bytes: int = 0):
+        """Forget the last fit and return device memory to the driver until at most keep_bytes remain."""
+        self._c(self._lib.ddx_trim(self._h, int(keep_bytes)))
 
     # prologue
     def upload_raw(self, csr):

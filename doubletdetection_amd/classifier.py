@@ -72,6 +72,27 @@ def _keep_contexts() -> bool:
     return os.environ.get("DDX_KEEP_CONTEXT", "1") not in ("", "0")
 
 
+def _park_limit_bytes() -> int:
+    """HBM the parked contexts of one GPU may hold between fits (DDX_PARK_MAX_GB, default 48): what goes beyond is
+    returned to the driver when a context is parked, largest holder first.  The switches a context reads from the
+    environment (DDX_SPMM, DDX_MIRROR, DDX_UPLOAD, ...) are re-read whenever a parked context starts its next fit."""
+    return int(float(os.environ.get("DDX_PARK_MAX_GB", "48")) * (1 << 30))
+
+
+def _park(device, ctx) -> None:
+    parked = _CONTEXT_POOL.setdefault(device, [])
+    parked.append(ctx)
+    limit = _park_limit_bytes()
+    held = [c.device_bytes() for c in parked]
+    while sum(held) > limit:
+        big = max(range(len(parked)), key=lambda i: held[i])
+        parked[big].trim(max(0, limit - (sum(held) - held[big])) if len(parked) == 1 else 0)
+        new = parked[big].device_bytes()
+        if new == held[big]:
+            break
+        held[big] = new
+
+
 def release_device_memory() -> None:
     """Destroy the parked device contexts and free their HBM."""
     while _CONTEXT_POOL:
@@ -108,7 +129,7 @@ class _HipEngine:
             if os.environ.get("DDX_ARENA_GUARD", "0") not in ("", "0"):
                 self.ctx.check_memory()                  # overflow detector (tests): raises, naming the buffer
             if _keep_contexts():
-                _CONTEXT_POOL.setdefault(self.device, []).append(self.ctx)
+                _park(self.device, self.ctx)
             else:
                 self.ctx.close()                         # frees every HBM buffer of the fit
             self.ctx = None
@@ -130,7 +151,7 @@ class _HipEngine:
         self.ctx.clone_counts_from(other.ctx)
 
     def run_iteration(self, parents, pseudocount, standard_scaling, n_components, q0, knn_k, include_self,
-                      graph_mode, gamma=None, pca_lock=None):
+                      graph_mode, gamma=None, pca_lock=None, verbose=False):
         """One boosting iteration on the device.  Returns the symmetric graph (indptr, indices, weights), or --
         when ``gamma`` is given -- the result of the synchronous pre-sweeps run on the device:
         (member, coarse indptr, coarse indices, coarse weights).
@@ -139,10 +160,16 @@ class _HipEngine:
         second stream buys is that its latency-bound stages (graph construction, community pre-sweeps, sorts, the small
         factorisations) run in the shadow of the other stream's operator products."""
         c = self.ctx
+        if verbose:
+            print("\nCreating synthetic doublets...")        # the reference's stage messages (dd.py:275-276,280-281,305-306,315-316)
         c.create_doublets(parents)
+        if verbose:
+            print("Normalizing...")
         c.lognormalise(pseudocount)
         if standard_scaling:
             c.scale(15.0)
+        if verbose:
+            print("Running PCA...")
         if pca_lock is not None:
             pca_lock.acquire()
         try:
@@ -150,6 +177,8 @@ class _HipEngine:
         finally:
             if pca_lock is not None:
                 pca_lock.release()
+        if verbose:
+            print("Clustering augmented data set...\n")
         c.knn(knn_k, include_self)
         if gamma is None:
             return c.build_graph(graph_mode)  # symmetric CSR assembled on the device
@@ -485,9 +514,10 @@ class BoostClassifier:
 
         t_fit0 = time.perf_counter()
         rank, world, backend = _dist_info()
-        if world > 1 and "DDX_UPLOAD_THREADS" not in os.environ:
-            # every rank packs its own copy of the matrix for the upload: share the host cores (one node assumed)
-            os.environ["DDX_UPLOAD_THREADS"] = str(max(4, min(48, (os.cpu_count() or 8) // (2 * world))))
+        if "DDX_UPLOAD_THREADS" not in os.environ:
+            # every rank packs its own copy of the matrix for the upload: share the host cores (one node assumed).
+            # Passed through the C-ABI (the pool is resized when the figure changes); the environment is not touched.
+            _lib.set_upload_threads(max(4, min(48, (os.cpu_count() or 8) // (2 * world))) if world > 1 else 0)
         staged = getattr(self, "_staged", None)
         if staged is not None and staged[0] is raw_counts:
             _, csr, leaders, restrict = staged                        # counts already resident in HBM
@@ -502,6 +532,7 @@ class BoostClassifier:
         drawer = ThreadPoolExecutor(max_workers=1)
         draws = drawer.submit(self._draw, num_cells, num_genes)     # overlaps the device prologue
         lanes = []
+        ok = False
         try:
             devs = list(leaders)
             if restrict:
@@ -516,10 +547,9 @@ class BoostClassifier:
             self._fit_resident(lanes, num_cells, num_genes, rank, world, backend, draws)
             self._host_timings["prologue"] = t_prologue
             self._host_timings["stage"] = t_staged - t_fit0
+            ok = True
         finally:
-            import sys
-
-            failed = sys.exc_info()[0] is not None
+            failed = not ok        # (sys.exc_info() would also be set when a caller's own `except` block runs this fit)
             t0 = time.perf_counter()
             try:
                 draws.result()             # never leave the Generator in use by a worker
@@ -758,7 +788,8 @@ class BoostClassifier:
                     if self.verbose:
                         print("Iteration {:3}/{}".format(i + 1, n_iters))
                     graph = engine.run_iteration(all_parents[i], self.pseudocount, self.standard_scaling, n_comp,
-                                                 q0, knn_k, include_self, graph_mode, gamma, pca_locks[dev])
+                                                 q0, knn_k, include_self, graph_mode, gamma, pca_locks[dev],
+                                                 **({"verbose": True} if self.verbose else {}))
                     pending[i] = pool.submit(self._cluster_and_score, graph, gamma, seed, min_cluster_size, num_cells, leiden,
                                              q_tol, restart_threads)
 

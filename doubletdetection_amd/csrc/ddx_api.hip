@@ -4,6 +4,7 @@
 #include <functional>
 #include <unistd.h>
 #include <mutex>
+#include <new>
 #include <cmath>
 #include <cstdarg>
 #include <thread>
@@ -50,6 +51,7 @@ int allow_dynamic_lds(ddx_ctx* ctx, const void* kernel, int bytes) {
 }
 
 void arena_hint(ddx_ctx* ctx, size_t bytes) {
+    if (ctx->arena_hint_forced) return;                  // ddx_reserve_hint decides
     if (bytes > ctx->arena.next_chunk) ctx->arena.next_chunk = bytes;
 }
 
@@ -77,6 +79,8 @@ void context_reset(ddx_ctx* ctx) {
     ctx->g_nodes = -1; ctx->g_entries = 0; ctx->g_d_indptr = nullptr; ctx->g_d_cols = nullptr; ctx->g_d_vals = nullptr;
     ctx->c_nodes = -1; ctx->c_entries = 0; ctx->c_d_member = nullptr; ctx->c_d_indptr = nullptr; ctx->c_d_cols = nullptr; ctx->c_d_vals = nullptr;
     ctx->lv_host_valid = false;
+    // a parked context starts its next fit with the switches of the environment as it is NOW (like a fresh one)
+    ctx->opt.read_environment();
 }
 
 void arena_destroy(ddx_ctx* ctx) {
@@ -100,11 +104,14 @@ int ensure(ddx_ctx* ctx, DevBuf& b, size_t bytes) {
         void* p = nullptr;
         hipError_t e = hipMalloc(&p, cap);
         if (e != hipSuccess && cap > want) {      // the guess was too greedy for what is left: take what is needed
+            (void)hipGetLastError();              // (the failure is sticky: a later DDX_HIP(hipGetLastError()) would report it)
             cap = want;
             e = hipMalloc(&p, cap);
         }
-        if (e != hipSuccess)
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
             return set_err(ctx, DDX_E_NOMEM, "hipMalloc(%zu bytes) failed: %s", cap, hipGetErrorString(e));
+        }
         A.chunks.push_back({p, cap, 0});
         ctx->dev_bytes += (int64_t)cap;
         A.next_chunk = std::max<size_t>((size_t)256 << 20, cap / 4);   // later chunks: a quarter of the first guess
@@ -302,6 +309,27 @@ int ddx_check_memory(ddx_ctx* ctx) {
     return DDX_OK;
 }
 
+int ddx_reserve_hint(ddx_ctx* ctx, int64_t bytes) {
+    REQUIRE_CTX(ctx);
+    if (bytes < 0) return set_err(ctx, DDX_E_ARG, "negative size");
+    ctx->arena.next_chunk = (size_t)bytes;
+    ctx->arena_hint_forced = bytes > 0;
+    return DDX_OK;
+}
+
+int ddx_trim(ddx_ctx* ctx, int64_t keep_bytes) {
+    REQUIRE_CTX(ctx);
+    USE_DEVICE(ctx);
+    context_reset(ctx);                                  // nothing of the last fit survives: every chunk is empty
+    while (!ctx->arena.chunks.empty() && ctx->dev_bytes > keep_bytes) {
+        Arena::Chunk c = ctx->arena.chunks.back();       // (the first chunk is the large one: it goes last)
+        ctx->arena.chunks.pop_back();
+        (void)hipFree(c.p);
+        ctx->dev_bytes -= (int64_t)c.cap;
+    }
+    return DDX_OK;
+}
+
 int ddx_device_bytes(const ddx_ctx* ctx, int64_t* bytes) {
     REQUIRE_CTX(ctx);
     if (!bytes) return DDX_E_ARG;
@@ -399,22 +427,28 @@ std::mutex g_pool_mutex;                     // one packed upload at a time per 
 std::atomic<int> g_pin_state{0};             // 0 none / too small, 1 being allocated, 2 ready
 void* g_pin_buf = nullptr;
 size_t g_pin_bytes = 0;
+size_t g_pin_failed = 0;                     // smallest size hipHostMalloc has refused in this process (0: none): not retried
+std::thread g_pin_thread;                    // the helper that pins the buffer (joined before the next one starts and at exit)
 void pin_allocate(size_t need, int device) {
     (void)hipSetDevice(device);
     if (g_pin_buf) { (void)hipHostFree(g_pin_buf); g_pin_buf = nullptr; g_pin_bytes = 0; }
     void* p = nullptr;
     if (hipHostMalloc(&p, need, hipHostMallocPortable) == hipSuccess) { g_pin_buf = p; g_pin_bytes = need; g_pin_state.store(2, std::memory_order_release); }
-    else { (void)hipGetLastError(); g_pin_state.store(0, std::memory_order_release); }
+    else { (void)hipGetLastError(); g_pin_failed = need; g_pin_state.store(0, std::memory_order_release); }
 }
+void pin_join() { if (g_pin_thread.joinable()) g_pin_thread.join(); }
 WorkerPool* g_pool = nullptr;
 pid_t g_pool_pid = 0;
+std::atomic<int> g_upload_threads{0};        // ddx_set_upload_threads (0: the default rule)
 // (called with g_pool_mutex held.  Threads do not survive fork(): a child process builds its own pool; the parent's
 // object is abandoned there -- never joined, never freed.)
 WorkerPool* upload_pool() {
+    unsigned hw = std::thread::hardware_concurrency();
+    unsigned n = std::max(4u, std::min(48u, hw ? hw / 2 : 8u));      // 48 threads pack 93 M entries in 6 ms, 24 in 10 ms
+    if (const int req = g_upload_threads.load()) n = (unsigned)req;
+    else if (const char* e = getenv("DDX_UPLOAD_THREADS")) n = (unsigned)std::max(1, atoi(e));
+    if (g_pool && g_pool_pid == getpid() && g_pool->size() != (int)n) { delete g_pool; g_pool = nullptr; }   // resized on request
     if (!g_pool || g_pool_pid != getpid()) {
-        unsigned hw = std::thread::hardware_concurrency();
-        unsigned n = std::max(4u, std::min(48u, hw ? hw / 2 : 8u));      // 48 threads pack 93 M entries in 6 ms, 24 in 10 ms
-        if (const char* e = getenv("DDX_UPLOAD_THREADS")) n = (unsigned)std::max(1, atoi(e));
         g_pool = new WorkerPool((int)n);
         g_pool_pid = getpid();
     }
@@ -435,14 +469,25 @@ static int upload_packed(ddx_ctx* ctx, int64_t nnz, int32_t n_genes, const int32
     if (!pool_lock.owns_lock()) return 1;
     {
         static pid_t pin_pid = 0;
-        if (pin_pid != getpid()) { pin_pid = getpid(); g_pin_state.store(0); g_pin_buf = nullptr; g_pin_bytes = 0; }   // (a forked child starts over)
+        if (pin_pid != getpid()) {                               // (a forked child starts over; the parent's helper thread does not exist here)
+            pin_pid = getpid(); g_pin_state.store(0); g_pin_buf = nullptr; g_pin_bytes = 0; g_pin_failed = 0;
+            new (&g_pin_thread) std::thread();
+        }
         const int st = g_pin_state.load(std::memory_order_acquire);
         if (st == 1) return 1;                                   // still being pinned
         if (st == 0 || g_pin_bytes < need) {
-            g_pin_state.store(1);
             const size_t want = need + need / 8;                 // (some room for the next, slightly larger matrix)
+            if (g_pin_failed && want >= g_pin_failed) return 1;  // the host refused to pin this much before: stay plain
+            pin_join();                                          // (a finished helper of an earlier, smaller request)
+            g_pin_state.store(1);
             if (ctx->opt.upload_wait) pin_allocate(want, ctx->device);
-            else { std::thread(pin_allocate, want, ctx->device).detach(); return 1; }
+            else {
+                // a process that exits while the helper is still pinning must not run hipHostMalloc during runtime teardown
+                static bool hooked = false;
+                if (!hooked) { hooked = true; std::atexit(pin_join); }
+                g_pin_thread = std::thread(pin_allocate, want, ctx->device);
+                return 1;
+            }
             if (g_pin_state.load() != 2) return 1;
         }
     }
@@ -492,7 +537,14 @@ static int upload_packed(ddx_ctx* ctx, int64_t nnz, int32_t n_genes, const int32
     (void)hipStreamSynchronize(ctx->stream);                                   // (the pinned buffer is reused by the next call)
     for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
     if (rc == DDX_E_HIP) return set_err(ctx, DDX_E_HIP, "packed upload failed");
+    if (rc != DDX_OK) release(ctx, ctx->raw_packed);      // not a packable matrix: the caller sends it plain, the 4 bytes per entry go back
     return rc;
+}
+
+int ddx_set_upload_threads(int32_t n) {
+    if (n < 0 || n > 1024) return set_err(nullptr, DDX_E_ARG, "thread count out of range");
+    g_upload_threads.store(n);
+    return DDX_OK;
 }
 
 int ddx_upload_raw(ddx_ctx* ctx, int64_t n_cells, int32_t n_genes, const int64_t* indptr, const int32_t* indices,

@@ -96,6 +96,7 @@ struct ddx_ctx {
     std::map<const void*, bool> lds_configured;   // kernels whose dynamic-LDS limit was raised on this context's device
     std::string err;
     int64_t dev_bytes = 0;
+    bool arena_hint_forced = false;   // ddx_reserve_hint: the library's own size guesses are ignored
 
     // ---- raw (all genes) matrix, only used by the on-device prologue -------------------------
     int64_t rawN = 0;

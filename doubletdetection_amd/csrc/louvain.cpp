@@ -2,7 +2,7 @@
 // (Blondel et al. 2008) with a resolution parameter.  It stands in for the native Louvain code the
 // reference reaches through phenograph.cluster (dd.py:320-322) and sc.tl.louvain (dd.py:337-342).
 // The specification -- visiting order, tie breaking, float64 operation order -- is the pure-Python
-// text in oracle/louvain_ref.py; this file must reproduce it bit for bit (tests/test_louvain.py).
+// text in oracle/louvain_ref.py; this file must reproduce it bit for bit (tests/test_host_native.py).
 // Compiled with -ffp-contract=off so that no multiply-add is fused.
 #include <algorithm>
 #include <chrono>

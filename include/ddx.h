@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DDX_ABI_VERSION 2
+#define DDX_ABI_VERSION 3
 
 #define DDX_OK 0
 #define DDX_E_ARG -1      /* invalid argument / stage called out of order */
@@ -56,6 +56,16 @@ int ddx_synchronize(ddx_ctx* ctx);
 int ddx_check_memory(ddx_ctx* ctx);
 /* bytes of device memory currently held by the context */
 int ddx_device_bytes(const ddx_ctx* ctx, int64_t* bytes);
+/* device memory policy.  A context obtains its memory in a few large chunks sized from the matrix it receives
+ * (dd.py:149-160 has no counterpart: the reference lives in host memory).  ddx_reserve_hint overrides the size of the
+ * next chunk the context requests (0: back to the library's own guess); a request the device cannot satisfy falls back
+ * to the exact size needed.  ddx_trim forgets the results of the last fit and returns chunks to the driver until at
+ * most keep_bytes stay with the context (0: everything) -- what dd.py:200-205 does with its host intermediates. */
+int ddx_reserve_hint(ddx_ctx* ctx, int64_t bytes);
+int ddx_trim(ddx_ctx* ctx, int64_t keep_bytes);
+/* host threads that pack the raw matrix for the PCIe upload (process-wide; 0 = default min(48, cores/2); several
+ * ranks of one node should share the cores) */
+int ddx_set_upload_threads(int32_t n);
 
 /* ---- fit() prologue: dd.py:165-184 ---------------------------------------------------------
  * ddx_gene_variances replaces dd.py:167-170: float32 population variance per gene,

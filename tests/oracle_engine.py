@@ -31,7 +31,7 @@ class OracleEngine:
         self.raw, self.lib, self.normed = other.raw, other.lib, other.normed
 
     def run_iteration(self, parents, pseudocount, standard_scaling, n_components, q0, knn_k, include_self, graph_mode, gamma=None,
-                      pca_lock=None):
+                      pca_lock=None, verbose=False):
         synth = orc.create_doublets(self.raw, parents)
         aug, _, _ = orc.lognormalise(self.normed, self.lib, synth, pseudocount)
         import scipy.sparse as sp
