@@ -81,8 +81,10 @@ _SIGNATURES = {
                                       C.c_int32, C.c_int32, c_i32_p, c_f64_p, c_i32_p]),
     "ddx_leiden": (C.c_int, [C.c_int64, c_i64_p, c_i32_p, c_f64_p, C.c_double, C.c_uint64, c_i32_p]),
     "ddx_leiden_sequential": (C.c_int, [C.c_int64, c_i64_p, c_i32_p, c_f64_p, C.c_double, C.c_uint64, c_i32_p]),
-    "ddx_presweep": (C.c_int, [C.c_int64, c_i64_p, c_i32_p, c_f64_p, C.c_double, C.c_int32, c_i32_p, c_i64_p, c_i64_p, c_i32_p, c_f64_p]),
+    "ddx_presweep": (C.c_int, [C.c_int64, c_i64_p, c_i32_p, c_f64_p, C.c_double, C.c_int32, C.c_int32, c_i32_p, c_i64_p, c_i64_p, c_i32_p, c_f64_p]),
+    "ddx_refine": (C.c_int, [C.c_int64, c_i64_p, c_i32_p, c_f64_p, c_i32_p, C.c_double, C.c_int32, C.c_int32, c_i32_p]),
     "ddx_coarsen_graph": (C.c_int, [C.c_void_p, C.c_double, C.c_int32, C.c_int32]),
+    "ddx_refine_communities": (C.c_int, [C.c_void_p, c_i32_p, C.c_double, C.c_int32, c_i32_p]),
     "ddx_get_coarse_size": (C.c_int, [C.c_void_p, c_i64_p, c_i64_p]),
     "ddx_get_coarse_graph": (C.c_int, [C.c_void_p, c_i32_p, c_i64_p, c_i32_p, c_f64_p]),
     "ddx_relabel_by_size": (C.c_int, [C.c_int64, c_i32_p, C.c_int64, c_i64_p]),
@@ -174,6 +176,8 @@ def louvain(indptr, indices, weights, gamma: float, seed: int):
 
 PRESWEEPS = 6         # DDX_PRESWEEPS of include/ddx.h
 PRESWEEP_LEVELS = 2   # DDX_PRESWEEP_LEVELS
+SUBROUNDS = 4         # DDX_SUBROUNDS
+REFINE_SWEEPS = 3     # DDX_REFINE_SWEEPS
 
 
 def louvain_sequential(indptr, indices, weights, gamma: float, seed: int):
@@ -229,7 +233,21 @@ def leiden_sequential(indptr, indices, weights, gamma: float, seed: int):
     return _leiden_call("ddx_leiden_sequential", indptr, indices, weights, gamma, seed)
 
 
-def presweep(indptr, indices, weights, gamma: float, sweeps: int = PRESWEEPS):
+def refine(indptr, indices, weights, labels, gamma: float, sweeps: int = REFINE_SWEEPS, subrounds: int = SUBROUNDS):
+    """Part C on the host: refinement sweeps on the original graph from `labels`.  Returns canonical labels int32[n]."""
+    lib = load()
+    indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+    indices = np.ascontiguousarray(indices, dtype=np.int32)
+    weights = np.ascontiguousarray(weights, dtype=np.float64)
+    labels = np.ascontiguousarray(labels, dtype=np.int32)
+    n = indptr.shape[0] - 1
+    out = np.empty(n, dtype=np.int32)
+    _check(lib.ddx_refine(n, _p(indptr, c_i64_p), _p(indices, c_i32_p), _p(weights, c_f64_p), _p(labels, c_i32_p), float(gamma),
+                          int(sweeps), int(subrounds), _p(out, c_i32_p)))
+    return out
+
+
+def presweep(indptr, indices, weights, gamma: float, sweeps: int = PRESWEEPS, subrounds: int = SUBROUNDS):
     """Part A on the host.  Returns (member int32[n], c_indptr, c_indices, c_weights)."""
     lib = load()
     indptr = np.ascontiguousarray(indptr, dtype=np.int64)
@@ -243,7 +261,7 @@ def presweep(indptr, indices, weights, gamma: float, sweeps: int = PRESWEEPS):
     c_weights = np.empty(max(nnz, 1), dtype=np.float64)
     nc = C.c_int64(0)
     _check(lib.ddx_presweep(n, _p(indptr, c_i64_p), _p(indices, c_i32_p), _p(weights, c_f64_p), float(gamma), int(sweeps),
-                            _p(member, c_i32_p), C.byref(nc), _p(c_indptr, c_i64_p), _p(c_indices, c_i32_p), _p(c_weights, c_f64_p)))
+                            int(subrounds), _p(member, c_i32_p), C.byref(nc), _p(c_indptr, c_i64_p), _p(c_indices, c_i32_p), _p(c_weights, c_f64_p)))
     k = nc.value
     e = int(c_indptr[k])
     return member, c_indptr[:k + 1].copy(), c_indices[:e].copy(), c_weights[:e].copy()
@@ -541,6 +559,13 @@ class Context:
         w = np.empty(e.value, dtype=np.float64)
         self._c(self._lib.ddx_get_coarse_graph(self._h, _p(member, c_i32_p), _p(ip, c_i64_p), _p(ix, c_i32_p), _p(w, c_f64_p)))
         return member, ip, ix, w
+
+    def refine_communities(self, coarse_labels, gamma: float, sweeps: int = REFINE_SWEEPS):
+        """Part C on the device: labels of the coarse nodes (part B's result) -> final labels of the original nodes."""
+        coarse_labels = np.ascontiguousarray(coarse_labels, dtype=np.int32)
+        out = np.empty(self._embM, dtype=np.int32)
+        self._c(self._lib.ddx_refine_communities(self._h, _p(coarse_labels, c_i32_p), float(gamma), int(sweeps), _p(out, c_i32_p)))
+        return out
 
     def graph_relations(self, mode: int):
         idx = np.empty((self._embM, self._K), dtype=np.int32)

@@ -154,7 +154,13 @@ class _HipEngine:
                       graph_mode, gamma=None, pca_lock=None, verbose=False):
         """One boosting iteration on the device.  Returns the symmetric graph (indptr, indices, weights), or --
         when ``gamma`` is given -- the result of the synchronous pre-sweeps run on the device:
-        (member, coarse indptr, coarse indices, coarse weights).
+        (member, coarse indptr, coarse indices, coarse weights)."""
+        self.first_half(parents, pseudocount, standard_scaling, n_components, q0, pca_lock, verbose)
+        return self.second_half(knn_k, include_self, graph_mode, gamma, verbose)
+
+    def first_half(self, parents, pseudocount, standard_scaling, n_components, q0, pca_lock=None, verbose=False):
+        """dd.py:275-314: synthetic doublets, normalisation, optional scaling, PCA.  Touches neither the graph nor the
+        coarsening work space of the previous iteration, so that iteration's part C can still follow (``refine``).
 
         ``pca_lock`` (optional, DDX_PCA_LOCK=1): the contexts (streams) of one GPU take turns in the PCA stage.  What a
         second stream buys is that its latency-bound stages (graph construction, community pre-sweeps, sorts, the small
@@ -177,6 +183,10 @@ class _HipEngine:
         finally:
             if pca_lock is not None:
                 pca_lock.release()
+
+    def second_half(self, knn_k, include_self, graph_mode, gamma=None, verbose=False):
+        """dd.py:315-343 up to the sequential part: kNN, graph, and (``gamma`` given) part A of the community detection."""
+        c = self.ctx
         if verbose:
             print("Clustering augmented data set...\n")
         c.knn(knn_k, include_self)
@@ -189,6 +199,11 @@ class _HipEngine:
             if err.code != _lib.E_UNSUPPORTED:
                 raise
             return c.fetch_graph()
+
+    def refine(self, coarse_labels, gamma):
+        """Part C of the community detection on the device: the labels part B gave to the coarse nodes of the LAST
+        second_half -> final labels of the augmented cells.  Valid until the next second_half of this engine."""
+        return self.ctx.refine_communities(coarse_labels, gamma)
 
     def _pca(self, n_components, q0):
         c = self.ctx
@@ -473,21 +488,14 @@ class BoostClassifier:
 
     @staticmethod
     def _cluster_and_score(graph, gamma, seed, min_cluster_size, num_cells, leiden=False, q_tol=None, threads=1):
-        """Host C++: Louvain (or Leiden) -> size-sorted labels -> per-community hypergeometric test."""
+        """Host C++ on a whole graph: Louvain (or Leiden), parts A + B + C -> size-sorted labels -> per-community
+        hypergeometric test.  (The device route splits this: part A and C on the GPU around ``_part_b``.)"""
         import time
 
         t0 = time.perf_counter()
         graph = graph() if callable(graph) else graph
         t1 = time.perf_counter()
-        if len(graph) == 4:                   # pre-sweeps already done on the device: finish on the coarse graph
-            member, indptr, indices, weights = graph
-            if leiden:
-                labels = _lib.leiden_sequential(indptr, indices, weights, gamma, seed)[member]
-            elif q_tol is not None:
-                labels = _lib.louvain_best_of(indptr, indices, weights, gamma, seed, q_tol, threads=threads, presweeps=False)[0][member]
-            else:
-                labels = _lib.louvain_sequential(indptr, indices, weights, gamma, seed)[0][member]
-        elif leiden:
+        if leiden:
             labels = _lib.leiden(*graph, gamma, seed)
         elif q_tol is not None:
             labels = _lib.louvain_best_of(*graph, gamma, seed, q_tol, threads=threads)[0]
@@ -498,6 +506,30 @@ class BoostClassifier:
         scores, logp = _lib.score_communities(full, num_cells)
         t3 = time.perf_counter()
         return full, scores, logp, (t1 - t0, t2 - t1, t3 - t2)
+
+    @staticmethod
+    def _part_b(coarse, gamma, seed, leiden=False, q_tol=None, threads=1):
+        """Part B (or B') of the community detection on the coarse graph part A left: labels of the coarse nodes."""
+        import time
+
+        t0 = time.perf_counter()
+        _, indptr, indices, weights = coarse
+        if leiden:
+            labels = _lib.leiden_sequential(indptr, indices, weights, gamma, seed)
+        elif q_tol is not None:
+            labels = _lib.louvain_best_of(indptr, indices, weights, gamma, seed, q_tol, threads=threads, presweeps=False)[0]
+        else:
+            labels = _lib.louvain_sequential(indptr, indices, weights, gamma, seed)[0]
+        return labels, time.perf_counter() - t0
+
+    @staticmethod
+    def _score_labels(labels, min_cluster_size, num_cells, t_louvain):
+        import time
+
+        t0 = time.perf_counter()
+        full = _lib.relabel_by_size(labels, min_cluster_size)
+        scores, logp = _lib.score_communities(full, num_cells)
+        return full, scores, logp, (0.0, t_louvain, time.perf_counter() - t0)
 
     # ------------------------------------------------------------------------------------------
     def fit(self, raw_counts: NDArray | sp_sparse.csr_matrix) -> "BoostClassifier":
@@ -783,15 +815,39 @@ class BoostClassifier:
             pending = {}
 
             def drive(k):
+                """The iterations of lane k.  The sequential part B of iteration i runs on a host worker while the GPU
+                already works on iteration i + 1 (doublets ... PCA); part C of iteration i (refinement on the device,
+                needs B's labels) is slotted in behind that PCA, before the next graph overwrites the previous one."""
                 dev, engine = lanes[k]
+                kw = {"verbose": True} if self.verbose else {}
+                split = hasattr(engine, "first_half") and hasattr(engine, "refine")
+                waiting = None                   # (iteration, future of its part B)
+
+                def finish(item):
+                    i, fut = item
+                    coarse_labels, t_b = fut.result()
+                    labels = engine.refine(coarse_labels, gamma)
+                    pending[i] = pool.submit(self._score_labels, labels, min_cluster_size, num_cells, t_b)
+
                 for i in share[k]:
                     if self.verbose:
                         print("Iteration {:3}/{}".format(i + 1, n_iters))
-                    graph = engine.run_iteration(all_parents[i], self.pseudocount, self.standard_scaling, n_comp,
-                                                 q0, knn_k, include_self, graph_mode, gamma, pca_locks[dev],
-                                                 **({"verbose": True} if self.verbose else {}))
-                    pending[i] = pool.submit(self._cluster_and_score, graph, gamma, seed, min_cluster_size, num_cells, leiden,
-                                             q_tol, restart_threads)
+                    if split:
+                        engine.first_half(all_parents[i], self.pseudocount, self.standard_scaling, n_comp, q0, pca_locks[dev], **kw)
+                        if waiting is not None:
+                            finish(waiting)
+                            waiting = None
+                        graph = engine.second_half(knn_k, include_self, graph_mode, gamma, **kw)
+                    else:
+                        graph = engine.run_iteration(all_parents[i], self.pseudocount, self.standard_scaling, n_comp,
+                                                     q0, knn_k, include_self, graph_mode, gamma, pca_locks[dev], **kw)
+                    if split and len(graph) == 4:
+                        waiting = (i, pool.submit(self._part_b, graph, gamma, seed, leiden, q_tol, restart_threads))
+                    else:
+                        pending[i] = pool.submit(self._cluster_and_score, graph, gamma, seed, min_cluster_size, num_cells, leiden,
+                                                 q_tol, restart_threads)
+                if waiting is not None:
+                    finish(waiting)
 
             self._on_each(range(len(lanes)), drive)
             host["device_stages"] = time.perf_counter() - t_dev0

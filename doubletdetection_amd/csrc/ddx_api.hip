@@ -65,7 +65,7 @@ void context_reset(ddx_ctx* ctx) {
                       &ctx->csc_s_row, &ctx->csc_s_raw, &ctx->csc_s_x, &ctx->sort_keys_in, &ctx->sort_keys_out,
                       &ctx->sort_vals_in, &ctx->sort_vals_out, &ctx->sort_tmp, &ctx->sort_rowid, &ctx->median, &ctx->lib_sorted, &ctx->lognorm_tab,
                       &ctx->zcol, &ctx->colmean, &ctx->colstat, &ctx->col_part, &ctx->pcaA, &ctx->pcaB, &ctx->pcaSmall,
-                      &ctx->pcaPartial, &ctx->pcaVec, &ctx->pcaPanel, &ctx->pcaOp, &ctx->pcaQ0, &ctx->rowseg, &ctx->rank_buf, &ctx->lv_buf, &ctx->lv_pack, &ctx->emb32, &ctx->emb64, &ctx->sing, &ctx->knn_idx,
+                      &ctx->pcaPartial, &ctx->pcaVec, &ctx->pcaPanel, &ctx->pcaOp, &ctx->pcaQ0, &ctx->rowseg, &ctx->rank_buf, &ctx->lv_buf, &ctx->lv_pack, &ctx->graph_buf, &ctx->emb32, &ctx->emb64, &ctx->sing, &ctx->knn_idx,
                       &ctx->knn_dist, &ctx->knn_sorted, &ctx->edge_w};
     for (DevBuf* b : bufs) { b->p = nullptr; b->cap = 0; b->blk = -1; }
     ctx->arena.blocks.clear();
@@ -914,6 +914,14 @@ int ddx_coarsen_graph(ddx_ctx* ctx, double gamma, int32_t sweeps, int32_t levels
     NEED(ctx->g_nodes >= 0, "no graph: call ddx_build_graph first");
     NEED(sweeps >= 0 && levels >= 1, "sweeps must be >= 0 and levels >= 1");
     return stage_coarsen_graph(ctx, gamma, sweeps, levels);
+}
+
+int ddx_refine_communities(ddx_ctx* ctx, const int32_t* coarse_labels, double gamma, int32_t sweeps, int32_t* labels_out) {
+    REQUIRE_CTX(ctx);
+    USE_DEVICE(ctx);
+    NEED(ctx->g_nodes >= 0 && ctx->c_nodes >= 0, "no graph / coarse graph on the device: ddx_build_graph and ddx_coarsen_graph come first");
+    NEED(coarse_labels && labels_out && sweeps >= 0, "bad arguments");
+    return stage_refine_communities(ctx, coarse_labels, gamma, sweeps, labels_out);
 }
 
 int ddx_get_coarse_size(ddx_ctx* ctx, int64_t* n_coarse, int64_t* n_entries) {

@@ -186,7 +186,8 @@ struct ddx_ctx {
     const unsigned long long* knn_window_total = nullptr;   // device counter: (query block, candidate tile) pairs screened by the emit pass
     double knn_window_pairs = 0.0;                          // the same count without pruning
 
-    // graph: symmetric CSR left on the device by ddx_build_graph (views into pcaPanel)
+    // graph: symmetric CSR left on the device by ddx_build_graph (views into graph_buf)
+    ddx::DevBuf graph_buf;
     int64_t g_nodes = -1, g_entries = 0;
     const int64_t* g_d_indptr = nullptr;
     const int32_t* g_d_cols = nullptr;
@@ -198,6 +199,14 @@ struct ddx_ctx {
     size_t lv_host_cap = 0;
     bool lv_host_valid = false;
     int64_t c_nodes = -1, c_entries = 0;
+    // what part C needs of the levels of part A: graph of level l (l = 0: the graph above) and member table V_l -> V_{l+1}
+    static constexpr int kLvKeep = 2;
+    int lv_levels = 0;
+    int64_t lv_n[kLvKeep] = {0, 0}, lv_E[kLvKeep] = {0, 0};
+    const int64_t* lv_indptr[kLvKeep] = {nullptr, nullptr};
+    const int32_t* lv_cols[kLvKeep] = {nullptr, nullptr};
+    const double* lv_w[kLvKeep] = {nullptr, nullptr};
+    const int32_t* lv_member[kLvKeep] = {nullptr, nullptr};
     const int32_t* c_d_member = nullptr;
     const int64_t* c_d_indptr = nullptr;
     const int32_t* c_d_cols = nullptr;
@@ -270,6 +279,7 @@ void assemble_graph(int64_t M, int K, const int32_t* idx, const double* w, std::
 int validate_csr(ddx_ctx* ctx, const int64_t* indptr, const int32_t* cols, const float* vals, int64_t N, int32_t G);
 int stage_rankings(ddx_ctx* ctx);
 int stage_coarsen_graph(ddx_ctx* ctx, double gamma, int32_t sweeps, int32_t levels);
+int stage_refine_communities(ddx_ctx* ctx, const int32_t* coarse_labels, double gamma, int32_t sweeps, int32_t* labels_out);
 int stage_gene_variances(ddx_ctx* ctx, float* var_out);
 int stage_select_columns(ddx_ctx* ctx, const int64_t* cols, int32_t n_cols);
 

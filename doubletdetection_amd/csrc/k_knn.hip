@@ -1248,15 +1248,18 @@ int stage_build_graph(ddx_ctx* ctx, int32_t mode) {
     const int K = ctx->K;
     const int64_t n = M * K;
     DDX_TRY(graph_weights_device(ctx, mode));
-    // workspace carved from the PCA panel buffer: offs i64[n+1] | keys u64[2n] x2 | vals f64[2n] x2 | indptr i64[M+1] | cols i32[2n] | cnt i32[n+1]
+    // workspace of its own (not the PCA panel buffer: the graph of iteration i must outlive the PCA of iteration i + 1, whose
+    // operator products run while the host finishes part B of iteration i -- part C then needs the graph again): offs i64[n+1] | keys u64[2n] x2 | vals f64[2n] x2 | indptr i64[M+1] | cols i32[2n] | cnt i32[n+1]
     // (sized by the same arithmetic that carves it: every piece is rounded up to 256 bytes)
     size_t bytes = 0;
     auto piece = [&](size_t sz) { const size_t o = bytes; bytes += (sz + 255) & ~(size_t)255; return o; };
     const size_t o_offs = piece(sizeof(int64_t) * (n + 1)), o_ka = piece(sizeof(uint64_t) * 2 * n), o_kb = piece(sizeof(uint64_t) * 2 * n);
     const size_t o_va = piece(sizeof(double) * 2 * n), o_vb = piece(sizeof(double) * 2 * n), o_ip = piece(sizeof(int64_t) * (M + 1));
     const size_t o_cols = piece(sizeof(int32_t) * 2 * n), o_cnt = piece(sizeof(int32_t) * (n + 1));
-    DDX_TRY(ensure(ctx, ctx->pcaPanel, bytes));
-    unsigned char* base = ctx->pcaPanel.as<unsigned char>();
+    ctx->g_nodes = -1;
+    ctx->c_nodes = -1;
+    DDX_TRY(ensure(ctx, ctx->graph_buf, bytes));
+    unsigned char* base = ctx->graph_buf.as<unsigned char>();
     int64_t* offs = reinterpret_cast<int64_t*>(base + o_offs);
     uint64_t* keys_a = reinterpret_cast<uint64_t*>(base + o_ka);
     uint64_t* keys_b = reinterpret_cast<uint64_t*>(base + o_kb);

@@ -1,9 +1,11 @@
-// Part A of the community-detection specification (oracle/louvain_ref.py:presweep) on the GPU: synchronous
-// sweeps of the local-moving step on integer-quantised weights, then an exact aggregation of the communities.
-// It is applied to the symmetric CSR that ddx_build_graph left on the device; the host only sees the aggregated
-// graph (a few thousand super-nodes) and finishes with the sequential multi-level optimisation
-// (ddx_louvain_sequential).  This replaces the Louvain stage inside phenograph.cluster / sc.tl.louvain
-// (dd.py:320-322, 337-342) together with louvain.cpp.
+// Parts A and C of the community-detection specification (oracle/louvain_ref.py:presweep, refine) on the GPU:
+// synchronous sub-round sweeps of the local-moving step on integer-quantised weights, followed (part A) by an exact
+// aggregation of the communities or started (part C) from the partition the sequential levels found.
+// Part A is applied to the symmetric CSR that ddx_build_graph left on the device; the host only sees the aggregated
+// graph (a few thousand super-nodes), runs the sequential multi-level optimisation on it (ddx_louvain_sequential) and
+// hands the labels of the super-nodes back for part C (ddx_refine_communities), which returns the final labels.
+// This replaces the Louvain stage inside phenograph.cluster / sc.tl.louvain (dd.py:320-322, 337-342) together with
+// louvain.cpp.
 //
 // Why it is exact and order-free: edge weights are rounded once to multiples of 2^-20 and every sum (node strength,
 // community total, node-to-community weight, aggregated edge weight) is an int64 sum -- atomics and sorts may
@@ -31,15 +33,15 @@ __global__ void k_lv_quantise(const double* __restrict__ w, int64_t E, int64_t* 
 
 // strength of every node (self loops included), identity communities, 2m, largest degree
 __global__ void k_lv_strength(const int64_t* __restrict__ indptr, const int64_t* __restrict__ wq, int64_t n, int64_t* __restrict__ K,
-                              int32_t* __restrict__ comm, unsigned long long* __restrict__ m2, int32_t* __restrict__ maxdeg,
-                              int32_t* __restrict__ nbig, int32_t* __restrict__ big_list) {
+                              int32_t* __restrict__ comm /* null: leave the partition alone */, unsigned long long* __restrict__ m2,
+                              int32_t* __restrict__ maxdeg, int32_t* __restrict__ nbig, int32_t* __restrict__ big_list) {
     const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= n) return;
     int64_t s = 0;
     const int64_t b = indptr[v], e = indptr[v + 1];
     for (int64_t p = b; p < e; ++p) s += wq[p];
     K[v] = s;
-    comm[v] = (int32_t)v;
+    if (comm) comm[v] = (int32_t)v;
     atomicAdd(m2, (unsigned long long)s);
     atomicMax(maxdeg, (int32_t)(e - b));
     if (e - b > 64) big_list[atomicAdd(nbig, 1)] = (int32_t)v;     // handled by the LDS variant of the sweep (any order)
@@ -78,7 +80,8 @@ __global__ void __launch_bounds__(256) k_lv_sweep(const int64_t* __restrict__ in
                                                   const int32_t* __restrict__ comm, const unsigned long long* __restrict__ tot,
                                                   const int32_t* __restrict__ size, int64_t n, double gamma, double m2d,
                                                   const int32_t* __restrict__ big_list, int32_t* __restrict__ next,
-                                                  unsigned long long* __restrict__ tot_clear, int32_t* __restrict__ size_clear) {
+                                                  unsigned long long* __restrict__ tot_clear, int32_t* __restrict__ size_clear,
+                                                  int cls_shift /* sweep number */, int cls_mod /* sub-rounds */, int cls_now /* this sub-round */) {
     __shared__ int32_t cS[1][BIG ? kLvCap : 1];
     __shared__ int64_t wS[1][BIG ? kLvCap : 1];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -92,6 +95,11 @@ __global__ void __launch_bounds__(256) k_lv_sweep(const int64_t* __restrict__ in
     const int deg = (int)(indptr[v + 1] - b);
     if (!BIG && deg > 64) return;
     const int32_t own = comm[v];
+    // sub-rounds: only the nodes of this sub-round's class decide, everybody else stays where it is
+    if ((int)(((((uint32_t)v * 2654435761u) >> 16) + (uint32_t)cls_shift) % (uint32_t)cls_mod) != cls_now) {
+        if (lane == 0) next[v] = own;
+        return;
+    }
     const int64_t kvi = K[v];
     const double kv = (double)kvi;
     double best_s = 0.0;
@@ -239,6 +247,40 @@ struct LvScratch {          // sized for the finest level, reused by the coarser
     int32_t *comm, *next, *size, *size2, *used, *renum, *big_list;
 };
 
+constexpr int kSubrounds = DDX_SUBROUNDS;
+
+// `sweeps` sweeps of `subrounds` synchronous sub-rounds from the partition in sc.comm; `cur` receives the array
+// (sc.comm or sc.next) that holds the result.  Every sub-round recomputes the community totals from scratch: they
+// ping-pong between two pairs of arrays, sub-round t reads pair t & 1 and clears the other one for sub-round t + 1
+// (tot | tot2 and size | size2 are adjacent pieces of the scratch buffer: one memset each clears both before the first).
+static int lv_sweeps(ddx_ctx* ctx, const LvGraph& in, double gamma, int32_t sweeps, int subrounds, const LvScratch& sc, int64_t m2,
+                     int32_t nbig, int32_t*& cur) {
+    const int64_t n = in.n;
+    hipStream_t st = ctx->stream;
+    cur = sc.comm;
+    int32_t* nxt = sc.next;
+    if (sweeps <= 0 || m2 <= 0) return DDX_OK;
+    DDX_HIP(ctx, hipMemsetAsync(sc.tot, 0, (size_t)(reinterpret_cast<unsigned char*>(sc.tot2) - reinterpret_cast<unsigned char*>(sc.tot)) + sizeof(int64_t) * n, st));
+    DDX_HIP(ctx, hipMemsetAsync(sc.size, 0, (size_t)(reinterpret_cast<unsigned char*>(sc.size2) - reinterpret_cast<unsigned char*>(sc.size)) + sizeof(int32_t) * n, st));
+    int t = 0;
+    for (int s = 0; s < sweeps; ++s) {
+        for (int r = 0; r < subrounds; ++r, ++t) {
+            unsigned long long* tot = (t & 1) ? sc.tot2 : sc.tot;
+            unsigned long long* tot_other = (t & 1) ? sc.tot : sc.tot2;
+            int32_t* size = (t & 1) ? sc.size2 : sc.size;
+            int32_t* size_other = (t & 1) ? sc.size : sc.size2;
+            k_lv_totals<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(cur, sc.K, n, tot, size);
+            k_lv_sweep<false><<<(unsigned)ceil_div(n, 4), 256, 0, st>>>(in.indptr, in.cols, sc.wq, sc.K, cur, tot, size, n, gamma, (double)m2, sc.big_list, nxt,
+                                                                        tot_other, size_other, s, subrounds, r);
+            if (nbig > 0)
+                k_lv_sweep<true><<<(unsigned)nbig, 64, 0, st>>>(in.indptr, in.cols, sc.wq, sc.K, cur, tot, size, nbig, gamma, (double)m2, sc.big_list, nxt,
+                                                                nullptr, nullptr, s, subrounds, r);
+            std::swap(cur, nxt);      // a sweep that moves nothing reproduces its input, so running all of them equals stopping early
+        }
+    }
+    return DDX_OK;
+}
+
 // one level: `sweeps` synchronous sweeps on `in`, exact aggregation into (member, out)
 static int coarsen_level(ddx_ctx* ctx, const LvGraph& in, double gamma, int32_t sweeps, const LvScratch& sc, int32_t* member,
                          int64_t* c_indptr, int32_t* c_cols, double* c_w, LvGraph& out) {
@@ -256,26 +298,7 @@ static int coarsen_level(ddx_ctx* ctx, const LvGraph& in, double gamma, int32_t 
     const int32_t nbig = (int32_t)(h_scal[1] >> 32);
     if (maxdeg > kLvCap) return set_err(ctx, DDX_E_UNSUPPORTED, "a node with %d neighbours exceeds the device sweep's capacity (%d)", maxdeg, kLvCap);
     int32_t* cur = sc.comm;
-    int32_t* nxt = sc.next;
-    // community totals ping-pong between two pairs of arrays: sweep s reads pair s & 1 and clears the other one for sweep s + 1
-    // (tot | tot2 and size | size2 are adjacent pieces of the scratch buffer: one memset each clears both before the first sweep)
-    if (sweeps > 0 && m2 > 0) {
-        DDX_HIP(ctx, hipMemsetAsync(sc.tot, 0, (size_t)(reinterpret_cast<unsigned char*>(sc.tot2) - reinterpret_cast<unsigned char*>(sc.tot)) + sizeof(int64_t) * n, st));
-        DDX_HIP(ctx, hipMemsetAsync(sc.size, 0, (size_t)(reinterpret_cast<unsigned char*>(sc.size2) - reinterpret_cast<unsigned char*>(sc.size)) + sizeof(int32_t) * n, st));
-    }
-    for (int s = 0; s < sweeps && m2 > 0; ++s) {
-        unsigned long long* tot = (s & 1) ? sc.tot2 : sc.tot;
-        unsigned long long* tot_other = (s & 1) ? sc.tot : sc.tot2;
-        int32_t* size = (s & 1) ? sc.size2 : sc.size;
-        int32_t* size_other = (s & 1) ? sc.size : sc.size2;
-        k_lv_totals<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(cur, sc.K, n, tot, size);
-        k_lv_sweep<false><<<(unsigned)ceil_div(n, 4), 256, 0, st>>>(in.indptr, in.cols, sc.wq, sc.K, cur, tot, size, n, gamma, (double)m2, sc.big_list, nxt,
-                                                                    tot_other, size_other);
-        if (nbig > 0)
-            k_lv_sweep<true><<<(unsigned)nbig, 64, 0, st>>>(in.indptr, in.cols, sc.wq, sc.K, cur, tot, size, nbig, gamma, (double)m2, sc.big_list, nxt,
-                                                            nullptr, nullptr);
-        std::swap(cur, nxt);      // a sweep that moves nothing reproduces its input, so running all of them equals stopping early
-    }
+    DDX_TRY(lv_sweeps(ctx, in, gamma, sweeps, kSubrounds, sc, m2, nbig, cur));
     // renumber the surviving communities by ascending id
     DDX_HIP(ctx, hipMemsetAsync(sc.used, 0, sizeof(int32_t) * (n + 1), st));
     k_lv_used<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(cur, n, sc.used);
@@ -327,68 +350,75 @@ __global__ void k_lv_pack(const double* __restrict__ w, const int64_t* __restric
     if (t < n) om[t] = member[t];
 }
 
+struct LvSets {             // two output sets the levels write alternately + the composed member tables
+    int32_t* member[2];
+    int64_t* indptr[2];
+    int32_t* cols[2];
+    double* w[2];
+    int32_t *total_a, *total_b;
+};
+
+// Layout of the work buffer for a graph of n nodes / E entries: scratch (wq, keys x2, vals, sums: E each; K, tot x2: n;
+// comm, next, size x2, used, renum, big_list: n) + the output sets.  Every piece is rounded up to 256 bytes; the buffer
+// is sized from the very arithmetic that carves it.  Returns the bytes needed; binds the pointers when base != null.
+static size_t lv_bind(unsigned char* base, int64_t n, int64_t E, LvScratch& sc, LvSets& o) {
+    size_t bytes = 0;
+    auto piece = [&](size_t sz) { const size_t at = bytes; bytes += (sz + 255) & ~(size_t)255; return base ? base + at : nullptr; };
+    sc.wq = reinterpret_cast<int64_t*>(piece(sizeof(int64_t) * E));
+    sc.keys_a = reinterpret_cast<uint64_t*>(piece(sizeof(uint64_t) * E));
+    sc.keys_b = reinterpret_cast<uint64_t*>(piece(sizeof(uint64_t) * E));
+    sc.vals_b = reinterpret_cast<int64_t*>(piece(sizeof(int64_t) * E));
+    sc.sums = reinterpret_cast<int64_t*>(piece(sizeof(int64_t) * E));
+    sc.K = reinterpret_cast<int64_t*>(piece(sizeof(int64_t) * n));
+    sc.tot = reinterpret_cast<unsigned long long*>(piece(sizeof(int64_t) * n));
+    sc.tot2 = reinterpret_cast<unsigned long long*>(piece(sizeof(int64_t) * n));
+    sc.comm = reinterpret_cast<int32_t*>(piece(sizeof(int32_t) * n));
+    sc.next = reinterpret_cast<int32_t*>(piece(sizeof(int32_t) * n));
+    sc.size = reinterpret_cast<int32_t*>(piece(sizeof(int32_t) * n));
+    sc.size2 = reinterpret_cast<int32_t*>(piece(sizeof(int32_t) * n));
+    sc.used = reinterpret_cast<int32_t*>(piece(sizeof(int32_t) * (n + 1)));
+    sc.renum = reinterpret_cast<int32_t*>(piece(sizeof(int32_t) * (n + 1)));
+    sc.big_list = reinterpret_cast<int32_t*>(piece(sizeof(int32_t) * n));
+    sc.scal = reinterpret_cast<unsigned long long*>(piece(256));        // [0] = 2m, [1] = max degree | #big nodes, [2] = runs
+    for (int i = 0; i < 2; ++i) {
+        o.member[i] = reinterpret_cast<int32_t*>(piece(sizeof(int32_t) * n));
+        o.indptr[i] = reinterpret_cast<int64_t*>(piece(sizeof(int64_t) * (n + 1)));
+        o.cols[i] = reinterpret_cast<int32_t*>(piece(sizeof(int32_t) * E));
+        o.w[i] = reinterpret_cast<double*>(piece(sizeof(double) * E));
+    }
+    o.total_a = reinterpret_cast<int32_t*>(piece(sizeof(int32_t) * n));
+    o.total_b = reinterpret_cast<int32_t*>(piece(sizeof(int32_t) * n));
+    return bytes;
+}
+
 int stage_coarsen_graph(ddx_ctx* ctx, double gamma, int32_t sweeps, int32_t levels) {
     const int64_t n = ctx->g_nodes;
     const int64_t E = ctx->g_entries;
     ctx->c_nodes = -1;
     ctx->lv_host_valid = false;
-    // scratch (wq, keys x2, vals, sums: E each; K, tot: n; comm, next, size, used, renum, big_list: n) + two output sets
-    // (member i32[n], indptr i64[n+1], cols i32[E], w f64[E]) that the levels write alternately + the composed member tables.
-    // The layout is computed first (every piece rounded up to 256 bytes) and the buffer sized from it.
-    size_t bytes = 0;
-    auto piece = [&](size_t sz) { const size_t o = bytes; bytes += (sz + 255) & ~(size_t)255; return o; };
-    const size_t o_wq = piece(sizeof(int64_t) * E), o_ka = piece(sizeof(uint64_t) * E), o_kb = piece(sizeof(uint64_t) * E);
-    const size_t o_vb = piece(sizeof(int64_t) * E), o_sums = piece(sizeof(int64_t) * E);
-    const size_t o_K = piece(sizeof(int64_t) * n), o_tot = piece(sizeof(int64_t) * n), o_tot2 = piece(sizeof(int64_t) * n);
-    const size_t o_comm = piece(sizeof(int32_t) * n), o_next = piece(sizeof(int32_t) * n), o_size = piece(sizeof(int32_t) * n), o_size2 = piece(sizeof(int32_t) * n);
-    const size_t o_used = piece(sizeof(int32_t) * (n + 1)), o_renum = piece(sizeof(int32_t) * (n + 1)), o_big = piece(sizeof(int32_t) * n);
-    const size_t o_scal = piece(256);
-    size_t o_member[2], o_indptr[2], o_cols[2], o_w[2];
-    for (int i = 0; i < 2; ++i) {
-        o_member[i] = piece(sizeof(int32_t) * n);
-        o_indptr[i] = piece(sizeof(int64_t) * (n + 1));
-        o_cols[i] = piece(sizeof(int32_t) * E);
-        o_w[i] = piece(sizeof(double) * E);
-    }
-    const size_t o_ta = piece(sizeof(int32_t) * n), o_tb = piece(sizeof(int32_t) * n);
-    DDX_TRY(ensure(ctx, ctx->lv_buf, bytes));
-    unsigned char* base = ctx->lv_buf.as<unsigned char>();
     LvScratch sc;
-    sc.wq = reinterpret_cast<int64_t*>(base + o_wq);
-    sc.keys_a = reinterpret_cast<uint64_t*>(base + o_ka);
-    sc.keys_b = reinterpret_cast<uint64_t*>(base + o_kb);
-    sc.vals_b = reinterpret_cast<int64_t*>(base + o_vb);
-    sc.sums = reinterpret_cast<int64_t*>(base + o_sums);
-    sc.K = reinterpret_cast<int64_t*>(base + o_K);
-    sc.tot = reinterpret_cast<unsigned long long*>(base + o_tot);
-    sc.tot2 = reinterpret_cast<unsigned long long*>(base + o_tot2);
-    sc.comm = reinterpret_cast<int32_t*>(base + o_comm);
-    sc.next = reinterpret_cast<int32_t*>(base + o_next);
-    sc.size = reinterpret_cast<int32_t*>(base + o_size);
-    sc.size2 = reinterpret_cast<int32_t*>(base + o_size2);
-    sc.used = reinterpret_cast<int32_t*>(base + o_used);
-    sc.renum = reinterpret_cast<int32_t*>(base + o_renum);
-    sc.big_list = reinterpret_cast<int32_t*>(base + o_big);
-    sc.scal = reinterpret_cast<unsigned long long*>(base + o_scal);   // [0] = 2m, [1] = max degree | #big nodes, [2] = runs
-    int32_t* member_set[2];
-    int64_t* indptr_set[2];
-    int32_t* cols_set[2];
-    double* w_set[2];
-    for (int i = 0; i < 2; ++i) {
-        member_set[i] = reinterpret_cast<int32_t*>(base + o_member[i]);
-        indptr_set[i] = reinterpret_cast<int64_t*>(base + o_indptr[i]);
-        cols_set[i] = reinterpret_cast<int32_t*>(base + o_cols[i]);
-        w_set[i] = reinterpret_cast<double*>(base + o_w[i]);
-    }
-    int32_t* total_a = reinterpret_cast<int32_t*>(base + o_ta);
-    int32_t* total_b = reinterpret_cast<int32_t*>(base + o_tb);
+    LvSets sets;
+    DDX_TRY(ensure(ctx, ctx->lv_buf, lv_bind(nullptr, n, E, sc, sets)));
+    lv_bind(ctx->lv_buf.as<unsigned char>(), n, E, sc, sets);
+    int32_t** member_set = sets.member;
+    int64_t** indptr_set = sets.indptr;
+    int32_t** cols_set = sets.cols;
+    double** w_set = sets.w;
+    int32_t* total_a = sets.total_a;
+    int32_t* total_b = sets.total_b;
     ScopedTimer t(ctx, "graph_coarsen");
     LvGraph cur;
     cur.n = n; cur.E = E; cur.indptr = ctx->g_d_indptr; cur.cols = ctx->g_d_cols; cur.w = ctx->g_d_vals;
     const int32_t* total = nullptr;          // member of every original node in the current coarse graph
+    ctx->lv_levels = levels;
     for (int lvl = 0; lvl < levels; ++lvl) {
         const int o = lvl & 1;
         LvGraph nextg;
+        if (lvl < ddx_ctx::kLvKeep) {           // (two output sets: the graphs of levels 0 and 1 survive two levels of part A)
+            ctx->lv_n[lvl] = cur.n; ctx->lv_E[lvl] = cur.E;
+            ctx->lv_indptr[lvl] = cur.indptr; ctx->lv_cols[lvl] = cur.cols; ctx->lv_w[lvl] = cur.w;
+            ctx->lv_member[lvl] = member_set[o];
+        }
         DDX_TRY(coarsen_level(ctx, cur, gamma, sweeps, sc, member_set[o], indptr_set[o], cols_set[o], w_set[o], nextg));
         if (!total) {
             total = member_set[o];
@@ -422,6 +452,69 @@ int stage_coarsen_graph(ddx_ctx* ctx, double gamma, int32_t sweeps, int32_t leve
     DDX_HIP(ctx, hipMemcpyAsync(ctx->lv_host, ctx->lv_pack.p, packed, hipMemcpyDeviceToHost, ctx->stream));
     DDX_HIP(ctx, hipGetLastError());
     ctx->lv_host_valid = true;
+    return DDX_OK;
+}
+
+// ---- part C on the device ----------------------------------------------------------------------------------------------
+// lab[v] = coarse_labels[member[v]]; first[l] = smallest v carrying label l
+__global__ void k_lv_project(const int32_t* __restrict__ member, const int32_t* __restrict__ coarse_labels, int64_t n, int32_t* __restrict__ lab,
+                             int32_t* __restrict__ first) {
+    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    const int32_t l = coarse_labels[member[v]];
+    lab[v] = l;
+    atomicMin(first + l, (int32_t)v);
+}
+
+__global__ void k_lv_name(const int32_t* __restrict__ lab, const int32_t* __restrict__ first, int64_t n, int32_t* __restrict__ comm) {
+    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < n) comm[v] = first[lab[v]];
+}
+
+int stage_refine_communities(ddx_ctx* ctx, const int32_t* coarse_labels, double gamma, int32_t sweeps, int32_t* labels_out) {
+    const int64_t n = ctx->g_nodes, E = ctx->g_entries, nc = ctx->c_nodes;
+    hipStream_t st = ctx->stream;
+    LvScratch sc;
+    LvSets sets;
+    if (lv_bind(nullptr, n, E, sc, sets) > ctx->lv_buf.cap) return set_err(ctx, DDX_E_ARG, "the coarsening work space is gone");
+    if (ctx->lv_levels < 1 || ctx->lv_levels > ddx_ctx::kLvKeep)
+        return set_err(ctx, DDX_E_UNSUPPORTED, "part C on the device follows at most %d levels of part A (%d were run)", ddx_ctx::kLvKeep, ctx->lv_levels);
+    lv_bind(ctx->lv_buf.as<unsigned char>(), n, E, sc, sets);
+    for (int64_t c = 0; c < nc; ++c)
+        if (coarse_labels[c] < 0 || coarse_labels[c] >= nc) return set_err(ctx, DDX_E_ARG, "coarse label %d out of range at %lld", coarse_labels[c], (long long)c);
+    ScopedTimer t(ctx, "graph_refine");
+    // the scratch of part A is free again: labels of the level above -> renum, smallest member per label -> used
+    DDX_HIP(ctx, hipMemcpyAsync(sc.renum, coarse_labels, sizeof(int32_t) * nc, hipMemcpyHostToDevice, st));
+    for (int level = ctx->lv_levels - 1; level >= 0; --level) {
+        LvGraph g;
+        g.n = ctx->lv_n[level]; g.E = ctx->lv_E[level]; g.indptr = ctx->lv_indptr[level]; g.cols = ctx->lv_cols[level]; g.w = ctx->lv_w[level];
+        DDX_HIP(ctx, hipMemsetAsync(sc.used, 0x7f, sizeof(int32_t) * (g.n + 1), st));
+        DDX_HIP(ctx, hipMemsetAsync(sc.scal, 0, 256, st));
+        k_lv_project<<<(unsigned)ceil_div(g.n, 256), 256, 0, st>>>(ctx->lv_member[level], sc.renum, g.n, sc.next, sc.used);
+        k_lv_name<<<(unsigned)ceil_div(g.n, 256), 256, 0, st>>>(sc.next, sc.used, g.n, sc.comm);
+        if (g.E > 0) k_lv_quantise<<<(unsigned)ceil_div(g.E, 256), 256, 0, st>>>(g.w, g.E, sc.wq);
+        k_lv_strength<<<(unsigned)ceil_div(g.n, 256), 256, 0, st>>>(g.indptr, sc.wq, g.n, sc.K, nullptr, sc.scal, reinterpret_cast<int32_t*>(sc.scal + 1),
+                                                                    reinterpret_cast<int32_t*>(sc.scal + 1) + 1, sc.big_list);
+        unsigned long long h_scal[2] = {0, 0};
+        DDX_HIP(ctx, hipMemcpyAsync(h_scal, sc.scal, sizeof(h_scal), hipMemcpyDeviceToHost, st));
+        DDX_HIP(ctx, hipStreamSynchronize(st));
+        const int64_t m2 = (int64_t)h_scal[0];
+        const int32_t nbig = (int32_t)(h_scal[1] >> 32);
+        int32_t* cur = sc.comm;
+        DDX_TRY(lv_sweeps(ctx, g, gamma, sweeps, kSubrounds, sc, m2, nbig, cur));
+        if (level > 0) DDX_HIP(ctx, hipMemcpyAsync(sc.renum, cur, sizeof(int32_t) * g.n, hipMemcpyDeviceToDevice, st));      // names of this level's communities are its node ids
+        else DDX_HIP(ctx, hipMemcpyAsync(labels_out, cur, sizeof(int32_t) * g.n, hipMemcpyDeviceToHost, st));
+    }
+    DDX_HIP(ctx, hipStreamSynchronize(st));
+    DDX_HIP(ctx, hipGetLastError());
+    // canonical numbering: by ascending smallest member = order of first appearance
+    std::vector<int32_t> rank((size_t)n, -1);
+    int32_t k = 0;
+    for (int64_t v = 0; v < n; ++v) {
+        int32_t& r = rank[labels_out[v]];
+        if (r < 0) r = k++;
+        labels_out[v] = r;
+    }
     return DDX_OK;
 }
 

@@ -1198,7 +1198,6 @@ static int pca_work_init(ddx_ctx* ctx, int L, PcaWork& w) {
 // exact-PCA regimes, where the Gram matrix is formed column block by column block.
 int stage_operator_apply(ddx_ctx* ctx, int32_t mode, const double* X, int32_t n, double* out) {
     t_opt = &ctx->opt;
-    ctx->g_nodes = -1;
     const int64_t M = ctx->M;
     const int32_t H = ctx->H;
     PcaWork w;
@@ -1230,7 +1229,6 @@ int stage_operator_apply(ddx_ctx* ctx, int32_t mode, const double* X, int32_t n,
 
 int stage_pca(ddx_ctx* ctx, int32_t C, int32_t oversample, int32_t n_iter, const double* q0, int64_t q0_rows) {
     t_opt = &ctx->opt;
-    ctx->g_nodes = -1;   // a graph left on the device lives in the panel buffer this stage overwrites
     const int L = C + oversample;
     if (L > kMaxL) return set_err(ctx, DDX_E_UNSUPPORTED, "sketch width %d exceeds %d", L, kMaxL);
     const int64_t M = ctx->M;

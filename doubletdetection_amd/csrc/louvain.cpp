@@ -225,69 +225,118 @@ void aggregate(const Graph& g, const std::vector<int32_t>& comm, Graph& out, std
 // ------------------------------------------------------------------------------------------------
 constexpr double kWeightScale = 1048576.0;   // 2^20
 
-void presweep(const Graph& g, double gamma, int sweeps, std::vector<int32_t>& member, Graph& coarse) {
+inline int node_class(int64_t v) { return (int)(((uint32_t)v * 2654435761u) >> 16); }
+
+void quantise(const Graph& g, std::vector<int64_t>& wq, std::vector<int64_t>& K, int64_t& m2) {
     const int64_t n = g.n();
     const int64_t nnz = (int64_t)g.indices.size();
-    std::vector<int64_t> wq(nnz);
+    wq.resize(nnz);
     for (int64_t e = 0; e < nnz; ++e) wq[e] = (int64_t)std::nearbyint(g.weights[e] * kWeightScale);
-    std::vector<int64_t> K(n, 0);
-    int64_t m2 = 0;
+    K.assign(n, 0);
+    m2 = 0;
     for (int64_t v = 0; v < n; ++v) {
         int64_t s = 0;
         for (int64_t e = g.indptr[v]; e < g.indptr[v + 1]; ++e) s += wq[e];
         K[v] = s;
         m2 += s;
     }
-    std::vector<int32_t> comm(n), next(n);
-    for (int64_t v = 0; v < n; ++v) comm[v] = (int32_t)v;
+}
+
+// `sweeps` sweeps of `subrounds` synchronous sub-rounds from the partition in comm (oracle/louvain_ref.py:_sync_sweeps):
+// in sub-round r of sweep s the nodes with (node_class(v) + s) % subrounds == r decide at once, the others stay.
+void sync_sweeps(const Graph& g, const std::vector<int64_t>& wq, const std::vector<int64_t>& K, int64_t m2, double gamma, int sweeps,
+                 int subrounds, std::vector<int32_t>& comm) {
+    const int64_t n = g.n();
+    if (subrounds < 1) subrounds = 1;
+    std::vector<int32_t> next(n);
     std::vector<int64_t> tot(n), acc(n, -1);
     std::vector<int32_t> size(n), seen;
     for (int sweep = 0; sweep < sweeps && m2 > 0; ++sweep) {
-        std::fill(tot.begin(), tot.end(), 0);
-        std::fill(size.begin(), size.end(), 0);
-        for (int64_t v = 0; v < n; ++v) {
-            tot[comm[v]] += K[v];
-            size[comm[v]]++;
-        }
         int64_t moves = 0;
-        const double m2d = (double)m2;
-        for (int64_t v = 0; v < n; ++v) {
-            const int32_t own = comm[v];
-            seen.clear();
-            for (int64_t e = g.indptr[v]; e < g.indptr[v + 1]; ++e) {
-                const int32_t u = g.indices[e];
-                if (u == v) continue;
-                const int32_t c = comm[u];
-                if (acc[c] < 0) {
-                    acc[c] = 0;
-                    seen.push_back(c);
+        for (int r = 0; r < subrounds; ++r) {
+            std::fill(tot.begin(), tot.end(), 0);
+            std::fill(size.begin(), size.end(), 0);
+            for (int64_t v = 0; v < n; ++v) {
+                tot[comm[v]] += K[v];
+                size[comm[v]]++;
+            }
+            const double m2d = (double)m2;
+            for (int64_t v = 0; v < n; ++v) {
+                const int32_t own = comm[v];
+                next[v] = own;
+                if ((node_class(v) + sweep) % subrounds != r) continue;
+                seen.clear();
+                for (int64_t e = g.indptr[v]; e < g.indptr[v + 1]; ++e) {
+                    const int32_t u = g.indices[e];
+                    if (u == v) continue;
+                    const int32_t c = comm[u];
+                    if (acc[c] < 0) {
+                        acc[c] = 0;
+                        seen.push_back(c);
+                    }
+                    acc[c] += wq[e];
                 }
-                acc[c] += wq[e];
-            }
-            const double kv = (double)K[v];
-            const int64_t w_own = acc[own] < 0 ? 0 : acc[own];
-            const double own_score = (double)w_own * m2d - (gamma * (double)(tot[own] - K[v])) * kv;
-            int32_t best = -1;
-            double best_score = 0.0;
-            for (int32_t c : seen) {
-                if (c == own) continue;
-                const double sc = (double)acc[c] * m2d - (gamma * (double)tot[c]) * kv;
-                if (best < 0 || sc > best_score || (sc == best_score && c < best)) {
-                    best = c;
-                    best_score = sc;
+                const double kv = (double)K[v];
+                const int64_t w_own = acc[own] < 0 ? 0 : acc[own];
+                const double own_score = (double)w_own * m2d - (gamma * (double)(tot[own] - K[v])) * kv;
+                int32_t best = -1;
+                double best_score = 0.0;
+                for (int32_t c : seen) {
+                    if (c == own) continue;
+                    const double sc = (double)acc[c] * m2d - (gamma * (double)tot[c]) * kv;
+                    if (best < 0 || sc > best_score || (sc == best_score && c < best)) {
+                        best = c;
+                        best_score = sc;
+                    }
+                }
+                for (int32_t c : seen) acc[c] = -1;
+                if (best >= 0 && best_score > own_score && !(size[own] == 1 && size[best] == 1 && best > own)) {
+                    next[v] = best;
+                    ++moves;
                 }
             }
-            for (int32_t c : seen) acc[c] = -1;
-            int32_t target = own;
-            if (best >= 0 && best_score > own_score && !(size[own] == 1 && size[best] == 1 && best > own)) {
-                target = best;
-                ++moves;
-            }
-            next[v] = target;
+            comm.swap(next);
         }
         if (moves == 0) break;
-        comm.swap(next);
     }
+}
+
+// labels 0..K-1 by ascending smallest member (oracle/louvain_ref.py:canonical_labels); ids in `labels` are < bound
+void canonical_labels(std::vector<int32_t>& labels, int64_t bound) {
+    const int64_t n = (int64_t)labels.size();
+    std::vector<int32_t> rank(bound, -1);
+    int32_t k = 0;
+    for (int64_t v = 0; v < n; ++v) {         // first occurrence in node order = smallest member
+        int32_t& r = rank[labels[v]];
+        if (r < 0) r = k++;
+        labels[v] = r;
+    }
+}
+
+// Part C: refinement sweeps on the original graph from the partition `labels` (any ids in [0, bound)); canonical result
+void refine(const Graph& g, double gamma, int sweeps, int subrounds, std::vector<int32_t>& labels, int64_t bound) {
+    const int64_t n = g.n();
+    std::vector<int32_t> first(bound, -1);
+    for (int64_t v = 0; v < n; ++v)
+        if (first[labels[v]] < 0) first[labels[v]] = (int32_t)v;
+    std::vector<int32_t> comm(n);
+    for (int64_t v = 0; v < n; ++v) comm[v] = first[labels[v]];       // a community is named by its smallest member
+    std::vector<int64_t> wq, K;
+    int64_t m2;
+    quantise(g, wq, K, m2);
+    sync_sweeps(g, wq, K, m2, gamma, sweeps, subrounds, comm);
+    labels.swap(comm);
+    canonical_labels(labels, n);
+}
+
+void presweep(const Graph& g, double gamma, int sweeps, int subrounds, std::vector<int32_t>& member, Graph& coarse) {
+    const int64_t n = g.n();
+    std::vector<int64_t> wq, K;
+    int64_t m2;
+    quantise(g, wq, K, m2);
+    std::vector<int32_t> comm(n);
+    for (int64_t v = 0; v < n; ++v) comm[v] = (int32_t)v;
+    sync_sweeps(g, wq, K, m2, gamma, sweeps, subrounds, comm);
     // exact aggregation; coarse nodes numbered by ascending community id
     std::vector<int32_t> renum(n, -1);
     for (int64_t v = 0; v < n; ++v) renum[comm[v]] = 0;
@@ -598,6 +647,32 @@ void leiden_levels(const Graph& g0, double gamma, uint64_t seed, std::vector<int
     }
 }
 
+// part A applied DDX_PRESWEEP_LEVELS times: graphs[0] = the original, graphs[l + 1] = aggregate of graphs[l], members[l]: V_l -> V_{l+1}
+void presweep_levels(const Graph& g0, double gamma, std::vector<Graph>& graphs, std::vector<std::vector<int32_t>>& members) {
+    graphs.clear();
+    members.clear();
+    graphs.push_back(g0);
+    for (int lvl = 0; lvl < DDX_PRESWEEP_LEVELS; ++lvl) {
+        Graph coarse;
+        std::vector<int32_t> member;
+        presweep(graphs.back(), gamma, DDX_PRESWEEPS, DDX_SUBROUNDS, member, coarse);
+        members.push_back(std::move(member));
+        graphs.push_back(std::move(coarse));
+    }
+}
+
+// part C on the way back down: lab labels the nodes of graphs.back(); on return it labels the nodes of graphs[0]
+void refine_down(const std::vector<Graph>& graphs, const std::vector<std::vector<int32_t>>& members, double gamma, std::vector<int32_t>& lab,
+                 bool refine_levels) {
+    for (int level = (int)members.size() - 1; level >= 0; --level) {
+        const std::vector<int32_t>& m = members[level];
+        std::vector<int32_t> down(m.size());
+        for (size_t v = 0; v < m.size(); ++v) down[v] = lab[m[v]];
+        if (refine_levels) refine(graphs[level], gamma, DDX_REFINE_SWEEPS, DDX_SUBROUNDS, down, graphs[level + 1].n() > 0 ? graphs[level + 1].n() : 1);
+        lab.swap(down);
+    }
+}
+
 int load_graph(int64_t n_nodes, const int64_t* indptr, const int32_t* indices, const double* weights, Graph& g) {
     if (n_nodes < 0 || !indptr) return DDX_E_ARG;
     const int64_t nnz = n_nodes ? indptr[n_nodes] : 0;
@@ -642,25 +717,21 @@ extern "C" int ddx_leiden(int64_t n_nodes, const int64_t* indptr, const int32_t*
                           uint64_t seed, int32_t* labels_out) {
     if (!labels_out) return DDX_E_ARG;
     if (n_nodes == 0) return DDX_OK;
-    Graph g, coarse;
-    const int rc = load_graph(n_nodes, indptr, indices, weights, g);
+    Graph g0;
+    const int rc = load_graph(n_nodes, indptr, indices, weights, g0);
     if (rc != DDX_OK) return rc;
-    std::vector<int32_t> total(n_nodes), member, partition;
-    for (int64_t v = 0; v < n_nodes; ++v) total[v] = (int32_t)v;
-    for (int lvl = 0; lvl < DDX_PRESWEEP_LEVELS; ++lvl) {
-        presweep(g, gamma, DDX_PRESWEEPS, member, coarse);
-        for (int64_t v = 0; v < n_nodes; ++v) total[v] = member[total[v]];
-        g.indptr.swap(coarse.indptr);
-        g.indices.swap(coarse.indices);
-        g.weights.swap(coarse.weights);
-    }
-    leiden_levels(g, gamma, seed, partition);
-    for (int64_t v = 0; v < n_nodes; ++v) labels_out[v] = partition[total[v]];
+    std::vector<Graph> graphs;
+    std::vector<std::vector<int32_t>> members;
+    presweep_levels(g0, gamma, graphs, members);
+    std::vector<int32_t> lab;
+    leiden_levels(graphs.back(), gamma, seed, lab);
+    refine_down(graphs, members, gamma, lab, true);
+    for (int64_t v = 0; v < n_nodes; ++v) labels_out[v] = lab[v];
     return DDX_OK;
 }
 
 extern "C" int ddx_presweep(int64_t n_nodes, const int64_t* indptr, const int32_t* indices, const double* weights, double gamma,
-                            int32_t sweeps, int32_t* member_out, int64_t* n_coarse_out, int64_t* c_indptr_out,
+                            int32_t sweeps, int32_t subrounds, int32_t* member_out, int64_t* n_coarse_out, int64_t* c_indptr_out,
                             int32_t* c_indices_out, double* c_weights_out) {
     if (!member_out || !n_coarse_out || !c_indptr_out) return DDX_E_ARG;
     *n_coarse_out = 0;
@@ -669,7 +740,7 @@ extern "C" int ddx_presweep(int64_t n_nodes, const int64_t* indptr, const int32_
     const int rc = load_graph(n_nodes, indptr, indices, weights, g);
     if (rc != DDX_OK) return rc;
     std::vector<int32_t> member;
-    presweep(g, gamma, sweeps, member, coarse);
+    presweep(g, gamma, sweeps, subrounds, member, coarse);
     const int64_t nc = coarse.n();
     *n_coarse_out = nc;
     for (int64_t v = 0; v < n_nodes; ++v) member_out[v] = member[v];
@@ -683,24 +754,39 @@ extern "C" int ddx_presweep(int64_t n_nodes, const int64_t* indptr, const int32_
     return DDX_OK;
 }
 
+extern "C" int ddx_refine(int64_t n_nodes, const int64_t* indptr, const int32_t* indices, const double* weights, const int32_t* labels_in,
+                          double gamma, int32_t sweeps, int32_t subrounds, int32_t* labels_out) {
+    if (!labels_out || !labels_in || sweeps < 0) return DDX_E_ARG;
+    if (n_nodes == 0) return DDX_OK;
+    Graph g;
+    const int rc = load_graph(n_nodes, indptr, indices, weights, g);
+    if (rc != DDX_OK) return rc;
+    std::vector<int32_t> lab(labels_in, labels_in + n_nodes);
+    int64_t bound = 0;
+    for (int64_t v = 0; v < n_nodes; ++v) {
+        if (lab[v] < 0) return DDX_E_ARG;
+        bound = std::max<int64_t>(bound, (int64_t)lab[v] + 1);
+    }
+    refine(g, gamma, sweeps, subrounds, lab, bound);
+    for (int64_t v = 0; v < n_nodes; ++v) labels_out[v] = lab[v];
+    return DDX_OK;
+}
+
 extern "C" int ddx_louvain(int64_t n_nodes, const int64_t* indptr, const int32_t* indices, const double* weights,
                            double gamma, uint64_t seed, int32_t* labels_out, double* quality_out) {
     if (!labels_out) return DDX_E_ARG;
     if (n_nodes == 0) return DDX_OK;
-    Graph g, coarse;
-    const int rc = load_graph(n_nodes, indptr, indices, weights, g);
+    Graph g0;
+    const int rc = load_graph(n_nodes, indptr, indices, weights, g0);
     if (rc != DDX_OK) return rc;
-    std::vector<int32_t> total(n_nodes), member, membership;
-    for (int64_t v = 0; v < n_nodes; ++v) total[v] = (int32_t)v;
-    for (int lvl = 0; lvl < DDX_PRESWEEP_LEVELS; ++lvl) {
-        presweep(g, gamma, DDX_PRESWEEPS, member, coarse);
-        for (int64_t v = 0; v < n_nodes; ++v) total[v] = member[total[v]];
-        g.indptr.swap(coarse.indptr);
-        g.indices.swap(coarse.indices);
-        g.weights.swap(coarse.weights);
-    }
-    sequential_levels(g, gamma, seed, membership, quality_out);
-    for (int64_t v = 0; v < n_nodes; ++v) labels_out[v] = membership[total[v]];
+    std::vector<Graph> graphs;
+    std::vector<std::vector<int32_t>> members;
+    presweep_levels(g0, gamma, graphs, members);
+    std::vector<int32_t> lab;
+    Graph top = graphs.back();                           // sequential_levels consumes its graph
+    sequential_levels(top, gamma, seed, lab, quality_out);
+    refine_down(graphs, members, gamma, lab, true);
+    for (int64_t v = 0; v < n_nodes; ++v) labels_out[v] = lab[v];
     return DDX_OK;
 }
 
@@ -717,19 +803,14 @@ extern "C" int ddx_louvain_best_of(int64_t n_nodes, const int64_t* indptr, const
     if (runs_out) *runs_out = 0;
     if (quality_out) *quality_out = 0.0;
     if (n_nodes == 0) return DDX_OK;
-    Graph g, coarse;
+    Graph g;
     const int rc = load_graph(n_nodes, indptr, indices, weights, g);
     if (rc != DDX_OK) return rc;
-    std::vector<int32_t> total(n_nodes), member;
-    for (int64_t v = 0; v < n_nodes; ++v) total[v] = (int32_t)v;
+    std::vector<Graph> graphs;
+    std::vector<std::vector<int32_t>> members;
     if (presweeps) {
-        for (int lvl = 0; lvl < DDX_PRESWEEP_LEVELS; ++lvl) {
-            presweep(g, gamma, DDX_PRESWEEPS, member, coarse);
-            for (int64_t v = 0; v < n_nodes; ++v) total[v] = member[total[v]];
-            g.indptr.swap(coarse.indptr);
-            g.indices.swap(coarse.indices);
-            g.weights.swap(coarse.weights);
-        }
+        presweep_levels(g, gamma, graphs, members);
+        g = graphs.back();
     }
     std::vector<int32_t> best;
     double best_q = 0.0;
@@ -763,7 +844,8 @@ extern "C" int ddx_louvain_best_of(int64_t n_nodes, const int64_t* indptr, const
             }
         }
     }
-    for (int64_t v = 0; v < n_nodes; ++v) labels_out[v] = best[total[v]];
+    if (presweeps) refine_down(graphs, members, gamma, best, true);      // part C on the kept run
+    for (int64_t v = 0; v < n_nodes; ++v) labels_out[v] = best[v];
     if (quality_out) *quality_out = best_q;
     if (runs_out) *runs_out = run;
     return DDX_OK;

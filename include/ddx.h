@@ -176,19 +176,24 @@ int ddx_get_graph(ddx_ctx* ctx, int64_t* indptr, int32_t* indices, double* weigh
 
 /* ---- community detection (see oracle/louvain_ref.py for the spec) --------------------------------
  * replaces the Louvain stage inside phenograph.cluster / sc.tl.louvain (dd.py:320-322, 337-342).
- * The specification has two parts: (A) DDX_PRESWEEP_LEVELS times { DDX_PRESWEEPS synchronous sweeps on
- * integer-quantised weights followed by an exact aggregation }, (B) sequential multi-level optimisation of the
- * aggregated graph.
- *   ddx_louvain            = A + B on the host (context-free, thread-safe);
- *   ddx_presweep           = one level of A on the host;   ddx_louvain_sequential = B on the host;
+ * The specification has three parts: (A) DDX_PRESWEEP_LEVELS times { DDX_PRESWEEPS synchronous sweeps of
+ * DDX_SUBROUNDS sub-rounds on integer-quantised weights followed by an exact aggregation }, (B) sequential multi-level
+ * optimisation of the aggregated graph, (C) DDX_REFINE_SWEEPS refinement sweeps (the moves of part A) on the original
+ * graph from the partition A + B found.  Quality is pinned against networkx's Louvain: tests/test_clustering_independent.py.
+ *   ddx_louvain            = A + B + C on the host (context-free, thread-safe);
+ *   ddx_presweep           = one level of A on the host;   ddx_louvain_sequential = B on the host;   ddx_refine = C on the host;
  *   ddx_coarsen_graph      = `levels` levels of A on the GPU, applied to the graph ddx_build_graph left on the device; the
- *                            result (member of every node + aggregated CSR) is read with ddx_get_coarse_*.
- * A on the GPU followed by ddx_louvain_sequential equals ddx_louvain bit for bit.
+ *                            result (member of every node + aggregated CSR) is read with ddx_get_coarse_*;
+ *   ddx_refine_communities = C on the GPU: takes the labels part B gave to the coarse nodes, returns the final labels of
+ *                            the original nodes (numbered by ascending smallest member).
+ * A on the GPU, ddx_louvain_sequential, C on the GPU equals ddx_louvain bit for bit.
  *   ddx_leiden_sequential  = part B' (Leiden: local moving, refinement, aggregation on the refined groups, iterated
  *                            until stable) in place of B -- replaces leidenalg behind sc.tl.leiden (dd.py:329,337-342);
- *   ddx_leiden             = A + B' on the host. */
+ *   ddx_leiden             = A + B' + C on the host. */
 #define DDX_PRESWEEPS 6
 #define DDX_PRESWEEP_LEVELS 2
+#define DDX_SUBROUNDS 4       /* sub-rounds per synchronous sweep: a quarter of the nodes decides at a time */
+#define DDX_REFINE_SWEEPS 3   /* part C: refinement sweeps on the original graph */
 int ddx_louvain(int64_t n_nodes, const int64_t* indptr, const int32_t* indices, const double* weights,
                 double gamma, uint64_t seed, int32_t* labels_out /* [n_nodes] */, double* quality_out);
 int ddx_louvain_sequential(int64_t n_nodes, const int64_t* indptr, const int32_t* indices, const double* weights,
@@ -200,15 +205,22 @@ int ddx_leiden_sequential(int64_t n_nodes, const int64_t* indptr, const int32_t*
 /* ddx_louvain_best_of: PhenoGraph's restart rule (upstream phenograph.core.runlouvain behind dd.py:320-322): part B is
  * run from seeds seed, seed+1, ...; a run replaces the best when its modularity is larger by more than q_tol; stop after
  * `stall` consecutive runs without such a gain (upstream: q_tol = 1e-3, 20 runs) or after max_runs.  presweeps != 0 runs
- * part A first (the host statement of ddx_coarsen_graph), presweeps == 0 takes the graph as it is (already coarsened on
- * the device).  `threads` host threads evaluate a batch of runs at once; the result does not depend on it. */
+ * part A first (the host statement of ddx_coarsen_graph) and part C on the kept run; presweeps == 0 takes the graph as it
+ * is (already coarsened on the device: part C then follows there, ddx_refine_communities).  `threads` host threads evaluate a batch of runs at once; the result does not depend on it. */
 int ddx_louvain_best_of(int64_t n_nodes, const int64_t* indptr, const int32_t* indices, const double* weights, double gamma,
                         uint64_t seed, double q_tol, int32_t stall, int32_t max_runs, int32_t threads, int32_t presweeps,
                         int32_t* labels_out /* [n_nodes] */, double* quality_out, int32_t* runs_out);
 int ddx_presweep(int64_t n_nodes, const int64_t* indptr, const int32_t* indices, const double* weights, double gamma,
-                 int32_t sweeps, int32_t* member_out /* [n_nodes] */, int64_t* n_coarse_out,
+                 int32_t sweeps, int32_t subrounds, int32_t* member_out /* [n_nodes] */, int64_t* n_coarse_out,
                  int64_t* c_indptr_out /* [n_nodes+1] */, int32_t* c_indices_out /* [nnz] */, double* c_weights_out /* [nnz] */);
+int ddx_refine(int64_t n_nodes, const int64_t* indptr, const int32_t* indices, const double* weights,
+               const int32_t* labels_in /* [n_nodes], any non-negative ids */, double gamma, int32_t sweeps, int32_t subrounds,
+               int32_t* labels_out /* [n_nodes] */);
 int ddx_coarsen_graph(ddx_ctx* ctx, double gamma, int32_t sweeps, int32_t levels);
+/* needs the graph of ddx_build_graph and the result of ddx_coarsen_graph still on the device (i.e. before the next
+ * ddx_pca / ddx_build_graph of this context) */
+int ddx_refine_communities(ddx_ctx* ctx, const int32_t* coarse_labels /* [n_coarse] */, double gamma, int32_t sweeps,
+                           int32_t* labels_out /* [n_nodes] */);
 int ddx_get_coarse_size(ddx_ctx* ctx, int64_t* n_coarse, int64_t* n_entries);
 int ddx_get_coarse_graph(ddx_ctx* ctx, int32_t* member /* [n_nodes] */, int64_t* indptr /* [n_coarse+1] */,
                          int32_t* indices, double* weights);

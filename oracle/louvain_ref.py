@@ -15,13 +15,28 @@ Algorithm (the published multi-level modularity optimisation with a resolution p
 **Part A -- synchronous pre-sweeps** (``presweep``, applied ``PRESWEEP_LEVELS`` times, each time to the graph the
 previous application aggregated; what the GPU runs, cf. the parallel Louvain variants of
 Lu, Halappanavar, Kalyanaraman 2015 and Naim et al. 2017).  Weights are quantised to integers
-``wq = rint(w * 2**20)`` so that every sum below is exact and independent of summation order.  For
-``PRESWEEPS`` sweeps (stopping early when nothing moves) *all* nodes decide at once from the same state:
+``wq = rint(w * 2**20)`` so that every sum below is exact and independent of summation order.  A sweep consists of
+``SUBROUNDS`` sub-rounds; in sub-round r of sweep s the nodes of class ``(h(v) + s) mod SUBROUNDS == r``
+(``h(v) = ((v * 2654435761) mod 2**32) >> 16``) decide *at once* from the same state, everybody else stays:
 ``score(v, c) = W(v,c) * 2m  -  gamma * (tot_c - [c == own] k_v) * k_v`` (float64, this operation order), the
 best community among the neighbours' communities (ties: smaller id) is taken if its score is strictly larger than
 staying, except that a node that is alone in its community does not move to another lone node with a larger id
-(the minimum-label rule that prevents two singletons from swapping for ever).  The communities are then
-aggregated exactly (integer sums, renumbered by ascending id).
+(the minimum-label rule that prevents two singletons from swapping for ever).  Community totals are recomputed
+between sub-rounds.  ``PRESWEEPS`` sweeps are made (stopping early when a whole sweep moves nothing), then the
+communities are aggregated exactly (integer sums, renumbered by ascending id).  Why sub-rounds: with every node
+deciding at once (the round-2 text) neighbours merge in arbitrary pairs at the first sweep and the sequential levels
+cannot undo those groups -- measured against networkx's Louvain (tests/test_clustering_independent.py) that cost
+0.03 of modularity on the resolution-4 neighbour graphs; a quarter of the nodes at a time behaves like the
+sequential sweep.
+
+**Part C -- refinement on the way back down** (``refine``; the uncoarsening refinement of multi-level Louvain,
+Rotta & Noack 2011): the partition part B (or B') produced is projected onto the nodes of the graph the LAST
+application of part A started from, every community named by its smallest member, and ``REFINE_SWEEPS`` sweeps of the
+very same sub-round moves are made on that (quantised) graph; the result is projected one level further down and
+refined there, and so on until the original graph: groups (then single nodes) that part A put on the wrong side of a
+community border change sides.  The result is numbered by ascending smallest member.  With parts A + B + C the build reaches the modularity of networkx's
+sequential Louvain on the reference's graphs to within 0.001 and the same number of communities
+(tests/golden/clustering_networkx.npz).
 
 **Part B -- sequential multi-level optimisation** of the aggregated graph:
 
@@ -62,11 +77,73 @@ _MASK = 0xFFFFFFFFFFFFFFFF
 MIN_GAIN = 1e-6
 PRESWEEPS = 6
 PRESWEEP_LEVELS = 2
+SUBROUNDS = 4
+REFINE_SWEEPS = 3
 WEIGHT_SCALE = float(1 << 20)
 LEIDEN_MAX_ITERATIONS = 16
 
 
-def presweep(indptr, indices, weights, gamma: float = 1.0, sweeps: int = PRESWEEPS):
+def _node_class(n: int) -> np.ndarray:
+    """h(v) = ((v * 2654435761) mod 2**32) >> 16 -- spreads consecutive ids over the sub-round classes."""
+    v = np.arange(n, dtype=np.uint64)
+    return (((v * np.uint64(2654435761)) & np.uint64(0xFFFFFFFF)) >> np.uint64(16)).astype(np.int64)
+
+
+def _sync_sweeps(indptr, indices, wq, comm, gamma: float, sweeps: int, subrounds: int):
+    """``sweeps`` sweeps of ``subrounds`` synchronous sub-rounds from the partition ``comm`` (community ids are node
+    ids) on integer weights ``wq``.  Returns the new ``comm``."""
+    n = len(indptr) - 1
+    rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(indptr))
+    K = np.zeros(n, dtype=np.int64)
+    np.add.at(K, rows, wq)
+    m2 = int(K.sum())
+    comm = np.asarray(comm, dtype=np.int64).copy()
+    noself = rows != indices
+    r_ns, u_ns, w_ns = rows[noself], indices[noself], wq[noself]
+    gamma = float(gamma)
+    h = _node_class(n)
+    subrounds = max(1, int(subrounds))
+    if m2 <= 0 or len(r_ns) == 0:
+        return comm
+    kvf = K.astype(np.float64)
+    for s in range(int(sweeps)):
+        moved = False
+        for r in range(subrounds):
+            tot = np.zeros(n, dtype=np.int64)
+            np.add.at(tot, comm, K)
+            size = np.bincount(comm, minlength=n)
+            key = r_ns * n + comm[u_ns]                       # (node, neighbour community)
+            order = np.argsort(key, kind="stable")
+            ks, ws = key[order], w_ns[order]
+            first = np.concatenate([[True], ks[1:] != ks[:-1]])
+            W = np.add.reduceat(ws, np.flatnonzero(first))    # exact integer sums
+            kv, kc = ks[first] // n, ks[first] % n
+            own = kc == comm[kv]
+            own_w = np.zeros(n, dtype=np.int64)
+            own_w[kv[own]] = W[own]
+            own_score = own_w.astype(np.float64) * float(m2) - (gamma * (tot[comm] - K).astype(np.float64)) * kvf
+            cand = ~own
+            cv, cc, cw = kv[cand], kc[cand], W[cand]
+            score = cw.astype(np.float64) * float(m2) - (gamma * tot[cc].astype(np.float64)) * kvf[cv]
+            o2 = np.lexsort((cc, -score, cv))                 # per node: best score first, ties by smaller community
+            cv2 = cv[o2]
+            f2 = np.concatenate([[True], cv2[1:] != cv2[:-1]]) if len(cv2) else np.zeros(0, dtype=bool)
+            bv, bc, bs = cv2[f2], cc[o2][f2], score[o2][f2]
+            move = bs > own_score[bv]
+            lone = (size[comm[bv]] == 1) & (size[bc] == 1) & (bc > comm[bv])
+            move &= ~lone
+            move &= ((h[bv] + s) % subrounds) == r            # only this sub-round's class decides
+            if move.any():
+                moved = True
+                new_comm = comm.copy()
+                new_comm[bv[move]] = bc[move]
+                comm = new_comm
+        if not moved:
+            break
+    return comm
+
+
+def presweep(indptr, indices, weights, gamma: float = 1.0, sweeps: int = PRESWEEPS, subrounds: int = SUBROUNDS):
     """Part A.  Returns (member, c_indptr, c_indices, c_weights): member[v] = coarse node of v (numbered by
     ascending community id) and the aggregated graph with float64 weights (integer sums / 2**20)."""
     indptr = np.asarray(indptr, dtype=np.int64)
@@ -74,45 +151,7 @@ def presweep(indptr, indices, weights, gamma: float = 1.0, sweeps: int = PRESWEE
     n = len(indptr) - 1
     wq = np.rint(np.asarray(weights, dtype=np.float64) * WEIGHT_SCALE).astype(np.int64)
     rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(indptr))
-    K = np.zeros(n, dtype=np.int64)
-    np.add.at(K, rows, wq)
-    m2 = int(K.sum())
-    comm = np.arange(n, dtype=np.int64)
-    noself = rows != indices
-    r_ns, u_ns, w_ns = rows[noself], indices[noself], wq[noself]
-    gamma = float(gamma)
-    for _ in range(int(sweeps) if m2 > 0 else 0):
-        tot = np.zeros(n, dtype=np.int64)
-        np.add.at(tot, comm, K)
-        size = np.bincount(comm, minlength=n)
-        if len(r_ns) == 0:
-            break
-        key = r_ns * n + comm[u_ns]                       # (node, neighbour community)
-        order = np.argsort(key, kind="stable")
-        ks, ws = key[order], w_ns[order]
-        first = np.concatenate([[True], ks[1:] != ks[:-1]])
-        W = np.add.reduceat(ws, np.flatnonzero(first))    # exact integer sums
-        kv, kc = ks[first] // n, ks[first] % n
-        own = kc == comm[kv]
-        own_w = np.zeros(n, dtype=np.int64)
-        own_w[kv[own]] = W[own]
-        kvf = K.astype(np.float64)
-        own_score = own_w.astype(np.float64) * float(m2) - (gamma * (tot[comm] - K).astype(np.float64)) * kvf
-        cand = ~own
-        cv, cc, cw = kv[cand], kc[cand], W[cand]
-        score = cw.astype(np.float64) * float(m2) - (gamma * tot[cc].astype(np.float64)) * kvf[cv]
-        o2 = np.lexsort((cc, -score, cv))                 # per node: best score first, ties by smaller community
-        cv2 = cv[o2]
-        f2 = np.concatenate([[True], cv2[1:] != cv2[:-1]]) if len(cv2) else np.zeros(0, dtype=bool)
-        bv, bc, bs = cv2[f2], cc[o2][f2], score[o2][f2]
-        move = bs > own_score[bv]
-        lone = (size[comm[bv]] == 1) & (size[bc] == 1) & (bc > comm[bv])
-        move &= ~lone
-        if not move.any():
-            break
-        new_comm = comm.copy()
-        new_comm[bv[move]] = bc[move]
-        comm = new_comm
+    comm = _sync_sweeps(indptr, indices, wq, np.arange(n, dtype=np.int64), gamma, sweeps, subrounds)
     used, member = np.unique(comm, return_inverse=True)
     nc = len(used)
     ckey = member[rows] * nc + member[indices]
@@ -129,6 +168,36 @@ def presweep(indptr, indices, weights, gamma: float = 1.0, sweeps: int = PRESWEE
     np.add.at(c_indptr, cr + 1, 1)
     c_indptr = np.cumsum(c_indptr)
     return member.astype(np.int64), c_indptr, ccol.astype(np.int64), W.astype(np.float64) / WEIGHT_SCALE
+
+
+def canonical_labels(labels) -> np.ndarray:
+    """Labels 0..K-1 numbered by ascending smallest member (independent of how the communities were named)."""
+    labels = np.asarray(labels)
+    n = len(labels)
+    if n == 0:
+        return np.zeros(0, dtype=np.int64)
+    _, inv = np.unique(labels, return_inverse=True)
+    first = np.full(inv.max() + 1, n, dtype=np.int64)
+    np.minimum.at(first, inv, np.arange(n, dtype=np.int64))
+    rank = np.empty(len(first), dtype=np.int64)
+    rank[np.argsort(first, kind="stable")] = np.arange(len(first))
+    return rank[inv]
+
+
+def refine(indptr, indices, weights, labels, gamma: float = 1.0, sweeps: int = REFINE_SWEEPS, subrounds: int = SUBROUNDS) -> np.ndarray:
+    """Part C.  ``labels``: any labelling of the original nodes.  Returns canonical labels after the refinement sweeps."""
+    indptr = np.asarray(indptr, dtype=np.int64)
+    indices = np.asarray(indices, dtype=np.int64)
+    labels = np.asarray(labels)
+    n = len(indptr) - 1
+    if n == 0:
+        return np.zeros(0, dtype=np.int64)
+    wq = np.rint(np.asarray(weights, dtype=np.float64) * WEIGHT_SCALE).astype(np.int64)
+    _, inv = np.unique(labels, return_inverse=True)
+    first = np.full(inv.max() + 1, n, dtype=np.int64)
+    np.minimum.at(first, inv, np.arange(n, dtype=np.int64))
+    comm = _sync_sweeps(indptr, indices, wq, first[inv], gamma, sweeps, subrounds)
+    return canonical_labels(comm)
 
 
 class SplitMix64:
@@ -261,14 +330,30 @@ def _aggregate(indptr, indices, weights, comm):
 
 
 def louvain(indptr, indices, weights, gamma: float = 1.0, seed: int = 0, presweeps: int = PRESWEEPS,
-            levels: int = PRESWEEP_LEVELS) -> np.ndarray:
-    """Community label per node (0..K-1, numbered by ascending representative id)."""
-    member = None
+            levels: int = PRESWEEP_LEVELS, refine_sweeps: int = REFINE_SWEEPS) -> np.ndarray:
+    """Parts A + B + C.  Community label per node (0..K-1, numbered by ascending smallest member; without pre-sweeps
+    there is nothing to refine and the labels are part B's, numbered by ascending representative id)."""
+    graphs, members = _presweep_levels(indptr, indices, weights, gamma, presweeps, levels)
+    lab = _louvain_sequential(*graphs[-1], gamma, seed)
+    return _refine_down(graphs, members, lab, gamma, refine_sweeps)
+
+
+def _presweep_levels(indptr, indices, weights, gamma, presweeps, levels):
+    """Part A applied ``levels`` times: ([graph_0, ..., graph_levels], [member_0, ..., member_{levels-1}])."""
+    graphs, members = [(indptr, indices, weights)], []
     for _ in range(levels if presweeps > 0 else 0):
-        m, indptr, indices, weights = presweep(indptr, indices, weights, gamma, presweeps)
-        member = m if member is None else m[member]
-    lab = _louvain_sequential(indptr, indices, weights, gamma, seed)
-    return lab if member is None else lab[member]
+        m, ip, ix, w = presweep(*graphs[-1], gamma, presweeps)
+        members.append(m)
+        graphs.append((ip, ix, w))
+    return graphs, members
+
+
+def _refine_down(graphs, members, lab, gamma, refine_sweeps):
+    """Part C: ``lab`` labels the nodes of graphs[-1]; refine on graphs[-2], ..., graphs[0]."""
+    lab = np.asarray(lab)
+    for level in range(len(members) - 1, -1, -1):
+        lab = refine(*graphs[level], lab[members[level]], gamma, refine_sweeps)
+    return lab
 
 
 def _louvain_sequential(indptr, indices, weights, gamma: float = 1.0, seed: int = 0, with_quality: bool = False):
@@ -292,24 +377,29 @@ def _louvain_sequential(indptr, indices, weights, gamma: float = 1.0, seed: int 
 
 
 def louvain_best_of(indptr, indices, weights, gamma: float = 1.0, seed: int = 0, q_tol: float = 1e-3, stall: int = 20,
-                    max_runs: int = 1000, presweeps: int = PRESWEEPS, presweep_levels: int = PRESWEEP_LEVELS):
+                    max_runs: int = 1000, presweeps: int = PRESWEEPS, presweep_levels: int = PRESWEEP_LEVELS,
+                    refine_sweeps: int = REFINE_SWEEPS):
     """PhenoGraph's restart rule around part B (upstream ``phenograph.core.runlouvain``, reached from dd.py:320-322 --
     restated, the package is absent): the Louvain executable is run again and again from another random node order; a
     run replaces the best result when its modularity exceeds the best by more than ``q_tol`` (1e-3 upstream); the loop
     ends after ``stall`` (20) consecutive runs without such a gain.  Upstream seeds every run from time / pid; here run r
     uses ``seed + r``, so the outcome is a function of (graph, gamma, seed, q_tol, stall).  Part A (the pre-sweeps) is
-    deterministic and runs once.  Returns (labels, quality of the kept run, number of runs)."""
-    member = None
-    for _ in range(presweep_levels if presweeps > 0 else 0):
-        m, indptr, indices, weights = presweep(indptr, indices, weights, gamma, presweeps)
-        member = m if member is None else m[member]
+    deterministic and runs once, and so does part C, applied to the run that was kept (``refine_sweeps=0``: the kept
+    run as it is, numbered as part B numbers it).  Returns (labels, quality part B reported for the kept run, number of runs)."""
+    graphs, members = _presweep_levels(indptr, indices, weights, gamma, presweeps, presweep_levels)
+    indptr, indices, weights = graphs[-1]
     best, best_q, run, updated = None, 0.0, 0, 0
     while run - updated < stall and run < max_runs:
         lab, q = _louvain_sequential(indptr, indices, weights, gamma, (seed + run) & 0xFFFFFFFFFFFFFFFF, with_quality=True)
         if best is None or q - best_q > q_tol:
             best, best_q, updated = lab, q, run
         run += 1
-    return (best if member is None else best[member]), best_q, run
+    if refine_sweeps > 0:
+        best = _refine_down(graphs, members, best, gamma, refine_sweeps)
+    else:
+        for m in reversed(members):
+            best = best[m]
+    return best, best_q, run
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -511,14 +601,11 @@ def _leiden_sequential(indptr, indices, weights, gamma: float = 1.0, seed: int =
 
 
 def leiden(indptr, indices, weights, gamma: float = 1.0, seed: int = 0, presweeps: int = PRESWEEPS,
-           levels: int = PRESWEEP_LEVELS) -> np.ndarray:
-    """Part A, then part B' on the aggregated graph."""
-    member = None
-    for _ in range(levels if presweeps > 0 else 0):
-        m, indptr, indices, weights = presweep(indptr, indices, weights, gamma, presweeps)
-        member = m if member is None else m[member]
-    lab = _leiden_sequential(indptr, indices, weights, gamma, seed)
-    return lab if member is None else lab[member]
+           levels: int = PRESWEEP_LEVELS, refine_sweeps: int = REFINE_SWEEPS) -> np.ndarray:
+    """Part A, part B' on the aggregated graph, part C on the way back down."""
+    graphs, members = _presweep_levels(indptr, indices, weights, gamma, presweeps, levels)
+    lab = _leiden_sequential(*graphs[-1], gamma, seed)
+    return _refine_down(graphs, members, lab, gamma, refine_sweeps)
 
 
 def modularity(indptr, indices, weights, labels, gamma: float = 1.0) -> float:

@@ -128,6 +128,9 @@ def _large_config_properties(data, n_top, k, graph_mode, include_self, seed=0, k
         np.testing.assert_array_equal(ix_dev, gr[1])
         np.testing.assert_array_equal(w_dev, gr[2])
         assert len(ip_dev) - 1 < M // 10
+        # part B on the host, part C on the device = the whole specification on the host
+        coarse = _lib.louvain_sequential(ip_dev, ix_dev, w_dev, gamma, 0)[0]
+        np.testing.assert_array_equal(ctx.refine_communities(coarse, gamma), _lib.louvain(ip, ix, w, gamma, 0)[0])
     finally:
         ctx.close()
 

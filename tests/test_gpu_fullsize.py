@@ -120,6 +120,8 @@ def test_pca_and_knn_properties(staged):
     np.testing.assert_array_equal(ix_dev, gr[1])
     np.testing.assert_array_equal(w_dev, gr[2])
     assert len(ip_dev) - 1 < M // 20                          # it coarsens by more than an order of magnitude
+    coarse = _lib.louvain_sequential(ip_dev, ix_dev, w_dev, 1.0, 0)[0]
+    np.testing.assert_array_equal(ctx.refine_communities(coarse, 1.0), _lib.louvain(ip, ix, w, 1.0, 0)[0])
 
 
 def test_operator_product_variants_agree_at_full_size(data, staged, monkeypatch):

@@ -395,10 +395,30 @@ def test_device_presweeps_match_host(ctx, case):
             np.testing.assert_array_equal(ip_dev, gr[0])
             np.testing.assert_array_equal(ix_dev, gr[1])
             np.testing.assert_array_equal(w_dev, gr[2])
-        # device A + host B = host A + B
+        # device A + host B + device C = host A + B + C, for the Louvain levels, PhenoGraph's restart rule and Leiden
         m_dev, ip_dev, ix_dev, w_dev = ctx.coarsen_graph(gamma)
-        lab = _lib.louvain_sequential(ip_dev, ix_dev, w_dev, gamma, 3)[0][m_dev]
-        np.testing.assert_array_equal(lab, _lib.louvain(ip, ix, w, gamma, 3)[0])
+        coarse = _lib.louvain_sequential(ip_dev, ix_dev, w_dev, gamma, 3)[0]
+        np.testing.assert_array_equal(ctx.refine_communities(coarse, gamma), _lib.louvain(ip, ix, w, gamma, 3)[0])
+        coarse = _lib.louvain_best_of(ip_dev, ix_dev, w_dev, gamma, 3, 1e-3, threads=4, presweeps=False)[0]
+        np.testing.assert_array_equal(ctx.refine_communities(coarse, gamma), _lib.louvain_best_of(ip, ix, w, gamma, 3, 1e-3, threads=4)[0])
+        coarse = _lib.leiden_sequential(ip_dev, ix_dev, w_dev, gamma, 3)
+        np.testing.assert_array_equal(ctx.refine_communities(coarse, gamma), _lib.leiden(ip, ix, w, gamma, 3))
+        # part C alone: any labelling of the coarse nodes, any number of sweeps; one level of part A
+        rng = np.random.default_rng(5)
+        arbitrary = rng.integers(0, max(2, len(ip_dev) // 7), size=len(ip_dev) - 1).astype(np.int32)
+        graphs, members = [(ip, ix, w)], []
+        for _ in range(_lib.PRESWEEP_LEVELS):
+            mm, *gr = _lib.presweep(*graphs[-1], gamma)
+            members.append(mm)
+            graphs.append(tuple(gr))
+        for sweeps in (0, 1, _lib.REFINE_SWEEPS):
+            lab = arbitrary
+            for level in range(len(members) - 1, -1, -1):
+                lab = _lib.refine(*graphs[level], lab[members[level]], gamma, sweeps)
+            np.testing.assert_array_equal(ctx.refine_communities(arbitrary, gamma, sweeps), lab)
+        m1, ip1, ix1, w1 = ctx.coarsen_graph(gamma, levels=1)
+        coarse = _lib.louvain_sequential(ip1, ix1, w1, gamma, 9)[0]
+        np.testing.assert_array_equal(ctx.refine_communities(coarse, gamma), _lib.refine(ip, ix, w, coarse[m1], gamma))
 
 
 def test_device_presweeps_high_degree_nodes(ctx):
@@ -419,6 +439,9 @@ def test_device_presweeps_high_degree_nodes(ctx):
     np.testing.assert_array_equal(ip_dev, ip_host)
     np.testing.assert_array_equal(ix_dev, ix_host)
     np.testing.assert_array_equal(w_dev, w_host)
+    # ... and part C on the same graph (the hubs go through the LDS path there too)
+    coarse = _lib.louvain_sequential(ip_dev, ix_dev, w_dev, 1.0, 0)[0]
+    np.testing.assert_array_equal(ctx.refine_communities(coarse, 1.0), _lib.refine(ip, ix, w, coarse[m_dev], 1.0))
 
 
 def test_device_presweeps_refuse_hubs_beyond_capacity_and_fit_falls_back(ctx):

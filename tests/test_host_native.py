@@ -63,10 +63,11 @@ def test_louvain_matches_python_specification_bit_for_bit(n, k, seed, weighted, 
     ref = louvain_ref.louvain(A.indptr, A.indices, A.data, gamma, seed)
     got, q = _lib.louvain(A.indptr, A.indices, A.data, gamma, seed)
     np.testing.assert_array_equal(got.astype(np.int64), ref)
-    # q is evaluated on the aggregated graph, whose weights are multiples of 2^-20
-    assert abs(q - louvain_ref.modularity(A.indptr, A.indices, A.data, ref, gamma)) < 1e-5
-    # sanity: it finds structure
+    # q is what part B reports on the aggregated graph (weights are multiples of 2^-20); part C only adds to it
+    assert louvain_ref.modularity(A.indptr, A.indices, A.data, ref, gamma) > q - 1e-5
+    # sanity: it finds structure, and the labels are numbered by ascending smallest member
     assert len(np.unique(got)) < n
+    np.testing.assert_array_equal(got, louvain_ref.canonical_labels(got))
 
 
 @pytest.mark.parametrize("n,k,seed,weighted,gamma", [
@@ -91,14 +92,18 @@ def test_leiden_matches_python_specification_bit_for_bit(n, k, seed, weighted, g
     q_louvain = louvain_ref.modularity(A.indptr, A.indices, A.data,
                                        _lib.louvain_sequential(A.indptr, A.indices, A.data, gamma, seed)[0], gamma)
     assert q_leiden > q_louvain - 0.01
-    # whole = pre-sweeps, then part B' on the aggregated graph
+    # whole = pre-sweeps, then part B' on the aggregated graph, then the refinement sweeps on the original one
     whole = _lib.leiden(A.indptr, A.indices, A.data, gamma, seed)
     np.testing.assert_array_equal(whole.astype(np.int64), louvain_ref.leiden(A.indptr, A.indices, A.data, gamma, seed))
-    total, g = None, (A.indptr, A.indices, A.data)
+    graphs, members = [(A.indptr, A.indices, A.data)], []
     for _ in range(_lib.PRESWEEP_LEVELS):
-        mm, *g = _lib.presweep(*g, gamma)
-        total = mm if total is None else mm[total]
-    np.testing.assert_array_equal(whole, _lib.leiden_sequential(*g, gamma, seed)[total])
+        mm, *g = _lib.presweep(*graphs[-1], gamma)
+        members.append(mm)
+        graphs.append(tuple(g))
+    lab = _lib.leiden_sequential(*graphs[-1], gamma, seed)
+    for level in range(len(members) - 1, -1, -1):
+        lab = _lib.refine(*graphs[level], lab[members[level]], gamma)
+    np.testing.assert_array_equal(whole, lab)
 
 
 def test_leiden_degenerate_graphs():
@@ -121,7 +126,8 @@ def test_leiden_degenerate_graphs():
 
 @pytest.mark.parametrize("n,k,seed,weighted,gamma", [(300, 6, 2, True, 1.0), (800, 5, 123, False, 4.0), (2000, 10, 9, True, 1.0)])
 def test_presweep_and_sequential_parts_match_specification(n, k, seed, weighted, gamma):
-    """Part A (synchronous sweeps + exact aggregation) and part B (sequential levels) separately, and A o B = whole."""
+    """Part A (synchronous sub-round sweeps + exact aggregation), part B (sequential levels) and part C (refinement sweeps)
+    separately, and C o B o A = whole."""
     A = _random_graph(n, k, seed, weighted)
     m_ref, ip_ref, ix_ref, w_ref = louvain_ref.presweep(A.indptr, A.indices, A.data, gamma)
     m, ip, ix, w = _lib.presweep(A.indptr, A.indices, A.data, gamma)
@@ -130,23 +136,39 @@ def test_presweep_and_sequential_parts_match_specification(n, k, seed, weighted,
     np.testing.assert_array_equal(ix, ix_ref)
     np.testing.assert_array_equal(w, w_ref)
     assert len(ip) - 1 < n                                   # it does coarsen
-    for sweeps in (0, 1, 3):
-        ms, ips, ixs, ws = _lib.presweep(A.indptr, A.indices, A.data, gamma, sweeps)
-        mr, ipr, ixr, wr = louvain_ref.presweep(A.indptr, A.indices, A.data, gamma, sweeps)
+    for sweeps, subrounds in ((0, 4), (1, 4), (3, 4), (3, 1), (2, 3), (6, 2)):
+        ms, ips, ixs, ws = _lib.presweep(A.indptr, A.indices, A.data, gamma, sweeps, subrounds)
+        mr, ipr, ixr, wr = louvain_ref.presweep(A.indptr, A.indices, A.data, gamma, sweeps, subrounds)
         np.testing.assert_array_equal(ms, mr)
         np.testing.assert_array_equal(ws, wr)
     seq, _ = _lib.louvain_sequential(ip, ix, w, gamma, seed)
     np.testing.assert_array_equal(seq.astype(np.int64), louvain_ref._louvain_sequential(ip_ref, ix_ref, w_ref, gamma, seed))
-    # the whole = PRESWEEP_LEVELS applications of part A, then part B
-    total, g = None, (A.indptr, A.indices, A.data)
+    # the whole = PRESWEEP_LEVELS applications of part A, then part B, then part C on every level on the way back down
+    graphs, members = [(A.indptr, A.indices, A.data)], []
     for _ in range(_lib.PRESWEEP_LEVELS):
-        mm, *g = _lib.presweep(*g, gamma)
-        total = mm if total is None else mm[total]
+        mm, *g = _lib.presweep(*graphs[-1], gamma)
+        members.append(mm)
+        graphs.append(tuple(g))
     whole, _ = _lib.louvain(A.indptr, A.indices, A.data, gamma, seed)
-    np.testing.assert_array_equal(whole, _lib.louvain_sequential(*g, gamma, seed)[0][total])
-    # the pre-sweeps cost no modularity worth mentioning against the purely sequential optimisation
+    lab = _lib.louvain_sequential(*graphs[-1], gamma, seed)[0]
+    after_b = lab
+    for mm in reversed(members):
+        after_b = after_b[mm]
+    for level in range(len(members) - 1, -1, -1):
+        lab = _lib.refine(*graphs[level], lab[members[level]], gamma)
+    np.testing.assert_array_equal(whole, lab)
+    # part C against its Python statement, from B's partition and from arbitrary labellings (any non-negative ids)
+    rng = np.random.default_rng(seed)
+    for labels in (after_b, rng.integers(0, 7, size=n) * 3 + 1, np.arange(n)[::-1].copy()):
+        for sweeps, subrounds in ((3, 4), (1, 1), (2, 2)):
+            np.testing.assert_array_equal(_lib.refine(A.indptr, A.indices, A.data, labels, gamma, sweeps, subrounds).astype(np.int64),
+                                          louvain_ref.refine(A.indptr, A.indices, A.data, labels, gamma, sweeps, subrounds))
+    np.testing.assert_array_equal(_lib.refine(A.indptr, A.indices, A.data, after_b, gamma, 0), louvain_ref.canonical_labels(after_b))
+    # refinement never loses modularity worth mentioning, and the whole is no worse than the purely sequential optimisation
     q_whole = louvain_ref.modularity(A.indptr, A.indices, A.data, whole, gamma)
+    q_b = louvain_ref.modularity(A.indptr, A.indices, A.data, after_b, gamma)
     q_seq = louvain_ref.modularity(A.indptr, A.indices, A.data, _lib.louvain_sequential(A.indptr, A.indices, A.data, gamma, seed)[0], gamma)
+    assert q_whole >= q_b - 1e-9
     assert q_whole > q_seq - 0.02
 
 
@@ -162,14 +184,14 @@ def test_best_of_restarts_matches_python_specification(n, k, seed, weighted, gam
         got, gq, gruns = _lib.louvain_best_of(A.indptr, A.indices, A.data, gamma, seed, q_tol, threads=threads)
         np.testing.assert_array_equal(got, lab)
         assert gq == q and gruns == runs
-    # the kept run is at least as good as the single deterministic run, and its Q is the modularity of its labels
+    # the kept run is at least as good as the single deterministic run; its Q is the modularity part B reported for it
+    # (part A quantises the weights to multiples of 2**-20 before part B sees them), which part C can only raise
     single, q_single = _lib.louvain(A.indptr, A.indices, A.data, gamma, seed)
     assert q >= q_single
     mq = louvain_ref.modularity(A.indptr, A.indices, A.data, lab, gamma)
-    # (part A quantises the weights to multiples of 2**-20 before part B sees them)
-    assert abs(mq - q) < 1e-4
+    assert mq > q - 1e-4
     # without part A the rule applies to the graph as given (how the classifier finishes a graph coarsened on the GPU)
-    lab2, q2, runs2 = louvain_ref.louvain_best_of(A.indptr, A.indices, A.data, gamma, seed, q_tol, presweeps=0)
+    lab2, q2, runs2 = louvain_ref.louvain_best_of(A.indptr, A.indices, A.data, gamma, seed, q_tol, presweeps=0, refine_sweeps=0)
     got2, gq2, gruns2 = _lib.louvain_best_of(A.indptr, A.indices, A.data, gamma, seed, q_tol, threads=3, presweeps=False)
     np.testing.assert_array_equal(got2, lab2)
     assert gq2 == q2 and gruns2 == runs2
