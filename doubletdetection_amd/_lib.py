@@ -82,7 +82,7 @@ _SIGNATURES = {
     "ddx_leiden": (C.c_int, [C.c_int64, c_i64_p, c_i32_p, c_f64_p, C.c_double, C.c_uint64, c_i32_p]),
     "ddx_leiden_sequential": (C.c_int, [C.c_int64, c_i64_p, c_i32_p, c_f64_p, C.c_double, C.c_uint64, c_i32_p]),
     "ddx_presweep": (C.c_int, [C.c_int64, c_i64_p, c_i32_p, c_f64_p, C.c_double, C.c_int32, C.c_int32, c_i32_p, c_i64_p, c_i64_p, c_i32_p, c_f64_p]),
-    "ddx_refine": (C.c_int, [C.c_int64, c_i64_p, c_i32_p, c_f64_p, c_i32_p, C.c_double, C.c_int32, C.c_int32, c_i32_p]),
+    "ddx_refine": (C.c_int, [C.c_int64, c_i64_p, c_i32_p, c_f64_p, c_i32_p, C.c_double, C.c_int32, C.c_int32, C.c_int32, c_i32_p]),
     "ddx_coarsen_graph": (C.c_int, [C.c_void_p, C.c_double, C.c_int32, C.c_int32]),
     "ddx_refine_communities": (C.c_int, [C.c_void_p, c_i32_p, C.c_double, C.c_int32, c_i32_p]),
     "ddx_get_coarse_size": (C.c_int, [C.c_void_p, c_i64_p, c_i64_p]),
@@ -233,8 +233,9 @@ def leiden_sequential(indptr, indices, weights, gamma: float, seed: int):
     return _leiden_call("ddx_leiden_sequential", indptr, indices, weights, gamma, seed)
 
 
-def refine(indptr, indices, weights, labels, gamma: float, sweeps: int = REFINE_SWEEPS, subrounds: int = SUBROUNDS):
-    """Part C on the host: refinement sweeps on the original graph from `labels`.  Returns canonical labels int32[n]."""
+def refine(indptr, indices, weights, labels, gamma: float, sweeps: int = REFINE_SWEEPS, subrounds: int = SUBROUNDS, canonical: bool = True):
+    """One level of part C on the host: refinement sweeps on a graph from `labels` (ids < n are kept as community ids).
+    Returns labels int32[n], numbered by ascending smallest member unless ``canonical=False`` (raw ids, to chain levels)."""
     lib = load()
     indptr = np.ascontiguousarray(indptr, dtype=np.int64)
     indices = np.ascontiguousarray(indices, dtype=np.int32)
@@ -243,8 +244,27 @@ def refine(indptr, indices, weights, labels, gamma: float, sweeps: int = REFINE_
     n = indptr.shape[0] - 1
     out = np.empty(n, dtype=np.int32)
     _check(lib.ddx_refine(n, _p(indptr, c_i64_p), _p(indices, c_i32_p), _p(weights, c_f64_p), _p(labels, c_i32_p), float(gamma),
-                          int(sweeps), int(subrounds), _p(out, c_i32_p)))
+                          int(sweeps), int(subrounds), 1 if canonical else 0, _p(out, c_i32_p)))
     return out
+
+
+def refine_down(graphs, members, labels, gamma: float, sweeps: int = REFINE_SWEEPS):
+    """Part C over all levels on the host, as ddx_louvain runs it: `labels` label the nodes of graphs[-1]; graphs[l + 1] is
+    the aggregate of graphs[l] with member table members[l].  Returns the canonical labels of the nodes of graphs[0]."""
+    lab = np.asarray(labels, dtype=np.int32)
+    for level in range(len(members) - 1, -1, -1):
+        lab = refine(*graphs[level], lab[members[level]], gamma, sweeps, canonical=(level == 0))
+    return lab
+
+
+def presweep_levels(indptr, indices, weights, gamma: float, levels: int = None):
+    """Part A applied `levels` times on the host: (graphs, members) as refine_down takes them."""
+    graphs, members = [(indptr, indices, weights)], []
+    for _ in range(PRESWEEP_LEVELS if levels is None else levels):
+        m, *g = presweep(*graphs[-1], gamma)
+        members.append(m)
+        graphs.append(tuple(g))
+    return graphs, members
 
 
 def presweep(indptr, indices, weights, gamma: float, sweeps: int = PRESWEEPS, subrounds: int = SUBROUNDS):

@@ -202,6 +202,8 @@ struct ddx_ctx {
     // what part C needs of the levels of part A: graph of level l (l = 0: the graph above) and member table V_l -> V_{l+1}
     static constexpr int kLvKeep = 2;
     int lv_levels = 0;
+    int64_t lv_m2 = 0;                                   // 2m of the quantised graph (the same on every level)
+    int32_t lv_maxdeg[kLvKeep] = {0, 0}, lv_nbig[kLvKeep] = {0, 0};
     int64_t lv_n[kLvKeep] = {0, 0}, lv_E[kLvKeep] = {0, 0};
     const int64_t* lv_indptr[kLvKeep] = {nullptr, nullptr};
     const int32_t* lv_cols[kLvKeep] = {nullptr, nullptr};

@@ -31,28 +31,38 @@ __global__ void k_lv_quantise(const double* __restrict__ w, int64_t E, int64_t* 
     if (e < E) wq[e] = (int64_t)rint(w[e] * kWeightScale);
 }
 
-// strength of every node (self loops included), identity communities, 2m, largest degree
-__global__ void k_lv_strength(const int64_t* __restrict__ indptr, const int64_t* __restrict__ wq, int64_t n, int64_t* __restrict__ K,
-                              int32_t* __restrict__ comm /* null: leave the partition alone */, unsigned long long* __restrict__ m2,
-                              int32_t* __restrict__ maxdeg, int32_t* __restrict__ nbig, int32_t* __restrict__ big_list) {
+// strength of every node (self loops included); every node its own community (comm = id, total = strength, one member);
+// 2m, the largest degree and the list of the nodes with more than 64 neighbours (those take the hash-table sweep).
+// scal: [0] = 2m, [1] = max degree (low 32 bits) | number of big nodes (high 32 bits)
+__global__ void __launch_bounds__(256) k_lv_strength(const int64_t* __restrict__ indptr, const int64_t* __restrict__ wq, int64_t n, int64_t* __restrict__ K,
+                                                     int32_t* __restrict__ comm, unsigned long long* __restrict__ tot, int32_t* __restrict__ size,
+                                                     unsigned long long* __restrict__ scal, int32_t* __restrict__ big_list) {
     const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= n) return;
     int64_t s = 0;
-    const int64_t b = indptr[v], e = indptr[v + 1];
-    for (int64_t p = b; p < e; ++p) s += wq[p];
-    K[v] = s;
-    if (comm) comm[v] = (int32_t)v;
-    atomicAdd(m2, (unsigned long long)s);
-    atomicMax(maxdeg, (int32_t)(e - b));
-    if (e - b > 64) big_list[atomicAdd(nbig, 1)] = (int32_t)v;     // handled by the LDS variant of the sweep (any order)
-}
-
-__global__ void k_lv_totals(const int32_t* __restrict__ comm, const int64_t* __restrict__ K, int64_t n,
-                            unsigned long long* __restrict__ tot, int32_t* __restrict__ size) {
-    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= n) return;
-    atomicAdd(tot + comm[v], (unsigned long long)K[v]);
-    atomicAdd(size + comm[v], 1);
+    int deg = 0;
+    if (v < n) {
+        const int64_t b = indptr[v], e = indptr[v + 1];
+        for (int64_t p = b; p < e; ++p) s += wq[p];
+        deg = (int)(e - b);
+        K[v] = s;
+        comm[v] = (int32_t)v;
+        tot[v] = (unsigned long long)s;
+        size[v] = 1;
+        if (deg > 64) big_list[atomicAdd(reinterpret_cast<int32_t*>(scal + 1) + 1, 1)] = (int32_t)v;     // (any order)
+    }
+    // one atomic per wave on the two shared scalars instead of one per node
+    int64_t ws = s;
+    int wd = deg;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        ws += ((int64_t)__shfl_xor((int)(ws >> 32), off, 64) << 32) | (uint32_t)__shfl_xor((int)ws, off, 64);
+        const int od = __shfl_xor(wd, off, 64);
+        wd = od > wd ? od : wd;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(scal, (unsigned long long)ws);
+        atomicMax(reinterpret_cast<int32_t*>(scal + 1), wd);
+    }
 }
 
 __device__ __forceinline__ int64_t shfl64(int64_t v, int src) {
@@ -71,115 +81,48 @@ __device__ __forceinline__ void wave_best(double& s, int32_t& c) {
     }
 }
 
-// One synchronous sweep: one wave per node decides from (comm, tot, size) and writes next[v].  Nodes with at most 64
-// neighbours (nearly all) are handled in registers by the BIG = false instance, which needs no LDS and so keeps the
-// CU full of waves (the work is a chain of dependent loads); the few others are listed in big_list and go through LDS.
-template <bool BIG>
+// One synchronous sub-round for the nodes of one class, v = first + step * i (class = v mod step): one wave per node
+// decides from (comm, tot, size) and writes next[v]; k_lv_apply then carries the moves out.  Nodes with at most 64
+// neighbours (nearly all on the original graph) are handled here in registers, which needs no LDS and so keeps the CU full
+// of waves (the work is a chain of dependent loads); the others are listed in big_list and go through k_lv_sweep_big.
 __global__ void __launch_bounds__(256) k_lv_sweep(const int64_t* __restrict__ indptr, const int32_t* __restrict__ cols,
                                                   const int64_t* __restrict__ wq, const int64_t* __restrict__ K,
                                                   const int32_t* __restrict__ comm, const unsigned long long* __restrict__ tot,
                                                   const int32_t* __restrict__ size, int64_t n, double gamma, double m2d,
-                                                  const int32_t* __restrict__ big_list, int32_t* __restrict__ next,
-                                                  unsigned long long* __restrict__ tot_clear, int32_t* __restrict__ size_clear,
-                                                  int cls_shift /* sweep number */, int cls_mod /* sub-rounds */, int cls_now /* this sub-round */) {
-    __shared__ int32_t cS[1][BIG ? kLvCap : 1];
-    __shared__ int64_t wS[1][BIG ? kLvCap : 1];
+                                                  int first, int step, int32_t* __restrict__ next) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    int64_t v = BIG ? (int64_t)blockIdx.x : (int64_t)blockIdx.x * 4 + wave;        // BIG: 64-thread workgroups
+    const int64_t v = first + (int64_t)step * ((int64_t)blockIdx.x * 4 + wave);
     if (v >= n) return;
-    // the totals of the NEXT sweep are accumulated into the other pair of arrays: clear entry v of it here (this
-    // instance visits every node id once), which replaces two memset launches per sweep
-    if (!BIG && lane == 0 && tot_clear) { tot_clear[v] = 0ull; size_clear[v] = 0; }
-    if (BIG) v = big_list[v];
     const int64_t b = indptr[v];
     const int deg = (int)(indptr[v + 1] - b);
-    if (!BIG && deg > 64) return;
+    if (deg > 64) return;                            // k_lv_sweep_big's
     const int32_t own = comm[v];
-    // sub-rounds: only the nodes of this sub-round's class decide, everybody else stays where it is
-    if ((int)(((((uint32_t)v * 2654435761u) >> 16) + (uint32_t)cls_shift) % (uint32_t)cls_mod) != cls_now) {
-        if (lane == 0) next[v] = own;
-        return;
-    }
     const int64_t kvi = K[v];
     const double kv = (double)kvi;
     double best_s = 0.0;
     int32_t best_c = -1;
     int64_t w_own = 0;
-    if (!BIG) {
-        int32_t c = -1;
-        int64_t w = 0;
-        if (lane < deg) {
-            const int32_t u = cols[b + lane];
-            w = wq[b + lane];
-            c = (u == (int32_t)v) ? -1 : comm[u];
+    int32_t c = -1;
+    int64_t w = 0;
+    if (lane < deg) {
+        const int32_t u = cols[b + lane];
+        w = wq[b + lane];
+        c = (u == (int32_t)v) ? -1 : comm[u];
+    }
+    int64_t W = 0;
+    bool leader = c >= 0;
+    for (int j = 0; j < deg; ++j) {
+        const int32_t cj = __shfl(c, j, 64);
+        const int64_t wj = shfl64(w, j);
+        if (cj == c) {
+            W += wj;
+            if (j < lane) leader = false;
         }
-        int64_t W = 0;
-        bool leader = c >= 0;
-        for (int j = 0; j < deg; ++j) {
-            const int32_t cj = __shfl(c, j, 64);
-            const int64_t wj = shfl64(w, j);
-            if (cj == c) {
-                W += wj;
-                if (j < lane) leader = false;
-            }
-            if (cj == own) w_own += wj;
-        }
-        if (leader && c != own) {
-            best_s = (double)W * m2d - (gamma * (double)(int64_t)tot[c]) * kv;
-            best_c = c;
-        }
-    } else {
-        // LDS path: sort the (community, weight) pairs of the node by community (wave-wide bitonic sort), then every
-        // run of equal communities is summed by the lane that finds its first element.  O(d log^2 d / 64) per lane.
-        const int d = deg < kLvCap ? deg : kLvCap;       // deg > kLvCap is rejected on the host before the launch
-        int P = 64;
-        while (P < d) P <<= 1;
-        for (int i = lane; i < P; i += 64) {
-            int32_t c = 0x7fffffff;                      // padding sorts last
-            int64_t wv = 0;
-            if (i < d) {
-                const int32_t u = cols[b + i];
-                c = (u == (int32_t)v) ? 0x7ffffffe : comm[u];     // self loops: a class of their own, ignored below
-                wv = wq[b + i];
-            }
-            cS[0][i] = c;
-            wS[0][i] = wv;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        for (int size = 2; size <= P; size <<= 1) {
-            for (int stride = size >> 1; stride > 0; stride >>= 1) {
-                for (int t = lane; t < (P >> 1); t += 64) {
-                    const int lo = ((t / stride) * stride * 2) + (t % stride);
-                    const int hi = lo + stride;
-                    const bool up = ((lo & size) == 0);
-                    const int32_t cl = cS[0][lo], ch = cS[0][hi];
-                    if ((cl > ch) == up) {
-                        const int64_t wl = wS[0][lo], wh = wS[0][hi];
-                        cS[0][lo] = ch; cS[0][hi] = cl;
-                        wS[0][lo] = wh; wS[0][hi] = wl;
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-        for (int i = lane; i < d; i += 64) {
-            const int32_t c = cS[0][i];
-            if (c >= 0x7ffffffe) continue;               // self loops / padding
-            if (i > 0 && cS[0][i - 1] == c) continue;    // not the first element of its run
-            int64_t W = 0;
-            for (int j = i; j < d && cS[0][j] == c; ++j) W += wS[0][j];
-            if (c == own) {
-                w_own = W;
-            } else {
-                const double s = (double)W * m2d - (gamma * (double)(int64_t)tot[c]) * kv;
-                if (best_c < 0 || s > best_s || (s == best_s && c < best_c)) { best_s = s; best_c = c; }
-            }
-        }
-        // the lane that led the own community holds w_own; everybody else 0
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) w_own += shfl64(w_own, lane ^ off);
+        if (cj == own) w_own += wj;
+    }
+    if (leader && c != own) {
+        best_s = (double)W * m2d - (gamma * (double)(int64_t)tot[c]) * kv;
+        best_c = c;
     }
     wave_best(best_s, best_c);
     if (lane == 0) {
@@ -188,6 +131,79 @@ __global__ void __launch_bounds__(256) k_lv_sweep(const int64_t* __restrict__ in
         if (best_c >= 0 && best_s > own_score && !(size[own] == 1 && size[best_c] == 1 && best_c > own)) target = best_c;
         next[v] = target;
     }
+}
+
+// The same decision for a node with more than 64 neighbours (coarse levels, hubs): one wave per listed node of the class
+// groups the neighbours' communities in an LDS hash table (integer sums: the insertion order does not matter), then the
+// lanes scan the table.  slots = power of two >= 2 * (largest degree of the level), 12 bytes each.
+__global__ void __launch_bounds__(64) k_lv_sweep_big(const int64_t* __restrict__ indptr, const int32_t* __restrict__ cols,
+                                                     const int64_t* __restrict__ wq, const int64_t* __restrict__ K,
+                                                     const int32_t* __restrict__ comm, const unsigned long long* __restrict__ tot,
+                                                     const int32_t* __restrict__ size, double gamma, double m2d, int first, int step,
+                                                     const int32_t* __restrict__ big_list, int slots, int32_t* __restrict__ next) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lv_smem[];
+    unsigned long long* wS = reinterpret_cast<unsigned long long*>(lv_smem);
+    int32_t* cS = reinterpret_cast<int32_t*>(wS + slots);
+    const int lane = threadIdx.x;
+    const int64_t v = big_list[blockIdx.x];
+    if ((int)(v % step) != first) return;
+    for (int i = lane; i < slots; i += 64) { cS[i] = -1; wS[i] = 0ull; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int64_t b = indptr[v];
+    const int deg = (int)(indptr[v + 1] - b);
+    const int32_t own = comm[v];
+    const unsigned mask = (unsigned)slots - 1u;
+    for (int i = lane; i < deg; i += 64) {
+        const int32_t u = cols[b + i];
+        if (u == (int32_t)v) continue;
+        const int32_t c = comm[u];
+        unsigned h = ((unsigned)c * 2654435761u) & mask;
+        for (;;) {
+            const int32_t old = atomicCAS(&cS[h], -1, c);
+            if (old == -1 || old == c) { atomicAdd(&wS[h], (unsigned long long)wq[b + i]); break; }
+            h = (h + 1u) & mask;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int64_t kvi = K[v];
+    const double kv = (double)kvi;
+    double best_s = 0.0;
+    int32_t best_c = -1;
+    int64_t w_own = 0;
+    for (int i = lane; i < slots; i += 64) {
+        const int32_t c = cS[i];
+        if (c < 0) continue;
+        const int64_t W = (int64_t)wS[i];
+        if (c == own) { w_own = W; continue; }
+        const double sc = (double)W * m2d - (gamma * (double)(int64_t)tot[c]) * kv;
+        if (best_c < 0 || sc > best_s || (sc == best_s && c < best_c)) { best_s = sc; best_c = c; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) w_own += shfl64(w_own, lane ^ off);      // one lane met the own community (or none)
+    wave_best(best_s, best_c);
+    if (lane == 0) {
+        const double own_score = (double)w_own * m2d - (gamma * (double)((int64_t)tot[own] - kvi)) * kv;
+        int32_t target = own;
+        if (best_c >= 0 && best_s > own_score && !(size[own] == 1 && size[best_c] == 1 && best_c > own)) target = best_c;
+        next[v] = target;
+    }
+}
+
+// carry out the moves of a sub-round: the totals follow the movers (integer atomics, exact in any order), nobody else
+__global__ void k_lv_apply(const int32_t* __restrict__ next, const int64_t* __restrict__ K, int64_t n, int first, int step,
+                           int32_t* __restrict__ comm, unsigned long long* __restrict__ tot, int32_t* __restrict__ size) {
+    const int64_t v = first + (int64_t)step * ((int64_t)blockIdx.x * blockDim.x + threadIdx.x);
+    if (v >= n) return;
+    const int32_t t = next[v], o = comm[v];
+    if (t == o) return;
+    const unsigned long long k = (unsigned long long)K[v];
+    atomicAdd(tot + t, k);
+    atomicAdd(tot + o, 0ull - k);
+    atomicAdd(size + t, 1);
+    atomicAdd(size + o, -1);
+    comm[v] = t;
 }
 
 __global__ void k_lv_used(const int32_t* __restrict__ comm, int64_t n, int32_t* __restrict__ used) {
@@ -240,56 +256,113 @@ struct LvGraph {            // a CSR on the device
     const double* w = nullptr;
 };
 
+constexpr int kLvKeep = ddx_ctx::kLvKeep;     // levels of part A whose graphs, strengths and member counts part C finds again
+
 struct LvScratch {          // sized for the finest level, reused by the coarser ones
-    int64_t *wq, *vals_b, *sums, *K;
+    int64_t *vals_b, *sums;
     uint64_t *keys_a, *keys_b;
-    unsigned long long *tot, *tot2, *scal;
-    int32_t *comm, *next, *size, *size2, *used, *renum, *big_list;
+    unsigned long long *tot, *scal;
+    int32_t *comm, *next, *size, *used, *renum, *lab;
+    // kept per level for part C (level l = the graph the (l+1)-th application of part A started from)
+    int64_t* wq[kLvKeep];       // quantised weights of the level's graph
+    int64_t* K[kLvKeep];        // node strengths
+    int32_t* csize[kLvKeep];    // members of every node of the level above
+    int32_t* big[kLvKeep];      // nodes with more than 64 neighbours
+    int64_t* Ktop;              // strengths of the nodes of the last aggregated graph
 };
+
+struct LvSets {             // two output sets the levels write alternately + the composed member tables
+    int32_t* member[2];
+    int64_t* indptr[2];
+    int32_t* cols[2];
+    double* w[2];
+    int32_t *total_a, *total_b;
+};
+
+// Layout of the work buffer for a graph of n nodes / E entries.  Every piece is rounded up to 256 bytes; the buffer is
+// sized from the very arithmetic that carves it.  Returns the bytes needed; binds the pointers when base != null.
+static size_t lv_bind(unsigned char* base, int64_t n, int64_t E, LvScratch& sc, LvSets& o) {
+    size_t bytes = 0;
+    auto piece = [&](size_t sz) { const size_t at = bytes; bytes += (sz + 255) & ~(size_t)255; return base ? base + at : nullptr; };
+    sc.keys_a = reinterpret_cast<uint64_t*>(piece(sizeof(uint64_t) * E));
+    sc.keys_b = reinterpret_cast<uint64_t*>(piece(sizeof(uint64_t) * E));
+    sc.vals_b = reinterpret_cast<int64_t*>(piece(sizeof(int64_t) * E));
+    sc.sums = reinterpret_cast<int64_t*>(piece(sizeof(int64_t) * E));
+    sc.tot = reinterpret_cast<unsigned long long*>(piece(sizeof(int64_t) * n));
+    sc.comm = reinterpret_cast<int32_t*>(piece(sizeof(int32_t) * n));
+    sc.next = reinterpret_cast<int32_t*>(piece(sizeof(int32_t) * n));
+    sc.size = reinterpret_cast<int32_t*>(piece(sizeof(int32_t) * n));
+    sc.used = reinterpret_cast<int32_t*>(piece(sizeof(int32_t) * (n + 1)));
+    sc.renum = reinterpret_cast<int32_t*>(piece(sizeof(int32_t) * (n + 1)));
+    sc.lab = reinterpret_cast<int32_t*>(piece(sizeof(int32_t) * n));
+    sc.scal = reinterpret_cast<unsigned long long*>(piece(256));        // [0] = 2m, [1] = max degree | #big nodes, [2] = runs
+    for (int l = 0; l < kLvKeep; ++l) {
+        sc.wq[l] = reinterpret_cast<int64_t*>(piece(sizeof(int64_t) * E));
+        sc.K[l] = reinterpret_cast<int64_t*>(piece(sizeof(int64_t) * n));
+        sc.csize[l] = reinterpret_cast<int32_t*>(piece(sizeof(int32_t) * n));
+        sc.big[l] = reinterpret_cast<int32_t*>(piece(sizeof(int32_t) * n));
+    }
+    sc.Ktop = reinterpret_cast<int64_t*>(piece(sizeof(int64_t) * n));
+    for (int i = 0; i < 2; ++i) {
+        o.member[i] = reinterpret_cast<int32_t*>(piece(sizeof(int32_t) * n));
+        o.indptr[i] = reinterpret_cast<int64_t*>(piece(sizeof(int64_t) * (n + 1)));
+        o.cols[i] = reinterpret_cast<int32_t*>(piece(sizeof(int32_t) * E));
+        o.w[i] = reinterpret_cast<double*>(piece(sizeof(double) * E));
+    }
+    o.total_a = reinterpret_cast<int32_t*>(piece(sizeof(int32_t) * n));
+    o.total_b = reinterpret_cast<int32_t*>(piece(sizeof(int32_t) * n));
+    return bytes;
+}
 
 constexpr int kSubrounds = DDX_SUBROUNDS;
 
-// `sweeps` sweeps of `subrounds` synchronous sub-rounds from the partition in sc.comm; `cur` receives the array
-// (sc.comm or sc.next) that holds the result.  Every sub-round recomputes the community totals from scratch: they
-// ping-pong between two pairs of arrays, sub-round t reads pair t & 1 and clears the other one for sub-round t + 1
-// (tot | tot2 and size | size2 are adjacent pieces of the scratch buffer: one memset each clears both before the first).
-static int lv_sweeps(ddx_ctx* ctx, const LvGraph& in, double gamma, int32_t sweeps, int subrounds, const LvScratch& sc, int64_t m2,
-                     int32_t nbig, int32_t*& cur) {
+// `sweeps` sweeps of `subrounds` synchronous sub-rounds on `in` from the partition in sc.comm with its totals in sc.tot /
+// sc.size (oracle/louvain_ref.py:_sync_sweeps): in sub-round r of sweep s the nodes with (v + s) mod subrounds == r decide
+// at once -- they are v = first, first + subrounds, ... , so a launch covers exactly them -- and k_lv_apply then moves
+// them and their share of the totals.  (A sweep that moves nothing changes nothing, so running all of them equals the
+// specification's early stop.)
+static int lv_sweeps(ddx_ctx* ctx, const LvGraph& in, const int64_t* wq, const int64_t* K, double gamma, int32_t sweeps, int subrounds,
+                     const LvScratch& sc, int64_t m2, const int32_t* big_list, int32_t nbig, int32_t maxdeg) {
     const int64_t n = in.n;
     hipStream_t st = ctx->stream;
-    cur = sc.comm;
-    int32_t* nxt = sc.next;
     if (sweeps <= 0 || m2 <= 0) return DDX_OK;
-    DDX_HIP(ctx, hipMemsetAsync(sc.tot, 0, (size_t)(reinterpret_cast<unsigned char*>(sc.tot2) - reinterpret_cast<unsigned char*>(sc.tot)) + sizeof(int64_t) * n, st));
-    DDX_HIP(ctx, hipMemsetAsync(sc.size, 0, (size_t)(reinterpret_cast<unsigned char*>(sc.size2) - reinterpret_cast<unsigned char*>(sc.size)) + sizeof(int32_t) * n, st));
-    int t = 0;
+    int slots = 128;
+    while (slots < 2 * maxdeg) slots <<= 1;
+    const size_t big_lds = (size_t)slots * 12;
+    if (nbig > 0 && big_lds > 64 * 1024) DDX_TRY(allow_dynamic_lds(ctx, reinterpret_cast<const void*>(&k_lv_sweep_big), 12 * 2 * kLvCap));
     for (int s = 0; s < sweeps; ++s) {
-        for (int r = 0; r < subrounds; ++r, ++t) {
-            unsigned long long* tot = (t & 1) ? sc.tot2 : sc.tot;
-            unsigned long long* tot_other = (t & 1) ? sc.tot : sc.tot2;
-            int32_t* size = (t & 1) ? sc.size2 : sc.size;
-            int32_t* size_other = (t & 1) ? sc.size : sc.size2;
-            k_lv_totals<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(cur, sc.K, n, tot, size);
-            k_lv_sweep<false><<<(unsigned)ceil_div(n, 4), 256, 0, st>>>(in.indptr, in.cols, sc.wq, sc.K, cur, tot, size, n, gamma, (double)m2, sc.big_list, nxt,
-                                                                        tot_other, size_other, s, subrounds, r);
+        for (int r = 0; r < subrounds; ++r) {
+            const int first = ((r - s) % subrounds + subrounds) % subrounds;
+            const int64_t cnt = first < n ? (n - first + subrounds - 1) / subrounds : 0;      // nodes of this class
+            if (cnt <= 0) continue;
+            k_lv_sweep<<<(unsigned)ceil_div(cnt, 4), 256, 0, st>>>(in.indptr, in.cols, wq, K, sc.comm, sc.tot, sc.size, n, gamma, (double)m2, first, subrounds, sc.next);
             if (nbig > 0)
-                k_lv_sweep<true><<<(unsigned)nbig, 64, 0, st>>>(in.indptr, in.cols, sc.wq, sc.K, cur, tot, size, nbig, gamma, (double)m2, sc.big_list, nxt,
-                                                                nullptr, nullptr, s, subrounds, r);
-            std::swap(cur, nxt);      // a sweep that moves nothing reproduces its input, so running all of them equals stopping early
+                k_lv_sweep_big<<<(unsigned)nbig, 64, big_lds, st>>>(in.indptr, in.cols, wq, K, sc.comm, sc.tot, sc.size, gamma, (double)m2, first, subrounds,
+                                                                    big_list, slots, sc.next);
+            k_lv_apply<<<(unsigned)ceil_div(cnt, 256), 256, 0, st>>>(sc.next, K, n, first, subrounds, sc.comm, sc.tot, sc.size);
         }
     }
     return DDX_OK;
 }
 
+// members and strength of every node of the aggregated graph: csize[renum[c]] = size[c], Knext[renum[c]] = tot[c]
+__global__ void k_lv_carry(const int32_t* __restrict__ used, const int32_t* __restrict__ renum, const int32_t* __restrict__ size,
+                           const unsigned long long* __restrict__ tot, int64_t n, int32_t* __restrict__ csize, int64_t* __restrict__ Knext) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n || !used[c]) return;
+    const int32_t r = renum[c];
+    if (csize) csize[r] = size[c];
+    Knext[r] = (int64_t)tot[c];
+}
+
 // one level: `sweeps` synchronous sweeps on `in`, exact aggregation into (member, out)
-static int coarsen_level(ddx_ctx* ctx, const LvGraph& in, double gamma, int32_t sweeps, const LvScratch& sc, int32_t* member,
-                         int64_t* c_indptr, int32_t* c_cols, double* c_w, LvGraph& out) {
+static int coarsen_level(ddx_ctx* ctx, const LvGraph& in, double gamma, int32_t sweeps, const LvScratch& sc, int64_t* wq, int64_t* K, int32_t* csize,
+                         int32_t* big_list, int64_t& m2_out, int32_t& maxdeg_out, int32_t& nbig_out, int32_t* member, int64_t* c_indptr, int32_t* c_cols, double* c_w, LvGraph& out) {
     const int64_t n = in.n, E = in.E;
     hipStream_t st = ctx->stream;
     DDX_HIP(ctx, hipMemsetAsync(sc.scal, 0, 256, st));
-    if (E > 0) k_lv_quantise<<<(unsigned)ceil_div(E, 256), 256, 0, st>>>(in.w, E, sc.wq);
-    k_lv_strength<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(in.indptr, sc.wq, n, sc.K, sc.comm, sc.scal, reinterpret_cast<int32_t*>(sc.scal + 1),
-                                                              reinterpret_cast<int32_t*>(sc.scal + 1) + 1, sc.big_list);
+    if (E > 0) k_lv_quantise<<<(unsigned)ceil_div(E, 256), 256, 0, st>>>(in.w, E, wq);
+    k_lv_strength<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(in.indptr, wq, n, K, sc.comm, sc.tot, sc.size, sc.scal, big_list);
     unsigned long long h_scal[2] = {0, 0};
     DDX_HIP(ctx, hipMemcpyAsync(h_scal, sc.scal, sizeof(h_scal), hipMemcpyDeviceToHost, st));
     DDX_HIP(ctx, hipStreamSynchronize(st));
@@ -297,8 +370,9 @@ static int coarsen_level(ddx_ctx* ctx, const LvGraph& in, double gamma, int32_t 
     const int32_t maxdeg = (int32_t)(h_scal[1] & 0xffffffffull);
     const int32_t nbig = (int32_t)(h_scal[1] >> 32);
     if (maxdeg > kLvCap) return set_err(ctx, DDX_E_UNSUPPORTED, "a node with %d neighbours exceeds the device sweep's capacity (%d)", maxdeg, kLvCap);
-    int32_t* cur = sc.comm;
-    DDX_TRY(lv_sweeps(ctx, in, gamma, sweeps, kSubrounds, sc, m2, nbig, cur));
+    m2_out = m2; maxdeg_out = maxdeg; nbig_out = nbig;
+    DDX_TRY(lv_sweeps(ctx, in, wq, K, gamma, sweeps, kSubrounds, sc, m2, big_list, nbig, maxdeg));
+    const int32_t* cur = sc.comm;
     // renumber the surviving communities by ascending id
     DDX_HIP(ctx, hipMemsetAsync(sc.used, 0, sizeof(int32_t) * (n + 1), st));
     k_lv_used<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(cur, n, sc.used);
@@ -309,16 +383,17 @@ static int coarsen_level(ddx_ctx* ctx, const LvGraph& in, double gamma, int32_t 
     const int end_bit = 2 * shift;
     int64_t* runs_d = reinterpret_cast<int64_t*>(sc.scal + 2);
     if (E > 0) {
-        DDX_HIP(ctx, prim::sort_pairs(nullptr, tmp_sort, sc.keys_a, sc.keys_b, sc.wq, sc.vals_b, (int)E, 0, end_bit, st));
+        DDX_HIP(ctx, prim::sort_pairs(nullptr, tmp_sort, sc.keys_a, sc.keys_b, wq, sc.vals_b, (int)E, 0, end_bit, st));
         DDX_HIP(ctx, prim::reduce_by_key_sum(nullptr, tmp_red, sc.keys_b, sc.keys_a, sc.vals_b, sc.sums, runs_d, (size_t)E, st));
     }
     DDX_TRY(ensure(ctx, ctx->sort_tmp, std::max(tmp_scan, std::max(tmp_sort, tmp_red))));
     DDX_HIP(ctx, prim::exclusive_sum(ctx->sort_tmp.p, tmp_scan, sc.used, sc.renum, (int)n + 1, st));
     k_lv_member<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(cur, sc.renum, n, member);
+    k_lv_carry<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(sc.used, sc.renum, sc.size, sc.tot, n, csize, sc.Ktop);
     int64_t runs = 0;
     if (E > 0) {
         k_lv_edge_keys<<<(unsigned)ceil_div(n, 4), 256, 0, st>>>(in.indptr, in.cols, member, n, shift, sc.keys_a);
-        DDX_HIP(ctx, prim::sort_pairs(ctx->sort_tmp.p, tmp_sort, sc.keys_a, sc.keys_b, sc.wq, sc.vals_b, (int)E, 0, end_bit, st));
+        DDX_HIP(ctx, prim::sort_pairs(ctx->sort_tmp.p, tmp_sort, sc.keys_a, sc.keys_b, wq, sc.vals_b, (int)E, 0, end_bit, st));
         DDX_HIP(ctx, prim::reduce_by_key_sum(ctx->sort_tmp.p, tmp_red, sc.keys_b, sc.keys_a, sc.vals_b, sc.sums, runs_d, (size_t)E, st));
     }
     int32_t nc = 0;
@@ -350,47 +425,6 @@ __global__ void k_lv_pack(const double* __restrict__ w, const int64_t* __restric
     if (t < n) om[t] = member[t];
 }
 
-struct LvSets {             // two output sets the levels write alternately + the composed member tables
-    int32_t* member[2];
-    int64_t* indptr[2];
-    int32_t* cols[2];
-    double* w[2];
-    int32_t *total_a, *total_b;
-};
-
-// Layout of the work buffer for a graph of n nodes / E entries: scratch (wq, keys x2, vals, sums: E each; K, tot x2: n;
-// comm, next, size x2, used, renum, big_list: n) + the output sets.  Every piece is rounded up to 256 bytes; the buffer
-// is sized from the very arithmetic that carves it.  Returns the bytes needed; binds the pointers when base != null.
-static size_t lv_bind(unsigned char* base, int64_t n, int64_t E, LvScratch& sc, LvSets& o) {
-    size_t bytes = 0;
-    auto piece = [&](size_t sz) { const size_t at = bytes; bytes += (sz + 255) & ~(size_t)255; return base ? base + at : nullptr; };
-    sc.wq = reinterpret_cast<int64_t*>(piece(sizeof(int64_t) * E));
-    sc.keys_a = reinterpret_cast<uint64_t*>(piece(sizeof(uint64_t) * E));
-    sc.keys_b = reinterpret_cast<uint64_t*>(piece(sizeof(uint64_t) * E));
-    sc.vals_b = reinterpret_cast<int64_t*>(piece(sizeof(int64_t) * E));
-    sc.sums = reinterpret_cast<int64_t*>(piece(sizeof(int64_t) * E));
-    sc.K = reinterpret_cast<int64_t*>(piece(sizeof(int64_t) * n));
-    sc.tot = reinterpret_cast<unsigned long long*>(piece(sizeof(int64_t) * n));
-    sc.tot2 = reinterpret_cast<unsigned long long*>(piece(sizeof(int64_t) * n));
-    sc.comm = reinterpret_cast<int32_t*>(piece(sizeof(int32_t) * n));
-    sc.next = reinterpret_cast<int32_t*>(piece(sizeof(int32_t) * n));
-    sc.size = reinterpret_cast<int32_t*>(piece(sizeof(int32_t) * n));
-    sc.size2 = reinterpret_cast<int32_t*>(piece(sizeof(int32_t) * n));
-    sc.used = reinterpret_cast<int32_t*>(piece(sizeof(int32_t) * (n + 1)));
-    sc.renum = reinterpret_cast<int32_t*>(piece(sizeof(int32_t) * (n + 1)));
-    sc.big_list = reinterpret_cast<int32_t*>(piece(sizeof(int32_t) * n));
-    sc.scal = reinterpret_cast<unsigned long long*>(piece(256));        // [0] = 2m, [1] = max degree | #big nodes, [2] = runs
-    for (int i = 0; i < 2; ++i) {
-        o.member[i] = reinterpret_cast<int32_t*>(piece(sizeof(int32_t) * n));
-        o.indptr[i] = reinterpret_cast<int64_t*>(piece(sizeof(int64_t) * (n + 1)));
-        o.cols[i] = reinterpret_cast<int32_t*>(piece(sizeof(int32_t) * E));
-        o.w[i] = reinterpret_cast<double*>(piece(sizeof(double) * E));
-    }
-    o.total_a = reinterpret_cast<int32_t*>(piece(sizeof(int32_t) * n));
-    o.total_b = reinterpret_cast<int32_t*>(piece(sizeof(int32_t) * n));
-    return bytes;
-}
-
 int stage_coarsen_graph(ddx_ctx* ctx, double gamma, int32_t sweeps, int32_t levels) {
     const int64_t n = ctx->g_nodes;
     const int64_t E = ctx->g_entries;
@@ -400,12 +434,6 @@ int stage_coarsen_graph(ddx_ctx* ctx, double gamma, int32_t sweeps, int32_t leve
     LvSets sets;
     DDX_TRY(ensure(ctx, ctx->lv_buf, lv_bind(nullptr, n, E, sc, sets)));
     lv_bind(ctx->lv_buf.as<unsigned char>(), n, E, sc, sets);
-    int32_t** member_set = sets.member;
-    int64_t** indptr_set = sets.indptr;
-    int32_t** cols_set = sets.cols;
-    double** w_set = sets.w;
-    int32_t* total_a = sets.total_a;
-    int32_t* total_b = sets.total_b;
     ScopedTimer t(ctx, "graph_coarsen");
     LvGraph cur;
     cur.n = n; cur.E = E; cur.indptr = ctx->g_d_indptr; cur.cols = ctx->g_d_cols; cur.w = ctx->g_d_vals;
@@ -413,18 +441,24 @@ int stage_coarsen_graph(ddx_ctx* ctx, double gamma, int32_t sweeps, int32_t leve
     ctx->lv_levels = levels;
     for (int lvl = 0; lvl < levels; ++lvl) {
         const int o = lvl & 1;
+        const int keep = lvl < kLvKeep ? lvl : kLvKeep - 1;       // (deeper levels reuse the last kept slot: part C refuses them)
         LvGraph nextg;
-        if (lvl < ddx_ctx::kLvKeep) {           // (two output sets: the graphs of levels 0 and 1 survive two levels of part A)
+        if (lvl < kLvKeep) {           // (two output sets: the graphs of levels 0 and 1 survive two levels of part A)
             ctx->lv_n[lvl] = cur.n; ctx->lv_E[lvl] = cur.E;
             ctx->lv_indptr[lvl] = cur.indptr; ctx->lv_cols[lvl] = cur.cols; ctx->lv_w[lvl] = cur.w;
-            ctx->lv_member[lvl] = member_set[o];
+            ctx->lv_member[lvl] = sets.member[o];
         }
-        DDX_TRY(coarsen_level(ctx, cur, gamma, sweeps, sc, member_set[o], indptr_set[o], cols_set[o], w_set[o], nextg));
+        int64_t m2 = 0;
+        int32_t maxdeg = 0, nbig = 0;
+        DDX_TRY(coarsen_level(ctx, cur, gamma, sweeps, sc, sc.wq[keep], sc.K[keep], sc.csize[keep], sc.big[keep], m2, maxdeg, nbig, sets.member[o],
+                              sets.indptr[o], sets.cols[o], sets.w[o], nextg));
+        if (lvl == 0) ctx->lv_m2 = m2;
+        if (lvl < kLvKeep) { ctx->lv_maxdeg[lvl] = maxdeg; ctx->lv_nbig[lvl] = nbig; }
         if (!total) {
-            total = member_set[o];
+            total = sets.member[o];
         } else {
-            int32_t* dst = (total == total_a) ? total_b : total_a;
-            k_lv_compose<<<(unsigned)ceil_div(n, 256), 256, 0, ctx->stream>>>(total, member_set[o], n, dst);
+            int32_t* dst = (total == sets.total_a) ? sets.total_b : sets.total_a;
+            k_lv_compose<<<(unsigned)ceil_div(n, 256), 256, 0, ctx->stream>>>(total, sets.member[o], n, dst);
             total = dst;
         }
         cur = nextg;
@@ -456,19 +490,24 @@ int stage_coarsen_graph(ddx_ctx* ctx, double gamma, int32_t sweeps, int32_t leve
 }
 
 // ---- part C on the device ----------------------------------------------------------------------------------------------
-// lab[v] = coarse_labels[member[v]]; first[l] = smallest v carrying label l
-__global__ void k_lv_project(const int32_t* __restrict__ member, const int32_t* __restrict__ coarse_labels, int64_t n, int32_t* __restrict__ lab,
-                             int32_t* __restrict__ first) {
-    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= n) return;
-    const int32_t l = coarse_labels[member[v]];
-    lab[v] = l;
-    atomicMin(first + l, (int32_t)v);
+// Communities keep the ids part B gave them (the label space of the coarsest graph) on the way down, so their totals are
+// carried from level to level unchanged (the aggregation preserves strengths); only the member counts are per level.
+// tot[lab[x]] += Ktop[x] over the nodes of the coarsest graph
+__global__ void k_lv_top_totals(const int32_t* __restrict__ lab, const int64_t* __restrict__ Ktop, int64_t nc, unsigned long long* __restrict__ tot) {
+    const int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x < nc) atomicAdd(tot + lab[x], (unsigned long long)Ktop[x]);
 }
 
-__global__ void k_lv_name(const int32_t* __restrict__ lab, const int32_t* __restrict__ first, int64_t n, int32_t* __restrict__ comm) {
+// size[lab[x]] += csize[x] over the nodes x of the level above (csize = how many nodes of this level x stands for)
+__global__ void k_lv_level_sizes(const int32_t* __restrict__ lab, const int32_t* __restrict__ csize, int64_t n_up, int32_t* __restrict__ size) {
+    const int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x < n_up) atomicAdd(size + lab[x], csize[x]);
+}
+
+// comm[v] = lab[member[v]]
+__global__ void k_lv_project(const int32_t* __restrict__ member, const int32_t* __restrict__ lab, int64_t n, int32_t* __restrict__ comm) {
     const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (v < n) comm[v] = first[lab[v]];
+    if (v < n) comm[v] = lab[member[v]];
 }
 
 int stage_refine_communities(ddx_ctx* ctx, const int32_t* coarse_labels, double gamma, int32_t sweeps, int32_t* labels_out) {
@@ -477,38 +516,32 @@ int stage_refine_communities(ddx_ctx* ctx, const int32_t* coarse_labels, double 
     LvScratch sc;
     LvSets sets;
     if (lv_bind(nullptr, n, E, sc, sets) > ctx->lv_buf.cap) return set_err(ctx, DDX_E_ARG, "the coarsening work space is gone");
-    if (ctx->lv_levels < 1 || ctx->lv_levels > ddx_ctx::kLvKeep)
-        return set_err(ctx, DDX_E_UNSUPPORTED, "part C on the device follows at most %d levels of part A (%d were run)", ddx_ctx::kLvKeep, ctx->lv_levels);
+    if (ctx->lv_levels < 1 || ctx->lv_levels > kLvKeep)
+        return set_err(ctx, DDX_E_UNSUPPORTED, "part C on the device follows at most %d levels of part A (%d were run)", kLvKeep, ctx->lv_levels);
     lv_bind(ctx->lv_buf.as<unsigned char>(), n, E, sc, sets);
     for (int64_t c = 0; c < nc; ++c)
         if (coarse_labels[c] < 0 || coarse_labels[c] >= nc) return set_err(ctx, DDX_E_ARG, "coarse label %d out of range at %lld", coarse_labels[c], (long long)c);
     ScopedTimer t(ctx, "graph_refine");
-    // the scratch of part A is free again: labels of the level above -> renum, smallest member per label -> used
-    DDX_HIP(ctx, hipMemcpyAsync(sc.renum, coarse_labels, sizeof(int32_t) * nc, hipMemcpyHostToDevice, st));
+    // 2m of the original graph = sum of all strengths (the same on every level)
+    DDX_HIP(ctx, hipMemcpyAsync(sc.lab, coarse_labels, sizeof(int32_t) * nc, hipMemcpyHostToDevice, st));
+    DDX_HIP(ctx, hipMemsetAsync(sc.tot, 0, sizeof(int64_t) * nc, st));
+    k_lv_top_totals<<<(unsigned)ceil_div(nc, 256), 256, 0, st>>>(sc.lab, sc.Ktop, nc, sc.tot);
+    int64_t n_up = nc;
     for (int level = ctx->lv_levels - 1; level >= 0; --level) {
         LvGraph g;
         g.n = ctx->lv_n[level]; g.E = ctx->lv_E[level]; g.indptr = ctx->lv_indptr[level]; g.cols = ctx->lv_cols[level]; g.w = ctx->lv_w[level];
-        DDX_HIP(ctx, hipMemsetAsync(sc.used, 0x7f, sizeof(int32_t) * (g.n + 1), st));
-        DDX_HIP(ctx, hipMemsetAsync(sc.scal, 0, 256, st));
-        k_lv_project<<<(unsigned)ceil_div(g.n, 256), 256, 0, st>>>(ctx->lv_member[level], sc.renum, g.n, sc.next, sc.used);
-        k_lv_name<<<(unsigned)ceil_div(g.n, 256), 256, 0, st>>>(sc.next, sc.used, g.n, sc.comm);
-        if (g.E > 0) k_lv_quantise<<<(unsigned)ceil_div(g.E, 256), 256, 0, st>>>(g.w, g.E, sc.wq);
-        k_lv_strength<<<(unsigned)ceil_div(g.n, 256), 256, 0, st>>>(g.indptr, sc.wq, g.n, sc.K, nullptr, sc.scal, reinterpret_cast<int32_t*>(sc.scal + 1),
-                                                                    reinterpret_cast<int32_t*>(sc.scal + 1) + 1, sc.big_list);
-        unsigned long long h_scal[2] = {0, 0};
-        DDX_HIP(ctx, hipMemcpyAsync(h_scal, sc.scal, sizeof(h_scal), hipMemcpyDeviceToHost, st));
-        DDX_HIP(ctx, hipStreamSynchronize(st));
-        const int64_t m2 = (int64_t)h_scal[0];
-        const int32_t nbig = (int32_t)(h_scal[1] >> 32);
-        int32_t* cur = sc.comm;
-        DDX_TRY(lv_sweeps(ctx, g, gamma, sweeps, kSubrounds, sc, m2, nbig, cur));
-        if (level > 0) DDX_HIP(ctx, hipMemcpyAsync(sc.renum, cur, sizeof(int32_t) * g.n, hipMemcpyDeviceToDevice, st));      // names of this level's communities are its node ids
-        else DDX_HIP(ctx, hipMemcpyAsync(labels_out, cur, sizeof(int32_t) * g.n, hipMemcpyDeviceToHost, st));
+        DDX_HIP(ctx, hipMemsetAsync(sc.size, 0, sizeof(int32_t) * nc, st));
+        k_lv_level_sizes<<<(unsigned)ceil_div(n_up, 256), 256, 0, st>>>(sc.lab, sc.csize[level], n_up, sc.size);
+        k_lv_project<<<(unsigned)ceil_div(g.n, 256), 256, 0, st>>>(ctx->lv_member[level], sc.lab, g.n, sc.comm);
+        DDX_TRY(lv_sweeps(ctx, g, sc.wq[level], sc.K[level], gamma, sweeps, kSubrounds, sc, ctx->lv_m2, sc.big[level], ctx->lv_nbig[level], ctx->lv_maxdeg[level]));
+        if (level > 0) DDX_HIP(ctx, hipMemcpyAsync(sc.lab, sc.comm, sizeof(int32_t) * g.n, hipMemcpyDeviceToDevice, st));
+        else DDX_HIP(ctx, hipMemcpyAsync(labels_out, sc.comm, sizeof(int32_t) * g.n, hipMemcpyDeviceToHost, st));
+        n_up = g.n;
     }
     DDX_HIP(ctx, hipStreamSynchronize(st));
     DDX_HIP(ctx, hipGetLastError());
     // canonical numbering: by ascending smallest member = order of first appearance
-    std::vector<int32_t> rank((size_t)n, -1);
+    std::vector<int32_t> rank((size_t)std::max<int64_t>(n, nc), -1);
     int32_t k = 0;
     for (int64_t v = 0; v < n; ++v) {
         int32_t& r = rank[labels_out[v]];

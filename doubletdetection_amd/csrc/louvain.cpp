@@ -225,8 +225,6 @@ void aggregate(const Graph& g, const std::vector<int32_t>& comm, Graph& out, std
 // ------------------------------------------------------------------------------------------------
 constexpr double kWeightScale = 1048576.0;   // 2^20
 
-inline int node_class(int64_t v) { return (int)(((uint32_t)v * 2654435761u) >> 16); }
-
 void quantise(const Graph& g, std::vector<int64_t>& wq, std::vector<int64_t>& K, int64_t& m2) {
     const int64_t n = g.n();
     const int64_t nnz = (int64_t)g.indices.size();
@@ -243,7 +241,7 @@ void quantise(const Graph& g, std::vector<int64_t>& wq, std::vector<int64_t>& K,
 }
 
 // `sweeps` sweeps of `subrounds` synchronous sub-rounds from the partition in comm (oracle/louvain_ref.py:_sync_sweeps):
-// in sub-round r of sweep s the nodes with (node_class(v) + s) % subrounds == r decide at once, the others stay.
+// in sub-round r of sweep s the nodes with (v + s) % subrounds == r decide at once, the others stay.
 void sync_sweeps(const Graph& g, const std::vector<int64_t>& wq, const std::vector<int64_t>& K, int64_t m2, double gamma, int sweeps,
                  int subrounds, std::vector<int32_t>& comm) {
     const int64_t n = g.n();
@@ -264,7 +262,7 @@ void sync_sweeps(const Graph& g, const std::vector<int64_t>& wq, const std::vect
             for (int64_t v = 0; v < n; ++v) {
                 const int32_t own = comm[v];
                 next[v] = own;
-                if ((node_class(v) + sweep) % subrounds != r) continue;
+                if ((int)((v + sweep) % subrounds) != r) continue;
                 seen.clear();
                 for (int64_t e = g.indptr[v]; e < g.indptr[v + 1]; ++e) {
                     const int32_t u = g.indices[e];
@@ -313,20 +311,21 @@ void canonical_labels(std::vector<int32_t>& labels, int64_t bound) {
     }
 }
 
-// Part C: refinement sweeps on the original graph from the partition `labels` (any ids in [0, bound)); canonical result
-void refine(const Graph& g, double gamma, int sweeps, int subrounds, std::vector<int32_t>& labels, int64_t bound) {
+// One level of part C: refinement sweeps on g from the partition `labels` (ids in [0, n) are the community ids; anything
+// else is canonicalised first).  canonical: number the result by ascending smallest member, else leave the raw ids.
+void refine(const Graph& g, double gamma, int sweeps, int subrounds, std::vector<int32_t>& labels, bool canonical) {
     const int64_t n = g.n();
-    std::vector<int32_t> first(bound, -1);
-    for (int64_t v = 0; v < n; ++v)
-        if (first[labels[v]] < 0) first[labels[v]] = (int32_t)v;
-    std::vector<int32_t> comm(n);
-    for (int64_t v = 0; v < n; ++v) comm[v] = first[labels[v]];       // a community is named by its smallest member
+    int32_t lo = 0, hi = -1;
+    for (int64_t v = 0; v < n; ++v) { lo = std::min(lo, labels[v]); hi = std::max(hi, labels[v]); }
+    if (lo < 0 || hi >= n) {
+        // (negative ids are rejected by the callers; ids >= n: rank by first appearance)
+        canonical_labels(labels, (int64_t)hi + 1);
+    }
     std::vector<int64_t> wq, K;
     int64_t m2;
     quantise(g, wq, K, m2);
-    sync_sweeps(g, wq, K, m2, gamma, sweeps, subrounds, comm);
-    labels.swap(comm);
-    canonical_labels(labels, n);
+    sync_sweeps(g, wq, K, m2, gamma, sweeps, subrounds, labels);
+    if (canonical) canonical_labels(labels, n);
 }
 
 void presweep(const Graph& g, double gamma, int sweeps, int subrounds, std::vector<int32_t>& member, Graph& coarse) {
@@ -668,9 +667,10 @@ void refine_down(const std::vector<Graph>& graphs, const std::vector<std::vector
         const std::vector<int32_t>& m = members[level];
         std::vector<int32_t> down(m.size());
         for (size_t v = 0; v < m.size(); ++v) down[v] = lab[m[v]];
-        if (refine_levels) refine(graphs[level], gamma, DDX_REFINE_SWEEPS, DDX_SUBROUNDS, down, graphs[level + 1].n() > 0 ? graphs[level + 1].n() : 1);
+        if (refine_levels) refine(graphs[level], gamma, DDX_REFINE_SWEEPS, DDX_SUBROUNDS, down, false);      // ids of part B throughout
         lab.swap(down);
     }
+    if (refine_levels && !members.empty()) canonical_labels(lab, graphs[0].n());
 }
 
 int load_graph(int64_t n_nodes, const int64_t* indptr, const int32_t* indices, const double* weights, Graph& g) {
@@ -755,19 +755,16 @@ extern "C" int ddx_presweep(int64_t n_nodes, const int64_t* indptr, const int32_
 }
 
 extern "C" int ddx_refine(int64_t n_nodes, const int64_t* indptr, const int32_t* indices, const double* weights, const int32_t* labels_in,
-                          double gamma, int32_t sweeps, int32_t subrounds, int32_t* labels_out) {
+                          double gamma, int32_t sweeps, int32_t subrounds, int32_t canonical, int32_t* labels_out) {
     if (!labels_out || !labels_in || sweeps < 0) return DDX_E_ARG;
     if (n_nodes == 0) return DDX_OK;
     Graph g;
     const int rc = load_graph(n_nodes, indptr, indices, weights, g);
     if (rc != DDX_OK) return rc;
     std::vector<int32_t> lab(labels_in, labels_in + n_nodes);
-    int64_t bound = 0;
-    for (int64_t v = 0; v < n_nodes; ++v) {
+    for (int64_t v = 0; v < n_nodes; ++v)
         if (lab[v] < 0) return DDX_E_ARG;
-        bound = std::max<int64_t>(bound, (int64_t)lab[v] + 1);
-    }
-    refine(g, gamma, sweeps, subrounds, lab, bound);
+    refine(g, gamma, sweeps, subrounds, lab, canonical != 0);
     for (int64_t v = 0; v < n_nodes; ++v) labels_out[v] = lab[v];
     return DDX_OK;
 }

@@ -179,9 +179,10 @@ int ddx_get_graph(ddx_ctx* ctx, int64_t* indptr, int32_t* indices, double* weigh
  * The specification has three parts: (A) DDX_PRESWEEP_LEVELS times { DDX_PRESWEEPS synchronous sweeps of
  * DDX_SUBROUNDS sub-rounds on integer-quantised weights followed by an exact aggregation }, (B) sequential multi-level
  * optimisation of the aggregated graph, (C) DDX_REFINE_SWEEPS refinement sweeps (the moves of part A) on the original
- * graph from the partition A + B found.  Quality is pinned against networkx's Louvain: tests/test_clustering_independent.py.
+ * graph from the partition A + B found (first on the graph the last level of A started from, then one level further
+ * down, ... ; a community keeps the id B gave it until the result is numbered by smallest member).  Quality is pinned against networkx's Louvain: tests/test_clustering_independent.py.
  *   ddx_louvain            = A + B + C on the host (context-free, thread-safe);
- *   ddx_presweep           = one level of A on the host;   ddx_louvain_sequential = B on the host;   ddx_refine = C on the host;
+ *   ddx_presweep           = one level of A on the host;   ddx_louvain_sequential = B on the host;   ddx_refine = one level of C on the host;
  *   ddx_coarsen_graph      = `levels` levels of A on the GPU, applied to the graph ddx_build_graph left on the device; the
  *                            result (member of every node + aggregated CSR) is read with ddx_get_coarse_*;
  *   ddx_refine_communities = C on the GPU: takes the labels part B gave to the coarse nodes, returns the final labels of
@@ -214,11 +215,12 @@ int ddx_presweep(int64_t n_nodes, const int64_t* indptr, const int32_t* indices,
                  int32_t sweeps, int32_t subrounds, int32_t* member_out /* [n_nodes] */, int64_t* n_coarse_out,
                  int64_t* c_indptr_out /* [n_nodes+1] */, int32_t* c_indices_out /* [nnz] */, double* c_weights_out /* [nnz] */);
 int ddx_refine(int64_t n_nodes, const int64_t* indptr, const int32_t* indices, const double* weights,
-               const int32_t* labels_in /* [n_nodes], any non-negative ids */, double gamma, int32_t sweeps, int32_t subrounds,
+               const int32_t* labels_in /* [n_nodes], non-negative; ids < n_nodes are kept as the community ids */, double gamma,
+               int32_t sweeps, int32_t subrounds, int32_t canonical /* 0: raw ids out (to chain levels), else numbered by smallest member */,
                int32_t* labels_out /* [n_nodes] */);
 int ddx_coarsen_graph(ddx_ctx* ctx, double gamma, int32_t sweeps, int32_t levels);
-/* needs the graph of ddx_build_graph and the result of ddx_coarsen_graph still on the device (i.e. before the next
- * ddx_pca / ddx_build_graph of this context) */
+/* needs the graph of ddx_build_graph and the work space of ddx_coarsen_graph still on the device, i.e. it must come
+ * before the next ddx_build_graph of this context (ddx_create_doublets ... ddx_pca of the next iteration may run in between) */
 int ddx_refine_communities(ddx_ctx* ctx, const int32_t* coarse_labels /* [n_coarse] */, double gamma, int32_t sweeps,
                            int32_t* labels_out /* [n_nodes] */);
 int ddx_get_coarse_size(ddx_ctx* ctx, int64_t* n_coarse, int64_t* n_entries);

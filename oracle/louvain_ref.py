@@ -16,8 +16,9 @@ Algorithm (the published multi-level modularity optimisation with a resolution p
 previous application aggregated; what the GPU runs, cf. the parallel Louvain variants of
 Lu, Halappanavar, Kalyanaraman 2015 and Naim et al. 2017).  Weights are quantised to integers
 ``wq = rint(w * 2**20)`` so that every sum below is exact and independent of summation order.  A sweep consists of
-``SUBROUNDS`` sub-rounds; in sub-round r of sweep s the nodes of class ``(h(v) + s) mod SUBROUNDS == r``
-(``h(v) = ((v * 2654435761) mod 2**32) >> 16``) decide *at once* from the same state, everybody else stays:
+``SUBROUNDS`` sub-rounds; in sub-round r of sweep s the nodes with ``(v + s) mod SUBROUNDS == r`` decide *at once*
+from the same state, everybody else stays (node numbers carry no structure -- cells come in arbitrary order, aggregated
+nodes are numbered by community id -- and if they did, neighbours i, i+1 deciding in different sub-rounds is what one wants):
 ``score(v, c) = W(v,c) * 2m  -  gamma * (tot_c - [c == own] k_v) * k_v`` (float64, this operation order), the
 best community among the neighbours' communities (ties: smaller id) is taken if its score is strictly larger than
 staying, except that a node that is alone in its community does not move to another lone node with a larger id
@@ -31,10 +32,10 @@ sequential sweep.
 
 **Part C -- refinement on the way back down** (``refine``; the uncoarsening refinement of multi-level Louvain,
 Rotta & Noack 2011): the partition part B (or B') produced is projected onto the nodes of the graph the LAST
-application of part A started from, every community named by its smallest member, and ``REFINE_SWEEPS`` sweeps of the
-very same sub-round moves are made on that (quantised) graph; the result is projected one level further down and
-refined there, and so on until the original graph: groups (then single nodes) that part A put on the wrong side of a
-community border change sides.  The result is numbered by ascending smallest member.  With parts A + B + C the build reaches the modularity of networkx's
+application of part A started from (a community keeps the id part B gave it, all the way down), and ``REFINE_SWEEPS``
+sweeps of the very same sub-round moves are made on that (quantised) graph; the result is projected one level further
+down and refined there, and so on until the original graph: groups (then single nodes) that part A put on the wrong side
+of a community border change sides.  The result is numbered by ascending smallest member.  With parts A + B + C the build reaches the modularity of networkx's
 sequential Louvain on the reference's graphs to within 0.001 and the same number of communities
 (tests/golden/clustering_networkx.npz).
 
@@ -83,15 +84,9 @@ WEIGHT_SCALE = float(1 << 20)
 LEIDEN_MAX_ITERATIONS = 16
 
 
-def _node_class(n: int) -> np.ndarray:
-    """h(v) = ((v * 2654435761) mod 2**32) >> 16 -- spreads consecutive ids over the sub-round classes."""
-    v = np.arange(n, dtype=np.uint64)
-    return (((v * np.uint64(2654435761)) & np.uint64(0xFFFFFFFF)) >> np.uint64(16)).astype(np.int64)
-
-
 def _sync_sweeps(indptr, indices, wq, comm, gamma: float, sweeps: int, subrounds: int):
-    """``sweeps`` sweeps of ``subrounds`` synchronous sub-rounds from the partition ``comm`` (community ids are node
-    ids) on integer weights ``wq``.  Returns the new ``comm``."""
+    """``sweeps`` sweeps of ``subrounds`` synchronous sub-rounds from the partition ``comm`` (community ids: any
+    integers in [0, n)) on integer weights ``wq``.  Returns the new ``comm``."""
     n = len(indptr) - 1
     rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(indptr))
     K = np.zeros(n, dtype=np.int64)
@@ -101,7 +96,7 @@ def _sync_sweeps(indptr, indices, wq, comm, gamma: float, sweeps: int, subrounds
     noself = rows != indices
     r_ns, u_ns, w_ns = rows[noself], indices[noself], wq[noself]
     gamma = float(gamma)
-    h = _node_class(n)
+    h = np.arange(n, dtype=np.int64)
     subrounds = max(1, int(subrounds))
     if m2 <= 0 or len(r_ns) == 0:
         return comm
@@ -184,20 +179,22 @@ def canonical_labels(labels) -> np.ndarray:
     return rank[inv]
 
 
-def refine(indptr, indices, weights, labels, gamma: float = 1.0, sweeps: int = REFINE_SWEEPS, subrounds: int = SUBROUNDS) -> np.ndarray:
-    """Part C.  ``labels``: any labelling of the original nodes.  Returns canonical labels after the refinement sweeps."""
+def refine(indptr, indices, weights, labels, gamma: float = 1.0, sweeps: int = REFINE_SWEEPS, subrounds: int = SUBROUNDS,
+           canonical: bool = True) -> np.ndarray:
+    """One level of part C: the refinement sweeps on a graph from the labelling ``labels`` of its nodes.  The labels are
+    the community ids (ties between equally good moves go to the smaller id); labels outside [0, n) are first replaced
+    by their canonical numbering.  Returns the canonical labels of the result (``canonical=False``: the raw ids)."""
     indptr = np.asarray(indptr, dtype=np.int64)
     indices = np.asarray(indices, dtype=np.int64)
-    labels = np.asarray(labels)
+    labels = np.asarray(labels, dtype=np.int64)
     n = len(indptr) - 1
     if n == 0:
         return np.zeros(0, dtype=np.int64)
     wq = np.rint(np.asarray(weights, dtype=np.float64) * WEIGHT_SCALE).astype(np.int64)
-    _, inv = np.unique(labels, return_inverse=True)
-    first = np.full(inv.max() + 1, n, dtype=np.int64)
-    np.minimum.at(first, inv, np.arange(n, dtype=np.int64))
-    comm = _sync_sweeps(indptr, indices, wq, first[inv], gamma, sweeps, subrounds)
-    return canonical_labels(comm)
+    if labels.min() < 0 or labels.max() >= n:
+        labels = canonical_labels(labels)
+    comm = _sync_sweeps(indptr, indices, wq, labels, gamma, sweeps, subrounds)
+    return canonical_labels(comm) if canonical else comm
 
 
 class SplitMix64:
@@ -352,8 +349,8 @@ def _refine_down(graphs, members, lab, gamma, refine_sweeps):
     """Part C: ``lab`` labels the nodes of graphs[-1]; refine on graphs[-2], ..., graphs[0]."""
     lab = np.asarray(lab)
     for level in range(len(members) - 1, -1, -1):
-        lab = refine(*graphs[level], lab[members[level]], gamma, refine_sweeps)
-    return lab
+        lab = refine(*graphs[level], lab[members[level]], gamma, refine_sweeps, canonical=False)     # ids of part B throughout
+    return canonical_labels(lab) if members else lab
 
 
 def _louvain_sequential(indptr, indices, weights, gamma: float = 1.0, seed: int = 0, with_quality: bool = False):

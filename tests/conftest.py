@@ -66,3 +66,37 @@ CASES = ["case_a_hvg_pheno", "case_b_transposed_louvain", "case_c_reftest_scaled
 def golden_case(request):
     g = load_golden(request.param)
     return request.param, g, golden_kwargs(g)
+
+
+def pca_against_f64_oracle(ctx, C=30, seed=0, chunk=4096):
+    """The device's randomized PCA at a BASELINE size against the float64 oracle on the SAME matrix: the augmented matrix
+    handed to PCA is read back densified (M x H float32, chunk by chunk), `orc.randomized_pca_f64` (sklearn's algorithm
+    in float64, oracle/dd_oracle.py) and sklearn's own PCA in float64 run on the host cores.  Bars: <= 1e-5 relative per
+    component against the float64 oracle, <= 1e-4 against sklearn (north star: 1e-4)."""
+    import time
+
+    from oracle import dd_oracle as orc
+
+    M, H = ctx.M, ctx.H
+    q0 = orc.pca_start_matrix(seed, H if M >= H else M, C + 10)
+    ctx.pca(C, q0)
+    emb, sing = ctx.embedding_f64()
+    t0 = time.perf_counter()
+    dense = np.empty((M, H), dtype=np.float32)
+    for r in range(0, M, chunk):
+        n = min(chunk, M - r)
+        dense[r:r + n] = ctx.aug_dense_rows(r, n)
+    t1 = time.perf_counter()
+    want, s_want, _ = orc.randomized_pca_f64(dense, C, seed)
+    t2 = time.perf_counter()
+    rel = orc.per_component_rel_dev(emb, want)
+    print(f"PCA {M} x {H}: device vs float64 oracle, relative deviation per component max {rel.max():.2e} (mean {rel.mean():.2e}); "
+          f"singular values max rel {np.abs(sing / s_want - 1).max():.2e}; read-back {t1 - t0:.1f} s, oracle {t2 - t1:.1f} s")
+    assert rel.max() <= 1e-5, rel
+    np.testing.assert_allclose(sing, s_want, rtol=1e-6)
+    del want
+    skl64 = orc.pca_sklearn(dense.astype(np.float64), C, seed)
+    rel_skl = orc.per_component_rel_dev(emb, skl64)
+    print(f"  vs sklearn PCA(svd_solver='auto') in float64: max {rel_skl.max():.2e} ({time.perf_counter() - t2:.1f} s)")
+    assert rel_skl.max() <= 1e-4, rel_skl
+    return rel.max(), rel_skl.max()

@@ -149,7 +149,8 @@ GRAPH_MODE = {"phenograph": 0, "scanpy_louvain": 2, "scanpy_leiden": 3}
 @pytest.mark.parametrize("flavour", list(cc.FLAVOURS))
 def test_device_community_detection_against_networkx_fixture(flavour):
     """kNN, graph, two levels of synchronous pre-sweeps on the GPU, the sequential levels (Louvain, PhenoGraph's restart
-    rule, or Leiden) as the product runs them: same bars as the host path, graph identical to the one networkx saw."""
+    rule, or Leiden) on the host, the refinement sweeps on the GPU again -- as the product runs them: same bars as the
+    host path, graph identical to the one networkx saw."""
     k, include_self, _, gamma, _, kind = cc.FLAVOURS[flavour]
     name = "large_" + flavour
     emb = large_embedding()
@@ -161,16 +162,18 @@ def test_device_community_detection_against_networkx_fixture(flavour):
         assert len(ix) == int(FIX[name + "_graph_entries"])            # (no duplicate points: no self-loops to drop)
         assert abs(w.sum() - float(FIX[name + "_graph_weight"])) <= 1e-6 * float(FIX[name + "_graph_weight"])
         member, cip, cix, cw = ctx.coarsen_graph(gamma)
-    runs = {}
-    if kind == "leiden":
-        runs["device pre-sweeps + Leiden"] = _lib.leiden_sequential(cip, cix, cw, gamma, 0)[member]
-    else:
-        runs["device pre-sweeps + sequential levels"] = _lib.louvain_sequential(cip, cix, cw, gamma, 0)[0][member]
-        if flavour == "phenograph":
-            runs["device pre-sweeps + best of restarts"] = _lib.louvain_best_of(cip, cix, cw, gamma, 0, 1e-3, threads=4, presweeps=False)[0][member]
+        # part B (or B', or B with PhenoGraph's restart rule) on the host, part C back on the device
+        runs = {}
+        if kind == "leiden":
+            runs["device pre-sweeps + Leiden + device refinement"] = ctx.refine_communities(_lib.leiden_sequential(cip, cix, cw, gamma, 0), gamma)
+        else:
+            runs["device pre-sweeps + sequential levels + device refinement"] = ctx.refine_communities(_lib.louvain_sequential(cip, cix, cw, gamma, 0)[0], gamma)
+            if flavour == "phenograph":
+                coarse = _lib.louvain_best_of(cip, cix, cw, gamma, 0, 1e-3, threads=4, presweeps=False)[0]
+                runs["device pre-sweeps + best of restarts + device refinement"] = ctx.refine_communities(coarse, gamma)
     for what, labels in runs.items():
         hold_to_fixture(name, ip, ix, w, labels, what)
-    # and the device route equals the host statement of the same two parts bit for bit
+    # and the device route equals the host statement of the same three parts bit for bit
     host = _lib.leiden(ip, ix, w, gamma, 0) if kind == "leiden" else _lib.louvain(ip, ix, w, gamma, 0)[0]
     first = next(iter(runs.values()))
     assert np.array_equal(host, first)

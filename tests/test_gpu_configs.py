@@ -165,6 +165,24 @@ def test_c3_stage_properties(data_c3):
     _large_config_properties(data_c3, 10_000, 30, 0, False)
 
 
+def test_c3_pca_matches_f64_oracle(data_c3):
+    """The headline configuration (100 000 x 30 000 -> 125 000 x 10 000 augmented matrix): the device PCA against the
+    float64 oracle and sklearn on the matrix read back from the device (dd.py:305-314)."""
+    from conftest import pca_against_f64_oracle
+    from doubletdetection_amd import _lib
+
+    N = data_c3.shape[0]
+    ctx = _lib.Context(0)
+    try:
+        ctx.upload_raw(data_c3)
+        ctx.select_columns(np.argsort(ctx.gene_variances())[-10_000:])
+        ctx.create_doublets(np.random.default_rng(0).choice(N, size=(N // 4, 2), replace=False))
+        ctx.lognormalise(0.1)
+        pca_against_f64_oracle(ctx)
+    finally:
+        ctx.close()
+
+
 def test_c3_fit_deterministic_and_ranks_planted_doublets(data_c3):
     N = data_c3.shape[0]
     clf = _fit_twice(data_c3, n_iters=4, random_state=0, n_jobs=-1)

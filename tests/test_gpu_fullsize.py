@@ -124,6 +124,15 @@ def test_pca_and_knn_properties(staged):
     np.testing.assert_array_equal(ctx.refine_communities(coarse, 1.0), _lib.louvain(ip, ix, w, 1.0, 0)[0])
 
 
+def test_c2_pca_matches_f64_oracle(staged):
+    """configs[1] (50 000 x 20 000 -> 62 500 x 10 000): device PCA against the float64 oracle and sklearn on the same matrix."""
+    from conftest import pca_against_f64_oracle
+
+    ctx = staged[0]
+    ctx.lognormalise(0.1)
+    pca_against_f64_oracle(ctx)
+
+
 def test_operator_product_variants_agree_at_full_size(data, staged, monkeypatch):
     """The same randomized PCA through the implementations of the operator products: LDS-staged float32
     operand with float32 products inside a trip (default), L2-gather float32 operand (DDX_SPMM=gather), L2-gather

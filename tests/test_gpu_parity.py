@@ -406,16 +406,9 @@ def test_device_presweeps_match_host(ctx, case):
         # part C alone: any labelling of the coarse nodes, any number of sweeps; one level of part A
         rng = np.random.default_rng(5)
         arbitrary = rng.integers(0, max(2, len(ip_dev) // 7), size=len(ip_dev) - 1).astype(np.int32)
-        graphs, members = [(ip, ix, w)], []
-        for _ in range(_lib.PRESWEEP_LEVELS):
-            mm, *gr = _lib.presweep(*graphs[-1], gamma)
-            members.append(mm)
-            graphs.append(tuple(gr))
+        graphs, members = _lib.presweep_levels(ip, ix, w, gamma)
         for sweeps in (0, 1, _lib.REFINE_SWEEPS):
-            lab = arbitrary
-            for level in range(len(members) - 1, -1, -1):
-                lab = _lib.refine(*graphs[level], lab[members[level]], gamma, sweeps)
-            np.testing.assert_array_equal(ctx.refine_communities(arbitrary, gamma, sweeps), lab)
+            np.testing.assert_array_equal(ctx.refine_communities(arbitrary, gamma, sweeps), _lib.refine_down(graphs, members, arbitrary, gamma, sweeps))
         m1, ip1, ix1, w1 = ctx.coarsen_graph(gamma, levels=1)
         coarse = _lib.louvain_sequential(ip1, ix1, w1, gamma, 9)[0]
         np.testing.assert_array_equal(ctx.refine_communities(coarse, gamma), _lib.refine(ip, ix, w, coarse[m1], gamma))

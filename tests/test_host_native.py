@@ -95,15 +95,8 @@ def test_leiden_matches_python_specification_bit_for_bit(n, k, seed, weighted, g
     # whole = pre-sweeps, then part B' on the aggregated graph, then the refinement sweeps on the original one
     whole = _lib.leiden(A.indptr, A.indices, A.data, gamma, seed)
     np.testing.assert_array_equal(whole.astype(np.int64), louvain_ref.leiden(A.indptr, A.indices, A.data, gamma, seed))
-    graphs, members = [(A.indptr, A.indices, A.data)], []
-    for _ in range(_lib.PRESWEEP_LEVELS):
-        mm, *g = _lib.presweep(*graphs[-1], gamma)
-        members.append(mm)
-        graphs.append(tuple(g))
-    lab = _lib.leiden_sequential(*graphs[-1], gamma, seed)
-    for level in range(len(members) - 1, -1, -1):
-        lab = _lib.refine(*graphs[level], lab[members[level]], gamma)
-    np.testing.assert_array_equal(whole, lab)
+    graphs, members = _lib.presweep_levels(A.indptr, A.indices, A.data, gamma)
+    np.testing.assert_array_equal(whole, _lib.refine_down(graphs, members, _lib.leiden_sequential(*graphs[-1], gamma, seed), gamma))
 
 
 def test_leiden_degenerate_graphs():
@@ -144,25 +137,20 @@ def test_presweep_and_sequential_parts_match_specification(n, k, seed, weighted,
     seq, _ = _lib.louvain_sequential(ip, ix, w, gamma, seed)
     np.testing.assert_array_equal(seq.astype(np.int64), louvain_ref._louvain_sequential(ip_ref, ix_ref, w_ref, gamma, seed))
     # the whole = PRESWEEP_LEVELS applications of part A, then part B, then part C on every level on the way back down
-    graphs, members = [(A.indptr, A.indices, A.data)], []
-    for _ in range(_lib.PRESWEEP_LEVELS):
-        mm, *g = _lib.presweep(*graphs[-1], gamma)
-        members.append(mm)
-        graphs.append(tuple(g))
+    graphs, members = _lib.presweep_levels(A.indptr, A.indices, A.data, gamma)
     whole, _ = _lib.louvain(A.indptr, A.indices, A.data, gamma, seed)
     lab = _lib.louvain_sequential(*graphs[-1], gamma, seed)[0]
     after_b = lab
     for mm in reversed(members):
         after_b = after_b[mm]
-    for level in range(len(members) - 1, -1, -1):
-        lab = _lib.refine(*graphs[level], lab[members[level]], gamma)
-    np.testing.assert_array_equal(whole, lab)
+    np.testing.assert_array_equal(whole, _lib.refine_down(graphs, members, lab, gamma))
     # part C against its Python statement, from B's partition and from arbitrary labellings (any non-negative ids)
     rng = np.random.default_rng(seed)
     for labels in (after_b, rng.integers(0, 7, size=n) * 3 + 1, np.arange(n)[::-1].copy()):
         for sweeps, subrounds in ((3, 4), (1, 1), (2, 2)):
-            np.testing.assert_array_equal(_lib.refine(A.indptr, A.indices, A.data, labels, gamma, sweeps, subrounds).astype(np.int64),
-                                          louvain_ref.refine(A.indptr, A.indices, A.data, labels, gamma, sweeps, subrounds))
+            for canonical in (True, False):
+                np.testing.assert_array_equal(_lib.refine(A.indptr, A.indices, A.data, labels, gamma, sweeps, subrounds, canonical).astype(np.int64),
+                                              louvain_ref.refine(A.indptr, A.indices, A.data, labels, gamma, sweeps, subrounds, canonical))
     np.testing.assert_array_equal(_lib.refine(A.indptr, A.indices, A.data, after_b, gamma, 0), louvain_ref.canonical_labels(after_b))
     # refinement never loses modularity worth mentioning, and the whole is no worse than the purely sequential optimisation
     q_whole = louvain_ref.modularity(A.indptr, A.indices, A.data, whole, gamma)
