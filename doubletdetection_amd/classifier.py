@@ -391,11 +391,11 @@ class BoostClassifier:
         if unknown:
             raise TypeError(f"unsupported clustering_kwargs for {self.clustering_algorithm}: {sorted(unknown)}")
 
-    # Device limits of the hand-written kernels: the randomized sketch holds at most 64 columns
-    # (n_components + 10 oversamples), the kNN kernels at most 64 embedding dimensions and 64 neighbours.
-    _MAX_SKETCH = 64
-    _MAX_EMBED = 64
-    _MAX_K = 64
+    # Device limits of the hand-written kernels: the kNN kernels take at most 128 embedding
+    # dimensions and 256 neighbours.  (The randomized sketch may have any width: beyond 64 columns the operator products
+    # run block by block over the sketch.)
+    _MAX_EMBED = 128
+    _MAX_K = 256
 
     def _cluster_plan(self):
         """(k, include_self, graph_mode, gamma, seed, min_cluster_size, leiden, q_tol) for the chosen algorithm
@@ -470,8 +470,6 @@ class BoostClassifier:
     def _check_device_limits(self, num_cells, num_genes):
         """Fail before anything is uploaded when a request exceeds what the device kernels hold (DESIGN.md section 7);
         the reference has no such limits, so say so instead of failing in the middle of a fit."""
-        num_synths = int(self.boost_rate * num_cells)
-        M = num_cells + num_synths
         n_comp = self.n_components
         k = self._cluster_plan()[0]
         if k > self._MAX_K:
@@ -479,12 +477,6 @@ class BoostClassifier:
         if n_comp > self._MAX_EMBED:
             raise NotImplementedError(f"n_components={n_comp}: the device kNN works on at most {self._MAX_EMBED} "
                                       "embedding dimensions")
-        sparse_branch = self.pseudocount == 1 and not self.standard_scaling
-        if not sparse_branch and 1 <= n_comp <= min(M, num_genes) and \
-                self._pca_regime(M, num_genes, n_comp) == "randomized" and n_comp + 10 > self._MAX_SKETCH:
-            raise NotImplementedError(f"n_components={n_comp}: the randomized PCA sketch (n_components + 10 columns) is "
-                                      f"limited to {self._MAX_SKETCH} columns on the device, i.e. n_components <= "
-                                      f"{self._MAX_SKETCH - 10}")
 
     @staticmethod
     def _cluster_and_score(graph, gamma, seed, min_cluster_size, num_cells, leiden=False, q_tol=None, threads=1):
@@ -922,10 +914,8 @@ class BoostClassifier:
             regime = "randomized"
         else:
             regime = "full"
-        if regime != "randomized" and min(M, H) > 4096:
-            raise NotImplementedError(
-                f"scikit-learn selects its exact '{regime}' PCA for a {M}x{H} matrix with n_components={n_comp}; "
-                "the GPU path diagonalises the smaller Gram matrix on the host and supports min(shape) <= 4096 there")
+        # (the exact regimes build the smaller Gram matrix from operator products on the device and diagonalise it on the
+        # host: any size works; beyond a few thousand rows / columns the host eigen-decomposition dominates)
         return regime
 
     def _gather_rows(self, local, mine, n_iters, num_cells, num_synths, rank, world, backend, device):

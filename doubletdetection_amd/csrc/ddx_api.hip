@@ -65,7 +65,7 @@ void context_reset(ddx_ctx* ctx) {
                       &ctx->csc_s_row, &ctx->csc_s_raw, &ctx->csc_s_x, &ctx->sort_keys_in, &ctx->sort_keys_out,
                       &ctx->sort_vals_in, &ctx->sort_vals_out, &ctx->sort_tmp, &ctx->sort_rowid, &ctx->median, &ctx->lib_sorted, &ctx->lognorm_tab,
                       &ctx->zcol, &ctx->colmean, &ctx->colstat, &ctx->col_part, &ctx->pcaA, &ctx->pcaB, &ctx->pcaSmall,
-                      &ctx->pcaPartial, &ctx->pcaVec, &ctx->pcaPanel, &ctx->pcaOp, &ctx->pcaQ0, &ctx->rowseg, &ctx->rank_buf, &ctx->lv_buf, &ctx->lv_pack, &ctx->graph_buf, &ctx->emb32, &ctx->emb64, &ctx->sing, &ctx->knn_idx,
+                      &ctx->pcaPartial, &ctx->pcaVec, &ctx->pcaPanel, &ctx->pcaOp, &ctx->pcaQ0, &ctx->pcaBlk, &ctx->rowseg, &ctx->rank_buf, &ctx->lv_buf, &ctx->lv_pack, &ctx->graph_buf, &ctx->emb32, &ctx->emb64, &ctx->sing, &ctx->knn_idx,
                       &ctx->knn_dist, &ctx->knn_sorted, &ctx->edge_w};
     for (DevBuf* b : bufs) { b->p = nullptr; b->cap = 0; b->blk = -1; }
     ctx->arena.blocks.clear();
@@ -823,7 +823,7 @@ int ddx_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
     REQUIRE_CTX(ctx);
     USE_DEVICE(ctx);
     NEED(ctx->have_emb, "no embedding");
-    NEED(k >= 1 && k <= 64, "k must be in [1,64]");
+    NEED(k >= 1 && k <= 256, "k must be in [1,256]");
     if ((int64_t)k + (include_self ? 0 : 1) > ctx->embM)
         return set_err(ctx, DDX_E_ARG, "k=%d too large for %lld points", k, (long long)ctx->embM);
     return stage_knn(ctx, k, include_self);

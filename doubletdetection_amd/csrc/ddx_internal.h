@@ -166,7 +166,7 @@ struct ddx_ctx {
 
     // PCA work space
     int32_t C = 0;
-    ddx::DevBuf pcaA, pcaB, pcaSmall, pcaPartial, pcaVec, pcaPanel, pcaOp, pcaQ0;
+    ddx::DevBuf pcaA, pcaB, pcaSmall, pcaPartial, pcaVec, pcaPanel, pcaOp, pcaQ0, pcaBlk;
     int64_t q0_rows = 0;             // shape of the start matrix kept in pcaQ0
     int32_t q0_cols = 0;
     ddx::DevBuf emb32;               // float  [M*C]

@@ -16,7 +16,7 @@
 
 namespace ddx {
 
-constexpr int kMaxDim = 64;
+constexpr int kMaxDim = 128;
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 
@@ -161,7 +161,7 @@ constexpr int kEmitRT = DDX_EMIT_RT;    // query tiles per wave in the emit pass
 template <int CP, int kBoundKeep>
 __global__ void __launch_bounds__(256) k_knn_bound(const float* __restrict__ Et, const float* __restrict__ nrm,
                                                    int64_t Mp, int K, int include_self, int64_t nsamp_tiles,
-                                                   int64_t tile_stride, float* __restrict__ thr_out) {
+                                                   int64_t tile_stride, int64_t tile_phase, int combine, float* __restrict__ thr_out) {
     constexpr int KS = CP / 4;
     constexpr int RT = kBoundRT, NV = 4 * RT;
     constexpr int kChunkTiles = chunk_tiles(CP);
@@ -183,9 +183,14 @@ __global__ void __launch_bounds__(256) k_knn_bound(const float* __restrict__ Et,
     const int64_t own_tile = q0 >> 4;
     const int64_t nchunks = (nsamp_tiles + kChunkTiles - 1) / kChunkTiles;
         // sample = the nsamp_tiles tiles around this block in first-component order (contiguous, see stage_knn)
-    int64_t tile0 = (((int64_t)blockIdx.x * 4) * RT) + 2 * RT - nsamp_tiles / 2;
-    if (tile0 > (Mp >> 4) - nsamp_tiles) tile0 = (Mp >> 4) - nsamp_tiles;
+    // (k > 16 * (kBoundKeep - 1): the window is dealt out over `tile_stride` launches, launch `tile_phase` taking every
+    // tile_stride-th tile and the ceil(k / tile_stride)-th smallest of ITS points; the largest of those bounds holds at
+    // least k points of the whole window below it -- `combine` keeps the maximum over the launches)
+    const int64_t span = nsamp_tiles * tile_stride;
+    int64_t tile0 = (((int64_t)blockIdx.x * 4) * RT) + 2 * RT - span / 2;
+    if (tile0 > (Mp >> 4) - span) tile0 = (Mp >> 4) - span;
     if (tile0 < 0) tile0 = 0;
+    tile0 += tile_phase;
     const float* Etw = Et + tile0 * 16 * CP;
     const float* nrmw = nrm + tile0 * 16;
 TileStage<CP> st;
@@ -249,14 +254,17 @@ TileStage<CP> st;
             if (rank[t] == K - 1) kth = best[v][t];
         // exactly one lane of the 16 holds the value of rank K-1: share it
         for (int o = 1; o < 16; o <<= 1) kth = fminf(kth, __shfl_xor(kth, o, 64));
-        if (jcol == 0) thr_out[q0 + (v >> 2) * 16 + rbase + (v & 3)] = kth;   // +inf when fewer than K sample points
+        if (jcol == 0) {                                                      // +inf when fewer than K sample points
+            float* dst = thr_out + q0 + (v >> 2) * 16 + rbase + (v & 3);
+            *dst = combine ? fmaxf(*dst, kth) : kth;
+        }
     }
 }
 
 template <int CP>
 __global__ void __launch_bounds__(256) k_knn_emit(const float* __restrict__ Et, const float* __restrict__ nrm,
                                                   const float* __restrict__ thr, int64_t Mp, int include_self,
-                                                  int32_t* __restrict__ ccount, int32_t* __restrict__ cbuf, const int32_t* __restrict__ win) {
+                                                  int32_t* __restrict__ ccount, int32_t* __restrict__ cbuf, const int32_t* __restrict__ win, int cap) {
     constexpr int KS = CP / 4;
     constexpr int RT = kEmitRT, NV = 4 * RT;
     constexpr int kChunkTiles = chunk_tiles(CP);
@@ -316,7 +324,7 @@ __global__ void __launch_bounds__(256) k_knn_emit(const float* __restrict__ Et, 
                     if (own && q == cand) continue;
                     // this wave is the only writer of its queries' lists: the slot counter lives in LDS
                     const int slot = atomicAdd(&lcnt[wave][lq], 1);
-                    if (slot < kCandCap) cbuf[q * kCandCap + slot] = cand;
+                    if (slot < cap) cbuf[q * cap + slot] = cand;
                 }
             }
         }
@@ -423,7 +431,7 @@ struct QueryTilesBf {
 template <int CP, int kBoundKeep>
 __global__ void __launch_bounds__(256) k_knn_bound_bf(const __bf16* __restrict__ Eb, const float* __restrict__ nrm,
                                                       int64_t Mp, int K, int include_self, int64_t nsamp_tiles,
-                                                      int64_t tile_stride, float* __restrict__ thr_out) {
+                                                      int64_t tile_stride, int64_t tile_phase, int combine, float* __restrict__ thr_out) {
     constexpr int RT = kBoundRT, NV = 4 * RT;
     constexpr int kChunkTiles = chunk_tiles(CP);
     constexpr int tile_vecs = 16 * CP * 4 / 16;
@@ -445,9 +453,14 @@ __global__ void __launch_bounds__(256) k_knn_bound_bf(const __bf16* __restrict__
     const int64_t own_tile = q0 >> 4;
     const int64_t nchunks = (nsamp_tiles + kChunkTiles - 1) / kChunkTiles;
         // sample = the nsamp_tiles tiles around this block in first-component order (contiguous, see stage_knn)
-    int64_t tile0 = (((int64_t)blockIdx.x * 4) * RT) + 2 * RT - nsamp_tiles / 2;
-    if (tile0 > (Mp >> 4) - nsamp_tiles) tile0 = (Mp >> 4) - nsamp_tiles;
+    // (k > 16 * (kBoundKeep - 1): the window is dealt out over `tile_stride` launches, launch `tile_phase` taking every
+    // tile_stride-th tile and the ceil(k / tile_stride)-th smallest of ITS points; the largest of those bounds holds at
+    // least k points of the whole window below it -- `combine` keeps the maximum over the launches)
+    const int64_t span = nsamp_tiles * tile_stride;
+    int64_t tile0 = (((int64_t)blockIdx.x * 4) * RT) + 2 * RT - span / 2;
+    if (tile0 > (Mp >> 4) - span) tile0 = (Mp >> 4) - span;
     if (tile0 < 0) tile0 = 0;
+    tile0 += tile_phase;
     const __bf16* Ebw = Eb + tile0 * 16 * CP * 2;
     const float* nrmw = nrm + tile0 * 16;
 TileStageBf<CP> st;
@@ -506,14 +519,17 @@ TileStageBf<CP> st;
         for (int t = 0; t < kBoundKeep; ++t)
             if (rank[t] == K - 1) kth = best[v][t];
         for (int o = 1; o < 16; o <<= 1) kth = fminf(kth, __shfl_xor(kth, o, 64));
-        if (jcol == 0) thr_out[q0 + (v >> 2) * 16 + rbase + (v & 3)] = kth;
+        if (jcol == 0) {                                                      // +inf when fewer than K sample points
+            float* dst = thr_out + q0 + (v >> 2) * 16 + rbase + (v & 3);
+            *dst = combine ? fmaxf(*dst, kth) : kth;
+        }
     }
 }
 
 template <int CP>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DDX_EMIT_WAVES, DDX_EMIT_WAVES))) k_knn_emit_bf(const __bf16* __restrict__ Eb, const float* __restrict__ nrm, const f4* __restrict__ start4,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CP <= 64 ? DDX_EMIT_WAVES : 2, CP <= 64 ? DDX_EMIT_WAVES : 2))) k_knn_emit_bf(const __bf16* __restrict__ Eb, const float* __restrict__ nrm, const f4* __restrict__ start4,
                                                      const float* __restrict__ thr, int64_t Mp, int include_self,
-                                                     int32_t* __restrict__ ccount, int32_t* __restrict__ cbuf, const int32_t* __restrict__ win, int dbg) {
+                                                     int32_t* __restrict__ ccount, int32_t* __restrict__ cbuf, const int32_t* __restrict__ win, int dbg, int cap) {
     constexpr int RT = kEmitRT, NV = 4 * RT;
     constexpr int kChunkTiles = chunk_tiles(CP);
     constexpr int tile_vecs = 16 * CP * 4 / 16;
@@ -575,7 +591,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DDX_EM
         if (ch + 1 < nchunks) stage(ch + 1, buf ^ 1);
         const int ntile = (int)((ntiles - ch * kChunkTiles) < kChunkTiles ? (ntiles - ch * kChunkTiles) : kChunkTiles);
         const f4* tb = lds_c[buf];
-        static_assert(CP == 32 || CP == 64, "");
+        static_assert(CP % 32 == 0, "");
         // one compare per pair; the wave-wide masks live in scalar registers
         auto judge = [&](const f4 (&acc)[RT], const int32_t tile) {
             unsigned long long any = 0, hm[NV];
@@ -597,7 +613,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DDX_EM
                     if (m16) {
                         if ((m16 >> jcol) & 1u) {
                             const int slot = cnt[v] + __popc(m16 & ((1u << jcol) - 1u));
-                            if (slot < kCandCap) cbuf[q * kCandCap + slot] = cand;
+                            if (slot < cap) cbuf[q * cap + slot] = cand;
                         }
                         cnt[v] += __popc(m16);
                     }
@@ -664,6 +680,8 @@ __device__ __forceinline__ double exact_d2(const float* q /* LDS, CP floats */, 
 
 constexpr int kSelMax = 1024;   // sort window of the select pass (power of two, >= kCandCap + 64)
 constexpr int kSelSmall = 256;  // queries with at most this many candidates (nearly all) sort in a small window: 4x the waves per CU
+constexpr int kSelHuge = 4096;  // k > 80: lists of up to kCandCapLarge entries (one wave per workgroup: 48 KB of LDS)
+constexpr int kCandCapLarge = 3072;
 
 // bitonic sort of d[0..P), ix[0..P) by (distance, index), ascending; one wave, P a power of two >= 64
 __device__ __forceinline__ void wave_sort(double* d, int32_t* ix, int P, int lane) {
@@ -684,27 +702,28 @@ __device__ __forceinline__ void wave_sort(double* d, int32_t* ix, int P, int lan
     }
 }
 
-// one wave per query (4 per block, no block-level synchronisation).  Two instances share the work: SELMAX = kSelSmall
-// takes the queries whose list fits that window, SELMAX = kSelMax the few longer (or overflowed) ones.
-template <int CP, int SELMAX>
-__global__ void __launch_bounds__(256) k_knn_select(const float* __restrict__ E, const int32_t* __restrict__ perm, int64_t M, int K,
+// one wave per query (WAVES per block, no block-level synchronisation).  The instances share the work by list length: an
+// instance takes the queries with lo < min(length, cap) <= hi (SELMAX = kSelSmall: nearly all; kSelMax: the few longer or
+// overflowed ones; kSelHuge: lists beyond 1024 entries, which only occur with the large cap of k > 80).
+template <int CP, int SELMAX, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES) k_knn_select(const float* __restrict__ E, const int32_t* __restrict__ perm, int64_t M, int K,
                                                     int include_self, const int32_t* __restrict__ ccount, const int32_t* __restrict__ cbuf,
                                                     int32_t* __restrict__ idx_out, double* __restrict__ dist_out,
-                                                    int32_t* __restrict__ n_overflow) {
-    __shared__ __attribute__((aligned(16))) double sd[4][SELMAX];
-    __shared__ int32_t si[4][SELMAX];
-    __shared__ __attribute__((aligned(16))) float sq[4][CP];
+                                                    int32_t* __restrict__ n_overflow, int cap, int lo, int hi) {
+    __shared__ __attribute__((aligned(16))) double sd[WAVES][SELMAX];
+    __shared__ int32_t si[WAVES][SELMAX];
+    __shared__ __attribute__((aligned(16))) float sq[WAVES][CP];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t q = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t q = (int64_t)blockIdx.x * WAVES + wave;
     if (q >= M) return;
     double* d = sd[wave];
     int32_t* ix = si[wave];
     float* qrow = sq[wave];
     for (int t = lane; t < CP; t += 64) qrow[t] = E[q * CP + t];
     const int cnt_all = ccount[q];
-    if ((SELMAX == kSelSmall) != (cnt_all <= kSelSmall)) return;      // the other instance's query
-    const bool overflow = cnt_all > kCandCap;
-    const int cnt = overflow ? kCandCap : cnt_all;
+    const bool overflow = cnt_all > cap;
+    const int cnt = overflow ? cap : cnt_all;
+    if (!(cnt > lo && cnt <= hi) && !(cnt == 0 && lo == 0)) return;      // another instance's query
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     // exact distances of the listed candidates, one per lane and step, then sort
@@ -714,7 +733,7 @@ __global__ void __launch_bounds__(256) k_knn_select(const float* __restrict__ E,
         double dv = __builtin_huge_val();
         int32_t iv = 0x7fffffff;
         if (t < cnt) {
-            const int64_t c = cbuf[q * kCandCap + t];
+            const int64_t c = cbuf[q * (int64_t)cap + t];
             dv = exact_d2<CP>(qrow, E + c * CP);
             iv = perm[c];                            // ties are broken by the caller's point ids
         }
@@ -821,15 +840,21 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
     const int64_t M = ctx->embM;
     const int C = ctx->C;
     if (C > kMaxDim) return set_err(ctx, DDX_E_UNSUPPORTED, "embedding dimension %d exceeds %d", C, kMaxDim);
-    if (k > 16 * (kBoundKeepLarge - 1)) return set_err(ctx, DDX_E_UNSUPPORTED, "k=%d exceeds %d", k, 16 * (kBoundKeepLarge - 1));
-    const bool keep_small = k <= 16 * (kBoundKeepSmall - 1);
-    const int CP = (C <= 32) ? 32 : 64;
+    constexpr int kMaxK = 256;
+    if (k > kMaxK) return set_err(ctx, DDX_E_UNSUPPORTED, "k=%d exceeds %d", k, kMaxK);
+    // k beyond what one bound launch ranks (16 lanes x (kBoundKeepLarge - 1) kept values per query): the sample window is
+    // dealt out over `groups` launches, each bounding the ceil(k / groups)-th neighbour among its share (k_knn_bound)
+    const int groups = (int)ceil_div(k, 16 * (kBoundKeepLarge - 1));
+    const int k_bound = (int)ceil_div(k, groups);
+    const bool keep_small = k_bound <= 16 * (kBoundKeepSmall - 1);
+    const int cap = k <= 16 * (kBoundKeepLarge - 1) ? kCandCap : kCandCapLarge;      // candidate slots per query
+    const int CP = (C <= 32) ? 32 : (C <= 64 ? 64 : 128);
     const int64_t Mp = ceil_div(M, 256) * 256;                 // whole blocks of queries in both MFMA passes
     // workspace (reuses the PCA row buffer): E [Mp*CP] | Et [Mp*CP] | Eb [Mp*CP as bf16 hi+lo] | nrm [Mp] | thr [Mp] | p1 [Mp] | keys [2*Mp]
     //            | ccount [Mp+64] | ids [2*Mp] | win [2*blocks] | cbuf [Mp*cap]
     const size_t f_words = (size_t)Mp * CP * 3 + 9 * (size_t)Mp + 16;
     const int64_t emit_blocks = Mp / (4 * 16 * kEmitRT);
-    const size_t i_words = (size_t)Mp + 64 + 2 * (size_t)Mp + 2 * (size_t)emit_blocks + 64 + (size_t)Mp * kCandCap;
+    const size_t i_words = (size_t)Mp + 64 + 2 * (size_t)Mp + 2 * (size_t)emit_blocks + 64 + (size_t)Mp * cap;
     DDX_TRY(ensure(ctx, ctx->pcaA, sizeof(float) * f_words + sizeof(int32_t) * i_words + 256));
     DDX_TRY(ensure(ctx, ctx->knn_idx, sizeof(int32_t) * (size_t)M * k));
     DDX_TRY(ensure(ctx, ctx->knn_dist, sizeof(double) * (size_t)M * k));
@@ -869,16 +894,21 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
     if (ctx->opt.knn_sample_tiles > 0) nsamp = ctx->opt.knn_sample_tiles;
     if (nsamp < 2 * (int64_t)ceil_div(k, 16) + 8) nsamp = 2 * (int64_t)ceil_div(k, 16) + 8;
     if (nsamp > ntiles) nsamp = ntiles;
-    const int64_t stride = 1;
+    const int64_t stride = groups;
+    const int64_t nsamp_g = std::max<int64_t>(1, nsamp / groups);                    // tiles per launch
     {
         ScopedTimer t(ctx, "knn_bound");
         const unsigned grid = (unsigned)(Mp / (4 * 16 * kBoundRT));
 #define DDX_BOUND_LAUNCH(KERNEL, OPERAND)                                                                                        \
     do {                                                                                                                       \
-        if (CP == 32 && keep_small) KERNEL<32, kBoundKeepSmall><<<grid, 256, 0, ctx->stream>>>(OPERAND, nrm, Mp, k, include_self, nsamp, stride, thr); \
-        else if (CP == 32) KERNEL<32, kBoundKeepLarge><<<grid, 256, 0, ctx->stream>>>(OPERAND, nrm, Mp, k, include_self, nsamp, stride, thr);      \
-        else if (keep_small) KERNEL<64, kBoundKeepSmall><<<grid, 256, 0, ctx->stream>>>(OPERAND, nrm, Mp, k, include_self, nsamp, stride, thr);    \
-        else KERNEL<64, kBoundKeepLarge><<<grid, 256, 0, ctx->stream>>>(OPERAND, nrm, Mp, k, include_self, nsamp, stride, thr);                    \
+        for (int g = 0; g < groups; ++g) {                                                                                     \
+            if (CP == 32 && keep_small) KERNEL<32, kBoundKeepSmall><<<grid, 256, 0, ctx->stream>>>(OPERAND, nrm, Mp, k_bound, include_self, nsamp_g, stride, g, g > 0, thr); \
+            else if (CP == 32) KERNEL<32, kBoundKeepLarge><<<grid, 256, 0, ctx->stream>>>(OPERAND, nrm, Mp, k_bound, include_self, nsamp_g, stride, g, g > 0, thr);      \
+            else if (CP == 64 && keep_small) KERNEL<64, kBoundKeepSmall><<<grid, 256, 0, ctx->stream>>>(OPERAND, nrm, Mp, k_bound, include_self, nsamp_g, stride, g, g > 0, thr); \
+            else if (CP == 64) KERNEL<64, kBoundKeepLarge><<<grid, 256, 0, ctx->stream>>>(OPERAND, nrm, Mp, k_bound, include_self, nsamp_g, stride, g, g > 0, thr);      \
+            else if (keep_small) KERNEL<128, kBoundKeepSmall><<<grid, 256, 0, ctx->stream>>>(OPERAND, nrm, Mp, k_bound, include_self, nsamp_g, stride, g, g > 0, thr);    \
+            else KERNEL<128, kBoundKeepLarge><<<grid, 256, 0, ctx->stream>>>(OPERAND, nrm, Mp, k_bound, include_self, nsamp_g, stride, g, g > 0, thr);                    \
+        }                                                                                                                      \
     } while (0)
         if (bf) DDX_BOUND_LAUNCH(k_knn_bound_bf, Eb);
         else DDX_BOUND_LAUNCH(k_knn_bound, Et);
@@ -889,21 +919,29 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
         const unsigned grid = (unsigned)emit_blocks;
         const int dbg_mode = ctx->opt.knn_ablation;     // timing ablations (wrong results): non-zero only in -DDDX_ABLATION builds
         k_knn_window<<<grid, 64, 0, ctx->stream>>>(p1, thr, nrm, Mp, win, reinterpret_cast<unsigned long long*>(ccount + Mp + 2));
-        if (bf && CP == 32) k_knn_emit_bf<32><<<grid, 256, 0, ctx->stream>>>(Eb, nrm, start4, thr, Mp, include_self, ccount, cbuf, win, dbg_mode);
-        else if (bf) k_knn_emit_bf<64><<<grid, 256, 0, ctx->stream>>>(Eb, nrm, start4, thr, Mp, include_self, ccount, cbuf, win, dbg_mode);
-        else if (CP == 32) k_knn_emit<32><<<grid, 256, 0, ctx->stream>>>(Et, nrm, thr, Mp, include_self, ccount, cbuf, win);
-        else k_knn_emit<64><<<grid, 256, 0, ctx->stream>>>(Et, nrm, thr, Mp, include_self, ccount, cbuf, win);
+        if (bf && CP == 32) k_knn_emit_bf<32><<<grid, 256, 0, ctx->stream>>>(Eb, nrm, start4, thr, Mp, include_self, ccount, cbuf, win, dbg_mode, cap);
+        else if (bf && CP == 64) k_knn_emit_bf<64><<<grid, 256, 0, ctx->stream>>>(Eb, nrm, start4, thr, Mp, include_self, ccount, cbuf, win, dbg_mode, cap);
+        else if (bf) k_knn_emit_bf<128><<<grid, 256, 0, ctx->stream>>>(Eb, nrm, start4, thr, Mp, include_self, ccount, cbuf, win, dbg_mode, cap);
+        else if (CP == 32) k_knn_emit<32><<<grid, 256, 0, ctx->stream>>>(Et, nrm, thr, Mp, include_self, ccount, cbuf, win, cap);
+        else if (CP == 64) k_knn_emit<64><<<grid, 256, 0, ctx->stream>>>(Et, nrm, thr, Mp, include_self, ccount, cbuf, win, cap);
+        else k_knn_emit<128><<<grid, 256, 0, ctx->stream>>>(Et, nrm, thr, Mp, include_self, ccount, cbuf, win, cap);
     }
     {
         ScopedTimer t(ctx, "knn_select");
         const unsigned g2 = (unsigned)ceil_div(M, 4);
-        if (CP == 32) {
-            k_knn_select<32, kSelSmall><<<g2, 256, 0, ctx->stream>>>(E, perm, M, k, include_self, ccount, cbuf, ctx->knn_idx.as<int32_t>(), ctx->knn_dist.as<double>(), ccount + Mp);
-            k_knn_select<32, kSelMax><<<g2, 256, 0, ctx->stream>>>(E, perm, M, k, include_self, ccount, cbuf, ctx->knn_idx.as<int32_t>(), ctx->knn_dist.as<double>(), ccount + Mp);
-        } else {
-            k_knn_select<64, kSelSmall><<<g2, 256, 0, ctx->stream>>>(E, perm, M, k, include_self, ccount, cbuf, ctx->knn_idx.as<int32_t>(), ctx->knn_dist.as<double>(), ccount + Mp);
-            k_knn_select<64, kSelMax><<<g2, 256, 0, ctx->stream>>>(E, perm, M, k, include_self, ccount, cbuf, ctx->knn_idx.as<int32_t>(), ctx->knn_dist.as<double>(), ccount + Mp);
-        }
+        int32_t* ki = ctx->knn_idx.as<int32_t>();
+        double* kd = ctx->knn_dist.as<double>();
+#define DDX_SELECT_LAUNCH(CPV)                                                                                                                          \
+    do {                                                                                                                                                \
+        k_knn_select<CPV, kSelSmall, 4><<<g2, 256, 0, ctx->stream>>>(E, perm, M, k, include_self, ccount, cbuf, ki, kd, ccount + Mp, cap, 0, kSelSmall);    \
+        k_knn_select<CPV, kSelMax, 4><<<g2, 256, 0, ctx->stream>>>(E, perm, M, k, include_self, ccount, cbuf, ki, kd, ccount + Mp, cap, kSelSmall, kSelMax); \
+        if (cap > kSelMax)                                                                                                                              \
+            k_knn_select<CPV, kSelHuge, 1><<<(unsigned)M, 64, 0, ctx->stream>>>(E, perm, M, k, include_self, ccount, cbuf, ki, kd, ccount + Mp, cap, kSelMax, kSelHuge); \
+    } while (0)
+        if (CP == 32) DDX_SELECT_LAUNCH(32);
+        else if (CP == 64) DDX_SELECT_LAUNCH(64);
+        else DDX_SELECT_LAUNCH(128);
+#undef DDX_SELECT_LAUNCH
     }
     DDX_HIP(ctx, hipGetLastError());
     if (ctx->opt.knn_debug) {
@@ -911,7 +949,7 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
         DDX_HIP(ctx, hipMemcpyAsync(h.data(), ccount, sizeof(int32_t) * (Mp + 1), hipMemcpyDeviceToHost, ctx->stream));
         DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
         double sum = 0; int mx = 0; int64_t over = 0;
-        for (int64_t i = 0; i < M; ++i) { sum += h[i]; if (h[i] > mx) mx = h[i]; over += h[i] > kCandCap; }
+        for (int64_t i = 0; i < M; ++i) { sum += h[i]; if (h[i] > mx) mx = h[i]; over += h[i] > cap; }
         std::vector<int32_t> hw(2 * emit_blocks);
         DDX_HIP(ctx, hipMemcpy(hw.data(), win, sizeof(int32_t) * 2 * emit_blocks, hipMemcpyDeviceToHost));
         double wsum = 0;

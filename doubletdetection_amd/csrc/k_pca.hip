@@ -923,6 +923,102 @@ __global__ void k_f64_to_f32(const double* __restrict__ in, int64_t n, float* __
     if (i < n) out[i] = (float)in[i];
 }
 
+// ---- sketches wider than kMaxL columns -----------------------------------------------------------------------------
+// The operator products run block by block over the sketch columns (kWideBlock = the width the LDS-staged kernels are
+// built for); the tall-skinny helpers get tiled variants whose LDS need does not grow with the sketch width.
+constexpr int kWideBlock = 40;
+
+// out[r][c] = in[r][c0 + c] for c < Lb, 0 for Lb <= c < B      (a column block of an R x L matrix, zero padded)
+__global__ void k_cols_pack(const double* __restrict__ in, int64_t R, int L, int c0, int Lb, int B, double* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= R * B) return;
+    const int64_t r = t / B;
+    const int c = (int)(t - r * B);
+    out[t] = c < Lb ? in[r * L + c0 + c] : 0.0;
+}
+
+__global__ void k_cols_unpack(const double* __restrict__ in, int64_t R, int B, int c0, int Lb, int L, double* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= R * Lb) return;
+    const int64_t r = t / Lb;
+    const int c = (int)(t - r * Lb);
+    out[r * L + c0 + c] = in[r * B + c];
+}
+
+// partial Gram of a block of rows, one 32 x 32 tile (ta <= tb) per workgroup: thread (i, j) owns the 2 x 2 entries
+// (2i, 2i+1) x (2j, 2j+1) of the tile; rows are staged 32 at a time; both triangles are written.  Fixed summation order.
+__global__ void __launch_bounds__(256) k_gram_tiled(const double* __restrict__ X, int64_t R, int L, int64_t rows_per_block, int ntiles,
+                                                    double* __restrict__ partial) {
+    __shared__ double xa[32][33], xb[32][33];
+    int ta = 0, rest = blockIdx.y;                 // tile pair number -> (ta, tb), ta <= tb
+    while (rest >= ntiles - ta) { rest -= ntiles - ta; ++ta; }
+    const int tb = ta + rest;
+    const int tid = threadIdx.x, i = tid >> 4, j = tid & 15;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = (r0 + rows_per_block < R) ? r0 + rows_per_block : R;
+    double acc[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+    for (int64_t rb = r0; rb < r1; rb += 32) {
+        const int nr = (int)((r1 - rb) < 32 ? (r1 - rb) : 32);
+        __syncthreads();
+        for (int t = tid; t < 32 * 32; t += 256) {
+            const int rr = t >> 5, cc = t & 31;
+            const int ca = ta * 32 + cc, cb = tb * 32 + cc;
+            xa[rr][cc] = (rr < nr && ca < L) ? X[(rb + rr) * L + ca] : 0.0;
+            xb[rr][cc] = (rr < nr && cb < L) ? X[(rb + rr) * L + cb] : 0.0;
+        }
+        __syncthreads();
+        for (int rr = 0; rr < nr; ++rr) {
+            const double a0 = xa[rr][2 * i], a1 = xa[rr][2 * i + 1], b0 = xb[rr][2 * j], b1 = xb[rr][2 * j + 1];
+            acc[0][0] = fma(a0, b0, acc[0][0]); acc[0][1] = fma(a0, b1, acc[0][1]);
+            acc[1][0] = fma(a1, b0, acc[1][0]); acc[1][1] = fma(a1, b1, acc[1][1]);
+        }
+    }
+    double* out = partial + (int64_t)blockIdx.x * L * L;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            const int a = ta * 32 + 2 * i + u, b = tb * 32 + 2 * j + v;
+            if (a < L && b < L && (ta < tb || a <= b)) {
+                out[a * L + b] = acc[u][v];
+                out[b * L + a] = acc[u][v];
+            }
+        }
+}
+
+// out[R x L2] = X[R x L] * T[L x L2], one 64 x 32 tile of the result per workgroup, the inner dimension in chunks of 32
+__global__ void __launch_bounds__(256) k_right_mult_tiled(const double* __restrict__ X, int64_t R, int L, const double* __restrict__ T, int L2,
+                                                          double* __restrict__ out) {
+    __shared__ double xs[64][33], ts[32][33];
+    const int tid = threadIdx.x, row = tid >> 2, cg = tid & 3;        // 8 result columns per thread
+    const int64_t r0 = (int64_t)blockIdx.x * 64;
+    const int c0 = blockIdx.y * 32;
+    double acc[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] = 0.0;
+    for (int p0 = 0; p0 < L; p0 += 32) {
+        __syncthreads();
+        for (int t = tid; t < 64 * 32; t += 256) {
+            const int rr = t >> 5, pp = t & 31;
+            xs[rr][pp] = (r0 + rr < R && p0 + pp < L) ? X[(r0 + rr) * L + p0 + pp] : 0.0;
+        }
+        for (int t = tid; t < 32 * 32; t += 256) {
+            const int pp = t >> 5, cc = t & 31;
+            ts[pp][cc] = (p0 + pp < L && c0 + cc < L2) ? T[(int64_t)(p0 + pp) * L2 + c0 + cc] : 0.0;
+        }
+        __syncthreads();
+        for (int pp = 0; pp < 32; ++pp) {
+            const double x = xs[row][pp];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u] = fma(x, ts[pp][cg * 8 + u], acc[u]);
+        }
+    }
+    if (r0 + row < R)
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (c0 + cg * 8 + u < L2) out[(r0 + row) * L2 + c0 + cg * 8 + u] = acc[u];
+}
+
 // ------------------------------------------------------------------------------------------------
 // host orchestration
 // ------------------------------------------------------------------------------------------------
@@ -944,6 +1040,10 @@ struct PcaWork {
     double* partial;   // scratch for block partials
     double* small;     // [4*L*L + 4*L]: G, Rinv, T, vecs
     int* flag;
+    // sketches wider than kMaxL: the products run on column blocks through `sub` (width kWideBlock)
+    PcaWork* sub = nullptr;
+    double* blkRow = nullptr;     // [M x kWideBlock]
+    double* blkCol = nullptr;     // [H x kWideBlock]
 };
 
 static int wcolsum(PcaWork& w, const double* X, int64_t R, const double* wgt, double* out) {
@@ -956,6 +1056,15 @@ static int wcolsum(PcaWork& w, const double* X, int64_t R, const double* wgt, do
 }
 
 static int gram(PcaWork& w, const double* X, int64_t R, double* G) {
+    if (w.L > kMaxL) {
+        int nbw = (int)std::min<int64_t>(128, ceil_div(R, 256));
+        const int64_t rpbw = ceil_div(R, nbw);
+        nbw = (int)ceil_div(R, rpbw);
+        const int nt = (w.L + 31) / 32;
+        k_gram_tiled<<<dim3((unsigned)nbw, (unsigned)(nt * (nt + 1) / 2)), 256, 0, w.ctx->stream>>>(X, R, w.L, rpbw, nt, w.partial);
+        k_reduce_partials<<<(unsigned)ceil_div(w.L * w.L, 4), 256, 0, w.ctx->stream>>>(w.partial, nbw, w.L * w.L, G);
+        return DDX_OK;
+    }
     int nb = (int)std::min<int64_t>(512, ceil_div(R, 128));      // pcaPartial holds 512 partial Gram matrices
     int64_t rpb = ceil_div(R, nb);
     nb = (int)ceil_div(R, rpb);
@@ -966,12 +1075,60 @@ static int gram(PcaWork& w, const double* X, int64_t R, double* G) {
     return DDX_OK;
 }
 
+static int right_mult(ddx_ctx* ctx, const double* X, int64_t R, int L, const double* T, int L2, double* out) {
+    if ((size_t)(L * L2 + 64 * L) * sizeof(double) <= 64 * 1024)
+        k_right_mult<<<(unsigned)ceil_div(R, 64), 256, sizeof(double) * (L * L2 + 64 * L), ctx->stream>>>(X, R, L, T, L2, out);
+    else
+        k_right_mult_tiled<<<dim3((unsigned)ceil_div(R, 64), (unsigned)ceil_div(L2, 32)), 256, 0, ctx->stream>>>(X, R, L, T, L2, out);
+    return DDX_OK;
+}
+
+// Cholesky factor and its inverse on the host (sketches wider than one wave handles): same pivot floor as k_chol_inv
+static void chol_inverse_host(int L, std::vector<double>& a, std::vector<double>& inv, int* flag) {
+    double maxd = 0.0;
+    for (int k = 0; k < L; ++k) maxd = std::max(maxd, a[(size_t)k * L + k]);
+    const double floor_v = maxd * 1e-26 + 1e-300;
+    for (int k = 0; k < L; ++k) {
+        double d = a[(size_t)k * L + k];
+        if (!(d > floor_v)) { d = floor_v; *flag |= 1; }
+        const double piv = std::sqrt(d);
+        a[(size_t)k * L + k] = piv;
+        for (int j = k + 1; j < L; ++j) a[(size_t)k * L + j] /= piv;
+        for (int i = k + 1; i < L; ++i) {
+            const double rki = a[(size_t)k * L + i];
+            for (int j = i; j < L; ++j) a[(size_t)i * L + j] -= rki * a[(size_t)k * L + j];
+        }
+    }
+    inv.assign((size_t)L * L, 0.0);
+    for (int j = 0; j < L; ++j) {
+        inv[(size_t)j * L + j] = 1.0 / a[(size_t)j * L + j];
+        for (int i = j - 1; i >= 0; --i) {
+            double s = 0.0;
+            for (int p = i + 1; p <= j; ++p) s += a[(size_t)i * L + p] * inv[(size_t)p * L + j];
+            inv[(size_t)i * L + j] = -s / a[(size_t)i * L + i];
+        }
+    }
+}
+
 // X <- X R^-1 with X^T X = R^T R  (one Cholesky-QR pass); result lands in `out`
 static int cholqr(PcaWork& w, const double* X, int64_t R, double* out) {
     double* G = w.small;
     double* Rinv = w.small + w.L * w.L;
     ScopedTimer t(w.ctx, "pca_orth");
     gram(w, X, R, G);
+    if (w.L > kMaxL) {
+        const int L = w.L;
+        std::vector<double> hG((size_t)L * L), hInv;
+        DDX_HIP(w.ctx, hipMemcpyAsync(hG.data(), G, sizeof(double) * L * L, hipMemcpyDeviceToHost, w.ctx->stream));
+        DDX_HIP(w.ctx, hipStreamSynchronize(w.ctx->stream));
+        int hflag = 0;
+        chol_inverse_host(L, hG, hInv, &hflag);
+        if (hflag) DDX_HIP(w.ctx, hipMemcpyAsync(w.flag, &hflag, sizeof(int), hipMemcpyHostToDevice, w.ctx->stream));
+        DDX_HIP(w.ctx, hipMemcpyAsync(Rinv, hInv.data(), sizeof(double) * L * L, hipMemcpyHostToDevice, w.ctx->stream));
+        right_mult(w.ctx, X, R, L, Rinv, L, out);
+        DDX_HIP(w.ctx, hipStreamSynchronize(w.ctx->stream));       // hInv / hflag are stack-backed
+        return DDX_OK;
+    }
     if (w.L == 40) k_chol_inv_reg<40><<<1, 64, 0, w.ctx->stream>>>(G, Rinv, w.flag);      // the default sketch width (30 + 10)
     else k_chol_inv<<<1, 64, 2 * sizeof(double) * w.L * w.L, w.ctx->stream>>>(G, w.L, Rinv, w.flag);
     float* out32 = nullptr;
@@ -1037,7 +1194,11 @@ static int launch_lds(ddx_ctx* c, const LdsSpmmArgs& a, int slots, unsigned grid
     return slots == 4 ? launch_lds_t<ROWS, 4, false, 2, kLdsOwnG>(c, a, grid, lds_bytes) : launch_lds_t<ROWS, 3, false, 2, kLdsOwnG>(c, a, grid, lds_bytes);
 }
 
+static int apply_rows_wide(PcaWork& w, const double* Qcol, double* Yrow);
+static int apply_cols_wide(PcaWork& w, const double* Yrow, double* Wcol);
+
 static int apply_rows(PcaWork& w, const double* Qcol, double* Yrow) {  // A Q : [H x L] -> [M x L]
+    if (w.L > kMaxL) return apply_rows_wide(w, Qcol, Yrow);
     ddx_ctx* c = w.ctx;
     double* tvec = w.small + 3 * w.L * w.L;
     {
@@ -1089,6 +1250,7 @@ static int apply_rows(PcaWork& w, const double* Qcol, double* Yrow) {  // A Q : 
 }
 
 static int apply_cols(PcaWork& w, const double* Yrow, double* Wcol) {  // A^T Y : [M x L] -> [H x L]
+    if (w.L > kMaxL) return apply_cols_wide(w, Yrow, Wcol);
     ddx_ctx* c = w.ctx;
     double* uvec = w.small + 3 * w.L * w.L + w.L;
     {
@@ -1141,6 +1303,28 @@ static int apply_cols(PcaWork& w, const double* Yrow, double* Wcol) {  // A^T Y 
     }
     k_sum_panels<<<(unsigned)ceil_div((int64_t)w.H * w.L, 256), 256, 0, c->stream>>>(c->pcaPanel.as<double>(), P, w.H, w.L, c->colmean.as<double>(),
                                                                                       uvec, Wcol);
+    return DDX_OK;
+}
+
+static int apply_rows_wide(PcaWork& w, const double* Qcol, double* Yrow) {
+    hipStream_t st = w.ctx->stream;
+    for (int c0 = 0; c0 < w.L; c0 += kWideBlock) {
+        const int Lb = std::min(kWideBlock, w.L - c0);
+        k_cols_pack<<<(unsigned)ceil_div((int64_t)w.H * kWideBlock, 256), 256, 0, st>>>(Qcol, w.H, w.L, c0, Lb, kWideBlock, w.blkCol);
+        DDX_TRY(apply_rows(*w.sub, w.blkCol, w.blkRow));
+        k_cols_unpack<<<(unsigned)ceil_div(w.M * Lb, 256), 256, 0, st>>>(w.blkRow, w.M, kWideBlock, c0, Lb, w.L, Yrow);
+    }
+    return DDX_OK;
+}
+
+static int apply_cols_wide(PcaWork& w, const double* Yrow, double* Wcol) {
+    hipStream_t st = w.ctx->stream;
+    for (int c0 = 0; c0 < w.L; c0 += kWideBlock) {
+        const int Lb = std::min(kWideBlock, w.L - c0);
+        k_cols_pack<<<(unsigned)ceil_div(w.M * kWideBlock, 256), 256, 0, st>>>(Yrow, w.M, w.L, c0, Lb, kWideBlock, w.blkRow);
+        DDX_TRY(apply_cols(*w.sub, w.blkRow, w.blkCol));
+        k_cols_unpack<<<(unsigned)ceil_div((int64_t)w.H * Lb, 256), 256, 0, st>>>(w.blkCol, w.H, kWideBlock, c0, Lb, w.L, Wcol);
+    }
     return DDX_OK;
 }
 
@@ -1230,7 +1414,7 @@ int stage_operator_apply(ddx_ctx* ctx, int32_t mode, const double* X, int32_t n,
 int stage_pca(ddx_ctx* ctx, int32_t C, int32_t oversample, int32_t n_iter, const double* q0, int64_t q0_rows) {
     t_opt = &ctx->opt;
     const int L = C + oversample;
-    if (L > kMaxL) return set_err(ctx, DDX_E_UNSUPPORTED, "sketch width %d exceeds %d", L, kMaxL);
+    const bool wide = L > kMaxL;         // the products run on column blocks of kWideBlock, the tall-skinny helpers tiled
     const int64_t M = ctx->M;
     const int32_t H = ctx->H;
     const bool transposed = M < H;
@@ -1240,10 +1424,12 @@ int stage_pca(ddx_ctx* ctx, int32_t C, int32_t oversample, int32_t n_iter, const
     // row-side (M x L) and column-side (H x L) buffers, two of each (ping/pong)
     DDX_TRY(ensure(ctx, ctx->pcaA, sizeof(double) * 2 * (size_t)M * L));
     DDX_TRY(ensure(ctx, ctx->pcaB, sizeof(double) * 2 * (size_t)H * L));
-    DDX_TRY(ensure(ctx, ctx->pcaSmall, sizeof(double) * (4 * L * L + 4 * L) + 256));
-    DDX_TRY(ensure(ctx, ctx->pcaPartial, sizeof(double) * 512 * (size_t)std::max(L * L, 128)));
+    constexpr int kSubSmall = 4 * kWideBlock * kWideBlock + 4 * kWideBlock;      // the block work's own small area behind the main one
+    DDX_TRY(ensure(ctx, ctx->pcaSmall, sizeof(double) * (4 * (size_t)L * L + 4 * L + kSubSmall) + 256));
+    DDX_TRY(ensure(ctx, ctx->pcaPartial, sizeof(double) * (wide ? 128 : 512) * (size_t)std::max(L * L, 128 * 4)));
     DDX_TRY(ensure(ctx, ctx->pcaVec, 256));
-    DDX_TRY(ensure(ctx, ctx->pcaPanel, sizeof(double) * (size_t)ceil_div(M, ctx->panel_rows) * H * L));
+    DDX_TRY(ensure(ctx, ctx->pcaPanel, sizeof(double) * (size_t)ceil_div(M, ctx->panel_rows) * H * (wide ? kWideBlock : L)));
+    if (wide) DDX_TRY(ensure(ctx, ctx->pcaBlk, sizeof(double) * (size_t)(M + H) * kWideBlock));
     DDX_TRY(ensure(ctx, ctx->emb64, sizeof(double) * (size_t)M * C));
     DDX_TRY(ensure(ctx, ctx->emb32, sizeof(float) * (size_t)M * C));
     DDX_TRY(ensure(ctx, ctx->sing, sizeof(double) * L));
@@ -1264,7 +1450,17 @@ int stage_pca(ddx_ctx* ctx, int32_t C, int32_t oversample, int32_t n_iter, const
     }
     w.M = M;
     w.H = H;
-    DDX_TRY(lds_setup(ctx, L, w));
+    PcaWork wsub;
+    if (wide) {
+        w.lds = false;
+        wsub = w;
+        wsub.L = kWideBlock;
+        wsub.lpn = (kWideBlock + 1) / 2;
+        wsub.slots = 64 / wsub.lpn;
+        DDX_TRY(lds_setup(ctx, kWideBlock, wsub));
+    } else {
+        DDX_TRY(lds_setup(ctx, L, w));
+    }
     const int64_t maxR = M > H ? M : (int64_t)H;
     DDX_TRY(ensure(ctx, ctx->pcaOp, sizeof(double) * (size_t)maxR * (L + 4)));
     w.op32 = ctx->pcaOp.as<float>();
@@ -1281,6 +1477,16 @@ int stage_pca(ddx_ctx* ctx, int32_t C, int32_t oversample, int32_t n_iter, const
     w.small = ctx->pcaSmall.as<double>();
     w.flag = ctx->pcaVec.as<int>();
     DDX_HIP(ctx, hipMemsetAsync(w.flag, 0, sizeof(int), ctx->stream));
+    if (wide) {
+        wsub.op32 = w.op32;
+        wsub.opQ = nullptr;                                   // (block products copy their operand each time)
+        wsub.partial = w.partial;
+        wsub.small = w.small + 4 * (size_t)L * L + 4 * L;
+        wsub.flag = w.flag;
+        w.sub = &wsub;
+        w.blkRow = ctx->pcaBlk.as<double>();
+        w.blkCol = w.blkRow + (size_t)M * kWideBlock;
+    }
 
     // the start matrix stays on the device: the boosting iterations of a fit all use the same seeded draw
     DDX_TRY(ensure(ctx, ctx->pcaQ0, sizeof(double) * (size_t)q0_rows * L));
@@ -1352,7 +1558,7 @@ int stage_pca(ddx_ctx* ctx, int32_t C, int32_t oversample, int32_t n_iter, const
     double* scratchHC = transposed ? colB : colA;      // H x C scratch (colA/colB are H x L >= H x C)
     {
         ScopedTimer t(ctx, "pca_finish");
-        k_right_mult<<<(unsigned)ceil_div(signR, 64), 256, sizeof(double) * (L * C + 64 * L), ctx->stream>>>(signSrc, signR, L, dT, C, scratchHC);
+        right_mult(ctx, signSrc, signR, L, dT, C, scratchHC);
         k_col_sign<<<C, 256, 0, ctx->stream>>>(scratchHC, signR, C, dSign);
     }
     std::vector<double> hsign(C);
@@ -1367,7 +1573,7 @@ int stage_pca(ddx_ctx* ctx, int32_t C, int32_t oversample, int32_t n_iter, const
     {
         ScopedTimer t(ctx, "pca_finish");
         const double* scoreSrc = transposed ? Bt : Qfinal;  // both M x L
-        k_right_mult<<<(unsigned)ceil_div(M, 64), 256, sizeof(double) * (L * C + 64 * L), ctx->stream>>>(scoreSrc, M, L, dT, C, ctx->emb64.as<double>());
+        right_mult(ctx, scoreSrc, M, L, dT, C, ctx->emb64.as<double>());
         k_f64_to_f32<<<(unsigned)ceil_div(M * C, 256), 256, 0, ctx->stream>>>(ctx->emb64.as<double>(), M * C, ctx->emb32.as<float>());
     }
     DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));  // T2/svals are stack-backed host buffers

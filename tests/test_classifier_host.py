@@ -230,8 +230,8 @@ def test_device_limits_raise_before_any_upload():
     counts = np.random.default_rng(0).poisson(1.0, size=(900, 700))
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        for kw in (dict(n_components=55, n_top_var_genes=0), dict(n_components=70, n_top_var_genes=0),
-                   dict(clustering_kwargs={"k": 65})):
+        for kw in (dict(n_components=129, n_top_var_genes=0), dict(n_components=400, n_top_var_genes=0),
+                   dict(clustering_kwargs={"k": 257})):
             clf = BoostClassifier(n_iters=2, **kw)
             clf._engine_factory = Untouchable
             with pytest.raises(NotImplementedError, match="device"):

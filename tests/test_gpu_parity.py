@@ -539,6 +539,55 @@ def test_other_sketch_widths_and_leiden(n_components, algo):
     np.testing.assert_allclose(clf.all_log_p_values_, ref.all_log_p_values_, rtol=1e-9, atol=1e-9)
 
 
+@pytest.mark.parametrize("n_components,k,algo", [(100, 100, "phenograph"), (60, 200, "phenograph"), (128, 30, "phenograph"), (70, None, "louvain")])
+def test_wide_sketches_many_dimensions_many_neighbours(n_components, k, algo):
+    """What the reference accepts and round 2 refused (dd.py:108-112, 320-322): n_components beyond 54 (sketches wider than
+    64 columns run block by block, the orthonormalisations tiled), embeddings of up to 128 dimensions and up to 256
+    neighbours in the kNN kernels (the bound pass split over several launches, longer candidate lists) -- stage by stage
+    against the float64 oracle, then the whole fit."""
+    from doubletdetection_amd import BoostClassifier, _lib
+    from doubletdetection_amd._synthetic import make_counts
+
+    counts = make_counts(2400, 900, density=0.2, n_types=6, seed=33)
+    ckw = {} if k is None else {"k": k}
+    kw = dict(n_iters=2, n_top_var_genes=800, n_components=n_components, clustering_algorithm=algo, clustering_kwargs=dict(ckw),
+              random_state=4)
+    with _lib.Context(0) as ctx:
+        _, sub = orc.select_hvg(sp.csr_matrix(counts, dtype=np.float32), 800)
+        ctx.upload_counts(sub)
+        parents = np.random.default_rng(4).choice(2400, size=(600, 2), replace=False)
+        ctx.create_doublets(parents)
+        ctx.lognormalise(0.1)
+        M, H = ctx.M, ctx.H
+        assert orc.sklearn_solver_policy(M, H, n_components) == "randomized"
+        ctx.pca(n_components, orc.pca_start_matrix(4, H, n_components + 10))
+        emb64, sing = ctx.embedding_f64()
+        dense = ctx.aug_dense_rows(0, M)
+        want, s_want, _ = orc.randomized_pca_f64(dense, n_components, 4)
+        rel = orc.per_component_rel_dev(emb64, want)
+        assert rel.max() <= 1e-5, rel
+        np.testing.assert_allclose(sing, s_want, rtol=1e-6)
+        kk = 30 if k is None else k
+        ctx.knn(kk, False)
+        idx, dist = ctx.get_knn()
+        ref_idx, ref_dist = orc.knn_bruteforce_f64(ctx.embedding(), kk, False)
+        np.testing.assert_array_equal(idx, ref_idx)
+        np.testing.assert_array_equal(dist, ref_dist)
+        G = orc.jaccard_graph(ref_idx, prune=True)
+        ip, ix, w = ctx.build_graph(0)
+        np.testing.assert_array_equal(ip, G.indptr)
+        np.testing.assert_array_equal(ix, G.indices)
+        np.testing.assert_allclose(w, G.data, rtol=1e-12)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        clf = BoostClassifier(**kw).fit(counts)
+        kw["clustering_kwargs"] = dict(ckw)
+        ref = orc.OracleClassifier(pca="f64", **kw).fit(counts)
+    np.testing.assert_array_equal(clf.communities_, ref.communities_)
+    np.testing.assert_array_equal(clf.all_scores_, ref.all_scores_)
+    np.testing.assert_allclose(clf.all_log_p_values_, ref.all_log_p_values_, rtol=1e-9, atol=1e-9)
+
+
 def test_api_corners_on_gpu(capsys):
     from doubletdetection_amd import BoostClassifier
 
