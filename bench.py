@@ -57,6 +57,9 @@ def parse():
     ap.add_argument("--scaling", action="store_true", help="standard_scaling=True")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-cells", type=int, default=20000)
+    ap.add_argument("--cpu-full", action="store_true", help="cpu_baseline on ALL cells (two iterations of the oracle at the full size: "
+                                                            "minutes and tens of GB of host memory; SURVEY.md section 8 d)")
+    ap.add_argument("--instrumented-steps", type=int, default=2, help="extra fits with per-kernel HIP events (N=1) behind the kernel tables")
     ap.add_argument("--resident-steps", type=int, default=2, help="extra fits on staged counts for value_resident (N=1)")
     ap.add_argument("--no-exclusive", action="store_true", help="skip the extra single-context fits behind roofline_exclusive")
     return ap.parse_args()
@@ -91,17 +94,18 @@ def kernel_models(N, G, H, S, nnz_aug, C, k, L=None, knn_window=1.0):
         # name: (bound, unit, work per launch, peak)
         "spmm_rows": ("hbm", "GB/s", (8 * nnz_aug + 8 * M * L + 8 * H * L + 8 * (M + 1)) / 1e9, HBM_PEAK_GBS),
         "spmm_cols": ("hbm", "GB/s", (8 * nnz_aug + 8 * H * L + 8 * M * L + 16 * (H + 1)) / 1e9, HBM_PEAK_GBS),
-        # distance screen on the bfloat16 MFMA: three products (hi*hi, hi*lo, lo*hi) per pair and component
-        # (the emit pass only screens the tile pairs its first-component window admits: measured fraction)
-        "knn_emit": ("mfma", "TFLOP/s", knn_window * 3 * 2.0 * Mp * Mp * CP / 1e12, BF16_PEAK_TFLOPS),
-        "knn_bound": ("mfma", "TFLOP/s", 3 * 2.0 * Mp * nsamp_tiles * 16 * CP / 1e12, BF16_PEAK_TFLOPS),
+        # distance screen on the bfloat16 MFMA.  USEFUL work: 2 flop per component and screened pair (the emit pass only
+        # screens the tile pairs its first-component window admits: measured fraction).  The kernel ISSUES three products
+        # (hi*hi, hi*lo, lo*hi) per pair on components padded to CP: see issued_per_launch below.
+        "knn_emit": ("mfma", "TFLOP/s", knn_window * 2.0 * M * M * C / 1e12, BF16_PEAK_TFLOPS),
+        "knn_bound": ("mfma", "TFLOP/s", 2.0 * M * nsamp_tiles * 16 * C / 1e12, BF16_PEAK_TFLOPS),
         "pca_orth": ("hbm", "GB/s", (24 * M * L) / 1e9, HBM_PEAK_GBS),
         "doublet_fill": ("hbm", "GB/s", (8 * (nnz_aug * 2 * S / max(M + S, 1)) * 2) / 1e9, HBM_PEAK_GBS),
         "lognorm_rows": ("hbm", "GB/s", (8 * nnz_aug + 8 * M) / 1e9, HBM_PEAK_GBS),
         "lognorm_cols": ("hbm", "GB/s", (12 * nnz_aug) / 1e9, HBM_PEAK_GBS),
         # counting-sort mirror of the synthetic rows: columns read twice (4 B), raw values once (4 B), (row, raw) written once (8 B)
         "mirror_build": ("hbm", "GB/s", (20 * nnz_aug * 2 * S / max(M + S, 1)) / 1e9, HBM_PEAK_GBS),
-    }
+    }, {"knn_emit": knn_window * 3 * 2.0 * Mp * Mp * CP / 1e12, "knn_bound": 3 * 2.0 * Mp * nsamp_tiles * 16 * CP / 1e12}
 
 
 def main():
@@ -126,7 +130,7 @@ def main():
     from doubletdetection_amd import BoostClassifier
     from doubletdetection_amd._synthetic import make_counts
 
-    os.environ["DDX_TIMING"] = "1"
+    os.environ["DDX_TIMING"] = "0"              # the timed steps run the production path: no per-kernel HIP events
     t_gen = time.perf_counter()
     X = make_counts(args.cells, args.genes, density=args.density, device=dev, seed=20250227)
     t_gen = time.perf_counter() - t_gen
@@ -156,33 +160,40 @@ def main():
     for _ in range(args.warmup):
         one_fit()
     elapsed = 0.0
-    timings = {}
     clf = None
     for _ in range(args.steps):
         clf, dt = one_fit()
         elapsed += dt
-        for name, (launches, ms) in clf._device_timings.items():
-            a = timings.setdefault(name, [0, 0.0])
-            a[0] += launches
-            a[1] += ms
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # ---- everything below is outside the timed region -------------------------------------------------------------------
     resident_elapsed = None
     exclusive = None
-    plain_elapsed = None
+    timings = {}
+    instr_elapsed, busy_ms = 0.0, 0.0
     if world == 1 and args.resident_steps > 0:
         resident_elapsed = sum(one_fit(resident=True)[1] for _ in range(args.resident_steps))
-        # the same fits without the per-kernel HIP events (two events per timed scope, ~1 300 scopes per fit)
-        os.environ["DDX_TIMING"] = "0"
-        plain_elapsed = sum(one_fit()[1] for _ in range(args.resident_steps))
+    if args.instrumented_steps > 0:          # (every rank: a fit ends with the ranks' collective)
+        # the same fits with two HIP events around every kernel scope (~1 400 scopes per fit): per-kernel times, and the
+        # wall-clock share during which at least one scope was running (union of the scope intervals of both streams)
         os.environ["DDX_TIMING"] = "1"
-    if world == 1 and getattr(clf, "_lanes_used", 1) > 1 and not args.no_exclusive:
-        # one more fit on a single device context: every kernel has the GPU to itself, so its HIP-event duration is the
-        # kernel's own (in the timed region two contexts share the GPU and a launch is stretched by its neighbours)
-        one_fit(streams_per_device=1)
-        exclusive = one_fit(streams_per_device=1)[0]._device_timings
+        one_fit()
+        for _ in range(args.instrumented_steps):
+            c2, dt = one_fit()
+            instr_elapsed += dt
+            busy_ms += c2._device_busy_ms or 0.0
+            for name, (launches, ms) in c2._device_timings.items():
+                a = timings.setdefault(name, [0, 0.0])
+                a[0] += launches
+                a[1] += ms
+        if getattr(clf, "_lanes_used", 1) > 1 and not args.no_exclusive:
+            # and on a single device context: every kernel has the GPU to itself, so its HIP-event duration is the
+            # kernel's own (with two contexts a launch is stretched by its neighbours)
+            one_fit(streams_per_device=1)
+            exclusive = one_fit(streams_per_device=1)[0]._device_timings
+        os.environ["DDX_TIMING"] = "0"
 
     if rank == 0:
         H = clf._num_genes
@@ -190,18 +201,23 @@ def main():
         nnz_aug = getattr(clf, "_last_nnz_aug", None) or int(X.nnz * 1.0)
         C = clf.n_components
         k = 30 if args.algorithm == "phenograph" else 10
-        models = kernel_models(N, G, H, S, nnz_aug, C, k, knn_window=getattr(clf, "_last_knn_window", 1.0))
+        models, issued = kernel_models(N, G, H, S, nnz_aug, C, k, knn_window=getattr(clf, "_last_knn_window", 1.0))
         gpu_ms = {n: v[1] for n, v in timings.items()}
         dominant = max(gpu_ms, key=gpu_ms.get) if gpu_ms else None
         def roof(name, timings=timings):
             bound, unit, work, peak = models[name]
             avg_s = timings[name][1] / max(timings[name][0], 1) / 1e3
             achieved = work / avg_s
-            return {"bound": bound, "kernel": name, "achieved": round(achieved, 2), "peak": peak, "unit": unit,
-                    "frac": round(achieved / peak, 4), "traffic": PMC_TRAFFIC_GB.get(name),
-                    "traffic_source": PMC_TRAFFIC_SOURCE if name in PMC_TRAFFIC_GB else None,
-                    "avg_launch_ms": round(avg_s * 1e3, 4), "launches": timings[name][0], "work_per_launch": round(work, 4)}
+            out = {"bound": bound, "kernel": name, "achieved": round(achieved, 2), "peak": peak, "unit": unit,
+                   "frac": round(achieved / peak, 4), "traffic": PMC_TRAFFIC_GB.get(name),
+                   "traffic_source": PMC_TRAFFIC_SOURCE if name in PMC_TRAFFIC_GB else None,
+                   "avg_launch_ms": round(avg_s * 1e3, 4), "launches": timings[name][0], "work_per_launch": round(work, 4)}
+            if name in issued:          # MFMA screens: useful flops above, what the kernel issues (3 products, padded) here
+                out["issued_per_launch"] = round(issued[name], 4)
+                out["issued_frac"] = round(issued[name] / avg_s / peak, 4)
+            return out
 
+        nsteps_i = max(args.instrumented_steps, 1)
         roofline_timed = roof(dominant) if dominant in models else None
         roofline_timed_all = [roof(n) for n in sorted(gpu_ms, key=gpu_ms.get, reverse=True) if n in models][:6]
         # When two device contexts share the GPU (the default), the HIP events around a launch also count the time the
@@ -210,24 +226,23 @@ def main():
         # comes from the fit that follows the timed steps on ONE context (same process, same data, same kernels, each
         # alone on the GPU); it agrees with `rocprofv3 --kernel-trace --stats` of `DDX_STREAMS=1 bench.py`
         # (profiles/*_kernel_stats_1stream.csv).  The timed-region figures are kept beside it.
-        roofline, roofline_all, roofline_source = roofline_timed, roofline_timed_all, "HIP events over the timed region"
+        roofline, roofline_all, roofline_source = roofline_timed, roofline_timed_all, "HIP events over the instrumented fits (two contexts)"
         if exclusive:
             ex = {n: [v[0], v[1]] for n, v in exclusive.items()}
             order = [n for n in sorted(ex, key=lambda n: -ex[n][1]) if n in models]
             roofline, roofline_all = roof(order[0], ex), [roof(n, ex) for n in order[:6]]
             roofline_source = ("HIP events over one fit on a single device context, run right after the timed steps (in the "
                                "timed region two contexts share the GPU and a launch's events include queueing behind the "
-                               "other stream: see roofline_timed_region)")
+                               "other stream: see roofline_two_contexts)")
         if roofline:
             roofline["measured"] = roofline_source
-        total_gpu_ms = sum(gpu_ms.values())
         out = {
             "metric": "cells/sec for full BoostClassifier.fit() (default n_iters)",
             "value": round(N * args.steps / elapsed, 2),
             "timed_region": "BoostClassifier(**kw).fit(host scipy CSR): check_array-equivalent validation + PCIe upload + "
-                            "HVG prologue + n_iters iterations + gather (dd.py:135-214)",
+                            "HVG prologue + n_iters iterations + gather (dd.py:135-214); production path (no per-kernel events)",
             "value_resident": (round(N * args.resident_steps / resident_elapsed, 2) if resident_elapsed else None),
-            "value_uninstrumented": (round(N * args.resident_steps / plain_elapsed, 2) if plain_elapsed else None),
+            "value_instrumented": (round(N * args.instrumented_steps / instr_elapsed, 2) if instr_elapsed else None),
             "unit": "cells/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -247,10 +262,13 @@ def main():
                        "host_threads": os.cpu_count()},
             "roofline": roofline,
             "roofline_top_kernels": roofline_all,
-            "roofline_timed_region": roofline_timed,
-            "roofline_timed_region_top_kernels": roofline_timed_all,
-            "gpu_kernel_ms_per_step": {n: round(v / args.steps, 3) for n, v in sorted(gpu_ms.items(), key=lambda kv: -kv[1])},
-            "gpu_busy_frac": round(total_gpu_ms / 1e3 / elapsed, 4),
+            "roofline_two_contexts": roofline_timed,
+            "roofline_two_contexts_top_kernels": roofline_timed_all,
+            "gpu_kernel_ms_per_step": {n: round(v / nsteps_i, 3) for n, v in sorted(gpu_ms.items(), key=lambda kv: -kv[1])},
+            "gpu_kernel_ms_per_step_note": "HIP-event spans summed over both device contexts of the instrumented fits (overlapping "
+                                           "streams: the sum exceeds the wall-clock); the timed steps themselves carry no events",
+            "gpu_busy_frac": (round(busy_ms / 1e3 / instr_elapsed, 4) if instr_elapsed and busy_ms else None),
+            "gpu_busy_frac_note": "union of the kernel-scope intervals of all streams / wall-clock of the instrumented fits",
             "host_seconds_last_step": {k2: round(v, 3) for k2, v in getattr(clf, "_host_timings", {}).items()},
             "datagen_s": round(t_gen, 2),
             "notes": "PCA = sklearn's randomized SVD as 16 sparse operator products per iteration (no dense H x H Gram is "
@@ -272,7 +290,7 @@ def cpu_baseline(X, args, kw):
     from doubletdetection_amd import _lib
     from oracle import dd_oracle as orc
 
-    n = min(args.cpu_sample_cells, X.shape[0])
+    n = X.shape[0] if args.cpu_full else min(args.cpu_sample_cells, X.shape[0])
     rows = np.sort(np.random.default_rng(0).choice(X.shape[0], size=n, replace=False))
     sample = X[rows]
     iters = 2        # ~10 s of CPU work on the GPU box's host
@@ -295,8 +313,9 @@ def cpu_baseline(X, args, kw):
     return {"value": round(n / full_fit, 2), "unit": "cells/s", "cores": os.cpu_count(), "kind": "port",
             "sample": f"{n} of {X.shape[0]} cells x {X.shape[1]} genes, {iters} iterations timed ({dt:.1f} s) and scaled to "
                       f"n_iters={args.iters}; dense log matrix + sklearn randomized PCA + exact kNN + host Louvain.  "
-                      "A row sample flatters the CPU: kNN and the Jaccard graph grow faster than linearly in the number of "
-                      "cells, so cells/s at the full size is lower than this figure",
+                      + ("All cells (SURVEY.md section 8 d)." if args.cpu_full else
+                         "A row sample flatters the CPU: kNN and the Jaccard graph grow faster than linearly in the number of "
+                         "cells, so cells/s at the full size is lower than this figure (profiles/r03_cpu_full.json: the full-size run)"),
             "stage_seconds": {k2: round(v, 3) for k2, v in o.timings.items()}}
 
 

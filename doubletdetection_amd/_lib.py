@@ -94,6 +94,8 @@ _SIGNATURES = {
     "ddx_timing_reset": (C.c_int, [C.c_void_p]),
     "ddx_timing_count": (C.c_int, [C.c_void_p, c_i32_p]),
     "ddx_timing_get": (C.c_int, [C.c_void_p, C.c_int32, C.c_char_p, c_i64_p, c_f64_p]),
+    "ddx_timing_reference": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ddx_timing_intervals": (C.c_int, [C.c_void_p, C.c_int64, c_f64_p, c_i64_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(sorted(_SIGNATURES))
@@ -599,6 +601,19 @@ class Context:
 
     def timing_reset(self):
         self._c(self._lib.ddx_timing_reset(self._h))
+
+    def timing_reference(self, share_with: "Context" = None):
+        """Clock origin of the scope intervals: now on this context's stream, or the origin of `share_with`."""
+        self._c(self._lib.ddx_timing_reference(self._h, share_with._h if share_with is not None else None))
+
+    def timing_intervals(self):
+        """[(begin_ms, end_ms)] of every timed scope since the last reset, relative to the clock origin."""
+        n = C.c_int64(0)
+        self._c(self._lib.ddx_timing_intervals(self._h, 0, None, C.byref(n)))
+        out = np.empty((n.value, 2), dtype=np.float64)
+        if n.value:
+            self._c(self._lib.ddx_timing_intervals(self._h, n.value, _p(out, c_f64_p), C.byref(n)))
+        return out
 
     def timings(self):
         n = C.c_int32(0)

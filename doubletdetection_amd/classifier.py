@@ -115,8 +115,10 @@ class _HipEngine:
         self.ctx = parked.pop() if parked else _lib.Context(device)
         timing = os.environ.get("DDX_TIMING") == "1"     # per-kernel HIP-event timing (bench.py / profiling)
         self.ctx.timing_enable(timing)
+        self.timing = timing
         if timing:
             self.ctx.timing_reset()
+            self.ctx.timing_reference()                  # clock origin of the scope intervals (followers adopt their leader's)
 
     def close(self, discard: bool = False):
         """Park the context for the next fit, or destroy it (``discard``: a fit that failed does not hand its context,
@@ -149,6 +151,8 @@ class _HipEngine:
     def clone_from(self, other):
         """Take over the resident counts of another engine on the same GPU (device-to-device, ddx_clone_counts)."""
         self.ctx.clone_counts_from(other.ctx)
+        if self.timing and other.timing:
+            self.ctx.timing_reference(other.ctx)         # one time axis for the streams of a GPU
 
     def run_iteration(self, parents, pseudocount, standard_scaling, n_components, q0, knn_k, include_self,
                       graph_mode, gamma=None, pca_lock=None, verbose=False):
@@ -272,6 +276,9 @@ class _HipEngine:
 
     def timings(self):
         return self.ctx.timings()
+
+    def timing_intervals(self):
+        return self.ctx.timing_intervals() if self.timing else np.zeros((0, 2))
 
     def aug_nnz(self):
         return self.ctx.aug_nnz()
@@ -858,6 +865,20 @@ class BoostClassifier:
             for name, (launches, ms) in (engine.timings() if hasattr(engine, "timings") else {}).items():
                 a = self._device_timings.get(name, (0, 0.0))
                 self._device_timings[name] = (a[0] + launches, a[1] + ms)
+        # share of the wall-clock during which at least one kernel scope of this process was running on a GPU (bench.py)
+        self._device_busy_ms = None
+        spans = [e.timing_intervals() for _, e in lanes if hasattr(e, "timing_intervals")]
+        spans = np.concatenate(spans) if spans else np.zeros((0, 2))
+        if len(spans) and len({d for d, _ in lanes}) == 1:
+            spans = spans[np.argsort(spans[:, 0])]
+            busy, cur_lo, cur_hi = 0.0, spans[0, 0], spans[0, 1]
+            for lo, hi in spans[1:]:
+                if lo > cur_hi:
+                    busy += cur_hi - cur_lo
+                    cur_lo, cur_hi = lo, hi
+                else:
+                    cur_hi = max(cur_hi, hi)
+            self._device_busy_ms = busy + (cur_hi - cur_lo)
         lead = lanes[0][1]
         if mine and hasattr(lead, "aug_nnz"):
             self._last_nnz_aug = lead.aug_nnz()     # stored entries of the last augmented matrix

@@ -203,6 +203,11 @@ int timing_flush(ddx_ctx* ctx) {
         if (hipEventElapsedTime(&ms, ev.start, ev.stop) == hipSuccess) {
             ctx->t_recs[ev.name_id].launches += 1;
             ctx->t_recs[ev.name_id].total_ms += ms;
+            float t0 = 0.f;
+            if (ctx->t_ref && hipEventElapsedTime(&t0, ctx->t_ref, ev.start) == hipSuccess) {
+                ctx->t_intervals.push_back(t0);
+                ctx->t_intervals.push_back(t0 + ms);
+            }
         }
         ctx->t_free.push_back(ev.start);
         ctx->t_free.push_back(ev.stop);
@@ -273,6 +278,8 @@ int ddx_destroy(ddx_ctx* ctx) {
     (void)timing_flush(ctx);
     for (hipEvent_t e : ctx->t_free) (void)hipEventDestroy(e);
     ctx->t_free.clear();
+    if (ctx->t_ref && ctx->t_ref_owned) (void)hipEventDestroy(ctx->t_ref);
+    ctx->t_ref = nullptr;
     context_reset(ctx);
     arena_destroy(ctx);
     if (ctx->lv_host) (void)hipHostFree(ctx->lv_host);
@@ -957,6 +964,7 @@ int ddx_timing_enable(ddx_ctx* ctx, int32_t on) {
     REQUIRE_CTX(ctx);
     USE_DEVICE(ctx);
     if (!on) DDX_TRY(timing_flush(ctx));
+    if (!on && !ctx->t_ref_owned) ctx->t_ref = nullptr;        // (a borrowed clock origin is not kept beyond the timed fits)
     ctx->timing = on != 0;
     return DDX_OK;
 }
@@ -966,6 +974,38 @@ int ddx_timing_reset(ddx_ctx* ctx) {
     USE_DEVICE(ctx);
     DDX_TRY(timing_flush(ctx));
     for (auto& r : ctx->t_recs) r = TimingRec();
+    ctx->t_intervals.clear();
+    return DDX_OK;
+}
+
+int ddx_timing_reference(ddx_ctx* ctx, ddx_ctx* share_with) {
+    REQUIRE_CTX(ctx);
+    USE_DEVICE(ctx);
+    if (share_with && share_with != ctx) {                 // the same clock origin as another context of this GPU
+        NEED(share_with->device == ctx->device && share_with->t_ref, "the other context has no reference on this device");
+        if (ctx->t_ref && ctx->t_ref_owned) (void)hipEventDestroy(ctx->t_ref);
+        ctx->t_ref = share_with->t_ref;
+        ctx->t_ref_owned = false;
+        return DDX_OK;
+    }
+    if (!ctx->t_ref || !ctx->t_ref_owned) {
+        ctx->t_ref = nullptr;
+        DDX_HIP(ctx, hipEventCreate(&ctx->t_ref));
+        ctx->t_ref_owned = true;
+    }
+    DDX_HIP(ctx, hipEventRecord(ctx->t_ref, ctx->stream));
+    DDX_HIP(ctx, hipEventSynchronize(ctx->t_ref));
+    return DDX_OK;
+}
+
+int ddx_timing_intervals(ddx_ctx* ctx, int64_t capacity, double* begin_end_ms, int64_t* n_out) {
+    REQUIRE_CTX(ctx);
+    USE_DEVICE(ctx);
+    DDX_TRY(timing_flush(ctx));
+    const int64_t n = (int64_t)ctx->t_intervals.size() / 2;
+    if (n_out) *n_out = n;
+    if (begin_end_ms)
+        for (int64_t i = 0; i < std::min(n, capacity) * 2; ++i) begin_end_ms[i] = (double)ctx->t_intervals[i];
     return DDX_OK;
 }
 

@@ -243,6 +243,13 @@ int ddx_timing_count(ddx_ctx* ctx, int32_t* n);
 /* i-th record: name (NUL-terminated, at most 63 chars), launches, total milliseconds */
 int ddx_timing_get(ddx_ctx* ctx, int32_t i, char* name_out /* [64] */, int64_t* launches, double* total_ms);
 
+/* wall-clock placement of the timed scopes: ddx_timing_reference records the clock origin on the context's stream (or
+ * adopts the origin of another context of the same GPU, so that the scopes of several streams share one time axis);
+ * ddx_timing_intervals returns (begin, end) in milliseconds after that origin for every scope timed since the last
+ * ddx_timing_reset -- bench.py merges them into the share of the wall-clock during which the GPU ran a kernel. */
+int ddx_timing_reference(ddx_ctx* ctx, ddx_ctx* share_with /* or NULL */);
+int ddx_timing_intervals(ddx_ctx* ctx, int64_t capacity, double* begin_end_ms /* [2*capacity] */, int64_t* n_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -9,8 +9,8 @@ repo=$(pwd)
 out=$repo/gpurun_out
 mkdir -p "$out"
 export TMPDIR=/tmp
-bench="python $repo/bench.py --steps 1 --warmup 1 --no-cpu-baseline --resident-steps 0 --no-exclusive"
-short="python $repo/bench.py --steps 1 --warmup 0 --iters 2 --no-cpu-baseline --resident-steps 0 --no-exclusive"
+bench="python $repo/bench.py --steps 1 --warmup 1 --no-cpu-baseline --resident-steps 0 --instrumented-steps 0 --no-exclusive"
+short="python $repo/bench.py --steps 1 --warmup 0 --iters 2 --no-cpu-baseline --resident-steps 0 --instrumented-steps 0 --no-exclusive"
 
 cd /tmp
 rm -rf /tmp/prof_stats

@@ -5,7 +5,7 @@ repo=$(pwd); out=$repo/gpurun_out; mkdir -p $out
 export TMPDIR=/tmp
 cd /tmp
 rm -rf /tmp/prof_stats1
-DDX_STREAMS=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats1 -- python $repo/bench.py --steps 1 --warmup 1 --no-cpu-baseline --resident-steps 0 --no-exclusive > $out/${tag}_1stream.log 2>&1
+DDX_STREAMS=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats1 -- python $repo/bench.py --steps 1 --warmup 1 --no-cpu-baseline --resident-steps 0 --instrumented-steps 0 --no-exclusive > $out/${tag}_1stream.log 2>&1
 f1=$(find /tmp/prof_stats1 -name "*kernel_stats.csv" | head -1)
 [ -n "$f1" ] && cp "$f1" $out/${tag}_kernel_stats_1stream.csv
 t=$(find /tmp/prof_stats1 -name "*kernel_trace.csv" | head -1)
