@@ -178,7 +178,7 @@ def louvain(indptr, indices, weights, gamma: float, seed: int):
 
 PRESWEEPS = 6         # DDX_PRESWEEPS of include/ddx.h
 PRESWEEP_LEVELS = 2   # DDX_PRESWEEP_LEVELS
-SUBROUNDS = 4         # DDX_SUBROUNDS
+SUBROUNDS = 2         # DDX_SUBROUNDS
 REFINE_SWEEPS = 3     # DDX_REFINE_SWEEPS
 
 

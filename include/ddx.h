@@ -193,7 +193,7 @@ int ddx_get_graph(ddx_ctx* ctx, int64_t* indptr, int32_t* indices, double* weigh
  *   ddx_leiden             = A + B' + C on the host. */
 #define DDX_PRESWEEPS 6
 #define DDX_PRESWEEP_LEVELS 2
-#define DDX_SUBROUNDS 4       /* sub-rounds per synchronous sweep: a quarter of the nodes decides at a time */
+#define DDX_SUBROUNDS 2       /* sub-rounds per synchronous sweep: half of the nodes decides at a time */
 #define DDX_REFINE_SWEEPS 3   /* part C: refinement sweeps on the original graph */
 int ddx_louvain(int64_t n_nodes, const int64_t* indptr, const int32_t* indices, const double* weights,
                 double gamma, uint64_t seed, int32_t* labels_out /* [n_nodes] */, double* quality_out);

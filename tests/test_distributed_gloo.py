@@ -48,7 +48,12 @@ def _worker(rank, world, port, case, n_iters, out_dir):
 
 
 @pytest.mark.parametrize("case,n_iters,world", [("case_c_reftest_scaled", 3, 2), ("case_a_hvg_pheno", 2, 2),
-                                                ("case_c_reftest_scaled", 5, 3), ("case_b_transposed_louvain", 2, 3)])
+                                                ("case_c_reftest_scaled", 5, 3), ("case_b_transposed_louvain", 2, 3),
+                                                # the driver's node: 8 ranks; the reference's default 10 iterations (ranks with
+                                                # two and with one), the 25 of BASELINE configs[2]/[3] (four and three), and
+                                                # fewer iterations than ranks (ranks without any)
+                                                ("case_c_reftest_scaled", 10, 8), ("case_b_transposed_louvain", 25, 8),
+                                                ("case_a_hvg_pheno", 5, 8)])
 def test_multi_rank_fit_equals_single_process(tmp_path, case, n_iters, world):
     """world ranks (uneven shares: 5 iterations over 3 ranks; a rank without any iteration: 2 over 3), each dealing its
     iterations out over two device contexts; the byte-packed all-gather leaves the complete result on every rank."""
