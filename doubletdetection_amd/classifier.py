@@ -222,25 +222,51 @@ class _HipEngine:
             c.pca(n_components, q0)
             self._q0_resident = q0
 
+    def _apply(self, X, mode, block=40):
+        """ddx_operator_apply on any number of vectors (the entry point takes at most 64 at a time)."""
+        X = np.asarray(X, dtype=np.float64)
+        if X.shape[1] <= 64:
+            return self.ctx.operator_apply(X, mode)
+        return np.hstack([self.ctx.operator_apply(np.ascontiguousarray(X[:, j:j + block]), mode) for j in range(0, X.shape[1], block)])
+
     def _pca_arpack(self, n_components, seed):
         """pseudocount == 1 without scaling keeps the matrix sparse upstream and switches sc.tl.pca to
         svd_solver="arpack" (dd.py:296-297,308): an implicitly-centred truncated SVD converged to machine
-        precision.  ARPACK's Lanczos recurrences run on the host (scipy, the very routine upstream uses);
-        every matrix-vector product is one SpMV on the device.  Start vector and sign convention as in
-        sklearn's PCA arpack branch (_init_arpack_v0, svd_flip(u_based_decision=False))."""
-        from scipy.sparse.linalg import LinearOperator, svds
+        precision.  scipy's ``svds(solver="arpack")`` -- what sklearn's PCA runs there -- is ARPACK's symmetric Lanczos
+        (``eigsh``) on the smaller Gram operator A^T A (or A A^T); the recurrences stay on the host (the very routine
+        upstream uses), every operator application is ONE device call (two sparse products back to back, only the short
+        vector crosses PCIe) instead of the two round trips with an M-vector in between that a matvec / rmatvec pair costs.
+        Start vector and sign convention as in sklearn's PCA arpack branch (_init_arpack_v0,
+        svd_flip(u_based_decision=False))."""
+        from scipy.sparse.linalg import LinearOperator, eigsh
 
         c = self.ctx
         M, H = c.M, c.H
-        op = LinearOperator((M, H), dtype=np.float64,
-                            matvec=lambda x: c.operator_apply(np.asarray(x, dtype=np.float64).reshape(H, 1), 0).ravel(),
-                            rmatvec=lambda y: c.operator_apply(np.asarray(y, dtype=np.float64).reshape(M, 1), 1).ravel())
-        v0 = np.random.RandomState(seed).uniform(-1, 1, size=min(M, H))
-        u, sv, vt = svds(op, k=n_components, tol=0.0, v0=v0, solver="arpack")
-        u, sv, vt = u[:, ::-1], sv[::-1], vt[::-1]
-        pick = np.argmax(np.abs(vt), axis=1)
-        signs = np.sign(vt[np.arange(vt.shape[0]), pick])
-        c.set_embedding((u * signs[None, :] * sv[None, :]).astype(np.float32))
+        small, mode = (H, 2) if H <= M else (M, 3)
+        self.arpack_products = 0
+
+        def gram(x):
+            self.arpack_products += 1
+            return c.operator_apply(np.asarray(x, dtype=np.float64).reshape(small, 1), mode).ravel()
+
+        op = LinearOperator((small, small), dtype=np.float64, matvec=gram)
+        v0 = np.random.RandomState(seed).uniform(-1, 1, size=small)
+        evals, evecs = eigsh(op, k=n_components, tol=0.0, v0=v0, which="LM")
+        top = np.argsort(evals)[::-1]
+        sv = np.sqrt(np.maximum(evals[top], 0.0))
+        evecs = evecs[:, top]
+        if H <= M:
+            comps = evecs                                           # H x C: right singular vectors
+            pick = np.argmax(np.abs(comps), axis=0)
+            signs = np.sign(comps[pick, np.arange(comps.shape[1])])
+            scores = self._apply(comps * signs, 0)                  # A V = U S
+        else:
+            left = evecs                                            # M x C: left singular vectors
+            comps = self._apply(left, 1) / np.where(sv > 0, sv, 1.0)
+            pick = np.argmax(np.abs(comps), axis=0)
+            signs = np.sign(comps[pick, np.arange(comps.shape[1])])
+            scores = left * sv * signs
+        c.set_embedding(scores.astype(np.float32))
 
     def _pca_exact(self, n_components, block=40):
         """sklearn's exact regimes ("full" / "covariance_eigh"): eigen-decomposition of the smaller Gram
@@ -264,12 +290,12 @@ class _HipEngine:
             scores = None
         else:
             left = evecs[:, top]                                    # M x C: left singular vectors
-            comps = c.operator_apply(left, 1) / np.where(sing > 0, sing, 1.0)
+            comps = self._apply(left, 1) / np.where(sing > 0, sing, 1.0)
             scores = left * sing
         pick = np.argmax(np.abs(comps), axis=0)
         signs = np.sign(comps[pick, np.arange(comps.shape[1])])
         if scores is None:
-            scores = c.operator_apply(comps * signs, 0)
+            scores = self._apply(comps * signs, 0)
         else:
             scores = scores * signs
         c.set_embedding(scores.astype(np.float32))

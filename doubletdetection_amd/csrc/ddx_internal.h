@@ -33,6 +33,7 @@ constexpr int kGatherPanelRows = 4096;   // measured optimum for the gather kern
 //   DDX_PCA_GATHER=f64     float64 operand gathers (gather kernels only)
 //   DDX_SPMM_GEOM=pair|quad, DDX_SPMM_TRIP=f64   variants of the LDS-staged products
 //   DDX_KNN_SCREEN=f32     float32 MFMA distance screen instead of the bfloat16 split
+//   DDX_KNN_FOLD=0         emit pass with explicit threshold compares (the first version)
 //   DDX_KNN_SAMPLE_TILES=n size of the bound pass's subset
 //   DDX_ROW_SUMS_SEQUENTIAL=1  always replay the sequential row sums (skip the exact-integer shortcut)
 //   DDX_KNN_DEBUG=1        print candidate-list statistics
@@ -45,6 +46,7 @@ struct Options {
     int spmm_geom = 0;               // 0 auto, 1 pair, 2 quad
     bool trip_packed = true;
     bool knn_bf16 = true;
+    bool knn_fold = true;            // DDX_KNN_FOLD=0: compare against the per-query threshold instead of folding it into the operands
     int64_t knn_sample_tiles = 0;    // 0 = default rule
     bool row_sums_sequential = false;
     bool knn_debug = false;

@@ -20,6 +20,9 @@ constexpr int kMaxDim = 128;
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 
+// slack of the bfloat16 distance screen, relative to |q|^2 + |c|^2 (derivation at the emit kernel)
+constexpr float kScreenSlackBf = 4.2e-5f;
+
 // ---- layouts -----------------------------------------------------------------------------------
 // E   : row-major float32 [Mp][CP]            (exact re-evaluation gathers whole rows)
 // Et  : MFMA operand layout, 16-point tiles:   Et[tile][s][k][j] = E[16*tile + j][4*s + k]
@@ -57,8 +60,51 @@ __global__ void k_knn_prepare(const float* __restrict__ in, const int32_t* __res
     }
     nrm[r] = (r < M) ? n : __builtin_huge_valf();
     // accumulator start value of the bfloat16 emit pass, as one MFMA C quad: -0.5*(1-slack)*|c|^2 (-inf for padding)
-    const float h = (r < M) ? -0.5f * (1.0f - 4.0e-5f) * n : -__builtin_huge_valf();
+    const float h = (r < M) ? -0.5f * (1.0f - kScreenSlackBf) * n : -__builtin_huge_valf();
     start4[r] = f4{h, h, h, h};
+}
+
+// Threshold folding for the emit pass (embeddings of at most 30 components: two of the 32 padded components are free).
+// The screen asks  acc > hr_q  with acc = q.c - 0.5 (1-s) |c|^2 from the matrix pipe and hr_q = 0.5 ((1-s) |q|^2 - T_q) a
+// constant of the query.  Give every CANDIDATE the value 1 in components 30 and 31 and every QUERY the value -hr_q there,
+// cut into four bfloat16 pieces (hi/lo of the two components: 32 mantissa bits, i.e. all of the float32): the matrix pipe
+// then delivers acc - hr_q and the screen is "any of the wave's accumulators positive" -- a v_max3 tree and ONE compare per
+// tile instead of eight compares and seven scalar ORs.  The four extra terms add four float32 roundings to the
+// accumulation (2.4e-7 relative to |q|^2 + |c|^2 + T/2), at most 4.8e-7 (|q|^2 + |c|^2) where it matters -- near the decision d2 = T, hence T <= 2 (|q|^2 + |c|^2) -- covered by raising the slack
+// from 4.0e-5 to 4.2e-5 (margin 1e-6 (|q|^2 + |c|^2)).
+// Queries without a bound pass everything (+3e38, finite: inf * 0 would poison the hi*lo product), padding queries
+// nothing (-3e38).  Eb itself (candidate role) is patched in place -- the bound pass, which needs the zeros, is over.
+__global__ void k_knn_fold(const float* __restrict__ nrm, const float* __restrict__ thr, int64_t Mp, __bf16* __restrict__ Eb,
+                           __bf16* __restrict__ Ebq) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // one thread per 16-byte vector of the operand image
+    if (t >= Mp * 8) return;                                               // CP = 32: tile x 2 parts x 64 lanes
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    u4 v = reinterpret_cast<const u4*>(Eb)[t];
+    const int lane = (int)(t & 63), part = (int)((t >> 6) & 1);
+    const int64_t tile = t >> 7;
+    if ((lane >> 4) == 3) {                                                // components 24..31 of point 16*tile + (lane & 15)
+        const int64_t r = tile * 16 + (lane & 15);
+        const float n = nrm[r], T = thr[r];
+        float x = -0.5f * ((1.0f - kScreenSlackBf) * n - T);               // -hr
+        if (!(n < __builtin_huge_valf())) x = -3.0e38f;
+        else if (!(T < __builtin_huge_valf())) x = 3.0e38f;
+        const __bf16 p1 = (__bf16)x;
+        const float r1 = x - (float)p1;
+        const __bf16 p2 = (__bf16)r1;
+        const float r2 = r1 - (float)p2;
+        const __bf16 p3 = (__bf16)r2;
+        const __bf16 p4 = (__bf16)(r2 - (float)p3);
+        const __bf16 a = part == 0 ? p1 : p2, b = part == 0 ? p3 : p4;     // (component 30, component 31) of this part
+        u4 q = v;
+        q.w = (uint32_t)__builtin_bit_cast(uint16_t, a) | ((uint32_t)__builtin_bit_cast(uint16_t, b) << 16);
+        reinterpret_cast<u4*>(Ebq)[t] = q;
+        const __bf16 one = (__bf16)1.0f;
+        const uint32_t ones = (uint32_t)__builtin_bit_cast(uint16_t, one) * 0x10001u;
+        v.w = part == 0 ? ones : 0u;                                       // candidates: hi = 1, lo = 0
+        reinterpret_cast<u4*>(Eb)[t] = v;
+    } else {
+        reinterpret_cast<u4*>(Ebq)[t] = v;
+    }
 }
 
 // Screen slack: |fl32(|q|^2 + |c|^2 - 2 q.c) - d2| <= (CP + 8) * 2^-24 * (|q|^2 + |c|^2) for the float32
@@ -340,7 +386,6 @@ __global__ void __launch_bounds__(256) k_knn_emit(const float* __restrict__ Et, 
 // accumulation of 3*32 exact products adds <= ~6e-6 sum|q_i c_i|: |error(q.c)| <= 1.8e-5 |q||c| <= 0.9e-5 (|q|^2+|c|^2);
 // doubled in the distance and with the float32 norms that is 2.5e-5 (|q|^2+|c|^2).  The slack below leaves 1.6x margin.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-constexpr float kScreenSlackBf = 4.0e-5f;
 
 template <int CP>
 struct TileStageBf {           // one chunk = chunk_tiles(CP) tiles x (hi|lo) x KB kilobytes = 16 KB, as for float32
@@ -526,8 +571,8 @@ TileStageBf<CP> st;
     }
 }
 
-template <int CP>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CP <= 64 ? DDX_EMIT_WAVES : 2, CP <= 64 ? DDX_EMIT_WAVES : 2))) k_knn_emit_bf(const __bf16* __restrict__ Eb, const float* __restrict__ nrm, const f4* __restrict__ start4,
+template <int CP, bool FOLD>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CP <= 64 ? DDX_EMIT_WAVES : 2, CP <= 64 ? DDX_EMIT_WAVES : 2))) k_knn_emit_bf(const __bf16* __restrict__ Eb, const __bf16* __restrict__ Ebq, const float* __restrict__ nrm, const f4* __restrict__ start4,
                                                      const float* __restrict__ thr, int64_t Mp, int include_self,
                                                      int32_t* __restrict__ ccount, int32_t* __restrict__ cbuf, const int32_t* __restrict__ win, int dbg, int cap) {
     constexpr int RT = kEmitRT, NV = 4 * RT;
@@ -538,7 +583,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CP <= 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t q0 = ((int64_t)blockIdx.x * 4 + wave) * (16 * RT);
     QueryTilesBf<CP, RT> qt;
-    qt.load(Eb, q0, lane);
+    qt.load(FOLD ? Ebq : Eb, q0, lane);          // FOLD: the query operands carry -hr in components 30 / 31 (k_knn_fold)
     const int rbase = 4 * (lane >> 4), jcol = lane & 15;
     // A wave is the only writer of its 16*RT queries' candidate lists, and the 16 lanes of a lane group see the same
     // NV queries: every lane keeps the NV slot counters of its group in registers (identical in the 16 lanes, updated
@@ -554,6 +599,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CP <= 
         if (!(n < __builtin_huge_valf())) hr[v] = __builtin_huge_valf();
         else if (!(t < __builtin_huge_valf())) hr[v] = -__builtin_huge_valf();
         if (dbg & 1) hr[v] = __builtin_huge_valf();          // experiment: nothing passes the screen
+        if (FOLD) hr[v] = 0.f;                               // the threshold travels inside the dot product
     }
     // candidate tiles whose first component can be within reach of any query of this block (k_knn_window)
     const int64_t t_lo = win[2 * blockIdx.x], ntiles = win[2 * blockIdx.x + 1] - t_lo;
@@ -595,10 +641,22 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CP <= 
         // one compare per pair; the wave-wide masks live in scalar registers
         auto judge = [&](const f4 (&acc)[RT], const int32_t tile) {
             unsigned long long any = 0, hm[NV];
+            if (FOLD) {
+                // one compare per tile: the largest of the wave's accumulators against zero (v_max3 tree)
+                float m = acc[0].x;
 #pragma unroll
-            for (int v = 0; v < NV; ++v) {
-                hm[v] = __ballot(acc[v >> 2][v & 3] > hr[v]);
-                any |= hm[v];
+                for (int v = 1; v < NV; ++v) m = fmaxf(m, acc[v >> 2][v & 3]);
+                any = __ballot(m > 0.f);
+                if (any) {
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) hm[v] = __ballot(acc[v >> 2][v & 3] > 0.f);
+                }
+            } else {
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    hm[v] = __ballot(acc[v >> 2][v & 3] > hr[v]);
+                    any |= hm[v];
+                }
             }
             if (any) {
                 const int32_t cand = tile * 16 + jcol;
@@ -854,7 +912,8 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
     //            | ccount [Mp+64] | ids [2*Mp] | win [2*blocks] | cbuf [Mp*cap]
     const size_t f_words = (size_t)Mp * CP * 3 + 9 * (size_t)Mp + 16;
     const int64_t emit_blocks = Mp / (4 * 16 * kEmitRT);
-    const size_t i_words = (size_t)Mp + 64 + 2 * (size_t)Mp + 2 * (size_t)emit_blocks + 64 + (size_t)Mp * cap;
+    const bool fold = ctx->opt.knn_bf16 && ctx->opt.knn_fold && C <= 30;          // threshold folded into the operands (k_knn_fold)
+    const size_t i_words = (size_t)Mp + 64 + 2 * (size_t)Mp + 2 * (size_t)emit_blocks + 64 + (size_t)Mp * cap + (fold ? (size_t)Mp * 32 + 16 : 0);
     DDX_TRY(ensure(ctx, ctx->pcaA, sizeof(float) * f_words + sizeof(int32_t) * i_words + 256));
     DDX_TRY(ensure(ctx, ctx->knn_idx, sizeof(int32_t) * (size_t)M * k));
     DDX_TRY(ensure(ctx, ctx->knn_dist, sizeof(double) * (size_t)M * k));
@@ -873,6 +932,7 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
     int32_t* perm = ids_in + Mp;
     int32_t* win = perm + Mp;
     int32_t* cbuf = win + 2 * emit_blocks + 64;
+    __bf16* Ebq = reinterpret_cast<__bf16*>((reinterpret_cast<uintptr_t>(cbuf + (size_t)Mp * cap) + 15) & ~(uintptr_t)15);   // query operands of the folded emit pass
     // Order the points by their first principal component (stable radix sort: ties by id).  Every pass below works
     // in that order: a query's neighbours are then confined to a window of positions around it (k_knn_window).
     {
@@ -919,9 +979,12 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
         const unsigned grid = (unsigned)emit_blocks;
         const int dbg_mode = ctx->opt.knn_ablation;     // timing ablations (wrong results): non-zero only in -DDDX_ABLATION builds
         k_knn_window<<<grid, 64, 0, ctx->stream>>>(p1, thr, nrm, Mp, win, reinterpret_cast<unsigned long long*>(ccount + Mp + 2));
-        if (bf && CP == 32) k_knn_emit_bf<32><<<grid, 256, 0, ctx->stream>>>(Eb, nrm, start4, thr, Mp, include_self, ccount, cbuf, win, dbg_mode, cap);
-        else if (bf && CP == 64) k_knn_emit_bf<64><<<grid, 256, 0, ctx->stream>>>(Eb, nrm, start4, thr, Mp, include_self, ccount, cbuf, win, dbg_mode, cap);
-        else if (bf) k_knn_emit_bf<128><<<grid, 256, 0, ctx->stream>>>(Eb, nrm, start4, thr, Mp, include_self, ccount, cbuf, win, dbg_mode, cap);
+        if (bf && fold) {
+            k_knn_fold<<<(unsigned)ceil_div(Mp * 8, 256), 256, 0, ctx->stream>>>(nrm, thr, Mp, Eb, Ebq);
+            k_knn_emit_bf<32, true><<<grid, 256, 0, ctx->stream>>>(Eb, Ebq, nrm, start4, thr, Mp, include_self, ccount, cbuf, win, dbg_mode, cap);
+        } else if (bf && CP == 32) k_knn_emit_bf<32, false><<<grid, 256, 0, ctx->stream>>>(Eb, Eb, nrm, start4, thr, Mp, include_self, ccount, cbuf, win, dbg_mode, cap);
+        else if (bf && CP == 64) k_knn_emit_bf<64, false><<<grid, 256, 0, ctx->stream>>>(Eb, Eb, nrm, start4, thr, Mp, include_self, ccount, cbuf, win, dbg_mode, cap);
+        else if (bf) k_knn_emit_bf<128, false><<<grid, 256, 0, ctx->stream>>>(Eb, Eb, nrm, start4, thr, Mp, include_self, ccount, cbuf, win, dbg_mode, cap);
         else if (CP == 32) k_knn_emit<32><<<grid, 256, 0, ctx->stream>>>(Et, nrm, thr, Mp, include_self, ccount, cbuf, win, cap);
         else if (CP == 64) k_knn_emit<64><<<grid, 256, 0, ctx->stream>>>(Et, nrm, thr, Mp, include_self, ccount, cbuf, win, cap);
         else k_knn_emit<128><<<grid, 256, 0, ctx->stream>>>(Et, nrm, thr, Mp, include_self, ccount, cbuf, win, cap);

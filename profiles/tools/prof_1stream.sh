@@ -18,9 +18,9 @@ for r in rows[-900:]:
     print(f'{(int(r["Start_Timestamp"]) - t0) / 1e6:10.3f} ms  {(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3:9.1f} us  {r["Kernel_Name"][:90]}')
 PY
 cd $repo
-python - <<'PY'
-import csv
-rows=list(csv.DictReader(open("gpurun_out/%s_kernel_stats_1stream.csv" % "$tag")))
+python - "$tag" <<'PY'
+import csv, sys
+rows=list(csv.DictReader(open("gpurun_out/%s_kernel_stats_1stream.csv" % sys.argv[1])))
 for r in rows[:28]:
     if 'at::' in r['Name'] or 'rocprim' in r['Name']: continue
     print(f"{r['Name'][:70]:70s} calls {r['Calls']:>6s} total_ms {float(r['TotalDurationNs'])/1e6:9.2f} avg_us {float(r['AverageNs'])/1e3:9.1f}")
