@@ -245,13 +245,23 @@ class _HipEngine:
         small, mode = (H, 2) if H <= M else (M, 3)
         self.arpack_products = 0
 
+        pad = np.zeros((small, 8))          # (the device products run twice as fast on 8 columns as on a single one)
+
         def gram(x):
             self.arpack_products += 1
-            return c.operator_apply(np.asarray(x, dtype=np.float64).reshape(small, 1), mode).ravel()
+            pad[:, 0] = np.asarray(x, dtype=np.float64).ravel()
+            return c.operator_apply(pad, mode)[:, 0]
 
         op = LinearOperator((small, small), dtype=np.float64, matvec=gram)
         v0 = np.random.RandomState(seed).uniform(-1, 1, size=small)
-        evals, evecs = eigsh(op, k=n_components, tol=0.0, v0=v0, which="LM")
+        try:        # ARPACK's own dense work (a few 61-column updates per step) is slower on 256 BLAS threads than on one
+            from threadpoolctl import threadpool_limits
+            limit = threadpool_limits(limits=1)
+        except Exception:          # threadpoolctl absent: correct, just slower
+            import contextlib
+            limit = contextlib.nullcontext()
+        with limit:
+            evals, evecs = eigsh(op, k=n_components, tol=0.0, v0=v0, which="LM")
         top = np.argsort(evals)[::-1]
         sv = np.sqrt(np.maximum(evals[top], 0.0))
         evecs = evecs[:, top]

@@ -141,6 +141,8 @@ void Options::read_environment() {
     g = getenv("DDX_KNN_SCREEN");
     knn_bf16 = !(g && g[0] == 'f' && g[1] == '3');
     knn_fold = !is(getenv("DDX_KNN_FOLD"), "0");
+    g = getenv("DDX_KNN_XCD_CHUNK");
+    knn_xcd_chunk = g ? atoi(g) : 32;
     g = getenv("DDX_KNN_SAMPLE_TILES");
     knn_sample_tiles = g ? atoll(g) : 0;
     row_sums_sequential = getenv("DDX_ROW_SUMS_SEQUENTIAL") != nullptr;

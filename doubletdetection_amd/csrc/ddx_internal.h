@@ -46,6 +46,7 @@ struct Options {
     int spmm_geom = 0;               // 0 auto, 1 pair, 2 quad
     bool trip_packed = true;
     bool knn_bf16 = true;
+    int knn_xcd_chunk = 32;          // DDX_KNN_XCD_CHUNK=n (0 = launch order): n consecutive query blocks of the MFMA passes share an XCD at a time
     bool knn_fold = true;            // DDX_KNN_FOLD=0: compare against the per-query threshold instead of folding it into the operands
     int64_t knn_sample_tiles = 0;    // 0 = default rule
     bool row_sums_sequential = false;

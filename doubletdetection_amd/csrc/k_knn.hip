@@ -136,6 +136,18 @@ constexpr int kCandCap = 768;      // candidate slots per query between the emit
 //              order in which survivors were appended.
 // ================================================================================================
 
+// Workgroup numbering of the MFMA passes.  Hardware workgroup b runs on XCD b % 8; consecutive query blocks screen nearly
+// the same candidate tiles.  With chunk > 0 the workgroups resident on one XCD at a time are `chunk` CONSECUTIVE query
+// blocks (so a candidate tile fetched into that XCD's L2 serves them all), and the XCDs take adjacent chunks of the query
+// range (so all of them meet the same mix of narrow and wide windows).  Returns -1 for the padding of the last chunk.
+__device__ __forceinline__ int64_t knn_block(int64_t nblocks, int chunk) {
+    const int64_t b = blockIdx.x;
+    if (chunk <= 0) return b < nblocks ? b : -1;
+    const int64_t xcd = b & 7, s = b >> 3;
+    const int64_t lb = ((s / chunk) * 8 + xcd) * chunk + (s % chunk);
+    return lb < nblocks ? lb : -1;
+}
+
 // ---- candidate tiles are staged through LDS once per block (4 waves share them) ---------------------
 // tiles per staged chunk: 16 KB of coordinates per buffer whatever the padded dimension
 #ifndef DDX_CHUNK_TILES32
@@ -476,14 +488,17 @@ struct QueryTilesBf {
 template <int CP, int kBoundKeep>
 __global__ void __launch_bounds__(256) k_knn_bound_bf(const __bf16* __restrict__ Eb, const float* __restrict__ nrm,
                                                       int64_t Mp, int K, int include_self, int64_t nsamp_tiles,
-                                                      int64_t tile_stride, int64_t tile_phase, int combine, float* __restrict__ thr_out) {
+                                                      int64_t tile_stride, int64_t tile_phase, int combine, float* __restrict__ thr_out,
+                                                      int xcd_chunk) {
     constexpr int RT = kBoundRT, NV = 4 * RT;
     constexpr int kChunkTiles = chunk_tiles(CP);
     constexpr int tile_vecs = 16 * CP * 4 / 16;
     __shared__ f4 lds_c[2][kChunkTiles * tile_vecs];
     __shared__ float lds_n[2][kChunkTiles * 16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t q0 = ((int64_t)blockIdx.x * 4 + wave) * (16 * RT);
+    const int64_t blk = knn_block(Mp / (4 * 16 * RT), xcd_chunk);
+    if (blk < 0) return;
+    const int64_t q0 = (blk * 4 + wave) * (16 * RT);
     QueryTilesBf<CP, RT> qt;
     qt.load(Eb, q0, lane);
     const int rbase = 4 * (lane >> 4), jcol = lane & 15;
@@ -502,7 +517,7 @@ __global__ void __launch_bounds__(256) k_knn_bound_bf(const __bf16* __restrict__
     // tile_stride-th tile and the ceil(k / tile_stride)-th smallest of ITS points; the largest of those bounds holds at
     // least k points of the whole window below it -- `combine` keeps the maximum over the launches)
     const int64_t span = nsamp_tiles * tile_stride;
-    int64_t tile0 = (((int64_t)blockIdx.x * 4) * RT) + 2 * RT - span / 2;
+    int64_t tile0 = ((blk * 4) * RT) + 2 * RT - span / 2;
     if (tile0 > (Mp >> 4) - span) tile0 = (Mp >> 4) - span;
     if (tile0 < 0) tile0 = 0;
     tile0 += tile_phase;
@@ -574,14 +589,17 @@ TileStageBf<CP> st;
 template <int CP, bool FOLD>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CP <= 64 ? DDX_EMIT_WAVES : 2, CP <= 64 ? DDX_EMIT_WAVES : 2))) k_knn_emit_bf(const __bf16* __restrict__ Eb, const __bf16* __restrict__ Ebq, const float* __restrict__ nrm, const f4* __restrict__ start4,
                                                      const float* __restrict__ thr, int64_t Mp, int include_self,
-                                                     int32_t* __restrict__ ccount, int32_t* __restrict__ cbuf, const int32_t* __restrict__ win, int dbg, int cap) {
+                                                     int32_t* __restrict__ ccount, int32_t* __restrict__ cbuf, const int32_t* __restrict__ win, int dbg, int cap,
+                                                     int xcd_chunk) {
     constexpr int RT = kEmitRT, NV = 4 * RT;
     constexpr int kChunkTiles = chunk_tiles(CP);
     constexpr int tile_vecs = 16 * CP * 4 / 16;
     __shared__ f4 lds_c[2][kChunkTiles * tile_vecs];
     __shared__ f4 lds_h[2][kChunkTiles * 16];     // accumulator start values -0.5*(1-slack)*|c|^2 (see commit_start)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t q0 = ((int64_t)blockIdx.x * 4 + wave) * (16 * RT);
+    const int64_t blk = knn_block(Mp / (4 * 16 * RT), xcd_chunk);
+    if (blk < 0) return;
+    const int64_t q0 = (blk * 4 + wave) * (16 * RT);
     QueryTilesBf<CP, RT> qt;
     qt.load(FOLD ? Ebq : Eb, q0, lane);          // FOLD: the query operands carry -hr in components 30 / 31 (k_knn_fold)
     const int rbase = 4 * (lane >> 4), jcol = lane & 15;
@@ -602,7 +620,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CP <= 
         if (FOLD) hr[v] = 0.f;                               // the threshold travels inside the dot product
     }
     // candidate tiles whose first component can be within reach of any query of this block (k_knn_window)
-    const int64_t t_lo = win[2 * blockIdx.x], ntiles = win[2 * blockIdx.x + 1] - t_lo;
+    const int64_t t_lo = win[2 * blk], ntiles = win[2 * blk + 1] - t_lo;
     if (ntiles <= 0) {                          // block-uniform: nothing can be within reach
         if (lane < 16 * kEmitRT) ccount[q0 + lane] = 0;
         return;
@@ -912,6 +930,7 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
     //            | ccount [Mp+64] | ids [2*Mp] | win [2*blocks] | cbuf [Mp*cap]
     const size_t f_words = (size_t)Mp * CP * 3 + 9 * (size_t)Mp + 16;
     const int64_t emit_blocks = Mp / (4 * 16 * kEmitRT);
+    const int xcd_chunk = ctx->opt.knn_xcd_chunk;                                  // DDX_KNN_XCD_CHUNK (0: workgroups in launch order)
     const bool fold = ctx->opt.knn_bf16 && ctx->opt.knn_fold && C <= 30;          // threshold folded into the operands (k_knn_fold)
     const size_t i_words = (size_t)Mp + 64 + 2 * (size_t)Mp + 2 * (size_t)emit_blocks + 64 + (size_t)Mp * cap + (fold ? (size_t)Mp * 32 + 16 : 0);
     DDX_TRY(ensure(ctx, ctx->pcaA, sizeof(float) * f_words + sizeof(int32_t) * i_words + 256));
@@ -958,33 +977,39 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
     const int64_t nsamp_g = std::max<int64_t>(1, nsamp / groups);                    // tiles per launch
     {
         ScopedTimer t(ctx, "knn_bound");
-        const unsigned grid = (unsigned)(Mp / (4 * 16 * kBoundRT));
+        const int64_t nb_bound = Mp / (4 * 16 * kBoundRT);
+        const unsigned grid = (unsigned)(bf && xcd_chunk > 0 ? ceil_div(nb_bound, 8 * (int64_t)xcd_chunk) * 8 * xcd_chunk : nb_bound);
 #define DDX_BOUND_LAUNCH(KERNEL, OPERAND)                                                                                        \
     do {                                                                                                                       \
         for (int g = 0; g < groups; ++g) {                                                                                     \
-            if (CP == 32 && keep_small) KERNEL<32, kBoundKeepSmall><<<grid, 256, 0, ctx->stream>>>(OPERAND, nrm, Mp, k_bound, include_self, nsamp_g, stride, g, g > 0, thr); \
-            else if (CP == 32) KERNEL<32, kBoundKeepLarge><<<grid, 256, 0, ctx->stream>>>(OPERAND, nrm, Mp, k_bound, include_self, nsamp_g, stride, g, g > 0, thr);      \
-            else if (CP == 64 && keep_small) KERNEL<64, kBoundKeepSmall><<<grid, 256, 0, ctx->stream>>>(OPERAND, nrm, Mp, k_bound, include_self, nsamp_g, stride, g, g > 0, thr); \
-            else if (CP == 64) KERNEL<64, kBoundKeepLarge><<<grid, 256, 0, ctx->stream>>>(OPERAND, nrm, Mp, k_bound, include_self, nsamp_g, stride, g, g > 0, thr);      \
-            else if (keep_small) KERNEL<128, kBoundKeepSmall><<<grid, 256, 0, ctx->stream>>>(OPERAND, nrm, Mp, k_bound, include_self, nsamp_g, stride, g, g > 0, thr);    \
-            else KERNEL<128, kBoundKeepLarge><<<grid, 256, 0, ctx->stream>>>(OPERAND, nrm, Mp, k_bound, include_self, nsamp_g, stride, g, g > 0, thr);                    \
+            if (CP == 32 && keep_small) KERNEL<32, kBoundKeepSmall><<<grid, 256, 0, ctx->stream>>>(OPERAND, nrm, Mp, k_bound, include_self, nsamp_g, stride, g, g > 0, thr XCDARG); \
+            else if (CP == 32) KERNEL<32, kBoundKeepLarge><<<grid, 256, 0, ctx->stream>>>(OPERAND, nrm, Mp, k_bound, include_self, nsamp_g, stride, g, g > 0, thr XCDARG);      \
+            else if (CP == 64 && keep_small) KERNEL<64, kBoundKeepSmall><<<grid, 256, 0, ctx->stream>>>(OPERAND, nrm, Mp, k_bound, include_self, nsamp_g, stride, g, g > 0, thr XCDARG); \
+            else if (CP == 64) KERNEL<64, kBoundKeepLarge><<<grid, 256, 0, ctx->stream>>>(OPERAND, nrm, Mp, k_bound, include_self, nsamp_g, stride, g, g > 0, thr XCDARG);      \
+            else if (keep_small) KERNEL<128, kBoundKeepSmall><<<grid, 256, 0, ctx->stream>>>(OPERAND, nrm, Mp, k_bound, include_self, nsamp_g, stride, g, g > 0, thr XCDARG);    \
+            else KERNEL<128, kBoundKeepLarge><<<grid, 256, 0, ctx->stream>>>(OPERAND, nrm, Mp, k_bound, include_self, nsamp_g, stride, g, g > 0, thr XCDARG);                    \
         }                                                                                                                      \
     } while (0)
+#define XCDARG , xcd_chunk
         if (bf) DDX_BOUND_LAUNCH(k_knn_bound_bf, Eb);
+#undef XCDARG
+#define XCDARG
         else DDX_BOUND_LAUNCH(k_knn_bound, Et);
+#undef XCDARG
 #undef DDX_BOUND_LAUNCH
     }
     {
         ScopedTimer t(ctx, "knn_emit");
         const unsigned grid = (unsigned)emit_blocks;
+        const unsigned grid_x = (unsigned)(xcd_chunk > 0 ? ceil_div(emit_blocks, 8 * (int64_t)xcd_chunk) * 8 * xcd_chunk : emit_blocks);
         const int dbg_mode = ctx->opt.knn_ablation;     // timing ablations (wrong results): non-zero only in -DDDX_ABLATION builds
         k_knn_window<<<grid, 64, 0, ctx->stream>>>(p1, thr, nrm, Mp, win, reinterpret_cast<unsigned long long*>(ccount + Mp + 2));
         if (bf && fold) {
             k_knn_fold<<<(unsigned)ceil_div(Mp * 8, 256), 256, 0, ctx->stream>>>(nrm, thr, Mp, Eb, Ebq);
-            k_knn_emit_bf<32, true><<<grid, 256, 0, ctx->stream>>>(Eb, Ebq, nrm, start4, thr, Mp, include_self, ccount, cbuf, win, dbg_mode, cap);
-        } else if (bf && CP == 32) k_knn_emit_bf<32, false><<<grid, 256, 0, ctx->stream>>>(Eb, Eb, nrm, start4, thr, Mp, include_self, ccount, cbuf, win, dbg_mode, cap);
-        else if (bf && CP == 64) k_knn_emit_bf<64, false><<<grid, 256, 0, ctx->stream>>>(Eb, Eb, nrm, start4, thr, Mp, include_self, ccount, cbuf, win, dbg_mode, cap);
-        else if (bf) k_knn_emit_bf<128, false><<<grid, 256, 0, ctx->stream>>>(Eb, Eb, nrm, start4, thr, Mp, include_self, ccount, cbuf, win, dbg_mode, cap);
+            k_knn_emit_bf<32, true><<<grid_x, 256, 0, ctx->stream>>>(Eb, Ebq, nrm, start4, thr, Mp, include_self, ccount, cbuf, win, dbg_mode, cap, xcd_chunk);
+        } else if (bf && CP == 32) k_knn_emit_bf<32, false><<<grid_x, 256, 0, ctx->stream>>>(Eb, Eb, nrm, start4, thr, Mp, include_self, ccount, cbuf, win, dbg_mode, cap, xcd_chunk);
+        else if (bf && CP == 64) k_knn_emit_bf<64, false><<<grid_x, 256, 0, ctx->stream>>>(Eb, Eb, nrm, start4, thr, Mp, include_self, ccount, cbuf, win, dbg_mode, cap, xcd_chunk);
+        else if (bf) k_knn_emit_bf<128, false><<<grid_x, 256, 0, ctx->stream>>>(Eb, Eb, nrm, start4, thr, Mp, include_self, ccount, cbuf, win, dbg_mode, cap, xcd_chunk);
         else if (CP == 32) k_knn_emit<32><<<grid, 256, 0, ctx->stream>>>(Et, nrm, thr, Mp, include_self, ccount, cbuf, win, cap);
         else if (CP == 64) k_knn_emit<64><<<grid, 256, 0, ctx->stream>>>(Et, nrm, thr, Mp, include_self, ccount, cbuf, win, cap);
         else k_knn_emit<128><<<grid, 256, 0, ctx->stream>>>(Et, nrm, thr, Mp, include_self, ccount, cbuf, win, cap);

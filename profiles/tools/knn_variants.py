@@ -18,6 +18,6 @@ for M in (125_000, 625_000):
         ctx.synchronize()
         t = {k: round(v[1], 3) for k, v in ctx.timings().items()}
     idx, _ = ctx.get_knn(with_dist=False)
-    print(os.environ.get("DDX_LIB", "default").split("/")[-1], "fold=" + os.environ.get("DDX_KNN_FOLD", "1"), M, t,
+    print(os.environ.get("DDX_LIB", "default").split("/")[-1], "fold=" + os.environ.get("DDX_KNN_FOLD", "1"), "xcd=" + os.environ.get("DDX_KNN_XCD_CHUNK", "0"), M, t,
           "window", round(ctx.knn_window_fraction(), 3), "crc", zlib.crc32(idx.tobytes()))
     ctx.close()
