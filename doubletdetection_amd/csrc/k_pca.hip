@@ -234,7 +234,16 @@ __global__ void __launch_bounds__(256) k_spmm_cols(const int64_t* __restrict__ c
 #ifndef DDX_SPMM_DBG
 #define DDX_SPMM_DBG 0      // ablation builds only (profiles/tools/spmm_ablation.sh): 1 no operand reads, 2 no entry fetches, 4 no staged reads, 8 no slice staging, 16 no trips, 32 no entry staging, 64 conflict-free operand rows
 #endif
-constexpr int kLdsOwnG = 6;        // outputs owned by one lane group
+#ifndef DDX_LDS_OWN
+#define DDX_LDS_OWN 6
+#endif
+#ifndef DDX_SPMM_NT
+#define DDX_SPMM_NT 0       // 1: stored entries are fetched with the non-temporal hint (they are read once; the operand slices should own the L2)
+#endif
+#ifndef DDX_SPMM_ROUNDSUM
+#define DDX_SPMM_ROUNDSUM 0 // 1: trip sums are added in float32 over a round (<= 64 entries) and enter the float64 accumulator once per round
+#endif
+constexpr int kLdsOwnG = DDX_LDS_OWN;        // outputs owned by one lane group
 #ifndef DDX_LDS_WAVES
 #define DDX_LDS_WAVES 16
 #endif
@@ -296,8 +305,13 @@ __device__ __forceinline__ LdsFetch<SLOTS> lds_fetch(const int32_t* __restrict__
         int32_t p = l[g] + r * kLdsChunk + lane;         // positions fit 31 bits (stage_create_doublets enforces it)
         p = p < h[g] ? p : l[g];
         if (DDX_SPMM_DBG & 2) p = l[g];
-        f.i[g] = idx[p];
-        f.x[g] = x[p];
+        if (DDX_SPMM_NT) {
+            f.i[g] = __builtin_nontemporal_load(idx + p);
+            f.x[g] = __builtin_nontemporal_load(x + p);
+        } else {
+            f.i[g] = idx[p];
+            f.x[g] = x[p];
+        }
     }
     return f;
 }
@@ -346,6 +360,7 @@ __device__ __forceinline__ void lds_round(const LdsFetch<SLOTS>& f, const int (&
     wave_lds_sync();
     if (PK) {
         const float* myf = reinterpret_cast<const float*>(myd);
+        fq rsum = (fq)(0.0f);
         for (int t0 = 0; t0 < ((DDX_SPMM_DBG & 16) ? 0 : nsteps); t0 += 8) {          // the staged round is zero-padded to 64 entries
             f4v fv[2];
             u4 ov[2];
@@ -402,8 +417,16 @@ __device__ __forceinline__ void lds_round(const LdsFetch<SLOTS>& f, const int (&
             p0 = __builtin_elementwise_fma(q[6], (fq)(fv[1].z), p0);
             p1 = __builtin_elementwise_fma(q[7], (fq)(fv[1].w), p1);
             p0 = p0 + p1;
+            if (DDX_SPMM_ROUNDSUM) {
+                rsum = rsum + p0;
+            } else {
 #pragma unroll
-            for (int c = 0; c < CPL; ++c) acc[c] += (double)p0[c];
+                for (int c = 0; c < CPL; ++c) acc[c] += (double)p0[c];
+            }
+        }
+        if (DDX_SPMM_ROUNDSUM) {
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) acc[c] += (double)rsum[c];
         }
         wave_lds_sync();
         return;
