@@ -73,10 +73,10 @@ def _keep_contexts() -> bool:
 
 
 def _park_limit_bytes() -> int:
-    """HBM the parked contexts of one GPU may hold between fits (DDX_PARK_MAX_GB, default 48): what goes beyond is
+    """HBM the parked contexts of one GPU may hold between fits (DDX_PARK_MAX_GB, default 128 of the 288): what goes beyond is
     returned to the driver when a context is parked, largest holder first.  The switches a context reads from the
     environment (DDX_SPMM, DDX_MIRROR, DDX_UPLOAD, ...) are re-read whenever a parked context starts its next fit."""
-    return int(float(os.environ.get("DDX_PARK_MAX_GB", "48")) * (1 << 30))
+    return int(float(os.environ.get("DDX_PARK_MAX_GB", "128")) * (1 << 30))
 
 
 def _park(device, ctx) -> None:
