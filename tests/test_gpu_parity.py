@@ -746,6 +746,33 @@ def test_unsupported_regimes_raise_clearly():
             BoostClassifier(n_iters=2, normalizer=lambda x: x).fit(rng.poisson(1.0, size=(600, 100)))
 
 
+def test_greedy_memory_chunk_falls_back_without_leaving_an_error_behind():
+    """The context asks the driver for one large chunk sized from the input; a request the device cannot satisfy falls
+    back to the exact size -- and the failed hipMalloc must not stay behind as HIP's sticky last error, which a later
+    hipGetLastError() check (end of build_csc, of the PCA, ...) would report as its own (round-2 advice).  ddx_trim
+    returns the chunks."""
+    from doubletdetection_amd import _lib
+    from doubletdetection_amd._synthetic import make_counts
+
+    counts = make_counts(3000, 900, density=0.1, n_types=4, seed=5)
+    with _lib.Context(0) as ctx:
+        ctx.reserve_hint(1 << 46)                                 # 64 TB: no device has that
+        ctx.upload_raw(counts)
+        ctx.select_columns(np.argsort(ctx.gene_variances())[-500:])
+        ctx.create_doublets(np.random.default_rng(0).choice(3000, size=(750, 2), replace=False))
+        ctx.lognormalise(0.1)
+        ctx.pca(20, orc.pca_start_matrix(0, 500, 30))             # ends with DDX_HIP(hipGetLastError())
+        ctx.knn(30, False)
+        ctx.build_graph(0)
+        held = ctx.device_bytes()
+        assert 0 < held < (8 << 30)                               # the exact-size fallback, not the greedy guess
+        ctx.trim(0)
+        assert ctx.device_bytes() == 0
+        ctx.reserve_hint(0)
+        ctx.upload_raw(counts)                                    # and the context is usable again
+        assert ctx.device_bytes() > 0
+
+
 def test_packed_upload_equals_plain_upload(monkeypatch):
     """dd.py:149-160 (the matrix handed to fit()).  The raw matrix travels packed (column | count << 16, 4 bytes per entry,
     host threads + pinned chunks) when every count is an integer below 65 536 and there are at most 65 536 genes, plain
