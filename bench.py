@@ -189,7 +189,7 @@ def main():
                 a = timings.setdefault(name, [0, 0.0])
                 a[0] += launches
                 a[1] += ms
-        if getattr(clf, "_lanes_used", 1) > 1 and not args.no_exclusive:
+        if world == 1 and getattr(clf, "_lanes_used", 1) > 1 and not args.no_exclusive:      # (N = 1 only: a per-rank condition must not decide about fits that end in a collective)
             # and on a single device context: every kernel has the GPU to itself, so its HIP-event duration is the
             # kernel's own (with two contexts a launch is stretched by its neighbours)
             one_fit(streams_per_device=1)
