@@ -133,3 +133,26 @@ def test_streams_and_devices_of_one_process_equal_single_lane():
             assert clf._lanes_used == min(kw["n_iters"], len(layout.get("devices", [0])) * layout["streams_per_device"])
             for name in ("all_log_p_values_", "all_scores_", "communities_", "synth_communities_"):
                 np.testing.assert_array_equal(getattr(clf, name), getattr(base, name))
+
+
+def test_bench_two_ranks_control_flow(tmp_path):
+    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one process per rank), with the collectives on
+    gloo so that two ranks can share this box's GPU(s): warm-up, timed steps, the instrumented fits that follow on every
+    rank, the max-over-ranks reduction and the single JSON line of rank 0 -- no rank may wait for a fit the others skip."""
+    import json
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    env = dict(os.environ, DDX_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("DDX_ARENA_GUARD", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--cells", "6000",
+           "--genes", "3000", "--density", "0.05", "--iters", "3", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["value"] > 0 and line["scaling"] == "strong"
+    assert line["roofline"] is not None and line["roofline"]["frac"] > 0
