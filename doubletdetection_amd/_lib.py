@@ -68,6 +68,7 @@ _SIGNATURES = {
     "ddx_get_embedding_f64": (C.c_int, [C.c_void_p, c_f64_p, c_f64_p]),
     "ddx_set_embedding": (C.c_int, [C.c_void_p, c_f32_p, C.c_int64, C.c_int32]),
     "ddx_knn": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    "ddx_knn_metric": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "ddx_get_knn": (C.c_int, [C.c_void_p, c_i32_p, c_f64_p]),
     "ddx_get_knn_window_fraction": (C.c_int, [C.c_void_p, c_f64_p]),
     "ddx_build_graph": (C.c_int, [C.c_void_p, C.c_int32]),
@@ -530,8 +531,13 @@ class Context:
         self._embM, self._C = int(emb.shape[0]), int(emb.shape[1])
 
     # kNN / graph
-    def knn(self, k: int, include_self: bool):
-        self._c(self._lib.ddx_knn(self._h, int(k), 1 if include_self else 0))
+    METRICS = {"euclidean": 0, "minkowski": 0, "manhattan": 1, "cosine": 2, "correlation": 3}
+
+    def knn(self, k: int, include_self: bool, metric: str = "euclidean"):
+        if metric in ("euclidean", "minkowski"):
+            self._c(self._lib.ddx_knn(self._h, int(k), 1 if include_self else 0))
+        else:
+            self._c(self._lib.ddx_knn_metric(self._h, int(k), 1 if include_self else 0, self.METRICS[metric]))
         self._K = int(k)
 
     def get_knn(self, with_dist: bool = True):

@@ -155,12 +155,12 @@ class _HipEngine:
             self.ctx.timing_reference(other.ctx)         # one time axis for the streams of a GPU
 
     def run_iteration(self, parents, pseudocount, standard_scaling, n_components, q0, knn_k, include_self,
-                      graph_mode, gamma=None, pca_lock=None, verbose=False):
+                      graph_mode, gamma=None, pca_lock=None, verbose=False, metric="euclidean"):
         """One boosting iteration on the device.  Returns the symmetric graph (indptr, indices, weights), or --
         when ``gamma`` is given -- the result of the synchronous pre-sweeps run on the device:
         (member, coarse indptr, coarse indices, coarse weights)."""
         self.first_half(parents, pseudocount, standard_scaling, n_components, q0, pca_lock, verbose)
-        return self.second_half(knn_k, include_self, graph_mode, gamma, verbose)
+        return self.second_half(knn_k, include_self, graph_mode, gamma, verbose, metric)
 
     def first_half(self, parents, pseudocount, standard_scaling, n_components, q0, pca_lock=None, verbose=False):
         """dd.py:275-314: synthetic doublets, normalisation, optional scaling, PCA.  Touches neither the graph nor the
@@ -188,12 +188,12 @@ class _HipEngine:
             if pca_lock is not None:
                 pca_lock.release()
 
-    def second_half(self, knn_k, include_self, graph_mode, gamma=None, verbose=False):
+    def second_half(self, knn_k, include_self, graph_mode, gamma=None, verbose=False, metric="euclidean"):
         """dd.py:315-343 up to the sequential part: kNN, graph, and (``gamma`` given) part A of the community detection."""
         c = self.ctx
         if verbose:
             print("Clustering augmented data set...\n")
-        c.knn(knn_k, include_self)
+        c.knn(knn_k, include_self, metric)
         if gamma is None:
             return c.build_graph(graph_mode)  # symmetric CSR assembled on the device
         c.build_graph(graph_mode, fetch=False)
@@ -461,8 +461,8 @@ class BoostClassifier:
                 unsupported("directed", True, "only the undirected Jaccard graphs are built")
             if not kw.get("jaccard", True):
                 unsupported("jaccard", False, "only the Jaccard graphs are built")
-            if kw.get("primary_metric", "euclidean") != "euclidean":
-                unsupported("primary_metric", kw["primary_metric"], "only the euclidean metric is implemented")
+            if str(kw.get("primary_metric", "euclidean")).lower() not in _lib.Context.METRICS:
+                unsupported("primary_metric", kw["primary_metric"], "implemented: euclidean, manhattan, cosine, correlation")
             if kw.get("nn_method", "kdtree") not in ("kdtree", "brute"):
                 unsupported("nn_method", kw["nn_method"], "the device search is exact ('kdtree' and 'brute' give it)")
             algo = kw.get("clustering_algo", "louvain")
@@ -509,6 +509,12 @@ class BoostClassifier:
         # unless use_weights=False
         weighted = bool(kw.get("use_weights", leiden))
         return 10, True, 3 if weighted else 2, float(kw["resolution"]), int(self.random_state), None, leiden, None
+
+    def _knn_metric(self):
+        """phenograph.cluster(primary_metric=...) (dd.py:320-322); scanpy's neighbours (dd.py:331-336) are euclidean."""
+        if self.clustering_algorithm != "phenograph":
+            return "euclidean"
+        return str(self.clustering_kwargs.get("primary_metric", "euclidean")).lower()
 
     def _check_device_limits(self, num_cells, num_genes):
         """Fail before anything is uploaded when a request exceeds what the device kernels hold (DESIGN.md section 7);
@@ -829,6 +835,7 @@ class BoostClassifier:
             q0 = None      # exact regime: no random start (engine builds and diagonalises the Gram matrix)
 
         knn_k, include_self, graph_mode, gamma, seed, min_cluster_size, leiden, q_tol = self._cluster_plan()
+        metric = self._knn_metric()
 
         # iteration i belongs to rank i % world (one process per GPU under torch.distributed); inside this process the
         # rank's iterations are dealt out over the lanes (GPUs x streams)
@@ -855,6 +862,9 @@ class BoostClassifier:
                 needs B's labels) is slotted in behind that PCA, before the next graph overwrites the previous one."""
                 dev, engine = lanes[k]
                 kw = {"verbose": True} if self.verbose else {}
+                kw2 = dict(kw)
+                if metric != "euclidean":
+                    kw2["metric"] = metric
                 split = hasattr(engine, "first_half") and hasattr(engine, "refine")
                 waiting = None                   # (iteration, future of its part B)
 
@@ -872,10 +882,10 @@ class BoostClassifier:
                         if waiting is not None:
                             finish(waiting)
                             waiting = None
-                        graph = engine.second_half(knn_k, include_self, graph_mode, gamma, **kw)
+                        graph = engine.second_half(knn_k, include_self, graph_mode, gamma, **kw2)
                     else:
                         graph = engine.run_iteration(all_parents[i], self.pseudocount, self.standard_scaling, n_comp,
-                                                     q0, knn_k, include_self, graph_mode, gamma, pca_locks[dev], **kw)
+                                                     q0, knn_k, include_self, graph_mode, gamma, pca_locks[dev], **kw2)
                     if split and len(graph) == 4:
                         waiting = (i, pool.submit(self._part_b, graph, gamma, seed, leiden, q_tol, restart_threads))
                     else:

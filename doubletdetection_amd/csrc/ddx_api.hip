@@ -839,6 +839,18 @@ int ddx_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
     return stage_knn(ctx, k, include_self);
 }
 
+int ddx_knn_metric(ddx_ctx* ctx, int32_t k, int32_t include_self, int32_t metric) {
+    REQUIRE_CTX(ctx);
+    USE_DEVICE(ctx);
+    NEED(ctx->have_emb, "no embedding");
+    NEED(k >= 1 && k <= 256, "k must be in [1,256]");
+    NEED(metric >= 0 && metric <= 3, "metric must be 0 (euclidean), 1 (manhattan), 2 (cosine) or 3 (correlation)");
+    if ((int64_t)k + (include_self ? 0 : 1) > ctx->embM)
+        return set_err(ctx, DDX_E_ARG, "k=%d too large for %lld points", k, (long long)ctx->embM);
+    if (metric == 0) return stage_knn(ctx, k, include_self);
+    return stage_knn_metric(ctx, k, include_self, metric);
+}
+
 int ddx_get_knn(ddx_ctx* ctx, int32_t* idx_out, double* dist_out) {
     REQUIRE_CTX(ctx);
     USE_DEVICE(ctx);

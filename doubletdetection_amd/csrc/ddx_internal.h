@@ -280,6 +280,7 @@ int stage_dense_rows(ddx_ctx* ctx, int64_t row0, int64_t nrows, float* out_host)
 int stage_pca(ddx_ctx* ctx, int32_t C, int32_t oversample, int32_t n_iter, const double* q0, int64_t q0_rows);
 int stage_operator_apply(ddx_ctx* ctx, int32_t transpose, const double* X, int32_t n, double* out);
 int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self);
+int stage_knn_metric(ddx_ctx* ctx, int32_t k, int32_t include_self, int32_t metric);
 int stage_build_graph(ddx_ctx* ctx, int32_t mode);
 int stage_graph_relations(ddx_ctx* ctx, int32_t mode, int32_t* idx_host, double* w_host);
 void assemble_graph(int64_t M, int K, const int32_t* idx, const double* w, std::vector<int64_t>& ip,

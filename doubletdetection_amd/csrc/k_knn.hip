@@ -866,6 +866,130 @@ __global__ void __launch_bounds__(64 * WAVES) k_knn_select(const float* __restri
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Other metrics (phenograph.cluster(primary_metric=...) behind dd.py:320-322: "manhattan" -> sklearn minkowski p = 1,
+// "cosine" / "correlation" -> sklearn brute force): an exact scan in float64, one wave per query.  Not a fast path -- every
+// query meets every point (M^2 C flop on the float64 VALU) -- but an exact one: candidates no farther than the current
+// bound are collected in an LDS window; a full window is sorted, cut to the k best, and its k-th distance becomes the
+// bound (so only the first windows see many candidates).  Ordering by (distance, index).  The distances are
+//   manhattan   sum_c |a_c - b_c|
+//   cosine      1 - a.b / (|a| |b|)     (rows are normalised first, a zero row stays zero: distance 1, as sklearn's normalize)
+//   correlation cosine of the rows after subtracting their means
+// dist2_out receives the squared distance (the convention of ddx_get_knn).
+// ------------------------------------------------------------------------------------------------
+// rows prepared for the scan: cosine -> x / |x|, correlation -> (x - mean) / |x - mean|, manhattan -> x     (float64)
+__global__ void k_knn_generic_prepare(const float* __restrict__ emb, int64_t M, int C, int metric, double* __restrict__ out) {
+#pragma clang fp contract(off)
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= M) return;
+    double mean = 0.0;
+    if (metric == 3) {
+        for (int c = 0; c < C; ++c) mean += (double)emb[r * C + c];
+        mean /= (double)C;
+    }
+    double n2 = 0.0;
+    for (int c = 0; c < C; ++c) {
+        const double v = (double)emb[r * C + c] - mean;
+        n2 += v * v;
+    }
+    const double scale = (metric == 1) ? 1.0 : (n2 > 0.0 ? 1.0 / sqrt(n2) : 1.0);
+    for (int c = 0; c < C; ++c) out[r * C + c] = ((double)emb[r * C + c] - mean) * scale;
+}
+
+template <int METRIC>   // 1 manhattan, 2 / 3 cosine on the prepared rows
+__global__ void __launch_bounds__(256) k_knn_generic(const double* __restrict__ X, int64_t M, int C, int K, int include_self,
+                                                     int32_t* __restrict__ idx_out, double* __restrict__ dist_out) {
+#pragma clang fp contract(off)
+    constexpr int WIN = 1024;
+    __shared__ __attribute__((aligned(16))) double sd[4][WIN];
+    __shared__ int32_t si[4][WIN];
+    extern __shared__ __attribute__((aligned(16))) unsigned char gen_smem[];
+    double* sq = reinterpret_cast<double*>(gen_smem);              // [4][C] query rows
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t q = (int64_t)blockIdx.x * 4 + wave;
+    if (q >= M) return;
+    double* d = sd[wave];
+    int32_t* ix = si[wave];
+    double* qrow = sq + (size_t)wave * C;
+    for (int t = lane; t < C; t += 64) qrow[t] = X[q * C + t];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    double bound = __builtin_huge_val();
+    int fill = 0;
+    for (int64_t c0 = 0; c0 < M; c0 += 64) {
+        const int64_t c = c0 + lane;
+        double dv = __builtin_huge_val();
+        bool keep = false;
+        if (c < M && (include_self || c != q)) {
+            const double* row = X + c * C;
+            double acc = 0.0;
+            if (METRIC == 1) {
+                for (int t = 0; t < C; ++t) acc = acc + fabs(qrow[t] - row[t]);
+                dv = acc;
+            } else {
+                for (int t = 0; t < C; ++t) acc = acc + qrow[t] * row[t];
+                dv = 1.0 - acc;
+                if (dv < 0.0) dv = 0.0;                                 // (rounding: a row against itself)
+            }
+            keep = dv <= bound;
+        }
+        const unsigned long long m = __ballot(keep);
+        const int n_new = __popcll(m);
+        if (fill + n_new > WIN) {                                   // sort, keep the k best, tighten the bound
+            for (int t = fill + lane; t < WIN; t += 64) { d[t] = __builtin_huge_val(); ix[t] = 0x7fffffff; }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            wave_sort(d, ix, WIN, lane);
+            fill = K;
+            bound = d[K - 1];
+            keep = keep && dv <= bound;
+        }
+        const unsigned long long m2 = __ballot(keep);
+        if (keep) {
+            const int pos = fill + __popcll(m2 & ((1ull << lane) - 1ull));
+            d[pos] = dv;
+            ix[pos] = (int32_t)c;
+        }
+        fill += __popcll(m2);
+    }
+    int P = 64;
+    while (P < fill) P <<= 1;
+    for (int t = fill + lane; t < P; t += 64) { d[t] = __builtin_huge_val(); ix[t] = 0x7fffffff; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    wave_sort(d, ix, P, lane);
+    const int kept = fill < K ? fill : K;
+    for (int s = lane; s < K; s += 64) {
+        const bool ok = s < kept && ix[s] != 0x7fffffff;
+        idx_out[q * K + s] = ok ? ix[s] : -1;
+        dist_out[q * K + s] = ok ? d[s] * d[s] : __builtin_huge_val();
+    }
+}
+
+int stage_knn_metric(ddx_ctx* ctx, int32_t k, int32_t include_self, int32_t metric) {
+    const int64_t M = ctx->embM;
+    const int C = ctx->C;
+    if (k > 256) return set_err(ctx, DDX_E_UNSUPPORTED, "k=%d exceeds 256", k);
+    DDX_TRY(ensure(ctx, ctx->pcaA, sizeof(double) * (size_t)M * C + 256));
+    DDX_TRY(ensure(ctx, ctx->knn_idx, sizeof(int32_t) * (size_t)M * k));
+    DDX_TRY(ensure(ctx, ctx->knn_dist, sizeof(double) * (size_t)M * k));
+    double* X = ctx->pcaA.as<double>();
+    ScopedTimer t(ctx, "knn_generic");
+    k_knn_generic_prepare<<<(unsigned)ceil_div(M, 256), 256, 0, ctx->stream>>>(ctx->emb32.as<float>(), M, C, metric, X);
+    const unsigned grid = (unsigned)ceil_div(M, 4);
+    const size_t lds = sizeof(double) * 4 * (size_t)C;
+    if (metric == 1)
+        k_knn_generic<1><<<grid, 256, lds, ctx->stream>>>(X, M, C, k, include_self, ctx->knn_idx.as<int32_t>(), ctx->knn_dist.as<double>());
+    else
+        k_knn_generic<2><<<grid, 256, lds, ctx->stream>>>(X, M, C, k, include_self, ctx->knn_idx.as<int32_t>(), ctx->knn_dist.as<double>());
+    DDX_HIP(ctx, hipGetLastError());
+    ctx->knn_window_total = nullptr;
+    ctx->K = k;
+    ctx->knn_self = include_self != 0;
+    ctx->have_knn = true;
+    return DDX_OK;
+}
+
 // sort key of the point order: the first principal component
 __global__ void k_knn_keys(const float* __restrict__ emb, int64_t M, int C, float* __restrict__ keys, int32_t* __restrict__ ids) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

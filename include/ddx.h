@@ -150,6 +150,9 @@ int ddx_set_embedding(ddx_ctx* ctx, const float* emb, int64_t n_rows, int32_t n_
  * components in order, no fused multiply-add), which is what the ordering is defined on.  include_self = 1 reproduces scanpy's n_neighbors convention (the point itself
  * is a candidate); include_self = 0 reproduces phenograph (self removed). */
 int ddx_knn(ddx_ctx* ctx, int32_t k, int32_t include_self);
+/* phenograph.cluster(primary_metric=...): 0 euclidean (= ddx_knn), 1 manhattan (sklearn minkowski p = 1), 2 cosine,
+ * 3 correlation (sklearn brute force).  Metrics 1-3 run an exact float64 scan of all pairs: correct, not fast. */
+int ddx_knn_metric(ddx_ctx* ctx, int32_t k, int32_t include_self, int32_t metric);
 int ddx_get_knn(ddx_ctx* ctx, int32_t* idx_out /* [M*k] */, double* dist2_out /* [M*k] or NULL */);
 /* statistics: share of the (query block, candidate tile) pairs the last ddx_knn had to screen after pruning on the
  * first component (1 = all pairs).  bench.py scales the distance-screen flop count with it. */

@@ -294,6 +294,32 @@ def knn_exact(emb: np.ndarray, k: int, include_self: bool, algorithm: str = "bru
     return idx, dist
 
 
+def knn_metric(emb: np.ndarray, k: int, include_self: bool, metric: str):
+    """phenograph.cluster(primary_metric=...) (dd.py:320-322 [upstream phenograph.core.find_neighbors], restated): "manhattan"
+    is sklearn's minkowski with p = 1, "cosine" / "correlation" go to sklearn's brute force; k + 1 neighbours, the point
+    itself dropped.  The arithmetic is scikit-learn's own (float64 here, so that ties fall by index)."""
+    from sklearn.neighbors import NearestNeighbors
+
+    e = np.asarray(emb, dtype=np.float64)
+    kk = k if include_self else k + 1
+    if metric == "manhattan":
+        nn = NearestNeighbors(n_neighbors=kk, algorithm="brute", metric="minkowski", p=1)
+    else:
+        nn = NearestNeighbors(n_neighbors=kk, algorithm="brute", metric=metric)
+    dist, idx = nn.fit(e).kneighbors(e)
+    if not include_self:
+        # drop the point itself (it is at distance 0; with duplicate points sklearn may list the duplicate first)
+        out_i = np.empty((e.shape[0], k), dtype=np.int64)
+        out_d = np.empty((e.shape[0], k))
+        for r in range(e.shape[0]):
+            keep = np.flatnonzero(idx[r] != r)[:k]
+            if len(keep) < k:
+                keep = np.arange(1, k + 1)
+            out_i[r], out_d[r] = idx[r, keep], dist[r, keep]
+        return out_i, out_d
+    return idx, dist
+
+
 def knn_bruteforce_f64(emb: np.ndarray, k: int, include_self: bool):
     """Independent float64 definition used to adjudicate ties: squared distances by direct
     differences, ordering by (distance, index).  O(M^2) memory in blocks; small M only."""
@@ -463,7 +489,11 @@ def cluster_embedding(emb: np.ndarray, algorithm: str, clustering_kwargs: dict, 
     kw = dict(clustering_kwargs or {})
     if algorithm == "phenograph":
         k = int(kw.get("k", 30))
-        idx, _ = knn_fn(emb, k, include_self=False)
+        metric = str(kw.get("primary_metric", "euclidean")).lower()
+        if metric in ("euclidean", "minkowski"):
+            idx, _ = knn_fn(emb, k, include_self=False)
+        else:
+            idx, _ = knn_metric(emb, k, False, metric)
         G = jaccard_graph(idx, prune=bool(kw.get("prune", True)))
         if kw.get("clustering_algo", "louvain") == "leiden":
             # phenograph hands resolution_parameter / seed to leidenalg only

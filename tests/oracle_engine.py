@@ -31,7 +31,7 @@ class OracleEngine:
         self.raw, self.lib, self.normed = other.raw, other.lib, other.normed
 
     def run_iteration(self, parents, pseudocount, standard_scaling, n_components, q0, knn_k, include_self, graph_mode, gamma=None,
-                      pca_lock=None, verbose=False):
+                      pca_lock=None, verbose=False, metric="euclidean"):
         synth = orc.create_doublets(self.raw, parents)
         aug, _, _ = orc.lognormalise(self.normed, self.lib, synth, pseudocount)
         import scipy.sparse as sp
@@ -45,7 +45,7 @@ class OracleEngine:
         # the product passes the start matrix it drew; the oracle draws the same one from the seed
         if emb is None:
             emb = orc.pca_f64(aug, n_components, self.seed)[0].astype(np.float32)
-        idx, dist = orc.knn_bruteforce_f64(emb, knn_k, include_self)
+        idx, dist = orc.knn_bruteforce_f64(emb, knn_k, include_self) if metric == "euclidean" else orc.knn_metric(emb, knn_k, include_self, metric)
         if graph_mode == 3:
             G = orc.umap_connectivities(idx, dist)
         elif graph_mode == 2:

@@ -199,7 +199,8 @@ def test_clustering_kwargs_never_silently_ignored():
     assert plan("phenograph", clustering_algo="leiden", resolution_parameter=2.5, seed=9, prune=False, k=15,
                 min_cluster_size=4) == (15, False, 1, 2.5, 9, 4, True, None)
     assert plan("phenograph", nn_method="brute", n_jobs=4, q_tol=1e-4, louvain_time_limit=10) == (30, False, 0, 1.0, 3, 10, False, 1e-4)
-    for bad in ({"directed": True}, {"jaccard": False}, {"primary_metric": "cosine"}, {"nn_method": "faiss"},
+    assert plan("phenograph", primary_metric="cosine") == (30, False, 0, 1.0, 3, 10, False, 1e-3)      # the metric only changes the kNN stage
+    for bad in ({"directed": True}, {"jaccard": False}, {"primary_metric": "chebyshev"}, {"nn_method": "faiss"},
                 {"partition_type": object()}, {"clustering_algo": "leiden", "n_iterations": 3},
                 {"clustering_algo": "leiden", "use_weights": False}):
         with pytest.raises(NotImplementedError):

@@ -592,6 +592,35 @@ def test_wide_sketches_many_dimensions_many_neighbours(n_components, k, algo):
     np.testing.assert_allclose(clf.all_log_p_values_, ref.all_log_p_values_, rtol=1e-9, atol=1e-9)
 
 
+@pytest.mark.parametrize("metric", ["manhattan", "cosine", "correlation"])
+def test_other_knn_metrics_against_sklearn(ctx, metric):
+    """phenograph.cluster(primary_metric=...) (dd.py:320-322): the exact float64 scan on the device against scikit-learn's
+    NearestNeighbors with the same metric (what upstream calls), on the reference-generated embedding of a golden case and on
+    a larger random one; then a whole fit against the oracle, whose kNN is sklearn's."""
+    from doubletdetection_amd import BoostClassifier
+    from doubletdetection_amd._synthetic import make_counts
+
+    g = load_golden("case_a_hvg_pheno")
+    for emb, k in ((g["pca_f32"][0], 30), (np.random.default_rng(3).normal(size=(5000, 20)).astype(np.float32), 45)):
+        ctx.set_embedding(emb)
+        ctx.knn(k, False, metric)
+        idx, dist = ctx.get_knn()
+        ref_idx, ref_dist = orc.knn_metric(emb, k, False, metric)
+        same = np.mean(np.all(idx == ref_idx, axis=1))
+        assert same >= 0.99, same                                   # (ties / last-bit differences of the dot products)
+        np.testing.assert_allclose(dist, ref_dist, rtol=1e-9, atol=1e-12)
+        assert np.all(idx != np.arange(emb.shape[0])[:, None])
+    counts = make_counts(900, 700, density=0.15, n_types=5, seed=21)
+    kw = dict(n_iters=2, n_top_var_genes=600, clustering_kwargs={"primary_metric": metric}, random_state=2)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        clf = BoostClassifier(**kw).fit(counts)
+        kw["clustering_kwargs"] = {"primary_metric": metric}
+        ref = orc.OracleClassifier(pca="f64", **kw).fit(counts)
+    agree = np.mean(clf.communities_ == ref.communities_)
+    assert agree >= 0.98, agree
+
+
 def test_api_corners_on_gpu(capsys):
     from doubletdetection_amd import BoostClassifier
 
