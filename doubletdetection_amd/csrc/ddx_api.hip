@@ -863,7 +863,8 @@ int ddx_get_knn(ddx_ctx* ctx, int32_t* idx_out, double* dist_out) {
 int ddx_get_knn_window_fraction(ddx_ctx* ctx, double* fraction) {
     REQUIRE_CTX(ctx);
     USE_DEVICE(ctx);
-    NEED(ctx->have_knn && ctx->knn_window_total && fraction, "no kNN result");
+    NEED(ctx->have_knn && fraction, "no kNN result");
+    if (!ctx->knn_window_total) { *fraction = 1.0; return DDX_OK; }      // (the scan of the other metrics meets every pair)
     unsigned long long total = 0;
     DDX_TRY(d2h(ctx, &total, ctx->knn_window_total, sizeof(total)));
     *fraction = ctx->knn_window_pairs > 0.0 ? (double)total / ctx->knn_window_pairs : 0.0;
