@@ -43,7 +43,7 @@ def oracle_graph(emb, flavour):
     # 0 for a point's distance to itself, which the umap weights would take for the nearest neighbour's distance)
     e = np.asarray(emb, dtype=np.float64)
     dist = np.sqrt(((e[:, None, :] - e[idx]) ** 2).sum(axis=2))
-    order = np.lexsort((idx, dist), axis=1) if False else np.argsort(dist, axis=1, kind="stable")
+    order = np.argsort(dist, axis=1, kind="stable")
     idx, dist = np.take_along_axis(idx, order, axis=1), np.take_along_axis(dist, order, axis=1)
     if kind == "jaccard_pruned":
         G = orc.jaccard_graph(idx, prune=True)
