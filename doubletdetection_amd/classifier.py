@@ -86,7 +86,7 @@ def _park(device, ctx) -> None:
     held = [c.device_bytes() for c in parked]
     while sum(held) > limit:
         big = max(range(len(parked)), key=lambda i: held[i])
-        parked[big].trim(max(0, limit - (sum(held) - held[big])) if len(parked) == 1 else 0)
+        parked[big].trim(max(0, limit - (sum(held) - held[big])))      # what the others leave of the allowance
         new = parked[big].device_bytes()
         if new == held[big]:
             break
