@@ -457,9 +457,10 @@ class BoostClassifier:
             #   min_cluster_size=10, jaccard=True, primary_metric="euclidean", n_jobs=-1, q_tol=1e-3,
             #   louvain_time_limit=2000, nn_method="kdtree", partition_type=None, resolution_parameter=1,
             #   n_iterations=-1, use_weights=True, seed=None)                        [dd.py:320-322]
-            if kw.get("directed", False):
-                unsupported("directed", True, "only the undirected Jaccard graphs are built")
             if not kw.get("jaccard", True):
+                # upstream's alternative is a Gaussian kernel of the raw distances with sigma = 1: in a 30-dimensional
+                # embedding the weights span tens of orders of magnitude, which the exact integer weight grid of the
+                # community detection (2^-20) cannot hold
                 unsupported("jaccard", False, "only the Jaccard graphs are built")
             if str(kw.get("primary_metric", "euclidean")).lower() not in _lib.Context.METRICS:
                 unsupported("primary_metric", kw["primary_metric"], "implemented: euclidean, manhattan, cosine, correlation")
@@ -471,7 +472,14 @@ class BoostClassifier:
             if kw.get("partition_type") is not None:
                 unsupported("partition_type", kw["partition_type"], "only RBConfigurationVertexPartition (the default)")
             k = int(kw.get("k", 30))
-            mode = 0 if kw.get("prune") else 1
+            directed = bool(kw.get("directed", False))
+            if directed and algo == "leiden":
+                unsupported("directed", True, "leidenalg's directed modularity of the one-sided Jaccard graph is not restated")
+            # directed=True skips upstream's symmetrisation (prune has no say then) and hands the edge i -> j of every
+            # neighbour pair to the Louvain converter, which stores each edge in both directions and adds the weights
+            # of duplicates: the undirected graph with J_ij once for one-sided and twice for mutual neighbours, i.e.
+            # twice the averaged graph -- and modularity does not see a common factor.
+            mode = 1 if (directed or not kw.get("prune")) else 0
             mcs = int(kw.get("min_cluster_size", 10))
             if algo == "leiden":
                 # upstream: leidenalg on the Jaccard graph with resolution_parameter / seed / use_weights / n_iterations
@@ -492,8 +500,9 @@ class BoostClassifier:
         #   flavor="vtraag", directed=True, use_weights=False, partition_type=None, neighbors_key=None, obsp=None, copy)
         # sc.tl.leiden(adata, resolution, restrict_to=None, random_state, key_added, adjacency=None, directed,
         #   use_weights=True, n_iterations=-1, partition_type=None, neighbors_key=None, obsp=None, copy, flavor)
-        if kw.get("directed", False):
-            unsupported("directed", True, "only undirected neighbour graphs are built")
+        # directed=True (scanpy's own default; the reference passes False, dd.py:415-416) turns the symmetric
+        # connectivities into an igraph with both orientations of every edge: out- and in-strengths are equal and the
+        # directed modularity is the undirected one term by term -- the same objective, so both values are accepted.
         for name in ("restrict_to", "adjacency", "neighbors_key", "obsp", "partition_type"):
             if kw.get(name) is not None:
                 unsupported(name, kw[name], "the graph is the one sc.pp.neighbors builds on the PCA embedding")

@@ -207,7 +207,7 @@ int timing_flush(ddx_ctx* ctx) {
             ctx->t_recs[ev.name_id].launches += 1;
             ctx->t_recs[ev.name_id].total_ms += ms;
             float t0 = 0.f;
-            if (ctx->t_ref && hipEventElapsedTime(&t0, ctx->t_ref, ev.start) == hipSuccess) {
+            if (ctx->t_ref && hipEventElapsedTime(&t0, ctx->t_ref.get(), ev.start) == hipSuccess) {
                 ctx->t_intervals.push_back(t0);
                 ctx->t_intervals.push_back(t0 + ms);
             }
@@ -281,8 +281,7 @@ int ddx_destroy(ddx_ctx* ctx) {
     (void)timing_flush(ctx);
     for (hipEvent_t e : ctx->t_free) (void)hipEventDestroy(e);
     ctx->t_free.clear();
-    if (ctx->t_ref && ctx->t_ref_owned) (void)hipEventDestroy(ctx->t_ref);
-    ctx->t_ref = nullptr;
+    ctx->t_ref.reset();
     context_reset(ctx);
     arena_destroy(ctx);
     if (ctx->lv_host) (void)hipHostFree(ctx->lv_host);
@@ -980,7 +979,6 @@ int ddx_timing_enable(ddx_ctx* ctx, int32_t on) {
     REQUIRE_CTX(ctx);
     USE_DEVICE(ctx);
     if (!on) DDX_TRY(timing_flush(ctx));
-    if (!on && !ctx->t_ref_owned) ctx->t_ref = nullptr;        // (a borrowed clock origin is not kept beyond the timed fits)
     ctx->timing = on != 0;
     return DDX_OK;
 }
@@ -999,18 +997,14 @@ int ddx_timing_reference(ddx_ctx* ctx, ddx_ctx* share_with) {
     USE_DEVICE(ctx);
     if (share_with && share_with != ctx) {                 // the same clock origin as another context of this GPU
         NEED(share_with->device == ctx->device && share_with->t_ref, "the other context has no reference on this device");
-        if (ctx->t_ref && ctx->t_ref_owned) (void)hipEventDestroy(ctx->t_ref);
         ctx->t_ref = share_with->t_ref;
-        ctx->t_ref_owned = false;
         return DDX_OK;
     }
-    if (!ctx->t_ref || !ctx->t_ref_owned) {
-        ctx->t_ref = nullptr;
-        DDX_HIP(ctx, hipEventCreate(&ctx->t_ref));
-        ctx->t_ref_owned = true;
-    }
-    DDX_HIP(ctx, hipEventRecord(ctx->t_ref, ctx->stream));
-    DDX_HIP(ctx, hipEventSynchronize(ctx->t_ref));
+    hipEvent_t e = nullptr;                                // a new origin (contexts that shared the old one keep it)
+    DDX_HIP(ctx, hipEventCreate(&e));
+    ctx->t_ref = std::shared_ptr<ihipEvent_t>(e, [](hipEvent_t x) { (void)hipEventDestroy(x); });
+    DDX_HIP(ctx, hipEventRecord(e, ctx->stream));
+    DDX_HIP(ctx, hipEventSynchronize(e));
     return DDX_OK;
 }
 

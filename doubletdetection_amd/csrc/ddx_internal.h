@@ -10,6 +10,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <memory>
 #include <vector>
 
 #include "../../include/ddx.h"
@@ -225,8 +226,9 @@ struct ddx_ctx {
     std::vector<ddx::PendingEvent> t_pending;
     std::vector<hipEvent_t> t_free;          // recycled events (creating a pair per scope cost more than recording it)
     std::map<const void*, int> t_by_ptr;     // scope names are string literals: their address identifies them
-    bool t_ref_owned = false;
-    hipEvent_t t_ref = nullptr;              // reference event (ddx_timing_reference): scope intervals are kept relative to it
+    // reference event (ddx_timing_reference): scope intervals are kept relative to it.  Shared between the contexts of
+    // one GPU that report on one clock; the last holder destroys the event.
+    std::shared_ptr<ihipEvent_t> t_ref;
     std::vector<float> t_intervals;          // (begin, end) in ms after t_ref of every timed scope since the last reset
 };
 

@@ -200,7 +200,11 @@ def test_clustering_kwargs_never_silently_ignored():
                 min_cluster_size=4) == (15, False, 1, 2.5, 9, 4, True, None)
     assert plan("phenograph", nn_method="brute", n_jobs=4, q_tol=1e-4, louvain_time_limit=10) == (30, False, 0, 1.0, 3, 10, False, 1e-4)
     assert plan("phenograph", primary_metric="cosine") == (30, False, 0, 1.0, 3, 10, False, 1e-3)      # the metric only changes the kNN stage
-    for bad in ({"directed": True}, {"jaccard": False}, {"primary_metric": "chebyshev"}, {"nn_method": "faiss"},
+    # directed=True: no symmetrisation upstream (prune is ignored), the Louvain converter adds both orientations:
+    # twice the averaged graph, the same partition
+    assert plan("phenograph", directed=True) == (30, False, 1, 1.0, 3, 10, False, 1e-3)
+    assert plan("phenograph", directed=True, prune=True) == (30, False, 1, 1.0, 3, 10, False, 1e-3)
+    for bad in ({"directed": True, "clustering_algo": "leiden"}, {"jaccard": False}, {"primary_metric": "chebyshev"}, {"nn_method": "faiss"},
                 {"partition_type": object()}, {"clustering_algo": "leiden", "n_iterations": 3},
                 {"clustering_algo": "leiden", "use_weights": False}):
         with pytest.raises(NotImplementedError):
@@ -212,7 +216,10 @@ def test_clustering_kwargs_never_silently_ignored():
     assert plan("louvain", use_weights=True, resolution=1.5) == (10, True, 3, 1.5, 3, None, False, None)
     assert plan("leiden") == (10, True, 3, 4.0, 3, None, True, None)
     assert plan("leiden", use_weights=False) == (10, True, 2, 4.0, 3, None, True, None)
-    for algo, bad in (("louvain", {"directed": True}), ("louvain", {"restrict_to": ("a", ["1"])}),
+    # scanpy's directed=True doubles every edge of the symmetric connectivities: the same modularity term by term
+    assert plan("louvain", directed=True) == plan("louvain", directed=False) == plan("louvain")
+    assert plan("leiden", directed=True) == plan("leiden")
+    for algo, bad in (("louvain", {"restrict_to": ("a", ["1"])}),
                       ("leiden", {"adjacency": 1}), ("louvain", {"obsp": "x"}), ("leiden", {"neighbors_key": "n"}),
                       ("louvain", {"partition_type": object()}), ("louvain", {"flavor": "igraph"}),
                       ("leiden", {"flavor": "igraph"}), ("leiden", {"n_iterations": 2})):
