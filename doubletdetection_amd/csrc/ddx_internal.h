@@ -208,6 +208,7 @@ struct ddx_ctx {
     int lv_levels = 0;
     int64_t lv_m2 = 0;                                   // 2m of the quantised graph (the same on every level)
     int32_t lv_maxdeg[kLvKeep] = {0, 0}, lv_nbig[kLvKeep] = {0, 0};
+    bool lv_narrow[kLvKeep] = {};            // the level's edge weights fit the 32-bit register sweep
     int64_t lv_n[kLvKeep] = {0, 0}, lv_E[kLvKeep] = {0, 0};
     const int64_t* lv_indptr[kLvKeep] = {nullptr, nullptr};
     const int32_t* lv_cols[kLvKeep] = {nullptr, nullptr};

@@ -778,6 +778,45 @@ __device__ __forceinline__ void wave_sort(double* d, int32_t* ix, int P, int lan
     }
 }
 
+// The same sort with the window in registers (P = 64 R entries, entry e = 64 r + lane): partners at least 64 apart sit in
+// one lane, the others are exchanged by lane permutes -- no LDS traffic, hence none of the bank conflicts the strided
+// pair accesses of wave_sort cost (9 in 10 of its LDS cycles).  Same network, same order.
+template <int R>
+__device__ __forceinline__ void wave_sort_regs(double (&d)[R], int32_t (&ix)[R], int lane) {
+#pragma unroll
+    for (int size = 2; size <= 64 * R; size <<= 1) {
+#pragma unroll
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            if (stride >= 64) {
+                const int rs = stride >> 6;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    if (r & rs) continue;
+                    const int r2 = r | rs;
+                    const bool up = (((r << 6) & size) == 0);
+                    const bool gt = d[r] > d[r2] || (d[r] == d[r2] && ix[r] > ix[r2]);
+                    if (gt == up) {
+                        const double td = d[r]; d[r] = d[r2]; d[r2] = td;
+                        const int32_t ti = ix[r]; ix[r] = ix[r2]; ix[r2] = ti;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int e = (r << 6) | lane;
+                    const bool up = ((e & size) == 0);
+                    const bool lower = ((lane & stride) == 0);
+                    const double od = __shfl_xor(d[r], stride, 64);
+                    const int32_t oi = __shfl_xor(ix[r], stride, 64);
+                    const bool other_less = od < d[r] || (od == d[r] && oi < ix[r]);
+                    const bool want_min = (lower == up);
+                    if (want_min == other_less && !(od == d[r] && oi == ix[r])) { d[r] = od; ix[r] = oi; }
+                }
+            }
+        }
+    }
+}
+
 // one wave per query (WAVES per block, no block-level synchronisation).  The instances share the work by list length: an
 // instance takes the queries with lo < min(length, cap) <= hi (SELMAX = kSelSmall: nearly all; kSelMax: the few longer or
 // overflowed ones; kSelHuge: lists beyond 1024 entries, which only occur with the large cap of k > 80).
@@ -805,20 +844,44 @@ __global__ void __launch_bounds__(64 * WAVES) k_knn_select(const float* __restri
     // exact distances of the listed candidates, one per lane and step, then sort
     int P = 64;
     while (P < cnt) P <<= 1;
-    for (int t = lane; t < P; t += 64) {
-        double dv = __builtin_huge_val();
-        int32_t iv = 0x7fffffff;
+    auto candidate = [&](int t, double& dv, int32_t& iv) {
+        dv = __builtin_huge_val();
+        iv = 0x7fffffff;
         if (t < cnt) {
             const int64_t c = cbuf[q * (int64_t)cap + t];
             dv = exact_d2<CP>(qrow, E + c * CP);
             iv = perm[c];                            // ties are broken by the caller's point ids
         }
-        d[t] = dv;
-        ix[t] = iv;
+    };
+    if (SELMAX == kSelSmall) {
+        // the common instance keeps the window in registers; it only lands in LDS for the write-out / the overflow path
+        auto sort_in_registers = [&](auto rtag) {
+            constexpr int R = decltype(rtag)::value;
+            double dr[R];
+            int32_t ir[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) candidate(r * 64 + lane, dr[r], ir[r]);
+            wave_sort_regs<R>(dr, ir, lane);
+#pragma unroll
+            for (int r = 0; r < R; ++r) { d[r * 64 + lane] = dr[r]; ix[r * 64 + lane] = ir[r]; }
+        };
+        if (P == 64) sort_in_registers(std::integral_constant<int, 1>());
+        else if (P == 128) sort_in_registers(std::integral_constant<int, 2>());
+        else sort_in_registers(std::integral_constant<int, 4>());
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    } else {
+        for (int t = lane; t < P; t += 64) {
+            double dv;
+            int32_t iv;
+            candidate(t, dv, iv);
+            d[t] = dv;
+            ix[t] = iv;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        wave_sort(d, ix, P, lane);
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    wave_sort(d, ix, P, lane);
     int kept = cnt < K ? cnt : K;
     if (overflow) {
         // The list was cut at kCandCap entries.  Its k-th exact distance is still an upper bound of the true
@@ -1244,7 +1307,10 @@ __global__ void __launch_bounds__(256) k_edge_weights(const int32_t* __restrict_
 
 // The same weights, one wave per node (K <= 64): N(i) sits sorted in LDS, lane l holds the l-th relation of i and,
 // relation by relation, the wave loads N(j) (one coalesced row), every lane looks its element up in N(i) by
-// binary search and a ballot counts the shared neighbours.  Four rows are in flight at a time.
+// binary search and a ballot counts the shared neighbours.  HALF (K <= 32, the shipped settings): the two halves of the
+// wave take two relations at a time -- lanes 0-31 the even one, lanes 32-63 the odd one -- so all 64 lanes search.
+// Four steps (four or eight rows) are in flight at a time.
+template <bool HALF>
 __global__ void __launch_bounds__(256) k_edge_weights_wave(const int32_t* __restrict__ idx, const int32_t* __restrict__ sorted,
                                                            int64_t M, int K, int mode, double* __restrict__ w_out) {
     __shared__ int32_t nS[4][64];
@@ -1256,20 +1322,35 @@ __global__ void __launch_bounds__(256) k_edge_weights_wave(const int32_t* __rest
     const int32_t myj = lane < K ? idx[i * K + lane] : -1;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    constexpr int PER = HALF ? 2 : 1;                // relations per step
+    const int half = HALF ? (lane >> 5) : 0;
+    const int sub = HALF ? (lane & 31) : lane;       // element of N(j) this lane looks up
     double myw = 0.0;
-    for (int t0 = 0; t0 < K; t0 += 4) {
+    auto weight = [&](int shared, bool mutual) -> double {
+        double w;
+        if (mode == 2) {
+            w = 1.0;
+        } else {
+            const double J = (double)shared / (2.0 * (double)K - (double)shared);
+            if (mode == 0) w = mutual ? J * J : 0.0;
+            else w = mutual ? (J + J) / 2.0 : J / 2.0;
+        }
+        return mutual ? w : -w;
+    };
+    for (int t0 = 0; t0 < K; t0 += 4 * PER) {
         int32_t j[4], y[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            j[u] = (t0 + u < K) ? __shfl(myj, t0 + u, 64) : -1;
+            const int rel = t0 + PER * u + half;
+            j[u] = rel < K ? __shfl(myj, rel, 64) : -1;
             const bool ok = j[u] >= 0 && j[u] != (int32_t)i;
-            y[u] = (ok && lane < K) ? sorted[(int64_t)j[u] * K + lane] : 0;
+            y[u] = (ok && sub < K) ? sorted[(int64_t)j[u] * K + sub] : 0;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            if (t0 + u >= K) break;
+            if (t0 + PER * u >= K) break;
             const bool ok = j[u] >= 0 && j[u] != (int32_t)i;
-            const bool valid = ok && lane < K;
+            const bool valid = ok && sub < K;
             bool found = false;
             if (valid) {
                 int lo = 0, hi = K;
@@ -1279,20 +1360,19 @@ __global__ void __launch_bounds__(256) k_edge_weights_wave(const int32_t* __rest
                 }
                 found = lo < K && Ni[lo] == y[u];
             }
-            const int shared = __popcll(__ballot(found));
-            const bool mutual = __ballot(valid && y[u] == (int32_t)i) != 0ull;
-            double w = 0.0;
-            if (ok) {
-                if (mode == 2) {
-                    w = 1.0;
-                } else {
-                    const double J = (double)shared / (2.0 * (double)K - (double)shared);
-                    if (mode == 0) w = mutual ? J * J : 0.0;
-                    else w = mutual ? (J + J) / 2.0 : J / 2.0;
-                }
-                w = mutual ? w : -w;
+            const unsigned long long fm = __ballot(found);
+            const unsigned long long mm = __ballot(valid && y[u] == (int32_t)i);
+            if (HALF) {
+                // (the relation's validity is known to its own lane: an invalid relation keeps weight 0)
+                const double w0 = weight(__popc((unsigned)fm), (unsigned)mm != 0u);
+                const double w1 = weight(__popc((unsigned)(fm >> 32)), (unsigned)(mm >> 32) != 0u);
+                const bool mine_ok = myj >= 0 && myj != (int32_t)i;
+                if (lane == t0 + 2 * u) myw = mine_ok ? w0 : 0.0;
+                if (lane == t0 + 2 * u + 1) myw = mine_ok ? w1 : 0.0;
+            } else {
+                const double w = ok ? weight(__popcll(fm), mm != 0ull) : 0.0;
+                if (lane == t0 + u) myw = w;
             }
-            if (lane == t0 + u) myw = w;
         }
     }
     if (lane < K) w_out[i * K + lane] = myw;
@@ -1483,9 +1563,12 @@ static int graph_weights_device(ddx_ctx* ctx, int32_t mode) {
         return DDX_OK;
     }
     k_sort_neighbours<<<(unsigned)ceil_div(M, 64), 64, sizeof(int32_t) * K * 64, ctx->stream>>>(ctx->knn_idx.as<int32_t>(), M, K, ctx->knn_sorted.as<int32_t>());
-    if (K <= 64)
-        k_edge_weights_wave<<<(unsigned)ceil_div(M, 4), 256, 0, ctx->stream>>>(ctx->knn_idx.as<int32_t>(), ctx->knn_sorted.as<int32_t>(), M, K, mode,
-                                                                               ctx->edge_w.as<double>());
+    if (K <= 32)
+        k_edge_weights_wave<true><<<(unsigned)ceil_div(M, 4), 256, 0, ctx->stream>>>(ctx->knn_idx.as<int32_t>(), ctx->knn_sorted.as<int32_t>(), M, K, mode,
+                                                                                     ctx->edge_w.as<double>());
+    else if (K <= 64)
+        k_edge_weights_wave<false><<<(unsigned)ceil_div(M, 4), 256, 0, ctx->stream>>>(ctx->knn_idx.as<int32_t>(), ctx->knn_sorted.as<int32_t>(), M, K, mode,
+                                                                                      ctx->edge_w.as<double>());
     else
         k_edge_weights<<<(unsigned)ceil_div(M * K, 256), 256, 0, ctx->stream>>>(ctx->knn_idx.as<int32_t>(), ctx->knn_sorted.as<int32_t>(), M, K, mode,
                                                                                 ctx->edge_w.as<double>());

@@ -16,6 +16,7 @@
 #include "ddx_prims.h"
 
 #include <algorithm>
+#include <type_traits>
 
 #include "ddx_internal.h"
 
@@ -33,16 +34,16 @@ __global__ void k_lv_quantise(const double* __restrict__ w, int64_t E, int64_t* 
 
 // strength of every node (self loops included); every node its own community (comm = id, total = strength, one member);
 // 2m, the largest degree and the list of the nodes with more than 64 neighbours (those take the hash-table sweep).
-// scal: [0] = 2m, [1] = max degree (low 32 bits) | number of big nodes (high 32 bits)
+// scal: [0] = 2m, [1] = max degree (low 32 bits) | number of big nodes (high 32 bits), [3] = largest edge weight
 __global__ void __launch_bounds__(256) k_lv_strength(const int64_t* __restrict__ indptr, const int64_t* __restrict__ wq, int64_t n, int64_t* __restrict__ K,
                                                      int32_t* __restrict__ comm, unsigned long long* __restrict__ tot, int32_t* __restrict__ size,
                                                      unsigned long long* __restrict__ scal, int32_t* __restrict__ big_list) {
     const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int64_t s = 0;
+    int64_t s = 0, wmax = 0;
     int deg = 0;
     if (v < n) {
         const int64_t b = indptr[v], e = indptr[v + 1];
-        for (int64_t p = b; p < e; ++p) s += wq[p];
+        for (int64_t p = b; p < e; ++p) { const int64_t w = wq[p]; s += w; wmax = w > wmax ? w : wmax; }
         deg = (int)(e - b);
         K[v] = s;
         comm[v] = (int32_t)v;
@@ -58,10 +59,13 @@ __global__ void __launch_bounds__(256) k_lv_strength(const int64_t* __restrict__
         ws += ((int64_t)__shfl_xor((int)(ws >> 32), off, 64) << 32) | (uint32_t)__shfl_xor((int)ws, off, 64);
         const int od = __shfl_xor(wd, off, 64);
         wd = od > wd ? od : wd;
+        const int64_t om = ((int64_t)__shfl_xor((int)(wmax >> 32), off, 64) << 32) | (uint32_t)__shfl_xor((int)wmax, off, 64);
+        wmax = om > wmax ? om : wmax;
     }
     if ((threadIdx.x & 63) == 0) {
         atomicAdd(scal, (unsigned long long)ws);
         atomicMax(reinterpret_cast<int32_t*>(scal + 1), wd);
+        atomicMax(scal + 3, (unsigned long long)wmax);
     }
 }
 
@@ -85,51 +89,92 @@ __device__ __forceinline__ void wave_best(double& s, int32_t& c) {
 // decides from (comm, tot, size) and writes next[v]; k_lv_apply then carries the moves out.  Nodes with at most 64
 // neighbours (nearly all on the original graph) are handled here in registers, which needs no LDS and so keeps the CU full
 // of waves (the work is a chain of dependent loads); the others are listed in big_list and go through k_lv_sweep_big.
+// Lane l holds neighbour l; W(v, c) is gathered neighbour by neighbour (readlane + one masked add), so every lane of a
+// community ends with the same W and the same score -- duplicates change nothing in the arg-max, and the weight to the
+// own community is read from the first lane that holds it.  W32: every quantised edge weight of the level is below 2^25
+// (always on the original graph, whose weights are at most 1), so 64 of them sum in 32 bits.
+// A wave decides kLvPerWave nodes, the loads of all of them issued before any is used (the kernel is a chain of four
+// dependent fetches: row bounds -> neighbours -> their communities -> those communities' totals).  Measured at the headline
+// size (62 500 nodes per launch): 1 node 32.2 us, 2 nodes 33.9 us -- the gathers, not the latency of the chain, set the pace.
+constexpr int kLvPerWave = 1;
+template <bool W32>
 __global__ void __launch_bounds__(256) k_lv_sweep(const int64_t* __restrict__ indptr, const int32_t* __restrict__ cols,
                                                   const int64_t* __restrict__ wq, const int64_t* __restrict__ K,
                                                   const int32_t* __restrict__ comm, const unsigned long long* __restrict__ tot,
                                                   const int32_t* __restrict__ size, int64_t n, double gamma, double m2d,
                                                   int first, int step, int32_t* __restrict__ next) {
+    typedef typename std::conditional<W32, uint32_t, int64_t>::type acc_t;
+    constexpr int NV = kLvPerWave;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t v = first + (int64_t)step * ((int64_t)blockIdx.x * 4 + wave);
-    if (v >= n) return;
-    const int64_t b = indptr[v];
-    const int deg = (int)(indptr[v + 1] - b);
-    if (deg > 64) return;                            // k_lv_sweep_big's
-    const int32_t own = comm[v];
-    const int64_t kvi = K[v];
-    const double kv = (double)kvi;
-    double best_s = 0.0;
-    int32_t best_c = -1;
-    int64_t w_own = 0;
-    int32_t c = -1;
-    int64_t w = 0;
-    if (lane < deg) {
-        const int32_t u = cols[b + lane];
-        w = wq[b + lane];
-        c = (u == (int32_t)v) ? -1 : comm[u];
+    const int64_t slot0 = ((int64_t)blockIdx.x * 4 + wave) * NV;
+    int64_t v[NV], b[NV], kvi[NV];
+    int deg[NV];
+    int32_t own[NV], c[NV], size_own[NV], size_c[NV];
+    unsigned long long tot_own[NV], tot_c[NV];
+    acc_t w[NV];
+    bool live[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        v[i] = first + (int64_t)step * (slot0 + i);
+        live[i] = v[i] < n;
+        const int64_t vv = live[i] ? v[i] : 0;
+        b[i] = indptr[vv];
+        deg[i] = (int)(indptr[vv + 1] - b[i]);
+        own[i] = comm[vv];
+        kvi[i] = K[vv];
+        live[i] = live[i] && deg[i] <= 64;          // (the others are k_lv_sweep_big's)
     }
-    int64_t W = 0;
-    bool leader = c >= 0;
-    for (int j = 0; j < deg; ++j) {
-        const int32_t cj = __shfl(c, j, 64);
-        const int64_t wj = shfl64(w, j);
-        if (cj == c) {
-            W += wj;
-            if (j < lane) leader = false;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        tot_own[i] = tot[own[i]];
+        size_own[i] = size[own[i]];
+        c[i] = -1;
+        w[i] = 0;
+        if (live[i] && lane < deg[i]) {
+            const int32_t u = cols[b[i] + lane];
+            w[i] = (acc_t)wq[b[i] + lane];
+            c[i] = (u == (int32_t)v[i]) ? -1 : comm[u];
         }
-        if (cj == own) w_own += wj;
     }
-    if (leader && c != own) {
-        best_s = (double)W * m2d - (gamma * (double)(int64_t)tot[c]) * kv;
-        best_c = c;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        tot_c[i] = c[i] >= 0 ? tot[c[i]] : 0ull;
+        size_c[i] = c[i] >= 0 ? size[c[i]] : 0;
     }
-    wave_best(best_s, best_c);
-    if (lane == 0) {
-        const double own_score = (double)w_own * m2d - (gamma * (double)((int64_t)tot[own] - kvi)) * kv;
-        int32_t target = own;
-        if (best_c >= 0 && best_s > own_score && !(size[own] == 1 && size[best_c] == 1 && best_c > own)) target = best_c;
-        next[v] = target;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        if (!live[i]) continue;                      // (wave-uniform)
+        const double kv = (double)kvi[i];
+        acc_t W = 0;
+        for (int j = 0; j < deg[i]; ++j) {
+            const int32_t cj = __builtin_amdgcn_readlane(c[i], j);
+            acc_t wj;
+            if (W32) wj = (acc_t)__builtin_amdgcn_readlane((int)w[i], j);
+            else wj = (acc_t)(((int64_t)__builtin_amdgcn_readlane((int)((int64_t)w[i] >> 32), j) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(int64_t)w[i], j));
+            W += (cj == c[i]) ? wj : (acc_t)0;
+        }
+        double best_s = 0.0;
+        int32_t best_c = -1;
+        if (c[i] >= 0 && c[i] != own[i]) {
+            best_s = (double)(int64_t)W * m2d - (gamma * (double)(int64_t)tot_c[i]) * kv;
+            best_c = c[i];
+        }
+        const unsigned long long own_lanes = __ballot(c[i] == own[i]);      // (own >= 0; the self loop carries c = -1)
+        int64_t w_own = 0;
+        if (own_lanes) {
+            const int src = __ffsll((long long)own_lanes) - 1;
+            if (W32) w_own = (int64_t)(uint32_t)__shfl((int)W, src, 64);
+            else w_own = shfl64((int64_t)W, src);
+        }
+        wave_best(best_s, best_c);
+        int32_t size_best = 0;
+        if (best_c >= 0) size_best = __shfl(size_c[i], __ffsll((long long)__ballot(c[i] == best_c)) - 1, 64);
+        if (lane == 0) {
+            const double own_score = (double)w_own * m2d - (gamma * (double)((int64_t)tot_own[i] - kvi[i])) * kv;
+            int32_t target = own[i];
+            if (best_c >= 0 && best_s > own_score && !(size_own[i] == 1 && size_best == 1 && best_c > own[i])) target = best_c;
+            next[v[i]] = target;
+        }
     }
 }
 
@@ -322,7 +367,7 @@ constexpr int kSubrounds = DDX_SUBROUNDS;
 // them and their share of the totals.  (A sweep that moves nothing changes nothing, so running all of them equals the
 // specification's early stop.)
 static int lv_sweeps(ddx_ctx* ctx, const LvGraph& in, const int64_t* wq, const int64_t* K, double gamma, int32_t sweeps, int subrounds,
-                     const LvScratch& sc, int64_t m2, const int32_t* big_list, int32_t nbig, int32_t maxdeg) {
+                     const LvScratch& sc, int64_t m2, const int32_t* big_list, int32_t nbig, int32_t maxdeg, bool narrow) {
     const int64_t n = in.n;
     hipStream_t st = ctx->stream;
     if (sweeps <= 0 || m2 <= 0) return DDX_OK;
@@ -335,7 +380,10 @@ static int lv_sweeps(ddx_ctx* ctx, const LvGraph& in, const int64_t* wq, const i
             const int first = ((r - s) % subrounds + subrounds) % subrounds;
             const int64_t cnt = first < n ? (n - first + subrounds - 1) / subrounds : 0;      // nodes of this class
             if (cnt <= 0) continue;
-            k_lv_sweep<<<(unsigned)ceil_div(cnt, 4), 256, 0, st>>>(in.indptr, in.cols, wq, K, sc.comm, sc.tot, sc.size, n, gamma, (double)m2, first, subrounds, sc.next);
+            if (narrow)
+                k_lv_sweep<true><<<(unsigned)ceil_div(cnt, 4 * kLvPerWave), 256, 0, st>>>(in.indptr, in.cols, wq, K, sc.comm, sc.tot, sc.size, n, gamma, (double)m2, first, subrounds, sc.next);
+            else
+                k_lv_sweep<false><<<(unsigned)ceil_div(cnt, 4 * kLvPerWave), 256, 0, st>>>(in.indptr, in.cols, wq, K, sc.comm, sc.tot, sc.size, n, gamma, (double)m2, first, subrounds, sc.next);
             if (nbig > 0)
                 k_lv_sweep_big<<<(unsigned)nbig, 64, big_lds, st>>>(in.indptr, in.cols, wq, K, sc.comm, sc.tot, sc.size, gamma, (double)m2, first, subrounds,
                                                                     big_list, slots, sc.next);
@@ -357,21 +405,22 @@ __global__ void k_lv_carry(const int32_t* __restrict__ used, const int32_t* __re
 
 // one level: `sweeps` synchronous sweeps on `in`, exact aggregation into (member, out)
 static int coarsen_level(ddx_ctx* ctx, const LvGraph& in, double gamma, int32_t sweeps, const LvScratch& sc, int64_t* wq, int64_t* K, int32_t* csize,
-                         int32_t* big_list, int64_t& m2_out, int32_t& maxdeg_out, int32_t& nbig_out, int32_t* member, int64_t* c_indptr, int32_t* c_cols, double* c_w, LvGraph& out) {
+                         int32_t* big_list, int64_t& m2_out, int32_t& maxdeg_out, int32_t& nbig_out, bool& narrow_out, int32_t* member, int64_t* c_indptr, int32_t* c_cols, double* c_w, LvGraph& out) {
     const int64_t n = in.n, E = in.E;
     hipStream_t st = ctx->stream;
     DDX_HIP(ctx, hipMemsetAsync(sc.scal, 0, 256, st));
     if (E > 0) k_lv_quantise<<<(unsigned)ceil_div(E, 256), 256, 0, st>>>(in.w, E, wq);
     k_lv_strength<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(in.indptr, wq, n, K, sc.comm, sc.tot, sc.size, sc.scal, big_list);
-    unsigned long long h_scal[2] = {0, 0};
+    unsigned long long h_scal[4] = {0, 0, 0, 0};
     DDX_HIP(ctx, hipMemcpyAsync(h_scal, sc.scal, sizeof(h_scal), hipMemcpyDeviceToHost, st));
     DDX_HIP(ctx, hipStreamSynchronize(st));
     const int64_t m2 = (int64_t)h_scal[0];
     const int32_t maxdeg = (int32_t)(h_scal[1] & 0xffffffffull);
     const int32_t nbig = (int32_t)(h_scal[1] >> 32);
     if (maxdeg > kLvCap) return set_err(ctx, DDX_E_UNSUPPORTED, "a node with %d neighbours exceeds the device sweep's capacity (%d)", maxdeg, kLvCap);
-    m2_out = m2; maxdeg_out = maxdeg; nbig_out = nbig;
-    DDX_TRY(lv_sweeps(ctx, in, wq, K, gamma, sweeps, kSubrounds, sc, m2, big_list, nbig, maxdeg));
+    const bool narrow = h_scal[3] < (1ull << 25);      // 64 such weights sum below 2^31: the register sweep adds them in 32 bits
+    m2_out = m2; maxdeg_out = maxdeg; nbig_out = nbig; narrow_out = narrow;
+    DDX_TRY(lv_sweeps(ctx, in, wq, K, gamma, sweeps, kSubrounds, sc, m2, big_list, nbig, maxdeg, narrow));
     const int32_t* cur = sc.comm;
     // renumber the surviving communities by ascending id
     DDX_HIP(ctx, hipMemsetAsync(sc.used, 0, sizeof(int32_t) * (n + 1), st));
@@ -450,10 +499,11 @@ int stage_coarsen_graph(ddx_ctx* ctx, double gamma, int32_t sweeps, int32_t leve
         }
         int64_t m2 = 0;
         int32_t maxdeg = 0, nbig = 0;
-        DDX_TRY(coarsen_level(ctx, cur, gamma, sweeps, sc, sc.wq[keep], sc.K[keep], sc.csize[keep], sc.big[keep], m2, maxdeg, nbig, sets.member[o],
+        bool narrow = false;
+        DDX_TRY(coarsen_level(ctx, cur, gamma, sweeps, sc, sc.wq[keep], sc.K[keep], sc.csize[keep], sc.big[keep], m2, maxdeg, nbig, narrow, sets.member[o],
                               sets.indptr[o], sets.cols[o], sets.w[o], nextg));
         if (lvl == 0) ctx->lv_m2 = m2;
-        if (lvl < kLvKeep) { ctx->lv_maxdeg[lvl] = maxdeg; ctx->lv_nbig[lvl] = nbig; }
+        if (lvl < kLvKeep) { ctx->lv_maxdeg[lvl] = maxdeg; ctx->lv_nbig[lvl] = nbig; ctx->lv_narrow[lvl] = narrow; }
         if (!total) {
             total = sets.member[o];
         } else {
@@ -533,7 +583,7 @@ int stage_refine_communities(ddx_ctx* ctx, const int32_t* coarse_labels, double 
         DDX_HIP(ctx, hipMemsetAsync(sc.size, 0, sizeof(int32_t) * nc, st));
         k_lv_level_sizes<<<(unsigned)ceil_div(n_up, 256), 256, 0, st>>>(sc.lab, sc.csize[level], n_up, sc.size);
         k_lv_project<<<(unsigned)ceil_div(g.n, 256), 256, 0, st>>>(ctx->lv_member[level], sc.lab, g.n, sc.comm);
-        DDX_TRY(lv_sweeps(ctx, g, sc.wq[level], sc.K[level], gamma, sweeps, kSubrounds, sc, ctx->lv_m2, sc.big[level], ctx->lv_nbig[level], ctx->lv_maxdeg[level]));
+        DDX_TRY(lv_sweeps(ctx, g, sc.wq[level], sc.K[level], gamma, sweeps, kSubrounds, sc, ctx->lv_m2, sc.big[level], ctx->lv_nbig[level], ctx->lv_maxdeg[level], ctx->lv_narrow[level]));
         if (level > 0) DDX_HIP(ctx, hipMemcpyAsync(sc.lab, sc.comm, sizeof(int32_t) * g.n, hipMemcpyDeviceToDevice, st));
         else DDX_HIP(ctx, hipMemcpyAsync(labels_out, sc.comm, sizeof(int32_t) * g.n, hipMemcpyDeviceToHost, st));
         n_up = g.n;
