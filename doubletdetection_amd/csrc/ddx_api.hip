@@ -5,6 +5,7 @@
 #include <unistd.h>
 #include <mutex>
 #include <new>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <thread>
@@ -148,7 +149,8 @@ void Options::read_environment() {
     row_sums_sequential = getenv("DDX_ROW_SUMS_SEQUENTIAL") != nullptr;
     knn_debug = getenv("DDX_KNN_DEBUG") != nullptr;
     upload_packed = !is(getenv("DDX_UPLOAD"), "plain");
-    upload_wait = is(getenv("DDX_UPLOAD"), "packed");
+    upload_form16 = !is(getenv("DDX_UPLOAD"), "packed32");
+    upload_wait = is(getenv("DDX_UPLOAD"), "packed") || is(getenv("DDX_UPLOAD"), "packed32");
     mirror_mode = is(getenv("DDX_MIRROR"), "sort") ? 0 : (is(getenv("DDX_MIRROR"), "scatter") ? 1 : 2);
     g = getenv("DDX_ARENA_GUARD");
     arena_guard = g && g[0] != '0' && g[0] != 0;
@@ -360,17 +362,64 @@ static int check_csr(ddx_ctx* ctx, int64_t n, int32_t g, const int64_t* indptr, 
 
 // ---- packed upload of the raw matrix ---------------------------------------------------------------------------------
 // dd.py:149-160 hands fit() a host matrix; its 8 bytes per stored entry (int32 column, float32 count) are what the PCIe
-// link carries at 54 GB/s -- 14 ms of a 210 ms fit.  Counts are small non-negative integers and there are fewer than 65 536
-// genes in practice: host threads pack an entry into 4 bytes (column | count << 16) straight into pinned memory, chunk by
-// chunk, while the previous chunk is on the link; a kernel expands every chunk on arrival.  Any entry that does not fit
-// (fractional, negative, >= 65 536, NaN) makes the whole call fall back to the plain copies -- the result is the same
-// device matrix bit for bit either way.
+// link carries at 57 GB/s -- 14 ms of a 210 ms fit.  Counts are small non-negative integers and columns ascend inside a
+// row by small steps (30 000 genes / 950 entries per row): host threads pack an entry into 2 bytes,
+//     step to the previous column of the row (1..255; the first entry steps from column -1) | count << 8 (0..255),
+// straight into pinned memory, chunk by chunk, while the previous chunk is on the link.  An entry that does not fit
+// (a longer step, a column order the validation will reject, a count that is fractional, negative, > 255, NaN, -0.0)
+// gets the code 0 and travels whole in a side list of (position, column, value) triples, so ANY matrix arrives bit for
+// bit; a matrix with more than one such entry in 32 is sent plain.  One kernel expands the rows once the last chunk is
+// there (a wave per row: prefix sum of the steps, restarted at the listed entries).  DDX_UPLOAD=packed32 selects the
+// first version of the scheme, column | count << 16 in 4 bytes, expanded chunk by chunk on arrival; there an entry that
+// does not fit (count >= 65 536, fractional, ...) makes the whole call fall back to the plain copies.
 __global__ void k_expand_packed(const uint32_t* __restrict__ packed, int64_t n, int32_t* __restrict__ idx, float* __restrict__ val) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     const uint32_t p = packed[t];
     idx[t] = (int32_t)(p & 0xffffu);
     val[t] = (float)(p >> 16);
+}
+
+// 2-byte form -> (column, value) arrays, one wave per row.  esc_pos ascends; an entry with code 0 is looked up there.
+__global__ void __launch_bounds__(256) k_expand_packed16(const uint16_t* __restrict__ code, const int64_t* __restrict__ indptr, int64_t n_rows,
+                                                         const int32_t* __restrict__ esc_pos, const int32_t* __restrict__ esc_col,
+                                                         const float* __restrict__ esc_val, int32_t n_esc,
+                                                         int32_t* __restrict__ idx, float* __restrict__ val) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const int64_t b = indptr[row], e = indptr[row + 1];
+    int32_t carry = -1;                                   // column of the entry before the block
+    for (int64_t base = b; base < e; base += 64) {
+        const int64_t i = base + lane;
+        const bool in = i < e;
+        const uint32_t c = in ? code[i] : 256u;          // (a lane past the end: count 1, step 0 -> adds nothing, listed nowhere)
+        const bool esc = in && (c & 255u) == 0u;
+        int32_t abs_col = 0;
+        float v = (float)(c >> 8);
+        if (esc) {
+            int lo = 0, hi = n_esc;                      // first listed position >= i (it is there)
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (esc_pos[mid] < (int32_t)i) lo = mid + 1; else hi = mid;
+            }
+            abs_col = esc_col[lo];
+            v = esc_val[lo];
+        }
+        int32_t s = esc ? 0 : (int32_t)(c & 255u);       // inclusive prefix sum of the steps
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int32_t t = __shfl_up(s, off, 64);
+            if (lane >= off) s += t;
+        }
+        const unsigned long long listed = __ballot(esc);
+        const unsigned long long upto = listed & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+        const int r = upto ? 63 - __clzll((long long)upto) : 0;
+        const int32_t col_r = __shfl(abs_col, r, 64), s_r = __shfl(s, r, 64);
+        const int32_t col = upto ? col_r + (s - s_r) : carry + s;
+        if (in) { idx[i] = col; val[i] = v; }
+        carry = __shfl(col, 63, 64);                      // (lanes past the end repeat the last column: step 0)
+    }
 }
 
 // host threads of the packed upload: created once per process, parked between calls (spawning 48 threads costs ~3 ms)
@@ -465,13 +514,57 @@ WorkerPool* upload_pool() {
 }
 }  // namespace
 
+struct PackEsc { int32_t pos, col; float val; };
+
+// entries [a, b) of the matrix -> 2-byte codes; entries that do not fit are appended to `esc` (ascending positions).
+// Rows are taken one at a time: the first entry of a row steps from column -1, the others from their predecessor, which
+// leaves a branch-free inner loop the compiler turns into vector code.
+#define DDX_PACK16_BODY                                                                                                          \
+    int64_t row = std::upper_bound(indptr, indptr + n_rows + 1, a) - indptr - 1;                                                 \
+    for (int64_t i = a; i < b;) {                                                                                                \
+        while (indptr[row + 1] <= i) ++row;                                                                                      \
+        const int64_t e = std::min(b, indptr[row + 1]);                                                                          \
+        const int64_t s = i;                                                                                                     \
+        uint32_t any = 0;                                                                                                        \
+        if (i == indptr[row]) {                                                                                                  \
+            any |= pack16_one((uint32_t)idx[i] + 1u, val[i], out + i);                                                           \
+            ++i;                                                                                                                 \
+        }                                                                                                                        \
+        for (; i < e; ++i) any |= pack16_one((uint32_t)idx[i] - (uint32_t)idx[i - 1], val[i], out + i);                          \
+        if (any)                                                                                                                 \
+            for (int64_t t = s; t < e; ++t)                                                                                      \
+                if (out[t] == 0) esc.push_back({(int32_t)t, idx[t], val[t]});                                                    \
+    }
+
+static inline uint32_t pack16_one(uint32_t step, float v, uint16_t* out) {
+    uint32_t bits;
+    memcpy(&bits, &v, 4);
+    const bool range = (v >= 0.0f) & (v <= 255.0f);                       // (false for NaN)
+    const int32_t c = (int32_t)(range ? v : 0.0f);
+    const bool ok = range & ((float)c == v) & (bits != 0x80000000u) & (step - 1u < 255u);
+    *out = ok ? (uint16_t)(step | ((uint32_t)c << 8)) : (uint16_t)0;
+    return ok ? 0u : 1u;
+}
+static void pack16_generic(const int64_t* indptr, int64_t n_rows, const int32_t* idx, const float* val, int64_t a, int64_t b, uint16_t* out,
+                           std::vector<PackEsc>& esc) {
+    DDX_PACK16_BODY
+}
+__attribute__((target("avx2"))) static void pack16_avx2(const int64_t* indptr, int64_t n_rows, const int32_t* idx, const float* val, int64_t a,
+                                                       int64_t b, uint16_t* out, std::vector<PackEsc>& esc) {
+    DDX_PACK16_BODY
+}
+
 // DDX_OK: the matrix is on the device; 1: not applicable (caller sends it plain)
-static int upload_packed(ddx_ctx* ctx, int64_t nnz, int32_t n_genes, const int32_t* indices, const float* data) {
-    if (n_genes > 65536 || nnz < ((int64_t)1 << 20) || nnz > ((int64_t)384 << 20)) return 1;
+static int upload_packed(ddx_ctx* ctx, int64_t n_cells, int64_t nnz, int32_t n_genes, const int64_t* indptr, const int32_t* indices,
+                         const float* data) {
+    const bool f16 = ctx->opt.upload_form16;
+    if ((!f16 && n_genes > 65536) || nnz < ((int64_t)1 << 20) || nnz > ((int64_t)384 << 20)) return 1;
     // 16 chunks: the first is on the link 0.6 ms after the call, the copies then follow each other on their own stream
     const int64_t chunk = std::max<int64_t>((nnz + 15) / 16, (int64_t)1 << 18);
     const int64_t nchunks = (nnz + chunk - 1) / chunk;
-    const size_t need = sizeof(uint32_t) * (size_t)nnz;
+    const size_t esz = f16 ? sizeof(uint16_t) : sizeof(uint32_t);
+    const size_t need = esz * (size_t)nnz;
+    const int64_t esc_cap = f16 ? nnz / 32 + 1 : 0;      // listed entries the device buffer has room for
     // one packed upload at a time: a second context staging at the same moment (several GPUs driven by one process)
     // sends its copy plain, in parallel, instead of queueing behind this one
     std::unique_lock<std::mutex> pool_lock(g_pool_mutex, std::try_to_lock);
@@ -501,31 +594,47 @@ static int upload_packed(ddx_ctx* ctx, int64_t nnz, int32_t n_genes, const int32
         }
     }
     if (!ctx->copy_stream && hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); ctx->copy_stream = nullptr; return 1; }
-    DDX_TRY(ensure(ctx, ctx->raw_packed, need));
-    uint32_t* pin = static_cast<uint32_t*>(g_pin_buf);
+    // device: the codes, then (2-byte form) room for the listed entries: positions | columns | values
+    const size_t codes_bytes = (need + 255) & ~(size_t)255;
+    DDX_TRY(ensure(ctx, ctx->raw_packed, codes_bytes + 12 * (size_t)esc_cap));
+    unsigned char* pin = static_cast<unsigned char*>(g_pin_buf);
     WorkerPool* pool = upload_pool();
     const int T = pool->size();
     std::vector<std::atomic<int>> done(nchunks);
     for (auto& d : done) d.store(0);
     std::atomic<int> bad{0};
+    std::atomic<int64_t> n_listed{0};
+    std::vector<std::vector<PackEsc>> listed(f16 ? (size_t)nchunks * T : 0);     // [chunk][thread]: ascending positions in that order
+    const bool avx2 = __builtin_cpu_supports("avx2");
     const std::function<void(int)> worker = [&](int w) {
         for (int64_t k = 0; k < nchunks; ++k) {
             if (bad.load(std::memory_order_relaxed)) return;
             const int64_t c0 = k * chunk, c1 = std::min(nnz, c0 + chunk), len = c1 - c0;
             const int64_t a = c0 + len * w / T, b = c0 + len * (w + 1) / T;
-            bool ok = true;
-            for (int64_t i = a; i < b; ++i) {
-                const float v = data[i];
-                const uint32_t iv = (uint32_t)(int32_t)v;                    // (garbage for NaN / huge values: caught by the comparison)
-                const uint32_t j = (uint32_t)indices[i];
-                ok = ok && (float)iv == v && iv < 65536u && j < 65536u && !(iv == 0u && std::signbit(v));   // (-0.0 would come back as +0.0)
-                pin[i] = j | (iv << 16);
+            if (f16) {
+                std::vector<PackEsc>& mine = listed[(size_t)k * T + w];
+                if (avx2) pack16_avx2(indptr, n_cells, indices, data, a, b, reinterpret_cast<uint16_t*>(pin), mine);
+                else pack16_generic(indptr, n_cells, indices, data, a, b, reinterpret_cast<uint16_t*>(pin), mine);
+                if (!mine.empty() && n_listed.fetch_add((int64_t)mine.size()) + (int64_t)mine.size() > esc_cap) { bad.store(1); return; }
+            } else {
+                uint32_t* out = reinterpret_cast<uint32_t*>(pin);
+                bool ok = true;
+                for (int64_t i = a; i < b; ++i) {
+                    const float v = data[i];
+                    const uint32_t iv = (uint32_t)(int32_t)v;                    // (garbage for NaN / huge values: caught by the comparison)
+                    const uint32_t j = (uint32_t)indices[i];
+                    ok = ok && (float)iv == v && iv < 65536u && j < 65536u && !(iv == 0u && std::signbit(v));   // (-0.0 would come back as +0.0)
+                    out[i] = j | (iv << 16);
+                }
+                if (!ok) { bad.store(1); return; }
             }
-            if (!ok) { bad.store(1); return; }
             done[k].fetch_add(1, std::memory_order_release);
         }
     };
     // the copies must not overtake whatever the main stream still does with the device buffers
+    const bool dbg = getenv("DDX_UPLOAD_DEBUG") != nullptr;
+    auto clk = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_in = clk();
     (void)hipStreamSynchronize(ctx->stream);
     pool->start(worker);
     std::vector<hipEvent_t> ev(nchunks, nullptr);
@@ -534,19 +643,57 @@ static int upload_packed(ddx_ctx* ctx, int64_t nnz, int32_t n_genes, const int32
         while (done[k].load(std::memory_order_acquire) < T && !bad.load()) std::this_thread::yield();
         if (bad.load()) { rc = 1; break; }
         const int64_t c0 = k * chunk, len = std::min(nnz, c0 + chunk) - c0;
-        uint32_t* dev = ctx->raw_packed.as<uint32_t>() + c0;
-        if (hipMemcpyAsync(dev, pin + c0, sizeof(uint32_t) * len, hipMemcpyHostToDevice, ctx->copy_stream) != hipSuccess ||
+        unsigned char* dev = ctx->raw_packed.as<unsigned char>() + esz * c0;
+        if (dbg && getenv("DDX_UPLOAD_DEBUG")[0] == '2') fprintf(stderr, "[ddx upload] chunk %lld packed +%.2f ms\n", (long long)k, clk() - t_in);
+        if (hipMemcpyAsync(dev, pin + esz * c0, esz * len, hipMemcpyHostToDevice, ctx->copy_stream) != hipSuccess ||
             hipEventCreateWithFlags(&ev[k], hipEventDisableTiming) != hipSuccess || hipEventRecord(ev[k], ctx->copy_stream) != hipSuccess ||
             hipStreamWaitEvent(ctx->stream, ev[k], 0) != hipSuccess) { rc = DDX_E_HIP; break; }
-        k_expand_packed<<<(unsigned)((len + 255) / 256), 256, 0, ctx->stream>>>(dev, len, ctx->raw_indices.as<int32_t>() + c0, ctx->raw_data.as<float>() + c0);
+        if (!f16)
+            k_expand_packed<<<(unsigned)((len + 255) / 256), 256, 0, ctx->stream>>>(reinterpret_cast<const uint32_t*>(dev), len, ctx->raw_indices.as<int32_t>() + c0,
+                                                                                    ctx->raw_data.as<float>() + c0);
     }
     if (rc != DDX_OK) bad.store(1);
+    const double t_issued = clk();
+    if (dbg && getenv("DDX_UPLOAD_DEBUG")[0] == '2') {
+        for (int64_t k = 0; k < nchunks; ++k)
+            if (ev[k]) { (void)hipEventSynchronize(ev[k]); fprintf(stderr, "[ddx upload] chunk %lld landed +%.2f ms\n", (long long)k, clk() - t_in); }
+    }
     pool->wait();
+    if (rc == DDX_OK && bad.load()) rc = 1;
+    std::vector<int32_t> pos, col;                        // (alive until the stream has taken them: the synchronisation below)
+    std::vector<float> val;
+    if (rc == DDX_OK && f16) {
+        // the listed entries, in ascending position ([chunk][thread] order), then one expansion of all rows (the stream waits
+        // for every chunk: the events above; raw_indptr went ahead on the same stream)
+        const int64_t n_esc = n_listed.load();
+        pos.resize((size_t)n_esc); col.resize((size_t)n_esc); val.resize((size_t)n_esc);
+        size_t t = 0;
+        for (const auto& part : listed)
+            for (const PackEsc& x : part) { pos[t] = x.pos; col[t] = x.col; val[t] = x.val; ++t; }
+        unsigned char* side = ctx->raw_packed.as<unsigned char>() + codes_bytes;
+        int32_t* d_pos = reinterpret_cast<int32_t*>(side);
+        int32_t* d_col = d_pos + esc_cap;
+        float* d_val = reinterpret_cast<float*>(d_col + esc_cap);
+        if (n_esc) {
+            if (hipMemcpyAsync(d_pos, pos.data(), 4 * (size_t)n_esc, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+                hipMemcpyAsync(d_col, col.data(), 4 * (size_t)n_esc, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+                hipMemcpyAsync(d_val, val.data(), 4 * (size_t)n_esc, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = DDX_E_HIP;
+        }
+        if (rc == DDX_OK)
+            k_expand_packed16<<<(unsigned)((n_cells + 3) / 4), 256, 0, ctx->stream>>>(ctx->raw_packed.as<uint16_t>(), ctx->raw_indptr.as<int64_t>(), n_cells, d_pos, d_col,
+                                                                                      d_val, (int32_t)n_esc, ctx->raw_indices.as<int32_t>(), ctx->raw_data.as<float>());
+        if (dbg) fprintf(stderr, "[ddx upload] %lld of %lld entries listed\n", (long long)n_esc, (long long)nnz);
+    }
+    const double t_packed = clk();
     (void)hipStreamSynchronize(ctx->copy_stream);
-    (void)hipStreamSynchronize(ctx->stream);                                   // (the pinned buffer is reused by the next call)
+    const double t_copied = clk();
+    (void)hipStreamSynchronize(ctx->stream);                                   // (the pinned buffer and the host lists are reused / freed)
+    if (dbg)
+        fprintf(stderr, "[ddx upload] %d-byte form, %d threads, %lld chunks: last copy issued +%.2f ms, packing joined +%.2f, copies done +%.2f, expanded +%.2f\n",
+                (int)esz, T, (long long)nchunks, t_issued - t_in, t_packed - t_in, t_copied - t_in, clk() - t_in);
     for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
     if (rc == DDX_E_HIP) return set_err(ctx, DDX_E_HIP, "packed upload failed");
-    if (rc != DDX_OK) release(ctx, ctx->raw_packed);      // not a packable matrix: the caller sends it plain, the 4 bytes per entry go back
+    if (rc != DDX_OK) release(ctx, ctx->raw_packed);      // not a packable matrix: the caller sends it plain, the packed bytes go back
     return rc;
 }
 
@@ -573,7 +720,7 @@ int ddx_upload_raw(ddx_ctx* ctx, int64_t n_cells, int32_t n_genes, const int64_t
     DDX_HIP(ctx, hipMemcpyAsync(ctx->raw_indptr.p, indptr, sizeof(int64_t) * (n_cells + 1), hipMemcpyHostToDevice,
                                 ctx->stream));
     if (nnz) {
-        int packed = ctx->opt.upload_packed ? upload_packed(ctx, nnz, n_genes, indices, data) : 1;
+        int packed = ctx->opt.upload_packed ? upload_packed(ctx, n_cells, nnz, n_genes, indptr, indices, data) : 1;
         if (packed < 0) return packed;
         if (packed != DDX_OK) {
             DDX_HIP(ctx, hipMemcpyAsync(ctx->raw_indices.p, indices, sizeof(int32_t) * nnz, hipMemcpyHostToDevice,

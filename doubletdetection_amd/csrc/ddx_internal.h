@@ -53,8 +53,9 @@ struct Options {
     bool row_sums_sequential = false;
     bool knn_debug = false;
     int mirror_mode = 2;             // column-major mirror: 2 counting sort placed by LDS tiles, 1 (DDX_MIRROR=scatter) counting sort with scattered stores, 0 (DDX_MIRROR=sort) radix sort
-    bool upload_packed = true;       // DDX_UPLOAD=plain: send the raw matrix as it is (8 bytes per entry) instead of packed (4)
-    bool upload_wait = false;        // DDX_UPLOAD=packed: wait for the pinned staging buffer instead of sending the first matrix plain (tests)
+    bool upload_packed = true;       // DDX_UPLOAD=plain: send the raw matrix as it is (8 bytes per entry) instead of packed
+    bool upload_form16 = true;       // DDX_UPLOAD=packed32: column | count << 16 (4 bytes per entry) instead of column step | count << 8 (2 bytes)
+    bool upload_wait = false;        // DDX_UPLOAD=packed / packed32: wait for the pinned staging buffer instead of sending the first matrix plain (tests)
     bool arena_guard = false;        // DDX_ARENA_GUARD=1: pattern-fill the pad behind every block, ddx_check_memory verifies it
     int knn_ablation = 0;            // only honoured under DDX_ABLATION
     void read_environment();

@@ -803,41 +803,73 @@ def test_greedy_memory_chunk_falls_back_without_leaving_an_error_behind():
 
 
 def test_packed_upload_equals_plain_upload(monkeypatch):
-    """dd.py:149-160 (the matrix handed to fit()).  The raw matrix travels packed (column | count << 16, 4 bytes per entry,
-    host threads + pinned chunks) when every count is an integer below 65 536 and there are at most 65 536 genes, plain
-    otherwise; both leave the same device matrix."""
+    """dd.py:149-160 (the matrix handed to fit()).  The raw matrix travels packed -- by default 2 bytes per entry (step from the
+    row's previous column | count << 8; entries that do not fit that are listed whole beside the codes), with
+    DDX_UPLOAD=packed32 4 bytes (column | count << 16; falls back to plain copies when a count does not fit) -- or plain;
+    all three leave the same device matrix, whatever the values."""
     from doubletdetection_amd import _lib
     from doubletdetection_amd._synthetic import make_counts
 
-    counts = make_counts(60_000, 3000, density=0.02, seed=4)            # > 2^20 stored entries: the packed path applies
-    counts.data[::1001] = 40_000.0                                        # large but representable counts
+    counts = make_counts(60_000, 3000, density=0.02, seed=4)            # > 2^20 stored entries: the packed paths apply
+    counts.data[::1001] = 40_000.0                                        # large but representable counts (listed / 4-byte form)
     assert counts.nnz > (1 << 20)
 
-    def restricted(env, mat):
+    def device_matrix(env, mat, columns=None):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         c = _lib.Context(0)
         try:
             c.upload_raw(mat)
             var = c.gene_variances()
-            c.select_columns(np.sort(np.argsort(var)[-500:]))
-            return var, c.get_counts()
+            c.select_columns(np.sort(np.argsort(var)[-500:]) if columns is None else columns)
+            return var, sp.csr_matrix(c.get_counts())
         finally:
             c.close()
             for k in env:
                 monkeypatch.delenv(k, raising=False)
 
-    # (DDX_UPLOAD=packed waits for the pinned staging buffer; by default the first matrix of a process travels plain
-    # while the buffer is being pinned in the background)
-    var_p, sub_p = restricted({"DDX_UPLOAD": "packed"}, counts)
-    var_q, sub_q = restricted({"DDX_UPLOAD": "plain"}, counts)
-    np.testing.assert_array_equal(var_p, var_q)
-    _same_csr(sub_p, sub_q)
-    # entries the packed form cannot hold (fractional, >= 65 536): the call falls back to the plain copies
+    # (DDX_UPLOAD=packed / packed32 wait for the pinned staging buffer; by default the first matrix of a process travels
+    # plain while the buffer is being pinned in the background)
+    var_q, sub_q = device_matrix({"DDX_UPLOAD": "plain"}, counts)
+    for form in ("packed", "packed32"):
+        var_p, sub_p = device_matrix({"DDX_UPLOAD": form}, counts)
+        np.testing.assert_array_equal(var_p, var_q)
+        _same_csr(sub_p, sub_q)
+    # entries neither code can hold (fractional, >= 65 536, 256), long column steps, empty rows, a row whose only column
+    # is the last one: the 2-byte form lists them, the 4-byte form falls back to the plain copies
     odd = counts.copy()
     odd.data[5] = 2.5
     odd.data[77] = 70_000.0
-    var_f, sub_f = restricted({"DDX_UPLOAD": "packed"}, odd)
-    var_g, sub_g = restricted({"DDX_UPLOAD": "plain"}, odd)
-    np.testing.assert_array_equal(var_f, var_g)
-    _same_csr(sub_f, sub_g)
+    odd.data[4321] = 255.0
+    odd.data[4322] = 256.0
+    odd.data[-3] = -0.0                                                   # a stored negative zero keeps its sign bit
+    lil = odd[:2000].tolil()
+    lil[7, :] = 0
+    lil[8, :] = 0
+    lil[8, 2999] = 3.0
+    odd = sp.vstack([lil.tocsr(), odd[2000:]]).tocsr().astype(np.float32)
+    odd.sort_indices()
+    assert odd.indptr[8] == odd.indptr[7] and odd.indptr[9] == odd.indptr[8] + 1
+    everything = np.arange(odd.shape[1])
+    var_g, all_g = device_matrix({"DDX_UPLOAD": "plain"}, odd, everything)
+    for form in ("packed", "packed32"):
+        var_f, all_f = device_matrix({"DDX_UPLOAD": form}, odd, everything)
+        np.testing.assert_array_equal(var_f, var_g)
+        _same_csr(all_f, all_g)
+    # the whole matrix came back: it is the caller's, sign bits included
+    _same_csr(all_g, odd)
+    assert np.array_equal(all_f.data.view(np.uint32), odd.data.view(np.uint32))
+    # a matrix the validation rejects is rejected the same way on every route (it arrives as it is)
+    broken = counts.copy()
+    row = int(np.argmax(np.diff(broken.indptr) > 3))
+    p0 = broken.indptr[row]
+    broken.indices[p0], broken.indices[p0 + 1] = broken.indices[p0 + 1], broken.indices[p0]
+    for form in ("plain", "packed", "packed32"):
+        monkeypatch.setenv("DDX_UPLOAD", form)
+        c = _lib.Context(0)
+        try:
+            with pytest.raises(_lib.DdxError):
+                c.upload_raw(broken)
+        finally:
+            c.close()
+            monkeypatch.delenv("DDX_UPLOAD")
