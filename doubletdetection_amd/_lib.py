@@ -40,6 +40,7 @@ _SIGNATURES = {
     "ddx_destroy": (C.c_int, [C.c_void_p]),
     "ddx_synchronize": (C.c_int, [C.c_void_p]),
     "ddx_device_bytes": (C.c_int, [C.c_void_p, c_i64_p]),
+    "ddx_device_memory": (C.c_int, [C.c_void_p, c_i64_p, c_i64_p]),
     "ddx_check_memory": (C.c_int, [C.c_void_p]),
     "ddx_reserve_hint": (C.c_int, [C.c_void_p, C.c_int64]),
     "ddx_trim": (C.c_int, [C.c_void_p, C.c_int64]),
@@ -381,6 +382,12 @@ class Context:
         v = C.c_int64(0)
         self._c(self._lib.ddx_device_bytes(self._h, C.byref(v)))
         return v.value
+
+    def device_memory(self):
+        """(free, total) bytes of the context's GPU as the driver reports them."""
+        f, t = C.c_int64(0), C.c_int64(0)
+        self._c(self._lib.ddx_device_memory(self._h, C.byref(f), C.byref(t)))
+        return f.value, t.value
 
     def reserve_hint(self, nbytes: int):
         """Size of the next memory chunk the context requests from the driver (0: the library's own guess)."""

@@ -348,7 +348,8 @@ class BoostClassifier:
         devices: list of GPU ordinals driven by THIS process (one host thread and at least one device context per GPU;
             boosting iterations are dealt out over them).  Default: ``[device]``.
         streams_per_device: device contexts (HIP streams) per GPU, each running its own boosting iterations; the
-            once-per-fit prologue is shared by device-to-device copies.  Default 2 (``DDX_STREAMS`` overrides).
+            once-per-fit prologue is shared by device-to-device copies.  Default: up to 5, evened out over the iterations and
+            bounded by the GPU's memory (``DDX_STREAMS`` overrides).
 
     Attributes after ``fit`` / ``predict``: ``all_log_p_values_``, ``all_scores_``, ``communities_``,
     ``labels_``, ``parents_``, ``suggested_score_cutoff_``, ``synth_communities_``, ``top_var_genes_``,
@@ -704,12 +705,34 @@ class BoostClassifier:
             return min(32, cores)
         return int(self.n_jobs)
 
-    def _stream_count(self):
+    _AUTO_STREAMS = 5
+
+    def _stream_count(self, n_mine=None, n_devices=1, leader=None):
+        """Device contexts per GPU.  An explicit ``streams_per_device`` / ``DDX_STREAMS`` is taken as it is.  Otherwise: up to
+        five -- with five the iterations overlap down to the sum of their GPU-filling kernels (two contexts leave 3 % on
+        the table at the benchmark shape) --, evened out over the rounds the share of iterations needs (10 iterations: 5
+        contexts x 2, 6 iterations: 3 x 2, not 5 + 1), and no more than the GPU's memory holds beside the leader."""
         n = self.streams_per_device
-        if n is None:
-            n = int(os.environ.get("DDX_STREAMS", "2"))
-        if n < 1:
-            raise ValueError("streams_per_device must be at least 1")
+        if n is None and "DDX_STREAMS" in os.environ:
+            n = int(os.environ["DDX_STREAMS"])
+        if n is not None:
+            if n < 1:
+                raise ValueError("streams_per_device must be at least 1")
+            return int(n)
+        if n_mine is None:
+            return self._AUTO_STREAMS
+        per_device = max(1, -(-int(n_mine) // max(1, n_devices)))          # iterations a GPU has to run
+        rounds = -(-per_device // self._AUTO_STREAMS)
+        n = -(-per_device // rounds)
+        ctx = getattr(leader, "ctx", None)
+        if ctx is not None and hasattr(ctx, "device_memory"):
+            held = max(1, ctx.device_bytes())
+            free, total = ctx.device_memory()
+            # a follower ends up as large as its leader (the leader's first chunk is sized for a whole fit); parked
+            # contexts of earlier fits are handed out again before anything new is allocated, so they count as room
+            parked = sum(c.device_bytes() for c in _CONTEXT_POOL.get(getattr(leader, "device", None), ()))
+            room = int(0.9 * (free + parked))
+            n = max(1, min(n, 1 + room // held))
         return int(n)
 
     @staticmethod
@@ -751,7 +774,7 @@ class BoostClassifier:
     def _open_lanes(self, leaders, n_mine):
         """[(device, engine)]: the leader context of every GPU plus streams_per_device - 1 followers that copy its resident
         counts device-to-device.  Lanes are ordered stream-major so that a short job reaches every GPU first."""
-        streams = self._stream_count()
+        streams = self._stream_count(n_mine, len(leaders), next(iter(leaders.values())))
         needed = max(1, n_mine)                  # a lane without an iteration to run is not opened
         lanes = [(dev, eng) for dev, eng in leaders.items()]
         followers = []

@@ -341,6 +341,16 @@ int ddx_trim(ddx_ctx* ctx, int64_t keep_bytes) {
     return DDX_OK;
 }
 
+int ddx_device_memory(ddx_ctx* ctx, int64_t* free_bytes, int64_t* total_bytes) {
+    REQUIRE_CTX(ctx);
+    USE_DEVICE(ctx);
+    size_t f = 0, t = 0;
+    DDX_HIP(ctx, hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = (int64_t)f;
+    if (total_bytes) *total_bytes = (int64_t)t;
+    return DDX_OK;
+}
+
 int ddx_device_bytes(const ddx_ctx* ctx, int64_t* bytes) {
     REQUIRE_CTX(ctx);
     if (!bytes) return DDX_E_ARG;

@@ -56,6 +56,9 @@ int ddx_synchronize(ddx_ctx* ctx);
 int ddx_check_memory(ddx_ctx* ctx);
 /* bytes of device memory currently held by the context */
 int ddx_device_bytes(const ddx_ctx* ctx, int64_t* bytes);
+/* free and total memory of the context's GPU as the driver reports them (hipMemGetInfo): what decides how many contexts
+ * can run the iterations of dd.py:192-198 side by side on one GPU */
+int ddx_device_memory(ddx_ctx* ctx, int64_t* free_bytes, int64_t* total_bytes);
 /* device memory policy.  A context obtains its memory in a few large chunks sized from the matrix it receives
  * (dd.py:149-160 has no counterpart: the reference lives in host memory).  ddx_reserve_hint overrides the size of the
  * next chunk the context requests (0: back to the library's own guess); a request the device cannot satisfy falls back

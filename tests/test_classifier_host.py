@@ -327,3 +327,38 @@ def test_lanes_do_not_change_results(monkeypatch, devices, streams):
     for e in made:
         if e.cloned_from is not None:
             assert e.cloned_from.device == e.device and e.cloned_from.cloned_from is None
+
+
+def test_contexts_per_gpu_follow_the_iterations_and_the_memory(monkeypatch):
+    """streams_per_device=None: up to five contexts per GPU, evened out over the rounds a GPU's share of the iterations
+    (dd.py:192-198) needs, and never more than the GPU's memory holds beside the leader; explicit settings are kept."""
+    monkeypatch.delenv("DDX_STREAMS", raising=False)
+    clf = BoostClassifier()
+    assert [clf._stream_count(n) for n in (1, 2, 4, 5, 6, 7, 10, 11, 25, 50)] == [1, 2, 4, 5, 3, 4, 5, 4, 5, 5]
+    assert clf._stream_count(10, n_devices=2) == 5 and clf._stream_count(10, n_devices=4) == 3
+    assert BoostClassifier(streams_per_device=2)._stream_count(10) == 2
+    monkeypatch.setenv("DDX_STREAMS", "3")
+    assert clf._stream_count(10) == 3
+    monkeypatch.delenv("DDX_STREAMS")
+    with pytest.raises(ValueError):
+        BoostClassifier(streams_per_device=0)._stream_count(10)
+
+    class Ctx:
+        def __init__(self, held, free):
+            self.held, self.free = held, free
+
+        def device_bytes(self):
+            return self.held
+
+        def device_memory(self):
+            return self.free, 288 << 30
+
+    class Leader:
+        device = 0
+
+        def __init__(self, held, free):
+            self.ctx = Ctx(held, free)
+
+    assert clf._stream_count(10, 1, Leader(40 << 30, 240 << 30)) == 5        # 4 followers of 40 GB fit into 216 GB
+    assert clf._stream_count(10, 1, Leader(60 << 30, 140 << 30)) == 3        # two more of 60 GB, not four
+    assert clf._stream_count(10, 1, Leader(100 << 30, 50 << 30)) == 1
