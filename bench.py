@@ -33,10 +33,10 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 
 # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide
-# coalesced reads, + WRITE_SIZE), headline workload, profiles/r03f_pmc_counters.txt; None = not collected
-PMC_TRAFFIC_GB = {"spmm_rows": 1.59, "spmm_cols": 1.56, "knn_emit": 1.09, "knn_bound": 0.05, "knn_select": 0.43,
+# coalesced reads, + WRITE_SIZE), headline workload, profiles/r03j_pmc_counters.txt; None = not collected
+PMC_TRAFFIC_GB = {"spmm_rows": 1.56, "spmm_cols": 1.59, "knn_emit": 1.08, "knn_bound": 0.05, "knn_select": 0.43,
                   "doublet_fill": 0.64, "mirror_build": 1.25, "lognorm_rows": 0.96, "lognorm_cols": 0.74}
-PMC_TRAFFIC_SOURCE = ("profiles/r03f_pmc_counters.txt (separate rocprofv3 --pmc passes of this command, round 3; a constant of this "
+PMC_TRAFFIC_SOURCE = ("profiles/r03j_pmc_counters.txt (separate rocprofv3 --pmc passes of this command, round 3; a constant of this "
                       "file, not re-measured by the run that prints it)")
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md)
