@@ -733,6 +733,10 @@ class BoostClassifier:
             parked = sum(c.device_bytes() for c in _CONTEXT_POOL.get(getattr(leader, "device", None), ()))
             room = int(0.9 * (free + parked))
             n = max(1, min(n, 1 + room // held))
+            if _keep_contexts():
+                # what a fit allocates should also fit the allowance of the parked contexts: a context trimmed at the end
+                # of every fit obtains its memory from the driver again at the start of the next (seconds at this size)
+                n = max(1, min(n, _park_limit_bytes() // held))
         return int(n)
 
     @staticmethod

@@ -359,6 +359,11 @@ def test_contexts_per_gpu_follow_the_iterations_and_the_memory(monkeypatch):
         def __init__(self, held, free):
             self.ctx = Ctx(held, free)
 
+    monkeypatch.setenv("DDX_PARK_MAX_GB", "256")
     assert clf._stream_count(10, 1, Leader(40 << 30, 240 << 30)) == 5        # 4 followers of 40 GB fit into 216 GB
+    monkeypatch.setenv("DDX_PARK_MAX_GB", "128")
+    assert clf._stream_count(10, 1, Leader(40 << 30, 240 << 30)) == 3        # ... but only three such contexts can stay parked
+    assert clf._stream_count(10, 1, Leader(12 << 30, 240 << 30)) == 5
+    monkeypatch.setenv("DDX_PARK_MAX_GB", "256")
     assert clf._stream_count(10, 1, Leader(60 << 30, 140 << 30)) == 3        # two more of 60 GB, not four
     assert clf._stream_count(10, 1, Leader(100 << 30, 50 << 30)) == 1
