@@ -80,6 +80,7 @@ void context_reset(ddx_ctx* ctx) {
     ctx->g_nodes = -1; ctx->g_entries = 0; ctx->g_d_indptr = nullptr; ctx->g_d_cols = nullptr; ctx->g_d_vals = nullptr;
     ctx->c_nodes = -1; ctx->c_entries = 0; ctx->c_d_member = nullptr; ctx->c_d_indptr = nullptr; ctx->c_d_cols = nullptr; ctx->c_d_vals = nullptr;
     ctx->lv_host_valid = false;
+    ctx->rowseg_rows = -1;
     // a parked context starts its next fit with the switches of the environment as it is NOW (like a fresh one)
     ctx->opt.read_environment();
 }

@@ -209,6 +209,8 @@ struct ddx_ctx {
     int lv_levels = 0;
     int64_t lv_m2 = 0;                                   // 2m of the quantised graph (the same on every level)
     int32_t lv_maxdeg[kLvKeep] = {0, 0}, lv_nbig[kLvKeep] = {0, 0};
+    int64_t rowseg_rows = -1;                // original rows whose slice segments (rowseg) are valid for this fit's matrix
+    int rowseg_ns = 0, rowseg_SR = 0;
     bool lv_narrow[kLvKeep] = {};            // the level's edge weights fit the 32-bit register sweep
     int64_t lv_n[kLvKeep] = {0, 0}, lv_E[kLvKeep] = {0, 0};
     const int64_t* lv_indptr[kLvKeep] = {nullptr, nullptr};

@@ -38,34 +38,46 @@ __global__ void k_lv_quantise(const double* __restrict__ w, int64_t E, int64_t* 
 __global__ void __launch_bounds__(256) k_lv_strength(const int64_t* __restrict__ indptr, const int64_t* __restrict__ wq, int64_t n, int64_t* __restrict__ K,
                                                      int32_t* __restrict__ comm, unsigned long long* __restrict__ tot, int32_t* __restrict__ size,
                                                      unsigned long long* __restrict__ scal, int32_t* __restrict__ big_list) {
-    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int64_t s = 0, wmax = 0;
-    int deg = 0;
-    if (v < n) {
-        const int64_t b = indptr[v], e = indptr[v + 1];
-        for (int64_t p = b; p < e; ++p) { const int64_t w = wq[p]; s += w; wmax = w > wmax ? w : wmax; }
-        deg = (int)(e - b);
-        K[v] = s;
-        comm[v] = (int32_t)v;
-        tot[v] = (unsigned long long)s;
-        size[v] = 1;
-        if (deg > 64) big_list[atomicAdd(reinterpret_cast<int32_t*>(scal + 1) + 1, 1)] = (int32_t)v;     // (any order)
+    // 16 lanes per node (consecutive entries of a row on consecutive lanes); a workgroup takes 256 nodes in 16 passes and
+    // ends with one atomic per wave on each shared scalar (a few thousand per launch: they all hit the same three words)
+    const int sub = threadIdx.x & 15;
+    auto xor64 = [](int64_t x, int off) { return ((int64_t)__shfl_xor((int)(x >> 32), off, 64) << 32) | (uint32_t)__shfl_xor((int)x, off, 64); };
+    int64_t ws = 0, wm = 0;
+    int wd = 0;
+    for (int pass = 0; pass < 16; ++pass) {
+        const int64_t v = (int64_t)blockIdx.x * 256 + pass * 16 + (threadIdx.x >> 4);
+        int64_t s = 0, wmax = 0;
+        int deg = 0;
+        if (v < n) {
+            const int64_t b = indptr[v], e = indptr[v + 1];
+            for (int64_t p = b + sub; p < e; p += 16) { const int64_t w = wq[p]; s += w; wmax = w > wmax ? w : wmax; }
+            deg = (int)(e - b);
+        }
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) s += xor64(s, off);      // the node's 16 lanes
+        if (v < n && sub == 0) {
+            K[v] = s;
+            comm[v] = (int32_t)v;
+            tot[v] = (unsigned long long)s;
+            size[v] = 1;
+            if (deg > 64) big_list[atomicAdd(reinterpret_cast<int32_t*>(scal + 1) + 1, 1)] = (int32_t)v;     // (any order)
+            ws += s;
+        }
+        wd = deg > wd ? deg : wd;
+        wm = wmax > wm ? wmax : wm;
     }
-    // one atomic per wave on the two shared scalars instead of one per node
-    int64_t ws = s;
-    int wd = deg;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
-        ws += ((int64_t)__shfl_xor((int)(ws >> 32), off, 64) << 32) | (uint32_t)__shfl_xor((int)ws, off, 64);
+        ws += xor64(ws, off);
         const int od = __shfl_xor(wd, off, 64);
         wd = od > wd ? od : wd;
-        const int64_t om = ((int64_t)__shfl_xor((int)(wmax >> 32), off, 64) << 32) | (uint32_t)__shfl_xor((int)wmax, off, 64);
-        wmax = om > wmax ? om : wmax;
+        const int64_t om = xor64(wm, off);
+        wm = om > wm ? om : wm;
     }
     if ((threadIdx.x & 63) == 0) {
         atomicAdd(scal, (unsigned long long)ws);
         atomicMax(reinterpret_cast<int32_t*>(scal + 1), wd);
-        atomicMax(scal + 3, (unsigned long long)wmax);
+        atomicMax(scal + 3, (unsigned long long)wm);
     }
 }
 

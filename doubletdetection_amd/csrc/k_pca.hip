@@ -626,9 +626,10 @@ __global__ void __launch_bounds__(kLdsThreads) k_spmm_lds(const LdsSpmmArgs a) {
 }
 
 // rowseg[row*(ns+1) + p] = offset inside row `row` of its first stored entry whose column is >= p*SR (p = ns: row length)
-__global__ void k_row_segments(const int64_t* __restrict__ indptr, const int32_t* __restrict__ cols, int64_t nrows, int ns,
+// (rows row0 .. nrows-1: the rows of the original cells keep their segments from iteration to iteration)
+__global__ void k_row_segments(const int64_t* __restrict__ indptr, const int32_t* __restrict__ cols, int64_t row0, int64_t nrows, int ns,
                                int SR, int32_t* __restrict__ rowseg) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t t = row0 * (ns + 1) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nrows * (ns + 1)) return;
     const int64_t row = t / (ns + 1);
     const int p = (int)(t - row * (ns + 1));
@@ -1367,11 +1368,17 @@ static int lds_setup(ddx_ctx* ctx, int L, PcaWork& w) {
     w.lds = true;
     w.rows_ns = (int)ceil_div(H, srmax);
     w.rows_SR = (int)((ceil_div(H, w.rows_ns) + 3) & ~3);
+    const void* before = ctx->rowseg.p;
     DDX_TRY(ensure(ctx, ctx->rowseg, sizeof(int32_t) * (size_t)M * (w.rows_ns + 1)));
     ScopedTimer t(ctx, "row_segments");
     DDX_TRY(stage_rankings(ctx));
-    k_row_segments<<<(unsigned)ceil_div(M * (w.rows_ns + 1), 256), 256, 0, ctx->stream>>>(ctx->aug_indptr.as<int64_t>(), ctx->aug_indices.as<int32_t>(), M, w.rows_ns,
-                                                                                       w.rows_SR, ctx->rowseg.as<int32_t>());
+    // the original cells' rows (columns fixed for the whole fit) are cut once; every iteration cuts its synthetic rows
+    const bool kept = before && before == ctx->rowseg.p && ctx->rowseg_rows == ctx->N && ctx->rowseg_ns == w.rows_ns && ctx->rowseg_SR == w.rows_SR;
+    const int64_t row0 = kept ? ctx->N : 0;
+    if (M > row0)
+        k_row_segments<<<(unsigned)ceil_div((M - row0) * (w.rows_ns + 1), 256), 256, 0, ctx->stream>>>(ctx->aug_indptr.as<int64_t>(), ctx->aug_indices.as<int32_t>(), row0, M,
+                                                                                                  w.rows_ns, w.rows_SR, ctx->rowseg.as<int32_t>());
+    ctx->rowseg_rows = ctx->N; ctx->rowseg_ns = w.rows_ns; ctx->rowseg_SR = w.rows_SR;
     return DDX_OK;
 }
 
