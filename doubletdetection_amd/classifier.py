@@ -538,7 +538,7 @@ class BoostClassifier:
                                       "embedding dimensions")
 
     @staticmethod
-    def _cluster_and_score(graph, gamma, seed, min_cluster_size, num_cells, leiden=False, q_tol=None, threads=1):
+    def _cluster_and_score(graph, gamma, seed, min_cluster_size, num_cells, leiden=False, q_tol=None, threads=1, sink=None):
         """Host C++ on a whole graph: Louvain (or Leiden), parts A + B + C -> size-sorted labels -> per-community
         hypergeometric test.  (The device route splits this: part A and C on the GPU around ``_part_b``.)"""
         import time
@@ -555,6 +555,8 @@ class BoostClassifier:
         t2 = time.perf_counter()
         full = _lib.relabel_by_size(labels, min_cluster_size)
         scores, logp = _lib.score_communities(full, num_cells)
+        if sink is not None:
+            sink(full, scores, logp)
         t3 = time.perf_counter()
         return full, scores, logp, (t1 - t0, t2 - t1, t3 - t2)
 
@@ -574,12 +576,14 @@ class BoostClassifier:
         return labels, time.perf_counter() - t0
 
     @staticmethod
-    def _score_labels(labels, min_cluster_size, num_cells, t_louvain):
+    def _score_labels(labels, min_cluster_size, num_cells, t_louvain, sink=None):
         import time
 
         t0 = time.perf_counter()
         full = _lib.relabel_by_size(labels, min_cluster_size)
         scores, logp = _lib.score_communities(full, num_cells)
+        if sink is not None:
+            sink(full, scores, logp)                 # the iteration's rows of the fitted attributes, written by this worker
         return full, scores, logp, (0.0, t_louvain, time.perf_counter() - t0)
 
     # ------------------------------------------------------------------------------------------
@@ -887,6 +891,27 @@ class BoostClassifier:
         # host threads one clustering job may use for its batch of restarts (the jobs of different iterations overlap)
         restart_threads = max(1, min(20, workers // max(1, min(workers, len(mine)))))
         local = {}
+        # Without a process group every iteration runs here: the worker that scores an iteration writes its rows of the
+        # fitted attributes itself (behind the GPU's work on the other iterations) instead of leaving 30 MB of copies to the
+        # end of fit().  With one, the rows travel through the gather first (_gather_rows).
+        direct = backend is None
+        if direct:
+            self.all_scores_ = np.empty((n_iters, num_cells))
+            self.all_log_p_values_ = np.empty((n_iters, num_cells))
+            all_communities = np.empty((n_iters, num_cells))
+            all_synth_communities = np.empty((n_iters, num_synths))
+
+        def sink_for(i):
+            if not direct:
+                return None
+
+            def sink(full, scores, logp):
+                self.all_scores_[i] = scores
+                self.all_log_p_values_[i] = logp
+                all_communities[i] = full[:num_cells]
+                all_synth_communities[i] = full[num_cells:]
+            return sink
+
         host = {"draws": time.perf_counter() - t_setup0, "device_stages": 0.0, "wait_workers": 0.0, "graph_assembly": 0.0, "louvain": 0.0, "score": 0.0}
         t_dev0 = time.perf_counter()
         with ThreadPoolExecutor(max_workers=max(1, min(workers, max(1, len(mine))))) as pool:
@@ -908,7 +933,7 @@ class BoostClassifier:
                     i, fut = item
                     coarse_labels, t_b = fut.result()
                     labels = engine.refine(coarse_labels, gamma)
-                    pending[i] = pool.submit(self._score_labels, labels, min_cluster_size, num_cells, t_b)
+                    pending[i] = pool.submit(self._score_labels, labels, min_cluster_size, num_cells, t_b, sink_for(i))
 
                 for i in share[k]:
                     if self.verbose:
@@ -926,7 +951,7 @@ class BoostClassifier:
                         waiting = (i, pool.submit(self._part_b, graph, gamma, seed, leiden, q_tol, restart_threads))
                     else:
                         pending[i] = pool.submit(self._cluster_and_score, graph, gamma, seed, min_cluster_size, num_cells, leiden,
-                                                 q_tol, restart_threads)
+                                                 q_tol, restart_threads, sink_for(i))
                 if waiting is not None:
                     finish(waiting)
 
@@ -968,17 +993,19 @@ class BoostClassifier:
             self._last_knn_window = lead.knn_window_fraction()   # share of the tile pairs the last kNN screened
 
         t_asm0 = time.perf_counter()
-        self.all_scores_ = np.zeros((n_iters, num_cells))
-        self.all_log_p_values_ = np.zeros((n_iters, num_cells))
-        all_communities = np.zeros((n_iters, num_cells))
-        all_synth_communities = np.zeros((n_iters, num_synths))
+        if not direct:
+            self.all_scores_ = np.zeros((n_iters, num_cells))
+            self.all_log_p_values_ = np.zeros((n_iters, num_cells))
+            all_communities = np.zeros((n_iters, num_cells))
+            all_synth_communities = np.zeros((n_iters, num_synths))
         rows = self._gather_rows(local, mine, n_iters, num_cells, num_synths, rank, world, backend, lanes[0][0])
         for i in range(n_iters):
             full, scores, logp = rows[i]
-            self.all_scores_[i] = scores
-            self.all_log_p_values_[i] = logp
-            all_communities[i] = full[:num_cells]
-            all_synth_communities[i] = full[num_cells:]
+            if not direct:
+                self.all_scores_[i] = scores
+                self.all_log_p_values_[i] = logp
+                all_communities[i] = full[:num_cells]
+                all_synth_communities[i] = full[num_cells:]
             if self.verbose:
                 sizes = np.unique(full, return_counts=True)[1].tolist()
                 print("Found clusters [{0}, ... {2}], with sizes: {1}\n".format(full.min(), sizes, full.max()))
