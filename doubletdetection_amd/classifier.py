@@ -648,6 +648,10 @@ class BoostClassifier:
                     self._discard(e)
                 else:
                     e.close()
+            if failed:
+                # the workers fill these row by row while the fit runs: a fit that failed leaves none of them half-written
+                for name in ("all_scores_", "all_log_p_values_", "communities_", "synth_communities_"):
+                    self.__dict__.pop(name, None)
         self._host_timings["close"] = time.perf_counter() - t0
         self._host_timings["fit_total"] = time.perf_counter() - t_fit0
         return self
