@@ -186,7 +186,7 @@ def main():
         resident_elapsed = sum(one_fit(resident=True)[1] for _ in range(args.resident_steps))
     if args.instrumented_steps > 0:          # (every rank: a fit ends with the ranks' collective)
         # the same fits with two HIP events around every kernel scope (~1 400 scopes per fit): per-kernel times, and the
-        # wall-clock share during which at least one scope was running (union of the scope intervals of both streams)
+        # wall-clock share during which at least one scope was running (union of the scope intervals of all streams)
         os.environ["DDX_TIMING"] = "1"
         one_fit()
         for _ in range(args.instrumented_steps):
@@ -199,7 +199,7 @@ def main():
                 a[1] += ms
         if world == 1 and getattr(clf, "_lanes_used", 1) > 1 and not args.no_exclusive:      # (N = 1 only: a per-rank condition must not decide about fits that end in a collective)
             # and on a single device context: every kernel has the GPU to itself, so its HIP-event duration is the
-            # kernel's own (with two contexts a launch is stretched by its neighbours)
+            # kernel's own (with several contexts a launch is stretched by its neighbours)
             one_fit(streams_per_device=1)
             exclusive = one_fit(streams_per_device=1)[0]._device_timings
         os.environ["DDX_TIMING"] = "0"
@@ -236,14 +236,14 @@ def main():
         # comes from the fit that follows the timed steps on ONE context (same process, same data, same kernels, each
         # alone on the GPU); it agrees with `rocprofv3 --kernel-trace --stats` of `DDX_STREAMS=1 bench.py`
         # (profiles/*_kernel_stats_1stream.csv).  The timed-region figures are kept beside it.
-        roofline, roofline_all, roofline_source = roofline_timed, roofline_timed_all, "HIP events over the instrumented fits (two contexts)"
+        roofline, roofline_all, roofline_source = roofline_timed, roofline_timed_all, "HIP events over the instrumented fits (several contexts share the GPU)"
         if exclusive:
             ex = {n: [v[0], v[1]] for n, v in exclusive.items()}
             order = [n for n in sorted(ex, key=lambda n: -ex[n][1]) if n in models]
             roofline, roofline_all = roof(order[0], ex), [roof(n, ex) for n in order[:6]]
             roofline_source = ("HIP events over one fit on a single device context, run right after the timed steps (in the "
-                               "timed region two contexts share the GPU and a launch's events include queueing behind the "
-                               "other stream: see roofline_two_contexts)")
+                               "timed region several contexts share the GPU and a launch's events include queueing behind the "
+                               "other streams: see roofline_shared_gpu)")
         if roofline:
             roofline["measured"] = roofline_source
         out = {
@@ -272,10 +272,10 @@ def main():
                        "host_threads": os.cpu_count()},
             "roofline": roofline,
             "roofline_top_kernels": roofline_all,
-            "roofline_two_contexts": roofline_timed,
-            "roofline_two_contexts_top_kernels": roofline_timed_all,
+            "roofline_shared_gpu": roofline_timed,
+            "roofline_shared_gpu_top_kernels": roofline_timed_all,
             "gpu_kernel_ms_per_step": {n: round(v / nsteps_i, 3) for n, v in sorted(gpu_ms.items(), key=lambda kv: -kv[1])},
-            "gpu_kernel_ms_per_step_note": "HIP-event spans summed over both device contexts of the instrumented fits (overlapping "
+            "gpu_kernel_ms_per_step_note": "HIP-event spans summed over all device contexts of the instrumented fits (overlapping "
                                            "streams: the sum exceeds the wall-clock); the timed steps themselves carry no events",
             "gpu_busy_frac": (round(busy_ms / 1e3 / instr_elapsed, 4) if instr_elapsed and busy_ms else None),
             "gpu_busy_frac_note": "union of the kernel-scope intervals of all streams / wall-clock of the instrumented fits",
