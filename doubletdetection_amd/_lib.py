@@ -41,6 +41,7 @@ _SIGNATURES = {
     "ddx_synchronize": (C.c_int, [C.c_void_p]),
     "ddx_device_bytes": (C.c_int, [C.c_void_p, c_i64_p]),
     "ddx_device_memory": (C.c_int, [C.c_void_p, c_i64_p, c_i64_p]),
+    "ddx_pack_rows16": (C.c_int, [C.c_int64, c_i64_p, c_i32_p, c_f32_p, C.POINTER(C.c_uint16), C.c_int64, c_i32_p, c_i32_p, c_f32_p, c_i64_p]),
     "ddx_check_memory": (C.c_int, [C.c_void_p]),
     "ddx_reserve_hint": (C.c_int, [C.c_void_p, C.c_int64]),
     "ddx_trim": (C.c_int, [C.c_void_p, C.c_int64]),
@@ -156,6 +157,24 @@ def device_count() -> int:
     n = C.c_int(0)
     rc = load().ddx_device_count(C.byref(n))
     return n.value if rc == 0 else 0
+
+
+def pack_rows16(indptr, indices, data, capacity=None):
+    """Host side of the 2-byte transfer form (ddx_pack_rows16): (codes uint16[nnz], listed positions, columns, values)."""
+    ip = np.ascontiguousarray(indptr, dtype=np.int64)
+    ix = np.ascontiguousarray(indices, dtype=np.int32)
+    d = np.ascontiguousarray(data, dtype=np.float32)
+    nnz = int(ip[-1])
+    cap = nnz if capacity is None else int(capacity)
+    codes = np.zeros(max(nnz, 1), dtype=np.uint16)
+    pos = np.zeros(max(cap, 1), dtype=np.int32)
+    col = np.zeros(max(cap, 1), dtype=np.int32)
+    val = np.zeros(max(cap, 1), dtype=np.float32)
+    n = C.c_int64(0)
+    _check(load().ddx_pack_rows16(len(ip) - 1, _p(ip, c_i64_p), _p(ix, c_i32_p), _p(d, c_f32_p), _p(codes, C.POINTER(C.c_uint16)), cap,
+                                  _p(pos, c_i32_p), _p(col, c_i32_p), _p(val, c_f32_p), C.byref(n)))
+    k = min(n.value, cap)
+    return codes[:nnz], pos[:k], col[:k], val[:k], n.value
 
 
 def set_upload_threads(n: int) -> None:

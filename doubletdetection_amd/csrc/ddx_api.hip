@@ -708,6 +708,27 @@ static int upload_packed(ddx_ctx* ctx, int64_t n_cells, int64_t nnz, int32_t n_g
     return rc;
 }
 
+int ddx_pack_rows16(int64_t n_rows, const int64_t* indptr, const int32_t* indices, const float* data, uint16_t* codes, int64_t capacity,
+                    int32_t* listed_pos, int32_t* listed_col, float* listed_val, int64_t* n_listed) {
+    if (n_rows < 0 || !indptr || !n_listed) return set_err(nullptr, DDX_E_ARG, "bad arguments");
+    DDX_TRY(check_csr(nullptr, n_rows, INT32_MAX, indptr, indices, data));
+    const int64_t nnz = indptr[n_rows];
+    if (nnz && !codes) return set_err(nullptr, DDX_E_ARG, "null output");
+    std::vector<PackEsc> esc;
+    if (nnz) {
+        if (__builtin_cpu_supports("avx2")) pack16_avx2(indptr, n_rows, indices, data, 0, nnz, codes, esc);
+        else pack16_generic(indptr, n_rows, indices, data, 0, nnz, codes, esc);
+    }
+    *n_listed = (int64_t)esc.size();
+    const int64_t keep = std::min<int64_t>(capacity, (int64_t)esc.size());
+    for (int64_t t = 0; t < keep; ++t) {
+        if (listed_pos) listed_pos[t] = esc[t].pos;
+        if (listed_col) listed_col[t] = esc[t].col;
+        if (listed_val) listed_val[t] = esc[t].val;
+    }
+    return DDX_OK;
+}
+
 int ddx_set_upload_threads(int32_t n) {
     if (n < 0 || n > 1024) return set_err(nullptr, DDX_E_ARG, "thread count out of range");
     g_upload_threads.store(n);

@@ -69,6 +69,13 @@ int ddx_trim(ddx_ctx* ctx, int64_t keep_bytes);
 /* host threads that pack the raw matrix for the PCIe upload (process-wide; 0 = default min(48, cores/2); several
  * ranks of one node should share the cores) */
 int ddx_set_upload_threads(int32_t n);
+/* The host side of the 2-byte transfer form of ddx_upload_raw (dd.py:149-160: the matrix fit() receives), exposed so that
+ * it can be checked without a GPU: codes[i] = step from the previous column of the row (1..255; the first entry of a row
+ * steps from column -1) | count << 8 (0..255), or 0 for an entry that does not fit; those are listed whole, in ascending
+ * position, in (listed_pos, listed_col, listed_val), at most `capacity` of them.  *n_listed receives their number (the
+ * arrays hold the first min(number, capacity)).  Context-free, single-threaded. */
+int ddx_pack_rows16(int64_t n_rows, const int64_t* indptr, const int32_t* indices, const float* data, uint16_t* codes,
+                    int64_t capacity, int32_t* listed_pos, int32_t* listed_col, float* listed_val, int64_t* n_listed);
 
 /* ---- fit() prologue: dd.py:165-184 ---------------------------------------------------------
  * ddx_gene_variances replaces dd.py:167-170: float32 population variance per gene,

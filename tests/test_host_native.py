@@ -226,3 +226,65 @@ def test_f8_score_communities_against_reference_lines():
         m = ~np.isnan(s)
         np.testing.assert_array_equal(s[m], g[key + "_scores"][m])          # integer ratio: bit exact
         np.testing.assert_allclose(lp[m], g[key + "_logp"][m], rtol=1e-9, atol=1e-9)
+
+
+def _expand_codes16(indptr, codes, pos, col, val):
+    """Independent statement of the 2-byte transfer form (include/ddx.h: ddx_pack_rows16): the expansion the device performs."""
+    listed = {int(p): (int(c), np.float32(v)) for p, c, v in zip(pos, col, val)}
+    nnz = int(indptr[-1])
+    idx = np.empty(nnz, dtype=np.int32)
+    data = np.empty(nnz, dtype=np.float32)
+    for r in range(len(indptr) - 1):
+        prev = -1
+        for i in range(int(indptr[r]), int(indptr[r + 1])):
+            step, count = int(codes[i]) & 255, int(codes[i]) >> 8
+            if step == 0:
+                assert count == 0 and i in listed
+                idx[i], data[i] = listed[i]
+            else:
+                assert i not in listed
+                idx[i], data[i] = prev + step, np.float32(count)
+            prev = int(idx[i])
+    return idx, data
+
+
+def test_two_byte_transfer_form_round_trips_any_matrix():
+    """dd.py:149-160 (the matrix handed to fit()): whatever the values and the column order, codes + listed entries expand to the
+    caller's arrays bit for bit; counts and steps that fit are not listed."""
+    import scipy.sparse as sp
+    from doubletdetection_amd import _lib
+
+    rng = np.random.default_rng(5)
+    # a typical count matrix: nothing is listed except first columns >= 255 / steps > 255 / counts > 255
+    A = sp.random(300, 4000, density=0.05, format="csr", random_state=3, data_rvs=lambda n: rng.integers(1, 40, n)).astype(np.float32)
+    A.sort_indices()
+    codes, pos, col, val, n = _lib.pack_rows16(A.indptr, A.indices, A.data)
+    assert n == len(pos) < 0.02 * A.nnz
+    idx, data = _expand_codes16(A.indptr, codes, pos, col, val)
+    assert np.array_equal(idx, A.indices) and np.array_equal(data.view(np.uint32), A.data.view(np.uint32))
+    assert np.all(np.diff(pos) > 0)
+    steps = np.diff(np.concatenate([[-1], A.indices]).astype(np.int64))
+    first = np.zeros(A.nnz, dtype=bool)
+    first[A.indptr[:-1][np.diff(A.indptr) > 0]] = True
+    steps[first] = A.indices[first] + 1
+    fits = (steps >= 1) & (steps <= 255) & (A.data <= 255)
+    assert np.array_equal(np.flatnonzero(~fits), pos)
+    assert np.array_equal(codes[fits], (steps[fits] + (A.data[fits].astype(np.int64) << 8)).astype(np.uint16))
+    # hostile content: unsorted and repeated columns, negative and huge columns, fractions, negatives, NaN, infinities, -0.0,
+    # 255 / 256, empty rows, a single enormous row
+    lens = np.array([0, 5, 0, 0, 700, 1, 3, 0], dtype=np.int64)
+    indptr = np.concatenate([[0], np.cumsum(lens)])
+    nnz = int(indptr[-1])
+    indices = rng.integers(-5, 70000, nnz).astype(np.int32)
+    indices[10:300] = np.sort(rng.choice(3000, 290, replace=False))          # a well-formed stretch inside the long row
+    data = rng.integers(0, 300, nnz).astype(np.float32)
+    special = np.array([2.5, -1.0, np.nan, np.inf, -np.inf, -0.0, 255.0, 256.0, 1e9, 0.0], dtype=np.float32)
+    data[: 7 * len(special) : 7] = special
+    codes, pos, col, val, n = _lib.pack_rows16(indptr, indices, data)
+    idx, out = _expand_codes16(indptr, codes, pos, col, val)
+    assert np.array_equal(idx, indices) and np.array_equal(out.view(np.uint32), data.view(np.uint32))
+    # a list that is too short reports the full number (the upload then falls back to the plain copies)
+    codes2, pos2, _, _, n2 = _lib.pack_rows16(indptr, indices, data, capacity=3)
+    assert n2 == n and len(pos2) == 3 and np.array_equal(codes2, codes)
+    with pytest.raises(_lib.DdxError):
+        _lib.pack_rows16(np.array([0, 3, 2]), indices[:3], data[:3])           # row pointer not monotone
