@@ -859,6 +859,14 @@ def test_packed_upload_equals_plain_upload(monkeypatch):
     # the whole matrix came back: it is the caller's, sign bits included
     _same_csr(all_g, odd)
     assert np.array_equal(all_f.data.view(np.uint32), odd.data.view(np.uint32))
+    # a matrix of fractions: every entry would have to be listed, so both packed routes hand over to the plain copies
+    halves = counts.copy()
+    halves.data *= np.float32(0.5)
+    var_h, sub_h = device_matrix({"DDX_UPLOAD": "plain"}, halves)
+    for form in ("packed", "packed32"):
+        var_p, sub_p = device_matrix({"DDX_UPLOAD": form}, halves)
+        np.testing.assert_array_equal(var_p, var_h)
+        _same_csr(sub_p, sub_h)
     # a matrix the validation rejects is rejected the same way on every route (it arrives as it is)
     broken = counts.copy()
     row = int(np.argmax(np.diff(broken.indptr) > 3))
