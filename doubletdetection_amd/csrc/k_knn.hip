@@ -215,6 +215,10 @@ constexpr int kBoundRT = 2;   // query tiles per wave in the bound pass (registe
 #endif
 constexpr int kEmitRT = DDX_EMIT_RT;    // query tiles per wave in the emit pass
 #define DDX_EMIT_WAVES (DDX_EMIT_RT <= 2 ? 4 : 3)
+// Waves per workgroup of the bfloat16 emit pass (they share the staged candidate chunks): 4, or 8 from kEmitWideFrom
+// points on -- measured per launch: 2 waves 3.50 / 60.3 ms (125 k / 625 k points), 4 waves 2.52 / 43.0 ms, 8 waves
+// 2.56 / 40.7 ms (at 125 k points 8 waves leave fewer than two workgroups per CU)
+constexpr int64_t kEmitWideFrom = 400000;
 
 template <int CP, int kBoundKeep>
 __global__ void __launch_bounds__(256) k_knn_bound(const float* __restrict__ Et, const float* __restrict__ nrm,
@@ -586,8 +590,8 @@ TileStageBf<CP> st;
     }
 }
 
-template <int CP, bool FOLD>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CP <= 64 ? DDX_EMIT_WAVES : 2, CP <= 64 ? DDX_EMIT_WAVES : 2))) k_knn_emit_bf(const __bf16* __restrict__ Eb, const __bf16* __restrict__ Ebq, const float* __restrict__ nrm, const f4* __restrict__ start4,
+template <int CP, bool FOLD, int kEmitBW>
+__global__ void __launch_bounds__(64 * kEmitBW) __attribute__((amdgpu_waves_per_eu(CP <= 64 ? DDX_EMIT_WAVES : 2, CP <= 64 ? DDX_EMIT_WAVES : 2))) k_knn_emit_bf(const __bf16* __restrict__ Eb, const __bf16* __restrict__ Ebq, const float* __restrict__ nrm, const f4* __restrict__ start4,
                                                      const float* __restrict__ thr, int64_t Mp, int include_self,
                                                      int32_t* __restrict__ ccount, int32_t* __restrict__ cbuf, const int32_t* __restrict__ win, int dbg, int cap,
                                                      int xcd_chunk) {
@@ -597,9 +601,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CP <= 
     __shared__ f4 lds_c[2][kChunkTiles * tile_vecs];
     __shared__ f4 lds_h[2][kChunkTiles * 16];     // accumulator start values -0.5*(1-slack)*|c|^2 (see commit_start)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t blk = knn_block(Mp / (4 * 16 * RT), xcd_chunk);
+    const int64_t blk = knn_block(Mp / (kEmitBW * 16 * RT), xcd_chunk);
     if (blk < 0) return;
-    const int64_t q0 = (blk * 4 + wave) * (16 * RT);
+    const int64_t q0 = (blk * kEmitBW + wave) * (16 * RT);
     QueryTilesBf<CP, RT> qt;
     qt.load(FOLD ? Ebq : Eb, q0, lane);          // FOLD: the query operands carry -hr in components 30 / 31 (k_knn_fold)
     const int rbase = 4 * (lane >> 4), jcol = lane & 15;
@@ -634,11 +638,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CP <= 
     const int64_t last_vec = ntiles * tile_vecs - 1, last_h = ntiles * 16 - 1;
     auto stage = [&](int64_t ch, int buf) {
 #pragma unroll
-        for (int u = 0; u < kChunkTiles * tile_vecs / 256; ++u) {
-            int64_t g = ch * (kChunkTiles * tile_vecs) + u * 256 + tid;
+        for (int u = 0; u < kChunkTiles * tile_vecs / (64 * kEmitBW); ++u) {
+            int64_t g = ch * (kChunkTiles * tile_vecs) + u * (64 * kEmitBW) + tid;
             if (g > last_vec) g = last_vec;                       // the ragged last chunk re-reads the last tile
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcE + g),
-                                             (__attribute__((address_space(3))) void*)(lds_c[buf] + u * 256 + wave * 64), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(lds_c[buf] + u * (64 * kEmitBW) + wave * 64), 16, 0, 0);
         }
         if (tid < kChunkTiles * 16) {                             // whole waves (kChunkTiles*16 is a multiple of 64)
             int64_t g = ch * (kChunkTiles * 16) + tid;
@@ -1065,9 +1069,10 @@ __global__ void k_knn_keys(const float* __restrict__ emb, int64_t M, int C, floa
 // can only matter for query q if d2(q,c) <= T_q, and d2(q,c) >= (q_1 - c_1)^2, so c_1 must lie within sqrt(T_q) of
 // q_1.  Points are sorted by that component, hence the admissible candidates of the whole block form one contiguous
 // range of tiles [win[2b], win[2b+1]).  The radius carries a 1e-5 relative margin for the float32 square root.
+template <int BW>      // waves (of 16 * kEmitRT queries) per emit block
 __global__ void __launch_bounds__(64) k_knn_window(const float* __restrict__ p1, const float* __restrict__ thr, const float* __restrict__ nrm,
                                                    int64_t Mp, int32_t* __restrict__ win, unsigned long long* __restrict__ total_tiles) {
-    constexpr int QB = 4 * 16 * kEmitRT;
+    constexpr int QB = BW * 16 * kEmitRT;
     const int lane = threadIdx.x;
     const int64_t qb = (int64_t)blockIdx.x * QB;
     float lo = __builtin_huge_valf(), hi = -__builtin_huge_valf();
@@ -1116,7 +1121,8 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
     // workspace (reuses the PCA row buffer): E [Mp*CP] | Et [Mp*CP] | Eb [Mp*CP as bf16 hi+lo] | nrm [Mp] | thr [Mp] | p1 [Mp] | keys [2*Mp]
     //            | ccount [Mp+64] | ids [2*Mp] | win [2*blocks] | cbuf [Mp*cap]
     const size_t f_words = (size_t)Mp * CP * 3 + 9 * (size_t)Mp + 16;
-    const int64_t emit_blocks = Mp / (4 * 16 * kEmitRT);
+    const bool wide = ctx->opt.knn_bf16 && M >= kEmitWideFrom && !getenv("DDX_KNN_EMIT_NARROW");     // 8-wave emit blocks
+    const int64_t emit_blocks = Mp / ((wide ? 8 : 4) * 16 * kEmitRT);
     const int xcd_chunk = ctx->opt.knn_xcd_chunk;                                  // DDX_KNN_XCD_CHUNK (0: workgroups in launch order)
     const bool fold = ctx->opt.knn_bf16 && ctx->opt.knn_fold && C <= 30;          // threshold folded into the operands (k_knn_fold)
     const size_t i_words = (size_t)Mp + 64 + 2 * (size_t)Mp + 2 * (size_t)emit_blocks + 64 + (size_t)Mp * cap + (fold ? (size_t)Mp * 32 + 16 : 0);
@@ -1190,13 +1196,20 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
         const unsigned grid = (unsigned)emit_blocks;
         const unsigned grid_x = (unsigned)(xcd_chunk > 0 ? ceil_div(emit_blocks, 8 * (int64_t)xcd_chunk) * 8 * xcd_chunk : emit_blocks);
         const int dbg_mode = ctx->opt.knn_ablation;     // timing ablations (wrong results): non-zero only in -DDDX_ABLATION builds
-        k_knn_window<<<grid, 64, 0, ctx->stream>>>(p1, thr, nrm, Mp, win, reinterpret_cast<unsigned long long*>(ccount + Mp + 2));
+        if (wide) k_knn_window<8><<<grid, 64, 0, ctx->stream>>>(p1, thr, nrm, Mp, win, reinterpret_cast<unsigned long long*>(ccount + Mp + 2));
+        else k_knn_window<4><<<grid, 64, 0, ctx->stream>>>(p1, thr, nrm, Mp, win, reinterpret_cast<unsigned long long*>(ccount + Mp + 2));
+#define DDX_EMIT_BF(CPV, FOLDV, QUERY)                                                                                                                      \
+    do {                                                                                                                                                    \
+        if (wide) k_knn_emit_bf<CPV, FOLDV, 8><<<grid_x, 512, 0, ctx->stream>>>(Eb, QUERY, nrm, start4, thr, Mp, include_self, ccount, cbuf, win, dbg_mode, cap, xcd_chunk); \
+        else k_knn_emit_bf<CPV, FOLDV, 4><<<grid_x, 256, 0, ctx->stream>>>(Eb, QUERY, nrm, start4, thr, Mp, include_self, ccount, cbuf, win, dbg_mode, cap, xcd_chunk);      \
+    } while (0)
         if (bf && fold) {
             k_knn_fold<<<(unsigned)ceil_div(Mp * 8, 256), 256, 0, ctx->stream>>>(nrm, thr, Mp, Eb, Ebq);
-            k_knn_emit_bf<32, true><<<grid_x, 256, 0, ctx->stream>>>(Eb, Ebq, nrm, start4, thr, Mp, include_self, ccount, cbuf, win, dbg_mode, cap, xcd_chunk);
-        } else if (bf && CP == 32) k_knn_emit_bf<32, false><<<grid_x, 256, 0, ctx->stream>>>(Eb, Eb, nrm, start4, thr, Mp, include_self, ccount, cbuf, win, dbg_mode, cap, xcd_chunk);
-        else if (bf && CP == 64) k_knn_emit_bf<64, false><<<grid_x, 256, 0, ctx->stream>>>(Eb, Eb, nrm, start4, thr, Mp, include_self, ccount, cbuf, win, dbg_mode, cap, xcd_chunk);
-        else if (bf) k_knn_emit_bf<128, false><<<grid_x, 256, 0, ctx->stream>>>(Eb, Eb, nrm, start4, thr, Mp, include_self, ccount, cbuf, win, dbg_mode, cap, xcd_chunk);
+            DDX_EMIT_BF(32, true, Ebq);
+        } else if (bf && CP == 32) DDX_EMIT_BF(32, false, Eb);
+        else if (bf && CP == 64) DDX_EMIT_BF(64, false, Eb);
+        else if (bf) DDX_EMIT_BF(128, false, Eb);
+#undef DDX_EMIT_BF
         else if (CP == 32) k_knn_emit<32><<<grid, 256, 0, ctx->stream>>>(Et, nrm, thr, Mp, include_self, ccount, cbuf, win, cap);
         else if (CP == 64) k_knn_emit<64><<<grid, 256, 0, ctx->stream>>>(Et, nrm, thr, Mp, include_self, ccount, cbuf, win, cap);
         else k_knn_emit<128><<<grid, 256, 0, ctx->stream>>>(Et, nrm, thr, Mp, include_self, ccount, cbuf, win, cap);
