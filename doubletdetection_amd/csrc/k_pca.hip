@@ -240,6 +240,9 @@ __global__ void __launch_bounds__(256) k_spmm_cols(const int64_t* __restrict__ c
 #ifndef DDX_SPMM_NT
 #define DDX_SPMM_NT 0       // 1: stored entries are fetched with the non-temporal hint (they are read once; the operand slices should own the L2)
 #endif
+#ifndef DDX_SPMM_HALFTRIP
+#define DDX_SPMM_HALFTRIP 1 // a round whose last trip would hold at most four steps ends with a half trip of four
+#endif
 #ifndef DDX_SPMM_ROUNDSUM
 #define DDX_SPMM_ROUNDSUM 0 // 1: trip sums are added in float32 over a round (<= 64 entries) and enter the float64 accumulator once per round
 #endif
@@ -361,7 +364,11 @@ __device__ __forceinline__ void lds_round(const LdsFetch<SLOTS>& f, const int (&
     if (PK) {
         const float* myf = reinterpret_cast<const float*>(myd);
         fq rsum = (fq)(0.0f);
-        for (int t0 = 0; t0 < ((DDX_SPMM_DBG & 16) ? 0 : nsteps); t0 += 8) {          // the staged round is zero-padded to 64 entries
+        // full trips of eight steps, then -- when one to four steps are left -- a half trip of four (the staged round is
+        // zero-padded to 64 entries; a zero entry adds an exact +0, so where the padding ends changes no bit of the sums)
+        const bool half_tail = DDX_SPMM_HALFTRIP && DDX_SPMM_OFF16 && !DDX_SPMM_DBG && !DDX_SPMM_ROUNDSUM && ((nsteps - 1) & 7) < 4;
+        const int nfull = half_tail ? (nsteps & ~7) : nsteps;
+        for (int t0 = 0; t0 < ((DDX_SPMM_DBG & 16) ? 0 : nfull); t0 += 8) {
             f4v fv[2];
             u4 ov[2];
 #pragma unroll
@@ -427,6 +434,31 @@ __device__ __forceinline__ void lds_round(const LdsFetch<SLOTS>& f, const int (&
         if (DDX_SPMM_ROUNDSUM) {
 #pragma unroll
             for (int c = 0; c < CPL; ++c) acc[c] += (double)rsum[c];
+        }
+        if (half_tail) {
+            typedef __attribute__((address_space(3))) const fq lds_fq;
+            typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+            const int t0 = nfull;
+            const f4v fv = *reinterpret_cast<const f4v*>(myf + t0);
+            const u2 pk16 = *reinterpret_cast<const u2*>(reinterpret_cast<const uint16_t*>(myoff) + t0);
+            const uint32_t rowb = (uint32_t)(ld * 4);
+            const uint32_t base3 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)opB;
+            fq q[4];
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+                uint32_t alo, ahi;
+                asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(alo) : "v"(pk16[w]), "s"(rowb), "v"(base3));
+                asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(ahi) : "v"(pk16[w]), "s"(rowb), "v"(base3));
+                q[2 * w] = *reinterpret_cast<lds_fq*>((uintptr_t)alo);
+                q[2 * w + 1] = *reinterpret_cast<lds_fq*>((uintptr_t)ahi);
+            }
+            fq p0 = q[0] * fv.x;
+            fq p1 = q[1] * fv.y;
+            p0 = __builtin_elementwise_fma(q[2], (fq)(fv.z), p0);
+            p1 = __builtin_elementwise_fma(q[3], (fq)(fv.w), p1);
+            p0 = p0 + p1;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) acc[c] += (double)p0[c];
         }
         wave_lds_sync();
         return;
