@@ -60,7 +60,8 @@ void arena_hint(ddx_ctx* ctx, size_t bytes) {
 // handed out again from the start).  Called by the entry points that make counts resident.
 void context_reset(ddx_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
-    DevBuf* bufs[] = {&ctx->raw_indptr, &ctx->raw_indices, &ctx->raw_data, &ctx->raw_packed, &ctx->aug_indptr, &ctx->aug_indices,
+    ctx->hvg_rows = -1;
+    DevBuf* bufs[] = {&ctx->raw_indptr, &ctx->raw_indices, &ctx->raw_data, &ctx->raw_packed, &ctx->hvg_state, &ctx->hvg_keys, &ctx->hvg_vals, &ctx->hvg_colptr, &ctx->aug_indptr, &ctx->aug_indices,
                       &ctx->aug_raw, &ctx->aug_x, &ctx->lib32, &ctx->lib64, &ctx->synth_counts, &ctx->parents, &ctx->pad_off,
                       &ctx->csc_o_colptr, &ctx->csc_o_row, &ctx->csc_o_raw, &ctx->csc_o_x, &ctx->csc_s_colptr,
                       &ctx->csc_s_row, &ctx->csc_s_raw, &ctx->csc_s_x, &ctx->sort_keys_in, &ctx->sort_keys_out,
@@ -392,12 +393,12 @@ __global__ void k_expand_packed(const uint32_t* __restrict__ packed, int64_t n, 
 }
 
 // 2-byte form -> (column, value) arrays, one wave per row.  esc_pos ascends; an entry with code 0 is looked up there.
-__global__ void __launch_bounds__(256) k_expand_packed16(const uint16_t* __restrict__ code, const int64_t* __restrict__ indptr, int64_t n_rows,
+__global__ void __launch_bounds__(256) k_expand_packed16(const uint16_t* __restrict__ code, const int64_t* __restrict__ indptr, int64_t row0, int64_t n_rows,
                                                          const int32_t* __restrict__ esc_pos, const int32_t* __restrict__ esc_col,
                                                          const float* __restrict__ esc_val, int32_t n_esc,
                                                          int32_t* __restrict__ idx, float* __restrict__ val) {
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t row = row0 + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);       // rows row0 .. n_rows - 1
     if (row >= n_rows) return;
     const int64_t b = indptr[row], e = indptr[row + 1];
     int32_t carry = -1;                                   // column of the entry before the block
@@ -650,6 +651,27 @@ static int upload_packed(ddx_ctx* ctx, int64_t n_cells, int64_t nnz, int32_t n_g
     pool->start(worker);
     std::vector<hipEvent_t> ev(nchunks, nullptr);
     int rc = DDX_OK;
+    // 2-byte form: rows complete after every chunk, the largest batch of entries they bring, the listed entries so far
+    std::vector<int64_t> rows_done_after((size_t)nchunks, 0);
+    int64_t rows_done = 0, fold_max = 1;
+    bool fold_ok = f16 && !getenv("DDX_HVG_WHOLE");
+    std::vector<int32_t> pos, col;                        // (alive and never reallocated until the stream has taken them: the synchronisation below)
+    std::vector<float> val;
+    unsigned char* side = ctx->raw_packed.as<unsigned char>() + codes_bytes;
+    int32_t* d_pos = reinterpret_cast<int32_t*>(side);
+    int32_t* d_col = d_pos + esc_cap;
+    float* d_val = reinterpret_cast<float*>(d_col + esc_cap);
+    if (f16) {
+        pos.reserve((size_t)esc_cap + 1); col.reserve((size_t)esc_cap + 1); val.reserve((size_t)esc_cap + 1);
+        int64_t prev = 0;
+        for (int64_t k = 0; k < nchunks; ++k) {
+            const int64_t c1 = std::min(nnz, (k + 1) * chunk);
+            const int64_t r1 = (std::upper_bound(indptr, indptr + n_cells + 1, c1) - indptr) - 1;      // rows whose last entry is in by now
+            rows_done_after[k] = r1;
+            fold_max = std::max(fold_max, indptr[r1] - indptr[prev]);
+            prev = r1;
+        }
+    }
     for (int64_t k = 0; k < nchunks && rc == DDX_OK; ++k) {
         while (done[k].load(std::memory_order_acquire) < T && !bad.load()) std::this_thread::yield();
         if (bad.load()) { rc = 1; break; }
@@ -659,9 +681,31 @@ static int upload_packed(ddx_ctx* ctx, int64_t n_cells, int64_t nnz, int32_t n_g
         if (hipMemcpyAsync(dev, pin + esz * c0, esz * len, hipMemcpyHostToDevice, ctx->copy_stream) != hipSuccess ||
             hipEventCreateWithFlags(&ev[k], hipEventDisableTiming) != hipSuccess || hipEventRecord(ev[k], ctx->copy_stream) != hipSuccess ||
             hipStreamWaitEvent(ctx->stream, ev[k], 0) != hipSuccess) { rc = DDX_E_HIP; break; }
-        if (!f16)
+        if (!f16) {
             k_expand_packed<<<(unsigned)((len + 255) / 256), 256, 0, ctx->stream>>>(reinterpret_cast<const uint32_t*>(dev), len, ctx->raw_indices.as<int32_t>() + c0,
                                                                                     ctx->raw_data.as<float>() + c0);
+            continue;
+        }
+        // 2-byte form: the entries this chunk lists go behind those of the earlier chunks (ascending positions), then the rows
+        // that END in this chunk are expanded and -- while the next chunk is on the link -- folded into the running gene sums
+        // of dd.py:167-170 (the stream has been told to wait for the chunk: the event above)
+        const size_t before = pos.size();
+        for (int w = 0; w < T; ++w)
+            for (const PackEsc& x : listed[(size_t)k * T + w]) { pos.push_back(x.pos); col.push_back(x.col); val.push_back(x.val); }
+        const size_t added = pos.size() - before;
+        if ((int64_t)pos.size() > esc_cap) { rc = 1; break; }
+        if (added &&
+            (hipMemcpyAsync(d_pos + before, pos.data() + before, 4 * added, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+             hipMemcpyAsync(d_col + before, col.data() + before, 4 * added, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+             hipMemcpyAsync(d_val + before, val.data() + before, 4 * added, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)) { rc = DDX_E_HIP; break; }
+        const int64_t row1 = rows_done_after[k];
+        if (row1 > rows_done) {
+            k_expand_packed16<<<(unsigned)((row1 - rows_done + 3) / 4), 256, 0, ctx->stream>>>(ctx->raw_packed.as<uint16_t>(), ctx->raw_indptr.as<int64_t>(), rows_done, row1, d_pos,
+                                                                                             d_col, d_val, (int32_t)pos.size(), ctx->raw_indices.as<int32_t>(),
+                                                                                             ctx->raw_data.as<float>());
+            if (fold_ok && gene_sums_fold(ctx, n_genes, n_cells, rows_done, row1, indptr[rows_done], indptr[row1], fold_max) != DDX_OK) fold_ok = false;
+            rows_done = row1;
+        }
     }
     if (rc != DDX_OK) bad.store(1);
     const double t_issued = clk();
@@ -671,30 +715,8 @@ static int upload_packed(ddx_ctx* ctx, int64_t n_cells, int64_t nnz, int32_t n_g
     }
     pool->wait();
     if (rc == DDX_OK && bad.load()) rc = 1;
-    std::vector<int32_t> pos, col;                        // (alive until the stream has taken them: the synchronisation below)
-    std::vector<float> val;
-    if (rc == DDX_OK && f16) {
-        // the listed entries, in ascending position ([chunk][thread] order), then one expansion of all rows (the stream waits
-        // for every chunk: the events above; raw_indptr went ahead on the same stream)
-        const int64_t n_esc = n_listed.load();
-        pos.resize((size_t)n_esc); col.resize((size_t)n_esc); val.resize((size_t)n_esc);
-        size_t t = 0;
-        for (const auto& part : listed)
-            for (const PackEsc& x : part) { pos[t] = x.pos; col[t] = x.col; val[t] = x.val; ++t; }
-        unsigned char* side = ctx->raw_packed.as<unsigned char>() + codes_bytes;
-        int32_t* d_pos = reinterpret_cast<int32_t*>(side);
-        int32_t* d_col = d_pos + esc_cap;
-        float* d_val = reinterpret_cast<float*>(d_col + esc_cap);
-        if (n_esc) {
-            if (hipMemcpyAsync(d_pos, pos.data(), 4 * (size_t)n_esc, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
-                hipMemcpyAsync(d_col, col.data(), 4 * (size_t)n_esc, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
-                hipMemcpyAsync(d_val, val.data(), 4 * (size_t)n_esc, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = DDX_E_HIP;
-        }
-        if (rc == DDX_OK)
-            k_expand_packed16<<<(unsigned)((n_cells + 3) / 4), 256, 0, ctx->stream>>>(ctx->raw_packed.as<uint16_t>(), ctx->raw_indptr.as<int64_t>(), n_cells, d_pos, d_col,
-                                                                                      d_val, (int32_t)n_esc, ctx->raw_indices.as<int32_t>(), ctx->raw_data.as<float>());
-        if (dbg) fprintf(stderr, "[ddx upload] %lld of %lld entries listed\n", (long long)n_esc, (long long)nnz);
-    }
+    if (rc == DDX_OK && f16 && dbg) fprintf(stderr, "[ddx upload] %lld of %lld entries listed\n", (long long)pos.size(), (long long)nnz);
+    if (rc != DDX_OK || !fold_ok) ctx->hvg_rows = -1;
     const double t_packed = clk();
     (void)hipStreamSynchronize(ctx->copy_stream);
     const double t_copied = clk();

@@ -111,6 +111,11 @@ struct ddx_ctx {
     std::vector<int64_t> h_raw_indptr;
     hipStream_t copy_stream = nullptr;   // the packed chunks travel on their own stream
     ddx::DevBuf raw_packed;          // the packed matrix on the device (expanded chunk by chunk)
+    // gene sums accumulated while the matrix arrives (ddx_upload_raw, 2-byte form): per gene the two running float32 sums of
+    // dd.py:167-170 in row order, carried from chunk to chunk; valid_rows = rows folded in so far (-1: none / another matrix)
+    ddx::DevBuf hvg_state, hvg_keys, hvg_vals, hvg_colptr;
+    int64_t hvg_rows = -1;
+    int32_t hvg_G = 0;
 
     // ---- HVG-restricted counts, resident for the whole fit -------------------------------------
     int64_t N = 0;
@@ -296,6 +301,9 @@ int stage_rankings(ddx_ctx* ctx);
 int stage_coarsen_graph(ddx_ctx* ctx, double gamma, int32_t sweeps, int32_t levels);
 int stage_refine_communities(ddx_ctx* ctx, const int32_t* coarse_labels, double gamma, int32_t sweeps, int32_t* labels_out);
 int stage_gene_variances(ddx_ctx* ctx, float* var_out);
+// fold the entries of rows [row0, row1) of the raw matrix (already on the device) into the running gene sums; row0 must be the
+// number of rows folded in so far (0 starts over).  max_entries: the largest number of entries one call will see.
+int gene_sums_fold(ddx_ctx* ctx, int32_t G, int64_t n_rows, int64_t row0, int64_t row1, int64_t e0, int64_t e1, int64_t max_entries);
 int stage_select_columns(ddx_ctx* ctx, const int64_t* cols, int32_t n_cols);
 
 // host-side numerics

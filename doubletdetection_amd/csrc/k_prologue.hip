@@ -71,14 +71,18 @@ __global__ void k_colptr_i32(const int32_t* __restrict__ keys, int64_t n, int32_
     colptr[j] = lo;
 }
 
+// state (or null): the two running sums per gene, read at the start and written back at the end -- the sequential additions
+// of a gene's entries then continue across calls (the rows of a matrix folded in a few at a time, in row order).
+// var_out (or null): the variance from the sums as they stand after this call.
 __global__ void __launch_bounds__(256) k_gene_var(const int64_t* __restrict__ colptr, const float* __restrict__ vals,
-                                                  int32_t G, float rinv, float* __restrict__ var_out) {
+                                                  int32_t G, float rinv, float* __restrict__ var_out, float* __restrict__ state) {
 #pragma clang fp contract(off)
     const int lane = threadIdx.x & 63;
     const int32_t g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (g >= G) return;
     const int64_t b = colptr[g], e = colptr[g + 1];
     float s1 = 0.f, s2 = 0.f;
+    if (state) { s1 = state[2 * g]; s2 = state[2 * g + 1]; }
     for (int64_t base = b; base < e; base += 64) {
         const int64_t p = base + lane;
         const float v = (p < e) ? vals[p] : 0.f;
@@ -102,14 +106,68 @@ __global__ void __launch_bounds__(256) k_gene_var(const int64_t* __restrict__ co
         }
     }
     if (lane == 0) {
-        const float m2 = s1 * s1;
-        var_out[g] = s2 - m2;
+        if (state) { state[2 * g] = s1; state[2 * g + 1] = s2; }
+        if (var_out) {
+            const float m2 = s1 * s1;
+            var_out[g] = s2 - m2;
+        }
     }
+}
+
+__global__ void k_variance_from_sums(const float* __restrict__ state, int32_t G, float* __restrict__ var_out) {
+#pragma clang fp contract(off)
+    const int32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    const float s1 = state[2 * g], s2 = state[2 * g + 1];
+    const float m2 = s1 * s1;
+    var_out[g] = s2 - m2;
+}
+
+int gene_sums_fold(ddx_ctx* ctx, int32_t G, int64_t n_rows, int64_t row0, int64_t row1, int64_t e0, int64_t e1, int64_t max_entries) {
+    if (row0 == 0) {
+        ctx->hvg_rows = -1;
+        ctx->hvg_G = G;
+        DDX_TRY(ensure(ctx, ctx->hvg_state, sizeof(float) * 2 * (size_t)G));
+        DDX_TRY(ensure(ctx, ctx->hvg_keys, sizeof(int32_t) * (size_t)(max_entries + 1)));
+        DDX_TRY(ensure(ctx, ctx->hvg_vals, sizeof(float) * (size_t)(max_entries + 1)));
+        DDX_TRY(ensure(ctx, ctx->hvg_colptr, sizeof(int64_t) * ((size_t)G + 1)));
+        DDX_HIP(ctx, hipMemsetAsync(ctx->hvg_state.p, 0, sizeof(float) * 2 * (size_t)G, ctx->stream));
+        ctx->hvg_rows = 0;
+    }
+    if (ctx->hvg_rows != row0 || ctx->hvg_G != G || e1 - e0 > max_entries) { ctx->hvg_rows = -1; return DDX_OK; }     // out of step: the caller falls back to the whole-matrix pass
+    const int64_t n = e1 - e0;
+    if (n > 0) {
+        int end_bit = 1;
+        while ((1 << end_bit) < G) ++end_bit;
+        size_t tmp_bytes = 0;
+        DDX_HIP(ctx, prim::sort_pairs(nullptr, tmp_bytes, ctx->raw_indices.as<int32_t>() + e0, ctx->hvg_keys.as<int32_t>(), ctx->raw_data.as<float>() + e0,
+                                      ctx->hvg_vals.as<float>(), (int)max_entries, 0, end_bit, ctx->stream));
+        DDX_TRY(ensure(ctx, ctx->sort_tmp, tmp_bytes));
+        DDX_HIP(ctx, prim::sort_pairs(ctx->sort_tmp.p, tmp_bytes, ctx->raw_indices.as<int32_t>() + e0, ctx->hvg_keys.as<int32_t>(), ctx->raw_data.as<float>() + e0,
+                                      ctx->hvg_vals.as<float>(), (int)n, 0, end_bit, ctx->stream));
+        k_colptr_i32<<<(unsigned)ceil_div(G + 1, 256), 256, 0, ctx->stream>>>(ctx->hvg_keys.as<int32_t>(), n, G, ctx->hvg_colptr.as<int64_t>());
+        const float rinv = (float)(1.0 / (double)n_rows);
+        k_gene_var<<<(unsigned)ceil_div(G, 4), 256, 0, ctx->stream>>>(ctx->hvg_colptr.as<int64_t>(), ctx->hvg_vals.as<float>(), G, rinv, nullptr, ctx->hvg_state.as<float>());
+    }
+    ctx->hvg_rows = row1;
+    return DDX_OK;
 }
 
 int stage_gene_variances(ddx_ctx* ctx, float* var_out) {
     const int64_t n = ctx->raw_nnz;
     const int32_t G = ctx->rawG;
+    if (ctx->hvg_rows == ctx->rawN && ctx->hvg_G == G && ctx->hvg_state.p && !getenv("DDX_HVG_WHOLE")) {
+        // the sums were folded in while the matrix arrived (ddx_upload_raw): only the last step is left
+        DevBuf var;
+        DDX_TRY(ensure(ctx, var, sizeof(float) * G));
+        ScopedTimer t(ctx, "hvg_variance");
+        k_variance_from_sums<<<(unsigned)ceil_div(G, 256), 256, 0, ctx->stream>>>(ctx->hvg_state.as<float>(), G, var.as<float>());
+        hipError_t e = hipMemcpyAsync(var_out, var.p, sizeof(float) * G, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        release(ctx, var);
+        if (e != hipSuccess) return set_err(ctx, DDX_E_HIP, "gene variance stage failed: %s", hipGetErrorString(e));
+        return DDX_OK;
+    }
     DevBuf keys_out, vals_out, colptr, var;
     int rc = DDX_OK;
     auto cleanup = [&]() { release(ctx, keys_out); release(ctx, vals_out); release(ctx, colptr); release(ctx, var); };
@@ -135,7 +193,7 @@ int stage_gene_variances(ddx_ctx* ctx, float* var_out) {
         ScopedTimer t(ctx, "hvg_variance");
         k_colptr_i32<<<(unsigned)ceil_div(G + 1, 256), 256, 0, ctx->stream>>>(keys_out.as<int32_t>(), n, G, colptr.as<int64_t>());
         const float rinv = (float)(1.0 / (double)ctx->rawN);
-        k_gene_var<<<(unsigned)ceil_div(G, 4), 256, 0, ctx->stream>>>(colptr.as<int64_t>(), vals_out.as<float>(), G, rinv, var.as<float>());
+        k_gene_var<<<(unsigned)ceil_div(G, 4), 256, 0, ctx->stream>>>(colptr.as<int64_t>(), vals_out.as<float>(), G, rinv, var.as<float>(), nullptr);
     }
     if (e == hipSuccess && rc == DDX_OK) e = hipMemcpyAsync(var_out, var.p, sizeof(float) * G, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess && rc == DDX_OK) e = hipStreamSynchronize(ctx->stream);
