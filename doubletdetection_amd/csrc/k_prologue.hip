@@ -165,6 +165,9 @@ int stage_gene_variances(ddx_ctx* ctx, float* var_out) {
         hipError_t e = hipMemcpyAsync(var_out, var.p, sizeof(float) * G, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         release(ctx, var);
+        // (the work space of the folding goes back to the context; a second call takes the whole-matrix pass)
+        release(ctx, ctx->hvg_keys); release(ctx, ctx->hvg_vals); release(ctx, ctx->hvg_colptr); release(ctx, ctx->hvg_state);
+        ctx->hvg_rows = -1;
         if (e != hipSuccess) return set_err(ctx, DDX_E_HIP, "gene variance stage failed: %s", hipGetErrorString(e));
         return DDX_OK;
     }

@@ -821,6 +821,8 @@ def test_packed_upload_equals_plain_upload(monkeypatch):
         try:
             c.upload_raw(mat)
             var = c.gene_variances()
+            # (the 2-byte route folds the gene sums in while the matrix arrives; a second call takes the one-pass route)
+            np.testing.assert_array_equal(c.gene_variances(), var)
             c.select_columns(np.sort(np.argsort(var)[-500:]) if columns is None else columns)
             return var, sp.csr_matrix(c.get_counts())
         finally:
