@@ -73,6 +73,7 @@ _SIGNATURES = {
     "ddx_knn_metric": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "ddx_get_knn": (C.c_int, [C.c_void_p, c_i32_p, c_f64_p]),
     "ddx_get_knn_window_fraction": (C.c_int, [C.c_void_p, c_f64_p]),
+    "ddx_get_knn_overflow_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "ddx_build_graph": (C.c_int, [C.c_void_p, C.c_int32]),
     "ddx_graph_relations": (C.c_int, [C.c_void_p, C.c_int32, c_i32_p, c_f64_p]),
     "ddx_assemble_graph": (C.c_int, [C.c_int64, C.c_int32, c_i32_p, c_f64_p, c_i64_p, c_i32_p, c_f64_p]),
@@ -576,6 +577,11 @@ class Context:
         f = C.c_double(0.0)
         self._c(self._lib.ddx_get_knn_window_fraction(self._h, C.byref(f)))
         return f.value
+
+    def knn_overflow_count(self) -> int:
+        n = C.c_int64(0)
+        self._c(self._lib.ddx_get_knn_overflow_count(self._h, C.byref(n)))
+        return int(n.value)
 
     def build_graph(self, mode: int, fetch: bool = True):
         self._c(self._lib.ddx_build_graph(self._h, int(mode)))

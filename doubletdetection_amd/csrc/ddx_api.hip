@@ -68,7 +68,7 @@ void context_reset(ddx_ctx* ctx) {
                       &ctx->sort_vals_in, &ctx->sort_vals_out, &ctx->sort_tmp, &ctx->sort_rowid, &ctx->median, &ctx->lib_sorted, &ctx->lognorm_tab,
                       &ctx->zcol, &ctx->colmean, &ctx->colstat, &ctx->col_part, &ctx->pcaA, &ctx->pcaB, &ctx->pcaSmall,
                       &ctx->pcaPartial, &ctx->pcaVec, &ctx->pcaPanel, &ctx->pcaOp, &ctx->pcaQ0, &ctx->pcaBlk, &ctx->rowseg, &ctx->rank_buf, &ctx->lv_buf, &ctx->lv_pack, &ctx->graph_buf, &ctx->emb32, &ctx->emb64, &ctx->sing, &ctx->knn_idx,
-                      &ctx->knn_dist, &ctx->knn_sorted, &ctx->edge_w};
+                      &ctx->knn_dist, &ctx->knn_sorted, &ctx->edge_w, &ctx->knn_cells};
     for (DevBuf* b : bufs) { b->p = nullptr; b->cap = 0; b->blk = -1; }
     ctx->arena.blocks.clear();
     for (auto& c : ctx->arena.chunks) c.off = 0;
@@ -78,6 +78,7 @@ void context_reset(ddx_ctx* ctx) {
     ctx->q0_rows = 0; ctx->q0_cols = 0;
     ctx->rank_rows = ctx->rank_cols = nullptr;
     ctx->knn_window_total = nullptr;
+    ctx->knn_overflow = nullptr;
     ctx->g_nodes = -1; ctx->g_entries = 0; ctx->g_d_indptr = nullptr; ctx->g_d_cols = nullptr; ctx->g_d_vals = nullptr;
     ctx->c_nodes = -1; ctx->c_entries = 0; ctx->c_d_member = nullptr; ctx->c_d_indptr = nullptr; ctx->c_d_cols = nullptr; ctx->c_d_vals = nullptr;
     ctx->lv_host_valid = false;
@@ -141,13 +142,17 @@ void Options::read_environment() {
     g = getenv("DDX_SPMM_GEOM");
     spmm_geom = is(g, "pair") ? 1 : (is(g, "quad") ? 2 : 0);
     trip_packed = !is(getenv("DDX_SPMM_TRIP"), "f64");
-    g = getenv("DDX_KNN_SCREEN");
-    knn_bf16 = !(g && g[0] == 'f' && g[1] == '3');
     knn_fold = !is(getenv("DDX_KNN_FOLD"), "0");
     g = getenv("DDX_KNN_XCD_CHUNK");
     knn_xcd_chunk = g ? atoi(g) : 32;
     g = getenv("DDX_KNN_SAMPLE_TILES");
     knn_sample_tiles = g ? atoll(g) : 0;
+    g = getenv("DDX_KNN_CELLS");
+    knn_cells = g ? atoi(g) : 0;
+    g = getenv("DDX_KNN_SAMPLE_EVERY");
+    knn_sample_every = g ? atoi(g) : 32;
+    g = getenv("DDX_KNN_EMIT_WAVES");
+    knn_emit_waves = g ? atoi(g) : 0;
     row_sums_sequential = getenv("DDX_ROW_SUMS_SEQUENTIAL") != nullptr;
     knn_debug = getenv("DDX_KNN_DEBUG") != nullptr;
     upload_packed = !is(getenv("DDX_UPLOAD"), "plain");
@@ -1068,6 +1073,16 @@ int ddx_get_knn_window_fraction(ddx_ctx* ctx, double* fraction) {
     unsigned long long total = 0;
     DDX_TRY(d2h(ctx, &total, ctx->knn_window_total, sizeof(total)));
     *fraction = ctx->knn_window_pairs > 0.0 ? (double)total / ctx->knn_window_pairs : 0.0;
+    return DDX_OK;
+}
+
+int ddx_get_knn_overflow_count(ddx_ctx* ctx, int64_t* n_queries) {
+    REQUIRE_CTX(ctx);
+    USE_DEVICE(ctx);
+    NEED(ctx->have_knn && n_queries, "no kNN result");
+    int32_t n = 0;
+    if (ctx->knn_overflow) DDX_TRY(d2h(ctx, &n, ctx->knn_overflow, sizeof(n)));
+    *n_queries = n;
     return DDX_OK;
 }
 

@@ -33,7 +33,6 @@ constexpr int kGatherPanelRows = 4096;   // measured optimum for the gather kern
 //   DDX_SPMM=gather        L2-gather operator products instead of the LDS-staged ones
 //   DDX_PCA_GATHER=f64     float64 operand gathers (gather kernels only)
 //   DDX_SPMM_GEOM=pair|quad, DDX_SPMM_TRIP=f64   variants of the LDS-staged products
-//   DDX_KNN_SCREEN=f32     float32 MFMA distance screen instead of the bfloat16 split
 //   DDX_KNN_FOLD=0         emit pass with explicit threshold compares (the first version)
 //   DDX_KNN_SAMPLE_TILES=n size of the bound pass's subset
 //   DDX_ROW_SUMS_SEQUENTIAL=1  always replay the sequential row sums (skip the exact-integer shortcut)
@@ -46,10 +45,12 @@ struct Options {
     bool gather_f32 = true;
     int spmm_geom = 0;               // 0 auto, 1 pair, 2 quad
     bool trip_packed = true;
-    bool knn_bf16 = true;
     int knn_xcd_chunk = 32;          // DDX_KNN_XCD_CHUNK=n (0 = launch order): n consecutive query blocks of the MFMA passes share an XCD at a time
     bool knn_fold = true;            // DDX_KNN_FOLD=0: compare against the per-query threshold instead of folding it into the operands
     int64_t knn_sample_tiles = 0;    // 0 = default rule
+    int knn_cells = 0;               // cells of the emit pass's pruning structure (0 = default rule, 1 = first-component windows only)
+    int knn_sample_every = 32;       // the bound pass's sample holds every n-th tile of the whole set (0: none)
+    int knn_emit_waves = 0;          // waves per emit block: 4, 8 or 16 (0 = default)
     bool row_sums_sequential = false;
     bool knn_debug = false;
     int mirror_mode = 2;             // column-major mirror: 2 counting sort placed by LDS tiles, 1 (DDX_MIRROR=scatter) counting sort with scattered stores, 0 (DDX_MIRROR=sort) radix sort
@@ -192,6 +193,8 @@ struct ddx_ctx {
     ddx::DevBuf knn_dist;            // double [M*K]
     ddx::DevBuf knn_sorted;          // int32 [M*K] neighbour lists sorted by index
     ddx::DevBuf edge_w;              // double [M*K]
+    ddx::DevBuf knn_cells;           // cells, interval tables and chunk lists of the emit pass (stage_knn)
+    const int32_t* knn_overflow = nullptr;   // device counter: queries whose candidate list overflowed (exact rescan)
     bool have_knn = false;
     const unsigned long long* knn_window_total = nullptr;   // device counter: (query block, candidate tile) pairs screened by the emit pass
     double knn_window_pairs = 0.0;                          // the same count without pruning

@@ -25,19 +25,15 @@ constexpr float kScreenSlackBf = 4.2e-5f;
 
 // ---- layouts -----------------------------------------------------------------------------------
 // E   : row-major float32 [Mp][CP]            (exact re-evaluation gathers whole rows)
-// Et  : MFMA operand layout, 16-point tiles:   Et[tile][s][k][j] = E[16*tile + j][4*s + k]
-//       so that lane l of a wave reads operand element (point l&15, component 4s + (l>>4)) at
-//       Et[tile*16*CP + s*64 + l] -- one fully coalesced 256-byte load per MFMA k-step, and the same
-//       formula serves the A operand (queries) and the B operand (candidates).
 // nrm : float32 squared norms; padding points carry +inf so they can never pass the screen.
 // Eb  : bfloat16 split operands for v_mfma_f32_16x16x32_bf16: every coordinate a is stored as
 //       hi = bf16(a) and lo = bf16(a - hi); for tile t, 32-component block kb and part p (0 = hi, 1 = lo)
 //       lane l = ((d % 32) / 8) * 16 + j holds components d = 32*kb + 8*(l>>4) + 0..7 of point 16*t + j as
 //       8 consecutive bf16 at Eb[(((t*KB + kb)*2 + p)*64 + l)*8], i.e. one coalesced 1 KB load per operand.
-// Points are laid out in the order `perm` (ascending first principal component, see stage_knn): row r of every
-// layout is embedding row perm[r];  p1[r] = its first component (+inf for padding rows).
+// Points are laid out in the order `perm` (cell by cell, ascending first principal component inside a cell, see
+// stage_knn): row r of every layout is embedding row perm[r];  p1[r] = its first component (+inf for padding rows).
 __global__ void k_knn_prepare(const float* __restrict__ in, const int32_t* __restrict__ perm, int64_t M, int64_t Mp, int C, int CP,
-                              float* __restrict__ E, float* __restrict__ Et, __bf16* __restrict__ Eb,
+                              float* __restrict__ E, __bf16* __restrict__ Eb,
                               float* __restrict__ nrm, float* __restrict__ p1, f4* __restrict__ start4) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= Mp) return;
@@ -50,7 +46,6 @@ __global__ void k_knn_prepare(const float* __restrict__ in, const int32_t* __res
     for (int d = 0; d < CP; ++d) {
         const float v = (r < M && d < C) ? in[src * C + d] : 0.f;
         E[r * CP + d] = v;
-        Et[tile * 16 * CP + (d >> 2) * 64 + (d & 3) * 16 + j] = v;
         const __bf16 hi = (__bf16)v;
         const __bf16 lo = (__bf16)(v - (float)hi);
         const int kb = d >> 5, lane = (((d & 31) >> 3) << 4) | j, e = d & 7;
@@ -107,11 +102,6 @@ __global__ void k_knn_fold(const float* __restrict__ nrm, const float* __restric
     }
 }
 
-// Screen slack: |fl32(|q|^2 + |c|^2 - 2 q.c) - d2| <= (CP + 8) * 2^-24 * (|q|^2 + |c|^2) for the float32
-// MFMA dot product (a k-ordered fmaf chain) and float32 norms (4.3e-6 at CP = 64).  The screen is evaluated
-// in the rearranged form  q.c > 0.5*(1-slack)*|c|^2 + 0.5*((1-slack)*|q|^2 - thr), whose extra float32
-// roundings (<= 2e-7 relative to the norms) are covered by the margin in 8e-6.
-constexpr float kScreenSlack = 8.0e-6f;
 // Smallest sample distances kept per lane and row in the bound pass.  Whatever the lanes keep, the k-th smallest of the
 // kept values is the k-th smallest of a subset, i.e. a valid upper bound; keeping 4 (instead of 6) loosens it for the
 // queries where one lane meets more than 4 of the k nearest sample points, and lets four waves share a SIMD.
@@ -120,26 +110,28 @@ constexpr int kBoundKeepLarge = 6;   // k <= 80
 constexpr int kCandCap = 768;      // candidate slots per query between the emit and select passes
 
 // ================================================================================================
-// exact kNN in three passes (16x16 query x candidate tiles on v_mfma_f32_16x16x32_bf16 with a bfloat16 hi/lo split,
-// or on v_mfma_f32_16x16x4_f32 with DDX_KNN_SCREEN=f32); points are in first-principal-component order:
-//   1. bound : over the tiles nearest to the query in that order, every lane keeps the kBoundKeep smallest
-//              *upper bounds* of the squared distance per screened row; the k-th smallest of the
+// exact kNN in three passes (16x16 query x candidate tiles on v_mfma_f32_16x16x32_bf16 with a bfloat16 hi/lo split);
+// the points are laid out cell by cell (section "Cells" below), first-principal-component order inside a cell:
+//   1. bound : over the tiles of the query's own cell and of the cells nearest to it, every lane keeps the kBoundKeep
+//              smallest *upper bounds* of the squared distance per screened row; the k-th smallest of the
 //              16*kBoundKeep kept values of a row is an upper bound T_q of the query's true k-th
 //              neighbour distance (k-th smallest of a subset >= k-th smallest of the whole set).
-//   2. emit  : over the contiguous tile range with |c_1 - q_1| <= sqrt(T_q) (k_knn_window), a pair survives when a
-//              *lower bound* of its squared distance is below T_q (so no true neighbour can be lost); survivors
-//              (about a hundred per query) are appended to the query's candidate list.
+//   2. emit  : over the candidate tiles that the cell test cannot rule out for the wave's 32 queries (k_knn_tilelists),
+//              a pair survives when a *lower bound* of its squared distance is below T_q (so no true neighbour can
+//              be lost); survivors (well under a hundred per query) are appended to the query's candidate list.
 //   3. select: one wave per query evaluates its candidates exactly (float64, the reference's
-//              arithmetic, one candidate per lane) and sorts them by (distance, index) in LDS; the
+//              arithmetic, one candidate per lane) and sorts them by (distance, index); the
 //              first k are the result.  A query whose list overflowed is re-scanned over all points
 //              by the same pass, so the result is exact in every case and independent of the
 //              order in which survivors were appended.
+// Both MFMA passes walk a LIST of tiles (the emit pass's with a mask of the block's waves that screen the tile): the tiles
+// of a step (8, or 4 for more than 32 components) are copied into LDS asynchronously from wherever they lie.
 // ================================================================================================
 
 // Workgroup numbering of the MFMA passes.  Hardware workgroup b runs on XCD b % 8; consecutive query blocks screen nearly
 // the same candidate tiles.  With chunk > 0 the workgroups resident on one XCD at a time are `chunk` CONSECUTIVE query
 // blocks (so a candidate tile fetched into that XCD's L2 serves them all), and the XCDs take adjacent chunks of the query
-// range (so all of them meet the same mix of narrow and wide windows).  Returns -1 for the padding of the last chunk.
+// range (so all of them meet the same mix of short and long lists).  Returns -1 for the padding of the last chunk.
 __device__ __forceinline__ int64_t knn_block(int64_t nblocks, int chunk) {
     const int64_t b = blockIdx.x;
     if (chunk <= 0) return b < nblocks ? b : -1;
@@ -148,300 +140,19 @@ __device__ __forceinline__ int64_t knn_block(int64_t nblocks, int chunk) {
     return lb < nblocks ? lb : -1;
 }
 
-// ---- candidate tiles are staged through LDS once per block (4 waves share them) ---------------------
-// tiles per staged chunk: 16 KB of coordinates per buffer whatever the padded dimension
-#ifndef DDX_CHUNK_TILES32
-#define DDX_CHUNK_TILES32 8
-#endif
-__host__ __device__ constexpr int chunk_tiles(int CP) { return CP <= 32 ? DDX_CHUNK_TILES32 : DDX_CHUNK_TILES32 / 2; }
-
-template <int CP>
-struct TileStage {
-    static constexpr int kChunkTiles = chunk_tiles(CP);
-    static constexpr int kFloats = kChunkTiles * 16 * CP;          // coordinates of one chunk
-    static constexpr int kPerThread = kFloats / 256;               // floats per thread (256 threads)
-    static_assert(kPerThread % 4 == 0, "chunk must split into float4 per thread");
-    f4 regs[kPerThread / 4];
-    float nreg;                                                    // threads 0..127 carry one norm each
-    // global -> registers (issue early), registers -> LDS (after the barrier that retires the old buffer)
-    __device__ __forceinline__ void fetch(const float* __restrict__ Et, const float* __restrict__ nrm, int64_t chunk,
-                                          int64_t n_chunk_tiles_total, int64_t tile_stride, int tid) {
-#pragma unroll
-        for (int u = 0; u < kPerThread / 4; ++u) {
-            const int f = (u * 256 + tid) * 4;                     // float offset inside the chunk
-            const int t = f / (16 * CP);                           // tile slot
-            int64_t tile = (chunk * kChunkTiles + t);
-            if (tile >= n_chunk_tiles_total) tile = n_chunk_tiles_total - 1;
-            regs[u] = *reinterpret_cast<const f4*>(Et + tile * tile_stride * 16 * CP + (f - t * 16 * CP));
-        }
-        if (tid < kChunkTiles * 16) {
-            int64_t tile = chunk * kChunkTiles + (tid >> 4);
-            if (tile >= n_chunk_tiles_total) tile = n_chunk_tiles_total - 1;
-            nreg = nrm[tile * tile_stride * 16 + (tid & 15)];
-        }
-    }
-    __device__ __forceinline__ void commit(float* lds_coords, float* lds_norms, int tid) const {
-#pragma unroll
-        for (int u = 0; u < kPerThread / 4; ++u) *reinterpret_cast<f4*>(lds_coords + (u * 256 + tid) * 4) = regs[u];
-        if (tid < kChunkTiles * 16) lds_norms[tid] = nreg;
-    }
-};
-
-template <int CP, int RT>
-struct QueryTiles {
-    static constexpr int KS = CP / 4;
-    float a[RT][KS];
-    __device__ __forceinline__ void load(const float* __restrict__ Et, int64_t q0, int lane) {
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int s = 0; s < KS; ++s) a[rt][s] = Et[((q0 >> 4) + rt) * 16 * CP + s * 64 + lane];
-    }
-    __device__ __forceinline__ void dots(const float* b, f4 (&acc)[RT]) const {
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) acc[rt] = f4{0.f, 0.f, 0.f, 0.f};
-        __builtin_amdgcn_s_setprio(1);     // keep the matrix pipe fed while co-resident waves do their compares
-#pragma unroll
-        for (int s = 0; s < KS; ++s)
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][s], b[s], acc[rt], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-    }
-};
+// tiles per staged step: 16 KB of coordinates per buffer whatever the padded dimension
+__host__ __device__ constexpr int chunk_tiles(int CP) { return CP <= 32 ? 8 : 4; }
 
 constexpr int kBoundRT = 2;   // query tiles per wave in the bound pass (register budget: 16 rows x kBoundKeep)
-#ifndef DDX_EMIT_RT
-#define DDX_EMIT_RT 2
-#endif
-constexpr int kEmitRT = DDX_EMIT_RT;    // query tiles per wave in the emit pass
-#define DDX_EMIT_WAVES (DDX_EMIT_RT <= 2 ? 4 : 3)
-// Waves per workgroup of the bfloat16 emit pass (they share the staged candidate chunks): 4, or 8 from kEmitWideFrom
-// points on -- measured per launch: 2 waves 3.50 / 60.3 ms (125 k / 625 k points), 4 waves 2.52 / 43.0 ms, 8 waves
-// 2.56 / 40.7 ms (at 125 k points 8 waves leave fewer than two workgroups per CU)
-constexpr int64_t kEmitWideFrom = 400000;
+constexpr int kEmitRT = 2;    // query tiles per wave in the emit pass
+constexpr int kEmitWaves = 16; // waves per workgroup of the emit pass (they share the staged candidate tiles)
 
-template <int CP, int kBoundKeep>
-__global__ void __launch_bounds__(256) k_knn_bound(const float* __restrict__ Et, const float* __restrict__ nrm,
-                                                   int64_t Mp, int K, int include_self, int64_t nsamp_tiles,
-                                                   int64_t tile_stride, int64_t tile_phase, int combine, float* __restrict__ thr_out) {
-    constexpr int KS = CP / 4;
-    constexpr int RT = kBoundRT, NV = 4 * RT;
-    constexpr int kChunkTiles = chunk_tiles(CP);
-    __shared__ __attribute__((aligned(16))) float lds_c[2][kChunkTiles * 16 * CP];
-    __shared__ float lds_n[2][kChunkTiles * 16];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t q0 = ((int64_t)blockIdx.x * 4 + wave) * (16 * RT);     // Mp is a multiple of 256: no partial blocks
-    QueryTiles<CP, RT> qt;
-    qt.load(Et, q0, lane);
-    const int rbase = 4 * (lane >> 4), jcol = lane & 15;
-    float nq[NV];
-#pragma unroll
-    for (int v = 0; v < NV; ++v) nq[v] = nrm[q0 + (v >> 2) * 16 + rbase + (v & 3)];
-    float best[NV][kBoundKeep];   // ascending
-#pragma unroll
-    for (int v = 0; v < NV; ++v)
-#pragma unroll
-        for (int t = 0; t < kBoundKeep; ++t) best[v][t] = __builtin_huge_valf();
-    const int64_t own_tile = q0 >> 4;
-    const int64_t nchunks = (nsamp_tiles + kChunkTiles - 1) / kChunkTiles;
-        // sample = the nsamp_tiles tiles around this block in first-component order (contiguous, see stage_knn)
-    // (k > 16 * (kBoundKeep - 1): the window is dealt out over `tile_stride` launches, launch `tile_phase` taking every
-    // tile_stride-th tile and the ceil(k / tile_stride)-th smallest of ITS points; the largest of those bounds holds at
-    // least k points of the whole window below it -- `combine` keeps the maximum over the launches)
-    const int64_t span = nsamp_tiles * tile_stride;
-    int64_t tile0 = (((int64_t)blockIdx.x * 4) * RT) + 2 * RT - span / 2;
-    if (tile0 > (Mp >> 4) - span) tile0 = (Mp >> 4) - span;
-    if (tile0 < 0) tile0 = 0;
-    tile0 += tile_phase;
-    const float* Etw = Et + tile0 * 16 * CP;
-    const float* nrmw = nrm + tile0 * 16;
-TileStage<CP> st;
-    st.fetch(Etw, nrmw, 0, nsamp_tiles, tile_stride, tid);
-    st.commit(lds_c[0], lds_n[0], tid);
-    __syncthreads();
-    for (int64_t ch = 0; ch < nchunks; ++ch) {
-        const int buf = (int)(ch & 1);
-        if (ch + 1 < nchunks) st.fetch(Etw, nrmw, ch + 1, nsamp_tiles, tile_stride, tid);
-        const int ntile = (int)((nsamp_tiles - ch * kChunkTiles) < kChunkTiles ? (nsamp_tiles - ch * kChunkTiles) : kChunkTiles);
-        for (int t = 0; t < ntile; ++t) {
-            const int64_t tile = tile0 + (ch * kChunkTiles + t) * tile_stride;
-            float b[KS];
-#pragma unroll
-            for (int s = 0; s < KS; ++s) b[s] = lds_c[buf][t * 16 * CP + s * 64 + lane];
-            const float nc = lds_n[buf][t * 16 + jcol];
-            f4 acc[RT];
-            qt.dots(b, acc);
-            const bool own = !include_self && (tile >= own_tile && tile < own_tile + RT);
-#pragma unroll
-            for (int v = 0; v < NV; ++v) {
-                const float dot = acc[v >> 2][v & 3];
-                const float n = nq[v] + nc;
-                float ub = fmaf(-2.f, dot, n) + kScreenSlack * n;        // upper bound of the exact squared distance
-                if (own && (tile * 16 + jcol) == (q0 + (v >> 2) * 16 + rbase + (v & 3))) ub = __builtin_huge_valf();
-                if (!(ub < best[v][kBoundKeep - 1])) continue;           // also rejects NaN (padding rows/candidates)
-                best[v][kBoundKeep - 1] = ub;
-#pragma unroll
-                for (int u = kBoundKeep - 1; u > 0; --u) {
-                    const float lo = fminf(best[v][u - 1], best[v][u]), hi = fmaxf(best[v][u - 1], best[v][u]);
-                    best[v][u - 1] = lo;
-                    best[v][u] = hi;
-                }
-            }
-        }
-        if (ch + 1 < nchunks) st.commit(lds_c[buf ^ 1], lds_n[buf ^ 1], tid);
-        __syncthreads();
-    }
-    // k-th smallest of the 16*kBoundKeep values of each row (held by the 16 lanes that share lane>>4)
-#pragma unroll
-    for (int v = 0; v < NV; ++v) {
-        float kth = __builtin_huge_valf();
-        int rank[kBoundKeep];
-#pragma unroll
-        for (int t = 0; t < kBoundKeep; ++t) rank[t] = 0;
-        for (int o = 0; o < 16; ++o) {
-            const int src = (lane & 48) | ((jcol + o) & 15);
-#pragma unroll
-            for (int u = 0; u < kBoundKeep; ++u) {
-                const float other = __shfl(best[v][u], src, 64);
-                const int okey = ((jcol + o) & 15) * kBoundKeep + u;      // tie-break key of the other value
-#pragma unroll
-                for (int t = 0; t < kBoundKeep; ++t) {
-                    const int mkey = jcol * kBoundKeep + t;
-                    rank[t] += (other < best[v][t] || (other == best[v][t] && okey < mkey)) ? 1 : 0;
-                }
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < kBoundKeep; ++t)
-            if (rank[t] == K - 1) kth = best[v][t];
-        // exactly one lane of the 16 holds the value of rank K-1: share it
-        for (int o = 1; o < 16; o <<= 1) kth = fminf(kth, __shfl_xor(kth, o, 64));
-        if (jcol == 0) {                                                      // +inf when fewer than K sample points
-            float* dst = thr_out + q0 + (v >> 2) * 16 + rbase + (v & 3);
-            *dst = combine ? fmaxf(*dst, kth) : kth;
-        }
-    }
-}
-
-template <int CP>
-__global__ void __launch_bounds__(256) k_knn_emit(const float* __restrict__ Et, const float* __restrict__ nrm,
-                                                  const float* __restrict__ thr, int64_t Mp, int include_self,
-                                                  int32_t* __restrict__ ccount, int32_t* __restrict__ cbuf, const int32_t* __restrict__ win, int cap) {
-    constexpr int KS = CP / 4;
-    constexpr int RT = kEmitRT, NV = 4 * RT;
-    constexpr int kChunkTiles = chunk_tiles(CP);
-    __shared__ __attribute__((aligned(16))) float lds_c[2][kChunkTiles * 16 * CP];
-    __shared__ float lds_n[2][kChunkTiles * 16];
-    __shared__ int32_t lcnt[4][16 * kEmitRT];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (lane < 16 * kEmitRT) lcnt[wave][lane] = 0;
-    const int64_t q0 = ((int64_t)blockIdx.x * 4 + wave) * (16 * RT);     // Mp is a multiple of 256: no partial blocks
-    QueryTiles<CP, RT> qt;
-    qt.load(Et, q0, lane);
-    const int rbase = 4 * (lane >> 4), jcol = lane & 15;
-    float hr[NV];   // 0.5*((1-slack)*|q|^2 - T_q): q.c must exceed 0.5*(1-slack)*|c|^2 + hr
-#pragma unroll
-    for (int v = 0; v < NV; ++v) {
-        const int64_t q = q0 + (v >> 2) * 16 + rbase + (v & 3);
-        const float n = nrm[q], t = thr[q];
-        hr[v] = 0.5f * ((1.0f - kScreenSlack) * n - t);
-        if (!(n < __builtin_huge_valf())) hr[v] = __builtin_huge_valf();       // padding query: nothing passes
-        else if (!(t < __builtin_huge_valf())) hr[v] = -__builtin_huge_valf(); // no bound: everything passes
-    }
-    // candidate tiles whose first component can be within reach of any query of this block (k_knn_window)
-    const int64_t t_lo = win[2 * blockIdx.x], ntiles = win[2 * blockIdx.x + 1] - t_lo;
-    if (ntiles <= 0) {                          // block-uniform: nothing can be within reach
-        if (lane < 16 * kEmitRT) ccount[q0 + lane] = 0;
-        return;
-    }
-    const int64_t own_tile = q0 >> 4;
-    const int64_t nchunks = (ntiles + kChunkTiles - 1) / kChunkTiles;
-    TileStage<CP> st;
-    st.fetch(Et + t_lo * 16 * CP, nrm + t_lo * 16, 0, ntiles, 1, tid);
-    st.commit(lds_c[0], lds_n[0], tid);
-    __syncthreads();
-    for (int64_t ch = 0; ch < nchunks; ++ch) {
-        const int buf = (int)(ch & 1);
-        if (ch + 1 < nchunks) st.fetch(Et + t_lo * 16 * CP, nrm + t_lo * 16, ch + 1, ntiles, 1, tid);
-        const int ntile = (int)((ntiles - ch * kChunkTiles) < kChunkTiles ? (ntiles - ch * kChunkTiles) : kChunkTiles);
-        for (int t = 0; t < ntile; ++t) {
-            const int64_t tile = t_lo + ch * kChunkTiles + t;
-            float b[KS];
-#pragma unroll
-            for (int s = 0; s < KS; ++s) b[s] = lds_c[buf][t * 16 * CP + s * 64 + lane];
-            const float hc = 0.5f * (1.0f - kScreenSlack) * lds_n[buf][t * 16 + jcol];   // +inf for padding candidates
-            f4 acc[RT];
-            qt.dots(b, acc);
-            unsigned hits = 0;
-#pragma unroll
-            for (int v = 0; v < NV; ++v) hits |= (acc[v >> 2][v & 3] > hc + hr[v]) ? (1u << v) : 0u;
-            if (__ballot(hits != 0)) {
-                const int32_t cand = (int32_t)(tile * 16 + jcol);
-                const bool own = !include_self && (tile >= own_tile && tile < own_tile + RT);
-                while (hits) {
-                    const int v = __ffs(hits) - 1;
-                    hits &= hits - 1;
-                    const int lq = (v >> 2) * 16 + rbase + (v & 3);
-                    const int64_t q = q0 + lq;
-                    if (own && q == cand) continue;
-                    // this wave is the only writer of its queries' lists: the slot counter lives in LDS
-                    const int slot = atomicAdd(&lcnt[wave][lq], 1);
-                    if (slot < cap) cbuf[q * cap + slot] = cand;
-                }
-            }
-        }
-        if (ch + 1 < nchunks) st.commit(lds_c[buf ^ 1], lds_n[buf ^ 1], tid);
-        __syncthreads();
-    }
-    if (lane < 16 * kEmitRT) ccount[q0 + lane] = lcnt[wave][lane];
-}
-
-// ---- bfloat16-split variant of the two MFMA passes ---------------------------------------------------------
-// q.c ~= qh.ch + qh.cl + ql.ch with three v_mfma_f32_16x16x32_bf16 (16x the f32 MFMA rate each).  Dropped
+// ---- bfloat16-split MFMA screen ----------------------------------------------------------------------------
+// q.c ~= qh.ch + qh.cl + ql.ch with three v_mfma_f32_16x16x32_bf16.  Dropped
 // terms (ql.cl and the residuals of the two-term split) are <= 3*2^-18 |q_i||c_i| per component, the float32
 // accumulation of 3*32 exact products adds <= ~6e-6 sum|q_i c_i|: |error(q.c)| <= 1.8e-5 |q||c| <= 0.9e-5 (|q|^2+|c|^2);
-// doubled in the distance and with the float32 norms that is 2.5e-5 (|q|^2+|c|^2).  The slack below leaves 1.6x margin.
+// doubled in the distance and with the float32 norms that is 2.5e-5 (|q|^2+|c|^2).  The slack kScreenSlackBf leaves 1.6x margin.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-template <int CP>
-struct TileStageBf {           // one chunk = chunk_tiles(CP) tiles x (hi|lo) x KB kilobytes = 16 KB, as for float32
-    static constexpr int kChunkTiles = chunk_tiles(CP);
-    static constexpr int kBytes = kChunkTiles * 16 * CP * 4;       // 2 parts x 2 bytes = 4 bytes per coordinate
-    static constexpr int kVec = kBytes / 16 / 256;                 // 16-byte vectors per thread
-    f4 regs[kVec];
-    float nreg;
-    __device__ __forceinline__ void fetch(const __bf16* __restrict__ Eb, const float* __restrict__ nrm, int64_t chunk,
-                                          int64_t ntiles_total, int64_t tile_stride, int tid) {
-        constexpr int tile_vecs = 16 * CP * 4 / 16;                // 16-byte vectors per tile
-#pragma unroll
-        for (int u = 0; u < kVec; ++u) {
-            const int vix = u * 256 + tid;
-            const int t = vix / tile_vecs;
-            int64_t tile = chunk * kChunkTiles + t;
-            if (tile >= ntiles_total) tile = ntiles_total - 1;
-            regs[u] = reinterpret_cast<const f4*>(Eb)[tile * tile_stride * tile_vecs + (vix - t * tile_vecs)];
-        }
-        if (tid < kChunkTiles * 16) {
-            int64_t tile = chunk * kChunkTiles + (tid >> 4);
-            if (tile >= ntiles_total) tile = ntiles_total - 1;
-            nreg = nrm[tile * tile_stride * 16 + (tid & 15)];
-        }
-    }
-    __device__ __forceinline__ void commit(f4* lds_c, float* lds_n, int tid) const {
-#pragma unroll
-        for (int u = 0; u < kVec; ++u) lds_c[u * 256 + tid] = regs[u];
-        if (tid < kChunkTiles * 16) lds_n[tid] = nreg;
-    }
-    // emit pass: instead of |c|^2 store the accumulator start value -0.5*(1-slack)*|c|^2, four times (one MFMA C quad)
-    __device__ __forceinline__ void commit_start(f4* lds_c, f4* lds_h, int tid) const {
-#pragma unroll
-        for (int u = 0; u < kVec; ++u) lds_c[u * 256 + tid] = regs[u];
-        if (tid < kChunkTiles * 16) {
-            const float h = -0.5f * (1.0f - kScreenSlackBf) * nreg;
-            lds_h[tid] = f4{h, h, h, h};
-        }
-    }
-};
 
 template <int CP, int RT>
 struct QueryTilesBf {
@@ -489,17 +200,51 @@ struct QueryTilesBf {
     }
 };
 
+// One step of a tile list copied into LDS by asynchronous global -> LDS loads (16 bytes per lane, LDS destination =
+// wave-uniform base + lane*16, no registers held).  `ent`: lane j (j < G) holds list entry j of the step; a tile is
+// CP*4 vectors, so the tile a wave copies with one instruction is wave-uniform.  PER = floats of per-point side data
+// copied along (4: the accumulator start quads of the emit pass, 1: the squared norms of the bound pass).
+template <int CP, int BW, int PER>
+__device__ __forceinline__ void stage_tiles(const f4* __restrict__ srcE, const float* __restrict__ side, f4* lds_c, float* lds_s, int ent, int tid,
+                                            int wave, int lane) {
+    constexpr int G = chunk_tiles(CP);
+    constexpr int tile_vecs = CP * 4;
+#pragma unroll
+    for (int u = 0; u < G * tile_vecs / (64 * BW); ++u) {
+        const int v0 = u * (64 * BW) + wave * 64;                   // first vector of this wave's instruction (wave-uniform)
+        const int slot = __builtin_amdgcn_readfirstlane(v0 / tile_vecs);
+        const int64_t tile = __builtin_amdgcn_readlane(ent, slot);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcE + tile * tile_vecs + (v0 % tile_vecs) + lane),
+                                         (__attribute__((address_space(3))) void*)(lds_c + v0), 16, 0, 0);
+    }
+    // side data: G tiles x 16 points, one item per lane
+    if (tid < G * 16) {                                           // whole waves (G*16 is 128 or 64)
+        const int64_t tile = __shfl(ent, tid >> 4, 64);
+        if (PER == 4)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(side + (tile * 16 + (tid & 15)) * 4),
+                                             (__attribute__((address_space(3))) void*)(lds_s + wave * 256), 16, 0, 0);
+        else
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(side + tile * 16 + (tid & 15)),
+                                             (__attribute__((address_space(3))) void*)(lds_s + wave * 64), 4, 0, 0);
+    }
+}
+
+// Bound pass.  blist[blk][*] = the block's sample (k_knn_boundlists): entries of bcount[blk] tiles.  k beyond what one launch
+// ranks (k > 16 * (kBoundKeep - 1)): the sample is dealt out over `stride` launches, launch `phase` taking every stride-th
+// entry and the ceil(k / stride)-th smallest of ITS points; the largest of those bounds holds at least k points of the
+// whole sample below it -- `combine` keeps the maximum over the launches.
 template <int CP, int kBoundKeep>
 __global__ void __launch_bounds__(256) k_knn_bound_bf(const __bf16* __restrict__ Eb, const float* __restrict__ nrm,
-                                                      int64_t Mp, int K, int include_self, int64_t nsamp_tiles,
-                                                      int64_t tile_stride, int64_t tile_phase, int combine, float* __restrict__ thr_out,
+                                                      int64_t Mp, int K, int include_self, const int32_t* __restrict__ blist, const int32_t* __restrict__ bcount,
+                                                      int64_t bcap, int stride, int phase, int combine, float* __restrict__ thr_out,
                                                       int xcd_chunk) {
     constexpr int RT = kBoundRT, NV = 4 * RT;
-    constexpr int kChunkTiles = chunk_tiles(CP);
-    constexpr int tile_vecs = 16 * CP * 4 / 16;
-    __shared__ f4 lds_c[2][kChunkTiles * tile_vecs];
-    __shared__ float lds_n[2][kChunkTiles * 16];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int G = chunk_tiles(CP);
+    constexpr int tile_vecs = CP * 4;
+    __shared__ f4 lds_c[2][G * tile_vecs];
+    __shared__ float lds_n[2][G * 16];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t blk = knn_block(Mp / (4 * 16 * RT), xcd_chunk);
     if (blk < 0) return;
     const int64_t q0 = (blk * 4 + wave) * (16 * RT);
@@ -515,51 +260,56 @@ __global__ void __launch_bounds__(256) k_knn_bound_bf(const __bf16* __restrict__
 #pragma unroll
         for (int t = 0; t < kBoundKeep; ++t) best[v][t] = __builtin_huge_valf();
     const int64_t own_tile = q0 >> 4;
-    const int64_t nchunks = (nsamp_tiles + kChunkTiles - 1) / kChunkTiles;
-        // sample = the nsamp_tiles tiles around this block in first-component order (contiguous, see stage_knn)
-    // (k > 16 * (kBoundKeep - 1): the window is dealt out over `tile_stride` launches, launch `tile_phase` taking every
-    // tile_stride-th tile and the ceil(k / tile_stride)-th smallest of ITS points; the largest of those bounds holds at
-    // least k points of the whole window below it -- `combine` keeps the maximum over the launches)
-    const int64_t span = nsamp_tiles * tile_stride;
-    int64_t tile0 = ((blk * 4) * RT) + 2 * RT - span / 2;
-    if (tile0 > (Mp >> 4) - span) tile0 = (Mp >> 4) - span;
-    if (tile0 < 0) tile0 = 0;
-    tile0 += tile_phase;
-    const __bf16* Ebw = Eb + tile0 * 16 * CP * 2;
-    const float* nrmw = nrm + tile0 * 16;
-TileStageBf<CP> st;
-    st.fetch(Ebw, nrmw, 0, nsamp_tiles, tile_stride, tid);
-    st.commit(lds_c[0], lds_n[0], tid);
-    __syncthreads();
-    for (int64_t ch = 0; ch < nchunks; ++ch) {
-        const int buf = (int)(ch & 1);
-        if (ch + 1 < nchunks) st.fetch(Ebw, nrmw, ch + 1, nsamp_tiles, tile_stride, tid);
-        const int ntile = (int)((nsamp_tiles - ch * kChunkTiles) < kChunkTiles ? (nsamp_tiles - ch * kChunkTiles) : kChunkTiles);
-        for (int t = 0; t < ntile; ++t) {
-            const int64_t tile = tile0 + (ch * kChunkTiles + t) * tile_stride;
-            const float nc = lds_n[buf][t * 16 + jcol];
-            f4 acc[RT];
-            qt.dots(lds_c[buf] + t * tile_vecs, lane, acc);
-            const bool own = !include_self && (tile >= own_tile && tile < own_tile + RT);
+    const int32_t* lst = blist + blk * bcap;
+    const int n_all = bcount[blk];
+    const int n = n_all > phase ? (n_all - phase + stride - 1) / stride : 0;       // entries of this launch
+    const int nsteps = (n + G - 1) / G;
+    auto entry = [&](int step) {                                                     // lane j < G: entry j of the step (the ragged end repeats the last one)
+        int i = step * G + (lane & (G - 1));
+        if (i > n - 1) i = n - 1;
+        return lst[phase + (int64_t)stride * i];
+    };
+    const f4* srcE = reinterpret_cast<const f4*>(Eb);
+    if (nsteps > 0) {
+        int e0 = entry(0), e1 = nsteps > 1 ? entry(1) : 0;
+        stage_tiles<CP, 4, 1>(srcE, nrm, lds_c[0], lds_n[0], e0, tid, wave, lane);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int step = 0; step < nsteps; ++step) {
+            const int buf = step & 1;
+            int e2 = 0;
+            if (step + 1 < nsteps) stage_tiles<CP, 4, 1>(srcE, nrm, lds_c[buf ^ 1], lds_n[buf ^ 1], e1, tid, wave, lane);
+            if (step + 2 < nsteps) e2 = entry(step + 2);
+            const int ntile = (n - step * G) < G ? (n - step * G) : G;
+            for (int t = 0; t < ntile; ++t) {
+                const int64_t tile = __builtin_amdgcn_readlane(e0, t);
+                const float nc = lds_n[buf][t * 16 + jcol];
+                f4 acc[RT];
+                qt.dots(lds_c[buf] + t * tile_vecs, lane, acc);
+                const bool own = !include_self && (tile >= own_tile && tile < own_tile + RT);
 #pragma unroll
-            for (int v = 0; v < NV; ++v) {
-                const float dot = acc[v >> 2][v & 3];
-                const float n = nq[v] + nc;
-                float ub = fmaf(-2.f, dot, n) + kScreenSlackBf * n;      // upper bound of the exact squared distance
-                if (own && (tile * 16 + jcol) == (q0 + (v >> 2) * 16 + rbase + (v & 3))) ub = __builtin_huge_valf();
-                if (!(ub < best[v][kBoundKeep - 1])) continue;
-                best[v][kBoundKeep - 1] = ub;
+                for (int v = 0; v < NV; ++v) {
+                    const float dot = acc[v >> 2][v & 3];
+                    const float nn = nq[v] + nc;
+                    float ub = fmaf(-2.f, dot, nn) + kScreenSlackBf * nn;     // upper bound of the exact squared distance
+                    if (own && (tile * 16 + jcol) == (q0 + (v >> 2) * 16 + rbase + (v & 3))) ub = __builtin_huge_valf();
+                    if (!(ub < best[v][kBoundKeep - 1])) continue;           // also rejects NaN (padding rows / candidates)
+                    best[v][kBoundKeep - 1] = ub;
 #pragma unroll
-                for (int u = kBoundKeep - 1; u > 0; --u) {
-                    const float lo = fminf(best[v][u - 1], best[v][u]), hi = fmaxf(best[v][u - 1], best[v][u]);
-                    best[v][u - 1] = lo;
-                    best[v][u] = hi;
+                    for (int u = kBoundKeep - 1; u > 0; --u) {
+                        const float lo = fminf(best[v][u - 1], best[v][u]), hi = fmaxf(best[v][u - 1], best[v][u]);
+                        best[v][u - 1] = lo;
+                        best[v][u] = hi;
+                    }
                 }
             }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the next step has landed before anyone crosses the barrier
+            __syncthreads();
+            e0 = e1;
+            e1 = e2;
         }
-        if (ch + 1 < nchunks) st.commit(lds_c[buf ^ 1], lds_n[buf ^ 1], tid);
-        __syncthreads();
     }
+    // k-th smallest of the 16*kBoundKeep values of each row (held by the 16 lanes that share lane>>4)
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
         float kth = __builtin_huge_valf();
@@ -571,7 +321,7 @@ TileStageBf<CP> st;
 #pragma unroll
             for (int u = 0; u < kBoundKeep; ++u) {
                 const float other = __shfl(best[v][u], src, 64);
-                const int okey = ((jcol + o) & 15) * kBoundKeep + u;
+                const int okey = ((jcol + o) & 15) * kBoundKeep + u;      // tie-break key of the other value
 #pragma unroll
                 for (int t = 0; t < kBoundKeep; ++t) {
                     const int mkey = jcol * kBoundKeep + t;
@@ -582,6 +332,7 @@ TileStageBf<CP> st;
 #pragma unroll
         for (int t = 0; t < kBoundKeep; ++t)
             if (rank[t] == K - 1) kth = best[v][t];
+        // exactly one lane of the 16 holds the value of rank K-1: share it
         for (int o = 1; o < 16; o <<= 1) kth = fminf(kth, __shfl_xor(kth, o, 64));
         if (jcol == 0) {                                                      // +inf when fewer than K sample points
             float* dst = thr_out + q0 + (v >> 2) * 16 + rbase + (v & 3);
@@ -590,17 +341,23 @@ TileStageBf<CP> st;
     }
 }
 
+// Emit pass.  elist[blk][*] / emask[blk][*]: tiles and the waves of the block that screen them, ecount[blk] entries (a multiple of
+// the step size, padded with mask-0 entries); candidates are appended to cbuf[q][*], ccount[q] counts them (beyond `cap`:
+// overflow).  The waves of a block share the staged tiles: the pass is bound by that staging traffic (L2 / Infinity Cache ->
+// LDS), not by the matrix pipe, so a block is as many waves as a workgroup holds (16: 512 queries per staged tile).
 template <int CP, bool FOLD, int kEmitBW>
-__global__ void __launch_bounds__(64 * kEmitBW) __attribute__((amdgpu_waves_per_eu(CP <= 64 ? DDX_EMIT_WAVES : 2, CP <= 64 ? DDX_EMIT_WAVES : 2))) k_knn_emit_bf(const __bf16* __restrict__ Eb, const __bf16* __restrict__ Ebq, const float* __restrict__ nrm, const f4* __restrict__ start4,
-                                                     const float* __restrict__ thr, int64_t Mp, int include_self,
-                                                     int32_t* __restrict__ ccount, int32_t* __restrict__ cbuf, const int32_t* __restrict__ win, int dbg, int cap,
-                                                     int xcd_chunk) {
+__global__ void __launch_bounds__(64 * kEmitBW) __attribute__((amdgpu_waves_per_eu(CP <= 64 ? 4 : 2, CP <= 64 ? 4 : 2)))
+k_knn_emit_bf(const __bf16* __restrict__ Eb, const __bf16* __restrict__ Ebq, const float* __restrict__ nrm, const f4* __restrict__ start4,
+              const float* __restrict__ thr, int64_t Mp, int include_self, int32_t* __restrict__ ccount, int32_t* __restrict__ cbuf,
+              const int32_t* __restrict__ elist, const uint32_t* __restrict__ emask, const int32_t* __restrict__ ecount, int64_t ecap, int dbg,
+              int cap, int xcd_chunk) {
     constexpr int RT = kEmitRT, NV = 4 * RT;
-    constexpr int kChunkTiles = chunk_tiles(CP);
-    constexpr int tile_vecs = 16 * CP * 4 / 16;
-    __shared__ f4 lds_c[2][kChunkTiles * tile_vecs];
-    __shared__ f4 lds_h[2][kChunkTiles * 16];     // accumulator start values -0.5*(1-slack)*|c|^2 (see commit_start)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int G = chunk_tiles(CP);
+    constexpr int tile_vecs = CP * 4;
+    __shared__ f4 lds_c[2][G * tile_vecs];
+    __shared__ f4 lds_h[2][G * 16];     // accumulator start values -0.5*(1-slack)*|c|^2, one MFMA C quad per candidate (k_knn_prepare)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t blk = knn_block(Mp / (kEmitBW * 16 * RT), xcd_chunk);
     if (blk < 0) return;
     const int64_t q0 = (blk * kEmitBW + wave) * (16 * RT);
@@ -623,42 +380,35 @@ __global__ void __launch_bounds__(64 * kEmitBW) __attribute__((amdgpu_waves_per_
         if (dbg & 1) hr[v] = __builtin_huge_valf();          // experiment: nothing passes the screen
         if (FOLD) hr[v] = 0.f;                               // the threshold travels inside the dot product
     }
-    // candidate tiles whose first component can be within reach of any query of this block (k_knn_window)
-    const int64_t t_lo = win[2 * blk], ntiles = win[2 * blk + 1] - t_lo;
-    if (ntiles <= 0) {                          // block-uniform: nothing can be within reach
+    const int nent = ecount[blk];
+    const int nsteps = nent / G;
+    if (nsteps <= 0) {                          // block-uniform: nothing can be within reach
         if (lane < 16 * kEmitRT) ccount[q0 + lane] = 0;
         return;
     }
+    const int32_t* lst = elist + blk * ecap;
+    const uint32_t* lmk = emask + blk * ecap;
     const int32_t own_tile = (int32_t)(q0 >> 4);
-    const int64_t nchunks = (ntiles + kChunkTiles - 1) / kChunkTiles;
-    // Chunk staging by asynchronous global -> LDS copies (16 bytes per lane, LDS destination = wave-uniform base +
-    // lane*16, no registers held): a chunk of kChunkTiles tiles is contiguous in Eb, as are its start quads.
-    const f4* srcE = reinterpret_cast<const f4*>(Eb) + t_lo * tile_vecs;
-    const f4* srcH = start4 + t_lo * 16;
-    const int64_t last_vec = ntiles * tile_vecs - 1, last_h = ntiles * 16 - 1;
-    auto stage = [&](int64_t ch, int buf) {
-#pragma unroll
-        for (int u = 0; u < kChunkTiles * tile_vecs / (64 * kEmitBW); ++u) {
-            int64_t g = ch * (kChunkTiles * tile_vecs) + u * (64 * kEmitBW) + tid;
-            if (g > last_vec) g = last_vec;                       // the ragged last chunk re-reads the last tile
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcE + g),
-                                             (__attribute__((address_space(3))) void*)(lds_c[buf] + u * (64 * kEmitBW) + wave * 64), 16, 0, 0);
-        }
-        if (tid < kChunkTiles * 16) {                             // whole waves (kChunkTiles*16 is a multiple of 64)
-            int64_t g = ch * (kChunkTiles * 16) + tid;
-            if (g > last_h) g = last_h;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcH + g),
-                                             (__attribute__((address_space(3))) void*)(lds_h[buf] + wave * 64), 16, 0, 0);
-        }
-    };
-    stage(0, 0);
+    const f4* srcE = reinterpret_cast<const f4*>(Eb);
+    const float* srcH = reinterpret_cast<const float*>(start4);
+    int e0 = lst[lane & (G - 1)], e1 = nsteps > 1 ? lst[G + (lane & (G - 1))] : 0;
+    unsigned m0 = lmk[lane & (G - 1)], m1 = nsteps > 1 ? lmk[G + (lane & (G - 1))] : 0u;
+    stage_tiles<CP, kEmitBW, 4>(srcE, srcH, lds_c[0], reinterpret_cast<float*>(lds_h[0]), e0, tid, wave, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int64_t ch = 0; ch < nchunks; ++ch) {
-        const int buf = (int)(ch & 1);
-        if (ch + 1 < nchunks) stage(ch + 1, buf ^ 1);
-        const int ntile = (int)((ntiles - ch * kChunkTiles) < kChunkTiles ? (ntiles - ch * kChunkTiles) : kChunkTiles);
+    for (int step = 0; step < nsteps; ++step) {
+        const int buf = step & 1;
+        int e2 = 0;
+        if (step + 1 < nsteps) stage_tiles<CP, kEmitBW, 4>(srcE, srcH, lds_c[buf ^ 1], reinterpret_cast<float*>(lds_h[buf ^ 1]), e1, tid, wave, lane);
+        unsigned m2 = 0u;
+        if (step + 2 < nsteps) {
+            e2 = lst[(step + 2) * G + (lane & (G - 1))];
+            m2 = lmk[(step + 2) * G + (lane & (G - 1))];
+        }
+        // this wave's tiles of the step (wave-uniform mask)
+        unsigned tmask = (unsigned)__ballot(lane < G && ((m0 >> wave) & 1u)) & ((1u << G) - 1u);
         const f4* tb = lds_c[buf];
+        const f4* th = lds_h[buf];
         static_assert(CP % 32 == 0, "");
         // one compare per pair; the wave-wide masks live in scalar registers
         auto judge = [&](const f4 (&acc)[RT], const int32_t tile) {
@@ -700,39 +450,57 @@ __global__ void __launch_bounds__(64 * kEmitBW) __attribute__((amdgpu_waves_per_
                 }
             }
         };
-        const int32_t tile0 = (int32_t)t_lo + (int32_t)ch * kChunkTiles;
+        auto tile_of = [&](int t) { return (int32_t)__builtin_amdgcn_readlane(e0, t); };
         if (CP == 32) {
-            // operands of the next tile are read from LDS while the current one is on the matrix pipe; two register
+            // operands of the wave's next tile are read from LDS while the current one is on the matrix pipe; two register
             // sets (A, B) alternate, two tiles per trip, so that nothing is copied between them
-            f4 ah_ = tb[lane], al_ = tb[64 + lane], as_ = lds_h[buf][jcol];
-            int t = 0;
-            for (; t + 1 < ntile; t += 2) {
-                const f4 bh_ = tb[(t + 1) * tile_vecs + lane], bl_ = tb[(t + 1) * tile_vecs + 64 + lane], bs_ = lds_h[buf][(t + 1) * 16 + jcol];
-                f4 acc[RT];
-                qt.dots_regs(ah_, al_, as_, acc);
-                judge(acc, tile0 + t);
-                const int t2 = t + 2 < ntile ? t + 2 : t + 1;
-                ah_ = tb[t2 * tile_vecs + lane];
-                al_ = tb[t2 * tile_vecs + 64 + lane];
-                as_ = lds_h[buf][t2 * 16 + jcol];
-                f4 acc2[RT];
-                qt.dots_regs(bh_, bl_, bs_, acc2);
-                judge(acc2, tile0 + t + 1);
-            }
-            if (t < ntile) {
-                f4 acc[RT];
-                qt.dots_regs(ah_, al_, as_, acc);
-                judge(acc, tile0 + t);
+            if (tmask) {
+                int t = __builtin_ctz(tmask);
+                tmask &= tmask - 1u;
+                f4 ah_ = tb[t * tile_vecs + lane], al_ = tb[t * tile_vecs + 64 + lane], as_ = th[t * 16 + jcol];
+                while (true) {
+                    int t1 = -1;
+                    f4 bh_ = ah_, bl_ = al_, bs_ = as_;
+                    if (tmask) {
+                        t1 = __builtin_ctz(tmask);
+                        tmask &= tmask - 1u;
+                        bh_ = tb[t1 * tile_vecs + lane];
+                        bl_ = tb[t1 * tile_vecs + 64 + lane];
+                        bs_ = th[t1 * 16 + jcol];
+                    }
+                    f4 acc[RT];
+                    qt.dots_regs(ah_, al_, as_, acc);
+                    judge(acc, tile_of(t));
+                    if (t1 < 0) break;
+                    t = -1;
+                    if (tmask) {
+                        t = __builtin_ctz(tmask);
+                        tmask &= tmask - 1u;
+                        ah_ = tb[t * tile_vecs + lane];
+                        al_ = tb[t * tile_vecs + 64 + lane];
+                        as_ = th[t * 16 + jcol];
+                    }
+                    f4 acc2[RT];
+                    qt.dots_regs(bh_, bl_, bs_, acc2);
+                    judge(acc2, tile_of(t1));
+                    if (t < 0) break;
+                }
             }
         } else {
-            for (int t = 0; t < ntile; ++t) {
+            while (tmask) {
+                const int t = __builtin_ctz(tmask);
+                tmask &= tmask - 1u;
                 f4 acc[RT];
-                qt.dots_from(tb + t * tile_vecs, lane, lds_h[buf][t * 16 + jcol], acc);
-                judge(acc, tile0 + t);
+                qt.dots_from(tb + t * tile_vecs, lane, th[t * 16 + jcol], acc);
+                judge(acc, tile_of(t));
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the next chunk has landed before anyone crosses the barrier
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the next step has landed before anyone crosses the barrier
         __syncthreads();
+        e0 = e1;
+        e1 = e2;
+        m0 = m1;
+        m1 = m2;
     }
     if (jcol == 0) {
 #pragma unroll
@@ -1051,10 +819,470 @@ int stage_knn_metric(ddx_ctx* ctx, int32_t k, int32_t include_self, int32_t metr
         k_knn_generic<2><<<grid, 256, lds, ctx->stream>>>(X, M, C, k, include_self, ctx->knn_idx.as<int32_t>(), ctx->knn_dist.as<double>());
     DDX_HIP(ctx, hipGetLastError());
     ctx->knn_window_total = nullptr;
+    ctx->knn_overflow = nullptr;
     ctx->K = k;
     ctx->knn_self = include_self != 0;
     ctx->have_knn = true;
     return DDX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Cells: the pruning structure of the emit pass.
+//
+// d(q, c) >= |u.q - u.c| for ANY vector u with |u| <= 1.  The points are grouped into Kc cells (a few rounds of Lloyd's
+// k-means on the 32 leading components, started from evenly spaced ranks of the first-component order) and laid out cell
+// by cell (cells in the order of their centres' first component, first-component order inside a cell).  A 16-point tile
+// has a nominal cell O (the cell of its first point).  For every tile t and every cell c the table S holds the interval
+// of  f_{O,c}(x) = u_{O,c}.x ,  u_{O,c} = (mu_c - mu_O) / |mu_c - mu_O| ,  over the points x of t  (lo / hi, widened by the
+// float32 rounding of the evaluation).  A query tile s (cell A) against a candidate tile t (cell B) along u_{A,B}:
+// the queries lie in [S_lo[s][B], S_hi[s][B]], the candidates in [-S_hi[t][A], -S_lo[t][A]] (u_{B,A} = -u_{A,B});
+// when the gap between the two intervals exceeds sqrt(max T_q of the query tile), no candidate of t can be within
+// reach of a query of s and the pair of tiles is never screened.  The direction between the two cell centres carries
+// their whole separation while a tile's extent along it is one coordinate's worth of spread: on the benchmark
+// embedding (12 cell types, 18 noise components) 15-20 % of the tile pairs survive, against 68 % for windows on the
+// first component alone -- bounding boxes or balls over the leading components prune next to nothing there
+// (profiles/r04_knn_prune_study.txt).  The test along the first component itself is kept beside it (it separates tiles
+// of one cell).  None of this can change the result: the screen stays conservative whatever the cells look like.
+// ------------------------------------------------------------------------------------------------
+constexpr int kCellDim = 32;                 // leading components the cells live in (zero padded)
+constexpr float kCellFix = 1048576.0f;       // fixed-point grid of the centre sums (2^20): integer sums are exact in any order
+constexpr int kCellRounds = 2;               // Lloyd rounds before the final assignment
+
+__device__ __forceinline__ unsigned ordered_bits(float v) {
+    const unsigned u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__global__ void k_cells_init(const float* __restrict__ emb, const int32_t* __restrict__ perm1, int64_t M, int C, int Kc,
+                             float* __restrict__ cen, float* __restrict__ cn) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= Kc) return;
+    int64_t pos = ((int64_t)c * M) / Kc + M / (2 * (int64_t)Kc);
+    if (pos >= M) pos = M - 1;
+    const int64_t src = perm1[pos];
+    float n = 0.f;
+    for (int d = 0; d < kCellDim; ++d) {
+        const float v = d < C ? emb[src * C + d] : 0.f;
+        cen[c * kCellDim + d] = v;
+        n = fmaf(v, v, n);
+    }
+    cn[c] = n;
+}
+
+// nearest centre of every point (ties: the smaller cell id): lane = point, the four waves of a block share the cells out
+__global__ void __launch_bounds__(256) k_cells_assign(const float* __restrict__ emb, int64_t M, int C, const float* __restrict__ cen,
+                                                      const float* __restrict__ cn, int Kc, int32_t* __restrict__ label) {
+    __shared__ unsigned long long best[4][64];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t r = (int64_t)blockIdx.x * 64 + lane;
+    float x[kCellDim];
+#pragma unroll
+    for (int d = 0; d < kCellDim; ++d) x[d] = (r < M && d < C) ? emb[r * C + d] : 0.f;
+    float bs = __builtin_huge_valf();
+    int bc = 0x7fffffff;
+    for (int c = w; c < Kc; c += 4) {
+        const float* mu = cen + (size_t)c * kCellDim;
+        float dot = 0.f;
+#pragma unroll
+        for (int d = 0; d < kCellDim; ++d) dot = fmaf(mu[d], x[d], dot);
+        const float s = fmaf(-2.f, dot, cn[c]);
+        if (s < bs) { bs = s; bc = c; }
+    }
+    best[w][lane] = ((unsigned long long)ordered_bits(bs) << 32) | (unsigned)bc;
+    __syncthreads();
+    if (w == 0 && r < M) {
+        unsigned long long b = best[0][lane];
+#pragma unroll
+        for (int o = 1; o < 4; ++o) b = best[o][lane] < b ? best[o][lane] : b;
+        int c = (int)(unsigned)(b & 0xffffffffull);
+        if (c >= Kc) c = 0;                                   // (NaN coordinates: validated away upstream)
+        label[r] = c;
+    }
+}
+
+__global__ void k_cells_accumulate(const float* __restrict__ emb, int64_t M, int C, const int32_t* __restrict__ label,
+                                   unsigned long long* __restrict__ sums, int32_t* __restrict__ counts) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= M) return;
+    const int c = label[r];
+    const int D = C < kCellDim ? C : kCellDim;
+    for (int d = 0; d < D; ++d) {
+        const long long v = (long long)rintf(emb[r * C + d] * kCellFix);
+        atomicAdd(&sums[(size_t)c * kCellDim + d], (unsigned long long)v);     // two's complement: exact in any order
+    }
+    atomicAdd(&counts[c], 1);
+}
+
+// centre = mean of the members (an empty cell keeps its centre); clears the sums for the next round
+__global__ void k_cells_mean(unsigned long long* __restrict__ sums, int32_t* __restrict__ counts, int Kc, float* __restrict__ cen,
+                             float* __restrict__ cn, int32_t* __restrict__ sizes) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= Kc) return;
+    const int n = counts[c];
+    float nn = 0.f;
+    for (int d = 0; d < kCellDim; ++d) {
+        float v = cen[c * kCellDim + d];
+        if (n > 0) v = (float)((double)(long long)sums[(size_t)c * kCellDim + d] / ((double)n * (double)kCellFix));
+        cen[c * kCellDim + d] = v;
+        nn = fmaf(v, v, nn);
+        sums[(size_t)c * kCellDim + d] = 0ull;
+    }
+    cn[c] = nn;
+    sizes[c] = n;
+    counts[c] = 0;
+}
+
+// cells ordered by the first component of their centres (ties by id): rank, centres re-indexed by rank
+__global__ void __launch_bounds__(1024) k_cells_rank(const float* __restrict__ cen, int Kc, int32_t* __restrict__ rank, float* __restrict__ cenR) {
+    __shared__ float key[1024];
+    const int c = threadIdx.x;
+    if (c < Kc) key[c] = cen[c * kCellDim];
+    __syncthreads();
+    if (c >= Kc) return;
+    int r = 0;
+    const float k = key[c];
+    for (int o = 0; o < Kc; ++o) r += (key[o] < k || (key[o] == k && o < c)) ? 1 : 0;
+    rank[c] = r;
+    for (int d = 0; d < kCellDim; ++d) cenR[r * kCellDim + d] = cen[c * kCellDim + d];
+}
+
+__global__ void k_cells_keys(const int32_t* __restrict__ perm1, const int32_t* __restrict__ label, const int32_t* __restrict__ rank, int64_t M,
+                             uint32_t* __restrict__ keys) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    keys[i] = (uint32_t)rank[label[perm1[i]]];
+}
+
+// 1 / |mu_B - mu_A|, shrunk by 1e-5 so that the direction is no longer than 1 whatever the float32 roundings; 0 on the diagonal
+__global__ void k_cells_invdist(const float* __restrict__ cenR, int Kc, float* __restrict__ invD) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)Kc * Kc) return;
+    const int a = (int)(t / Kc), b = (int)(t % Kc);
+    float d2 = 0.f;
+    for (int d = 0; d < kCellDim; ++d) {
+        const float v = cenR[b * kCellDim + d] - cenR[a * kCellDim + d];
+        d2 = fmaf(v, v, d2);
+    }
+    invD[t] = (a != b && d2 > 0.f) ? (1.0f - 1e-5f) / sqrtf(d2) : 0.f;
+}
+
+// nominal cell and first-component interval of every tile; largest squared norm (float bits, non-negative: integer max)
+__global__ void k_knn_tileinfo(const uint32_t* __restrict__ cellpos, const float* __restrict__ p1, const float* __restrict__ nrm, int64_t M,
+                               int64_t ntiles, int32_t* __restrict__ tilecell, float* __restrict__ tp1lo, float* __restrict__ tp1hi,
+                               unsigned* __restrict__ r2max) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntiles) return;
+    float lo = __builtin_huge_valf(), hi = -__builtin_huge_valf(), nmax = 0.f;
+    for (int j = 0; j < 16; ++j) {
+        const int64_t r = t * 16 + j;
+        if (r >= M) break;
+        lo = fminf(lo, p1[r]);
+        hi = fmaxf(hi, p1[r]);
+        nmax = fmaxf(nmax, nrm[r]);
+    }
+    tilecell[t] = t * 16 < M ? (int32_t)cellpos[t * 16] : 0;
+    tp1lo[t] = lo;
+    tp1hi[t] = hi;
+    if (nmax > 0.f) atomicMax(r2max, __float_as_uint(nmax));
+}
+
+// S[t][c] (and its transpose St[c][t]): interval of u_{O(t),c}.x over the points of tile t, see above.
+// Rounding: every dot product is a 32-term float32 fma chain, |error| <= 1.92e-6 |mu| |x| <= 1.92e-6 R2 (R2 = largest squared
+// norm; the centres are means of points); two of them, times 1/D, plus the roundings of the subtraction and the
+// product (<= 1.2e-7 |f|): the margin 6e-6 R2 / D + 3e-7 |f| covers it with room to spare.
+// Block = 4 waves = 16 tiles; lane = point.  The intervals of 64 cells are collected in LDS and written out in rows.
+__global__ void __launch_bounds__(256) k_knn_slabs(const float* __restrict__ E, int CP, const float* __restrict__ nrm, const int32_t* __restrict__ tilecell,
+                                                   const float* __restrict__ cenR, const float* __restrict__ invD, int Kc, int64_t ntiles,
+                                                   const unsigned* __restrict__ r2max, float* __restrict__ S_lo, float* __restrict__ S_hi,
+                                                   float* __restrict__ St_lo, float* __restrict__ St_hi) {
+    __shared__ float slo[16][65], shi[16][65];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int64_t r = (int64_t)blockIdx.x * 256 + tid;
+    const int64_t tile = r >> 4;
+    const int tl = tid >> 4;                                   // tile of the block
+    const bool pad = !(nrm[r] < __builtin_huge_valf());
+    float x[kCellDim];
+#pragma unroll
+    for (int d = 0; d < kCellDim; ++d) x[d] = E[r * CP + d];
+    const int O = tilecell[tile];
+    float pO = 0.f;
+    {
+        const float* mu = cenR + (size_t)O * kCellDim;
+#pragma unroll
+        for (int d = 0; d < kCellDim; ++d) pO = fmaf(mu[d], x[d], pO);
+    }
+    const float R2 = __uint_as_float(*r2max) * 1.01f;
+    const float* iDrow = invD + (size_t)O * Kc;
+    for (int c0 = 0; c0 < Kc; c0 += 64) {
+        const int cend = (Kc - c0) < 64 ? (Kc - c0) : 64;
+        for (int cc = 0; cc < cend; ++cc) {
+            const int c = c0 + cc;
+            const float* mu = cenR + (size_t)c * kCellDim;
+            float p = 0.f;
+#pragma unroll
+            for (int d = 0; d < kCellDim; ++d) p = fmaf(mu[d], x[d], p);
+            const float iD = iDrow[c];
+            const float f = (p - pO) * iD;
+            const float m = 6e-6f * R2 * iD + 3e-7f * fabsf(f);
+            float lo = pad ? __builtin_huge_valf() : f - m;
+            float hi = pad ? -__builtin_huge_valf() : f + m;
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+                lo = fminf(lo, __shfl_xor(lo, o, 64));
+                hi = fmaxf(hi, __shfl_xor(hi, o, 64));
+            }
+            if ((lane & 15) == 0) { slo[tl][cc] = lo; shi[tl][cc] = hi; }
+        }
+        __syncthreads();
+        // natural layout: 16 rows of `cend` consecutive cells
+        for (int e = tid; e < 16 * 64; e += 256) {
+            const int t = e >> 6, cc = e & 63;
+            const int64_t tg = (int64_t)blockIdx.x * 16 + t;
+            if (cc < cend && tg < ntiles) {
+                S_lo[tg * Kc + c0 + cc] = slo[t][cc];
+                S_hi[tg * Kc + c0 + cc] = shi[t][cc];
+            }
+        }
+        // transposed layout: per cell 16 consecutive tiles
+        for (int e = tid; e < 16 * 64; e += 256) {
+            const int cc = e >> 4, t = e & 15;
+            const int64_t tg = (int64_t)blockIdx.x * 16 + t;
+            if (cc < cend && tg < ntiles) {
+                St_lo[(size_t)(c0 + cc) * ntiles + tg] = slo[t][cc];
+                St_hi[(size_t)(c0 + cc) * ntiles + tg] = shi[t][cc];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// Per emit block (BW waves of 2 query tiles): the list of candidate tiles that at least one of its waves has to screen,
+// elist = the tiles (ascending), emask = those waves, padded with mask-0 entries to a multiple of G (the emit pass's step).
+// A lane tests one candidate tile against its wave's two query tiles; a round covers 64 * BW tiles.
+template <int BW>
+__global__ void __launch_bounds__(64 * BW) k_knn_tilelists(const float* __restrict__ S_lo, const float* __restrict__ S_hi, const float* __restrict__ St_lo,
+                                                           const float* __restrict__ St_hi, const int32_t* __restrict__ tilecell,
+                                                           const float* __restrict__ tp1lo, const float* __restrict__ tp1hi, const float* __restrict__ thr,
+                                                           const float* __restrict__ nrm, int64_t ntiles, int Kc, int G, int32_t* __restrict__ elist,
+                                                           uint32_t* __restrict__ emask, int32_t* __restrict__ ecount, int64_t ecap,
+                                                           unsigned long long* __restrict__ total) {
+    __shared__ unsigned long long wm[BW][BW];
+    __shared__ int wcnt[BW];
+    __shared__ int s_last;
+    if (threadIdx.x == 0) s_last = 0;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t blk = blockIdx.x;
+    const int64_t s0 = (blk * BW + wave) * kEmitRT;                  // first query tile of the wave
+    static_assert(kEmitRT == 2, "two query tiles per wave");
+    // reach of the two query tiles: lanes 0-15 tile s0, lanes 16-31 tile s0 + 1
+    float rs[2];
+    {
+        float r = -__builtin_huge_valf();
+        if (lane < 32) {
+            const int64_t q = s0 * 16 + lane;
+            if (nrm[q] < __builtin_huge_valf()) {
+                const float T = thr[q];
+                r = T < __builtin_huge_valf() ? sqrtf(fmaxf(T, 0.f)) * 1.00001f + 1e-30f : __builtin_huge_valf();
+            }
+        }
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) r = fmaxf(r, __shfl_xor(r, o, 64));
+        rs[0] = __shfl(r, 0, 64);
+        rs[1] = __shfl(r, 16, 64);
+    }
+    int A[2];
+    float q1lo[2], q1hi[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        A[u] = tilecell[s0 + u];
+        q1lo[u] = tp1lo[s0 + u];
+        q1hi[u] = tp1hi[s0 + u];
+    }
+    int32_t* lst = elist + blk * ecap;
+    uint32_t* lmk = emask + blk * ecap;
+    int count = 0;
+    unsigned long long screened = 0;
+    for (int64_t base = 0; base < ntiles; base += 64 * BW) {
+#pragma unroll
+        for (int j = 0; j < BW; ++j) {
+            const int64_t t = base + 64 * j + lane;
+            bool pass = false;
+            if (t < ntiles) {
+                const int B = tilecell[t];
+                const float c1l = tp1lo[t], c1h = tp1hi[t];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const float a = St_lo[(size_t)A[u] * ntiles + t], b = St_hi[(size_t)A[u] * ntiles + t];
+                    const float ql = S_lo[(s0 + u) * Kc + B], qh = S_hi[(s0 + u) * Kc + B];
+                    const float gap = fmaxf(fmaxf(-b - qh, ql + a), fmaxf(c1l - q1hi[u], q1lo[u] - c1h));
+                    pass = pass || !(gap > rs[u]);
+                }
+            }
+            const unsigned long long m = __ballot(pass);
+            if (lane == 0) wm[wave][j] = m;
+        }
+        __syncthreads();
+        // thread (wave j, lane) owns tile base + 64 j + lane: collect the waves that screen it
+        unsigned mask = 0;
+#pragma unroll
+        for (int w = 0; w < BW; ++w) mask |= (unsigned)((wm[w][wave] >> lane) & 1ull) << w;
+        const unsigned long long anyb = __ballot(mask != 0u);
+        if (lane == 0) wcnt[wave] = __popcll(anyb);
+        __syncthreads();
+        int before = 0, all = 0;
+#pragma unroll
+        for (int w = 0; w < BW; ++w) {
+            const int c = wcnt[w];
+            before += w < wave ? c : 0;
+            all += c;
+        }
+        if (mask != 0u) {
+            const int64_t t = base + 64 * wave + lane;
+            const int slot = count + before + __popcll(anyb & ((1ull << lane) - 1ull));
+            lst[slot] = (int32_t)t;
+            lmk[slot] = mask;
+            screened += (unsigned long long)__popc(mask);
+        }
+        if (mask != 0u) atomicMax(&s_last, (int)(base + 64 * wave + lane));      // the padding repeats the last listed tile
+        count += all;
+        __syncthreads();
+    }
+    const int lt_all = s_last;
+    const int padded = (count + G - 1) / G * G;
+    if (tid < padded - count) { lst[count + tid] = lt_all; lmk[count + tid] = 0; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) screened += __shfl_xor(screened, o, 64);
+    if (lane == 0) atomicAdd(total, screened);                       // statistics only (bench.py's flop count)
+    if (tid == 0) ecount[blk] = padded;
+}
+
+// Cells by distance from cell A (one block per cell, Kc <= 1024 threads' worth): nlist[A][*] = tiles of the other cells, nearest
+// cell first, up to `budget` tiles; ncount[A] = how many.  ctile[c] = first tile whose nominal cell is c (ctile[Kc] = number of
+// real tiles).
+__global__ void __launch_bounds__(1024) k_cells_neighbours(const float* __restrict__ cenR, const int32_t* __restrict__ ctile, int Kc, int budget,
+                                                           int32_t* __restrict__ nlist, int32_t* __restrict__ ncount) {
+    __shared__ float dist[1024];
+    __shared__ int order[1024];
+    __shared__ int cum[1025];
+    const int A = blockIdx.x, c = threadIdx.x;
+    if (c < Kc) {
+        float d2 = 0.f;
+        for (int d = 0; d < kCellDim; ++d) {
+            const float v = cenR[c * kCellDim + d] - cenR[A * kCellDim + d];
+            d2 = fmaf(v, v, d2);
+        }
+        dist[c] = c == A ? -1.f : d2;
+    }
+    __syncthreads();
+    if (c < Kc) {
+        const float k = dist[c];
+        int r = 0;
+        for (int o = 0; o < Kc; ++o) r += (dist[o] < k || (dist[o] == k && o < c)) ? 1 : 0;
+        order[r] = c;                                               // order[0] = A
+    }
+    __syncthreads();
+    // inclusive prefix of the tile counts in that order (cell A itself counts nothing)
+    int mine = 0;
+    if (c < Kc && c > 0) { const int cell = order[c]; mine = ctile[cell + 1] - ctile[cell]; }
+    cum[c + 1] = mine;
+    if (c == 0) cum[0] = 0;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int add = c + 1 > o ? cum[c + 1 - o] : 0;
+        __syncthreads();
+        cum[c + 1] += add;
+        __syncthreads();
+    }
+    if (c < Kc && c > 0) {
+        const int cell = order[c], start = cum[c];                   // tiles of the cells before this one
+        const int t0 = ctile[cell], nt = ctile[cell + 1] - t0;
+        for (int j = 0; j < nt && start + j < budget; ++j) nlist[(size_t)A * budget + start + j] = t0 + j;
+    }
+    if (c == 0) ncount[A] = cum[Kc] < budget ? cum[Kc] : budget;
+}
+
+// Sample of every bound block (128 queries = 8 tiles, which may lie in two cells): the tiles of its own cell(s) around it
+// (a cell is in first-component order), then the tiles of the cells nearest to its first and to its last cell, taken in turn,
+// nsamp tiles in all where there are that many.  No tile may be listed twice (the k-th smallest of a multiset is not a
+// bound): a bitmap over the tiles in LDS (dynamic, ceil(ntiles / 32) words) keeps track.
+__global__ void __launch_bounds__(64) k_knn_boundlists(const int32_t* __restrict__ tilecell, const int32_t* __restrict__ ctile, const int32_t* __restrict__ nlist,
+                                                       const int32_t* __restrict__ ncount, int Kc, int budget, int nsamp, int ntr, int every,
+                                                       int32_t* __restrict__ blist, int32_t* __restrict__ bcount) {
+    extern __shared__ unsigned seen[];
+    const int64_t b = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int t_blk = (int)(b * 4 * kBoundRT);
+    const int t_end = min(t_blk + 4 * kBoundRT, ntr);              // real tiles of the block
+    for (int i = lane; i < (ntr + 31) / 32; i += 64) seen[i] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    int32_t* dst = blist + b * (int64_t)nsamp;
+    if (t_blk >= ntr) {                                            // a block of padding queries
+        if (lane == 0) bcount[b] = 0;
+        return;
+    }
+    const int A0 = tilecell[t_blk], A1 = tilecell[t_end - 1];
+    const int ts = ctile[A0], te = ctile[A1 + 1];
+    const int others = Kc > 1 ? ncount[A0] + (A1 != A0 ? ncount[A1] : 0) : 0;
+    int own = te - ts;
+    if (own > nsamp) own = nsamp;
+    if (others >= nsamp / 2 && own > nsamp / 2) own = nsamp / 2;     // big cells leave half of the sample to their neighbours
+    int lo = (t_blk + t_end) / 2 - own / 2;
+    if (lo > te - own) lo = te - own;
+    if (lo < ts) lo = ts;
+    for (int i = lane; i < own; i += 64) {
+        dst[i] = lo + i;
+        atomicOr(&seen[(lo + i) >> 5], 1u << ((lo + i) & 31));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    int count = own;
+    // every `every`-th tile of the whole set: whatever the cells look like, a uniform sample of a 1/every share of the points
+    // bounds the k-th distance by the (k * every)-th one -- it is what keeps a query that lies far from its own cell from
+    // collecting tens of thousands of candidates
+    if (Kc > 1 && every > 0) {
+        for (int base = (int)(b % every); base < ntr && count < nsamp; base += 64 * every) {
+            const int t = base + lane * every;
+            bool keep = false;
+            if (t < ntr) {
+                const unsigned bit = 1u << (t & 31);
+                keep = (atomicOr(&seen[t >> 5], bit) & bit) == 0u;
+            }
+            const unsigned long long m = __ballot(keep);
+            const int pos = count + __popcll(m & ((1ull << lane) - 1ull));
+            if (keep && pos < nsamp) dst[pos] = t;
+            count += __popcll(m);
+            if (count > nsamp) count = nsamp;
+        }
+    }
+    if (Kc > 1) {
+        const int n0 = ncount[A0], n1 = A1 != A0 ? ncount[A1] : 0;
+        const int32_t* l0 = nlist + (size_t)A0 * budget;
+        const int32_t* l1 = nlist + (size_t)A1 * budget;
+        for (int base = 0; (base < n0 || base < n1) && count < nsamp; base += 64) {
+#pragma unroll
+            for (int which = 0; which < 2; ++which) {
+                const int n = which ? n1 : n0;
+                const int32_t* l = which ? l1 : l0;
+                bool keep = false;
+                int e = 0;
+                if (base + lane < n) {
+                    e = l[base + lane];
+                    const int t = e;
+                    const unsigned bit = 1u << (t & 31);
+                    keep = (atomicOr(&seen[t >> 5], bit) & bit) == 0u;       // tiles of one list are distinct: no two lanes race for a bit
+                }
+                const unsigned long long m = __ballot(keep);
+                const int pos = count + __popcll(m & ((1ull << lane) - 1ull));
+                if (keep && pos < nsamp) dst[pos] = e;
+                count += __popcll(m);
+                if (count > nsamp) count = nsamp;
+            }
+        }
+    }
+    if (lane == 0) bcount[b] = count;
 }
 
 // sort key of the point order: the first principal component
@@ -1065,43 +1293,21 @@ __global__ void k_knn_keys(const float* __restrict__ emb, int64_t M, int C, floa
     ids[r] = (int32_t)r;
 }
 
-// Candidate window of one emit block (its 4*16*kEmitRT consecutive queries in first-component order): a candidate c
-// can only matter for query q if d2(q,c) <= T_q, and d2(q,c) >= (q_1 - c_1)^2, so c_1 must lie within sqrt(T_q) of
-// q_1.  Points are sorted by that component, hence the admissible candidates of the whole block form one contiguous
-// range of tiles [win[2b], win[2b+1]).  The radius carries a 1e-5 relative margin for the float32 square root.
-template <int BW>      // waves (of 16 * kEmitRT queries) per emit block
-__global__ void __launch_bounds__(64) k_knn_window(const float* __restrict__ p1, const float* __restrict__ thr, const float* __restrict__ nrm,
-                                                   int64_t Mp, int32_t* __restrict__ win, unsigned long long* __restrict__ total_tiles) {
-    constexpr int QB = BW * 16 * kEmitRT;
-    const int lane = threadIdx.x;
-    const int64_t qb = (int64_t)blockIdx.x * QB;
-    float lo = __builtin_huge_valf(), hi = -__builtin_huge_valf();
-    for (int t = lane; t < QB; t += 64) {
-        const int64_t q = qb + t;
-        if (!(nrm[q] < __builtin_huge_valf())) continue;          // padding query
-        const float T = thr[q];
-        const float x = p1[q];
-        const float r = T < __builtin_huge_valf() ? sqrtf(fmaxf(T, 0.f)) * 1.00001f + fabsf(x) * 2.4e-7f + 1e-30f : __builtin_huge_valf();
-        lo = fminf(lo, x - r);
-        hi = fmaxf(hi, x + r);
-    }
-    for (int o = 32; o > 0; o >>= 1) {
-        lo = fminf(lo, __shfl_xor(lo, o, 64));
-        hi = fmaxf(hi, __shfl_xor(hi, o, 64));
-    }
-    if (lane != 0) return;
-    int64_t first = 0, last = 0;
-    if (lo <= hi) {
-        int64_t a = 0, b = Mp;                       // first position with p1 >= lo
-        while (a < b) { const int64_t m = (a + b) >> 1; if (p1[m] < lo) a = m + 1; else b = m; }
-        first = a;
-        a = first; b = Mp;                           // first position with p1 > hi
-        while (a < b) { const int64_t m = (a + b) >> 1; if (p1[m] <= hi) a = m + 1; else b = m; }
-        last = a;
-    }
-    win[2 * blockIdx.x] = (int32_t)(first >> 4);
-    win[2 * blockIdx.x + 1] = (int32_t)((last + 15) >> 4);
-    atomicAdd(total_tiles, (unsigned long long)(((last + 15) >> 4) - (first >> 4)));     // statistics only (bench.py's flop count)
+// number of cells for M points: cells of about 320 points (20 tiles), at most 1024; small inputs keep the plain
+// first-component order (one cell: the tile test reduces to the first-component windows)
+static int default_cells(int64_t M) {
+    if (M < 16384) return 1;
+    const int64_t want = ceil_div(ceil_div(M, 320), 64) * 64;
+    return (int)std::min<int64_t>(1024, std::max<int64_t>(64, want));
+}
+
+// first tile whose nominal cell is >= c (the nominal cells ascend along the tiles): ctile[0..Kc], ctile[Kc] = real tiles
+__global__ void k_cells_tilestart(const int32_t* __restrict__ tilecell, int ntr, int Kc, int32_t* __restrict__ ctile) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c > Kc) return;
+    int a = 0, b = ntr;
+    while (a < b) { const int m = (a + b) >> 1; if (tilecell[m] < c) a = m + 1; else b = m; }
+    ctile[c] = a;
 }
 
 int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
@@ -1110,109 +1316,188 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
     if (C > kMaxDim) return set_err(ctx, DDX_E_UNSUPPORTED, "embedding dimension %d exceeds %d", C, kMaxDim);
     constexpr int kMaxK = 256;
     if (k > kMaxK) return set_err(ctx, DDX_E_UNSUPPORTED, "k=%d exceeds %d", k, kMaxK);
-    // k beyond what one bound launch ranks (16 lanes x (kBoundKeepLarge - 1) kept values per query): the sample window is
-    // dealt out over `groups` launches, each bounding the ceil(k / groups)-th neighbour among its share (k_knn_bound)
+    if (M >= ((int64_t)1 << 24)) return set_err(ctx, DDX_E_UNSUPPORTED, "kNN of %lld points (the bound lists' bitmap holds 2^24)", (long long)M);
+    // k beyond what one bound launch ranks (16 lanes x (kBoundKeepLarge - 1) kept values per query): the sample is
+    // dealt out over `groups` launches, each bounding the ceil(k / groups)-th neighbour among its share (k_knn_bound_bf)
     const int groups = (int)ceil_div(k, 16 * (kBoundKeepLarge - 1));
     const int k_bound = (int)ceil_div(k, groups);
     const bool keep_small = k_bound <= 16 * (kBoundKeepSmall - 1);
     const int cap = k <= 16 * (kBoundKeepLarge - 1) ? kCandCap : kCandCapLarge;      // candidate slots per query
     const int CP = (C <= 32) ? 32 : (C <= 64 ? 64 : 128);
-    const int64_t Mp = ceil_div(M, 256) * 256;                 // whole blocks of queries in both MFMA passes
-    // workspace (reuses the PCA row buffer): E [Mp*CP] | Et [Mp*CP] | Eb [Mp*CP as bf16 hi+lo] | nrm [Mp] | thr [Mp] | p1 [Mp] | keys [2*Mp]
-    //            | ccount [Mp+64] | ids [2*Mp] | win [2*blocks] | cbuf [Mp*cap]
-    const size_t f_words = (size_t)Mp * CP * 3 + 9 * (size_t)Mp + 16;
-    const bool wide = ctx->opt.knn_bf16 && M >= kEmitWideFrom && !getenv("DDX_KNN_EMIT_NARROW");     // 8-wave emit blocks
-    const int64_t emit_blocks = Mp / ((wide ? 8 : 4) * 16 * kEmitRT);
-    const int xcd_chunk = ctx->opt.knn_xcd_chunk;                                  // DDX_KNN_XCD_CHUNK (0: workgroups in launch order)
-    const bool fold = ctx->opt.knn_bf16 && ctx->opt.knn_fold && C <= 30;          // threshold folded into the operands (k_knn_fold)
-    const size_t i_words = (size_t)Mp + 64 + 2 * (size_t)Mp + 2 * (size_t)emit_blocks + 64 + (size_t)Mp * cap + (fold ? (size_t)Mp * 32 + 16 : 0);
+    const int G = chunk_tiles(CP);                               // tiles per staged step
+    const int64_t Mp = ceil_div(M, 512) * 512;                 // whole blocks of queries in both MFMA passes
+    const int64_t ntiles = Mp >> 4;
+    const int ntr = (int)ceil_div(M, 16);                        // tiles that hold points
+    int Kc = ctx->opt.knn_cells > 0 ? ctx->opt.knn_cells : default_cells(M);
+    if (Kc > 1024) Kc = 1024;
+    if ((int64_t)Kc > M) Kc = (int)std::max<int64_t>(1, M);
+    int BW = ctx->opt.knn_emit_waves;                            // waves per emit block (they share the staged tiles)
+    if (BW != 4 && BW != 8 && BW != 16) BW = kEmitWaves;
+    const int64_t emit_blocks = Mp / (BW * 16 * kEmitRT);
+    const int64_t bound_blocks = Mp / (4 * 16 * kBoundRT);
+    const int xcd_chunk = ctx->opt.knn_xcd_chunk;                                  // 0: workgroups in launch order
+    const bool fold = ctx->opt.knn_fold && C <= 30;                                // threshold folded into the operands (k_knn_fold)
+    // sample of the bound pass: grows with the point count (1/16 of the tiles, at least 512) -- a fixed-size subset would hold
+    // an ever smaller share of the true neighbours, T_q would loosen and the candidate lists overflow
+    int64_t nsamp = std::max<int64_t>(512, ntiles / 16);
+    if (ctx->opt.knn_sample_tiles > 0) nsamp = ctx->opt.knn_sample_tiles;
+    if (nsamp < 2 * (int64_t)ceil_div(k, 16) + 8) nsamp = 2 * (int64_t)ceil_div(k, 16) + 8;
+    if (nsamp > ntr) nsamp = ntr;
+    // workspace (reuses the PCA row buffer): E [Mp*CP] | Eb [Mp*CP as bf16 hi+lo] | nrm [Mp] | thr [Mp] | p1 [Mp] | keys [2*Mp]
+    //            | start4 [4*Mp] | ccount [Mp+64] | ids [2*Mp] | cbuf [Mp*cap] | Ebq
+    const size_t f_words = (size_t)Mp * CP * 2 + 9 * (size_t)Mp + 16;
+    const size_t i_words = (size_t)Mp + 64 + 2 * (size_t)Mp + 64 + (size_t)Mp * cap + (fold ? (size_t)Mp * 32 + 16 : 0);
     DDX_TRY(ensure(ctx, ctx->pcaA, sizeof(float) * f_words + sizeof(int32_t) * i_words + 256));
     DDX_TRY(ensure(ctx, ctx->knn_idx, sizeof(int32_t) * (size_t)M * k));
     DDX_TRY(ensure(ctx, ctx->knn_dist, sizeof(double) * (size_t)M * k));
     float* E = ctx->pcaA.as<float>();
-    float* Et = E + (size_t)Mp * CP;
-    __bf16* Eb = reinterpret_cast<__bf16*>(Et + (size_t)Mp * CP);      // 2 parts x 2 bytes = CP floats per point
-    float* nrm = Et + 2 * (size_t)Mp * CP;
+    __bf16* Eb = reinterpret_cast<__bf16*>(E + (size_t)Mp * CP);       // 2 parts x 2 bytes = CP floats per point
+    float* nrm = E + 2 * (size_t)Mp * CP;
     float* thr = nrm + Mp;
     float* p1 = thr + Mp;
     float* keys_in = p1 + Mp;
     float* keys_out = keys_in + Mp;
-    f4* start4 = reinterpret_cast<f4*>(keys_out + Mp + ((4 - ((3 * (size_t)Mp * CP + 5 * (size_t)Mp) & 3)) & 3));   // 16-byte aligned
-    const bool bf = ctx->opt.knn_bf16;                                  // DDX_KNN_SCREEN=f32 selects the float32 MFMA screen
+    f4* start4 = reinterpret_cast<f4*>(keys_out + Mp + ((4 - ((2 * (size_t)Mp * CP + 5 * (size_t)Mp) & 3)) & 3));   // 16-byte aligned
     int32_t* ccount = reinterpret_cast<int32_t*>(reinterpret_cast<float*>(start4) + 4 * (size_t)Mp);   // [Mp] + overflow counter at [Mp]
     int32_t* ids_in = ccount + Mp + 64;
     int32_t* perm = ids_in + Mp;
-    int32_t* win = perm + Mp;
-    int32_t* cbuf = win + 2 * emit_blocks + 64;
+    int32_t* cbuf = perm + Mp + 64;
     __bf16* Ebq = reinterpret_cast<__bf16*>((reinterpret_cast<uintptr_t>(cbuf + (size_t)Mp * cap) + 15) & ~(uintptr_t)15);   // query operands of the folded emit pass
-    // Order the points by their first principal component (stable radix sort: ties by id).  Every pass below works
-    // in that order: a query's neighbours are then confined to a window of positions around it (k_knn_window).
+    // cell work space (a buffer of its own)
+    const int64_t ecap = ntiles + 8;
+    size_t cw = 0;
+    auto carve = [&](size_t bytes) { const size_t o = cw; cw += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_label = carve(sizeof(int32_t) * (size_t)M), o_kin = carve(sizeof(uint32_t) * (size_t)M), o_cellpos = carve(sizeof(uint32_t) * (size_t)M);
+    const size_t o_perm1 = carve(sizeof(int32_t) * (size_t)M);
+    const size_t o_cen = carve(sizeof(float) * (size_t)Kc * kCellDim), o_cenR = carve(sizeof(float) * (size_t)Kc * kCellDim), o_cn = carve(sizeof(float) * (size_t)Kc);
+    const size_t o_sums = carve(sizeof(unsigned long long) * (size_t)Kc * kCellDim), o_counts = carve(sizeof(int32_t) * (size_t)Kc + 16);
+    const size_t o_sizes = carve(sizeof(int32_t) * (size_t)Kc), o_rank = carve(sizeof(int32_t) * (size_t)Kc), o_invD = carve(sizeof(float) * (size_t)Kc * Kc);
+    const size_t o_ctile = carve(sizeof(int32_t) * ((size_t)Kc + 1)), o_ncount = carve(sizeof(int32_t) * (size_t)Kc), o_nlist = carve(sizeof(int32_t) * (size_t)Kc * nsamp);
+    const size_t o_tilecell = carve(sizeof(int32_t) * (size_t)ntiles), o_t1lo = carve(sizeof(float) * (size_t)ntiles), o_t1hi = carve(sizeof(float) * (size_t)ntiles);
+    const size_t o_Slo = carve(sizeof(float) * (size_t)ntiles * Kc), o_Shi = carve(sizeof(float) * (size_t)ntiles * Kc);
+    const size_t o_Stlo = carve(sizeof(float) * (size_t)ntiles * Kc), o_Sthi = carve(sizeof(float) * (size_t)ntiles * Kc);
+    const size_t o_blist = carve(sizeof(int32_t) * (size_t)bound_blocks * nsamp), o_bcount = carve(sizeof(int32_t) * (size_t)bound_blocks);
+    const size_t o_elist = carve(sizeof(int32_t) * (size_t)emit_blocks * ecap), o_emask = carve(sizeof(uint32_t) * (size_t)emit_blocks * ecap);
+    const size_t o_ecount = carve(sizeof(int32_t) * (size_t)emit_blocks);
+    DDX_TRY(ensure(ctx, ctx->knn_cells, cw));
+    char* cb = ctx->knn_cells.as<char>();
+    int32_t* label = reinterpret_cast<int32_t*>(cb + o_label);
+    uint32_t* kin = reinterpret_cast<uint32_t*>(cb + o_kin);
+    uint32_t* cellpos = reinterpret_cast<uint32_t*>(cb + o_cellpos);
+    int32_t* perm1 = reinterpret_cast<int32_t*>(cb + o_perm1);
+    float* cen = reinterpret_cast<float*>(cb + o_cen);
+    float* cenR = reinterpret_cast<float*>(cb + o_cenR);
+    float* cn = reinterpret_cast<float*>(cb + o_cn);
+    unsigned long long* sums = reinterpret_cast<unsigned long long*>(cb + o_sums);
+    int32_t* counts = reinterpret_cast<int32_t*>(cb + o_counts);       // [Kc] + largest squared norm (float bits) at [Kc + 1]
+    unsigned* r2max = reinterpret_cast<unsigned*>(counts + Kc + 1);
+    int32_t* sizes = reinterpret_cast<int32_t*>(cb + o_sizes);
+    int32_t* rank = reinterpret_cast<int32_t*>(cb + o_rank);
+    float* invD = reinterpret_cast<float*>(cb + o_invD);
+    int32_t* ctile = reinterpret_cast<int32_t*>(cb + o_ctile);
+    int32_t* ncount = reinterpret_cast<int32_t*>(cb + o_ncount);
+    int32_t* nlist = reinterpret_cast<int32_t*>(cb + o_nlist);
+    int32_t* tilecell = reinterpret_cast<int32_t*>(cb + o_tilecell);
+    float* t1lo = reinterpret_cast<float*>(cb + o_t1lo);
+    float* t1hi = reinterpret_cast<float*>(cb + o_t1hi);
+    float* S_lo = reinterpret_cast<float*>(cb + o_Slo);
+    float* S_hi = reinterpret_cast<float*>(cb + o_Shi);
+    float* St_lo = reinterpret_cast<float*>(cb + o_Stlo);
+    float* St_hi = reinterpret_cast<float*>(cb + o_Sthi);
+    int32_t* blist = reinterpret_cast<int32_t*>(cb + o_blist);
+    int32_t* bcount = reinterpret_cast<int32_t*>(cb + o_bcount);
+    int32_t* elist = reinterpret_cast<int32_t*>(cb + o_elist);
+    uint32_t* emask = reinterpret_cast<uint32_t*>(cb + o_emask);
+    int32_t* ecount = reinterpret_cast<int32_t*>(cb + o_ecount);
+    const float* emb = ctx->emb32.as<float>();
+    // Order of the points: cell by cell, first principal component inside a cell (stable radix sorts: ties by id).  Every
+    // pass below works in that order.
     {
         ScopedTimer t(ctx, "knn_prepare");
-        k_knn_keys<<<(unsigned)ceil_div(M, 256), 256, 0, ctx->stream>>>(ctx->emb32.as<float>(), M, C, keys_in, ids_in);
+        k_knn_keys<<<(unsigned)ceil_div(M, 256), 256, 0, ctx->stream>>>(emb, M, C, keys_in, ids_in);
         size_t tmp_bytes = 0;
-        DDX_HIP(ctx, prim::sort_pairs(nullptr, tmp_bytes, keys_in, keys_out, ids_in, perm, (int)M, 0, 32, ctx->stream));
+        DDX_HIP(ctx, prim::sort_pairs(nullptr, tmp_bytes, keys_in, keys_out, ids_in, Kc > 1 ? perm1 : perm, (int)M, 0, 32, ctx->stream));
         DDX_TRY(ensure(ctx, ctx->sort_tmp, tmp_bytes));
-        DDX_HIP(ctx, prim::sort_pairs(ctx->sort_tmp.p, tmp_bytes, keys_in, keys_out, ids_in, perm, (int)M, 0, 32, ctx->stream));
-        k_knn_prepare<<<(unsigned)ceil_div(Mp, 256), 256, 0, ctx->stream>>>(ctx->emb32.as<float>(), perm, M, Mp, C, CP, E, Et, Eb, nrm, p1, start4);
+        DDX_HIP(ctx, prim::sort_pairs(ctx->sort_tmp.p, tmp_bytes, keys_in, keys_out, ids_in, Kc > 1 ? perm1 : perm, (int)M, 0, 32, ctx->stream));
+        DDX_HIP(ctx, hipMemsetAsync(sums, 0, sizeof(unsigned long long) * (size_t)Kc * kCellDim, ctx->stream));
+        DDX_HIP(ctx, hipMemsetAsync(counts, 0, sizeof(int32_t) * (size_t)Kc + 16, ctx->stream));
+    }
+    if (Kc > 1) {
+        ScopedTimer t(ctx, "knn_cells");
+        const unsigned gK = (unsigned)ceil_div(Kc, 256), gM = (unsigned)ceil_div(M, 256), gA = (unsigned)ceil_div(M, 64);
+        k_cells_init<<<gK, 256, 0, ctx->stream>>>(emb, perm1, M, C, Kc, cen, cn);
+        for (int round = 0; round <= kCellRounds; ++round) {
+            k_cells_assign<<<gA, 256, 0, ctx->stream>>>(emb, M, C, cen, cn, Kc, label);
+            k_cells_accumulate<<<gM, 256, 0, ctx->stream>>>(emb, M, C, label, sums, counts);
+            k_cells_mean<<<gK, 256, 0, ctx->stream>>>(sums, counts, Kc, cen, cn, sizes);
+        }
+        k_cells_rank<<<1, 1024, 0, ctx->stream>>>(cen, Kc, rank, cenR);
+        k_cells_keys<<<gM, 256, 0, ctx->stream>>>(perm1, label, rank, M, kin);
+        int bits = 1;
+        while ((1 << bits) < Kc) ++bits;
+        size_t tb2 = 0;
+        DDX_HIP(ctx, prim::sort_pairs(nullptr, tb2, kin, cellpos, perm1, perm, (int)M, 0, bits, ctx->stream));
+        DDX_TRY(ensure(ctx, ctx->sort_tmp, tb2));
+        DDX_HIP(ctx, prim::sort_pairs(ctx->sort_tmp.p, tb2, kin, cellpos, perm1, perm, (int)M, 0, bits, ctx->stream));
+        k_cells_invdist<<<(unsigned)ceil_div((int64_t)Kc * Kc, 256), 256, 0, ctx->stream>>>(cenR, Kc, invD);
+    } else {
+        DDX_HIP(ctx, hipMemsetAsync(cellpos, 0, sizeof(uint32_t) * (size_t)M, ctx->stream));
+        DDX_HIP(ctx, hipMemsetAsync(cenR, 0, sizeof(float) * kCellDim, ctx->stream));
+        DDX_HIP(ctx, hipMemsetAsync(invD, 0, sizeof(float), ctx->stream));
+    }
+    {
+        ScopedTimer t(ctx, "knn_tables");
+        k_knn_prepare<<<(unsigned)ceil_div(Mp, 256), 256, 0, ctx->stream>>>(emb, perm, M, Mp, C, CP, E, Eb, nrm, p1, start4);
+        k_knn_tileinfo<<<(unsigned)ceil_div(ntiles, 256), 256, 0, ctx->stream>>>(cellpos, p1, nrm, M, ntiles, tilecell, t1lo, t1hi, r2max);
+        k_cells_tilestart<<<(unsigned)ceil_div(Kc + 1, 256), 256, 0, ctx->stream>>>(tilecell, ntr, Kc, ctile);
+        if (Kc > 1) k_cells_neighbours<<<(unsigned)Kc, 1024, 0, ctx->stream>>>(cenR, ctile, Kc, (int)nsamp, nlist, ncount);
+        k_knn_boundlists<<<(unsigned)bound_blocks, 64, sizeof(unsigned) * (size_t)((ntr + 31) / 32 + 1), ctx->stream>>>(tilecell, ctile, nlist, ncount, Kc, (int)nsamp, (int)nsamp, ntr, ctx->opt.knn_sample_every, blist, bcount);
+        k_knn_slabs<<<(unsigned)(Mp / 256), 256, 0, ctx->stream>>>(E, CP, nrm, tilecell, cenR, invD, Kc, ntiles, r2max, S_lo, S_hi, St_lo, St_hi);
     }
     DDX_HIP(ctx, hipMemsetAsync(ccount, 0, sizeof(int32_t) * (Mp + 64), ctx->stream));
-    // Bound pass: the K-th smallest distance inside the nsamp tiles nearest to the query in first-component order is
-    // an upper bound of its true K-th distance (any subset gives one; this subset holds most of the true neighbours).
-    const int64_t ntiles = Mp >> 4;
-    // The subset grows with the point count (1/16 of the tiles, at least 512): a fixed-size subset would hold an ever
-    // smaller share of the true neighbours, T_q would loosen and the candidate lists overflow.
-    int64_t nsamp = std::max<int64_t>(512, ntiles / 16);
-    if (ctx->opt.knn_sample_tiles > 0) nsamp = ctx->opt.knn_sample_tiles;
-    if (nsamp < 2 * (int64_t)ceil_div(k, 16) + 8) nsamp = 2 * (int64_t)ceil_div(k, 16) + 8;
-    if (nsamp > ntiles) nsamp = ntiles;
-    const int64_t stride = groups;
-    const int64_t nsamp_g = std::max<int64_t>(1, nsamp / groups);                    // tiles per launch
     {
         ScopedTimer t(ctx, "knn_bound");
-        const int64_t nb_bound = Mp / (4 * 16 * kBoundRT);
-        const unsigned grid = (unsigned)(bf && xcd_chunk > 0 ? ceil_div(nb_bound, 8 * (int64_t)xcd_chunk) * 8 * xcd_chunk : nb_bound);
-#define DDX_BOUND_LAUNCH(KERNEL, OPERAND)                                                                                        \
-    do {                                                                                                                       \
-        for (int g = 0; g < groups; ++g) {                                                                                     \
-            if (CP == 32 && keep_small) KERNEL<32, kBoundKeepSmall><<<grid, 256, 0, ctx->stream>>>(OPERAND, nrm, Mp, k_bound, include_self, nsamp_g, stride, g, g > 0, thr XCDARG); \
-            else if (CP == 32) KERNEL<32, kBoundKeepLarge><<<grid, 256, 0, ctx->stream>>>(OPERAND, nrm, Mp, k_bound, include_self, nsamp_g, stride, g, g > 0, thr XCDARG);      \
-            else if (CP == 64 && keep_small) KERNEL<64, kBoundKeepSmall><<<grid, 256, 0, ctx->stream>>>(OPERAND, nrm, Mp, k_bound, include_self, nsamp_g, stride, g, g > 0, thr XCDARG); \
-            else if (CP == 64) KERNEL<64, kBoundKeepLarge><<<grid, 256, 0, ctx->stream>>>(OPERAND, nrm, Mp, k_bound, include_self, nsamp_g, stride, g, g > 0, thr XCDARG);      \
-            else if (keep_small) KERNEL<128, kBoundKeepSmall><<<grid, 256, 0, ctx->stream>>>(OPERAND, nrm, Mp, k_bound, include_self, nsamp_g, stride, g, g > 0, thr XCDARG);    \
-            else KERNEL<128, kBoundKeepLarge><<<grid, 256, 0, ctx->stream>>>(OPERAND, nrm, Mp, k_bound, include_self, nsamp_g, stride, g, g > 0, thr XCDARG);                    \
-        }                                                                                                                      \
-    } while (0)
-#define XCDARG , xcd_chunk
-        if (bf) DDX_BOUND_LAUNCH(k_knn_bound_bf, Eb);
-#undef XCDARG
-#define XCDARG
-        else DDX_BOUND_LAUNCH(k_knn_bound, Et);
-#undef XCDARG
-#undef DDX_BOUND_LAUNCH
+        const unsigned grid = (unsigned)(xcd_chunk > 0 ? ceil_div(bound_blocks, 8 * (int64_t)xcd_chunk) * 8 * xcd_chunk : bound_blocks);
+        for (int g = 0; g < groups; ++g) {
+#define DDX_BOUND(CPV, KEEP) k_knn_bound_bf<CPV, KEEP><<<grid, 256, 0, ctx->stream>>>(Eb, nrm, Mp, k_bound, include_self, blist, bcount, nsamp, groups, g, g > 0, thr, xcd_chunk)
+            if (CP == 32 && keep_small) DDX_BOUND(32, kBoundKeepSmall);
+            else if (CP == 32) DDX_BOUND(32, kBoundKeepLarge);
+            else if (CP == 64 && keep_small) DDX_BOUND(64, kBoundKeepSmall);
+            else if (CP == 64) DDX_BOUND(64, kBoundKeepLarge);
+            else if (keep_small) DDX_BOUND(128, kBoundKeepSmall);
+            else DDX_BOUND(128, kBoundKeepLarge);
+#undef DDX_BOUND
+        }
+    }
+    unsigned long long* wtotal = reinterpret_cast<unsigned long long*>(ccount + Mp + 2);
+    {
+        ScopedTimer t(ctx, "knn_lists");
+        const unsigned grid = (unsigned)emit_blocks;
+#define DDX_LISTS(BWV) k_knn_tilelists<BWV><<<grid, 64 * BWV, 0, ctx->stream>>>(S_lo, S_hi, St_lo, St_hi, tilecell, t1lo, t1hi, thr, nrm, ntiles, Kc, G, elist, emask, ecount, ecap, wtotal)
+        if (BW == 16) DDX_LISTS(16);
+        else if (BW == 8) DDX_LISTS(8);
+        else DDX_LISTS(4);
+#undef DDX_LISTS
     }
     {
         ScopedTimer t(ctx, "knn_emit");
-        const unsigned grid = (unsigned)emit_blocks;
         const unsigned grid_x = (unsigned)(xcd_chunk > 0 ? ceil_div(emit_blocks, 8 * (int64_t)xcd_chunk) * 8 * xcd_chunk : emit_blocks);
         const int dbg_mode = ctx->opt.knn_ablation;     // timing ablations (wrong results): non-zero only in -DDDX_ABLATION builds
-        if (wide) k_knn_window<8><<<grid, 64, 0, ctx->stream>>>(p1, thr, nrm, Mp, win, reinterpret_cast<unsigned long long*>(ccount + Mp + 2));
-        else k_knn_window<4><<<grid, 64, 0, ctx->stream>>>(p1, thr, nrm, Mp, win, reinterpret_cast<unsigned long long*>(ccount + Mp + 2));
-#define DDX_EMIT_BF(CPV, FOLDV, QUERY)                                                                                                                      \
-    do {                                                                                                                                                    \
-        if (wide) k_knn_emit_bf<CPV, FOLDV, 8><<<grid_x, 512, 0, ctx->stream>>>(Eb, QUERY, nrm, start4, thr, Mp, include_self, ccount, cbuf, win, dbg_mode, cap, xcd_chunk); \
-        else k_knn_emit_bf<CPV, FOLDV, 4><<<grid_x, 256, 0, ctx->stream>>>(Eb, QUERY, nrm, start4, thr, Mp, include_self, ccount, cbuf, win, dbg_mode, cap, xcd_chunk);      \
+#define DDX_EMIT_ONE(CPV, FOLDV, QUERY, BWV) k_knn_emit_bf<CPV, FOLDV, BWV><<<grid_x, 64 * BWV, 0, ctx->stream>>>(Eb, QUERY, nrm, start4, thr, Mp, include_self, ccount, cbuf, elist, emask, ecount, ecap, dbg_mode, cap, xcd_chunk)
+#define DDX_EMIT_BF(CPV, FOLDV, QUERY)                          \
+    do {                                                        \
+        if (BW == 16) DDX_EMIT_ONE(CPV, FOLDV, QUERY, 16);      \
+        else if (BW == 8) DDX_EMIT_ONE(CPV, FOLDV, QUERY, 8);   \
+        else DDX_EMIT_ONE(CPV, FOLDV, QUERY, 4);                \
     } while (0)
-        if (bf && fold) {
+        if (fold) {
             k_knn_fold<<<(unsigned)ceil_div(Mp * 8, 256), 256, 0, ctx->stream>>>(nrm, thr, Mp, Eb, Ebq);
             DDX_EMIT_BF(32, true, Ebq);
-        } else if (bf && CP == 32) DDX_EMIT_BF(32, false, Eb);
-        else if (bf && CP == 64) DDX_EMIT_BF(64, false, Eb);
-        else if (bf) DDX_EMIT_BF(128, false, Eb);
+        } else if (CP == 32) DDX_EMIT_BF(32, false, Eb);
+        else if (CP == 64) DDX_EMIT_BF(64, false, Eb);
+        else DDX_EMIT_BF(128, false, Eb);
 #undef DDX_EMIT_BF
-        else if (CP == 32) k_knn_emit<32><<<grid, 256, 0, ctx->stream>>>(Et, nrm, thr, Mp, include_self, ccount, cbuf, win, cap);
-        else if (CP == 64) k_knn_emit<64><<<grid, 256, 0, ctx->stream>>>(Et, nrm, thr, Mp, include_self, ccount, cbuf, win, cap);
-        else k_knn_emit<128><<<grid, 256, 0, ctx->stream>>>(Et, nrm, thr, Mp, include_self, ccount, cbuf, win, cap);
+#undef DDX_EMIT_ONE
     }
     {
         ScopedTimer t(ctx, "knn_select");
@@ -1236,17 +1521,56 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
         std::vector<int32_t> h(Mp + 1);
         DDX_HIP(ctx, hipMemcpyAsync(h.data(), ccount, sizeof(int32_t) * (Mp + 1), hipMemcpyDeviceToHost, ctx->stream));
         DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        double sum = 0; int mx = 0; int64_t over = 0;
-        for (int64_t i = 0; i < M; ++i) { sum += h[i]; if (h[i] > mx) mx = h[i]; over += h[i] > cap; }
-        std::vector<int32_t> hw(2 * emit_blocks);
-        DDX_HIP(ctx, hipMemcpy(hw.data(), win, sizeof(int32_t) * 2 * emit_blocks, hipMemcpyDeviceToHost));
-        double wsum = 0;
-        for (int64_t b = 0; b < emit_blocks; ++b) wsum += hw[2 * b + 1] - hw[2 * b];
-        fprintf(stderr, "[knn] k=%d sample tiles=%lld: candidates/query mean %.1f max %d, overflowed %lld (counter %d); emit window %.1f%% of the tiles\n",
-                k, (long long)nsamp, sum / M, mx, (long long)over, h[Mp], 100.0 * wsum / ((double)emit_blocks * (double)ntiles));
+        double sum = 0; int mx = 0; int64_t over = 0, longer = 0;
+        for (int64_t i = 0; i < M; ++i) { sum += h[i]; if (h[i] > mx) mx = h[i]; over += h[i] > cap; longer += h[i] > kSelSmall; }
+        std::vector<int32_t> hl(emit_blocks);
+        DDX_HIP(ctx, hipMemcpy(hl.data(), ecount, sizeof(int32_t) * emit_blocks, hipMemcpyDeviceToHost));
+        unsigned long long scr = 0;
+        DDX_HIP(ctx, hipMemcpy(&scr, wtotal, sizeof(scr), hipMemcpyDeviceToHost));
+        double lsum = 0;
+        for (int64_t b = 0; b < emit_blocks; ++b) lsum += hl[b];
+        int smin = (int)M, smax = (int)M;
+        if (Kc > 1) {
+            std::vector<int32_t> hs(Kc);
+            DDX_HIP(ctx, hipMemcpy(hs.data(), sizes, sizeof(int32_t) * Kc, hipMemcpyDeviceToHost));
+            smin = smax = hs[0];
+            for (int c = 1; c < Kc; ++c) { smin = std::min(smin, hs[c]); smax = std::max(smax, hs[c]); }
+        }
+        fprintf(stderr, "[knn] k=%d cells=%d (sizes %d..%d) sample tiles=%lld: candidates/query mean %.1f max %d, %lld beyond 256, overflowed %lld (counter %d); "
+                        "emit block stages %.1f%% of the tiles, a wave screens %.1f%%\n",
+                k, Kc, smin, smax, (long long)nsamp, sum / M, mx, (long long)longer, (long long)over, h[Mp], 100.0 * lsum / ((double)emit_blocks * (double)ntiles),
+                100.0 * (double)scr / ((double)(Mp / 32) * (double)ntiles));
     }
-    ctx->knn_window_total = reinterpret_cast<const unsigned long long*>(ccount + Mp + 2);
-    ctx->knn_window_pairs = (double)emit_blocks * (double)ntiles;
+    if (ctx->opt.knn_debug) {
+        // how the work is spread: tiles screened per wave, and how far single queries' bounds stand out in their tile
+        std::vector<int32_t> he(emit_blocks);
+        std::vector<uint32_t> hm((size_t)emit_blocks * ecap);
+        DDX_HIP(ctx, hipMemcpy(he.data(), ecount, sizeof(int32_t) * emit_blocks, hipMemcpyDeviceToHost));
+        DDX_HIP(ctx, hipMemcpy(hm.data(), emask, sizeof(uint32_t) * hm.size(), hipMemcpyDeviceToHost));
+        std::vector<int> per_wave;
+        for (int64_t b = 0; b < emit_blocks; ++b) {
+            std::vector<int> c(BW, 0);
+            for (int i = 0; i < he[b]; ++i) for (int w = 0; w < BW; ++w) c[w] += (hm[b * ecap + i] >> w) & 1u;
+            for (int w = 0; w < BW; ++w) per_wave.push_back(c[w]);
+        }
+        std::sort(per_wave.begin(), per_wave.end());
+        auto q = [&](double f) { return 100.0 * per_wave[(size_t)(f * (per_wave.size() - 1))] / (double)ntiles; };
+        std::vector<float> ht(Mp);
+        DDX_HIP(ctx, hipMemcpy(ht.data(), thr, sizeof(float) * Mp, hipMemcpyDeviceToHost));
+        int64_t r15 = 0, r2 = 0, r3 = 0;
+        for (int64_t t = 0; t < M / 16; ++t) {
+            float v[16];
+            for (int j = 0; j < 16; ++j) v[j] = ht[t * 16 + j];
+            std::sort(v, v + 16);
+            const float med = v[7];
+            for (int j = 0; j < 16; ++j) { r15 += v[j] > 1.5f * med; r2 += v[j] > 2.f * med; r3 += v[j] > 3.f * med; }
+        }
+        fprintf(stderr, "[knn] tiles screened per wave (%% of all): median %.1f, 90%% %.1f, 99%% %.1f, 99.9%% %.1f, max %.1f; bounds above 1.5 / 2 / 3 x their tile's median: %lld / %lld / %lld\n",
+                q(0.5), q(0.9), q(0.99), q(0.999), q(1.0), (long long)r15, (long long)r2, (long long)r3);
+    }
+    ctx->knn_window_total = wtotal;
+    ctx->knn_window_pairs = (double)(Mp / (16 * kEmitRT)) * (double)ntiles;     // (wave of 32 queries, candidate tile) pairs
+    ctx->knn_overflow = ccount + Mp;
     ctx->K = k;
     ctx->knn_self = include_self != 0;
     ctx->have_knn = true;

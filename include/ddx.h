@@ -164,9 +164,12 @@ int ddx_knn(ddx_ctx* ctx, int32_t k, int32_t include_self);
  * 3 correlation (sklearn brute force).  Metrics 1-3 run an exact float64 scan of all pairs: correct, not fast. */
 int ddx_knn_metric(ddx_ctx* ctx, int32_t k, int32_t include_self, int32_t metric);
 int ddx_get_knn(ddx_ctx* ctx, int32_t* idx_out /* [M*k] */, double* dist2_out /* [M*k] or NULL */);
-/* statistics: share of the (query block, candidate tile) pairs the last ddx_knn had to screen after pruning on the
- * first component (1 = all pairs).  bench.py scales the distance-screen flop count with it. */
+/* statistics: share of the (32 queries, 16-candidate tile) pairs the last ddx_knn had to screen after the cell / first-
+ * component pruning (1 = all pairs).  bench.py scales the distance-screen flop count with it. */
 int ddx_get_knn_window_fraction(ddx_ctx* ctx, double* fraction);
+/* statistics: queries of the last ddx_knn whose candidate list overflowed its slots and were re-scanned exactly against
+ * every point (the result is exact either way; the parity tests make a point of checking those queries). */
+int ddx_get_knn_overflow_count(ddx_ctx* ctx, int64_t* n_queries);
 
 /* ---- graph construction (device) ------------------------------------------------------------
  * mode 0: PhenoGraph Jaccard graph, prune=True  (mutual kNN, weight J_ij*J_ji)
