@@ -151,6 +151,8 @@ void Options::read_environment() {
     knn_cells = g ? atoi(g) : 0;
     g = getenv("DDX_KNN_SAMPLE_EVERY");
     knn_sample_every = g ? atoi(g) : 32;
+    g = getenv("DDX_KNN_SEG_STEPS");
+    knn_seg_steps = g ? atoi(g) : 0;
     g = getenv("DDX_KNN_EMIT_WAVES");
     knn_emit_waves = g ? atoi(g) : 0;
     row_sums_sequential = getenv("DDX_ROW_SUMS_SEQUENTIAL") != nullptr;

@@ -50,6 +50,7 @@ struct Options {
     int64_t knn_sample_tiles = 0;    // 0 = default rule
     int knn_cells = 0;               // cells of the emit pass's pruning structure (0 = default rule, 1 = first-component windows only)
     int knn_sample_every = 32;       // the bound pass's sample holds every n-th tile of the whole set (0: none)
+    int knn_seg_steps = 0;           // steps of a block's tile list per emit work item (0 = default)
     int knn_emit_waves = 0;          // waves per emit block: 4, 8 or 16 (0 = default)
     bool row_sums_sequential = false;
     bool knn_debug = false;

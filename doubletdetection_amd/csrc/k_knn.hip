@@ -145,7 +145,9 @@ __host__ __device__ constexpr int chunk_tiles(int CP) { return CP <= 32 ? 8 : 4;
 
 constexpr int kBoundRT = 2;   // query tiles per wave in the bound pass (register budget: 16 rows x kBoundKeep)
 constexpr int kEmitRT = 2;    // query tiles per wave in the emit pass
-constexpr int kEmitWaves = 16; // waves per workgroup of the emit pass (they share the staged candidate tiles)
+constexpr int kEmitWaves = 4;  // waves per workgroup of the emit pass (they share the staged candidate tiles)
+constexpr int kEmitSegSteps = 8;    // steps (of 8 or 4 tiles) of a block's list that one workgroup screens
+constexpr int kEmitLocal = 32;      // candidates per query that a work item buffers in LDS before it reserves slots in the query's list
 
 // ---- bfloat16-split MFMA screen ----------------------------------------------------------------------------
 // q.c ~= qh.ch + qh.cl + ql.ch with three v_mfma_f32_16x16x32_bf16.  Dropped
@@ -350,16 +352,23 @@ __global__ void __launch_bounds__(64 * kEmitBW) __attribute__((amdgpu_waves_per_
 k_knn_emit_bf(const __bf16* __restrict__ Eb, const __bf16* __restrict__ Ebq, const float* __restrict__ nrm, const f4* __restrict__ start4,
               const float* __restrict__ thr, int64_t Mp, int include_self, int32_t* __restrict__ ccount, int32_t* __restrict__ cbuf,
               const int32_t* __restrict__ elist, const uint32_t* __restrict__ emask, const int32_t* __restrict__ ecount, int64_t ecap, int dbg,
-              int cap, int xcd_chunk) {
+              int cap, int nseg, int seg_steps) {
     constexpr int RT = kEmitRT, NV = 4 * RT;
     constexpr int G = chunk_tiles(CP);
     constexpr int tile_vecs = CP * 4;
     __shared__ f4 lds_c[2][G * tile_vecs];
     __shared__ f4 lds_h[2][G * 16];     // accumulator start values -0.5*(1-slack)*|c|^2, one MFMA C quad per candidate (k_knn_prepare)
+    __shared__ int32_t lbuf[kEmitBW][16 * RT][kEmitLocal];     // candidates of this work item, per query
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int64_t blk = knn_block(Mp / (kEmitBW * 16 * RT), xcd_chunk);
-    if (blk < 0) return;
+    // work item = (query block, segment of its list): workgroup id = blk * nseg + seg.  nseg is a multiple of 8, so the same
+    // segment of consecutive query blocks -- nearly the same candidate tiles -- runs on one XCD at about the same time.
+    const int64_t blk = blockIdx.x / nseg;
+    const int seg = (int)(blockIdx.x % nseg);
+    const int nent = ecount[blk];
+    const int s_lo = seg * seg_steps;
+    if (s_lo * G >= nent) return;                // (block-uniform) the list ends before this segment
+    const int nsteps = min(nent / G - s_lo, seg_steps);
     const int64_t q0 = (blk * kEmitBW + wave) * (16 * RT);
     QueryTilesBf<CP, RT> qt;
     qt.load(FOLD ? Ebq : Eb, q0, lane);          // FOLD: the query operands carry -hr in components 30 / 31 (k_knn_fold)
@@ -380,14 +389,8 @@ k_knn_emit_bf(const __bf16* __restrict__ Eb, const __bf16* __restrict__ Ebq, con
         if (dbg & 1) hr[v] = __builtin_huge_valf();          // experiment: nothing passes the screen
         if (FOLD) hr[v] = 0.f;                               // the threshold travels inside the dot product
     }
-    const int nent = ecount[blk];
-    const int nsteps = nent / G;
-    if (nsteps <= 0) {                          // block-uniform: nothing can be within reach
-        if (lane < 16 * kEmitRT) ccount[q0 + lane] = 0;
-        return;
-    }
-    const int32_t* lst = elist + blk * ecap;
-    const uint32_t* lmk = emask + blk * ecap;
+    const int32_t* lst = elist + blk * ecap + (int64_t)s_lo * G;
+    const uint32_t* lmk = emask + blk * ecap + (int64_t)s_lo * G;
     const int32_t own_tile = (int32_t)(q0 >> 4);
     const f4* srcE = reinterpret_cast<const f4*>(Eb);
     const float* srcH = reinterpret_cast<const float*>(start4);
@@ -441,10 +444,16 @@ k_knn_emit_bf(const __bf16* __restrict__ Eb, const __bf16* __restrict__ Ebq, con
                     if (own) m &= ~__ballot(q == cand);          // a point is not its own neighbour
                     const unsigned m16 = (unsigned)(m >> (lane & 48)) & 0xffffu;     // the 16 candidates of this lane group's query
                     if (m16) {
-                        if ((m16 >> jcol) & 1u) {
-                            const int slot = cnt[v] + __popc(m16 & ((1u << jcol) - 1u));
-                            if (slot < cap) cbuf[q * cap + slot] = cand;
+                        const int lq = (v >> 2) * 16 + rbase + (v & 3);
+                        if (cnt[v] + __popc(m16) > kEmitLocal) {     // (the 16 lanes of the group agree) buffer full: move it to the list
+                            int b = 0;
+                            if (jcol == 0) b = atomicAdd(&ccount[q], cnt[v]);
+                            b = __shfl(b, lane & 48, 64);
+                            for (int i = jcol; i < cnt[v]; i += 16)
+                                if (b + i < cap) cbuf[q * cap + b + i] = lbuf[wave][lq][i];
+                            cnt[v] = 0;
                         }
+                        if ((m16 >> jcol) & 1u) lbuf[wave][lq][cnt[v] + __popc(m16 & ((1u << jcol) - 1u))] = cand;
                         cnt[v] += __popc(m16);
                     }
                 }
@@ -502,9 +511,23 @@ k_knn_emit_bf(const __bf16* __restrict__ Eb, const __bf16* __restrict__ Ebq, con
         m0 = m1;
         m1 = m2;
     }
-    if (jcol == 0) {
+    // hand the item's candidates over: per query one atomic reserves the slots (several items append to one list: the order
+    // of a list depends on the run, the select pass sorts it), then the 16 lanes of the group copy
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    int base[NV];
 #pragma unroll
-        for (int v = 0; v < NV; ++v) ccount[q0 + (v >> 2) * 16 + rbase + (v & 3)] = cnt[v];
+    for (int v = 0; v < NV; ++v) {
+        base[v] = 0;
+        if (jcol == 0 && cnt[v] > 0) base[v] = atomicAdd(&ccount[q0 + (v >> 2) * 16 + rbase + (v & 3)], cnt[v]);
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int n = cnt[v];
+        const int b = __shfl(base[v], lane & 48, 64);
+        const int lq = (v >> 2) * 16 + rbase + (v & 3);
+        for (int i = jcol; i < n; i += 16)
+            if (b + i < cap) cbuf[(q0 + lq) * cap + b + i] = lbuf[wave][lq][i];
     }
 }
 
@@ -596,7 +619,8 @@ template <int CP, int SELMAX, int WAVES>
 __global__ void __launch_bounds__(64 * WAVES) k_knn_select(const float* __restrict__ E, const int32_t* __restrict__ perm, int64_t M, int K,
                                                     int include_self, const int32_t* __restrict__ ccount, const int32_t* __restrict__ cbuf,
                                                     int32_t* __restrict__ idx_out, double* __restrict__ dist_out,
-                                                    int32_t* __restrict__ n_overflow, int cap, int lo, int hi) {
+                                                    int32_t* __restrict__ n_overflow, int32_t* __restrict__ ovf_q, double* __restrict__ ovf_bound,
+                                                    int cap, int lo, int hi) {
     __shared__ __attribute__((aligned(16))) double sd[WAVES][SELMAX];
     __shared__ int32_t si[WAVES][SELMAX];
     __shared__ __attribute__((aligned(16))) float sq[WAVES][CP];
@@ -654,50 +678,107 @@ __global__ void __launch_bounds__(64 * WAVES) k_knn_select(const float* __restri
         __builtin_amdgcn_wave_barrier();
         wave_sort(d, ix, P, lane);
     }
-    int kept = cnt < K ? cnt : K;
+    const int kept = cnt < K ? cnt : K;
     if (overflow) {
-        // The list was cut at kCandCap entries.  Its k-th exact distance is still an upper bound of the true
-        // k-th distance: rescan every point exactly, keep those not beyond it, and sort again.
-        if (lane == 0) atomicAdd(n_overflow, 1);
-        const double bound = d[K - 1];
-        int fill = 0;                               // entries appended behind nothing: the window restarts empty
-        for (int64_t c0 = 0; c0 < M; c0 += 64) {
-            const int64_t c = c0 + lane;
-            double dv = __builtin_huge_val();
-            bool keep = false;
-            if (c < M && (include_self || c != q)) {
-                dv = exact_d2<CP>(qrow, E + c * CP);
-                keep = dv <= bound;
-            }
-            const unsigned long long m = __ballot(keep);
-            const int n_new = __popcll(m);
-            if (fill + n_new > SELMAX) {           // pathological ties: compact to the best K and go on
-                for (int t = fill + lane; t < SELMAX; t += 64) { d[t] = __builtin_huge_val(); ix[t] = 0x7fffffff; }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                wave_sort(d, ix, SELMAX, lane);
-                fill = K;
-            }
-            if (keep) {
-                const int pos = fill + __popcll(m & ((1ull << lane) - 1ull));
-                d[pos] = dv;
-                ix[pos] = perm[c];
-            }
-            fill += n_new;
+        // The list was cut at `cap` entries.  Its k-th exact distance is still an upper bound of the true k-th
+        // distance: k_knn_rescan goes over every point with it.
+        if (lane == 0) {
+            const int slot = atomicAdd(n_overflow, 1);
+            ovf_q[slot] = (int32_t)q;
+            ovf_bound[slot] = d[K - 1];
         }
-        P = 64;
-        while (P < fill) P <<= 1;
-        for (int t = fill + lane; t < P; t += 64) { d[t] = __builtin_huge_val(); ix[t] = 0x7fffffff; }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        wave_sort(d, ix, P, lane);
-        kept = fill < K ? fill : K;
+        return;
     }
     const int64_t qo = perm[q];                     // row of the caller's table
     for (int s = lane; s < K; s += 64) {
         const bool ok = s < kept && ix[s] != 0x7fffffff;
         idx_out[qo * K + s] = ok ? ix[s] : -1;
         dist_out[qo * K + s] = ok ? d[s] : __builtin_huge_val();
+    }
+}
+
+// Queries whose candidate list overflowed: exact scan of ALL points with the bound the select pass derived from the cut
+// list, one workgroup of 8 waves per query.  Every wave scans an eighth of the points and keeps those within the bound in
+// its own LDS window (a full window is sorted, cut to the K best and its K-th distance becomes the wave's bound); the K
+// nearest of all points are among the waves' K best, which wave 0 merges.  Same arithmetic and tie rule as the select pass.
+constexpr int kRescanWaves = 8, kRescanWin = 1024;
+template <int CP>
+__global__ void __launch_bounds__(64 * kRescanWaves) k_knn_rescan(const float* __restrict__ E, const int32_t* __restrict__ perm, int64_t M, int K, int include_self,
+                                                                  const int32_t* __restrict__ n_overflow, const int32_t* __restrict__ ovf_q,
+                                                                  const double* __restrict__ ovf_bound, int32_t* __restrict__ idx_out, double* __restrict__ dist_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char rs_smem[];
+    double* sd = reinterpret_cast<double*>(rs_smem);                                        // [waves][win] + merge [waves * 256]
+    int32_t* si = reinterpret_cast<int32_t*>(sd + kRescanWaves * kRescanWin + kRescanWaves * 256);
+    float* sq = reinterpret_cast<float*>(si + kRescanWaves * kRescanWin + kRescanWaves * 256);   // [CP] query row
+    __shared__ int s_fill[kRescanWaves];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = *n_overflow;
+    for (int it = blockIdx.x; it < n; it += gridDim.x) {
+        const int64_t q = ovf_q[it];
+        for (int t = threadIdx.x; t < CP; t += blockDim.x) sq[t] = E[q * CP + t];
+        __syncthreads();
+        double* d = sd + wave * kRescanWin;
+        int32_t* ix = si + wave * kRescanWin;
+        double bound = ovf_bound[it];
+        int fill = 0;
+        for (int64_t c0 = (int64_t)wave * 64; c0 < M; c0 += 64 * kRescanWaves) {
+            const int64_t c = c0 + lane;
+            double dv = __builtin_huge_val();
+            bool keep = false;
+            if (c < M && (include_self || c != q)) {
+                dv = exact_d2<CP>(sq, E + c * CP);
+                keep = dv <= bound;
+            }
+            unsigned long long m = __ballot(keep);
+            if (fill + __popcll(m) > kRescanWin) {       // sort, keep the K best, tighten the bound
+                for (int t = fill + lane; t < kRescanWin; t += 64) { d[t] = __builtin_huge_val(); ix[t] = 0x7fffffff; }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                wave_sort(d, ix, kRescanWin, lane);
+                fill = K;
+                bound = d[K - 1];
+                keep = keep && dv <= bound;
+                m = __ballot(keep);
+            }
+            if (keep) {
+                const int pos = fill + __popcll(m & ((1ull << lane) - 1ull));
+                d[pos] = dv;
+                ix[pos] = perm[c];
+            }
+            fill += __popcll(m);
+        }
+        int P = 64;
+        while (P < fill) P <<= 1;
+        for (int t = fill + lane; t < P; t += 64) { d[t] = __builtin_huge_val(); ix[t] = 0x7fffffff; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        wave_sort(d, ix, P, lane);
+        if (lane == 0) s_fill[wave] = fill < K ? fill : K;
+        __syncthreads();
+        if (wave == 0) {
+            double* md = sd + kRescanWaves * kRescanWin;
+            int32_t* mi = si + kRescanWaves * kRescanWin;
+            int total = 0;
+            for (int w = 0; w < kRescanWaves; ++w) {
+                const int nw = s_fill[w];
+                for (int t = lane; t < nw; t += 64) { md[total + t] = sd[w * kRescanWin + t]; mi[total + t] = si[w * kRescanWin + t]; }
+                total += nw;
+            }
+            int PM = 64;
+            while (PM < total) PM <<= 1;
+            for (int t = total + lane; t < PM; t += 64) { md[t] = __builtin_huge_val(); mi[t] = 0x7fffffff; }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            wave_sort(md, mi, PM, lane);
+            const int kept = total < K ? total : K;
+            const int64_t qo = perm[q];
+            for (int t = lane; t < K; t += 64) {
+                const bool ok = t < kept && mi[t] != 0x7fffffff;
+                idx_out[qo * K + t] = ok ? mi[t] : -1;
+                dist_out[qo * K + t] = ok ? md[t] : __builtin_huge_val();
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -846,7 +927,8 @@ int stage_knn_metric(ddx_ctx* ctx, int32_t k, int32_t include_self, int32_t metr
 // ------------------------------------------------------------------------------------------------
 constexpr int kCellDim = 32;                 // leading components the cells live in (zero padded)
 constexpr float kCellFix = 1048576.0f;       // fixed-point grid of the centre sums (2^20): integer sums are exact in any order
-constexpr int kCellRounds = 2;               // Lloyd rounds before the final assignment
+constexpr int kCellRounds = 2;               // Lloyd rounds (on every kCellSub-th point of the first-component order) before the assignment
+constexpr int kCellSub = 4;
 
 __device__ __forceinline__ unsigned ordered_bits(float v) {
     const unsigned u = __float_as_uint(v);
@@ -869,16 +951,23 @@ __global__ void k_cells_init(const float* __restrict__ emb, const int32_t* __res
     cn[c] = n;
 }
 
-// nearest centre of every point (ties: the smaller cell id): lane = point, the four waves of a block share the cells out
-__global__ void __launch_bounds__(256) k_cells_assign(const float* __restrict__ emb, int64_t M, int C, const float* __restrict__ cen,
-                                                      const float* __restrict__ cn, int Kc, int32_t* __restrict__ label) {
+// nearest centre of point ids[stride * i], i < n (ties: the smaller cell id): lane = point, the four waves of a block share
+// the cells out.  label / dcen (squared distance to that centre, >= 0) are indexed by the point's id.
+__global__ void __launch_bounds__(256) k_cells_assign(const float* __restrict__ emb, const int32_t* __restrict__ ids, int64_t n, int stride, int C,
+                                                      const float* __restrict__ cen, const float* __restrict__ cn, int Kc,
+                                                      int32_t* __restrict__ label, float* __restrict__ dcen) {
     __shared__ unsigned long long best[4][64];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t r = (int64_t)blockIdx.x * 64 + lane;
+    const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+    const int64_t r = i < n ? ids[i * stride] : 0;
     float x[kCellDim];
+    float xn = 0.f;
 #pragma unroll
-    for (int d = 0; d < kCellDim; ++d) x[d] = (r < M && d < C) ? emb[r * C + d] : 0.f;
+    for (int d = 0; d < kCellDim; ++d) {
+        x[d] = (i < n && d < C) ? emb[r * C + d] : 0.f;
+        xn = fmaf(x[d], x[d], xn);
+    }
     float bs = __builtin_huge_valf();
     int bc = 0x7fffffff;
     for (int c = w; c < Kc; c += 4) {
@@ -891,20 +980,26 @@ __global__ void __launch_bounds__(256) k_cells_assign(const float* __restrict__ 
     }
     best[w][lane] = ((unsigned long long)ordered_bits(bs) << 32) | (unsigned)bc;
     __syncthreads();
-    if (w == 0 && r < M) {
+    if (w == 0 && i < n) {
         unsigned long long b = best[0][lane];
 #pragma unroll
         for (int o = 1; o < 4; ++o) b = best[o][lane] < b ? best[o][lane] : b;
         int c = (int)(unsigned)(b & 0xffffffffull);
         if (c >= Kc) c = 0;                                   // (NaN coordinates: validated away upstream)
         label[r] = c;
+        if (dcen) {
+            const unsigned ob = (unsigned)(b >> 32);
+            const float s = __uint_as_float((ob & 0x80000000u) ? (ob & 0x7fffffffu) : ~ob);
+            dcen[r] = fmaxf(s + xn, 0.f);
+        }
     }
 }
 
-__global__ void k_cells_accumulate(const float* __restrict__ emb, int64_t M, int C, const int32_t* __restrict__ label,
-                                   unsigned long long* __restrict__ sums, int32_t* __restrict__ counts) {
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= M) return;
+__global__ void k_cells_accumulate(const float* __restrict__ emb, const int32_t* __restrict__ ids, int64_t n, int stride, int C,
+                                   const int32_t* __restrict__ label, unsigned long long* __restrict__ sums, int32_t* __restrict__ counts) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t r = ids[i * stride];
     const int c = label[r];
     const int D = C < kCellDim ? C : kCellDim;
     for (int d = 0; d < D; ++d) {
@@ -916,7 +1011,7 @@ __global__ void k_cells_accumulate(const float* __restrict__ emb, int64_t M, int
 
 // centre = mean of the members (an empty cell keeps its centre); clears the sums for the next round
 __global__ void k_cells_mean(unsigned long long* __restrict__ sums, int32_t* __restrict__ counts, int Kc, float* __restrict__ cen,
-                             float* __restrict__ cn, int32_t* __restrict__ sizes) {
+                             float* __restrict__ cn) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= Kc) return;
     const int n = counts[c];
@@ -929,7 +1024,6 @@ __global__ void k_cells_mean(unsigned long long* __restrict__ sums, int32_t* __r
         sums[(size_t)c * kCellDim + d] = 0ull;
     }
     cn[c] = nn;
-    sizes[c] = n;
     counts[c] = 0;
 }
 
@@ -947,11 +1041,11 @@ __global__ void __launch_bounds__(1024) k_cells_rank(const float* __restrict__ c
     for (int d = 0; d < kCellDim; ++d) cenR[r * kCellDim + d] = cen[c * kCellDim + d];
 }
 
-__global__ void k_cells_keys(const int32_t* __restrict__ perm1, const int32_t* __restrict__ label, const int32_t* __restrict__ rank, int64_t M,
+__global__ void k_cells_keys(const int32_t* __restrict__ order, const int32_t* __restrict__ label, const int32_t* __restrict__ rank, int64_t M,
                              uint32_t* __restrict__ keys) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M) return;
-    keys[i] = (uint32_t)rank[label[perm1[i]]];
+    keys[i] = (uint32_t)rank[label[order[i]]];
 }
 
 // 1 / |mu_B - mu_A|, shrunk by 1e-5 so that the direction is no longer than 1 whatever the float32 roundings; 0 on the diagonal
@@ -1293,11 +1387,11 @@ __global__ void k_knn_keys(const float* __restrict__ emb, int64_t M, int C, floa
     ids[r] = (int32_t)r;
 }
 
-// number of cells for M points: cells of about 320 points (20 tiles), at most 1024; small inputs keep the plain
+// number of cells for M points: cells of about 512 points (32 tiles), at most 1024; small inputs keep the plain
 // first-component order (one cell: the tile test reduces to the first-component windows)
 static int default_cells(int64_t M) {
     if (M < 16384) return 1;
-    const int64_t want = ceil_div(ceil_div(M, 320), 64) * 64;
+    const int64_t want = ceil_div(ceil_div(M, 512), 64) * 64;
     return (int)std::min<int64_t>(1024, std::max<int64_t>(64, want));
 }
 
@@ -1371,7 +1465,7 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
     const size_t o_perm1 = carve(sizeof(int32_t) * (size_t)M);
     const size_t o_cen = carve(sizeof(float) * (size_t)Kc * kCellDim), o_cenR = carve(sizeof(float) * (size_t)Kc * kCellDim), o_cn = carve(sizeof(float) * (size_t)Kc);
     const size_t o_sums = carve(sizeof(unsigned long long) * (size_t)Kc * kCellDim), o_counts = carve(sizeof(int32_t) * (size_t)Kc + 16);
-    const size_t o_sizes = carve(sizeof(int32_t) * (size_t)Kc), o_rank = carve(sizeof(int32_t) * (size_t)Kc), o_invD = carve(sizeof(float) * (size_t)Kc * Kc);
+    const size_t o_rank = carve(sizeof(int32_t) * (size_t)Kc), o_invD = carve(sizeof(float) * (size_t)Kc * Kc);
     const size_t o_ctile = carve(sizeof(int32_t) * ((size_t)Kc + 1)), o_ncount = carve(sizeof(int32_t) * (size_t)Kc), o_nlist = carve(sizeof(int32_t) * (size_t)Kc * nsamp);
     const size_t o_tilecell = carve(sizeof(int32_t) * (size_t)ntiles), o_t1lo = carve(sizeof(float) * (size_t)ntiles), o_t1hi = carve(sizeof(float) * (size_t)ntiles);
     const size_t o_Slo = carve(sizeof(float) * (size_t)ntiles * Kc), o_Shi = carve(sizeof(float) * (size_t)ntiles * Kc);
@@ -1379,6 +1473,7 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
     const size_t o_blist = carve(sizeof(int32_t) * (size_t)bound_blocks * nsamp), o_bcount = carve(sizeof(int32_t) * (size_t)bound_blocks);
     const size_t o_elist = carve(sizeof(int32_t) * (size_t)emit_blocks * ecap), o_emask = carve(sizeof(uint32_t) * (size_t)emit_blocks * ecap);
     const size_t o_ecount = carve(sizeof(int32_t) * (size_t)emit_blocks);
+    const size_t o_ovq = carve(sizeof(int32_t) * (size_t)Mp), o_ovb = carve(sizeof(double) * (size_t)Mp);
     DDX_TRY(ensure(ctx, ctx->knn_cells, cw));
     char* cb = ctx->knn_cells.as<char>();
     int32_t* label = reinterpret_cast<int32_t*>(cb + o_label);
@@ -1391,7 +1486,6 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
     unsigned long long* sums = reinterpret_cast<unsigned long long*>(cb + o_sums);
     int32_t* counts = reinterpret_cast<int32_t*>(cb + o_counts);       // [Kc] + largest squared norm (float bits) at [Kc + 1]
     unsigned* r2max = reinterpret_cast<unsigned*>(counts + Kc + 1);
-    int32_t* sizes = reinterpret_cast<int32_t*>(cb + o_sizes);
     int32_t* rank = reinterpret_cast<int32_t*>(cb + o_rank);
     float* invD = reinterpret_cast<float*>(cb + o_invD);
     int32_t* ctile = reinterpret_cast<int32_t*>(cb + o_ctile);
@@ -1409,6 +1503,8 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
     int32_t* elist = reinterpret_cast<int32_t*>(cb + o_elist);
     uint32_t* emask = reinterpret_cast<uint32_t*>(cb + o_emask);
     int32_t* ecount = reinterpret_cast<int32_t*>(cb + o_ecount);
+    int32_t* ovf_q = reinterpret_cast<int32_t*>(cb + o_ovq);
+    double* ovf_bound = reinterpret_cast<double*>(cb + o_ovb);
     const float* emb = ctx->emb32.as<float>();
     // Order of the points: cell by cell, first principal component inside a cell (stable radix sorts: ties by id).  Every
     // pass below works in that order.
@@ -1426,11 +1522,20 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
         ScopedTimer t(ctx, "knn_cells");
         const unsigned gK = (unsigned)ceil_div(Kc, 256), gM = (unsigned)ceil_div(M, 256), gA = (unsigned)ceil_div(M, 64);
         k_cells_init<<<gK, 256, 0, ctx->stream>>>(emb, perm1, M, C, Kc, cen, cn);
-        for (int round = 0; round <= kCellRounds; ++round) {
-            k_cells_assign<<<gA, 256, 0, ctx->stream>>>(emb, M, C, cen, cn, Kc, label);
-            k_cells_accumulate<<<gM, 256, 0, ctx->stream>>>(emb, M, C, label, sums, counts);
-            k_cells_mean<<<gK, 256, 0, ctx->stream>>>(sums, counts, Kc, cen, cn, sizes);
+        const int sub = M >= (int64_t)Kc * 64 * kCellSub ? kCellSub : 1;
+        const int64_t ns = M / sub;
+        for (int round = 0; round < kCellRounds; ++round) {
+            k_cells_assign<<<(unsigned)ceil_div(ns, 64), 256, 0, ctx->stream>>>(emb, perm1, ns, sub, C, cen, cn, Kc, label, nullptr);
+            k_cells_accumulate<<<(unsigned)ceil_div(ns, 256), 256, 0, ctx->stream>>>(emb, perm1, ns, sub, C, label, sums, counts);
+            k_cells_mean<<<gK, 256, 0, ctx->stream>>>(sums, counts, Kc, cen, cn);
         }
+        // order inside a cell: by distance from its centre (the few points far from every centre -- whose intervals along any
+        // direction are wide -- end up together in the last tiles of their cell instead of widening many tiles)
+        k_cells_assign<<<gA, 256, 0, ctx->stream>>>(emb, ids_in, M, 1, C, cen, cn, Kc, label, keys_in);
+        size_t tb1 = 0;
+        DDX_HIP(ctx, prim::sort_pairs(nullptr, tb1, keys_in, keys_out, ids_in, perm1, (int)M, 0, 32, ctx->stream));
+        DDX_TRY(ensure(ctx, ctx->sort_tmp, tb1));
+        DDX_HIP(ctx, prim::sort_pairs(ctx->sort_tmp.p, tb1, keys_in, keys_out, ids_in, perm1, (int)M, 0, 32, ctx->stream));
         k_cells_rank<<<1, 1024, 0, ctx->stream>>>(cen, Kc, rank, cenR);
         k_cells_keys<<<gM, 256, 0, ctx->stream>>>(perm1, label, rank, M, kin);
         int bits = 1;
@@ -1481,9 +1586,11 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
     }
     {
         ScopedTimer t(ctx, "knn_emit");
-        const unsigned grid_x = (unsigned)(xcd_chunk > 0 ? ceil_div(emit_blocks, 8 * (int64_t)xcd_chunk) * 8 * xcd_chunk : emit_blocks);
+        const int seg_steps = ctx->opt.knn_seg_steps > 0 ? ctx->opt.knn_seg_steps : kEmitSegSteps;
+        const int nseg = (int)(ceil_div(ceil_div(ecap, G), (int64_t)seg_steps * 8) * 8);     // segments of the longest possible list, a multiple of 8
+        const unsigned grid_x = (unsigned)(emit_blocks * nseg);
         const int dbg_mode = ctx->opt.knn_ablation;     // timing ablations (wrong results): non-zero only in -DDDX_ABLATION builds
-#define DDX_EMIT_ONE(CPV, FOLDV, QUERY, BWV) k_knn_emit_bf<CPV, FOLDV, BWV><<<grid_x, 64 * BWV, 0, ctx->stream>>>(Eb, QUERY, nrm, start4, thr, Mp, include_self, ccount, cbuf, elist, emask, ecount, ecap, dbg_mode, cap, xcd_chunk)
+#define DDX_EMIT_ONE(CPV, FOLDV, QUERY, BWV) k_knn_emit_bf<CPV, FOLDV, BWV><<<grid_x, 64 * BWV, 0, ctx->stream>>>(Eb, QUERY, nrm, start4, thr, Mp, include_self, ccount, cbuf, elist, emask, ecount, ecap, dbg_mode, cap, nseg, seg_steps)
 #define DDX_EMIT_BF(CPV, FOLDV, QUERY)                          \
     do {                                                        \
         if (BW == 16) DDX_EMIT_ONE(CPV, FOLDV, QUERY, 16);      \
@@ -1506,14 +1613,21 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
         double* kd = ctx->knn_dist.as<double>();
 #define DDX_SELECT_LAUNCH(CPV)                                                                                                                          \
     do {                                                                                                                                                \
-        k_knn_select<CPV, kSelSmall, 4><<<g2, 256, 0, ctx->stream>>>(E, perm, M, k, include_self, ccount, cbuf, ki, kd, ccount + Mp, cap, 0, kSelSmall);    \
-        k_knn_select<CPV, kSelMax, 4><<<g2, 256, 0, ctx->stream>>>(E, perm, M, k, include_self, ccount, cbuf, ki, kd, ccount + Mp, cap, kSelSmall, kSelMax); \
+        k_knn_select<CPV, kSelSmall, 4><<<g2, 256, 0, ctx->stream>>>(E, perm, M, k, include_self, ccount, cbuf, ki, kd, ccount + Mp, ovf_q, ovf_bound, cap, 0, kSelSmall);    \
+        k_knn_select<CPV, kSelMax, 4><<<g2, 256, 0, ctx->stream>>>(E, perm, M, k, include_self, ccount, cbuf, ki, kd, ccount + Mp, ovf_q, ovf_bound, cap, kSelSmall, kSelMax); \
         if (cap > kSelMax)                                                                                                                              \
-            k_knn_select<CPV, kSelHuge, 1><<<(unsigned)M, 64, 0, ctx->stream>>>(E, perm, M, k, include_self, ccount, cbuf, ki, kd, ccount + Mp, cap, kSelMax, kSelHuge); \
+            k_knn_select<CPV, kSelHuge, 1><<<(unsigned)M, 64, 0, ctx->stream>>>(E, perm, M, k, include_self, ccount, cbuf, ki, kd, ccount + Mp, ovf_q, ovf_bound, cap, kSelMax, kSelHuge); \
     } while (0)
-        if (CP == 32) DDX_SELECT_LAUNCH(32);
-        else if (CP == 64) DDX_SELECT_LAUNCH(64);
-        else DDX_SELECT_LAUNCH(128);
+        const size_t rs_lds = (size_t)(kRescanWaves * kRescanWin + kRescanWaves * 256) * (sizeof(double) + sizeof(int32_t)) + sizeof(float) * CP;
+#define DDX_RESCAN(CPV)                                                                                                                       \
+    do {                                                                                                                                      \
+        DDX_TRY(allow_dynamic_lds(ctx, reinterpret_cast<const void*>(&k_knn_rescan<CPV>), (int)rs_lds));                                      \
+        k_knn_rescan<CPV><<<512, 64 * kRescanWaves, rs_lds, ctx->stream>>>(E, perm, M, k, include_self, ccount + Mp, ovf_q, ovf_bound, ki, kd); \
+    } while (0)
+        if (CP == 32) { DDX_SELECT_LAUNCH(32); DDX_RESCAN(32); }
+        else if (CP == 64) { DDX_SELECT_LAUNCH(64); DDX_RESCAN(64); }
+        else { DDX_SELECT_LAUNCH(128); DDX_RESCAN(128); }
+#undef DDX_RESCAN
 #undef DDX_SELECT_LAUNCH
     }
     DDX_HIP(ctx, hipGetLastError());
@@ -1531,8 +1645,10 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
         for (int64_t b = 0; b < emit_blocks; ++b) lsum += hl[b];
         int smin = (int)M, smax = (int)M;
         if (Kc > 1) {
-            std::vector<int32_t> hs(Kc);
-            DDX_HIP(ctx, hipMemcpy(hs.data(), sizes, sizeof(int32_t) * Kc, hipMemcpyDeviceToHost));
+            std::vector<uint32_t> hc(M);
+            DDX_HIP(ctx, hipMemcpy(hc.data(), cellpos, sizeof(uint32_t) * M, hipMemcpyDeviceToHost));
+            std::vector<int> hs(Kc, 0);
+            for (int64_t i = 0; i < M; ++i) ++hs[hc[i]];
             smin = smax = hs[0];
             for (int c = 1; c < Kc; ++c) { smin = std::min(smin, hs[c]); smax = std::max(smax, hs[c]); }
         }
