@@ -17,7 +17,7 @@ LIB = os.path.join(HERE, "libddx.so")
 
 # per-file flags: the kNN screen compares MFMA results right away -- keep the accumulators in VGPRs (no v_accvgpr_read)
 EXTRA_FLAGS = {"k_knn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
-HIP_SOURCES = ["ddx_api.hip", "k_sparse.hip", "k_pca.hip", "k_knn.hip", "k_prologue.hip", "k_louvain.hip"]
+HIP_SOURCES = ["ddx_api.hip", "k_sparse.hip", "k_pca.hip", "k_bitplane.hip", "k_knn.hip", "k_prologue.hip", "k_louvain.hip"]
 CXX_SOURCES = ["louvain.cpp", "hostmath.cpp"]
 HEADERS = ["ddx_internal.h", "ddx_prims.h", os.path.join("..", "..", "include", "ddx.h")]
 

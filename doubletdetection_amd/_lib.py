@@ -74,6 +74,7 @@ _SIGNATURES = {
     "ddx_get_knn": (C.c_int, [C.c_void_p, c_i32_p, c_f64_p]),
     "ddx_get_knn_window_fraction": (C.c_int, [C.c_void_p, c_f64_p]),
     "ddx_get_knn_overflow_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "ddx_get_knn_candidate_counts": (C.c_int, [C.c_void_p, c_i32_p]),
     "ddx_build_graph": (C.c_int, [C.c_void_p, C.c_int32]),
     "ddx_graph_relations": (C.c_int, [C.c_void_p, C.c_int32, c_i32_p, c_f64_p]),
     "ddx_assemble_graph": (C.c_int, [C.c_int64, C.c_int32, c_i32_p, c_f64_p, c_i64_p, c_i32_p, c_f64_p]),
@@ -582,6 +583,11 @@ class Context:
         n = C.c_int64(0)
         self._c(self._lib.ddx_get_knn_overflow_count(self._h, C.byref(n)))
         return int(n.value)
+
+    def knn_candidate_counts(self) -> np.ndarray:
+        out = np.empty(self._embM, dtype=np.int32)
+        self._c(self._lib.ddx_get_knn_candidate_counts(self._h, _p(out, c_i32_p)))
+        return out
 
     def build_graph(self, mode: int, fetch: bool = True):
         self._c(self._lib.ddx_build_graph(self._h, int(mode)))

@@ -68,7 +68,7 @@ void context_reset(ddx_ctx* ctx) {
                       &ctx->sort_vals_in, &ctx->sort_vals_out, &ctx->sort_tmp, &ctx->sort_rowid, &ctx->median, &ctx->lib_sorted, &ctx->lognorm_tab,
                       &ctx->zcol, &ctx->colmean, &ctx->colstat, &ctx->col_part, &ctx->pcaA, &ctx->pcaB, &ctx->pcaSmall,
                       &ctx->pcaPartial, &ctx->pcaVec, &ctx->pcaPanel, &ctx->pcaOp, &ctx->pcaQ0, &ctx->pcaBlk, &ctx->rowseg, &ctx->rank_buf, &ctx->lv_buf, &ctx->lv_pack, &ctx->graph_buf, &ctx->emb32, &ctx->emb64, &ctx->sing, &ctx->knn_idx,
-                      &ctx->knn_dist, &ctx->knn_sorted, &ctx->edge_w, &ctx->knn_cells};
+                      &ctx->knn_dist, &ctx->knn_sorted, &ctx->edge_w, &ctx->knn_cells, &ctx->bp_buf, &ctx->bp_work};
     for (DevBuf* b : bufs) { b->p = nullptr; b->cap = 0; b->blk = -1; }
     ctx->arena.blocks.clear();
     for (auto& c : ctx->arena.chunks) c.off = 0;
@@ -79,10 +79,13 @@ void context_reset(ddx_ctx* ctx) {
     ctx->rank_rows = ctx->rank_cols = nullptr;
     ctx->knn_window_total = nullptr;
     ctx->knn_overflow = nullptr;
+    ctx->knn_ccount = nullptr;
+    ctx->knn_perm = nullptr;
     ctx->g_nodes = -1; ctx->g_entries = 0; ctx->g_d_indptr = nullptr; ctx->g_d_cols = nullptr; ctx->g_d_vals = nullptr;
     ctx->c_nodes = -1; ctx->c_entries = 0; ctx->c_d_member = nullptr; ctx->c_d_indptr = nullptr; ctx->c_d_cols = nullptr; ctx->c_d_vals = nullptr;
     ctx->lv_host_valid = false;
     ctx->rowseg_rows = -1;
+    ctx->bp = ddx::BitPlanes();
     // a parked context starts its next fit with the switches of the environment as it is NOW (like a fresh one)
     ctx->opt.read_environment();
 }
@@ -157,6 +160,7 @@ void Options::read_environment() {
     knn_emit_waves = g ? atoi(g) : 0;
     row_sums_sequential = getenv("DDX_ROW_SUMS_SEQUENTIAL") != nullptr;
     knn_debug = getenv("DDX_KNN_DEBUG") != nullptr;
+    bitplane = is(getenv("DDX_BITPLANE"), "1");
     upload_packed = !is(getenv("DDX_UPLOAD"), "plain");
     upload_form16 = !is(getenv("DDX_UPLOAD"), "packed32");
     upload_wait = is(getenv("DDX_UPLOAD"), "packed") || is(getenv("DDX_UPLOAD"), "packed32");
@@ -1086,6 +1090,13 @@ int ddx_get_knn_overflow_count(ddx_ctx* ctx, int64_t* n_queries) {
     if (ctx->knn_overflow) DDX_TRY(d2h(ctx, &n, ctx->knn_overflow, sizeof(n)));
     *n_queries = n;
     return DDX_OK;
+}
+
+int ddx_get_knn_candidate_counts(ddx_ctx* ctx, int32_t* counts_out) {
+    REQUIRE_CTX(ctx);
+    USE_DEVICE(ctx);
+    NEED(ctx->have_knn && counts_out, "no kNN result");
+    return stage_knn_candidate_counts(ctx, counts_out);
 }
 
 int ddx_build_graph(ddx_ctx* ctx, int32_t mode) {

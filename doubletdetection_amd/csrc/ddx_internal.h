@@ -54,6 +54,7 @@ struct Options {
     int knn_emit_waves = 0;          // waves per emit block: 4, 8 or 16 (0 = default)
     bool row_sums_sequential = false;
     bool knn_debug = false;
+    bool bitplane = false;           // experiment (profiles/r04_bitplane_notes.txt): the original rows' entries equal to 1 as bitmaps on the integer matrix cores
     int mirror_mode = 2;             // column-major mirror: 2 counting sort placed by LDS tiles, 1 (DDX_MIRROR=scatter) counting sort with scattered stores, 0 (DDX_MIRROR=sort) radix sort
     bool upload_packed = true;       // DDX_UPLOAD=plain: send the raw matrix as it is (8 bytes per entry) instead of packed
     bool upload_form16 = true;       // DDX_UPLOAD=packed32: column | count << 16 (4 bytes per entry) instead of column step | count << 8 (2 bytes)
@@ -81,6 +82,30 @@ struct Arena {
     std::vector<Chunk> chunks;
     std::vector<Block> blocks;
     size_t next_chunk = (size_t)256 << 20;     // size of the next chunk to request (ddx reserves a better guess at upload)
+};
+
+// Bit-plane operator products (k_bitplane.hip): bitmaps of the original cells' entries equal to 1, the reduced sparse
+// structures of their other entries (views into ctx->bp_buf, built once per fit), per-product work space (ctx->bp_work)
+struct BitPlanes {
+    bool ready = false;              // structures built for this fit's counts
+    bool values = false;             // reduced values / row scales refreshed for this iteration's matrix
+    int KBc = 0;                     // 64-column blocks
+    int64_t KBr = 0, ntile_r = 0, ntile_c = 0, nrest = 0;
+    uint64_t* bm_rows = nullptr;     // [(row tile * KBc + kb) * 16 + r]
+    uint64_t* bm_cols = nullptr;     // [(column tile * KBr + kbr) * 16 + c]
+    int64_t* rest_indptr = nullptr;  // reduced CSR of the original rows: [N + 1], cols / position in the full arrays / value
+    int32_t* rest_cols = nullptr;
+    int32_t* rest_pos = nullptr;
+    float* rest_x = nullptr;
+    int64_t* restm_colptr = nullptr; // reduced column-major mirror: [P_o * H + 1], rows / position in the full mirror / value
+    int32_t* restm_row = nullptr;
+    int32_t* restm_pos = nullptr;
+    float* restm_x = nullptr;
+    double* srow = nullptr;          // [N] s_i = x_i(1) - z
+    void* qd = nullptr;              // operand digits
+    double* cmax = nullptr;          // [64] column maxima of the operand
+    int32_t* part = nullptr;         // digit sums per chunk of the A^T Y product
+    double* w1 = nullptr;            // [H x L] result of the A^T Y product
 };
 
 struct TimingRec {
@@ -195,7 +220,11 @@ struct ddx_ctx {
     ddx::DevBuf knn_sorted;          // int32 [M*K] neighbour lists sorted by index
     ddx::DevBuf edge_w;              // double [M*K]
     ddx::DevBuf knn_cells;           // cells, interval tables and chunk lists of the emit pass (stage_knn)
+    ddx::DevBuf bp_buf, bp_work;     // bit-plane products: per-fit structures / per-product work space
+    ddx::BitPlanes bp;
     const int32_t* knn_overflow = nullptr;   // device counter: queries whose candidate list overflowed (exact rescan)
+    const int32_t* knn_ccount = nullptr;     // candidates listed per query (kNN point order) and that order (views into the kNN work space)
+    const int32_t* knn_perm = nullptr;
     bool have_knn = false;
     const unsigned long long* knn_window_total = nullptr;   // device counter: (query block, candidate tile) pairs screened by the emit pass
     double knn_window_pairs = 0.0;                          // the same count without pruning
@@ -220,6 +249,7 @@ struct ddx_ctx {
     int32_t lv_maxdeg[kLvKeep] = {0, 0}, lv_nbig[kLvKeep] = {0, 0};
     int64_t rowseg_rows = -1;                // original rows whose slice segments (rowseg) are valid for this fit's matrix
     int rowseg_ns = 0, rowseg_SR = 0;
+    bool bp_rowseg = false;                  // the original rows' segments were cut from the reduced (bit-plane) rows
     bool lv_narrow[kLvKeep] = {};            // the level's edge weights fit the 32-bit register sweep
     int64_t lv_n[kLvKeep] = {0, 0}, lv_E[kLvKeep] = {0, 0};
     const int64_t* lv_indptr[kLvKeep] = {nullptr, nullptr};
@@ -296,12 +326,13 @@ int stage_pca(ddx_ctx* ctx, int32_t C, int32_t oversample, int32_t n_iter, const
 int stage_operator_apply(ddx_ctx* ctx, int32_t transpose, const double* X, int32_t n, double* out);
 int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self);
 int stage_knn_metric(ddx_ctx* ctx, int32_t k, int32_t include_self, int32_t metric);
+int stage_knn_candidate_counts(ddx_ctx* ctx, int32_t* host_out);
 int stage_build_graph(ddx_ctx* ctx, int32_t mode);
 int stage_graph_relations(ddx_ctx* ctx, int32_t mode, int32_t* idx_host, double* w_host);
 void assemble_graph(int64_t M, int K, const int32_t* idx, const double* w, std::vector<int64_t>& ip,
                     std::vector<int32_t>& gi, std::vector<double>& gw);
 int validate_csr(ddx_ctx* ctx, const int64_t* indptr, const int32_t* cols, const float* vals, int64_t N, int32_t G);
-int stage_rankings(ddx_ctx* ctx);
+int stage_rankings(ddx_ctx* ctx, const int64_t* reduced_indptr = nullptr);   // reduced_indptr: row pointer of the original rows' entries that stay sparse (bit-plane mode)
 int stage_coarsen_graph(ddx_ctx* ctx, double gamma, int32_t sweeps, int32_t levels);
 int stage_refine_communities(ddx_ctx* ctx, const int32_t* coarse_labels, double gamma, int32_t sweeps, int32_t* labels_out);
 int stage_gene_variances(ddx_ctx* ctx, float* var_out);
@@ -309,6 +340,11 @@ int stage_gene_variances(ddx_ctx* ctx, float* var_out);
 // number of rows folded in so far (0 starts over).  max_entries: the largest number of entries one call will see.
 int gene_sums_fold(ddx_ctx* ctx, int32_t G, int64_t n_rows, int64_t row0, int64_t row1, int64_t e0, int64_t e1, int64_t max_entries);
 int stage_select_columns(ddx_ctx* ctx, const int64_t* cols, int32_t n_cols);
+// bit-plane products (k_bitplane.hip)
+int bp_build(ddx_ctx* ctx);
+int bp_refresh(ddx_ctx* ctx);
+int bp_rows_product(ddx_ctx* ctx, const double* Q, int L, int ld, double* Y, float* Y32);
+int bp_cols_product(ddx_ctx* ctx, const double* Y, int L, int ld, const double** w1);
 
 // host-side numerics
 void jacobi_eigh(int n, double* a /* n*n row-major, destroyed */, double* evals, double* evecs);

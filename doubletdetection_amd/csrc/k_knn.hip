@@ -901,6 +901,8 @@ int stage_knn_metric(ddx_ctx* ctx, int32_t k, int32_t include_self, int32_t metr
     DDX_HIP(ctx, hipGetLastError());
     ctx->knn_window_total = nullptr;
     ctx->knn_overflow = nullptr;
+    ctx->knn_ccount = nullptr;
+    ctx->knn_perm = nullptr;
     ctx->K = k;
     ctx->knn_self = include_self != 0;
     ctx->have_knn = true;
@@ -1395,6 +1397,22 @@ static int default_cells(int64_t M) {
     return (int)std::min<int64_t>(1024, std::max<int64_t>(64, want));
 }
 
+// candidates the emit pass listed for every query, in the caller's point order (statistics for the parity tests)
+__global__ void k_knn_counts_by_id(const int32_t* __restrict__ ccount, const int32_t* __restrict__ perm, int64_t M, int32_t* __restrict__ out) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < M) out[perm[r]] = ccount[r];
+}
+
+int stage_knn_candidate_counts(ddx_ctx* ctx, int32_t* host_out) {
+    if (!ctx->knn_ccount || !ctx->knn_perm) return set_err(ctx, DDX_E_ARG, "no euclidean kNN result");
+    const int64_t M = ctx->embM;
+    DDX_TRY(ensure(ctx, ctx->sort_vals_out, sizeof(int32_t) * (size_t)M));
+    k_knn_counts_by_id<<<(unsigned)ceil_div(M, 256), 256, 0, ctx->stream>>>(ctx->knn_ccount, ctx->knn_perm, M, ctx->sort_vals_out.as<int32_t>());
+    DDX_HIP(ctx, hipMemcpyAsync(host_out, ctx->sort_vals_out.p, sizeof(int32_t) * (size_t)M, hipMemcpyDeviceToHost, ctx->stream));
+    DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return DDX_OK;
+}
+
 // first tile whose nominal cell is >= c (the nominal cells ascend along the tiles): ctile[0..Kc], ctile[Kc] = real tiles
 __global__ void k_cells_tilestart(const int32_t* __restrict__ tilecell, int ntr, int Kc, int32_t* __restrict__ ctile) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1687,6 +1705,8 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
     ctx->knn_window_total = wtotal;
     ctx->knn_window_pairs = (double)(Mp / (16 * kEmitRT)) * (double)ntiles;     // (wave of 32 queries, candidate tile) pairs
     ctx->knn_overflow = ccount + Mp;
+    ctx->knn_ccount = ccount;
+    ctx->knn_perm = perm;
     ctx->K = k;
     ctx->knn_self = include_self != 0;
     ctx->have_knn = true;

@@ -273,6 +273,8 @@ struct LdsSpmmArgs {
     const int32_t* perm;          // outputs sorted by stored entries (descending): rank -> output
     // ROWS
     const int64_t* indptr; const int32_t* cols; const float* x; const float* zcol; const int32_t* rowseg; const double* tvec;
+    // ROWS, bit-plane mode: rows < nsplit (the original cells) keep only their entries other than 1, in arrays of their own
+    const int64_t* indptr_r; const int32_t* cols_r; const float* x_r; int64_t nsplit;
     // COLS
     const int64_t* cp_o; const int32_t* row_o; const float* x_o; int P_o;
     const int64_t* cp_s; const int32_t* row_s; const float* x_s; int p_s0, P_s;
@@ -300,21 +302,15 @@ template <int SLOTS> struct LdsFetch {
 // segment re-read its first entry (always a readable address), so the loads are unconditional and nothing
 // consumes them before the staging step of the *next* round -- that is what keeps them in flight.
 template <int SLOTS>
-__device__ __forceinline__ LdsFetch<SLOTS> lds_fetch(const int32_t* __restrict__ idx, const float* __restrict__ x,
+__device__ __forceinline__ LdsFetch<SLOTS> lds_fetch(const int32_t* const (&idx)[SLOTS], const float* const (&x)[SLOTS],
                                                      const int32_t (&l)[SLOTS], const int32_t (&h)[SLOTS], int r, int lane) {
     LdsFetch<SLOTS> f;
 #pragma unroll
     for (int g = 0; g < SLOTS; ++g) {
         int32_t p = l[g] + r * kLdsChunk + lane;         // positions fit 31 bits (stage_create_doublets enforces it)
         p = p < h[g] ? p : l[g];
-        if (DDX_SPMM_DBG & 2) p = l[g];
-        if (DDX_SPMM_NT) {
-            f.i[g] = __builtin_nontemporal_load(idx + p);
-            f.x[g] = __builtin_nontemporal_load(x + p);
-        } else {
-            f.i[g] = idx[p];
-            f.x[g] = x[p];
-        }
+        f.i[g] = idx[g][p];
+        f.x[g] = x[g][p];
     }
     return f;
 }
@@ -491,7 +487,7 @@ __device__ __forceinline__ void lds_round(const LdsFetch<SLOTS>& f, const int (&
 // services a ds_read_b128 -- {0-3,12-15,20-27}, {4-11,16-19,28-31} and the same + 32 -- so the lanes served in one
 // LDS cycle all read the same operand row (no bank conflicts) or the same staged entry (broadcast).  A lane holds
 // four adjacent sketch columns; with ld = 40 ten of the 16 lanes of a group work.
-template <bool ROWS, int SLOTS, bool PK, int CPL, int OWN>
+template <bool ROWS, int SLOTS, bool PK, int CPL, int OWN, bool DUAL = false>
 __global__ void __launch_bounds__(kLdsThreads) k_spmm_lds(const LdsSpmmArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     float* opS = reinterpret_cast<float*>(smem);
@@ -534,7 +530,8 @@ __global__ void __launch_bounds__(kLdsThreads) k_spmm_lds(const LdsSpmmArgs a) {
     const int64_t myout = lane < PERW ? out_index(lane) : a.nOut;
     const bool mine = myout < a.nOut;
     int64_t rowbase = 0;
-    if (ROWS && mine) rowbase = a.indptr[myout];
+    const int reduced = (DUAL && ROWS && mine && myout < a.nsplit) ? 1 : 0;      // an original cell's row in bit-plane mode: the reduced arrays
+    if (ROWS && mine) rowbase = reduced ? a.indptr_r[myout] : a.indptr[myout];
     float zmine = 0.0f;                              // COLS: z of the owned column, handed out by readlane
     if (!ROWS && mine) zmine = a.zcol[myout];
     double acc[OWN][CPL];
@@ -588,25 +585,34 @@ __global__ void __launch_bounds__(kLdsThreads) k_spmm_lds(const LdsSpmmArgs a) {
             }
 
             // unit k covers the SLOTS segments of local outputs k*SLOTS + g
-            auto unit_bounds = [&](int k, int32_t (&l)[SLOTS], int32_t (&h)[SLOTS], int& maxlen) {
+            auto unit_bounds = [&](int k, int32_t (&l)[SLOTS], int32_t (&h)[SLOTS], const int32_t* (&ip)[SLOTS], const float* (&xp)[SLOTS], int& maxlen) {
                 maxlen = 0;
 #pragma unroll
                 for (int g = 0; g < SLOTS; ++g) {
                     l[g] = __builtin_amdgcn_readlane(lo, k * SLOTS + g);
                     h[g] = __builtin_amdgcn_readlane(hi, k * SLOTS + g);
+                    const bool red = DUAL && ROWS && __builtin_amdgcn_readlane(reduced, k * SLOTS + g) != 0;
+                    ip[g] = red ? a.cols_r : sidx;
+                    xp[g] = red ? a.x_r : sx;
                     const int len = h[g] - l[g];
                     maxlen = len > maxlen ? len : maxlen;
                 }
             };
             int32_t l[SLOTS], h[SLOTS];
+            const int32_t* ip[SLOTS];
+            const float* xp[SLOTS];
             int maxlen;
-            unit_bounds(0, l, h, maxlen);
-            LdsFetch<SLOTS> cur = lds_fetch<SLOTS>(sidx, sx, l, h, 0, lane);
+            unit_bounds(0, l, h, ip, xp, maxlen);
+            LdsFetch<SLOTS> cur = lds_fetch<SLOTS>(ip, xp, l, h, 0, lane);
 #pragma unroll
             for (int k = 0; k < OWN; ++k) {
                 int32_t l2[SLOTS], h2[SLOTS];
+                const int32_t* ip2[SLOTS];
+                const float* xp2[SLOTS];
+#pragma unroll
+                for (int g = 0; g < SLOTS; ++g) { l2[g] = 0; h2[g] = 0; ip2[g] = sidx; xp2[g] = sx; }
                 int maxlen2 = 0;
-                if (k + 1 < OWN) unit_bounds(k + 1, l2, h2, maxlen2);
+                if (k + 1 < OWN) unit_bounds(k + 1, l2, h2, ip2, xp2, maxlen2);
                 double zc[SLOTS];
 #pragma unroll
                 for (int g = 0; g < SLOTS; ++g)
@@ -614,8 +620,8 @@ __global__ void __launch_bounds__(kLdsThreads) k_spmm_lds(const LdsSpmmArgs a) {
                 for (int r = 0;; ++r) {
                     const bool more = (r + 1) * kLdsChunk < maxlen;
                     LdsFetch<SLOTS> nxt = cur;
-                    if (more) nxt = lds_fetch<SLOTS>(sidx, sx, l, h, r + 1, lane);
-                    else if (k + 1 < OWN) nxt = lds_fetch<SLOTS>(sidx, sx, l2, h2, 0, lane);
+                    if (more) nxt = lds_fetch<SLOTS>(ip, xp, l, h, r + 1, lane);
+                    else if (k + 1 < OWN) nxt = lds_fetch<SLOTS>(ip2, xp2, l2, h2, 0, lane);
                     const int left = maxlen - r * kLdsChunk;
                     if (left > 0) {
                         const int nsteps = left < kLdsChunk ? left : kLdsChunk;
@@ -629,7 +635,7 @@ __global__ void __launch_bounds__(kLdsThreads) k_spmm_lds(const LdsSpmmArgs a) {
                 }
                 if (k + 1 < OWN) {
 #pragma unroll
-                    for (int g = 0; g < SLOTS; ++g) { l[g] = l2[g]; h[g] = h2[g]; }
+                    for (int g = 0; g < SLOTS; ++g) { l[g] = l2[g]; h[g] = h2[g]; ip[g] = ip2[g]; xp[g] = xp2[g]; }
                     maxlen = maxlen2;
                 }
             }
@@ -688,13 +694,14 @@ __global__ void k_operand_copy(const double* __restrict__ in, int64_t R, int L, 
 
 // W[j,c] = sum_p Wp[p][j][c] - m_j u_c   (panels added in order)
 __global__ void k_sum_panels(const double* __restrict__ Wp, int P, int32_t H, int L, const double* __restrict__ colmean,
-                             const double* __restrict__ uvec, double* __restrict__ W) {
+                             const double* __restrict__ uvec, double* __restrict__ W, const double* __restrict__ extra = nullptr) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (int64_t)H * L) return;
     const int64_t j = t / L;
     const int c = (int)(t - j * L);
     double s = 0.0;
     for (int p = 0; p < P; ++p) s += Wp[(int64_t)p * H * L + t];
+    if (extra) s += extra[t];                            // the bit-plane part of the product
     W[t] = s - colmean[j] * uvec[c];
 }
 
@@ -1092,6 +1099,7 @@ struct PcaWork {
     int64_t M;
     int32_t H;
     bool lds;          // LDS-staged products (needs gather32 and a slice that fits the LDS)
+    bool bitplane = false;   // the original rows' entries equal to 1 go through the bit-plane products (k_bitplane.hip)
     int rows_SR = 0, rows_ns = 0;   // A Q: slice height / slice count of the H-row operand
     double* partial;   // scratch for block partials
     double* small;     // [4*L*L + 4*L]: G, Rinv, T, vecs
@@ -1232,6 +1240,11 @@ static int lds_owners(int64_t nOut, int slots, int ld) {
 
 template <bool ROWS, int SLOTS, bool PK, int CPL, int OWN>
 static int launch_lds_t(ddx_ctx* c, const LdsSpmmArgs& a, unsigned grid, size_t lds_bytes) {
+    if (ROWS && a.nsplit > 0) {                    // bit-plane mode: the original rows read their reduced arrays
+        DDX_TRY(allow_dynamic_lds(c, reinterpret_cast<const void*>(&k_spmm_lds<ROWS, SLOTS, PK, CPL, OWN, true>), (int)kLdsBudget));
+        k_spmm_lds<ROWS, SLOTS, PK, CPL, OWN, true><<<grid, kLdsThreads, lds_bytes, c->stream>>>(a);
+        return DDX_OK;
+    }
     DDX_TRY(allow_dynamic_lds(c, reinterpret_cast<const void*>(&k_spmm_lds<ROWS, SLOTS, PK, CPL, OWN>), (int)kLdsBudget));
     k_spmm_lds<ROWS, SLOTS, PK, CPL, OWN><<<grid, kLdsThreads, lds_bytes, c->stream>>>(a);
     return DDX_OK;
@@ -1288,8 +1301,14 @@ static int apply_rows(PcaWork& w, const double* Qcol, double* Yrow) {  // A Q : 
         a.z_uniform = c->scaled ? 0 : 1;              // unscaled: every column's unstored value is log(pseudocount)
         a.zval = c->zvalue;
         a.perm = c->rank_rows;
+        a.nsplit = 0;
+        if (w.bitplane) {                               // the original rows' ones are added by the bit-plane product below
+            a.indptr_r = c->bp.rest_indptr; a.cols_r = c->bp.rest_cols; a.x_r = c->bp.rest_x; a.nsplit = c->N;
+        }
         const size_t lds_bytes = (size_t)a.SR * a.ld * 4 + (size_t)((a.SR + 3) & ~3) * 4 + lds_stage_bytes(slots, lds_packed());
-        return launch_lds<true>(c, a, slots, (unsigned)a.owners, lds_bytes);
+        DDX_TRY(launch_lds<true>(c, a, slots, (unsigned)a.owners, lds_bytes));
+        if (w.bitplane) DDX_TRY(bp_rows_product(c, Qcol, w.L, a.ld, Yrow, a.out32));
+        return DDX_OK;
     }
     if (w.gather32) {
         const int ld = (w.L + 3) & ~3, lpn = ld / 4;
@@ -1334,14 +1353,17 @@ static int apply_cols(PcaWork& w, const double* Yrow, double* Wcol) {  // A^T Y 
         a.groups = std::max(1, std::min(P, 512 * kLdsWgPerCu / a.owners));
         a.zcol = c->zcol.as<float>();
         a.cp_o = c->csc_o_colptr.as<int64_t>(); a.row_o = c->csc_o_row.as<int32_t>(); a.x_o = c->csc_o_x.as<float>(); a.P_o = c->P_o;
+        if (w.bitplane) { a.cp_o = c->bp.restm_colptr; a.row_o = c->bp.restm_row; a.x_o = c->bp.restm_x; }
         a.cp_s = c->csc_s_colptr.as<int64_t>(); a.row_s = c->csc_s_row.as<int32_t>(); a.x_s = c->csc_s_x.as<float>();
         a.p_s0 = c->p_s0; a.P_s = c->P_s;
         a.out = c->pcaPanel.as<double>();
         a.perm = c->rank_cols;
         const size_t lds_bytes = (size_t)a.SR * a.ld * 4 + lds_stage_bytes(slots, lds_packed());
         DDX_TRY(launch_lds<false>(c, a, slots, (unsigned)(a.owners * a.groups), lds_bytes));
+        const double* w1 = nullptr;
+        if (w.bitplane) DDX_TRY(bp_cols_product(c, Yrow, w.L, a.ld, &w1));
         k_sum_panels<<<(unsigned)ceil_div((int64_t)w.H * w.L, 256), 256, 0, c->stream>>>(c->pcaPanel.as<double>(), a.groups, w.H, w.L, c->colmean.as<double>(),
-                                                                                          uvec, Wcol);
+                                                                                          uvec, Wcol, w1);
         return DDX_OK;
     }
     if (w.gather32) {
@@ -1400,17 +1422,31 @@ static int lds_setup(ddx_ctx* ctx, int L, PcaWork& w) {
     w.lds = true;
     w.rows_ns = (int)ceil_div(H, srmax);
     w.rows_SR = (int)((ceil_div(H, w.rows_ns) + 3) & ~3);
+    // bit planes: unscaled matrix (the value of a count of 1 then depends on the row only), at most 64 sketch columns
+    w.bitplane = ctx->opt.bitplane && !ctx->scaled && ld <= 64 && ctx->N >= 16 && ctx->have_lognorm;
+    if (w.bitplane) {
+        const bool fresh = !ctx->bp.ready;
+        DDX_TRY(bp_build(ctx));
+        DDX_TRY(bp_refresh(ctx));
+        if (fresh) ctx->rowseg_rows = -1;              // the original rows' segments now refer to the reduced rows
+    }
     const void* before = ctx->rowseg.p;
     DDX_TRY(ensure(ctx, ctx->rowseg, sizeof(int32_t) * (size_t)M * (w.rows_ns + 1)));
     ScopedTimer t(ctx, "row_segments");
-    DDX_TRY(stage_rankings(ctx));
+    DDX_TRY(stage_rankings(ctx, w.bitplane ? ctx->bp.rest_indptr : nullptr));
     // the original cells' rows (columns fixed for the whole fit) are cut once; every iteration cuts its synthetic rows
-    const bool kept = before && before == ctx->rowseg.p && ctx->rowseg_rows == ctx->N && ctx->rowseg_ns == w.rows_ns && ctx->rowseg_SR == w.rows_SR;
-    const int64_t row0 = kept ? ctx->N : 0;
-    if (M > row0)
-        k_row_segments<<<(unsigned)ceil_div((M - row0) * (w.rows_ns + 1), 256), 256, 0, ctx->stream>>>(ctx->aug_indptr.as<int64_t>(), ctx->aug_indices.as<int32_t>(), row0, M,
-                                                                                                  w.rows_ns, w.rows_SR, ctx->rowseg.as<int32_t>());
-    ctx->rowseg_rows = ctx->N; ctx->rowseg_ns = w.rows_ns; ctx->rowseg_SR = w.rows_SR;
+    const bool kept = before && before == ctx->rowseg.p && ctx->rowseg_rows == ctx->N && ctx->rowseg_ns == w.rows_ns && ctx->rowseg_SR == w.rows_SR &&
+                      ctx->bp_rowseg == w.bitplane;
+    const int64_t N = ctx->N;
+    if (!kept && N > 0) {
+        const int64_t* ip = w.bitplane ? ctx->bp.rest_indptr : ctx->aug_indptr.as<int64_t>();
+        const int32_t* ix = w.bitplane ? ctx->bp.rest_cols : ctx->aug_indices.as<int32_t>();
+        k_row_segments<<<(unsigned)ceil_div(N * (w.rows_ns + 1), 256), 256, 0, ctx->stream>>>(ip, ix, 0, N, w.rows_ns, w.rows_SR, ctx->rowseg.as<int32_t>());
+    }
+    if (M > N)
+        k_row_segments<<<(unsigned)ceil_div((M - N) * (w.rows_ns + 1), 256), 256, 0, ctx->stream>>>(ctx->aug_indptr.as<int64_t>(), ctx->aug_indices.as<int32_t>(), N, M,
+                                                                                                w.rows_ns, w.rows_SR, ctx->rowseg.as<int32_t>());
+    ctx->rowseg_rows = ctx->N; ctx->rowseg_ns = w.rows_ns; ctx->rowseg_SR = w.rows_SR; ctx->bp_rowseg = w.bitplane;
     return DDX_OK;
 }
 
@@ -1461,10 +1497,10 @@ int stage_operator_apply(ddx_ctx* ctx, int32_t mode, const double* X, int32_t n,
     DDX_HIP(ctx, hipMemcpyAsync(in_d, X, sizeof(double) * (size_t)(in_rows ? M : (int64_t)H) * n, hipMemcpyHostToDevice, ctx->stream));
     double* res = nullptr;
     switch (mode) {
-        case 0: apply_rows(w, colA, rowA); res = rowA; break;
-        case 1: apply_cols(w, rowA, colA); res = colA; break;
-        case 2: apply_rows(w, colA, rowA); apply_cols(w, rowA, colB); res = colB; break;
-        case 3: apply_cols(w, rowA, colA); apply_rows(w, colA, rowB); res = rowB; break;
+        case 0: DDX_TRY(apply_rows(w, colA, rowA)); res = rowA; break;
+        case 1: DDX_TRY(apply_cols(w, rowA, colA)); res = colA; break;
+        case 2: DDX_TRY(apply_rows(w, colA, rowA)); DDX_TRY(apply_cols(w, rowA, colB)); res = colB; break;
+        case 3: DDX_TRY(apply_cols(w, rowA, colA)); DDX_TRY(apply_rows(w, colA, rowB)); res = rowB; break;
         default: return set_err(ctx, DDX_E_ARG, "operator mode must be 0..3");
     }
     DDX_HIP(ctx, hipMemcpyAsync(out, res, sizeof(double) * (size_t)(out_rows ? M : (int64_t)H) * n, hipMemcpyDeviceToHost, ctx->stream));

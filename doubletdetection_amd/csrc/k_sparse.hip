@@ -309,7 +309,7 @@ __global__ void k_col_lengths(const int64_t* __restrict__ cp_o, int P_o, const i
 
 // Rankings used by the LDS-staged operator products: rows and columns sorted by their number of stored entries
 // (descending, ties by index -- the radix sort is stable).  Rebuilt per iteration: the synthetic rows change.
-int stage_rankings(ddx_ctx* ctx) {
+int stage_rankings(ddx_ctx* ctx, const int64_t* reduced_indptr) {
     const int64_t M = ctx->M;
     const int32_t H = ctx->H;
     const int64_t n = M + H;
@@ -319,6 +319,8 @@ int stage_rankings(ddx_ctx* ctx) {
     int32_t* ids_in = reinterpret_cast<int32_t*>(keys_out + n);
     int32_t* ids_out = ids_in + n;
     k_row_lengths<<<(unsigned)ceil_div(M, 256), 256, 0, ctx->stream>>>(ctx->aug_indptr.as<int64_t>(), M, keys_in, ids_in);
+    if (reduced_indptr && ctx->N > 0)      // bit-plane mode: an original row's sparse work is its entries other than 1
+        k_row_lengths<<<(unsigned)ceil_div(ctx->N, 256), 256, 0, ctx->stream>>>(reduced_indptr, ctx->N, keys_in, ids_in);
     k_col_lengths<<<(unsigned)ceil_div(H, 256), 256, 0, ctx->stream>>>(ctx->csc_o_colptr.as<int64_t>(), ctx->P_o, ctx->csc_s_colptr.as<int64_t>(), ctx->P_s, H,
                                                                        keys_in + M, ids_in + M);
     size_t tmp_r = 0, tmp_c = 0;
@@ -833,6 +835,10 @@ int stage_upload_counts(ddx_ctx* ctx, int64_t N, int32_t H, const int64_t* indpt
     ctx->S = 0;
     ctx->M = N;
     ctx->have_synth = ctx->have_lognorm = ctx->scaled = ctx->have_emb = ctx->have_knn = false;
+    // whatever was derived from the previous resident rows is stale: the slice segments of the A Q pass (a second
+    // ddx_select_columns of the same width would otherwise keep the old rows' segments) and the bit planes
+    ctx->rowseg_rows = -1;
+    ctx->bp.ready = ctx->bp.values = false;
     DDX_TRY(ensure(ctx, ctx->lib32, sizeof(float) * (N + N / 2 + 2)));
     DDX_TRY(ensure(ctx, ctx->lib64, sizeof(double) * (N + N / 2 + 2)));
     {
@@ -1297,6 +1303,7 @@ if (ctx->counts_exact)
     }
     DDX_HIP(ctx, hipGetLastError());
     ctx->pseudocount = pseudocount;
+    ctx->bp.values = false;              // the reduced structures of the bit-plane products hold the last iteration's values
     ctx->have_lognorm = true;
     ctx->scaled = false;
     ctx->have_emb = ctx->have_knn = false;

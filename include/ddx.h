@@ -170,6 +170,9 @@ int ddx_get_knn_window_fraction(ddx_ctx* ctx, double* fraction);
 /* statistics: queries of the last ddx_knn whose candidate list overflowed its slots and were re-scanned exactly against
  * every point (the result is exact either way; the parity tests make a point of checking those queries). */
 int ddx_get_knn_overflow_count(ddx_ctx* ctx, int64_t* n_queries);
+/* statistics: candidates the distance screen listed for every query of the last ddx_knn (more than the list holds = that query
+ * overflowed); the parity tests pick the queries with the longest lists from it. */
+int ddx_get_knn_candidate_counts(ddx_ctx* ctx, int32_t* counts_out /* [M] */);
 
 /* ---- graph construction (device) ------------------------------------------------------------
  * mode 0: PhenoGraph Jaccard graph, prune=True  (mutual kNN, weight J_ij*J_ji)

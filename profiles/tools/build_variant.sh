@@ -8,7 +8,7 @@ src=$root/doubletdetection_amd/csrc
 out=$root/profiles/tools/variants
 obj=$out/obj_$name
 mkdir -p "$obj"
-for f in ddx_api k_sparse k_pca k_knn k_prologue k_louvain; do
+for f in ddx_api k_sparse k_pca k_bitplane k_knn k_prologue k_louvain; do
     extra=""; [ $f = k_knn ] && extra="-mllvm -amdgpu-mfma-vgpr-form"
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $extra "$@" -c $src/$f.hip -o $obj/$f.o &
 done
