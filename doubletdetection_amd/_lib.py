@@ -12,7 +12,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DDX_LIB") or os.path.join(_HERE, "libddx.so")      # DDX_LIB: an experimental build (profiles/tools)
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _lib = None
 
@@ -72,6 +72,9 @@ _SIGNATURES = {
     "ddx_knn": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "ddx_knn_metric": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "ddx_get_knn": (C.c_int, [C.c_void_p, c_i32_p, c_f64_p]),
+    "ddx_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p]),
+    "ddx_pca_exact_sparse": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_int32, c_f64_p, C.POINTER(C.c_int32), C.c_void_p,
+                                       C.c_void_p]),
     "ddx_get_knn_window_fraction": (C.c_int, [C.c_void_p, c_f64_p]),
     "ddx_get_knn_overflow_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "ddx_get_knn_candidate_counts": (C.c_int, [C.c_void_p, c_i32_p]),
@@ -352,6 +355,59 @@ def score_communities(full, num_cells: int):
 
 
 # ---- device context ----------------------------------------------------------------------------
+# Tuning / diagnostic switches applied to every context this process opens (ddx_set_option; include/ddx.h lists the keys).
+# ``OPTIONS`` is the programmatic handle; the environment variable DDX_OPTIONS="key=value,key=value" is read here, in the
+# Python host layer, for tools and tests -- the library itself never looks at the environment.
+OPTIONS: dict = {}
+
+
+def current_options() -> dict:
+    opts = {}
+    for item in os.environ.get("DDX_OPTIONS", "").split(","):
+        if item.strip():
+            k, _, v = item.partition("=")
+            opts[k.strip()] = v.strip()
+    opts.update({str(k): str(v) for k, v in OPTIONS.items()})
+    return opts
+
+
+import contextlib
+import threading
+
+_blas_lock = threading.Lock()
+_blas_depth = 0
+_blas_limit = None
+
+
+@contextlib.contextmanager
+def single_threaded_blas():
+    """The host's BLAS / LAPACK on ONE thread while any caller is inside (small dense problems: a 256-thread pool costs more
+    than it returns, and its workers keep spinning afterwards -- which slows the kernel launches of every lane of the
+    process).  The limit is process-wide, so it is reference-counted: the first entry sets it, the last exit lifts it,
+    whatever order the lanes (threads) come and go in."""
+    global _blas_depth, _blas_limit
+    with _blas_lock:
+        if _blas_depth == 0:
+            try:
+                from threadpoolctl import threadpool_limits
+
+                _blas_limit = threadpool_limits(limits=1)
+            except Exception:          # threadpoolctl absent: correct, just slower
+                _blas_limit = None
+        _blas_depth += 1
+    try:
+        yield
+    finally:
+        with _blas_lock:
+            _blas_depth -= 1
+            if _blas_depth == 0 and _blas_limit is not None:
+                _blas_limit.restore_original_limits()
+                _blas_limit = None
+
+
+_EIGH_FN = C.CFUNCTYPE(C.c_int, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p)
+
+
 class Context:
     """One GPU, one stream, all device buffers of a fit (ddx_ctx)."""
 
@@ -361,11 +417,26 @@ class Context:
         _check(self._lib.ddx_create(int(device), C.byref(self._h)))
         self.device = device
         self.N = self.H = self.S = 0
+        self._guard = False
+        self.apply_options()
+
+    def set_option(self, key: str, value) -> None:
+        self._c(self._lib.ddx_set_option(self._h, str(key).encode(), str(value).encode()))
+        if key == "arena_guard":
+            self._guard = str(value) not in ("", "0")
+        elif key == "defaults":
+            self._guard = False
+
+    def apply_options(self, options: dict | None = None) -> None:
+        """Every switch back to its default, then the process-wide ones (``OPTIONS`` / DDX_OPTIONS) and ``options``."""
+        self.set_option("defaults", "")
+        for k, v in {**current_options(), **(options or {})}.items():
+            self.set_option(k, v)
 
     def close(self):
         if self._h:
             try:
-                if os.environ.get("DDX_ARENA_GUARD", "0") not in ("", "0"):
+                if self._guard:
                     rc = self._lib.ddx_check_memory(self._h)
                     if rc == -4:                        # DDX_E_NUMERIC: a buffer was overrun
                         _check(rc, self._h)
@@ -531,6 +602,46 @@ class Context:
             self._c(self._lib.ddx_pca(self._h, int(n_components), int(n_oversamples), int(n_iter), _p(q0, c_f64_p), q0.shape[0]))
         self._C = int(n_components)
         self._embM = self.M
+
+    def pca_exact_sparse(self, n_components: int, start, tol: float = 1e-7, max_steps: int = 12, n_oversamples: int = 10) -> int:
+        """Block Lanczos PCA of the sparse operator (ddx_pca_exact_sparse); returns the number of steps taken.  The small
+        projected eigenproblem is solved by numpy.linalg.eigh (LAPACK), handed to the library as a callback."""
+        start = np.ascontiguousarray(start, dtype=np.float64)
+        steps = C.c_int32(0)
+        failure = []
+
+        def eigh(n, n_largest, a, w, _user):
+            try:
+                mat = np.ctypeslib.as_array(a, shape=(n, n))
+                vals_out = np.ctypeslib.as_array(w, shape=(n,))
+                # block tridiagonal up to rounding: LAPACK's banded solver for the wanted pairs only
+                rows, cols = np.nonzero(np.abs(mat) > 1e-11 * np.abs(mat).max())
+                band = int(np.abs(rows - cols).max()) if len(rows) else 0
+                if n > 160 and band < n // 3:
+                    from scipy.linalg import eig_banded
+
+                    ab = np.zeros((band + 1, n))
+                    for d in range(band + 1):                 # lower form: ab[d, j] = a[j + d, j]
+                        ab[d, :n - d] = np.diagonal(mat, -d)
+                    vals, vecs = eig_banded(ab, lower=True, select="i", select_range=(n - n_largest, n - 1))
+                else:
+                    vals, vecs = np.linalg.eigh(mat)
+                    vals, vecs = vals[n - n_largest:], vecs[:, n - n_largest:]
+                mat[:, n - n_largest:] = vecs
+                vals_out[n - n_largest:] = vals
+                return 0
+            except Exception as err:          # (never let an exception cross the C boundary)
+                failure.append(err)
+                return 1
+
+        cb = _EIGH_FN(eigh)
+        with single_threaded_blas():
+            self._c(self._lib.ddx_pca_exact_sparse(self._h, int(n_components), int(n_oversamples), float(tol), int(max_steps),
+                                                   _p(start, c_f64_p), C.byref(steps), C.cast(cb, C.c_void_p), None))
+        if failure:
+            raise failure[0]
+        self._embM, self._C = self.M, int(n_components)
+        return int(steps.value)
 
     def operator_apply(self, X, mode: int):
         """Products with the centred matrix A held by the context (include/ddx.h: ddx_operator_apply):

@@ -72,17 +72,24 @@ def _keep_contexts() -> bool:
     return os.environ.get("DDX_KEEP_CONTEXT", "1") not in ("", "0")
 
 
-def _park_limit_bytes() -> int:
-    """HBM the parked contexts of one GPU may hold between fits (DDX_PARK_MAX_GB, default 128 of the 288): what goes beyond is
-    returned to the driver when a context is parked, largest holder first.  The switches a context reads from the
-    environment (DDX_SPMM, DDX_MIRROR, DDX_UPLOAD, ...) are re-read whenever a parked context starts its next fit."""
-    return int(float(os.environ.get("DDX_PARK_MAX_GB", "128")) * (1 << 30))
+def _park_limit_bytes(total_bytes: int | None = None) -> int:
+    """HBM the parked contexts of one GPU may hold between fits: a quarter of the GPU's memory by default (72 of the 288 GB of
+    an MI355X -- whatever else shares the GPU keeps the rest; DDX_PARK_MAX_GB raises or lowers it).  What goes beyond is
+    returned to the driver when a context is parked, largest holder first."""
+    env = os.environ.get("DDX_PARK_MAX_GB")
+    if env:
+        return int(float(env) * (1 << 30))
+    return int(0.25 * (total_bytes if total_bytes else 288 << 30))
 
 
 def _park(device, ctx) -> None:
     parked = _CONTEXT_POOL.setdefault(device, [])
     parked.append(ctx)
-    limit = _park_limit_bytes()
+    try:
+        total = ctx.device_memory()[1]
+    except Exception:
+        total = None
+    limit = _park_limit_bytes(total)
     held = [c.device_bytes() for c in parked]
     while sum(held) > limit:
         big = max(range(len(parked)), key=lambda i: held[i])
@@ -112,7 +119,11 @@ class _HipEngine:
     def __init__(self, device: int):
         self.device = device
         parked = _CONTEXT_POOL.get(device)
-        self.ctx = parked.pop() if parked else _lib.Context(device)
+        if parked:
+            self.ctx = parked.pop()
+            self.ctx.apply_options()                     # a parked context starts its next fit with the switches as they are NOW
+        else:
+            self.ctx = _lib.Context(device)
         timing = os.environ.get("DDX_TIMING") == "1"     # per-kernel HIP-event timing (bench.py / profiling)
         self.ctx.timing_enable(timing)
         self.timing = timing
@@ -128,7 +139,7 @@ class _HipEngine:
                 ctx, self.ctx = self.ctx, None
                 ctx.close()
                 return
-            if os.environ.get("DDX_ARENA_GUARD", "0") not in ("", "0"):
+            if self.ctx._guard:
                 self.ctx.check_memory()                  # overflow detector (tests): raises, naming the buffer
             if _keep_contexts():
                 _park(self.device, self.ctx)
@@ -231,52 +242,18 @@ class _HipEngine:
 
     def _pca_arpack(self, n_components, seed):
         """pseudocount == 1 without scaling keeps the matrix sparse upstream and switches sc.tl.pca to
-        svd_solver="arpack" (dd.py:296-297,308): an implicitly-centred truncated SVD converged to machine
-        precision.  scipy's ``svds(solver="arpack")`` -- what sklearn's PCA runs there -- is ARPACK's symmetric Lanczos
-        (``eigsh``) on the smaller Gram operator A^T A (or A A^T); the recurrences stay on the host (the very routine
-        upstream uses), every operator application is ONE device call (two sparse products back to back, only the short
-        vector crosses PCIe) instead of the two round trips with an M-vector in between that a matvec / rmatvec pair costs.
-        Start vector and sign convention as in sklearn's PCA arpack branch (_init_arpack_v0,
-        svd_flip(u_based_decision=False))."""
-        from scipy.sparse.linalg import LinearOperator, eigsh
-
+        svd_solver="arpack" (dd.py:296-297,308): an implicitly-centred truncated SVD converged to tolerance.  Upstream's
+        ARPACK is a single-vector Lanczos on the smaller Gram operator (232 passes over the matrix per PCA at
+        configs[1]); the device runs the block version of the same Krylov method behind one C-ABI call
+        (``ddx_pca_exact_sparse``: one pair of 40-column products per step, full re-orthogonalisation, Rayleigh-Ritz of the
+        small projected matrix), until the residual of every wanted pair is below 1e-5 of its eigenvalue -- the scores then sit
+        within 1e-5 of ARPACK's (profiles/r04_block_lanczos.txt), the tolerance they are compared at being 1e-4.  The start block is drawn as the randomized PCA draws its own; the converged subspace does
+        not depend on it.  Sign convention as in sklearn's PCA arpack branch (svd_flip(u_based_decision=False))."""
         c = self.ctx
-        M, H = c.M, c.H
-        small, mode = (H, 2) if H <= M else (M, 3)
-        self.arpack_products = 0
-
-        pad = np.zeros((small, 8))          # (the device products run twice as fast on 8 columns as on a single one)
-
-        def gram(x):
-            self.arpack_products += 1
-            pad[:, 0] = np.asarray(x, dtype=np.float64).ravel()
-            return c.operator_apply(pad, mode)[:, 0]
-
-        op = LinearOperator((small, small), dtype=np.float64, matvec=gram)
-        v0 = np.random.RandomState(seed).uniform(-1, 1, size=small)
-        try:        # ARPACK's own dense work (a few 61-column updates per step) is slower on 256 BLAS threads than on one
-            from threadpoolctl import threadpool_limits
-            limit = threadpool_limits(limits=1)
-        except Exception:          # threadpoolctl absent: correct, just slower
-            import contextlib
-            limit = contextlib.nullcontext()
-        with limit:
-            evals, evecs = eigsh(op, k=n_components, tol=0.0, v0=v0, which="LM")
-        top = np.argsort(evals)[::-1]
-        sv = np.sqrt(np.maximum(evals[top], 0.0))
-        evecs = evecs[:, top]
-        if H <= M:
-            comps = evecs                                           # H x C: right singular vectors
-            pick = np.argmax(np.abs(comps), axis=0)
-            signs = np.sign(comps[pick, np.arange(comps.shape[1])])
-            scores = self._apply(comps * signs, 0)                  # A V = U S
-        else:
-            left = evecs                                            # M x C: left singular vectors
-            comps = self._apply(left, 1) / np.where(sv > 0, sv, 1.0)
-            pick = np.argmax(np.abs(comps), axis=0)
-            signs = np.sign(comps[pick, np.arange(comps.shape[1])])
-            scores = left * sv * signs
-        c.set_embedding(scores.astype(np.float32))
+        small = min(c.M, c.H)
+        over = max(0, min(10, small - n_components))
+        start = np.random.RandomState(seed).normal(size=(small, n_components + over))
+        self.lanczos_steps = c.pca_exact_sparse(n_components, start, tol=1e-5, max_steps=40, n_oversamples=over)
 
     def _pca_exact(self, n_components, block=40):
         """sklearn's exact regimes ("full" / "covariance_eigh"): eigen-decomposition of the smaller Gram
@@ -744,7 +721,7 @@ class BoostClassifier:
             if _keep_contexts():
                 # what a fit allocates should also fit the allowance of the parked contexts: a context trimmed at the end
                 # of every fit obtains its memory from the driver again at the start of the next (seconds at this size)
-                n = max(1, min(n, _park_limit_bytes() // held))
+                n = max(1, min(n, _park_limit_bytes(total) // held))
         return int(n)
 
     @staticmethod

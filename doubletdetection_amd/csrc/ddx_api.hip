@@ -86,8 +86,6 @@ void context_reset(ddx_ctx* ctx) {
     ctx->lv_host_valid = false;
     ctx->rowseg_rows = -1;
     ctx->bp = ddx::BitPlanes();
-    // a parked context starts its next fit with the switches of the environment as it is NOW (like a fresh one)
-    ctx->opt.read_environment();
 }
 
 void arena_destroy(ddx_ctx* ctx) {
@@ -136,41 +134,57 @@ int ensure(ddx_ctx* ctx, DevBuf& b, size_t bytes) {
     return DDX_OK;
 }
 
-void Options::read_environment() {
-    auto is = [](const char* v, const char* want) { return v && std::strcmp(v, want) == 0; };
-    const char* g = getenv("DDX_SPMM");
-    spmm_lds = !(g && (g[0] == 'g' || g[0] == 'G'));
-    g = getenv("DDX_PCA_GATHER");
-    gather_f32 = !(g && (g[0] == 'f' || g[0] == 'F') && g[1] == '6');
-    g = getenv("DDX_SPMM_GEOM");
-    spmm_geom = is(g, "pair") ? 1 : (is(g, "quad") ? 2 : 0);
-    trip_packed = !is(getenv("DDX_SPMM_TRIP"), "f64");
-    knn_fold = !is(getenv("DDX_KNN_FOLD"), "0");
-    g = getenv("DDX_KNN_XCD_CHUNK");
-    knn_xcd_chunk = g ? atoi(g) : 32;
-    g = getenv("DDX_KNN_SAMPLE_TILES");
-    knn_sample_tiles = g ? atoll(g) : 0;
-    g = getenv("DDX_KNN_CELLS");
-    knn_cells = g ? atoi(g) : 0;
-    g = getenv("DDX_KNN_SAMPLE_EVERY");
-    knn_sample_every = g ? atoi(g) : 32;
-    g = getenv("DDX_KNN_SEG_STEPS");
-    knn_seg_steps = g ? atoi(g) : 0;
-    g = getenv("DDX_KNN_EMIT_WAVES");
-    knn_emit_waves = g ? atoi(g) : 0;
-    row_sums_sequential = getenv("DDX_ROW_SUMS_SEQUENTIAL") != nullptr;
-    knn_debug = getenv("DDX_KNN_DEBUG") != nullptr;
-    bitplane = is(getenv("DDX_BITPLANE"), "1");
-    upload_packed = !is(getenv("DDX_UPLOAD"), "plain");
-    upload_form16 = !is(getenv("DDX_UPLOAD"), "packed32");
-    upload_wait = is(getenv("DDX_UPLOAD"), "packed") || is(getenv("DDX_UPLOAD"), "packed32");
-    mirror_mode = is(getenv("DDX_MIRROR"), "sort") ? 0 : (is(getenv("DDX_MIRROR"), "scatter") ? 1 : 2);
-    g = getenv("DDX_ARENA_GUARD");
-    arena_guard = g && g[0] != '0' && g[0] != 0;
+// One switchboard for every tuning / diagnostic choice (ddx_set_option).  The library never reads the environment.
+// Returns false for an unknown key or a value the key does not take.
+bool Options::set(const char* key, const char* value) {
+    const std::string k = key ? key : "", v = value ? value : "";
+    auto on = [&]() { return !(v.empty() || v == "0" || v == "off" || v == "false"); };
+    auto num = [&](long long lo, long long hi, long long* out) {
+        char* end = nullptr;
+        const long long x = std::strtoll(v.c_str(), &end, 10);
+        if (v.empty() || (end && *end) || x < lo || x > hi) return false;
+        *out = x;
+        return true;
+    };
+    long long x = 0;
+    if (k == "defaults") { *this = Options(); return true; }
+    if (k == "spmm") { if (v == "lds") spmm_lds = true; else if (v == "gather") spmm_lds = false; else return false; return true; }
+    if (k == "pca_gather") { if (v == "f32") gather_f32 = true; else if (v == "f64") gather_f32 = false; else return false; return true; }
+    if (k == "spmm_geom") { if (v == "auto") spmm_geom = 0; else if (v == "pair") spmm_geom = 1; else if (v == "quad") spmm_geom = 2; else return false; return true; }
+    if (k == "spmm_trip") { if (v == "packed") trip_packed = true; else if (v == "f64") trip_packed = false; else return false; return true; }
+    if (k == "bitplane") { bitplane = on(); return true; }
+    if (k == "knn_fold") { knn_fold = on(); return true; }
+    if (k == "knn_xcd_chunk") { if (!num(0, 4096, &x)) return false; knn_xcd_chunk = (int)x; return true; }
+    if (k == "knn_sample_tiles") { if (!num(0, 1 << 24, &x)) return false; knn_sample_tiles = x; return true; }
+    if (k == "knn_sample_every") { if (!num(0, 1 << 20, &x)) return false; knn_sample_every = (int)x; return true; }
+    if (k == "knn_cells") { if (!num(0, 1024, &x)) return false; knn_cells = (int)x; return true; }
+    if (k == "knn_seg_steps") { if (!num(0, 1 << 20, &x)) return false; knn_seg_steps = (int)x; return true; }
+    if (k == "knn_emit_waves") { if (!num(0, 16, &x)) return false; knn_emit_waves = (int)x; return true; }
+    if (k == "knn_debug") { knn_debug = on(); return true; }
+    if (k == "pca_debug") { pca_debug = on(); return true; }
+    if (k == "row_sums") { if (v == "auto") row_sums_sequential = false; else if (v == "sequential") row_sums_sequential = true; else return false; return true; }
+    if (k == "mirror") { if (v == "tiles") mirror_mode = 2; else if (v == "scatter") mirror_mode = 1; else if (v == "sort") mirror_mode = 0; else return false; return true; }
+    if (k == "upload") {
+        if (v == "auto") { upload_packed = true; upload_form16 = true; upload_wait = false; }
+        else if (v == "plain") { upload_packed = false; upload_form16 = true; upload_wait = false; }
+        else if (v == "packed") { upload_packed = true; upload_form16 = true; upload_wait = true; }
+        else if (v == "packed32") { upload_packed = true; upload_form16 = false; upload_wait = true; }
+        else return false;
+        return true;
+    }
+    if (k == "upload_debug") { if (!num(0, 2, &x)) return false; upload_debug = (int)x; return true; }
+    if (k == "hvg_fold") { hvg_fold = on(); return true; }
+    if (k == "arena_guard") { arena_guard = on(); return true; }
+    if (k == "knn_ablation") {
 #ifdef DDX_ABLATION
-    g = getenv("DDX_KNN_EXPERIMENT");
-    knn_ablation = g ? atoi(g) : 0;
+        if (!num(0, 255, &x)) return false;
+        knn_ablation = (int)x;
+        return true;
+#else
+        return false;                      // timing ablations give wrong results: only in -DDDX_ABLATION builds (profiles/tools)
 #endif
+    }
+    return false;
 }
 
 static bool timing_event(ddx_ctx* ctx, hipEvent_t* ev) {
@@ -279,7 +293,6 @@ int ddx_create(int device, ddx_ctx** out) {
     ddx_ctx* c = new (std::nothrow) ddx_ctx();
     if (!c) return set_err(nullptr, DDX_E_NOMEM, "out of host memory");
     c->device = device;
-    c->opt.read_environment();
     e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         delete c;
@@ -527,7 +540,6 @@ WorkerPool* upload_pool() {
     unsigned hw = std::thread::hardware_concurrency();
     unsigned n = std::max(4u, std::min(48u, hw ? hw / 2 : 8u));      // 48 threads pack 93 M entries in 6 ms, 24 in 10 ms
     if (const int req = g_upload_threads.load()) n = (unsigned)req;
-    else if (const char* e = getenv("DDX_UPLOAD_THREADS")) n = (unsigned)std::max(1, atoi(e));
     if (g_pool && g_pool_pid == getpid() && g_pool->size() != (int)n) { delete g_pool; g_pool = nullptr; }   // resized on request
     if (!g_pool || g_pool_pid != getpid()) {
         g_pool = new WorkerPool((int)n);
@@ -655,7 +667,7 @@ static int upload_packed(ddx_ctx* ctx, int64_t n_cells, int64_t nnz, int32_t n_g
         }
     };
     // the copies must not overtake whatever the main stream still does with the device buffers
-    const bool dbg = getenv("DDX_UPLOAD_DEBUG") != nullptr;
+    const bool dbg = ctx->opt.upload_debug > 0;
     auto clk = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_in = clk();
     (void)hipStreamSynchronize(ctx->stream);
@@ -665,7 +677,7 @@ static int upload_packed(ddx_ctx* ctx, int64_t n_cells, int64_t nnz, int32_t n_g
     // 2-byte form: rows complete after every chunk, the largest batch of entries they bring, the listed entries so far
     std::vector<int64_t> rows_done_after((size_t)nchunks, 0);
     int64_t rows_done = 0, fold_max = 1;
-    bool fold_ok = f16 && !getenv("DDX_HVG_WHOLE");
+    bool fold_ok = f16 && ctx->opt.hvg_fold;
     std::vector<int32_t> pos, col;                        // (alive and never reallocated until the stream has taken them: the synchronisation below)
     std::vector<float> val;
     unsigned char* side = ctx->raw_packed.as<unsigned char>() + codes_bytes;
@@ -688,7 +700,7 @@ static int upload_packed(ddx_ctx* ctx, int64_t n_cells, int64_t nnz, int32_t n_g
         if (bad.load()) { rc = 1; break; }
         const int64_t c0 = k * chunk, len = std::min(nnz, c0 + chunk) - c0;
         unsigned char* dev = ctx->raw_packed.as<unsigned char>() + esz * c0;
-        if (dbg && getenv("DDX_UPLOAD_DEBUG")[0] == '2') fprintf(stderr, "[ddx upload] chunk %lld packed +%.2f ms\n", (long long)k, clk() - t_in);
+        if (ctx->opt.upload_debug > 1) fprintf(stderr, "[ddx upload] chunk %lld packed +%.2f ms\n", (long long)k, clk() - t_in);
         if (hipMemcpyAsync(dev, pin + esz * c0, esz * len, hipMemcpyHostToDevice, ctx->copy_stream) != hipSuccess ||
             hipEventCreateWithFlags(&ev[k], hipEventDisableTiming) != hipSuccess || hipEventRecord(ev[k], ctx->copy_stream) != hipSuccess ||
             hipStreamWaitEvent(ctx->stream, ev[k], 0) != hipSuccess) { rc = DDX_E_HIP; break; }
@@ -720,7 +732,7 @@ static int upload_packed(ddx_ctx* ctx, int64_t n_cells, int64_t nnz, int32_t n_g
     }
     if (rc != DDX_OK) bad.store(1);
     const double t_issued = clk();
-    if (dbg && getenv("DDX_UPLOAD_DEBUG")[0] == '2') {
+    if (ctx->opt.upload_debug > 1) {
         for (int64_t k = 0; k < nchunks; ++k)
             if (ev[k]) { (void)hipEventSynchronize(ev[k]); fprintf(stderr, "[ddx upload] chunk %lld landed +%.2f ms\n", (long long)k, clk() - t_in); }
     }
@@ -1089,6 +1101,23 @@ int ddx_get_knn_overflow_count(ddx_ctx* ctx, int64_t* n_queries) {
     int32_t n = 0;
     if (ctx->knn_overflow) DDX_TRY(d2h(ctx, &n, ctx->knn_overflow, sizeof(n)));
     *n_queries = n;
+    return DDX_OK;
+}
+
+int ddx_pca_exact_sparse(ddx_ctx* ctx, int32_t n_components, int32_t n_oversamples, double tol, int32_t max_steps, const double* start,
+                         int32_t* steps_out, ddx_eigh_fn eigh, void* eigh_user) {
+    REQUIRE_CTX(ctx);
+    USE_DEVICE(ctx);
+    NEED(ctx->have_lognorm, "ddx_lognormalise first");
+    NEED(start && n_components >= 1 && n_oversamples >= 0 && tol > 0.0, "ddx_pca_exact_sparse: start matrix, n_components >= 1, tol > 0");
+    NEED((int64_t)n_components + n_oversamples <= std::min<int64_t>(ctx->M, ctx->H), "more vectors than the matrix has rows / columns");
+    return stage_pca_block_lanczos(ctx, n_components, n_oversamples, tol, max_steps, start, steps_out, eigh, eigh_user);
+}
+
+int ddx_set_option(ddx_ctx* ctx, const char* key, const char* value) {
+    REQUIRE_CTX(ctx);
+    if (!key) return set_err(ctx, DDX_E_ARG, "ddx_set_option: no key");
+    if (!ctx->opt.set(key, value)) return set_err(ctx, DDX_E_ARG, "ddx_set_option: unknown key or value '%s' = '%s'", key, value ? value : "");
     return DDX_OK;
 }
 

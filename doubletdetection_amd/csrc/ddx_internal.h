@@ -28,18 +28,8 @@ constexpr int kWave = 64;  // gfx950 wavefront
 #endif
 constexpr int kLdsPanelRows = DDX_LDS_PANEL_ROWS;
 constexpr int kGatherPanelRows = 4096;   // measured optimum for the gather kernels (8192: +19 %, 2048: +5 %)
-// Tuning / diagnostic switches.  The environment is read ONCE, when the context is created (ddx_create); a context
-// never looks at the environment again, so a variable changed in the middle of a fit cannot change its results.
-//   DDX_SPMM=gather        L2-gather operator products instead of the LDS-staged ones
-//   DDX_PCA_GATHER=f64     float64 operand gathers (gather kernels only)
-//   DDX_SPMM_GEOM=pair|quad, DDX_SPMM_TRIP=f64   variants of the LDS-staged products
-//   DDX_KNN_FOLD=0         emit pass with explicit threshold compares (the first version)
-//   DDX_KNN_SAMPLE_TILES=n size of the bound pass's subset
-//   DDX_ROW_SUMS_SEQUENTIAL=1  always replay the sequential row sums (skip the exact-integer shortcut)
-//   DDX_KNN_DEBUG=1        print candidate-list statistics
-//   DDX_MIRROR=sort        column-major mirror by radix sort (the counting sort's reference)
-//   DDX_ARENA_GUARD=1      overflow detector: see ddx_check_memory
-// Switches that produce wrong results (timing ablations) exist only in builds with -DDDX_ABLATION.
+// Tuning / diagnostic switches of a context, set through ddx_set_option (include/ddx.h lists the keys); the library never
+// reads the environment.  Switches that produce wrong results (timing ablations) exist only in builds with -DDDX_ABLATION.
 struct Options {
     bool spmm_lds = true;
     bool gather_f32 = true;
@@ -54,6 +44,7 @@ struct Options {
     int knn_emit_waves = 0;          // waves per emit block: 4, 8 or 16 (0 = default)
     bool row_sums_sequential = false;
     bool knn_debug = false;
+    bool pca_debug = false;          // progress of the block Lanczos solver on stderr
     bool bitplane = false;           // experiment (profiles/r04_bitplane_notes.txt): the original rows' entries equal to 1 as bitmaps on the integer matrix cores
     int mirror_mode = 2;             // column-major mirror: 2 counting sort placed by LDS tiles, 1 (DDX_MIRROR=scatter) counting sort with scattered stores, 0 (DDX_MIRROR=sort) radix sort
     bool upload_packed = true;       // DDX_UPLOAD=plain: send the raw matrix as it is (8 bytes per entry) instead of packed
@@ -61,7 +52,9 @@ struct Options {
     bool upload_wait = false;        // DDX_UPLOAD=packed / packed32: wait for the pinned staging buffer instead of sending the first matrix plain (tests)
     bool arena_guard = false;        // DDX_ARENA_GUARD=1: pattern-fill the pad behind every block, ddx_check_memory verifies it
     int knn_ablation = 0;            // only honoured under DDX_ABLATION
-    void read_environment();
+    int upload_debug = 0;            // 1: timings of the upload on stderr, 2: per chunk
+    bool hvg_fold = true;            // gene sums folded in while the packed matrix arrives (off: one pass after the upload)
+    bool set(const char* key, const char* value);
 };
 
 struct DevBuf {
@@ -324,6 +317,8 @@ int stage_scale(ddx_ctx* ctx, float max_value);
 int stage_dense_rows(ddx_ctx* ctx, int64_t row0, int64_t nrows, float* out_host);
 int stage_pca(ddx_ctx* ctx, int32_t C, int32_t oversample, int32_t n_iter, const double* q0, int64_t q0_rows);
 int stage_operator_apply(ddx_ctx* ctx, int32_t transpose, const double* X, int32_t n, double* out);
+int stage_pca_block_lanczos(ddx_ctx* ctx, int32_t C, int32_t oversample, double tol, int32_t max_steps, const double* q0, int32_t* steps_out,
+                            ddx_eigh_fn eigh, void* eigh_user);
 int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self);
 int stage_knn_metric(ddx_ctx* ctx, int32_t k, int32_t include_self, int32_t metric);
 int stage_knn_candidate_counts(ddx_ctx* ctx, int32_t* host_out);

@@ -15,6 +15,7 @@
 // half step: only the spanned subspace enters the next step, so the float64 result is the same to ~1e-12
 // (oracle/dd_oracle.py:randomized_pca_f64 checks this); the final basis gets two passes (CholQR2).
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 
@@ -1686,6 +1687,301 @@ int stage_pca(ddx_ctx* ctx, int32_t C, int32_t oversample, int32_t n_iter, const
                    "fewer independent directions than n_components + n_oversamples; trailing components are arbitrary";
         return DDX_W_RANK;
     }
+    return DDX_OK;
+}
+
+static void sym_eigh_ql(int n, double* v, double* d);
+
+// ------------------------------------------------------------------------------------------------
+// Exact truncated PCA of the sparse operator: block Lanczos (dd.py:296-297,308 -- pseudocount == 1 keeps the matrix sparse
+// and sc.tl.pca switches to svd_solver="arpack", i.e. a truncated SVD converged to tolerance).
+//
+// Upstream's ARPACK is a single-vector Lanczos: 232 operator applications per PCA at configs[1], each one a pass over the
+// matrix.  The block version builds the same Krylov space L vectors at a time -- every step is ONE pair of the 40-column
+// LDS-staged products -- with full re-orthogonalisation against all earlier blocks (two passes of classical Gram-Schmidt
+// by small cross-Gram kernels, Cholesky-QR twice), collects the projected matrix T = V^T (A^T A) V from the
+// orthogonalisation coefficients, and stops when the Ritz pairs of the wanted components have residuals below tol * theta
+// (residual of a pair = |T[j+1][j] z_j|, the part of the operator's image that left the space).  Everything tall stays on
+// the device; the host sees the small coefficient blocks and solves the (j+1) L eigenproblem of T (Householder + QL).
+// Works on the smaller side: A^T A (vectors of length H) when H <= M, A A^T otherwise.
+// ------------------------------------------------------------------------------------------------
+// partial[b] = X^T W over the block's rows (L x L, row-major), L <= 64
+__global__ void __launch_bounds__(256) k_cross_gram_partial(const double* __restrict__ X, const double* __restrict__ W, int64_t R, int L, int64_t rows_per_block,
+                                                            double* __restrict__ partial) {
+    extern __shared__ double cg_s[];                  // [2][32][L] row tiles of X and W
+    double* xs = cg_s;
+    double* ws = cg_s + 32 * L;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < R ? r0 + rows_per_block : R;
+    const int npair = L * L;
+    double acc[16];                                   // pairs t = threadIdx.x + 256 u  (L <= 64: at most 16 per thread)
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc[u] = 0.0;
+    for (int64_t rb = r0; rb < r1; rb += 32) {
+        const int nr = (int)(r1 - rb < 32 ? r1 - rb : 32);
+        for (int e = threadIdx.x; e < nr * L; e += 256) { xs[e] = X[rb * L + e]; ws[e] = W[rb * L + e]; }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int t = threadIdx.x + 256 * u;
+            if (t < npair) {
+                const int i = t / L, j = t - i * L;
+                double a = acc[u];
+                for (int r = 0; r < nr; ++r) a = fma(xs[r * L + i], ws[r * L + j], a);
+                acc[u] = a;
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int t = threadIdx.x + 256 * u;
+        if (t < npair) partial[(int64_t)blockIdx.x * npair + t] = acc[u];
+    }
+}
+
+// W -= V G   (R x L, G: L x L row-major in device memory)
+__global__ void __launch_bounds__(256) k_block_subtract(const double* __restrict__ V, const double* __restrict__ G, int64_t R, int L, double* __restrict__ W) {
+    extern __shared__ double bs_g[];                  // G
+    for (int e = threadIdx.x; e < L * L; e += 256) bs_g[e] = G[e];
+    __syncthreads();
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= R * L) return;
+    const int64_t r = t / L;
+    const int c = (int)(t - r * L);
+    double a = 0.0;
+    for (int k = 0; k < L; ++k) a = fma(V[r * L + k], bs_g[k * L + c], a);
+    W[t] -= a;
+}
+
+// out (+)= V Z   (R x L times L x L2)
+__global__ void __launch_bounds__(256) k_block_accumulate(const double* __restrict__ V, const double* __restrict__ Z, int64_t R, int L, int L2, int first,
+                                                          double* __restrict__ out) {
+    extern __shared__ double ba_z[];
+    for (int e = threadIdx.x; e < L * L2; e += 256) ba_z[e] = Z[e];
+    __syncthreads();
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= R * L2) return;
+    const int64_t r = t / L2;
+    const int c = (int)(t - r * L2);
+    double a = first ? 0.0 : out[t];
+    for (int k = 0; k < L; ++k) a = fma(V[r * L + k], ba_z[k * L2 + c], a);
+    out[t] = a;
+}
+
+__global__ void k_scale_cols(const double* __restrict__ in, int64_t R, int L, int C, const double* __restrict__ f, double* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= R * C) return;
+    const int64_t r = t / C;
+    const int c = (int)(t - r * C);
+    out[t] = in[r * L + c] * f[c];
+}
+
+static int cross_gram(PcaWork& w, const double* X, const double* W, int64_t R, double* G_dev, double* G_host) {
+    const int L = w.L;
+    int nb = (int)std::min<int64_t>(256, ceil_div(R, 64));
+    const int64_t rpb = ceil_div(ceil_div(R, nb), 32) * 32;
+    nb = (int)ceil_div(R, rpb);
+    k_cross_gram_partial<<<nb, 256, sizeof(double) * 64 * L, w.ctx->stream>>>(X, W, R, L, rpb, w.partial);
+    k_reduce_partials<<<(unsigned)ceil_div(L * L, 4), 256, 0, w.ctx->stream>>>(w.partial, nb, L * L, G_dev);
+    if (G_host) DDX_HIP(w.ctx, hipMemcpyAsync(G_host, G_dev, sizeof(double) * L * L, hipMemcpyDeviceToHost, w.ctx->stream));
+    return DDX_OK;
+}
+
+int stage_pca_block_lanczos(ddx_ctx* ctx, int32_t C, int32_t oversample, double tol, int32_t max_steps, const double* q0, int32_t* steps_out,
+                            ddx_eigh_fn eigh, void* eigh_user) {
+    t_opt = &ctx->opt;
+    const int L = C + oversample;
+    if (L > kMaxL) return set_err(ctx, DDX_E_UNSUPPORTED, "block Lanczos: %d components + %d exceed %d columns", C, oversample, kMaxL);
+    const int64_t M = ctx->M;
+    const int32_t H = ctx->H;
+    const bool cols_side = H <= M;                     // vectors of length H, operator A^T A
+    const int64_t R = cols_side ? (int64_t)H : M, Ro = cols_side ? M : (int64_t)H;
+    if (max_steps < 2) max_steps = 2;
+    if ((int64_t)(max_steps + 1) * L > R) max_steps = (int)std::max<int64_t>(1, R / L - 1);
+    DDX_TRY(ensure(ctx, ctx->pcaA, sizeof(double) * 2 * (size_t)M * L));
+    DDX_TRY(ensure(ctx, ctx->pcaB, sizeof(double) * 2 * (size_t)H * L));
+    DDX_TRY(ensure(ctx, ctx->pcaSmall, sizeof(double) * (8 * (size_t)L * L + 8 * L) + 256));
+    DDX_TRY(ensure(ctx, ctx->pcaPartial, sizeof(double) * 512 * (size_t)std::max(L * L, 128 * 4)));
+    DDX_TRY(ensure(ctx, ctx->pcaVec, 256));
+    DDX_TRY(ensure(ctx, ctx->pcaPanel, sizeof(double) * (size_t)ceil_div(M, ctx->panel_rows) * H * L));
+    DDX_TRY(ensure(ctx, ctx->pcaBlk, sizeof(double) * (size_t)(max_steps + 2) * R * L));
+    DDX_TRY(ensure(ctx, ctx->emb64, sizeof(double) * (size_t)M * C));
+    DDX_TRY(ensure(ctx, ctx->emb32, sizeof(float) * (size_t)M * C));
+    DDX_TRY(ensure(ctx, ctx->sing, sizeof(double) * L));
+    double* rowA = ctx->pcaA.as<double>();
+    double* rowB = rowA + (size_t)M * L;
+    double* colA = ctx->pcaB.as<double>();
+    double* colB = colA + (size_t)H * L;
+    double* Vall = ctx->pcaBlk.as<double>();
+    auto Vblk = [&](int j) { return Vall + (size_t)j * R * L; };
+    PcaWork w;
+    w.ctx = ctx; w.L = L; w.lpn = (L + 1) / 2; w.slots = 64 / w.lpn; w.gather32 = ctx->opt.gather_f32; w.M = M; w.H = H;
+    DDX_TRY(lds_setup(ctx, L, w));
+    const int64_t maxR = M > H ? M : (int64_t)H;
+    DDX_TRY(ensure(ctx, ctx->pcaOp, sizeof(double) * (size_t)maxR * (L + 4)));
+    w.op32 = ctx->pcaOp.as<float>();
+    if (w.lds) {
+        w.opQ = w.op32 + (size_t)maxR * (L + 4);
+        w.opQ_of = w.opY_of = nullptr;
+        if (((L + 3) & ~3) != L) DDX_HIP(ctx, hipMemsetAsync(w.op32, 0, sizeof(double) * (size_t)maxR * (L + 4), ctx->stream));
+    }
+    w.partial = ctx->pcaPartial.as<double>();
+    w.small = ctx->pcaSmall.as<double>();
+    w.flag = ctx->pcaVec.as<int>();
+    DDX_HIP(ctx, hipMemsetAsync(w.flag, 0, sizeof(int), ctx->stream));
+    double* dG = w.small + 4 * L * L + 4 * L;          // cross-Gram block (the first 4 L^2 + 4 L belong to cholqr and the products)
+    double* dZ = dG + L * L;                           // L x L block of Ritz vectors
+    // small side scratch: W (the image of a block), T1 (a second block)
+    double* Wb = cols_side ? colA : rowA;
+    double* T1 = cols_side ? colB : rowB;
+    double* Yo = cols_side ? rowA : colA;              // the other side's image
+    auto op = [&](const double* X, double* Wout) -> int {          // Wout = (A^T A or A A^T) X
+        if (cols_side) { DDX_TRY(apply_rows(w, X, Yo)); DDX_TRY(apply_cols(w, Yo, Wout)); }
+        else { DDX_TRY(apply_cols(w, X, Yo)); DDX_TRY(apply_rows(w, Yo, Wout)); }
+        return DDX_OK;
+    };
+    // V_0 = orth(start)
+    DDX_HIP(ctx, hipMemcpyAsync(Wb, q0, sizeof(double) * (size_t)R * L, hipMemcpyHostToDevice, ctx->stream));
+    DDX_TRY(cholqr(w, Wb, R, T1));
+    DDX_TRY(cholqr(w, T1, R, Vblk(0)));
+    const int nmax = (max_steps + 1) * L;
+    std::vector<double> T((size_t)nmax * nmax, 0.0), Gh((size_t)L * L), work, theta, Tsub((size_t)L * L);
+    auto add_block = [&](int bi, int bj, const std::vector<double>& G, bool accumulate) {     // T[bi][bj] (+)= G, mirrored
+        for (int a = 0; a < L; ++a)
+            for (int b = 0; b < L; ++b) {
+                double& t = T[(size_t)(bi * L + a) * nmax + bj * L + b];
+                t = accumulate ? t + G[(size_t)a * L + b] : G[(size_t)a * L + b];
+                T[(size_t)(bj * L + b) * nmax + bi * L + a] = t;
+            }
+    };
+    const unsigned gsub = (unsigned)ceil_div(R * L, 256);
+    int steps = 0;
+    std::vector<double> Z;                              // Ritz vectors of the last solve: n x n row-major, columns = vectors
+    int n = 0;
+    double t_prod = 0.0, t_orth = 0.0, t_ritz = 0.0;
+    int next_check = 8, prev_step = 0;
+    double prev_res = -1.0;
+    auto now = [&]() { (void)hipStreamSynchronize(ctx->stream); return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const bool dbg = ctx->opt.pca_debug;
+    for (int j = 0; j < max_steps; ++j) {
+        double t0 = dbg ? now() : 0.0;
+        DDX_TRY(op(Vblk(j), Wb));
+        if (dbg) { const double t1 = now(); t_prod += t1 - t0; t0 = t1; }
+        for (int pass = 0; pass < 2; ++pass)
+            for (int i = 0; i <= j; ++i) {
+                DDX_TRY(cross_gram(w, Vblk(i), Wb, R, dG, Gh.data()));
+                k_block_subtract<<<gsub, 256, sizeof(double) * L * L, ctx->stream>>>(Vblk(i), dG, R, L, Wb);
+                DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                add_block(i, j, Gh, pass > 0);
+            }
+        // next block: orth(remainder), made orthogonal to the earlier blocks once more (a remainder that has lost rank -- converged
+        // directions -- leaves arbitrary vectors behind the Cholesky floor)
+        DDX_TRY(cholqr(w, Wb, R, T1));
+        for (int i = 0; i <= j; ++i) {
+            DDX_TRY(cross_gram(w, Vblk(i), T1, R, dG, nullptr));
+            k_block_subtract<<<gsub, 256, sizeof(double) * L * L, ctx->stream>>>(Vblk(i), dG, R, L, T1);
+        }
+        DDX_TRY(cholqr(w, T1, R, Vblk(j + 1)));
+        DDX_TRY(cross_gram(w, Vblk(j + 1), Wb, R, dG, Tsub.data()));              // T[j+1][j] = V_{j+1}^T (remainder)
+        DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (dbg) { const double t1 = now(); t_orth += t1 - t0; t0 = t1; }
+        steps = j + 1;
+        // Rayleigh-Ritz on the blocks 0..j -- the host's solve, as costly as several steps once the space is large: at steps 8
+        // and 12, then where the residual's decay so far says the tolerance is met (at most 8 steps ahead), and at the last step
+        const bool last = j + 1 >= max_steps || (int64_t)(j + 3) * L > R;
+        if (!last && j + 1 < next_check) continue;
+        n = (j + 1) * L;
+        Z.assign((size_t)n * n, 0.0);
+        theta.assign(n, 0.0);
+        for (int a = 0; a < n; ++a)
+            for (int b = 0; b < n; ++b) Z[(size_t)a * n + b] = 0.5 * (T[(size_t)a * nmax + b] + T[(size_t)b * nmax + a]);
+        for (size_t t = 0; t < Z.size(); ++t)
+            if (!std::isfinite(Z[t])) return set_err(ctx, DDX_E_NUMERIC, "block Lanczos: non-finite projected matrix (degenerate input matrix?)");
+        // eigenvectors in the columns of Z, eigenvalues ascending: the caller's solver (LAPACK behind numpy.linalg.eigh for
+        // the Python host) or the built-in Householder + QL
+        if (eigh) {
+            if (eigh(n, std::min(n, L), Z.data(), theta.data(), eigh_user) != 0) return set_err(ctx, DDX_E_NUMERIC, "block Lanczos: the caller's eigen-solver failed");
+        } else {
+            sym_eigh_ql(n, Z.data(), theta.data());
+        }
+        double worst = 0.0;
+        for (int c = 0; c < C && c < n; ++c) {
+            const int col = n - 1 - c;
+            double r2 = 0.0;
+            for (int a = 0; a < L; ++a) {
+                double sacc = 0.0;
+                for (int b = 0; b < L; ++b) sacc += Tsub[(size_t)a * L + b] * Z[(size_t)(j * L + b) * n + col];
+                r2 += sacc * sacc;
+            }
+            const double th = std::fabs(theta[col]);
+            worst = std::max(worst, th > 0.0 ? std::sqrt(r2) / th : 0.0);
+        }
+        if (dbg) {
+            t_ritz += now() - t0;
+            fprintf(stderr, "[lanczos] step %d: n = %d, worst residual / eigenvalue %.2e; so far products %.1f ms, orthogonalisation %.1f ms, Ritz %.1f ms\n", j + 1, n, worst,
+                    t_prod, t_orth, t_ritz);
+        }
+        if (worst <= tol || last) break;
+        if (prev_res > 0.0 && worst > 0.0 && worst < prev_res) {
+            const double rate = std::pow(worst / prev_res, 1.0 / (double)(j + 1 - prev_step));      // per step, < 1
+            const double need = std::log(tol / worst) / std::log(rate);
+            next_check = j + 1 + (int)std::min(8.0, std::max(2.0, std::ceil(need)));
+        } else {
+            next_check = j + 1 + 4;
+        }
+        prev_res = worst;
+        prev_step = j + 1;
+    }
+    if (steps_out) *steps_out = steps;
+    // X = V Z[:, top L] (small side x L; only the first C columns are results, the rest fills the product's width)
+    const int nb = n / L;
+    std::vector<double> Zb((size_t)L * L), svals(L, 0.0);
+    for (int c = 0; c < L; ++c) svals[c] = std::sqrt(std::max(c < n ? theta[n - 1 - c] : 0.0, 0.0));
+    for (int i = 0; i < nb; ++i) {
+        for (int a = 0; a < L; ++a)
+            for (int c = 0; c < L; ++c) Zb[(size_t)a * L + c] = c < n ? Z[(size_t)(i * L + a) * n + (n - 1 - c)] : 0.0;
+        DDX_HIP(ctx, hipMemcpyAsync(dZ, Zb.data(), sizeof(double) * L * L, hipMemcpyHostToDevice, ctx->stream));
+        k_block_accumulate<<<gsub, 256, sizeof(double) * L * L, ctx->stream>>>(Vblk(i), dZ, R, L, L, i == 0, Wb);
+        DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));          // Zb is reused
+    }
+    // components (H x L) for the sign decision, scores (M x C) = U S
+    w.opQ_of = w.opY_of = nullptr;                      // (the accumulated block has no float32 mirror yet)
+    double* dSign = w.small + 3 * L * L + 2 * L;
+    std::vector<double> hsign(L, 1.0), f(L, 1.0);
+    const double* comps;
+    const double* left = nullptr;
+    if (cols_side) {
+        comps = Wb;                                      // right singular vectors
+    } else {
+        DDX_TRY(apply_cols(w, Wb, colA));                // A^T U = V S
+        comps = colA;
+        left = Wb;
+    }
+    k_col_sign<<<L, 256, 0, ctx->stream>>>(comps, H, L, dSign);
+    DDX_HIP(ctx, hipMemcpyAsync(hsign.data(), dSign, sizeof(double) * L, hipMemcpyDeviceToHost, ctx->stream));
+    DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    double* dF = w.small + 3 * L * L + 3 * L;
+    const double* scoreSrc;
+    if (cols_side) {
+        DDX_TRY(apply_rows(w, Wb, rowB));                // A V = U S
+        scoreSrc = rowB;
+        for (int c = 0; c < L; ++c) f[c] = hsign[c] != 0.0 ? hsign[c] : 1.0;
+    } else {
+        scoreSrc = left;
+        for (int c = 0; c < L; ++c) f[c] = (hsign[c] != 0.0 ? hsign[c] : 1.0) * svals[c];
+    }
+    DDX_HIP(ctx, hipMemcpyAsync(dF, f.data(), sizeof(double) * L, hipMemcpyHostToDevice, ctx->stream));
+    k_scale_cols<<<(unsigned)ceil_div(M * C, 256), 256, 0, ctx->stream>>>(scoreSrc, M, L, C, dF, ctx->emb64.as<double>());
+    k_f64_to_f32<<<(unsigned)ceil_div(M * C, 256), 256, 0, ctx->stream>>>(ctx->emb64.as<double>(), M * C, ctx->emb32.as<float>());
+    DDX_HIP(ctx, hipMemcpyAsync(ctx->sing.p, svals.data(), sizeof(double) * C, hipMemcpyHostToDevice, ctx->stream));
+    DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    DDX_HIP(ctx, hipGetLastError());
+    (void)Ro;
+    ctx->C = C;
+    ctx->embM = M;
+    ctx->have_emb = true;
+    ctx->have_knn = false;
     return DDX_OK;
 }
 

@@ -156,7 +156,7 @@ int gene_sums_fold(ddx_ctx* ctx, int32_t G, int64_t n_rows, int64_t row0, int64_
 int stage_gene_variances(ddx_ctx* ctx, float* var_out) {
     const int64_t n = ctx->raw_nnz;
     const int32_t G = ctx->rawG;
-    if (ctx->hvg_rows == ctx->rawN && ctx->hvg_G == G && ctx->hvg_state.p && !getenv("DDX_HVG_WHOLE")) {
+    if (ctx->hvg_rows == ctx->rawN && ctx->hvg_G == G && ctx->hvg_state.p && ctx->opt.hvg_fold) {
         // the sums were folded in while the matrix arrived (ddx_upload_raw): only the last step is left
         DevBuf var;
         DDX_TRY(ensure(ctx, var, sizeof(float) * G));

@@ -136,7 +136,11 @@ bool one_level(const Graph& g, double gamma, SplitMix64& rng, std::vector<int32_
         }
         for (int32_t c : seen) neigh_w[c] = -1.0;
     };
-    const bool dbg = std::getenv("DDX_LOUVAIN_DEBUG") != nullptr;
+#ifdef DDX_LOUVAIN_DEBUG
+    const bool dbg = true;           // trace of the passes on stderr: debug builds only (-DDDX_LOUVAIN_DEBUG)
+#else
+    const bool dbg = false;
+#endif
     while (true) {
         const double cur_q = new_q;
         moves = 0;
@@ -390,7 +394,11 @@ void sequential_levels(Graph& g, double gamma, uint64_t seed, std::vector<int32_
     for (int64_t v = 0; v < n_nodes; ++v) membership[v] = (int32_t)v;
     std::vector<int32_t> comm, renum;
     double q = 0.0;
-    const bool dbg = std::getenv("DDX_LOUVAIN_DEBUG") != nullptr;
+#ifdef DDX_LOUVAIN_DEBUG
+    const bool dbg = true;           // trace of the passes on stderr: debug builds only (-DDDX_LOUVAIN_DEBUG)
+#else
+    const bool dbg = false;
+#endif
     while (true) {
         auto t0 = std::chrono::steady_clock::now();
         const bool improved = one_level(g, gamma, rng, comm, &q);

@@ -17,7 +17,8 @@
  *     may be driven from different host threads (one process per GPU is the intended deployment);
  *   - device results stay resident between stages; the ddx_get_* calls copy intermediates back for
  *     stage-wise parity tests and are not needed in production;
- *   - no C++ exceptions cross the boundary; no global mutable state besides the thread-local error.
+ *   - no C++ exceptions cross the boundary; no global mutable state besides the thread-local error and the packing
+ *     threads of ddx_set_upload_threads; the library never reads the environment (ddx_set_option is the one switchboard).
  *
  * Shapes: N cells, H genes (after HVG restriction), S synthetic doublets, M = N + S, C components,
  *         L = C + n_oversamples sketch width.
@@ -31,7 +32,7 @@
 extern "C" {
 #endif
 
-#define DDX_ABI_VERSION 3
+#define DDX_ABI_VERSION 4
 
 #define DDX_OK 0
 #define DDX_E_ARG -1      /* invalid argument / stage called out of order */
@@ -51,7 +52,34 @@ int ddx_device_count(int* count);
 int ddx_create(int device, ddx_ctx** out);
 int ddx_destroy(ddx_ctx* ctx);
 int ddx_synchronize(ddx_ctx* ctx);
-/* overflow detector (contexts created with DDX_ARENA_GUARD=1 in the environment): every device buffer is followed by a
+/* Tuning and diagnostic switches of a context: one key / value call, both plain strings.  None of them changes what a fit
+ * returns beyond the tolerances stated in DESIGN.md section 4 (the operator-product variants differ in the last bits of the
+ * PCA scores); unknown keys and values the key does not take return DDX_E_ARG.  A switch holds until it is set again.
+ *   defaults          (any value) every switch back to its default
+ *   spmm              lds | gather      operator products with the operand staged in LDS (default) or gathered from L2
+ *   pca_gather        f32 | f64         operand copy of the gather kernels (default f32)
+ *   spmm_geom         auto | pair | quad   lane geometry of the LDS-staged products
+ *   spmm_trip         packed | f64      trip products in packed float32 (default) or float64
+ *   bitplane          0 | 1             experiment: the original rows' entries equal to 1 as bitmaps on the int8 matrix cores
+ *   mirror            tiles | scatter | sort   how the column-major mirror is built (default tiles; the others are its references)
+ *   upload            auto | plain | packed | packed32   transfer form of ddx_upload_raw (auto: 2-byte form once the pinned
+ *                                       buffer exists, plain until then; packed / packed32 wait for the buffer)
+ *   upload_debug      0 | 1 | 2         timings of the upload on stderr
+ *   hvg_fold          1 | 0             gene sums folded in while the packed matrix arrives
+ *   row_sums          auto | sequential replay scipy's sequential float32 row sums even for exact integer counts
+ *   knn_cells         n                 cells of the kNN pruning structure (0 = by size, 1 = first-component windows only)
+ *   knn_sample_tiles  n                 tiles in the bound pass's sample (0 = by size)
+ *   knn_sample_every  n                 the sample holds every n-th tile of the whole set (0 = none; default 32)
+ *   knn_seg_steps     n                 steps of a block's tile list per emit work item (0 = default)
+ *   knn_emit_waves    4 | 8 | 16        waves per emit workgroup (0 = default)
+ *   knn_fold          1 | 0             threshold folded into the screen's operands
+ *   knn_xcd_chunk     n                 consecutive query blocks of the bound pass per XCD (0 = launch order)
+ *   knn_debug         0 | 1             statistics of the kNN passes on stderr
+ *   pca_debug         0 | 1             progress of ddx_pca_exact_sparse on stderr
+ *   arena_guard       0 | 1             pattern-filled pad behind every device buffer (see ddx_check_memory)
+ *   knn_ablation      n                 timing ablations with wrong results: builds with -DDDX_ABLATION only */
+int ddx_set_option(ddx_ctx* ctx, const char* key, const char* value);
+/* overflow detector (option arena_guard = 1, set before the first upload): every device buffer is followed by a
  * pattern-filled pad; returns DDX_E_NUMERIC and names the buffer if a kernel wrote past the end of one */
 int ddx_check_memory(ddx_ctx* ctx);
 /* bytes of device memory currently held by the context */
@@ -141,6 +169,22 @@ int ddx_scale(ddx_ctx* ctx, float max_value);
  * Produces the M x C float32 embedding (U*S, sign-fixed on the components) on the device. */
 int ddx_pca(ddx_ctx* ctx, int32_t n_components, int32_t n_oversamples, int32_t n_iter,
             const double* q0, int64_t q0_rows);
+/* ---- sc.tl.pca(svd_solver="arpack") on the sparse matrix: dd.py:296-297, 308 (pseudocount == 1) -----------------
+ * Truncated SVD of the implicitly centred operator converged to a tolerance, by block Lanczos on the smaller Gram operator
+ * (A^T A when H <= M, A A^T otherwise): every step is one pair of (n_components + n_oversamples)-column sparse products on
+ * the device, full re-orthogonalisation, Rayleigh-Ritz of the projected matrix on the host; stops when the residual of
+ * every wanted Ritz pair is below tol times its eigenvalue, or after max_steps steps.
+ * start: float64 row-major [min(M, H) x (n_components + n_oversamples)] start block (any full-rank matrix; the host
+ *        draws RandomState(seed).normal as it does for ddx_pca).  *steps_out (may be NULL) receives the steps taken.
+ * eigh:  the host's symmetric eigen-solver for the projected matrix (a few hundred rows; block tridiagonal up to rounding,
+ *        blocks of n_components + n_oversamples): a[n*n] row-major symmetric on entry; on exit the eigenvectors of the
+ *        n_largest largest eigenvalues in its LAST n_largest columns and those eigenvalues, ascending, in the last
+ *        n_largest entries of w[n] (the rest is not read); returns 0.  The Python host passes LAPACK's banded solver
+ *        (scipy.linalg.eig_banded); NULL selects the library's own Householder + QL (correct, single-threaded, O(n^3)).
+ * Produces the M x C float32 embedding (U*S, sign-fixed on the components) on the device, like ddx_pca. */
+typedef int (*ddx_eigh_fn)(int32_t n, int32_t n_largest, double* a, double* w, void* user);
+int ddx_pca_exact_sparse(ddx_ctx* ctx, int32_t n_components, int32_t n_oversamples, double tol, int32_t max_steps,
+                         const double* start, int32_t* steps_out, ddx_eigh_fn eigh, void* eigh_user);
 /* The centred operator itself, for sklearn's exact regimes (svd_solver "full" / "covariance_eigh", chosen by
  * PCA(svd_solver="auto") for small inputs, sklearn/decomposition/_pca.py:524-536): the host builds the
  * small Gram matrix from products with unit vectors, takes its eigen-decomposition and projects.

@@ -16,7 +16,7 @@ from doubletdetection_amd import _lib
 from doubletdetection_amd._synthetic import make_counts
 
 X = make_counts(N, G, density=DENS, device="cuda:0")
-os.environ["DDX_KNN_DEBUG"] = "1"
+_lib.OPTIONS["knn_debug"] = "1"
 
 
 def embedding():
@@ -61,7 +61,7 @@ def brute(queries, k=30):
 
 ref = None
 for kc in cells:
-    os.environ["DDX_KNN_CELLS"] = str(kc)
+    _lib.OPTIONS["knn_cells"] = str(kc)
     ctx = _lib.Context(0)
     ctx.timing_enable(True)
     ctx.set_embedding(emb)

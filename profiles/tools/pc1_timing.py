@@ -21,6 +21,41 @@ for n in (1, 8, 40):
     for _ in range(20):
         c.operator_apply(x, 2)
     print(f"A^T A x, {n} vector(s): {(time.perf_counter() - t0) / 20 * 1e3:.3f} ms per call")
+start = np.random.RandomState(0).normal(size=(H, 40))
+results = {}
+for ms in (8, 12, 16, 20, 24):
+    c.pca_exact_sparse(30, start, tol=1e-9, max_steps=ms)
+    t0 = time.perf_counter()
+    st = c.pca_exact_sparse(30, start, tol=1e-9, max_steps=ms)
+    results[ms] = (time.perf_counter() - t0, st, c.embedding().astype(np.float64))
+# against scipy's ARPACK (what upstream runs) driven by the same device operator
+from scipy.sparse.linalg import LinearOperator, eigsh
+pad = np.zeros((H, 8))
+def gram(x):
+    pad[:, 0] = np.asarray(x, dtype=np.float64).ravel()
+    return c.operator_apply(pad, 2)[:, 0]
 t0 = time.perf_counter()
-eng._pca_arpack(30, 0)
-print(f"ARPACK PCA: {time.perf_counter() - t0:.3f} s, {eng.arpack_products} Gram-operator products")
+ev, V = eigsh(LinearOperator((H, H), dtype=np.float64, matvec=gram), k=30, tol=0.0, v0=np.random.RandomState(0).uniform(-1, 1, size=H), which="LM")
+print(f"host ARPACK on the device operator: {time.perf_counter() - t0:.2f} s")
+top = np.argsort(ev)[::-1]
+V = V[:, top]
+sg = np.sign(V[np.argmax(np.abs(V), axis=0), np.arange(30)])
+ref = c.operator_apply(V * sg, 0)
+for ms, (dt, st, emb) in results.items():
+    rel = np.linalg.norm(emb - ref, axis=0) / np.linalg.norm(ref, axis=0)
+    print(f"block Lanczos, {st:2d} steps: {dt * 1e3:7.1f} ms; scores against ARPACK's, relative per component: 1-12 max {rel[:12].max():.1e}, 13-30 max {rel[12:].max():.1e}")
+# the default path's randomized PCA on the same matrix, for scale
+q0 = np.random.RandomState(0).normal(size=(H, 40)).astype(np.float32).astype(np.float64)
+c.pca(30, q0)
+t0 = time.perf_counter()
+c.pca(30, q0); c.synchronize()
+print(f"randomized PCA (default path): {(time.perf_counter() - t0) * 1e3:.1f} ms")
+
+for tol in (1e-5, 1e-6, 1e-7):
+    c.pca_exact_sparse(30, start, tol=tol, max_steps=40)
+    t0 = time.perf_counter()
+    st = c.pca_exact_sparse(30, start, tol=tol, max_steps=40)
+    dt = time.perf_counter() - t0
+    emb = c.embedding().astype(np.float64)
+    rel = np.linalg.norm(emb - ref, axis=0) / np.linalg.norm(ref, axis=0)
+    print(f"tol {tol:.0e}: {st} steps, {dt * 1e3:.1f} ms, scores against ARPACK's max {rel.max():.1e}")

@@ -13,7 +13,10 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 # every device context made by the tests carries pattern-filled pads behind its buffers; BoostClassifier checks them when
 # a fit ends, the module-level contexts of the stage tests when they are closed (tests/test_gpu_*.py)
-os.environ.setdefault("DDX_ARENA_GUARD", "1")
+# (process-wide option of the package's contexts -- doubletdetection_amd._lib.OPTIONS -- not an environment variable)
+from doubletdetection_amd import _lib as _ddx_lib  # noqa: E402
+
+_ddx_lib.OPTIONS.setdefault("arena_guard", "1")
 
 
 def pytest_configure(config):

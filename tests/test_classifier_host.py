@@ -359,6 +359,9 @@ def test_contexts_per_gpu_follow_the_iterations_and_the_memory(monkeypatch):
         def __init__(self, held, free):
             self.ctx = Ctx(held, free)
 
+    monkeypatch.delenv("DDX_PARK_MAX_GB", raising=False)
+    assert clf._stream_count(10, 1, Leader(12 << 30, 240 << 30)) == 5        # default allowance: a quarter of the GPU (72 GB)
+    assert clf._stream_count(10, 1, Leader(30 << 30, 240 << 30)) == 2
     monkeypatch.setenv("DDX_PARK_MAX_GB", "256")
     assert clf._stream_count(10, 1, Leader(40 << 30, 240 << 30)) == 5        # 4 followers of 40 GB fit into 216 GB
     monkeypatch.setenv("DDX_PARK_MAX_GB", "128")

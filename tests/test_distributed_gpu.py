@@ -146,7 +146,6 @@ def test_bench_two_ranks_control_flow(tmp_path):
     from conftest import ROOT
 
     env = dict(os.environ, DDX_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    env.pop("DDX_ARENA_GUARD", None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--cells", "6000",
            "--genes", "3000", "--density", "0.05", "--iters", "3", "--no-cpu-baseline"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)

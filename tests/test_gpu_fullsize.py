@@ -135,8 +135,8 @@ def test_c2_pca_matches_f64_oracle(staged):
 
 def test_operator_product_variants_agree_at_full_size(data, staged, monkeypatch):
     """The same randomized PCA through the implementations of the operator products: LDS-staged float32
-    operand with float32 products inside a trip (default), L2-gather float32 operand (DDX_SPMM=gather), L2-gather
-    float64 operand (DDX_PCA_GATHER=f64), LDS with float64 products, LDS in the quad geometry.
+    operand with float32 products inside a trip (default), L2-gather float32 operand (option spmm=gather), L2-gather
+    float64 operand (pca_gather=f64), LDS with float64 products, LDS in the quad geometry.
     The first two compute the same products up to the float32 trip sums and the summation order; the
     float64 mode differs by the float32 rounding of the operand copies (< 1e-5 per component, as in the small
     oracle test)."""
@@ -153,7 +153,7 @@ def test_operator_product_variants_agree_at_full_size(data, staged, monkeypatch)
 
     def other(env):
         for k, v in env.items():
-            monkeypatch.setenv(k, v)
+            monkeypatch.setitem(_lib.OPTIONS, k, v)
         c2 = _lib.Context(0)                        # the panel height of the mirror is fixed at upload
         try:
             c2.upload_raw(data)
@@ -166,26 +166,26 @@ def test_operator_product_variants_agree_at_full_size(data, staged, monkeypatch)
         finally:
             c2.close()
             for k in env:
-                monkeypatch.delenv(k, raising=False)
+                monkeypatch.delitem(_lib.OPTIONS, k, raising=False)
 
     # the column-major mirror built by counting sort (default) and by the stable radix sort it replaces hold the same
     # entries in the same order: bit-identical scores
     # (default: counting sort placed by LDS tiles; "scatter": counting sort with scattered stores; "sort": radix sort)
     for mode in ("sort", "scatter"):
-        emb_m, sing_m = other({"DDX_MIRROR": mode})
+        emb_m, sing_m = other({"mirror": mode})
         np.testing.assert_array_equal(emb_m, emb_lds)
         np.testing.assert_array_equal(sing_m, sing_lds)
-    emb_g, sing_g = other({"DDX_SPMM": "gather"})
+    emb_g, sing_g = other({"spmm": "gather"})
     # (rounding noise of the two summation orders, amplified through seven power iterations of unconverged
     # trailing components: 4e-10 observed on the singular values)
     np.testing.assert_allclose(sing_g, sing_lds, rtol=1e-8)
     rel_g = np.linalg.norm(emb_g - emb_lds, axis=0) / np.linalg.norm(emb_lds, axis=0)
     assert rel_g.max() < 1e-6, rel_g.max()
-    emb_f, sing_f = other({"DDX_SPMM": "gather", "DDX_PCA_GATHER": "f64"})
+    emb_f, sing_f = other({"spmm": "gather", "pca_gather": "f64"})
     rel = np.linalg.norm(emb_f - emb_lds, axis=0) / np.linalg.norm(emb_f, axis=0)
     assert rel.max() < 1e-5, rel.max()
     # the other two LDS variants: float64 products inside a trip, and the quad geometry at width 40
-    for env in ({"DDX_SPMM_TRIP": "f64"}, {"DDX_SPMM_GEOM": "quad"}):
+    for env in ({"spmm_trip": "f64"}, {"spmm_geom": "quad"}):
         emb_v, sing_v = other(env)
         np.testing.assert_allclose(sing_v, sing_lds, rtol=1e-8)
         rel_v = np.linalg.norm(emb_v - emb_lds, axis=0) / np.linalg.norm(emb_lds, axis=0)

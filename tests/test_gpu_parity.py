@@ -176,7 +176,7 @@ def test_column_mirror_placement_modes(monkeypatch):
 
     def products(env):
         for k, v in env.items():
-            monkeypatch.setenv(k, v)
+            monkeypatch.setitem(_lib.OPTIONS, k, v)
         c = _lib.Context(0)
         try:
             c.upload_counts(counts)
@@ -187,11 +187,11 @@ def test_column_mirror_placement_modes(monkeypatch):
         finally:
             c.close()
             for k in env:
-                monkeypatch.delenv(k, raising=False)
+                monkeypatch.delitem(_lib.OPTIONS, k, raising=False)
 
     X, tiles = products({})
-    _, scatter = products({"DDX_MIRROR": "scatter"})
-    _, sort = products({"DDX_MIRROR": "sort"})
+    _, scatter = products({"mirror": "scatter"})
+    _, sort = products({"mirror": "sort"})
     np.testing.assert_array_equal(tiles, sort)
     np.testing.assert_array_equal(scatter, sort)
     # against the row-major copy: A^T Y = (X - 1 mu^T)^T Y
@@ -254,11 +254,11 @@ def test_scaled_matrix(ctx):
                                   "case_d_replace_single"])
 def test_pca_scores(case, gather, monkeypatch):
     # default: the operator products gather a float32-rounded copy of the 40-column iterate (float64
-    # products and sums); DDX_PCA_GATHER=f64 gathers the float64 iterate itself.  A context reads the environment once,
+    # products and sums); option pca_gather=f64 gathers the float64 iterate itself.  A context takes the process-wide options
     # when it is created: make one for this setting.
     from doubletdetection_amd import _lib
 
-    monkeypatch.setenv("DDX_PCA_GATHER", gather)
+    monkeypatch.setitem(_lib.OPTIONS, "pca_gather", gather)
     with _lib.Context(0) as ctx:
         _pca_scores_body(ctx, case, gather)
 
@@ -805,7 +805,7 @@ def test_greedy_memory_chunk_falls_back_without_leaving_an_error_behind():
 def test_packed_upload_equals_plain_upload(monkeypatch):
     """dd.py:149-160 (the matrix handed to fit()).  The raw matrix travels packed -- by default 2 bytes per entry (step from the
     row's previous column | count << 8; entries that do not fit that are listed whole beside the codes), with
-    DDX_UPLOAD=packed32 4 bytes (column | count << 16; falls back to plain copies when a count does not fit) -- or plain;
+    upload=packed32 4 bytes (column | count << 16; falls back to plain copies when a count does not fit) -- or plain;
     all three leave the same device matrix, whatever the values."""
     from doubletdetection_amd import _lib
     from doubletdetection_amd._synthetic import make_counts
@@ -816,7 +816,7 @@ def test_packed_upload_equals_plain_upload(monkeypatch):
 
     def device_matrix(env, mat, columns=None):
         for k, v in env.items():
-            monkeypatch.setenv(k, v)
+            monkeypatch.setitem(_lib.OPTIONS, k, v)
         c = _lib.Context(0)
         try:
             c.upload_raw(mat)
@@ -828,13 +828,13 @@ def test_packed_upload_equals_plain_upload(monkeypatch):
         finally:
             c.close()
             for k in env:
-                monkeypatch.delenv(k, raising=False)
+                monkeypatch.delitem(_lib.OPTIONS, k, raising=False)
 
-    # (DDX_UPLOAD=packed / packed32 wait for the pinned staging buffer; by default the first matrix of a process travels
+    # (upload=packed / packed32 wait for the pinned staging buffer; by default the first matrix of a process travels
     # plain while the buffer is being pinned in the background)
-    var_q, sub_q = device_matrix({"DDX_UPLOAD": "plain"}, counts)
+    var_q, sub_q = device_matrix({"upload": "plain"}, counts)
     for form in ("packed", "packed32"):
-        var_p, sub_p = device_matrix({"DDX_UPLOAD": form}, counts)
+        var_p, sub_p = device_matrix({"upload": form}, counts)
         np.testing.assert_array_equal(var_p, var_q)
         _same_csr(sub_p, sub_q)
     # entries neither code can hold (fractional, >= 65 536, 256), long column steps, empty rows, a row whose only column
@@ -853,9 +853,9 @@ def test_packed_upload_equals_plain_upload(monkeypatch):
     odd.sort_indices()
     assert odd.indptr[8] == odd.indptr[7] and odd.indptr[9] == odd.indptr[8] + 1
     everything = np.arange(odd.shape[1])
-    var_g, all_g = device_matrix({"DDX_UPLOAD": "plain"}, odd, everything)
+    var_g, all_g = device_matrix({"upload": "plain"}, odd, everything)
     for form in ("packed", "packed32"):
-        var_f, all_f = device_matrix({"DDX_UPLOAD": form}, odd, everything)
+        var_f, all_f = device_matrix({"upload": form}, odd, everything)
         np.testing.assert_array_equal(var_f, var_g)
         _same_csr(all_f, all_g)
     # the whole matrix came back: it is the caller's, sign bits included
@@ -864,9 +864,9 @@ def test_packed_upload_equals_plain_upload(monkeypatch):
     # a matrix of fractions: every entry would have to be listed, so both packed routes hand over to the plain copies
     halves = counts.copy()
     halves.data *= np.float32(0.5)
-    var_h, sub_h = device_matrix({"DDX_UPLOAD": "plain"}, halves)
+    var_h, sub_h = device_matrix({"upload": "plain"}, halves)
     for form in ("packed", "packed32"):
-        var_p, sub_p = device_matrix({"DDX_UPLOAD": form}, halves)
+        var_p, sub_p = device_matrix({"upload": form}, halves)
         np.testing.assert_array_equal(var_p, var_h)
         _same_csr(sub_p, sub_h)
     # a matrix the validation rejects is rejected the same way on every route (it arrives as it is)
@@ -875,11 +875,11 @@ def test_packed_upload_equals_plain_upload(monkeypatch):
     p0 = broken.indptr[row]
     broken.indices[p0], broken.indices[p0 + 1] = broken.indices[p0 + 1], broken.indices[p0]
     for form in ("plain", "packed", "packed32"):
-        monkeypatch.setenv("DDX_UPLOAD", form)
+        monkeypatch.setitem(_lib.OPTIONS, "upload", form)
         c = _lib.Context(0)
         try:
             with pytest.raises(_lib.DdxError):
                 c.upload_raw(broken)
         finally:
             c.close()
-            monkeypatch.delenv("DDX_UPLOAD")
+            monkeypatch.delitem(_lib.OPTIONS, "upload")
