@@ -32,14 +32,40 @@ if ROOT not in sys.path:
 
 import numpy as np  # noqa: E402
 
-# HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide
-# coalesced reads, + WRITE_SIZE), headline workload, profiles/r03j_pmc_counters.txt; None = not collected
-PMC_TRAFFIC_GB = {"spmm_rows": 1.56, "spmm_cols": 1.59, "knn_emit": 1.08, "knn_bound": 0.05, "knn_select": 0.43,
-                  "doublet_fill": 0.64, "mirror_build": 1.25, "lognorm_rows": 0.96, "lognorm_cols": 0.74}
-PMC_TRAFFIC_SOURCE = ("profiles/r03j_pmc_counters.txt (separate rocprofv3 --pmc passes of this command, round 3; a constant of this "
-                      "file, not re-measured by the run that prints it)")
+# HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide coalesced
+# reads, + WRITE_SIZE) of this command at the headline workload: profiles/pmc_traffic.json, written by
+# `profiles/summarise_pmc.py --traffic-json` at the end of profiles/collect.sh (no literals here: re-collect, copy, commit)
+def _pmc_traffic():
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+            d = json.load(fh)
+        return d.get("kernels", {}), d.get("source")
+    except Exception:
+        return {}, None
+
+
+PMC_TRAFFIC_GB, PMC_TRAFFIC_SOURCE = _pmc_traffic()
+
+
+def _cpu_full():
+    """The full-size CPU run (`bench.py --cpu-full`: two iterations of the oracle on ALL cells, minutes) is too long for the
+    default run; the committed record of the last one is quoted beside the sampled baseline."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_cpu_full.json")))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as fh:
+            cb = json.load(fh)["cpu_baseline"]
+        return {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"], "sample": cb["sample"],
+                "source": os.path.relpath(files[-1], ROOT)}
+    except Exception:
+        return None
+
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md)
+LDS_PEAK_GBS = 256 * 128 * 2.4     # 256 CUs x 128 bytes per clock x 2.4 GHz = 78.6 TB/s of LDS reads (MI355X_MICROARCH.md)
 FP64_PEAK_TFLOPS = 78.6      # FP64 vector / FP64 MFMA peak, dense
 FP32_PEAK_TFLOPS = 157.3
 BF16_PEAK_TFLOPS = 2500.0     # dense bf16 MFMA peak (MI355X_MICROARCH.md; not the 2:1-sparsity figure)
@@ -63,6 +89,7 @@ def parse():
     ap.add_argument("--instrumented-steps", type=int, default=2, help="extra fits with per-kernel HIP events (N=1) behind the kernel tables")
     ap.add_argument("--resident-steps", type=int, default=2, help="extra fits on staged counts for value_resident (N=1)")
     ap.add_argument("--no-exclusive", action="store_true", help="skip the extra single-context fits behind roofline_exclusive")
+    ap.add_argument("--option", action="append", default=[], metavar="KEY=VALUE", help="ddx_set_option switch for every context (include/ddx.h), repeatable")
     return ap.parse_args()
 
 
@@ -89,7 +116,7 @@ def kernel_models(N, G, H, S, nnz_aug, C, k, L=None, knn_window=1.0):
     M = N + S
     L = L or (C + 10)
     CP = 32 if C <= 32 else 64
-    Mp = -(-M // 256) * 256
+    Mp = -(-M // 512) * 512
     nsamp_tiles = min(max(512, (Mp // 16) // 16), Mp // 16)      # tiles of the bound pass's subset (stage_knn)
     return {
         # name: (bound, unit, work per launch, peak)
@@ -136,8 +163,12 @@ def main():
             raise SystemExit(f"bench.py: {dist.get_world_size()} ranks joined, expected {args.gpus}")
     dev = f"cuda:{device_index}"
 
-    from doubletdetection_amd import BoostClassifier
+    from doubletdetection_amd import BoostClassifier, _lib
     from doubletdetection_amd._synthetic import make_counts
+
+    for item in args.option:
+        key, _, value = item.partition("=")
+        _lib.OPTIONS[key] = value
 
     os.environ["DDX_TIMING"] = "0"              # the timed steps run the production path: no per-kernel HIP events
     t_gen = time.perf_counter()
@@ -209,6 +240,7 @@ def main():
         S = int(clf.boost_rate * N)
         nnz_aug = getattr(clf, "_last_nnz_aug", None) or int(X.nnz * 1.0)
         C = clf.n_components
+        L_ = C + 10
         k = 30 if args.algorithm == "phenograph" else 10
         models, issued = kernel_models(N, G, H, S, nnz_aug, C, k, knn_window=getattr(clf, "_last_knn_window", 1.0))
         gpu_ms = {n: v[1] for n, v in timings.items()}
@@ -222,6 +254,13 @@ def main():
                    "frac": round(achieved / peak, 4), "traffic": PMC_TRAFFIC_GB.get(name),
                    "traffic_source": PMC_TRAFFIC_SOURCE if name in PMC_TRAFFIC_GB else None,
                    "avg_launch_ms": round(avg_s * 1e3, 4), "launches": timings[name][0], "work_per_launch": round(work, 4)}
+            if name in ("spmm_rows", "spmm_cols"):
+                # the products are bound on chip: every stored entry reads one operand row (ld floats) from LDS -- how far the
+                # launch is from THAT bound (the HBM fraction above says how far it is from the bound it could have)
+                lds_gb = nnz_aug * (((L_ + 3) // 4) * 4) * 4 / 1e9
+                out["lds_bound"] = {"bytes_per_launch_GB": round(lds_gb, 3), "peak_GBs": LDS_PEAK_GBS, "achieved_GBs": round(lds_gb / avg_s, 1),
+                                    "frac": round(lds_gb / avg_s / LDS_PEAK_GBS, 4),
+                                    "floor_ms": round(lds_gb / LDS_PEAK_GBS * 1e3, 3)}
             if name in issued:          # MFMA screens: useful flops above, what the kernel issues (3 products, padded) here
                 out["issued_per_launch"] = round(issued[name], 4)
                 out["issued_frac"] = round(issued[name] / avg_s / peak, 4)
@@ -287,6 +326,9 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(X, args, kw)
+        full = _cpu_full()
+        if full and (N, G) == (100_000, 30_000):
+            out["cpu_baseline_full"] = full
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -930,6 +930,10 @@ class BoostClassifier:
                                                      q0, knn_k, include_self, graph_mode, gamma, pca_locks[dev], **kw2)
                     if split and len(graph) == 4:
                         waiting = (i, pool.submit(self._part_b, graph, gamma, seed, leiden, q_tol, restart_threads))
+                    elif len(graph) == 4:
+                        # engine contract: a 3-tuple is the whole symmetric graph (indptr, indices, weights); a 4-tuple (member,
+                        # coarse indptr, indices, weights) is the result of the device pre-sweeps and needs `refine` for part C
+                        raise TypeError("an engine that returns a pre-coarsened graph must also provide first_half / second_half / refine")
                     else:
                         pending[i] = pool.submit(self._cluster_and_score, graph, gamma, seed, min_cluster_size, num_cells, leiden,
                                                  q_tol, restart_threads, sink_for(i))

@@ -522,7 +522,8 @@ std::atomic<int> g_pin_state{0};             // 0 none / too small, 1 being allo
 void* g_pin_buf = nullptr;
 size_t g_pin_bytes = 0;
 size_t g_pin_failed = 0;                     // smallest size hipHostMalloc has refused in this process (0: none): not retried
-std::thread g_pin_thread;                    // the helper that pins the buffer (joined before the next one starts and at exit)
+std::thread* g_pin_thread = nullptr;         // the helper that pins the buffer (joined before the next one starts and at exit); on the heap so that a
+                                             // forked child, where the parent's thread does not exist, can abandon the object instead of destroying it
 void pin_allocate(size_t need, int device) {
     (void)hipSetDevice(device);
     if (g_pin_buf) { (void)hipHostFree(g_pin_buf); g_pin_buf = nullptr; g_pin_bytes = 0; }
@@ -530,7 +531,7 @@ void pin_allocate(size_t need, int device) {
     if (hipHostMalloc(&p, need, hipHostMallocPortable) == hipSuccess) { g_pin_buf = p; g_pin_bytes = need; g_pin_state.store(2, std::memory_order_release); }
     else { (void)hipGetLastError(); g_pin_failed = need; g_pin_state.store(0, std::memory_order_release); }
 }
-void pin_join() { if (g_pin_thread.joinable()) g_pin_thread.join(); }
+void pin_join() { if (g_pin_thread && g_pin_thread->joinable()) g_pin_thread->join(); }
 WorkerPool* g_pool = nullptr;
 pid_t g_pool_pid = 0;
 std::atomic<int> g_upload_threads{0};        // ddx_set_upload_threads (0: the default rule)
@@ -608,7 +609,7 @@ static int upload_packed(ddx_ctx* ctx, int64_t n_cells, int64_t nnz, int32_t n_g
         static pid_t pin_pid = 0;
         if (pin_pid != getpid()) {                               // (a forked child starts over; the parent's helper thread does not exist here)
             pin_pid = getpid(); g_pin_state.store(0); g_pin_buf = nullptr; g_pin_bytes = 0; g_pin_failed = 0;
-            new (&g_pin_thread) std::thread();
+            g_pin_thread = nullptr;                              // (abandoned, never joined or freed: it belongs to the parent)
         }
         const int st = g_pin_state.load(std::memory_order_acquire);
         if (st == 1) return 1;                                   // still being pinned
@@ -622,7 +623,8 @@ static int upload_packed(ddx_ctx* ctx, int64_t n_cells, int64_t nnz, int32_t n_g
                 // a process that exits while the helper is still pinning must not run hipHostMalloc during runtime teardown
                 static bool hooked = false;
                 if (!hooked) { hooked = true; std::atexit(pin_join); }
-                g_pin_thread = std::thread(pin_allocate, want, ctx->device);
+                delete g_pin_thread;                             // (joined above)
+                g_pin_thread = new std::thread(pin_allocate, want, ctx->device);
                 return 1;
             }
             if (g_pin_state.load() != 2) return 1;

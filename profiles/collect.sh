@@ -43,4 +43,6 @@ cd "$repo"
     echo "# per-dispatch averages; FETCH_SIZE/WRITE_SIZE in KB; fetch_x2_MB = FETCH_SIZE doubled (gfx950 wide-read correction)"
     python profiles/summarise_pmc.py fetch=/tmp/prof_fetch write=/tmp/prof_write l2=/tmp/prof_l2
 } > "$out/${tag}_pmc_counters.txt"
+# the table bench.py's `roofline.traffic` is read from (profiles/pmc_traffic.json: copy it there together with the summaries)
+python profiles/summarise_pmc.py --traffic-json "$out/pmc_traffic.json" fetch=/tmp/prof_fetch write=/tmp/prof_write source="profiles/${tag}_pmc_counters.txt (separate rocprofv3 --pmc passes of: $short)"
 tail -3 "$out/${tag}_stats_bench.log"

@@ -10,6 +10,7 @@ reads (MI355X_MICROARCH.md, HBM section), so the "x2" column is the number to co
 import collections
 import csv
 import glob
+import json
 import os
 import re
 import sys
@@ -24,7 +25,59 @@ def short(name: str) -> str:
     return name.replace("void ", "").strip()
 
 
+# kernel name -> timing scope of bench.py (the scopes a launch of which runs several kernels list all of them; the first is
+# the one whose dispatches are counted as launches of the scope)
+SCOPES = {
+    "spmm_rows": ["ddx::k_spmm_lds<true"],
+    "spmm_cols": ["ddx::k_spmm_lds<false", "ddx::k_sum_panels"],
+    "knn_emit": ["ddx::k_knn_emit_bf", "ddx::k_knn_fold"],
+    "knn_bound": ["ddx::k_knn_bound_bf"],
+    "knn_select": ["ddx::k_knn_select", "ddx::k_knn_rescan"],
+    "knn_lists": ["ddx::k_knn_tilelists"],
+    "doublet_fill": ["ddx::k_doublet_fill"],
+    "mirror_build": ["ddx::k_mirror_tiles", "ddx::k_mirror_count", "ddx::k_mirror_prefix"],
+    "lognorm_rows": ["ddx::k_lognorm_rows", "ddx::k_lognorm_table"],
+    "lognorm_cols": ["ddx::k_lognorm_csc"],
+}
+
+
+def traffic_table(fetch_dir, write_dir):
+    """HBM GB per launch of every scope: FETCH_SIZE doubled (gfx950 wide-read correction, MI355X_MICROARCH.md) + WRITE_SIZE,
+    both reported in KB by rocprofv3, summed over the scope's kernels and divided by the dispatches of its first kernel."""
+    def totals(d, counter):
+        tot, n = collections.defaultdict(float), collections.defaultdict(set)
+        for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            with open(path, newline="") as fh:
+                for row in csv.DictReader(fh):
+                    if row["Counter_Name"] == counter:
+                        k = short(row["Kernel_Name"])
+                        tot[k] += float(row["Counter_Value"])
+                        n[k].add(row["Dispatch_Id"])
+        return tot, {k: len(v) for k, v in n.items()}
+
+    fetch, nf = totals(fetch_dir, "FETCH_SIZE")
+    write, _ = totals(write_dir, "WRITE_SIZE")
+    out = {}
+    for scope, prefixes in SCOPES.items():
+        members = [k for k in fetch if any(k.startswith(pfx) for pfx in prefixes)]
+        lead = [k for k in members if k.startswith(prefixes[0])]
+        launches = sum(nf.get(k, 0) for k in lead)
+        if not launches:
+            continue
+        kb = sum(2.0 * fetch[k] + write.get(k, 0.0) for k in members)
+        out[scope] = round(kb * 1024.0 / launches / 1e9, 4)
+    return out
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--traffic-json":
+        # python profiles/summarise_pmc.py --traffic-json out.json fetch=<dir> write=<dir> source="..."
+        kv = dict(a.split("=", 1) for a in sys.argv[3:])
+        table = traffic_table(kv["fetch"], kv["write"])
+        with open(sys.argv[2], "w") as fh:
+            json.dump({"source": kv.get("source", ""), "unit": "GB of HBM traffic per launch (FETCH_SIZE x 2 + WRITE_SIZE)", "kernels": table}, fh, indent=1)
+        print(table)
+        return
     for arg in sys.argv[1:]:
         tag, d = arg.split("=", 1)
         acc = collections.defaultdict(lambda: collections.defaultdict(float))
