@@ -676,19 +676,22 @@ class BoostClassifier:
             return [int(self.device)]
         return [int(os.environ.get("LOCAL_RANK", "0")) if world > 1 else 0]
 
-    def _host_threads(self):
+    def _host_threads(self, world: int = 1):
         """Host threads for community detection + scoring (they run while the GPU works on the next iteration).
         n_jobs > 1: that many; n_jobs <= 0: every core; n_jobs == 1 (the reference's default, where it only sizes
-        PhenoGraph's process pool) leaves the choice to the library: min(32, cores).  DDX_HOST_THREADS overrides."""
+        PhenoGraph's process pool) leaves the choice to the library: min(32, cores).  DDX_HOST_THREADS overrides.
+        With one process per GPU (``world`` ranks on this node, dd.py:192-198 sharded) the ranks share the host: every
+        automatic figure is a rank's share, cores // world -- 8 ranks x 5 contexts x 20 restart threads would otherwise
+        be 800 runnable threads on one node."""
         env = os.environ.get("DDX_HOST_THREADS")
         if env:
             return max(1, int(env))
-        cores = os.cpu_count() or 1
+        cores = max(1, (os.cpu_count() or 1) // max(1, int(world)))
         if self.n_jobs is None or self.n_jobs <= 0:
             return cores
         if self.n_jobs == 1:
             return min(32, cores)
-        return int(self.n_jobs)
+        return max(1, min(int(self.n_jobs), cores) if world > 1 else int(self.n_jobs))
 
     _AUTO_STREAMS = 5
 
@@ -868,9 +871,11 @@ class BoostClassifier:
         # 222.5) -- the hardware scheduler interleaves the streams at least as well, so the default is no lock.
         use_lock = os.environ.get("DDX_PCA_LOCK", "0") not in ("", "0")
         pca_locks = {dev: (threading.Lock() if use_lock and sum(1 for d, _ in lanes if d == dev) > 1 else None) for dev, _ in lanes}
-        workers = self._host_threads()
+        workers = self._host_threads(world)
+        self._host_threads_used = workers
         # host threads one clustering job may use for its batch of restarts (the jobs of different iterations overlap)
         restart_threads = max(1, min(20, workers // max(1, min(workers, len(mine)))))
+        self._restart_threads_used = restart_threads
         local = {}
         # Without a process group every iteration runs here: the worker that scores an iteration writes its rows of the
         # fitted attributes itself (behind the GPU's work on the other iterations) instead of leaving 30 MB of copies to the

@@ -146,7 +146,7 @@ __host__ __device__ constexpr int chunk_tiles(int CP) { return CP <= 32 ? 8 : 4;
 constexpr int kBoundRT = 2;   // query tiles per wave in the bound pass (register budget: 16 rows x kBoundKeep)
 constexpr int kEmitRT = 2;    // query tiles per wave in the emit pass
 constexpr int kEmitWaves = 4;  // waves per workgroup of the emit pass (they share the staged candidate tiles)
-constexpr int kEmitSegSteps = 8;    // steps (of 8 or 4 tiles) of a block's list that one workgroup screens
+constexpr int kEmitSegSteps = 4;    // steps (of 8 or 4 tiles) of a block's list that one workgroup screens
 constexpr int kEmitLocal = 32;      // candidates per query that a work item buffers in LDS before it reserves slots in the query's list
 
 // ---- bfloat16-split MFMA screen ----------------------------------------------------------------------------
@@ -697,15 +697,19 @@ __global__ void __launch_bounds__(64 * WAVES) k_knn_select(const float* __restri
     }
 }
 
-// Queries whose candidate list overflowed: exact scan of ALL points with the bound the select pass derived from the cut
-// list, one workgroup of 8 waves per query.  Every wave scans an eighth of the points and keeps those within the bound in
-// its own LDS window (a full window is sorted, cut to the K best and its K-th distance becomes the wave's bound); the K
-// nearest of all points are among the waves' K best, which wave 0 merges.  Same arithmetic and tie rule as the select pass.
-constexpr int kRescanWaves = 8, kRescanWin = 1024;
+// Queries whose candidate list overflowed: exact scan with the bound the select pass derived from the cut list, one workgroup
+// of 16 waves per query, over the tiles the emit pass listed for the query's wave (every point within the query's bound T_q
+// lies in one of them -- that is what the lists are -- so nothing beyond them can be among the K nearest).  Every wave takes
+// a share of the tiles and keeps the points within the bound in its own LDS window (a full window is sorted, cut to the K
+// best and its K-th distance becomes the wave's bound); the K nearest are among the waves' K best, which wave 0 merges.
+// Same arithmetic and tie rule as the select pass.
+constexpr int kRescanWaves = 16, kRescanWin = 512;
 template <int CP>
 __global__ void __launch_bounds__(64 * kRescanWaves) k_knn_rescan(const float* __restrict__ E, const int32_t* __restrict__ perm, int64_t M, int K, int include_self,
                                                                   const int32_t* __restrict__ n_overflow, const int32_t* __restrict__ ovf_q,
-                                                                  const double* __restrict__ ovf_bound, int32_t* __restrict__ idx_out, double* __restrict__ dist_out) {
+                                                                  const double* __restrict__ ovf_bound, const int32_t* __restrict__ elist,
+                                                                  const uint32_t* __restrict__ emask, const int32_t* __restrict__ ecount, int64_t ecap, int BW,
+                                                                  int32_t* __restrict__ idx_out, double* __restrict__ dist_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rs_smem[];
     double* sd = reinterpret_cast<double*>(rs_smem);                                        // [waves][win] + merge [waves * 256]
     int32_t* si = reinterpret_cast<int32_t*>(sd + kRescanWaves * kRescanWin + kRescanWaves * 256);
@@ -721,11 +725,18 @@ __global__ void __launch_bounds__(64 * kRescanWaves) k_knn_rescan(const float* _
         int32_t* ix = si + wave * kRescanWin;
         double bound = ovf_bound[it];
         int fill = 0;
-        for (int64_t c0 = (int64_t)wave * 64; c0 < M; c0 += 64 * kRescanWaves) {
-            const int64_t c = c0 + lane;
+        const int64_t blk = q / (BW * 16 * kEmitRT);
+        const int qwave = (int)((q / (16 * kEmitRT)) % BW);
+        const int32_t* lst = elist + blk * ecap;
+        const uint32_t* lmk = emask + blk * ecap;
+        const int nent = ecount[blk];
+        for (int e0 = wave * 4; e0 < nent; e0 += 4 * kRescanWaves) {            // four tiles per wave and step
+            const int e = e0 + (lane >> 4);
+            int64_t c = -1;
+            if (e < nent && ((lmk[e] >> qwave) & 1u)) c = (int64_t)lst[e] * 16 + (lane & 15);
             double dv = __builtin_huge_val();
             bool keep = false;
-            if (c < M && (include_self || c != q)) {
+            if (c >= 0 && c < M && (include_self || c != q)) {
                 dv = exact_d2<CP>(sq, E + c * CP);
                 keep = dv <= bound;
             }
@@ -997,18 +1008,20 @@ __global__ void __launch_bounds__(256) k_cells_assign(const float* __restrict__ 
     }
 }
 
+// (thread = (point, component): the 32 lanes of a point add to 32 consecutive sums of its cell)
 __global__ void k_cells_accumulate(const float* __restrict__ emb, const int32_t* __restrict__ ids, int64_t n, int stride, int C,
                                    const int32_t* __restrict__ label, unsigned long long* __restrict__ sums, int32_t* __restrict__ counts) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = t / kCellDim;
+    const int d = (int)(t % kCellDim);
     if (i >= n) return;
     const int64_t r = ids[i * stride];
     const int c = label[r];
-    const int D = C < kCellDim ? C : kCellDim;
-    for (int d = 0; d < D; ++d) {
+    if (d < C) {
         const long long v = (long long)rintf(emb[r * C + d] * kCellFix);
         atomicAdd(&sums[(size_t)c * kCellDim + d], (unsigned long long)v);     // two's complement: exact in any order
     }
-    atomicAdd(&counts[c], 1);
+    if (d == 0) atomicAdd(&counts[c], 1);
 }
 
 // centre = mean of the members (an empty cell keeps its centre); clears the sums for the next round
@@ -1544,7 +1557,7 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
         const int64_t ns = M / sub;
         for (int round = 0; round < kCellRounds; ++round) {
             k_cells_assign<<<(unsigned)ceil_div(ns, 64), 256, 0, ctx->stream>>>(emb, perm1, ns, sub, C, cen, cn, Kc, label, nullptr);
-            k_cells_accumulate<<<(unsigned)ceil_div(ns, 256), 256, 0, ctx->stream>>>(emb, perm1, ns, sub, C, label, sums, counts);
+            k_cells_accumulate<<<(unsigned)ceil_div(ns * kCellDim, 256), 256, 0, ctx->stream>>>(emb, perm1, ns, sub, C, label, sums, counts);
             k_cells_mean<<<gK, 256, 0, ctx->stream>>>(sums, counts, Kc, cen, cn);
         }
         // order inside a cell: by distance from its centre (the few points far from every centre -- whose intervals along any
@@ -1604,7 +1617,7 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
     }
     {
         ScopedTimer t(ctx, "knn_emit");
-        const int seg_steps = ctx->opt.knn_seg_steps > 0 ? ctx->opt.knn_seg_steps : kEmitSegSteps;
+        const int seg_steps = ctx->opt.knn_seg_steps > 0 ? ctx->opt.knn_seg_steps : (M >= 400000 ? 2 * kEmitSegSteps : kEmitSegSteps);   // (measured: 1.33 ms at 125 k points with 4, 18.6 ms at 625 k with 8)
         const int nseg = (int)(ceil_div(ceil_div(ecap, G), (int64_t)seg_steps * 8) * 8);     // segments of the longest possible list, a multiple of 8
         const unsigned grid_x = (unsigned)(emit_blocks * nseg);
         const int dbg_mode = ctx->opt.knn_ablation;     // timing ablations (wrong results): non-zero only in -DDDX_ABLATION builds
@@ -1640,7 +1653,7 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
 #define DDX_RESCAN(CPV)                                                                                                                       \
     do {                                                                                                                                      \
         DDX_TRY(allow_dynamic_lds(ctx, reinterpret_cast<const void*>(&k_knn_rescan<CPV>), (int)rs_lds));                                      \
-        k_knn_rescan<CPV><<<512, 64 * kRescanWaves, rs_lds, ctx->stream>>>(E, perm, M, k, include_self, ccount + Mp, ovf_q, ovf_bound, ki, kd); \
+        k_knn_rescan<CPV><<<512, 64 * kRescanWaves, rs_lds, ctx->stream>>>(E, perm, M, k, include_self, ccount + Mp, ovf_q, ovf_bound, elist, emask, ecount, ecap, BW, ki, kd); \
     } while (0)
         if (CP == 32) { DDX_SELECT_LAUNCH(32); DDX_RESCAN(32); }
         else if (CP == 64) { DDX_SELECT_LAUNCH(64); DDX_RESCAN(64); }

@@ -42,7 +42,8 @@ def _worker(rank, world, port, case, n_iters, out_dir):
             labels = clf.predict()
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), scores=clf.all_scores_, logp=clf.all_log_p_values_,
                  comm=clf.communities_, synth=clf.synth_communities_, parents=np.asarray(clf.parents_),
-                 labels=labels, voting=clf.voting_average_)
+                 labels=labels, voting=clf.voting_average_,
+                 threads=np.array([clf._host_threads_used, clf._restart_threads_used, os.cpu_count() or 1]))
     finally:
         dist.destroy_process_group()
 
@@ -85,6 +86,9 @@ def test_multi_rank_fit_equals_single_process(tmp_path, case, n_iters, world):
         np.testing.assert_array_equal(r["logp"], single.all_log_p_values_)
         np.testing.assert_array_equal(r["labels"], single_labels)
         np.testing.assert_array_equal(r["voting"], single.voting_average_)
+        # the ranks of a node share its cores: a rank's host workers and its restart batches stay inside cores // world
+        workers, restarts, cores = (int(v) for v in r["threads"])
+        assert 1 <= workers <= max(1, cores // world) and 1 <= restarts <= workers
     # iterations the golden run also did must reproduce the reference's own output
     k = min(n_iters, g["communities"].shape[0])
     np.testing.assert_array_equal(single.communities_[:k], g["communities"][:k])
