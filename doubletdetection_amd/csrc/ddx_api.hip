@@ -159,7 +159,7 @@ bool Options::set(const char* key, const char* value) {
     if (k == "knn_sample_every") { if (!num(0, 1 << 20, &x)) return false; knn_sample_every = (int)x; return true; }
     if (k == "knn_cells") { if (!num(0, 1024, &x)) return false; knn_cells = (int)x; return true; }
     if (k == "knn_seg_steps") { if (!num(0, 1 << 20, &x)) return false; knn_seg_steps = (int)x; return true; }
-    if (k == "knn_emit_waves") { if (!num(0, 16, &x)) return false; knn_emit_waves = (int)x; return true; }
+    if (k == "knn_emit_waves") { if (!num(0, 8, &x)) return false; knn_emit_waves = (int)x; return true; }
     if (k == "knn_debug") { knn_debug = on(); return true; }
     if (k == "pca_debug") { pca_debug = on(); return true; }
     if (k == "row_sums") { if (v == "auto") row_sums_sequential = false; else if (v == "sequential") row_sums_sequential = true; else return false; return true; }

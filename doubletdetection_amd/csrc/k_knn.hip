@@ -144,6 +144,7 @@ __device__ __forceinline__ int64_t knn_block(int64_t nblocks, int chunk) {
 __host__ __device__ constexpr int chunk_tiles(int CP) { return CP <= 32 ? 8 : 4; }
 
 constexpr int kBoundRT = 2;   // query tiles per wave in the bound pass (register budget: 16 rows x kBoundKeep)
+constexpr int kBoundWaves = 8; // waves per workgroup of the bound pass: they share the staged sample, and staging is what bounds the pass
 constexpr int kEmitRT = 2;    // query tiles per wave in the emit pass
 constexpr int kEmitWaves = 4;  // waves per workgroup of the emit pass (they share the staged candidate tiles)
 constexpr int kEmitSegSteps = 4;    // steps (of 8 or 4 tiles) of a block's list that one workgroup screens
@@ -236,7 +237,7 @@ __device__ __forceinline__ void stage_tiles(const f4* __restrict__ srcE, const f
 // entry and the ceil(k / stride)-th smallest of ITS points; the largest of those bounds holds at least k points of the
 // whole sample below it -- `combine` keeps the maximum over the launches.
 template <int CP, int kBoundKeep>
-__global__ void __launch_bounds__(256) k_knn_bound_bf(const __bf16* __restrict__ Eb, const float* __restrict__ nrm,
+__global__ void __launch_bounds__(64 * kBoundWaves) k_knn_bound_bf(const __bf16* __restrict__ Eb, const float* __restrict__ nrm,
                                                       int64_t Mp, int K, int include_self, const int32_t* __restrict__ blist, const int32_t* __restrict__ bcount,
                                                       int64_t bcap, int stride, int phase, int combine, float* __restrict__ thr_out,
                                                       int xcd_chunk) {
@@ -247,9 +248,9 @@ __global__ void __launch_bounds__(256) k_knn_bound_bf(const __bf16* __restrict__
     __shared__ float lds_n[2][G * 16];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int64_t blk = knn_block(Mp / (4 * 16 * RT), xcd_chunk);
+    const int64_t blk = knn_block(Mp / (kBoundWaves * 16 * RT), xcd_chunk);
     if (blk < 0) return;
-    const int64_t q0 = (blk * 4 + wave) * (16 * RT);
+    const int64_t q0 = (blk * kBoundWaves + wave) * (16 * RT);
     QueryTilesBf<CP, RT> qt;
     qt.load(Eb, q0, lane);
     const int rbase = 4 * (lane >> 4), jcol = lane & 15;
@@ -274,13 +275,13 @@ __global__ void __launch_bounds__(256) k_knn_bound_bf(const __bf16* __restrict__
     const f4* srcE = reinterpret_cast<const f4*>(Eb);
     if (nsteps > 0) {
         int e0 = entry(0), e1 = nsteps > 1 ? entry(1) : 0;
-        stage_tiles<CP, 4, 1>(srcE, nrm, lds_c[0], lds_n[0], e0, tid, wave, lane);
+        stage_tiles<CP, kBoundWaves, 1>(srcE, nrm, lds_c[0], lds_n[0], e0, tid, wave, lane);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         for (int step = 0; step < nsteps; ++step) {
             const int buf = step & 1;
             int e2 = 0;
-            if (step + 1 < nsteps) stage_tiles<CP, 4, 1>(srcE, nrm, lds_c[buf ^ 1], lds_n[buf ^ 1], e1, tid, wave, lane);
+            if (step + 1 < nsteps) stage_tiles<CP, kBoundWaves, 1>(srcE, nrm, lds_c[buf ^ 1], lds_n[buf ^ 1], e1, tid, wave, lane);
             if (step + 2 < nsteps) e2 = entry(step + 2);
             const int ntile = (n - step * G) < G ? (n - step * G) : G;
             for (int t = 0; t < ntile; ++t) {
@@ -343,7 +344,7 @@ __global__ void __launch_bounds__(256) k_knn_bound_bf(const __bf16* __restrict__
     }
 }
 
-// Emit pass.  elist[blk][*] / emask[blk][*]: tiles and the waves of the block that screen them, ecount[blk] entries (a multiple of
+// Emit pass.  elist[blk][*]: tile | (waves of the block that screen it) << 24, ecount[blk] entries (a multiple of
 // the step size, padded with mask-0 entries); candidates are appended to cbuf[q][*], ccount[q] counts them (beyond `cap`:
 // overflow).  The waves of a block share the staged tiles: the pass is bound by that staging traffic (L2 / Infinity Cache ->
 // LDS), not by the matrix pipe, so a block is as many waves as a workgroup holds (16: 512 queries per staged tile).
@@ -351,7 +352,7 @@ template <int CP, bool FOLD, int kEmitBW>
 __global__ void __launch_bounds__(64 * kEmitBW) __attribute__((amdgpu_waves_per_eu(CP <= 64 ? 4 : 2, CP <= 64 ? 4 : 2)))
 k_knn_emit_bf(const __bf16* __restrict__ Eb, const __bf16* __restrict__ Ebq, const float* __restrict__ nrm, const f4* __restrict__ start4,
               const float* __restrict__ thr, int64_t Mp, int include_self, int32_t* __restrict__ ccount, int32_t* __restrict__ cbuf,
-              const int32_t* __restrict__ elist, const uint32_t* __restrict__ emask, const int32_t* __restrict__ ecount, int64_t ecap, int dbg,
+              const int32_t* __restrict__ elist, const int32_t* __restrict__ ecount, int64_t ecap, int dbg,
               int cap, int nseg, int seg_steps) {
     constexpr int RT = kEmitRT, NV = 4 * RT;
     constexpr int G = chunk_tiles(CP);
@@ -390,26 +391,22 @@ k_knn_emit_bf(const __bf16* __restrict__ Eb, const __bf16* __restrict__ Ebq, con
         if (FOLD) hr[v] = 0.f;                               // the threshold travels inside the dot product
     }
     const int32_t* lst = elist + blk * ecap + (int64_t)s_lo * G;
-    const uint32_t* lmk = emask + blk * ecap + (int64_t)s_lo * G;
     const int32_t own_tile = (int32_t)(q0 >> 4);
     const f4* srcE = reinterpret_cast<const f4*>(Eb);
     const float* srcH = reinterpret_cast<const float*>(start4);
-    int e0 = lst[lane & (G - 1)], e1 = nsteps > 1 ? lst[G + (lane & (G - 1))] : 0;
-    unsigned m0 = lmk[lane & (G - 1)], m1 = nsteps > 1 ? lmk[G + (lane & (G - 1))] : 0u;
+    // (p: packed entries, lane j < G holds entry j of the step; e: their tile numbers)
+    int p0 = lst[lane & (G - 1)], p1 = nsteps > 1 ? lst[G + (lane & (G - 1))] : 0;
+    int e0 = p0 & 0xffffff;
     stage_tiles<CP, kEmitBW, 4>(srcE, srcH, lds_c[0], reinterpret_cast<float*>(lds_h[0]), e0, tid, wave, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int step = 0; step < nsteps; ++step) {
         const int buf = step & 1;
-        int e2 = 0;
-        if (step + 1 < nsteps) stage_tiles<CP, kEmitBW, 4>(srcE, srcH, lds_c[buf ^ 1], reinterpret_cast<float*>(lds_h[buf ^ 1]), e1, tid, wave, lane);
-        unsigned m2 = 0u;
-        if (step + 2 < nsteps) {
-            e2 = lst[(step + 2) * G + (lane & (G - 1))];
-            m2 = lmk[(step + 2) * G + (lane & (G - 1))];
-        }
+        int p2 = 0;
+        if (step + 1 < nsteps) stage_tiles<CP, kEmitBW, 4>(srcE, srcH, lds_c[buf ^ 1], reinterpret_cast<float*>(lds_h[buf ^ 1]), p1 & 0xffffff, tid, wave, lane);
+        if (step + 2 < nsteps) p2 = lst[(step + 2) * G + (lane & (G - 1))];
         // this wave's tiles of the step (wave-uniform mask)
-        unsigned tmask = (unsigned)__ballot(lane < G && ((m0 >> wave) & 1u)) & ((1u << G) - 1u);
+        unsigned tmask = (unsigned)__ballot(lane < G && ((((unsigned)p0 >> 24) >> wave) & 1u)) & ((1u << G) - 1u);
         const f4* tb = lds_c[buf];
         const f4* th = lds_h[buf];
         static_assert(CP % 32 == 0, "");
@@ -506,10 +503,9 @@ k_knn_emit_bf(const __bf16* __restrict__ Eb, const __bf16* __restrict__ Ebq, con
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the next step has landed before anyone crosses the barrier
         __syncthreads();
-        e0 = e1;
-        e1 = e2;
-        m0 = m1;
-        m1 = m2;
+        p0 = p1;
+        p1 = p2;
+        e0 = p0 & 0xffffff;
     }
     // hand the item's candidates over: per query one atomic reserves the slots (several items append to one list: the order
     // of a list depends on the run, the select pass sorts it), then the 16 lanes of the group copy
@@ -708,7 +704,7 @@ template <int CP>
 __global__ void __launch_bounds__(64 * kRescanWaves) k_knn_rescan(const float* __restrict__ E, const int32_t* __restrict__ perm, int64_t M, int K, int include_self,
                                                                   const int32_t* __restrict__ n_overflow, const int32_t* __restrict__ ovf_q,
                                                                   const double* __restrict__ ovf_bound, const int32_t* __restrict__ elist,
-                                                                  const uint32_t* __restrict__ emask, const int32_t* __restrict__ ecount, int64_t ecap, int BW,
+                                                                  const int32_t* __restrict__ ecount, int64_t ecap, int BW,
                                                                   int32_t* __restrict__ idx_out, double* __restrict__ dist_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rs_smem[];
     double* sd = reinterpret_cast<double*>(rs_smem);                                        // [waves][win] + merge [waves * 256]
@@ -728,12 +724,11 @@ __global__ void __launch_bounds__(64 * kRescanWaves) k_knn_rescan(const float* _
         const int64_t blk = q / (BW * 16 * kEmitRT);
         const int qwave = (int)((q / (16 * kEmitRT)) % BW);
         const int32_t* lst = elist + blk * ecap;
-        const uint32_t* lmk = emask + blk * ecap;
         const int nent = ecount[blk];
         for (int e0 = wave * 4; e0 < nent; e0 += 4 * kRescanWaves) {            // four tiles per wave and step
             const int e = e0 + (lane >> 4);
             int64_t c = -1;
-            if (e < nent && ((lmk[e] >> qwave) & 1u)) c = (int64_t)lst[e] * 16 + (lane & 15);
+            if (e < nent && ((((unsigned)lst[e] >> 24) >> qwave) & 1u)) c = (int64_t)(lst[e] & 0xffffff) * 16 + (lane & 15);
             double dv = __builtin_huge_val();
             bool keep = false;
             if (c >= 0 && c < M && (include_self || c != q)) {
@@ -1167,14 +1162,14 @@ __global__ void __launch_bounds__(256) k_knn_slabs(const float* __restrict__ E, 
 }
 
 // Per emit block (BW waves of 2 query tiles): the list of candidate tiles that at least one of its waves has to screen,
-// elist = the tiles (ascending), emask = those waves, padded with mask-0 entries to a multiple of G (the emit pass's step).
+// elist = tile | waves << 24 (tiles ascending), padded with mask-0 entries to a multiple of G (the emit pass's step).
 // A lane tests one candidate tile against its wave's two query tiles; a round covers 64 * BW tiles.
 template <int BW>
 __global__ void __launch_bounds__(64 * BW) k_knn_tilelists(const float* __restrict__ S_lo, const float* __restrict__ S_hi, const float* __restrict__ St_lo,
                                                            const float* __restrict__ St_hi, const int32_t* __restrict__ tilecell,
                                                            const float* __restrict__ tp1lo, const float* __restrict__ tp1hi, const float* __restrict__ thr,
                                                            const float* __restrict__ nrm, int64_t ntiles, int Kc, int G, int32_t* __restrict__ elist,
-                                                           uint32_t* __restrict__ emask, int32_t* __restrict__ ecount, int64_t ecap,
+                                                           int32_t* __restrict__ ecount, int64_t ecap,
                                                            unsigned long long* __restrict__ total) {
     __shared__ unsigned long long wm[BW][BW];
     __shared__ int wcnt[BW];
@@ -1210,7 +1205,6 @@ __global__ void __launch_bounds__(64 * BW) k_knn_tilelists(const float* __restri
         q1hi[u] = tp1hi[s0 + u];
     }
     int32_t* lst = elist + blk * ecap;
-    uint32_t* lmk = emask + blk * ecap;
     int count = 0;
     unsigned long long screened = 0;
     for (int64_t base = 0; base < ntiles; base += 64 * BW) {
@@ -1250,8 +1244,7 @@ __global__ void __launch_bounds__(64 * BW) k_knn_tilelists(const float* __restri
         if (mask != 0u) {
             const int64_t t = base + 64 * wave + lane;
             const int slot = count + before + __popcll(anyb & ((1ull << lane) - 1ull));
-            lst[slot] = (int32_t)t;
-            lmk[slot] = mask;
+            lst[slot] = (int32_t)((uint32_t)t | mask << 24);
             screened += (unsigned long long)__popc(mask);
         }
         if (mask != 0u) atomicMax(&s_last, (int)(base + 64 * wave + lane));      // the padding repeats the last listed tile
@@ -1260,7 +1253,7 @@ __global__ void __launch_bounds__(64 * BW) k_knn_tilelists(const float* __restri
     }
     const int lt_all = s_last;
     const int padded = (count + G - 1) / G * G;
-    if (tid < padded - count) { lst[count + tid] = lt_all; lmk[count + tid] = 0; }
+    if (tid < padded - count) lst[count + tid] = lt_all;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) screened += __shfl_xor(screened, o, 64);
     if (lane == 0) atomicAdd(total, screened);                       // statistics only (bench.py's flop count)
@@ -1312,7 +1305,7 @@ __global__ void __launch_bounds__(1024) k_cells_neighbours(const float* __restri
     if (c == 0) ncount[A] = cum[Kc] < budget ? cum[Kc] : budget;
 }
 
-// Sample of every bound block (128 queries = 8 tiles, which may lie in two cells): the tiles of its own cell(s) around it
+// Sample of every bound block (kBoundWaves x 32 queries, which may lie in two or three cells): the tiles of its own cell(s) around it
 // (a cell is in first-component order), then the tiles of the cells nearest to its first and to its last cell, taken in turn,
 // nsamp tiles in all where there are that many.  No tile may be listed twice (the k-th smallest of a multiset is not a
 // bound): a bitmap over the tiles in LDS (dynamic, ceil(ntiles / 32) words) keeps track.
@@ -1322,8 +1315,8 @@ __global__ void __launch_bounds__(64) k_knn_boundlists(const int32_t* __restrict
     extern __shared__ unsigned seen[];
     const int64_t b = blockIdx.x;
     const int lane = threadIdx.x;
-    const int t_blk = (int)(b * 4 * kBoundRT);
-    const int t_end = min(t_blk + 4 * kBoundRT, ntr);              // real tiles of the block
+    const int t_blk = (int)(b * kBoundWaves * kBoundRT);
+    const int t_end = min(t_blk + kBoundWaves * kBoundRT, ntr);              // real tiles of the block
     for (int i = lane; i < (ntr + 31) / 32; i += 64) seen[i] = 0u;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -1457,9 +1450,9 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
     if (Kc > 1024) Kc = 1024;
     if ((int64_t)Kc > M) Kc = (int)std::max<int64_t>(1, M);
     int BW = ctx->opt.knn_emit_waves;                            // waves per emit block (they share the staged tiles)
-    if (BW != 4 && BW != 8 && BW != 16) BW = kEmitWaves;
+    if (BW != 4 && BW != 8) BW = kEmitWaves;                      // (a list entry carries 8 wave bits)
     const int64_t emit_blocks = Mp / (BW * 16 * kEmitRT);
-    const int64_t bound_blocks = Mp / (4 * 16 * kBoundRT);
+    const int64_t bound_blocks = Mp / (kBoundWaves * 16 * kBoundRT);
     const int xcd_chunk = ctx->opt.knn_xcd_chunk;                                  // 0: workgroups in launch order
     const bool fold = ctx->opt.knn_fold && C <= 30;                                // threshold folded into the operands (k_knn_fold)
     // sample of the bound pass: grows with the point count (1/16 of the tiles, at least 512) -- a fixed-size subset would hold
@@ -1502,7 +1495,7 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
     const size_t o_Slo = carve(sizeof(float) * (size_t)ntiles * Kc), o_Shi = carve(sizeof(float) * (size_t)ntiles * Kc);
     const size_t o_Stlo = carve(sizeof(float) * (size_t)ntiles * Kc), o_Sthi = carve(sizeof(float) * (size_t)ntiles * Kc);
     const size_t o_blist = carve(sizeof(int32_t) * (size_t)bound_blocks * nsamp), o_bcount = carve(sizeof(int32_t) * (size_t)bound_blocks);
-    const size_t o_elist = carve(sizeof(int32_t) * (size_t)emit_blocks * ecap), o_emask = carve(sizeof(uint32_t) * (size_t)emit_blocks * ecap);
+    const size_t o_elist = carve(sizeof(int32_t) * (size_t)emit_blocks * ecap);
     const size_t o_ecount = carve(sizeof(int32_t) * (size_t)emit_blocks);
     const size_t o_ovq = carve(sizeof(int32_t) * (size_t)Mp), o_ovb = carve(sizeof(double) * (size_t)Mp);
     DDX_TRY(ensure(ctx, ctx->knn_cells, cw));
@@ -1532,7 +1525,6 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
     int32_t* blist = reinterpret_cast<int32_t*>(cb + o_blist);
     int32_t* bcount = reinterpret_cast<int32_t*>(cb + o_bcount);
     int32_t* elist = reinterpret_cast<int32_t*>(cb + o_elist);
-    uint32_t* emask = reinterpret_cast<uint32_t*>(cb + o_emask);
     int32_t* ecount = reinterpret_cast<int32_t*>(cb + o_ecount);
     int32_t* ovf_q = reinterpret_cast<int32_t*>(cb + o_ovq);
     double* ovf_bound = reinterpret_cast<double*>(cb + o_ovb);
@@ -1595,7 +1587,7 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
         ScopedTimer t(ctx, "knn_bound");
         const unsigned grid = (unsigned)(xcd_chunk > 0 ? ceil_div(bound_blocks, 8 * (int64_t)xcd_chunk) * 8 * xcd_chunk : bound_blocks);
         for (int g = 0; g < groups; ++g) {
-#define DDX_BOUND(CPV, KEEP) k_knn_bound_bf<CPV, KEEP><<<grid, 256, 0, ctx->stream>>>(Eb, nrm, Mp, k_bound, include_self, blist, bcount, nsamp, groups, g, g > 0, thr, xcd_chunk)
+#define DDX_BOUND(CPV, KEEP) k_knn_bound_bf<CPV, KEEP><<<grid, 64 * kBoundWaves, 0, ctx->stream>>>(Eb, nrm, Mp, k_bound, include_self, blist, bcount, nsamp, groups, g, g > 0, thr, xcd_chunk)
             if (CP == 32 && keep_small) DDX_BOUND(32, kBoundKeepSmall);
             else if (CP == 32) DDX_BOUND(32, kBoundKeepLarge);
             else if (CP == 64 && keep_small) DDX_BOUND(64, kBoundKeepSmall);
@@ -1609,9 +1601,8 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
     {
         ScopedTimer t(ctx, "knn_lists");
         const unsigned grid = (unsigned)emit_blocks;
-#define DDX_LISTS(BWV) k_knn_tilelists<BWV><<<grid, 64 * BWV, 0, ctx->stream>>>(S_lo, S_hi, St_lo, St_hi, tilecell, t1lo, t1hi, thr, nrm, ntiles, Kc, G, elist, emask, ecount, ecap, wtotal)
-        if (BW == 16) DDX_LISTS(16);
-        else if (BW == 8) DDX_LISTS(8);
+#define DDX_LISTS(BWV) k_knn_tilelists<BWV><<<grid, 64 * BWV, 0, ctx->stream>>>(S_lo, S_hi, St_lo, St_hi, tilecell, t1lo, t1hi, thr, nrm, ntiles, Kc, G, elist, ecount, ecap, wtotal)
+        if (BW == 8) DDX_LISTS(8);
         else DDX_LISTS(4);
 #undef DDX_LISTS
     }
@@ -1621,11 +1612,10 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
         const int nseg = (int)(ceil_div(ceil_div(ecap, G), (int64_t)seg_steps * 8) * 8);     // segments of the longest possible list, a multiple of 8
         const unsigned grid_x = (unsigned)(emit_blocks * nseg);
         const int dbg_mode = ctx->opt.knn_ablation;     // timing ablations (wrong results): non-zero only in -DDDX_ABLATION builds
-#define DDX_EMIT_ONE(CPV, FOLDV, QUERY, BWV) k_knn_emit_bf<CPV, FOLDV, BWV><<<grid_x, 64 * BWV, 0, ctx->stream>>>(Eb, QUERY, nrm, start4, thr, Mp, include_self, ccount, cbuf, elist, emask, ecount, ecap, dbg_mode, cap, nseg, seg_steps)
+#define DDX_EMIT_ONE(CPV, FOLDV, QUERY, BWV) k_knn_emit_bf<CPV, FOLDV, BWV><<<grid_x, 64 * BWV, 0, ctx->stream>>>(Eb, QUERY, nrm, start4, thr, Mp, include_self, ccount, cbuf, elist, ecount, ecap, dbg_mode, cap, nseg, seg_steps)
 #define DDX_EMIT_BF(CPV, FOLDV, QUERY)                          \
     do {                                                        \
-        if (BW == 16) DDX_EMIT_ONE(CPV, FOLDV, QUERY, 16);      \
-        else if (BW == 8) DDX_EMIT_ONE(CPV, FOLDV, QUERY, 8);   \
+        if (BW == 8) DDX_EMIT_ONE(CPV, FOLDV, QUERY, 8);        \
         else DDX_EMIT_ONE(CPV, FOLDV, QUERY, 4);                \
     } while (0)
         if (fold) {
@@ -1653,7 +1643,7 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
 #define DDX_RESCAN(CPV)                                                                                                                       \
     do {                                                                                                                                      \
         DDX_TRY(allow_dynamic_lds(ctx, reinterpret_cast<const void*>(&k_knn_rescan<CPV>), (int)rs_lds));                                      \
-        k_knn_rescan<CPV><<<512, 64 * kRescanWaves, rs_lds, ctx->stream>>>(E, perm, M, k, include_self, ccount + Mp, ovf_q, ovf_bound, elist, emask, ecount, ecap, BW, ki, kd); \
+        k_knn_rescan<CPV><<<128, 64 * kRescanWaves, rs_lds, ctx->stream>>>(E, perm, M, k, include_self, ccount + Mp, ovf_q, ovf_bound, elist, ecount, ecap, BW, ki, kd); \
     } while (0)
         if (CP == 32) { DDX_SELECT_LAUNCH(32); DDX_RESCAN(32); }
         else if (CP == 64) { DDX_SELECT_LAUNCH(64); DDX_RESCAN(64); }
@@ -1691,13 +1681,13 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
     if (ctx->opt.knn_debug) {
         // how the work is spread: tiles screened per wave, and how far single queries' bounds stand out in their tile
         std::vector<int32_t> he(emit_blocks);
-        std::vector<uint32_t> hm((size_t)emit_blocks * ecap);
+        std::vector<int32_t> hm((size_t)emit_blocks * ecap);
         DDX_HIP(ctx, hipMemcpy(he.data(), ecount, sizeof(int32_t) * emit_blocks, hipMemcpyDeviceToHost));
-        DDX_HIP(ctx, hipMemcpy(hm.data(), emask, sizeof(uint32_t) * hm.size(), hipMemcpyDeviceToHost));
+        DDX_HIP(ctx, hipMemcpy(hm.data(), elist, sizeof(int32_t) * hm.size(), hipMemcpyDeviceToHost));
         std::vector<int> per_wave;
         for (int64_t b = 0; b < emit_blocks; ++b) {
             std::vector<int> c(BW, 0);
-            for (int i = 0; i < he[b]; ++i) for (int w = 0; w < BW; ++w) c[w] += (hm[b * ecap + i] >> w) & 1u;
+            for (int i = 0; i < he[b]; ++i) for (int w = 0; w < BW; ++w) c[w] += (((unsigned)hm[b * ecap + i] >> 24) >> w) & 1u;
             for (int w = 0; w < BW; ++w) per_wave.push_back(c[w]);
         }
         std::sort(per_wave.begin(), per_wave.end());

@@ -71,7 +71,7 @@ int ddx_synchronize(ddx_ctx* ctx);
  *   knn_sample_tiles  n                 tiles in the bound pass's sample (0 = by size)
  *   knn_sample_every  n                 the sample holds every n-th tile of the whole set (0 = none; default 32)
  *   knn_seg_steps     n                 steps of a block's tile list per emit work item (0 = default)
- *   knn_emit_waves    4 | 8 | 16        waves per emit workgroup (0 = default)
+ *   knn_emit_waves    4 | 8             waves per emit workgroup (0 = default)
  *   knn_fold          1 | 0             threshold folded into the screen's operands
  *   knn_xcd_chunk     n                 consecutive query blocks of the bound pass per XCD (0 = launch order)
  *   knn_debug         0 | 1             statistics of the kNN passes on stderr
