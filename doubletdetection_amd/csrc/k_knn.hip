@@ -608,6 +608,28 @@ __device__ __forceinline__ void wave_sort_regs(double (&d)[R], int32_t (&ix)[R],
     }
 }
 
+// bitonic sort of an LDS window of P <= 512 entries through registers (wave_sort_regs: no strided LDS pair accesses); larger
+// windows fall back to the in-LDS network
+__device__ __forceinline__ void wave_sort_window(double* d, int32_t* ix, int P, int lane) {
+    auto via_regs = [&](auto rtag) {
+        constexpr int R = decltype(rtag)::value;
+        double dr[R];
+        int32_t ir[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) { dr[r] = d[r * 64 + lane]; ir[r] = ix[r * 64 + lane]; }
+        wave_sort_regs<R>(dr, ir, lane);
+#pragma unroll
+        for (int r = 0; r < R; ++r) { d[r * 64 + lane] = dr[r]; ix[r * 64 + lane] = ir[r]; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    if (P == 64) via_regs(std::integral_constant<int, 1>());
+    else if (P == 128) via_regs(std::integral_constant<int, 2>());
+    else if (P == 256) via_regs(std::integral_constant<int, 4>());
+    else if (P == 512) via_regs(std::integral_constant<int, 8>());
+    else wave_sort(d, ix, P, lane);
+}
+
 // one wave per query (WAVES per block, no block-level synchronisation).  The instances share the work by list length: an
 // instance takes the queries with lo < min(length, cap) <= hi (SELMAX = kSelSmall: nearly all; kSelMax: the few longer or
 // overflowed ones; kSelHuge: lists beyond 1024 entries, which only occur with the large cap of k > 80).
@@ -699,48 +721,76 @@ __global__ void __launch_bounds__(64 * WAVES) k_knn_select(const float* __restri
 // a share of the tiles and keeps the points within the bound in its own LDS window (a full window is sorted, cut to the K
 // best and its K-th distance becomes the wave's bound); the K nearest are among the waves' K best, which wave 0 merges.
 // Same arithmetic and tie rule as the select pass.
-constexpr int kRescanWaves = 16, kRescanWin = 512;
+constexpr int kCellDim = 32;                 // leading components the cells live in (zero padded)
+constexpr int kRescanWaves = 16, kRescanWin = 512, kRescanChunk = 1024;
 template <int CP>
 __global__ void __launch_bounds__(64 * kRescanWaves) k_knn_rescan(const float* __restrict__ E, const int32_t* __restrict__ perm, int64_t M, int K, int include_self,
                                                                   const int32_t* __restrict__ n_overflow, const int32_t* __restrict__ ovf_q,
                                                                   const double* __restrict__ ovf_bound, const int32_t* __restrict__ elist,
                                                                   const int32_t* __restrict__ ecount, int64_t ecap, int BW,
-                                                                  int32_t* __restrict__ idx_out, double* __restrict__ dist_out) {
+                                                                  const int32_t* __restrict__ tilecell, const float* __restrict__ cenR, const float* __restrict__ invD,
+                                                                  int Kc, int64_t ntiles, const unsigned* __restrict__ r2max, const float* __restrict__ St_lo,
+                                                                  const float* __restrict__ St_hi, const float* __restrict__ tr_lo, const float* __restrict__ tr_hi,
+                                                                  int32_t* __restrict__ idx_out, double* __restrict__ dist_out, long long* __restrict__ dbg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rs_smem[];
     double* sd = reinterpret_cast<double*>(rs_smem);                                        // [waves][win] + merge [waves * 256]
     int32_t* si = reinterpret_cast<int32_t*>(sd + kRescanWaves * kRescanWin + kRescanWaves * 256);
     float* sq = reinterpret_cast<float*>(si + kRescanWaves * kRescanWin + kRescanWaves * 256);   // [CP] query row
     __shared__ int s_fill[kRescanWaves];
+    __shared__ int32_t s_tiles[kRescanChunk];
+    __shared__ int s_ntile, s_kept;
+    __shared__ float s_dq[1024], s_pq[1024];                    // the query against every cell centre: distance, dot product
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = *n_overflow;
     for (int it = blockIdx.x; it < n; it += gridDim.x) {
         const int64_t q = ovf_q[it];
+        if (dbg && it < 4096 && threadIdx.x == 0) dbg[it * 8 + 0] = wall_clock64();
         for (int t = threadIdx.x; t < CP; t += blockDim.x) sq[t] = E[q * CP + t];
         __syncthreads();
         double* d = sd + wave * kRescanWin;
         int32_t* ix = si + wave * kRescanWin;
         double bound = ovf_bound[it];
         int fill = 0;
+        // The bound is tighter than the T_q the lists were made for, and the query is one point, not a tile of 16: the cell
+        // tests are worth repeating.  Against a tile of cell B (centre mu_B) a point within r of the query lies (a) at a distance
+        // from mu_B within r of the query's, (b) along (mu_B - mu_A) / |mu_B - mu_A| within r of the query's projection.  The
+        // tile's intervals are tr_lo / tr_hi (k_knn_slabs) and St_lo / St_hi; the query's side is computed here with the
+        // margins of k_knn_slabs.  (a) is the one that tells for the usual customer, a query far from every centre.
+        for (int c = threadIdx.x; c < Kc; c += blockDim.x) {
+            const float* mu = cenR + (size_t)c * kCellDim;
+            float pq = 0.f, dq = 0.f;
+#pragma unroll
+            for (int t = 0; t < kCellDim; ++t) {
+                pq = fmaf(mu[t], sq[t], pq);
+                const float v = sq[t] - mu[t];
+                dq = fmaf(v, v, dq);
+            }
+            s_pq[c] = pq;
+            s_dq[c] = sqrtf(dq);
+        }
+        if (threadIdx.x == 0) s_kept = 0;
+        __syncthreads();
+        const int cellA = tilecell[q >> 4];
+        const float pA = s_pq[cellA];
+        const float R2 = __uint_as_float(*r2max) * 1.01f;
+        const float reach = (float)(sqrt(bound) * 1.00002) + 1e-30f;
+        const float* iDrow = invD + (size_t)cellA * Kc;
+        const float* stl = St_lo + (size_t)cellA * ntiles;
+        const float* sth = St_hi + (size_t)cellA * ntiles;
         const int64_t blk = q / (BW * 16 * kEmitRT);
         const int qwave = (int)((q / (16 * kEmitRT)) % BW);
         const int32_t* lst = elist + blk * ecap;
         const int nent = ecount[blk];
-        for (int e0 = wave * 4; e0 < nent; e0 += 4 * kRescanWaves) {            // four tiles per wave and step
-            const int e = e0 + (lane >> 4);
-            int64_t c = -1;
-            if (e < nent && ((((unsigned)lst[e] >> 24) >> qwave) & 1u)) c = (int64_t)(lst[e] & 0xffffff) * 16 + (lane & 15);
-            double dv = __builtin_huge_val();
-            bool keep = false;
-            if (c >= 0 && c < M && (include_self || c != q)) {
-                dv = exact_d2<CP>(sq, E + c * CP);
-                keep = dv <= bound;
-            }
+        // The list is taken in chunks: the whole workgroup reads a chunk's entries (one coalesced load), keeps the tiles of the
+        // query's wave packed in LDS, and the waves then go over those -- eight tiles (two points per lane) per wave and step,
+        // so that the only dependent global loads of a step are the points' rows, two of them in flight per lane.
+        auto push = [&](bool keep, double dv, int64_t c) {
             unsigned long long m = __ballot(keep);
             if (fill + __popcll(m) > kRescanWin) {       // sort, keep the K best, tighten the bound
                 for (int t = fill + lane; t < kRescanWin; t += 64) { d[t] = __builtin_huge_val(); ix[t] = 0x7fffffff; }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                wave_sort(d, ix, kRescanWin, lane);
+                wave_sort_window(d, ix, kRescanWin, lane);
                 fill = K;
                 bound = d[K - 1];
                 keep = keep && dv <= bound;
@@ -752,15 +802,79 @@ __global__ void __launch_bounds__(64 * kRescanWaves) k_knn_rescan(const float* _
                 ix[pos] = perm[c];
             }
             fill += __popcll(m);
+        };
+        for (int base = 0; base < nent; base += kRescanChunk) {
+            if (threadIdx.x == 0) s_ntile = 0;
+            __syncthreads();
+            for (int j = threadIdx.x; j < kRescanChunk; j += 64 * kRescanWaves) {
+                const int e = base + j;
+                bool on = false;
+                int32_t tile = 0;
+                if (e < nent) {
+                    const unsigned v = (unsigned)lst[e];
+                    on = ((v >> 24) >> qwave) & 1u;
+                    tile = (int32_t)(v & 0xffffffu);
+                    if (on) {
+                        const int B = tilecell[tile];
+                        const float dq = s_dq[B];
+                        const float ga = fmaxf(dq * (1.f - 1e-5f) - tr_hi[tile] * (1.f + 1e-5f), tr_lo[tile] * (1.f - 1e-5f) - dq * (1.f + 1e-5f));
+                        const float iD = iDrow[B];
+                        const float f = (s_pq[B] - pA) * iD;
+                        const float mg = 6e-6f * R2 * iD + 3e-7f * fabsf(f);
+                        const float gb = fmaxf(f - mg + stl[tile], -sth[tile] - f - mg);
+                        on = !(fmaxf(ga, gb) > reach);
+                    }
+                }
+                const unsigned long long m = __ballot(on);
+                int wbase = 0;
+                if (lane == 0 && m) { wbase = atomicAdd(&s_ntile, __popcll(m)); if (dbg) atomicAdd(&s_kept, __popcll(m)); }
+                wbase = __builtin_amdgcn_readfirstlane(wbase);
+                if (on) s_tiles[wbase + __popcll(m & ((1ull << lane) - 1ull))] = tile;
+            }
+            __syncthreads();
+            const int nt = s_ntile;
+            for (int t0 = wave * 8; t0 < nt; t0 += 8 * kRescanWaves) {
+                const int ta = t0 + (lane >> 4), tb = ta + 4;
+                int64_t ca = -1, cb = -1;
+                if (ta < nt) ca = (int64_t)s_tiles[ta] * 16 + (lane & 15);
+                if (tb < nt) cb = (int64_t)s_tiles[tb] * 16 + (lane & 15);
+                const bool oka = ca >= 0 && ca < M && (include_self || ca != q);
+                const bool okb = cb >= 0 && cb < M && (include_self || cb != q);
+                // float32 first: a sum of rounded squares is within 34 * 2^-24 = 2e-6 of the float64 one, relatively, so anything
+                // beyond the bound by more than 1e-5 cannot pass the exact test -- which most points then never reach
+                const float* ra = E + (oka ? ca : 0) * CP;
+                const float* rb = E + (okb ? cb : 0) * CP;
+                float fa = 0.f, fb = 0.f;
+#pragma unroll
+                for (int t = 0; t < CP; t += 4) {
+                    const f4 x = *reinterpret_cast<const f4*>(sq + t);
+                    const f4 ya = *reinterpret_cast<const f4*>(ra + t);
+                    const f4 yb = *reinterpret_cast<const f4*>(rb + t);
+                    const f4 da = x - ya, db = x - yb;
+                    fa = fmaf(da.x, da.x, fa); fa = fmaf(da.y, da.y, fa); fa = fmaf(da.z, da.z, fa); fa = fmaf(da.w, da.w, fa);
+                    fb = fmaf(db.x, db.x, fb); fb = fmaf(db.y, db.y, fb); fb = fmaf(db.z, db.z, fb); fb = fmaf(db.w, db.w, fb);
+                }
+                const double lim = bound * 1.00001 + 1e-30;
+                double dva = __builtin_huge_val(), dvb = __builtin_huge_val();
+                bool ka = false, kb = false;
+                if (oka && (double)fa <= lim) { dva = exact_d2<CP>(sq, ra); ka = dva <= bound; }
+                if (okb && (double)fb <= lim) { dvb = exact_d2<CP>(sq, rb); kb = dvb <= bound; }
+                push(ka, dva, ca);
+                kb = kb && dvb <= bound;
+                push(kb, dvb, cb);
+            }
+            __syncthreads();
         }
+        if (dbg && it < 4096 && threadIdx.x == 0) { dbg[it * 8 + 1] = wall_clock64(); dbg[it * 8 + 4] = nent; dbg[it * 8 + 5] = s_kept; }
         int P = 64;
         while (P < fill) P <<= 1;
         for (int t = fill + lane; t < P; t += 64) { d[t] = __builtin_huge_val(); ix[t] = 0x7fffffff; }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        wave_sort(d, ix, P, lane);
+        wave_sort_window(d, ix, P, lane);
         if (lane == 0) s_fill[wave] = fill < K ? fill : K;
         __syncthreads();
+        if (dbg && it < 4096 && threadIdx.x == 0) dbg[it * 8 + 2] = wall_clock64();
         if (wave == 0) {
             double* md = sd + kRescanWaves * kRescanWin;
             int32_t* mi = si + kRescanWaves * kRescanWin;
@@ -775,7 +889,7 @@ __global__ void __launch_bounds__(64 * kRescanWaves) k_knn_rescan(const float* _
             for (int t = total + lane; t < PM; t += 64) { md[t] = __builtin_huge_val(); mi[t] = 0x7fffffff; }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            wave_sort(md, mi, PM, lane);
+            wave_sort_window(md, mi, PM, lane);
             const int kept = total < K ? total : K;
             const int64_t qo = perm[q];
             for (int t = lane; t < K; t += 64) {
@@ -785,6 +899,7 @@ __global__ void __launch_bounds__(64 * kRescanWaves) k_knn_rescan(const float* _
             }
         }
         __syncthreads();
+        if (dbg && it < 4096 && threadIdx.x == 0) { dbg[it * 8 + 3] = wall_clock64(); dbg[it * 8 + 6] = blockIdx.x; }
     }
 }
 
@@ -933,7 +1048,6 @@ int stage_knn_metric(ddx_ctx* ctx, int32_t k, int32_t include_self, int32_t metr
 // (profiles/r04_knn_prune_study.txt).  The test along the first component itself is kept beside it (it separates tiles
 // of one cell).  None of this can change the result: the screen stays conservative whatever the cells look like.
 // ------------------------------------------------------------------------------------------------
-constexpr int kCellDim = 32;                 // leading components the cells live in (zero padded)
 constexpr float kCellFix = 1048576.0f;       // fixed-point grid of the centre sums (2^20): integer sums are exact in any order
 constexpr int kCellRounds = 2;               // Lloyd rounds (on every kCellSub-th point of the first-component order) before the assignment
 constexpr int kCellSub = 4;
@@ -1099,7 +1213,7 @@ __global__ void k_knn_tileinfo(const uint32_t* __restrict__ cellpos, const float
 __global__ void __launch_bounds__(256) k_knn_slabs(const float* __restrict__ E, int CP, const float* __restrict__ nrm, const int32_t* __restrict__ tilecell,
                                                    const float* __restrict__ cenR, const float* __restrict__ invD, int Kc, int64_t ntiles,
                                                    const unsigned* __restrict__ r2max, float* __restrict__ S_lo, float* __restrict__ S_hi,
-                                                   float* __restrict__ St_lo, float* __restrict__ St_hi) {
+                                                   float* __restrict__ St_lo, float* __restrict__ St_hi, float* __restrict__ tr_lo, float* __restrict__ tr_hi) {
     __shared__ float slo[16][65], shi[16][65];
     const int tid = threadIdx.x, lane = tid & 63;
     const int64_t r = (int64_t)blockIdx.x * 256 + tid;
@@ -1113,8 +1227,23 @@ __global__ void __launch_bounds__(256) k_knn_slabs(const float* __restrict__ E, 
     float pO = 0.f;
     {
         const float* mu = cenR + (size_t)O * kCellDim;
+        float dO = 0.f;
 #pragma unroll
-        for (int d = 0; d < kCellDim; ++d) pO = fmaf(mu[d], x[d], pO);
+        for (int d = 0; d < kCellDim; ++d) {
+            pO = fmaf(mu[d], x[d], pO);
+            const float v = x[d] - mu[d];
+            dO = fmaf(v, v, dO);
+        }
+        // distance from the tile's own centre (first kCellDim components: a projection, so never more than the full distance);
+        // a sum of 32 rounded squares of rounded differences is within 5e-6 of the true one, relatively: the users widen by 1e-5
+        dO = sqrtf(dO);
+        float lo = pad ? __builtin_huge_valf() : dO, hi = pad ? -__builtin_huge_valf() : dO;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+            lo = fminf(lo, __shfl_xor(lo, o, 64));
+            hi = fmaxf(hi, __shfl_xor(hi, o, 64));
+        }
+        if ((lane & 15) == 0 && tile < ntiles) { tr_lo[tile] = lo; tr_hi[tile] = hi; }
     }
     const float R2 = __uint_as_float(*r2max) * 1.01f;
     const float* iDrow = invD + (size_t)O * Kc;
@@ -1492,6 +1621,7 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
     const size_t o_rank = carve(sizeof(int32_t) * (size_t)Kc), o_invD = carve(sizeof(float) * (size_t)Kc * Kc);
     const size_t o_ctile = carve(sizeof(int32_t) * ((size_t)Kc + 1)), o_ncount = carve(sizeof(int32_t) * (size_t)Kc), o_nlist = carve(sizeof(int32_t) * (size_t)Kc * nsamp);
     const size_t o_tilecell = carve(sizeof(int32_t) * (size_t)ntiles), o_t1lo = carve(sizeof(float) * (size_t)ntiles), o_t1hi = carve(sizeof(float) * (size_t)ntiles);
+    const size_t o_trlo = carve(sizeof(float) * (size_t)ntiles), o_trhi = carve(sizeof(float) * (size_t)ntiles);
     const size_t o_Slo = carve(sizeof(float) * (size_t)ntiles * Kc), o_Shi = carve(sizeof(float) * (size_t)ntiles * Kc);
     const size_t o_Stlo = carve(sizeof(float) * (size_t)ntiles * Kc), o_Sthi = carve(sizeof(float) * (size_t)ntiles * Kc);
     const size_t o_blist = carve(sizeof(int32_t) * (size_t)bound_blocks * nsamp), o_bcount = carve(sizeof(int32_t) * (size_t)bound_blocks);
@@ -1518,6 +1648,8 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
     int32_t* tilecell = reinterpret_cast<int32_t*>(cb + o_tilecell);
     float* t1lo = reinterpret_cast<float*>(cb + o_t1lo);
     float* t1hi = reinterpret_cast<float*>(cb + o_t1hi);
+    float* tr_lo = reinterpret_cast<float*>(cb + o_trlo);
+    float* tr_hi = reinterpret_cast<float*>(cb + o_trhi);
     float* S_lo = reinterpret_cast<float*>(cb + o_Slo);
     float* S_hi = reinterpret_cast<float*>(cb + o_Shi);
     float* St_lo = reinterpret_cast<float*>(cb + o_Stlo);
@@ -1580,7 +1712,7 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
         k_cells_tilestart<<<(unsigned)ceil_div(Kc + 1, 256), 256, 0, ctx->stream>>>(tilecell, ntr, Kc, ctile);
         if (Kc > 1) k_cells_neighbours<<<(unsigned)Kc, 1024, 0, ctx->stream>>>(cenR, ctile, Kc, (int)nsamp, nlist, ncount);
         k_knn_boundlists<<<(unsigned)bound_blocks, 64, sizeof(unsigned) * (size_t)((ntr + 31) / 32 + 1), ctx->stream>>>(tilecell, ctile, nlist, ncount, Kc, (int)nsamp, (int)nsamp, ntr, ctx->opt.knn_sample_every, blist, bcount);
-        k_knn_slabs<<<(unsigned)(Mp / 256), 256, 0, ctx->stream>>>(E, CP, nrm, tilecell, cenR, invD, Kc, ntiles, r2max, S_lo, S_hi, St_lo, St_hi);
+        k_knn_slabs<<<(unsigned)(Mp / 256), 256, 0, ctx->stream>>>(E, CP, nrm, tilecell, cenR, invD, Kc, ntiles, r2max, S_lo, S_hi, St_lo, St_hi, tr_lo, tr_hi);
     }
     DDX_HIP(ctx, hipMemsetAsync(ccount, 0, sizeof(int32_t) * (Mp + 64), ctx->stream));
     {
@@ -1643,13 +1775,26 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
 #define DDX_RESCAN(CPV)                                                                                                                       \
     do {                                                                                                                                      \
         DDX_TRY(allow_dynamic_lds(ctx, reinterpret_cast<const void*>(&k_knn_rescan<CPV>), (int)rs_lds));                                      \
-        k_knn_rescan<CPV><<<128, 64 * kRescanWaves, rs_lds, ctx->stream>>>(E, perm, M, k, include_self, ccount + Mp, ovf_q, ovf_bound, elist, ecount, ecap, BW, ki, kd); \
+        k_knn_rescan<CPV><<<128, 64 * kRescanWaves, rs_lds, ctx->stream>>>(E, perm, M, k, include_self, ccount + Mp, ovf_q, ovf_bound, elist, ecount, ecap, BW, tilecell, cenR, invD, Kc, ntiles, r2max, St_lo, St_hi, tr_lo, tr_hi, ki, kd, rdbg); \
     } while (0)
+        long long* rdbg = nullptr;
+        if (ctx->opt.knn_debug) { DDX_HIP(ctx, hipMalloc(&rdbg, sizeof(long long) * 8 * 4096)); DDX_HIP(ctx, hipMemsetAsync(rdbg, 0, sizeof(long long) * 8 * 4096, ctx->stream)); }
         if (CP == 32) { DDX_SELECT_LAUNCH(32); DDX_RESCAN(32); }
         else if (CP == 64) { DDX_SELECT_LAUNCH(64); DDX_RESCAN(64); }
         else { DDX_SELECT_LAUNCH(128); DDX_RESCAN(128); }
 #undef DDX_RESCAN
 #undef DDX_SELECT_LAUNCH
+        if (rdbg) {
+            std::vector<long long> hd(8 * 4096);
+            DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            DDX_HIP(ctx, hipMemcpy(hd.data(), rdbg, sizeof(long long) * hd.size(), hipMemcpyDeviceToHost));
+            DDX_HIP(ctx, hipFree(rdbg));
+            long long t0 = 0;
+            for (int i = 0; i < 4096; ++i) if (hd[i * 8] && (!t0 || hd[i * 8] < t0)) t0 = hd[i * 8];
+            for (int i = 0; i < 4096 && hd[i * 8]; ++i)
+                fprintf(stderr, "[knn rescan] query %d block %lld: start %.1f us, scan %.1f, sorts %.1f, merge %.1f; list %lld entries, %lld tiles scanned\n", i, hd[i * 8 + 6],
+                        (hd[i * 8] - t0) * 0.01, (hd[i * 8 + 1] - hd[i * 8]) * 0.01, (hd[i * 8 + 2] - hd[i * 8 + 1]) * 0.01, (hd[i * 8 + 3] - hd[i * 8 + 2]) * 0.01, hd[i * 8 + 4], hd[i * 8 + 5]);
+        }
     }
     DDX_HIP(ctx, hipGetLastError());
     if (ctx->opt.knn_debug) {
