@@ -262,6 +262,10 @@ __global__ void __launch_bounds__(64 * kBoundWaves) k_knn_bound_bf(const __bf16*
     for (int v = 0; v < NV; ++v)
 #pragma unroll
         for (int t = 0; t < kBoundKeep; ++t) best[v][t] = __builtin_huge_valf();
+    float tau[NV];                                  // see the shortcut in the loop: -inf lets everything through while a list is not full
+#pragma unroll
+    for (int v = 0; v < NV; ++v) tau[v] = nq[v] < __builtin_huge_valf() ? -__builtin_huge_valf() : __builtin_huge_valf();     // (padding queries: nothing ever passes)
+    constexpr float kHalfOnePlusSlack = 0.5f * (1.f + kScreenSlackBf);
     const int64_t own_tile = q0 >> 4;
     const int32_t* lst = blist + blk * bcap;
     const int n_all = bcount[blk];
@@ -290,6 +294,18 @@ __global__ void __launch_bounds__(64 * kBoundWaves) k_knn_bound_bf(const __bf16*
                 f4 acc[RT];
                 qt.dots(lds_c[buf] + t * tile_vecs, lane, acc);
                 const bool own = !include_self && (tile >= own_tile && tile < own_tile + RT);
+                // Most tiles change nothing once the lists have filled: ub < best  <=>  dot - tau > c with tau = ((1 + slack) |q|^2 -
+                // best) / 2 per query and c = (1 + slack) |c|^2 / 2 per candidate -- one subtraction per pair, a maximum tree and one
+                // compare per lane; only when some lane of the wave sees a candidate does the wave run the exact test below.  (The
+                // shortcut rounds differently from the test it stands for; letting a borderline candidate go or sending one
+                // through in vain changes a bound by nothing that matters -- any k-th smallest of upper bounds of sample points is
+                // a valid threshold.)
+                {
+                    float m = acc[0].x - tau[0];
+#pragma unroll
+                    for (int v = 1; v < NV; ++v) m = fmaxf(m, acc[v >> 2][v & 3] - tau[v]);
+                    if (!__builtin_amdgcn_readfirstlane((int)(__ballot(m > kHalfOnePlusSlack * nc * (1.f - 4e-7f)) != 0ull))) continue;
+                }
 #pragma unroll
                 for (int v = 0; v < NV; ++v) {
                     const float dot = acc[v >> 2][v & 3];
@@ -304,6 +320,7 @@ __global__ void __launch_bounds__(64 * kBoundWaves) k_knn_bound_bf(const __bf16*
                         best[v][u - 1] = lo;
                         best[v][u] = hi;
                     }
+                    tau[v] = 0.5f * ((1.f + kScreenSlackBf) * nq[v] - best[v][kBoundKeep - 1]);
                 }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the next step has landed before anyone crosses the barrier
