@@ -1711,6 +1711,8 @@ __global__ void __launch_bounds__(256) k_cross_gram_partial(const double* __rest
     extern __shared__ double cg_s[];                  // [2][32][L] row tiles of X and W
     double* xs = cg_s;
     double* ws = cg_s + 32 * L;
+    X += (size_t)blockIdx.y * R * L;                   // batched over the stored blocks (grid.y): block i against the same W
+    partial += (size_t)blockIdx.y * gridDim.x * L * L;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     const int64_t r1 = r0 + rows_per_block < R ? r0 + rows_per_block : R;
     const int npair = L * L;
@@ -1738,6 +1740,50 @@ __global__ void __launch_bounds__(256) k_cross_gram_partial(const double* __rest
         const int t = threadIdx.x + 256 * u;
         if (t < npair) partial[(int64_t)blockIdx.x * npair + t] = acc[u];
     }
+}
+
+// out[i][c] = sum_b partial[i][b][c] (the batched form of k_reduce_partials: grid.y = i)
+__global__ void __launch_bounds__(256) k_reduce_partials_batched(const double* __restrict__ partial, int nblocks, int width, double* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (c >= width) return;
+    const double* p = partial + (size_t)blockIdx.y * nblocks * width;
+    double s = 0.0;
+    for (int b = lane; b < nblocks; b += 64) s += p[(int64_t)b * width + c];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (lane == 0) out[(size_t)blockIdx.y * width + c] = s;
+}
+
+// W -= sum_i V_i G_i over the nblk stored blocks (V_i: R x L at V + i R L, G_i: L x L at G + i L L)
+__global__ void __launch_bounds__(256) k_block_subtract_all(const double* __restrict__ V, const double* __restrict__ G, int64_t R, int L, int nblk,
+                                                            double* __restrict__ W) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= R * L) return;
+    const int64_t r = t / L;
+    const int c = (int)(t - r * L);
+    double a = 0.0;
+    for (int i = 0; i < nblk; ++i) {
+        const double* v = V + ((size_t)i * R + r) * L;
+        const double* g = G + (size_t)i * L * L + c;
+        for (int k = 0; k < L; ++k) a = fma(v[k], g[(size_t)k * L], a);
+    }
+    W[t] -= a;
+}
+
+// out = sum_i V_i Z_i   (same layout as k_block_subtract_all)
+__global__ void __launch_bounds__(256) k_block_combine_all(const double* __restrict__ V, const double* __restrict__ Z, int64_t R, int L, int nblk,
+                                                           double* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= R * L) return;
+    const int64_t r = t / L;
+    const int c = (int)(t - r * L);
+    double a = 0.0;
+    for (int i = 0; i < nblk; ++i) {
+        const double* v = V + ((size_t)i * R + r) * L;
+        const double* z = Z + (size_t)i * L * L + c;
+        for (int k = 0; k < L; ++k) a = fma(v[k], z[(size_t)k * L], a);
+    }
+    out[t] = a;
 }
 
 // W -= V G   (R x L, G: L x L row-major in device memory)
@@ -1788,6 +1834,18 @@ static int cross_gram(PcaWork& w, const double* X, const double* W, int64_t R, d
     return DDX_OK;
 }
 
+// G_i = V_i^T W for the blocks i < nblk at once (device: G_dev[i]; host copy when asked -- asynchronous, the caller synchronises)
+static int cross_gram_all(PcaWork& w, const double* Vall, int nblk, const double* W, int64_t R, double* G_dev, double* G_host) {
+    const int L = w.L;
+    int nb = (int)std::min<int64_t>(256, ceil_div(R, 64));
+    const int64_t rpb = ceil_div(ceil_div(R, nb), 32) * 32;
+    nb = (int)ceil_div(R, rpb);
+    k_cross_gram_partial<<<dim3((unsigned)nb, (unsigned)nblk), 256, sizeof(double) * 64 * L, w.ctx->stream>>>(Vall, W, R, L, rpb, w.partial);
+    k_reduce_partials_batched<<<dim3((unsigned)ceil_div(L * L, 4), (unsigned)nblk), 256, 0, w.ctx->stream>>>(w.partial, nb, L * L, G_dev);
+    if (G_host) DDX_HIP(w.ctx, hipMemcpyAsync(G_host, G_dev, sizeof(double) * (size_t)nblk * L * L, hipMemcpyDeviceToHost, w.ctx->stream));
+    return DDX_OK;
+}
+
 int stage_pca_block_lanczos(ddx_ctx* ctx, int32_t C, int32_t oversample, double tol, int32_t max_steps, const double* q0, int32_t* steps_out,
                             ddx_eigh_fn eigh, void* eigh_user) {
     t_opt = &ctx->opt;
@@ -1801,8 +1859,8 @@ int stage_pca_block_lanczos(ddx_ctx* ctx, int32_t C, int32_t oversample, double 
     if ((int64_t)(max_steps + 1) * L > R) max_steps = (int)std::max<int64_t>(1, R / L - 1);
     DDX_TRY(ensure(ctx, ctx->pcaA, sizeof(double) * 2 * (size_t)M * L));
     DDX_TRY(ensure(ctx, ctx->pcaB, sizeof(double) * 2 * (size_t)H * L));
-    DDX_TRY(ensure(ctx, ctx->pcaSmall, sizeof(double) * (8 * (size_t)L * L + 8 * L) + 256));
-    DDX_TRY(ensure(ctx, ctx->pcaPartial, sizeof(double) * 512 * (size_t)std::max(L * L, 128 * 4)));
+    DDX_TRY(ensure(ctx, ctx->pcaSmall, sizeof(double) * ((8 + (size_t)max_steps + 2) * L * L + 8 * L) + 256));
+    DDX_TRY(ensure(ctx, ctx->pcaPartial, sizeof(double) * 256 * ((size_t)max_steps + 2) * (size_t)std::max(L * L, 128 * 4)));
     DDX_TRY(ensure(ctx, ctx->pcaVec, 256));
     DDX_TRY(ensure(ctx, ctx->pcaPanel, sizeof(double) * (size_t)ceil_div(M, ctx->panel_rows) * H * L));
     DDX_TRY(ensure(ctx, ctx->pcaBlk, sizeof(double) * (size_t)(max_steps + 2) * R * L));
@@ -1832,6 +1890,7 @@ int stage_pca_block_lanczos(ddx_ctx* ctx, int32_t C, int32_t oversample, double 
     DDX_HIP(ctx, hipMemsetAsync(w.flag, 0, sizeof(int), ctx->stream));
     double* dG = w.small + 4 * L * L + 4 * L;          // cross-Gram block (the first 4 L^2 + 4 L belong to cholqr and the products)
     double* dZ = dG + L * L;                           // L x L block of Ritz vectors
+    double* dGall = dZ + 2 * L * L;                    // cross-Gram blocks against every stored block: (max_steps + 1) L^2
     // small side scratch: W (the image of a block), T1 (a second block)
     double* Wb = cols_side ? colA : rowA;
     double* T1 = cols_side ? colB : rowB;
@@ -1846,7 +1905,7 @@ int stage_pca_block_lanczos(ddx_ctx* ctx, int32_t C, int32_t oversample, double 
     DDX_TRY(cholqr(w, Wb, R, T1));
     DDX_TRY(cholqr(w, T1, R, Vblk(0)));
     const int nmax = (max_steps + 1) * L;
-    std::vector<double> T((size_t)nmax * nmax, 0.0), Gh((size_t)L * L), work, theta, Tsub((size_t)L * L);
+    std::vector<double> T((size_t)nmax * nmax, 0.0), Gh((size_t)L * L), Gall, work, theta, Tsub((size_t)L * L);
     auto add_block = [&](int bi, int bj, const std::vector<double>& G, bool accumulate) {     // T[bi][bj] (+)= G, mirrored
         for (int a = 0; a < L; ++a)
             for (int b = 0; b < L; ++b) {
@@ -1868,20 +1927,23 @@ int stage_pca_block_lanczos(ddx_ctx* ctx, int32_t C, int32_t oversample, double 
         double t0 = dbg ? now() : 0.0;
         DDX_TRY(op(Vblk(j), Wb));
         if (dbg) { const double t1 = now(); t_prod += t1 - t0; t0 = t1; }
-        for (int pass = 0; pass < 2; ++pass)
+        // two passes of block Gram-Schmidt against ALL stored blocks at once: one batched cross-Gram, one subtraction and one
+        // copy of the coefficients per pass (the first version went block by block: 2 (j + 1) round trips per step)
+        for (int pass = 0; pass < 2; ++pass) {
+            Gall.resize((size_t)(j + 1) * L * L);
+            DDX_TRY(cross_gram_all(w, Vall, j + 1, Wb, R, dGall, Gall.data()));
+            k_block_subtract_all<<<gsub, 256, 0, ctx->stream>>>(Vall, dGall, R, L, j + 1, Wb);
+            DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
             for (int i = 0; i <= j; ++i) {
-                DDX_TRY(cross_gram(w, Vblk(i), Wb, R, dG, Gh.data()));
-                k_block_subtract<<<gsub, 256, sizeof(double) * L * L, ctx->stream>>>(Vblk(i), dG, R, L, Wb);
-                DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                std::copy(Gall.begin() + (size_t)i * L * L, Gall.begin() + (size_t)(i + 1) * L * L, Gh.begin());
                 add_block(i, j, Gh, pass > 0);
             }
+        }
         // next block: orth(remainder), made orthogonal to the earlier blocks once more (a remainder that has lost rank -- converged
         // directions -- leaves arbitrary vectors behind the Cholesky floor)
         DDX_TRY(cholqr(w, Wb, R, T1));
-        for (int i = 0; i <= j; ++i) {
-            DDX_TRY(cross_gram(w, Vblk(i), T1, R, dG, nullptr));
-            k_block_subtract<<<gsub, 256, sizeof(double) * L * L, ctx->stream>>>(Vblk(i), dG, R, L, T1);
-        }
+        DDX_TRY(cross_gram_all(w, Vall, j + 1, T1, R, dGall, nullptr));
+        k_block_subtract_all<<<gsub, 256, 0, ctx->stream>>>(Vall, dGall, R, L, j + 1, T1);
         DDX_TRY(cholqr(w, T1, R, Vblk(j + 1)));
         DDX_TRY(cross_gram(w, Vblk(j + 1), Wb, R, dG, Tsub.data()));              // T[j+1][j] = V_{j+1}^T (remainder)
         DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1936,15 +1998,14 @@ int stage_pca_block_lanczos(ddx_ctx* ctx, int32_t C, int32_t oversample, double 
     if (steps_out) *steps_out = steps;
     // X = V Z[:, top L] (small side x L; only the first C columns are results, the rest fills the product's width)
     const int nb = n / L;
-    std::vector<double> Zb((size_t)L * L), svals(L, 0.0);
+    std::vector<double> Zb((size_t)std::max(nb, 1) * L * L), svals(L, 0.0);
     for (int c = 0; c < L; ++c) svals[c] = std::sqrt(std::max(c < n ? theta[n - 1 - c] : 0.0, 0.0));
-    for (int i = 0; i < nb; ++i) {
+    for (int i = 0; i < nb; ++i)
         for (int a = 0; a < L; ++a)
-            for (int c = 0; c < L; ++c) Zb[(size_t)a * L + c] = c < n ? Z[(size_t)(i * L + a) * n + (n - 1 - c)] : 0.0;
-        DDX_HIP(ctx, hipMemcpyAsync(dZ, Zb.data(), sizeof(double) * L * L, hipMemcpyHostToDevice, ctx->stream));
-        k_block_accumulate<<<gsub, 256, sizeof(double) * L * L, ctx->stream>>>(Vblk(i), dZ, R, L, L, i == 0, Wb);
-        DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));          // Zb is reused
-    }
+            for (int c = 0; c < L; ++c) Zb[((size_t)i * L + a) * L + c] = c < n ? Z[(size_t)(i * L + a) * n + (n - 1 - c)] : 0.0;
+    DDX_HIP(ctx, hipMemcpyAsync(dGall, Zb.data(), sizeof(double) * (size_t)nb * L * L, hipMemcpyHostToDevice, ctx->stream));
+    k_block_combine_all<<<gsub, 256, 0, ctx->stream>>>(Vall, dGall, R, L, nb, Wb);
+    DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));          // Zb leaves scope
     // components (H x L) for the sign decision, scores (M x C) = U S
     w.opQ_of = w.opY_of = nullptr;                      // (the accumulated block has no float32 mirror yet)
     double* dSign = w.small + 3 * L * L + 2 * L;

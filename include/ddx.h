@@ -180,7 +180,7 @@ int ddx_pca(ddx_ctx* ctx, int32_t n_components, int32_t n_oversamples, int32_t n
  *        blocks of n_components + n_oversamples): a[n*n] row-major symmetric on entry; on exit the eigenvectors of the
  *        n_largest largest eigenvalues in its LAST n_largest columns and those eigenvalues, ascending, in the last
  *        n_largest entries of w[n] (the rest is not read); returns 0.  The Python host passes LAPACK's banded solver
- *        (scipy.linalg.eig_banded); NULL selects the library's own Householder + QL (correct, single-threaded, O(n^3)).
+ *        (scipy.linalg.eigh, driver "evr", wanted pairs only); NULL selects the library's own Householder + QL (correct, single-threaded, O(n^3)).
  * Produces the M x C float32 embedding (U*S, sign-fixed on the components) on the device, like ddx_pca. */
 typedef int (*ddx_eigh_fn)(int32_t n, int32_t n_largest, double* a, double* w, void* user);
 int ddx_pca_exact_sparse(ddx_ctx* ctx, int32_t n_components, int32_t n_oversamples, double tol, int32_t max_steps,
