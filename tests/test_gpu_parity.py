@@ -883,3 +883,40 @@ def test_packed_upload_equals_plain_upload(monkeypatch):
         finally:
             c.close()
             monkeypatch.delitem(_lib.OPTIONS, "upload")
+
+
+def test_second_column_selection_after_a_pca_matches_a_fresh_context():
+    """dd.py:165-184 through the C-ABI: ddx_select_columns may be called again on the same raw matrix after a PCA has run
+    (BoostClassifier never does -- every fit uploads -- but the boundary allows it).  The row segments the LDS-staged products
+    cache for the original cells belong to the first selection; the second one must not reuse them: same width, other
+    columns, embedding compared with a context that only ever saw the second selection."""
+    from doubletdetection_amd import _lib
+    from doubletdetection_amd._synthetic import make_counts
+
+    N, G, H = 20_000, 4000, 1500                       # large enough for the LDS-staged products (and their row segments)
+    counts = make_counts(N, G, density=0.06, seed=21)
+    parents = np.random.default_rng(3).choice(N, size=(N // 4, 2), replace=False)
+    q0 = np.random.RandomState(0).normal(size=(H, 40)).astype(np.float32).astype(np.float64)
+
+    def embedding(ctx, cols):
+        ctx.select_columns(cols)
+        ctx.create_doublets(parents)
+        ctx.lognormalise(0.1)
+        ctx.pca(30, q0)
+        return ctx.embedding().copy()
+
+    a = _lib.Context(0)
+    b = _lib.Context(0)
+    try:
+        a.upload_raw(counts)
+        order = np.argsort(a.gene_variances())
+        cols_a, cols_b = np.sort(order[-H:]), np.sort(order[-2 * H:-H])
+        first = embedding(a, cols_a)
+        second = embedding(a, cols_b)                  # same context, same width, other columns
+        b.upload_raw(counts)
+        fresh = embedding(b, cols_b)
+        np.testing.assert_array_equal(second, fresh)
+        assert not np.array_equal(first, second)
+    finally:
+        a.close()
+        b.close()
