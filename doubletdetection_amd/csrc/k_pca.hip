@@ -1705,7 +1705,8 @@ static void sym_eigh_ql(int n, double* v, double* d);
 // the device; the host sees the small coefficient blocks and solves the (j+1) L eigenproblem of T (Householder + QL).
 // Works on the smaller side: A^T A (vectors of length H) when H <= M, A A^T otherwise.
 // ------------------------------------------------------------------------------------------------
-// partial[b] = X^T W over the block's rows (L x L, row-major), L <= 64
+// partial[b] = X^T W over the block's rows (L x L, row-major), L <= 64.  Thread (ta, tb) of the 16 x 16 owns the pairs
+// (ta + 16 p, tb + 16 q): per staged row four values of X and four of W feed sixteen multiply-adds.
 __global__ void __launch_bounds__(256) k_cross_gram_partial(const double* __restrict__ X, const double* __restrict__ W, int64_t R, int L, int64_t rows_per_block,
                                                             double* __restrict__ partial) {
     extern __shared__ double cg_s[];                  // [2][32][L] row tiles of X and W
@@ -1715,31 +1716,37 @@ __global__ void __launch_bounds__(256) k_cross_gram_partial(const double* __rest
     partial += (size_t)blockIdx.y * gridDim.x * L * L;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     const int64_t r1 = r0 + rows_per_block < R ? r0 + rows_per_block : R;
-    const int npair = L * L;
-    double acc[16];                                   // pairs t = threadIdx.x + 256 u  (L <= 64: at most 16 per thread)
+    const int ta = threadIdx.x >> 4, tb = threadIdx.x & 15;
+    double acc[4][4];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) acc[u] = 0.0;
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[p][q] = 0.0;
     for (int64_t rb = r0; rb < r1; rb += 32) {
         const int nr = (int)(r1 - rb < 32 ? r1 - rb : 32);
         for (int e = threadIdx.x; e < nr * L; e += 256) { xs[e] = X[rb * L + e]; ws[e] = W[rb * L + e]; }
         __syncthreads();
+        for (int r = 0; r < nr; ++r) {
+            double xv[4], wv[4];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int t = threadIdx.x + 256 * u;
-            if (t < npair) {
-                const int i = t / L, j = t - i * L;
-                double a = acc[u];
-                for (int r = 0; r < nr; ++r) a = fma(xs[r * L + i], ws[r * L + j], a);
-                acc[u] = a;
+            for (int p = 0; p < 4; ++p) {
+                xv[p] = ta + 16 * p < L ? xs[r * L + ta + 16 * p] : 0.0;
+                wv[p] = tb + 16 * p < L ? ws[r * L + tb + 16 * p] : 0.0;
             }
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[p][q] = fma(xv[p], wv[q], acc[p][q]);
         }
         __syncthreads();
     }
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
-        const int t = threadIdx.x + 256 * u;
-        if (t < npair) partial[(int64_t)blockIdx.x * npair + t] = acc[u];
-    }
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = ta + 16 * p, j = tb + 16 * q;
+            if (i < L && j < L) partial[(int64_t)blockIdx.x * L * L + i * L + j] = acc[p][q];
+        }
 }
 
 // out[i][c] = sum_b partial[i][b][c] (the batched form of k_reduce_partials: grid.y = i)
@@ -1754,36 +1761,52 @@ __global__ void __launch_bounds__(256) k_reduce_partials_batched(const double* _
     if (lane == 0) out[(size_t)blockIdx.y * width + c] = s;
 }
 
-// W -= sum_i V_i G_i over the nblk stored blocks (V_i: R x L at V + i R L, G_i: L x L at G + i L L)
-__global__ void __launch_bounds__(256) k_block_subtract_all(const double* __restrict__ V, const double* __restrict__ G, int64_t R, int L, int nblk,
-                                                            double* __restrict__ W) {
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= R * L) return;
-    const int64_t r = t / L;
-    const int c = (int)(t - r * L);
-    double a = 0.0;
+// out = (SUBTRACT ? out : 0) -/+ sum_i V_i G_i over the nblk stored blocks (V_i: R x L at V + i R L, G_i: L x L at G + i L L).
+// A workgroup takes 64 rows: per block i the coefficient block and the 64 x L tile of V_i are staged in LDS (rows padded by one
+// value against bank conflicts); thread (row pair rl / rl + 32, column class cg) keeps 2 x 8 sums for columns cg + 8 q.
+template <bool SUBTRACT>
+__global__ void __launch_bounds__(256) k_block_apply_all(const double* __restrict__ V, const double* __restrict__ G, int64_t R, int L, int nblk,
+                                                         double* __restrict__ out) {
+    extern __shared__ double ba_s[];                  // G_i [L x L] | V tile [64 x (L + 1)]
+    double* gs = ba_s;
+    double* vs = ba_s + L * L;
+    const int rl = threadIdx.x >> 3, cg = threadIdx.x & 7;
+    const int64_t row0 = (int64_t)blockIdx.x * 64;
+    const int nr = (int)(R - row0 < 64 ? R - row0 : 64);
+    double acc[2][8];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[u][q] = 0.0;
     for (int i = 0; i < nblk; ++i) {
-        const double* v = V + ((size_t)i * R + r) * L;
-        const double* g = G + (size_t)i * L * L + c;
-        for (int k = 0; k < L; ++k) a = fma(v[k], g[(size_t)k * L], a);
+        __syncthreads();
+        for (int e = threadIdx.x; e < L * L; e += 256) gs[e] = G[(size_t)i * L * L + e];
+        const double* src = V + ((size_t)i * R + row0) * L;
+        for (int e = threadIdx.x; e < nr * L; e += 256) { const int r = e / L; vs[r * (L + 1) + (e - r * L)] = src[e]; }
+        __syncthreads();
+        for (int k = 0; k < L; ++k) {
+            const double v0 = vs[rl * (L + 1) + k], v1 = vs[(rl + 32) * (L + 1) + k];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int col = cg + 8 * q;
+                const double g = col < L ? gs[k * L + col] : 0.0;
+                acc[0][q] = fma(v0, g, acc[0][q]);
+                acc[1][q] = fma(v1, g, acc[1][q]);
+            }
+        }
     }
-    W[t] -= a;
-}
-
-// out = sum_i V_i Z_i   (same layout as k_block_subtract_all)
-__global__ void __launch_bounds__(256) k_block_combine_all(const double* __restrict__ V, const double* __restrict__ Z, int64_t R, int L, int nblk,
-                                                           double* __restrict__ out) {
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= R * L) return;
-    const int64_t r = t / L;
-    const int c = (int)(t - r * L);
-    double a = 0.0;
-    for (int i = 0; i < nblk; ++i) {
-        const double* v = V + ((size_t)i * R + r) * L;
-        const double* z = Z + (size_t)i * L * L + c;
-        for (int k = 0; k < L; ++k) a = fma(v[k], z[(size_t)k * L], a);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int r = rl + 32 * u;
+        if (r >= nr) continue;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int col = cg + 8 * q;
+            if (col >= L) continue;
+            double* o = out + (row0 + r) * L + col;
+            *o = SUBTRACT ? *o - acc[u][q] : acc[u][q];
+        }
     }
-    out[t] = a;
 }
 
 // W -= V G   (R x L, G: L x L row-major in device memory)
@@ -1914,7 +1937,10 @@ int stage_pca_block_lanczos(ddx_ctx* ctx, int32_t C, int32_t oversample, double 
                 T[(size_t)(bj * L + b) * nmax + bi * L + a] = t;
             }
     };
-    const unsigned gsub = (unsigned)ceil_div(R * L, 256);
+    const unsigned gtile = (unsigned)ceil_div(R, 64);
+    const size_t tile_lds = sizeof(double) * ((size_t)L * L + 64 * (size_t)(L + 1));      // 65 KB at L = 64
+    DDX_TRY(allow_dynamic_lds(ctx, reinterpret_cast<const void*>(&k_block_apply_all<true>), (int)tile_lds));
+    DDX_TRY(allow_dynamic_lds(ctx, reinterpret_cast<const void*>(&k_block_apply_all<false>), (int)tile_lds));
     int steps = 0;
     std::vector<double> Z;                              // Ritz vectors of the last solve: n x n row-major, columns = vectors
     int n = 0;
@@ -1932,7 +1958,7 @@ int stage_pca_block_lanczos(ddx_ctx* ctx, int32_t C, int32_t oversample, double 
         for (int pass = 0; pass < 2; ++pass) {
             Gall.resize((size_t)(j + 1) * L * L);
             DDX_TRY(cross_gram_all(w, Vall, j + 1, Wb, R, dGall, Gall.data()));
-            k_block_subtract_all<<<gsub, 256, 0, ctx->stream>>>(Vall, dGall, R, L, j + 1, Wb);
+            k_block_apply_all<true><<<gtile, 256, tile_lds, ctx->stream>>>(Vall, dGall, R, L, j + 1, Wb);
             DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
             for (int i = 0; i <= j; ++i) {
                 std::copy(Gall.begin() + (size_t)i * L * L, Gall.begin() + (size_t)(i + 1) * L * L, Gh.begin());
@@ -1943,7 +1969,7 @@ int stage_pca_block_lanczos(ddx_ctx* ctx, int32_t C, int32_t oversample, double 
         // directions -- leaves arbitrary vectors behind the Cholesky floor)
         DDX_TRY(cholqr(w, Wb, R, T1));
         DDX_TRY(cross_gram_all(w, Vall, j + 1, T1, R, dGall, nullptr));
-        k_block_subtract_all<<<gsub, 256, 0, ctx->stream>>>(Vall, dGall, R, L, j + 1, T1);
+        k_block_apply_all<true><<<gtile, 256, tile_lds, ctx->stream>>>(Vall, dGall, R, L, j + 1, T1);
         DDX_TRY(cholqr(w, T1, R, Vblk(j + 1)));
         DDX_TRY(cross_gram(w, Vblk(j + 1), Wb, R, dG, Tsub.data()));              // T[j+1][j] = V_{j+1}^T (remainder)
         DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -2004,7 +2030,7 @@ int stage_pca_block_lanczos(ddx_ctx* ctx, int32_t C, int32_t oversample, double 
         for (int a = 0; a < L; ++a)
             for (int c = 0; c < L; ++c) Zb[((size_t)i * L + a) * L + c] = c < n ? Z[(size_t)(i * L + a) * n + (n - 1 - c)] : 0.0;
     DDX_HIP(ctx, hipMemcpyAsync(dGall, Zb.data(), sizeof(double) * (size_t)nb * L * L, hipMemcpyHostToDevice, ctx->stream));
-    k_block_combine_all<<<gsub, 256, 0, ctx->stream>>>(Vall, dGall, R, L, nb, Wb);
+    k_block_apply_all<false><<<gtile, 256, tile_lds, ctx->stream>>>(Vall, dGall, R, L, nb, Wb);
     DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));          // Zb leaves scope
     // components (H x L) for the sign decision, scores (M x C) = U S
     w.opQ_of = w.opY_of = nullptr;                      // (the accumulated block has no float32 mirror yet)
