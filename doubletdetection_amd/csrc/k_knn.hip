@@ -1541,12 +1541,15 @@ __global__ void k_knn_keys(const float* __restrict__ emb, int64_t M, int C, floa
     ids[r] = (int32_t)r;
 }
 
-// number of cells for M points: cells of about 512 points (32 tiles), at most 1024; small inputs keep the plain
-// first-component order (one cell: the tile test reduces to the first-component windows)
+// number of cells for M points: cells of about 768 points (48 tiles), at most 512; small inputs keep the plain
+// first-component order (one cell: the tile test reduces to the first-component windows).  Measured, all stages of a search
+// in ms (profiles/r04_knn_notes.txt): 125 k points 64 / 128 / 192 / 256 / 384 cells 3.15 / 3.11 / 3.09 / 3.23 / 3.72; 625 k points
+// 256 / 384 / 512 / 640 / 1024 cells 30.5 / 30.0 / 29.9 / 30.5 / 33.8 (two rounds of k-means place a thousand centres worse than
+// five hundred, and the per-tile tables grow with the cell count)
 static int default_cells(int64_t M) {
     if (M < 16384) return 1;
-    const int64_t want = ceil_div(ceil_div(M, 512), 64) * 64;
-    return (int)std::min<int64_t>(1024, std::max<int64_t>(64, want));
+    const int64_t want = ceil_div(ceil_div(M, 768), 64) * 64;
+    return (int)std::min<int64_t>(512, std::max<int64_t>(64, want));
 }
 
 // candidates the emit pass listed for every query, in the caller's point order (statistics for the parity tests)
