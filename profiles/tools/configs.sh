@@ -3,5 +3,5 @@ run() { python bench.py "$@" --no-cpu-baseline --instrumented-steps 0 --no-exclu
 run --cells 50000 --genes 20000 --density 0.05
 run --algorithm louvain --scaling
 run --algorithm leiden
-run --cells 500000 --genes 33000 --density 0.02 --steps 3 --warmup 1
+run --cells 500000 --genes 33000 --density 0.02 --steps 4 --warmup 2
 rocm-smi --showmeminfo vram | grep Used
