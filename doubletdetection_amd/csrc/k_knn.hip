@@ -370,7 +370,7 @@ __global__ void __launch_bounds__(64 * kEmitBW) __attribute__((amdgpu_waves_per_
 k_knn_emit_bf(const __bf16* __restrict__ Eb, const __bf16* __restrict__ Ebq, const float* __restrict__ nrm, const f4* __restrict__ start4,
               const float* __restrict__ thr, int64_t Mp, int include_self, int32_t* __restrict__ ccount, int32_t* __restrict__ cbuf,
               const int32_t* __restrict__ elist, const int32_t* __restrict__ ecount, int64_t ecap, int dbg,
-              int cap, int nseg, int seg_steps) {
+              int cap, int nseg, int seg_steps, long long* __restrict__ tdbg) {
     constexpr int RT = kEmitRT, NV = 4 * RT;
     constexpr int G = chunk_tiles(CP);
     constexpr int tile_vecs = CP * 4;
@@ -387,6 +387,7 @@ k_knn_emit_bf(const __bf16* __restrict__ Eb, const __bf16* __restrict__ Ebq, con
     const int s_lo = seg * seg_steps;
     if (s_lo * G >= nent) return;                // (block-uniform) the list ends before this segment
     const int nsteps = min(nent / G - s_lo, seg_steps);
+    if (tdbg && tid == 0) { tdbg[4 * (size_t)blockIdx.x] = wall_clock64(); tdbg[4 * (size_t)blockIdx.x + 2] = nsteps; }
     const int64_t q0 = (blk * kEmitBW + wave) * (16 * RT);
     QueryTilesBf<CP, RT> qt;
     qt.load(FOLD ? Ebq : Eb, q0, lane);          // FOLD: the query operands carry -hr in components 30 / 31 (k_knn_fold)
@@ -541,6 +542,10 @@ k_knn_emit_bf(const __bf16* __restrict__ Eb, const __bf16* __restrict__ Ebq, con
         const int lq = (v >> 2) * 16 + rbase + (v & 3);
         for (int i = jcol; i < n; i += 16)
             if (b + i < cap) cbuf[(q0 + lq) * cap + b + i] = lbuf[wave][lq][i];
+    }
+    if (tdbg) {
+        __syncthreads();
+        if (tid == 0) tdbg[4 * (size_t)blockIdx.x + 1] = wall_clock64();
     }
 }
 
@@ -1764,7 +1769,9 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
         const int nseg = (int)(ceil_div(ceil_div(ecap, G), (int64_t)seg_steps * 8) * 8);     // segments of the longest possible list, a multiple of 8
         const unsigned grid_x = (unsigned)(emit_blocks * nseg);
         const int dbg_mode = ctx->opt.knn_ablation;     // timing ablations (wrong results): non-zero only in -DDDX_ABLATION builds
-#define DDX_EMIT_ONE(CPV, FOLDV, QUERY, BWV) k_knn_emit_bf<CPV, FOLDV, BWV><<<grid_x, 64 * BWV, 0, ctx->stream>>>(Eb, QUERY, nrm, start4, thr, Mp, include_self, ccount, cbuf, elist, ecount, ecap, dbg_mode, cap, nseg, seg_steps)
+        long long* tdbg = nullptr;                       // knn_debug: start / end / steps of every work item
+        if (ctx->opt.knn_debug) { DDX_HIP(ctx, hipMalloc(&tdbg, sizeof(long long) * 4 * (size_t)grid_x)); DDX_HIP(ctx, hipMemsetAsync(tdbg, 0, sizeof(long long) * 4 * (size_t)grid_x, ctx->stream)); }
+#define DDX_EMIT_ONE(CPV, FOLDV, QUERY, BWV) k_knn_emit_bf<CPV, FOLDV, BWV><<<grid_x, 64 * BWV, 0, ctx->stream>>>(Eb, QUERY, nrm, start4, thr, Mp, include_self, ccount, cbuf, elist, ecount, ecap, dbg_mode, cap, nseg, seg_steps, tdbg)
 #define DDX_EMIT_BF(CPV, FOLDV, QUERY)                          \
     do {                                                        \
         if (BW == 8) DDX_EMIT_ONE(CPV, FOLDV, QUERY, 8);        \
@@ -1778,6 +1785,44 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
         else DDX_EMIT_BF(128, false, Eb);
 #undef DDX_EMIT_BF
 #undef DDX_EMIT_ONE
+        if (tdbg) {
+            std::vector<long long> ht(4 * (size_t)grid_x);
+            DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            DDX_HIP(ctx, hipMemcpy(ht.data(), tdbg, sizeof(long long) * ht.size(), hipMemcpyDeviceToHost));
+            DDX_HIP(ctx, hipFree(tdbg));
+            long long t0 = 0, t1 = 0;
+            std::vector<std::pair<long long, int>> ev;
+            std::vector<double> dur;
+            double steps = 0;
+            for (size_t i = 0; i < grid_x; ++i) {
+                if (!ht[4 * i]) continue;
+                if (!t0 || ht[4 * i] < t0) t0 = ht[4 * i];
+                t1 = std::max(t1, ht[4 * i + 1]);
+                ev.emplace_back(ht[4 * i], 1);
+                ev.emplace_back(ht[4 * i + 1], -1);
+                dur.push_back((ht[4 * i + 1] - ht[4 * i]) * 0.01);
+                steps += (double)ht[4 * i + 2];
+            }
+            std::sort(ev.begin(), ev.end());
+            std::sort(dur.begin(), dur.end());
+            // resident work items over time: average, and per tenth of the span
+            const double span = (t1 - t0) * 0.01;
+            std::vector<double> tenth(10, 0.0);
+            int cur = 0;
+            double area = 0;
+            for (size_t i = 0; i + 1 < ev.size(); ++i) {
+                cur += ev[i].second;
+                const double a = (ev[i + 1].first - ev[i].first) * 0.01 * cur;
+                area += a;
+                tenth[std::min<size_t>(9, (size_t)((ev[i].first - t0) * 0.01 / span * 10))] += a;
+            }
+            if (!dur.empty()) {
+                fprintf(stderr, "[knn emit] %zu work items with work (of %u launched), %.0f steps; span %.1f us; item duration us: median %.2f, 90%% %.2f, 99%% %.2f, max %.2f; resident items: average %.1f;"
+                                " per tenth of the span:", dur.size(), grid_x, steps, span, dur[dur.size() / 2], dur[dur.size() * 9 / 10], dur[dur.size() * 99 / 100], dur.back(), area / span);
+                for (int i = 0; i < 10; ++i) fprintf(stderr, " %.0f", tenth[i] / (span / 10));
+                fprintf(stderr, "\n");
+            }
+        }
     }
     {
         ScopedTimer t(ctx, "knn_select");
