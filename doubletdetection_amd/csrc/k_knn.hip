@@ -148,7 +148,7 @@ constexpr int kBoundWaves = 8; // waves per workgroup of the bound pass: they sh
 constexpr int kEmitRT = 2;    // query tiles per wave in the emit pass
 constexpr int kEmitWaves = 4;  // waves per workgroup of the emit pass (they share the staged candidate tiles)
 constexpr int kEmitSegSteps = 4;    // steps (of 8 or 4 tiles) of a block's list that one workgroup screens
-constexpr int kEmitLocal = 32;      // candidates per query that a work item buffers in LDS before it reserves slots in the query's list
+constexpr int kEmitLog = 64;       // hits a wave logs in LDS before it files them (one lane per entry)
 
 // ---- bfloat16-split MFMA screen ----------------------------------------------------------------------------
 // q.c ~= qh.ch + qh.cl + ql.ch with three v_mfma_f32_16x16x32_bf16.  Dropped
@@ -376,7 +376,7 @@ k_knn_emit_bf(const __bf16* __restrict__ Eb, const __bf16* __restrict__ Ebq, con
     constexpr int tile_vecs = CP * 4;
     __shared__ f4 lds_c[2][G * tile_vecs];
     __shared__ f4 lds_h[2][G * 16];     // accumulator start values -0.5*(1-slack)*|c|^2, one MFMA C quad per candidate (k_knn_prepare)
-    __shared__ int32_t lbuf[kEmitBW][16 * RT][kEmitLocal];     // candidates of this work item, per query
+    __shared__ unsigned long long hlog[kEmitBW][kEmitLog][2];  // hits of this wave: (ballot mask, tile | v << 32), decoded 64 at a time
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // work item = (query block, segment of its list): workgroup id = blk * nseg + seg.  nseg is a multiple of 8, so the same
@@ -392,14 +392,34 @@ k_knn_emit_bf(const __bf16* __restrict__ Eb, const __bf16* __restrict__ Ebq, con
     QueryTilesBf<CP, RT> qt;
     qt.load(FOLD ? Ebq : Eb, q0, lane);          // FOLD: the query operands carry -hr in components 30 / 31 (k_knn_fold)
     const int rbase = 4 * (lane >> 4), jcol = lane & 15;
-    // A wave is the only writer of its 16*RT queries' candidate lists, and the 16 lanes of a lane group see the same
-    // NV queries: every lane keeps the NV slot counters of its group in registers (identical in the 16 lanes, updated
-    // by all of them from the ballot masks), so appending needs no atomics and no cross-lane traffic.
-    int cnt[NV];
+    // Hits are rare (about five candidates per wave and step) and the code that files one runs for the whole wave: the pass
+    // only LOGS a hit -- the ballot mask of one accumulator slot of one tile, 16 bytes written by one lane -- and decodes the log
+    // 64 entries at a time, a lane per entry: query and candidate from the bit positions, one atomic per candidate for its
+    // slot in the query's list (several work items append to one list: its order depends on the run, the select pass sorts it).
+    int nlog = 0;                                   // wave-uniform
+    auto flush_log = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane < nlog) {
+            unsigned long long m = hlog[wave][lane][0];
+            const unsigned long long tv = hlog[wave][lane][1];
+            const int32_t tile = (int32_t)(tv & 0xffffffffull);
+            const int v = (int)(tv >> 32);
+            while (m) {
+                const int b = __builtin_ctzll(m);
+                m &= m - 1ull;
+                const int64_t q = q0 + (v >> 2) * 16 + 4 * (b >> 4) + (v & 3);
+                const int slot = atomicAdd(&ccount[q], 1);
+                if (slot < cap) cbuf[q * cap + slot] = tile * 16 + (b & 15);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        nlog = 0;
+    };
     float hr[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
-        cnt[v] = 0;
         const int64_t q = q0 + (v >> 2) * 16 + rbase + (v & 3);
         const float n = nrm[q], t = thr[q];
         hr[v] = 0.5f * ((1.0f - kScreenSlackBf) * n - t);
@@ -455,22 +475,13 @@ k_knn_emit_bf(const __bf16* __restrict__ Eb, const __bf16* __restrict__ Ebq, con
                 for (int v = 0; v < NV; ++v) {
                     unsigned long long m = hm[v];
                     if (m == 0ull) continue;                     // wave-uniform: usually at most one of the masks is set
-                    const int64_t q = q0 + (v >> 2) * 16 + rbase + (v & 3);
-                    if (own) m &= ~__ballot(q == cand);          // a point is not its own neighbour
-                    const unsigned m16 = (unsigned)(m >> (lane & 48)) & 0xffffu;     // the 16 candidates of this lane group's query
-                    if (m16) {
-                        const int lq = (v >> 2) * 16 + rbase + (v & 3);
-                        if (cnt[v] + __popc(m16) > kEmitLocal) {     // (the 16 lanes of the group agree) buffer full: move it to the list
-                            int b = 0;
-                            if (jcol == 0) b = atomicAdd(&ccount[q], cnt[v]);
-                            b = __shfl(b, lane & 48, 64);
-                            for (int i = jcol; i < cnt[v]; i += 16)
-                                if (b + i < cap) cbuf[q * cap + b + i] = lbuf[wave][lq][i];
-                            cnt[v] = 0;
-                        }
-                        if ((m16 >> jcol) & 1u) lbuf[wave][lq][cnt[v] + __popc(m16 & ((1u << jcol) - 1u))] = cand;
-                        cnt[v] += __popc(m16);
+                    if (own) m &= ~__ballot((q0 + (v >> 2) * 16 + rbase + (v & 3)) == cand);     // a point is not its own neighbour
+                    if (m == 0ull) continue;
+                    if (lane == 0) {
+                        hlog[wave][nlog][0] = m;
+                        hlog[wave][nlog][1] = (unsigned long long)(uint32_t)tile | ((unsigned long long)v << 32);
                     }
+                    if (++nlog == kEmitLog) flush_log();
                 }
             }
         };
@@ -525,24 +536,7 @@ k_knn_emit_bf(const __bf16* __restrict__ Eb, const __bf16* __restrict__ Ebq, con
         p1 = p2;
         e0 = p0 & 0xffffff;
     }
-    // hand the item's candidates over: per query one atomic reserves the slots (several items append to one list: the order
-    // of a list depends on the run, the select pass sorts it), then the 16 lanes of the group copy
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    int base[NV];
-#pragma unroll
-    for (int v = 0; v < NV; ++v) {
-        base[v] = 0;
-        if (jcol == 0 && cnt[v] > 0) base[v] = atomicAdd(&ccount[q0 + (v >> 2) * 16 + rbase + (v & 3)], cnt[v]);
-    }
-#pragma unroll
-    for (int v = 0; v < NV; ++v) {
-        const int n = cnt[v];
-        const int b = __shfl(base[v], lane & 48, 64);
-        const int lq = (v >> 2) * 16 + rbase + (v & 3);
-        for (int i = jcol; i < n; i += 16)
-            if (b + i < cap) cbuf[(q0 + lq) * cap + b + i] = lbuf[wave][lq][i];
-    }
+    if (nlog) flush_log();
     if (tdbg) {
         __syncthreads();
         if (tid == 0) tdbg[4 * (size_t)blockIdx.x + 1] = wall_clock64();

@@ -16,7 +16,7 @@ from doubletdetection_amd import _lib
 from doubletdetection_amd._synthetic import make_counts
 
 X = make_counts(N, G, density=DENS, device="cuda:0")
-_lib.OPTIONS["knn_debug"] = "1"
+_lib.OPTIONS["knn_debug"] = os.environ.get("KNN_DEBUG", "1")
 
 
 def embedding():
