@@ -624,7 +624,7 @@ __device__ __forceinline__ void wave_sort_regs(double (&d)[R], int32_t (&ix)[R],
     }
 }
 
-// bitonic sort of an LDS window of P <= 512 entries through registers (wave_sort_regs: no strided LDS pair accesses); larger
+// bitonic sort of an LDS window of P <= 1024 entries through registers (wave_sort_regs: no strided LDS pair accesses); larger
 // windows fall back to the in-LDS network
 __device__ __forceinline__ void wave_sort_window(double* d, int32_t* ix, int P, int lane) {
     auto via_regs = [&](auto rtag) {
@@ -643,6 +643,7 @@ __device__ __forceinline__ void wave_sort_window(double* d, int32_t* ix, int P, 
     else if (P == 128) via_regs(std::integral_constant<int, 2>());
     else if (P == 256) via_regs(std::integral_constant<int, 4>());
     else if (P == 512) via_regs(std::integral_constant<int, 8>());
+    else if (P == 1024) via_regs(std::integral_constant<int, 16>());
     else wave_sort(d, ix, P, lane);
 }
 
@@ -710,7 +711,7 @@ __global__ void __launch_bounds__(64 * WAVES) k_knn_select(const float* __restri
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        wave_sort(d, ix, P, lane);
+        wave_sort_window(d, ix, P, lane);           // through registers up to 1024 entries
     }
     const int kept = cnt < K ? cnt : K;
     if (overflow) {
