@@ -294,21 +294,18 @@ __global__ void __launch_bounds__(64 * kBoundWaves) k_knn_bound_bf(const __bf16*
                 f4 acc[RT];
                 qt.dots(lds_c[buf] + t * tile_vecs, lane, acc);
                 const bool own = !include_self && (tile >= own_tile && tile < own_tile + RT);
-                // Most tiles change nothing once the lists have filled: ub < best  <=>  dot - tau > c with tau = ((1 + slack) |q|^2 -
-                // best) / 2 per query and c = (1 + slack) |c|^2 / 2 per candidate -- one subtraction per pair, a maximum tree and one
-                // compare per lane; only when some lane of the wave sees a candidate does the wave run the exact test below.  (The
-                // shortcut rounds differently from the test it stands for; letting a borderline candidate go or sending one
-                // through in vain changes a bound by nothing that matters -- any k-th smallest of upper bounds of sample points is
-                // a valid threshold.)
-                {
-                    float m = acc[0].x - tau[0];
-#pragma unroll
-                    for (int v = 1; v < NV; ++v) m = fmaxf(m, acc[v >> 2][v & 3] - tau[v]);
-                    if (!__builtin_amdgcn_readfirstlane((int)(__ballot(m > kHalfOnePlusSlack * nc * (1.f - 4e-7f)) != 0ull))) continue;
-                }
+                // Most (tile, accumulator slot) pairs change nothing once the lists have filled: ub < best  <=>  dot - tau > c with
+                // tau = ((1 + slack) |q|^2 - best) / 2 per query and c = (1 + slack) |c|^2 / 2 per candidate -- one subtraction and
+                // one compare per pair; only the slots in which some lane of the wave sees a candidate run the exact test below
+                // (a slot holds 64 of the wave's 512 four-best lists: after j tiles it still has a taker with probability ~256 / j).
+                // The shortcut rounds differently from the test it stands for; letting a borderline candidate go or sending one
+                // through in vain changes a bound by nothing that matters -- any k-th smallest of upper bounds of sample points
+                // is a valid threshold.
+                const float cthr = kHalfOnePlusSlack * nc * (1.f - 4e-7f);
 #pragma unroll
                 for (int v = 0; v < NV; ++v) {
                     const float dot = acc[v >> 2][v & 3];
+                    if (__ballot(dot - tau[v] > cthr) == 0ull) continue;
                     const float nn = nq[v] + nc;
                     float ub = fmaf(-2.f, dot, nn) + kScreenSlackBf * nn;     // upper bound of the exact squared distance
                     if (own && (tile * 16 + jcol) == (q0 + (v >> 2) * 16 + rbase + (v & 3))) ub = __builtin_huge_valf();
