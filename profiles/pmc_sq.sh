@@ -11,5 +11,5 @@ for ctrs in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_INS
   timeout 600 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d /tmp/p$i -- $short > $repo/gpurun_out/${tag}_pmc_sq_$i.log 2>&1
 done
 cd $repo
-python profiles/summarise_pmc.py a=/tmp/p1 b=/tmp/p2 c=/tmp/p3 d=/tmp/p4 e=/tmp/p5 f=/tmp/p6 g=/tmp/p7 | grep -E "spmm_lds|knn_emit|knn_bound|knn_select|mirror_tiles|lv_sweep|lv_apply" > gpurun_out/${tag}_pmc_sq.txt
+python profiles/summarise_pmc.py a=/tmp/p1 b=/tmp/p2 c=/tmp/p3 d=/tmp/p4 e=/tmp/p5 f=/tmp/p6 g=/tmp/p7 | grep -E "spmm_lds|k_bp_|knn_emit|knn_bound|knn_select|knn_rescan|mirror_tiles|lv_sweep|lv_apply" > gpurun_out/${tag}_pmc_sq.txt
 cat gpurun_out/${tag}_pmc_sq.txt
