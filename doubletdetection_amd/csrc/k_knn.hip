@@ -1601,9 +1601,9 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
     const int64_t bound_blocks = Mp / (kBoundWaves * 16 * kBoundRT);
     const int xcd_chunk = ctx->opt.knn_xcd_chunk;                                  // 0: workgroups in launch order
     const bool fold = ctx->opt.knn_fold && C <= 30;                                // threshold folded into the operands (k_knn_fold)
-    // sample of the bound pass: grows with the point count (1/16 of the tiles, at least 512) -- a fixed-size subset would hold
+    // sample of the bound pass: grows with the point count (1/24 of the tiles, at least 512) -- a fixed-size subset would hold
     // an ever smaller share of the true neighbours, T_q would loosen and the candidate lists overflow
-    int64_t nsamp = std::max<int64_t>(512, ntiles / 16);
+    int64_t nsamp = std::max<int64_t>(512, ntiles / 24);          // (625 k points: 2442 / 1800 / 1536 / 1280 tiles -> 25.5 / 24.9 / 24.7 / 27.0 ms per search)
     if (ctx->opt.knn_sample_tiles > 0) nsamp = ctx->opt.knn_sample_tiles;
     if (nsamp < 2 * (int64_t)ceil_div(k, 16) + 8) nsamp = 2 * (int64_t)ceil_div(k, 16) + 8;
     if (nsamp > ntr) nsamp = ntr;
