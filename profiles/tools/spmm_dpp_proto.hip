@@ -112,6 +112,67 @@ __global__ void __launch_bounds__(1024) k_loop96(const float* __restrict__ op, i
     if (active) out[(size_t)(blockIdx.x * 1024 + threadIdx.x)] = acc[0] + acc[1] + acc[2];
 }
 
+// Split of the 40 sketch columns into 32 + 8.  Pass 1: a half row (8 lanes x 16 bytes) reads the first 32 columns of an entry's operand row,
+// so a DPP row serves two entries per step and a wave eight (the two halves get their (offset, value) by two bank-masked row_newbcast
+// moves each).  Pass 2: the last 8 columns, two lanes per entry, four entries per DPP row and step (one per bank of four lanes).
+template <int PITCHB>
+__global__ void __launch_bounds__(1024) k_split(const float* __restrict__ op, int rounds, double* __restrict__ out, int pass) {
+    extern __shared__ __align__(16) float lds[];
+    for (int i = threadIdx.x; i < kRows * (PITCHB / 4); i += 1024) lds[i] = op[i % (kRows * 40)];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, j = lane & 15;
+    const uint32_t base3 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const float*)lds;
+    const uint32_t lane_base1 = base3 + (j & 7) * 16;                       // pass 1: columns 4 (j & 7) .. + 3
+    const uint32_t lane_base2 = base3 + 128 + (j & 1) * 16;                 // pass 2: columns 32 + 4 (j & 1) .. + 3 (lanes 0-1 of each bank of 4)
+    double acc[4] = {0, 0, 0, 0};
+    uint32_t seed = (blockIdx.x * 1024 + threadIdx.x) * 2654435761u + 12345u;
+    for (int r = 0; r < rounds; ++r) {
+        uint32_t offs[4], vals[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            seed = seed * 1664525u + 1013904223u;
+            offs[u] = ((seed >> 8) % kRows) * PITCHB;
+            vals[u] = __float_as_uint(1.0f + (float)(seed & 255) * 0.001f);
+        }
+        if (pass == 1) {
+            // step s of a register U: entries 2 s (lanes 0-7 of the row) and 2 s + 1 (lanes 8-15): broadcast lanes 2 s and 2 s + 1
+#define BC2(REG, N) ((uint32_t)__builtin_amdgcn_update_dpp((int)__builtin_amdgcn_update_dpp(0, (int)(REG), 0x150 + 2 * (N), 0xf, 0x3, false), (int)(REG), 0x150 + 2 * (N) + 1, 0xf, 0xc, false))
+#define STEP1(U, N)                                                                                                      \
+    {                                                                                                                    \
+        const uint32_t a = lane_base1 + BC2(offs[U], N);                                                                 \
+        const float v = __uint_as_float(BC2(vals[U], N));                                                                \
+        const f4 q = *reinterpret_cast<const __attribute__((address_space(3))) f4*>((uintptr_t)a);                      \
+        p = __builtin_elementwise_fma(q, (f4)(v), p);                                                                    \
+    }
+#define TRIP1(U)                                                                                                         \
+    {                                                                                                                    \
+        f4 p = (f4)(0.f);                                                                                                \
+        STEP1(U, 0) STEP1(U, 1) STEP1(U, 2) STEP1(U, 3) STEP1(U, 4) STEP1(U, 5) STEP1(U, 6) STEP1(U, 7)                  \
+        acc[0] += (double)p.x; acc[1] += (double)p.y; acc[2] += (double)p.z; acc[3] += (double)p.w;                      \
+    }
+            TRIP1(0) TRIP1(1) TRIP1(2) TRIP1(3)
+        } else {
+            // step s of a register U: entries 4 s + b for the four banks b: broadcast lanes 4 s + b into bank b
+#define BC4(REG, N) ((uint32_t)__builtin_amdgcn_update_dpp((int)__builtin_amdgcn_update_dpp((int)__builtin_amdgcn_update_dpp((int)__builtin_amdgcn_update_dpp(0, (int)(REG), 0x150 + 4 * (N), 0xf, 0x1, false), (int)(REG), 0x150 + 4 * (N) + 1, 0xf, 0x2, false), (int)(REG), 0x150 + 4 * (N) + 2, 0xf, 0x4, false), (int)(REG), 0x150 + 4 * (N) + 3, 0xf, 0x8, false))
+#define STEP2(U, N)                                                                                                      \
+    {                                                                                                                    \
+        const uint32_t a = lane_base2 + BC4(offs[U], N);                                                                 \
+        const float v = __uint_as_float(BC4(vals[U], N));                                                                \
+        const f4 q = *reinterpret_cast<const __attribute__((address_space(3))) f4*>((uintptr_t)a);                      \
+        p = __builtin_elementwise_fma(q, (f4)(v), p);                                                                    \
+    }
+#define TRIP2(U0, U1)                                                                                                    \
+    {                                                                                                                    \
+        f4 p = (f4)(0.f);                                                                                                \
+        STEP2(U0, 0) STEP2(U0, 1) STEP2(U0, 2) STEP2(U0, 3) STEP2(U1, 0) STEP2(U1, 1) STEP2(U1, 2) STEP2(U1, 3)          \
+        acc[0] += (double)p.x; acc[1] += (double)p.y; acc[2] += (double)p.z; acc[3] += (double)p.w;                      \
+    }
+            TRIP2(0, 1) TRIP2(2, 3)
+        }
+    }
+    out[(size_t)(blockIdx.x * 1024 + threadIdx.x)] = acc[0] + acc[1] + acc[2] + acc[3];
+}
+
 int main() {
     const int rounds = 2000, blocks = 256;
     float* op; double* out;
@@ -163,6 +224,22 @@ int main() {
         const double wave_steps = (double)rounds * 64 * 16, cyc = ms * 1e-3 * 2.4e9;
         printf("ds_read_b96, 14 lanes x 3 columns, lane stride %d B, pitch %d B (eight reads in flight, no overlap across trips): %.3f ms, %.2f CU-cycles per wave-step = %.2f per stored entry\n",
                v96 ? 16 : 12, pitchb, ms, cyc / wave_steps, cyc / wave_steps / 4);
+    }
+    for (int pass = 1; pass <= 2; ++pass) {
+        const size_t lds_bytes = sizeof(float) * kRows * 40;
+        auto ks = k_split<160>;
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        hipLaunchKernelGGL(ks, dim3(blocks), dim3(1024), lds_bytes, 0, op, 10, out, pass);
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(ks, dim3(blocks), dim3(1024), lds_bytes, 0, op, rounds, out, pass);
+        CK(hipEventRecord(e1));
+        CK(hipDeviceSynchronize());
+        float ms = 0;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        const double entries = (double)rounds * 256 * 16, cyc = ms * 1e-3 * 2.4e9;      // 256 entries per wave and round, 16 waves per CU
+        printf("split 32 + 8, pass %d (%s), pitch 160 B, random rows: %.3f ms = %.2f CU-cycles per stored entry\n", pass,
+               pass == 1 ? "32 columns, 8 entries per wave-step" : "8 columns, 16 entries per wave-step", ms, cyc / entries);
     }
     return 0;
 }
