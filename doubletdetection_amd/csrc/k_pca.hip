@@ -1857,10 +1857,11 @@ static int cross_gram(PcaWork& w, const double* X, const double* W, int64_t R, d
     return DDX_OK;
 }
 
+constexpr int kCrossGramChunks = 64;      // row chunks per stored block in the batched cross-Gram
 // G_i = V_i^T W for the blocks i < nblk at once (device: G_dev[i]; host copy when asked -- asynchronous, the caller synchronises)
 static int cross_gram_all(PcaWork& w, const double* Vall, int nblk, const double* W, int64_t R, double* G_dev, double* G_host) {
     const int L = w.L;
-    int nb = (int)std::min<int64_t>(256, ceil_div(R, 64));
+    int nb = (int)std::min<int64_t>(kCrossGramChunks, ceil_div(R, 64));      // (x nblk workgroups: plenty, and the partial sums stay small)
     const int64_t rpb = ceil_div(ceil_div(R, nb), 32) * 32;
     nb = (int)ceil_div(R, rpb);
     k_cross_gram_partial<<<dim3((unsigned)nb, (unsigned)nblk), 256, sizeof(double) * 64 * L, w.ctx->stream>>>(Vall, W, R, L, rpb, w.partial);
@@ -1883,7 +1884,7 @@ int stage_pca_block_lanczos(ddx_ctx* ctx, int32_t C, int32_t oversample, double 
     DDX_TRY(ensure(ctx, ctx->pcaA, sizeof(double) * 2 * (size_t)M * L));
     DDX_TRY(ensure(ctx, ctx->pcaB, sizeof(double) * 2 * (size_t)H * L));
     DDX_TRY(ensure(ctx, ctx->pcaSmall, sizeof(double) * ((8 + (size_t)max_steps + 2) * L * L + 8 * L) + 256));
-    DDX_TRY(ensure(ctx, ctx->pcaPartial, sizeof(double) * 256 * ((size_t)max_steps + 2) * (size_t)std::max(L * L, 128 * 4)));
+    DDX_TRY(ensure(ctx, ctx->pcaPartial, sizeof(double) * std::max<size_t>(512 * (size_t)std::max(L * L, 128 * 4), (size_t)kCrossGramChunks * ((size_t)max_steps + 2) * L * L)));
     DDX_TRY(ensure(ctx, ctx->pcaVec, 256));
     DDX_TRY(ensure(ctx, ctx->pcaPanel, sizeof(double) * (size_t)ceil_div(M, ctx->panel_rows) * H * L));
     DDX_TRY(ensure(ctx, ctx->pcaBlk, sizeof(double) * (size_t)(max_steps + 2) * R * L));
