@@ -45,14 +45,17 @@ void release(ddx_ctx* ctx, DevBuf& b) {
 }
 
 int allow_dynamic_lds(ddx_ctx* ctx, const void* kernel, int bytes) {
-    if (ctx->lds_configured.count(kernel)) return DDX_OK;
+    auto it = ctx->lds_configured.find(kernel);
+    if (it != ctx->lds_configured.end() && it->second >= bytes) return DDX_OK;      // (a later, larger request raises the limit again)
     DDX_HIP(ctx, hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    ctx->lds_configured[kernel] = true;
+    ctx->lds_configured[kernel] = bytes;
     return DDX_OK;
 }
 
 void arena_hint(ddx_ctx* ctx, size_t bytes) {
     if (ctx->arena_hint_forced) return;                  // ddx_reserve_hint decides
+    if (!ctx->arena.chunks.empty()) return;              // a context that holds its first chunk grows by quarters of it (a parked context's next fit
+                                                         // must not take a second full-size chunk because one buffer came out larger)
     if (bytes > ctx->arena.next_chunk) ctx->arena.next_chunk = bytes;
 }
 
@@ -68,7 +71,7 @@ void context_reset(ddx_ctx* ctx) {
                       &ctx->sort_vals_in, &ctx->sort_vals_out, &ctx->sort_tmp, &ctx->sort_rowid, &ctx->median, &ctx->lib_sorted, &ctx->lognorm_tab,
                       &ctx->zcol, &ctx->colmean, &ctx->colstat, &ctx->col_part, &ctx->pcaA, &ctx->pcaB, &ctx->pcaSmall,
                       &ctx->pcaPartial, &ctx->pcaVec, &ctx->pcaPanel, &ctx->pcaOp, &ctx->pcaQ0, &ctx->pcaBlk, &ctx->rowseg, &ctx->rank_buf, &ctx->lv_buf, &ctx->lv_pack, &ctx->graph_buf, &ctx->emb32, &ctx->emb64, &ctx->sing, &ctx->knn_idx,
-                      &ctx->knn_dist, &ctx->knn_sorted, &ctx->edge_w, &ctx->knn_cells, &ctx->bp_buf, &ctx->bp_work};
+                      &ctx->knn_dist, &ctx->knn_sorted, &ctx->edge_w, &ctx->knn_cells, &ctx->bp_buf, &ctx->bp_work, &ctx->bp_synth};
     for (DevBuf* b : bufs) { b->p = nullptr; b->cap = 0; b->blk = -1; }
     ctx->arena.blocks.clear();
     for (auto& c : ctx->arena.chunks) c.off = 0;
@@ -152,14 +155,15 @@ bool Options::set(const char* key, const char* value) {
     if (k == "pca_gather") { if (v == "f32") gather_f32 = true; else if (v == "f64") gather_f32 = false; else return false; return true; }
     if (k == "spmm_geom") { if (v == "auto") spmm_geom = 0; else if (v == "pair") spmm_geom = 1; else if (v == "quad") spmm_geom = 2; else return false; return true; }
     if (k == "spmm_trip") { if (v == "packed") trip_packed = true; else if (v == "f64") trip_packed = false; else return false; return true; }
-    if (k == "bitplane") { bitplane = on(); return true; }
+    if (k == "bitplane") { if (v == "auto") bitplane = 1; else if (!num(0, 2, &x)) return false; else bitplane = (int)x; return true; }
+    if (k == "bp_digits") { if (!num(3, 4, &x)) return false; bp_digits = (int)x; return true; }
     if (k == "knn_fold") { knn_fold = on(); return true; }
     if (k == "knn_xcd_chunk") { if (!num(0, 4096, &x)) return false; knn_xcd_chunk = (int)x; return true; }
     if (k == "knn_sample_tiles") { if (!num(0, 1 << 24, &x)) return false; knn_sample_tiles = x; return true; }
     if (k == "knn_sample_every") { if (!num(0, 1 << 20, &x)) return false; knn_sample_every = (int)x; return true; }
     if (k == "knn_cells") { if (!num(0, 1024, &x)) return false; knn_cells = (int)x; return true; }
     if (k == "knn_seg_steps") { if (!num(0, 1 << 20, &x)) return false; knn_seg_steps = (int)x; return true; }
-    if (k == "knn_emit_waves") { if (!num(0, 8, &x)) return false; knn_emit_waves = (int)x; return true; }
+    if (k == "knn_emit_waves") { if (!num(0, 8, &x) || (x != 0 && x != 4 && x != 8)) return false; knn_emit_waves = (int)x; return true; }
     if (k == "knn_debug") { knn_debug = on(); return true; }
     if (k == "pca_debug") { pca_debug = on(); return true; }
     if (k == "row_sums") { if (v == "auto") row_sums_sequential = false; else if (v == "sequential") row_sums_sequential = true; else return false; return true; }

@@ -45,7 +45,8 @@ struct Options {
     bool row_sums_sequential = false;
     bool knn_debug = false;
     bool pca_debug = false;          // progress of the block Lanczos solver on stderr
-    bool bitplane = false;           // experiment (profiles/r04_bitplane_notes.txt): the original rows' entries equal to 1 as bitmaps on the integer matrix cores
+    int bitplane = 1;                // entries equal to 1 as bitmaps on the int8 matrix cores (k_bitplane.hip): 0 off, 1 when the matrix is large enough, 2 always
+    int bp_digits = 3;               // 8-bit digits of the operand's fixed point in those products (3: 22 bits below the column maximum, 4: 30)
     int mirror_mode = 2;             // column-major mirror: 2 counting sort placed by LDS tiles, 1 (DDX_MIRROR=scatter) counting sort with scattered stores, 0 (DDX_MIRROR=sort) radix sort
     bool upload_packed = true;       // DDX_UPLOAD=plain: send the raw matrix as it is (8 bytes per entry) instead of packed
     bool upload_form16 = true;       // DDX_UPLOAD=packed32: column | count << 16 (4 bytes per entry) instead of column step | count << 8 (2 bytes)
@@ -77,28 +78,36 @@ struct Arena {
     size_t next_chunk = (size_t)256 << 20;     // size of the next chunk to request (ddx reserves a better guess at upload)
 };
 
-// Bit-plane operator products (k_bitplane.hip): bitmaps of the original cells' entries equal to 1, the reduced sparse
-// structures of their other entries (views into ctx->bp_buf, built once per fit), per-product work space (ctx->bp_work)
+// Bit-plane operator products (k_bitplane.hip): bitmaps of the entries equal to 1 (all rows of the augmented matrix, by rows
+// and by columns), the reduced sparse structures of the other entries (views into ctx->bp_buf built once per fit; the synthetic
+// rows' parts are rewritten every iteration, their mirror lives in ctx->bp_synth), per-product work space (ctx->bp_work)
 struct BitPlanes {
-    bool ready = false;              // structures built for this fit's counts
-    bool values = false;             // reduced values / row scales refreshed for this iteration's matrix
-    int KBc = 0;                     // 64-column blocks
-    int64_t KBr = 0, ntile_r = 0, ntile_c = 0, nrest = 0;
-    uint64_t* bm_rows = nullptr;     // [(row tile * KBc + kb) * 16 + r]
-    uint64_t* bm_cols = nullptr;     // [(column tile * KBr + kbr) * 16 + c]
-    int64_t* rest_indptr = nullptr;  // reduced CSR of the original rows: [N + 1], cols / position in the full arrays / value
+    bool ready = false;              // geometry + the original rows' structures built for this fit's counts
+    bool values = false;             // synthetic rows' structures, reduced values and row scales refreshed for this iteration's matrix
+    int SKc = 0;                     // stages of 256 matrix columns
+    int64_t Npad = 0;                // original rows padded to a multiple of 256: the synthetic rows' padded indices start here
+    int64_t ntile_o = 0, ntile_s = 0, ntile_c = 0;       // 32-row tiles: originals (padded), synthetic rows (this iteration), columns
+    int64_t cap_rows = 0;            // padded rows the bitmaps have room for
+    int64_t SKr = 0, SKr_cap = 0, SKr_used = 0;          // stages of 256 padded rows: layout stride of the column bitmap (= capacity) / in use
+    int64_t nrest_o = 0, nrest_s = 0, cap_rest = 0, cap_rest_s = 0, cap_srow = 0;
+    void* bm_rows = nullptr;         // [(row tile * SKc + sk) * 64 + r * 2 + h] 16-byte words
+    void* bm_cols = nullptr;         // [(column tile * SKr + skr) * 64 + c * 2 + h]
+    int64_t* rest_indptr = nullptr;  // reduced CSR of ALL rows: [M + 1]; cols / value; rest_pos: position of an original row's entry in the full arrays
     int32_t* rest_cols = nullptr;
     int32_t* rest_pos = nullptr;
     float* rest_x = nullptr;
-    int64_t* restm_colptr = nullptr; // reduced column-major mirror: [P_o * H + 1], rows / position in the full mirror / value
+    int64_t* restm_colptr = nullptr; // reduced column-major mirror of the original rows: [P_o * H + 1], rows / position in the full mirror / value
     int32_t* restm_row = nullptr;
     int32_t* restm_pos = nullptr;
     float* restm_x = nullptr;
-    double* srow = nullptr;          // [N] s_i = x_i(1) - z
+    int64_t* restm_s_colptr = nullptr;   // ... of the synthetic rows: [P_s * H + 1], rows / value
+    int32_t* restm_s_row = nullptr;
+    float* restm_s_x = nullptr;
+    double* srow = nullptr;          // [M] s_i = x_i(1) - z
     void* qd = nullptr;              // operand digits
     double* cmax = nullptr;          // [64] column maxima of the operand
-    int32_t* part = nullptr;         // digit sums per chunk of the A^T Y product
-    double* w1 = nullptr;            // [H x L] result of the A^T Y product
+    double* cscale = nullptr;        // [64] 2^-shift per column
+    double* part = nullptr;          // partial blocks of the A^T Y product, one per chunk of the rows
 };
 
 struct TimingRec {
@@ -118,7 +127,7 @@ struct ddx_ctx {
     hipStream_t stream = nullptr;
     ddx::Options opt;
     ddx::Arena arena;
-    std::map<const void*, bool> lds_configured;   // kernels whose dynamic-LDS limit was raised on this context's device
+    std::map<const void*, int> lds_configured;    // kernels whose dynamic-LDS limit was raised on this context's device, and to how many bytes
     std::string err;
     int64_t dev_bytes = 0;
     bool arena_hint_forced = false;   // ddx_reserve_hint: the library's own size guesses are ignored
@@ -141,6 +150,7 @@ struct ddx_ctx {
     int64_t N = 0;
     int32_t H = 0;
     int64_t nnz = 0;                 // stored entries of the N x H counts
+    int64_t nnz_aug = 0;             // ... of the augmented matrix (known after ddx_lognormalise)
     std::vector<int64_t> h_indptr;   // host copy of the row pointer (capacity planning)
     bool have_counts = false;
     bool counts_exact = false;       // counts are small non-negative integers: row sums are exact in any order
@@ -213,7 +223,7 @@ struct ddx_ctx {
     ddx::DevBuf knn_sorted;          // int32 [M*K] neighbour lists sorted by index
     ddx::DevBuf edge_w;              // double [M*K]
     ddx::DevBuf knn_cells;           // cells, interval tables and chunk lists of the emit pass (stage_knn)
-    ddx::DevBuf bp_buf, bp_work;     // bit-plane products: per-fit structures / per-product work space
+    ddx::DevBuf bp_buf, bp_work, bp_synth;   // bit-plane products: per-fit structures / per-product work space / the synthetic rows' reduced mirror
     ddx::BitPlanes bp;
     const int32_t* knn_overflow = nullptr;   // device counter: queries whose candidate list overflowed (exact rescan)
     const int32_t* knn_ccount = nullptr;     // candidates listed per query (kNN point order) and that order (views into the kNN work space)
@@ -327,7 +337,8 @@ int stage_graph_relations(ddx_ctx* ctx, int32_t mode, int32_t* idx_host, double*
 void assemble_graph(int64_t M, int K, const int32_t* idx, const double* w, std::vector<int64_t>& ip,
                     std::vector<int32_t>& gi, std::vector<double>& gw);
 int validate_csr(ddx_ctx* ctx, const int64_t* indptr, const int32_t* cols, const float* vals, int64_t N, int32_t G);
-int stage_rankings(ddx_ctx* ctx, const int64_t* reduced_indptr = nullptr);   // reduced_indptr: row pointer of the original rows' entries that stay sparse (bit-plane mode)
+// rankings of the rows / columns by stored entries; the arrays given are the ones the sparse products will walk (bit-plane mode: the reduced ones)
+int stage_rankings(ddx_ctx* ctx, const int64_t* indptr, const int64_t* cp_o, const int64_t* cp_s);
 int stage_coarsen_graph(ddx_ctx* ctx, double gamma, int32_t sweeps, int32_t levels);
 int stage_refine_communities(ddx_ctx* ctx, const int32_t* coarse_labels, double gamma, int32_t sweeps, int32_t* labels_out);
 int stage_gene_variances(ddx_ctx* ctx, float* var_out);
@@ -338,8 +349,8 @@ int stage_select_columns(ddx_ctx* ctx, const int64_t* cols, int32_t n_cols);
 // bit-plane products (k_bitplane.hip)
 int bp_build(ddx_ctx* ctx);
 int bp_refresh(ddx_ctx* ctx);
-int bp_rows_product(ddx_ctx* ctx, const double* Q, int L, int ld, double* Y, float* Y32);
-int bp_cols_product(ddx_ctx* ctx, const double* Y, int L, int ld, const double** w1);
+int bp_rows_product(ddx_ctx* ctx, const double* Q, int L, double* Y);
+int bp_cols_product(ddx_ctx* ctx, const double* Y, int L, const double** part, int* chunks);
 
 // host-side numerics
 void jacobi_eigh(int n, double* a /* n*n row-major, destroyed */, double* evals, double* evecs);

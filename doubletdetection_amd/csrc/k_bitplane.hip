@@ -5,18 +5,29 @@
 //
 //      L  =  diag(s) B  +  R ,      s_i = x_i(1) - z ,   B = [count == 1] (zeros and ones),   R = the entries with other counts
 //
-// R keeps going through the LDS-staged sparse kernels (k_pca.hip).  B is kept as a BITMAP -- one bit per (row, column), 16
-// times less memory traffic than the 8 bytes per entry of the sparse form -- and multiplied on the matrix cores in exact
-// integer arithmetic: the float64 operand is cut column by column into a 31-bit fixed-point number, that number into four
-// signed 8-bit digits, and  B . digit_d  runs on v_mfma_i32_16x16x64_i8 (zeros and ones against 8-bit digits, 32-bit sums:
-// no rounding anywhere, any order gives the same bits).  The four digit sums are recombined in 64-bit integers, scaled
-// back and by s_i in float64.  Against the float32 operand copy of the sparse path (24 bits relative to each element) the
-// fixed point carries 31 bits relative to the column's largest element.
+// R keeps going through the LDS-staged sparse kernels (k_pca.hip) -- they simply see a matrix with a tenth of the entries.
+// B is kept as a BITMAP -- one bit per (row, column), 64 times less memory traffic than the 8 bytes per entry of the sparse
+// form -- and multiplied on the matrix cores in exact integer arithmetic: the float64 operand is cut column by column into
+// a fixed-point number of ND signed 8-bit digits (ND = 3: 22 bits below the column's largest element, ND = 4: 30), and
+// B . digit_d runs on v_mfma_i32_32x32x32_i8 (zeros and ones against 8-bit digits, 32-bit sums: no rounding anywhere, any
+// order gives the same bits).  The digit sums are recombined, scaled back and by s_i in float64.
 //
-// Only the original cells' rows take this route (their pattern is fixed for a fit: the bitmaps, the reduced sparse
-// structures and their positions in the full arrays are built once per fit and context); the synthetic doublets, new in
-// every iteration, stay sparse.  Scaled matrices (standard_scaling: the value then depends on the column too) and
-// sketches wider than 64 columns keep the plain sparse products.
+// Round 5 (round 4's first version: original rows only, 16 x 16 x 64 tiles over 48 padded columns x 4 digits, one barrier
+// per 64 matrix columns, digit sums through global memory: 0.22 - 0.26 ms per product and 9 ms of structure building per
+// context and fit -- not faster than the sparse kernel it relieved):
+//   * ALL rows take the route: the synthetic doublets' bitmaps and reduced structures are rebuilt every iteration;
+//   * the (sketch column, digit) pairs are flattened into one N index, f = column * ND + digit: 40 columns x 4 digits are
+//     exactly five 32-wide tiles, 40 x 3 digits four (128 for 120);
+//   * stages of 256 matrix columns (eight MFMA k-steps) per barrier, three stages of digits in LDS by asynchronous copies,
+//     the operand fragments read two MFMA groups ahead (the two waves of a SIMD leave a barrier together: without the
+//     prefetch both sit in the same LDS round trip), the bitmap words straight into registers one stage ahead;
+//   * the epilogue recombines the digits through LDS and writes the float64 result (A Q) or one partial block per chunk of
+//     the k dimension (A^T Y) -- no digit sums in global memory, no combine kernels.
+// Measured stand-alone (profiles/tools/bp2_proto.hip, profiles/r05_bitplane_notes.txt): the matrix pipe is busy 82 % of the
+// kernel's cycles; the clock drops to ~1.6 GHz under it (power), which is what the wall-clock sees.
+//
+// Scaled matrices (standard_scaling: the value then depends on the column too) and sketches wider than 40 columns keep the
+// plain sparse products.
 #include "ddx_prims.h"
 
 #include "ddx_internal.h"
@@ -24,81 +35,118 @@
 namespace ddx {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
-constexpr int kBpDigits = 4;
+typedef int v16i __attribute__((ext_vector_type(16)));
 
-// ---- once per fit: bitmaps and reduced structures ---------------------------------------------------------------
-// bitmap of the rows: word (tile, kb, r) holds columns kb*64 .. +63 of row tile*16 + r; layout [(tile * KB + kb) * 16 + r]
-__global__ void k_bp_rows_bitmap(const int64_t* __restrict__ indptr, const int32_t* __restrict__ cols, const float* __restrict__ raw, int64_t N, int KB,
-                                 uint64_t* __restrict__ bm) {
-    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t ntile = (N + 15) >> 4;
-    if (w >= ntile * KB * 16) return;
-    const int r = (int)(w & 15);
-    const int64_t tk = w >> 4;
-    const int64_t tile = tk / KB;
-    const int kb = (int)(tk - tile * KB);
-    const int64_t row = tile * 16 + r;
-    uint64_t v = 0;
-    if (row < N) {
-        const int64_t b = indptr[row], e = indptr[row + 1];
-        const int32_t c0 = kb * 64;
-        int64_t lo = b, hi = e;
-        while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (cols[mid] < c0) lo = mid + 1; else hi = mid; }
-        for (int64_t p = lo; p < e && cols[p] < c0 + 64; ++p)
-            if (raw[p] == 1.0f) v |= 1ull << (cols[p] - c0);
-    }
-    bm[w] = v;
+constexpr int kBpStageCols = 256;       // matrix columns (k) per LDS stage = eight MFMA k-steps of 32
+constexpr int kBpSteps = 8;
+constexpr int kBpWaves = 8;             // waves per workgroup of the product kernel
+constexpr int kBpStages = 3;
+
+// padded row index ("k space" of the A^T Y product, tile space of the A Q product): the original rows are padded to a multiple
+// of 256, the synthetic rows follow.  pr -> row of the augmented matrix, or -1
+__device__ __forceinline__ int64_t bp_row_of(int64_t pr, int64_t Npad, int64_t N, int64_t M) {
+    if (pr < Npad) return pr < N ? pr : -1;
+    const int64_t r = N + (pr - Npad);
+    return r < M ? r : -1;
 }
 
-// the same bits by columns: word (ctile, kbr, c) holds rows kbr*64 .. +63 of column ctile*16 + c.  One wave per 64 x 64 block.
-__global__ void __launch_bounds__(256) k_bp_transpose(const uint64_t* __restrict__ bm, int64_t N, int32_t H, int KB, int64_t KBr,
-                                                      uint64_t* __restrict__ bmT) {
+// ---- bitmaps ---------------------------------------------------------------------------------------------------------
+// Row bitmap: 16-byte word (tile, sk, r, h) holds columns sk*256 + h*128 .. +127 of padded row tile*32 + r;
+// layout [(tile * SK + sk) * 64 + r * 2 + h]: the 32 rows x 256 columns of a (tile, stage) pair are one contiguous KB.
+// One workgroup per tile: the tile's image is assembled in LDS (integer atomics: bits set in any order), `sk_chunk` stages at
+// a time, and written out in full lines.
+__global__ void __launch_bounds__(256) k_bp_rows_bitmap(const int64_t* __restrict__ indptr, const int32_t* __restrict__ cols, const float* __restrict__ raw,
+                                                        int64_t tile0, int64_t Npad, int64_t N, int64_t M, int SK, int sk_chunk, v4i* __restrict__ bm) {
+    extern __shared__ __align__(16) uint32_t bp_img[];              // [32 rows][sk_chunk * 8 words]
+    const int64_t tile = tile0 + blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wpr = sk_chunk * 8;                                    // words per row of the image
+    for (int sk0 = 0; sk0 < SK; sk0 += sk_chunk) {
+        const int nsk = SK - sk0 < sk_chunk ? SK - sk0 : sk_chunk;
+        for (int i = threadIdx.x; i < 32 * wpr; i += 256) bp_img[i] = 0u;
+        __syncthreads();
+        const int32_t c_lo = sk0 * kBpStageCols, c_hi = (sk0 + nsk) * kBpStageCols;
+        for (int r = wave; r < 32; r += 4) {
+            const int64_t row = bp_row_of(tile * 32 + r, Npad, N, M);
+            if (row < 0) continue;
+            const int64_t b = indptr[row], e = indptr[row + 1];
+            for (int64_t p = b + lane; p < e; p += 64) {
+                const int32_t c = cols[p];
+                if (raw[p] == 1.0f && c >= c_lo && c < c_hi) atomicOr(&bp_img[r * wpr + ((c - c_lo) >> 5)], 1u << (c & 31));
+            }
+        }
+        __syncthreads();
+        // 16-byte pieces (sk, r, h) -> out[(tile * SK + sk0 + sk) * 64 + r * 2 + h]
+        for (int i = threadIdx.x; i < nsk * 64; i += 256) {
+            const int sk = i >> 6, rh = i & 63, r = rh >> 1, h = rh & 1;
+            const uint32_t* src = bp_img + r * wpr + sk * 8 + h * 4;
+            bm[(tile * SK + sk0 + sk) * 64 + rh] = v4i{(int)src[0], (int)src[1], (int)src[2], (int)src[3]};
+        }
+        __syncthreads();
+    }
+}
+
+// The same bits by columns: word (ctile, skr, c, h) holds padded rows skr*256 + h*128 .. +127 of column ctile*32 + c.
+// One wave per 64 (padded rows) x 64 (columns) block: lane = row reads its 64 column bits, 64 ballots transpose them.
+// prow0: first padded row of the range to transpose (a multiple of 64), nblk_r: 64-row blocks of the range.
+__global__ void __launch_bounds__(256) k_bp_transpose(const v4i* __restrict__ bm, int64_t prow0, int64_t nblk_r, int SKc, int64_t SKr, int32_t Hpad32,
+                                                      v4i* __restrict__ bmT) {
     const int lane = threadIdx.x & 63;
     const int64_t blk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (blk >= KBr * KB) return;
-    const int64_t rb = blk / KB;
-    const int kb = (int)(blk - rb * KB);
-    const int64_t row = rb * 64 + lane;
-    const uint64_t w = row < N ? bm[((row >> 4) * KB + kb) * 16 + (row & 15)] : 0ull;
+    const int nblk_c = SKc * 4;                                      // 64-column blocks
+    if (blk >= nblk_r * nblk_c) return;
+    const int64_t rb = blk / nblk_c;
+    const int cb = (int)(blk - rb * nblk_c);
+    const int64_t pr = prow0 + rb * 64 + lane;                       // this lane's padded row
+    // columns cb*64 .. +63 of row pr: stage sk = cb / 4, half h = (cb & 3) >> 1, 64-bit half (cb & 1) of the 16-byte word
+    const uint64_t* src = reinterpret_cast<const uint64_t*>(bm + ((pr >> 5) * SKc + (cb >> 2)) * 64 + (pr & 31) * 2 + ((cb & 3) >> 1));
+    const uint64_t w = src[cb & 1];
     uint64_t mine = 0;
     for (int c = 0; c < 64; ++c) {
         const uint64_t t = __ballot((w >> c) & 1ull);
         if (lane == c) mine = t;
     }
-    const int64_t col = (int64_t)kb * 64 + lane;
-    if (col < (((int64_t)H + 15) & ~(int64_t)15)) bmT[((col >> 4) * KBr + rb) * 16 + (col & 15)] = mine;
+    const int32_t col = cb * 64 + lane;
+    if (col >= Hpad32) return;
+    const int64_t pr0 = prow0 + rb * 64;
+    uint64_t* dst = reinterpret_cast<uint64_t*>(bmT + ((int64_t)(col >> 5) * SKr + (pr0 >> 8)) * 64 + (col & 31) * 2 + ((pr0 & 255) >> 7));
+    dst[(pr0 & 127) >> 6] = mine;
 }
 
+// ---- reduced structures: the entries other than 1 ----------------------------------------------------------------------
 __global__ void k_bp_flags(const float* __restrict__ raw, int64_t n, int32_t* __restrict__ flag) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i > n) return;
     flag[i] = (i < n && raw[i] != 1.0f) ? 1 : 0;            // (element n: 0, so that the scan's last element is the total)
 }
 
-__global__ void k_bp_compact(const int32_t* __restrict__ flag, const int32_t* __restrict__ scan, const int32_t* __restrict__ idx, int64_t n,
-                             int32_t* __restrict__ idx_out, int32_t* __restrict__ pos_out) {
+// kept entries -> idx_out / pos_out (pos: position in the full arrays, for the per-iteration value refresh; may be null) / x_out (may be null)
+__global__ void k_bp_compact(const int32_t* __restrict__ flag, const int32_t* __restrict__ scan, const int32_t* __restrict__ idx, const float* __restrict__ x,
+                             int64_t n, int32_t* __restrict__ idx_out, int32_t* __restrict__ pos_out, float* __restrict__ x_out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n || !flag[i]) return;
-    idx_out[scan[i]] = idx[i];
-    pos_out[scan[i]] = (int32_t)i;
+    const int32_t o = scan[i];
+    idx_out[o] = idx[i];
+    if (pos_out) pos_out[o] = (int32_t)i;
+    if (x_out) x_out[o] = x[i];
 }
 
-__global__ void k_bp_pointers(const int64_t* __restrict__ ptr, int64_t nptr, const int32_t* __restrict__ scan, int64_t* __restrict__ out) {
+// out[i] = base + scan[ptr[i] - e0]
+__global__ void k_bp_pointers(const int64_t* __restrict__ ptr, int64_t nptr, int64_t e0, const int32_t* __restrict__ scan, int64_t base, int64_t* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nptr) return;
-    out[i] = scan[ptr[i]];
+    out[i] = base + scan[ptr[i] - e0];
 }
 
-// ---- once per iteration: values of the reduced structures, row scales ---------------------------------------------
 __global__ void k_bp_gather(const float* __restrict__ x, const int32_t* __restrict__ pos, int64_t n, float* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = x[pos[i]];
 }
 
 // s_i = x_i(1) - z, the float32 difference the sparse path forms for such an entry (exactly what the float64 difference rounds to)
-__global__ void k_bp_row_scale(const float* __restrict__ tab, int tab_stride, float z, int64_t N, double* __restrict__ s) {
+__global__ void k_bp_row_scale(const float* __restrict__ tab, int tab_stride, float z, int64_t M, double* __restrict__ s) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < N) s[i] = (double)(tab[i * tab_stride] - z);
+    if (i < M) s[i] = (double)(tab[i * tab_stride] - z);
 }
 
 // ---- per product: the operand as digits -------------------------------------------------------------------------------
@@ -122,47 +170,60 @@ __global__ void __launch_bounds__(256) k_bp_colmax(const double* __restrict__ X,
     }
 }
 
-// shift of column c: |X 2^sh| <= 2^30
-__device__ __forceinline__ int bp_shift(double cmax) {
+// shift of a column: |X 2^sh| <= 2^(8 ND - 2), so that the last balanced digit stays inside int8
+__device__ __forceinline__ int bp_shift(double cmax, int ND) {
     if (!(cmax > 0.0) || !(cmax < 1e300)) return 0;
     int e;
     (void)frexp(cmax, &e);                                   // cmax = m 2^e, 0.5 <= m < 1
-    return 30 - e;
+    return 8 * ND - 2 - e;
 }
 
-// digits in the B-operand layout of v_mfma_i32_16x16x64_i8: qd[((kb * NCB + cb) * 4 + d) * 64 + lane] = 16 bytes =
-// digit d of rows k = kb*64 + (lane >> 4)*16 + 0..15, column cb*16 + (lane & 15)
-__global__ void __launch_bounds__(256) k_bp_digits(const double* __restrict__ X, const double* __restrict__ wgt, int64_t R, int L, int NCB,
-                                                   const double* __restrict__ cmax, int64_t KB, v4i* __restrict__ qd) {
+// cscale[c] = 2^-shift(c): what the product kernel multiplies the recombined integer by
+__global__ void k_bp_scales(const double* __restrict__ cmax, int L, int ND, double* __restrict__ cscale) {
+    const int c = threadIdx.x;
+    if (c < 64) cscale[c] = c < L ? ldexp(1.0, -bp_shift(cmax[c], ND)) : 0.0;
+}
+
+// digits in the B-operand layout of v_mfma_i32_32x32x32_i8:
+//   qd[((sk * 8 + s) * NT + nt) * 64 + h * 32 + n] = 16 bytes e = 0..15: digit d of column c, f = nt * 32 + n = c * ND + d,
+//   operand row k = sk * 256 + h * 128 + s * 16 + e  (ROWMAP: k is a padded row index of the augmented matrix)
+// One thread per (sk, s, h, column slot): 16 operand values -> ND vectors.  Slots past L write the zero padding of the last tile.
+template <int ND, bool ROWMAP>
+__global__ void __launch_bounds__(256) k_bp_digits(const double* __restrict__ X, const double* __restrict__ wgt, int64_t R, int L, int NT, int nslot,
+                                                   const double* __restrict__ cmax, int64_t SK, int64_t Npad, int64_t N, v4i* __restrict__ qd) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= KB * NCB * 64) return;
-    const int lane = (int)(t & 63);
-    const int64_t u = t >> 6;
-    const int cb = (int)(u % NCB);
-    const int64_t kb = u / NCB;
-    const int col = cb * 16 + (lane & 15);
-    const int g = lane >> 4;
-    unsigned out[kBpDigits][4] = {};
-    if (col < L) {
-        const double scale = ldexp(1.0, bp_shift(cmax[col]));
+    if (t >= SK * kBpSteps * 2 * nslot) return;
+    const int slot = (int)(t % nslot);
+    int64_t u = t / nslot;
+    const int h = (int)(u & 1); u >>= 1;
+    const int s = (int)(u & 7);
+    const int64_t sk = u >> 3;
+    unsigned out[ND][4] = {};
+    if (slot < L) {
+        const double scale = ldexp(1.0, bp_shift(cmax[slot], ND));
+        const double lim = ldexp(1.0, 8 * ND - 2);
         for (int e = 0; e < 16; ++e) {
-            const int64_t k = kb * 64 + g * 16 + e;
+            const int64_t k = sk * kBpStageCols + h * 128 + s * 16 + e;
+            const int64_t row = ROWMAP ? bp_row_of(k, Npad, N, R) : (k < R ? k : -1);
             int v = 0;
-            if (k < R) {
-                const double x = wgt ? wgt[k] * X[k * L + col] : X[k * L + col];
+            if (row >= 0) {
+                const double x = wgt ? wgt[row] * X[row * L + slot] : X[row * L + slot];
                 const double q = rint(x * scale);
-                v = (q >= -1073741824.0 && q <= 1073741824.0) ? (int)q : 0;       // (non-finite operands: zero; caught by the rank check upstream)
+                v = (q >= -lim && q <= lim) ? (int)q : 0;          // (non-finite operands: zero; caught by the rank check upstream)
             }
 #pragma unroll
-            for (int d = 0; d < kBpDigits; ++d) {
-                const int dg = d + 1 < kBpDigits ? ((v + 128) & 255) - 128 : v;    // balanced digits; the last one is what is left (|.| <= 65)
+            for (int d = 0; d < ND; ++d) {
+                const int dg = d + 1 < ND ? ((v + 128) & 255) - 128 : v;    // balanced digits; the last one is what is left (|.| <= 65)
                 v = (v - dg) >> 8;
                 out[d][e >> 2] |= (unsigned)(uint8_t)(int8_t)dg << (8 * (e & 3));
             }
         }
     }
 #pragma unroll
-    for (int d = 0; d < kBpDigits; ++d) qd[((kb * NCB + cb) * kBpDigits + d) * 64 + lane] = v4i{(int)out[d][0], (int)out[d][1], (int)out[d][2], (int)out[d][3]};
+    for (int d = 0; d < ND; ++d) {
+        const int f = slot * ND + d;
+        if (f < NT * 32) qd[((sk * kBpSteps + s) * NT + (f >> 5)) * 64 + h * 32 + (f & 31)] = v4i{(int)out[d][0], (int)out[d][1], (int)out[d][2], (int)out[d][3]};
+    }
 }
 
 // 16 bits -> 16 bytes of 0 / 1 (the A operand of the MFMA)
@@ -173,141 +234,146 @@ __device__ __forceinline__ v4i bp_expand16(unsigned bits) {
     return r;
 }
 
-// Digit sums S_d = B . digit_d over k-blocks [kb0, kb1) for the tiles of this workgroup (WAVES waves x RT tiles of 16
-// bitmap rows), written to part[chunk][row][col][d] (int32) for the combine kernels.
-// Both operands of a k-block -- the digit blocks (NCB x 4 KB) and the workgroup's bitmap words (RT * WAVES x 128 bytes) --
-// arrive in LDS by asynchronous copies into a ring of stages, stages - 1 k-blocks ahead.  What a CU can take in is about
-// 10 bytes per clock, whatever the source (MI355X_MICROARCH.md), so the digit blocks are shared by as many rows as the
-// register file allows: 8 waves x 64 rows (252 registers per lane: the 16 x 48 x 4-digit accumulators of four tiles).
-// A wave issues a fixed number of copies per k-block (waves of the first half carry the odd piece), so "at most
-// (stages - 2) * that many outstanding" means the next k-block has landed (memory operations of a wave complete in
-// issue order; the loop issues nothing else).
-template <int RT, int WAVES, int NCB>
-__global__ void __launch_bounds__(64 * WAVES) k_bp_product(const uint64_t* __restrict__ bm, const v4i* __restrict__ qd, int64_t ntile, int64_t KB, int kb_per_chunk,
-                                                           int64_t nrows, int32_t* __restrict__ part) {
-    constexpr int kStages = NCB <= 3 ? 4 : 3;                     // (64 KB of static LDS at most)
-    constexpr int kDigVecs = NCB * kBpDigits * 64;               // 16-byte vectors of digits per k-block
-    constexpr int kBmWords = RT * WAVES * 16;                    // 8-byte bitmap words per k-block
-    constexpr int kDigPieces = kDigVecs / 64;                    // one piece = one wave-wide copy (1 KB)
-    constexpr int kBmPieces = kBmWords * 2 / 64;                 // (4-byte copies: 256 bytes per wave-wide copy)
-    static_assert(kBmPieces % WAVES == 0, "bitmap pieces divide evenly");
-    constexpr int kDigLo = kDigPieces / WAVES, kDigExtra = kDigPieces % WAVES;   // waves < kDigExtra carry one more piece
-    __shared__ v4i lds_d[kStages][kDigVecs];
-    __shared__ uint64_t lds_b[kStages][kBmWords];
+struct BpProductArgs {
+    const v4i* bm;            // bitmap [tile][SK][64]
+    const v4i* qd;            // digits [SK][8][NT][64]
+    int64_t ntile;            // 32-row tiles of the bitmap
+    int SK;                   // stages of the k dimension in use
+    int64_t SKstride;         // stages per tile in the bitmap's layout (>= SK)
+    int sk_per_chunk;         // stages per chunk (grid.y chunks)
+    int L;                    // sketch columns
+    const double* cscale;     // [64] 2^-shift per column
+    // ROWS (A Q): output row = bp_row_of(tile * 32 + r); out[row][c] = srow[row] * value
+    const double* srow; int64_t Npad, N, M;
+    // COLS (A^T Y): output row = tile * 32 + r < nOut; out[(chunk * nOut + row)][c] = value
+    int64_t nOut;
+    double* out;
+};
+
+// S = B . digits for RT tiles of 32 bitmap rows per wave, over the stages of this workgroup's chunk; see the file header.
+template <int RT, int NT, int ND, bool ROWS>
+__global__ void __launch_bounds__(64 * kBpWaves) k_bp_product(const BpProductArgs a) {
+    constexpr int kVecs = kBpSteps * NT * 64;                    // 16-byte vectors of digits per stage
+    constexpr int kPieces = kVecs / 64;                          // wave-wide copies (1 KB each) per stage
+    constexpr int kLo = kPieces / kBpWaves, kExtra = kPieces % kBpWaves;   // waves < kExtra carry one more piece
+    extern __shared__ __align__(16) unsigned char bp_smem[];
+    v4i* lds = reinterpret_cast<v4i*>(bp_smem);                  // [kBpStages][kVecs]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int64_t tileb = (int64_t)blockIdx.x * (WAVES * RT);    // first tile of the workgroup
+    const int64_t tile0 = ((int64_t)blockIdx.x * kBpWaves + wave) * RT;
     const int chunk = blockIdx.y;
-    const int64_t kb0 = (int64_t)chunk * kb_per_chunk, kb1 = kb0 + kb_per_chunk < KB ? kb0 + kb_per_chunk : KB;
-    const int r = lane & 15, g = lane >> 4;
-    v4i acc[RT][NCB][kBpDigits];
+    const int sk0 = chunk * a.sk_per_chunk;
+    const int sk1 = sk0 + a.sk_per_chunk < a.SK ? sk0 + a.sk_per_chunk : a.SK;
+    v16i acc[RT][NT];
 #pragma unroll
     for (int t = 0; t < RT; ++t)
 #pragma unroll
-        for (int c = 0; c < NCB; ++c)
+        for (int c = 0; c < NT; ++c)
 #pragma unroll
-            for (int d = 0; d < kBpDigits; ++d) acc[t][c][d] = v4i{0, 0, 0, 0};
-    const uint32_t* bm32 = reinterpret_cast<const uint32_t*>(bm);
-    auto stage = [&](int64_t kb, int st) {                       // (a k-block past the end re-reads the last one: harmless, same count)
-        const int64_t k = kb < kb1 ? kb : kb1 - 1;
-#pragma unroll
-        for (int u = 0; u <= kDigLo; ++u) {
-            const int piece = u * WAVES + wave;
-            if (u < kDigLo || wave < kDigExtra)                   // (wave-uniform)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qd + k * kDigVecs + piece * 64 + lane),
-                                                 (__attribute__((address_space(3))) void*)(lds_d[st] + piece * 64), 16, 0, 0);
-        }
-#pragma unroll
-        for (int u = 0; u < kBmPieces / WAVES; ++u) {
-            const int w0 = (u * WAVES + wave) * 64;               // 4-byte items of the stage's bitmap image; word = item / 2
-            const int item = w0 + lane;
-            int64_t tile = tileb + (item >> 5);                   // 32 items (16 words) per tile
-            if (tile >= ntile) tile = ntile - 1;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bm32 + ((tile * KB + k) * 16) * 2 + (item & 31)),
-                                             (__attribute__((address_space(3))) void*)(reinterpret_cast<uint32_t*>(lds_b[st]) + w0), 4, 0, 0);
-        }
-    };
-    auto wait_next = [&]() {                                     // all but the copies of the newest kStages - 2 k-blocks have landed
-        if (wave < kDigExtra) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kStages - 2) * (kDigLo + 1 + kBmPieces / WAVES)) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kStages - 2) * (kDigLo + kBmPieces / WAVES)) : "memory");
-    };
-#pragma unroll
-    for (int st = 0; st < kStages - 1; ++st) stage(kb0 + st, st);
-    wait_next();
-    __syncthreads();
-    for (int64_t kb = kb0; kb < kb1; ++kb) {
-        const int st = (int)((kb - kb0) % kStages);
-        stage(kb + kStages - 1, (int)((kb - kb0 + kStages - 1) % kStages));
-        v4i a[RT];
-#pragma unroll
-        for (int t = 0; t < RT; ++t) {
-            const uint64_t w = lds_b[st][(wave * RT + t) * 16 + r];
-            a[t] = bp_expand16((unsigned)(w >> (16 * g)) & 0xffffu);
-        }
-#pragma unroll
-        for (int c = 0; c < NCB; ++c)
-#pragma unroll
-            for (int d = 0; d < kBpDigits; ++d) {
-                const v4i b = lds_d[st][(c * kBpDigits + d) * 64 + lane];
-#pragma unroll
-                for (int t = 0; t < RT; ++t) acc[t][c][d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[t], b, acc[t][c][d], 0, 0, 0);
-            }
-        wait_next();
-        __syncthreads();
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // (the copies issued past the end)
-    // C/D layout: column = lane & 15, row = (lane >> 4) * 4 + reg
-    const int64_t tile0 = tileb + (int64_t)wave * RT;
+            for (int i = 0; i < 16; ++i) acc[t][c][i] = 0;
+    const v4i* bmp[RT];
 #pragma unroll
     for (int t = 0; t < RT; ++t) {
-        if (tile0 + t >= ntile) continue;
+        const int64_t tile = tile0 + t < a.ntile ? tile0 + t : a.ntile - 1;
+        bmp[t] = a.bm + tile * a.SKstride * 64 + (lane & 31) * 2 + (lane >> 5);       // lane (h, r) reads word r*2 + h
+    }
+    auto stage = [&](int sk, int st) {                           // (a stage past the end re-reads the last one: harmless, same count)
+        const int k = sk < sk1 ? sk : sk1 - 1;
 #pragma unroll
-        for (int c = 0; c < NCB; ++c)
+        for (int u = 0; u <= kLo; ++u) {
+            const int piece = u * kBpWaves + wave;
+            if (u < kLo || wave < kExtra)                         // (wave-uniform)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.qd + (int64_t)k * kVecs + piece * 64 + lane),
+                                                 (__attribute__((address_space(3))) void*)(lds + st * kVecs + piece * 64), 16, 0, 0);
+        }
+    };
+    auto bits = [&](int sk, v4i (&w)[RT]) {
+        const int k = sk < sk1 ? sk : sk1 - 1;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int64_t row = (tile0 + t) * 16 + g * 4 + q;
-                if (row >= nrows) continue;
-                v4i o;
+        for (int t = 0; t < RT; ++t) w[t] = bmp[t][(int64_t)k * 64];
+    };
+    v4i w0[RT], w1[RT];
+    bits(sk0, w0);
+    stage(sk0, 0);
+    stage(sk0 + 1, 1);
+#pragma unroll 1
+    for (int sk = sk0; sk < sk1; ++sk) {
+        const int it = sk - sk0;
+        // the copies of stage sk have landed: all but the newest stage's copies are complete (a wave's memory operations complete in
+        // issue order; the bit loads were issued before those copies)
+        if (wave < kExtra) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kLo + 1) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kLo) : "memory");
+        __syncthreads();                                          // ... for every wave; and everybody is done with stage sk - 1's buffer
+        bits(sk + 1, w1);
+        stage(sk + 2, (it + 2) % kBpStages);
+        const v4i* cur = lds + (it % kBpStages) * kVecs + lane;
+        // operand fragments are read PF groups ahead of the MFMAs that use them
+        constexpr int PF = 2, NG = kBpSteps * NT;
+        v4i bq[PF + 1];
 #pragma unroll
-                for (int d = 0; d < kBpDigits; ++d) o[d] = acc[t][c][d][q];
-                *reinterpret_cast<v4i*>(part + (((int64_t)chunk * nrows + row) * (NCB * 16) + c * 16 + r) * kBpDigits) = o;
+        for (int p = 0; p < PF; ++p) bq[p] = cur[p * 64];
+        v4i av[RT], an[RT];
+#pragma unroll
+        for (int t = 0; t < RT; ++t) av[t] = bp_expand16((unsigned)w0[t][0] & 0xffffu);
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi) {
+            const int s = gi / NT, c = gi % NT;
+            if (gi + PF < NG) bq[(gi + PF) % (PF + 1)] = cur[(gi + PF) * 64];
+            if (c == 0 && s + 1 < kBpSteps) {
+#pragma unroll
+                for (int t = 0; t < RT; ++t) an[t] = bp_expand16(((unsigned)w0[t][(s + 1) >> 1] >> (16 * ((s + 1) & 1))) & 0xffffu);
             }
+            const v4i b = bq[gi % (PF + 1)];
+#pragma unroll
+            for (int t = 0; t < RT; ++t) acc[t][c] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[t], b, acc[t][c], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (c == NT - 1) {
+#pragma unroll
+                for (int t = 0; t < RT; ++t) av[t] = an[t];
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < RT; ++t) w0[t] = w1[t];
     }
-}
-
-__device__ __forceinline__ double bp_value(const int32_t* __restrict__ part, int chunks, int64_t nrows, int64_t row, int ncols, int col, double cmax) {
-    long long V = 0;
-    for (int ch = 0; ch < chunks; ++ch) {
-        const v4i p = *reinterpret_cast<const v4i*>(part + (((int64_t)ch * nrows + row) * ncols + col) * kBpDigits);
-        V += (long long)p[0] + ((long long)p[1] << 8) + ((long long)p[2] << 16) + ((long long)p[3] << 24);     // integers: exact in any order
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // (the copies issued past the end)
+    __syncthreads();                                              // the stage buffers become the epilogue's scratch
+    // Epilogue.  C/D layout of the 32 x 32 tile: column n = lane & 31, register i holds row (i / 4) * 8 + (lane >> 5) * 4 + (i % 4).
+    // A band of 8 rows (registers 4b .. 4b+3 of both lane halves) goes through this wave's LDS scratch as int32 [8][F + 4]; every lane
+    // then recombines the ND digits of its (row, column) outputs: V = sum_d 256^d S_d, an exact float64 integer.
+    constexpr int F = NT * 32, FS = F + 4;
+    int32_t* scr = reinterpret_cast<int32_t*>(bp_smem) + wave * (8 * FS);
+    const int n = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+        const int64_t tile = tile0 + t;
+        if (tile >= a.ntile) continue;                            // (wave-uniform)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+#pragma unroll
+            for (int c = 0; c < NT; ++c)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) scr[(hh * 4 + q) * FS + c * 32 + n] = acc[t][c][b * 4 + q];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (int o = lane; o < 8 * a.L; o += 64) {
+                const int rr = o / a.L, col = o - rr * a.L;
+                const int32_t* dp = scr + rr * FS + col * ND;
+                double V = (double)dp[ND - 1];
+#pragma unroll
+                for (int d = ND - 2; d >= 0; --d) V = V * 256.0 + (double)dp[d];      // exact: integers below 2^53
+                const double val = V * a.cscale[col];                                // a power of two: exact
+                const int64_t pr = tile * 32 + b * 8 + rr;
+                if (ROWS) {
+                    const int64_t row = bp_row_of(pr, a.Npad, a.N, a.M);
+                    if (row >= 0) a.out[row * a.L + col] = a.srow[row] * val;
+                } else if (pr < a.nOut) {
+                    a.out[((int64_t)chunk * a.nOut + pr) * a.L + col] = val;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
     }
-    return ldexp((double)V, -bp_shift(cmax));
-}
-
-// A Q:   Y[i][c] += s_i S[i][c] for the original rows (the sparse kernel left the other entries' sum minus the centring term there);
-//        Y32 = the float32 copy [. x ld] the A^T Y pass gathers (zero in the padding columns)
-__global__ void k_bp_combine_rows(const int32_t* __restrict__ part, int chunks, int64_t N, int NCB, int L, int ld, const double* __restrict__ cmax,
-                                  const double* __restrict__ srow, double* __restrict__ Y, float* __restrict__ Y32) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= N * ld) return;
-    const int64_t i = t / ld;
-    const int c = (int)(t - i * ld);
-    double y = 0.0;
-    if (c < L) {
-        y = Y[i * L + c] + srow[i] * bp_value(part, chunks, N, i, NCB * 16, c, cmax[c]);
-        Y[i * L + c] = y;
-    }
-    if (Y32) Y32[t] = (float)y;
-}
-
-// A^T Y:  W1[j][c] = S[j][c]   ([H x L] float64; k_sum_panels adds it to the sparse kernels' panel sums)
-__global__ void k_bp_combine_cols(const int32_t* __restrict__ part, int chunks, int64_t nrows_pad, int32_t H, int NCB, int L, const double* __restrict__ cmax,
-                                  double* __restrict__ out) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (int64_t)H * L) return;
-    const int64_t j = t / L;
-    const int c = (int)(t - j * L);
-    out[t] = bp_value(part, chunks, nrows_pad, j, NCB * 16, c, cmax[c]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -315,8 +381,45 @@ __global__ void k_bp_combine_cols(const int32_t* __restrict__ part, int chunks, 
 // ------------------------------------------------------------------------------------------------
 static size_t bp_align(size_t v) { return (v + 255) & ~(size_t)255; }
 
-// Builds the bitmaps and the reduced structures of the original cells' rows from the resident counts and their
-// column-major mirror.  Once per fit and context (ctx->bp.ready).
+static int bp_launch_bitmaps(ddx_ctx* ctx, int64_t tile0, int64_t ntiles) {
+    BitPlanes& bp = ctx->bp;
+    if (ntiles <= 0) return DDX_OK;
+    const int sk_chunk = std::min(bp.SKc, 48);                    // 32 rows x 48 stages x 32 bytes = 48 KB of LDS
+    k_bp_rows_bitmap<<<(unsigned)ntiles, 256, (size_t)32 * sk_chunk * 32, ctx->stream>>>(ctx->aug_indptr.as<int64_t>(), ctx->aug_indices.as<int32_t>(),
+                                                                                        ctx->aug_raw.as<float>(), tile0, bp.Npad, ctx->N, ctx->M, bp.SKc, sk_chunk, reinterpret_cast<v4i*>(bp.bm_rows));
+    const int64_t nblk_r = ntiles / 2 + (ntiles & 1);             // 64-row blocks (tile0 is even: Npad is a multiple of 256)
+    const int64_t nblk = nblk_r * bp.SKc * 4;
+    k_bp_transpose<<<(unsigned)ceil_div(nblk, 4), 256, 0, ctx->stream>>>(reinterpret_cast<const v4i*>(bp.bm_rows), tile0 * 32, nblk_r, bp.SKc, bp.SKr, (int32_t)(bp.ntile_c * 32),
+                                                                         reinterpret_cast<v4i*>(bp.bm_cols));
+    return DDX_OK;
+}
+
+// flags -> scan -> compaction of n entries (raw values `raw`, indices `idx`); returns the kept count in *kept (synchronises)
+static int bp_reduce(ddx_ctx* ctx, const float* raw, const int32_t* idx, const float* x, int64_t n, int32_t* idx_out, int32_t* pos_out, float* x_out,
+                     int64_t cap_out, int32_t* kept, bool count_only, int32_t** scan_out) {
+    DDX_TRY(ensure(ctx, ctx->sort_keys_in, sizeof(int32_t) * (size_t)(n + 1)));
+    DDX_TRY(ensure(ctx, ctx->sort_keys_out, sizeof(int32_t) * (size_t)(n + 1)));
+    int32_t* flag = ctx->sort_keys_in.as<int32_t>();
+    int32_t* scan = ctx->sort_keys_out.as<int32_t>();
+    size_t tmp = 0;
+    DDX_HIP(ctx, prim::exclusive_sum(nullptr, tmp, flag, scan, (size_t)(n + 1), ctx->stream));
+    DDX_TRY(ensure(ctx, ctx->sort_tmp, tmp));
+    const unsigned ge = (unsigned)ceil_div(n + 1, 256);
+    k_bp_flags<<<ge, 256, 0, ctx->stream>>>(raw, n, flag);
+    DDX_HIP(ctx, prim::exclusive_sum(ctx->sort_tmp.p, tmp, flag, scan, (size_t)(n + 1), ctx->stream));
+    if (scan_out) *scan_out = scan;
+    if (count_only) {
+        DDX_HIP(ctx, hipMemcpyAsync(kept, scan + n, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return DDX_OK;
+    }
+    (void)cap_out;
+    k_bp_compact<<<ge, 256, 0, ctx->stream>>>(flag, scan, idx, x, n, idx_out, pos_out, x_out);
+    return DDX_OK;
+}
+
+// Builds what lasts for a fit: the geometry, the original cells' bitmaps (by rows and by columns) and the reduced structures of
+// their other entries (with positions in the full arrays, for the per-iteration value refresh).  Once per fit and context.
 int bp_build(ddx_ctx* ctx) {
     BitPlanes& bp = ctx->bp;
     if (bp.ready) return DDX_OK;
@@ -324,60 +427,65 @@ int bp_build(ddx_ctx* ctx) {
     const int32_t H = ctx->H;
     const int64_t nnz = ctx->nnz;
     ScopedTimer t(ctx, "bitplane_build");
-    bp.KBc = (int)ceil_div(H, 64);
-    bp.KBr = ceil_div(N, 64);
-    bp.ntile_r = ceil_div(N, 16);
-    bp.ntile_c = ceil_div(H, 16);
+    bp.SKc = (int)ceil_div(H, kBpStageCols);
+    bp.Npad = ceil_div(N, kBpStageCols) * kBpStageCols;
+    bp.ntile_o = bp.Npad / 32;
+    const int64_t Scap = N / 2 + 2;                               // room for the synthetic rows (grows on demand in bp_refresh)
+    bp.cap_rows = bp.Npad + ceil_div(Scap, kBpStageCols) * kBpStageCols;
+    bp.ntile_c = ceil_div(H, 32);
     const int64_t nseg = (int64_t)ctx->P_o * H;                   // (panel, column) segments of the originals' mirror
-    // pass 1: flags + scans (scratch in sort_keys_in / sort_keys_out), totals to the host
-    DDX_TRY(ensure(ctx, ctx->sort_keys_in, sizeof(int32_t) * (size_t)(nnz + 1)));
-    DDX_TRY(ensure(ctx, ctx->sort_keys_out, sizeof(int32_t) * (size_t)(nnz + 1)));
-    int32_t* flag = ctx->sort_keys_in.as<int32_t>();
-    int32_t* scan = ctx->sort_keys_out.as<int32_t>();
-    size_t tmp = 0;
-    DDX_HIP(ctx, prim::exclusive_sum(nullptr, tmp, flag, scan, (size_t)(nnz + 1), ctx->stream));
-    DDX_TRY(ensure(ctx, ctx->sort_tmp, tmp));
-    const unsigned ge = (unsigned)ceil_div(nnz + 1, 256);
+    // pass 1: how many entries other than 1
     int32_t total_r = 0, total_m = 0;
-    // row-major
-    k_bp_flags<<<ge, 256, 0, ctx->stream>>>(ctx->aug_raw.as<float>(), nnz, flag);
-    DDX_HIP(ctx, prim::exclusive_sum(ctx->sort_tmp.p, tmp, flag, scan, (size_t)(nnz + 1), ctx->stream));
-    DDX_HIP(ctx, hipMemcpyAsync(&total_r, scan + nnz, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    bp.nrest = total_r;
-    // one buffer for everything that lives as long as the fit
+    int32_t* scan = nullptr;
+    DDX_TRY(bp_reduce(ctx, ctx->aug_raw.as<float>(), nullptr, nullptr, nnz, nullptr, nullptr, nullptr, 0, &total_r, true, &scan));
+    bp.nrest_o = total_r;
+    bp.cap_rest_s = std::max<int64_t>(ctx->cap_synth / 3, 1024);   // (a synthetic row keeps ~15 % of its entries; grows on demand)
+    // one buffer for everything that lasts for the fit
     size_t off = 0;
     auto carve = [&](size_t bytes) { const size_t o = off; off += bp_align(bytes); return o; };
-    const size_t o_bmr = carve(sizeof(uint64_t) * (size_t)bp.ntile_r * bp.KBc * 16), o_bmc = carve(sizeof(uint64_t) * (size_t)bp.ntile_c * bp.KBr * 16);
-    const size_t o_rip = carve(sizeof(int64_t) * (size_t)(N + 1)), o_rc = carve(sizeof(int32_t) * (size_t)total_r), o_rp = carve(sizeof(int32_t) * (size_t)total_r);
-    const size_t o_rx = carve(sizeof(float) * (size_t)total_r + 256);
-    const size_t o_mcp = carve(sizeof(int64_t) * (size_t)(nseg + 1)), o_mr = carve(sizeof(int32_t) * (size_t)total_r), o_mp = carve(sizeof(int32_t) * (size_t)total_r);
-    const size_t o_mx = carve(sizeof(float) * (size_t)total_r + 256), o_s = carve(sizeof(double) * (size_t)N);
+    const int64_t ntile_all = bp.cap_rows / 32, SKr_cap = bp.cap_rows / kBpStageCols;
+    bp.SKr_cap = SKr_cap;
+    const size_t o_bmr = carve(sizeof(v4i) * (size_t)ntile_all * bp.SKc * 64), o_bmc = carve(sizeof(v4i) * (size_t)bp.ntile_c * SKr_cap * 64);
+    const int64_t cap_rest = total_r + bp.cap_rest_s;
+    const size_t o_rip = carve(sizeof(int64_t) * (size_t)(N + Scap + 2)), o_rc = carve(sizeof(int32_t) * (size_t)cap_rest + 256), o_rx = carve(sizeof(float) * (size_t)cap_rest + 256);
+    const size_t o_rp = carve(sizeof(int32_t) * (size_t)total_r + 256);
+    const size_t o_mcp = carve(sizeof(int64_t) * (size_t)(nseg + 1)), o_mr = carve(sizeof(int32_t) * (size_t)total_r + 256), o_mp = carve(sizeof(int32_t) * (size_t)total_r + 256);
+    const size_t o_mx = carve(sizeof(float) * (size_t)total_r + 256), o_s = carve(sizeof(double) * (size_t)(N + Scap + 2));
     DDX_TRY(ensure(ctx, ctx->bp_buf, off));
     char* b = ctx->bp_buf.as<char>();
-    bp.bm_rows = reinterpret_cast<uint64_t*>(b + o_bmr);
-    bp.bm_cols = reinterpret_cast<uint64_t*>(b + o_bmc);
+    bp.bm_rows = b + o_bmr;
+    bp.bm_cols = b + o_bmc;
     bp.rest_indptr = reinterpret_cast<int64_t*>(b + o_rip);
     bp.rest_cols = reinterpret_cast<int32_t*>(b + o_rc);
-    bp.rest_pos = reinterpret_cast<int32_t*>(b + o_rp);
     bp.rest_x = reinterpret_cast<float*>(b + o_rx);
+    bp.rest_pos = reinterpret_cast<int32_t*>(b + o_rp);
     bp.restm_colptr = reinterpret_cast<int64_t*>(b + o_mcp);
     bp.restm_row = reinterpret_cast<int32_t*>(b + o_mr);
     bp.restm_pos = reinterpret_cast<int32_t*>(b + o_mp);
     bp.restm_x = reinterpret_cast<float*>(b + o_mx);
     bp.srow = reinterpret_cast<double*>(b + o_s);
-    k_bp_compact<<<ge, 256, 0, ctx->stream>>>(flag, scan, ctx->aug_indices.as<int32_t>(), nnz, bp.rest_cols, bp.rest_pos);
-    k_bp_pointers<<<(unsigned)ceil_div(N + 1, 256), 256, 0, ctx->stream>>>(ctx->aug_indptr.as<int64_t>(), N + 1, scan, bp.rest_indptr);
+    bp.cap_srow = N + Scap + 2;
+    bp.cap_rest = cap_rest;
+    // the column bitmap's padding (rows between N and Npad, columns past H) must read as zeros; the synthetic stages are rewritten every iteration
+    DDX_HIP(ctx, hipMemsetAsync(bp.bm_cols, 0, sizeof(v4i) * (size_t)bp.ntile_c * SKr_cap * 64, ctx->stream));
+    DDX_HIP(ctx, hipMemsetAsync(bp.bm_rows, 0, sizeof(v4i) * (size_t)ntile_all * bp.SKc * 64, ctx->stream));
+    const unsigned ge = (unsigned)ceil_div(nnz + 1, 256);
+    int32_t* flag = ctx->sort_keys_in.as<int32_t>();
+    // row-major (the scan of pass 1 is still in place)
+    k_bp_compact<<<ge, 256, 0, ctx->stream>>>(flag, scan, ctx->aug_indices.as<int32_t>(), nullptr, nnz, bp.rest_cols, bp.rest_pos, nullptr);
+    k_bp_pointers<<<(unsigned)ceil_div(N + 1, 256), 256, 0, ctx->stream>>>(ctx->aug_indptr.as<int64_t>(), N + 1, 0, scan, 0, bp.rest_indptr);
     // column-major mirror (same entries in (panel, column, row) order)
-    k_bp_flags<<<ge, 256, 0, ctx->stream>>>(ctx->csc_o_raw.as<float>(), nnz, flag);
-    DDX_HIP(ctx, prim::exclusive_sum(ctx->sort_tmp.p, tmp, flag, scan, (size_t)(nnz + 1), ctx->stream));
+    DDX_TRY(bp_reduce(ctx, ctx->csc_o_raw.as<float>(), ctx->csc_o_row.as<int32_t>(), nullptr, nnz, bp.restm_row, bp.restm_pos, nullptr, total_r, &total_m, false, &scan));
     DDX_HIP(ctx, hipMemcpyAsync(&total_m, scan + nnz, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    k_bp_compact<<<ge, 256, 0, ctx->stream>>>(flag, scan, ctx->csc_o_row.as<int32_t>(), nnz, bp.restm_row, bp.restm_pos);
-    k_bp_pointers<<<(unsigned)ceil_div(nseg + 1, 256), 256, 0, ctx->stream>>>(ctx->csc_o_colptr.as<int64_t>(), nseg + 1, scan, bp.restm_colptr);
-    // bitmaps
-    k_bp_rows_bitmap<<<(unsigned)ceil_div(bp.ntile_r * bp.KBc * 16, 256), 256, 0, ctx->stream>>>(ctx->aug_indptr.as<int64_t>(), ctx->aug_indices.as<int32_t>(),
-                                                                                                ctx->aug_raw.as<float>(), N, bp.KBc, bp.bm_rows);
-    k_bp_transpose<<<(unsigned)ceil_div(bp.KBr * bp.KBc, 4), 256, 0, ctx->stream>>>(bp.bm_rows, N, H, bp.KBc, bp.KBr, bp.bm_cols);
+    k_bp_pointers<<<(unsigned)ceil_div(nseg + 1, 256), 256, 0, ctx->stream>>>(ctx->csc_o_colptr.as<int64_t>(), nseg + 1, 0, scan, 0, bp.restm_colptr);
+    // bitmaps of the original rows.  SKr is provisional (no synthetic rows yet): the layout of the column bitmap uses the CAPACITY
+    bp.SKr = bp.SKr_cap;
+    const int64_t M_keep = ctx->M;
+    ctx->M = ctx->N;                                              // (bp_row_of: no synthetic rows in this pass)
+    DDX_TRY(allow_dynamic_lds(ctx, reinterpret_cast<const void*>(&k_bp_rows_bitmap), 64 * 1024));
+    const int rc = bp_launch_bitmaps(ctx, 0, bp.ntile_o);
+    ctx->M = M_keep;
+    DDX_TRY(rc);
     DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     DDX_HIP(ctx, hipGetLastError());
     if (total_m != total_r) return set_err(ctx, DDX_E_NUMERIC, "bit planes: the mirror holds %d entries other than 1, the rows %d", total_m, total_r);
@@ -386,82 +494,159 @@ int bp_build(ddx_ctx* ctx) {
     return DDX_OK;
 }
 
-// values of this iteration's matrix for the reduced structures (after ddx_lognormalise)
+// What changes with the iteration: the synthetic rows' bitmaps and reduced structures (rows and mirror), the reduced values of the
+// original rows, the row scales.  After ddx_lognormalise.
 int bp_refresh(ddx_ctx* ctx) {
     BitPlanes& bp = ctx->bp;
     if (bp.values) return DDX_OK;
+    const int64_t N = ctx->N, M = ctx->M, S = ctx->S;
+    const int32_t H = ctx->H;
     ScopedTimer t(ctx, "bitplane_values");
-    if (bp.nrest > 0) {
-        const unsigned g = (unsigned)ceil_div(bp.nrest, 256);
-        k_bp_gather<<<g, 256, 0, ctx->stream>>>(ctx->aug_x.as<float>(), bp.rest_pos, bp.nrest, bp.rest_x);
-        k_bp_gather<<<g, 256, 0, ctx->stream>>>(ctx->csc_o_x.as<float>(), bp.restm_pos, bp.nrest, bp.restm_x);
+    if (bp.Npad + ceil_div(S, kBpStageCols) * kBpStageCols > bp.cap_rows || M + 2 > bp.cap_srow) {
+        // more synthetic rows than planned for (boost_rate > 0.5): start over with a larger plan
+        return set_err(ctx, DDX_E_UNSUPPORTED, "bit planes: %lld synthetic rows exceed the planned capacity", (long long)S);
     }
-    k_bp_row_scale<<<(unsigned)ceil_div(ctx->N, 256), 256, 0, ctx->stream>>>(ctx->lognorm_tab.as<float>(), 16, ctx->zvalue, ctx->N, bp.srow);
+    bp.ntile_s = ceil_div(S, 32);
+    bp.ntile_s += bp.ntile_s & 1;                                 // whole 64-row blocks for the transpose
+    bp.SKr = bp.SKr_cap;
+    bp.SKr_used = bp.Npad / kBpStageCols + ceil_div(S, kBpStageCols);
+    // reduced values of the original rows
+    if (bp.nrest_o > 0) {
+        const unsigned g = (unsigned)ceil_div(bp.nrest_o, 256);
+        k_bp_gather<<<g, 256, 0, ctx->stream>>>(ctx->aug_x.as<float>(), bp.rest_pos, bp.nrest_o, bp.rest_x);
+        k_bp_gather<<<g, 256, 0, ctx->stream>>>(ctx->csc_o_x.as<float>(), bp.restm_pos, bp.nrest_o, bp.restm_x);
+    }
+    k_bp_row_scale<<<(unsigned)ceil_div(M, 256), 256, 0, ctx->stream>>>(ctx->lognorm_tab.as<float>(), 16, ctx->zvalue, M, bp.srow);
+    bp.nrest_s = 0;
+    if (S > 0) {
+        // synthetic rows: reduced CSR behind the original rows' (one array, one row pointer over all M rows)
+        const int64_t e0 = ctx->nnz;
+        const int64_t n_s = ctx->nnz_aug - e0;                     // (read back by ddx_lognormalise)
+        int32_t kept = 0;
+        int32_t* scan = nullptr;
+        DDX_TRY(bp_reduce(ctx, ctx->aug_raw.as<float>() + e0, nullptr, nullptr, n_s, nullptr, nullptr, nullptr, 0, &kept, true, &scan));
+        if (kept > bp.cap_rest_s) return set_err(ctx, DDX_E_UNSUPPORTED, "bit planes: %d reduced synthetic entries exceed the planned %lld", kept, (long long)bp.cap_rest_s);
+        bp.nrest_s = kept;
+        const unsigned ge = (unsigned)ceil_div(n_s + 1, 256);
+        int32_t* flag = ctx->sort_keys_in.as<int32_t>();
+        k_bp_compact<<<ge, 256, 0, ctx->stream>>>(flag, scan, ctx->aug_indices.as<int32_t>() + e0, ctx->aug_x.as<float>() + e0, n_s, bp.rest_cols + bp.nrest_o, nullptr,
+                                                  bp.rest_x + bp.nrest_o);
+        k_bp_pointers<<<(unsigned)ceil_div(S + 1, 256), 256, 0, ctx->stream>>>(ctx->aug_indptr.as<int64_t>() + N, S + 1, e0, scan, bp.nrest_o, bp.rest_indptr + N);
+        // reduced mirror of the synthetic rows (its own arrays, sized for the iteration)
+        const int64_t nseg_s = (int64_t)(ctx->P_s > 0 ? ctx->P_s : 1) * H;
+        size_t off = 0;
+        auto carve = [&](size_t bytes) { const size_t o = off; off += bp_align(bytes); return o; };
+        const size_t o_cp = carve(sizeof(int64_t) * (size_t)(nseg_s + 1)), o_r = carve(sizeof(int32_t) * (size_t)kept + 256), o_x = carve(sizeof(float) * (size_t)kept + 256);
+        DDX_TRY(ensure(ctx, ctx->bp_synth, off));
+        char* b = ctx->bp_synth.as<char>();
+        bp.restm_s_colptr = reinterpret_cast<int64_t*>(b + o_cp);
+        bp.restm_s_row = reinterpret_cast<int32_t*>(b + o_r);
+        bp.restm_s_x = reinterpret_cast<float*>(b + o_x);
+        int32_t kept_m = 0;
+        DDX_TRY(bp_reduce(ctx, ctx->csc_s_raw.as<float>(), ctx->csc_s_row.as<int32_t>(), ctx->csc_s_x.as<float>(), n_s, bp.restm_s_row, nullptr, bp.restm_s_x, kept, &kept_m,
+                          false, &scan));
+        k_bp_pointers<<<(unsigned)ceil_div(nseg_s + 1, 256), 256, 0, ctx->stream>>>(ctx->csc_s_colptr.as<int64_t>(), nseg_s + 1, 0, scan, 0, bp.restm_s_colptr);
+        // bitmaps of the synthetic rows (tiles behind the padded originals)
+        DDX_TRY(bp_launch_bitmaps(ctx, bp.ntile_o, bp.ntile_s));
+    }
+    DDX_HIP(ctx, hipGetLastError());
     bp.values = true;
     return DDX_OK;
 }
 
-constexpr int kBpRT = 4, kBpWaves = 8;   // 64 bitmap rows per wave, 512 per workgroup
-constexpr int kBpColChunks = 12;         // the A^T Y product splits the rows (its k dimension) over this many workgroups per column block
-
-static int bp_workspace(ddx_ctx* ctx, int NCB) {
+static int bp_workspace(ddx_ctx* ctx, int NT, int chunks) {
     BitPlanes& bp = ctx->bp;
-    const int64_t KBmax = std::max<int64_t>(bp.KBc, bp.KBr);
-    const size_t dig = bp_align(sizeof(v4i) * (size_t)KBmax * NCB * kBpDigits * 64);
-    const size_t prt = bp_align(sizeof(int32_t) * (size_t)std::max<int64_t>(ctx->N, (int64_t)kBpColChunks * bp.ntile_c * 16) * NCB * 16 * kBpDigits);
-    const size_t need = dig + bp_align(sizeof(double) * 64) + prt + bp_align(sizeof(double) * (size_t)ctx->H * 64);
+    const int64_t SKmax = std::max<int64_t>(bp.SKc, bp.SKr_cap);
+    const size_t dig = bp_align(sizeof(v4i) * (size_t)SKmax * kBpSteps * NT * 64);
+    const size_t prt = bp_align(sizeof(double) * (size_t)chunks * ctx->H * 64);
+    const size_t need = dig + bp_align(sizeof(double) * 128) + prt;
     DDX_TRY(ensure(ctx, ctx->bp_work, need));
     char* b = ctx->bp_work.as<char>();
     bp.qd = b;
     bp.cmax = reinterpret_cast<double*>(b + dig);
-    bp.part = reinterpret_cast<int32_t*>(b + dig + bp_align(sizeof(double) * 64));
-    bp.w1 = reinterpret_cast<double*>(b + dig + bp_align(sizeof(double) * 64) + prt);
+    bp.cscale = bp.cmax + 64;
+    bp.part = reinterpret_cast<double*>(b + dig + bp_align(sizeof(double) * 128));
     return DDX_OK;
 }
 
-template <int NCB>
-static void bp_launch(ddx_ctx* ctx, const uint64_t* bm, const v4i* qd, int64_t ntile, int64_t KB, int chunks, int per, int64_t nrows, int32_t* part) {
-    const dim3 grid((unsigned)ceil_div(ntile, kBpRT * kBpWaves), (unsigned)chunks);
-    k_bp_product<kBpRT, kBpWaves, NCB><<<grid, 64 * kBpWaves, 0, ctx->stream>>>(bm, qd, ntile, KB, per, nrows, part);
+template <int RT, int NT, int ND, bool ROWS>
+static int bp_launch_t(ddx_ctx* ctx, const BpProductArgs& a, int chunks) {
+    const size_t lds = (size_t)kBpStages * kBpSteps * NT * 64 * 16;
+    DDX_TRY(allow_dynamic_lds(ctx, reinterpret_cast<const void*>(&k_bp_product<RT, NT, ND, ROWS>), (int)lds));
+    const dim3 grid((unsigned)ceil_div(a.ntile, kBpWaves * RT), (unsigned)chunks);
+    k_bp_product<RT, NT, ND, ROWS><<<grid, 64 * kBpWaves, lds, ctx->stream>>>(a);
+    return DDX_OK;
 }
 
-static void bp_product(ddx_ctx* ctx, int NCB, const uint64_t* bm, const v4i* qd, int64_t ntile, int64_t KB, int chunks, int per, int64_t nrows, int32_t* part) {
-    if (NCB == 1) bp_launch<1>(ctx, bm, qd, ntile, KB, chunks, per, nrows, part);
-    else if (NCB == 2) bp_launch<2>(ctx, bm, qd, ntile, KB, chunks, per, nrows, part);
-    else if (NCB == 3) bp_launch<3>(ctx, bm, qd, ntile, KB, chunks, per, nrows, part);
-    else bp_launch<4>(ctx, bm, qd, ntile, KB, chunks, per, nrows, part);
+template <bool ROWS>
+static int bp_launch(ddx_ctx* ctx, const BpProductArgs& a, int chunks, int ND, int RT) {
+    if (ND == 3) return RT == 1 ? bp_launch_t<1, 4, 3, ROWS>(ctx, a, chunks) : bp_launch_t<2, 4, 3, ROWS>(ctx, a, chunks);
+    return RT == 1 ? bp_launch_t<1, 5, 4, ROWS>(ctx, a, chunks) : bp_launch_t<2, 5, 4, ROWS>(ctx, a, chunks);
 }
 
-// Y[i][:] += s_i (B Q)[i][:] for the original cells' rows i < N; Y32 (may be null): the float32 copy [M x ld] refreshed for those rows
-int bp_rows_product(ddx_ctx* ctx, const double* Q, int L, int ld, double* Y, float* Y32) {
+// tiles per wave: the geometry that fills the GPU's 256 compute units better over whole rounds of workgroups
+static int bp_pick_rt(int64_t ntile, int chunks) {
+    double best = -1.0;
+    int pick = 2;
+    for (int rt = 2; rt >= 1; --rt) {
+        const int64_t wgs = ceil_div(ntile, kBpWaves * rt) * chunks;
+        const double rounds = (double)ceil_div(wgs, 256);
+        const double eff = (double)ntile * chunks / (rounds * 256.0 * kBpWaves * rt) * (rt == 2 ? 1.0 : 0.93);     // (one tile per wave re-reads every operand fragment: slower per tile)
+        if (eff > best) { best = eff; pick = rt; }
+    }
+    return pick;
+}
+
+// Y[i][:] = s_i (B Q)[i][:] for every row i of the augmented matrix (plain stores: the sparse product that follows adds its part)
+int bp_rows_product(ddx_ctx* ctx, const double* Q, int L, double* Y) {
     BitPlanes& bp = ctx->bp;
-    const int NCB = (ld + 15) / 16;
-    DDX_TRY(bp_workspace(ctx, NCB));
+    const int ND = ctx->opt.bp_digits == 4 ? 4 : 3;
+    const int NT = ND == 3 ? 4 : 5;
+    DDX_TRY(bp_workspace(ctx, NT, 1));
     v4i* qd = reinterpret_cast<v4i*>(bp.qd);
+    ScopedTimer t(ctx, "bitplane_rows");
     DDX_HIP(ctx, hipMemsetAsync(bp.cmax, 0, sizeof(double) * 64, ctx->stream));
     k_bp_colmax<<<(unsigned)std::min<int64_t>(256, ceil_div(ctx->H, 64)), 256, 0, ctx->stream>>>(Q, nullptr, ctx->H, L, bp.cmax);
-    k_bp_digits<<<(unsigned)ceil_div((int64_t)bp.KBc * NCB * 64, 256), 256, 0, ctx->stream>>>(Q, nullptr, ctx->H, L, NCB, bp.cmax, bp.KBc, qd);
-    bp_product(ctx, NCB, bp.bm_rows, qd, bp.ntile_r, bp.KBc, 1, bp.KBc, ctx->N, bp.part);
-    k_bp_combine_rows<<<(unsigned)ceil_div(ctx->N * ld, 256), 256, 0, ctx->stream>>>(bp.part, 1, ctx->N, NCB, L, ld, bp.cmax, bp.srow, Y, Y32);
-    return DDX_OK;
+    k_bp_scales<<<1, 64, 0, ctx->stream>>>(bp.cmax, L, ND, bp.cscale);
+    const int nslot = (NT * 32 + ND - 1) / ND;
+    const int64_t nthreads = (int64_t)bp.SKc * kBpSteps * 2 * nslot;
+    if (ND == 3) k_bp_digits<3, false><<<(unsigned)ceil_div(nthreads, 256), 256, 0, ctx->stream>>>(Q, nullptr, ctx->H, L, NT, nslot, bp.cmax, bp.SKc, 0, 0, qd);
+    else k_bp_digits<4, false><<<(unsigned)ceil_div(nthreads, 256), 256, 0, ctx->stream>>>(Q, nullptr, ctx->H, L, NT, nslot, bp.cmax, bp.SKc, 0, 0, qd);
+    BpProductArgs a{};
+    a.bm = reinterpret_cast<const v4i*>(bp.bm_rows); a.qd = qd; a.ntile = bp.ntile_o + bp.ntile_s; a.SK = bp.SKc; a.SKstride = bp.SKc; a.sk_per_chunk = bp.SKc; a.L = L;
+    a.cscale = bp.cscale;
+    a.srow = bp.srow; a.Npad = bp.Npad; a.N = ctx->N; a.M = ctx->M; a.nOut = ctx->M; a.out = Y;
+    return bp_launch<true>(ctx, a, 1, ND, bp_pick_rt(a.ntile, 1));
 }
 
-// W1[j][:] = sum over the original cells i < N of B[i][j] s_i Y[i][:]   ([H x L] float64, returned in *w1)
-int bp_cols_product(ddx_ctx* ctx, const double* Y, int L, int ld, const double** w1) {
+// partial blocks of W1[j][:] = sum over the rows i of B[i][j] s_i Y[i][:]: *chunks blocks [H x L] float64 at *part, to be added by k_sum_panels
+int bp_cols_product(ddx_ctx* ctx, const double* Y, int L, const double** part, int* chunks_out) {
     BitPlanes& bp = ctx->bp;
-    const int NCB = (ld + 15) / 16;
-    DDX_TRY(bp_workspace(ctx, NCB));
+    const int ND = ctx->opt.bp_digits == 4 ? 4 : 3;
+    const int NT = ND == 3 ? 4 : 5;
+    const int64_t SK = bp.SKr_used;
+    // chunks of the k dimension (the padded rows): enough workgroups for a whole round of the GPU
+    const int64_t wgcols = ceil_div(bp.ntile_c, kBpWaves * 2);
+    int chunks = (int)std::max<int64_t>(1, std::min<int64_t>(SK, 256 / std::max<int64_t>(1, wgcols)));
+    const int per = (int)ceil_div(SK, chunks);
+    chunks = (int)ceil_div(SK, per);
+    DDX_TRY(bp_workspace(ctx, NT, chunks));
     v4i* qd = reinterpret_cast<v4i*>(bp.qd);
+    ScopedTimer t(ctx, "bitplane_cols");
     DDX_HIP(ctx, hipMemsetAsync(bp.cmax, 0, sizeof(double) * 64, ctx->stream));
-    k_bp_colmax<<<(unsigned)std::min<int64_t>(1024, ceil_div(ctx->N, 64)), 256, 0, ctx->stream>>>(Y, bp.srow, ctx->N, L, bp.cmax);
-    k_bp_digits<<<(unsigned)ceil_div(bp.KBr * NCB * 64, 256), 256, 0, ctx->stream>>>(Y, bp.srow, ctx->N, L, NCB, bp.cmax, bp.KBr, qd);
-    const int chunks = (int)std::min<int64_t>(kBpColChunks, bp.KBr);
-    const int per = (int)ceil_div(bp.KBr, chunks);
-    const int used = (int)ceil_div(bp.KBr, per);
-    const int64_t rows_pad = bp.ntile_c * 16;
-    bp_product(ctx, NCB, bp.bm_cols, qd, bp.ntile_c, bp.KBr, used, per, rows_pad, bp.part);
-    k_bp_combine_cols<<<(unsigned)ceil_div((int64_t)ctx->H * L, 256), 256, 0, ctx->stream>>>(bp.part, used, rows_pad, ctx->H, NCB, L, bp.cmax, bp.w1);
-    *w1 = bp.w1;
+    k_bp_colmax<<<(unsigned)std::min<int64_t>(1024, ceil_div(ctx->M, 64)), 256, 0, ctx->stream>>>(Y, bp.srow, ctx->M, L, bp.cmax);
+    k_bp_scales<<<1, 64, 0, ctx->stream>>>(bp.cmax, L, ND, bp.cscale);
+    const int nslot = (NT * 32 + ND - 1) / ND;
+    const int64_t nthreads = SK * kBpSteps * 2 * nslot;
+    if (ND == 3) k_bp_digits<3, true><<<(unsigned)ceil_div(nthreads, 256), 256, 0, ctx->stream>>>(Y, bp.srow, ctx->M, L, NT, nslot, bp.cmax, SK, bp.Npad, ctx->N, qd);
+    else k_bp_digits<4, true><<<(unsigned)ceil_div(nthreads, 256), 256, 0, ctx->stream>>>(Y, bp.srow, ctx->M, L, NT, nslot, bp.cmax, SK, bp.Npad, ctx->N, qd);
+    BpProductArgs a{};
+    a.bm = reinterpret_cast<const v4i*>(bp.bm_cols); a.qd = qd; a.ntile = bp.ntile_c; a.SK = (int)SK; a.SKstride = bp.SKr; a.sk_per_chunk = per; a.L = L;
+    a.cscale = bp.cscale; a.nOut = ctx->H; a.out = bp.part;
+    // (the bitmap's stage stride is the capacity SKr; the stages in use are [0, SKr_used): the chunks cover only those)
+    DDX_TRY(bp_launch<false>(ctx, a, chunks, ND, 2));
+    *part = bp.part;
+    *chunks_out = chunks;
     return DDX_OK;
 }
 

@@ -274,8 +274,7 @@ struct LdsSpmmArgs {
     const int32_t* perm;          // outputs sorted by stored entries (descending): rank -> output
     // ROWS
     const int64_t* indptr; const int32_t* cols; const float* x; const float* zcol; const int32_t* rowseg; const double* tvec;
-    // ROWS, bit-plane mode: rows < nsplit (the original cells) keep only their entries other than 1, in arrays of their own
-    const int64_t* indptr_r; const int32_t* cols_r; const float* x_r; int64_t nsplit;
+    int accumulate;               // ROWS, bit-plane mode: `out` already holds the bit-plane part of the product (k_bitplane.hip); the sparse part is added to it
     // COLS
     const int64_t* cp_o; const int32_t* row_o; const float* x_o; int P_o;
     const int64_t* cp_s; const int32_t* row_s; const float* x_s; int p_s0, P_s;
@@ -488,7 +487,7 @@ __device__ __forceinline__ void lds_round(const LdsFetch<SLOTS>& f, const int (&
 // services a ds_read_b128 -- {0-3,12-15,20-27}, {4-11,16-19,28-31} and the same + 32 -- so the lanes served in one
 // LDS cycle all read the same operand row (no bank conflicts) or the same staged entry (broadcast).  A lane holds
 // four adjacent sketch columns; with ld = 40 ten of the 16 lanes of a group work.
-template <bool ROWS, int SLOTS, bool PK, int CPL, int OWN, bool DUAL = false>
+template <bool ROWS, int SLOTS, bool PK, int CPL, int OWN>
 __global__ void __launch_bounds__(kLdsThreads) k_spmm_lds(const LdsSpmmArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     float* opS = reinterpret_cast<float*>(smem);
@@ -531,8 +530,7 @@ __global__ void __launch_bounds__(kLdsThreads) k_spmm_lds(const LdsSpmmArgs a) {
     const int64_t myout = lane < PERW ? out_index(lane) : a.nOut;
     const bool mine = myout < a.nOut;
     int64_t rowbase = 0;
-    const int reduced = (DUAL && ROWS && mine && myout < a.nsplit) ? 1 : 0;      // an original cell's row in bit-plane mode: the reduced arrays
-    if (ROWS && mine) rowbase = reduced ? a.indptr_r[myout] : a.indptr[myout];
+    if (ROWS && mine) rowbase = a.indptr[myout];
     float zmine = 0.0f;                              // COLS: z of the owned column, handed out by readlane
     if (!ROWS && mine) zmine = a.zcol[myout];
     double acc[OWN][CPL];
@@ -592,9 +590,8 @@ __global__ void __launch_bounds__(kLdsThreads) k_spmm_lds(const LdsSpmmArgs a) {
                 for (int g = 0; g < SLOTS; ++g) {
                     l[g] = __builtin_amdgcn_readlane(lo, k * SLOTS + g);
                     h[g] = __builtin_amdgcn_readlane(hi, k * SLOTS + g);
-                    const bool red = DUAL && ROWS && __builtin_amdgcn_readlane(reduced, k * SLOTS + g) != 0;
-                    ip[g] = red ? a.cols_r : sidx;
-                    xp[g] = red ? a.x_r : sx;
+                    ip[g] = sidx;
+                    xp[g] = sx;
                     const int len = h[g] - l[g];
                     maxlen = len > maxlen ? len : maxlen;
                 }
@@ -652,7 +649,8 @@ __global__ void __launch_bounds__(kLdsThreads) k_spmm_lds(const LdsSpmmArgs a) {
                 const int col = CPL * sub + c;
                 if (col < a.L) {
                     if (ROWS) {
-                        const double y = acc[k][c] - a.tvec[col];
+                        double y = acc[k][c] - a.tvec[col];
+                        if (a.accumulate) y += a.out[o * a.L + col];
                         a.out[o * a.L + col] = y;
                         if (a.out32) a.out32[o * a.ld + col] = (float)y;
                     } else {
@@ -695,14 +693,14 @@ __global__ void k_operand_copy(const double* __restrict__ in, int64_t R, int L, 
 
 // W[j,c] = sum_p Wp[p][j][c] - m_j u_c   (panels added in order)
 __global__ void k_sum_panels(const double* __restrict__ Wp, int P, int32_t H, int L, const double* __restrict__ colmean,
-                             const double* __restrict__ uvec, double* __restrict__ W, const double* __restrict__ extra = nullptr) {
+                             const double* __restrict__ uvec, double* __restrict__ W, const double* __restrict__ extra = nullptr, int nextra = 0) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (int64_t)H * L) return;
     const int64_t j = t / L;
     const int c = (int)(t - j * L);
     double s = 0.0;
     for (int p = 0; p < P; ++p) s += Wp[(int64_t)p * H * L + t];
-    if (extra) s += extra[t];                            // the bit-plane part of the product
+    for (int p = 0; p < nextra; ++p) s += extra[(int64_t)p * H * L + t];       // the bit-plane part of the product, one block per chunk of the rows
     W[t] = s - colmean[j] * uvec[c];
 }
 
@@ -1241,11 +1239,6 @@ static int lds_owners(int64_t nOut, int slots, int ld) {
 
 template <bool ROWS, int SLOTS, bool PK, int CPL, int OWN>
 static int launch_lds_t(ddx_ctx* c, const LdsSpmmArgs& a, unsigned grid, size_t lds_bytes) {
-    if (ROWS && a.nsplit > 0) {                    // bit-plane mode: the original rows read their reduced arrays
-        DDX_TRY(allow_dynamic_lds(c, reinterpret_cast<const void*>(&k_spmm_lds<ROWS, SLOTS, PK, CPL, OWN, true>), (int)kLdsBudget));
-        k_spmm_lds<ROWS, SLOTS, PK, CPL, OWN, true><<<grid, kLdsThreads, lds_bytes, c->stream>>>(a);
-        return DDX_OK;
-    }
     DDX_TRY(allow_dynamic_lds(c, reinterpret_cast<const void*>(&k_spmm_lds<ROWS, SLOTS, PK, CPL, OWN>), (int)kLdsBudget));
     k_spmm_lds<ROWS, SLOTS, PK, CPL, OWN><<<grid, kLdsThreads, lds_bytes, c->stream>>>(a);
     return DDX_OK;
@@ -1275,6 +1268,9 @@ static int apply_rows(PcaWork& w, const double* Qcol, double* Yrow) {  // A Q : 
         ScopedTimer t(c, "pca_colsum");
         wcolsum(w, Qcol, w.H, c->colmean.as<double>(), tvec);
     }
+    // Y = diag(s) B Q on the matrix cores first (a timing scope of its own); the sparse kernel then sees only the entries other
+    // than 1 and adds its part
+    if (w.lds && w.bitplane) DDX_TRY(bp_rows_product(c, Qcol, w.L, Yrow));
     ScopedTimer t(c, "spmm_rows");
     const unsigned grid = (unsigned)ceil_div(w.M, 4);
     if (w.lds) {
@@ -1302,13 +1298,13 @@ static int apply_rows(PcaWork& w, const double* Qcol, double* Yrow) {  // A Q : 
         a.z_uniform = c->scaled ? 0 : 1;              // unscaled: every column's unstored value is log(pseudocount)
         a.zval = c->zvalue;
         a.perm = c->rank_rows;
-        a.nsplit = 0;
-        if (w.bitplane) {                               // the original rows' ones are added by the bit-plane product below
-            a.indptr_r = c->bp.rest_indptr; a.cols_r = c->bp.rest_cols; a.x_r = c->bp.rest_x; a.nsplit = c->N;
+        a.accumulate = 0;
+        if (w.bitplane) {
+            a.indptr = c->bp.rest_indptr; a.cols = c->bp.rest_cols; a.x = c->bp.rest_x;
+            a.accumulate = 1;
         }
         const size_t lds_bytes = (size_t)a.SR * a.ld * 4 + (size_t)((a.SR + 3) & ~3) * 4 + lds_stage_bytes(slots, lds_packed());
         DDX_TRY(launch_lds<true>(c, a, slots, (unsigned)a.owners, lds_bytes));
-        if (w.bitplane) DDX_TRY(bp_rows_product(c, Qcol, w.L, a.ld, Yrow, a.out32));
         return DDX_OK;
     }
     if (w.gather32) {
@@ -1336,6 +1332,9 @@ static int apply_cols(PcaWork& w, const double* Yrow, double* Wcol) {  // A^T Y 
     const int P = (int)ceil_div(w.M, c->panel_rows);
     const int groups = (w.H + 3) / 4;
     const int64_t grid = 8 * ceil_div(P, 8) * groups;
+    const double* w1 = nullptr;                     // bit-plane part of the product: nw1 partial blocks
+    int nw1 = 0;
+    if (w.lds && w.bitplane) DDX_TRY(bp_cols_product(c, Yrow, w.L, &w1, &nw1));
     ScopedTimer t(c, "spmm_cols");
     if (w.lds) {
         LdsSpmmArgs a{};
@@ -1354,17 +1353,18 @@ static int apply_cols(PcaWork& w, const double* Yrow, double* Wcol) {  // A^T Y 
         a.groups = std::max(1, std::min(P, 512 * kLdsWgPerCu / a.owners));
         a.zcol = c->zcol.as<float>();
         a.cp_o = c->csc_o_colptr.as<int64_t>(); a.row_o = c->csc_o_row.as<int32_t>(); a.x_o = c->csc_o_x.as<float>(); a.P_o = c->P_o;
-        if (w.bitplane) { a.cp_o = c->bp.restm_colptr; a.row_o = c->bp.restm_row; a.x_o = c->bp.restm_x; }
         a.cp_s = c->csc_s_colptr.as<int64_t>(); a.row_s = c->csc_s_row.as<int32_t>(); a.x_s = c->csc_s_x.as<float>();
+        if (w.bitplane) {                               // the reduced mirrors: entries other than 1
+            a.cp_o = c->bp.restm_colptr; a.row_o = c->bp.restm_row; a.x_o = c->bp.restm_x;
+            if (c->P_s > 0) { a.cp_s = c->bp.restm_s_colptr; a.row_s = c->bp.restm_s_row; a.x_s = c->bp.restm_s_x; }
+        }
         a.p_s0 = c->p_s0; a.P_s = c->P_s;
         a.out = c->pcaPanel.as<double>();
         a.perm = c->rank_cols;
         const size_t lds_bytes = (size_t)a.SR * a.ld * 4 + lds_stage_bytes(slots, lds_packed());
         DDX_TRY(launch_lds<false>(c, a, slots, (unsigned)(a.owners * a.groups), lds_bytes));
-        const double* w1 = nullptr;
-        if (w.bitplane) DDX_TRY(bp_cols_product(c, Yrow, w.L, a.ld, &w1));
         k_sum_panels<<<(unsigned)ceil_div((int64_t)w.H * w.L, 256), 256, 0, c->stream>>>(c->pcaPanel.as<double>(), a.groups, w.H, w.L, c->colmean.as<double>(),
-                                                                                          uvec, Wcol, w1);
+                                                                                          uvec, Wcol, w1, nw1);
         return DDX_OK;
     }
     if (w.gather32) {
@@ -1423,8 +1423,10 @@ static int lds_setup(ddx_ctx* ctx, int L, PcaWork& w) {
     w.lds = true;
     w.rows_ns = (int)ceil_div(H, srmax);
     w.rows_SR = (int)((ceil_div(H, w.rows_ns) + 3) & ~3);
-    // bit planes: unscaled matrix (the value of a count of 1 then depends on the row only), at most 64 sketch columns
-    w.bitplane = ctx->opt.bitplane && !ctx->scaled && ld <= 64 && ctx->N >= 16 && ctx->have_lognorm;
+    // bit planes: unscaled matrix (the value of a count of 1 then depends on the row only), a sketch whose digits fit the kernel's
+    // tiles (40 columns), and -- unless forced -- a matrix large enough for the dense passes to pay
+    w.bitplane = ctx->opt.bitplane != 0 && !ctx->scaled && L <= 40 && ctx->have_lognorm && ctx->N >= 32 && ctx->S <= ctx->N / 2 &&
+                 (ctx->opt.bitplane == 2 || ctx->N >= 4096);
     if (w.bitplane) {
         const bool fresh = !ctx->bp.ready;
         DDX_TRY(bp_build(ctx));
@@ -1434,19 +1436,18 @@ static int lds_setup(ddx_ctx* ctx, int L, PcaWork& w) {
     const void* before = ctx->rowseg.p;
     DDX_TRY(ensure(ctx, ctx->rowseg, sizeof(int32_t) * (size_t)M * (w.rows_ns + 1)));
     ScopedTimer t(ctx, "row_segments");
-    DDX_TRY(stage_rankings(ctx, w.bitplane ? ctx->bp.rest_indptr : nullptr));
+    const int64_t* row_ip = w.bitplane ? ctx->bp.rest_indptr : ctx->aug_indptr.as<int64_t>();
+    const int32_t* row_ix = w.bitplane ? ctx->bp.rest_cols : ctx->aug_indices.as<int32_t>();
+    DDX_TRY(stage_rankings(ctx, row_ip, w.bitplane ? ctx->bp.restm_colptr : ctx->csc_o_colptr.as<int64_t>(),
+                           (w.bitplane && ctx->P_s > 0) ? ctx->bp.restm_s_colptr : ctx->csc_s_colptr.as<int64_t>()));
     // the original cells' rows (columns fixed for the whole fit) are cut once; every iteration cuts its synthetic rows
     const bool kept = before && before == ctx->rowseg.p && ctx->rowseg_rows == ctx->N && ctx->rowseg_ns == w.rows_ns && ctx->rowseg_SR == w.rows_SR &&
                       ctx->bp_rowseg == w.bitplane;
     const int64_t N = ctx->N;
-    if (!kept && N > 0) {
-        const int64_t* ip = w.bitplane ? ctx->bp.rest_indptr : ctx->aug_indptr.as<int64_t>();
-        const int32_t* ix = w.bitplane ? ctx->bp.rest_cols : ctx->aug_indices.as<int32_t>();
-        k_row_segments<<<(unsigned)ceil_div(N * (w.rows_ns + 1), 256), 256, 0, ctx->stream>>>(ip, ix, 0, N, w.rows_ns, w.rows_SR, ctx->rowseg.as<int32_t>());
-    }
+    if (!kept && N > 0)
+        k_row_segments<<<(unsigned)ceil_div(N * (w.rows_ns + 1), 256), 256, 0, ctx->stream>>>(row_ip, row_ix, 0, N, w.rows_ns, w.rows_SR, ctx->rowseg.as<int32_t>());
     if (M > N)
-        k_row_segments<<<(unsigned)ceil_div((M - N) * (w.rows_ns + 1), 256), 256, 0, ctx->stream>>>(ctx->aug_indptr.as<int64_t>(), ctx->aug_indices.as<int32_t>(), N, M,
-                                                                                                w.rows_ns, w.rows_SR, ctx->rowseg.as<int32_t>());
+        k_row_segments<<<(unsigned)ceil_div((M - N) * (w.rows_ns + 1), 256), 256, 0, ctx->stream>>>(row_ip, row_ix, N, M, w.rows_ns, w.rows_SR, ctx->rowseg.as<int32_t>());
     ctx->rowseg_rows = ctx->N; ctx->rowseg_ns = w.rows_ns; ctx->rowseg_SR = w.rows_SR; ctx->bp_rowseg = w.bitplane;
     return DDX_OK;
 }

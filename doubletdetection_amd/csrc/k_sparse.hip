@@ -309,7 +309,7 @@ __global__ void k_col_lengths(const int64_t* __restrict__ cp_o, int P_o, const i
 
 // Rankings used by the LDS-staged operator products: rows and columns sorted by their number of stored entries
 // (descending, ties by index -- the radix sort is stable).  Rebuilt per iteration: the synthetic rows change.
-int stage_rankings(ddx_ctx* ctx, const int64_t* reduced_indptr) {
+int stage_rankings(ddx_ctx* ctx, const int64_t* indptr, const int64_t* cp_o, const int64_t* cp_s) {
     const int64_t M = ctx->M;
     const int32_t H = ctx->H;
     const int64_t n = M + H;
@@ -318,11 +318,8 @@ int stage_rankings(ddx_ctx* ctx, const int64_t* reduced_indptr) {
     uint32_t* keys_out = keys_in + n;
     int32_t* ids_in = reinterpret_cast<int32_t*>(keys_out + n);
     int32_t* ids_out = ids_in + n;
-    k_row_lengths<<<(unsigned)ceil_div(M, 256), 256, 0, ctx->stream>>>(ctx->aug_indptr.as<int64_t>(), M, keys_in, ids_in);
-    if (reduced_indptr && ctx->N > 0)      // bit-plane mode: an original row's sparse work is its entries other than 1
-        k_row_lengths<<<(unsigned)ceil_div(ctx->N, 256), 256, 0, ctx->stream>>>(reduced_indptr, ctx->N, keys_in, ids_in);
-    k_col_lengths<<<(unsigned)ceil_div(H, 256), 256, 0, ctx->stream>>>(ctx->csc_o_colptr.as<int64_t>(), ctx->P_o, ctx->csc_s_colptr.as<int64_t>(), ctx->P_s, H,
-                                                                       keys_in + M, ids_in + M);
+    k_row_lengths<<<(unsigned)ceil_div(M, 256), 256, 0, ctx->stream>>>(indptr, M, keys_in, ids_in);
+    k_col_lengths<<<(unsigned)ceil_div(H, 256), 256, 0, ctx->stream>>>(cp_o, ctx->P_o, cp_s, ctx->P_s, H, keys_in + M, ids_in + M);
     size_t tmp_r = 0, tmp_c = 0;
     int bits_r = 1, bits_c = 1;                 // a row holds at most H entries, a column at most M: sort only those bits
     while (((int64_t)1 << bits_r) <= H) ++bits_r;
@@ -812,7 +809,7 @@ int stage_upload_counts(ddx_ctx* ctx, int64_t N, int32_t H, const int64_t* indpt
     const int64_t nnz = from_device ? ctx->nnz : indptr[N];
     if (nnz >= (int64_t)1 << 31) return set_err(ctx, DDX_E_UNSUPPORTED, "more than 2^31-1 stored entries");
     if (!from_device) {
-        arena_hint(ctx, (size_t)nnz * 80 + (size_t)N * 6000 + ((size_t)1 << 30));
+        arena_hint(ctx, (size_t)nnz * 90 + (size_t)N * 6000 + ((size_t)1 << 30));
         // worst-case-ish room for the synthetic part (default boost_rate 0.25 needs ~0.5*nnz); grows on demand
         const int64_t cap_s = nnz / 2 + nnz / 8 + 1024;
         DDX_TRY(ensure(ctx, ctx->aug_indptr, sizeof(int64_t) * (N + N / 2 + 2)));
@@ -877,7 +874,7 @@ int stage_clone_counts(ddx_ctx* ctx, const ddx_ctx* src) {
     const int32_t H = src->H;
     const int64_t cap_s = nnz / 2 + nnz / 8 + 1024;
     ctx->have_counts = false;
-    arena_hint(ctx, (size_t)nnz * 80 + (size_t)N * 6000 + ((size_t)1 << 30));
+    arena_hint(ctx, (size_t)nnz * 90 + (size_t)N * 6000 + ((size_t)1 << 30));
     DDX_TRY(ensure(ctx, ctx->aug_indptr, sizeof(int64_t) * (N + N / 2 + 2)));
     DDX_TRY(ensure(ctx, ctx->aug_indices, sizeof(int32_t) * (size_t)(nnz + cap_s)));
     DDX_TRY(ensure(ctx, ctx->aug_raw, sizeof(float) * (size_t)(nnz + cap_s)));
@@ -1235,6 +1232,7 @@ int stage_lognormalise(ddx_ctx* ctx, float pseudocount) {
     DDX_HIP(ctx, hipMemcpyAsync(&nnz_aug, ctx->aug_indptr.as<int64_t>() + M, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
     DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const int64_t nnz_s = nnz_aug - ctx->nnz;
+    ctx->nnz_aug = nnz_aug;
     if (S) {
         ScopedTimer t(ctx, "row_sums");
 if (ctx->counts_exact)

@@ -60,7 +60,11 @@ int ddx_synchronize(ddx_ctx* ctx);
  *   pca_gather        f32 | f64         operand copy of the gather kernels (default f32)
  *   spmm_geom         auto | pair | quad   lane geometry of the LDS-staged products
  *   spmm_trip         packed | f64      trip products in packed float32 (default) or float64
- *   bitplane          0 | 1             experiment: the original rows' entries equal to 1 as bitmaps on the int8 matrix cores
+ *   bitplane          auto | 0 | 1 | 2  stored entries equal to 1 as bitmaps on the int8 matrix cores, the others through the sparse products
+ *                                       (auto = 1: when the matrix is unscaled, the sketch at most 40 columns wide and there are at least 4096 cells;
+ *                                       2: whenever the matrix is unscaled and the sketch fits; 0: plain sparse products)
+ *   bp_digits         3 | 4             8-bit digits of the operand's fixed point in the bit-plane products (3: 22 bits below the
+ *                                       column's largest element -- default; 4: 30 bits)
  *   mirror            tiles | scatter | sort   how the column-major mirror is built (default tiles; the others are its references)
  *   upload            auto | plain | packed | packed32   transfer form of ddx_upload_raw (auto: 2-byte form once the pinned
  *                                       buffer exists, plain until then; packed / packed32 wait for the buffer)
