@@ -745,7 +745,7 @@ class BoostClassifier:
         leaders = {}
         try:
             for dev in self._device_list(world):
-                leaders[dev] = self._engine_factory(dev)
+                leaders[dev] = self._fit_switches(self._engine_factory(dev))
             put = (lambda e: e.stage_raw(csr)) if restrict else (lambda e: e.upload(csr))
             try:
                 self._on_each(leaders.values(), put)
@@ -763,6 +763,15 @@ class BoostClassifier:
             raise
         return csr, leaders, restrict
 
+    def _fit_switches(self, engine):
+        """Switches of a device context that follow from this fit's parameters: the bit planes of the operator products
+        (k_bitplane.hip) are built when the counts become resident, so a fit that cannot use them -- a scaled matrix, whose
+        values depend on the column, or a sketch wider than 40 columns -- says so before the upload."""
+        ctx = getattr(engine, "ctx", None)
+        if ctx is not None and hasattr(ctx, "set_option") and (self.standard_scaling or self.n_components + 10 > 40):
+            ctx.set_option("bitplane", "0")
+        return engine
+
     def _open_lanes(self, leaders, n_mine):
         """[(device, engine)]: the leader context of every GPU plus streams_per_device - 1 followers that copy its resident
         counts device-to-device.  Lanes are ordered stream-major so that a short job reaches every GPU first."""
@@ -778,7 +787,7 @@ class BoostClassifier:
         made = []
         try:
             for dev, leader in followers:
-                f = self._engine_factory(dev)
+                f = self._fit_switches(self._engine_factory(dev))
                 made.append((dev, f))
             # a leader must be idle while it is copied: the followers of different GPUs copy side by side
             self._on_each(list(zip(made, followers)), lambda p: p[0][1].clone_from(p[1][1]))

@@ -46,7 +46,7 @@ struct Options {
     bool knn_debug = false;
     bool pca_debug = false;          // progress of the block Lanczos solver on stderr
     int bitplane = 1;                // entries equal to 1 as bitmaps on the int8 matrix cores (k_bitplane.hip): 0 off, 1 when the matrix is large enough, 2 always
-    int bp_digits = 3;               // 8-bit digits of the operand's fixed point in those products (3: 22 bits below the column maximum, 4: 30)
+    int bp_digits = 4;               // 8-bit digits of the operand's fixed point in those products (4: 30 bits below the column maximum, 3: 22)
     int mirror_mode = 2;             // column-major mirror: 2 counting sort placed by LDS tiles, 1 (DDX_MIRROR=scatter) counting sort with scattered stores, 0 (DDX_MIRROR=sort) radix sort
     bool upload_packed = true;       // DDX_UPLOAD=plain: send the raw matrix as it is (8 bytes per entry) instead of packed
     bool upload_form16 = true;       // DDX_UPLOAD=packed32: column | count << 16 (4 bytes per entry) instead of column step | count << 8 (2 bytes)
@@ -90,6 +90,8 @@ struct BitPlanes {
     int64_t cap_rows = 0;            // padded rows the bitmaps have room for
     int64_t SKr = 0, SKr_cap = 0, SKr_used = 0;          // stages of 256 padded rows: layout stride of the column bitmap (= capacity) / in use
     int64_t nrest_o = 0, nrest_s = 0, cap_rest = 0, cap_rest_s = 0, cap_srow = 0;
+    int64_t want_rest_s = 0;         // room for the synthetic rows' reduced entries asked for by an iteration that ran out of it
+    size_t buf_bytes = 0;            // bytes of ctx->bp_buf in use (what a follower context copies)
     void* bm_rows = nullptr;         // [(row tile * SKc + sk) * 64 + r * 2 + h] 16-byte words
     void* bm_cols = nullptr;         // [(column tile * SKr + skr) * 64 + c * 2 + h]
     int64_t* rest_indptr = nullptr;  // reduced CSR of ALL rows: [M + 1]; cols / value; rest_pos: position of an original row's entry in the full arrays
@@ -348,6 +350,8 @@ int gene_sums_fold(ddx_ctx* ctx, int32_t G, int64_t n_rows, int64_t row0, int64_
 int stage_select_columns(ddx_ctx* ctx, const int64_t* cols, int32_t n_cols);
 // bit-plane products (k_bitplane.hip)
 int bp_build(ddx_ctx* ctx);
+int bp_clone(ddx_ctx* ctx, const ddx_ctx* src);
+bool bp_wanted_at_upload(const ddx_ctx* ctx);
 int bp_refresh(ddx_ctx* ctx);
 int bp_rows_product(ddx_ctx* ctx, const double* Q, int L, double* Y);
 int bp_cols_product(ddx_ctx* ctx, const double* Y, int L, const double** part, int* chunks);

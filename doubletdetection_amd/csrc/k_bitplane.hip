@@ -30,6 +30,8 @@
 // plain sparse products.
 #include "ddx_prims.h"
 
+#include <type_traits>
+
 #include "ddx_internal.h"
 
 namespace ddx {
@@ -439,7 +441,7 @@ int bp_build(ddx_ctx* ctx) {
     int32_t* scan = nullptr;
     DDX_TRY(bp_reduce(ctx, ctx->aug_raw.as<float>(), nullptr, nullptr, nnz, nullptr, nullptr, nullptr, 0, &total_r, true, &scan));
     bp.nrest_o = total_r;
-    bp.cap_rest_s = std::max<int64_t>(ctx->cap_synth / 3, 1024);   // (a synthetic row keeps ~15 % of its entries; grows on demand)
+    bp.cap_rest_s = std::max<int64_t>(std::max<int64_t>(ctx->cap_synth / 3, bp.want_rest_s), 1024);   // (a synthetic row keeps ~15 % of its entries)
     // one buffer for everything that lasts for the fit
     size_t off = 0;
     auto carve = [&](size_t bytes) { const size_t o = off; off += bp_align(bytes); return o; };
@@ -452,6 +454,7 @@ int bp_build(ddx_ctx* ctx) {
     const size_t o_mcp = carve(sizeof(int64_t) * (size_t)(nseg + 1)), o_mr = carve(sizeof(int32_t) * (size_t)total_r + 256), o_mp = carve(sizeof(int32_t) * (size_t)total_r + 256);
     const size_t o_mx = carve(sizeof(float) * (size_t)total_r + 256), o_s = carve(sizeof(double) * (size_t)(N + Scap + 2));
     DDX_TRY(ensure(ctx, ctx->bp_buf, off));
+    bp.buf_bytes = off;
     char* b = ctx->bp_buf.as<char>();
     bp.bm_rows = b + o_bmr;
     bp.bm_cols = b + o_bmc;
@@ -494,6 +497,32 @@ int bp_build(ddx_ctx* ctx) {
     return DDX_OK;
 }
 
+// The per-fit structures of another context of the same GPU, device to device (a follower of the fit: building them again
+// would cost every context the passes over all stored entries).
+int bp_clone(ddx_ctx* ctx, const ddx_ctx* src) {
+    ctx->bp = BitPlanes();
+    if (!src->bp.ready) return DDX_OK;
+    DDX_TRY(ensure(ctx, ctx->bp_buf, src->bp.buf_bytes));
+    DDX_HIP(ctx, hipMemcpyAsync(ctx->bp_buf.p, src->bp_buf.p, src->bp.buf_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    BitPlanes bp = src->bp;
+    const ptrdiff_t delta = ctx->bp_buf.as<char>() - src->bp_buf.as<char>();
+    auto move = [&](auto*& p) { if (p) p = reinterpret_cast<std::remove_reference_t<decltype(p)>>(reinterpret_cast<char*>(p) + delta); };
+    move(bp.bm_rows); move(bp.bm_cols); move(bp.rest_indptr); move(bp.rest_cols); move(bp.rest_pos); move(bp.rest_x);
+    move(bp.restm_colptr); move(bp.restm_row); move(bp.restm_pos); move(bp.restm_x); move(bp.srow);
+    bp.restm_s_colptr = nullptr; bp.restm_s_row = nullptr; bp.restm_s_x = nullptr;          // (views into the source's per-iteration buffers)
+    bp.qd = nullptr; bp.cmax = nullptr; bp.cscale = nullptr; bp.part = nullptr;
+    bp.values = false;
+    bp.ntile_s = 0; bp.nrest_s = 0;
+    ctx->bp = bp;
+    return DDX_OK;
+}
+
+// whether the counts just made resident should get their bit planes right away (the leader of a fit builds, its followers copy)
+bool bp_wanted_at_upload(const ddx_ctx* ctx) {
+    const Options& o = ctx->opt;
+    return o.bitplane != 0 && o.gather_f32 && ctx->N >= 32 && (o.bitplane == 2 || ctx->N >= 4096);
+}
+
 // What changes with the iteration: the synthetic rows' bitmaps and reduced structures (rows and mirror), the reduced values of the
 // original rows, the row scales.  After ddx_lognormalise.
 int bp_refresh(ddx_ctx* ctx) {
@@ -525,7 +554,14 @@ int bp_refresh(ddx_ctx* ctx) {
         int32_t kept = 0;
         int32_t* scan = nullptr;
         DDX_TRY(bp_reduce(ctx, ctx->aug_raw.as<float>() + e0, nullptr, nullptr, n_s, nullptr, nullptr, nullptr, 0, &kept, true, &scan));
-        if (kept > bp.cap_rest_s) return set_err(ctx, DDX_E_UNSUPPORTED, "bit planes: %d reduced synthetic entries exceed the planned %lld", kept, (long long)bp.cap_rest_s);
+        if (kept > bp.cap_rest_s) {
+            // more entries other than 1 among the synthetic rows than planned for: build the per-fit structures again with room for them
+            bp.want_rest_s = (int64_t)kept + kept / 2;
+            bp.ready = false;
+            DDX_TRY(bp_build(ctx));
+            ctx->rowseg_rows = -1;
+            return bp_refresh(ctx);
+        }
         bp.nrest_s = kept;
         const unsigned ge = (unsigned)ceil_div(n_s + 1, 256);
         int32_t* flag = ctx->sort_keys_in.as<int32_t>();

@@ -61,7 +61,7 @@ template <typename T>
 __global__ void __launch_bounds__(256) k_spmm_rows(const int64_t* __restrict__ indptr, const int32_t* __restrict__ cols,
                                                    const float* __restrict__ x, const float* __restrict__ zcol,
                                                    const T* __restrict__ Q, int ld, int L, int lpn, int slots,
-                                                   const double* __restrict__ tvec, int64_t M, double* __restrict__ Y) {
+                                                   const double* __restrict__ tvec, int64_t M, double* __restrict__ Y, int accumulate = 0) {
     constexpr int VW = Gather<T>::VW;
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -109,7 +109,7 @@ __global__ void __launch_bounds__(256) k_spmm_rows(const int64_t* __restrict__ i
     for (int c = 0; c < VW; ++c) {
         double sum = acc[c];
         for (int s = 1; s < slots; ++s) sum += __shfl(acc[c], lane + s * lpn, 64);
-        if (slot == 0 && c0 + c < L) Y[row * L + c0 + c] = sum - tvec[c0 + c];
+        if (slot == 0 && c0 + c < L) Y[row * L + c0 + c] = sum - tvec[c0 + c] + (accumulate ? Y[row * L + c0 + c] : 0.0);
     }
 }
 
@@ -1270,7 +1270,7 @@ static int apply_rows(PcaWork& w, const double* Qcol, double* Yrow) {  // A Q : 
     }
     // Y = diag(s) B Q on the matrix cores first (a timing scope of its own); the sparse kernel then sees only the entries other
     // than 1 and adds its part
-    if (w.lds && w.bitplane) DDX_TRY(bp_rows_product(c, Qcol, w.L, Yrow));
+    if (w.bitplane) DDX_TRY(bp_rows_product(c, Qcol, w.L, Yrow));
     ScopedTimer t(c, "spmm_rows");
     const unsigned grid = (unsigned)ceil_div(w.M, 4);
     if (w.lds) {
@@ -1310,6 +1310,10 @@ static int apply_rows(PcaWork& w, const double* Qcol, double* Yrow) {  // A Q : 
     if (w.gather32) {
         const int ld = (w.L + 3) & ~3, lpn = ld / 4;
         const float* op = prepared_operand<float>(w, Qcol, w.H, ld);
+        if (w.bitplane)
+            k_spmm_rows<float><<<grid, 256, 0, c->stream>>>(c->bp.rest_indptr, c->bp.rest_cols, c->bp.rest_x, c->zcol.as<float>(), op, ld, w.L, lpn, 64 / lpn, tvec, w.M,
+                                                            Yrow, 1);
+        else
         k_spmm_rows<float><<<grid, 256, 0, c->stream>>>(c->aug_indptr.as<int64_t>(), c->aug_indices.as<int32_t>(), c->aug_x.as<float>(),
                                                         c->zcol.as<float>(), op, ld, w.L, lpn, 64 / lpn, tvec, w.M, Yrow);
     } else {
@@ -1334,7 +1338,7 @@ static int apply_cols(PcaWork& w, const double* Yrow, double* Wcol) {  // A^T Y 
     const int64_t grid = 8 * ceil_div(P, 8) * groups;
     const double* w1 = nullptr;                     // bit-plane part of the product: nw1 partial blocks
     int nw1 = 0;
-    if (w.lds && w.bitplane) DDX_TRY(bp_cols_product(c, Yrow, w.L, &w1, &nw1));
+    if (w.bitplane) DDX_TRY(bp_cols_product(c, Yrow, w.L, &w1, &nw1));
     ScopedTimer t(c, "spmm_cols");
     if (w.lds) {
         LdsSpmmArgs a{};
@@ -1370,6 +1374,12 @@ static int apply_cols(PcaWork& w, const double* Yrow, double* Wcol) {  // A^T Y 
     if (w.gather32) {
         const int ld = (w.L + 3) & ~3, lpn = ld / 4;
         const float* op = prepared_operand<float>(w, Yrow, w.M, ld);
+        if (w.bitplane)
+            k_spmm_cols<float><<<(unsigned)grid, 256, 0, c->stream>>>(c->bp.restm_colptr, c->bp.restm_row, c->bp.restm_x, c->P_o,
+                                                                  c->P_s > 0 ? c->bp.restm_s_colptr : c->csc_s_colptr.as<int64_t>(), c->P_s > 0 ? c->bp.restm_s_row : c->csc_s_row.as<int32_t>(),
+                                                                  c->P_s > 0 ? c->bp.restm_s_x : c->csc_s_x.as<float>(), c->p_s0,
+                                                                  c->P_s, P, w.H, c->zcol.as<float>(), op, ld, w.L, lpn, 64 / lpn, c->pcaPanel.as<double>());
+        else
         k_spmm_cols<float><<<(unsigned)grid, 256, 0, c->stream>>>(c->csc_o_colptr.as<int64_t>(), c->csc_o_row.as<int32_t>(), c->csc_o_x.as<float>(), c->P_o,
                                                               c->csc_s_colptr.as<int64_t>(), c->csc_s_row.as<int32_t>(), c->csc_s_x.as<float>(), c->p_s0,
                                                               c->P_s, P, w.H, c->zcol.as<float>(), op, ld, w.L, lpn, 64 / lpn, c->pcaPanel.as<double>());
@@ -1381,7 +1391,7 @@ static int apply_cols(PcaWork& w, const double* Yrow, double* Wcol) {  // A^T Y 
                                                                c->P_s, P, w.H, c->zcol.as<float>(), op, ld, w.L, lpn, 64 / lpn, c->pcaPanel.as<double>());
     }
     k_sum_panels<<<(unsigned)ceil_div((int64_t)w.H * w.L, 256), 256, 0, c->stream>>>(c->pcaPanel.as<double>(), P, w.H, w.L, c->colmean.as<double>(),
-                                                                                      uvec, Wcol);
+                                                                                      uvec, Wcol, w1, nw1);
     return DDX_OK;
 }
 
@@ -1408,8 +1418,24 @@ static int apply_cols_wide(PcaWork& w, const double* Yrow, double* Wcol) {
 }
 
 // decide whether the LDS-staged products apply and build the row-segment table of the A Q pass
+static int bp_setup(ddx_ctx* ctx, int L, PcaWork& w) {
+    // bit planes: unscaled matrix (the value of a count of 1 then depends on the row only), a sketch whose digits fit the kernel's
+    // tiles (40 columns), and -- unless forced -- a matrix large enough for the dense passes to pay
+    w.bitplane = ctx->opt.bitplane != 0 && w.gather32 && !ctx->scaled && L <= 40 && ctx->have_lognorm && ctx->N >= 32 && ctx->S <= ctx->N / 2 &&
+                 (ctx->opt.bitplane == 2 || ctx->N >= 4096);
+    if (w.bitplane) {
+        const bool fresh = !ctx->bp.ready;
+        DDX_TRY(bp_build(ctx));
+        DDX_TRY(bp_refresh(ctx));
+        if (fresh) ctx->rowseg_rows = -1;              // the original rows' segments now refer to the reduced rows
+    }
+    return DDX_OK;
+}
+
 static int lds_setup(ddx_ctx* ctx, int L, PcaWork& w) {
     w.lds = false;
+    w.bitplane = false;
+    if (w.gather32 && !ctx->opt.spmm_lds) return bp_setup(ctx, L, w);
     if (!(w.gather32 && ctx->opt.spmm_lds)) return DDX_OK;
     const int64_t M = ctx->M;
     const int32_t H = ctx->H;
@@ -1423,16 +1449,7 @@ static int lds_setup(ddx_ctx* ctx, int L, PcaWork& w) {
     w.lds = true;
     w.rows_ns = (int)ceil_div(H, srmax);
     w.rows_SR = (int)((ceil_div(H, w.rows_ns) + 3) & ~3);
-    // bit planes: unscaled matrix (the value of a count of 1 then depends on the row only), a sketch whose digits fit the kernel's
-    // tiles (40 columns), and -- unless forced -- a matrix large enough for the dense passes to pay
-    w.bitplane = ctx->opt.bitplane != 0 && !ctx->scaled && L <= 40 && ctx->have_lognorm && ctx->N >= 32 && ctx->S <= ctx->N / 2 &&
-                 (ctx->opt.bitplane == 2 || ctx->N >= 4096);
-    if (w.bitplane) {
-        const bool fresh = !ctx->bp.ready;
-        DDX_TRY(bp_build(ctx));
-        DDX_TRY(bp_refresh(ctx));
-        if (fresh) ctx->rowseg_rows = -1;              // the original rows' segments now refer to the reduced rows
-    }
+    DDX_TRY(bp_setup(ctx, L, w));
     const void* before = ctx->rowseg.p;
     DDX_TRY(ensure(ctx, ctx->rowseg, sizeof(int32_t) * (size_t)M * (w.rows_ns + 1)));
     ScopedTimer t(ctx, "row_segments");

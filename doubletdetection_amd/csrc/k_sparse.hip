@@ -861,6 +861,7 @@ int stage_upload_counts(ddx_ctx* ctx, int64_t N, int32_t H, const int64_t* indpt
     ctx->panel_rows = (ctx->opt.spmm_lds && ctx->opt.gather_f32) ? kLdsPanelRows : kGatherPanelRows;
     ctx->P_o = (int32_t)ceil_div(N, ctx->panel_rows);
     DDX_TRY(build_csc(ctx, 0, nnz, 0, N, 0, ctx->P_o, ctx->csc_o_colptr, ctx->csc_o_row, ctx->csc_o_raw));
+    if (bp_wanted_at_upload(ctx)) DDX_TRY(bp_build(ctx));        // bitmaps + reduced structures of the original rows, once per fit: the followers copy them
     DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->have_counts = true;
     return DDX_OK;
@@ -909,6 +910,8 @@ int stage_clone_counts(ddx_ctx* ctx, const ddx_ctx* src) {
     ctx->P_o = src->P_o;
     ctx->counts_exact = src->counts_exact;
     ctx->have_synth = ctx->have_lognorm = ctx->scaled = ctx->have_emb = ctx->have_knn = false;
+    ctx->rowseg_rows = -1;
+    DDX_TRY(bp_clone(ctx, src));
     DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->have_counts = true;
     return DDX_OK;

@@ -63,8 +63,9 @@ int ddx_synchronize(ddx_ctx* ctx);
  *   bitplane          auto | 0 | 1 | 2  stored entries equal to 1 as bitmaps on the int8 matrix cores, the others through the sparse products
  *                                       (auto = 1: when the matrix is unscaled, the sketch at most 40 columns wide and there are at least 4096 cells;
  *                                       2: whenever the matrix is unscaled and the sketch fits; 0: plain sparse products)
- *   bp_digits         3 | 4             8-bit digits of the operand's fixed point in the bit-plane products (3: 22 bits below the
- *                                       column's largest element -- default; 4: 30 bits)
+ *   bp_digits         4 | 3             8-bit digits of the operand's fixed point in the bit-plane products (4: 30 bits below the
+ *                                       column's largest element -- default, PCA scores within 4e-7 of the float64 oracle at the
+ *                                       BASELINE sizes; 3: 22 bits, a fifth fewer matrix instructions, 4e-6)
  *   mirror            tiles | scatter | sort   how the column-major mirror is built (default tiles; the others are its references)
  *   upload            auto | plain | packed | packed32   transfer form of ddx_upload_raw (auto: 2-byte form once the pinned
  *                                       buffer exists, plain until then; packed / packed32 wait for the buffer)

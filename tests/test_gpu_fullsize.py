@@ -134,12 +134,14 @@ def test_c2_pca_matches_f64_oracle(staged):
 
 
 def test_operator_product_variants_agree_at_full_size(data, staged, monkeypatch):
-    """The same randomized PCA through the implementations of the operator products: LDS-staged float32
-    operand with float32 products inside a trip (default), L2-gather float32 operand (option spmm=gather), L2-gather
-    float64 operand (pca_gather=f64), LDS with float64 products, LDS in the quad geometry.
-    The first two compute the same products up to the float32 trip sums and the summation order; the
+    """The same randomized PCA through the implementations of the operator products: bit planes on the int8 matrix cores
+    + LDS-staged sparse products for the entries other than 1 (the default from 4096 cells on; four or three 8-bit digits),
+    the LDS-staged float32 operand with float32 products inside a trip for every entry (bitplane=0, the default of
+    rounds 1-4), L2-gather float32 operand (option spmm=gather), L2-gather float64 operand (pca_gather=f64), LDS with
+    float64 products, LDS in the quad geometry.
+    The sparse variants compute the same products up to the float32 trip sums and the summation order; the
     float64 mode differs by the float32 rounding of the operand copies (< 1e-5 per component, as in the small
-    oracle test)."""
+    oracle test); the bit planes replace nine in ten of those roundings by a 30-bit (22-bit) fixed point."""
     import os
 
     from doubletdetection_amd import _lib
@@ -149,7 +151,7 @@ def test_operator_product_variants_agree_at_full_size(data, staged, monkeypatch)
     M, H, C = ctx.M, ctx.H, 30
     q0 = np.random.RandomState(0).normal(size=(H, C + 10)).astype(np.float32).astype(np.float64)
     ctx.pca(C, q0)
-    emb_lds, sing_lds = ctx.embedding_f64()
+    emb_bp, sing_bp = ctx.embedding_f64()           # the default: bit planes, four digits
 
     def other(env):
         for k, v in env.items():
@@ -168,28 +170,42 @@ def test_operator_product_variants_agree_at_full_size(data, staged, monkeypatch)
             for k in env:
                 monkeypatch.delitem(_lib.OPTIONS, k, raising=False)
 
+    def rel_dev(a, b):
+        return (np.linalg.norm(a - b, axis=0) / np.linalg.norm(b, axis=0)).max()
+
+    emb_lds, sing_lds = other({"bitplane": "0"})
     # the column-major mirror built by counting sort (default) and by the stable radix sort it replaces hold the same
     # entries in the same order: bit-identical scores
     # (default: counting sort placed by LDS tiles; "scatter": counting sort with scattered stores; "sort": radix sort)
     for mode in ("sort", "scatter"):
-        emb_m, sing_m = other({"mirror": mode})
+        emb_m, sing_m = other({"mirror": mode, "bitplane": "0"})
         np.testing.assert_array_equal(emb_m, emb_lds)
         np.testing.assert_array_equal(sing_m, sing_lds)
+        emb_m, sing_m = other({"mirror": mode})     # ... and the reduced mirrors of the bit-plane route are cut from it
+        np.testing.assert_array_equal(emb_m, emb_bp)
+        np.testing.assert_array_equal(sing_m, sing_bp)
     emb_g, sing_g = other({"spmm": "gather"})
     # (rounding noise of the two summation orders, amplified through seven power iterations of unconverged
     # trailing components: 4e-10 observed on the singular values)
     np.testing.assert_allclose(sing_g, sing_lds, rtol=1e-8)
-    rel_g = np.linalg.norm(emb_g - emb_lds, axis=0) / np.linalg.norm(emb_lds, axis=0)
-    assert rel_g.max() < 1e-6, rel_g.max()
+    assert rel_dev(emb_g, emb_lds) < 1e-6
     emb_f, sing_f = other({"spmm": "gather", "pca_gather": "f64"})
-    rel = np.linalg.norm(emb_f - emb_lds, axis=0) / np.linalg.norm(emb_f, axis=0)
-    assert rel.max() < 1e-5, rel.max()
+    assert rel_dev(emb_lds, emb_f) < 1e-5
     # the other two LDS variants: float64 products inside a trip, and the quad geometry at width 40
-    for env in ({"spmm_trip": "f64"}, {"spmm_geom": "quad"}):
+    for env in ({"spmm_trip": "f64", "bitplane": "0"}, {"spmm_geom": "quad", "bitplane": "0"}):
         emb_v, sing_v = other(env)
         np.testing.assert_allclose(sing_v, sing_lds, rtol=1e-8)
-        rel_v = np.linalg.norm(emb_v - emb_lds, axis=0) / np.linalg.norm(emb_lds, axis=0)
-        assert rel_v.max() < 2e-6, (env, rel_v.max())
+        assert rel_dev(emb_v, emb_lds) < 2e-6, env
+    # bit planes against the all-float64 run: closer than the float32 operand copies with four digits, inside the bar with three
+    d4, d_lds = rel_dev(emb_bp, emb_f), rel_dev(emb_lds, emb_f)
+    emb_3, sing_3 = other({"bp_digits": "3"})
+    d3 = rel_dev(emb_3, emb_f)
+    print(f"against the float64-gather run: bit planes 4 digits {d4:.2e}, 3 digits {d3:.2e}, float32 operand copies {d_lds:.2e}")
+    np.testing.assert_allclose(sing_bp, sing_f, rtol=1e-8)
+    assert d4 < 2e-6 and d3 < 1e-5, (d4, d3)
+    # forced on / off does not depend on the automatic rule
+    emb_2, sing_2 = other({"bitplane": "2"})
+    np.testing.assert_array_equal(emb_2, emb_bp)
 
 
 @pytest.mark.parametrize("algorithm", ["louvain", "leiden"])

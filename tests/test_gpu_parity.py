@@ -249,22 +249,29 @@ def test_scaled_matrix(ctx):
 
 
 # ---- a9: randomized PCA (dd.py:305-314 -> sklearn) ----------------------------------------------------
-@pytest.mark.parametrize("gather", ["f32", "f64"])
+@pytest.mark.parametrize("gather", ["f32", "f64", "bitplane", "bitplane3"])
 @pytest.mark.parametrize("case", ["case_a_hvg_pheno", "case_b_transposed_louvain", "case_c_reftest_scaled",
                                   "case_d_replace_single"])
 def test_pca_scores(case, gather, monkeypatch):
     # default: the operator products gather a float32-rounded copy of the 40-column iterate (float64
     # products and sums); option pca_gather=f64 gathers the float64 iterate itself.  A context takes the process-wide options
     # when it is created: make one for this setting.
+    # "bitplane" / "bitplane3": the entries equal to 1 through the int8 matrix cores with four / three digits (k_bitplane.hip;
+    # the automatic rule only takes that route from 4096 cells on: forced here; the scaled case keeps the sparse products)
     from doubletdetection_amd import _lib
 
-    monkeypatch.setitem(_lib.OPTIONS, "pca_gather", gather)
+    if gather.startswith("bitplane"):
+        monkeypatch.setitem(_lib.OPTIONS, "bitplane", "2")
+        monkeypatch.setitem(_lib.OPTIONS, "bp_digits", "3" if gather.endswith("3") else "4")
+    else:
+        monkeypatch.setitem(_lib.OPTIONS, "pca_gather", gather)
     with _lib.Context(0) as ctx:
         _pca_scores_body(ctx, case, gather)
 
 
 def _pca_scores_body(ctx, case, gather):
-    tol = 1e-7 if gather == "f64" else 1e-5     # bar: 1e-4 (sklearn f32 vs f64 differs by up to 8e-4)
+    # bar: 1e-4 (sklearn f32 vs f64 differs by up to 8e-4); three digits on these 500-cell matrices: 2e-5 (4e-6 at the BASELINE sizes)
+    tol = {"f64": 1e-7, "bitplane3": 5e-5}.get(gather, 1e-5)
     g = load_golden(case)
     kw = golden_kwargs(g)
     raw = csr_from(g, "raw_hvg")
@@ -286,7 +293,7 @@ def _pca_scores_body(ctx, case, gather):
     want, s_want, _ = orc.randomized_pca_f64(X, C, seed, round_q0_f32=True)
     dev = orc.per_component_rel_dev(emb64, want)
     assert dev.max() < tol, dev
-    np.testing.assert_allclose(sing, s_want, rtol=1e-9 if gather == "f64" else 1e-7)
+    np.testing.assert_allclose(sing, s_want, rtol=1e-9 if gather == "f64" else (1e-6 if gather == "bitplane3" else 1e-7))
     # (2) H3 acceptance band against scikit-learn itself: <= 1e-4 of the float64 run, and no further
     #     from the float32 run the reference performs than sklearn-f64 is
     ref64 = g["pca_it0_sklearn_f64"]
@@ -470,11 +477,14 @@ def test_device_presweeps_refuse_hubs_beyond_capacity_and_fit_falls_back(ctx):
 
 
 # ---- whole fit -------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("route", ["auto", "bitplane"])
 @pytest.mark.parametrize("case", ["case_a_hvg_pheno", "case_b_transposed_louvain", "case_c_reftest_scaled",
                                   "case_d_replace_single"])
-def test_fit_matches_oracle_and_reference_run(case):
-    from doubletdetection_amd import BoostClassifier
+def test_fit_matches_oracle_and_reference_run(case, route, monkeypatch):
+    from doubletdetection_amd import BoostClassifier, _lib
 
+    if route == "bitplane":                       # the route the BASELINE sizes take, forced onto the golden matrices
+        monkeypatch.setitem(_lib.OPTIONS, "bitplane", "2")
     g = load_golden(case)
     kw = golden_kwargs(g)
     counts = csr_from(g, "counts")
