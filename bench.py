@@ -69,6 +69,7 @@ LDS_PEAK_GBS = 256 * 128 * 2.4     # 256 CUs x 128 bytes per clock x 2.4 GHz = 7
 FP64_PEAK_TFLOPS = 78.6      # FP64 vector / FP64 MFMA peak, dense
 FP32_PEAK_TFLOPS = 157.3
 BF16_PEAK_TFLOPS = 2500.0     # dense bf16 MFMA peak (MI355X_MICROARCH.md; not the 2:1-sparsity figure)
+I8_PEAK_TOPS = 5000.0         # dense int8 MFMA: twice the bf16 rate (MI355X_MICROARCH.md: 16x16x64 / 32x32x32 i8 at 2x bf16; microbenchmark ceiling 4450, profiles/r05_bitplane_notes.txt)
 
 
 def parse():
@@ -108,7 +109,7 @@ def spawn_ranks(n):
     return subprocess.call(cmd, env=env)
 
 
-def kernel_models(N, G, H, S, nnz_aug, C, k, L=None, knn_window=1.0):
+def kernel_models(N, G, H, S, nnz_aug, C, k, L=None, knn_window=1.0, bitplane=None):
     """Algorithmic work per launch of the kernels that can dominate.
 
     HBM-bound kernels: bytes that must cross HBM once (matrix entries 8 B each + dense operands in and out).
@@ -117,11 +118,16 @@ def kernel_models(N, G, H, S, nnz_aug, C, k, L=None, knn_window=1.0):
     L = L or (C + 10)
     CP = 32 if C <= 32 else 64
     Mp = -(-M // 512) * 512
-    nsamp_tiles = min(max(512, (Mp // 16) // 16), Mp // 16)      # tiles of the bound pass's subset (stage_knn)
-    return {
+    nsamp_tiles = min(max(512, (Mp // 16) // 24), Mp // 16)      # tiles of the bound pass's subset (stage_knn: max(512, tiles / 24))
+    # Bit-plane route (csrc/k_bitplane.hip): the stored entries equal to 1 are multiplied as bitmaps on the int8 matrix cores, the
+    # sparse kernels walk the others.  The sparse kernels' algorithmic bytes are then those of the entries they walk; the matrix-core
+    # kernels are priced by the int8 multiply-adds of the formulation (every (row, column) bit against L columns x ND digits).
+    bp = bitplane if (bitplane and bitplane.get("active")) else None
+    nnz_sparse = (bp["rest_original"] + bp["rest_synthetic"]) if bp else nnz_aug
+    models = {
         # name: (bound, unit, work per launch, peak)
-        "spmm_rows": ("hbm", "GB/s", (8 * nnz_aug + 8 * M * L + 8 * H * L + 8 * (M + 1)) / 1e9, HBM_PEAK_GBS),
-        "spmm_cols": ("hbm", "GB/s", (8 * nnz_aug + 8 * H * L + 8 * M * L + 16 * (H + 1)) / 1e9, HBM_PEAK_GBS),
+        "spmm_rows": ("hbm", "GB/s", (8 * nnz_sparse + 8 * M * L + 8 * H * L + 8 * (M + 1)) / 1e9, HBM_PEAK_GBS),
+        "spmm_cols": ("hbm", "GB/s", (8 * nnz_sparse + 8 * H * L + 8 * M * L + 16 * (H + 1)) / 1e9, HBM_PEAK_GBS),
         # distance screen on the bfloat16 MFMA.  USEFUL work: 2 flop per component and screened pair (the emit pass only
         # screens the tile pairs its first-component window admits: measured fraction).  The kernel ISSUES three products
         # (hi*hi, hi*lo, lo*hi) per pair on components padded to CP: see issued_per_launch below.
@@ -133,7 +139,18 @@ def kernel_models(N, G, H, S, nnz_aug, C, k, L=None, knn_window=1.0):
         "lognorm_cols": ("hbm", "GB/s", (12 * nnz_aug) / 1e9, HBM_PEAK_GBS),
         # counting-sort mirror of the synthetic rows: columns read twice (4 B), raw values once (4 B), (row, raw) written once (8 B)
         "mirror_build": ("hbm", "GB/s", (20 * nnz_aug * 2 * S / max(M + S, 1)) / 1e9, HBM_PEAK_GBS),
-    }, {"knn_emit": knn_window * 3 * 2.0 * Mp * Mp * CP / 1e12, "knn_bound": 3 * 2.0 * Mp * nsamp_tiles * 16 * CP / 1e12}
+    }
+    issued = {"knn_emit": knn_window * 3 * 2.0 * Mp * Mp * CP / 1e12, "knn_bound": 3 * 2.0 * Mp * nsamp_tiles * 16 * CP / 1e12}
+    if bp:
+        nd = bp["digits"]
+        nt32 = 4 if nd == 3 else 5                                # 32-wide tiles of the flattened (column, digit) index
+        m_pad = -(-N // 256) * 256 + -(-S // 64) * 64             # rows the kernels touch (originals padded to 256, synthetic rows to 64)
+        h_pad, k_rows = -(-H // 256) * 256, -(-N // 256) * 256 + -(-S // 256) * 256
+        models["bitplane_rows"] = ("mfma", "TOP/s", 2.0 * M * H * L * nd / 1e12, I8_PEAK_TOPS)
+        models["bitplane_cols"] = ("mfma", "TOP/s", 2.0 * M * H * L * nd / 1e12, I8_PEAK_TOPS)
+        issued["bitplane_rows"] = 2.0 * m_pad * h_pad * nt32 * 32 / 1e12
+        issued["bitplane_cols"] = 2.0 * (-(-H // 32) * 32) * k_rows * nt32 * 32 / 1e12
+    return models, issued
 
 
 def main():
@@ -242,7 +259,8 @@ def main():
         C = clf.n_components
         L_ = C + 10
         k = 30 if args.algorithm == "phenograph" else 10
-        models, issued = kernel_models(N, G, H, S, nnz_aug, C, k, knn_window=getattr(clf, "_last_knn_window", 1.0))
+        bp_stats = getattr(clf, "_last_bitplane", None)
+        models, issued = kernel_models(N, G, H, S, nnz_aug, C, k, knn_window=getattr(clf, "_last_knn_window", 1.0), bitplane=bp_stats)
         gpu_ms = {n: v[1] for n, v in timings.items()}
         modelled = [n for n in gpu_ms if n in models]
         dominant = max(modelled, key=gpu_ms.get) if modelled else None      # the dominant kernel among those with a byte / flop model
@@ -285,6 +303,23 @@ def main():
                                "other streams: see roofline_shared_gpu)")
         if roofline:
             roofline["measured"] = roofline_source
+        # one operator product as a whole against the bytes it would have to move as ONE pass over the stored entries (the figure
+        # rounds 1-4 quoted for the single sparse kernel): all its kernels' time, bit-plane preparation included
+        product = None
+        src_t = ({n: [v[0], v[1]] for n, v in exclusive.items()} if exclusive else timings)
+        if "spmm_rows" in src_t and "spmm_cols" in src_t:
+            def per_launch(n):
+                return src_t[n][1] / max(src_t[n][0], 1) if n in src_t else 0.0
+            full_gb = (8 * nnz_aug + 8 * (N + S) * L_ + 8 * H * L_ + 8 * (N + S + 1)) / 1e9
+            prep = per_launch("bitplane_prep")
+            product = {}
+            for side, mf in (("rows", "bitplane_rows"), ("cols", "bitplane_cols")):
+                ms = per_launch("spmm_" + side) + per_launch(mf) + prep
+                product["A Q" if side == "rows" else "A^T Y"] = {
+                    "ms_per_product": round(ms, 4), "kernels_ms": {"sparse": round(per_launch("spmm_" + side), 4), "matrix_cores": round(per_launch(mf), 4),
+                                                                  "preparation": round(prep, 4)},
+                    "one_pass_bytes_GB": round(full_gb, 4), "achieved_GBs": round(full_gb / (ms / 1e3), 1) if ms else None,
+                    "frac_of_hbm_peak": round(full_gb / (ms / 1e3) / HBM_PEAK_GBS, 4) if ms else None}
         out = {
             "metric": "cells/sec for full BoostClassifier.fit() (default n_iters)",
             "value": round(N * args.steps / elapsed, 2),
@@ -300,7 +335,8 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f32 products, f64 sums",
+            "dtype": ("int8 digits (30-bit fixed point) x bits on the matrix cores + f32 products, f64 sums" if (bp_stats and bp_stats.get("active"))
+                      else "f32 products, f64 sums"),
             "data": "synthetic",
             "config": {"workload": f"synthetic {N}x{G} counts, {X.nnz / (N * G):.3%} nnz, n_iters={args.iters}, "
                                    f"n_top_var_genes=10000, n_components=30, boost_rate=0.25, "
@@ -311,6 +347,8 @@ def main():
                        "host_threads": os.cpu_count()},
             "roofline": roofline,
             "roofline_top_kernels": roofline_all,
+            "operator_product": product,
+            "bitplane": bp_stats,
             "roofline_shared_gpu": roofline_timed,
             "roofline_shared_gpu_top_kernels": roofline_timed_all,
             "gpu_kernel_ms_per_step": {n: round(v / nsteps_i, 3) for n, v in sorted(gpu_ms.items(), key=lambda kv: -kv[1])},
@@ -320,9 +358,12 @@ def main():
             "gpu_busy_frac_note": "union of the kernel-scope intervals of all streams / wall-clock of the instrumented fits",
             "host_seconds_last_step": {k2: round(v, 3) for k2, v in getattr(clf, "_host_timings", {}).items()},
             "datagen_s": round(t_gen, 2),
-            "notes": "PCA = sklearn's randomized SVD as 16 sparse operator products per iteration (no dense H x H Gram is "
-                     "formed, DESIGN.md section 3), so there is no MFMA Gram step to report; the MFMA units run the kNN "
-                     "distance screen (knn_emit / knn_bound rows of roofline_top_kernels)",
+            "notes": "PCA = sklearn's randomized SVD as 16 operator products per iteration (no dense H x H Gram is formed, DESIGN.md "
+                     "section 3).  Round 5: each product = the stored entries equal to 1 as bitmaps against 8-bit digits of the operand on "
+                     "the int8 matrix cores (bitplane_rows / bitplane_cols: MFMA-bound rows of roofline_top_kernels, exact integer "
+                     "arithmetic) + the other entries through the LDS-staged sparse kernel (spmm_rows / spmm_cols); `operator_product` "
+                     "prices a whole product against one pass over all stored entries.  The kNN distance screen runs on the bf16 MFMA "
+                     "(knn_emit / knn_bound)",
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(X, args, kw)

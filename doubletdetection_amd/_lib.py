@@ -23,6 +23,8 @@ c_f64_p = C.POINTER(C.c_double)
 
 
 E_ARG = -1           # DDX_E_ARG of include/ddx.h
+E_HIP = -2           # DDX_E_HIP
+W_UNCONVERGED = 2    # DDX_W_UNCONVERGED
 E_UNSUPPORTED = -5   # DDX_E_UNSUPPORTED
 
 
@@ -78,6 +80,7 @@ _SIGNATURES = {
     "ddx_get_knn_window_fraction": (C.c_int, [C.c_void_p, c_f64_p]),
     "ddx_get_knn_overflow_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "ddx_get_knn_candidate_counts": (C.c_int, [C.c_void_p, c_i32_p]),
+    "ddx_get_bitplane_stats": (C.c_int, [C.c_void_p, c_i64_p]),
     "ddx_build_graph": (C.c_int, [C.c_void_p, C.c_int32]),
     "ddx_graph_relations": (C.c_int, [C.c_void_p, C.c_int32, c_i32_p, c_f64_p]),
     "ddx_assemble_graph": (C.c_int, [C.c_int64, C.c_int32, c_i32_p, c_f64_p, c_i64_p, c_i32_p, c_f64_p]),
@@ -631,10 +634,13 @@ class Context:
 
         cb = _EIGH_FN(eigh)
         with single_threaded_blas():
-            self._c(self._lib.ddx_pca_exact_sparse(self._h, int(n_components), int(n_oversamples), float(tol), int(max_steps),
-                                                   _p(start, c_f64_p), C.byref(steps), C.cast(cb, C.c_void_p), None))
+            rc = self._lib.ddx_pca_exact_sparse(self._h, int(n_components), int(n_oversamples), float(tol), int(max_steps),
+                                                _p(start, c_f64_p), C.byref(steps), C.cast(cb, C.c_void_p), None)
         if failure:
             raise failure[0]
+        self.lanczos_converged = rc != W_UNCONVERGED          # (a positive code: the best Ritz pairs found are in place; the caller decides)
+        if rc != W_UNCONVERGED:
+            self._c(rc)
         self._embM, self._C = self.M, int(n_components)
         return int(steps.value)
 
@@ -689,6 +695,12 @@ class Context:
         n = C.c_int64(0)
         self._c(self._lib.ddx_get_knn_overflow_count(self._h, C.byref(n)))
         return int(n.value)
+
+    def bitplane_stats(self) -> dict:
+        """Did the last PCA's operator products take the bit-plane route, and what is left to the sparse products."""
+        out = np.zeros(4, dtype=np.int64)
+        self._c(self._lib.ddx_get_bitplane_stats(self._h, _p(out, c_i64_p)))
+        return {"active": bool(out[0]), "rest_original": int(out[1]), "rest_synthetic": int(out[2]), "digits": int(out[3])}
 
     def knn_candidate_counts(self) -> np.ndarray:
         out = np.empty(self._embM, dtype=np.int32)

@@ -252,8 +252,25 @@ class _HipEngine:
         c = self.ctx
         small = min(c.M, c.H)
         over = max(0, min(10, small - n_components))
-        start = np.random.RandomState(seed).normal(size=(small, n_components + over))
-        self.lanczos_steps = c.pca_exact_sparse(n_components, start, tol=1e-5, max_steps=40, n_oversamples=over)
+        width = n_components + over
+        self.lanczos_steps = 0
+        if small <= 20 * width:
+            # a Krylov space of 40-column blocks cannot grow far in so few dimensions (fewer than ~8 blocks leave the trailing
+            # components unconverged): upstream's ARPACK is exact at every size, and so is the eigen-decomposition of the
+            # (at most 800 x 800) Gram matrix
+            self._pca_exact(n_components)
+            return
+        start = np.random.RandomState(seed).normal(size=(small, width))
+        # residual 1e-6 of the eigenvalue (upstream: eigsh(tol=0), i.e. working precision; the scores are compared at 1e-4): convergence is
+        # superlinear, a digit costs about two steps (profiles/r05_block_lanczos.txt)
+        self.lanczos_steps = c.pca_exact_sparse(n_components, start, tol=1e-6, max_steps=48, n_oversamples=over)
+        if not getattr(c, "lanczos_converged", True):
+            if small <= 8192:
+                self._pca_exact(n_components)       # still cheap, and exact
+            else:
+                warnings.warn("truncated PCA of the sparse operator (pseudocount == 1): the block Lanczos solver stopped before its "
+                              f"tolerance after {self.lanczos_steps} steps; trailing components may be off by more than 1e-5",
+                              RuntimeWarning, stacklevel=2)
 
     def _pca_exact(self, n_components, block=40):
         """sklearn's exact regimes ("full" / "covariance_eigh"): eigen-decomposition of the smaller Gram
@@ -298,6 +315,9 @@ class _HipEngine:
 
     def knn_window_fraction(self):
         return self.ctx.knn_window_fraction()
+
+    def bitplane_stats(self):
+        return self.ctx.bitplane_stats()
 
 
 class BoostClassifier:
@@ -990,6 +1010,7 @@ class BoostClassifier:
             self._last_nnz_aug = lead.aug_nnz()     # stored entries of the last augmented matrix
         if mine and hasattr(lead, "knn_window_fraction"):
             self._last_knn_window = lead.knn_window_fraction()   # share of the tile pairs the last kNN screened
+            self._last_bitplane = lead.bitplane_stats() if hasattr(lead, "bitplane_stats") else None
 
         t_asm0 = time.perf_counter()
         if not direct:

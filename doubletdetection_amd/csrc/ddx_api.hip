@@ -45,6 +45,7 @@ void release(ddx_ctx* ctx, DevBuf& b) {
 }
 
 int allow_dynamic_lds(ddx_ctx* ctx, const void* kernel, int bytes) {
+    if (ctx->opt.fault == 1) return set_err(ctx, DDX_E_HIP, "dynamic LDS limit of %d bytes refused (fault injection)", bytes);
     auto it = ctx->lds_configured.find(kernel);
     if (it != ctx->lds_configured.end() && it->second >= bytes) return DDX_OK;      // (a later, larger request raises the limit again)
     DDX_HIP(ctx, hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
@@ -165,6 +166,7 @@ bool Options::set(const char* key, const char* value) {
     if (k == "knn_seg_steps") { if (!num(0, 1 << 20, &x)) return false; knn_seg_steps = (int)x; return true; }
     if (k == "knn_emit_waves") { if (!num(0, 8, &x) || (x != 0 && x != 4 && x != 8)) return false; knn_emit_waves = (int)x; return true; }
     if (k == "knn_debug") { knn_debug = on(); return true; }
+    if (k == "fault") { if (!num(0, 1, &x)) return false; fault = (int)x; return true; }
     if (k == "pca_debug") { pca_debug = on(); return true; }
     if (k == "row_sums") { if (v == "auto") row_sums_sequential = false; else if (v == "sequential") row_sums_sequential = true; else return false; return true; }
     if (k == "mirror") { if (v == "tiles") mirror_mode = 2; else if (v == "scatter") mirror_mode = 1; else if (v == "sort") mirror_mode = 0; else return false; return true; }
@@ -1107,6 +1109,17 @@ int ddx_get_knn_overflow_count(ddx_ctx* ctx, int64_t* n_queries) {
     int32_t n = 0;
     if (ctx->knn_overflow) DDX_TRY(d2h(ctx, &n, ctx->knn_overflow, sizeof(n)));
     *n_queries = n;
+    return DDX_OK;
+}
+
+int ddx_get_bitplane_stats(ddx_ctx* ctx, int64_t* out) {
+    REQUIRE_CTX(ctx);
+    NEED(out, "null output");
+    const bool on = ctx->bp.ready && ctx->bp.values;
+    out[0] = on ? 1 : 0;
+    out[1] = on ? ctx->bp.nrest_o : 0;
+    out[2] = on ? ctx->bp.nrest_s : 0;
+    out[3] = ctx->opt.bp_digits == 3 ? 3 : 4;
     return DDX_OK;
 }
 

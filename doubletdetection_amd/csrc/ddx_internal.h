@@ -54,6 +54,7 @@ struct Options {
     bool arena_guard = false;        // DDX_ARENA_GUARD=1: pattern-fill the pad behind every block, ddx_check_memory verifies it
     int knn_ablation = 0;            // only honoured under DDX_ABLATION
     int upload_debug = 0;            // 1: timings of the upload on stderr, 2: per chunk
+    int fault = 0;                   // fault injection (tests): 1 = allow_dynamic_lds fails
     bool hvg_fold = true;            // gene sums folded in while the packed matrix arrives (off: one pass after the upload)
     bool set(const char* key, const char* value);
 };
@@ -107,8 +108,8 @@ struct BitPlanes {
     float* restm_s_x = nullptr;
     double* srow = nullptr;          // [M] s_i = x_i(1) - z
     void* qd = nullptr;              // operand digits
-    double* cmax = nullptr;          // [64] column maxima of the operand
-    double* cscale = nullptr;        // [64] 2^-shift per column
+    double* cmax = nullptr;          // [2][64] column maxima of the operand: Q side, Y side
+    const double* ymax_of = nullptr; // the row-side matrix whose maxima (of diag(s) Y) the sparse A Q kernel has just left in cmax[64..]
     double* part = nullptr;          // partial blocks of the A^T Y product, one per chunk of the rows
 };
 

@@ -180,20 +180,17 @@ __device__ __forceinline__ int bp_shift(double cmax, int ND) {
     return 8 * ND - 2 - e;
 }
 
-// cscale[c] = 2^-shift(c): what the product kernel multiplies the recombined integer by
-__global__ void k_bp_scales(const double* __restrict__ cmax, int L, int ND, double* __restrict__ cscale) {
-    const int c = threadIdx.x;
-    if (c < 64) cscale[c] = c < L ? ldexp(1.0, -bp_shift(cmax[c], ND)) : 0.0;
-}
-
 // digits in the B-operand layout of v_mfma_i32_32x32x32_i8:
 //   qd[((sk * 8 + s) * NT + nt) * 64 + h * 32 + n] = 16 bytes e = 0..15: digit d of column c, f = nt * 32 + n = c * ND + d,
 //   operand row k = sk * 256 + h * 128 + s * 16 + e  (ROWMAP: k is a padded row index of the augmented matrix)
 // One thread per (sk, s, h, column slot): 16 operand values -> ND vectors.  Slots past L write the zero padding of the last tile.
 template <int ND, bool ROWMAP>
 __global__ void __launch_bounds__(256) k_bp_digits(const double* __restrict__ X, const double* __restrict__ wgt, int64_t R, int L, int NT, int nslot,
-                                                   const double* __restrict__ cmax, int64_t SK, int64_t Npad, int64_t N, v4i* __restrict__ qd) {
+                                                   const double* __restrict__ cmax, int64_t SK, int64_t Npad, int64_t N, v4i* __restrict__ qd,
+                                                   double* __restrict__ zero_me) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // the column maxima of the OTHER operand side are collected next (by atomic maxima, into zeros): nobody reads the old ones any more
+    if (zero_me && t < 64) zero_me[t] = 0.0;
     if (t >= SK * kBpSteps * 2 * nslot) return;
     const int slot = (int)(t % nslot);
     int64_t u = t / nslot;
@@ -244,7 +241,7 @@ struct BpProductArgs {
     int64_t SKstride;         // stages per tile in the bitmap's layout (>= SK)
     int sk_per_chunk;         // stages per chunk (grid.y chunks)
     int L;                    // sketch columns
-    const double* cscale;     // [64] 2^-shift per column
+    const double* cmax;       // [64] largest |operand| per column: the value of a digit sum is V 2^-shift(cmax)
     // ROWS (A Q): output row = bp_row_of(tile * 32 + r); out[row][c] = srow[row] * value
     const double* srow; int64_t Npad, N, M;
     // COLS (A^T Y): output row = tile * 32 + r < nOut; out[(chunk * nOut + row)][c] = value
@@ -345,6 +342,14 @@ __global__ void __launch_bounds__(64 * kBpWaves) k_bp_product(const BpProductArg
     constexpr int F = NT * 32, FS = F + 4;
     int32_t* scr = reinterpret_cast<int32_t*>(bp_smem) + wave * (8 * FS);
     const int n = lane & 31, hh = lane >> 5;
+    // output o = lane + 64 i of a band is (row o / L, column o % L): this lane's columns and their scales 2^-shift
+    constexpr int kOutPerLane = (8 * 40 + 63) / 64;
+    double myscale[kOutPerLane];
+#pragma unroll
+    for (int i = 0; i < kOutPerLane; ++i) {
+        const int o = lane + 64 * i;
+        myscale[i] = o < 8 * a.L ? ldexp(1.0, -bp_shift(a.cmax[o % a.L], ND)) : 0.0;
+    }
 #pragma unroll
     for (int t = 0; t < RT; ++t) {
         const int64_t tile = tile0 + t;
@@ -357,13 +362,16 @@ __global__ void __launch_bounds__(64 * kBpWaves) k_bp_product(const BpProductArg
                 for (int q = 0; q < 4; ++q) scr[(hh * 4 + q) * FS + c * 32 + n] = acc[t][c][b * 4 + q];
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            for (int o = lane; o < 8 * a.L; o += 64) {
+#pragma unroll
+            for (int i = 0; i < kOutPerLane; ++i) {
+                const int o = lane + 64 * i;
+                if (o >= 8 * a.L) break;
                 const int rr = o / a.L, col = o - rr * a.L;
                 const int32_t* dp = scr + rr * FS + col * ND;
                 double V = (double)dp[ND - 1];
 #pragma unroll
                 for (int d = ND - 2; d >= 0; --d) V = V * 256.0 + (double)dp[d];      // exact: integers below 2^53
-                const double val = V * a.cscale[col];                                // a power of two: exact
+                const double val = V * myscale[i];                                   // a power of two: exact
                 const int64_t pr = tile * 32 + b * 8 + rr;
                 if (ROWS) {
                     const int64_t row = bp_row_of(pr, a.Npad, a.N, a.M);
@@ -382,6 +390,7 @@ __global__ void __launch_bounds__(64 * kBpWaves) k_bp_product(const BpProductArg
 // host side
 // ------------------------------------------------------------------------------------------------
 static size_t bp_align(size_t v) { return (v + 255) & ~(size_t)255; }
+static int bp_workspace(ddx_ctx* ctx);
 
 static int bp_launch_bitmaps(ddx_ctx* ctx, int64_t tile0, int64_t ntiles) {
     BitPlanes& bp = ctx->bp;
@@ -510,7 +519,7 @@ int bp_clone(ddx_ctx* ctx, const ddx_ctx* src) {
     move(bp.bm_rows); move(bp.bm_cols); move(bp.rest_indptr); move(bp.rest_cols); move(bp.rest_pos); move(bp.rest_x);
     move(bp.restm_colptr); move(bp.restm_row); move(bp.restm_pos); move(bp.restm_x); move(bp.srow);
     bp.restm_s_colptr = nullptr; bp.restm_s_row = nullptr; bp.restm_s_x = nullptr;          // (views into the source's per-iteration buffers)
-    bp.qd = nullptr; bp.cmax = nullptr; bp.cscale = nullptr; bp.part = nullptr;
+    bp.qd = nullptr; bp.cmax = nullptr; bp.part = nullptr; bp.ymax_of = nullptr;
     bp.values = false;
     bp.ntile_s = 0; bp.nrest_s = 0;
     ctx->bp = bp;
@@ -585,23 +594,36 @@ int bp_refresh(ddx_ctx* ctx) {
         // bitmaps of the synthetic rows (tiles behind the padded originals)
         DDX_TRY(bp_launch_bitmaps(ctx, bp.ntile_o, bp.ntile_s));
     }
+    DDX_TRY(bp_workspace(ctx));
     DDX_HIP(ctx, hipGetLastError());
     bp.values = true;
     return DDX_OK;
 }
 
-static int bp_workspace(ddx_ctx* ctx, int NT, int chunks) {
+// chunks of the k dimension of the A^T Y product (the padded rows): enough workgroups for a whole round of the GPU
+static int bp_col_chunks(const BitPlanes& bp, int64_t SK, int* per_out) {
+    const int64_t wgcols = ceil_div(bp.ntile_c, kBpWaves * 2);
+    int chunks = (int)std::max<int64_t>(1, std::min<int64_t>(SK, 256 / std::max<int64_t>(1, wgcols)));
+    const int per = (int)ceil_div(SK, chunks);
+    if (per_out) *per_out = per;
+    return (int)ceil_div(SK, per);
+}
+
+// work space of the products, sized once per iteration (bp_refresh) for both of them: digits | column maxima (Q side, Y side) | partial blocks
+static int bp_workspace(ddx_ctx* ctx) {
     BitPlanes& bp = ctx->bp;
     const int64_t SKmax = std::max<int64_t>(bp.SKc, bp.SKr_cap);
-    const size_t dig = bp_align(sizeof(v4i) * (size_t)SKmax * kBpSteps * NT * 64);
-    const size_t prt = bp_align(sizeof(double) * (size_t)chunks * ctx->H * 64);
+    const size_t dig = bp_align(sizeof(v4i) * (size_t)SKmax * kBpSteps * 5 * 64);
+    const int chunks = bp_col_chunks(bp, bp.SKr_cap, nullptr);
+    const size_t prt = bp_align(sizeof(double) * (size_t)chunks * ctx->H * 40);
     const size_t need = dig + bp_align(sizeof(double) * 128) + prt;
     DDX_TRY(ensure(ctx, ctx->bp_work, need));
     char* b = ctx->bp_work.as<char>();
     bp.qd = b;
-    bp.cmax = reinterpret_cast<double*>(b + dig);
-    bp.cscale = bp.cmax + 64;
+    bp.cmax = reinterpret_cast<double*>(b + dig);                 // [0..63]: Q side, [64..127]: Y side
     bp.part = reinterpret_cast<double*>(b + dig + bp_align(sizeof(double) * 128));
+    DDX_HIP(ctx, hipMemsetAsync(bp.cmax, 0, sizeof(double) * 128, ctx->stream));
+    bp.ymax_of = nullptr;
     return DDX_OK;
 }
 
@@ -633,53 +655,60 @@ static int bp_pick_rt(int64_t ntile, int chunks) {
     return pick;
 }
 
-// Y[i][:] = s_i (B Q)[i][:] for every row i of the augmented matrix (plain stores: the sparse product that follows adds its part)
+// Y[i][:] = s_i (B Q)[i][:] for every row i of the augmented matrix (plain stores: the sparse product that follows adds its part
+// and, through *ymax, collects the column maxima of diag(s) Y that the A^T Y product will cut its digits by)
 int bp_rows_product(ddx_ctx* ctx, const double* Q, int L, double* Y) {
     BitPlanes& bp = ctx->bp;
-    const int ND = ctx->opt.bp_digits == 4 ? 4 : 3;
+    const int ND = ctx->opt.bp_digits == 3 ? 3 : 4;
     const int NT = ND == 3 ? 4 : 5;
-    DDX_TRY(bp_workspace(ctx, NT, 1));
     v4i* qd = reinterpret_cast<v4i*>(bp.qd);
-    ScopedTimer t(ctx, "bitplane_rows");
-    DDX_HIP(ctx, hipMemsetAsync(bp.cmax, 0, sizeof(double) * 64, ctx->stream));
-    k_bp_colmax<<<(unsigned)std::min<int64_t>(256, ceil_div(ctx->H, 64)), 256, 0, ctx->stream>>>(Q, nullptr, ctx->H, L, bp.cmax);
-    k_bp_scales<<<1, 64, 0, ctx->stream>>>(bp.cmax, L, ND, bp.cscale);
-    const int nslot = (NT * 32 + ND - 1) / ND;
-    const int64_t nthreads = (int64_t)bp.SKc * kBpSteps * 2 * nslot;
-    if (ND == 3) k_bp_digits<3, false><<<(unsigned)ceil_div(nthreads, 256), 256, 0, ctx->stream>>>(Q, nullptr, ctx->H, L, NT, nslot, bp.cmax, bp.SKc, 0, 0, qd);
-    else k_bp_digits<4, false><<<(unsigned)ceil_div(nthreads, 256), 256, 0, ctx->stream>>>(Q, nullptr, ctx->H, L, NT, nslot, bp.cmax, bp.SKc, 0, 0, qd);
+    double* cmaxQ = bp.cmax;
+    double* cmaxY = bp.cmax + 64;
+    {
+        ScopedTimer t(ctx, "bitplane_prep");
+        k_bp_colmax<<<(unsigned)std::min<int64_t>(256, ceil_div(ctx->H, 64)), 256, 0, ctx->stream>>>(Q, nullptr, ctx->H, L, cmaxQ);      // (into zeros: bp_refresh / the last Y-side digits)
+        const int nslot = (NT * 32 + ND - 1) / ND;
+        const int64_t nthreads = std::max<int64_t>(64, (int64_t)bp.SKc * kBpSteps * 2 * nslot);
+        if (ND == 3) k_bp_digits<3, false><<<(unsigned)ceil_div(nthreads, 256), 256, 0, ctx->stream>>>(Q, nullptr, ctx->H, L, NT, nslot, cmaxQ, bp.SKc, 0, 0, qd, cmaxY);
+        else k_bp_digits<4, false><<<(unsigned)ceil_div(nthreads, 256), 256, 0, ctx->stream>>>(Q, nullptr, ctx->H, L, NT, nslot, cmaxQ, bp.SKc, 0, 0, qd, cmaxY);
+    }
+    bp.ymax_of = nullptr;
     BpProductArgs a{};
     a.bm = reinterpret_cast<const v4i*>(bp.bm_rows); a.qd = qd; a.ntile = bp.ntile_o + bp.ntile_s; a.SK = bp.SKc; a.SKstride = bp.SKc; a.sk_per_chunk = bp.SKc; a.L = L;
-    a.cscale = bp.cscale;
+    a.cmax = cmaxQ;
     a.srow = bp.srow; a.Npad = bp.Npad; a.N = ctx->N; a.M = ctx->M; a.nOut = ctx->M; a.out = Y;
+    ScopedTimer t(ctx, "bitplane_rows");
     return bp_launch<true>(ctx, a, 1, ND, bp_pick_rt(a.ntile, 1));
 }
 
 // partial blocks of W1[j][:] = sum over the rows i of B[i][j] s_i Y[i][:]: *chunks blocks [H x L] float64 at *part, to be added by k_sum_panels
 int bp_cols_product(ddx_ctx* ctx, const double* Y, int L, const double** part, int* chunks_out) {
     BitPlanes& bp = ctx->bp;
-    const int ND = ctx->opt.bp_digits == 4 ? 4 : 3;
+    const int ND = ctx->opt.bp_digits == 3 ? 3 : 4;
     const int NT = ND == 3 ? 4 : 5;
     const int64_t SK = bp.SKr_used;
-    // chunks of the k dimension (the padded rows): enough workgroups for a whole round of the GPU
-    const int64_t wgcols = ceil_div(bp.ntile_c, kBpWaves * 2);
-    int chunks = (int)std::max<int64_t>(1, std::min<int64_t>(SK, 256 / std::max<int64_t>(1, wgcols)));
-    const int per = (int)ceil_div(SK, chunks);
-    chunks = (int)ceil_div(SK, per);
-    DDX_TRY(bp_workspace(ctx, NT, chunks));
+    int per = 1;
+    const int chunks = bp_col_chunks(bp, SK, &per);
     v4i* qd = reinterpret_cast<v4i*>(bp.qd);
-    ScopedTimer t(ctx, "bitplane_cols");
-    DDX_HIP(ctx, hipMemsetAsync(bp.cmax, 0, sizeof(double) * 64, ctx->stream));
-    k_bp_colmax<<<(unsigned)std::min<int64_t>(1024, ceil_div(ctx->M, 64)), 256, 0, ctx->stream>>>(Y, bp.srow, ctx->M, L, bp.cmax);
-    k_bp_scales<<<1, 64, 0, ctx->stream>>>(bp.cmax, L, ND, bp.cscale);
-    const int nslot = (NT * 32 + ND - 1) / ND;
-    const int64_t nthreads = SK * kBpSteps * 2 * nslot;
-    if (ND == 3) k_bp_digits<3, true><<<(unsigned)ceil_div(nthreads, 256), 256, 0, ctx->stream>>>(Y, bp.srow, ctx->M, L, NT, nslot, bp.cmax, SK, bp.Npad, ctx->N, qd);
-    else k_bp_digits<4, true><<<(unsigned)ceil_div(nthreads, 256), 256, 0, ctx->stream>>>(Y, bp.srow, ctx->M, L, NT, nslot, bp.cmax, SK, bp.Npad, ctx->N, qd);
+    double* cmaxQ = bp.cmax;
+    double* cmaxY = bp.cmax + 64;
+    {
+        ScopedTimer t(ctx, "bitplane_prep");
+        if (bp.ymax_of != Y) {                                    // Y was not written by the sparse A Q kernel of this context: its maxima by a pass of their own
+            DDX_HIP(ctx, hipMemsetAsync(cmaxY, 0, sizeof(double) * 64, ctx->stream));
+            k_bp_colmax<<<(unsigned)std::min<int64_t>(1024, ceil_div(ctx->M, 64)), 256, 0, ctx->stream>>>(Y, bp.srow, ctx->M, L, cmaxY);
+        }
+        const int nslot = (NT * 32 + ND - 1) / ND;
+        const int64_t nthreads = std::max<int64_t>(64, SK * kBpSteps * 2 * nslot);
+        if (ND == 3) k_bp_digits<3, true><<<(unsigned)ceil_div(nthreads, 256), 256, 0, ctx->stream>>>(Y, bp.srow, ctx->M, L, NT, nslot, cmaxY, SK, bp.Npad, ctx->N, qd, cmaxQ);
+        else k_bp_digits<4, true><<<(unsigned)ceil_div(nthreads, 256), 256, 0, ctx->stream>>>(Y, bp.srow, ctx->M, L, NT, nslot, cmaxY, SK, bp.Npad, ctx->N, qd, cmaxQ);
+    }
+    bp.ymax_of = nullptr;
     BpProductArgs a{};
     a.bm = reinterpret_cast<const v4i*>(bp.bm_cols); a.qd = qd; a.ntile = bp.ntile_c; a.SK = (int)SK; a.SKstride = bp.SKr; a.sk_per_chunk = per; a.L = L;
-    a.cscale = bp.cscale; a.nOut = ctx->H; a.out = bp.part;
+    a.cmax = cmaxY; a.nOut = ctx->H; a.out = bp.part;
     // (the bitmap's stage stride is the capacity SKr; the stages in use are [0, SKr_used): the chunks cover only those)
+    ScopedTimer t(ctx, "bitplane_cols");
     DDX_TRY(bp_launch<false>(ctx, a, chunks, ND, 2));
     *part = bp.part;
     *chunks_out = chunks;

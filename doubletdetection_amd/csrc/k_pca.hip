@@ -275,6 +275,8 @@ struct LdsSpmmArgs {
     // ROWS
     const int64_t* indptr; const int32_t* cols; const float* x; const float* zcol; const int32_t* rowseg; const double* tvec;
     int accumulate;               // ROWS, bit-plane mode: `out` already holds the bit-plane part of the product (k_bitplane.hip); the sparse part is added to it
+    const double* srow;           // ... and the largest |srow[i] y[i][c]| per column goes to ymax[c] (atomic maxima of the bit patterns: exact in any
+    unsigned long long* ymax;     //     order): what the A^T Y product cuts its digits by
     // COLS
     const int64_t* cp_o; const int32_t* row_o; const float* x_o; int P_o;
     const int64_t* cp_s; const int32_t* row_s; const float* x_s; int p_s0, P_s;
@@ -640,6 +642,9 @@ __global__ void __launch_bounds__(kLdsThreads) k_spmm_lds(const LdsSpmmArgs a) {
         }
     }
     // every lane group writes its own outputs
+    double cm[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) cm[c] = 0.0;
 #pragma unroll
     for (int k = 0; k < OWN; ++k) {
         const int64_t o = __shfl(myout, k * SLOTS + slot, 64);     // the bounds lane of this group's k-th output knows it
@@ -652,6 +657,7 @@ __global__ void __launch_bounds__(kLdsThreads) k_spmm_lds(const LdsSpmmArgs a) {
                         double y = acc[k][c] - a.tvec[col];
                         if (a.accumulate) y += a.out[o * a.L + col];
                         a.out[o * a.L + col] = y;
+                        if (a.ymax) { const double v = fabs(a.srow[o] * y); cm[c] = v > cm[c] ? v : cm[c]; }
                         if (a.out32) a.out32[o * a.ld + col] = (float)y;
                     } else {
                         a.out[((int64_t)group * a.nOut + o) * a.L + col] = acc[k][c];
@@ -659,6 +665,19 @@ __global__ void __launch_bounds__(kLdsThreads) k_spmm_lds(const LdsSpmmArgs a) {
                 }
             }
         }
+    }
+    if (ROWS && a.ymax) {                               // (uniform) column maxima: lanes -> LDS -> one global atomic per column and workgroup
+        unsigned long long* red = reinterpret_cast<unsigned long long*>(smem);
+        __syncthreads();                                // everybody is done with the operand slice
+        if (threadIdx.x < 64) red[threadIdx.x] = 0ull;
+        __syncthreads();
+        if (active) {
+#pragma unroll
+            for (int c = 0; c < CPL; ++c)
+                if (CPL * sub + c < a.L && cm[c] > 0.0) atomicMax(&red[CPL * sub + c], (unsigned long long)__double_as_longlong(cm[c]));
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < a.L && red[threadIdx.x]) atomicMax(a.ymax + threadIdx.x, red[threadIdx.x]);
     }
 }
 
@@ -1098,7 +1117,8 @@ struct PcaWork {
     int64_t M;
     int32_t H;
     bool lds;          // LDS-staged products (needs gather32 and a slice that fits the LDS)
-    bool bitplane = false;   // the original rows' entries equal to 1 go through the bit-plane products (k_bitplane.hip)
+    bool bitplane = false;   // the entries equal to 1 go through the bit-plane products (k_bitplane.hip)
+    bool fused_ymax = true;  // the sparse A Q kernel's column maxima may serve the A^T Y product that follows (off where row-side matrices are rewritten in place)
     int rows_SR = 0, rows_ns = 0;   // A Q: slice height / slice count of the H-row operand
     double* partial;   // scratch for block partials
     double* small;     // [4*L*L + 4*L]: G, Rinv, T, vecs
@@ -1177,8 +1197,9 @@ static void chol_inverse_host(int L, std::vector<double>& a, std::vector<double>
 static int cholqr(PcaWork& w, const double* X, int64_t R, double* out) {
     double* G = w.small;
     double* Rinv = w.small + w.L * w.L;
+    if (w.ctx->bp.ymax_of == out) w.ctx->bp.ymax_of = nullptr;      // (the matrix whose column maxima were taken is overwritten)
     ScopedTimer t(w.ctx, "pca_orth");
-    gram(w, X, R, G);
+    DDX_TRY(gram(w, X, R, G));
     if (w.L > kMaxL) {
         const int L = w.L;
         std::vector<double> hG((size_t)L * L), hInv;
@@ -1188,7 +1209,7 @@ static int cholqr(PcaWork& w, const double* X, int64_t R, double* out) {
         chol_inverse_host(L, hG, hInv, &hflag);
         if (hflag) DDX_HIP(w.ctx, hipMemcpyAsync(w.flag, &hflag, sizeof(int), hipMemcpyHostToDevice, w.ctx->stream));
         DDX_HIP(w.ctx, hipMemcpyAsync(Rinv, hInv.data(), sizeof(double) * L * L, hipMemcpyHostToDevice, w.ctx->stream));
-        right_mult(w.ctx, X, R, L, Rinv, L, out);
+        DDX_TRY(right_mult(w.ctx, X, R, L, Rinv, L, out));
         DDX_HIP(w.ctx, hipStreamSynchronize(w.ctx->stream));       // hInv / hflag are stack-backed
         return DDX_OK;
     }
@@ -1241,6 +1262,7 @@ template <bool ROWS, int SLOTS, bool PK, int CPL, int OWN>
 static int launch_lds_t(ddx_ctx* c, const LdsSpmmArgs& a, unsigned grid, size_t lds_bytes) {
     DDX_TRY(allow_dynamic_lds(c, reinterpret_cast<const void*>(&k_spmm_lds<ROWS, SLOTS, PK, CPL, OWN>), (int)kLdsBudget));
     k_spmm_lds<ROWS, SLOTS, PK, CPL, OWN><<<grid, kLdsThreads, lds_bytes, c->stream>>>(a);
+    DDX_HIP(c, hipGetLastError());                // (a refused launch must not leave the iterate as it was)
     return DDX_OK;
 }
 
@@ -1266,7 +1288,7 @@ static int apply_rows(PcaWork& w, const double* Qcol, double* Yrow) {  // A Q : 
     double* tvec = w.small + 3 * w.L * w.L;
     {
         ScopedTimer t(c, "pca_colsum");
-        wcolsum(w, Qcol, w.H, c->colmean.as<double>(), tvec);
+        DDX_TRY(wcolsum(w, Qcol, w.H, c->colmean.as<double>(), tvec));
     }
     // Y = diag(s) B Q on the matrix cores first (a timing scope of its own); the sparse kernel then sees only the entries other
     // than 1 and adds its part
@@ -1302,6 +1324,9 @@ static int apply_rows(PcaWork& w, const double* Qcol, double* Yrow) {  // A Q : 
         if (w.bitplane) {
             a.indptr = c->bp.rest_indptr; a.cols = c->bp.rest_cols; a.x = c->bp.rest_x;
             a.accumulate = 1;
+            a.srow = c->bp.srow;
+            a.ymax = reinterpret_cast<unsigned long long*>(c->bp.cmax + 64);
+            c->bp.ymax_of = w.fused_ymax ? Yrow : nullptr;
         }
         const size_t lds_bytes = (size_t)a.SR * a.ld * 4 + (size_t)((a.SR + 3) & ~3) * 4 + lds_stage_bytes(slots, lds_packed());
         DDX_TRY(launch_lds<true>(c, a, slots, (unsigned)a.owners, lds_bytes));
@@ -1331,7 +1356,7 @@ static int apply_cols(PcaWork& w, const double* Yrow, double* Wcol) {  // A^T Y 
     double* uvec = w.small + 3 * w.L * w.L + w.L;
     {
         ScopedTimer t(c, "pca_colsum");
-        wcolsum(w, Yrow, w.M, nullptr, uvec);
+        DDX_TRY(wcolsum(w, Yrow, w.M, nullptr, uvec));
     }
     const int P = (int)ceil_div(w.M, c->panel_rows);
     const int groups = (w.H + 3) / 4;
@@ -1621,33 +1646,33 @@ int stage_pca(ddx_ctx* ctx, int32_t C, int32_t oversample, int32_t n_iter, const
         // subspace, and in float64 a single step of A^T A (condition (s1/s40)^2) loses nothing measurable
         // (scores agree with the LU-per-half-step evaluation to 1e-12)
         for (int it = 0; it < n_iter; ++it) {
-            apply_rows(w, colA, rowA);
-            apply_cols(w, rowA, colB);
-            cholqr(w, colB, H, colA);
+            DDX_TRY(apply_rows(w, colA, rowA));
+            DDX_TRY(apply_cols(w, rowA, colB));
+            DDX_TRY(cholqr(w, colB, H, colA));
         }
-        apply_rows(w, colA, rowA);
-        cholqr(w, rowA, M, rowB);
-        cholqr(w, rowB, M, rowA);       // second pass: orthonormal to working precision
-        apply_cols(w, rowA, colB);
+        DDX_TRY(apply_rows(w, colA, rowA));
+        DDX_TRY(cholqr(w, rowA, M, rowB));
+        DDX_TRY(cholqr(w, rowB, M, rowA));       // second pass: orthonormal to working precision
+        DDX_TRY(apply_cols(w, rowA, colB));
         Qfinal = rowA; RQ = M;
         Bt = colB; RB = H;
     } else {
         DDX_HIP(ctx, hipMemcpyAsync(rowA, ctx->pcaQ0.p, sizeof(double) * (size_t)M * L, hipMemcpyDeviceToDevice, ctx->stream));
         for (int it = 0; it < n_iter; ++it) {
-            apply_cols(w, rowA, colA);
-            apply_rows(w, colA, rowB);
-            cholqr(w, rowB, M, rowA);
+            DDX_TRY(apply_cols(w, rowA, colA));
+            DDX_TRY(apply_rows(w, colA, rowB));
+            DDX_TRY(cholqr(w, rowB, M, rowA));
         }
-        apply_cols(w, rowA, colA);
-        cholqr(w, colA, H, colB);
-        cholqr(w, colB, H, colA);
-        apply_rows(w, colA, rowB);
+        DDX_TRY(apply_cols(w, rowA, colA));
+        DDX_TRY(cholqr(w, colA, H, colB));
+        DDX_TRY(cholqr(w, colB, H, colA));
+        DDX_TRY(apply_rows(w, colA, rowB));
         Qfinal = colA; RQ = H;
         Bt = rowB; RB = M;
     }
     // small eigenproblem: B B^T = Bt^T Bt = Uhat diag(s^2) Uhat^T
     double* G = w.small;
-    gram(w, Bt, RB, G);
+    DDX_TRY(gram(w, Bt, RB, G));
     std::vector<double> hG((size_t)L * L), evals(L), evecs((size_t)L * L);
     DDX_HIP(ctx, hipMemcpyAsync(hG.data(), G, sizeof(double) * L * L, hipMemcpyDeviceToHost, ctx->stream));
     int hflag = 0;
@@ -1675,7 +1700,7 @@ int stage_pca(ddx_ctx* ctx, int32_t C, int32_t oversample, int32_t n_iter, const
     double* scratchHC = transposed ? colB : colA;      // H x C scratch (colA/colB are H x L >= H x C)
     {
         ScopedTimer t(ctx, "pca_finish");
-        right_mult(ctx, signSrc, signR, L, dT, C, scratchHC);
+        DDX_TRY(right_mult(ctx, signSrc, signR, L, dT, C, scratchHC));
         k_col_sign<<<C, 256, 0, ctx->stream>>>(scratchHC, signR, C, dSign);
     }
     std::vector<double> hsign(C);
@@ -1690,7 +1715,7 @@ int stage_pca(ddx_ctx* ctx, int32_t C, int32_t oversample, int32_t n_iter, const
     {
         ScopedTimer t(ctx, "pca_finish");
         const double* scoreSrc = transposed ? Bt : Qfinal;  // both M x L
-        right_mult(ctx, scoreSrc, M, L, dT, C, ctx->emb64.as<double>());
+        DDX_TRY(right_mult(ctx, scoreSrc, M, L, dT, C, ctx->emb64.as<double>()));
         k_f64_to_f32<<<(unsigned)ceil_div(M * C, 256), 256, 0, ctx->stream>>>(ctx->emb64.as<double>(), M * C, ctx->emb32.as<float>());
     }
     DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));  // T2/svals are stack-backed host buffers
@@ -1918,6 +1943,7 @@ int stage_pca_block_lanczos(ddx_ctx* ctx, int32_t C, int32_t oversample, double 
     PcaWork w;
     w.ctx = ctx; w.L = L; w.lpn = (L + 1) / 2; w.slots = 64 / w.lpn; w.gather32 = ctx->opt.gather_f32; w.M = M; w.H = H;
     DDX_TRY(lds_setup(ctx, L, w));
+    w.fused_ymax = cols_side;              // (row-side blocks are re-orthogonalised in place between the products)
     const int64_t maxR = M > H ? M : (int64_t)H;
     DDX_TRY(ensure(ctx, ctx->pcaOp, sizeof(double) * (size_t)maxR * (L + 4)));
     w.op32 = ctx->pcaOp.as<float>();
@@ -1965,7 +1991,8 @@ int stage_pca_block_lanczos(ddx_ctx* ctx, int32_t C, int32_t oversample, double 
     int n = 0;
     double t_prod = 0.0, t_orth = 0.0, t_ritz = 0.0;
     int next_check = 8, prev_step = 0;
-    double prev_res = -1.0;
+    double prev_res = -1.0, last_res = -1.0;
+    bool converged = false;
     auto now = [&]() { (void)hipStreamSynchronize(ctx->stream); return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const bool dbg = ctx->opt.pca_debug;
     for (int j = 0; j < max_steps; ++j) {
@@ -2029,6 +2056,8 @@ int stage_pca_block_lanczos(ddx_ctx* ctx, int32_t C, int32_t oversample, double 
             fprintf(stderr, "[lanczos] step %d: n = %d, worst residual / eigenvalue %.2e; so far products %.1f ms, orthogonalisation %.1f ms, Ritz %.1f ms\n", j + 1, n, worst,
                     t_prod, t_orth, t_ritz);
         }
+        last_res = worst;
+        if (worst <= tol) converged = true;
         if (worst <= tol || last) break;
         if (prev_res > 0.0 && worst > 0.0 && worst < prev_res) {
             const double rate = std::pow(worst / prev_res, 1.0 / (double)(j + 1 - prev_step));      // per step, < 1
@@ -2088,6 +2117,13 @@ int stage_pca_block_lanczos(ddx_ctx* ctx, int32_t C, int32_t oversample, double 
     ctx->embM = M;
     ctx->have_emb = true;
     ctx->have_knn = false;
+    if (!converged) {
+        // not fatal here: the embedding holds the best Ritz pairs of the space that was built.  Upstream's ARPACK is converged to
+        // working precision at every size, so the caller falls back to an exact decomposition or tells the user.
+        ctx->err = "block Lanczos stopped after " + std::to_string(steps) + " steps (" + std::to_string((long long)(steps + 1) * L) + " of " +
+                   std::to_string((long long)R) + " dimensions) with a relative residual of " + std::to_string(last_res) + " > tolerance " + std::to_string(tol);
+        return DDX_W_UNCONVERGED;
+    }
     return DDX_OK;
 }
 

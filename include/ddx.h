@@ -42,6 +42,8 @@ extern "C" {
 #define DDX_E_UNSUPPORTED -5
 /* positive codes: the call succeeded and its results are valid; ddx_last_error(ctx) holds a warning text */
 #define DDX_W_RANK 1      /* ddx_pca: the sketch is wider than the numerical rank of the matrix */
+#define DDX_W_UNCONVERGED 2   /* ddx_pca_exact_sparse: the Krylov space ran out (step limit, or the matrix is too small for it) before the
+                                 wanted pairs met the tolerance; the embedding holds the best Ritz pairs found -- the caller decides */
 
 typedef struct ddx_ctx ddx_ctx;
 
@@ -78,6 +80,7 @@ int ddx_synchronize(ddx_ctx* ctx);
  *   knn_seg_steps     n                 steps of a block's tile list per emit work item (0 = default)
  *   knn_emit_waves    4 | 8             waves per emit workgroup (0 = default)
  *   knn_fold          1 | 0             threshold folded into the screen's operands
+ *   fault             0 | 1             fault injection for the error-path tests: 1 = every request for a larger dynamic-LDS limit is refused
  *   knn_xcd_chunk     n                 consecutive query blocks of the bound pass per XCD (0 = launch order)
  *   knn_debug         0 | 1             statistics of the kNN passes on stderr
  *   pca_debug         0 | 1             progress of ddx_pca_exact_sparse on stderr
@@ -222,6 +225,10 @@ int ddx_get_knn_overflow_count(ddx_ctx* ctx, int64_t* n_queries);
 /* statistics: candidates the distance screen listed for every query of the last ddx_knn (more than the list holds = that query
  * overflowed); the parity tests pick the queries with the longest lists from it. */
 int ddx_get_knn_candidate_counts(ddx_ctx* ctx, int32_t* counts_out /* [M] */);
+/* statistics of the bit-plane route of the last ddx_pca (sc.tl.pca call site, dd.py:305-314; csrc/k_bitplane.hip):
+ * out[0] = 1 when the last iteration's operator products took it, out[1] / out[2] = stored entries other than 1 of the original /
+ * synthetic rows (what the sparse products still walk), out[3] = 8-bit digits per operand value.  bench.py prices the kernels by it. */
+int ddx_get_bitplane_stats(ddx_ctx* ctx, int64_t* out /* [4] */);
 
 /* ---- graph construction (device) ------------------------------------------------------------
  * mode 0: PhenoGraph Jaccard graph, prune=True  (mutual kNN, weight J_ij*J_ji)

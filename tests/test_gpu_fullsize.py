@@ -133,6 +133,40 @@ def test_c2_pca_matches_f64_oracle(staged):
     pca_against_f64_oracle(ctx)
 
 
+def test_c2_sparse_pca_scores_match_an_exact_decomposition(staged):
+    """pseudocount = 1 at configs[1] (dd.py:296-297,308: sparse matrix, ARPACK upstream): the block Lanczos solver on the device
+    (ddx_pca_exact_sparse, with the tolerance the classifier uses) against the exact truncated PCA of the matrix read back from
+    the device -- eigen-decomposition of the 10 000 x 10 000 Gram matrix of the centred matrix in float64.  Bar: 1e-4 per
+    component (north star), components 1..30."""
+    import time
+
+    ctx = staged[0]
+    ctx.lognormalise(1.0)
+    M, H, C = ctx.M, ctx.H, 30
+    start = np.random.RandomState(0).normal(size=(H, C + 10))
+    t0 = time.perf_counter()
+    steps = ctx.pca_exact_sparse(C, start, tol=1e-6, max_steps=48)
+    ctx.synchronize()
+    t1 = time.perf_counter()
+    assert ctx.lanczos_converged
+    emb, sing = ctx.embedding_f64()
+    A = np.empty((M, H), dtype=np.float64)
+    for r in range(0, M, 4096):
+        n = min(4096, M - r)
+        A[r:r + n] = ctx.aug_dense_rows(r, n)
+    A -= A.mean(axis=0)
+    evals, evecs = np.linalg.eigh(A.T @ A)
+    V = evecs[:, ::-1][:, :C]
+    V = V * np.sign(V[np.argmax(np.abs(V), axis=0), np.arange(C)])
+    want = A @ V
+    rel = np.linalg.norm(emb - want, axis=0) / np.linalg.norm(want, axis=0)
+    print(f"block Lanczos {M} x {H}: {steps} steps, {1e3 * (t1 - t0):.1f} ms; scores against the exact decomposition: max {rel.max():.2e} "
+          f"(signal components 1-12: {rel[:12].max():.2e}); singular values max rel {np.abs(sing / np.sqrt(evals[::-1][:C]) - 1).max():.2e}")
+    assert rel.max() <= 1e-4, rel
+    np.testing.assert_allclose(sing, np.sqrt(evals[::-1][:C]), rtol=1e-7)
+    ctx.lognormalise(0.1)                              # (the module's other tests expect the default matrix)
+
+
 def test_operator_product_variants_agree_at_full_size(data, staged, monkeypatch):
     """The same randomized PCA through the implementations of the operator products: bit planes on the int8 matrix cores
     + LDS-staged sparse products for the entries other than 1 (the default from 4096 cells on; four or three 8-bit digits),

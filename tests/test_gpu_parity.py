@@ -714,6 +714,69 @@ def test_sparse_arpack_path_pseudocount_one(ctx):
     assert agree_ref > 0.95, agree_ref
 
 
+def test_sparse_path_on_few_genes_is_exact():
+    """pseudocount=1 with 100 - 200 highly variable genes: a Krylov space of 40-column blocks has no room to converge in so few
+    dimensions (round 4 returned whatever one or two steps gave, silently); the host now takes the exact decomposition of the
+    small Gram matrix there -- ARPACK upstream is exact at every size -- and the fit equals the float64 oracle."""
+    from doubletdetection_amd import BoostClassifier
+    from doubletdetection_amd._synthetic import make_counts
+
+    counts = make_counts(1200, 600, density=0.2, n_types=5, seed=21)
+    for ntop in (100, 160, 320):
+        kw = dict(n_top_var_genes=ntop, pseudocount=1.0, n_iters=2, random_state=3, clustering_algorithm="louvain")
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            clf = BoostClassifier(**kw).fit(counts)
+            ref = orc.OracleClassifier(pca="f64", **kw).fit(counts)
+        np.testing.assert_array_equal(np.asarray(clf.parents_), np.asarray(ref.parents_))
+        agree = np.mean(clf.communities_ == ref.communities_)
+        assert agree > 0.98, (ntop, agree)
+        np.testing.assert_allclose(clf.all_scores_[clf.communities_ == ref.communities_], ref.all_scores_[clf.communities_ == ref.communities_], rtol=0.05, atol=0.02)
+
+
+def test_block_lanczos_reports_an_unconverged_solve(ctx):
+    """ddx_pca_exact_sparse with too few steps for its tolerance returns DDX_W_UNCONVERGED (the best Ritz pairs in place): the caller
+    is told instead of handed an unconverged embedding as if it were the answer."""
+    from doubletdetection_amd._synthetic import make_counts
+
+    counts = make_counts(3000, 1500, density=0.1, n_types=5, seed=5)
+    ctx.upload_counts(counts)
+    ctx.create_doublets(np.random.default_rng(0).choice(3000, size=(750, 2), replace=False))
+    ctx.lognormalise(1.0)
+    start = np.random.RandomState(0).normal(size=(1500, 40))
+    steps = ctx.pca_exact_sparse(30, start, tol=1e-12, max_steps=3)
+    assert steps == 3 and ctx.lanczos_converged is False
+    steps = ctx.pca_exact_sparse(30, start, tol=1e-6, max_steps=36)
+    assert ctx.lanczos_converged is True and steps < 36
+    emb, _ = ctx.embedding_f64()
+    X = ctx.aug_dense_rows(0, ctx.M)
+    want, _, _ = orc.exact_pca_f64(X, 30)
+    dev = orc.per_component_rel_dev(emb, want)
+    assert dev.max() < 1e-4, dev
+
+
+def test_a_failing_stage_inside_the_pca_surfaces_as_an_error():
+    """Error path (fault injection, option fault=1: every request for a larger dynamic-LDS limit is refused): the first operator
+    product of ddx_pca cannot be launched -- the call must return the HIP error, not DDX_OK on an untouched iterate."""
+    from doubletdetection_amd import _lib
+    from doubletdetection_amd._synthetic import make_counts
+
+    counts = make_counts(2000, 900, density=0.1, n_types=4, seed=2)
+    with _lib.Context(0) as c:
+        c.upload_counts(counts)
+        c.create_doublets(np.random.default_rng(1).choice(2000, size=(500, 2), replace=False))
+        c.lognormalise(0.1)
+        q0 = orc.pca_start_matrix(0, 900, 40)
+        c.set_option("fault", "1")
+        with pytest.raises(_lib.DdxError) as err:
+            c.pca(30, q0)
+        assert err.value.code == _lib.E_HIP and "fault injection" in str(err.value)
+        c.set_option("fault", "0")
+        c.pca(30, q0)                                   # and the context is usable again
+        emb, _ = c.embedding_f64()
+        assert np.isfinite(emb).all()
+
+
 def test_fit_with_empty_cells_and_empty_genes():
     """Ragged input: cells without any count (library size 0: sklearn's row normalisation leaves them untouched, their
     log-normalised row is the constant log(pseudocount)), genes nobody expresses, a cell with a single count.  The
