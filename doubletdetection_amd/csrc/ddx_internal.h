@@ -99,9 +99,9 @@ struct BitPlanes {
     int32_t* rest_cols = nullptr;
     int32_t* rest_pos = nullptr;
     float* rest_x = nullptr;
-    int64_t* restm_colptr = nullptr; // reduced column-major mirror of the original rows: [P_o * H + 1], rows / position in the full mirror / value
+    int64_t* restm_colptr = nullptr; // reduced column-major mirror of the original rows: [P_o * H + 1], rows / counts / value
     int32_t* restm_row = nullptr;
-    int32_t* restm_pos = nullptr;
+    float* restm_raw = nullptr;      // (its counts: the values follow from them and the iteration's table)
     float* restm_x = nullptr;
     int64_t* restm_s_colptr = nullptr;   // ... of the synthetic rows: [P_s * H + 1], rows / value
     int32_t* restm_s_row = nullptr;
@@ -226,7 +226,9 @@ struct ddx_ctx {
     ddx::DevBuf knn_sorted;          // int32 [M*K] neighbour lists sorted by index
     ddx::DevBuf edge_w;              // double [M*K]
     ddx::DevBuf knn_cells;           // cells, interval tables and chunk lists of the emit pass (stage_knn)
-    ddx::DevBuf bp_buf, bp_work, bp_synth;   // bit-plane products: per-fit structures / per-product work space / the synthetic rows' reduced mirror
+    ddx::DevBuf bp_buf, bp_work;     // bit-plane products: per-fit structures / per-product work space
+    ddx::DevBuf bp_ms_colptr, bp_ms_row, bp_ms_x;   // ... the synthetic rows' reduced mirror (rebuilt every iteration)
+    bool mirror_full = false;        // csc_s_* and csc_*_x hold this iteration's full mirror (the bit-plane route leaves it out: ensure_full_mirror)
     ddx::BitPlanes bp;
     const int32_t* knn_overflow = nullptr;   // device counter: queries whose candidate list overflowed (exact rescan)
     const int32_t* knn_ccount = nullptr;     // candidates listed per query (kNN point order) and that order (views into the kNN work space)
@@ -351,6 +353,9 @@ int gene_sums_fold(ddx_ctx* ctx, int32_t G, int64_t n_rows, int64_t row0, int64_
 int stage_select_columns(ddx_ctx* ctx, const int64_t* cols, int32_t n_cols);
 // bit-plane products (k_bitplane.hip)
 int bp_build(ddx_ctx* ctx);
+int ensure_full_mirror(ddx_ctx* ctx);
+int bp_reduced_mirrors(ddx_ctx* ctx);
+int bp_colmean(ddx_ctx* ctx, const double* parts, int nparts);
 int bp_clone(ddx_ctx* ctx, const ddx_ctx* src);
 bool bp_wanted_at_upload(const ddx_ctx* ctx);
 int bp_refresh(ddx_ctx* ctx);

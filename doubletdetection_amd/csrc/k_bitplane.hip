@@ -391,6 +391,9 @@ __global__ void __launch_bounds__(64 * kBpWaves) k_bp_product(const BpProductArg
 // ------------------------------------------------------------------------------------------------
 static size_t bp_align(size_t v) { return (v + 255) & ~(size_t)255; }
 static int bp_workspace(ddx_ctx* ctx);
+static int bp_col_chunks(const BitPlanes& bp, int64_t SK, int* per_out);
+struct BpProductArgs;
+template <int RT, int NT, int ND, bool ROWS> static int bp_launch_t(ddx_ctx* ctx, const BpProductArgs& a, int chunks);
 
 static int bp_launch_bitmaps(ddx_ctx* ctx, int64_t tile0, int64_t ntiles) {
     BitPlanes& bp = ctx->bp;
@@ -460,7 +463,7 @@ int bp_build(ddx_ctx* ctx) {
     const int64_t cap_rest = total_r + bp.cap_rest_s;
     const size_t o_rip = carve(sizeof(int64_t) * (size_t)(N + Scap + 2)), o_rc = carve(sizeof(int32_t) * (size_t)cap_rest + 256), o_rx = carve(sizeof(float) * (size_t)cap_rest + 256);
     const size_t o_rp = carve(sizeof(int32_t) * (size_t)total_r + 256);
-    const size_t o_mcp = carve(sizeof(int64_t) * (size_t)(nseg + 1)), o_mr = carve(sizeof(int32_t) * (size_t)total_r + 256), o_mp = carve(sizeof(int32_t) * (size_t)total_r + 256);
+    const size_t o_mcp = carve(sizeof(int64_t) * (size_t)(nseg + 1)), o_mr = carve(sizeof(int32_t) * (size_t)total_r + 256), o_mp = carve(sizeof(float) * (size_t)total_r + 256);
     const size_t o_mx = carve(sizeof(float) * (size_t)total_r + 256), o_s = carve(sizeof(double) * (size_t)(N + Scap + 2));
     DDX_TRY(ensure(ctx, ctx->bp_buf, off));
     bp.buf_bytes = off;
@@ -473,7 +476,7 @@ int bp_build(ddx_ctx* ctx) {
     bp.rest_pos = reinterpret_cast<int32_t*>(b + o_rp);
     bp.restm_colptr = reinterpret_cast<int64_t*>(b + o_mcp);
     bp.restm_row = reinterpret_cast<int32_t*>(b + o_mr);
-    bp.restm_pos = reinterpret_cast<int32_t*>(b + o_mp);
+    bp.restm_raw = reinterpret_cast<float*>(b + o_mp);
     bp.restm_x = reinterpret_cast<float*>(b + o_mx);
     bp.srow = reinterpret_cast<double*>(b + o_s);
     bp.cap_srow = N + Scap + 2;
@@ -487,7 +490,7 @@ int bp_build(ddx_ctx* ctx) {
     k_bp_compact<<<ge, 256, 0, ctx->stream>>>(flag, scan, ctx->aug_indices.as<int32_t>(), nullptr, nnz, bp.rest_cols, bp.rest_pos, nullptr);
     k_bp_pointers<<<(unsigned)ceil_div(N + 1, 256), 256, 0, ctx->stream>>>(ctx->aug_indptr.as<int64_t>(), N + 1, 0, scan, 0, bp.rest_indptr);
     // column-major mirror (same entries in (panel, column, row) order)
-    DDX_TRY(bp_reduce(ctx, ctx->csc_o_raw.as<float>(), ctx->csc_o_row.as<int32_t>(), nullptr, nnz, bp.restm_row, bp.restm_pos, nullptr, total_r, &total_m, false, &scan));
+    DDX_TRY(bp_reduce(ctx, ctx->csc_o_raw.as<float>(), ctx->csc_o_row.as<int32_t>(), ctx->csc_o_raw.as<float>(), nnz, bp.restm_row, nullptr, bp.restm_raw, total_r, &total_m, false, &scan));
     DDX_HIP(ctx, hipMemcpyAsync(&total_m, scan + nnz, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     k_bp_pointers<<<(unsigned)ceil_div(nseg + 1, 256), 256, 0, ctx->stream>>>(ctx->csc_o_colptr.as<int64_t>(), nseg + 1, 0, scan, 0, bp.restm_colptr);
     // bitmaps of the original rows.  SKr is provisional (no synthetic rows yet): the layout of the column bitmap uses the CAPACITY
@@ -517,7 +520,7 @@ int bp_clone(ddx_ctx* ctx, const ddx_ctx* src) {
     const ptrdiff_t delta = ctx->bp_buf.as<char>() - src->bp_buf.as<char>();
     auto move = [&](auto*& p) { if (p) p = reinterpret_cast<std::remove_reference_t<decltype(p)>>(reinterpret_cast<char*>(p) + delta); };
     move(bp.bm_rows); move(bp.bm_cols); move(bp.rest_indptr); move(bp.rest_cols); move(bp.rest_pos); move(bp.rest_x);
-    move(bp.restm_colptr); move(bp.restm_row); move(bp.restm_pos); move(bp.restm_x); move(bp.srow);
+    move(bp.restm_colptr); move(bp.restm_row); move(bp.restm_raw); move(bp.restm_x); move(bp.srow);
     bp.restm_s_colptr = nullptr; bp.restm_s_row = nullptr; bp.restm_s_x = nullptr;          // (views into the source's per-iteration buffers)
     bp.qd = nullptr; bp.cmax = nullptr; bp.part = nullptr; bp.ymax_of = nullptr;
     bp.values = false;
@@ -532,72 +535,91 @@ bool bp_wanted_at_upload(const ddx_ctx* ctx) {
     return o.bitplane != 0 && o.gather_f32 && ctx->N >= 32 && (o.bitplane == 2 || ctx->N >= 4096);
 }
 
-// What changes with the iteration: the synthetic rows' bitmaps and reduced structures (rows and mirror), the reduced values of the
-// original rows, the row scales.  After ddx_lognormalise.
-int bp_refresh(ddx_ctx* ctx) {
+// What changes with the iteration, after the row-major normalisation (called by ddx_lognormalise when the route is expected, else by
+// the first PCA that takes it): the reduced values of the original rows (row-major: gathered from the full array; mirror: evaluated
+// from the reduced mirror's own counts), the row scales, the synthetic rows' reduced CSR, their reduced mirror (built straight from
+// it), their bitmaps -- and the column means, whose bit-plane part is one narrow product on the matrix cores.  The full column-major
+// mirror of the iteration is not needed for any of it.
+constexpr int kBpRetry = 1000;          // (internal) the per-fit structures were too small for this iteration: build them again and repeat
+static int bp_refresh_once(ddx_ctx* ctx) {
     BitPlanes& bp = ctx->bp;
     if (bp.values) return DDX_OK;
     const int64_t N = ctx->N, M = ctx->M, S = ctx->S;
-    const int32_t H = ctx->H;
-    ScopedTimer t(ctx, "bitplane_values");
-    if (bp.Npad + ceil_div(S, kBpStageCols) * kBpStageCols > bp.cap_rows || M + 2 > bp.cap_srow) {
-        // more synthetic rows than planned for (boost_rate > 0.5): start over with a larger plan
+    if (bp.Npad + ceil_div(S, kBpStageCols) * kBpStageCols > bp.cap_rows || M + 2 > bp.cap_srow)
         return set_err(ctx, DDX_E_UNSUPPORTED, "bit planes: %lld synthetic rows exceed the planned capacity", (long long)S);
-    }
     bp.ntile_s = ceil_div(S, 32);
     bp.ntile_s += bp.ntile_s & 1;                                 // whole 64-row blocks for the transpose
     bp.SKr = bp.SKr_cap;
     bp.SKr_used = bp.Npad / kBpStageCols + ceil_div(S, kBpStageCols);
-    // reduced values of the original rows
-    if (bp.nrest_o > 0) {
-        const unsigned g = (unsigned)ceil_div(bp.nrest_o, 256);
-        k_bp_gather<<<g, 256, 0, ctx->stream>>>(ctx->aug_x.as<float>(), bp.rest_pos, bp.nrest_o, bp.rest_x);
-        k_bp_gather<<<g, 256, 0, ctx->stream>>>(ctx->csc_o_x.as<float>(), bp.restm_pos, bp.nrest_o, bp.restm_x);
-    }
-    k_bp_row_scale<<<(unsigned)ceil_div(M, 256), 256, 0, ctx->stream>>>(ctx->lognorm_tab.as<float>(), 16, ctx->zvalue, M, bp.srow);
-    bp.nrest_s = 0;
-    if (S > 0) {
-        // synthetic rows: reduced CSR behind the original rows' (one array, one row pointer over all M rows)
-        const int64_t e0 = ctx->nnz;
-        const int64_t n_s = ctx->nnz_aug - e0;                     // (read back by ddx_lognormalise)
-        int32_t kept = 0;
-        int32_t* scan = nullptr;
-        DDX_TRY(bp_reduce(ctx, ctx->aug_raw.as<float>() + e0, nullptr, nullptr, n_s, nullptr, nullptr, nullptr, 0, &kept, true, &scan));
-        if (kept > bp.cap_rest_s) {
-            // more entries other than 1 among the synthetic rows than planned for: build the per-fit structures again with room for them
-            bp.want_rest_s = (int64_t)kept + kept / 2;
-            bp.ready = false;
-            DDX_TRY(bp_build(ctx));
-            ctx->rowseg_rows = -1;
-            return bp_refresh(ctx);
-        }
-        bp.nrest_s = kept;
-        const unsigned ge = (unsigned)ceil_div(n_s + 1, 256);
-        int32_t* flag = ctx->sort_keys_in.as<int32_t>();
-        k_bp_compact<<<ge, 256, 0, ctx->stream>>>(flag, scan, ctx->aug_indices.as<int32_t>() + e0, ctx->aug_x.as<float>() + e0, n_s, bp.rest_cols + bp.nrest_o, nullptr,
-                                                  bp.rest_x + bp.nrest_o);
-        k_bp_pointers<<<(unsigned)ceil_div(S + 1, 256), 256, 0, ctx->stream>>>(ctx->aug_indptr.as<int64_t>() + N, S + 1, e0, scan, bp.nrest_o, bp.rest_indptr + N);
-        // reduced mirror of the synthetic rows (its own arrays, sized for the iteration)
-        const int64_t nseg_s = (int64_t)(ctx->P_s > 0 ? ctx->P_s : 1) * H;
-        size_t off = 0;
-        auto carve = [&](size_t bytes) { const size_t o = off; off += bp_align(bytes); return o; };
-        const size_t o_cp = carve(sizeof(int64_t) * (size_t)(nseg_s + 1)), o_r = carve(sizeof(int32_t) * (size_t)kept + 256), o_x = carve(sizeof(float) * (size_t)kept + 256);
-        DDX_TRY(ensure(ctx, ctx->bp_synth, off));
-        char* b = ctx->bp_synth.as<char>();
-        bp.restm_s_colptr = reinterpret_cast<int64_t*>(b + o_cp);
-        bp.restm_s_row = reinterpret_cast<int32_t*>(b + o_r);
-        bp.restm_s_x = reinterpret_cast<float*>(b + o_x);
-        int32_t kept_m = 0;
-        DDX_TRY(bp_reduce(ctx, ctx->csc_s_raw.as<float>(), ctx->csc_s_row.as<int32_t>(), ctx->csc_s_x.as<float>(), n_s, bp.restm_s_row, nullptr, bp.restm_s_x, kept, &kept_m,
-                          false, &scan));
-        k_bp_pointers<<<(unsigned)ceil_div(nseg_s + 1, 256), 256, 0, ctx->stream>>>(ctx->csc_s_colptr.as<int64_t>(), nseg_s + 1, 0, scan, 0, bp.restm_s_colptr);
-        // bitmaps of the synthetic rows (tiles behind the padded originals)
-        DDX_TRY(bp_launch_bitmaps(ctx, bp.ntile_o, bp.ntile_s));
-    }
     DDX_TRY(bp_workspace(ctx));
+    bp.nrest_s = 0;
+    {
+        ScopedTimer t(ctx, "bitplane_values");
+        if (bp.nrest_o > 0)
+            k_bp_gather<<<(unsigned)ceil_div(bp.nrest_o, 256), 256, 0, ctx->stream>>>(ctx->aug_x.as<float>(), bp.rest_pos, bp.nrest_o, bp.rest_x);
+        k_bp_row_scale<<<(unsigned)ceil_div(M, 256), 256, 0, ctx->stream>>>(ctx->lognorm_tab.as<float>(), 16, ctx->zvalue, M, bp.srow);
+        if (S > 0) {
+            // synthetic rows: reduced CSR behind the original rows' (one array, one row pointer over all M rows)
+            const int64_t e0 = ctx->nnz;
+            const int64_t n_s = ctx->nnz_aug - e0;                     // (read back by ddx_lognormalise)
+            int32_t kept = 0;
+            int32_t* scan = nullptr;
+            DDX_TRY(bp_reduce(ctx, ctx->aug_raw.as<float>() + e0, nullptr, nullptr, n_s, nullptr, nullptr, nullptr, 0, &kept, true, &scan));
+            if (kept > bp.cap_rest_s) {
+                // more entries other than 1 among the synthetic rows than planned for: build the per-fit structures again with room for them
+                bp.want_rest_s = (int64_t)kept + kept / 2;
+                bp.ready = false;
+                return kBpRetry;
+            }
+            bp.nrest_s = kept;
+            const unsigned ge = (unsigned)ceil_div(n_s + 1, 256);
+            int32_t* flag = ctx->sort_keys_in.as<int32_t>();
+            k_bp_compact<<<ge, 256, 0, ctx->stream>>>(flag, scan, ctx->aug_indices.as<int32_t>() + e0, ctx->aug_x.as<float>() + e0, n_s, bp.rest_cols + bp.nrest_o, nullptr,
+                                                      bp.rest_x + bp.nrest_o);
+            k_bp_pointers<<<(unsigned)ceil_div(S + 1, 256), 256, 0, ctx->stream>>>(ctx->aug_indptr.as<int64_t>() + N, S + 1, e0, scan, bp.nrest_o, bp.rest_indptr + N);
+            // bitmaps of the synthetic rows (tiles behind the padded originals)
+            DDX_TRY(bp_launch_bitmaps(ctx, bp.ntile_o, bp.ntile_s));
+        }
+    }
+    // reduced mirrors: the synthetic rows' built from their reduced CSR (scope mirror_build), the originals' values (lognorm_cols)
+    DDX_TRY(bp_reduced_mirrors(ctx));
+    // column means: sums of the entries equal to 1 = B^T s on the matrix cores (one column of four digits), + the reduced mirrors' sums
+    {
+        const int64_t SK = bp.SKr_used;
+        int per = 1;
+        const int chunks = bp_col_chunks(bp, SK, &per);
+        v4i* qd = reinterpret_cast<v4i*>(bp.qd);
+        double* cmaxS = bp.cmax + 128;
+        {
+            ScopedTimer t(ctx, "bitplane_prep");
+            k_bp_colmax<<<(unsigned)std::min<int64_t>(1024, ceil_div(M, 64)), 256, 0, ctx->stream>>>(bp.srow, nullptr, M, 1, cmaxS);     // (into zeros: bp_workspace)
+            const int nslot = 8;
+            const int64_t nthreads = std::max<int64_t>(64, SK * kBpSteps * 2 * nslot);
+            k_bp_digits<4, true><<<(unsigned)ceil_div(nthreads, 256), 256, 0, ctx->stream>>>(bp.srow, nullptr, M, 1, 1, nslot, cmaxS, SK, bp.Npad, N, qd, nullptr);
+        }
+        BpProductArgs a{};
+        a.bm = reinterpret_cast<const v4i*>(bp.bm_cols); a.qd = qd; a.ntile = bp.ntile_c; a.SK = (int)SK; a.SKstride = bp.SKr; a.sk_per_chunk = per; a.L = 1;
+        a.cmax = cmaxS; a.nOut = ctx->H; a.out = bp.part;
+        {
+            ScopedTimer t(ctx, "bitplane_cols");
+            DDX_TRY((bp_launch_t<2, 1, 4, false>(ctx, a, chunks)));
+        }
+        DDX_TRY(bp_colmean(ctx, bp.part, chunks));
+    }
     DDX_HIP(ctx, hipGetLastError());
     bp.values = true;
     return DDX_OK;
+}
+
+int bp_refresh(ddx_ctx* ctx) {
+    int rc = bp_refresh_once(ctx);
+    if (rc == kBpRetry) {
+        DDX_TRY(bp_build(ctx));
+        ctx->rowseg_rows = -1;
+        rc = bp_refresh_once(ctx);
+        if (rc == kBpRetry) return set_err(ctx, DDX_E_NOMEM, "bit planes: the synthetic rows' reduced entries do not fit the rebuilt structures");
+    }
+    return rc;
 }
 
 // chunks of the k dimension of the A^T Y product (the padded rows): enough workgroups for a whole round of the GPU
@@ -616,13 +638,13 @@ static int bp_workspace(ddx_ctx* ctx) {
     const size_t dig = bp_align(sizeof(v4i) * (size_t)SKmax * kBpSteps * 5 * 64);
     const int chunks = bp_col_chunks(bp, bp.SKr_cap, nullptr);
     const size_t prt = bp_align(sizeof(double) * (size_t)chunks * ctx->H * 40);
-    const size_t need = dig + bp_align(sizeof(double) * 128) + prt;
+    const size_t need = dig + bp_align(sizeof(double) * 192) + prt;
     DDX_TRY(ensure(ctx, ctx->bp_work, need));
     char* b = ctx->bp_work.as<char>();
     bp.qd = b;
-    bp.cmax = reinterpret_cast<double*>(b + dig);                 // [0..63]: Q side, [64..127]: Y side
-    bp.part = reinterpret_cast<double*>(b + dig + bp_align(sizeof(double) * 128));
-    DDX_HIP(ctx, hipMemsetAsync(bp.cmax, 0, sizeof(double) * 128, ctx->stream));
+    bp.cmax = reinterpret_cast<double*>(b + dig);                 // [0..63]: Q side, [64..127]: Y side, [128..]: the row scales (column means)
+    bp.part = reinterpret_cast<double*>(b + dig + bp_align(sizeof(double) * 192));
+    DDX_HIP(ctx, hipMemsetAsync(bp.cmax, 0, sizeof(double) * 192, ctx->stream));
     bp.ymax_of = nullptr;
     return DDX_OK;
 }

@@ -1252,8 +1252,13 @@ static bool lds_quad(int ld) {
 constexpr int kLdsOwnQuad = 4;     // outputs owned by one lane group in the quad geometry (4 x 4 float64 accumulators)
 static int lds_slots(int ld) { return lds_quad(ld) ? (ld <= 64 ? 4 : 0) : (ld <= 32 ? 4 : (ld <= 42 ? 3 : 0)); }
 static int lds_lpn(int ld) { return (lds_quad(ld) || ld <= 32) ? 16 : ld / 2; }
-static int lds_owners(int64_t nOut, int slots, int ld) {
-    const int64_t need = ceil_div(nOut, (int64_t)kLdsWaves * slots * (lds_quad(ld) ? kLdsOwnQuad : kLdsOwnG));
+// outputs per lane group of the A^T Y kernel in bit-plane mode: the mirror it walks holds a tenth of the entries, and what is left of
+// its time is staging the 123 KB operand slices -- twice the columns per workgroup halve the slice loads (0.272 -> 0.230 ms per launch
+// at the headline; the A Q kernel, whose workgroups each stage the whole operand anyway, does not gain: 0.226 -> 0.227)
+constexpr int kLdsOwnSparseCols = 12;
+static int lds_own(int ld, bool sparse_cols) { return lds_quad(ld) ? kLdsOwnQuad : ((sparse_cols && lds_packed() && lds_slots(ld) == 3) ? kLdsOwnSparseCols : kLdsOwnG); }
+static int lds_owners(int64_t nOut, int slots, int ld, bool sparse_cols = false) {
+    const int64_t need = ceil_div(nOut, (int64_t)kLdsWaves * slots * lds_own(ld, sparse_cols));
     constexpr int64_t per_round = 256 * kLdsWgPerCu;
     return (int)(need <= per_round ? need : per_round * ceil_div(need, per_round));     // whole rounds of resident workgroups
 }
@@ -1272,8 +1277,9 @@ static int launch_lds_t(ddx_ctx* c, const LdsSpmmArgs& a, unsigned grid, size_t 
 static bool lds_packed() { return t_opt->trip_packed; }
 
 template <bool ROWS>
-static int launch_lds(ddx_ctx* c, const LdsSpmmArgs& a, int slots, unsigned grid, size_t lds_bytes) {
+static int launch_lds(ddx_ctx* c, const LdsSpmmArgs& a, int slots, unsigned grid, size_t lds_bytes, bool sparse_cols = false) {
     if (lds_quad(a.ld)) return launch_lds_t<ROWS, 4, true, 4, kLdsOwnQuad>(c, a, grid, lds_bytes);
+    if (!ROWS && lds_own(a.ld, sparse_cols) == kLdsOwnSparseCols) return launch_lds_t<ROWS, 3, true, 2, kLdsOwnSparseCols>(c, a, grid, lds_bytes);
     if (lds_packed())
         return slots == 4 ? launch_lds_t<ROWS, 4, true, 2, kLdsOwnG>(c, a, grid, lds_bytes) : launch_lds_t<ROWS, 3, true, 2, kLdsOwnG>(c, a, grid, lds_bytes);
     return slots == 4 ? launch_lds_t<ROWS, 4, false, 2, kLdsOwnG>(c, a, grid, lds_bytes) : launch_lds_t<ROWS, 3, false, 2, kLdsOwnG>(c, a, grid, lds_bytes);
@@ -1358,6 +1364,7 @@ static int apply_cols(PcaWork& w, const double* Yrow, double* Wcol) {  // A^T Y 
         ScopedTimer t(c, "pca_colsum");
         DDX_TRY(wcolsum(w, Yrow, w.M, nullptr, uvec));
     }
+    if (!w.bitplane) DDX_TRY(ensure_full_mirror(c));     // (ddx_lognormalise leaves it out when the bit-plane route is expected)
     const int P = (int)ceil_div(w.M, c->panel_rows);
     const int groups = (w.H + 3) / 4;
     const int64_t grid = 8 * ceil_div(P, 8) * groups;
@@ -1378,7 +1385,7 @@ static int apply_cols(PcaWork& w, const double* Yrow, double* Wcol) {  // A^T Y 
         if (w.opQ && w.opQ_of == Wcol) w.opQ_of = nullptr;   // the result overwrites a mirrored matrix
         if (w.opQ && w.opY_of == Wcol) w.opY_of = nullptr;
         a.opRows = w.M; a.SR = c->panel_rows; a.nslices = P;
-        a.nOut = w.H; a.owners = lds_owners(w.H, slots, a.ld);
+        a.nOut = w.H; a.owners = lds_owners(w.H, slots, a.ld, w.bitplane);
         a.groups = std::max(1, std::min(P, 512 * kLdsWgPerCu / a.owners));
         a.zcol = c->zcol.as<float>();
         a.cp_o = c->csc_o_colptr.as<int64_t>(); a.row_o = c->csc_o_row.as<int32_t>(); a.x_o = c->csc_o_x.as<float>(); a.P_o = c->P_o;
@@ -1391,7 +1398,7 @@ static int apply_cols(PcaWork& w, const double* Yrow, double* Wcol) {  // A^T Y 
         a.out = c->pcaPanel.as<double>();
         a.perm = c->rank_cols;
         const size_t lds_bytes = (size_t)a.SR * a.ld * 4 + lds_stage_bytes(slots, lds_packed());
-        DDX_TRY(launch_lds<false>(c, a, slots, (unsigned)(a.owners * a.groups), lds_bytes));
+        DDX_TRY(launch_lds<false>(c, a, slots, (unsigned)(a.owners * a.groups), lds_bytes, w.bitplane));
         k_sum_panels<<<(unsigned)ceil_div((int64_t)w.H * w.L, 256), 256, 0, c->stream>>>(c->pcaPanel.as<double>(), a.groups, w.H, w.L, c->colmean.as<double>(),
                                                                                           uvec, Wcol, w1, nw1);
         return DDX_OK;
@@ -1478,6 +1485,7 @@ static int lds_setup(ddx_ctx* ctx, int L, PcaWork& w) {
     const void* before = ctx->rowseg.p;
     DDX_TRY(ensure(ctx, ctx->rowseg, sizeof(int32_t) * (size_t)M * (w.rows_ns + 1)));
     ScopedTimer t(ctx, "row_segments");
+    if (!w.bitplane) DDX_TRY(ensure_full_mirror(ctx));
     const int64_t* row_ip = w.bitplane ? ctx->bp.rest_indptr : ctx->aug_indptr.as<int64_t>();
     const int32_t* row_ix = w.bitplane ? ctx->bp.rest_cols : ctx->aug_indices.as<int32_t>();
     DDX_TRY(stage_rankings(ctx, row_ip, w.bitplane ? ctx->bp.restm_colptr : ctx->csc_o_colptr.as<int64_t>(),

@@ -661,15 +661,19 @@ __global__ void __launch_bounds__(1024, 8) k_mirror_tiles(const int32_t* __restr
     TILE_STAMP(6);
 }
 
-static int build_csc_sorted(ddx_ctx* ctx, int64_t e0, int64_t n, int64_t row_lo, int64_t row_hi, int32_t panel0,
+// the CSR a mirror is built from: row pointer over all rows, columns, and the per-entry payload that travels with the row index
+// (the raw counts for the full mirrors; the log-normalised values for the reduced mirror of the synthetic rows, k_bitplane.hip)
+struct MirrorSrc { const int64_t* indptr; const int32_t* cols; const float* payload; };
+
+static int build_csc_sorted(ddx_ctx* ctx, const MirrorSrc& src, int64_t e0, int64_t n, int64_t row_lo, int64_t row_hi, int32_t panel0,
                             int32_t npanels, DevBuf& colptr, DevBuf& rows, DevBuf& raws);
 
 // Build the (panel, column)-ordered mirror of CSR entries [e0, e0+n) (rows [row_lo,row_hi)).
-static int build_csc(ddx_ctx* ctx, int64_t e0, int64_t n, int64_t row_lo, int64_t row_hi, int32_t panel0,
+static int build_csc(ddx_ctx* ctx, const MirrorSrc& src, int64_t e0, int64_t n, int64_t row_lo, int64_t row_hi, int32_t panel0,
                      int32_t npanels, DevBuf& colptr, DevBuf& rows, DevBuf& raws) {
     const int32_t H = ctx->H;
     if (H > kMirrorMaxH || ctx->panel_rows % kMirrorSub != 0 || ctx->panel_rows / kMirrorSub >= 65536 || ctx->opt.mirror_mode == 0 || n == 0)
-        return build_csc_sorted(ctx, e0, n, row_lo, row_hi, panel0, npanels, colptr, rows, raws);
+        return build_csc_sorted(ctx, src, e0, n, row_lo, row_hi, panel0, npanels, colptr, rows, raws);
     const int64_t nkeys = (int64_t)npanels * H;
     if (nkeys >= ((int64_t)1 << 30)) return set_err(ctx, DDX_E_UNSUPPORTED, "panel x column key space too large");
     const int32_t sub_rows = ctx->panel_rows / kMirrorSub;
@@ -701,8 +705,7 @@ static int build_csc(ddx_ctx* ctx, int64_t e0, int64_t n, int64_t row_lo, int64_
         bnd = ctx->sort_keys_out.as<uint32_t>();
     }
     ScopedTimer t(ctx, "mirror_build");
-    k_mirror_count<<<(unsigned)n_sb, kMirrorThreads, lds, ctx->stream>>>(ctx->aug_indptr.as<int64_t>(), ctx->aug_indices.as<int32_t>(), row_lo, row_hi,
-                                                                         sub_rows, sb0, H, cnt, W, wpp, bnd);
+    k_mirror_count<<<(unsigned)n_sb, kMirrorThreads, lds, ctx->stream>>>(src.indptr, src.cols, row_lo, row_hi, sub_rows, sb0, H, cnt, W, wpp, bnd);
     k_mirror_prefix<<<(unsigned)ceil_div(nkeys, 256), 256, 0, ctx->stream>>>(cnt, sb0, n_sb, panel0, npanels, H, tot);
     size_t tmp_bytes = 0;
     DDX_HIP(ctx, prim::exclusive_sum(nullptr, tmp_bytes, tot, scan, (size_t)nkeys, ctx->stream));
@@ -713,7 +716,7 @@ static int build_csc(ddx_ctx* ctx, int64_t e0, int64_t n, int64_t row_lo, int64_
         const int64_t ntiles = (int64_t)wpp * npanels;
         DDX_TRY(allow_dynamic_lds(ctx, reinterpret_cast<const void*>(&k_mirror_tiles), (int)kTileLds));
         k_mirror_tiles<<<(unsigned)(ceil_div(ntiles, (int64_t)8) * 8), 1024, kTileLds, ctx->stream>>>(
-            ctx->aug_indices.as<int32_t>(), ctx->aug_raw.as<float>(), row_lo, row_hi, panel0, H, W, wpp, (int32_t)ntiles, bnd, colptr.as<int64_t>(), rows.as<int32_t>(), raws.as<float>());
+            src.cols, src.payload, row_lo, row_hi, panel0, H, W, wpp, (int32_t)ntiles, bnd, colptr.as<int64_t>(), rows.as<int32_t>(), raws.as<float>());
 #ifdef DDX_TILE_PROF
         {
             unsigned long long h[8];
@@ -727,8 +730,8 @@ static int build_csc(ddx_ctx* ctx, int64_t e0, int64_t n, int64_t row_lo, int64_
         }
 #endif
     } else {
-        k_mirror_scatter<<<(unsigned)n_sb, kMirrorThreads, lds, ctx->stream>>>(ctx->aug_indptr.as<int64_t>(), ctx->aug_indices.as<int32_t>(),
-                                                                               ctx->aug_raw.as<float>(), row_lo, row_hi, sub_rows, sb0, panel0, H, cnt,
+        k_mirror_scatter<<<(unsigned)n_sb, kMirrorThreads, lds, ctx->stream>>>(src.indptr, src.cols,
+                                                                               src.payload, row_lo, row_hi, sub_rows, sb0, panel0, H, cnt,
                                                                                colptr.as<int64_t>(), rows.as<int32_t>(), raws.as<float>());
     }
     DDX_HIP(ctx, hipGetLastError());
@@ -739,7 +742,7 @@ static int build_csc(ddx_ctx* ctx, int64_t e0, int64_t n, int64_t row_lo, int64_
 // Fallback (very wide matrices, DDX_MIRROR=sort): the same mirror by a stable radix sort.
 // Build the (panel, column)-ordered mirror of CSR entries [e0, e0+n) (rows [row_lo,row_hi)): stable radix
 // sort of (key, position) pairs -> inside a (panel, column) segment entries are in increasing row order.
-static int build_csc_sorted(ddx_ctx* ctx, int64_t e0, int64_t n, int64_t row_lo, int64_t row_hi, int32_t panel0,
+static int build_csc_sorted(ddx_ctx* ctx, const MirrorSrc& src, int64_t e0, int64_t n, int64_t row_lo, int64_t row_hi, int32_t panel0,
                             int32_t npanels, DevBuf& colptr, DevBuf& rows, DevBuf& raws) {
     const int32_t H = ctx->H;
     const int64_t nkeys64 = (int64_t)npanels * H;
@@ -756,7 +759,7 @@ static int build_csc_sorted(ddx_ctx* ctx, int64_t e0, int64_t n, int64_t row_lo,
     DDX_TRY(ensure(ctx, ctx->sort_vals_out, sizeof(uint32_t) * n));
     DDX_TRY(ensure(ctx, ctx->sort_rowid, sizeof(int32_t) * n));
     k_iota_u32<<<(unsigned)ceil_div(n, 256), 256, 0, ctx->stream>>>(ctx->sort_vals_in.as<uint32_t>(), n, (uint32_t)e0);
-    k_panel_keys<<<(unsigned)ceil_div(row_hi - row_lo, 4), 256, 0, ctx->stream>>>(ctx->aug_indptr.as<int64_t>(), ctx->aug_indices.as<int32_t>(),
+    k_panel_keys<<<(unsigned)ceil_div(row_hi - row_lo, 4), 256, 0, ctx->stream>>>(src.indptr, src.cols,
                                                                                  row_lo, row_hi - row_lo, H, panel0, ctx->panel_rows, e0,
                                                                                  ctx->sort_keys_in.as<int32_t>(), ctx->sort_rowid.as<int32_t>());
     int end_bit = 1;
@@ -777,7 +780,7 @@ static int build_csc_sorted(ddx_ctx* ctx, int64_t e0, int64_t n, int64_t row_lo,
         k_colptr_from_sorted<<<(unsigned)ceil_div(nkeys + 1, 256), 256, 0, ctx->stream>>>(ctx->sort_keys_out.as<int32_t>(), n, nkeys,
                                                                                           colptr.as<int64_t>());
         k_csc_gather<<<(unsigned)ceil_div(n, 256), 256, 0, ctx->stream>>>(ctx->sort_vals_out.as<uint32_t>(), n, e0, ctx->sort_rowid.as<int32_t>(),
-                                                                          ctx->aug_raw.as<float>(), rows.as<int32_t>(), raws.as<float>());
+                                                                          src.payload, rows.as<int32_t>(), raws.as<float>());
     }
     DDX_HIP(ctx, hipGetLastError());
     return DDX_OK;
@@ -860,7 +863,8 @@ int stage_upload_counts(ddx_ctx* ctx, int64_t N, int32_t H, const int64_t* indpt
     DDX_TRY(ensure(ctx, ctx->csc_o_x, sizeof(float) * (size_t)(nnz + 1)));
     ctx->panel_rows = (ctx->opt.spmm_lds && ctx->opt.gather_f32) ? kLdsPanelRows : kGatherPanelRows;
     ctx->P_o = (int32_t)ceil_div(N, ctx->panel_rows);
-    DDX_TRY(build_csc(ctx, 0, nnz, 0, N, 0, ctx->P_o, ctx->csc_o_colptr, ctx->csc_o_row, ctx->csc_o_raw));
+    const MirrorSrc full{ctx->aug_indptr.as<int64_t>(), ctx->aug_indices.as<int32_t>(), ctx->aug_raw.as<float>()};
+    DDX_TRY(build_csc(ctx, full, 0, nnz, 0, N, 0, ctx->P_o, ctx->csc_o_colptr, ctx->csc_o_row, ctx->csc_o_raw));
     if (bp_wanted_at_upload(ctx)) DDX_TRY(bp_build(ctx));        // bitmaps + reduced structures of the original rows, once per fit: the followers copy them
     DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->have_counts = true;
@@ -951,6 +955,8 @@ int stage_create_doublets(ddx_ctx* ctx, int64_t S, const int64_t* parents) {
     ctx->S = S;
     ctx->M = N + S;
     ctx->have_lognorm = ctx->scaled = ctx->have_emb = ctx->have_knn = false;
+    ctx->mirror_full = false;
+    ctx->bp.values = false;
     if (S) {
         DDX_HIP(ctx, hipMemcpyAsync(ctx->parents.p, parents, sizeof(int64_t) * 2 * S, hipMemcpyHostToDevice, ctx->stream));
         // one merge per doublet: rows are written at padded offsets into the (not yet rebuilt) mirror buffers, counted
@@ -1197,7 +1203,8 @@ __global__ void __launch_bounds__(256) k_col_partials(const int64_t* __restrict_
 }
 
 __global__ void k_col_reduce(const double* __restrict__ part_o, int P_o, int64_t nseg_o, const double* __restrict__ part_s, int P_s,
-                             int64_t nseg_s, int32_t H, int64_t M, int mode, double* __restrict__ out) {
+                             int64_t nseg_s, int32_t H, int64_t M, int mode, double* __restrict__ out, const double* __restrict__ extra = nullptr,
+                             int nextra = 0) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= H) return;
     double a = 0.0, b = 0.0;
@@ -1209,36 +1216,102 @@ __global__ void k_col_reduce(const double* __restrict__ part_o, int P_o, int64_t
         a += part_s[(int64_t)p * H + j];
         if (mode) b += part_s[nseg_s + (int64_t)p * H + j];
     }
+    for (int p = 0; p < nextra; ++p) a += extra[(int64_t)p * H + j];     // (bit-plane mode: the entries equal to 1, one block per chunk of the rows)
     if (mode == 0) out[j] = a / (double)M;
     else { out[2 * j] = a; out[2 * j + 1] = b; }
 }
 
-static int col_sums(ddx_ctx* ctx, int mode, double* out) {
+// column sums over the given pair of (panel, column)-ordered mirrors (+ `nextra` blocks of H ready-made sums)
+static int col_sums_of(ddx_ctx* ctx, const int64_t* cp_o, const float* x_o, const int64_t* cp_s, const float* x_s, int mode, double* out,
+                       const double* extra = nullptr, int nextra = 0) {
     const int32_t H = ctx->H;
     const int64_t nseg_o = (int64_t)ctx->P_o * H, nseg_s = (int64_t)ctx->P_s * H;
     DDX_TRY(ensure(ctx, ctx->col_part, sizeof(double) * 2 * (size_t)(nseg_o + nseg_s + 2)));
     double* part_o = ctx->col_part.as<double>();
     double* part_s = part_o + 2 * nseg_o;
-    if (nseg_o) k_col_partials<<<(unsigned)ceil_div(nseg_o, 16), 256, 0, ctx->stream>>>(ctx->csc_o_colptr.as<int64_t>(), ctx->csc_o_x.as<float>(), nseg_o, H,
-                                                                                     ctx->zcol.as<float>(), mode, part_o);
-    if (nseg_s) k_col_partials<<<(unsigned)ceil_div(nseg_s, 16), 256, 0, ctx->stream>>>(ctx->csc_s_colptr.as<int64_t>(), ctx->csc_s_x.as<float>(), nseg_s, H,
-                                                                                     ctx->zcol.as<float>(), mode, part_s);
-    k_col_reduce<<<(unsigned)ceil_div(H, 256), 256, 0, ctx->stream>>>(part_o, ctx->P_o, nseg_o, part_s, ctx->P_s, nseg_s, H, ctx->M, mode, out);
+    if (nseg_o) k_col_partials<<<(unsigned)ceil_div(nseg_o, 16), 256, 0, ctx->stream>>>(cp_o, x_o, nseg_o, H, ctx->zcol.as<float>(), mode, part_o);
+    if (nseg_s) k_col_partials<<<(unsigned)ceil_div(nseg_s, 16), 256, 0, ctx->stream>>>(cp_s, x_s, nseg_s, H, ctx->zcol.as<float>(), mode, part_s);
+    k_col_reduce<<<(unsigned)ceil_div(H, 256), 256, 0, ctx->stream>>>(part_o, ctx->P_o, nseg_o, part_s, ctx->P_s, nseg_s, H, ctx->M, mode, out, extra, nextra);
     return DDX_OK;
+}
+
+static int col_sums(ddx_ctx* ctx, int mode, double* out) {
+    return col_sums_of(ctx, ctx->csc_o_colptr.as<int64_t>(), ctx->csc_o_x.as<float>(), ctx->csc_s_colptr.as<int64_t>(), ctx->csc_s_x.as<float>(), mode, out);
+}
+
+// values of a (panel, column)-ordered mirror (rows, raw counts) from this iteration's normalisation: x[t] = lognorm(raw[t], row)
+static int lognorm_mirror(ddx_ctx* ctx, const int32_t* rows, const float* raw, const int64_t* colptr, int32_t npanels, int32_t panel0, float* x) {
+    if (npanels <= 0) return DDX_OK;
+    const int use_log1p = (ctx->pseudocount == 1.0f);
+    const size_t lds = sizeof(float) * (size_t)ctx->panel_rows * kLognormTab;
+    if (lds <= 64 * 1024) {
+        DDX_TRY(allow_dynamic_lds(ctx, reinterpret_cast<const void*>(&k_lognorm_csc), (int)lds));
+        k_lognorm_csc<<<(unsigned)(npanels * kLognormParts), 512, lds, ctx->stream>>>(rows, raw, colptr, ctx->H, panel0, ctx->panel_rows, ctx->M, ctx->lib64.as<double>(),
+                                                                                     ctx->median.as<float>(), ctx->lognorm_tab.as<float>(), ctx->pseudocount, use_log1p, x);
+    } else {
+        k_lognorm_csc_direct<<<2048, 256, 0, ctx->stream>>>(rows, raw, colptr, npanels * ctx->H, ctx->lib64.as<double>(), ctx->median.as<float>(), ctx->pseudocount,
+                                                            use_log1p, x);
+    }
+    return DDX_OK;
+}
+
+// The full column-major mirror of this iteration's matrix -- the synthetic rows' part and the values of both parts.  The bit-plane
+// route (k_bitplane.hip) does without it (its reduced mirrors hold a tenth of the entries), so ddx_lognormalise leaves it out when
+// that route is expected; whoever needs it after all (ddx_scale, the plain sparse products, ddx_operator_apply) asks here.
+int ensure_full_mirror(ddx_ctx* ctx) {
+    if (ctx->mirror_full) return DDX_OK;
+    if (!ctx->have_lognorm) return set_err(ctx, DDX_E_ARG, "the column-major mirror needs ddx_lognormalise first");
+    const int64_t N = ctx->N, M = ctx->M;
+    const MirrorSrc full{ctx->aug_indptr.as<int64_t>(), ctx->aug_indices.as<int32_t>(), ctx->aug_raw.as<float>()};
+    DDX_TRY(build_csc(ctx, full, ctx->nnz, ctx->nnz_aug - ctx->nnz, N, M, ctx->p_s0, ctx->P_s > 0 ? ctx->P_s : 1, ctx->csc_s_colptr, ctx->csc_s_row, ctx->csc_s_raw));
+    {
+        ScopedTimer t(ctx, "lognorm_cols");
+        DDX_TRY(lognorm_mirror(ctx, ctx->csc_o_row.as<int32_t>(), ctx->csc_o_raw.as<float>(), ctx->csc_o_colptr.as<int64_t>(), ctx->P_o, 0, ctx->csc_o_x.as<float>()));
+        if (ctx->P_s > 0)
+            DDX_TRY(lognorm_mirror(ctx, ctx->csc_s_row.as<int32_t>(), ctx->csc_s_raw.as<float>(), ctx->csc_s_colptr.as<int64_t>(), ctx->P_s, ctx->p_s0, ctx->csc_s_x.as<float>()));
+        else if (ctx->panel_rows * kLognormTab * sizeof(float) > 64 * 1024)        // (the direct kernel walks colptr[nkeys]: one empty panel)
+            DDX_TRY(lognorm_mirror(ctx, ctx->csc_s_row.as<int32_t>(), ctx->csc_s_raw.as<float>(), ctx->csc_s_colptr.as<int64_t>(), 1, ctx->p_s0, ctx->csc_s_x.as<float>()));
+    }
+    DDX_HIP(ctx, hipGetLastError());
+    ctx->mirror_full = true;
+    return DDX_OK;
+}
+
+// bit-plane mode, once per iteration (called by bp_refresh): the reduced mirror of the synthetic rows, built straight from their
+// reduced CSR with the log-normalised values as the payload, and the values of the original rows' reduced mirror
+int bp_reduced_mirrors(ddx_ctx* ctx) {
+    BitPlanes& bp = ctx->bp;
+    const int32_t H = ctx->H;
+    const int32_t np = ctx->P_s > 0 ? ctx->P_s : 1;
+    DDX_TRY(ensure(ctx, ctx->bp_ms_row, sizeof(int32_t) * (size_t)(bp.nrest_s + 64)));
+    DDX_TRY(ensure(ctx, ctx->bp_ms_x, sizeof(float) * (size_t)(bp.nrest_s + 64)));
+    const MirrorSrc red{bp.rest_indptr, bp.rest_cols, bp.rest_x};
+    DDX_TRY(build_csc(ctx, red, bp.nrest_o, bp.nrest_s, ctx->N, ctx->M, ctx->p_s0, np, ctx->bp_ms_colptr, ctx->bp_ms_row, ctx->bp_ms_x));
+    bp.restm_s_colptr = ctx->bp_ms_colptr.as<int64_t>();
+    bp.restm_s_row = ctx->bp_ms_row.as<int32_t>();
+    bp.restm_s_x = ctx->bp_ms_x.as<float>();
+    (void)H;
+    return lognorm_mirror(ctx, bp.restm_row, bp.restm_raw, bp.restm_colptr, ctx->P_o, 0, bp.restm_x);
+}
+
+// bit-plane mode: colmean = (sums of the entries equal to 1, `nparts` blocks from the matrix cores, + sums over the reduced mirrors) / M
+int bp_colmean(ddx_ctx* ctx, const double* parts, int nparts) {
+    BitPlanes& bp = ctx->bp;
+    ScopedTimer t(ctx, "col_sums");
+    return col_sums_of(ctx, bp.restm_colptr, bp.restm_x, bp.restm_s_colptr, bp.restm_s_x, 0, ctx->colmean.as<double>(), parts, nparts);
 }
 
 int stage_lognormalise(ddx_ctx* ctx, float pseudocount) {
     const int64_t N = ctx->N, S = ctx->S, M = ctx->M;
     const int32_t H = ctx->H;
-    // exact number of synthetic entries (one 8-byte read-back per iteration; sizes the radix sort)
+    // exact number of synthetic entries (one 8-byte read-back per iteration; sizes the sorts)
     int64_t nnz_aug = 0;
     DDX_HIP(ctx, hipMemcpyAsync(&nnz_aug, ctx->aug_indptr.as<int64_t>() + M, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
     DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    const int64_t nnz_s = nnz_aug - ctx->nnz;
     ctx->nnz_aug = nnz_aug;
     if (S) {
         ScopedTimer t(ctx, "row_sums");
-if (ctx->counts_exact)
+        if (ctx->counts_exact)
             k_row_sums_exact<<<(unsigned)ceil_div(S, 4), 256, 0, ctx->stream>>>(ctx->aug_indptr.as<int64_t>(), ctx->aug_raw.as<float>(), N, S,
                                                                       ctx->lib32.as<float>(), ctx->lib64.as<double>());
         else
@@ -1256,10 +1329,8 @@ if (ctx->counts_exact)
         DDX_HIP(ctx, prim::sort_keys(ctx->sort_tmp.p, tmp_bytes, ctx->lib32.as<float>(), ctx->lib_sorted.as<float>(), (int)M, 0, 32, ctx->stream));
         k_median_from_sorted<<<1, 64, 0, ctx->stream>>>(ctx->lib_sorted.as<float>(), M, ctx->median.as<float>());
     }
-    // column-major mirror of the synthetic rows
     ctx->p_s0 = (int32_t)(N / ctx->panel_rows);
     ctx->P_s = S ? (int32_t)((M - 1) / ctx->panel_rows) - ctx->p_s0 + 1 : 0;
-    DDX_TRY(build_csc(ctx, ctx->nnz, nnz_s, N, M, ctx->p_s0, ctx->P_s > 0 ? ctx->P_s : 1, ctx->csc_s_colptr, ctx->csc_s_row, ctx->csc_s_raw));
     const int use_log1p = (pseudocount == 1.0f);
     DDX_TRY(ensure(ctx, ctx->lognorm_tab, sizeof(float) * (size_t)M * kLognormTab));
     float* tab_rows = ctx->lognorm_tab.as<float>();
@@ -1272,42 +1343,27 @@ if (ctx->counts_exact)
                                                                           ctx->lib64.as<double>(), ctx->median.as<float>(), tab_rows,
                                                                           pseudocount, use_log1p, M, rows_per_wave, ctx->aug_x.as<float>());
     }
-    {
-        ScopedTimer t(ctx, "lognorm_cols");
-        const size_t lds = sizeof(float) * (size_t)ctx->panel_rows * kLognormTab;
-        if (lds <= 64 * 1024) {
-            DDX_TRY(allow_dynamic_lds(ctx, reinterpret_cast<const void*>(&k_lognorm_csc), (int)lds));
-            k_lognorm_csc<<<(unsigned)(ctx->P_o * kLognormParts), 512, lds, ctx->stream>>>(
-                ctx->csc_o_row.as<int32_t>(), ctx->csc_o_raw.as<float>(), ctx->csc_o_colptr.as<int64_t>(), H, 0, ctx->panel_rows, M,
-                ctx->lib64.as<double>(), ctx->median.as<float>(), tab_rows, pseudocount, use_log1p, ctx->csc_o_x.as<float>());
-            if (ctx->P_s > 0)
-                k_lognorm_csc<<<(unsigned)(ctx->P_s * kLognormParts), 512, lds, ctx->stream>>>(
-                    ctx->csc_s_row.as<int32_t>(), ctx->csc_s_raw.as<float>(), ctx->csc_s_colptr.as<int64_t>(), H, ctx->p_s0, ctx->panel_rows, M,
-                    ctx->lib64.as<double>(), ctx->median.as<float>(), tab_rows, pseudocount, use_log1p, ctx->csc_s_x.as<float>());
-        } else {
-            k_lognorm_csc_direct<<<2048, 256, 0, ctx->stream>>>(ctx->csc_o_row.as<int32_t>(), ctx->csc_o_raw.as<float>(), ctx->csc_o_colptr.as<int64_t>(),
-                                                                ctx->P_o * H, ctx->lib64.as<double>(), ctx->median.as<float>(), pseudocount, use_log1p,
-                                                                ctx->csc_o_x.as<float>());
-            k_lognorm_csc_direct<<<2048, 256, 0, ctx->stream>>>(ctx->csc_s_row.as<int32_t>(), ctx->csc_s_raw.as<float>(), ctx->csc_s_colptr.as<int64_t>(),
-                                                                (ctx->P_s > 0 ? ctx->P_s : 1) * H, ctx->lib64.as<double>(), ctx->median.as<float>(), pseudocount,
-                                                                use_log1p, ctx->csc_s_x.as<float>());
-        }
-    }
     DDX_TRY(ensure(ctx, ctx->zcol, sizeof(float) * H));
     DDX_TRY(ensure(ctx, ctx->colmean, sizeof(double) * H));
     const float z = use_log1p ? 0.f : (float)std::log((double)pseudocount);
     k_fill_f32<<<(unsigned)ceil_div(H, 256), 256, 0, ctx->stream>>>(ctx->zcol.as<float>(), H, z);
     ctx->zvalue = z;
-    {
+    ctx->pseudocount = pseudocount;
+    ctx->bp.values = false;              // the bit-plane structures hold the last iteration's values
+    ctx->mirror_full = false;
+    ctx->have_lognorm = true;
+    ctx->scaled = false;
+    ctx->have_emb = ctx->have_knn = false;
+    if (bp_wanted_at_upload(ctx) && ctx->bp.ready && S <= N / 2) {
+        // the bit-plane route is expected to serve this matrix: its structures (a tenth of the entries in sparse form) are all the
+        // products need, and they also give the column means -- the full mirror is only built if somebody asks (ensure_full_mirror)
+        DDX_TRY(bp_refresh(ctx));
+    } else {
+        DDX_TRY(ensure_full_mirror(ctx));
         ScopedTimer t(ctx, "col_sums");
         DDX_TRY(col_sums(ctx, 0, ctx->colmean.as<double>()));
     }
     DDX_HIP(ctx, hipGetLastError());
-    ctx->pseudocount = pseudocount;
-    ctx->bp.values = false;              // the reduced structures of the bit-plane products hold the last iteration's values
-    ctx->have_lognorm = true;
-    ctx->scaled = false;
-    ctx->have_emb = ctx->have_knn = false;
     return DDX_OK;
 }
 
@@ -1373,6 +1429,7 @@ __global__ void k_scale_zcol(const double* __restrict__ mean, const double* __re
 }
 
 int stage_scale(ddx_ctx* ctx, float max_value) {
+    DDX_TRY(ensure_full_mirror(ctx));                 // (the bit-plane route left it out: a scaled matrix takes the plain sparse products)
     const int32_t H = ctx->H;
     const int64_t M = ctx->M;
     DDX_TRY(ensure(ctx, ctx->colstat, sizeof(double) * 4 * H));

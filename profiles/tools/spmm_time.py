@@ -27,7 +27,7 @@ for rep in range(2):
     except Exception as e:  # noqa: BLE001
         print("pca:", str(e)[:80])
 t = ctx.timings()
-out = {k: round(v[1] / max(v[0], 1), 4) for k, v in t.items() if k.startswith("spmm")}
+out = {k: round(v[1] / max(v[0], 1), 4) for k, v in t.items() if k.startswith("spmm") or k.startswith("bitplane")}
 try:
     ctx.timing_reset()
     ctx.knn(30, False)
