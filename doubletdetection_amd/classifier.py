@@ -808,9 +808,12 @@ class BoostClassifier:
         try:
             for dev, leader in followers:
                 f = self._fit_switches(self._engine_factory(dev))
+                # The copy itself waits until the follower's own host thread starts (`_fit_resident`: the first thing a lane
+                # does): what it reads of the leader -- the original cells' rows, their mirror, their bit planes -- is
+                # constant for the fit, so the leader is already on its first iteration while its followers copy (round 4
+                # copied here, with the leader idle: 4 x 3.5 GB device to device before any iteration began).
+                f._clone_source = leader
                 made.append((dev, f))
-            # a leader must be idle while it is copied: the followers of different GPUs copy side by side
-            self._on_each(list(zip(made, followers)), lambda p: p[0][1].clone_from(p[1][1]))
         except Exception:
             for _, f in made:
                 self._discard(f)
@@ -937,6 +940,10 @@ class BoostClassifier:
                 already works on iteration i + 1 (doublets ... PCA); part C of iteration i (refinement on the device,
                 needs B's labels) is slotted in behind that PCA, before the next graph overwrites the previous one."""
                 dev, engine = lanes[k]
+                src = getattr(engine, "_clone_source", None)
+                if src is not None:                  # a follower: take over the leader's resident counts first (_open_lanes)
+                    engine._clone_source = None
+                    engine.clone_from(src)
                 kw = {"verbose": True} if self.verbose else {}
                 kw2 = dict(kw)
                 if metric != "euclidean":

@@ -614,6 +614,9 @@ static int bp_refresh_once(ddx_ctx* ctx) {
 int bp_refresh(ddx_ctx* ctx) {
     int rc = bp_refresh_once(ctx);
     if (rc == kBpRetry) {
+        // (the old structures are abandoned, not released: a follower context may be copying them at this moment; the arena takes the block
+        // back when the context is reset for its next fit)
+        ctx->bp_buf = DevBuf();
         DDX_TRY(bp_build(ctx));
         ctx->rowseg_rows = -1;
         rc = bp_refresh_once(ctx);
