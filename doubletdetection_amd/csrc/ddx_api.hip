@@ -72,7 +72,7 @@ void context_reset(ddx_ctx* ctx) {
                       &ctx->sort_vals_in, &ctx->sort_vals_out, &ctx->sort_tmp, &ctx->sort_rowid, &ctx->median, &ctx->lib_sorted, &ctx->lognorm_tab,
                       &ctx->zcol, &ctx->colmean, &ctx->colstat, &ctx->col_part, &ctx->pcaA, &ctx->pcaB, &ctx->pcaSmall,
                       &ctx->pcaPartial, &ctx->pcaVec, &ctx->pcaPanel, &ctx->pcaOp, &ctx->pcaQ0, &ctx->pcaBlk, &ctx->rowseg, &ctx->rank_buf, &ctx->lv_buf, &ctx->lv_pack, &ctx->graph_buf, &ctx->emb32, &ctx->emb64, &ctx->sing, &ctx->knn_idx,
-                      &ctx->knn_dist, &ctx->knn_sorted, &ctx->edge_w, &ctx->knn_cells, &ctx->bp_buf, &ctx->bp_work, &ctx->bp_ms_colptr, &ctx->bp_ms_row, &ctx->bp_ms_x};
+                      &ctx->knn_dist, &ctx->knn_sorted, &ctx->edge_w, &ctx->knn_cells, &ctx->bp_buf, &ctx->bp_work, &ctx->bp_ms_colptr, &ctx->bp_ms_row, &ctx->bp_ms_x, &ctx->pk_ptr[0], &ctx->pk_ptr[1], &ctx->pk_blocks[0], &ctx->pk_blocks[1]};
     for (DevBuf* b : bufs) { b->p = nullptr; b->cap = 0; b->blk = -1; }
     ctx->arena.blocks.clear();
     for (auto& c : ctx->arena.chunks) c.off = 0;
@@ -89,6 +89,8 @@ void context_reset(ddx_ctx* ctx) {
     ctx->c_nodes = -1; ctx->c_entries = 0; ctx->c_d_member = nullptr; ctx->c_d_indptr = nullptr; ctx->c_d_cols = nullptr; ctx->c_d_vals = nullptr;
     ctx->lv_host_valid = false;
     ctx->rowseg_rows = -1;
+    ctx->pk_valid[0] = ctx->pk_valid[1] = false;
+    ctx->mirror_full = false;
     ctx->bp = ddx::BitPlanes();
 }
 
@@ -157,6 +159,8 @@ bool Options::set(const char* key, const char* value) {
     if (k == "spmm_geom") { if (v == "auto") spmm_geom = 0; else if (v == "pair") spmm_geom = 1; else if (v == "quad") spmm_geom = 2; else return false; return true; }
     if (k == "spmm_trip") { if (v == "packed") trip_packed = true; else if (v == "f64") trip_packed = false; else return false; return true; }
     if (k == "bitplane") { if (v == "auto") bitplane = 1; else if (!num(0, 2, &x)) return false; else bitplane = (int)x; return true; }
+    if (k == "residual") { if (v == "packed") residual_packed = true; else if (v == "plain") residual_packed = false; else return false; return true; }
+    if (k == "residual_rows_own") { if (!num(6, 12, &x) || (x != 6 && x != 12)) return false; residual_rows_own = (int)x; return true; }
     if (k == "bp_digits") { if (!num(3, 4, &x)) return false; bp_digits = (int)x; return true; }
     if (k == "knn_fold") { knn_fold = on(); return true; }
     if (k == "knn_xcd_chunk") { if (!num(0, 4096, &x)) return false; knn_xcd_chunk = (int)x; return true; }

@@ -54,6 +54,8 @@ struct Options {
     bool arena_guard = false;        // DDX_ARENA_GUARD=1: pattern-fill the pad behind every block, ddx_check_memory verifies it
     int knn_ablation = 0;            // only honoured under DDX_ABLATION
     int upload_debug = 0;            // 1: timings of the upload on stderr, 2: per chunk
+    bool residual_packed = true;     // bit-plane mode: the sparse products read this iteration's entries from wave-ordered packed blocks (k_spmm_packed) instead of the CSR / mirror (k_spmm_lds)
+    int residual_rows_own = 12;      // outputs per lane group of the packed A Q kernel (12: one round of workgroups, each operand slice staged once per CU -- 0.157 ms per launch at the headline; 6: 0.177)
     int fault = 0;                   // fault injection (tests): 1 = allow_dynamic_lds fails
     bool hvg_fold = true;            // gene sums folded in while the packed matrix arrives (off: one pass after the upload)
     bool set(const char* key, const char* value);
@@ -228,6 +230,9 @@ struct ddx_ctx {
     ddx::DevBuf knn_cells;           // cells, interval tables and chunk lists of the emit pass (stage_knn)
     ddx::DevBuf bp_buf, bp_work;     // bit-plane products: per-fit structures / per-product work space
     ddx::DevBuf bp_ms_colptr, bp_ms_row, bp_ms_x;   // ... the synthetic rows' reduced mirror (rebuilt every iteration)
+    ddx::DevBuf pk_ptr[2], pk_blocks[2];   // packed residual products (k_pca.hip: k_pack_residual): [A Q, A^T Y] block tables and blocks of this iteration
+    bool pk_valid[2] = {false, false};
+    int64_t pk_nblocks[2] = {0, 0};
     bool mirror_full = false;        // csc_s_* and csc_*_x hold this iteration's full mirror (the bit-plane route leaves it out: ensure_full_mirror)
     ddx::BitPlanes bp;
     const int32_t* knn_overflow = nullptr;   // device counter: queries whose candidate list overflowed (exact rescan)

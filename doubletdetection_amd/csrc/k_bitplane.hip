@@ -553,6 +553,7 @@ static int bp_refresh_once(ddx_ctx* ctx) {
     bp.SKr_used = bp.Npad / kBpStageCols + ceil_div(S, kBpStageCols);
     DDX_TRY(bp_workspace(ctx));
     bp.nrest_s = 0;
+    ctx->pk_valid[0] = ctx->pk_valid[1] = false;             // the packed blocks of the sparse products describe the last iteration's matrix
     {
         ScopedTimer t(ctx, "bitplane_values");
         if (bp.nrest_o > 0)

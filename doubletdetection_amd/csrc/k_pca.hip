@@ -19,6 +19,8 @@
 #include <cmath>
 #include <cstdlib>
 
+#include "ddx_prims.h"
+
 #include "ddx_internal.h"
 
 namespace ddx {
@@ -681,6 +683,289 @@ __global__ void __launch_bounds__(kLdsThreads) k_spmm_lds(const LdsSpmmArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Packed residual products (bit-plane mode, round 5).  Once the entries equal to 1 have gone to the matrix cores, a (row, slice)
+// segment of the A Q pass holds ~7 entries and a round of k_spmm_lds above -- segment bounds by readlane, six 4-byte fetches, index
+// arithmetic, six staging stores, two wave syncs, for ONE partial trip -- costs five times what its entries cost: 0.22 ms for a tenth
+// of the entries against 0.65 ms for all of them.  But that staging work is the same in all sixteen products of an iteration (the
+// matrix does not change between them), so it is done ONCE per iteration by k_pack_residual and the products read the result:
+//
+//   * same ownership as k_spmm_lds (wave = 3 lane groups x OWN outputs, ranked outputs interleaved over waves and workgroups),
+//     same operand slices, same trips of 8 / 4 steps in the same order -- the sums are bit-identical to k_spmm_lds';
+//   * per (wave, slice) the steps of its OWN units are concatenated into QUADS of 4 lock-step steps (3 slots x 4 entries:
+//     float32 x - z and 16-bit operand row inside the slice, zero padded), twelve quads to a self-describing 1 KB BLOCK
+//     (header: quads per unit in this block);
+//   * the product kernel copies a wave's next block global -> LDS asynchronously (one 1 KB instruction, double buffered) while it
+//     works through the current one: per block one header read and then nothing but trips.
+// ------------------------------------------------------------------------------------------------
+constexpr int kPkQuadBytes = 80;        // val[3][4] float32 (48) | idx[3][4] uint16 (24) | pad (8): 16-byte aligned
+constexpr int kPkQuads = 12;            // quads per block
+constexpr int kPkHeader = 64;           // bytes before the first quad: quads per unit (uint8, at most 12 units)
+constexpr int kPkBlockBytes = kPkHeader + kPkQuads * kPkQuadBytes;   // 1024
+static_assert(kPkBlockBytes == 1024, "a block is one wave-wide 16-byte copy");
+constexpr int kPkMaxOwn = 12;
+
+struct PackedArgs {
+    LdsSpmmArgs a;                // geometry, sources, outputs as for k_spmm_lds (ROWS: indptr / cols / x / rowseg; COLS: the mirrors)
+    int own;                      // outputs per lane group
+    int nsl;                      // slices a workgroup walks (ROWS: all of them; COLS: every groups-th)
+    const int32_t* blkptr;        // [waves x (nsl + 1)] block range of a wave's t-th slice
+    const unsigned char* blocks;  // the packed blocks
+};
+
+// the segment of local output m = (k, g) of wave `wave` of workgroup (owner, group) in slice s: up to two source ranges
+struct PkSeg { const int32_t* idx[2]; const float* x[2]; int32_t lo[2], hi[2]; };
+
+template <bool ROWS>
+__device__ __forceinline__ PkSeg pk_segment(const LdsSpmmArgs& a, int64_t out, int s) {
+    PkSeg sg;
+    sg.idx[0] = sg.idx[1] = a.cols; sg.x[0] = sg.x[1] = a.x;
+    sg.lo[0] = sg.hi[0] = sg.lo[1] = sg.hi[1] = 0;
+    if (out >= a.nOut) return sg;
+    if (ROWS) {
+        const int64_t base = a.indptr[out];
+        const int32_t* rs = a.rowseg + out * (a.nslices + 1) + s;
+        sg.lo[0] = (int32_t)(base + rs[0]); sg.hi[0] = (int32_t)(base + rs[1]);
+    } else {
+        if (s < a.P_o) {
+            sg.idx[0] = a.row_o; sg.x[0] = a.x_o;
+            sg.lo[0] = (int32_t)a.cp_o[(int64_t)s * a.nOut + out]; sg.hi[0] = (int32_t)a.cp_o[(int64_t)s * a.nOut + out + 1];
+        }
+        const int ps = s - a.p_s0;
+        if (ps >= 0 && ps < a.P_s) {
+            sg.idx[1] = a.row_s; sg.x[1] = a.x_s;
+            sg.lo[1] = (int32_t)a.cp_s[(int64_t)ps * a.nOut + out]; sg.hi[1] = (int32_t)a.cp_s[(int64_t)ps * a.nOut + out + 1];
+        }
+    }
+    return sg;
+}
+
+// One wave of this kernel = one wave of the product kernel (wg = workgroup index of the product launch, w = its wave).
+// fill == 0: cnt[(wg * 16 + w) * (nsl + 1) + t] = blocks of the wave's t-th slice.   fill == 1: writes the blocks (zeroed beforehand).
+template <bool ROWS>
+__global__ void __launch_bounds__(256) k_pack_residual(const LdsSpmmArgs a, int own, int nsl, int nwg, int32_t* __restrict__ ptr, unsigned char* __restrict__ blocks, int fill) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wgl = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wgl >= (int64_t)nwg * kLdsWaves) return;
+    const int bid = (int)(wgl / kLdsWaves), wave = (int)(wgl % kLdsWaves);
+    const int owner = bid % a.owners, group = bid / a.owners;
+    const int perw = 3 * own;
+    const int k = lane / 3, g = lane - 3 * k;
+    int64_t out = a.nOut;
+    if (lane < perw) {
+        const int64_t rank = (((int64_t)k * kLdsWaves + wave) * a.owners + owner) * 3 + g;
+        out = rank < a.nOut ? (int64_t)a.perm[rank] : a.nOut;
+    }
+    const float z = ROWS ? a.zval : (out < a.nOut ? a.zcol[out] : 0.0f);
+    for (int t = 0; t < nsl; ++t) {
+        const int s = ROWS ? t : group + t * a.groups;
+        PkSeg sg = pk_segment<ROWS>(a, s < a.nslices ? out : a.nOut, s < a.nslices ? s : 0);
+        // (the two sources of a segment -- the original rows' and the synthetic rows' mirror in the one panel that straddles row N --
+        // keep trips of their own, as in k_spmm_lds: the float32 trip sums then group the same entries)
+        const int n0 = sg.hi[0] - sg.lo[0], n1 = sg.hi[1] - sg.lo[1];
+        // quads of the lane's unit = ceil(longest of its three segments / 4) per source; prefix over the units before it
+        const int b3 = 3 * k < 64 ? 3 * k : 0;
+        int mx0 = __shfl(n0, b3, 64), mx1 = __shfl(n1, b3, 64);
+        mx0 = max(mx0, __shfl(n0, b3 + 1 < 64 ? b3 + 1 : 0, 64)); mx1 = max(mx1, __shfl(n1, b3 + 1 < 64 ? b3 + 1 : 0, 64));
+        mx0 = max(mx0, __shfl(n0, b3 + 2 < 64 ? b3 + 2 : 0, 64)); mx1 = max(mx1, __shfl(n1, b3 + 2 < 64 ? b3 + 2 : 0, 64));
+        const int nq0 = lane < perw ? (mx0 + 3) >> 2 : 0;
+        const int nq = lane < perw ? nq0 + ((mx1 + 3) >> 2) : 0;
+        int pre = 0, total = 0;
+        for (int kk = 0; kk < own; ++kk) {
+            const int v = __shfl(nq, 3 * kk, 64);
+            if (kk < k) pre += v;
+            total += v;
+        }
+        const int64_t slot = wgl * (nsl + 1) + t;
+        if (!fill) {
+            if (lane == 0) ptr[slot] = (total + kPkQuads - 1) / kPkQuads;
+            continue;
+        }
+        if (lane >= perw || nq == 0) continue;
+        const int64_t blk0 = ptr[slot];
+        if (g == 0) {                                     // header bytes of the blocks this unit's quads fall into
+            for (int bb = pre / kPkQuads; bb <= (pre + nq - 1) / kPkQuads; ++bb) {
+                const int lo = max(pre, bb * kPkQuads), hi = min(pre + nq, (bb + 1) * kPkQuads);
+                blocks[(blk0 + bb) * kPkBlockBytes + k] = (unsigned char)(hi - lo);
+            }
+        }
+        const int32_t base = s * a.SR;
+        for (int e = 0; e < n0 + n1; ++e) {              // (the padding behind a segment stays zero: the buffer was cleared)
+            const int src = e < n0 ? 0 : 1;
+            const int es = src == 0 ? e : e - n0;        // position inside its source
+            const int32_t p = sg.lo[src] + es;
+            const float v = sg.x[src][p] - z;             // x - z in float32: the correctly rounded difference (as k_spmm_lds stages it)
+            const int32_t i = sg.idx[src][p] - base;
+            const int qpos = pre + (src == 0 ? 0 : nq0) + (es >> 2), st = es & 3;
+            unsigned char* q = blocks + (blk0 + qpos / kPkQuads) * kPkBlockBytes + kPkHeader + (qpos % kPkQuads) * kPkQuadBytes;
+            reinterpret_cast<float*>(q)[g * 4 + st] = v;
+            reinterpret_cast<uint16_t*>(q + 48)[g * 4 + st] = (uint16_t)i;
+        }
+    }
+}
+
+template <bool ROWS, int OWN>
+__global__ void __launch_bounds__(kLdsThreads) k_spmm_packed(const PackedArgs pa) {
+    typedef float fq __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(3))) const fq lds_fq;
+    typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+    const LdsSpmmArgs& a = pa.a;
+    extern __shared__ __align__(16) unsigned char smem[];
+    float* opS = reinterpret_cast<float*>(smem);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    unsigned char* stg = smem + (((size_t)a.SR * a.ld * 4 + 15) & ~(size_t)15) + (size_t)wave * (2 * kPkBlockBytes);     // two block buffers per wave
+    int slot = lane / a.lpn, sub = lane - slot * a.lpn;
+    const bool active = slot < 3 && 2 * sub < a.ld;
+    if (slot >= 3) slot = 2;                         // idle lanes shadow the last group (reads only)
+    if (2 * sub >= a.ld) sub = 0;
+    const int owner = (int)(blockIdx.x % a.owners);
+    const int group = (int)(blockIdx.x / a.owners);
+    constexpr int PERW = 3 * OWN;
+    auto out_index = [&](int m) -> int64_t {
+        const int k = m / 3, g = m - k * 3;
+        const int64_t rank = (((int64_t)k * kLdsWaves + wave) * a.owners + owner) * 3 + g;
+        return rank < a.nOut ? (int64_t)a.perm[rank] : a.nOut;
+    };
+    const int64_t myout = lane < PERW ? out_index(lane) : a.nOut;
+    double acc[OWN][2];
+#pragma unroll
+    for (int k = 0; k < OWN; ++k) acc[k][0] = acc[k][1] = 0.0;
+    const int32_t* bp = pa.blkptr + ((int64_t)blockIdx.x * kLdsWaves + wave) * (pa.nsl + 1);
+    const uint32_t rowb = (uint32_t)(a.ld * 4);
+    const uint32_t base3 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)(smem + 8 * sub);
+    auto copy_block = [&](int32_t b, int buf) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa.blocks + (int64_t)b * kPkBlockBytes + lane * 16),
+                                         (__attribute__((address_space(3))) void*)(stg + buf * kPkBlockBytes), 16, 0, 0);
+    };
+    for (int t = 0; t < pa.nsl; ++t) {
+        const int s = ROWS ? t : group + t * a.groups;
+        if (s >= a.nslices) break;
+        __syncthreads();                                // everybody is done with the previous slice
+        const int32_t b0 = bp[t], b1 = bp[t + 1];
+        {
+            const int64_t r0 = (int64_t)s * a.SR;
+            const int nr = (int)((a.opRows - r0) < a.SR ? (a.opRows - r0) : a.SR);
+            const int nvec = (nr * a.ld + 3) >> 2;
+            const f4v* src = reinterpret_cast<const f4v*>(a.op + r0 * a.ld);
+            f4v* dst = reinterpret_cast<f4v*>(opS);
+            for (int base = wave * 64; base < nvec; base += kLdsThreads)
+                if (base + lane < nvec)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + base + lane),
+                                                     (__attribute__((address_space(3))) void*)(dst + base), 16, 0, 0);
+            if (b0 < b1) copy_block(b0, 0);             // (the wave's first block of this slice travels with the slice)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        for (int32_t b = b0; b < b1; ++b) {
+            const int buf = (b - b0) & 1;
+            if (b + 1 < b1) {
+                copy_block(b + 1, buf ^ 1);
+                asm volatile("s_waitcnt vmcnt(1)" ::: "memory");     // block b has landed (a wave's copies complete in order)
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            const unsigned char* blk = stg + buf * kPkBlockBytes;
+            // quads per unit of this block: three 32-bit words of four counts each, wave-uniform
+            const uint32_t* hw = reinterpret_cast<const uint32_t*>(blk);
+            uint32_t hdr[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) hdr[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)hw[i]);
+            const unsigned char* qp = blk + kPkHeader + slot * 16;      // this group's values of quad 0; its indices at + 48 - slot * 8
+            const unsigned char* ip = blk + kPkHeader + 48 + slot * 8;
+#pragma unroll
+            for (int k = 0; k < OWN; ++k) {
+                const int n = (int)((hdr[k >> 2] >> (8 * (k & 3))) & 0xffu);
+                int q = 0;
+                for (; q + 1 < n; q += 2) {              // a trip of eight steps = two quads
+                    const f4v f0 = *reinterpret_cast<const f4v*>(qp), f1 = *reinterpret_cast<const f4v*>(qp + kPkQuadBytes);
+                    const u2 i0 = *reinterpret_cast<const u2*>(ip), i1 = *reinterpret_cast<const u2*>(ip + kPkQuadBytes);
+                    fq v[8];
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const uint32_t pk = w < 2 ? i0[w] : i1[w - 2];
+                        uint32_t alo, ahi;
+                        asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(alo) : "v"(pk), "s"(rowb), "v"(base3));
+                        asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(ahi) : "v"(pk), "s"(rowb), "v"(base3));
+                        v[2 * w] = *reinterpret_cast<lds_fq*>((uintptr_t)alo);
+                        v[2 * w + 1] = *reinterpret_cast<lds_fq*>((uintptr_t)ahi);
+                    }
+                    fq p0 = v[0] * f0.x;
+                    fq p1 = v[1] * f0.y;
+                    p0 = __builtin_elementwise_fma(v[2], (fq)(f0.z), p0);
+                    p1 = __builtin_elementwise_fma(v[3], (fq)(f0.w), p1);
+                    p0 = __builtin_elementwise_fma(v[4], (fq)(f1.x), p0);
+                    p1 = __builtin_elementwise_fma(v[5], (fq)(f1.y), p1);
+                    p0 = __builtin_elementwise_fma(v[6], (fq)(f1.z), p0);
+                    p1 = __builtin_elementwise_fma(v[7], (fq)(f1.w), p1);
+                    p0 = p0 + p1;
+                    acc[k][0] += (double)p0[0];
+                    acc[k][1] += (double)p0[1];
+                    qp += 2 * kPkQuadBytes; ip += 2 * kPkQuadBytes;
+                }
+                if (q < n) {                             // a half trip of four
+                    const f4v f0 = *reinterpret_cast<const f4v*>(qp);
+                    const u2 i0 = *reinterpret_cast<const u2*>(ip);
+                    fq v[4];
+#pragma unroll
+                    for (int w = 0; w < 2; ++w) {
+                        uint32_t alo, ahi;
+                        asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(alo) : "v"(i0[w]), "s"(rowb), "v"(base3));
+                        asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(ahi) : "v"(i0[w]), "s"(rowb), "v"(base3));
+                        v[2 * w] = *reinterpret_cast<lds_fq*>((uintptr_t)alo);
+                        v[2 * w + 1] = *reinterpret_cast<lds_fq*>((uintptr_t)ahi);
+                    }
+                    fq p0 = v[0] * f0.x;
+                    fq p1 = v[1] * f0.y;
+                    p0 = __builtin_elementwise_fma(v[2], (fq)(f0.z), p0);
+                    p1 = __builtin_elementwise_fma(v[3], (fq)(f0.w), p1);
+                    p0 = p0 + p1;
+                    acc[k][0] += (double)p0[0];
+                    acc[k][1] += (double)p0[1];
+                    qp += kPkQuadBytes; ip += kPkQuadBytes;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // (the buffer is overwritten two blocks from now)
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    // every lane group writes its own outputs (as k_spmm_lds)
+    double cm[2] = {0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < OWN; ++k) {
+        const int64_t o = __shfl(myout, k * 3 + slot, 64);
+        if (active && o < a.nOut) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int col = 2 * sub + c;
+                if (col < a.L) {
+                    if (ROWS) {
+                        double y = acc[k][c] - a.tvec[col];
+                        if (a.accumulate) y += a.out[o * a.L + col];
+                        a.out[o * a.L + col] = y;
+                        if (a.ymax) { const double v = fabs(a.srow[o] * y); cm[c] = v > cm[c] ? v : cm[c]; }
+                        if (a.out32) a.out32[o * a.ld + col] = (float)y;
+                    } else {
+                        a.out[((int64_t)group * a.nOut + o) * a.L + col] = acc[k][c];
+                    }
+                }
+            }
+        }
+    }
+    if (ROWS && a.ymax) {
+        unsigned long long* red = reinterpret_cast<unsigned long long*>(smem);
+        __syncthreads();
+        if (threadIdx.x < 64) red[threadIdx.x] = 0ull;
+        __syncthreads();
+        if (active) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+                if (2 * sub + c < a.L && cm[c] > 0.0) atomicMax(&red[2 * sub + c], (unsigned long long)__double_as_longlong(cm[c]));
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < a.L && red[threadIdx.x]) atomicMax(a.ymax + threadIdx.x, red[threadIdx.x]);
+    }
+}
+
 // rowseg[row*(ns+1) + p] = offset inside row `row` of its first stored entry whose column is >= p*SR (p = ns: row length)
 // (rows row0 .. nrows-1: the rows of the original cells keep their segments from iteration to iteration)
 __global__ void k_row_segments(const int64_t* __restrict__ indptr, const int32_t* __restrict__ cols, int64_t row0, int64_t nrows, int ns,
@@ -1285,6 +1570,57 @@ static int launch_lds(ddx_ctx* c, const LdsSpmmArgs& a, int slots, unsigned grid
     return slots == 4 ? launch_lds_t<ROWS, 4, false, 2, kLdsOwnG>(c, a, grid, lds_bytes) : launch_lds_t<ROWS, 3, false, 2, kLdsOwnG>(c, a, grid, lds_bytes);
 }
 
+// packed residual products (bit-plane mode): the wave-ordered blocks of this iteration's reduced matrix, built at the first product that
+// needs them (ctx->pk_valid is cleared by bp_refresh); see k_pack_residual / k_spmm_packed
+static bool packed_applies(const ddx_ctx* c, const LdsSpmmArgs& a, int slots) {
+    return c->opt.residual_packed && lds_packed() && !lds_quad(a.ld) && slots == 3 && a.ld == 40 && a.lpn == 20;
+}
+
+template <bool ROWS>
+static int pack_residual(ddx_ctx* c, const LdsSpmmArgs& a, int own, int nsl, int nwg) {
+    const int side = ROWS ? 0 : 1;
+    ScopedTimer t(c, "residual_pack");
+    const int64_t nwaves = (int64_t)nwg * kLdsWaves;
+    const size_t n = (size_t)nwaves * (nsl + 1) + 1;
+    DDX_TRY(ensure(c, c->pk_ptr[side], sizeof(int32_t) * 2 * n));
+    int32_t* cnt = c->pk_ptr[side].as<int32_t>();
+    int32_t* ptr = cnt + n;
+    DDX_HIP(c, hipMemsetAsync(cnt, 0, sizeof(int32_t) * n, c->stream));
+    const unsigned grid = (unsigned)ceil_div(nwaves, 4);
+    k_pack_residual<ROWS><<<grid, 256, 0, c->stream>>>(a, own, nsl, nwg, cnt, nullptr, 0);
+    size_t tmp = 0;
+    DDX_HIP(c, prim::exclusive_sum(nullptr, tmp, cnt, ptr, n, c->stream));
+    DDX_TRY(ensure(c, c->sort_tmp, tmp));
+    DDX_HIP(c, prim::exclusive_sum(c->sort_tmp.p, tmp, cnt, ptr, n, c->stream));
+    int32_t total = 0;
+    DDX_HIP(c, hipMemcpyAsync(&total, ptr + (n - 1), sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    DDX_HIP(c, hipStreamSynchronize(c->stream));
+    DDX_TRY(ensure(c, c->pk_blocks[side], (size_t)(total + 1) * kPkBlockBytes));
+    DDX_HIP(c, hipMemsetAsync(c->pk_blocks[side].p, 0, (size_t)(total + 1) * kPkBlockBytes, c->stream));
+    k_pack_residual<ROWS><<<grid, 256, 0, c->stream>>>(a, own, nsl, nwg, ptr, c->pk_blocks[side].as<unsigned char>(), 1);
+    DDX_HIP(c, hipGetLastError());
+    c->pk_nblocks[side] = total;
+    c->pk_valid[side] = true;
+    return DDX_OK;
+}
+
+template <bool ROWS, int OWN>
+static int launch_packed(ddx_ctx* c, const LdsSpmmArgs& a, int nsl, unsigned grid) {
+    const int side = ROWS ? 0 : 1;
+    if (!c->pk_valid[side]) DDX_TRY((pack_residual<ROWS>(c, a, OWN, nsl, (int)grid)));
+    PackedArgs pa{};
+    pa.a = a; pa.own = OWN; pa.nsl = nsl;
+    const size_t n = (size_t)grid * kLdsWaves * (nsl + 1) + 1;
+    pa.blkptr = c->pk_ptr[side].as<int32_t>() + n;
+    pa.blocks = c->pk_blocks[side].as<unsigned char>();
+    const size_t lds_bytes = (((size_t)a.SR * a.ld * 4 + 15) & ~(size_t)15) + (size_t)kLdsWaves * 2 * kPkBlockBytes;
+    DDX_TRY(allow_dynamic_lds(c, reinterpret_cast<const void*>(&k_spmm_packed<ROWS, OWN>), (int)kLdsBudget));
+    ScopedTimer t(c, ROWS ? "spmm_rows" : "spmm_cols");
+    k_spmm_packed<ROWS, OWN><<<grid, kLdsThreads, lds_bytes, c->stream>>>(pa);
+    DDX_HIP(c, hipGetLastError());
+    return DDX_OK;
+}
+
 static int apply_rows_wide(PcaWork& w, const double* Qcol, double* Yrow);
 static int apply_cols_wide(PcaWork& w, const double* Yrow, double* Wcol);
 
@@ -1299,7 +1635,6 @@ static int apply_rows(PcaWork& w, const double* Qcol, double* Yrow) {  // A Q : 
     // Y = diag(s) B Q on the matrix cores first (a timing scope of its own); the sparse kernel then sees only the entries other
     // than 1 and adds its part
     if (w.bitplane) DDX_TRY(bp_rows_product(c, Qcol, w.L, Yrow));
-    ScopedTimer t(c, "spmm_rows");
     const unsigned grid = (unsigned)ceil_div(w.M, 4);
     if (w.lds) {
         LdsSpmmArgs a{};
@@ -1334,10 +1669,19 @@ static int apply_rows(PcaWork& w, const double* Qcol, double* Yrow) {  // A Q : 
             a.ymax = reinterpret_cast<unsigned long long*>(c->bp.cmax + 64);
             c->bp.ymax_of = w.fused_ymax ? Yrow : nullptr;
         }
+        if (w.bitplane && packed_applies(c, a, slots)) {
+            if (c->opt.residual_rows_own == kLdsOwnSparseCols) {
+                a.owners = lds_owners(w.M, slots, a.ld, true);
+                return launch_packed<true, kLdsOwnSparseCols>(c, a, a.nslices, (unsigned)a.owners);
+            }
+            return launch_packed<true, kLdsOwnG>(c, a, a.nslices, (unsigned)a.owners);
+        }
         const size_t lds_bytes = (size_t)a.SR * a.ld * 4 + (size_t)((a.SR + 3) & ~3) * 4 + lds_stage_bytes(slots, lds_packed());
+        ScopedTimer t(c, "spmm_rows");
         DDX_TRY(launch_lds<true>(c, a, slots, (unsigned)a.owners, lds_bytes));
         return DDX_OK;
     }
+    ScopedTimer t(c, "spmm_rows");
     if (w.gather32) {
         const int ld = (w.L + 3) & ~3, lpn = ld / 4;
         const float* op = prepared_operand<float>(w, Qcol, w.H, ld);
@@ -1371,7 +1715,6 @@ static int apply_cols(PcaWork& w, const double* Yrow, double* Wcol) {  // A^T Y 
     const double* w1 = nullptr;                     // bit-plane part of the product: nw1 partial blocks
     int nw1 = 0;
     if (w.bitplane) DDX_TRY(bp_cols_product(c, Yrow, w.L, &w1, &nw1));
-    ScopedTimer t(c, "spmm_cols");
     if (w.lds) {
         LdsSpmmArgs a{};
         a.ld = (w.L + 3) & ~3; a.L = w.L; a.lpn = lds_lpn(a.ld);
@@ -1397,12 +1740,19 @@ static int apply_cols(PcaWork& w, const double* Yrow, double* Wcol) {  // A^T Y 
         a.p_s0 = c->p_s0; a.P_s = c->P_s;
         a.out = c->pcaPanel.as<double>();
         a.perm = c->rank_cols;
-        const size_t lds_bytes = (size_t)a.SR * a.ld * 4 + lds_stage_bytes(slots, lds_packed());
-        DDX_TRY(launch_lds<false>(c, a, slots, (unsigned)(a.owners * a.groups), lds_bytes, w.bitplane));
+        if (w.bitplane && packed_applies(c, a, slots) && lds_own(a.ld, true) == kLdsOwnSparseCols) {
+            DDX_TRY((launch_packed<false, kLdsOwnSparseCols>(c, a, (int)ceil_div(P, a.groups), (unsigned)(a.owners * a.groups))));
+        } else {
+            const size_t lds_bytes = (size_t)a.SR * a.ld * 4 + lds_stage_bytes(slots, lds_packed());
+            ScopedTimer t(c, "spmm_cols");
+            DDX_TRY(launch_lds<false>(c, a, slots, (unsigned)(a.owners * a.groups), lds_bytes, w.bitplane));
+        }
+        ScopedTimer t(c, "spmm_cols");
         k_sum_panels<<<(unsigned)ceil_div((int64_t)w.H * w.L, 256), 256, 0, c->stream>>>(c->pcaPanel.as<double>(), a.groups, w.H, w.L, c->colmean.as<double>(),
                                                                                           uvec, Wcol, w1, nw1);
         return DDX_OK;
     }
+    ScopedTimer t(c, "spmm_cols");
     if (w.gather32) {
         const int ld = (w.L + 3) & ~3, lpn = ld / 4;
         const float* op = prepared_operand<float>(w, Yrow, w.M, ld);

@@ -65,6 +65,9 @@ int ddx_synchronize(ddx_ctx* ctx);
  *   bitplane          auto | 0 | 1 | 2  stored entries equal to 1 as bitmaps on the int8 matrix cores, the others through the sparse products
  *                                       (auto = 1: when the matrix is unscaled, the sketch at most 40 columns wide and there are at least 4096 cells;
  *                                       2: whenever the matrix is unscaled and the sketch fits; 0: plain sparse products)
+ *   residual          packed | plain    bit-plane mode: the sparse products walk wave-ordered packed blocks built once per iteration (default)
+ *                                       or the reduced CSR / mirror directly (same entries, same order; equal to rounding)
+ *   residual_rows_own 12 | 6            outputs per lane group of the packed A Q kernel
  *   bp_digits         4 | 3             8-bit digits of the operand's fixed point in the bit-plane products (4: 30 bits below the
  *                                       column's largest element -- default, PCA scores within 4e-7 of the float64 oracle at the
  *                                       BASELINE sizes; 3: 22 bits, a fifth fewer matrix instructions, 4e-6)

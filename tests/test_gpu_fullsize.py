@@ -240,6 +240,12 @@ def test_operator_product_variants_agree_at_full_size(data, staged, monkeypatch)
     # forced on / off does not depend on the automatic rule
     emb_2, sing_2 = other({"bitplane": "2"})
     np.testing.assert_array_equal(emb_2, emb_bp)
+    # the sparse part of the bit-plane route through the packed blocks (default) and straight from the reduced CSR / mirror: the same
+    # entries against the same operand copies in the same order; only where a unit's steps continue in the next 1 KB block does a
+    # trip of eight become two of four (float32 sums inside a trip): rounding noise
+    emb_p, sing_p = other({"residual": "plain"})
+    np.testing.assert_allclose(sing_p, sing_bp, rtol=1e-9)
+    assert rel_dev(emb_p, emb_bp) < 1e-6
 
 
 @pytest.mark.parametrize("algorithm", ["louvain", "leiden"])
