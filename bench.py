@@ -314,7 +314,7 @@ def main():
             prep = per_launch("bitplane_prep")
             product = {}
             for side, mf in (("rows", "bitplane_rows"), ("cols", "bitplane_cols")):
-                ms = per_launch("spmm_" + side) + per_launch(mf) + prep
+                ms = per_launch("spmm_" + side) + per_launch(mf) + prep + (per_launch("spmm_sum") if side == "cols" else 0.0)
                 product["A Q" if side == "rows" else "A^T Y"] = {
                     "ms_per_product": round(ms, 4), "kernels_ms": {"sparse": round(per_launch("spmm_" + side), 4), "matrix_cores": round(per_launch(mf), 4),
                                                                   "preparation": round(prep, 4)},

@@ -740,13 +740,17 @@ __device__ __forceinline__ PkSeg pk_segment(const LdsSpmmArgs& a, int64_t out, i
     return sg;
 }
 
-// One wave of this kernel = one wave of the product kernel (wg = workgroup index of the product launch, w = its wave).
-// fill == 0: cnt[(wg * 16 + w) * (nsl + 1) + t] = blocks of the wave's t-th slice.   fill == 1: writes the blocks (zeroed beforehand).
+// One wave of this kernel = one (wave of the product kernel, slice) pair: wgl = product workgroup * 16 + wave, t = index in that
+// workgroup's slice list.  Lane m < 3 own looks after segment (k, g) = (m / 3, m % 3); the entries of all segments are then spread
+// over the 64 lanes (a wave scan of the lengths, a binary search per entry) so that the copy runs at full width.
+// fill == 0: ptr[wgl * (nsl + 1) + t] = blocks the pair needs.   fill == 1: ptr holds the block offsets; writes the blocks (zeroed beforehand).
 template <bool ROWS>
 __global__ void __launch_bounds__(256) k_pack_residual(const LdsSpmmArgs a, int own, int nsl, int nwg, int32_t* __restrict__ ptr, unsigned char* __restrict__ blocks, int fill) {
     const int lane = threadIdx.x & 63;
-    const int64_t wgl = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (wgl >= (int64_t)nwg * kLdsWaves) return;
+    const int64_t pair = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pair >= (int64_t)nwg * kLdsWaves * nsl) return;
+    const int64_t wgl = pair / nsl;
+    const int t = (int)(pair - wgl * nsl);
     const int bid = (int)(wgl / kLdsWaves), wave = (int)(wgl % kLdsWaves);
     const int owner = bid % a.owners, group = bid / a.owners;
     const int perw = 3 * own;
@@ -756,50 +760,77 @@ __global__ void __launch_bounds__(256) k_pack_residual(const LdsSpmmArgs a, int 
         const int64_t rank = (((int64_t)k * kLdsWaves + wave) * a.owners + owner) * 3 + g;
         out = rank < a.nOut ? (int64_t)a.perm[rank] : a.nOut;
     }
+    const int s = ROWS ? t : group + t * a.groups;
+    const PkSeg sg = pk_segment<ROWS>(a, s < a.nslices ? out : a.nOut, s < a.nslices ? s : 0);
+    // (the two sources of a segment -- the original rows' and the synthetic rows' mirror in the one panel that straddles row N --
+    // keep trips of their own, as in k_spmm_lds)
+    const int n0 = sg.hi[0] - sg.lo[0], n1 = sg.hi[1] - sg.lo[1];
+    // quads of the lane's unit = ceil(longest of its three segments / 4) per source; prefix over the units before it
+    const int b3 = 3 * k < 62 ? 3 * k : 0;
+    int mx0 = max(max(__shfl(n0, b3, 64), __shfl(n0, b3 + 1, 64)), __shfl(n0, b3 + 2, 64));
+    int mx1 = max(max(__shfl(n1, b3, 64), __shfl(n1, b3 + 1, 64)), __shfl(n1, b3 + 2, 64));
+    const int nq0 = lane < perw ? (mx0 + 3) >> 2 : 0;
+    const int nq = lane < perw ? nq0 + ((mx1 + 3) >> 2) : 0;
+    int pre = 0, total = 0;
+    for (int kk = 0; kk < own; ++kk) {
+        const int v = __shfl(nq, 3 * kk, 64);
+        if (kk < k) pre += v;
+        total += v;
+    }
+    const int64_t slot = wgl * (nsl + 1) + t;
+    if (!fill) {
+        if (lane == 0) ptr[slot] = (total + kPkQuads - 1) / kPkQuads;
+        return;
+    }
+    if (total == 0) return;
+    const int64_t blk0 = ptr[slot];
+    if (lane < perw && g == 0 && nq > 0) {                // header bytes of the blocks this unit's quads fall into
+        for (int bb = pre / kPkQuads; bb <= (pre + nq - 1) / kPkQuads; ++bb) {
+            const int lo = max(pre, bb * kPkQuads), hi = min(pre + nq, (bb + 1) * kPkQuads);
+            blocks[(blk0 + bb) * kPkBlockBytes + k] = (unsigned char)(hi - lo);
+        }
+    }
+    // inclusive scan of the segment lengths over the lanes
+    const int len = n0 + n1;
+    int incl = len;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
+    }
+    const int n_all = __shfl(incl, 63, 64);
     const float z = ROWS ? a.zval : (out < a.nOut ? a.zcol[out] : 0.0f);
-    for (int t = 0; t < nsl; ++t) {
-        const int s = ROWS ? t : group + t * a.groups;
-        PkSeg sg = pk_segment<ROWS>(a, s < a.nslices ? out : a.nOut, s < a.nslices ? s : 0);
-        // (the two sources of a segment -- the original rows' and the synthetic rows' mirror in the one panel that straddles row N --
-        // keep trips of their own, as in k_spmm_lds: the float32 trip sums then group the same entries)
-        const int n0 = sg.hi[0] - sg.lo[0], n1 = sg.hi[1] - sg.lo[1];
-        // quads of the lane's unit = ceil(longest of its three segments / 4) per source; prefix over the units before it
-        const int b3 = 3 * k < 64 ? 3 * k : 0;
-        int mx0 = __shfl(n0, b3, 64), mx1 = __shfl(n1, b3, 64);
-        mx0 = max(mx0, __shfl(n0, b3 + 1 < 64 ? b3 + 1 : 0, 64)); mx1 = max(mx1, __shfl(n1, b3 + 1 < 64 ? b3 + 1 : 0, 64));
-        mx0 = max(mx0, __shfl(n0, b3 + 2 < 64 ? b3 + 2 : 0, 64)); mx1 = max(mx1, __shfl(n1, b3 + 2 < 64 ? b3 + 2 : 0, 64));
-        const int nq0 = lane < perw ? (mx0 + 3) >> 2 : 0;
-        const int nq = lane < perw ? nq0 + ((mx1 + 3) >> 2) : 0;
-        int pre = 0, total = 0;
-        for (int kk = 0; kk < own; ++kk) {
-            const int v = __shfl(nq, 3 * kk, 64);
-            if (kk < k) pre += v;
-            total += v;
+    const int32_t base = s * a.SR;
+    for (int e0 = 0; e0 < n_all; e0 += 64) {             // (all lanes stay in the loop: they are shuffle sources)
+        const int e = e0 + lane;
+        // the segment that holds entry e: the first lane whose inclusive count exceeds e
+        int lo = 0, hi = 63;
+        const int ee = e < n_all ? e : n_all - 1;
+#pragma unroll
+        for (int it = 0; it < 6; ++it) {
+            const int mid = (lo + hi) >> 1;
+            const int v = __shfl(incl, mid, 64);
+            if (v > ee) hi = mid; else lo = mid + 1;
         }
-        const int64_t slot = wgl * (nsl + 1) + t;
-        if (!fill) {
-            if (lane == 0) ptr[slot] = (total + kPkQuads - 1) / kPkQuads;
-            continue;
-        }
-        if (lane >= perw || nq == 0) continue;
-        const int64_t blk0 = ptr[slot];
-        if (g == 0) {                                     // header bytes of the blocks this unit's quads fall into
-            for (int bb = pre / kPkQuads; bb <= (pre + nq - 1) / kPkQuads; ++bb) {
-                const int lo = max(pre, bb * kPkQuads), hi = min(pre + nq, (bb + 1) * kPkQuads);
-                blocks[(blk0 + bb) * kPkBlockBytes + k] = (unsigned char)(hi - lo);
-            }
-        }
-        const int32_t base = s * a.SR;
-        for (int e = 0; e < n0 + n1; ++e) {              // (the padding behind a segment stays zero: the buffer was cleared)
-            const int src = e < n0 ? 0 : 1;
-            const int es = src == 0 ? e : e - n0;        // position inside its source
-            const int32_t p = sg.lo[src] + es;
-            const float v = sg.x[src][p] - z;             // x - z in float32: the correctly rounded difference (as k_spmm_lds stages it)
-            const int32_t i = sg.idx[src][p] - base;
-            const int qpos = pre + (src == 0 ? 0 : nq0) + (es >> 2), st = es & 3;
+        const int m = lo;
+        const int m_incl = __shfl(incl, m, 64), m_len = __shfl(len, m, 64), m_n0 = __shfl(n0, m, 64);
+        const int m_lo0 = __shfl(sg.lo[0], m, 64), m_lo1 = __shfl(sg.lo[1], m, 64);
+        const int m_pre = __shfl(pre, m, 64), m_nq0 = __shfl(nq0, m, 64);
+        const float m_z = __shfl(z, m, 64);
+        if (e < n_all) {
+            const int el = ee - (m_incl - m_len);            // position inside segment m
+            const int src = el < m_n0 ? 0 : 1;
+            const int es = src == 0 ? el : el - m_n0;
+            const int32_t p = (src == 0 ? m_lo0 : m_lo1) + es;
+            const float* xs = ROWS ? a.x : (src == 0 ? a.x_o : a.x_s);
+            const int32_t* is = ROWS ? a.cols : (src == 0 ? a.row_o : a.row_s);
+            const float v = xs[p] - m_z;                     // x - z in float32: the correctly rounded difference (as k_spmm_lds stages it)
+            const int32_t i = is[p] - base;
+            const int mg = m % 3;
+            const int qpos = m_pre + (src == 0 ? 0 : m_nq0) + (es >> 2), st = es & 3;
             unsigned char* q = blocks + (blk0 + qpos / kPkQuads) * kPkBlockBytes + kPkHeader + (qpos % kPkQuads) * kPkQuadBytes;
-            reinterpret_cast<float*>(q)[g * 4 + st] = v;
-            reinterpret_cast<uint16_t*>(q + 48)[g * 4 + st] = (uint16_t)i;
+            reinterpret_cast<float*>(q)[mg * 4 + st] = v;
+            reinterpret_cast<uint16_t*>(q + 48)[mg * 4 + st] = (uint16_t)i;
         }
     }
 }
@@ -1586,7 +1617,7 @@ static int pack_residual(ddx_ctx* c, const LdsSpmmArgs& a, int own, int nsl, int
     int32_t* cnt = c->pk_ptr[side].as<int32_t>();
     int32_t* ptr = cnt + n;
     DDX_HIP(c, hipMemsetAsync(cnt, 0, sizeof(int32_t) * n, c->stream));
-    const unsigned grid = (unsigned)ceil_div(nwaves, 4);
+    const unsigned grid = (unsigned)ceil_div(nwaves * nsl, 4);          // one wave per (product wave, slice) pair
     k_pack_residual<ROWS><<<grid, 256, 0, c->stream>>>(a, own, nsl, nwg, cnt, nullptr, 0);
     size_t tmp = 0;
     DDX_HIP(c, prim::exclusive_sum(nullptr, tmp, cnt, ptr, n, c->stream));
@@ -1747,7 +1778,7 @@ static int apply_cols(PcaWork& w, const double* Yrow, double* Wcol) {  // A^T Y 
             ScopedTimer t(c, "spmm_cols");
             DDX_TRY(launch_lds<false>(c, a, slots, (unsigned)(a.owners * a.groups), lds_bytes, w.bitplane));
         }
-        ScopedTimer t(c, "spmm_cols");
+        ScopedTimer t(c, "spmm_sum");
         k_sum_panels<<<(unsigned)ceil_div((int64_t)w.H * w.L, 256), 256, 0, c->stream>>>(c->pcaPanel.as<double>(), a.groups, w.H, w.L, c->colmean.as<double>(),
                                                                                           uvec, Wcol, w1, nw1);
         return DDX_OK;
