@@ -879,8 +879,11 @@ __global__ void __launch_bounds__(kLdsThreads) k_spmm_packed(const PackedArgs pa
             const int nvec = (nr * a.ld + 3) >> 2;
             const f4v* src = reinterpret_cast<const f4v*>(a.op + r0 * a.ld);
             f4v* dst = reinterpret_cast<f4v*>(opS);
+#ifndef DDX_PK_DBG
+#define DDX_PK_DBG 0        // ablation builds only (timing; wrong results): 1 no operand-slice staging, 2 no trips
+#endif
             for (int base = wave * 64; base < nvec; base += kLdsThreads)
-                if (base + lane < nvec)
+                if (base + lane < nvec && !(DDX_PK_DBG & 1))
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + base + lane),
                                                      (__attribute__((address_space(3))) void*)(dst + base), 16, 0, 0);
             if (b0 < b1) copy_block(b0, 0);             // (the wave's first block of this slice travels with the slice)
@@ -905,7 +908,7 @@ __global__ void __launch_bounds__(kLdsThreads) k_spmm_packed(const PackedArgs pa
             const unsigned char* ip = blk + kPkHeader + 48 + slot * 8;
 #pragma unroll
             for (int k = 0; k < OWN; ++k) {
-                const int n = (int)((hdr[k >> 2] >> (8 * (k & 3))) & 0xffu);
+                const int n = (DDX_PK_DBG & 2) ? 0 : (int)((hdr[k >> 2] >> (8 * (k & 3))) & 0xffu);
                 int q = 0;
                 for (; q + 1 < n; q += 2) {              // a trip of eight steps = two quads
                     const f4v f0 = *reinterpret_cast<const f4v*>(qp), f1 = *reinterpret_cast<const f4v*>(qp + kPkQuadBytes);
