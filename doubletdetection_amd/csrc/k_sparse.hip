@@ -159,9 +159,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
                                                       const int64_t* __restrict__ out_off /* [S]: start of row s in the outputs */,
                                                       int32_t* __restrict__ out_indices, float* __restrict__ out_val,
                                                       int32_t* __restrict__ counts /* [S]: entries written, or null */) {
-    __shared__ int32_t t_col[kMergeTile];
-    __shared__ float t_val[kMergeTile];
-    __shared__ int32_t t_keep[kMergeTile];
     __shared__ int32_t wsum[4];
     __shared__ int32_t run_base;
     __shared__ int32_t s_idx[kMergeStage];          // both parents' column lists when they fit: the searches then run in LDS
@@ -194,49 +191,49 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
     }
     const int64_t o0 = out_off[s];
     if (tid == 0) run_base = 0;
+    // Merge path (round 5; rounds 1-4 let every element find its merged position by a binary search in the other row: ~12 LDS reads
+    // per element).  The merged sequence -- elements of A and B by (column, A before B) -- is cut into runs of PER positions, one per
+    // thread: the thread finds where its run starts on the merge path (ONE binary search over the diagonal i + j = d) and then
+    // merges PER steps sequentially.  An element of B that follows its equal in A is the "matched" one: A's element carries the sum
+    // (float32, __fadd_rn: the reference's scipy addition), B's slot is dropped; exact zeros are dropped as before.
+    constexpr int PER = kMergeTile / 256;
     for (int t0 = 0; t0 < L; t0 += kMergeTile) {
-        for (int i = tid; i < kMergeTile; i += 256) t_keep[i] = 0;
-        __syncthreads();
-        // A elements whose merged position falls in this tile.  Positions are increasing in i, so the
-        // candidates are i in [max(0, t0 - lb), min(la, t0 + tile)).
-        int ilo = t0 - lb; if (ilo < 0) ilo = 0;
-        int ihi = t0 + kMergeTile; if (ihi > la) ihi = la;
-        for (int i = ilo + tid; i < ihi; i += 256) {
-            const int32_t col = A[i];
-            const float va = val[a0 + i];                  // (requested before the search, used after it)
-            const int r = lower_bound_i32(B, lb, col);
-            const int p = i + r - t0;
-            if (p >= 0 && p < kMergeTile) {
-                float v = va;
-                if (r < lb && B[r] == col) v = __fadd_rn(v, val[b0 + r]);
-                t_col[p] = col;
-                t_val[p] = v;
-                t_keep[p] = (v != 0.f);
+        const int d0 = t0 + tid * PER;                  // first merged position of this thread
+        int i = 0, j = 0;
+        if (d0 < L) {
+            // smallest i in [max(0, d0 - lb), min(d0, la)] with A[i] > B[d0 - i - 1] (i.e. B[d0 - i - 1] already precedes A[i]);
+            // A goes first among equals, so "A[i] > B[..]" is strict
+            int lo = d0 - lb > 0 ? d0 - lb : 0, hi = d0 < la ? d0 : la;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (A[mid] <= B[d0 - mid - 1]) lo = mid + 1; else hi = mid;
             }
+            i = lo; j = d0 - lo;
         }
-        int jlo = t0 - la; if (jlo < 0) jlo = 0;
-        int jhi = t0 + kMergeTile; if (jhi > lb) jhi = lb;
-        for (int j = jlo + tid; j < jhi; j += 256) {
-            const int32_t col = B[j];
-            const float v = val[b0 + j];                   // (requested before the search, used after it)
-            const int r = upper_bound_i32(A, la, col);
-            const int p = j + r - t0;
-            if (p >= 0 && p < kMergeTile) {
-                const bool matched = (r > 0 && A[r - 1] == col);
-                t_col[p] = col;
-                t_val[p] = v;
-                t_keep[p] = (!matched && v != 0.f);
-            }
-        }
-        __syncthreads();
-        // compaction: each thread owns 8 consecutive merged positions
-        constexpr int PER = kMergeTile / 256;
-        int local[PER];
+        int32_t ocol[PER];
+        float oval[PER];
+        int keep[PER];
         int tot = 0;
 #pragma unroll
         for (int q = 0; q < PER; ++q) {
-            local[q] = tot;
-            tot += t_keep[tid * PER + q];
+            ocol[q] = 0; oval[q] = 0.f; keep[q] = 0;
+            if (d0 + q < L) {
+                const bool takeA = i < la && (j >= lb || A[i] <= B[j]);
+                if (takeA) {
+                    const int32_t col = A[i];
+                    float v = val[a0 + i];
+                    if (j < lb && B[j] == col) v = __fadd_rn(v, val[b0 + j]);      // its equal in B follows in the next slot
+                    ocol[q] = col; oval[q] = v; keep[q] = (v != 0.f);
+                    ++i;
+                } else {
+                    const int32_t col = B[j];
+                    const bool matched = i > 0 && A[i - 1] == col;
+                    const float v = val[b0 + j];
+                    ocol[q] = col; oval[q] = v; keep[q] = (!matched && v != 0.f);
+                    ++j;
+                }
+            }
+            tot += keep[q];
         }
         int x = tot;
         for (int off = 1; off < 64; off <<= 1) {
@@ -247,17 +244,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
         __syncthreads();
         int woff = 0;
         for (int t = 0; t < w; ++t) woff += wsum[t];
-        const int base = run_base + woff + x - tot;
+        int base = run_base + woff + x - tot;
+        const int first = base;
 #pragma unroll
         for (int q = 0; q < PER; ++q) {
-            const int p = tid * PER + q;
-            if (t_keep[p]) {
-                out_indices[o0 + base + local[q]] = t_col[p];
-                out_val[o0 + base + local[q]] = t_val[p];
+            if (keep[q]) {
+                out_indices[o0 + base] = ocol[q];
+                out_val[o0 + base] = oval[q];
+                ++base;
             }
         }
         __syncthreads();
-        if (tid == 255) run_base = base + tot;
+        if (tid == 255) run_base = first + tot;
         __syncthreads();
     }
     if (counts && tid == 0) counts[s] = run_base;
