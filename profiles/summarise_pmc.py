@@ -28,8 +28,12 @@ def short(name: str) -> str:
 # kernel name -> timing scope of bench.py (the scopes a launch of which runs several kernels list all of them; the first is
 # the one whose dispatches are counted as launches of the scope)
 SCOPES = {
-    "spmm_rows": ["ddx::k_spmm_lds<true"],
-    "spmm_cols": ["ddx::k_spmm_lds<false", "ddx::k_sum_panels"],
+    "spmm_rows": ["ddx::k_spmm_packed<true", "ddx::k_spmm_lds<true"],
+    "spmm_cols": ["ddx::k_spmm_packed<false", "ddx::k_spmm_lds<false"],
+    "spmm_sum": ["ddx::k_sum_panels"],
+    "bitplane_rows": ["ddx::k_bp_product<2, 5, 4, true", "ddx::k_bp_product<2, 4, 3, true"],
+    "bitplane_cols": ["ddx::k_bp_product<2, 5, 4, false", "ddx::k_bp_product<2, 4, 3, false"],
+    "residual_pack": ["ddx::k_pack_residual"],
     "knn_emit": ["ddx::k_knn_emit_bf", "ddx::k_knn_fold"],
     "knn_bound": ["ddx::k_knn_bound_bf"],
     "knn_select": ["ddx::k_knn_select", "ddx::k_knn_rescan"],
