@@ -2382,7 +2382,7 @@ int stage_pca_block_lanczos(ddx_ctx* ctx, int32_t C, int32_t oversample, double 
     std::vector<double> Z;                              // Ritz vectors of the last solve: n x n row-major, columns = vectors
     int n = 0;
     double t_prod = 0.0, t_orth = 0.0, t_ritz = 0.0;
-    int next_check = 8, prev_step = 0;
+    int next_check = 12, prev_step = 0;
     double prev_res = -1.0, last_res = -1.0;
     bool converged = false;
     auto now = [&]() { (void)hipStreamSynchronize(ctx->stream); return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -2451,10 +2451,14 @@ int stage_pca_block_lanczos(ddx_ctx* ctx, int32_t C, int32_t oversample, double 
         last_res = worst;
         if (worst <= tol) converged = true;
         if (worst <= tol || last) break;
-        if (prev_res > 0.0 && worst > 0.0 && worst < prev_res) {
-            const double rate = std::pow(worst / prev_res, 1.0 / (double)(j + 1 - prev_step));      // per step, < 1
-            const double need = std::log(tol / worst) / std::log(rate);
-            next_check = j + 1 + (int)std::min(8.0, std::max(2.0, std::ceil(need)));
+        // the next solve where the decay says the tolerance is met.  A solve costs as much as ~20 steps by now (n = 880: 31 ms on the
+        // host against 1.4 ms per step on the device, profiles/r05_block_lanczos.txt), and the decay accelerates (0.25 decades per step
+        // early, 0.5 late): rather a step too many than a solve too many -- 0.8 of the steps the observed rate asks for, a rate of 0.5
+        // per step assumed at the first check
+        if (worst > 0.0) {
+            const double rate = (prev_res > 0.0 && worst < prev_res) ? std::pow(worst / prev_res, 1.0 / (double)(j + 1 - prev_step)) : 0.5;      // per step, < 1
+            const double need = std::log(tol / worst) / std::log(std::min(rate, 0.9));
+            next_check = j + 1 + (int)std::min(12.0, std::max(2.0, std::ceil(0.8 * need)));
         } else {
             next_check = j + 1 + 4;
         }
