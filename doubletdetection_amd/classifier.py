@@ -603,18 +603,43 @@ class BoostClassifier:
             # Passed through the C-ABI (the pool is resized when the figure changes); the environment is not touched.
             _lib.set_upload_threads(max(4, min(48, (os.cpu_count() or 8) // (2 * world))) if world > 1 else 0)
         staged = getattr(self, "_staged", None)
+        drawer = ThreadPoolExecutor(max_workers=1)
+        draws = None
         if staged is not None and staged[0] is raw_counts:
             _, csr, leaders, restrict = staged                        # counts already resident in HBM
             t_fit0 = time.perf_counter()
         else:
             self._drop_stage()
-            csr, leaders, restrict = self._stage(raw_counts, rank, world)
+            # The host's random draws (ten parent draws without replacement: ~10 ms at the headline size) need nothing but the shape:
+            # they start NOW, behind the validation and the upload (ctypes drops the GIL), instead of behind the device prologue
+            # only -- the first iterations used to wait ~4 ms for them.  The reference draws nothing before check_array has passed
+            # (dd.py:149-155 precede dd.py:394), so a fit that fails while staging puts the generator back where it was.
+            shape = getattr(raw_counts, "shape", None)
+            if shape is not None and len(shape) == 2 and shape[0] >= 1 and shape[1] >= 1:
+                rng_state = self.rng.bit_generator.state
+                g_early = self.n_top_var_genes if 0 < self.n_top_var_genes < shape[1] else shape[1]
+                draws = drawer.submit(self._draw, int(shape[0]), int(g_early))
+            try:
+                csr, leaders, restrict = self._stage(raw_counts, rank, world)
+            except BaseException:
+                if draws is not None:
+                    try:
+                        draws.result()
+                    except Exception:
+                        pass
+                    self.rng.bit_generator.state = rng_state
+                drawer.shutdown(wait=True)
+                raise
         self._staged = None
         t_staged = time.perf_counter()
         num_cells = csr.shape[0]
         num_genes = self.n_top_var_genes if restrict else csr.shape[1]
-        drawer = ThreadPoolExecutor(max_workers=1)
-        draws = drawer.submit(self._draw, num_cells, num_genes)     # overlaps the device prologue
+        if draws is not None and (int(shape[0]), int(g_early)) != (num_cells, num_genes):      # (cannot happen: the staged matrix has the input's shape)
+            draws.result()
+            self.rng.bit_generator.state = rng_state
+            draws = None
+        if draws is None:
+            draws = drawer.submit(self._draw, num_cells, num_genes)     # overlaps the device prologue
         lanes = []
         ok = False
         try:

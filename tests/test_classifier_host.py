@@ -150,6 +150,23 @@ def test_second_fit_continues_the_rng_stream(monkeypatch):
     np.testing.assert_array_equal(second[0], g["parents"][1])
 
 
+def test_a_fit_that_fails_while_staging_leaves_the_rng_stream_untouched(monkeypatch):
+    """The parent draws start before the input has been validated (they overlap the upload); upstream draws nothing before
+    check_array has passed (dd.py:149-155 precede dd.py:394): after a rejected input the next fit draws what a fresh stream draws."""
+    g = load_golden("case_c_reftest_scaled")
+    monkeypatch.setattr(BoostClassifier, "_engine_factory", staticmethod(make_engine_factory(0)))
+    clf = BoostClassifier(n_iters=1, clustering_algorithm="louvain", standard_scaling=True)
+    counts = csr_from(g, "counts")
+    bad = counts.toarray().astype(np.float64)
+    bad[3, 4] = np.nan
+    with pytest.raises(ValueError):
+        clf.fit(bad)
+    clf.fit(counts)
+    np.testing.assert_array_equal(np.asarray(clf.parents_)[0], g["parents"][0])
+    clf.fit(counts)
+    np.testing.assert_array_equal(np.asarray(clf.parents_)[0], g["parents"][1])
+
+
 def test_reference_plot_functions_accept_the_classifier(monkeypatch):
     """doubletdetection.plot.convergence / threshold only read ``n_iters`` and
     ``all_log_p_values_`` (plot.py:65-66,123); run the reference's own plotting code on a fitted drop-in and
