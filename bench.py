@@ -261,7 +261,7 @@ def main():
         k = 30 if args.algorithm == "phenograph" else 10
         bp_stats = getattr(clf, "_last_bitplane", None)
         models, issued = kernel_models(N, G, H, S, nnz_aug, C, k, knn_window=getattr(clf, "_last_knn_window", 1.0), bitplane=bp_stats)
-        gpu_ms = {n: v[1] for n, v in timings.items()}
+        gpu_ms = {n: v[1] for n, v in timings.items() if v[0] > 0 and v[1] > 0}
         modelled = [n for n in gpu_ms if n in models]
         dominant = max(modelled, key=gpu_ms.get) if modelled else None      # the dominant kernel among those with a byte / flop model
         def roof(name, timings=timings):

@@ -1038,8 +1038,10 @@ class BoostClassifier:
                     cur_hi = max(cur_hi, hi)
             self._device_busy_ms = busy + (cur_hi - cur_lo)
         lead = lanes[0][1]
-        if mine and hasattr(lead, "aug_nnz"):
-            self._last_nnz_aug = lead.aug_nnz()     # stored entries of the last augmented matrix
+        if mine and hasattr(lead, "aug_nnz") and getattr(lead, "timing", False):
+            # stored entries of the last augmented matrix (a diagnostic for bench.py's byte models; asking makes the device write the
+            # merged rows of the last iteration's doublets, which the bit-plane route otherwise never does -- so only when profiling)
+            self._last_nnz_aug = lead.aug_nnz()
         if mine and hasattr(lead, "knn_window_fraction"):
             self._last_knn_window = lead.knn_window_fraction()   # share of the tile pairs the last kNN screened
             self._last_bitplane = lead.bitplane_stats() if hasattr(lead, "bitplane_stats") else None

@@ -91,6 +91,7 @@ void context_reset(ddx_ctx* ctx) {
     ctx->rowseg_rows = -1;
     ctx->pk_valid[0] = ctx->pk_valid[1] = false;
     ctx->mirror_full = false;
+    ctx->synth_rows = ctx->rows_x = true;
     ctx->bp = ddx::BitPlanes();
 }
 
@@ -161,6 +162,7 @@ bool Options::set(const char* key, const char* value) {
     if (k == "bitplane") { if (v == "auto") bitplane = 1; else if (!num(0, 2, &x)) return false; else bitplane = (int)x; return true; }
     if (k == "residual") { if (v == "packed") residual_packed = true; else if (v == "plain") residual_packed = false; else return false; return true; }
     if (k == "residual_rows_own") { if (!num(6, 12, &x) || (x != 6 && x != 12)) return false; residual_rows_own = (int)x; return true; }
+    if (k == "synthetic") { if (v == "derived") synthetic_derived = true; else if (v == "merged") synthetic_derived = false; else return false; return true; }
     if (k == "bp_digits") { if (!num(3, 4, &x)) return false; bp_digits = (int)x; return true; }
     if (k == "knn_fold") { knn_fold = on(); return true; }
     if (k == "knn_xcd_chunk") { if (!num(0, 4096, &x)) return false; knn_xcd_chunk = (int)x; return true; }
@@ -932,6 +934,7 @@ int ddx_get_synth_nnz(ddx_ctx* ctx, int64_t* nnz) {
     REQUIRE_CTX(ctx);
     USE_DEVICE(ctx);
     NEED(ctx->have_synth, "no synthetic doublets");
+    DDX_TRY(ensure_full_rows(ctx));
     int64_t last = 0;
     DDX_TRY(d2h(ctx, &last, ctx->aug_indptr.as<int64_t>() + ctx->M, sizeof(int64_t)));
     *nnz = last - ctx->nnz;
@@ -942,6 +945,7 @@ int ddx_get_synth(ddx_ctx* ctx, int64_t* indptr, int32_t* indices, float* data) 
     REQUIRE_CTX(ctx);
     USE_DEVICE(ctx);
     NEED(ctx->have_synth, "no synthetic doublets");
+    DDX_TRY(ensure_full_rows(ctx));
     DDX_TRY(d2h(ctx, indptr, ctx->aug_indptr.as<int64_t>() + ctx->N, sizeof(int64_t) * (ctx->S + 1)));
     int64_t base = ctx->nnz;
     int64_t n = indptr[ctx->S] - base;
@@ -973,6 +977,7 @@ int ddx_get_aug_nnz(ddx_ctx* ctx, int64_t* nnz) {
     REQUIRE_CTX(ctx);
     USE_DEVICE(ctx);
     NEED(ctx->have_synth, "no synthetic doublets");
+    DDX_TRY(ensure_full_rows(ctx));
     return d2h(ctx, nnz, ctx->aug_indptr.as<int64_t>() + ctx->M, sizeof(int64_t));
 }
 
@@ -980,6 +985,7 @@ int ddx_get_aug_values(ddx_ctx* ctx, float* values_out, float* zero_value_out) {
     REQUIRE_CTX(ctx);
     USE_DEVICE(ctx);
     NEED(ctx->have_lognorm, "ddx_lognormalise must run first");
+    DDX_TRY(ensure_full_rows(ctx));
     int64_t n = 0;
     DDX_TRY(d2h(ctx, &n, ctx->aug_indptr.as<int64_t>() + ctx->M, sizeof(int64_t)));
     if (values_out) DDX_TRY(d2h(ctx, values_out, ctx->aug_x.p, sizeof(float) * n));
@@ -991,6 +997,7 @@ int ddx_get_aug_dense_rows(ddx_ctx* ctx, int64_t row0, int64_t nrows, float* out
     REQUIRE_CTX(ctx);
     USE_DEVICE(ctx);
     NEED(ctx->have_lognorm, "ddx_lognormalise must run first");
+    DDX_TRY(ensure_full_rows(ctx));
     NEED(row0 >= 0 && nrows >= 0 && row0 + nrows <= ctx->M, "row range out of bounds");
     if (!nrows) return DDX_OK;
     return stage_dense_rows(ctx, row0, nrows, out);

@@ -56,6 +56,7 @@ struct Options {
     int upload_debug = 0;            // 1: timings of the upload on stderr, 2: per chunk
     bool residual_packed = true;     // bit-plane mode: the sparse products read this iteration's entries from wave-ordered packed blocks (k_spmm_packed) instead of the CSR / mirror (k_spmm_lds)
     int residual_rows_own = 12;      // outputs per lane group of the packed A Q kernel (12: one round of workgroups, each operand slice staged once per CU -- 0.157 ms per launch at the headline; 6: 0.177)
+    bool synthetic_derived = true;   // bit-plane route: a doublet's bitmap row and reduced entries from its parents' (k_bp_synth); false: from the merged row
     int fault = 0;                   // fault injection (tests): 1 = allow_dynamic_lds fails
     bool hvg_fold = true;            // gene sums folded in while the packed matrix arrives (off: one pass after the upload)
     bool set(const char* key, const char* value);
@@ -97,9 +98,10 @@ struct BitPlanes {
     size_t buf_bytes = 0;            // bytes of ctx->bp_buf in use (what a follower context copies)
     void* bm_rows = nullptr;         // [(row tile * SKc + sk) * 64 + r * 2 + h] 16-byte words
     void* bm_cols = nullptr;         // [(column tile * SKr + skr) * 64 + c * 2 + h]
-    int64_t* rest_indptr = nullptr;  // reduced CSR of ALL rows: [M + 1]; cols / value; rest_pos: position of an original row's entry in the full arrays
-    int32_t* rest_cols = nullptr;
-    int32_t* rest_pos = nullptr;
+    int64_t* rest_indptr = nullptr;  // reduced CSR of ALL rows: [M + 1]; cols / value; rest_raw, rest_row: count and row of an ORIGINAL row's entry
+    int32_t* rest_cols = nullptr;    // (the values of those follow from them and the iteration's table; the synthetic rows' are derived from
+    int32_t* rest_row = nullptr;     //  their parents' bitmaps and reduced rows: k_bp_synth)
+    float* rest_raw = nullptr;
     float* rest_x = nullptr;
     int64_t* restm_colptr = nullptr; // reduced column-major mirror of the original rows: [P_o * H + 1], rows / counts / value
     int32_t* restm_row = nullptr;
@@ -233,6 +235,9 @@ struct ddx_ctx {
     ddx::DevBuf pk_ptr[2], pk_blocks[2];   // packed residual products (k_pca.hip: k_pack_residual): [A Q, A^T Y] block tables and blocks of this iteration
     bool pk_valid[2] = {false, false};
     int64_t pk_nblocks[2] = {0, 0};
+    bool synth_rows = true;          // rows N..M of the row-major arrays hold the current doublets (the bit-plane route derives its structures from
+                                     // the parents' and leaves them out: ensure_full_rows builds them when somebody asks)
+    bool rows_x = true;              // aug_x holds this iteration's values (same)
     bool mirror_full = false;        // csc_s_* and csc_*_x hold this iteration's full mirror (the bit-plane route leaves it out: ensure_full_mirror)
     ddx::BitPlanes bp;
     const int32_t* knn_overflow = nullptr;   // device counter: queries whose candidate list overflowed (exact rescan)
@@ -327,6 +332,30 @@ struct ScopedTimer {
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+
+// ---- log-normalisation of one stored entry (shared by k_sparse.hip and k_bitplane.hip) -------------------------
+// the reference's element transform, evaluated in the reference's rounding order:
+//   normed = float32( v / (double)rowsum )      sklearn inplace_csr_row_normalize_l1 (rowsum==0: unchanged)
+//   scaled = normed * median                     float32 multiply                    (dd.py:293)
+//   x      = log(scaled + pc)  |  log1p(scaled)  float32 result                      (dd.py:295 / :297)
+// The log itself is evaluated in float64 and rounded once, i.e. the correctly rounded float32 value.
+__device__ __forceinline__ float lognorm_value(float v, double rowsum, float med, float pc, bool use_log1p) {
+#pragma clang fp contract(off)
+    const float normed = (rowsum == 0.0) ? v : (float)((double)v / rowsum);
+    const float scaled = normed * med;          // plain operators: the pragma above forbids fusing
+    if (use_log1p) return (float)log1p((double)scaled);
+    const float shifted = scaled + pc;
+    return (float)log((double)shifted);
+}
+
+constexpr int kLognormTab = 16;     // counts 1..16 of every row are evaluated once per iteration (lognorm_tab)
+
+__device__ __forceinline__ int small_count(float v, int kmax) {       // 1..kmax for such an integer count, else 0
+    const int iv = (int)v;
+    return (v == (float)iv && iv >= 1 && iv <= kmax) ? iv : 0;
+}
+
+
 // ---- stage entry points implemented in the .hip files ------------------------------------------
 int stage_upload_counts(ddx_ctx* ctx, int64_t N, int32_t H, const int64_t* indptr, const int32_t* indices,
                         const float* data, bool from_device);
@@ -359,6 +388,10 @@ int stage_select_columns(ddx_ctx* ctx, const int64_t* cols, int32_t n_cols);
 // bit-plane products (k_bitplane.hip)
 int bp_build(ddx_ctx* ctx);
 int ensure_full_mirror(ddx_ctx* ctx);
+int ensure_full_rows(ddx_ctx* ctx);           // rows N..M of the row-major arrays and aug_x, when the lean iteration left them out
+int bp_synth_libs(ddx_ctx* ctx);
+int scan_counts(ddx_ctx* ctx, const int32_t* in, int64_t n, int64_t base, int64_t* out);   // out[i] = base + sum of in[0..i), i = 0..n
+bool bp_lean(const ddx_ctx* ctx);              // this context's iterations derive the synthetic rows' structures from the parents'
 int bp_reduced_mirrors(ddx_ctx* ctx);
 int bp_colmean(ddx_ctx* ctx, const double* parts, int nparts);
 int bp_clone(ddx_ctx* ctx, const ddx_ctx* src);

@@ -140,9 +140,159 @@ __global__ void k_bp_pointers(const int64_t* __restrict__ ptr, int64_t nptr, int
     out[i] = base + scan[ptr[i] - e0];
 }
 
-__global__ void k_bp_gather(const float* __restrict__ x, const int32_t* __restrict__ pos, int64_t n, float* __restrict__ out) {
+// row of every entry of a reduced CSR (once per fit: the original rows' reduced values are evaluated entry by entry)
+__global__ void __launch_bounds__(256) k_bp_rows_of(const int64_t* __restrict__ indptr, int64_t nrows, int32_t* __restrict__ row_out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= nrows) return;
+    const int64_t e = indptr[r + 1];
+    for (int64_t p = indptr[r] + lane; p < e; p += 64) row_out[p] = (int32_t)r;
+}
+
+// this iteration's value of an entry from its count and row: the (row, count) table, the full evaluation for the rare others
+__device__ __forceinline__ float bp_value(float c, int64_t row, const float* __restrict__ tab, const double* __restrict__ lib64, float med, float pc, int use_log1p) {
+    const int k = small_count(c, kLognormTab);
+    return k ? tab[row * kLognormTab + (k - 1)] : lognorm_value(c, lib64[row], med, pc, use_log1p != 0);
+}
+
+__global__ void k_bp_values(const float* __restrict__ raw, const int32_t* __restrict__ rows, int64_t n, const float* __restrict__ tab, const double* __restrict__ lib64,
+                            const float* __restrict__ med, float pc, int use_log1p, float* __restrict__ x) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = x[pos[i]];
+    if (i < n) x[i] = bp_value(raw[i], rows[i], tab, lib64, med[0], pc, use_log1p);
+}
+
+// ---- synthetic rows straight from their parents' structures ---------------------------------------------------------------
+// A doublet's counts are the sums of its parents' (dd.py:406-410; scipy drops exact zeros), and the parents are rows whose
+// structures exist for the whole fit: the bitmap B (count == 1) and the reduced row R (other stored counts; counts here are
+// non-negative integers -- ddx_ctx::counts_exact --, so an entry of R is an explicit zero or >= 2).  With NZ = B | [R != 0]:
+//     bitmap of the doublet     (B0 & ~NZ1) | (B1 & ~NZ0)                      one parent has a 1, the other nothing
+//     its reduced columns       (NZ0 & NZ1) | ([R0 != 0] & ~NZ1) | ([R1 != 0] & ~NZ0)
+// so the merged row (k_doublet_fill, on ~900 entries per parent) never has to exist: one wave per doublet reads 2 x 1.25 KB of
+// bitmap and 2 x ~90 reduced entries.  Pass 1 (FILL = false) writes the bitmap row and counts the reduced entries; after the
+// scan of the counts pass 2 writes them -- column and this iteration's VALUE, slots in column order by popcount ranks, the same
+// order the merge gives.  LDS per wave: five arrays of W = 8 * SK words (the two bitmaps, the two [R != 0] masks, the ranks).
+__device__ __forceinline__ int64_t bp_word_of(int64_t pr, int d, int SK) {          // 32-bit word d of padded row pr in the row bitmap
+    return (((pr >> 5) * SK + (d >> 3)) * 64 + (pr & 31) * 2 + ((d & 7) >> 2)) * 4 + (d & 3);
+}
+
+__device__ __forceinline__ float bp_lookup(const int32_t* __restrict__ cols, const float* __restrict__ raw, int n, int32_t j) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (cols[mid] < j) lo = mid + 1; else hi = mid;
+    }
+    return (lo < n && cols[lo] == j) ? raw[lo] : 0.f;
+}
+
+template <bool FILL>
+__global__ void __launch_bounds__(256) k_bp_synth(uint32_t* bm, int SK, int64_t Npad, int64_t N, int64_t S, int64_t nrows_pad, const int64_t* __restrict__ parents,
+                                                  const int64_t* __restrict__ rip, const int32_t* rcols, const float* __restrict__ rraw, int32_t* __restrict__ cnt,
+                                                  const float* __restrict__ tab, const double* __restrict__ lib64, const float* __restrict__ med, float pc, int use_log1p,
+                                                  int32_t* cols_out, float* __restrict__ x_out) {
+    extern __shared__ __align__(16) uint32_t bp_syn[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int W = SK * 8;
+    const int64_t s = (int64_t)blockIdx.x * 4 + wave;
+    if (s >= nrows_pad) return;
+    const int64_t pr_out = Npad + s;
+    if (s >= S) {                                                     // padding rows of the last tiles: no bits
+        if (!FILL) for (int d = lane; d < W; d += 64) bm[bp_word_of(pr_out, d, SK)] = 0u;
+        return;
+    }
+    uint32_t* b0 = bp_syn + (size_t)wave * 5 * W;
+    uint32_t* b1 = b0 + W;
+    uint32_t* r0 = b1 + W;
+    uint32_t* r1 = r0 + W;
+    uint32_t* pre = r1 + W;
+    const int64_t p0 = parents[2 * s], p1 = parents[2 * s + 1];
+    for (int d = lane; d < W; d += 64) {
+        b0[d] = bm[bp_word_of(p0, d, SK)];
+        b1[d] = bm[bp_word_of(p1, d, SK)];
+        r0[d] = 0u;
+        r1[d] = 0u;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int64_t ra0 = rip[p0], ra1 = rip[p1];
+    const int rn0 = (int)(rip[p0 + 1] - ra0), rn1 = (int)(rip[p1 + 1] - ra1);
+    for (int e = lane; e < rn0; e += 64)
+        if (rraw[ra0 + e] != 0.f) { const int32_t c = rcols[ra0 + e]; atomicOr(&r0[c >> 5], 1u << (c & 31)); }
+    for (int e = lane; e < rn1; e += 64)
+        if (rraw[ra1 + e] != 0.f) { const int32_t c = rcols[ra1 + e]; atomicOr(&r1[c >> 5], 1u << (c & 31)); }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    auto reduced_word = [&](int d) {
+        const uint32_t nz0 = b0[d] | r0[d], nz1 = b1[d] | r1[d];
+        return (nz0 & nz1) | (r0[d] & ~nz1) | (r1[d] & ~nz0);
+    };
+    int carry = 0;
+    for (int k0 = 0; k0 < W; k0 += 64) {
+        const int d = k0 + lane;
+        uint32_t res = 0u;
+        if (d < W) {
+            res = reduced_word(d);
+            if (!FILL) {
+                const uint32_t nz0 = b0[d] | r0[d], nz1 = b1[d] | r1[d];
+                bm[bp_word_of(pr_out, d, SK)] = (b0[d] & ~nz1) | (b1[d] & ~nz0);
+            }
+        }
+        const int c = __popc(res);
+        int x = c;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int y = __shfl_up(x, off, 64);
+            if (lane >= off) x += y;
+        }
+        if (FILL && d < W) pre[d] = (uint32_t)(carry + x - c);
+        carry += __shfl(x, 63, 64);
+    }
+    if (!FILL) {
+        if (lane == 0) cnt[s] = carry;
+        return;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int64_t row = N + s;
+    const int64_t base = rip[row];
+    const float m = med[0];
+    auto emit = [&](int32_t j, float c) {
+        const int d = j >> 5;
+        const int slot = (int)pre[d] + __popc(reduced_word(d) & ((1u << (j & 31)) - 1u));
+        cols_out[base + slot] = j;
+        x_out[base + slot] = bp_value(c, row, tab, lib64, m, pc, use_log1p);
+    };
+    for (int e = lane; e < rn0; e += 64) {                            // parent 0's counts >= 2 (+ whatever parent 1 holds there)
+        const float c = rraw[ra0 + e];
+        if (c == 0.f) continue;
+        const int32_t j = rcols[ra0 + e];
+        const uint32_t bit = 1u << (j & 31);
+        const float c1 = (b1[j >> 5] & bit) ? 1.f : ((r1[j >> 5] & bit) ? bp_lookup(rcols + ra1, rraw + ra1, rn1, j) : 0.f);
+        emit(j, __fadd_rn(c, c1));
+    }
+    for (int e = lane; e < rn1; e += 64) {                            // parent 1's counts >= 2 where parent 0 holds 1 or nothing
+        const float c = rraw[ra1 + e];
+        if (c == 0.f) continue;
+        const int32_t j = rcols[ra1 + e];
+        const uint32_t bit = 1u << (j & 31);
+        if (r0[j >> 5] & bit) continue;
+        emit(j, __fadd_rn((b0[j >> 5] & bit) ? 1.f : 0.f, c));
+    }
+    for (int d = lane; d < W; d += 64) {                              // 1 + 1
+        uint32_t ov = b0[d] & b1[d];
+        while (ov) {
+            const int b = __ffs(ov) - 1;
+            ov &= ov - 1u;
+            emit(d * 32 + b, 2.f);
+        }
+    }
+}
+
+// library sizes of the doublets from their parents' (exact: integers below 2^23, see k_counts_exact)
+__global__ void k_bp_synth_libs(const int64_t* __restrict__ parents, int64_t N, int64_t S, float* __restrict__ lib32, double* __restrict__ lib64) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    const float v = __fadd_rn(lib32[parents[2 * s]], lib32[parents[2 * s + 1]]);
+    lib32[N + s] = v;
+    lib64[N + s] = (double)v;
 }
 
 // s_i = x_i(1) - z, the float32 difference the sparse path forms for such an entry (exactly what the float64 difference rounds to)
@@ -395,10 +545,11 @@ static int bp_col_chunks(const BitPlanes& bp, int64_t SK, int* per_out);
 struct BpProductArgs;
 template <int RT, int NT, int ND, bool ROWS> static int bp_launch_t(ddx_ctx* ctx, const BpProductArgs& a, int chunks);
 
-static int bp_launch_bitmaps(ddx_ctx* ctx, int64_t tile0, int64_t ntiles) {
+static int bp_launch_bitmaps(ddx_ctx* ctx, int64_t tile0, int64_t ntiles, bool rows_too = true) {
     BitPlanes& bp = ctx->bp;
     if (ntiles <= 0) return DDX_OK;
     const int sk_chunk = std::min(bp.SKc, 48);                    // 32 rows x 48 stages x 32 bytes = 48 KB of LDS
+    if (rows_too)
     k_bp_rows_bitmap<<<(unsigned)ntiles, 256, (size_t)32 * sk_chunk * 32, ctx->stream>>>(ctx->aug_indptr.as<int64_t>(), ctx->aug_indices.as<int32_t>(),
                                                                                         ctx->aug_raw.as<float>(), tile0, bp.Npad, ctx->N, ctx->M, bp.SKc, sk_chunk, reinterpret_cast<v4i*>(bp.bm_rows));
     const int64_t nblk_r = ntiles / 2 + (ntiles & 1);             // 64-row blocks (tile0 is even: Npad is a multiple of 256)
@@ -462,7 +613,7 @@ int bp_build(ddx_ctx* ctx) {
     const size_t o_bmr = carve(sizeof(v4i) * (size_t)ntile_all * bp.SKc * 64), o_bmc = carve(sizeof(v4i) * (size_t)bp.ntile_c * SKr_cap * 64);
     const int64_t cap_rest = total_r + bp.cap_rest_s;
     const size_t o_rip = carve(sizeof(int64_t) * (size_t)(N + Scap + 2)), o_rc = carve(sizeof(int32_t) * (size_t)cap_rest + 256), o_rx = carve(sizeof(float) * (size_t)cap_rest + 256);
-    const size_t o_rp = carve(sizeof(int32_t) * (size_t)total_r + 256);
+    const size_t o_rp = carve(sizeof(int32_t) * (size_t)total_r + 256), o_rr = carve(sizeof(float) * (size_t)total_r + 256);
     const size_t o_mcp = carve(sizeof(int64_t) * (size_t)(nseg + 1)), o_mr = carve(sizeof(int32_t) * (size_t)total_r + 256), o_mp = carve(sizeof(float) * (size_t)total_r + 256);
     const size_t o_mx = carve(sizeof(float) * (size_t)total_r + 256), o_s = carve(sizeof(double) * (size_t)(N + Scap + 2));
     DDX_TRY(ensure(ctx, ctx->bp_buf, off));
@@ -473,7 +624,8 @@ int bp_build(ddx_ctx* ctx) {
     bp.rest_indptr = reinterpret_cast<int64_t*>(b + o_rip);
     bp.rest_cols = reinterpret_cast<int32_t*>(b + o_rc);
     bp.rest_x = reinterpret_cast<float*>(b + o_rx);
-    bp.rest_pos = reinterpret_cast<int32_t*>(b + o_rp);
+    bp.rest_row = reinterpret_cast<int32_t*>(b + o_rp);
+    bp.rest_raw = reinterpret_cast<float*>(b + o_rr);
     bp.restm_colptr = reinterpret_cast<int64_t*>(b + o_mcp);
     bp.restm_row = reinterpret_cast<int32_t*>(b + o_mr);
     bp.restm_raw = reinterpret_cast<float*>(b + o_mp);
@@ -487,8 +639,9 @@ int bp_build(ddx_ctx* ctx) {
     const unsigned ge = (unsigned)ceil_div(nnz + 1, 256);
     int32_t* flag = ctx->sort_keys_in.as<int32_t>();
     // row-major (the scan of pass 1 is still in place)
-    k_bp_compact<<<ge, 256, 0, ctx->stream>>>(flag, scan, ctx->aug_indices.as<int32_t>(), nullptr, nnz, bp.rest_cols, bp.rest_pos, nullptr);
+    k_bp_compact<<<ge, 256, 0, ctx->stream>>>(flag, scan, ctx->aug_indices.as<int32_t>(), ctx->aug_raw.as<float>(), nnz, bp.rest_cols, nullptr, bp.rest_raw);
     k_bp_pointers<<<(unsigned)ceil_div(N + 1, 256), 256, 0, ctx->stream>>>(ctx->aug_indptr.as<int64_t>(), N + 1, 0, scan, 0, bp.rest_indptr);
+    k_bp_rows_of<<<(unsigned)ceil_div(N, 4), 256, 0, ctx->stream>>>(bp.rest_indptr, N, bp.rest_row);
     // column-major mirror (same entries in (panel, column, row) order)
     DDX_TRY(bp_reduce(ctx, ctx->csc_o_raw.as<float>(), ctx->csc_o_row.as<int32_t>(), ctx->csc_o_raw.as<float>(), nnz, bp.restm_row, nullptr, bp.restm_raw, total_r, &total_m, false, &scan));
     DDX_HIP(ctx, hipMemcpyAsync(&total_m, scan + nnz, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -509,6 +662,12 @@ int bp_build(ddx_ctx* ctx) {
     return DDX_OK;
 }
 
+int bp_synth_libs(ddx_ctx* ctx) {
+    ScopedTimer t(ctx, "row_sums");
+    k_bp_synth_libs<<<(unsigned)ceil_div(ctx->S, 256), 256, 0, ctx->stream>>>(ctx->parents.as<int64_t>(), ctx->N, ctx->S, ctx->lib32.as<float>(), ctx->lib64.as<double>());
+    return DDX_OK;
+}
+
 // The per-fit structures of another context of the same GPU, device to device (a follower of the fit: building them again
 // would cost every context the passes over all stored entries).
 int bp_clone(ddx_ctx* ctx, const ddx_ctx* src) {
@@ -519,7 +678,7 @@ int bp_clone(ddx_ctx* ctx, const ddx_ctx* src) {
     BitPlanes bp = src->bp;
     const ptrdiff_t delta = ctx->bp_buf.as<char>() - src->bp_buf.as<char>();
     auto move = [&](auto*& p) { if (p) p = reinterpret_cast<std::remove_reference_t<decltype(p)>>(reinterpret_cast<char*>(p) + delta); };
-    move(bp.bm_rows); move(bp.bm_cols); move(bp.rest_indptr); move(bp.rest_cols); move(bp.rest_pos); move(bp.rest_x);
+    move(bp.bm_rows); move(bp.bm_cols); move(bp.rest_indptr); move(bp.rest_cols); move(bp.rest_row); move(bp.rest_raw); move(bp.rest_x);
     move(bp.restm_colptr); move(bp.restm_row); move(bp.restm_raw); move(bp.restm_x); move(bp.srow);
     bp.restm_s_colptr = nullptr; bp.restm_s_row = nullptr; bp.restm_s_x = nullptr;          // (views into the source's per-iteration buffers)
     bp.qd = nullptr; bp.cmax = nullptr; bp.part = nullptr; bp.ymax_of = nullptr;
@@ -556,10 +715,37 @@ static int bp_refresh_once(ddx_ctx* ctx) {
     ctx->pk_valid[0] = ctx->pk_valid[1] = false;             // the packed blocks of the sparse products describe the last iteration's matrix
     {
         ScopedTimer t(ctx, "bitplane_values");
+        const int use_log1p = (ctx->pseudocount == 1.0f);
         if (bp.nrest_o > 0)
-            k_bp_gather<<<(unsigned)ceil_div(bp.nrest_o, 256), 256, 0, ctx->stream>>>(ctx->aug_x.as<float>(), bp.rest_pos, bp.nrest_o, bp.rest_x);
+            k_bp_values<<<(unsigned)ceil_div(bp.nrest_o, 256), 256, 0, ctx->stream>>>(bp.rest_raw, bp.rest_row, bp.nrest_o, ctx->lognorm_tab.as<float>(), ctx->lib64.as<double>(),
+                                                                                     ctx->median.as<float>(), ctx->pseudocount, use_log1p, bp.rest_x);
         k_bp_row_scale<<<(unsigned)ceil_div(M, 256), 256, 0, ctx->stream>>>(ctx->lognorm_tab.as<float>(), 16, ctx->zvalue, M, bp.srow);
-        if (S > 0) {
+        if (S > 0 && !ctx->synth_rows) {
+            // the doublets' bitmap rows and reduced CSR straight from their parents' (k_bp_synth): count, scan, fill
+            const int64_t nrows_pad = bp.ntile_s * 32;
+            const size_t lds = sizeof(uint32_t) * 4 * 5 * (size_t)bp.SKc * 8;
+            DDX_TRY(allow_dynamic_lds(ctx, reinterpret_cast<const void*>(&k_bp_synth<false>), (int)lds));
+            DDX_TRY(allow_dynamic_lds(ctx, reinterpret_cast<const void*>(&k_bp_synth<true>), (int)lds));
+            const unsigned g = (unsigned)ceil_div(nrows_pad, 4);
+            int32_t* cnt = ctx->synth_counts.as<int32_t>();
+            k_bp_synth<false><<<g, 256, lds, ctx->stream>>>(reinterpret_cast<uint32_t*>(bp.bm_rows), bp.SKc, bp.Npad, N, S, nrows_pad, ctx->parents.as<int64_t>(), bp.rest_indptr,
+                                                            bp.rest_cols, bp.rest_raw, cnt, nullptr, nullptr, nullptr, 0.f, 0, nullptr, nullptr);
+            DDX_TRY(scan_counts(ctx, cnt, S, bp.nrest_o, bp.rest_indptr + N));
+            int64_t last = 0;
+            DDX_HIP(ctx, hipMemcpyAsync(&last, bp.rest_indptr + M, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+            DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            const int64_t kept = last - bp.nrest_o;
+            if (kept > bp.cap_rest_s) {
+                bp.want_rest_s = kept + kept / 2;
+                bp.ready = false;
+                return kBpRetry;
+            }
+            bp.nrest_s = kept;
+            k_bp_synth<true><<<g, 256, lds, ctx->stream>>>(reinterpret_cast<uint32_t*>(bp.bm_rows), bp.SKc, bp.Npad, N, S, nrows_pad, ctx->parents.as<int64_t>(), bp.rest_indptr,
+                                                           bp.rest_cols, bp.rest_raw, nullptr, ctx->lognorm_tab.as<float>(), ctx->lib64.as<double>(), ctx->median.as<float>(),
+                                                           ctx->pseudocount, use_log1p, bp.rest_cols, bp.rest_x);
+            DDX_TRY(bp_launch_bitmaps(ctx, bp.ntile_o, bp.ntile_s, false));       // (the transpose only)
+        } else if (S > 0) {
             // synthetic rows: reduced CSR behind the original rows' (one array, one row pointer over all M rows)
             const int64_t e0 = ctx->nnz;
             const int64_t n_s = ctx->nnz_aug - e0;                     // (read back by ddx_lognormalise)

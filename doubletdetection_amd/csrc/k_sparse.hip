@@ -149,6 +149,11 @@ __global__ void __launch_bounds__(1024) k_scan_counts(const int32_t* __restrict_
     if (tid == 0) out[n] = carry;
 }
 
+int scan_counts(ddx_ctx* ctx, const int32_t* in, int64_t n, int64_t base, int64_t* out) {
+    k_scan_counts<<<1, 1024, 0, ctx->stream>>>(in, n, base, out);
+    return DDX_OK;
+}
+
 constexpr int kMergeTile = 2048;
 constexpr int kMergeStage = 3840;     // column entries of both parents staged in LDS (15 KB: four workgroups per CU)
 
@@ -922,6 +927,35 @@ int stage_clone_counts(ddx_ctx* ctx, const ddx_ctx* src) {
 // ------------------------------------------------------------------------------------------------
 // stage: create doublets
 // ------------------------------------------------------------------------------------------------
+static int lognorm_rows(ddx_ctx* ctx);
+
+// one merge per doublet: rows are written at padded offsets into the (not yet rebuilt) mirror buffers, counted on the way,
+// scanned into the row pointer and moved to their final positions
+static int materialise_synthetic(ddx_ctx* ctx) {
+    const int64_t N = ctx->N, S = ctx->S;
+    if (S) {
+        DDX_TRY(ensure(ctx, ctx->pad_off, sizeof(int64_t) * (S + 1)));
+        DDX_HIP(ctx, hipMemcpyAsync(ctx->pad_off.p, ctx->h_pad_off.data(), sizeof(int64_t) * (S + 1), hipMemcpyHostToDevice, ctx->stream));
+        {
+            ScopedTimer t(ctx, "doublet_fill");
+            k_doublet_fill<<<(unsigned)S, 256, 0, ctx->stream>>>(ctx->aug_indptr.as<int64_t>(), ctx->aug_indices.as<int32_t>(),
+                                                                 ctx->aug_raw.as<float>(), ctx->parents.as<int64_t>(), ctx->pad_off.as<int64_t>(),
+                                                                 ctx->csc_s_row.as<int32_t>(), ctx->csc_s_raw.as<float>(), ctx->synth_counts.as<int32_t>());
+        }
+        k_scan_counts<<<1, 1024, 0, ctx->stream>>>(ctx->synth_counts.as<int32_t>(), S, ctx->nnz, ctx->aug_indptr.as<int64_t>() + N);
+        {
+            ScopedTimer t(ctx, "doublet_compact");
+            k_doublet_compact<<<(unsigned)ceil_div(S, 4), 256, 0, ctx->stream>>>(ctx->pad_off.as<int64_t>(), ctx->csc_s_row.as<int32_t>(), ctx->csc_s_raw.as<float>(),
+                                                                                 ctx->aug_indptr.as<int64_t>() + N, S, ctx->aug_indices.as<int32_t>(),
+                                                                                 ctx->aug_raw.as<float>());
+        }
+        DDX_HIP(ctx, hipGetLastError());
+        ctx->mirror_full = false;             // (the fill used the synthetic mirror's buffers as its scratch)
+    }
+    ctx->synth_rows = true;
+    return DDX_OK;
+}
+
 int stage_create_doublets(ddx_ctx* ctx, int64_t S, const int64_t* parents) {
     const int64_t N = ctx->N;
     // capacity from the host copy of the row pointer: |row p0| + |row p1| bounds each synthetic row; the running sum
@@ -955,28 +989,29 @@ int stage_create_doublets(ddx_ctx* ctx, int64_t S, const int64_t* parents) {
     ctx->have_lognorm = ctx->scaled = ctx->have_emb = ctx->have_knn = false;
     ctx->mirror_full = false;
     ctx->bp.values = false;
-    if (S) {
-        DDX_HIP(ctx, hipMemcpyAsync(ctx->parents.p, parents, sizeof(int64_t) * 2 * S, hipMemcpyHostToDevice, ctx->stream));
-        // one merge per doublet: rows are written at padded offsets into the (not yet rebuilt) mirror buffers, counted
-        // on the way, scanned into the row pointer and moved to their final positions
-        DDX_TRY(ensure(ctx, ctx->pad_off, sizeof(int64_t) * (S + 1)));
-        DDX_HIP(ctx, hipMemcpyAsync(ctx->pad_off.p, ctx->h_pad_off.data(), sizeof(int64_t) * (S + 1), hipMemcpyHostToDevice, ctx->stream));
-        {
-            ScopedTimer t(ctx, "doublet_fill");
-            k_doublet_fill<<<(unsigned)S, 256, 0, ctx->stream>>>(ctx->aug_indptr.as<int64_t>(), ctx->aug_indices.as<int32_t>(),
-                                                                 ctx->aug_raw.as<float>(), ctx->parents.as<int64_t>(), ctx->pad_off.as<int64_t>(),
-                                                                 ctx->csc_s_row.as<int32_t>(), ctx->csc_s_raw.as<float>(), ctx->synth_counts.as<int32_t>());
-        }
-        k_scan_counts<<<1, 1024, 0, ctx->stream>>>(ctx->synth_counts.as<int32_t>(), S, ctx->nnz, ctx->aug_indptr.as<int64_t>() + N);
-        {
-            ScopedTimer t(ctx, "doublet_compact");
-            k_doublet_compact<<<(unsigned)ceil_div(S, 4), 256, 0, ctx->stream>>>(ctx->pad_off.as<int64_t>(), ctx->csc_s_row.as<int32_t>(), ctx->csc_s_raw.as<float>(),
-                                                                                 ctx->aug_indptr.as<int64_t>() + N, S, ctx->aug_indices.as<int32_t>(),
-                                                                                 ctx->aug_raw.as<float>());
-        }
-        DDX_HIP(ctx, hipGetLastError());
-    }
+    ctx->synth_rows = ctx->rows_x = false;
+    if (S) DDX_HIP(ctx, hipMemcpyAsync(ctx->parents.p, parents, sizeof(int64_t) * 2 * S, hipMemcpyHostToDevice, ctx->stream));
     ctx->have_synth = true;
+    // The bit-plane route derives everything it needs of a doublet from its parents' structures (k_bp_synth): the merged rows
+    // are then only written when somebody asks for them (ensure_full_rows)
+    if (bp_lean(ctx)) return DDX_OK;
+    return materialise_synthetic(ctx);
+}
+
+bool bp_lean(const ddx_ctx* ctx) {
+    return ctx->opt.synthetic_derived && bp_wanted_at_upload(ctx) && ctx->bp.ready && ctx->counts_exact && ctx->S > 0 && ctx->S <= ctx->N / 2 &&
+           ctx->bp.SKc * 8 * 20 * sizeof(uint32_t) <= 128 * 1024;
+}
+
+// rows N..M of the row-major arrays for the current doublets, and this iteration's values of all rows
+int ensure_full_rows(ddx_ctx* ctx) {
+    if (!ctx->have_synth) return DDX_OK;
+    if (!ctx->synth_rows) {
+        DDX_TRY(materialise_synthetic(ctx));
+        DDX_HIP(ctx, hipMemcpyAsync(&ctx->nnz_aug, ctx->aug_indptr.as<int64_t>() + ctx->M, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+        DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    if (!ctx->rows_x && ctx->have_lognorm) DDX_TRY(lognorm_rows(ctx));
     return DDX_OK;
 }
 
@@ -992,25 +1027,10 @@ __global__ void k_median_from_sorted(const float* __restrict__ sorted, int64_t M
     }
 }
 
-// the reference's element transform, evaluated in the reference's rounding order:
-//   normed = float32( v / (double)rowsum )      sklearn inplace_csr_row_normalize_l1 (rowsum==0: unchanged)
-//   scaled = normed * median                     float32 multiply                    (dd.py:293)
-//   x      = log(scaled + pc)  |  log1p(scaled)  float32 result                      (dd.py:295 / :297)
-// The log itself is evaluated in float64 and rounded once, i.e. the correctly rounded float32 value.
-__device__ __forceinline__ float lognorm_value(float v, double rowsum, float med, float pc, bool use_log1p) {
-#pragma clang fp contract(off)
-    const float normed = (rowsum == 0.0) ? v : (float)((double)v / rowsum);
-    const float scaled = normed * med;          // plain operators: the pragma above forbids fusing
-    if (use_log1p) return (float)log1p((double)scaled);
-    const float shifted = scaled + pc;
-    return (float)log((double)shifted);
-}
-
 // Most stored entries are small integer counts, and lognorm_value is a function of (count, row): in the row-major pass
 // the values of the counts 1..16 are evaluated once per row and every entry with such a count takes its value from
 // there -- the same function of the same arguments, hence the same bits.  Anything else (larger or fractional counts, explicit zeros) is queued per wave and evaluated 64
 // at a time, so that the ~150 float64 instructions of a division and a logarithm are spent on full waves only.
-constexpr int kLognormTab = 16;
 
 __global__ void k_lognorm_table(const double* __restrict__ lib64, const float* __restrict__ med, float pc, int use_log1p, int64_t M,
                                 float* __restrict__ tab) {
@@ -1019,11 +1039,6 @@ __global__ void k_lognorm_table(const double* __restrict__ lib64, const float* _
     const int64_t row = t / kLognormTab;
     const int c = (int)(t - row * kLognormTab) + 1;
     tab[t] = lognorm_value((float)c, lib64[row], med[0], pc, use_log1p != 0);
-}
-
-__device__ __forceinline__ int small_count(float v, int kmax) {       // 1..kmax for such an integer count, else 0
-    const int iv = (int)v;
-    return (v == (float)iv && iv >= 1 && iv <= kmax) ? iv : 0;
 }
 
 // per-wave queue of entries that need the full evaluation
@@ -1259,6 +1274,7 @@ static int lognorm_mirror(ddx_ctx* ctx, const int32_t* rows, const float* raw, c
 int ensure_full_mirror(ddx_ctx* ctx) {
     if (ctx->mirror_full) return DDX_OK;
     if (!ctx->have_lognorm) return set_err(ctx, DDX_E_ARG, "the column-major mirror needs ddx_lognormalise first");
+    DDX_TRY(ensure_full_rows(ctx));
     const int64_t N = ctx->N, M = ctx->M;
     const MirrorSrc full{ctx->aug_indptr.as<int64_t>(), ctx->aug_indices.as<int32_t>(), ctx->aug_raw.as<float>()};
     DDX_TRY(build_csc(ctx, full, ctx->nnz, ctx->nnz_aug - ctx->nnz, N, M, ctx->p_s0, ctx->P_s > 0 ? ctx->P_s : 1, ctx->csc_s_colptr, ctx->csc_s_row, ctx->csc_s_raw));
@@ -1299,22 +1315,39 @@ int bp_colmean(ddx_ctx* ctx, const double* parts, int nparts) {
     return col_sums_of(ctx, bp.restm_colptr, bp.restm_x, bp.restm_s_colptr, bp.restm_s_x, 0, ctx->colmean.as<double>(), parts, nparts);
 }
 
+// values of every stored entry of the row-major arrays (needs the iteration's table, median and library sizes)
+static int lognorm_rows(ddx_ctx* ctx) {
+    const int rows_per_wave = 8;          // the queue of rare entries fills over several rows
+    k_lognorm_rows<<<(unsigned)ceil_div(ctx->M, 4 * rows_per_wave), 256, 0, ctx->stream>>>(ctx->aug_indptr.as<int64_t>(), ctx->aug_raw.as<float>(), ctx->lib64.as<double>(),
+                                                                                          ctx->median.as<float>(), ctx->lognorm_tab.as<float>(), ctx->pseudocount,
+                                                                                          ctx->pseudocount == 1.0f, ctx->M, rows_per_wave, ctx->aug_x.as<float>());
+    ctx->rows_x = true;
+    return DDX_OK;
+}
+
 int stage_lognormalise(ddx_ctx* ctx, float pseudocount) {
     const int64_t N = ctx->N, S = ctx->S, M = ctx->M;
     const int32_t H = ctx->H;
-    // exact number of synthetic entries (one 8-byte read-back per iteration; sizes the sorts)
-    int64_t nnz_aug = 0;
-    DDX_HIP(ctx, hipMemcpyAsync(&nnz_aug, ctx->aug_indptr.as<int64_t>() + M, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
-    DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->nnz_aug = nnz_aug;
-    if (S) {
-        ScopedTimer t(ctx, "row_sums");
-        if (ctx->counts_exact)
-            k_row_sums_exact<<<(unsigned)ceil_div(S, 4), 256, 0, ctx->stream>>>(ctx->aug_indptr.as<int64_t>(), ctx->aug_raw.as<float>(), N, S,
-                                                                      ctx->lib32.as<float>(), ctx->lib64.as<double>());
-        else
-            k_row_sums<<<(unsigned)ceil_div(S, 4), 256, 0, ctx->stream>>>(ctx->aug_indptr.as<int64_t>(), ctx->aug_raw.as<float>(), N, S,
-                                                                      ctx->lib32.as<float>(), ctx->lib64.as<double>());
+    const bool lean = bp_wanted_at_upload(ctx) && ctx->bp.ready && S <= N / 2;       // the bit-plane route is expected to serve this matrix
+    const bool derived = lean && !ctx->synth_rows && bp_lean(ctx);                   // ... and the doublets exist as parents only
+    if (derived) {
+        DDX_TRY(bp_synth_libs(ctx));          // lib[p0] + lib[p1]: exact, the counts being small integers
+    } else {
+        if (!ctx->synth_rows) DDX_TRY(materialise_synthetic(ctx));
+        // exact number of synthetic entries (one 8-byte read-back per iteration; sizes the sorts)
+        int64_t nnz_aug = 0;
+        DDX_HIP(ctx, hipMemcpyAsync(&nnz_aug, ctx->aug_indptr.as<int64_t>() + M, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+        DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->nnz_aug = nnz_aug;
+        if (S) {
+            ScopedTimer t(ctx, "row_sums");
+            if (ctx->counts_exact)
+                k_row_sums_exact<<<(unsigned)ceil_div(S, 4), 256, 0, ctx->stream>>>(ctx->aug_indptr.as<int64_t>(), ctx->aug_raw.as<float>(), N, S,
+                                                                                    ctx->lib32.as<float>(), ctx->lib64.as<double>());
+            else
+                k_row_sums<<<(unsigned)ceil_div(S, 4), 256, 0, ctx->stream>>>(ctx->aug_indptr.as<int64_t>(), ctx->aug_raw.as<float>(), N, S,
+                                                                              ctx->lib32.as<float>(), ctx->lib64.as<double>());
+        }
     }
     // median of the augmented library sizes
     DDX_TRY(ensure(ctx, ctx->lib_sorted, sizeof(float) * M));
@@ -1331,15 +1364,13 @@ int stage_lognormalise(ddx_ctx* ctx, float pseudocount) {
     ctx->P_s = S ? (int32_t)((M - 1) / ctx->panel_rows) - ctx->p_s0 + 1 : 0;
     const int use_log1p = (pseudocount == 1.0f);
     DDX_TRY(ensure(ctx, ctx->lognorm_tab, sizeof(float) * (size_t)M * kLognormTab));
-    float* tab_rows = ctx->lognorm_tab.as<float>();
+    ctx->pseudocount = pseudocount;
     {
         ScopedTimer t(ctx, "lognorm_rows");
         k_lognorm_table<<<(unsigned)ceil_div(M * kLognormTab, 256), 256, 0, ctx->stream>>>(ctx->lib64.as<double>(), ctx->median.as<float>(), pseudocount,
-                                                                                          use_log1p, M, tab_rows);
-        const int rows_per_wave = 8;          // the queue of rare entries fills over several rows
-        k_lognorm_rows<<<(unsigned)ceil_div(M, 4 * rows_per_wave), 256, 0, ctx->stream>>>(ctx->aug_indptr.as<int64_t>(), ctx->aug_raw.as<float>(),
-                                                                          ctx->lib64.as<double>(), ctx->median.as<float>(), tab_rows,
-                                                                          pseudocount, use_log1p, M, rows_per_wave, ctx->aug_x.as<float>());
+                                                                                          use_log1p, M, ctx->lognorm_tab.as<float>());
+        ctx->rows_x = false;
+        if (!derived) DDX_TRY(lognorm_rows(ctx));       // (derived: the bit-plane structures take their values from the table; aug_x on demand)
     }
     DDX_TRY(ensure(ctx, ctx->zcol, sizeof(float) * H));
     DDX_TRY(ensure(ctx, ctx->colmean, sizeof(double) * H));
@@ -1352,7 +1383,7 @@ int stage_lognormalise(ddx_ctx* ctx, float pseudocount) {
     ctx->have_lognorm = true;
     ctx->scaled = false;
     ctx->have_emb = ctx->have_knn = false;
-    if (bp_wanted_at_upload(ctx) && ctx->bp.ready && S <= N / 2) {
+    if (lean) {
         // the bit-plane route is expected to serve this matrix: its structures (a tenth of the entries in sparse form) are all the
         // products need, and they also give the column means -- the full mirror is only built if somebody asks (ensure_full_mirror)
         DDX_TRY(bp_refresh(ctx));

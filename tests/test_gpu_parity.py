@@ -788,6 +788,69 @@ def test_bitplane_route_corner_shapes(monkeypatch):
             np.testing.assert_allclose(got, A.T @ x, rtol=1e-6, atol=1e-6)
 
 
+def test_doublets_derived_from_their_parents_structures():
+    """Bit-plane route: a doublet's bitmap row, reduced entries and library size are derived from its parents' structures (k_bp_synth)
+    instead of from the merged row (option synthetic=merged: k_doublet_fill + flags / scan / compaction).  Both constructions must give
+    the SAME structures, hence bit-identical PCA scores -- on counts with explicit stored zeros, counts beyond the (row, count) table,
+    overlaps of every kind (1 + 1, 1 + c, c + c') and a doublet of a cell with itself; and whoever asks for the merged rows, their values
+    or dense rows afterwards gets exactly the oracle's (built on demand: ensure_full_rows)."""
+    from doubletdetection_amd import _lib
+    from doubletdetection_amd._synthetic import make_counts
+
+    rng = np.random.default_rng(17)
+    counts = make_counts(3000, 1100, density=0.12, n_types=5, seed=4).tocsr().astype(np.float32)
+    counts.data[rng.random(counts.nnz) < 0.02] = 0.0                       # explicit zeros stay stored
+    big = rng.random(counts.nnz) < 0.01
+    counts.data[big] = rng.integers(17, 400, size=int(big.sum())).astype(np.float32)
+    N, H = counts.shape
+    S = 900
+    parents = rng.choice(N, size=(S, 2), replace=True)
+    parents[0] = (5, 5)
+    parents[1] = (parents[2][1], parents[2][0])
+    results = {}
+    for how in ("derived", "merged"):
+        with _lib.Context(0) as c:
+            c.set_option("bitplane", "2")
+            c.set_option("synthetic", how)
+            c.timing_enable(True)
+            c.upload_counts(counts)
+            for it in range(2):                                              # (a second iteration on the same context: other parents)
+                par = parents if it == 0 else parents[::-1].copy()
+                c.create_doublets(par)
+                c.lognormalise(0.1)
+                c.pca(30, orc.pca_start_matrix(0, H, 40))
+                stats = c.bitplane_stats()
+                assert stats["active"]
+                emb, sing = c.embedding_f64()
+                results[(how, it)] = (emb.copy(), sing.copy(), stats["rest_synthetic"], c.aug_lib())
+            # the derived construction never wrote a merged row; the first read-back below makes it do so (once)
+            assert c.timings().get("doublet_fill", (0, 0.0))[0] == (0 if how == "derived" else 2)
+            # read-backs after the lean iteration: the merged rows, this iteration's values, dense rows
+            syn = c.get_synth()
+            assert c.timings()["doublet_fill"][0] == (1 if how == "derived" else 2)
+            want = orc.create_doublets(counts, parents[::-1])
+            want.sort_indices()
+            np.testing.assert_array_equal(syn.indptr, want.indptr)
+            np.testing.assert_array_equal(syn.indices, want.indices)
+            np.testing.assert_array_equal(syn.data, want.data)
+            assert c.aug_nnz() == counts.nnz + want.nnz
+            dense = c.aug_dense_rows(N, S)
+            ref, ref_lib, ref_med = orc.lognormalise(orc.l1_normalise_rows(counts), orc.library_sizes(counts), want, 0.1)
+            assert _ulp_diff(dense, np.asarray(ref)[N:]).max() <= 4                             # (numpy's float32 log: see test_lognormalised_matrix)
+            lib, med = c.aug_lib()
+            np.testing.assert_array_equal(lib, ref_lib.astype(np.float32))
+            assert med == np.float32(ref_med)
+            results[(how, "dense")] = dense
+    np.testing.assert_array_equal(results[("derived", "dense")], results[("merged", "dense")])
+    for it in range(2):
+        d, m = results[("derived", it)], results[("merged", it)]
+        assert d[2] == m[2] and d[2] > 0
+        np.testing.assert_array_equal(d[3][0], m[3][0])
+        assert d[3][1] == m[3][1]
+        np.testing.assert_array_equal(d[1], m[1])
+        np.testing.assert_array_equal(d[0], m[0])
+
+
 def test_a_failing_stage_inside_the_pca_surfaces_as_an_error():
     """Error path (fault injection, option fault=1: every request for a larger dynamic-LDS limit is refused): the first operator
     product of ddx_pca cannot be launched -- the call must return the HIP error, not DDX_OK on an untouched iterate."""
