@@ -230,6 +230,7 @@ def main():
     exclusive = None
     timings = {}
     instr_elapsed, busy_ms = 0.0, 0.0
+    diag = None                                  # an instrumented fit: it also reads the diagnostics the production path leaves on the device
     if world == 1 and args.resident_steps > 0:
         resident_elapsed = sum(one_fit(resident=True)[1] for _ in range(args.resident_steps))
     if args.instrumented_steps > 0:          # (every rank: a fit ends with the ranks' collective)
@@ -239,6 +240,7 @@ def main():
         one_fit()
         for _ in range(args.instrumented_steps):
             c2, dt = one_fit()
+            diag = c2
             instr_elapsed += dt
             busy_ms += c2._device_busy_ms or 0.0
             for name, (launches, ms) in c2._device_timings.items():
@@ -255,7 +257,7 @@ def main():
     if rank == 0:
         H = clf._num_genes
         S = int(clf.boost_rate * N)
-        nnz_aug = getattr(clf, "_last_nnz_aug", None) or int(X.nnz * 1.0)
+        nnz_aug = getattr(diag, "_last_nnz_aug", None) or getattr(clf, "_last_nnz_aug", None) or int(X.nnz * 1.0)
         C = clf.n_components
         L_ = C + 10
         k = 30 if args.algorithm == "phenograph" else 10
@@ -275,7 +277,8 @@ def main():
             if name in ("spmm_rows", "spmm_cols"):
                 # the products are bound on chip: every stored entry reads one operand row (ld floats) from LDS -- how far the
                 # launch is from THAT bound (the HBM fraction above says how far it is from the bound it could have)
-                lds_gb = nnz_aug * (((L_ + 3) // 4) * 4) * 4 / 1e9
+                ent = nnz_aug if not (bp_stats and bp_stats.get("active")) else bp_stats["rest_original"] + bp_stats["rest_synthetic"]
+                lds_gb = ent * (((L_ + 3) // 4) * 4) * 4 / 1e9
                 out["lds_bound"] = {"bytes_per_launch_GB": round(lds_gb, 3), "peak_GBs": LDS_PEAK_GBS, "achieved_GBs": round(lds_gb / avg_s, 1),
                                     "frac": round(lds_gb / avg_s / LDS_PEAK_GBS, 4),
                                     "floor_ms": round(lds_gb / LDS_PEAK_GBS * 1e3, 3)}
@@ -320,6 +323,24 @@ def main():
                                                                   "preparation": round(prep, 4)},
                     "one_pass_bytes_GB": round(full_gb, 4), "achieved_GBs": round(full_gb / (ms / 1e3), 1) if ms else None,
                     "frac_of_hbm_peak": round(full_gb / (ms / 1e3) / HBM_PEAK_GBS, 4) if ms else None}
+        roofline_single = roofline
+        if product and bp_stats and bp_stats.get("active"):
+            # The dominant unit of work is one operator product, which this round is several launches: the bitmap product on the matrix
+            # cores, the packed sparse kernel on the other entries, the partial sums and the operand preparation.  It is priced as a
+            # whole against ONE pass over all stored entries (SURVEY section 8 d: 8 bytes per stored entry + the dense operand and
+            # result), the slower side quoted; the kernels one by one follow in roofline_top_kernels.
+            side = max(product, key=lambda k: product[k]["ms_per_product"])
+            pr = product[side]
+            names = ["bitplane_cols", "spmm_cols", "spmm_sum", "bitplane_prep"] if side == "A^T Y" else ["bitplane_rows", "spmm_rows", "bitplane_prep"]
+            traffic = [PMC_TRAFFIC_GB.get(n) for n in names if n != "bitplane_prep"]
+            roofline = {"bound": "hbm", "kernel": f"operator product {side} = " + " + ".join(names), "achieved": pr["achieved_GBs"], "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": pr["frac_of_hbm_peak"],
+                        "traffic": round(sum(traffic), 4) if all(t is not None for t in traffic) else None,
+                        "traffic_source": PMC_TRAFFIC_SOURCE, "avg_launch_ms": pr["ms_per_product"],
+                        "launches": src_t["spmm_cols" if side == "A^T Y" else "spmm_rows"][0], "work_per_launch": pr["one_pass_bytes_GB"],
+                        "parts_ms": pr["kernels_ms"], "measured": roofline_source,
+                        "note": "achieved = bytes of one pass over all stored entries / the time of all launches of one product; the largest "
+                                "single kernel is in roofline_dominant_kernel"}
         out = {
             "metric": "cells/sec for full BoostClassifier.fit() (default n_iters)",
             "value": round(N * args.steps / elapsed, 2),
@@ -346,6 +367,7 @@ def main():
                                    "(streams) per GPU",
                        "host_threads": os.cpu_count()},
             "roofline": roofline,
+            "roofline_dominant_kernel": roofline_single,
             "roofline_top_kernels": roofline_all,
             "operator_product": product,
             "bitplane": bp_stats,

@@ -91,6 +91,7 @@ void context_reset(ddx_ctx* ctx) {
     ctx->rowseg_rows = -1;
     ctx->pk_valid[0] = ctx->pk_valid[1] = false;
     ctx->mirror_full = false;
+    ctx->mirror_o = false;
     ctx->synth_rows = ctx->rows_x = true;
     ctx->bp = ddx::BitPlanes();
 }
@@ -256,6 +257,7 @@ int timing_flush(ddx_ctx* ctx) {
         ctx->t_free.push_back(ev.start);
         ctx->t_free.push_back(ev.stop);
     }
+    (void)hipGetLastError();                    // (a scope whose stop was never recorded must not surface as the next call's error)
     ctx->t_pending.clear();
     return DDX_OK;
 }

@@ -238,6 +238,7 @@ struct ddx_ctx {
     bool synth_rows = true;          // rows N..M of the row-major arrays hold the current doublets (the bit-plane route derives its structures from
                                      // the parents' and leaves them out: ensure_full_rows builds them when somebody asks)
     bool rows_x = true;              // aug_x holds this iteration's values (same)
+    bool mirror_o = false;           // csc_o_colptr / _row / _raw hold the original rows' full mirror (bit-plane route: built when somebody asks)
     bool mirror_full = false;        // csc_s_* and csc_*_x hold this iteration's full mirror (the bit-plane route leaves it out: ensure_full_mirror)
     ddx::BitPlanes bp;
     const int32_t* knn_overflow = nullptr;   // device counter: queries whose candidate list overflowed (exact rescan)
@@ -393,6 +394,7 @@ int bp_synth_libs(ddx_ctx* ctx);
 int scan_counts(ddx_ctx* ctx, const int32_t* in, int64_t n, int64_t base, int64_t* out);   // out[i] = base + sum of in[0..i), i = 0..n
 bool bp_lean(const ddx_ctx* ctx);              // this context's iterations derive the synthetic rows' structures from the parents'
 int bp_reduced_mirrors(ddx_ctx* ctx);
+int bp_originals_mirror(ddx_ctx* ctx);
 int bp_colmean(ddx_ctx* ctx, const double* parts, int nparts);
 int bp_clone(ddx_ctx* ctx, const ddx_ctx* src);
 bool bp_wanted_at_upload(const ddx_ctx* ctx);

@@ -148,7 +148,7 @@ constexpr int kBoundWaves = 8; // waves per workgroup of the bound pass: they sh
 constexpr int kEmitRT = 2;    // query tiles per wave in the emit pass
 constexpr int kEmitWaves = 4;  // waves per workgroup of the emit pass (they share the staged candidate tiles)
 constexpr int kEmitSegSteps = 4;    // steps (of 8 or 4 tiles) of a block's list that one workgroup screens
-constexpr int kEmitLog = 64;       // hits a wave logs in LDS before it files them (one lane per entry)
+constexpr int kEmitLog = 128;      // records a wave logs in LDS before it files them (a tile adds up to 64: filed when fewer are free)
 
 // ---- bfloat16-split MFMA screen ----------------------------------------------------------------------------
 // q.c ~= qh.ch + qh.cl + ql.ch with three v_mfma_f32_16x16x32_bf16.  Dropped
@@ -373,7 +373,7 @@ k_knn_emit_bf(const __bf16* __restrict__ Eb, const __bf16* __restrict__ Ebq, con
     constexpr int tile_vecs = CP * 4;
     __shared__ f4 lds_c[2][G * tile_vecs];
     __shared__ f4 lds_h[2][G * 16];     // accumulator start values -0.5*(1-slack)*|c|^2, one MFMA C quad per candidate (k_knn_prepare)
-    __shared__ unsigned long long hlog[kEmitBW][kEmitLog][2];  // hits of this wave: (ballot mask, tile | v << 32), decoded 64 at a time
+    __shared__ unsigned long long hlog[kEmitBW][kEmitLog];     // hits of this wave, one record per LANE with a hit: tile | lane << 24 | (its accumulator slots that passed) << 32
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // work item = (query block, segment of its list): workgroup id = blk * nseg + seg.  nseg is a multiple of 8, so the same
@@ -389,25 +389,29 @@ k_knn_emit_bf(const __bf16* __restrict__ Eb, const __bf16* __restrict__ Ebq, con
     QueryTilesBf<CP, RT> qt;
     qt.load(FOLD ? Ebq : Eb, q0, lane);          // FOLD: the query operands carry -hr in components 30 / 31 (k_knn_fold)
     const int rbase = 4 * (lane >> 4), jcol = lane & 15;
-    // Hits are rare (about five candidates per wave and step) and the code that files one runs for the whole wave: the pass
-    // only LOGS a hit -- the ballot mask of one accumulator slot of one tile, 16 bytes written by one lane -- and decodes the log
-    // 64 entries at a time, a lane per entry: query and candidate from the bit positions, one atomic per candidate for its
-    // slot in the query's list (several work items append to one list: its order depends on the run, the select pass sorts it).
+    // Most tiles leave a hit or two somewhere in the wave (~70 survivors per query), so what runs per tile WITH a hit is the hot
+    // path: a lane with a hit writes ONE 8-byte record -- the tile, its lane number, the bits of its accumulator slots that passed --
+    // at a slot from the ballot's prefix count; no per-slot ballots, no scalar branching per slot (rounds 3-4: ~60 instructions per
+    // tile with a hit).  The log is decoded a lane per record when fewer than 64 records are free: query and candidate from the lane
+    // number and bit positions, the query itself dropped there, one atomic per candidate for its slot in the query's list (several
+    // work items append to one list: its order depends on the run, the select pass sorts it).
     int nlog = 0;                                   // wave-uniform
     auto flush_log = [&]() {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (lane < nlog) {
-            unsigned long long m = hlog[wave][lane][0];
-            const unsigned long long tv = hlog[wave][lane][1];
-            const int32_t tile = (int32_t)(tv & 0xffffffffull);
-            const int v = (int)(tv >> 32);
-            while (m) {
-                const int b = __builtin_ctzll(m);
-                m &= m - 1ull;
-                const int64_t q = q0 + (v >> 2) * 16 + 4 * (b >> 4) + (v & 3);
+        for (int i = lane; i < nlog; i += 64) {
+            const unsigned long long rec = hlog[wave][i];
+            const int32_t tile = (int32_t)(rec & 0xffffffull);
+            const int ln = (int)((rec >> 24) & 63ull);
+            unsigned mk = (unsigned)(rec >> 32);
+            const int32_t cand = tile * 16 + (ln & 15);
+            while (mk) {
+                const int v = __builtin_ctz(mk);
+                mk &= mk - 1u;
+                const int64_t q = q0 + (v >> 2) * 16 + 4 * (ln >> 4) + (v & 3);
+                if (!include_self && q == cand) continue;              // a point is not its own neighbour
                 const int slot = atomicAdd(&ccount[q], 1);
-                if (slot < cap) cbuf[q * cap + slot] = tile * 16 + (b & 15);
+                if (slot < cap) cbuf[q * cap + slot] = cand;
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -426,7 +430,6 @@ k_knn_emit_bf(const __bf16* __restrict__ Eb, const __bf16* __restrict__ Ebq, con
         if (FOLD) hr[v] = 0.f;                               // the threshold travels inside the dot product
     }
     const int32_t* lst = elist + blk * ecap + (int64_t)s_lo * G;
-    const int32_t own_tile = (int32_t)(q0 >> 4);
     const f4* srcE = reinterpret_cast<const f4*>(Eb);
     const float* srcH = reinterpret_cast<const float*>(start4);
     // (p: packed entries, lane j < G holds entry j of the step; e: their tile numbers)
@@ -445,42 +448,34 @@ k_knn_emit_bf(const __bf16* __restrict__ Eb, const __bf16* __restrict__ Ebq, con
         const f4* tb = lds_c[buf];
         const f4* th = lds_h[buf];
         static_assert(CP % 32 == 0, "");
-        // one compare per pair; the wave-wide masks live in scalar registers
         auto judge = [&](const f4 (&acc)[RT], const int32_t tile) {
-            unsigned long long any = 0, hm[NV];
+            unsigned mk = 0;
+            unsigned long long any;
             if (FOLD) {
                 // one compare per tile: the largest of the wave's accumulators against zero (v_max3 tree)
                 float m = acc[0].x;
 #pragma unroll
                 for (int v = 1; v < NV; ++v) m = fmaxf(m, acc[v >> 2][v & 3]);
                 any = __ballot(m > 0.f);
-                if (any) {
+                if (any == 0ull) return;
+                // the slots that passed, from the sign bits (two instructions per slot; +0 counts as passed: the select pass evaluates
+                // every candidate exactly, one more is harmless)
+                unsigned neg = 0;
 #pragma unroll
-                    for (int v = 0; v < NV; ++v) hm[v] = __ballot(acc[v >> 2][v & 3] > 0.f);
-                }
+                for (int v = 0; v < NV; ++v) neg |= (__float_as_uint(acc[v >> 2][v & 3]) >> 31) << v;
+                mk = m > 0.f ? (~neg & ((1u << NV) - 1u)) : 0u;
             } else {
 #pragma unroll
-                for (int v = 0; v < NV; ++v) {
-                    hm[v] = __ballot(acc[v >> 2][v & 3] > hr[v]);
-                    any |= hm[v];
-                }
+                for (int v = 0; v < NV; ++v) mk |= (acc[v >> 2][v & 3] > hr[v] ? 1u : 0u) << v;
+                any = __ballot(mk != 0u);
+                if (any == 0ull) return;
             }
-            if (any) {
-                const int32_t cand = tile * 16 + jcol;
-                const bool own = !include_self && (tile >= own_tile && tile < own_tile + RT);
-#pragma unroll
-                for (int v = 0; v < NV; ++v) {
-                    unsigned long long m = hm[v];
-                    if (m == 0ull) continue;                     // wave-uniform: usually at most one of the masks is set
-                    if (own) m &= ~__ballot((q0 + (v >> 2) * 16 + rbase + (v & 3)) == cand);     // a point is not its own neighbour
-                    if (m == 0ull) continue;
-                    if (lane == 0) {
-                        hlog[wave][nlog][0] = m;
-                        hlog[wave][nlog][1] = (unsigned long long)(uint32_t)tile | ((unsigned long long)v << 32);
-                    }
-                    if (++nlog == kEmitLog) flush_log();
-                }
+            if (mk != 0u) {
+                const int slot = nlog + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(any >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)any, 0u));
+                hlog[wave][slot] = (unsigned long long)((uint32_t)tile | (uint32_t)lane << 24) | ((unsigned long long)mk << 32);
             }
+            nlog += __popcll(any);
+            if (nlog > kEmitLog - 64) flush_log();
         };
         auto tile_of = [&](int t) { return (int32_t)__builtin_amdgcn_readlane(e0, t); };
         if (CP == 32) {
@@ -1322,12 +1317,12 @@ __global__ void __launch_bounds__(64 * BW) k_knn_tilelists(const float* __restri
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t blk = blockIdx.x;
     const int64_t s0 = (blk * BW + wave) * kEmitRT;                  // first query tile of the wave
-    static_assert(kEmitRT == 2, "two query tiles per wave");
-    // reach of the two query tiles: lanes 0-15 tile s0, lanes 16-31 tile s0 + 1
-    float rs[2];
+    static_assert(16 * kEmitRT <= 64, "a lane per query of the wave");
+    // reach of the wave's query tiles: lanes 16 u .. 16 u + 15 hold tile s0 + u
+    float rs[kEmitRT];
     {
         float r = -__builtin_huge_valf();
-        if (lane < 32) {
+        if (lane < 16 * kEmitRT) {
             const int64_t q = s0 * 16 + lane;
             if (nrm[q] < __builtin_huge_valf()) {
                 const float T = thr[q];
@@ -1336,13 +1331,13 @@ __global__ void __launch_bounds__(64 * BW) k_knn_tilelists(const float* __restri
         }
 #pragma unroll
         for (int o = 1; o < 16; o <<= 1) r = fmaxf(r, __shfl_xor(r, o, 64));
-        rs[0] = __shfl(r, 0, 64);
-        rs[1] = __shfl(r, 16, 64);
-    }
-    int A[2];
-    float q1lo[2], q1hi[2];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < kEmitRT; ++u) rs[u] = __shfl(r, 16 * u, 64);
+    }
+    int A[kEmitRT];
+    float q1lo[kEmitRT], q1hi[kEmitRT];
+#pragma unroll
+    for (int u = 0; u < kEmitRT; ++u) {
         A[u] = tilecell[s0 + u];
         q1lo[u] = tp1lo[s0 + u];
         q1hi[u] = tp1hi[s0 + u];
@@ -1359,7 +1354,7 @@ __global__ void __launch_bounds__(64 * BW) k_knn_tilelists(const float* __restri
                 const int B = tilecell[t];
                 const float c1l = tp1lo[t], c1h = tp1hi[t];
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
+                for (int u = 0; u < kEmitRT; ++u) {
                     const float a = St_lo[(size_t)A[u] * ntiles + t], b = St_hi[(size_t)A[u] * ntiles + t];
                     const float ql = S_lo[(s0 + u) * Kc + B], qh = S_hi[(s0 + u) * Kc + B];
                     const float gap = fmaxf(fmaxf(-b - qh, ql + a), fmaxf(c1l - q1hi[u], q1lo[u] - c1h));

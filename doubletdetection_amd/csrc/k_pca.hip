@@ -1659,6 +1659,7 @@ static int apply_rows_wide(PcaWork& w, const double* Qcol, double* Yrow);
 static int apply_cols_wide(PcaWork& w, const double* Yrow, double* Wcol);
 
 static int apply_rows(PcaWork& w, const double* Qcol, double* Yrow) {  // A Q : [H x L] -> [M x L]
+    if (!w.bitplane) DDX_TRY(ensure_full_rows(w.ctx));     // (the bit-plane route leaves the doublets' rows and the row-major values out)
     if (w.L > kMaxL) return apply_rows_wide(w, Qcol, Yrow);
     ddx_ctx* c = w.ctx;
     double* tvec = w.small + 3 * w.L * w.L;

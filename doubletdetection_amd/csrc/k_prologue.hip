@@ -300,6 +300,71 @@ __global__ void __launch_bounds__(1024) k_scan_rows(const int32_t* __restrict__ 
     if (tid == 0) out[n] = carry;
 }
 
+// The same compaction with the kept entries written in the order of their NEW column numbers (the selected genes are numbered by
+// variance rank, dd.py:283, so a row's kept entries change order): a wave marks the row's new columns in a bitmap of H bits in
+// LDS, prefix-sums the words' popcounts, and an entry's slot is the number of marked columns below its own -- no sort of the
+// compacted rows afterwards (rounds 1-4: a segmented radix sort of all kept entries, 1.1 ms at the headline).  W = ceil(H / 32).
+__global__ void __launch_bounds__(256) k_compact_ranked(const int64_t* __restrict__ indptr, const int32_t* __restrict__ cols,
+                                                        const float* __restrict__ vals, const int32_t* __restrict__ newid,
+                                                        int64_t N, int W, const int64_t* __restrict__ out_ptr,
+                                                        int32_t* __restrict__ out_cols, float* __restrict__ out_vals) {
+    extern __shared__ uint32_t ck_lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+    if (row >= N) return;
+    uint32_t* bm = ck_lds + (size_t)wave * 2 * W;
+    uint32_t* pre = bm + W;
+    for (int d = lane; d < W; d += 64) bm[d] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int64_t b = indptr[row], e = indptr[row + 1];
+    for (int64_t p = b + lane; p < e; p += 256) {
+        int32_t j[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) j[u] = p + 64 * u < e ? cols[p + 64 * u] : -1;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) j[u] = j[u] >= 0 ? newid[j[u]] : -1;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (j[u] >= 0) atomicOr(&bm[j[u] >> 5], 1u << (j[u] & 31));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    int carry = 0;
+    for (int k0 = 0; k0 < W; k0 += 64) {
+        const int d = k0 + lane;
+        const int c = d < W ? __popc(bm[d]) : 0;
+        int x = c;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int y = __shfl_up(x, off, 64);
+            if (lane >= off) x += y;
+        }
+        if (d < W) pre[d] = (uint32_t)(carry + x - c);
+        carry += __shfl(x, 63, 64);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int64_t o = out_ptr[row];
+    for (int64_t p = b + lane; p < e; p += 256) {
+        int32_t j[4];
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            j[u] = p + 64 * u < e ? cols[p + 64 * u] : -1;
+            v[u] = p + 64 * u < e ? vals[p + 64 * u] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) j[u] = j[u] >= 0 ? newid[j[u]] : -1;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (j[u] >= 0) {
+                const int slot = (int)pre[j[u] >> 5] + __popc(bm[j[u] >> 5] & ((1u << (j[u] & 31)) - 1u));
+                out_cols[o + slot] = j[u];
+                out_vals[o + slot] = v[u];
+            }
+    }
+}
+
 int stage_select_columns(ddx_ctx* ctx, const int64_t* cols, int32_t H) {
     const int64_t N = ctx->rawN;
     const int32_t G = ctx->rawG;
@@ -335,9 +400,19 @@ int stage_select_columns(ddx_ctx* ctx, const int64_t* cols, int32_t H) {
     PR_TRY(ensure(ctx, ctx->aug_raw, sizeof(float) * (size_t)(kept + cap_s)));
     PR_TRY(ensure(ctx, ctx->aug_x, sizeof(float) * (size_t)(kept + cap_s)));
     ctx->cap_synth = cap_s;
-    PR_TRY(ensure(ctx, tk, sizeof(int32_t) * (size_t)(kept + 1)));
-    PR_TRY(ensure(ctx, tv, sizeof(float) * (size_t)(kept + 1)));
-    if (kept > 0) {
+    const int W = (H + 31) / 32;
+    const size_t ranked_lds = sizeof(uint32_t) * 4 * 2 * (size_t)W;
+    if (kept > 0 && ranked_lds <= 64 * 1024) {
+        // compaction straight into new-column order
+        PR_TRY(allow_dynamic_lds(ctx, reinterpret_cast<const void*>(&k_compact_ranked), (int)ranked_lds));
+        ScopedTimer t(ctx, "hvg_select");
+        k_compact_ranked<<<(unsigned)ceil_div(N, 4), 256, ranked_lds, ctx->stream>>>(ctx->raw_indptr.as<int64_t>(), ctx->raw_indices.as<int32_t>(),
+                                                                                    ctx->raw_data.as<float>(), newid.as<int32_t>(), N, W,
+                                                                                    ctx->aug_indptr.as<int64_t>(), ctx->aug_indices.as<int32_t>(), ctx->aug_raw.as<float>());
+    } else if (kept > 0) {
+        // (more selected columns than a wave's bitmap holds: order-preserving compaction, then a segmented sort of the rows)
+        PR_TRY(ensure(ctx, tk, sizeof(int32_t) * (size_t)(kept + 1)));
+        PR_TRY(ensure(ctx, tv, sizeof(float) * (size_t)(kept + 1)));
         int end_bit = 1;
         while ((1 << end_bit) < H) ++end_bit;
         size_t tmp_bytes = 0;

@@ -810,6 +810,31 @@ static int ensure_keep(ddx_ctx* ctx, DevBuf& b, size_t bytes, size_t keep_bytes)
 // ------------------------------------------------------------------------------------------------
 // stage: upload counts
 // ------------------------------------------------------------------------------------------------
+// the (panel, column)-ordered mirror of the original rows (counts as the payload; the values follow per iteration)
+static int originals_mirror(ddx_ctx* ctx) {
+    if (ctx->mirror_o) return DDX_OK;
+    const int64_t nnz = ctx->nnz;
+    DDX_TRY(ensure(ctx, ctx->csc_o_row, sizeof(int32_t) * (size_t)(nnz + 1)));
+    DDX_TRY(ensure(ctx, ctx->csc_o_raw, sizeof(float) * (size_t)(nnz + 1)));
+    DDX_TRY(ensure(ctx, ctx->csc_o_x, sizeof(float) * (size_t)(nnz + 1)));
+    const MirrorSrc full{ctx->aug_indptr.as<int64_t>(), ctx->aug_indices.as<int32_t>(), ctx->aug_raw.as<float>()};
+    DDX_TRY(build_csc(ctx, full, 0, nnz, 0, ctx->N, 0, ctx->P_o, ctx->csc_o_colptr, ctx->csc_o_row, ctx->csc_o_raw));
+    ctx->mirror_o = true;
+    return DDX_OK;
+}
+
+// bit-plane mode, once per fit (bp_build): the reduced mirror of the original rows from their reduced CSR, into the per-fit buffer
+int bp_originals_mirror(ddx_ctx* ctx) {
+    BitPlanes& bp = ctx->bp;
+    const size_t nseg = (size_t)ctx->P_o * ctx->H;
+    DevBuf cp, rw, pl;                                             // (views into ctx->bp_buf: nothing to grow, nothing to release)
+    cp.p = bp.restm_colptr; cp.cap = sizeof(int64_t) * (nseg + 1);
+    rw.p = bp.restm_row; rw.cap = sizeof(int32_t) * (size_t)bp.nrest_o + 256;
+    pl.p = bp.restm_raw; pl.cap = sizeof(float) * (size_t)bp.nrest_o + 256;
+    const MirrorSrc red{bp.rest_indptr, bp.rest_cols, bp.rest_raw};
+    return build_csc(ctx, red, 0, bp.nrest_o, 0, ctx->N, 0, ctx->P_o, cp, rw, pl);
+}
+
 int stage_upload_counts(ddx_ctx* ctx, int64_t N, int32_t H, const int64_t* indptr, const int32_t* indices,
                         const float* data, bool from_device) {
     const int64_t nnz = from_device ? ctx->nnz : indptr[N];
@@ -861,14 +886,17 @@ int stage_upload_counts(ddx_ctx* ctx, int64_t N, int32_t H, const int64_t* indpt
             k_row_sums<<<(unsigned)ceil_div(N, 4), 256, 0, ctx->stream>>>(ctx->aug_indptr.as<int64_t>(), ctx->aug_raw.as<float>(), 0, N,
                                                                           ctx->lib32.as<float>(), ctx->lib64.as<double>());
     }
-    DDX_TRY(ensure(ctx, ctx->csc_o_row, sizeof(int32_t) * (size_t)(nnz + 1)));
-    DDX_TRY(ensure(ctx, ctx->csc_o_raw, sizeof(float) * (size_t)(nnz + 1)));
-    DDX_TRY(ensure(ctx, ctx->csc_o_x, sizeof(float) * (size_t)(nnz + 1)));
     ctx->panel_rows = (ctx->opt.spmm_lds && ctx->opt.gather_f32) ? kLdsPanelRows : kGatherPanelRows;
     ctx->P_o = (int32_t)ceil_div(N, ctx->panel_rows);
-    const MirrorSrc full{ctx->aug_indptr.as<int64_t>(), ctx->aug_indices.as<int32_t>(), ctx->aug_raw.as<float>()};
-    DDX_TRY(build_csc(ctx, full, 0, nnz, 0, N, 0, ctx->P_o, ctx->csc_o_colptr, ctx->csc_o_row, ctx->csc_o_raw));
-    if (bp_wanted_at_upload(ctx)) DDX_TRY(bp_build(ctx));        // bitmaps + reduced structures of the original rows, once per fit: the followers copy them
+    ctx->mirror_o = false;
+    if (bp_wanted_at_upload(ctx)) {
+        // bitmaps + reduced structures of the original rows, once per fit (the followers copy them).  The bit-plane route never reads
+        // the full column-major mirror of the original rows -- its reduced mirror is built from the reduced rows --, so that one
+        // (a pass over all stored entries, 8 bytes each to keep and to copy to every follower) waits for somebody to ask: ensure_full_mirror
+        DDX_TRY(bp_build(ctx));
+    } else {
+        DDX_TRY(originals_mirror(ctx));
+    }
     DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->have_counts = true;
     return DDX_OK;
@@ -889,11 +917,13 @@ int stage_clone_counts(ddx_ctx* ctx, const ddx_ctx* src) {
     DDX_TRY(ensure(ctx, ctx->aug_x, sizeof(float) * (size_t)(nnz + cap_s)));
     DDX_TRY(ensure(ctx, ctx->lib32, sizeof(float) * (N + N / 2 + 2)));
     DDX_TRY(ensure(ctx, ctx->lib64, sizeof(double) * (N + N / 2 + 2)));
-    DDX_TRY(ensure(ctx, ctx->csc_o_row, sizeof(int32_t) * (size_t)(nnz + 1)));
-    DDX_TRY(ensure(ctx, ctx->csc_o_raw, sizeof(float) * (size_t)(nnz + 1)));
-    DDX_TRY(ensure(ctx, ctx->csc_o_x, sizeof(float) * (size_t)(nnz + 1)));
     const size_t cp_bytes = sizeof(int64_t) * ((size_t)src->P_o * H + 1);
-    DDX_TRY(ensure(ctx, ctx->csc_o_colptr, cp_bytes));
+    if (src->mirror_o) {
+        DDX_TRY(ensure(ctx, ctx->csc_o_row, sizeof(int32_t) * (size_t)(nnz + 1)));
+        DDX_TRY(ensure(ctx, ctx->csc_o_raw, sizeof(float) * (size_t)(nnz + 1)));
+        DDX_TRY(ensure(ctx, ctx->csc_o_x, sizeof(float) * (size_t)(nnz + 1)));
+        DDX_TRY(ensure(ctx, ctx->csc_o_colptr, cp_bytes));
+    }
     DDX_TRY(ensure(ctx, ctx->median, 256));
     auto copy = [&](DevBuf& d, const DevBuf& s, size_t bytes) -> hipError_t {
         return bytes ? hipMemcpyAsync(d.p, s.p, bytes, hipMemcpyDeviceToDevice, ctx->stream) : hipSuccess;
@@ -903,9 +933,12 @@ int stage_clone_counts(ddx_ctx* ctx, const ddx_ctx* src) {
     DDX_HIP(ctx, copy(ctx->aug_raw, src->aug_raw, sizeof(float) * nnz));
     DDX_HIP(ctx, copy(ctx->lib32, src->lib32, sizeof(float) * N));
     DDX_HIP(ctx, copy(ctx->lib64, src->lib64, sizeof(double) * N));
-    DDX_HIP(ctx, copy(ctx->csc_o_colptr, src->csc_o_colptr, cp_bytes));
-    DDX_HIP(ctx, copy(ctx->csc_o_row, src->csc_o_row, sizeof(int32_t) * nnz));
-    DDX_HIP(ctx, copy(ctx->csc_o_raw, src->csc_o_raw, sizeof(float) * nnz));
+    if (src->mirror_o) {
+        DDX_HIP(ctx, copy(ctx->csc_o_colptr, src->csc_o_colptr, cp_bytes));
+        DDX_HIP(ctx, copy(ctx->csc_o_row, src->csc_o_row, sizeof(int32_t) * nnz));
+        DDX_HIP(ctx, copy(ctx->csc_o_raw, src->csc_o_raw, sizeof(float) * nnz));
+    }
+    ctx->mirror_o = src->mirror_o;
     ctx->cap_synth = cap_s;
     ctx->h_indptr = src->h_indptr;
     ctx->N = N;
@@ -1275,6 +1308,7 @@ int ensure_full_mirror(ddx_ctx* ctx) {
     if (ctx->mirror_full) return DDX_OK;
     if (!ctx->have_lognorm) return set_err(ctx, DDX_E_ARG, "the column-major mirror needs ddx_lognormalise first");
     DDX_TRY(ensure_full_rows(ctx));
+    DDX_TRY(originals_mirror(ctx));
     const int64_t N = ctx->N, M = ctx->M;
     const MirrorSrc full{ctx->aug_indptr.as<int64_t>(), ctx->aug_indices.as<int32_t>(), ctx->aug_raw.as<float>()};
     DDX_TRY(build_csc(ctx, full, ctx->nnz, ctx->nnz_aug - ctx->nnz, N, M, ctx->p_s0, ctx->P_s > 0 ? ctx->P_s : 1, ctx->csc_s_colptr, ctx->csc_s_row, ctx->csc_s_raw));

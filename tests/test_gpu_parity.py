@@ -823,8 +823,14 @@ def test_doublets_derived_from_their_parents_structures():
                 assert stats["active"]
                 emb, sing = c.embedding_f64()
                 results[(how, it)] = (emb.copy(), sing.copy(), stats["rest_synthetic"], c.aug_lib())
-            # the derived construction never wrote a merged row; the first read-back below makes it do so (once)
+            # the derived construction never wrote a merged row; the first consumer of the rows -- here a plain float64 product A x
+            # (ddx_operator_apply, the exact-PCA regimes' entry point) -- makes it do so, once
             assert c.timings().get("doublet_fill", (0, 0.0))[0] == (0 if how == "derived" else 2)
+            xop = np.random.default_rng(23).normal(size=(H, 3))
+            ax = c.operator_apply(xop, 0)
+            assert c.timings()["doublet_fill"][0] == (1 if how == "derived" else 2)
+            A = c.aug_dense_rows(0, N + S).astype(np.float64)
+            np.testing.assert_allclose(ax, (A - A.mean(axis=0)) @ xop, rtol=1e-6, atol=1e-6)
             # read-backs after the lean iteration: the merged rows, this iteration's values, dense rows
             syn = c.get_synth()
             assert c.timings()["doublet_fill"][0] == (1 if how == "derived" else 2)
