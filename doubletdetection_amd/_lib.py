@@ -12,7 +12,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DDX_LIB") or os.path.join(_HERE, "libddx.so")      # DDX_LIB: an experimental build (profiles/tools)
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _lib = None
 
@@ -81,6 +81,7 @@ _SIGNATURES = {
     "ddx_get_knn_overflow_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "ddx_get_knn_candidate_counts": (C.c_int, [C.c_void_p, c_i32_p]),
     "ddx_get_bitplane_stats": (C.c_int, [C.c_void_p, c_i64_p]),
+    "ddx_get_upload_form": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "ddx_build_graph": (C.c_int, [C.c_void_p, C.c_int32]),
     "ddx_graph_relations": (C.c_int, [C.c_void_p, C.c_int32, c_i32_p, c_f64_p]),
     "ddx_assemble_graph": (C.c_int, [C.c_int64, C.c_int32, c_i32_p, c_f64_p, c_i64_p, c_i32_p, c_f64_p]),
@@ -695,6 +696,12 @@ class Context:
         n = C.c_int64(0)
         self._c(self._lib.ddx_get_knn_overflow_count(self._h, C.byref(n)))
         return int(n.value)
+
+    def upload_form(self) -> int:
+        """How the last upload_raw crossed the link: 0 plain arrays, 1 packed by this context, 2 another context's packed image."""
+        v = C.c_int32(0)
+        self._c(self._lib.ddx_get_upload_form(self._h, C.byref(v)))
+        return int(v.value)
 
     def bitplane_stats(self) -> dict:
         """Did the last PCA's operator products take the bit-plane route, and what is left to the sparse products."""

@@ -549,6 +549,24 @@ void pin_join() { if (g_pin_thread && g_pin_thread->joinable()) g_pin_thread->jo
 WorkerPool* g_pool = nullptr;
 pid_t g_pool_pid = 0;
 std::atomic<int> g_upload_threads{0};        // ddx_set_upload_threads (0: the default rule)
+struct PackEsc { int32_t pos, col; float val; };
+// The packed image is the same for every GPU: while one context packs (it holds g_pool_mutex), other contexts of the process that
+// stage the SAME host arrays at that moment (one leader per GPU, classifier.py:_stage) attach to its job and send the chunks it
+// finishes to their own device from the same pinned buffer, instead of falling back to the plain arrays.
+struct PackShare {
+    const int64_t* indptr; const int32_t* indices; const float* data;      // the job's identity
+    int64_t n_cells, nnz; int32_t n_genes; bool f16;
+    int64_t chunk, nchunks; int T;
+    unsigned char* pin;
+    std::atomic<int>* done;                                  // [nchunks] threads that have finished chunk k
+    std::atomic<int>* bad;                                   // the matrix turned out not to be packable
+    const std::vector<std::vector<PackEsc>>* listed;         // [chunk][thread] entries outside the 2-byte form
+    pid_t pid;                                               // (a forked child must not attach to its parent's job)
+    int readers = 0;                                         // attached contexts still copying (g_share_mutex)
+};
+std::mutex g_share_mutex;
+std::condition_variable g_share_cv;
+PackShare* g_share = nullptr;                // the job other contexts may attach to (nullptr: none / closed)
 // (called with g_pool_mutex held.  Threads do not survive fork(): a child process builds its own pool; the parent's
 // object is abandoned there -- never joined, never freed.)
 WorkerPool* upload_pool() {
@@ -563,8 +581,6 @@ WorkerPool* upload_pool() {
     return g_pool;
 }
 }  // namespace
-
-struct PackEsc { int32_t pos, col; float val; };
 
 // entries [a, b) of the matrix -> 2-byte codes; entries that do not fit are appended to `esc` (ascending positions).
 // Rows are taken one at a time: the first entry of a row steps from column -1, the others from their predecessor, which
@@ -604,6 +620,108 @@ __attribute__((target("avx2"))) static void pack16_avx2(const int64_t* indptr, i
     DDX_PACK16_BODY
 }
 
+// The consumer side of a packed upload: sends the chunks of job `sh` to `ctx` as the packing threads finish them and expands them
+// there.  Run by the context that packs and by every context attached to its job.  DDX_OK / 1 (not packable) / DDX_E_HIP.
+static int send_packed(ddx_ctx* ctx, const PackShare& sh, bool owner, double t_in) {
+    const bool f16 = sh.f16;
+    const int64_t nnz = sh.nnz, n_cells = sh.n_cells, chunk = sh.chunk, nchunks = sh.nchunks;
+    const int32_t n_genes = sh.n_genes;
+    const int64_t* indptr = sh.indptr;
+    const int T = sh.T;
+    const size_t esz = f16 ? sizeof(uint16_t) : sizeof(uint32_t);
+    const size_t need = esz * (size_t)nnz;
+    const int64_t esc_cap = f16 ? nnz / 32 + 1 : 0;      // listed entries the device buffer has room for
+    const size_t codes_bytes = (need + 255) & ~(size_t)255;
+    unsigned char* pin = sh.pin;
+    std::atomic<int>& bad = *sh.bad;
+    const std::vector<std::vector<PackEsc>>& listed = *sh.listed;
+    const bool dbg = ctx->opt.upload_debug > 0;
+    auto clk = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    std::vector<hipEvent_t> ev(nchunks, nullptr);
+    int rc = DDX_OK;
+    // 2-byte form: rows complete after every chunk, the largest batch of entries they bring, the listed entries so far
+    std::vector<int64_t> rows_done_after((size_t)nchunks, 0);
+    int64_t rows_done = 0, fold_max = 1;
+    bool fold_ok = f16 && ctx->opt.hvg_fold;
+    std::vector<int32_t> pos, col;                        // (alive and never reallocated until the stream has taken them: the synchronisation below)
+    std::vector<float> val;
+    unsigned char* side = ctx->raw_packed.as<unsigned char>() + codes_bytes;
+    int32_t* d_pos = reinterpret_cast<int32_t*>(side);
+    int32_t* d_col = d_pos + esc_cap;
+    float* d_val = reinterpret_cast<float*>(d_col + esc_cap);
+    if (f16) {
+        pos.reserve((size_t)esc_cap + 1); col.reserve((size_t)esc_cap + 1); val.reserve((size_t)esc_cap + 1);
+        int64_t prev = 0;
+        for (int64_t k = 0; k < nchunks; ++k) {
+            const int64_t c1 = std::min(nnz, (k + 1) * chunk);
+            const int64_t r1 = (std::upper_bound(indptr, indptr + n_cells + 1, c1) - indptr) - 1;      // rows whose last entry is in by now
+            rows_done_after[k] = r1;
+            fold_max = std::max(fold_max, indptr[r1] - indptr[prev]);
+            prev = r1;
+        }
+    }
+    for (int64_t k = 0; k < nchunks && rc == DDX_OK; ++k) {
+        while (sh.done[k].load(std::memory_order_acquire) < T && !bad.load()) std::this_thread::yield();
+        if (bad.load()) { rc = 1; break; }
+        const int64_t c0 = k * chunk, len = std::min(nnz, c0 + chunk) - c0;
+        unsigned char* dev = ctx->raw_packed.as<unsigned char>() + esz * c0;
+        if (ctx->opt.upload_debug > 1) fprintf(stderr, "[ddx upload] chunk %lld packed +%.2f ms\n", (long long)k, clk() - t_in);
+        if (hipMemcpyAsync(dev, pin + esz * c0, esz * len, hipMemcpyHostToDevice, ctx->copy_stream) != hipSuccess ||
+            hipEventCreateWithFlags(&ev[k], hipEventDisableTiming) != hipSuccess || hipEventRecord(ev[k], ctx->copy_stream) != hipSuccess ||
+            hipStreamWaitEvent(ctx->stream, ev[k], 0) != hipSuccess) { rc = DDX_E_HIP; break; }
+        if (!f16) {
+            k_expand_packed<<<(unsigned)((len + 255) / 256), 256, 0, ctx->stream>>>(reinterpret_cast<const uint32_t*>(dev), len, ctx->raw_indices.as<int32_t>() + c0,
+                                                                                    ctx->raw_data.as<float>() + c0);
+            continue;
+        }
+        // 2-byte form: the entries this chunk lists go behind those of the earlier chunks (ascending positions), then the rows
+        // that END in this chunk are expanded and -- while the next chunk is on the link -- folded into the running gene sums
+        // of dd.py:167-170 (the stream has been told to wait for the chunk: the event above)
+        const size_t before = pos.size();
+        for (int w = 0; w < T; ++w)
+            for (const PackEsc& x : listed[(size_t)k * T + w]) { pos.push_back(x.pos); col.push_back(x.col); val.push_back(x.val); }
+        const size_t added = pos.size() - before;
+        if ((int64_t)pos.size() > esc_cap) { rc = 1; break; }
+        if (added &&
+            (hipMemcpyAsync(d_pos + before, pos.data() + before, 4 * added, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+             hipMemcpyAsync(d_col + before, col.data() + before, 4 * added, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+             hipMemcpyAsync(d_val + before, val.data() + before, 4 * added, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)) { rc = DDX_E_HIP; break; }
+        const int64_t row1 = rows_done_after[k];
+        if (row1 > rows_done) {
+            k_expand_packed16<<<(unsigned)((row1 - rows_done + 3) / 4), 256, 0, ctx->stream>>>(ctx->raw_packed.as<uint16_t>(), ctx->raw_indptr.as<int64_t>(), rows_done, row1, d_pos,
+                                                                                             d_col, d_val, (int32_t)pos.size(), ctx->raw_indices.as<int32_t>(),
+                                                                                             ctx->raw_data.as<float>());
+            if (fold_ok && gene_sums_fold(ctx, n_genes, n_cells, rows_done, row1, indptr[rows_done], indptr[row1], fold_max) != DDX_OK) fold_ok = false;
+            rows_done = row1;
+        }
+    }
+    if (rc != DDX_OK && owner) bad.store(1);               // (stops the packing threads; an attached context's own failure is its own)
+    const double t_issued = clk();
+    if (ctx->opt.upload_debug > 1) {
+        for (int64_t k = 0; k < nchunks; ++k)
+            if (ev[k]) { (void)hipEventSynchronize(ev[k]); fprintf(stderr, "[ddx upload] chunk %lld landed +%.2f ms\n", (long long)k, clk() - t_in); }
+    }
+    if (rc == DDX_OK && bad.load()) rc = 1;
+    if (rc == DDX_OK && f16 && dbg) fprintf(stderr, "[ddx upload] %lld of %lld entries listed\n", (long long)pos.size(), (long long)nnz);
+    if (rc != DDX_OK || !fold_ok) ctx->hvg_rows = -1;
+    (void)hipStreamSynchronize(ctx->copy_stream);
+    const double t_copied = clk();
+    (void)hipStreamSynchronize(ctx->stream);                                   // (the pinned buffer and the host lists are reused / freed)
+    if (dbg)
+        fprintf(stderr, "[ddx upload] %d-byte form%s, %d threads, %lld chunks: last copy issued +%.2f ms, copies done +%.2f, expanded +%.2f\n",
+                (int)esz, owner ? "" : " (another context's packing)", T, (long long)nchunks, t_issued - t_in, t_copied - t_in, clk() - t_in);
+    for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
+    return rc;
+}
+
+// device buffer of the packed form: the codes, then (2-byte form) room for the listed entries: positions | columns | values
+static int packed_device_buffer(ddx_ctx* ctx, bool f16, int64_t nnz) {
+    const size_t need = (f16 ? sizeof(uint16_t) : sizeof(uint32_t)) * (size_t)nnz;
+    const int64_t esc_cap = f16 ? nnz / 32 + 1 : 0;
+    if (!ctx->copy_stream && hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); ctx->copy_stream = nullptr; return 1; }
+    return ensure(ctx, ctx->raw_packed, ((need + 255) & ~(size_t)255) + 12 * (size_t)esc_cap);
+}
+
 // DDX_OK: the matrix is on the device; 1: not applicable (caller sends it plain)
 static int upload_packed(ddx_ctx* ctx, int64_t n_cells, int64_t nnz, int32_t n_genes, const int64_t* indptr, const int32_t* indices,
                          const float* data) {
@@ -615,15 +733,43 @@ static int upload_packed(ddx_ctx* ctx, int64_t n_cells, int64_t nnz, int32_t n_g
     const size_t esz = f16 ? sizeof(uint16_t) : sizeof(uint32_t);
     const size_t need = esz * (size_t)nnz;
     const int64_t esc_cap = f16 ? nnz / 32 + 1 : 0;      // listed entries the device buffer has room for
-    // one packed upload at a time: a second context staging at the same moment (several GPUs driven by one process)
-    // sends its copy plain, in parallel, instead of queueing behind this one
+    auto clk = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    ctx->upload_form = 0;
+    // one packing at a time per process.  A second context staging at the same moment (several GPUs driven by one process) attaches
+    // to the running job when it is packing the same host arrays, and sends its copy plain, in parallel, when it is not.
+    // (g_share_mutex is held from before the attempt on g_pool_mutex until the job is published: whoever fails to get the pool
+    // then sees the job of whoever got it.)
+    std::unique_lock<std::mutex> share_lock(g_share_mutex);
     std::unique_lock<std::mutex> pool_lock(g_pool_mutex, std::try_to_lock);
-    if (!pool_lock.owns_lock()) return 1;
+    if (!pool_lock.owns_lock()) {
+        PackShare* sh = g_share;
+        if (!sh || sh->pid != getpid() || sh->indptr != indptr || sh->indices != indices || sh->data != data || sh->n_cells != n_cells || sh->nnz != nnz ||
+            sh->n_genes != n_genes || sh->f16 != f16 || sh->bad->load())
+            return 1;
+        ++sh->readers;
+        share_lock.unlock();
+        const double t_in = clk();
+        int rc = packed_device_buffer(ctx, f16, nnz);
+        if (rc == DDX_OK) {
+            (void)hipStreamSynchronize(ctx->stream);       // the copies must not overtake whatever the main stream still does with the device buffers
+            rc = send_packed(ctx, *sh, false, t_in);
+        }
+        share_lock.lock();
+        --sh->readers;
+        g_share_cv.notify_all();
+        share_lock.unlock();
+        if (rc == DDX_E_HIP) return set_err(ctx, DDX_E_HIP, "packed upload failed");
+        if (rc < 0) return rc;
+        if (rc != DDX_OK) release(ctx, ctx->raw_packed);
+        else ctx->upload_form = 2;
+        return rc;
+    }
     {
         static pid_t pin_pid = 0;
         if (pin_pid != getpid()) {                               // (a forked child starts over; the parent's helper thread does not exist here)
             pin_pid = getpid(); g_pin_state.store(0); g_pin_buf = nullptr; g_pin_bytes = 0; g_pin_failed = 0;
             g_pin_thread = nullptr;                              // (abandoned, never joined or freed: it belongs to the parent)
+            g_share = nullptr;
         }
         const int st = g_pin_state.load(std::memory_order_acquire);
         if (st == 1) return 1;                                   // still being pinned
@@ -644,10 +790,10 @@ static int upload_packed(ddx_ctx* ctx, int64_t n_cells, int64_t nnz, int32_t n_g
             if (g_pin_state.load() != 2) return 1;
         }
     }
-    if (!ctx->copy_stream && hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); ctx->copy_stream = nullptr; return 1; }
-    // device: the codes, then (2-byte form) room for the listed entries: positions | columns | values
-    const size_t codes_bytes = (need + 255) & ~(size_t)255;
-    DDX_TRY(ensure(ctx, ctx->raw_packed, codes_bytes + 12 * (size_t)esc_cap));
+    {
+        const int rc = packed_device_buffer(ctx, f16, nnz);
+        if (rc != DDX_OK) return rc;
+    }
     unsigned char* pin = static_cast<unsigned char*>(g_pin_buf);
     WorkerPool* pool = upload_pool();
     const int T = pool->size();
@@ -682,90 +828,23 @@ static int upload_packed(ddx_ctx* ctx, int64_t n_cells, int64_t nnz, int32_t n_g
             done[k].fetch_add(1, std::memory_order_release);
         }
     };
-    // the copies must not overtake whatever the main stream still does with the device buffers
-    const bool dbg = ctx->opt.upload_debug > 0;
-    auto clk = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    PackShare share{indptr, indices, data, n_cells, nnz, n_genes, f16, chunk, nchunks, T, pin, done.data(), &bad, &listed, getpid()};
+    g_share = &share;
+    share_lock.unlock();
     const double t_in = clk();
-    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamSynchronize(ctx->stream);               // the copies must not overtake whatever the main stream still does with the device buffers
     pool->start(worker);
-    std::vector<hipEvent_t> ev(nchunks, nullptr);
-    int rc = DDX_OK;
-    // 2-byte form: rows complete after every chunk, the largest batch of entries they bring, the listed entries so far
-    std::vector<int64_t> rows_done_after((size_t)nchunks, 0);
-    int64_t rows_done = 0, fold_max = 1;
-    bool fold_ok = f16 && ctx->opt.hvg_fold;
-    std::vector<int32_t> pos, col;                        // (alive and never reallocated until the stream has taken them: the synchronisation below)
-    std::vector<float> val;
-    unsigned char* side = ctx->raw_packed.as<unsigned char>() + codes_bytes;
-    int32_t* d_pos = reinterpret_cast<int32_t*>(side);
-    int32_t* d_col = d_pos + esc_cap;
-    float* d_val = reinterpret_cast<float*>(d_col + esc_cap);
-    if (f16) {
-        pos.reserve((size_t)esc_cap + 1); col.reserve((size_t)esc_cap + 1); val.reserve((size_t)esc_cap + 1);
-        int64_t prev = 0;
-        for (int64_t k = 0; k < nchunks; ++k) {
-            const int64_t c1 = std::min(nnz, (k + 1) * chunk);
-            const int64_t r1 = (std::upper_bound(indptr, indptr + n_cells + 1, c1) - indptr) - 1;      // rows whose last entry is in by now
-            rows_done_after[k] = r1;
-            fold_max = std::max(fold_max, indptr[r1] - indptr[prev]);
-            prev = r1;
-        }
-    }
-    for (int64_t k = 0; k < nchunks && rc == DDX_OK; ++k) {
-        while (done[k].load(std::memory_order_acquire) < T && !bad.load()) std::this_thread::yield();
-        if (bad.load()) { rc = 1; break; }
-        const int64_t c0 = k * chunk, len = std::min(nnz, c0 + chunk) - c0;
-        unsigned char* dev = ctx->raw_packed.as<unsigned char>() + esz * c0;
-        if (ctx->opt.upload_debug > 1) fprintf(stderr, "[ddx upload] chunk %lld packed +%.2f ms\n", (long long)k, clk() - t_in);
-        if (hipMemcpyAsync(dev, pin + esz * c0, esz * len, hipMemcpyHostToDevice, ctx->copy_stream) != hipSuccess ||
-            hipEventCreateWithFlags(&ev[k], hipEventDisableTiming) != hipSuccess || hipEventRecord(ev[k], ctx->copy_stream) != hipSuccess ||
-            hipStreamWaitEvent(ctx->stream, ev[k], 0) != hipSuccess) { rc = DDX_E_HIP; break; }
-        if (!f16) {
-            k_expand_packed<<<(unsigned)((len + 255) / 256), 256, 0, ctx->stream>>>(reinterpret_cast<const uint32_t*>(dev), len, ctx->raw_indices.as<int32_t>() + c0,
-                                                                                    ctx->raw_data.as<float>() + c0);
-            continue;
-        }
-        // 2-byte form: the entries this chunk lists go behind those of the earlier chunks (ascending positions), then the rows
-        // that END in this chunk are expanded and -- while the next chunk is on the link -- folded into the running gene sums
-        // of dd.py:167-170 (the stream has been told to wait for the chunk: the event above)
-        const size_t before = pos.size();
-        for (int w = 0; w < T; ++w)
-            for (const PackEsc& x : listed[(size_t)k * T + w]) { pos.push_back(x.pos); col.push_back(x.col); val.push_back(x.val); }
-        const size_t added = pos.size() - before;
-        if ((int64_t)pos.size() > esc_cap) { rc = 1; break; }
-        if (added &&
-            (hipMemcpyAsync(d_pos + before, pos.data() + before, 4 * added, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
-             hipMemcpyAsync(d_col + before, col.data() + before, 4 * added, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
-             hipMemcpyAsync(d_val + before, val.data() + before, 4 * added, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)) { rc = DDX_E_HIP; break; }
-        const int64_t row1 = rows_done_after[k];
-        if (row1 > rows_done) {
-            k_expand_packed16<<<(unsigned)((row1 - rows_done + 3) / 4), 256, 0, ctx->stream>>>(ctx->raw_packed.as<uint16_t>(), ctx->raw_indptr.as<int64_t>(), rows_done, row1, d_pos,
-                                                                                             d_col, d_val, (int32_t)pos.size(), ctx->raw_indices.as<int32_t>(),
-                                                                                             ctx->raw_data.as<float>());
-            if (fold_ok && gene_sums_fold(ctx, n_genes, n_cells, rows_done, row1, indptr[rows_done], indptr[row1], fold_max) != DDX_OK) fold_ok = false;
-            rows_done = row1;
-        }
-    }
-    if (rc != DDX_OK) bad.store(1);
-    const double t_issued = clk();
-    if (ctx->opt.upload_debug > 1) {
-        for (int64_t k = 0; k < nchunks; ++k)
-            if (ev[k]) { (void)hipEventSynchronize(ev[k]); fprintf(stderr, "[ddx upload] chunk %lld landed +%.2f ms\n", (long long)k, clk() - t_in); }
-    }
+    int rc = send_packed(ctx, share, true, t_in);
     pool->wait();
     if (rc == DDX_OK && bad.load()) rc = 1;
-    if (rc == DDX_OK && f16 && dbg) fprintf(stderr, "[ddx upload] %lld of %lld entries listed\n", (long long)pos.size(), (long long)nnz);
-    if (rc != DDX_OK || !fold_ok) ctx->hvg_rows = -1;
-    const double t_packed = clk();
-    (void)hipStreamSynchronize(ctx->copy_stream);
-    const double t_copied = clk();
-    (void)hipStreamSynchronize(ctx->stream);                                   // (the pinned buffer and the host lists are reused / freed)
-    if (dbg)
-        fprintf(stderr, "[ddx upload] %d-byte form, %d threads, %lld chunks: last copy issued +%.2f ms, packing joined +%.2f, copies done +%.2f, expanded +%.2f\n",
-                (int)esz, T, (long long)nchunks, t_issued - t_in, t_packed - t_in, t_copied - t_in, clk() - t_in);
-    for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
+    // close the job: nobody attaches any more; the pinned buffer, the lists and the counters stay until the attached contexts are done
+    share_lock.lock();
+    g_share = nullptr;
+    g_share_cv.wait(share_lock, [&] { return share.readers == 0; });
+    share_lock.unlock();
     if (rc == DDX_E_HIP) return set_err(ctx, DDX_E_HIP, "packed upload failed");
-    if (rc != DDX_OK) release(ctx, ctx->raw_packed);      // not a packable matrix: the caller sends it plain, the packed bytes go back
+    if (rc != DDX_OK) { ctx->hvg_rows = -1; release(ctx, ctx->raw_packed); }      // not a packable matrix: the caller sends it plain, the packed bytes go back
+    else ctx->upload_form = 1;
     return rc;
 }
 
@@ -812,6 +891,7 @@ int ddx_upload_raw(ddx_ctx* ctx, int64_t n_cells, int32_t n_genes, const int64_t
     DDX_TRY(ensure(ctx, ctx->raw_data, sizeof(float) * (size_t)(nnz + 1)));
     DDX_HIP(ctx, hipMemcpyAsync(ctx->raw_indptr.p, indptr, sizeof(int64_t) * (n_cells + 1), hipMemcpyHostToDevice,
                                 ctx->stream));
+    ctx->upload_form = 0;
     if (nnz) {
         int packed = ctx->opt.upload_packed ? upload_packed(ctx, n_cells, nnz, n_genes, indptr, indices, data) : 1;
         if (packed < 0) return packed;
@@ -1122,6 +1202,13 @@ int ddx_get_knn_overflow_count(ddx_ctx* ctx, int64_t* n_queries) {
     int32_t n = 0;
     if (ctx->knn_overflow) DDX_TRY(d2h(ctx, &n, ctx->knn_overflow, sizeof(n)));
     *n_queries = n;
+    return DDX_OK;
+}
+
+int ddx_get_upload_form(ddx_ctx* ctx, int32_t* form) {
+    REQUIRE_CTX(ctx);
+    NEED(form, "null output");
+    *form = ctx->upload_form;
     return DDX_OK;
 }
 

@@ -41,7 +41,7 @@ struct Options {
     int knn_cells = 0;               // cells of the emit pass's pruning structure (0 = default rule, 1 = first-component windows only)
     int knn_sample_every = 32;       // the bound pass's sample holds every n-th tile of the whole set (0: none)
     int knn_seg_steps = 0;           // steps of a block's tile list per emit work item (0 = default)
-    int knn_emit_waves = 0;          // waves per emit block: 4, 8 or 16 (0 = default)
+    int knn_emit_waves = 0;          // waves per emit block: 4 or 8 (0 = default)
     bool row_sums_sequential = false;
     bool knn_debug = false;
     bool pca_debug = false;          // progress of the block Lanczos solver on stderr
@@ -159,6 +159,7 @@ struct ddx_ctx {
     int64_t nnz = 0;                 // stored entries of the N x H counts
     int64_t nnz_aug = 0;             // ... of the augmented matrix (known after ddx_lognormalise)
     std::vector<int64_t> h_indptr;   // host copy of the row pointer (capacity planning)
+    int upload_form = 0;             // how the last ddx_upload_raw sent the matrix: 0 plain arrays, 1 packed here, 2 the packed image of another context's upload
     bool have_counts = false;
     bool counts_exact = false;       // counts are small non-negative integers: row sums are exact in any order
 

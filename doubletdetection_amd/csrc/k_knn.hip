@@ -1723,7 +1723,9 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
         k_knn_tileinfo<<<(unsigned)ceil_div(ntiles, 256), 256, 0, ctx->stream>>>(cellpos, p1, nrm, M, ntiles, tilecell, t1lo, t1hi, r2max);
         k_cells_tilestart<<<(unsigned)ceil_div(Kc + 1, 256), 256, 0, ctx->stream>>>(tilecell, ntr, Kc, ctile);
         if (Kc > 1) k_cells_neighbours<<<(unsigned)Kc, 1024, 0, ctx->stream>>>(cenR, ctile, Kc, (int)nsamp, nlist, ncount);
-        k_knn_boundlists<<<(unsigned)bound_blocks, 64, sizeof(unsigned) * (size_t)((ntr + 31) / 32 + 1), ctx->stream>>>(tilecell, ctile, nlist, ncount, Kc, (int)nsamp, (int)nsamp, ntr, ctx->opt.knn_sample_every, blist, bcount);
+        const size_t bl_lds = sizeof(unsigned) * (size_t)((ntr + 31) / 32 + 1);        // one bit per tile: 128 KB at the 2^24-point limit
+        if (bl_lds > 64 * 1024) DDX_TRY(allow_dynamic_lds(ctx, reinterpret_cast<const void*>(&k_knn_boundlists), (int)bl_lds));
+        k_knn_boundlists<<<(unsigned)bound_blocks, 64, bl_lds, ctx->stream>>>(tilecell, ctile, nlist, ncount, Kc, (int)nsamp, (int)nsamp, ntr, ctx->opt.knn_sample_every, blist, bcount);
         k_knn_slabs<<<(unsigned)(Mp / 256), 256, 0, ctx->stream>>>(E, CP, nrm, tilecell, cenR, invD, Kc, ntiles, r2max, S_lo, S_hi, St_lo, St_hi, tr_lo, tr_hi);
     }
     DDX_HIP(ctx, hipMemsetAsync(ccount, 0, sizeof(int32_t) * (Mp + 64), ctx->stream));

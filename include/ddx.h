@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define DDX_ABI_VERSION 4
+#define DDX_ABI_VERSION 5
 
 #define DDX_OK 0
 #define DDX_E_ARG -1      /* invalid argument / stage called out of order */
@@ -228,6 +228,10 @@ int ddx_get_knn_overflow_count(ddx_ctx* ctx, int64_t* n_queries);
 /* statistics: candidates the distance screen listed for every query of the last ddx_knn (more than the list holds = that query
  * overflowed); the parity tests pick the queries with the longest lists from it. */
 int ddx_get_knn_candidate_counts(ddx_ctx* ctx, int32_t* counts_out /* [M] */);
+/* how the last ddx_upload_raw of this context crossed the PCIe link (dd.py:149-160, the matrix fit() receives): 0 = the plain CSR
+ * arrays, 1 = the 2- / 4-byte packed form, packed by this call, 2 = the packed image another context of the process was building from
+ * the same host arrays at that moment (one packing per process when it drives several GPUs). */
+int ddx_get_upload_form(ddx_ctx* ctx, int32_t* form);
 /* statistics of the bit-plane route of the last ddx_pca (sc.tl.pca call site, dd.py:305-314; csrc/k_bitplane.hip):
  * out[0] = 1 when the last iteration's operator products took it, out[1] / out[2] = stored entries other than 1 of the original /
  * synthetic rows (what the sparse products still walk), out[3] = 8-bit digits per operand value.  bench.py prices the kernels by it. */
