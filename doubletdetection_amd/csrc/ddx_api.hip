@@ -743,8 +743,10 @@ static int upload_packed(ddx_ctx* ctx, int64_t n_cells, int64_t nnz, int32_t n_g
     std::unique_lock<std::mutex> pool_lock(g_pool_mutex, std::try_to_lock);
     if (!pool_lock.owns_lock()) {
         PackShare* sh = g_share;
-        if (!sh || sh->pid != getpid() || sh->indptr != indptr || sh->indices != indices || sh->data != data || sh->n_cells != n_cells || sh->nnz != nnz ||
-            sh->n_genes != n_genes || sh->f16 != f16 || sh->bad->load())
+        // (the row pointer is compared by content: the Python binding widens scipy's 32-bit indptr into a fresh array per call)
+        if (!sh || sh->pid != getpid() || sh->indices != indices || sh->data != data || sh->n_cells != n_cells || sh->nnz != nnz ||
+            sh->n_genes != n_genes || sh->f16 != f16 || sh->bad->load() ||
+            (sh->indptr != indptr && memcmp(sh->indptr, indptr, sizeof(int64_t) * (size_t)(n_cells + 1)) != 0))
             return 1;
         ++sh->readers;
         share_lock.unlock();

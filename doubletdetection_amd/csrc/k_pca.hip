@@ -694,16 +694,16 @@ __global__ void __launch_bounds__(kLdsThreads) k_spmm_lds(const LdsSpmmArgs a) {
 //     same operand slices, same trips of 8 / 4 steps in the same order -- the sums are bit-identical to k_spmm_lds';
 //   * per (wave, slice) the steps of its OWN units are concatenated into QUADS of 4 lock-step steps (3 slots x 4 entries:
 //     float32 x - z and 16-bit operand row inside the slice, zero padded), twelve quads to a self-describing 1 KB BLOCK
-//     (header: quads per unit in this block);
-//   * the product kernel copies a wave's next block global -> LDS asynchronously (one 1 KB instruction, double buffered) while it
-//     works through the current one: per block one header read and then nothing but trips.
+//     (header: quads per unit in this block); a wave's blocks lie one behind the other in memory, slice after slice;
+//   * the product kernel copies a wave's blocks global -> LDS asynchronously (one 1 KB instruction each) into a ring of two or three
+//     buffers, ahead of the one it works through and WHATEVER slice they belong to: per block one header read and then nothing but
+//     trips.
 // ------------------------------------------------------------------------------------------------
 constexpr int kPkQuadBytes = 80;        // val[3][4] float32 (48) | idx[3][4] uint16 (24) | pad (8): 16-byte aligned
 constexpr int kPkQuads = 12;            // quads per block
 constexpr int kPkHeader = 64;           // bytes before the first quad: quads per unit (uint8, at most 12 units)
 constexpr int kPkBlockBytes = kPkHeader + kPkQuads * kPkQuadBytes;   // 1024
 static_assert(kPkBlockBytes == 1024, "a block is one wave-wide 16-byte copy");
-constexpr int kPkMaxOwn = 12;
 
 struct PackedArgs {
     LdsSpmmArgs a;                // geometry, sources, outputs as for k_spmm_lds (ROWS: indptr / cols / x / rowseg; COLS: the mirrors)
@@ -835,8 +835,9 @@ __global__ void __launch_bounds__(256) k_pack_residual(const LdsSpmmArgs a, int 
     }
 }
 
-template <bool ROWS, int OWN>
+template <bool ROWS, int OWN, int RING>
 __global__ void __launch_bounds__(kLdsThreads) k_spmm_packed(const PackedArgs pa) {
+    constexpr int kPkRing = RING;       // block buffers per wave: the current block and the next RING - 1, already on their way
     typedef float fq __attribute__((ext_vector_type(2)));
     typedef __attribute__((address_space(3))) const fq lds_fq;
     typedef uint32_t u2 __attribute__((ext_vector_type(2)));
@@ -844,7 +845,7 @@ __global__ void __launch_bounds__(kLdsThreads) k_spmm_packed(const PackedArgs pa
     extern __shared__ __align__(16) unsigned char smem[];
     float* opS = reinterpret_cast<float*>(smem);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    unsigned char* stg = smem + (((size_t)a.SR * a.ld * 4 + 15) & ~(size_t)15) + (size_t)wave * (2 * kPkBlockBytes);     // two block buffers per wave
+    unsigned char* stg = smem + (((size_t)a.SR * a.ld * 4 + 15) & ~(size_t)15) + (size_t)wave * (kPkRing * kPkBlockBytes);     // the wave's ring of block buffers
     int slot = lane / a.lpn, sub = lane - slot * a.lpn;
     const bool active = slot < 3 && 2 * sub < a.ld;
     if (slot >= 3) slot = 2;                         // idle lanes shadow the last group (reads only)
@@ -864,15 +865,22 @@ __global__ void __launch_bounds__(kLdsThreads) k_spmm_packed(const PackedArgs pa
     const int32_t* bp = pa.blkptr + ((int64_t)blockIdx.x * kLdsWaves + wave) * (pa.nsl + 1);
     const uint32_t rowb = (uint32_t)(a.ld * 4);
     const uint32_t base3 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)(smem + 8 * sub);
-    auto copy_block = [&](int32_t b, int buf) {
+    // the wave's blocks: [bbeg, bend), block b into buffer (b - bbeg) % kPkRing
+    const int32_t bbeg = __builtin_amdgcn_readfirstlane(bp[0]);
+    const int32_t bend = __builtin_amdgcn_readfirstlane(bp[pa.nsl]);      // (slices past the last one hold no blocks)
+    auto copy_block = [&](int32_t b) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa.blocks + (int64_t)b * kPkBlockBytes + lane * 16),
-                                         (__attribute__((address_space(3))) void*)(stg + buf * kPkBlockBytes), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void*)(stg + ((b - bbeg) % kPkRing) * kPkBlockBytes), 16, 0, 0);
     };
+    int32_t nf = bbeg;                                  // the next block to ask for
+    for (; nf < bend && nf < bbeg + kPkRing; ++nf) copy_block(nf);
+    int32_t b = bbeg;                                   // the next block to work through
     for (int t = 0; t < pa.nsl; ++t) {
         const int s = ROWS ? t : group + t * a.groups;
         if (s >= a.nslices) break;
-        __syncthreads();                                // everybody is done with the previous slice
-        const int32_t b0 = bp[t], b1 = bp[t + 1];
+        // everybody is done with the previous slice.  (A bare barrier: __syncthreads() would also wait for the block copies in flight.)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const int32_t b1v = bp[t + 1];                  // (arrives with the slice)
         {
             const int64_t r0 = (int64_t)s * a.SR;
             const int nr = (int)((a.opRows - r0) < a.SR ? (a.opRows - r0) : a.SR);
@@ -886,19 +894,19 @@ __global__ void __launch_bounds__(kLdsThreads) k_spmm_packed(const PackedArgs pa
                 if (base + lane < nvec && !(DDX_PK_DBG & 1))
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + base + lane),
                                                      (__attribute__((address_space(3))) void*)(dst + base), 16, 0, 0);
-            if (b0 < b1) copy_block(b0, 0);             // (the wave's first block of this slice travels with the slice)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (the slice -- and with it every block asked for so far)
         }
-        __syncthreads();
-        for (int32_t b = b0; b < b1; ++b) {
-            const int buf = (b - b0) & 1;
-            if (b + 1 < b1) {
-                copy_block(b + 1, buf ^ 1);
-                asm volatile("s_waitcnt vmcnt(1)" ::: "memory");     // block b has landed (a wave's copies complete in order)
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            const unsigned char* blk = stg + buf * kPkBlockBytes;
+        const int32_t b1 = __builtin_amdgcn_readfirstlane(b1v);
+        asm volatile("s_barrier" ::: "memory");
+        for (; b < b1; ++b) {
+            // block b has landed once at most the copies asked for after it are in flight (a wave's copies complete in order)
+            const int newer = nf - 1 - b;
+            if (kPkRing > 3 && newer >= 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else if (kPkRing > 2 && newer == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else if (newer == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            static_assert(kPkRing >= 2 && kPkRing <= 4, "the wait counts above");
+            const unsigned char* blk = stg + ((b - bbeg) % kPkRing) * kPkBlockBytes;
             // quads per unit of this block: three 32-bit words of four counts each, wave-uniform
             const uint32_t* hw = reinterpret_cast<const uint32_t*>(blk);
             uint32_t hdr[3];
@@ -958,8 +966,9 @@ __global__ void __launch_bounds__(kLdsThreads) k_spmm_packed(const PackedArgs pa
                     qp += kPkQuadBytes; ip += kPkQuadBytes;
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // (the buffer is overwritten two blocks from now)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // (the buffer is handed to the copy of block b + kPkRing)
             __builtin_amdgcn_wave_barrier();
+            if (nf < bend) { copy_block(nf); ++nf; }
         }
     }
     // every lane group writes its own outputs (as k_spmm_lds)
@@ -1638,6 +1647,15 @@ static int pack_residual(ddx_ctx* c, const LdsSpmmArgs& a, int own, int nsl, int
     return DDX_OK;
 }
 
+template <bool ROWS, int OWN, int RING>
+static int launch_packed_ring(ddx_ctx* c, const PackedArgs& pa, unsigned grid, size_t lds_bytes) {
+    DDX_TRY(allow_dynamic_lds(c, reinterpret_cast<const void*>(&k_spmm_packed<ROWS, OWN, RING>), (int)kLdsBudget));
+    ScopedTimer t(c, ROWS ? "spmm_rows" : "spmm_cols");
+    k_spmm_packed<ROWS, OWN, RING><<<grid, kLdsThreads, lds_bytes, c->stream>>>(pa);
+    DDX_HIP(c, hipGetLastError());
+    return DDX_OK;
+}
+
 template <bool ROWS, int OWN>
 static int launch_packed(ddx_ctx* c, const LdsSpmmArgs& a, int nsl, unsigned grid) {
     const int side = ROWS ? 0 : 1;
@@ -1647,12 +1665,15 @@ static int launch_packed(ddx_ctx* c, const LdsSpmmArgs& a, int nsl, unsigned gri
     const size_t n = (size_t)grid * kLdsWaves * (nsl + 1) + 1;
     pa.blkptr = c->pk_ptr[side].as<int32_t>() + n;
     pa.blocks = c->pk_blocks[side].as<unsigned char>();
-    const size_t lds_bytes = (((size_t)a.SR * a.ld * 4 + 15) & ~(size_t)15) + (size_t)kLdsWaves * 2 * kPkBlockBytes;
-    DDX_TRY(allow_dynamic_lds(c, reinterpret_cast<const void*>(&k_spmm_packed<ROWS, OWN>), (int)kLdsBudget));
-    ScopedTimer t(c, ROWS ? "spmm_rows" : "spmm_cols");
-    k_spmm_packed<ROWS, OWN><<<grid, kLdsThreads, lds_bytes, c->stream>>>(pa);
-    DDX_HIP(c, hipGetLastError());
-    return DDX_OK;
+    // as many block buffers per wave as fit beside the operand slice (the headline's A Q slices of 716 rows leave room for three, the
+    // 784-row slices of A^T Y for two)
+    const size_t slice_bytes = ((size_t)a.SR * a.ld * 4 + 15) & ~(size_t)15;
+#ifndef DDX_PK_RING2
+#define DDX_PK_RING2 0      // variant builds only: 1 = two buffers everywhere
+#endif
+    const bool three = !DDX_PK_RING2 && slice_bytes + (size_t)kLdsWaves * 3 * kPkBlockBytes <= (size_t)kLdsBudget;
+    if (three) return launch_packed_ring<ROWS, OWN, 3>(c, pa, grid, slice_bytes + (size_t)kLdsWaves * 3 * kPkBlockBytes);
+    return launch_packed_ring<ROWS, OWN, 2>(c, pa, grid, slice_bytes + (size_t)kLdsWaves * 2 * kPkBlockBytes);
 }
 
 static int apply_rows_wide(PcaWork& w, const double* Qcol, double* Yrow);

@@ -1095,3 +1095,62 @@ def test_second_column_selection_after_a_pca_matches_a_fresh_context():
     finally:
         a.close()
         b.close()
+
+
+def test_contexts_staging_the_same_matrix_share_one_packing(monkeypatch):
+    """dd.py:149-160 with several GPUs driven by one process (classifier.py:_stage, one leader context per GPU uploading the same
+    host matrix from its own thread): the 2-byte image is packed ONCE; the contexts that arrive while it is being packed attach
+    to the job and copy its chunks from the same pinned buffer (ddx_get_upload_form = 2) instead of sending the plain arrays.
+    Whatever route a context took, its device matrix is the caller's."""
+    import threading
+
+    from doubletdetection_amd import _lib
+    from doubletdetection_amd._synthetic import make_counts
+
+    counts = make_counts(120_000, 6000, density=0.03, seed=11)           # 21 M stored entries: a few milliseconds of packing
+    counts.data[::977] = 300.0                                            # some entries outside the 2-byte code (listed beside it)
+    monkeypatch.setitem(_lib.OPTIONS, "upload", "packed")                 # (waits for the pinned buffer instead of going plain once)
+    n_ctx = 4
+    ctxs = [_lib.Context(0) for _ in range(n_ctx)]
+    try:
+        ctxs[0].upload_raw(counts)                                        # pins the staging buffer, grows the arena
+        assert ctxs[0].upload_form() == 1
+        seen = set()
+        for attempt in range(5):
+            errors, forms = [], [None] * n_ctx
+            gate = threading.Barrier(n_ctx)
+
+            def stage(i):
+                try:
+                    gate.wait()
+                    ctxs[i].upload_raw(counts)
+                    forms[i] = ctxs[i].upload_form()
+                except Exception as err:                                  # noqa: BLE001
+                    errors.append(err)
+
+            threads = [threading.Thread(target=stage, args=(i,)) for i in range(n_ctx)]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+            assert not errors, errors
+            assert sorted(forms).count(1) >= 1, forms                     # somebody packed
+            seen.update(forms)
+            var0 = ctxs[0].gene_variances()
+            cols = np.sort(np.argsort(var0)[-400:])
+            ref = None
+            for c in ctxs:
+                np.testing.assert_array_equal(c.gene_variances(), var0)
+                c.select_columns(cols)
+                got = sp.csr_matrix(c.get_counts())
+                if ref is None:
+                    ref = got
+                    _same_csr(got, counts[:, cols].tocsr())
+                else:
+                    _same_csr(got, ref)
+            if 2 in seen:
+                break
+        assert 2 in seen, f"no context ever attached to a running packing job: {seen}"
+    finally:
+        for c in ctxs:
+            c.close()
