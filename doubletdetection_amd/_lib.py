@@ -485,6 +485,15 @@ class Context:
         self._c(self._lib.ddx_device_memory(self._h, C.byref(f), C.byref(t)))
         return f.value, t.value
 
+    def follower_bytes(self) -> int:
+        """Device memory a context that clones this one's counts starts with (stage_clone_counts, csrc/k_sparse.hip: its first chunk is
+        sized from the RESTRICTED counts -- no raw matrix, no HVG temporaries), so that the number of contexts a GPU is given
+        need not assume every follower is as large as its leader.  0 when this context holds no counts."""
+        nnz = C.c_int64(0)
+        if self._lib.ddx_get_counts_nnz(self._h, C.byref(nnz)) != 0:
+            return 0
+        return int(nnz.value) * 90 + int(getattr(self, "N", 0) or 0) * 6000 + (1 << 30)
+
     def reserve_hint(self, nbytes: int):
         """Size of the next memory chunk the context requests from the driver (0: the library's own guess)."""
         self._c(self._lib.ddx_reserve_hint(self._h, int(nbytes)))

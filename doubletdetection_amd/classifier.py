@@ -763,13 +763,22 @@ class BoostClassifier:
             free, total = ctx.device_memory()
             # a follower ends up as large as its leader (the leader's first chunk is sized for a whole fit); parked
             # contexts of earlier fits are handed out again before anything new is allocated, so they count as room
-            parked = sum(c.device_bytes() for c in _CONTEXT_POOL.get(getattr(leader, "device", None), ()))
+            pool = [c.device_bytes() for c in _CONTEXT_POOL.get(getattr(leader, "device", None), ())]
+            parked = sum(pool)
+            # a follower holds the restricted counts only (no raw matrix, no HVG temporaries): what its first chunk will be,
+            # or what the followers of the previous fit grew to (the parked contexts other than the largest)
+            fol = held
+            estimate = getattr(ctx, "follower_bytes", None)
+            if estimate is not None:
+                est = int(estimate())
+                if est > 0:
+                    fol = max(1, min(held, max([est] + sorted(pool)[:-1])))
             room = int(0.9 * (free + parked))
-            n = max(1, min(n, 1 + room // held))
+            n = max(1, min(n, 1 + room // fol))
             if _keep_contexts():
                 # what a fit allocates should also fit the allowance of the parked contexts: a context trimmed at the end
                 # of every fit obtains its memory from the driver again at the start of the next (seconds at this size)
-                n = max(1, min(n, _park_limit_bytes(total) // held))
+                n = max(1, min(n, 1 + max(0, _park_limit_bytes(total) - held) // fol))
         return int(n)
 
     @staticmethod

@@ -13,4 +13,6 @@ for i in range(n):
     clf = BoostClassifier(n_iters=10, random_state=0)
     t0 = time.perf_counter(); clf.fit(X); dt = time.perf_counter() - t0
     ht = clf._host_timings
-    print(f"fit {i}: {dt * 1e3:7.1f} ms  stage {ht['stage'] * 1e3:6.1f}  prologue {ht['prologue'] * 1e3:5.1f}  device stages {ht['device_stages'] * 1e3:6.1f}  close {ht['close'] * 1e3:5.1f}", flush=True)
+    from doubletdetection_amd import classifier as _cl
+    sizes = [round(c.device_bytes() / 2**30, 1) for d in _cl._CONTEXT_POOL.values() for c in d]
+    print(f"fit {i}: {dt * 1e3:7.1f} ms  contexts (GiB) {sizes}  stage {ht['stage'] * 1e3:6.1f}  prologue {ht['prologue'] * 1e3:5.1f}  device stages {ht['device_stages'] * 1e3:6.1f}  close {ht['close'] * 1e3:5.1f}", flush=True)

@@ -387,3 +387,23 @@ def test_contexts_per_gpu_follow_the_iterations_and_the_memory(monkeypatch):
     monkeypatch.setenv("DDX_PARK_MAX_GB", "256")
     assert clf._stream_count(10, 1, Leader(60 << 30, 140 << 30)) == 3        # two more of 60 GB, not four
     assert clf._stream_count(10, 1, Leader(100 << 30, 50 << 30)) == 1
+    # a follower holds the restricted counts only: a 38 GB leader and a 30 GB follower fit the default 72 GB (configs[3] on one GPU),
+    # two 38 GB contexts would not
+    monkeypatch.delenv("DDX_PARK_MAX_GB", raising=False)
+
+    class SizedCtx(Ctx):
+        def __init__(self, held, free, follower):
+            super().__init__(held, free)
+            self.follower = follower
+
+        def follower_bytes(self):
+            return self.follower
+
+    lead = Leader(38 << 30, 240 << 30)
+    assert clf._stream_count(10, 1, lead) == 1
+    lead.ctx = SizedCtx(38 << 30, 240 << 30, 30 << 30)
+    assert clf._stream_count(10, 1, lead) == 2
+    lead.ctx = SizedCtx(38 << 30, 240 << 30, 0)                              # no counts yet: as large as the leader
+    assert clf._stream_count(10, 1, lead) == 1
+    lead.ctx = SizedCtx(11 << 30, 240 << 30, 9 << 30)
+    assert clf._stream_count(10, 1, lead) == 5
