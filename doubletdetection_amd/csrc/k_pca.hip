@@ -835,6 +835,9 @@ __global__ void __launch_bounds__(256) k_pack_residual(const LdsSpmmArgs a, int 
     }
 }
 
+#ifndef DDX_PK_DBG
+#define DDX_PK_DBG 0        // ablation builds only (timing; wrong results): 1 no operand-slice staging, 2 no trips, 4 no block copies
+#endif
 template <bool ROWS, int OWN, int RING>
 __global__ void __launch_bounds__(kLdsThreads) k_spmm_packed(const PackedArgs pa) {
     constexpr int kPkRing = RING;       // block buffers per wave: the current block and the next RING - 1, already on their way
@@ -869,6 +872,7 @@ __global__ void __launch_bounds__(kLdsThreads) k_spmm_packed(const PackedArgs pa
     const int32_t bbeg = __builtin_amdgcn_readfirstlane(bp[0]);
     const int32_t bend = __builtin_amdgcn_readfirstlane(bp[pa.nsl]);      // (slices past the last one hold no blocks)
     auto copy_block = [&](int32_t b) {
+        if (DDX_PK_DBG & 4) return;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa.blocks + (int64_t)b * kPkBlockBytes + lane * 16),
                                          (__attribute__((address_space(3))) void*)(stg + ((b - bbeg) % kPkRing) * kPkBlockBytes), 16, 0, 0);
     };
@@ -887,9 +891,6 @@ __global__ void __launch_bounds__(kLdsThreads) k_spmm_packed(const PackedArgs pa
             const int nvec = (nr * a.ld + 3) >> 2;
             const f4v* src = reinterpret_cast<const f4v*>(a.op + r0 * a.ld);
             f4v* dst = reinterpret_cast<f4v*>(opS);
-#ifndef DDX_PK_DBG
-#define DDX_PK_DBG 0        // ablation builds only (timing; wrong results): 1 no operand-slice staging, 2 no trips
-#endif
             for (int base = wave * 64; base < nvec; base += kLdsThreads)
                 if (base + lane < nvec && !(DDX_PK_DBG & 1))
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + base + lane),
