@@ -564,8 +564,8 @@ struct PackShare {
     pid_t pid;                                               // (a forked child must not attach to its parent's job)
     int readers = 0;                                         // attached contexts still copying (g_share_mutex)
 };
-std::mutex g_share_mutex;
-std::condition_variable g_share_cv;
+std::timed_mutex g_share_mutex;              // (timed: a forked child may inherit it locked by a thread that does not exist there)
+std::condition_variable_any g_share_cv;
 PackShare* g_share = nullptr;                // the job other contexts may attach to (nullptr: none / closed)
 // (called with g_pool_mutex held.  Threads do not survive fork(): a child process builds its own pool; the parent's
 // object is abandoned there -- never joined, never freed.)
@@ -739,7 +739,8 @@ static int upload_packed(ddx_ctx* ctx, int64_t n_cells, int64_t nnz, int32_t n_g
     // to the running job when it is packing the same host arrays, and sends its copy plain, in parallel, when it is not.
     // (g_share_mutex is held from before the attempt on g_pool_mutex until the job is published: whoever fails to get the pool
     // then sees the job of whoever got it.)
-    std::unique_lock<std::mutex> share_lock(g_share_mutex);
+    std::unique_lock<std::timed_mutex> share_lock(g_share_mutex, std::chrono::milliseconds(500));
+    if (!share_lock.owns_lock()) return 1;
     std::unique_lock<std::mutex> pool_lock(g_pool_mutex, std::try_to_lock);
     if (!pool_lock.owns_lock()) {
         PackShare* sh = g_share;
