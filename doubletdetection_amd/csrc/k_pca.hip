@@ -1666,8 +1666,8 @@ static int launch_packed(ddx_ctx* c, const LdsSpmmArgs& a, int nsl, unsigned gri
     const size_t n = (size_t)grid * kLdsWaves * (nsl + 1) + 1;
     pa.blkptr = c->pk_ptr[side].as<int32_t>() + n;
     pa.blocks = c->pk_blocks[side].as<unsigned char>();
-    // as many block buffers per wave as fit beside the operand slice (the headline's A Q slices of 716 rows leave room for three, the
-    // 784-row slices of A^T Y for two)
+    // as many block buffers per wave as fit beside the operand slice: two beside the 772- / 784-row slices of the headline, three
+    // beside slices of at most 716 rows
     const size_t slice_bytes = ((size_t)a.SR * a.ld * 4 + 15) & ~(size_t)15;
 #ifndef DDX_PK_RING2
 #define DDX_PK_RING2 0      // variant builds only: 1 = two buffers everywhere
