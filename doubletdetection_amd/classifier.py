@@ -345,8 +345,8 @@ class BoostClassifier:
         devices: list of GPU ordinals driven by THIS process (one host thread and at least one device context per GPU;
             boosting iterations are dealt out over them).  Default: ``[device]``.
         streams_per_device: device contexts (HIP streams) per GPU, each running its own boosting iterations; the
-            once-per-fit prologue is shared by device-to-device copies.  Default: up to 5, evened out over the iterations and
-            bounded by the GPU's memory (``DDX_STREAMS`` overrides).
+            once-per-fit prologue is shared by device-to-device copies.  Default: up to 7 (one per iteration when the GPU has
+            fewer to run), bounded by the GPU's memory (``DDX_STREAMS`` overrides).
 
     Attributes after ``fit`` / ``predict``: ``all_log_p_values_``, ``all_scores_``, ``communities_``,
     ``labels_``, ``parents_``, ``suggested_score_cutoff_``, ``synth_communities_``, ``top_var_genes_``,
@@ -738,13 +738,17 @@ class BoostClassifier:
             return min(32, cores)
         return max(1, min(int(self.n_jobs), cores) if world > 1 else int(self.n_jobs))
 
-    _AUTO_STREAMS = 5
+    _AUTO_STREAMS = 7
 
     def _stream_count(self, n_mine=None, n_devices=1, leader=None):
-        """Device contexts per GPU.  An explicit ``streams_per_device`` / ``DDX_STREAMS`` is taken as it is.  Otherwise: up to
-        five -- with five the iterations overlap down to the sum of their GPU-filling kernels (two contexts leave 3 % on
-        the table at the benchmark shape) --, evened out over the rounds the share of iterations needs (10 iterations: 5
-        contexts x 2, 6 iterations: 3 x 2, not 5 + 1), and no more than the GPU's memory holds beside the leader."""
+        """Device contexts per GPU.  An explicit ``streams_per_device`` / ``DDX_STREAMS`` is taken as it is.  Otherwise: one per
+        iteration the GPU has to run, up to seven, and no more than the GPU's memory and the parking allowance hold beside the
+        leader.  Measured at the headline shape at the end of round 5 (ms per fit, same box, alternating): 10 iterations on
+        5 / 6 / 7 / 8 contexts 120 / 122 / 114 / 118, 25 iterations on 5 / 7 / 8 contexts 282 / 263 / 269, 6 iterations on 3 / 6
+        contexts 84 / 82 -- the iterations of a round run in step (all in their PCA, then all in their kNN); uneven shares
+        (7 contexts: 3 x 2 + 4 x 1 iterations) pull them apart, and kernels that do not compete for the same unit overlap
+        better.  (Rounds 3-4 evened the shares out -- 10 iterations: 5 x 2 -- when a product kernel filled every CU's LDS and
+        the contexts took turns at the PCA anyway.)"""
         n = self.streams_per_device
         if n is None and "DDX_STREAMS" in os.environ:
             n = int(os.environ["DDX_STREAMS"])
@@ -755,8 +759,7 @@ class BoostClassifier:
         if n_mine is None:
             return self._AUTO_STREAMS
         per_device = max(1, -(-int(n_mine) // max(1, n_devices)))          # iterations a GPU has to run
-        rounds = -(-per_device // self._AUTO_STREAMS)
-        n = -(-per_device // rounds)
+        n = min(self._AUTO_STREAMS, per_device)
         ctx = getattr(leader, "ctx", None)
         if ctx is not None and hasattr(ctx, "device_memory"):
             held = max(1, ctx.device_bytes())

@@ -347,11 +347,11 @@ def test_lanes_do_not_change_results(monkeypatch, devices, streams):
 
 
 def test_contexts_per_gpu_follow_the_iterations_and_the_memory(monkeypatch):
-    """streams_per_device=None: up to five contexts per GPU, evened out over the rounds a GPU's share of the iterations
-    (dd.py:192-198) needs, and never more than the GPU's memory holds beside the leader; explicit settings are kept."""
+    """streams_per_device=None: one context per iteration of a GPU's share (dd.py:192-198), up to seven, and never more than
+    the GPU's memory and the parking allowance hold beside the leader; explicit settings are kept."""
     monkeypatch.delenv("DDX_STREAMS", raising=False)
     clf = BoostClassifier()
-    assert [clf._stream_count(n) for n in (1, 2, 4, 5, 6, 7, 10, 11, 25, 50)] == [1, 2, 4, 5, 3, 4, 5, 4, 5, 5]
+    assert [clf._stream_count(n) for n in (1, 2, 4, 5, 6, 7, 10, 11, 25, 50)] == [1, 2, 4, 5, 6, 7, 7, 7, 7, 7]
     assert clf._stream_count(10, n_devices=2) == 5 and clf._stream_count(10, n_devices=4) == 3
     assert BoostClassifier(streams_per_device=2)._stream_count(10) == 2
     monkeypatch.setenv("DDX_STREAMS", "3")
@@ -377,13 +377,13 @@ def test_contexts_per_gpu_follow_the_iterations_and_the_memory(monkeypatch):
             self.ctx = Ctx(held, free)
 
     monkeypatch.delenv("DDX_PARK_MAX_GB", raising=False)
-    assert clf._stream_count(10, 1, Leader(12 << 30, 240 << 30)) == 5        # default allowance: a quarter of the GPU (72 GB)
+    assert clf._stream_count(10, 1, Leader(12 << 30, 240 << 30)) == 6        # default allowance: a quarter of the GPU (72 GB)
     assert clf._stream_count(10, 1, Leader(30 << 30, 240 << 30)) == 2
     monkeypatch.setenv("DDX_PARK_MAX_GB", "256")
-    assert clf._stream_count(10, 1, Leader(40 << 30, 240 << 30)) == 5        # 4 followers of 40 GB fit into 216 GB
+    assert clf._stream_count(10, 1, Leader(40 << 30, 240 << 30)) == 6        # 5 followers of 40 GB fit into 216 GB
     monkeypatch.setenv("DDX_PARK_MAX_GB", "128")
     assert clf._stream_count(10, 1, Leader(40 << 30, 240 << 30)) == 3        # ... but only three such contexts can stay parked
-    assert clf._stream_count(10, 1, Leader(12 << 30, 240 << 30)) == 5
+    assert clf._stream_count(10, 1, Leader(12 << 30, 240 << 30)) == 7
     monkeypatch.setenv("DDX_PARK_MAX_GB", "256")
     assert clf._stream_count(10, 1, Leader(60 << 30, 140 << 30)) == 3        # two more of 60 GB, not four
     assert clf._stream_count(10, 1, Leader(100 << 30, 50 << 30)) == 1
@@ -406,4 +406,4 @@ def test_contexts_per_gpu_follow_the_iterations_and_the_memory(monkeypatch):
     lead.ctx = SizedCtx(38 << 30, 240 << 30, 0)                              # no counts yet: as large as the leader
     assert clf._stream_count(10, 1, lead) == 1
     lead.ctx = SizedCtx(11 << 30, 240 << 30, 9 << 30)
-    assert clf._stream_count(10, 1, lead) == 5
+    assert clf._stream_count(10, 1, lead) == 7
