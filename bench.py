@@ -64,6 +64,25 @@ def _cpu_full():
         return None
 
 
+def cpu_allowance():
+    """CPUs' worth of time the container may use (cgroup CFS quota), or None when there is no limit.  A pod can show 256 CPUs and be
+    allowed 16: threads beyond the allowance are throttled, so the CPU baseline is run on -- and reported with -- the allowance."""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            return max(1, int(int(quota) / int(period)))
+    except Exception:
+        pass
+    try:
+        quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if quota > 0:
+            return max(1, quota // period)
+    except Exception:
+        pass
+    return None
+
+
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md)
 LDS_PEAK_GBS = 256 * 128 * 2.4     # 256 CUs x 128 bytes per clock x 2.4 GHz = 78.6 TB/s of LDS reads (MI355X_MICROARCH.md)
 FP64_PEAK_TFLOPS = 78.6      # FP64 vector / FP64 MFMA peak, dense
@@ -365,7 +384,7 @@ def main():
                        "n_iters": args.iters,
                        "sharding": f"iterations over {world} rank(s) x {getattr(clf, '_lanes_used', 1)} device context(s) "
                                    "(streams) per GPU",
-                       "host_threads": os.cpu_count()},
+                       "host_threads": os.cpu_count(), "host_cpu_allowance": cpu_allowance()},
             "roofline": roofline,
             "roofline_dominant_kernel": roofline_single,
             "roofline_top_kernels": roofline_all,
@@ -405,6 +424,8 @@ def cpu_baseline(X, args, kw):
     from doubletdetection_amd import _lib
     from oracle import dd_oracle as orc
 
+    allowed = cpu_allowance()
+    cores = min(os.cpu_count() or 1, allowed) if allowed else (os.cpu_count() or 1)
     n = X.shape[0] if args.cpu_full else min(args.cpu_sample_cells, X.shape[0])
     rows = np.sort(np.random.default_rng(0).choice(X.shape[0], size=n, replace=False))
     sample = X[rows]
@@ -414,18 +435,40 @@ def cpu_baseline(X, args, kw):
         return _lib.louvain(indptr, indices, weights, gamma, seed)[0].astype(np.int64)
 
     def native_best_of(indptr, indices, weights, gamma, seed, q_tol):
-        return _lib.louvain_best_of(indptr, indices, weights, gamma, seed, q_tol, threads=min(20, os.cpu_count() or 1))[0].astype(np.int64)
+        return _lib.louvain_best_of(indptr, indices, weights, gamma, seed, q_tol, threads=min(20, cores))[0].astype(np.int64)
+
+    def knn_allowed_cores(emb, k, include_self):
+        # sklearn's exact search on the cores the container may use (n_jobs=-1 would start one job per VISIBLE CPU)
+        from sklearn.neighbors import NearestNeighbors
+
+        kk = k if include_self else k + 1
+        nn = NearestNeighbors(n_neighbors=kk, algorithm="kd_tree" if not include_self else "brute", n_jobs=cores).fit(emb)
+        dist, idx = nn.kneighbors(emb)
+        if not include_self:
+            idx, dist = idx[:, 1:], dist[:, 1:]
+        return idx, dist
 
     okw = dict(n_iters=iters, clustering_algorithm=kw["clustering_algorithm"], standard_scaling=kw["standard_scaling"],
-               random_state=0, louvain_fn=native_louvain, best_of_fn=native_best_of, knn_fn=orc._knn_sklearn_all_cores)
+               random_state=0, louvain_fn=native_louvain, best_of_fn=native_best_of,
+               knn_fn=knn_allowed_cores if allowed else orc._knn_sklearn_all_cores)
+    import contextlib
+
+    limit = contextlib.nullcontext()
+    if allowed:
+        try:
+            from threadpoolctl import threadpool_limits
+
+            limit = threadpool_limits(limits=cores)         # BLAS / OpenMP pools sized for the allowance, not for the visible CPUs
+        except Exception:
+            pass
     t0 = time.perf_counter()
-    with warnings.catch_warnings():
+    with warnings.catch_warnings(), limit:
         warnings.simplefilter("ignore")
         o = orc.OracleClassifier(**okw).fit(sample)
     dt = time.perf_counter() - t0
     per_iter = (dt - o.timings["prologue"]) / iters
     full_fit = o.timings["prologue"] + per_iter * args.iters     # iterations are identical work
-    return {"value": round(n / full_fit, 2), "unit": "cells/s", "cores": os.cpu_count(), "kind": "port",
+    return {"value": round(n / full_fit, 2), "unit": "cells/s", "cores": cores, "cpus_visible": os.cpu_count(), "cpu_allowance": allowed, "kind": "port",
             "sample": f"{n} of {X.shape[0]} cells x {X.shape[1]} genes, {iters} iterations timed ({dt:.1f} s) and scaled to "
                       f"n_iters={args.iters}; dense log matrix + sklearn randomized PCA + exact kNN + host Louvain.  "
                       + ("All cells (SURVEY.md section 8 d)." if args.cpu_full else

@@ -304,6 +304,20 @@ int ddx_create(int device, ddx_ctx** out) {
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return set_err(nullptr, DDX_E_UNSUPPORTED, "libddx is built for gfx950 only; device %d is %s", device,
                        prop.gcnArchName);
+    {
+        // Host threads that wait for this GPU sleep on an interrupt instead of spinning (the runtime's choice with few devices): a fit
+        // keeps up to seven threads waiting -- 0.85 s of CPU time per 0.12 s fit spinning, 0.4 - 0.5 s blocking, and not a millisecond
+        // slower (profiles/tools/cpu_quota_check.py) --, and the pods these GPUs come in have a CPU allowance far below the CPUs they
+        // show.  Once per device and process; ddx_set_option(ctx, "host_wait", "spin") changes it back.
+        static std::mutex once_mutex;
+        static std::vector<char> done;
+        std::lock_guard<std::mutex> lock(once_mutex);
+        if ((int)done.size() < n) done.resize((size_t)n, 0);
+        if (!done[device]) {
+            done[device] = 1;
+            if (hipSetDeviceFlags(hipDeviceScheduleBlockingSync) != hipSuccess) (void)hipGetLastError();
+        }
+    }
     ddx_ctx* c = new (std::nothrow) ddx_ctx();
     if (!c) return set_err(nullptr, DDX_E_NOMEM, "out of host memory");
     c->device = device;
@@ -1239,6 +1253,17 @@ int ddx_pca_exact_sparse(ddx_ctx* ctx, int32_t n_components, int32_t n_oversampl
 int ddx_set_option(ddx_ctx* ctx, const char* key, const char* value) {
     REQUIRE_CTX(ctx);
     if (!key) return set_err(ctx, DDX_E_ARG, "ddx_set_option: no key");
+    if (std::string(key) == "host_wait") {
+        // how host threads wait for the GPU (a property of the device in this process, not of the context): "spin" (the runtime's
+        // default with few devices: lowest latency, one busy CPU per waiting thread) or "block" (the waiting thread sleeps on an
+        // interrupt: what a rank should use when the host's CPU allowance is smaller than the number of waiting threads)
+        const std::string v = value ? value : "";
+        if (v != "spin" && v != "block" && v != "yield" && v != "auto") return set_err(ctx, DDX_E_ARG, "ddx_set_option: host_wait = spin | yield | block | auto");
+        USE_DEVICE(ctx);
+        const unsigned flag = v == "spin" ? hipDeviceScheduleSpin : v == "yield" ? hipDeviceScheduleYield : v == "block" ? hipDeviceScheduleBlockingSync : hipDeviceScheduleAuto;
+        DDX_HIP(ctx, hipSetDeviceFlags(flag));
+        return DDX_OK;
+    }
     if (!ctx->opt.set(key, value)) return set_err(ctx, DDX_E_ARG, "ddx_set_option: unknown key or value '%s' = '%s'", key, value ? value : "");
     return DDX_OK;
 }

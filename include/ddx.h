@@ -75,6 +75,9 @@ int ddx_synchronize(ddx_ctx* ctx);
  *   upload            auto | plain | packed | packed32   transfer form of ddx_upload_raw (auto: 2-byte form once the pinned
  *                                       buffer exists, plain until then; packed / packed32 wait for the buffer)
  *   upload_debug      0 | 1 | 2         timings of the upload on stderr
+ *   host_wait         block | spin | yield | auto   how host threads wait for the context's GPU (hipSetDeviceFlags: a property of the
+ *                                       device in this process, not of the context).  libddx's default is block: a waiting thread
+ *                                       sleeps instead of keeping a CPU busy (half the CPU time of a fit, no slower)
  *   hvg_fold          1 | 0             gene sums folded in while the packed matrix arrives
  *   row_sums          auto | sequential replay scipy's sequential float32 row sums even for exact integer counts
  *   knn_cells         n                 cells of the kNN pruning structure (0 = by size, 1 = first-component windows only)
