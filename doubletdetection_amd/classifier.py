@@ -601,7 +601,7 @@ class BoostClassifier:
         if "DDX_UPLOAD_THREADS" not in os.environ:
             # every rank packs its own copy of the matrix for the upload: share the host cores (one node assumed).
             # Passed through the C-ABI (the pool is resized when the figure changes); the environment is not touched.
-            _lib.set_upload_threads(max(4, min(48, (os.cpu_count() or 8) // (2 * world))) if world > 1 else 0)
+            _lib.set_upload_threads(max(4, min(16, (os.cpu_count() or 8) // (2 * world))) if world > 1 else 0)
         staged = getattr(self, "_staged", None)
         drawer = ThreadPoolExecutor(max_workers=1)
         draws = None

@@ -585,7 +585,10 @@ PackShare* g_share = nullptr;                // the job other contexts may attac
 // object is abandoned there -- never joined, never freed.)
 WorkerPool* upload_pool() {
     unsigned hw = std::thread::hardware_concurrency();
-    unsigned n = std::max(4u, std::min(48u, hw ? hw / 2 : 8u));      // 48 threads pack 93 M entries in 6 ms, 24 in 10 ms
+    // 16 threads: the packing is bound by the host's memory system, not by the number of threads (8 / 16 / 48 threads: 6.7 / 6.9 / 6.6 ms
+    // per upload at the headline shape at the end of round 5), and 48 threads burn 0.24 s of CPU time per upload against 0.1 s --
+    // which counts where the container's CPU allowance is a fraction of the CPUs it shows (profiles/tools/cpu_quota_check.py)
+    unsigned n = std::max(4u, std::min(16u, hw ? hw / 2 : 8u));
     if (const int req = g_upload_threads.load()) n = (unsigned)req;
     if (g_pool && g_pool_pid == getpid() && g_pool->size() != (int)n) { delete g_pool; g_pool = nullptr; }   // resized on request
     if (!g_pool || g_pool_pid != getpid()) {
