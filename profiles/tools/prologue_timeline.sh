@@ -1,4 +1,4 @@
-# kernels of the LAST fit of a short bench run from its first kernel to the first doublet fill (the per-fit fixed part), with start
+# kernels of the LAST fit of a short bench run from its first kernel to the first doublet kernel (the per-fit fixed part), with start
 # times relative to the first, and the largest gaps:  bash profiles/tools/prologue_timeline.sh <tag>
 set -u
 tag=${1:-r05x}
@@ -20,10 +20,10 @@ except Exception as e:
 rows.sort()
 starts = [a for a, b, n in rows if "k_validate_csr" in n]
 t0 = starts[-1]
-fills = [a for a, b, n in rows if "k_doublet_fill" in n and a > t0]
+fills = [a for a, b, n in rows if ("k_bp_synth" in n or "k_doublet_fill" in n) and a > t0]
 t1 = fills[0] if fills else rows[-1][1]
 sel = [(a, b, n) for a, b, n in rows if t0 - 12_000_000 <= a <= t1 + 1_000_000]
-print(f"validate_csr -> first doublet fill: {(t1 - t0) / 1e6:.2f} ms")
+print(f"validate_csr -> first doublet kernel: {(t1 - t0) / 1e6:.2f} ms")
 prev_end = None
 for a, b, n in sel:
     gap = (a - prev_end) / 1e3 if prev_end else 0.0
