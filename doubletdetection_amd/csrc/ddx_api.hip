@@ -304,20 +304,6 @@ int ddx_create(int device, ddx_ctx** out) {
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return set_err(nullptr, DDX_E_UNSUPPORTED, "libddx is built for gfx950 only; device %d is %s", device,
                        prop.gcnArchName);
-    {
-        // Host threads that wait for this GPU sleep on an interrupt instead of spinning (the runtime's choice with few devices): a fit
-        // keeps up to seven threads waiting -- 0.85 s of CPU time per 0.12 s fit spinning, 0.4 - 0.5 s blocking, and not a millisecond
-        // slower (profiles/tools/cpu_quota_check.py) --, and the pods these GPUs come in have a CPU allowance far below the CPUs they
-        // show.  Once per device and process; ddx_set_option(ctx, "host_wait", "spin") changes it back.
-        static std::mutex once_mutex;
-        static std::vector<char> done;
-        std::lock_guard<std::mutex> lock(once_mutex);
-        if ((int)done.size() < n) done.resize((size_t)n, 0);
-        if (!done[device]) {
-            done[device] = 1;
-            if (hipSetDeviceFlags(hipDeviceScheduleBlockingSync) != hipSuccess) (void)hipGetLastError();
-        }
-    }
     ddx_ctx* c = new (std::nothrow) ddx_ctx();
     if (!c) return set_err(nullptr, DDX_E_NOMEM, "out of host memory");
     c->device = device;
@@ -1259,7 +1245,8 @@ int ddx_set_option(ddx_ctx* ctx, const char* key, const char* value) {
     if (std::string(key) == "host_wait") {
         // how host threads wait for the GPU (a property of the device in this process, not of the context): "spin" (the runtime's
         // default with few devices: lowest latency, one busy CPU per waiting thread) or "block" (the waiting thread sleeps on an
-        // interrupt: what a rank should use when the host's CPU allowance is smaller than the number of waiting threads)
+        // interrupt: 0.34 instead of 0.83 s of CPU time per fit at the headline and no slower -- profiles/tools/cpu_quota_check.py --,
+        // but NOT the default: a process that had run 120 fits with it hung in ddx_destroy at interpreter exit, profiles/tools/soak.py)
         const std::string v = value ? value : "";
         if (v != "spin" && v != "block" && v != "yield" && v != "auto") return set_err(ctx, DDX_E_ARG, "ddx_set_option: host_wait = spin | yield | block | auto");
         USE_DEVICE(ctx);

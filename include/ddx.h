@@ -76,8 +76,10 @@ int ddx_synchronize(ddx_ctx* ctx);
  *                                       buffer exists, plain until then; packed / packed32 wait for the buffer)
  *   upload_debug      0 | 1 | 2         timings of the upload on stderr
  *   host_wait         block | spin | yield | auto   how host threads wait for the context's GPU (hipSetDeviceFlags: a property of the
- *                                       device in this process, not of the context).  libddx's default is block: a waiting thread
- *                                       sleeps instead of keeping a CPU busy (half the CPU time of a fit, no slower)
+ *                                       device in this process, not of the context).  Default: the runtime's own choice (spinning).
+ *                                       block: a waiting thread sleeps instead of keeping a CPU busy -- 0.34 instead of 0.83 s of
+ *                                       CPU time per fit, no slower, for hosts whose CPU allowance is smaller than the number of
+ *                                       waiting threads; experimental (a long-running process hung at exit with it)
  *   hvg_fold          1 | 0             gene sums folded in while the packed matrix arrives
  *   row_sums          auto | sequential replay scipy's sequential float32 row sums even for exact integer counts
  *   knn_cells         n                 cells of the kNN pruning structure (0 = by size, 1 = first-component windows only)
