@@ -64,6 +64,10 @@ void arena_hint(ddx_ctx* ctx, size_t bytes) {
 // handed out again from the start).  Called by the entry points that make counts resident.
 void context_reset(ddx_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
+    {
+        std::lock_guard<std::mutex> lock(ctx->view_mu);       // the buffers the view points into are about to be handed out again
+        ctx->view = ddx::CloneView();
+    }
     ctx->hvg_rows = -1;
     DevBuf* bufs[] = {&ctx->raw_indptr, &ctx->raw_indices, &ctx->raw_data, &ctx->raw_packed, &ctx->hvg_state, &ctx->hvg_keys, &ctx->hvg_vals, &ctx->hvg_colptr, &ctx->aug_indptr, &ctx->aug_indices,
                       &ctx->aug_raw, &ctx->aug_x, &ctx->lib32, &ctx->lib64, &ctx->synth_counts, &ctx->parents, &ctx->pad_off,
@@ -947,11 +951,11 @@ int ddx_upload_counts(ddx_ctx* ctx, int64_t n_cells, int32_t n_genes, const int6
 int ddx_clone_counts(ddx_ctx* ctx, ddx_ctx* src) {
     REQUIRE_CTX(ctx);
     NEED(src && src != ctx, "source context must be another context");
-    NEED(src->have_counts, "source context holds no counts");
     if (src->device != ctx->device)
         return set_err(ctx, DDX_E_UNSUPPORTED, "ddx_clone_counts: contexts live on different GPUs (%d, %d)", ctx->device, src->device);
     USE_DEVICE(ctx);
-    DDX_HIP(ctx, hipStreamSynchronize(src->stream));
+    // (no wait on the source's stream: what is copied was complete when the source published it -- CloneView --, and the source may be
+    // running its own iterations on another host thread by now)
     context_reset(ctx);
     return stage_clone_counts(ctx, src);
 }

@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <memory>
 #include <vector>
@@ -115,6 +116,24 @@ struct BitPlanes {
     double* cmax = nullptr;          // [2][64] column maxima of the operand: Q side, Y side
     const double* ymax_of = nullptr; // the row-side matrix whose maxima (of diag(s) Y) the sparse A Q kernel has just left in cmax[64..]
     double* part = nullptr;          // partial blocks of the A^T Y product, one per chunk of the rows
+};
+
+// What another context of the same GPU copies when it takes over a context's resident counts (ddx_clone_counts, dd.py:178-184's
+// memoised inputs).  Published under ddx_ctx::view_mu when the counts have become resident (end of stage_upload_counts) and
+// withdrawn when the context starts its next fit.  Contract: the device pointers stay valid, and the bytes a follower copies from
+// them stay constant, for as long as the view is valid -- a buffer that has to grow while the fit runs is ABANDONED to the arena
+// (ensure_keep; bp_refresh's rebuild), never released for reuse, and later changes of the context (a full mirror built on demand,
+// rebuilt bit planes) do not touch the view.  So the source may be in the middle of its iterations while followers copy.
+struct CloneView {
+    bool valid = false;
+    int64_t N = 0, nnz = 0;
+    int32_t H = 0, panel_rows = 0, P_o = 0;
+    bool counts_exact = false, mirror_o = false;
+    const void *aug_indptr = nullptr, *aug_indices = nullptr, *aug_raw = nullptr, *lib32 = nullptr, *lib64 = nullptr;
+    const void *csc_o_colptr = nullptr, *csc_o_row = nullptr, *csc_o_raw = nullptr;
+    std::vector<int64_t> h_indptr;
+    BitPlanes bp;                    // the per-fit structures as they stood at publication (pointers into bp_buf)
+    const void* bp_buf = nullptr;
 };
 
 struct TimingRec {
@@ -242,6 +261,8 @@ struct ddx_ctx {
     bool mirror_o = false;           // csc_o_colptr / _row / _raw hold the original rows' full mirror (bit-plane route: built when somebody asks)
     bool mirror_full = false;        // csc_s_* and csc_*_x hold this iteration's full mirror (the bit-plane route leaves it out: ensure_full_mirror)
     ddx::BitPlanes bp;
+    ddx::CloneView view;             // what followers copy (see CloneView); guarded by view_mu
+    std::mutex view_mu;
     const int32_t* knn_overflow = nullptr;   // device counter: queries whose candidate list overflowed (exact rescan)
     const int32_t* knn_ccount = nullptr;     // candidates listed per query (kNN point order) and that order (views into the kNN work space)
     const int32_t* knn_perm = nullptr;
@@ -361,7 +382,8 @@ __device__ __forceinline__ int small_count(float v, int kmax) {       // 1..kmax
 // ---- stage entry points implemented in the .hip files ------------------------------------------
 int stage_upload_counts(ddx_ctx* ctx, int64_t N, int32_t H, const int64_t* indptr, const int32_t* indices,
                         const float* data, bool from_device);
-int stage_clone_counts(ddx_ctx* ctx, const ddx_ctx* src);
+int stage_clone_counts(ddx_ctx* ctx, ddx_ctx* src);
+void publish_clone_view(ddx_ctx* ctx);
 int stage_create_doublets(ddx_ctx* ctx, int64_t S, const int64_t* parents);
 int stage_lognormalise(ddx_ctx* ctx, float pseudocount);
 int stage_scale(ddx_ctx* ctx, float max_value);
@@ -397,7 +419,7 @@ bool bp_lean(const ddx_ctx* ctx);              // this context's iterations deri
 int bp_reduced_mirrors(ddx_ctx* ctx);
 int bp_originals_mirror(ddx_ctx* ctx);
 int bp_colmean(ddx_ctx* ctx, const double* parts, int nparts);
-int bp_clone(ddx_ctx* ctx, const ddx_ctx* src);
+int bp_clone(ddx_ctx* ctx, const CloneView& src);
 bool bp_wanted_at_upload(const ddx_ctx* ctx);
 int bp_refresh(ddx_ctx* ctx);
 int bp_rows_product(ddx_ctx* ctx, const double* Q, int L, double* Y);

@@ -671,13 +671,15 @@ int bp_synth_libs(ddx_ctx* ctx) {
 
 // The per-fit structures of another context of the same GPU, device to device (a follower of the fit: building them again
 // would cost every context the passes over all stored entries).
-int bp_clone(ddx_ctx* ctx, const ddx_ctx* src) {
+int bp_clone(ddx_ctx* ctx, const CloneView& src) {
     ctx->bp = BitPlanes();
-    if (!src->bp.ready) return DDX_OK;
-    DDX_TRY(ensure(ctx, ctx->bp_buf, src->bp.buf_bytes));
-    DDX_HIP(ctx, hipMemcpyAsync(ctx->bp_buf.p, src->bp_buf.p, src->bp.buf_bytes, hipMemcpyDeviceToDevice, ctx->stream));
-    BitPlanes bp = src->bp;
-    const ptrdiff_t delta = ctx->bp_buf.as<char>() - src->bp_buf.as<char>();
+    if (!src.bp.ready) return DDX_OK;
+    DDX_TRY(ensure(ctx, ctx->bp_buf, src.bp.buf_bytes));
+    // (the parts of the buffer the source rewrites every iteration -- reduced values, row scales, the synthetic rows' bitmaps and reduced
+    // entries -- may arrive torn: this context's own bp_refresh rewrites every one of them before anything reads them)
+    DDX_HIP(ctx, hipMemcpyAsync(ctx->bp_buf.p, src.bp_buf, src.bp.buf_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    BitPlanes bp = src.bp;
+    const ptrdiff_t delta = ctx->bp_buf.as<char>() - reinterpret_cast<const char*>(src.bp_buf);
     auto move = [&](auto*& p) { if (p) p = reinterpret_cast<std::remove_reference_t<decltype(p)>>(reinterpret_cast<char*>(p) + delta); };
     move(bp.bm_rows); move(bp.bm_cols); move(bp.rest_indptr); move(bp.rest_cols); move(bp.rest_row); move(bp.rest_raw); move(bp.rest_x);
     move(bp.restm_colptr); move(bp.restm_row); move(bp.restm_raw); move(bp.restm_x); move(bp.srow);

@@ -789,7 +789,8 @@ static int build_csc_sorted(ddx_ctx* ctx, const MirrorSrc& src, int64_t e0, int6
     return DDX_OK;
 }
 
-// grow a buffer while keeping its first keep_bytes
+// grow a buffer while keeping its first keep_bytes.  The old block is abandoned to the arena (handed out again when the context is
+// reset for its next fit), not released: a follower context may be copying the original cells' part of it at this moment (CloneView)
 static int ensure_keep(ddx_ctx* ctx, DevBuf& b, size_t bytes, size_t keep_bytes) {
     if (bytes <= b.cap && b.p) return DDX_OK;
     DevBuf nb;
@@ -802,7 +803,6 @@ static int ensure_keep(ddx_ctx* ctx, DevBuf& b, size_t bytes, size_t keep_bytes)
             return set_err(ctx, DDX_E_HIP, "device copy during growth failed: %s", hipGetErrorString(e));
         }
     }
-    release(ctx, b);
     b = nb;
     return DDX_OK;
 }
@@ -899,15 +899,39 @@ int stage_upload_counts(ddx_ctx* ctx, int64_t N, int32_t H, const int64_t* indpt
     }
     DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->have_counts = true;
+    publish_clone_view(ctx);
     return DDX_OK;
+}
+
+// the resident counts are complete (the stream has been drained): what followers may copy from now on, see CloneView
+void publish_clone_view(ddx_ctx* ctx) {
+    std::lock_guard<std::mutex> lock(ctx->view_mu);
+    CloneView& v = ctx->view;
+    v.N = ctx->N; v.nnz = ctx->nnz; v.H = ctx->H; v.panel_rows = ctx->panel_rows; v.P_o = ctx->P_o;
+    v.counts_exact = ctx->counts_exact; v.mirror_o = ctx->mirror_o;
+    v.aug_indptr = ctx->aug_indptr.p; v.aug_indices = ctx->aug_indices.p; v.aug_raw = ctx->aug_raw.p;
+    v.lib32 = ctx->lib32.p; v.lib64 = ctx->lib64.p;
+    v.csc_o_colptr = ctx->csc_o_colptr.p; v.csc_o_row = ctx->csc_o_row.p; v.csc_o_raw = ctx->csc_o_raw.p;
+    v.h_indptr = ctx->h_indptr;
+    v.bp = ctx->bp;
+    v.bp_buf = ctx->bp_buf.p;
+    v.valid = true;
 }
 
 // ------------------------------------------------------------------------------------------------
 // stage: clone the resident counts of another context on the same GPU (device-to-device)
 // ------------------------------------------------------------------------------------------------
-int stage_clone_counts(ddx_ctx* ctx, const ddx_ctx* src) {
-    const int64_t N = src->N, nnz = src->nnz;
-    const int32_t H = src->H;
+int stage_clone_counts(ddx_ctx* ctx, ddx_ctx* src) {
+    // everything is read from the view the source published when its counts became resident -- never from the source's live state, which
+    // its own iterations may be changing on another thread at this moment
+    CloneView v;
+    {
+        std::lock_guard<std::mutex> lock(src->view_mu);
+        v = src->view;
+    }
+    if (!v.valid) return set_err(ctx, DDX_E_ARG, "source context holds no counts");
+    const int64_t N = v.N, nnz = v.nnz;
+    const int32_t H = v.H;
     const int64_t cap_s = nnz / 2 + nnz / 8 + 1024;
     ctx->have_counts = false;
     arena_hint(ctx, (size_t)nnz * 90 + (size_t)N * 6000 + ((size_t)1 << 30));
@@ -917,43 +941,44 @@ int stage_clone_counts(ddx_ctx* ctx, const ddx_ctx* src) {
     DDX_TRY(ensure(ctx, ctx->aug_x, sizeof(float) * (size_t)(nnz + cap_s)));
     DDX_TRY(ensure(ctx, ctx->lib32, sizeof(float) * (N + N / 2 + 2)));
     DDX_TRY(ensure(ctx, ctx->lib64, sizeof(double) * (N + N / 2 + 2)));
-    const size_t cp_bytes = sizeof(int64_t) * ((size_t)src->P_o * H + 1);
-    if (src->mirror_o) {
+    const size_t cp_bytes = sizeof(int64_t) * ((size_t)v.P_o * H + 1);
+    if (v.mirror_o) {
         DDX_TRY(ensure(ctx, ctx->csc_o_row, sizeof(int32_t) * (size_t)(nnz + 1)));
         DDX_TRY(ensure(ctx, ctx->csc_o_raw, sizeof(float) * (size_t)(nnz + 1)));
         DDX_TRY(ensure(ctx, ctx->csc_o_x, sizeof(float) * (size_t)(nnz + 1)));
         DDX_TRY(ensure(ctx, ctx->csc_o_colptr, cp_bytes));
     }
     DDX_TRY(ensure(ctx, ctx->median, 256));
-    auto copy = [&](DevBuf& d, const DevBuf& s, size_t bytes) -> hipError_t {
-        return bytes ? hipMemcpyAsync(d.p, s.p, bytes, hipMemcpyDeviceToDevice, ctx->stream) : hipSuccess;
+    auto copy = [&](DevBuf& d, const void* s, size_t bytes) -> hipError_t {
+        return bytes ? hipMemcpyAsync(d.p, s, bytes, hipMemcpyDeviceToDevice, ctx->stream) : hipSuccess;
     };
-    DDX_HIP(ctx, copy(ctx->aug_indptr, src->aug_indptr, sizeof(int64_t) * (N + 1)));
-    DDX_HIP(ctx, copy(ctx->aug_indices, src->aug_indices, sizeof(int32_t) * nnz));
-    DDX_HIP(ctx, copy(ctx->aug_raw, src->aug_raw, sizeof(float) * nnz));
-    DDX_HIP(ctx, copy(ctx->lib32, src->lib32, sizeof(float) * N));
-    DDX_HIP(ctx, copy(ctx->lib64, src->lib64, sizeof(double) * N));
-    if (src->mirror_o) {
-        DDX_HIP(ctx, copy(ctx->csc_o_colptr, src->csc_o_colptr, cp_bytes));
-        DDX_HIP(ctx, copy(ctx->csc_o_row, src->csc_o_row, sizeof(int32_t) * nnz));
-        DDX_HIP(ctx, copy(ctx->csc_o_raw, src->csc_o_raw, sizeof(float) * nnz));
+    DDX_HIP(ctx, copy(ctx->aug_indptr, v.aug_indptr, sizeof(int64_t) * (N + 1)));
+    DDX_HIP(ctx, copy(ctx->aug_indices, v.aug_indices, sizeof(int32_t) * nnz));
+    DDX_HIP(ctx, copy(ctx->aug_raw, v.aug_raw, sizeof(float) * nnz));
+    DDX_HIP(ctx, copy(ctx->lib32, v.lib32, sizeof(float) * N));
+    DDX_HIP(ctx, copy(ctx->lib64, v.lib64, sizeof(double) * N));
+    if (v.mirror_o) {
+        DDX_HIP(ctx, copy(ctx->csc_o_colptr, v.csc_o_colptr, cp_bytes));
+        DDX_HIP(ctx, copy(ctx->csc_o_row, v.csc_o_row, sizeof(int32_t) * nnz));
+        DDX_HIP(ctx, copy(ctx->csc_o_raw, v.csc_o_raw, sizeof(float) * nnz));
     }
-    ctx->mirror_o = src->mirror_o;
+    ctx->mirror_o = v.mirror_o;
     ctx->cap_synth = cap_s;
-    ctx->h_indptr = src->h_indptr;
+    ctx->h_indptr = std::move(v.h_indptr);
     ctx->N = N;
     ctx->H = H;
     ctx->nnz = nnz;
     ctx->S = 0;
     ctx->M = N;
-    ctx->panel_rows = src->panel_rows;
-    ctx->P_o = src->P_o;
-    ctx->counts_exact = src->counts_exact;
+    ctx->panel_rows = v.panel_rows;
+    ctx->P_o = v.P_o;
+    ctx->counts_exact = v.counts_exact;
     ctx->have_synth = ctx->have_lognorm = ctx->scaled = ctx->have_emb = ctx->have_knn = false;
     ctx->rowseg_rows = -1;
-    DDX_TRY(bp_clone(ctx, src));
+    DDX_TRY(bp_clone(ctx, v));
     DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->have_counts = true;
+    publish_clone_view(ctx);
     return DDX_OK;
 }
 

@@ -140,9 +140,12 @@ int ddx_upload_counts(ddx_ctx* ctx, int64_t n_cells, int32_t n_genes, const int6
                       const int32_t* indices, const float* data);
 /* ddx_clone_counts: make `dst` hold the same resident counts as `src` (everything ddx_upload_counts / ddx_select_columns
  *   left there: restricted CSR, library sizes, column-major mirror) by device-to-device copies -- no PCIe traffic, no
- *   recomputation.  Both contexts must live on the same GPU; `src` must be idle during the call.  This is how several
- *   contexts (streams) of one GPU share the once-per-fit prologue (dd.py:165-184) and then run different boosting
- *   iterations (dd.py:192-198) concurrently. */
+ *   recomputation.  Both contexts must live on the same GPU.  `src` may be running its own boosting iterations on another host
+ *   thread during the call: what is copied is the view `src` published when its counts became resident (original cells' rows,
+ *   library sizes, per-fit structures), whose buffers `src` neither rewrites nor hands out again before its next
+ *   ddx_upload_* / ddx_select_columns (a buffer that must grow mid-fit is abandoned until then, not reused); `src` must not
+ *   start its NEXT fit (or be destroyed) while a clone is in flight.  This is how several contexts (streams) of one GPU share
+ *   the once-per-fit prologue (dd.py:165-184) and then run different boosting iterations (dd.py:192-198) concurrently. */
 int ddx_clone_counts(ddx_ctx* dst, ddx_ctx* src);
 int ddx_get_counts_nnz(ddx_ctx* ctx, int64_t* nnz);
 int ddx_get_counts(ddx_ctx* ctx, int64_t* indptr /* [N+1] */, int32_t* indices, float* data);
