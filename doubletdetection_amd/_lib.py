@@ -714,9 +714,10 @@ class Context:
 
     def bitplane_stats(self) -> dict:
         """Did the last PCA's operator products take the bit-plane route, and what is left to the sparse products."""
-        out = np.zeros(4, dtype=np.int64)
+        out = np.zeros(8, dtype=np.int64)
         self._c(self._lib.ddx_get_bitplane_stats(self._h, _p(out, c_i64_p)))
-        return {"active": bool(out[0]), "rest_original": int(out[1]), "rest_synthetic": int(out[2]), "digits": int(out[3])}
+        return {"active": bool(out[0]), "rest_original": int(out[1]), "rest_synthetic": int(out[2]), "digits": int(out[3]),
+                "scaled": bool(out[4]), "demoted_columns": int(out[5])}
 
     def knn_candidate_counts(self) -> np.ndarray:
         out = np.empty(self._embM, dtype=np.int32)

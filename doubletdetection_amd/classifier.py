@@ -173,7 +173,7 @@ class _HipEngine:
         self.first_half(parents, pseudocount, standard_scaling, n_components, q0, pca_lock, verbose)
         return self.second_half(knn_k, include_self, graph_mode, gamma, verbose, metric)
 
-    def first_half(self, parents, pseudocount, standard_scaling, n_components, q0, pca_lock=None, verbose=False):
+    def first_half(self, parents, pseudocount, standard_scaling, n_components, q0, pca_lock=None, verbose=False, after_scale=None):
         """dd.py:275-314: synthetic doublets, normalisation, optional scaling, PCA.  Touches neither the graph nor the
         coarsening work space of the previous iteration, so that iteration's part C can still follow (``refine``).
 
@@ -189,6 +189,8 @@ class _HipEngine:
         c.lognormalise(pseudocount)
         if standard_scaling:
             c.scale(15.0)
+        if after_scale is not None:
+            after_scale()                 # (the leader's first scaling has fixed the per-fit structures its followers copy)
         if verbose:
             print("Running PCA...")
         if pca_lock is not None:
@@ -821,12 +823,10 @@ class BoostClassifier:
         return csr, leaders, restrict
 
     def _fit_switches(self, engine):
-        """Switches of a device context that follow from this fit's parameters: the bit planes of the operator products
-        (k_bitplane.hip) are built when the counts become resident, so a fit that cannot use them -- a scaled matrix, whose
-        values depend on the column, or a sketch wider than 40 columns -- says so before the upload."""
-        ctx = getattr(engine, "ctx", None)
-        if ctx is not None and hasattr(ctx, "set_option") and (self.standard_scaling or self.n_components + 10 > 40):
-            ctx.set_option("bitplane", "0")
+        """Switches of a device context that follow from this fit's parameters (set before the upload: the bit planes of the
+        operator products, k_bitplane.hip, are built when the counts become resident).  None are needed since round 6: scaled
+        matrices take the bit-plane route (1 / sd_j is a diagonal factor, ddx_scale) and sketches wider than 40 columns run
+        their products in 40-column blocks on it (ddx_pca)."""
         return engine
 
     def _open_lanes(self, leaders, n_mine):
@@ -848,7 +848,10 @@ class BoostClassifier:
                 # The copy itself waits until the follower's own host thread starts (`_fit_resident`: the first thing a lane
                 # does): what it reads of the leader -- the original cells' rows, their mirror, their bit planes -- is
                 # constant for the fit, so the leader is already on its first iteration while its followers copy (round 4
-                # copied here, with the leader idle: 4 x 3.5 GB device to device before any iteration began).
+                # copied here, with the leader idle: 4 x 3.5 GB device to device before any iteration began).  The library's side of
+                # that contract is ddx.h's ddx_clone_counts: the view a leader publishes stays valid and constant for the fit.
+                # With standard_scaling the leader's FIRST scaling may still move columns out of the bitmaps (the ones whose entries
+                # could reach the clip): its followers copy after that (`_fit_resident`), or each would repeat the rebuild.
                 f._clone_source = leader
                 made.append((dev, f))
         except Exception:
@@ -967,6 +970,11 @@ class BoostClassifier:
                 all_synth_communities[i] = full[num_cells:]
             return sink
 
+        # per-fit structures of a leader are final once its first scaling has run (no scaling: from the start)
+        structures_final = {id(eng): threading.Event() for _, eng in lanes if getattr(eng, "_clone_source", None) is None}
+        if not self.standard_scaling:
+            for ev in structures_final.values():
+                ev.set()
         host = {"draws": time.perf_counter() - t_setup0, "device_stages": 0.0, "wait_workers": 0.0, "graph_assembly": 0.0, "louvain": 0.0, "score": 0.0}
         t_dev0 = time.perf_counter()
         with ThreadPoolExecutor(max_workers=max(1, min(workers, max(1, len(mine))))) as pool:
@@ -978,9 +986,20 @@ class BoostClassifier:
                 needs B's labels) is slotted in behind that PCA, before the next graph overwrites the previous one."""
                 dev, engine = lanes[k]
                 src = getattr(engine, "_clone_source", None)
+                final = structures_final.get(id(engine))
                 if src is not None:                  # a follower: take over the leader's resident counts first (_open_lanes)
                     engine._clone_source = None
+                    ev = structures_final.get(id(src))
+                    if ev is not None:
+                        ev.wait()
                     engine.clone_from(src)
+                try:
+                    iterate(k, dev, engine, final)
+                finally:
+                    if final is not None:
+                        final.set()              # (a leader that failed, or ran on a test engine, must not leave its followers waiting)
+
+            def iterate(k, dev, engine, final):
                 kw = {"verbose": True} if self.verbose else {}
                 kw2 = dict(kw)
                 if metric != "euclidean":
@@ -998,7 +1017,10 @@ class BoostClassifier:
                     if self.verbose:
                         print("Iteration {:3}/{}".format(i + 1, n_iters))
                     if split:
-                        engine.first_half(all_parents[i], self.pseudocount, self.standard_scaling, n_comp, q0, pca_locks[dev], **kw)
+                        kw1 = kw
+                        if final is not None and not final.is_set() and isinstance(engine, _HipEngine):
+                            kw1 = dict(kw, after_scale=final.set)
+                        engine.first_half(all_parents[i], self.pseudocount, self.standard_scaling, n_comp, q0, pca_locks[dev], **kw1)
                         if waiting is not None:
                             finish(waiting)
                             waiting = None

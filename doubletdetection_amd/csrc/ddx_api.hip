@@ -76,7 +76,7 @@ void context_reset(ddx_ctx* ctx) {
                       &ctx->sort_vals_in, &ctx->sort_vals_out, &ctx->sort_tmp, &ctx->sort_rowid, &ctx->median, &ctx->lib_sorted, &ctx->lognorm_tab,
                       &ctx->zcol, &ctx->colmean, &ctx->colstat, &ctx->col_part, &ctx->pcaA, &ctx->pcaB, &ctx->pcaSmall,
                       &ctx->pcaPartial, &ctx->pcaVec, &ctx->pcaPanel, &ctx->pcaOp, &ctx->pcaQ0, &ctx->pcaBlk, &ctx->rowseg, &ctx->rank_buf, &ctx->lv_buf, &ctx->lv_pack, &ctx->graph_buf, &ctx->emb32, &ctx->emb64, &ctx->sing, &ctx->knn_idx,
-                      &ctx->knn_dist, &ctx->knn_sorted, &ctx->edge_w, &ctx->knn_cells, &ctx->bp_buf, &ctx->bp_work, &ctx->bp_ms_colptr, &ctx->bp_ms_row, &ctx->bp_ms_x, &ctx->pk_ptr[0], &ctx->pk_ptr[1], &ctx->pk_blocks[0], &ctx->pk_blocks[1]};
+                      &ctx->knn_dist, &ctx->knn_sorted, &ctx->edge_w, &ctx->knn_cells, &ctx->bp_buf, &ctx->bp_work, &ctx->bp_demote, &ctx->bp_ms_colptr, &ctx->bp_ms_row, &ctx->bp_ms_x, &ctx->pk_ptr[0], &ctx->pk_ptr[1], &ctx->pk_blocks[0], &ctx->pk_blocks[1]};
     for (DevBuf* b : bufs) { b->p = nullptr; b->cap = 0; b->blk = -1; }
     ctx->arena.blocks.clear();
     for (auto& c : ctx->arena.chunks) c.off = 0;
@@ -97,6 +97,7 @@ void context_reset(ddx_ctx* ctx) {
     ctx->mirror_full = false;
     ctx->mirror_o = false;
     ctx->synth_rows = ctx->rows_x = true;
+    ctx->rows_scaled = false;
     ctx->bp = ddx::BitPlanes();
 }
 
@@ -344,6 +345,26 @@ int ddx_synchronize(ddx_ctx* ctx) {
     return DDX_OK;
 }
 
+// name of the context buffer that block `blk` of the arena backs (diagnostics of ddx_check_memory)
+static const char* buffer_name(const ddx_ctx* c, int blk) {
+#define DDX_NAMED(b) {#b, &c->b}
+    const struct { const char* name; const DevBuf* buf; } named[] = {
+        DDX_NAMED(raw_indptr), DDX_NAMED(raw_indices), DDX_NAMED(raw_data), DDX_NAMED(raw_packed), DDX_NAMED(hvg_state), DDX_NAMED(hvg_keys), DDX_NAMED(hvg_vals),
+        DDX_NAMED(hvg_colptr), DDX_NAMED(aug_indptr), DDX_NAMED(aug_indices), DDX_NAMED(aug_raw), DDX_NAMED(aug_x), DDX_NAMED(lib32), DDX_NAMED(lib64),
+        DDX_NAMED(synth_counts), DDX_NAMED(parents), DDX_NAMED(pad_off), DDX_NAMED(csc_o_colptr), DDX_NAMED(csc_o_row), DDX_NAMED(csc_o_raw), DDX_NAMED(csc_o_x),
+        DDX_NAMED(csc_s_colptr), DDX_NAMED(csc_s_row), DDX_NAMED(csc_s_raw), DDX_NAMED(csc_s_x), DDX_NAMED(sort_keys_in), DDX_NAMED(sort_keys_out), DDX_NAMED(sort_vals_in),
+        DDX_NAMED(sort_vals_out), DDX_NAMED(sort_tmp), DDX_NAMED(sort_rowid), DDX_NAMED(rowseg), DDX_NAMED(rank_buf), DDX_NAMED(median), DDX_NAMED(lib_sorted),
+        DDX_NAMED(lognorm_tab), DDX_NAMED(zcol), DDX_NAMED(colmean), DDX_NAMED(colstat), DDX_NAMED(col_part), DDX_NAMED(pcaA), DDX_NAMED(pcaB), DDX_NAMED(pcaSmall),
+        DDX_NAMED(pcaPartial), DDX_NAMED(pcaVec), DDX_NAMED(pcaPanel), DDX_NAMED(pcaOp), DDX_NAMED(pcaQ0), DDX_NAMED(pcaBlk), DDX_NAMED(emb32), DDX_NAMED(emb64), DDX_NAMED(sing),
+        DDX_NAMED(knn_idx), DDX_NAMED(knn_dist), DDX_NAMED(knn_sorted), DDX_NAMED(edge_w), DDX_NAMED(knn_cells), DDX_NAMED(bp_buf), DDX_NAMED(bp_work), DDX_NAMED(bp_demote),
+        DDX_NAMED(bp_ms_colptr), DDX_NAMED(bp_ms_row), DDX_NAMED(bp_ms_x), DDX_NAMED(pk_ptr[0]), DDX_NAMED(pk_ptr[1]), DDX_NAMED(pk_blocks[0]), DDX_NAMED(pk_blocks[1]),
+        DDX_NAMED(graph_buf), DDX_NAMED(lv_buf), DDX_NAMED(lv_pack)};
+#undef DDX_NAMED
+    for (const auto& e : named)
+        if (e.buf->p && e.buf->blk == blk) return e.name;
+    return "a buffer since released, abandoned or local to a stage";
+}
+
 int ddx_check_memory(ddx_ctx* ctx) {
     REQUIRE_CTX(ctx);
     USE_DEVICE(ctx);
@@ -357,8 +378,8 @@ int ddx_check_memory(ddx_ctx* ctx) {
         DDX_HIP(ctx, hipMemcpy(h.data(), pad, kArenaPad, hipMemcpyDeviceToHost));
         for (size_t i = 0; i < kArenaPad; ++i)
             if (h[i] != 0xA5)
-                return set_err(ctx, DDX_E_NUMERIC, "buffer overflow: block %d (%zu bytes at chunk %d + %zu) was written %zu bytes past its end",
-                               n, blk.size - kArenaPad, blk.chunk, blk.off, i + 1);
+                return set_err(ctx, DDX_E_NUMERIC, "buffer overflow: block %d = %s (%zu bytes at chunk %d + %zu) was written %zu bytes past its end",
+                               n, buffer_name(ctx, n), blk.size - kArenaPad, blk.chunk, blk.off, i + 1);
         ++n;
     }
     return DDX_OK;
@@ -1230,6 +1251,9 @@ int ddx_get_bitplane_stats(ddx_ctx* ctx, int64_t* out) {
     out[1] = on ? ctx->bp.nrest_o : 0;
     out[2] = on ? ctx->bp.nrest_s : 0;
     out[3] = ctx->opt.bp_digits == 3 ? 3 : 4;
+    out[4] = (on && ctx->bp.scaled) ? 1 : 0;
+    out[5] = ctx->bp.ready ? ctx->bp.n_demoted : 0;
+    out[6] = out[7] = 0;
     return DDX_OK;
 }
 

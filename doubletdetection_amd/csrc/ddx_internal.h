@@ -116,6 +116,17 @@ struct BitPlanes {
     double* cmax = nullptr;          // [2][64] column maxima of the operand: Q side, Y side
     const double* ymax_of = nullptr; // the row-side matrix whose maxima (of diag(s) Y) the sparse A Q kernel has just left in cmax[64..]
     double* part = nullptr;          // partial blocks of the A^T Y product, one per chunk of the rows
+    // standard scaling (sc.pp.scale, dd.py:302-303) on this route: an entry equal to 1 becomes s_i / sd_j as long as it is not clipped, so the
+    // bitmaps stay what they are and 1 / sd_j goes into the operand (A Q) / the epilogue (A^T Y).  Columns in which an entry equal to 1 could
+    // reach the clip are DEMOTED for the fit: none of their entries are in the bitmaps, all of them sit in the reduced structures with their own
+    // (clipped) values.  demote: the per-column flags on the host (empty: none), copied with the struct to follower contexts; the device copy
+    // is ctx->bp_demote
+    std::vector<uint8_t> demote;
+    int64_t n_demoted = 0;
+    bool demote_decided = false;     // the first scaling of the fit has chosen the columns (with a margin); later ones only verify
+    bool scaled = false;             // the reduced values, zcol and colmean describe the scaled matrix (bp_scale); inv_sd is valid
+    const double* inv_sd = nullptr;  // [H] 1 / sd_j of this iteration (view into ctx->colstat)
+    double* rowop = nullptr;         // [cap_srow x 3] per-row operand of the scale statistics (s, x(1)^2, 1)
 };
 
 // What another context of the same GPU copies when it takes over a context's resident counts (ddx_clone_counts, dd.py:178-184's
@@ -223,6 +234,7 @@ struct ddx_ctx {
     float zvalue = 0.f;              // value of the unstored entries before scaling: log(pseudocount), or 0 for log1p
     bool have_lognorm = false;
     bool scaled = false;
+    float scale_max = 0.f;           // max_value of the scaling in force (ddx_scale); mean / sd of its columns: colstat + 2H / + 3H
     ddx::DevBuf median;              // float [1] (+ scratch)
     ddx::DevBuf lib_sorted;          // float [M]
     ddx::DevBuf lognorm_tab;         // float [M x 16] log-normalised value of the counts 1..16 in every row (row-major pass)
@@ -251,6 +263,8 @@ struct ddx_ctx {
     ddx::DevBuf edge_w;              // double [M*K]
     ddx::DevBuf knn_cells;           // cells, interval tables and chunk lists of the emit pass (stage_knn)
     ddx::DevBuf bp_buf, bp_work;     // bit-plane products: per-fit structures / per-product work space
+    ddx::DevBuf bp_demote;           // uint8 [H] device copy of bp.demote (zeros: no column demoted)
+    bool rows_scaled = false;        // aug_x holds the SCALED values of this iteration (the bit-plane route scales its reduced structures only)
     ddx::DevBuf bp_ms_colptr, bp_ms_row, bp_ms_x;   // ... the synthetic rows' reduced mirror (rebuilt every iteration)
     ddx::DevBuf pk_ptr[2], pk_blocks[2];   // packed residual products (k_pca.hip: k_pack_residual): [A Q, A^T Y] block tables and blocks of this iteration
     bool pk_valid[2] = {false, false};
@@ -422,6 +436,9 @@ int bp_colmean(ddx_ctx* ctx, const double* parts, int nparts);
 int bp_clone(ddx_ctx* ctx, const CloneView& src);
 bool bp_wanted_at_upload(const ddx_ctx* ctx);
 int bp_refresh(ddx_ctx* ctx);
+int bp_scale(ddx_ctx* ctx, float max_value);          // sc.pp.scale on the bit-plane structures (k_sparse.hip)
+int bp_scale_sums(ddx_ctx* ctx, const double** parts, int* chunks);     // per column: sums of s_i, x_i(1)^2 and 1 over the bitmap's entries
+int bp_rebuild_demoted(ddx_ctx* ctx, const std::vector<uint8_t>& want);
 int bp_rows_product(ddx_ctx* ctx, const double* Q, int L, double* Y);
 int bp_cols_product(ddx_ctx* ctx, const double* Y, int L, const double** part, int* chunks);
 

@@ -26,8 +26,11 @@
 // Measured stand-alone (profiles/tools/bp2_proto.hip, profiles/r05_bitplane_notes.txt): the matrix pipe is busy 82 % of the
 // kernel's cycles; the clock drops to ~1.6 GHz under it (power), which is what the wall-clock sees.
 //
-// Scaled matrices (standard_scaling: the value then depends on the column too) and sketches wider than 40 columns keep the
-// plain sparse products.
+// Scaled matrices (standard_scaling, dd.py:302-303): (x - mean_j) / sd_j makes the value of an unclipped entry equal to 1
+// s_i / sd_j, a diagonal factor -- the bitmaps stay what they are, 1 / sd_j goes into the operand rows before the digits (A Q)
+// and into the epilogue of A^T Y (k_sum_panels), the statistics come from one narrow product (columns s, x(1)^2, 1).  Columns in
+// which such an entry could reach the +-max_value clip are demoted for the fit: all their entries sit in the reduced structures
+// with their own clipped values (bp_scale in k_sparse.hip; BitPlanes::demote).
 #include "ddx_prims.h"
 
 #include <type_traits>
@@ -58,7 +61,8 @@ __device__ __forceinline__ int64_t bp_row_of(int64_t pr, int64_t Npad, int64_t N
 // One workgroup per tile: the tile's image is assembled in LDS (integer atomics: bits set in any order), `sk_chunk` stages at
 // a time, and written out in full lines.
 __global__ void __launch_bounds__(256) k_bp_rows_bitmap(const int64_t* __restrict__ indptr, const int32_t* __restrict__ cols, const float* __restrict__ raw,
-                                                        int64_t tile0, int64_t Npad, int64_t N, int64_t M, int SK, int sk_chunk, v4i* __restrict__ bm) {
+                                                        int64_t tile0, int64_t Npad, int64_t N, int64_t M, int SK, int sk_chunk, const uint8_t* __restrict__ demoted,
+                                                        v4i* __restrict__ bm) {
     extern __shared__ __align__(16) uint32_t bp_img[];              // [32 rows][sk_chunk * 8 words]
     const int64_t tile = tile0 + blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -74,7 +78,7 @@ __global__ void __launch_bounds__(256) k_bp_rows_bitmap(const int64_t* __restric
             const int64_t b = indptr[row], e = indptr[row + 1];
             for (int64_t p = b + lane; p < e; p += 64) {
                 const int32_t c = cols[p];
-                if (raw[p] == 1.0f && c >= c_lo && c < c_hi) atomicOr(&bp_img[r * wpr + ((c - c_lo) >> 5)], 1u << (c & 31));
+                if (raw[p] == 1.0f && c >= c_lo && c < c_hi && !demoted[c]) atomicOr(&bp_img[r * wpr + ((c - c_lo) >> 5)], 1u << (c & 31));
             }
         }
         __syncthreads();
@@ -116,10 +120,11 @@ __global__ void __launch_bounds__(256) k_bp_transpose(const v4i* __restrict__ bm
 }
 
 // ---- reduced structures: the entries other than 1 ----------------------------------------------------------------------
-__global__ void k_bp_flags(const float* __restrict__ raw, int64_t n, int32_t* __restrict__ flag) {
+// (an entry stays out of the bitmaps -- goes to the reduced structures -- when its count is not 1 or its column is demoted)
+__global__ void k_bp_flags(const float* __restrict__ raw, const int32_t* __restrict__ cols, const uint8_t* __restrict__ demoted, int64_t n, int32_t* __restrict__ flag) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i > n) return;
-    flag[i] = (i < n && raw[i] != 1.0f) ? 1 : 0;            // (element n: 0, so that the scan's last element is the total)
+    flag[i] = (i < n && (raw[i] != 1.0f || demoted[cols[i]])) ? 1 : 0;            // (element n: 0, so that the scan's last element is the total)
 }
 
 // kept entries -> idx_out / pos_out (pos: position in the full arrays, for the per-iteration value refresh; may be null) / x_out (may be null)
@@ -164,7 +169,9 @@ __global__ void k_bp_values(const float* __restrict__ raw, const int32_t* __rest
 // ---- synthetic rows straight from their parents' structures ---------------------------------------------------------------
 // A doublet's counts are the sums of its parents' (dd.py:406-410; scipy drops exact zeros), and the parents are rows whose
 // structures exist for the whole fit: the bitmap B (count == 1) and the reduced row R (other stored counts; counts here are
-// non-negative integers -- ddx_ctx::counts_exact --, so an entry of R is an explicit zero or >= 2).  With NZ = B | [R != 0]:
+// non-negative integers -- ddx_ctx::counts_exact --, so an entry of R is an explicit zero or >= 2; in a DEMOTED column B has no
+// bits and R holds the counts equal to 1 as well: the formulas below then give bitmap 0 and reduced R0 | R1 there, which is what
+// a demoted column's doublet entries must be).  With NZ = B | [R != 0]:
 //     bitmap of the doublet     (B0 & ~NZ1) | (B1 & ~NZ0)                      one parent has a 1, the other nothing
 //     its reduced columns       (NZ0 & NZ1) | ([R0 != 0] & ~NZ1) | ([R1 != 0] & ~NZ0)
 // so the merged row (k_doublet_fill, on ~900 entries per parent) never has to exist: one wave per doublet reads 2 x 1.25 KB of
@@ -551,7 +558,8 @@ static int bp_launch_bitmaps(ddx_ctx* ctx, int64_t tile0, int64_t ntiles, bool r
     const int sk_chunk = std::min(bp.SKc, 48);                    // 32 rows x 48 stages x 32 bytes = 48 KB of LDS
     if (rows_too)
     k_bp_rows_bitmap<<<(unsigned)ntiles, 256, (size_t)32 * sk_chunk * 32, ctx->stream>>>(ctx->aug_indptr.as<int64_t>(), ctx->aug_indices.as<int32_t>(),
-                                                                                        ctx->aug_raw.as<float>(), tile0, bp.Npad, ctx->N, ctx->M, bp.SKc, sk_chunk, reinterpret_cast<v4i*>(bp.bm_rows));
+                                                                                        ctx->aug_raw.as<float>(), tile0, bp.Npad, ctx->N, ctx->M, bp.SKc, sk_chunk, ctx->bp_demote.as<uint8_t>(),
+                                                                                        reinterpret_cast<v4i*>(bp.bm_rows));
     const int64_t nblk_r = ntiles / 2 + (ntiles & 1);             // 64-row blocks (tile0 is even: Npad is a multiple of 256)
     const int64_t nblk = nblk_r * bp.SKc * 4;
     k_bp_transpose<<<(unsigned)ceil_div(nblk, 4), 256, 0, ctx->stream>>>(reinterpret_cast<const v4i*>(bp.bm_rows), tile0 * 32, nblk_r, bp.SKc, bp.SKr, (int32_t)(bp.ntile_c * 32),
@@ -561,7 +569,7 @@ static int bp_launch_bitmaps(ddx_ctx* ctx, int64_t tile0, int64_t ntiles, bool r
 
 // flags -> scan -> compaction of n entries (raw values `raw`, indices `idx`); returns the kept count in *kept (synchronises)
 static int bp_reduce(ddx_ctx* ctx, const float* raw, const int32_t* idx, const float* x, int64_t n, int32_t* idx_out, int32_t* pos_out, float* x_out,
-                     int64_t cap_out, int32_t* kept, bool count_only, int32_t** scan_out) {
+                     int64_t cap_out, int32_t* kept, bool count_only, int32_t** scan_out, const int32_t* cols) {
     DDX_TRY(ensure(ctx, ctx->sort_keys_in, sizeof(int32_t) * (size_t)(n + 1)));
     DDX_TRY(ensure(ctx, ctx->sort_keys_out, sizeof(int32_t) * (size_t)(n + 1)));
     int32_t* flag = ctx->sort_keys_in.as<int32_t>();
@@ -570,7 +578,7 @@ static int bp_reduce(ddx_ctx* ctx, const float* raw, const int32_t* idx, const f
     DDX_HIP(ctx, prim::exclusive_sum(nullptr, tmp, flag, scan, (size_t)(n + 1), ctx->stream));
     DDX_TRY(ensure(ctx, ctx->sort_tmp, tmp));
     const unsigned ge = (unsigned)ceil_div(n + 1, 256);
-    k_bp_flags<<<ge, 256, 0, ctx->stream>>>(raw, n, flag);
+    k_bp_flags<<<ge, 256, 0, ctx->stream>>>(raw, cols, ctx->bp_demote.as<uint8_t>(), n, flag);
     DDX_HIP(ctx, prim::exclusive_sum(ctx->sort_tmp.p, tmp, flag, scan, (size_t)(n + 1), ctx->stream));
     if (scan_out) *scan_out = scan;
     if (count_only) {
@@ -602,7 +610,13 @@ int bp_build(ddx_ctx* ctx) {
     // pass 1: how many entries other than 1
     int32_t total_r = 0;
     int32_t* scan = nullptr;
-    DDX_TRY(bp_reduce(ctx, ctx->aug_raw.as<float>(), nullptr, nullptr, nnz, nullptr, nullptr, nullptr, 0, &total_r, true, &scan));
+    // the demoted columns of this fit (scaled matrices; none before the first scaling has chosen them)
+    DDX_TRY(ensure(ctx, ctx->bp_demote, (size_t)H + 256));
+    if ((int64_t)bp.demote.size() == H && bp.n_demoted > 0)
+        DDX_HIP(ctx, hipMemcpyAsync(ctx->bp_demote.p, bp.demote.data(), (size_t)H, hipMemcpyHostToDevice, ctx->stream));
+    else
+        DDX_HIP(ctx, hipMemsetAsync(ctx->bp_demote.p, 0, (size_t)H, ctx->stream));
+    DDX_TRY(bp_reduce(ctx, ctx->aug_raw.as<float>(), nullptr, nullptr, nnz, nullptr, nullptr, nullptr, 0, &total_r, true, &scan, ctx->aug_indices.as<int32_t>()));
     bp.nrest_o = total_r;
     bp.cap_rest_s = std::max<int64_t>(std::max<int64_t>(ctx->cap_synth / 3, bp.want_rest_s), 1024);   // (a synthetic row keeps ~15 % of its entries)
     // one buffer for everything that lasts for the fit
@@ -686,7 +700,14 @@ int bp_clone(ddx_ctx* ctx, const CloneView& src) {
     bp.restm_s_colptr = nullptr; bp.restm_s_row = nullptr; bp.restm_s_x = nullptr;          // (views into the source's per-iteration buffers)
     bp.qd = nullptr; bp.cmax = nullptr; bp.part = nullptr; bp.ymax_of = nullptr;
     bp.values = false;
+    bp.scaled = false; bp.inv_sd = nullptr; bp.rowop = nullptr;
     bp.ntile_s = 0; bp.nrest_s = 0;
+    DDX_TRY(ensure(ctx, ctx->bp_demote, (size_t)src.H + 256));
+    if ((int64_t)bp.demote.size() == src.H && bp.n_demoted > 0)
+        DDX_HIP(ctx, hipMemcpyAsync(ctx->bp_demote.p, bp.demote.data(), (size_t)src.H, hipMemcpyHostToDevice, ctx->stream));
+    else
+        DDX_HIP(ctx, hipMemsetAsync(ctx->bp_demote.p, 0, (size_t)src.H, ctx->stream));
+    DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));          // (the host vector is a local copy)
     ctx->bp = bp;
     return DDX_OK;
 }
@@ -715,6 +736,8 @@ static int bp_refresh_once(ddx_ctx* ctx) {
     bp.SKr_used = bp.Npad / kBpStageCols + ceil_div(S, kBpStageCols);
     DDX_TRY(bp_workspace(ctx));
     bp.nrest_s = 0;
+    bp.scaled = false;
+    bp.inv_sd = nullptr;
     ctx->pk_valid[0] = ctx->pk_valid[1] = false;             // the packed blocks of the sparse products describe the last iteration's matrix
     {
         ScopedTimer t(ctx, "bitplane_values");
@@ -754,7 +777,7 @@ static int bp_refresh_once(ddx_ctx* ctx) {
             const int64_t n_s = ctx->nnz_aug - e0;                     // (read back by ddx_lognormalise)
             int32_t kept = 0;
             int32_t* scan = nullptr;
-            DDX_TRY(bp_reduce(ctx, ctx->aug_raw.as<float>() + e0, nullptr, nullptr, n_s, nullptr, nullptr, nullptr, 0, &kept, true, &scan));
+            DDX_TRY(bp_reduce(ctx, ctx->aug_raw.as<float>() + e0, nullptr, nullptr, n_s, nullptr, nullptr, nullptr, 0, &kept, true, &scan, ctx->aug_indices.as<int32_t>() + e0));
             if (kept > bp.cap_rest_s) {
                 // more entries other than 1 among the synthetic rows than planned for: build the per-fit structures again with room for them
                 bp.want_rest_s = (int64_t)kept + kept / 2;
@@ -829,14 +852,18 @@ static int bp_workspace(ddx_ctx* ctx) {
     BitPlanes& bp = ctx->bp;
     const int64_t SKmax = std::max<int64_t>(bp.SKc, bp.SKr_cap);
     const size_t dig = bp_align(sizeof(v4i) * (size_t)SKmax * kBpSteps * 5 * 64);
-    const int chunks = bp_col_chunks(bp, bp.SKr_cap, nullptr);
+    // (the chunk count of a product follows from the stages IN USE, ceil(SK / ceil(SK / c)) <= c with c the bound below -- which the count
+    // for the capacity does not bound: 8192 cells x 6000 genes cut 40 used stages into 20 chunks, 49 stages of capacity into 17)
+    const int chunks = (int)std::max<int64_t>(1, std::min<int64_t>(bp.SKr_cap, 256 / std::max<int64_t>(1, ceil_div(bp.ntile_c, kBpWaves * 2))));
     const size_t prt = bp_align(sizeof(double) * (size_t)chunks * ctx->H * 40);
-    const size_t need = dig + bp_align(sizeof(double) * 192) + prt;
+    const size_t rop = bp_align(sizeof(double) * 3 * (size_t)bp.cap_srow);
+    const size_t need = dig + bp_align(sizeof(double) * 192) + prt + rop;
     DDX_TRY(ensure(ctx, ctx->bp_work, need));
     char* b = ctx->bp_work.as<char>();
     bp.qd = b;
-    bp.cmax = reinterpret_cast<double*>(b + dig);                 // [0..63]: Q side, [64..127]: Y side, [128..]: the row scales (column means)
+    bp.cmax = reinterpret_cast<double*>(b + dig);                 // [0..63]: Q side, [64..127]: Y side, [128..]: the row scales (column means, scale statistics)
     bp.part = reinterpret_cast<double*>(b + dig + bp_align(sizeof(double) * 192));
+    bp.rowop = reinterpret_cast<double*>(b + dig + bp_align(sizeof(double) * 192) + prt);
     DDX_HIP(ctx, hipMemsetAsync(bp.cmax, 0, sizeof(double) * 192, ctx->stream));
     bp.ymax_of = nullptr;
     return DDX_OK;
@@ -881,11 +908,13 @@ int bp_rows_product(ddx_ctx* ctx, const double* Q, int L, double* Y) {
     double* cmaxY = bp.cmax + 64;
     {
         ScopedTimer t(ctx, "bitplane_prep");
-        k_bp_colmax<<<(unsigned)std::min<int64_t>(256, ceil_div(ctx->H, 64)), 256, 0, ctx->stream>>>(Q, nullptr, ctx->H, L, cmaxQ);      // (into zeros: bp_refresh / the last Y-side digits)
+        // scaled matrix: the operand is diag(1 / sd) Q -- the digits are cut from the weighted rows, the bitmaps and the row scales stay
+        const double* wq = bp.scaled ? bp.inv_sd : nullptr;
+        k_bp_colmax<<<(unsigned)std::min<int64_t>(256, ceil_div(ctx->H, 64)), 256, 0, ctx->stream>>>(Q, wq, ctx->H, L, cmaxQ);      // (into zeros: bp_refresh / the last Y-side digits)
         const int nslot = (NT * 32 + ND - 1) / ND;
         const int64_t nthreads = std::max<int64_t>(64, (int64_t)bp.SKc * kBpSteps * 2 * nslot);
-        if (ND == 3) k_bp_digits<3, false><<<(unsigned)ceil_div(nthreads, 256), 256, 0, ctx->stream>>>(Q, nullptr, ctx->H, L, NT, nslot, cmaxQ, bp.SKc, 0, 0, qd, cmaxY);
-        else k_bp_digits<4, false><<<(unsigned)ceil_div(nthreads, 256), 256, 0, ctx->stream>>>(Q, nullptr, ctx->H, L, NT, nslot, cmaxQ, bp.SKc, 0, 0, qd, cmaxY);
+        if (ND == 3) k_bp_digits<3, false><<<(unsigned)ceil_div(nthreads, 256), 256, 0, ctx->stream>>>(Q, wq, ctx->H, L, NT, nslot, cmaxQ, bp.SKc, 0, 0, qd, cmaxY);
+        else k_bp_digits<4, false><<<(unsigned)ceil_div(nthreads, 256), 256, 0, ctx->stream>>>(Q, wq, ctx->H, L, NT, nslot, cmaxQ, bp.SKc, 0, 0, qd, cmaxY);
     }
     bp.ymax_of = nullptr;
     BpProductArgs a{};
@@ -927,6 +956,73 @@ int bp_cols_product(ddx_ctx* ctx, const double* Y, int L, const double** part, i
     DDX_TRY(bp_launch<false>(ctx, a, chunks, ND, 2));
     *part = bp.part;
     *chunks_out = chunks;
+    return DDX_OK;
+}
+
+// ---- standard scaling on this route ----------------------------------------------------------------------------------------
+// per row the three operands of the scale statistics: s_i = x_i(1) - z (what an entry equal to 1 adds to sum(x - z)), the float32
+// square of x_i(1) (what it adds to the sum of squares, oracle: mean of float32 squares) and 1 (the count)
+__global__ void k_bp_row_stats(const float* __restrict__ tab, int tab_stride, float z, int64_t M, double* __restrict__ op) {
+#pragma clang fp contract(off)
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    const float x1 = tab[i * tab_stride];
+    const float sq = x1 * x1;
+    op[3 * i] = (double)(x1 - z);
+    op[3 * i + 1] = (double)sq;
+    op[3 * i + 2] = 1.0;
+}
+
+// B^T [s | x(1)^2 | 1]: *chunks partial blocks [H x 3] float64 at *parts (one narrow product on the matrix cores: three columns of four
+// digits; the count column is exact, the other two carry 30 bits below the column's largest element)
+int bp_scale_sums(ddx_ctx* ctx, const double** parts, int* chunks_out) {
+    BitPlanes& bp = ctx->bp;
+    const int64_t M = ctx->M, SK = bp.SKr_used;
+    int per = 1;
+    const int chunks = bp_col_chunks(bp, SK, &per);
+    v4i* qd = reinterpret_cast<v4i*>(bp.qd);
+    double* cmaxS = bp.cmax + 128;
+    {
+        ScopedTimer t(ctx, "bitplane_prep");
+        DDX_HIP(ctx, hipMemsetAsync(cmaxS, 0, sizeof(double) * 64, ctx->stream));
+        k_bp_row_stats<<<(unsigned)ceil_div(M, 256), 256, 0, ctx->stream>>>(ctx->lognorm_tab.as<float>(), kLognormTab, ctx->zvalue, M, bp.rowop);
+        k_bp_colmax<<<(unsigned)std::min<int64_t>(1024, ceil_div(M, 64)), 256, 0, ctx->stream>>>(bp.rowop, nullptr, M, 3, cmaxS);
+        const int nslot = 8;
+        const int64_t nthreads = std::max<int64_t>(64, SK * kBpSteps * 2 * nslot);
+        k_bp_digits<4, true><<<(unsigned)ceil_div(nthreads, 256), 256, 0, ctx->stream>>>(bp.rowop, nullptr, M, 3, 1, nslot, cmaxS, SK, bp.Npad, ctx->N, qd, nullptr);
+    }
+    bp.ymax_of = nullptr;
+    BpProductArgs a{};
+    a.bm = reinterpret_cast<const v4i*>(bp.bm_cols); a.qd = qd; a.ntile = bp.ntile_c; a.SK = (int)SK; a.SKstride = bp.SKr; a.sk_per_chunk = per; a.L = 3;
+    a.cmax = cmaxS; a.nOut = ctx->H; a.out = bp.part;
+    {
+        ScopedTimer t(ctx, "bitplane_cols");
+        DDX_TRY((bp_launch_t<2, 1, 4, false>(ctx, a, chunks)));
+    }
+    *parts = bp.part;
+    *chunks_out = chunks;
+    return DDX_OK;
+}
+
+// the per-fit structures again with the columns `want` demoted, and this iteration's (unscaled) values on them; followers that clone from
+// now on get the new structures (the old buffer is abandoned, not released: a follower may be copying it)
+int bp_rebuild_demoted(ddx_ctx* ctx, const std::vector<uint8_t>& want) {
+    BitPlanes& bp = ctx->bp;
+    int64_t n = 0;
+    for (uint8_t f : want) n += f ? 1 : 0;
+    std::vector<uint8_t> keep = want;
+    const int64_t want_rest_s = bp.want_rest_s;
+    bp.ready = false;
+    bp.values = false;
+    ctx->bp_buf = DevBuf();
+    bp.demote = std::move(keep);
+    bp.n_demoted = n;
+    bp.demote_decided = true;
+    bp.want_rest_s = want_rest_s;
+    DDX_TRY(bp_build(ctx));
+    ctx->rowseg_rows = -1;
+    DDX_TRY(bp_refresh(ctx));
+    publish_clone_view(ctx);
     return DDX_OK;
 }
 

@@ -824,8 +824,10 @@ __global__ void __launch_bounds__(256) k_pack_residual(const LdsSpmmArgs a, int 
             const int32_t p = (src == 0 ? m_lo0 : m_lo1) + es;
             const float* xs = ROWS ? a.x : (src == 0 ? a.x_o : a.x_s);
             const int32_t* is = ROWS ? a.cols : (src == 0 ? a.row_o : a.row_s);
-            const float v = xs[p] - m_z;                     // x - z in float32: the correctly rounded difference (as k_spmm_lds stages it)
-            const int32_t i = is[p] - base;
+            const int32_t ii = is[p];
+            const float zz = (ROWS && !a.z_uniform) ? a.zcol[ii] : m_z;     // (A Q on a scaled matrix: the unstored value depends on the entry's column)
+            const float v = xs[p] - zz;                      // x - z in float32: the correctly rounded difference (as k_spmm_lds stages it)
+            const int32_t i = ii - base;
             const int mg = m % 3;
             const int qpos = m_pre + (src == 0 ? 0 : m_nq0) + (es >> 2), st = es & 3;
             unsigned char* q = blocks + (blk0 + qpos / kPkQuads) * kPkBlockBytes + kPkHeader + (qpos % kPkQuads) * kPkQuadBytes;
@@ -1041,15 +1043,18 @@ __global__ void k_operand_copy(const double* __restrict__ in, int64_t R, int L, 
 
 // W[j,c] = sum_p Wp[p][j][c] - m_j u_c   (panels added in order)
 __global__ void k_sum_panels(const double* __restrict__ Wp, int P, int32_t H, int L, const double* __restrict__ colmean,
-                             const double* __restrict__ uvec, double* __restrict__ W, const double* __restrict__ extra = nullptr, int nextra = 0) {
+                             const double* __restrict__ uvec, double* __restrict__ W, const double* __restrict__ extra = nullptr, int nextra = 0,
+                             const double* __restrict__ escale = nullptr) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (int64_t)H * L) return;
     const int64_t j = t / L;
     const int c = (int)(t - j * L);
     double s = 0.0;
     for (int p = 0; p < P; ++p) s += Wp[(int64_t)p * H * L + t];
-    for (int p = 0; p < nextra; ++p) s += extra[(int64_t)p * H * L + t];       // the bit-plane part of the product, one block per chunk of the rows
-    W[t] = s - colmean[j] * uvec[c];
+    double e = 0.0;
+    for (int p = 0; p < nextra; ++p) e += extra[(int64_t)p * H * L + t];       // the bit-plane part of the product, one block per chunk of the rows
+    if (escale) e *= escale[j];                                                // (scaled matrix: B^T diag(s) Y comes out of the matrix cores, 1 / sd_j is applied here)
+    W[t] = (s + e) - colmean[j] * uvec[c];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1682,7 +1687,7 @@ static int apply_cols_wide(PcaWork& w, const double* Yrow, double* Wcol);
 
 static int apply_rows(PcaWork& w, const double* Qcol, double* Yrow) {  // A Q : [H x L] -> [M x L]
     if (!w.bitplane) DDX_TRY(ensure_full_rows(w.ctx));     // (the bit-plane route leaves the doublets' rows and the row-major values out)
-    if (w.L > kMaxL) return apply_rows_wide(w, Qcol, Yrow);
+    if (w.sub) return apply_rows_wide(w, Qcol, Yrow);
     ddx_ctx* c = w.ctx;
     double* tvec = w.small + 3 * w.L * w.L;
     {
@@ -1758,7 +1763,7 @@ static int apply_rows(PcaWork& w, const double* Qcol, double* Yrow) {  // A Q : 
 }
 
 static int apply_cols(PcaWork& w, const double* Yrow, double* Wcol) {  // A^T Y : [M x L] -> [H x L]
-    if (w.L > kMaxL) return apply_cols_wide(w, Yrow, Wcol);
+    if (w.sub) return apply_cols_wide(w, Yrow, Wcol);
     ddx_ctx* c = w.ctx;
     double* uvec = w.small + 3 * w.L * w.L + w.L;
     {
@@ -1806,7 +1811,7 @@ static int apply_cols(PcaWork& w, const double* Yrow, double* Wcol) {  // A^T Y 
         }
         ScopedTimer t(c, "spmm_sum");
         k_sum_panels<<<(unsigned)ceil_div((int64_t)w.H * w.L, 256), 256, 0, c->stream>>>(c->pcaPanel.as<double>(), a.groups, w.H, w.L, c->colmean.as<double>(),
-                                                                                          uvec, Wcol, w1, nw1);
+                                                                                          uvec, Wcol, w1, nw1, (w.bitplane && c->bp.scaled) ? c->bp.inv_sd : nullptr);
         return DDX_OK;
     }
     ScopedTimer t(c, "spmm_cols");
@@ -1830,7 +1835,7 @@ static int apply_cols(PcaWork& w, const double* Yrow, double* Wcol) {  // A^T Y 
                                                                c->P_s, P, w.H, c->zcol.as<float>(), op, ld, w.L, lpn, 64 / lpn, c->pcaPanel.as<double>());
     }
     k_sum_panels<<<(unsigned)ceil_div((int64_t)w.H * w.L, 256), 256, 0, c->stream>>>(c->pcaPanel.as<double>(), P, w.H, w.L, c->colmean.as<double>(),
-                                                                                      uvec, Wcol, w1, nw1);
+                                                                                      uvec, Wcol, w1, nw1, (w.bitplane && c->bp.scaled) ? c->bp.inv_sd : nullptr);
     return DDX_OK;
 }
 
@@ -1857,11 +1862,18 @@ static int apply_cols_wide(PcaWork& w, const double* Yrow, double* Wcol) {
 }
 
 // decide whether the LDS-staged products apply and build the row-segment table of the A Q pass
+// would the bit-plane products serve a sketch of L columns on this context's matrix (see bp_setup)
+static bool bp_possible(const ddx_ctx* ctx, int L, bool gather32) {
+    return ctx->opt.bitplane != 0 && gather32 && L <= 40 && ctx->have_lognorm && ctx->N >= 32 && ctx->S <= ctx->N / 2 &&
+           (ctx->opt.bitplane == 2 || ctx->N >= 4096) && (!ctx->scaled || (ctx->bp.ready && ctx->bp.values && ctx->bp.scaled));
+}
+
 static int bp_setup(ddx_ctx* ctx, int L, PcaWork& w) {
-    // bit planes: unscaled matrix (the value of a count of 1 then depends on the row only), a sketch whose digits fit the kernel's
-    // tiles (40 columns), and -- unless forced -- a matrix large enough for the dense passes to pay
-    w.bitplane = ctx->opt.bitplane != 0 && w.gather32 && !ctx->scaled && L <= 40 && ctx->have_lognorm && ctx->N >= 32 && ctx->S <= ctx->N / 2 &&
-                 (ctx->opt.bitplane == 2 || ctx->N >= 4096);
+    // bit planes: a sketch whose digits fit the kernel's tiles (40 columns), and -- unless forced -- a matrix large enough for the dense
+    // passes to pay.  A scaled matrix takes the route when ddx_scale scaled the bit-plane structures (bp_scale: it does whenever they hold
+    // the iteration's values); one scaled on the full arrays keeps the plain products.
+    // Wider sketches reach this with L = kWideBlock: stage_pca runs their products block by block (apply_*_wide).
+    w.bitplane = bp_possible(ctx, L, w.gather32);
     if (w.bitplane) {
         const bool fresh = !ctx->bp.ready;
         DDX_TRY(bp_build(ctx));
@@ -1971,7 +1983,10 @@ int stage_operator_apply(ddx_ctx* ctx, int32_t mode, const double* X, int32_t n,
 int stage_pca(ddx_ctx* ctx, int32_t C, int32_t oversample, int32_t n_iter, const double* q0, int64_t q0_rows) {
     t_opt = &ctx->opt;
     const int L = C + oversample;
-    const bool wide = L > kMaxL;         // the products run on column blocks of kWideBlock, the tall-skinny helpers tiled
+    const bool tall_tiled = L > kMaxL;   // the tall-skinny helpers run tiled, the Cholesky factor on the host (gram / cholqr test w.L themselves)
+    // the products run on column blocks of kWideBlock: always beyond kMaxL columns; from 41 columns on when the bit planes can serve the
+    // blocks (two 40-column block products on the matrix cores + the packed residue beat one plain product of the quad geometry)
+    const bool wide = tall_tiled || (L > kWideBlock && bp_possible(ctx, kWideBlock, ctx->opt.gather_f32) && ctx->opt.spmm_lds);
     const int64_t M = ctx->M;
     const int32_t H = ctx->H;
     const bool transposed = M < H;
@@ -1983,7 +1998,7 @@ int stage_pca(ddx_ctx* ctx, int32_t C, int32_t oversample, int32_t n_iter, const
     DDX_TRY(ensure(ctx, ctx->pcaB, sizeof(double) * 2 * (size_t)H * L));
     constexpr int kSubSmall = 4 * kWideBlock * kWideBlock + 4 * kWideBlock;      // the block work's own small area behind the main one
     DDX_TRY(ensure(ctx, ctx->pcaSmall, sizeof(double) * (4 * (size_t)L * L + 4 * L + kSubSmall) + 256));
-    DDX_TRY(ensure(ctx, ctx->pcaPartial, sizeof(double) * (wide ? 128 : 512) * (size_t)std::max(L * L, 128 * 4)));
+    DDX_TRY(ensure(ctx, ctx->pcaPartial, sizeof(double) * (tall_tiled ? 128 : 512) * (size_t)std::max(L * L, 128 * 4)));
     DDX_TRY(ensure(ctx, ctx->pcaVec, 256));
     DDX_TRY(ensure(ctx, ctx->pcaPanel, sizeof(double) * (size_t)ceil_div(M, ctx->panel_rows) * H * (wide ? kWideBlock : L)));
     if (wide) DDX_TRY(ensure(ctx, ctx->pcaBlk, sizeof(double) * (size_t)(M + H) * kWideBlock));
@@ -2014,6 +2029,7 @@ int stage_pca(ddx_ctx* ctx, int32_t C, int32_t oversample, int32_t n_iter, const
         wsub.L = kWideBlock;
         wsub.lpn = (kWideBlock + 1) / 2;
         wsub.slots = 64 / wsub.lpn;
+        wsub.fused_ymax = false;                              // (the block buffers are rewritten between the two products of a power iteration)
         DDX_TRY(lds_setup(ctx, kWideBlock, wsub));
     } else {
         DDX_TRY(lds_setup(ctx, L, w));

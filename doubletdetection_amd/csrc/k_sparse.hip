@@ -866,7 +866,10 @@ int stage_upload_counts(ddx_ctx* ctx, int64_t N, int32_t H, const int64_t* indpt
     // whatever was derived from the previous resident rows is stale: the slice segments of the A Q pass (a second
     // ddx_select_columns of the same width would otherwise keep the old rows' segments) and the bit planes
     ctx->rowseg_rows = -1;
-    ctx->bp.ready = ctx->bp.values = false;
+    ctx->bp.ready = ctx->bp.values = ctx->bp.scaled = false;
+    ctx->bp.demote.clear();
+    ctx->bp.n_demoted = 0;
+    ctx->bp.demote_decided = false;
     DDX_TRY(ensure(ctx, ctx->lib32, sizeof(float) * (N + N / 2 + 2)));
     DDX_TRY(ensure(ctx, ctx->lib64, sizeof(double) * (N + N / 2 + 2)));
     {
@@ -986,6 +989,8 @@ int stage_clone_counts(ddx_ctx* ctx, ddx_ctx* src) {
 // stage: create doublets
 // ------------------------------------------------------------------------------------------------
 static int lognorm_rows(ddx_ctx* ctx);
+static int scale_full_rows(ddx_ctx* ctx);
+static int scale_full_mirror(ddx_ctx* ctx);
 
 // one merge per doublet: rows are written at padded offsets into the (not yet rebuilt) mirror buffers, counted on the way,
 // scanned into the row pointer and moved to their final positions
@@ -1070,6 +1075,8 @@ int ensure_full_rows(ddx_ctx* ctx) {
         DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     if (!ctx->rows_x && ctx->have_lognorm) DDX_TRY(lognorm_rows(ctx));
+    // (a matrix scaled on the bit-plane structures: the row-major values follow when somebody asks for them)
+    if (ctx->scaled && ctx->have_lognorm && !ctx->rows_scaled) DDX_TRY(scale_full_rows(ctx));
     return DDX_OK;
 }
 
@@ -1275,7 +1282,7 @@ __global__ void __launch_bounds__(256) k_col_partials(const int64_t* __restrict_
 
 __global__ void k_col_reduce(const double* __restrict__ part_o, int P_o, int64_t nseg_o, const double* __restrict__ part_s, int P_s,
                              int64_t nseg_s, int32_t H, int64_t M, int mode, double* __restrict__ out, const double* __restrict__ extra = nullptr,
-                             int nextra = 0) {
+                             int nextra = 0, const double* __restrict__ escale = nullptr) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= H) return;
     double a = 0.0, b = 0.0;
@@ -1287,14 +1294,14 @@ __global__ void k_col_reduce(const double* __restrict__ part_o, int P_o, int64_t
         a += part_s[(int64_t)p * H + j];
         if (mode) b += part_s[nseg_s + (int64_t)p * H + j];
     }
-    for (int p = 0; p < nextra; ++p) a += extra[(int64_t)p * H + j];     // (bit-plane mode: the entries equal to 1, one block per chunk of the rows)
+    for (int p = 0; p < nextra; ++p) a += (escale ? escale[j] : 1.0) * extra[(int64_t)p * H + j];     // (bit-plane mode: the entries equal to 1, one block per chunk of the rows)
     if (mode == 0) out[j] = a / (double)M;
     else { out[2 * j] = a; out[2 * j + 1] = b; }
 }
 
 // column sums over the given pair of (panel, column)-ordered mirrors (+ `nextra` blocks of H ready-made sums)
 static int col_sums_of(ddx_ctx* ctx, const int64_t* cp_o, const float* x_o, const int64_t* cp_s, const float* x_s, int mode, double* out,
-                       const double* extra = nullptr, int nextra = 0) {
+                       const double* extra = nullptr, int nextra = 0, const double* escale = nullptr) {
     const int32_t H = ctx->H;
     const int64_t nseg_o = (int64_t)ctx->P_o * H, nseg_s = (int64_t)ctx->P_s * H;
     DDX_TRY(ensure(ctx, ctx->col_part, sizeof(double) * 2 * (size_t)(nseg_o + nseg_s + 2)));
@@ -1302,7 +1309,7 @@ static int col_sums_of(ddx_ctx* ctx, const int64_t* cp_o, const float* x_o, cons
     double* part_s = part_o + 2 * nseg_o;
     if (nseg_o) k_col_partials<<<(unsigned)ceil_div(nseg_o, 16), 256, 0, ctx->stream>>>(cp_o, x_o, nseg_o, H, ctx->zcol.as<float>(), mode, part_o);
     if (nseg_s) k_col_partials<<<(unsigned)ceil_div(nseg_s, 16), 256, 0, ctx->stream>>>(cp_s, x_s, nseg_s, H, ctx->zcol.as<float>(), mode, part_s);
-    k_col_reduce<<<(unsigned)ceil_div(H, 256), 256, 0, ctx->stream>>>(part_o, ctx->P_o, nseg_o, part_s, ctx->P_s, nseg_s, H, ctx->M, mode, out, extra, nextra);
+    k_col_reduce<<<(unsigned)ceil_div(H, 256), 256, 0, ctx->stream>>>(part_o, ctx->P_o, nseg_o, part_s, ctx->P_s, nseg_s, H, ctx->M, mode, out, extra, nextra, escale);
     return DDX_OK;
 }
 
@@ -1345,6 +1352,7 @@ int ensure_full_mirror(ddx_ctx* ctx) {
         else if (ctx->panel_rows * kLognormTab * sizeof(float) > 64 * 1024)        // (the direct kernel walks colptr[nkeys]: one empty panel)
             DDX_TRY(lognorm_mirror(ctx, ctx->csc_s_row.as<int32_t>(), ctx->csc_s_raw.as<float>(), ctx->csc_s_colptr.as<int64_t>(), 1, ctx->p_s0, ctx->csc_s_x.as<float>()));
     }
+    if (ctx->scaled) DDX_TRY(scale_full_mirror(ctx));       // (scaled on the bit-plane structures before anybody needed the full mirror)
     DDX_HIP(ctx, hipGetLastError());
     ctx->mirror_full = true;
     return DDX_OK;
@@ -1381,6 +1389,7 @@ static int lognorm_rows(ddx_ctx* ctx) {
                                                                                           ctx->median.as<float>(), ctx->lognorm_tab.as<float>(), ctx->pseudocount,
                                                                                           ctx->pseudocount == 1.0f, ctx->M, rows_per_wave, ctx->aug_x.as<float>());
     ctx->rows_x = true;
+    ctx->rows_scaled = false;
     return DDX_OK;
 }
 
@@ -1516,11 +1525,36 @@ __global__ void k_scale_zcol(const double* __restrict__ mean, const double* __re
     if (j < H) zcol[j] = scale_value(zcol[j], mean[j], sd[j], maxv);
 }
 
+// the scaling in force applied to the full arrays that were (re)built after it (ensure_full_rows / ensure_full_mirror)
+static int scale_full_rows(ddx_ctx* ctx) {
+    const int32_t H = ctx->H;
+    const double* mean = ctx->colstat.as<double>() + 2 * H;
+    const double* sd = ctx->colstat.as<double>() + 3 * H;
+    ScopedTimer t(ctx, "scale");
+    k_scale_rows<<<2048, 256, 0, ctx->stream>>>(ctx->aug_indices.as<int32_t>(), ctx->M, ctx->aug_indptr.as<int64_t>(), mean, sd, ctx->scale_max, ctx->aug_x.as<float>());
+    ctx->rows_scaled = true;
+    return DDX_OK;
+}
+
+static int scale_full_mirror(ddx_ctx* ctx) {
+    const int32_t H = ctx->H;
+    const double* mean = ctx->colstat.as<double>() + 2 * H;
+    const double* sd = ctx->colstat.as<double>() + 3 * H;
+    ScopedTimer t(ctx, "scale");
+    k_scale_cols<<<(unsigned)H, 256, 0, ctx->stream>>>(ctx->csc_o_colptr.as<int64_t>(), ctx->P_o, H, mean, sd, ctx->scale_max, ctx->csc_o_x.as<float>());
+    k_scale_cols<<<(unsigned)H, 256, 0, ctx->stream>>>(ctx->csc_s_colptr.as<int64_t>(), ctx->P_s, H, mean, sd, ctx->scale_max, ctx->csc_s_x.as<float>());
+    return DDX_OK;
+}
+
 int stage_scale(ddx_ctx* ctx, float max_value) {
-    DDX_TRY(ensure_full_mirror(ctx));                 // (the bit-plane route left it out: a scaled matrix takes the plain sparse products)
     const int32_t H = ctx->H;
     const int64_t M = ctx->M;
-    DDX_TRY(ensure(ctx, ctx->colstat, sizeof(double) * 4 * H));
+    DDX_TRY(ensure(ctx, ctx->colstat, sizeof(double) * 8 * H + 256));
+    ctx->scale_max = max_value;
+    // the bit-plane structures hold this iteration's matrix (ddx_lognormalise took the lean route): scale THEM -- a tenth of the entries in
+    // sparse form, the rest through 1 / sd in the matrix-core products -- and leave the full arrays to whoever asks (ensure_full_*)
+    if (ctx->bp.ready && ctx->bp.values && !ctx->mirror_full) return bp_scale(ctx, max_value);
+    DDX_TRY(ensure_full_mirror(ctx));
     double* stat = ctx->colstat.as<double>();
     double* mean = stat + 2 * H;
     double* sd = stat + 3 * H;
@@ -1530,12 +1564,126 @@ int stage_scale(ddx_ctx* ctx, float max_value) {
                                                                        ctx->P_s, ctx->zcol.as<float>(), M, H, mean, sd);
     k_scale_rows<<<2048, 256, 0, ctx->stream>>>(ctx->aug_indices.as<int32_t>(), M, ctx->aug_indptr.as<int64_t>(), mean, sd, max_value,
                                                 ctx->aug_x.as<float>());
+    ctx->rows_scaled = true;
     k_scale_cols<<<(unsigned)H, 256, 0, ctx->stream>>>(ctx->csc_o_colptr.as<int64_t>(), ctx->P_o, H, mean, sd, max_value, ctx->csc_o_x.as<float>());
     k_scale_cols<<<(unsigned)H, 256, 0, ctx->stream>>>(ctx->csc_s_colptr.as<int64_t>(), ctx->P_s, H, mean, sd, max_value, ctx->csc_s_x.as<float>());
     k_scale_zcol<<<(unsigned)ceil_div(H, 256), 256, 0, ctx->stream>>>(mean, sd, max_value, H, ctx->zcol.as<float>());
     DDX_TRY(col_sums(ctx, 0, ctx->colmean.as<double>()));
     DDX_HIP(ctx, hipGetLastError());
     ctx->scaled = true;
+    ctx->bp.values = false;                          // (the bit-plane structures, if any, describe the unscaled matrix)
+    ctx->have_emb = ctx->have_knn = false;
+    return DDX_OK;
+}
+
+// ---- sc.pp.scale on the bit-plane structures (dd.py:302-303) -----------------------------------------------------------------
+// Statistics of column j from three sources: the reduced mirrors (sums of x - z and of float32 squares, counts from the segment
+// pointers) and the bitmap's entries (B^T [s | x(1)^2 | 1] from the matrix cores).  Same formulas as k_scale_stats.  Besides mean and sd:
+// inv_sd, bsum = (B^T s)_j (the bitmap's share of the new column mean is bsum / sd), and the clip test of the column's entries equal to 1:
+// unclipped they become s_i / sd_j + zr_j with zr_j = (z - mean_j) / sd_j, s_i > 0; none of them reaches +-maxv when zr_j >= -maxv
+// and smax / sd_j + zr_j <= maxv (smax: the largest s of any row -- conservative).  flags[0] counts the columns still in the bitmaps that
+// fail the test (the structures must be rebuilt with them demoted), flags[1] those that fail it with the safety margin `tight` < 1
+// (chosen at the first scaling of a fit); want[j] = demoted already, or failing with the margin.
+__global__ void k_bp_scale_stats(const double* __restrict__ stat, const int64_t* __restrict__ cp_o, int P_o, const int64_t* __restrict__ cp_s, int P_s,
+                                 const double* __restrict__ parts, int nparts, const float* __restrict__ zcol, int64_t M, int32_t H, float maxv, double tight,
+                                 const double* __restrict__ smax_p, const uint8_t* __restrict__ demoted, double* __restrict__ mean_out, double* __restrict__ sd_out,
+                                 double* __restrict__ inv_out, double* __restrict__ bsum_out, uint8_t* __restrict__ want, int* __restrict__ flags) {
+#pragma clang fp contract(off)
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= H) return;
+    const double z = (double)zcol[j];
+    int64_t stored = 0;
+    for (int p = 0; p < P_o; ++p) stored += cp_o[(int64_t)p * H + j + 1] - cp_o[(int64_t)p * H + j];
+    for (int p = 0; p < P_s; ++p) stored += cp_s[(int64_t)p * H + j + 1] - cp_s[(int64_t)p * H + j];
+    double bs = 0.0, bq = 0.0, bc = 0.0;
+    for (int p = 0; p < nparts; ++p) {
+        const double* b = parts + ((int64_t)p * H + j) * 3;
+        bs += b[0]; bq += b[1]; bc += b[2];
+    }
+    const double cnt = (double)stored + rint(bc);
+    const float zsq = zcol[j] * zcol[j];
+    const double zz = (double)zsq;
+    const double mean = z + (stat[2 * j] + bs) / (double)M;
+    const double mean_sq = ((stat[2 * j + 1] + bq) + ((double)M - cnt) * zz) / (double)M;
+    double var = mean_sq - mean * mean;
+    if (M != 1) var *= (double)M / (double)(M - 1);
+    double sd = (var > 0.0) ? sqrt(var) : 0.0;
+    if (sd == 0.0) sd = 1.0;
+    mean_out[j] = mean;
+    sd_out[j] = sd;
+    inv_out[j] = 1.0 / sd;
+    bsum_out[j] = bs;
+    uint8_t w = demoted[j];
+    if (maxv > 0.f && !w) {
+        const double zr = (z - mean) / sd, top = smax_p[0] / sd + zr, lim = (double)maxv;
+        if (zr < -lim || top > lim) atomicAdd(&flags[0], 1);
+        if (zr < -lim * tight || top > lim * tight) { atomicAdd(&flags[1], 1); w = 1; }
+    }
+    want[j] = w;
+}
+
+__global__ void k_bp_scale_rest(const int32_t* __restrict__ cols, int64_t n, const double* __restrict__ mean, const double* __restrict__ sd, float maxv,
+                                float* __restrict__ x) {
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t j = cols[t];
+        x[t] = scale_value(x[t], mean[j], sd[j], maxv);
+    }
+}
+
+constexpr double kBpClipMargin = 0.9;      // a column is demoted at the first scaling of a fit when an entry equal to 1 could come within 10 % of the clip
+
+int bp_scale(ddx_ctx* ctx, float max_value) {
+    BitPlanes& bp = ctx->bp;
+    const int32_t H = ctx->H;
+    const int64_t M = ctx->M;
+    double* stat = ctx->colstat.as<double>();
+    double* mean = stat + 2 * H;
+    double* sd = stat + 3 * H;
+    double* inv = stat + 4 * H;
+    double* bsum = stat + 5 * H;
+    uint8_t* want = reinterpret_cast<uint8_t*>(stat + 6 * H);
+    int* flags = reinterpret_cast<int*>(stat + 7 * H);
+    for (int attempt = 0;; ++attempt) {
+        const double* parts = nullptr;
+        int nparts = 0;
+        DDX_TRY(bp_scale_sums(ctx, &parts, &nparts));
+        int hflags[2] = {0, 0};
+        {
+            ScopedTimer t(ctx, "scale");
+            DDX_TRY(col_sums_of(ctx, bp.restm_colptr, bp.restm_x, bp.restm_s_colptr, bp.restm_s_x, 1, stat));
+            DDX_HIP(ctx, hipMemsetAsync(flags, 0, 2 * sizeof(int), ctx->stream));
+            k_bp_scale_stats<<<(unsigned)ceil_div(H, 256), 256, 0, ctx->stream>>>(stat, bp.restm_colptr, ctx->P_o, bp.restm_s_colptr, ctx->P_s, parts, nparts, ctx->zcol.as<float>(), M, H,
+                                                                                  max_value, kBpClipMargin, bp.cmax + 128, ctx->bp_demote.as<uint8_t>(), mean, sd, inv, bsum, want, flags);
+            DDX_HIP(ctx, hipMemcpyAsync(hflags, flags, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        const bool choose = !bp.demote_decided && hflags[1] > 0;
+        if (hflags[0] == 0 && !choose) break;
+        if (attempt) return set_err(ctx, DDX_E_NUMERIC, "standard scaling: %d columns still reach the clip after their demotion", hflags[0]);
+        // columns whose entries equal to 1 reach the clip (or, at the first scaling of the fit, come close): out of the bitmaps for the
+        // rest of the fit, then the statistics again on the rebuilt structures (the sums themselves do not depend on the split)
+        std::vector<uint8_t> hwant((size_t)H);
+        DDX_HIP(ctx, hipMemcpyAsync(hwant.data(), want, (size_t)H, hipMemcpyDeviceToHost, ctx->stream));
+        DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        DDX_TRY(bp_rebuild_demoted(ctx, hwant));
+    }
+    bp.demote_decided = true;
+    {
+        ScopedTimer t(ctx, "scale");
+        const int64_t n_rest = bp.nrest_o + bp.nrest_s;
+        if (n_rest > 0) k_bp_scale_rest<<<(unsigned)std::min<int64_t>(4096, ceil_div(n_rest, 256)), 256, 0, ctx->stream>>>(bp.rest_cols, n_rest, mean, sd, max_value, bp.rest_x);
+        k_scale_cols<<<(unsigned)H, 256, 0, ctx->stream>>>(bp.restm_colptr, ctx->P_o, H, mean, sd, max_value, bp.restm_x);
+        if (ctx->P_s > 0) k_scale_cols<<<(unsigned)H, 256, 0, ctx->stream>>>(bp.restm_s_colptr, ctx->P_s, H, mean, sd, max_value, bp.restm_s_x);
+        k_scale_zcol<<<(unsigned)ceil_div(H, 256), 256, 0, ctx->stream>>>(mean, sd, max_value, H, ctx->zcol.as<float>());
+        // new column means: (bitmap share (B^T s)_j / sd_j + sums of x' - z'_j over the reduced mirrors) / M
+        DDX_TRY(col_sums_of(ctx, bp.restm_colptr, bp.restm_x, bp.restm_s_colptr, bp.restm_s_x, 0, ctx->colmean.as<double>(), bsum, 1, inv));
+    }
+    DDX_HIP(ctx, hipGetLastError());
+    bp.scaled = true;
+    bp.inv_sd = inv;
+    ctx->pk_valid[0] = ctx->pk_valid[1] = false;
+    ctx->scaled = true;
+    ctx->rows_scaled = false;
     ctx->have_emb = ctx->have_knn = false;
     return DDX_OK;
 }

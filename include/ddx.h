@@ -242,8 +242,10 @@ int ddx_get_knn_candidate_counts(ddx_ctx* ctx, int32_t* counts_out /* [M] */);
 int ddx_get_upload_form(ddx_ctx* ctx, int32_t* form);
 /* statistics of the bit-plane route of the last ddx_pca (sc.tl.pca call site, dd.py:305-314; csrc/k_bitplane.hip):
  * out[0] = 1 when the last iteration's operator products took it, out[1] / out[2] = stored entries other than 1 of the original /
- * synthetic rows (what the sparse products still walk), out[3] = 8-bit digits per operand value.  bench.py prices the kernels by it. */
-int ddx_get_bitplane_stats(ddx_ctx* ctx, int64_t* out /* [4] */);
+ * synthetic rows (what the sparse products still walk), out[3] = 8-bit digits per operand value, out[4] = 1 when the matrix was scaled
+ * on these structures (ddx_scale, dd.py:302-303), out[5] = columns demoted from the bitmaps because an entry equal to 1 could reach the
+ * scaling's clip (all their entries are among out[1] / out[2]), out[6..7] reserved.  bench.py prices the kernels by it. */
+int ddx_get_bitplane_stats(ddx_ctx* ctx, int64_t* out /* [8] */);
 
 /* ---- graph construction (device) ------------------------------------------------------------
  * mode 0: PhenoGraph Jaccard graph, prune=True  (mutual kNN, weight J_ij*J_ji)
