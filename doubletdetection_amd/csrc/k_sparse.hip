@@ -1611,11 +1611,27 @@ __global__ void k_bp_scale_stats(const double* __restrict__ stat, const int64_t*
     if (sd == 0.0) sd = 1.0;
     mean_out[j] = mean;
     sd_out[j] = sd;
-    inv_out[j] = 1.0 / sd;
     bsum_out[j] = bs;
     uint8_t w = demoted[j];
+    // The factor the matrix-core products apply to column j's entries equal to 1.  What the dense matrix holds for such an entry is the
+    // float32 x'_ij against the float32 background z'_j, i.e. L_ij = s_i / sd_j + c_j with c_j = (z - mean_j) / sd_j - z'_j, the rounding
+    // of the background -- the same for every entry of the column, and a perturbation that is coherent along a column moves the
+    // principal components far more than the entries' individual roundings do.  It is folded into the factor through the column's
+    // mean s (c_j s_i / sbar_j: exact in the column's sum, what is left has zero mean over the column).  A demoted column has no bits:
+    // factor 0, so that its (large) 1 / sd does not take digits away from the others.
+    const double zr = (z - mean) / sd;
+    double inv = 0.0;
+    if (!w) {
+        inv = 1.0 / sd;
+        if (bs > 0.0 && bc >= 0.5) {
+            const float zs = scale_value(zcol[j], mean, sd, maxv);
+            const double c = zr - (double)zs;
+            if (fabs(c) <= 1e-5 * (fabs(zr) + 1.0)) inv += c * rint(bc) / bs;      // (a clipped background is no rounding: that column is about to be demoted)
+        }
+    }
+    inv_out[j] = inv;
     if (maxv > 0.f && !w) {
-        const double zr = (z - mean) / sd, top = smax_p[0] / sd + zr, lim = (double)maxv;
+        const double top = smax_p[0] / sd + zr, lim = (double)maxv;
         if (zr < -lim || top > lim) atomicAdd(&flags[0], 1);
         if (zr < -lim * tight || top > lim * tight) { atomicAdd(&flags[1], 1); w = 1; }
     }

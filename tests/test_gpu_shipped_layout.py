@@ -5,7 +5,7 @@ The headline fit is: automatic bit-plane route (from 4096 cells on) x doublets d
 leader already iterates.  The golden cases force that route onto 500-cell matrices with two lanes; here it is taken the way
 production takes it -- default options, sizes at which it is selected by itself:
 
-* 8 192 x 6 000 (the CPU oracle is still affordable): seven lanes == one lane, attribute by attribute; the seven-lane fit ==
+* 8 192 x 6 400 restricted to its 6 000 most variable genes (the CPU oracle is still affordable): seven lanes == one lane, attribute by attribute; the seven-lane fit ==
   `oracle.OracleClassifier(pca="f64")` (communities and scores identical, log p 1e-9);
 * BASELINE configs[1] (50 000 x 20 000, 5 %): seven lanes == one lane;
 * followers that clone while the leader's create_doublets has to GROW the buffers they are copying from (boost_rate 0.5 at
@@ -23,7 +23,7 @@ from oracle import dd_oracle as orc
 
 pytestmark = pytest.mark.gpu
 
-ATTRS = ("all_log_p_values_", "all_scores_", "communities_", "synth_communities_", "top_var_genes_")
+ATTRS = ("all_log_p_values_", "all_scores_", "communities_", "synth_communities_")
 
 
 def _native_louvain(indptr, indices, weights, gamma, seed):
@@ -53,6 +53,9 @@ def _same_fit(a, b):
     np.testing.assert_array_equal(np.asarray(a.parents_), np.asarray(b.parents_))
     for name in ATTRS:
         np.testing.assert_array_equal(getattr(a, name), getattr(b, name), err_msg=name)
+    assert hasattr(a, "top_var_genes_") == hasattr(b, "top_var_genes_")      # (dd.py:165-176: only set when genes are dropped)
+    if hasattr(a, "top_var_genes_"):
+        np.testing.assert_array_equal(a.top_var_genes_, b.top_var_genes_)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         assert np.array_equal(a.predict(), b.predict(), equal_nan=True)
@@ -62,17 +65,17 @@ def _same_fit(a, b):
 def data_8k():
     from doubletdetection_amd._synthetic import make_counts
 
-    return make_counts(8192, 6000, density=0.08, n_types=8, doublet_frac=0.08, seed=606)
+    return make_counts(8192, 6400, density=0.08, n_types=8, doublet_frac=0.08, seed=606)
 
 
 @pytest.fixture(scope="module")
 def fit_8k_seven(data_8k):
-    return _fit(data_8k, 7, n_iters=7, random_state=0)
+    return _fit(data_8k, 7, n_iters=7, random_state=0, n_top_var_genes=6000)
 
 
 def test_seven_contexts_equal_one_context_on_the_automatic_bitplane_route(data_8k, fit_8k_seven):
     """(a) default options at 8 192 cells: BoostClassifier(n_iters=7, streams_per_device=7) == streams_per_device=1."""
-    one = _fit(data_8k, 1, n_iters=7, random_state=0)
+    one = _fit(data_8k, 1, n_iters=7, random_state=0, n_top_var_genes=6000)
     _same_fit(fit_8k_seven, one)
 
 
@@ -81,7 +84,8 @@ def test_seven_context_fit_matches_the_float64_oracle(data_8k, fit_8k_seven):
     clf = fit_8k_seven
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        ref = orc.OracleClassifier(pca="f64", louvain_fn=_native_louvain, best_of_fn=_native_best_of, n_iters=7, random_state=0).fit(data_8k)
+        ref = orc.OracleClassifier(pca="f64", louvain_fn=_native_louvain, best_of_fn=_native_best_of, n_iters=7, random_state=0,
+                                   n_top_var_genes=6000).fit(data_8k)
     np.testing.assert_array_equal(clf.top_var_genes_, ref.top_var_genes_)
     np.testing.assert_array_equal(np.asarray(clf.parents_), np.asarray(ref.parents_))
     agree = float(np.mean(clf.communities_ == ref.communities_))
