@@ -68,6 +68,21 @@ def _dist_info():
 _CONTEXT_POOL: dict = {}          # device -> [parked _lib.Context, ...]
 
 
+def _cpu_allowance() -> float:
+    """CPUs' worth of time this process may use: the cgroup quota when there is one (the pods these GPUs come in show 256 CPUs and
+    allow 16), else the CPUs it may run on."""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            return max(1.0, float(quota) / float(period))
+    except (OSError, ValueError):
+        pass
+    try:
+        return float(len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        return float(os.cpu_count() or 1)
+
+
 def _keep_contexts() -> bool:
     return os.environ.get("DDX_KEEP_CONTEXT", "1") not in ("", "0")
 
@@ -822,11 +837,18 @@ class BoostClassifier:
             raise
         return csr, leaders, restrict
 
-    def _fit_switches(self, engine):
-        """Switches of a device context that follow from this fit's parameters (set before the upload: the bit planes of the
-        operator products, k_bitplane.hip, are built when the counts become resident).  None are needed since round 6: scaled
-        matrices take the bit-plane route (1 / sd_j is a diagonal factor, ddx_scale) and sketches wider than 40 columns run
-        their products in 40-column blocks on it (ddx_pca)."""
+    def _fit_switches(self, engine, world=None):
+        """Switches of a device context that follow from this fit's circumstances.  (The bit planes of the operator products need
+        none since round 6: scaled matrices take that route -- 1 / sd_j is a diagonal factor, ddx_scale -- and sketches wider than
+        40 columns run their products in 40-column blocks on it, ddx_pca.)  How the lane threads wait for the GPU: spinning (the
+        runtime's way, lowest latency) keeps one CPU busy per waiting thread; with several ranks on one node, or fewer CPUs allowed
+        than lanes, they sleep between polls instead (option host_wait=block, ddx.h) -- unless the caller chose (DDX_OPTIONS / OPTIONS)."""
+        ctx = getattr(engine, "ctx", None)
+        if ctx is not None and hasattr(ctx, "set_option") and "host_wait" not in _lib.current_options():
+            if world is None:
+                world = _dist_info()[1]
+            lanes = self.streams_per_device or self._AUTO_STREAMS
+            ctx.set_option("host_wait", "block" if (world > 1 or _cpu_allowance() < lanes * world + 1) else "spin")
         return engine
 
     def _open_lanes(self, leaders, n_mine):

@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <thread>
+#include <time.h>
 
 #include "ddx_internal.h"
 
@@ -24,6 +25,34 @@ int set_err(ddx_ctx* ctx, int code, const char* fmt, ...) {
     va_end(ap);
     if (ctx) ctx->err = buf; else g_tls_err = buf;
     return code;
+}
+
+// Every host wait of the library.  The runtime's hipStreamSynchronize spins: a waiting lane thread keeps a CPU busy (0.83 s of CPU time per
+// 0.12 s fit with seven lanes; the pods these GPUs come in allow 16 CPUs' worth of time).  Round 5 asked the runtime to block instead
+// (hipSetDeviceFlags(hipDeviceScheduleBlockingSync)) and a process that had run 120 fits then hung at exit: hipFree's SyncAllStreams waited on a
+// completion nobody signalled any more (profiles/r06_host_wait_hang.txt: stack of the hung process) -- the flag was set on a device torch had
+// already made active.  So the library waits by itself and leaves the device's flags alone: record an event, poll it -- a short spin for the
+// common few-microsecond waits, then sleeps of ~20 us between polls.
+hipError_t wait_stream(ddx_ctx* ctx) {
+    if (ctx->opt.host_wait != 1) return hipStreamSynchronize(ctx->stream);
+    if (!ctx->wait_ev) {
+        const hipError_t e = hipEventCreateWithFlags(&ctx->wait_ev, hipEventDisableTiming);
+        if (e != hipSuccess) { ctx->wait_ev = nullptr; return hipStreamSynchronize(ctx->stream); }
+    }
+    hipError_t e = hipEventRecord(ctx->wait_ev, ctx->stream);
+    if (e != hipSuccess) return e;
+    for (int i = 0; i < 64; ++i) {
+        e = hipEventQuery(ctx->wait_ev);
+        if (e != hipErrorNotReady) return e;
+    }
+    const struct timespec nap = {0, 20000};
+    for (;;) {
+        e = hipEventQuery(ctx->wait_ev);
+        if (e != hipErrorNotReady) break;
+        nanosleep(&nap, nullptr);
+    }
+    (void)hipGetLastError();                     // (hipErrorNotReady is not an error to report later)
+    return e;
 }
 
 void release(ddx_ctx* ctx, DevBuf& b) {
@@ -63,7 +92,7 @@ void arena_hint(ddx_ctx* ctx, size_t bytes) {
 // A context starts a new fit: forget every buffer and result of the previous one, keep the chunks (their memory is
 // handed out again from the start).  Called by the entry points that make counts resident.
 void context_reset(ddx_ctx* ctx) {
-    (void)hipStreamSynchronize(ctx->stream);
+    (void)wait_stream(ctx);
     {
         std::lock_guard<std::mutex> lock(ctx->view_mu);       // the buffers the view points into are about to be handed out again
         ctx->view = ddx::CloneView();
@@ -165,6 +194,7 @@ bool Options::set(const char* key, const char* value) {
     if (k == "pca_gather") { if (v == "f32") gather_f32 = true; else if (v == "f64") gather_f32 = false; else return false; return true; }
     if (k == "spmm_geom") { if (v == "auto") spmm_geom = 0; else if (v == "pair") spmm_geom = 1; else if (v == "quad") spmm_geom = 2; else return false; return true; }
     if (k == "spmm_trip") { if (v == "packed") trip_packed = true; else if (v == "f64") trip_packed = false; else return false; return true; }
+    if (k == "host_wait") { if (v == "block") host_wait = 1; else if (v == "spin" || v == "auto") host_wait = 0; else return false; return true; }
     if (k == "bitplane") { if (v == "auto") bitplane = 1; else if (!num(0, 2, &x)) return false; else bitplane = (int)x; return true; }
     if (k == "residual") { if (v == "packed") residual_packed = true; else if (v == "plain") residual_packed = false; else return false; return true; }
     if (k == "residual_rows_own") { if (!num(6, 12, &x) || (x != 6 && x != 12)) return false; residual_rows_own = (int)x; return true; }
@@ -247,7 +277,7 @@ void timing_end(ddx_ctx* ctx) {
 
 int timing_flush(ddx_ctx* ctx) {
     if (ctx->t_pending.empty()) return DDX_OK;
-    DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    DDX_HIP(ctx, wait_stream(ctx));
     for (auto& ev : ctx->t_pending) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, ev.start, ev.stop) == hipSuccess) {
@@ -323,17 +353,28 @@ int ddx_create(int device, ddx_ctx** out) {
 
 int ddx_destroy(ddx_ctx* ctx) {
     if (!ctx) return DDX_OK;
+    const bool dbg = ctx->opt.upload_debug > 0;
+    auto step = [&](const char* what) { if (dbg) { fprintf(stderr, "[ddx_destroy %p] %s\n", (void*)ctx, what); fflush(stderr); } };
+    step("set device");
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
+    step("stream synchronize");
+    (void)wait_stream(ctx);
+    step("timing flush");
     (void)timing_flush(ctx);
     for (hipEvent_t e : ctx->t_free) (void)hipEventDestroy(e);
     ctx->t_free.clear();
     ctx->t_ref.reset();
+    step("context reset");
     context_reset(ctx);
+    step("arena destroy (hipFree)");
     arena_destroy(ctx);
+    step("host free");
     if (ctx->lv_host) (void)hipHostFree(ctx->lv_host);
+    step("stream destroy");
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+    if (ctx->wait_ev) (void)hipEventDestroy(ctx->wait_ev);
     (void)hipStreamDestroy(ctx->stream);
+    step("done");
     delete ctx;
     return DDX_OK;
 }
@@ -341,7 +382,7 @@ int ddx_destroy(ddx_ctx* ctx) {
 int ddx_synchronize(ddx_ctx* ctx) {
     REQUIRE_CTX(ctx);
     USE_DEVICE(ctx);
-    DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    DDX_HIP(ctx, wait_stream(ctx));
     return DDX_OK;
 }
 
@@ -369,7 +410,7 @@ int ddx_check_memory(ddx_ctx* ctx) {
     REQUIRE_CTX(ctx);
     USE_DEVICE(ctx);
     if (!ctx->opt.arena_guard) return set_err(ctx, DDX_E_ARG, "the context was created without DDX_ARENA_GUARD=1");
-    DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    DDX_HIP(ctx, wait_stream(ctx));
     std::vector<unsigned char> h(kArenaPad);
     int n = 0;
     for (const auto& blk : ctx->arena.blocks) {
@@ -734,7 +775,7 @@ static int send_packed(ddx_ctx* ctx, const PackShare& sh, bool owner, double t_i
     if (rc != DDX_OK || !fold_ok) ctx->hvg_rows = -1;
     (void)hipStreamSynchronize(ctx->copy_stream);
     const double t_copied = clk();
-    (void)hipStreamSynchronize(ctx->stream);                                   // (the pinned buffer and the host lists are reused / freed)
+    (void)wait_stream(ctx);                                   // (the pinned buffer and the host lists are reused / freed)
     if (dbg)
         fprintf(stderr, "[ddx upload] %d-byte form%s, %d threads, %lld chunks: last copy issued +%.2f ms, copies done +%.2f, expanded +%.2f\n",
                 (int)esz, owner ? "" : " (another context's packing)", T, (long long)nchunks, t_issued - t_in, t_copied - t_in, clk() - t_in);
@@ -782,7 +823,7 @@ static int upload_packed(ddx_ctx* ctx, int64_t n_cells, int64_t nnz, int32_t n_g
         const double t_in = clk();
         int rc = packed_device_buffer(ctx, f16, nnz);
         if (rc == DDX_OK) {
-            (void)hipStreamSynchronize(ctx->stream);       // the copies must not overtake whatever the main stream still does with the device buffers
+            (void)wait_stream(ctx);       // the copies must not overtake whatever the main stream still does with the device buffers
             rc = send_packed(ctx, *sh, false, t_in);
         }
         share_lock.lock();
@@ -863,7 +904,7 @@ static int upload_packed(ddx_ctx* ctx, int64_t n_cells, int64_t nnz, int32_t n_g
     g_share = &share;
     share_lock.unlock();
     const double t_in = clk();
-    (void)hipStreamSynchronize(ctx->stream);               // the copies must not overtake whatever the main stream still does with the device buffers
+    (void)wait_stream(ctx);               // the copies must not overtake whatever the main stream still does with the device buffers
     pool->start(worker);
     int rc = send_packed(ctx, share, true, t_in);
     pool->wait();
@@ -984,7 +1025,7 @@ int ddx_clone_counts(ddx_ctx* ctx, ddx_ctx* src) {
 static int d2h(ddx_ctx* ctx, void* dst, const void* src, size_t bytes) {
     if (!bytes) return DDX_OK;
     DDX_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    DDX_HIP(ctx, wait_stream(ctx));
     return DDX_OK;
 }
 
@@ -1175,7 +1216,7 @@ int ddx_set_embedding(ddx_ctx* ctx, const float* emb, int64_t n_rows, int32_t n_
     DDX_TRY(ensure(ctx, ctx->emb32, sizeof(float) * n_rows * n_components));
     DDX_HIP(ctx, hipMemcpyAsync(ctx->emb32.p, emb, sizeof(float) * n_rows * n_components, hipMemcpyHostToDevice,
                                 ctx->stream));
-    DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    DDX_HIP(ctx, wait_stream(ctx));
     ctx->embM = n_rows;
     ctx->C = n_components;
     ctx->have_emb = true;
@@ -1270,18 +1311,6 @@ int ddx_pca_exact_sparse(ddx_ctx* ctx, int32_t n_components, int32_t n_oversampl
 int ddx_set_option(ddx_ctx* ctx, const char* key, const char* value) {
     REQUIRE_CTX(ctx);
     if (!key) return set_err(ctx, DDX_E_ARG, "ddx_set_option: no key");
-    if (std::string(key) == "host_wait") {
-        // how host threads wait for the GPU (a property of the device in this process, not of the context): "spin" (the runtime's
-        // default with few devices: lowest latency, one busy CPU per waiting thread) or "block" (the waiting thread sleeps on an
-        // interrupt: 0.34 instead of 0.83 s of CPU time per fit at the headline and no slower -- profiles/tools/cpu_quota_check.py --,
-        // but NOT the default: a process that had run 120 fits with it hung in ddx_destroy at interpreter exit, profiles/tools/soak.py)
-        const std::string v = value ? value : "";
-        if (v != "spin" && v != "block" && v != "yield" && v != "auto") return set_err(ctx, DDX_E_ARG, "ddx_set_option: host_wait = spin | yield | block | auto");
-        USE_DEVICE(ctx);
-        const unsigned flag = v == "spin" ? hipDeviceScheduleSpin : v == "yield" ? hipDeviceScheduleYield : v == "block" ? hipDeviceScheduleBlockingSync : hipDeviceScheduleAuto;
-        DDX_HIP(ctx, hipSetDeviceFlags(flag));
-        return DDX_OK;
-    }
     if (!ctx->opt.set(key, value)) return set_err(ctx, DDX_E_ARG, "ddx_set_option: unknown key or value '%s' = '%s'", key, value ? value : "");
     return DDX_OK;
 }
@@ -1349,7 +1378,7 @@ int ddx_get_graph(ddx_ctx* ctx, int64_t* indptr, int32_t* indices, double* weigh
         DDX_HIP(ctx, hipMemcpyAsync(indices, ctx->g_d_cols, sizeof(int32_t) * ctx->g_entries, hipMemcpyDeviceToHost, ctx->stream));
         DDX_HIP(ctx, hipMemcpyAsync(weights, ctx->g_d_vals, sizeof(double) * ctx->g_entries, hipMemcpyDeviceToHost, ctx->stream));
     }
-    DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    DDX_HIP(ctx, wait_stream(ctx));
     return DDX_OK;
 }
 
@@ -1382,7 +1411,7 @@ int ddx_get_coarse_graph(ddx_ctx* ctx, int32_t* member, int64_t* indptr, int32_t
     REQUIRE_CTX(ctx);
     USE_DEVICE(ctx);
     NEED(ctx->c_nodes >= 0 && ctx->g_nodes >= 0 && ctx->lv_host_valid, "no coarse graph");
-    DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));        // the packed copy issued by ddx_coarsen_graph has landed
+    DDX_HIP(ctx, wait_stream(ctx));        // the packed copy issued by ddx_coarsen_graph has landed
     const int64_t E = ctx->c_entries, nc = ctx->c_nodes, n = ctx->g_nodes;
     const double* hw = static_cast<const double*>(ctx->lv_host);
     const int64_t* hi = reinterpret_cast<const int64_t*>(hw + E);

@@ -60,6 +60,8 @@ struct Options {
     bool synthetic_derived = true;   // bit-plane route: a doublet's bitmap row and reduced entries from its parents' (k_bp_synth); false: from the merged row
     int fault = 0;                   // fault injection (tests): 1 = allow_dynamic_lds fails
     bool hvg_fold = true;            // gene sums folded in while the packed matrix arrives (off: one pass after the upload)
+    int host_wait = 0;               // how a host thread waits for its stream (ddx::wait_stream): 0 the runtime's hipStreamSynchronize (spins), 1 "block": an event is polled
+                                     // with sleeps in between (a waiting thread costs a few per cent of a CPU instead of a whole one)
     bool set(const char* key, const char* value);
 };
 
@@ -115,6 +117,8 @@ struct BitPlanes {
     void* qd = nullptr;              // operand digits
     double* cmax = nullptr;          // [2][64] column maxima of the operand: Q side, Y side
     const double* ymax_of = nullptr; // the row-side matrix whose maxima (of diag(s) Y) the sparse A Q kernel has just left in cmax[64..]
+    const double* qmax_of = nullptr; // the column-side matrix whose (weighted) maxima the Cholesky-QR's right multiplication has just left in cmax[0..63]
+    bool qmax_zeroed = false;        // cmax[0..63] are zeros (the last Y-side digit kernel cleared them): maxima may be collected into them
     double* part = nullptr;          // partial blocks of the A^T Y product, one per chunk of the rows
     // standard scaling (sc.pp.scale, dd.py:302-303) on this route: an entry equal to 1 becomes s_i / sd_j as long as it is not clipped, so the
     // bitmaps stay what they are and 1 / sd_j goes into the operand (A Q) / the epilogue (A^T Y).  Columns in which an entry equal to 1 could
@@ -176,6 +180,7 @@ struct ddx_ctx {
     ddx::DevBuf raw_indptr, raw_indices, raw_data;
     std::vector<int64_t> h_raw_indptr;
     hipStream_t copy_stream = nullptr;   // the packed chunks travel on their own stream
+    hipEvent_t wait_ev = nullptr;        // the event ddx::wait_stream polls (option host_wait=block)
     ddx::DevBuf raw_packed;          // the packed matrix on the device (expanded chunk by chunk)
     // gene sums accumulated while the matrix arrives (ddx_upload_raw, 2-byte form): per gene the two running float32 sums of
     // dd.py:167-170 in row order, carried from chunk to chunk; valid_rows = rows folded in so far (-1: none / another matrix)
@@ -333,6 +338,8 @@ struct ddx_ctx {
 namespace ddx {
 
 int set_err(ddx_ctx* ctx, int code, const char* fmt, ...);
+// wait until everything queued on the context's stream has finished (every host wait of the library goes through here: option host_wait)
+hipError_t wait_stream(ddx_ctx* ctx);
 int ensure(ddx_ctx* ctx, DevBuf& b, size_t bytes);
 void release(ddx_ctx* ctx, DevBuf& b);
 void arena_hint(ddx_ctx* ctx, size_t bytes);      // expected total need: sizes the next chunk

@@ -583,7 +583,7 @@ static int bp_reduce(ddx_ctx* ctx, const float* raw, const int32_t* idx, const f
     if (scan_out) *scan_out = scan;
     if (count_only) {
         DDX_HIP(ctx, hipMemcpyAsync(kept, scan + n, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-        DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        DDX_HIP(ctx, wait_stream(ctx));
         return DDX_OK;
     }
     (void)cap_out;
@@ -670,7 +670,7 @@ int bp_build(ddx_ctx* ctx) {
     const int rc = bp_launch_bitmaps(ctx, 0, bp.ntile_o);
     ctx->M = M_keep;
     DDX_TRY(rc);
-    DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    DDX_HIP(ctx, wait_stream(ctx));
     DDX_HIP(ctx, hipGetLastError());
     bp.ready = true;
     bp.values = false;
@@ -707,7 +707,7 @@ int bp_clone(ddx_ctx* ctx, const CloneView& src) {
         DDX_HIP(ctx, hipMemcpyAsync(ctx->bp_demote.p, bp.demote.data(), (size_t)src.H, hipMemcpyHostToDevice, ctx->stream));
     else
         DDX_HIP(ctx, hipMemsetAsync(ctx->bp_demote.p, 0, (size_t)src.H, ctx->stream));
-    DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));          // (the host vector is a local copy)
+    DDX_HIP(ctx, wait_stream(ctx));          // (the host vector is a local copy)
     ctx->bp = bp;
     return DDX_OK;
 }
@@ -759,7 +759,7 @@ static int bp_refresh_once(ddx_ctx* ctx) {
             DDX_TRY(scan_counts(ctx, cnt, S, bp.nrest_o, bp.rest_indptr + N));
             int64_t last = 0;
             DDX_HIP(ctx, hipMemcpyAsync(&last, bp.rest_indptr + M, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
-            DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            DDX_HIP(ctx, wait_stream(ctx));
             const int64_t kept = last - bp.nrest_o;
             if (kept > bp.cap_rest_s) {
                 bp.want_rest_s = kept + kept / 2;
@@ -866,6 +866,8 @@ static int bp_workspace(ddx_ctx* ctx) {
     bp.rowop = reinterpret_cast<double*>(b + dig + bp_align(sizeof(double) * 192) + prt);
     DDX_HIP(ctx, hipMemsetAsync(bp.cmax, 0, sizeof(double) * 192, ctx->stream));
     bp.ymax_of = nullptr;
+    bp.qmax_of = nullptr;
+    bp.qmax_zeroed = true;
     return DDX_OK;
 }
 
@@ -910,7 +912,12 @@ int bp_rows_product(ddx_ctx* ctx, const double* Q, int L, double* Y) {
         ScopedTimer t(ctx, "bitplane_prep");
         // scaled matrix: the operand is diag(1 / sd) Q -- the digits are cut from the weighted rows, the bitmaps and the row scales stay
         const double* wq = bp.scaled ? bp.inv_sd : nullptr;
-        k_bp_colmax<<<(unsigned)std::min<int64_t>(256, ceil_div(ctx->H, 64)), 256, 0, ctx->stream>>>(Q, wq, ctx->H, L, cmaxQ);      // (into zeros: bp_refresh / the last Y-side digits)
+        if (bp.qmax_of != Q) {                                    // (else: left there by the kernel that produced Q, k_right_mult)
+            if (!bp.qmax_zeroed) DDX_HIP(ctx, hipMemsetAsync(cmaxQ, 0, sizeof(double) * 64, ctx->stream));
+            k_bp_colmax<<<(unsigned)std::min<int64_t>(256, ceil_div(ctx->H, 64)), 256, 0, ctx->stream>>>(Q, wq, ctx->H, L, cmaxQ);      // (into zeros)
+        }
+        bp.qmax_of = nullptr;
+        bp.qmax_zeroed = false;
         const int nslot = (NT * 32 + ND - 1) / ND;
         const int64_t nthreads = std::max<int64_t>(64, (int64_t)bp.SKc * kBpSteps * 2 * nslot);
         if (ND == 3) k_bp_digits<3, false><<<(unsigned)ceil_div(nthreads, 256), 256, 0, ctx->stream>>>(Q, wq, ctx->H, L, NT, nslot, cmaxQ, bp.SKc, 0, 0, qd, cmaxY);
@@ -948,6 +955,8 @@ int bp_cols_product(ddx_ctx* ctx, const double* Y, int L, const double** part, i
         else k_bp_digits<4, true><<<(unsigned)ceil_div(nthreads, 256), 256, 0, ctx->stream>>>(Y, bp.srow, ctx->M, L, NT, nslot, cmaxY, SK, bp.Npad, ctx->N, qd, cmaxQ);
     }
     bp.ymax_of = nullptr;
+    bp.qmax_zeroed = true;                                        // (zero_me of the digit kernel above)
+    bp.qmax_of = nullptr;
     BpProductArgs a{};
     a.bm = reinterpret_cast<const v4i*>(bp.bm_cols); a.qd = qd; a.ntile = bp.ntile_c; a.SK = (int)SK; a.SKstride = bp.SKr; a.sk_per_chunk = per; a.L = L;
     a.cmax = cmaxY; a.nOut = ctx->H; a.out = bp.part;

@@ -1556,7 +1556,7 @@ int stage_knn_candidate_counts(ddx_ctx* ctx, int32_t* host_out) {
     DDX_TRY(ensure(ctx, ctx->sort_vals_out, sizeof(int32_t) * (size_t)M));
     k_knn_counts_by_id<<<(unsigned)ceil_div(M, 256), 256, 0, ctx->stream>>>(ctx->knn_ccount, ctx->knn_perm, M, ctx->sort_vals_out.as<int32_t>());
     DDX_HIP(ctx, hipMemcpyAsync(host_out, ctx->sort_vals_out.p, sizeof(int32_t) * (size_t)M, hipMemcpyDeviceToHost, ctx->stream));
-    DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    DDX_HIP(ctx, wait_stream(ctx));
     return DDX_OK;
 }
 
@@ -1776,7 +1776,7 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
 #undef DDX_EMIT_ONE
         if (tdbg) {
             std::vector<long long> ht(4 * (size_t)grid_x);
-            DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            DDX_HIP(ctx, wait_stream(ctx));
             DDX_HIP(ctx, hipMemcpy(ht.data(), tdbg, sizeof(long long) * ht.size(), hipMemcpyDeviceToHost));
             DDX_HIP(ctx, hipFree(tdbg));
             long long t0 = 0, t1 = 0;
@@ -1840,7 +1840,7 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
 #undef DDX_SELECT_LAUNCH
         if (rdbg) {
             std::vector<long long> hd(8 * 4096);
-            DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            DDX_HIP(ctx, wait_stream(ctx));
             DDX_HIP(ctx, hipMemcpy(hd.data(), rdbg, sizeof(long long) * hd.size(), hipMemcpyDeviceToHost));
             DDX_HIP(ctx, hipFree(rdbg));
             long long t0 = 0;
@@ -1854,7 +1854,7 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
     if (ctx->opt.knn_debug) {
         std::vector<int32_t> h(Mp + 1);
         DDX_HIP(ctx, hipMemcpyAsync(h.data(), ccount, sizeof(int32_t) * (Mp + 1), hipMemcpyDeviceToHost, ctx->stream));
-        DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        DDX_HIP(ctx, wait_stream(ctx));
         double sum = 0; int mx = 0; int64_t over = 0, longer = 0;
         for (int64_t i = 0; i < M; ++i) { sum += h[i]; if (h[i] > mx) mx = h[i]; over += h[i] > cap; longer += h[i] > kSelSmall; }
         std::vector<int32_t> hl(emit_blocks);
@@ -2174,7 +2174,7 @@ int stage_graph_relations(ddx_ctx* ctx, int32_t mode, int32_t* idx_host, double*
     DDX_TRY(graph_weights_device(ctx, mode));
     DDX_HIP(ctx, hipMemcpyAsync(idx_host, ctx->knn_idx.p, sizeof(int32_t) * (size_t)M * K, hipMemcpyDeviceToHost, ctx->stream));
     DDX_HIP(ctx, hipMemcpyAsync(w_host, ctx->edge_w.p, sizeof(double) * (size_t)M * K, hipMemcpyDeviceToHost, ctx->stream));
-    DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    DDX_HIP(ctx, wait_stream(ctx));
     return DDX_OK;
 }
 
@@ -2292,7 +2292,7 @@ int stage_build_graph(ddx_ctx* ctx, int32_t mode) {
         DDX_HIP(ctx, prim::exclusive_sum(ctx->sort_tmp.p, tmp_bytes, cnt, offs, (int)n + 1, ctx->stream));
         DDX_HIP(ctx, hipMemcpyAsync(&E, offs + n, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
         k_pair_emit<<<(unsigned)ceil_div(n, 256), 256, 0, ctx->stream>>>(ctx->knn_idx.as<int32_t>(), ctx->edge_w.as<double>(), n, K, shift, offs, keys_a, vals_a);
-        DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        DDX_HIP(ctx, wait_stream(ctx));
         if (E > 0) {
             // the sort picks its algorithm (single block / merge / onesweep) by the element count, and each has its own
             // temporary-storage need: ask again for the actual count

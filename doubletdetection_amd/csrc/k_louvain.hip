@@ -425,7 +425,7 @@ static int coarsen_level(ddx_ctx* ctx, const LvGraph& in, double gamma, int32_t 
     k_lv_strength<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(in.indptr, wq, n, K, sc.comm, sc.tot, sc.size, sc.scal, big_list);
     unsigned long long h_scal[4] = {0, 0, 0, 0};
     DDX_HIP(ctx, hipMemcpyAsync(h_scal, sc.scal, sizeof(h_scal), hipMemcpyDeviceToHost, st));
-    DDX_HIP(ctx, hipStreamSynchronize(st));
+    DDX_HIP(ctx, wait_stream(ctx));
     const int64_t m2 = (int64_t)h_scal[0];
     const int32_t maxdeg = (int32_t)(h_scal[1] & 0xffffffffull);
     const int32_t nbig = (int32_t)(h_scal[1] >> 32);
@@ -460,7 +460,7 @@ static int coarsen_level(ddx_ctx* ctx, const LvGraph& in, double gamma, int32_t 
     int32_t nc = 0;
     DDX_HIP(ctx, hipMemcpyAsync(&nc, sc.renum + n, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     DDX_HIP(ctx, hipMemcpyAsync(&runs, runs_d, sizeof(int64_t), hipMemcpyDeviceToHost, st));
-    DDX_HIP(ctx, hipStreamSynchronize(st));
+    DDX_HIP(ctx, wait_stream(ctx));
     if (E == 0) runs = 0;
     if (runs > 0) k_lv_unpack<<<(unsigned)ceil_div(runs, 256), 256, 0, st>>>(sc.keys_a, sc.sums, runs, shift, c_cols, c_w);
     k_lv_rowptr<<<(unsigned)ceil_div((int64_t)nc + 1, 256), 256, 0, st>>>(sc.keys_a, runs, nc, shift, c_indptr);
@@ -600,7 +600,7 @@ int stage_refine_communities(ddx_ctx* ctx, const int32_t* coarse_labels, double 
         else DDX_HIP(ctx, hipMemcpyAsync(labels_out, sc.comm, sizeof(int32_t) * g.n, hipMemcpyDeviceToHost, st));
         n_up = g.n;
     }
-    DDX_HIP(ctx, hipStreamSynchronize(st));
+    DDX_HIP(ctx, wait_stream(ctx));
     DDX_HIP(ctx, hipGetLastError());
     // canonical numbering: by ascending smallest member = order of first appearance
     std::vector<int32_t> rank((size_t)std::max<int64_t>(n, nc), -1);

@@ -266,6 +266,34 @@ constexpr int kLdsOStride = kLdsChunk + 4;    // uint32
 constexpr int lds_value_bytes(bool pk) { return pk ? kLdsOStride * 4 : kLdsDStride * 8; }
 constexpr int lds_stage_bytes(int slots, bool pk) { return kLdsWaves * slots * (lds_value_bytes(pk) + kLdsOStride * 4); }
 
+// The block that finishes LAST adds the blocks' partials (round 6: the separate reduction launch is gone -- 26 launches per boosting
+// iteration).  Every block publishes its partial (device-scope release), takes a ticket from `counter`; the holder of the last ticket sees
+// all of them (acquire) and reduces in the FIXED order of k_reduce_partials -- one wave per output, lanes over interleaved blocks, butterfly
+// -- so the result does not depend on which block came last.  It puts the counter back to zero for the next launch on the stream.
+__device__ __forceinline__ bool last_block_ticket(int* counter, int nblocks) {
+    __shared__ int s_last;
+    __threadfence();                                     // this block's partials are visible device-wide before its ticket is
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int t = atomicAdd(counter, 1);
+        s_last = (t == nblocks - 1) ? 1 : 0;
+        if (s_last) *counter = 0;
+    }
+    __syncthreads();
+    if (s_last) __threadfence();                         // (acquire: the other blocks' partials, not this CU's cached lines)
+    return s_last != 0;
+}
+
+__device__ __forceinline__ void reduce_partials_block(const double* __restrict__ partial, int nblocks, int width, double* __restrict__ out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    for (int c = wave; c < width; c += nwaves) {
+        double s = 0.0;
+        for (int b = lane; b < nblocks; b += 64) s += __builtin_nontemporal_load(&partial[(int64_t)b * width + c]);
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (lane == 0) out[c] = s;
+    }
+}
+
 struct LdsSpmmArgs {
     const float* op;     // operand, row-major [opRows x ld] float32
     int ld, L, lpn;
@@ -286,6 +314,9 @@ struct LdsSpmmArgs {
     float zval;
     double* out;                  // ROWS: Y [M x L];  COLS: partials [groups x H x L]
     float* out32;                 // ROWS: padded float32 copy of Y [M x ld] for the A^T Y pass that follows (or null)
+    // ROWS (k_spmm_packed): usum != nullptr: also the column sums of Y (the rank-one correction of the A^T Y product that follows, a launch of its
+    // own otherwise): one partial per workgroup into upart, added in workgroup order by the one that finishes last (ticket ucount)
+    double* usum; double* upart; int* ucount;
 };
 
 __device__ __forceinline__ void wave_lds_sync() {
@@ -975,7 +1006,7 @@ __global__ void __launch_bounds__(kLdsThreads) k_spmm_packed(const PackedArgs pa
         }
     }
     // every lane group writes its own outputs (as k_spmm_lds)
-    double cm[2] = {0.0, 0.0};
+    double cm[2] = {0.0, 0.0}, cs[2] = {0.0, 0.0};
 #pragma unroll
     for (int k = 0; k < OWN; ++k) {
         const int64_t o = __shfl(myout, k * 3 + slot, 64);
@@ -988,6 +1019,7 @@ __global__ void __launch_bounds__(kLdsThreads) k_spmm_packed(const PackedArgs pa
                         double y = acc[k][c] - a.tvec[col];
                         if (a.accumulate) y += a.out[o * a.L + col];
                         a.out[o * a.L + col] = y;
+                        cs[c] += y;
                         if (a.ymax) { const double v = fabs(a.srow[o] * y); cm[c] = v > cm[c] ? v : cm[c]; }
                         if (a.out32) a.out32[o * a.ld + col] = (float)y;
                     } else {
@@ -1009,6 +1041,23 @@ __global__ void __launch_bounds__(kLdsThreads) k_spmm_packed(const PackedArgs pa
         }
         __syncthreads();
         if ((int)threadIdx.x < a.L && red[threadIdx.x]) atomicMax(a.ymax + threadIdx.x, red[threadIdx.x]);
+    }
+    if (ROWS && a.usum) {
+        // column sums of this workgroup's rows: (wave, lane group) partials through LDS, added in that order; then the last workgroup adds the workgroups'
+        double* cs_s = reinterpret_cast<double*>(smem) + 64;          // (behind the 64 maxima)
+        __syncthreads();
+        if (active) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+                if (2 * sub + c < a.L) cs_s[(wave * 3 + slot) * a.L + 2 * sub + c] = cs[c];
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < a.L) {
+            double t = 0.0;
+            for (int g = 0; g < kLdsWaves * 3; ++g) t += cs_s[g * a.L + threadIdx.x];
+            a.upart[(int64_t)blockIdx.x * a.L + threadIdx.x] = t;
+        }
+        if (last_block_ticket(a.ucount, (int)gridDim.x)) reduce_partials_block(a.upart, (int)gridDim.x, a.L, a.usum);
     }
 }
 
@@ -1060,10 +1109,10 @@ __global__ void k_sum_panels(const double* __restrict__ Wp, int P, int32_t H, in
 // ------------------------------------------------------------------------------------------------
 // tall-skinny helpers on R x L row-major float64 matrices (all reductions in fixed order)
 // ------------------------------------------------------------------------------------------------
-// partial[b][c] = sum over the block's rows of w_r * X[r,c]   (w == nullptr: ones)
+// partial[b][c] = sum over the block's rows of w_r * X[r,c]   (w == nullptr: ones); out[c] = sum of the partials (last block)
 __global__ void __launch_bounds__(256) k_wcolsum_partial(const double* __restrict__ X, int64_t R, int L,
                                                          const double* __restrict__ wgt, int64_t rows_per_block,
-                                                         double* __restrict__ partial) {
+                                                         double* __restrict__ partial, int* __restrict__ counter = nullptr, double* __restrict__ out = nullptr) {
     __shared__ double red[256];
     const int tid = threadIdx.x;
     const int groups = 256 / L;            // row lanes per block (L <= 128 -> >= 2)
@@ -1092,6 +1141,7 @@ __global__ void __launch_bounds__(256) k_wcolsum_partial(const double* __restric
         for (int gg = 0; gg < groups; ++gg) s += red[gg * L + tid];
         partial[(int64_t)blockIdx.x * L + tid] = s;
     }
+    if (counter && last_block_ticket(counter, (int)gridDim.x)) reduce_partials_block(partial, (int)gridDim.x, L, out);
 }
 
 // out[c] = sum_b partial[b][c]: one wave per output; lanes take interleaved blocks, then a fixed butterfly
@@ -1105,11 +1155,73 @@ __global__ void __launch_bounds__(256) k_reduce_partials(const double* __restric
     if (lane == 0) out[c] = s;
 }
 
+// The same factorisation and inverse with the matrix in registers (sketch width LT known at compile time, one
+// column per lane, everything unrolled): entries of other columns arrive through v_readlane instead of LDS round
+// trips, which bound the kernel above (68 us at L = 40 against ~25 us here).
+__device__ __forceinline__ double lane_value(double v, int j) {
+    const int64_t b = __builtin_bit_cast(int64_t, v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)b, j);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(b >> 32), j);
+    return __builtin_bit_cast(double, ((int64_t)hi << 32) | (int64_t)lo);
+}
+
+template <int LT>
+__device__ __forceinline__ void chol_inv_reg_wave(const double* __restrict__ G, double* __restrict__ Rinv, int* __restrict__ flag) {
+    const int lane = threadIdx.x & 63;
+    const int col = lane < LT ? lane : LT - 1;          // idle lanes shadow the last column
+    double a[LT];
+#pragma unroll
+    for (int i = 0; i < LT; ++i) a[i] = G[i * LT + col];
+    double maxd = 0.0;
+#pragma unroll
+    for (int k = 0; k < LT; ++k) maxd = fmax(maxd, lane_value(a[k], k));
+    const double floor_v = maxd * 1e-26 + 1e-300;
+#pragma unroll
+    for (int k = 0; k < LT; ++k) {
+        double d = lane_value(a[k], k);
+        if (!(d > floor_v)) {
+            d = floor_v;
+            if (lane == 0) atomicOr(flag, 1);
+        }
+        const double piv = sqrt(d);
+        const double r = a[k] / piv;                     // R[k][lane] for lane > k
+        a[k] = lane == k ? piv : r;
+#pragma unroll
+        for (int i = k + 1; i < LT; ++i) a[i] -= lane_value(r, i) * r;     // meaningful for lane >= i
+    }
+    // column `lane` of the inverse of the upper-triangular factor, bottom up
+    double x[LT];
+#pragma unroll
+    for (int i = LT - 1; i >= 0; --i) {
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int p = i + 1; p < LT; ++p) {
+            const double rip = lane_value(a[i], p);      // R[i][p]
+            if ((p - i) & 1) s0 += rip * x[p]; else s1 += rip * x[p];      // x[p] = 0 beyond the diagonal
+        }
+        const double rii = lane_value(a[i], i);
+        x[i] = i == lane ? 1.0 / rii : (i < lane ? -(s0 + s1) / rii : 0.0);
+    }
+    if (lane < LT) {
+#pragma unroll
+        for (int i = 0; i < LT; ++i) Rinv[i * LT + lane] = x[i];
+    }
+}
+
+template <int LT>
+__global__ void __launch_bounds__(64) k_chol_inv_reg(const double* __restrict__ G, double* __restrict__ Rinv, int* __restrict__ flag) {
+    chol_inv_reg_wave<LT>(G, Rinv, flag);
+}
+
 // partial Gram: G_b = X_b^T X_b for a block of rows, staged through LDS in 32-row tiles.  Only the pairs a <= b
 // are accumulated (each thread owns a few of the L(L+1)/2), both triangles are written.
+// counter != nullptr: the block that finishes last adds the partials into Gout (last_block_ticket / reduce_partials_block) and, when Rinv is
+// given (sketch width 40), goes straight on to the Cholesky factor and its inverse on its first wave: Gram partials, their reduction and
+// the factorisation were three launches of the Cholesky-QR chain, one per power iteration.
 template <int MAXP>   // pairs per thread: ceil(L(L+1)/2 / 256)
 __global__ void __launch_bounds__(256) k_gram_partial(const double* __restrict__ X, int64_t R, int L,
-                                                      int64_t rows_per_block, double* __restrict__ partial) {
+                                                      int64_t rows_per_block, double* __restrict__ partial, int* __restrict__ counter = nullptr,
+                                                      double* __restrict__ Gout = nullptr, double* __restrict__ Rinv = nullptr, int* __restrict__ flag = nullptr) {
     extern __shared__ __attribute__((aligned(16))) double tile[];  // [32][L]
     const int tid = threadIdx.x;
     const int npairs = L * (L + 1) / 2;
@@ -1153,6 +1265,14 @@ __global__ void __launch_bounds__(256) k_gram_partial(const double* __restrict__
             double* out = partial + (int64_t)blockIdx.x * L * L;
             out[pa[q] * L + pb[q]] = acc[q];
             out[pb[q] * L + pa[q]] = acc[q];
+        }
+    }
+    if (counter && last_block_ticket(counter, (int)gridDim.x)) {
+        reduce_partials_block(partial, (int)gridDim.x, L * L, Gout);
+        if (Rinv) {
+            __threadfence_block();
+            __syncthreads();
+            if (MAXP <= 4 && L == 40 && tid < 64) chol_inv_reg_wave<40>(Gout, Rinv, flag);
         }
     }
 }
@@ -1222,67 +1342,21 @@ __global__ void __launch_bounds__(64) k_chol_inv(const double* __restrict__ G, i
     for (int t = lane; t < L * L; t += 64) Rinv[t] = inv[t];
 }
 
-// The same factorisation and inverse with the matrix in registers (sketch width LT known at compile time, one
-// column per lane, everything unrolled): entries of other columns arrive through v_readlane instead of LDS round
-// trips, which bound the kernel above (68 us at L = 40 against ~25 us here).
-__device__ __forceinline__ double lane_value(double v, int j) {
-    const int64_t b = __builtin_bit_cast(int64_t, v);
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)b, j);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(b >> 32), j);
-    return __builtin_bit_cast(double, ((int64_t)hi << 32) | (int64_t)lo);
-}
-
-template <int LT>
-__global__ void __launch_bounds__(64) k_chol_inv_reg(const double* __restrict__ G, double* __restrict__ Rinv, int* __restrict__ flag) {
-    const int lane = threadIdx.x;
-    const int col = lane < LT ? lane : LT - 1;          // idle lanes shadow the last column
-    double a[LT];
-#pragma unroll
-    for (int i = 0; i < LT; ++i) a[i] = G[i * LT + col];
-    double maxd = 0.0;
-#pragma unroll
-    for (int k = 0; k < LT; ++k) maxd = fmax(maxd, lane_value(a[k], k));
-    const double floor_v = maxd * 1e-26 + 1e-300;
-#pragma unroll
-    for (int k = 0; k < LT; ++k) {
-        double d = lane_value(a[k], k);
-        if (!(d > floor_v)) {
-            d = floor_v;
-            if (lane == 0) atomicOr(flag, 1);
-        }
-        const double piv = sqrt(d);
-        const double r = a[k] / piv;                     // R[k][lane] for lane > k
-        a[k] = lane == k ? piv : r;
-#pragma unroll
-        for (int i = k + 1; i < LT; ++i) a[i] -= lane_value(r, i) * r;     // meaningful for lane >= i
-    }
-    // column `lane` of the inverse of the upper-triangular factor, bottom up
-    double x[LT];
-#pragma unroll
-    for (int i = LT - 1; i >= 0; --i) {
-        double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-        for (int p = i + 1; p < LT; ++p) {
-            const double rip = lane_value(a[i], p);      // R[i][p]
-            if ((p - i) & 1) s0 += rip * x[p]; else s1 += rip * x[p];      // x[p] = 0 beyond the diagonal
-        }
-        const double rii = lane_value(a[i], i);
-        x[i] = i == lane ? 1.0 / rii : (i < lane ? -(s0 + s1) / rii : 0.0);
-    }
-    if (lane < LT) {
-#pragma unroll
-        for (int i = 0; i < LT; ++i) Rinv[i * LT + lane] = x[i];
-    }
-}
-
 // out[R x L2] = X[R x L] * T[L x L2]   (64 rows per block, X tile and T staged in LDS)
 // out32 != nullptr: also the padded float32 copy of the result that the next operator product stages (ld32 columns)
+// cmax != nullptr: also the largest |cw_r out[r][c]| per column (cw == nullptr: ones), by integer atomicMax into zeros -- what the bit-plane
+//   A Q product cuts its digits by (k_bp_colmax as a launch of its own otherwise); needs 64 * L2 more doubles of LDS
+// tw != nullptr: also tvec[c] = sum_r tw_r out[r][c] (the rank-one correction m^T Q of the A Q product that follows: a k_wcolsum_partial launch
+//   otherwise): one partial per block in row order, added by the block that finishes last in a fixed order; same extra LDS
 __global__ void __launch_bounds__(256) k_right_mult(const double* __restrict__ X, int64_t R, int L,
                                                     const double* __restrict__ T, int L2, double* __restrict__ out,
-                                                    float* __restrict__ out32 = nullptr, int ld32 = 0) {
-    extern __shared__ __attribute__((aligned(16))) double sm[];  // T[L*L2] then xt[64*L]
+                                                    float* __restrict__ out32 = nullptr, int ld32 = 0, const double* __restrict__ cw = nullptr,
+                                                    unsigned long long* __restrict__ cmax = nullptr, const double* __restrict__ tw = nullptr,
+                                                    double* __restrict__ tpart = nullptr, int* __restrict__ counter = nullptr, double* __restrict__ tvec = nullptr) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];  // T[L*L2] then xt[64*L] (then y[64*L2])
     double* t_s = sm;
     double* x_s = sm + L * L2;
+    double* y_s = x_s + 64 * L;
     const int tid = threadIdx.x;
     const int64_t r0 = (int64_t)blockIdx.x * 64;
     const int nr = (int)((R - r0) < 64 ? (R - r0) : 64);
@@ -1302,7 +1376,27 @@ __global__ void __launch_bounds__(256) k_right_mult(const double* __restrict__ X
         for (int p = 0; p < L; ++p) s = fma(x_s[r * L + p], t_s[p * L2 + c], s);
         out[(r0 + r) * L2 + c] = s;
         if (out32) out32[(r0 + r) * ld32 + c] = (float)s;
+        if (cmax || tw) y_s[o] = s;
     }
+    if (cmax || tw) __syncthreads();
+    if (tw) {
+        if (tid < L2) {
+            double a = 0.0;
+            for (int r = 0; r < nr; ++r) a += tw[r0 + r] * y_s[r * L2 + tid];
+            tpart[(int64_t)blockIdx.x * L2 + tid] = a;
+        }
+    }
+    if (cmax) {
+        if (tid < L2) {
+            double m = 0.0;
+            for (int r = 0; r < nr; ++r) {
+                const double v = fabs(cw ? cw[r0 + r] * y_s[r * L2 + tid] : y_s[r * L2 + tid]);
+                m = v > m ? v : m;
+            }
+            if (m > 0.0) atomicMax(cmax + tid, (unsigned long long)__double_as_longlong(m));
+        }
+    }
+    if (tw && last_block_ticket(counter, (int)gridDim.x)) reduce_partials_block(tpart, (int)gridDim.x, L2, tvec);
 }
 
 // per column c of X[R x C]: index of the largest |value| (first occurrence), then its sign
@@ -1453,6 +1547,10 @@ struct PcaWork {
     bool lds;          // LDS-staged products (needs gather32 and a slice that fits the LDS)
     bool bitplane = false;   // the entries equal to 1 go through the bit-plane products (k_bitplane.hip)
     bool fused_ymax = true;  // the sparse A Q kernel's column maxima may serve the A^T Y product that follows (off where row-side matrices are rewritten in place)
+    const double* uvec_of = nullptr;   // the row-side matrix whose column sums the packed A Q kernel has just left in `small + 3 L^2 + L`
+    const double* tvec_of = nullptr;   // the column-side matrix whose m^T Q the Cholesky-QR's right multiplication has just left in `small + 3 L^2`
+    bool fused_qmax = false; // the Cholesky-QR's right multiplication leaves the column maxima of its result for the A Q product that follows (stage_pca's power
+                             // iterations only: nothing rewrites the basis between the two)
     int rows_SR = 0, rows_ns = 0;   // A Q: slice height / slice count of the H-row operand
     double* partial;   // scratch for block partials
     double* small;     // [4*L*L + 4*L]: G, Rinv, T, vecs
@@ -1463,16 +1561,18 @@ struct PcaWork {
     double* blkCol = nullptr;     // [H x kWideBlock]
 };
 
+constexpr int kCounterColsum = 8, kCounterGram = 9, kCounterUsum = 10;       // tickets of the last-block reductions (ints of PcaWork::flag's buffer, zero between launches)
+
 static int wcolsum(PcaWork& w, const double* X, int64_t R, const double* wgt, double* out) {
     int nb = (int)std::min<int64_t>(512, ceil_div(R, 256));
     int64_t rpb = ceil_div(R, nb);
     nb = (int)ceil_div(R, rpb);
-    k_wcolsum_partial<<<nb, 256, 0, w.ctx->stream>>>(X, R, w.L, wgt, rpb, w.partial);
-    k_reduce_partials<<<(unsigned)ceil_div(w.L, 4), 256, 0, w.ctx->stream>>>(w.partial, nb, w.L, out);
+    k_wcolsum_partial<<<nb, 256, 0, w.ctx->stream>>>(X, R, w.L, wgt, rpb, w.partial, w.flag + kCounterColsum, out);
     return DDX_OK;
 }
 
-static int gram(PcaWork& w, const double* X, int64_t R, double* G) {
+// G = X^T X; chol_to != nullptr (only honoured at the default sketch width 40): also Rinv = inverse of G's Cholesky factor, same launch
+static int gram(PcaWork& w, const double* X, int64_t R, double* G, double* chol_to = nullptr) {
     if (w.L > kMaxL) {
         int nbw = (int)std::min<int64_t>(128, ceil_div(R, 256));
         const int64_t rpbw = ceil_div(R, nbw);
@@ -1482,13 +1582,13 @@ static int gram(PcaWork& w, const double* X, int64_t R, double* G) {
         k_reduce_partials<<<(unsigned)ceil_div(w.L * w.L, 4), 256, 0, w.ctx->stream>>>(w.partial, nbw, w.L * w.L, G);
         return DDX_OK;
     }
-    int nb = (int)std::min<int64_t>(512, ceil_div(R, 128));      // pcaPartial holds 512 partial Gram matrices
+    // (128 blocks at most: the block that finishes last adds their partial matrices itself)
+    int nb = (int)std::min<int64_t>(128, ceil_div(R, 128));      // pcaPartial holds 512 partial Gram matrices
     int64_t rpb = ceil_div(R, nb);
     nb = (int)ceil_div(R, rpb);
-    const int LL = w.L * w.L;
-    if (w.L * (w.L + 1) / 2 <= 4 * 256) k_gram_partial<4><<<nb, 256, sizeof(double) * 32 * w.L, w.ctx->stream>>>(X, R, w.L, rpb, w.partial);
-    else k_gram_partial<(kMaxL * (kMaxL + 1) / 2 + 255) / 256><<<nb, 256, sizeof(double) * 32 * w.L, w.ctx->stream>>>(X, R, w.L, rpb, w.partial);
-    k_reduce_partials<<<(unsigned)ceil_div(LL, 4), 256, 0, w.ctx->stream>>>(w.partial, nb, LL, G);
+    int* counter = w.flag + kCounterGram;
+    if (w.L * (w.L + 1) / 2 <= 4 * 256) k_gram_partial<4><<<nb, 256, sizeof(double) * 32 * w.L, w.ctx->stream>>>(X, R, w.L, rpb, w.partial, counter, G, chol_to, w.flag);
+    else k_gram_partial<(kMaxL * (kMaxL + 1) / 2 + 255) / 256><<<nb, 256, sizeof(double) * 32 * w.L, w.ctx->stream>>>(X, R, w.L, rpb, w.partial, counter, G, nullptr, nullptr);
     return DDX_OK;
 }
 
@@ -1533,22 +1633,22 @@ static int cholqr(PcaWork& w, const double* X, int64_t R, double* out) {
     double* Rinv = w.small + w.L * w.L;
     if (w.ctx->bp.ymax_of == out) w.ctx->bp.ymax_of = nullptr;      // (the matrix whose column maxima were taken is overwritten)
     ScopedTimer t(w.ctx, "pca_orth");
-    DDX_TRY(gram(w, X, R, G));
+    DDX_TRY(gram(w, X, R, G, w.L == 40 ? Rinv : nullptr));
     if (w.L > kMaxL) {
         const int L = w.L;
         std::vector<double> hG((size_t)L * L), hInv;
         DDX_HIP(w.ctx, hipMemcpyAsync(hG.data(), G, sizeof(double) * L * L, hipMemcpyDeviceToHost, w.ctx->stream));
-        DDX_HIP(w.ctx, hipStreamSynchronize(w.ctx->stream));
+        DDX_HIP(w.ctx, wait_stream(w.ctx));
         int hflag = 0;
         chol_inverse_host(L, hG, hInv, &hflag);
         if (hflag) DDX_HIP(w.ctx, hipMemcpyAsync(w.flag, &hflag, sizeof(int), hipMemcpyHostToDevice, w.ctx->stream));
         DDX_HIP(w.ctx, hipMemcpyAsync(Rinv, hInv.data(), sizeof(double) * L * L, hipMemcpyHostToDevice, w.ctx->stream));
         DDX_TRY(right_mult(w.ctx, X, R, L, Rinv, L, out));
-        DDX_HIP(w.ctx, hipStreamSynchronize(w.ctx->stream));       // hInv / hflag are stack-backed
+        DDX_HIP(w.ctx, wait_stream(w.ctx));       // hInv / hflag are stack-backed
         return DDX_OK;
     }
-    if (w.L == 40) k_chol_inv_reg<40><<<1, 64, 0, w.ctx->stream>>>(G, Rinv, w.flag);      // the default sketch width (30 + 10)
-    else k_chol_inv<<<1, 64, 2 * sizeof(double) * w.L * w.L, w.ctx->stream>>>(G, w.L, Rinv, w.flag);
+    // (sketch width 40, the default 30 + 10: factorised by the Gram kernel's last block, in registers)
+    if (w.L != 40) k_chol_inv<<<1, 64, 2 * sizeof(double) * w.L * w.L, w.ctx->stream>>>(G, w.L, Rinv, w.flag);
     float* out32 = nullptr;
     const int ld = (w.L + 3) & ~3;
     if (w.lds && w.opQ) {
@@ -1557,7 +1657,19 @@ static int cholqr(PcaWork& w, const double* X, int64_t R, double* out) {
         if (R == w.H) { out32 = w.opQ; w.opQ_of = out; }
         else if (R == w.M) { out32 = w.op32; w.opY_of = out; }
     }
-    k_right_mult<<<(unsigned)ceil_div(R, 64), 256, sizeof(double) * (w.L * w.L + 64 * w.L), w.ctx->stream>>>(X, R, w.L, Rinv, w.L, out, out32, ld);
+    // bit-plane route: the column maxima of the next A Q operand (diag(1 / sd) Q on a scaled matrix) fall out of this kernel -- into the
+    // slots the last Y-side digit kernel zeroed (k_bp_digits: zero_me)
+    BitPlanes& bp = w.ctx->bp;
+    const bool fuse = w.fused_qmax && R == w.H && w.L <= 64;      // `out` is the operand of the next A Q product
+    const bool qmax = fuse && w.bitplane && bp.cmax && bp.qmax_zeroed;
+    if (bp.qmax_of == out) bp.qmax_of = nullptr;
+    if (w.tvec_of == out) w.tvec_of = nullptr;
+    if (w.uvec_of == out) w.uvec_of = nullptr;
+    k_right_mult<<<(unsigned)ceil_div(R, 64), 256, sizeof(double) * (w.L * w.L + 64 * w.L + (fuse ? 64 * w.L : 0)), w.ctx->stream>>>(
+        X, R, w.L, Rinv, w.L, out, out32, ld, qmax ? (bp.scaled ? bp.inv_sd : nullptr) : nullptr, qmax ? reinterpret_cast<unsigned long long*>(bp.cmax) : nullptr,
+        fuse ? w.ctx->colmean.as<double>() : nullptr, w.partial, w.flag + kCounterColsum, w.small + 3 * w.L * w.L);
+    if (fuse) w.tvec_of = out;
+    if (qmax) { bp.qmax_of = out; bp.qmax_zeroed = false; }
     return DDX_OK;
 }
 
@@ -1643,7 +1755,7 @@ static int pack_residual(ddx_ctx* c, const LdsSpmmArgs& a, int own, int nsl, int
     DDX_HIP(c, prim::exclusive_sum(c->sort_tmp.p, tmp, cnt, ptr, n, c->stream));
     int32_t total = 0;
     DDX_HIP(c, hipMemcpyAsync(&total, ptr + (n - 1), sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-    DDX_HIP(c, hipStreamSynchronize(c->stream));
+    DDX_HIP(c, wait_stream(c));
     DDX_TRY(ensure(c, c->pk_blocks[side], (size_t)(total + 1) * kPkBlockBytes));
     DDX_HIP(c, hipMemsetAsync(c->pk_blocks[side].p, 0, (size_t)(total + 1) * kPkBlockBytes, c->stream));
     k_pack_residual<ROWS><<<grid, 256, 0, c->stream>>>(a, own, nsl, nwg, ptr, c->pk_blocks[side].as<unsigned char>(), 1);
@@ -1690,10 +1802,12 @@ static int apply_rows(PcaWork& w, const double* Qcol, double* Yrow) {  // A Q : 
     if (w.sub) return apply_rows_wide(w, Qcol, Yrow);
     ddx_ctx* c = w.ctx;
     double* tvec = w.small + 3 * w.L * w.L;
-    {
+    if (w.uvec_of == Yrow) w.uvec_of = nullptr;
+    if (w.tvec_of != Qcol) {                            // (else: left there by the kernel that produced Qcol, k_right_mult)
         ScopedTimer t(c, "pca_colsum");
         DDX_TRY(wcolsum(w, Qcol, w.H, c->colmean.as<double>(), tvec));
     }
+    w.tvec_of = nullptr;
     // Y = diag(s) B Q on the matrix cores first (a timing scope of its own); the sparse kernel then sees only the entries other
     // than 1 and adds its part
     if (w.bitplane) DDX_TRY(bp_rows_product(c, Qcol, w.L, Yrow));
@@ -1732,6 +1846,9 @@ static int apply_rows(PcaWork& w, const double* Qcol, double* Yrow) {  // A Q : 
             c->bp.ymax_of = w.fused_ymax ? Yrow : nullptr;
         }
         if (w.bitplane && packed_applies(c, a, slots)) {
+            // (the column sums of Y for the A^T Y product that follows: from this kernel's epilogue)
+            a.usum = w.small + 3 * w.L * w.L + w.L; a.upart = w.partial; a.ucount = w.flag + kCounterUsum;
+            w.uvec_of = Yrow;
             if (c->opt.residual_rows_own == kLdsOwnSparseCols) {
                 a.owners = lds_owners(w.M, slots, a.ld, true);
                 return launch_packed<true, kLdsOwnSparseCols>(c, a, a.nslices, (unsigned)a.owners);
@@ -1765,8 +1882,10 @@ static int apply_rows(PcaWork& w, const double* Qcol, double* Yrow) {  // A Q : 
 static int apply_cols(PcaWork& w, const double* Yrow, double* Wcol) {  // A^T Y : [M x L] -> [H x L]
     if (w.sub) return apply_cols_wide(w, Yrow, Wcol);
     ddx_ctx* c = w.ctx;
+    if (c->bp.qmax_of == Wcol) c->bp.qmax_of = nullptr;     // (the result overwrites a matrix whose by-products are held)
+    if (w.tvec_of == Wcol) w.tvec_of = nullptr;
     double* uvec = w.small + 3 * w.L * w.L + w.L;
-    {
+    if (w.uvec_of != Yrow) {                            // (else: left there by the kernel that produced Yrow, k_spmm_packed)
         ScopedTimer t(c, "pca_colsum");
         DDX_TRY(wcolsum(w, Yrow, w.M, nullptr, uvec));
     }
@@ -1937,6 +2056,7 @@ static int pca_work_init(ddx_ctx* ctx, int L, PcaWork& w) {
     w.partial = ctx->pcaPartial.as<double>();
     w.small = ctx->pcaSmall.as<double>();
     w.flag = ctx->pcaVec.as<int>();
+    DDX_HIP(ctx, hipMemsetAsync(w.flag, 0, 16 * sizeof(int), ctx->stream));       // rank flag + the tickets of the last-block reductions
     w.gather32 = ctx->opt.gather_f32;
     w.lds = false;
     const int64_t maxR = M > H ? M : (int64_t)H;
@@ -1975,7 +2095,7 @@ int stage_operator_apply(ddx_ctx* ctx, int32_t mode, const double* X, int32_t n,
         default: return set_err(ctx, DDX_E_ARG, "operator mode must be 0..3");
     }
     DDX_HIP(ctx, hipMemcpyAsync(out, res, sizeof(double) * (size_t)(out_rows ? M : (int64_t)H) * n, hipMemcpyDeviceToHost, ctx->stream));
-    DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    DDX_HIP(ctx, wait_stream(ctx));
     DDX_HIP(ctx, hipGetLastError());
     return DDX_OK;
 }
@@ -2033,6 +2153,7 @@ int stage_pca(ddx_ctx* ctx, int32_t C, int32_t oversample, int32_t n_iter, const
         DDX_TRY(lds_setup(ctx, kWideBlock, wsub));
     } else {
         DDX_TRY(lds_setup(ctx, L, w));
+        w.fused_qmax = true;
     }
     const int64_t maxR = M > H ? M : (int64_t)H;
     DDX_TRY(ensure(ctx, ctx->pcaOp, sizeof(double) * (size_t)maxR * (L + 4)));
@@ -2049,7 +2170,7 @@ int stage_pca(ddx_ctx* ctx, int32_t C, int32_t oversample, int32_t n_iter, const
     w.partial = ctx->pcaPartial.as<double>();
     w.small = ctx->pcaSmall.as<double>();
     w.flag = ctx->pcaVec.as<int>();
-    DDX_HIP(ctx, hipMemsetAsync(w.flag, 0, sizeof(int), ctx->stream));
+    DDX_HIP(ctx, hipMemsetAsync(w.flag, 0, 16 * sizeof(int), ctx->stream));       // rank flag + the tickets of the last-block reductions
     if (wide) {
         wsub.op32 = w.op32;
         wsub.opQ = nullptr;                                   // (block products copy their operand each time)
@@ -2108,7 +2229,7 @@ int stage_pca(ddx_ctx* ctx, int32_t C, int32_t oversample, int32_t n_iter, const
     DDX_HIP(ctx, hipMemcpyAsync(hG.data(), G, sizeof(double) * L * L, hipMemcpyDeviceToHost, ctx->stream));
     int hflag = 0;
     DDX_HIP(ctx, hipMemcpyAsync(&hflag, w.flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    DDX_HIP(ctx, wait_stream(ctx));
     for (size_t t = 0; t < hG.size(); ++t)
         if (!std::isfinite(hG[t])) return set_err(ctx, DDX_E_NUMERIC, "non-finite sketch (degenerate input matrix?)");
     // symmetrise against rounding, then Jacobi
@@ -2136,7 +2257,7 @@ int stage_pca(ddx_ctx* ctx, int32_t C, int32_t oversample, int32_t n_iter, const
     }
     std::vector<double> hsign(C);
     DDX_HIP(ctx, hipMemcpyAsync(hsign.data(), dSign, sizeof(double) * C, hipMemcpyDeviceToHost, ctx->stream));
-    DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    DDX_HIP(ctx, wait_stream(ctx));
     for (int c = 0; c < C; ++c) {
         const double f = hsign[c] * (transposed ? 1.0 : svals[c]);
         for (int a = 0; a < L; ++a) T2[(size_t)a * C + c] = T1[(size_t)a * C + c] * f;
@@ -2149,7 +2270,7 @@ int stage_pca(ddx_ctx* ctx, int32_t C, int32_t oversample, int32_t n_iter, const
         DDX_TRY(right_mult(ctx, scoreSrc, M, L, dT, C, ctx->emb64.as<double>()));
         k_f64_to_f32<<<(unsigned)ceil_div(M * C, 256), 256, 0, ctx->stream>>>(ctx->emb64.as<double>(), M * C, ctx->emb32.as<float>());
     }
-    DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));  // T2/svals are stack-backed host buffers
+    DDX_HIP(ctx, wait_stream(ctx));  // T2/svals are stack-backed host buffers
     DDX_HIP(ctx, hipGetLastError());
     ctx->C = C;
     ctx->embM = M;
@@ -2386,7 +2507,7 @@ int stage_pca_block_lanczos(ddx_ctx* ctx, int32_t C, int32_t oversample, double 
     w.partial = ctx->pcaPartial.as<double>();
     w.small = ctx->pcaSmall.as<double>();
     w.flag = ctx->pcaVec.as<int>();
-    DDX_HIP(ctx, hipMemsetAsync(w.flag, 0, sizeof(int), ctx->stream));
+    DDX_HIP(ctx, hipMemsetAsync(w.flag, 0, 16 * sizeof(int), ctx->stream));       // rank flag + the tickets of the last-block reductions
     double* dG = w.small + 4 * L * L + 4 * L;          // cross-Gram block (the first 4 L^2 + 4 L belong to cholqr and the products)
     double* dZ = dG + L * L;                           // L x L block of Ritz vectors
     double* dGall = dZ + 2 * L * L;                    // cross-Gram blocks against every stored block: (max_steps + 1) L^2
@@ -2424,7 +2545,7 @@ int stage_pca_block_lanczos(ddx_ctx* ctx, int32_t C, int32_t oversample, double 
     int next_check = 12, prev_step = 0;
     double prev_res = -1.0, last_res = -1.0;
     bool converged = false;
-    auto now = [&]() { (void)hipStreamSynchronize(ctx->stream); return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    auto now = [&]() { (void)wait_stream(ctx); return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const bool dbg = ctx->opt.pca_debug;
     for (int j = 0; j < max_steps; ++j) {
         double t0 = dbg ? now() : 0.0;
@@ -2436,7 +2557,7 @@ int stage_pca_block_lanczos(ddx_ctx* ctx, int32_t C, int32_t oversample, double 
             Gall.resize((size_t)(j + 1) * L * L);
             DDX_TRY(cross_gram_all(w, Vall, j + 1, Wb, R, dGall, Gall.data()));
             k_block_apply_all<true><<<gtile, 256, tile_lds, ctx->stream>>>(Vall, dGall, R, L, j + 1, Wb);
-            DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            DDX_HIP(ctx, wait_stream(ctx));
             for (int i = 0; i <= j; ++i) {
                 std::copy(Gall.begin() + (size_t)i * L * L, Gall.begin() + (size_t)(i + 1) * L * L, Gh.begin());
                 add_block(i, j, Gh, pass > 0);
@@ -2449,7 +2570,7 @@ int stage_pca_block_lanczos(ddx_ctx* ctx, int32_t C, int32_t oversample, double 
         k_block_apply_all<true><<<gtile, 256, tile_lds, ctx->stream>>>(Vall, dGall, R, L, j + 1, T1);
         DDX_TRY(cholqr(w, T1, R, Vblk(j + 1)));
         DDX_TRY(cross_gram(w, Vblk(j + 1), Wb, R, dG, Tsub.data()));              // T[j+1][j] = V_{j+1}^T (remainder)
-        DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        DDX_HIP(ctx, wait_stream(ctx));
         if (dbg) { const double t1 = now(); t_orth += t1 - t0; t0 = t1; }
         steps = j + 1;
         // Rayleigh-Ritz on the blocks 0..j -- the host's solve, as costly as several steps once the space is large: at steps 8
@@ -2514,7 +2635,7 @@ int stage_pca_block_lanczos(ddx_ctx* ctx, int32_t C, int32_t oversample, double 
             for (int c = 0; c < L; ++c) Zb[((size_t)i * L + a) * L + c] = c < n ? Z[(size_t)(i * L + a) * n + (n - 1 - c)] : 0.0;
     DDX_HIP(ctx, hipMemcpyAsync(dGall, Zb.data(), sizeof(double) * (size_t)nb * L * L, hipMemcpyHostToDevice, ctx->stream));
     k_block_apply_all<false><<<gtile, 256, tile_lds, ctx->stream>>>(Vall, dGall, R, L, nb, Wb);
-    DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));          // Zb leaves scope
+    DDX_HIP(ctx, wait_stream(ctx));          // Zb leaves scope
     // components (H x L) for the sign decision, scores (M x C) = U S
     w.opQ_of = w.opY_of = nullptr;                      // (the accumulated block has no float32 mirror yet)
     double* dSign = w.small + 3 * L * L + 2 * L;
@@ -2530,7 +2651,7 @@ int stage_pca_block_lanczos(ddx_ctx* ctx, int32_t C, int32_t oversample, double 
     }
     k_col_sign<<<L, 256, 0, ctx->stream>>>(comps, H, L, dSign);
     DDX_HIP(ctx, hipMemcpyAsync(hsign.data(), dSign, sizeof(double) * L, hipMemcpyDeviceToHost, ctx->stream));
-    DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    DDX_HIP(ctx, wait_stream(ctx));
     double* dF = w.small + 3 * L * L + 3 * L;
     const double* scoreSrc;
     if (cols_side) {
@@ -2545,7 +2666,7 @@ int stage_pca_block_lanczos(ddx_ctx* ctx, int32_t C, int32_t oversample, double 
     k_scale_cols<<<(unsigned)ceil_div(M * C, 256), 256, 0, ctx->stream>>>(scoreSrc, M, L, C, dF, ctx->emb64.as<double>());
     k_f64_to_f32<<<(unsigned)ceil_div(M * C, 256), 256, 0, ctx->stream>>>(ctx->emb64.as<double>(), M * C, ctx->emb32.as<float>());
     DDX_HIP(ctx, hipMemcpyAsync(ctx->sing.p, svals.data(), sizeof(double) * C, hipMemcpyHostToDevice, ctx->stream));
-    DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    DDX_HIP(ctx, wait_stream(ctx));
     DDX_HIP(ctx, hipGetLastError());
     (void)Ro;
     ctx->C = C;

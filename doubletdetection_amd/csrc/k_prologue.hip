@@ -53,7 +53,7 @@ int validate_csr(ddx_ctx* ctx, const int64_t* indptr, const int32_t* cols, const
     DDX_HIP(ctx, hipMemsetAsync(flag, 0, sizeof(int), ctx->stream));
     k_validate_csr<<<(unsigned)ceil_div(N, 4), 256, 0, ctx->stream>>>(indptr, cols, vals, N, G, flag);
     DDX_HIP(ctx, hipMemcpyAsync(&h, flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    DDX_HIP(ctx, wait_stream(ctx));
     if (h & 1) return set_err(ctx, DDX_E_ARG, "counts contain a non-finite value (NaN or infinity)");
     if (h & 2) return set_err(ctx, DDX_E_ARG, "CSR column index outside [0, %d)", G);
     if (h & 4) return set_err(ctx, DDX_E_ARG, "CSR rows must hold strictly increasing column indices (sorted, no duplicates)");
@@ -163,7 +163,7 @@ int stage_gene_variances(ddx_ctx* ctx, float* var_out) {
         ScopedTimer t(ctx, "hvg_variance");
         k_variance_from_sums<<<(unsigned)ceil_div(G, 256), 256, 0, ctx->stream>>>(ctx->hvg_state.as<float>(), G, var.as<float>());
         hipError_t e = hipMemcpyAsync(var_out, var.p, sizeof(float) * G, hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess) e = wait_stream(ctx);
         release(ctx, var);
         // (the work space of the folding goes back to the context; a second call takes the whole-matrix pass)
         release(ctx, ctx->hvg_keys); release(ctx, ctx->hvg_vals); release(ctx, ctx->hvg_colptr); release(ctx, ctx->hvg_state);
@@ -199,7 +199,7 @@ int stage_gene_variances(ddx_ctx* ctx, float* var_out) {
         k_gene_var<<<(unsigned)ceil_div(G, 4), 256, 0, ctx->stream>>>(colptr.as<int64_t>(), vals_out.as<float>(), G, rinv, var.as<float>(), nullptr);
     }
     if (e == hipSuccess && rc == DDX_OK) e = hipMemcpyAsync(var_out, var.p, sizeof(float) * G, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess && rc == DDX_OK) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess && rc == DDX_OK) e = wait_stream(ctx);
     cleanup();
     if (rc != DDX_OK) return rc;
     if (e != hipSuccess) return set_err(ctx, DDX_E_HIP, "gene variance stage failed: %s", hipGetErrorString(e));
@@ -392,7 +392,7 @@ int stage_select_columns(ddx_ctx* ctx, const int64_t* cols, int32_t H) {
     }
     ctx->h_indptr.resize(N + 1);
     PR_HIP(hipMemcpyAsync(ctx->h_indptr.data(), ctx->aug_indptr.p, sizeof(int64_t) * (N + 1), hipMemcpyDeviceToHost, ctx->stream));
-    PR_HIP(hipStreamSynchronize(ctx->stream));
+    PR_HIP(wait_stream(ctx));
     kept = ctx->h_indptr[N];
     if (kept >= (int64_t)1 << 31) { cleanup(); return set_err(ctx, DDX_E_UNSUPPORTED, "more than 2^31-1 stored entries"); }
     const int64_t cap_s = kept / 2 + kept / 8 + 1024;
@@ -429,7 +429,7 @@ int stage_select_columns(ddx_ctx* ctx, const int64_t* cols, int32_t H) {
                                                            tv.as<float>(), ctx->aug_raw.as<float>(), (int)kept, (int)N, offs, offs + 1,
                                                            0, end_bit, ctx->stream));
     }
-    PR_HIP(hipStreamSynchronize(ctx->stream));
+    PR_HIP(wait_stream(ctx));
     cleanup();
 #undef PR_TRY
 #undef PR_HIP

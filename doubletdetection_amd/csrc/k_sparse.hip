@@ -723,7 +723,7 @@ static int build_csc(ddx_ctx* ctx, const MirrorSrc& src, int64_t e0, int64_t n, 
 #ifdef DDX_TILE_PROF
         {
             unsigned long long h[8];
-            hipStreamSynchronize(ctx->stream);
+            wait_stream(ctx);
             hipMemcpyFromSymbol(h, HIP_SYMBOL(g_tile_prof), sizeof(h));
             fprintf(stderr, "tile phases (100 MHz ticks per tile, %lld tiles):", (long long)ntiles);
             for (int i = 1; i < 7; ++i) fprintf(stderr, " %.1f", (double)h[i] / (double)ntiles);
@@ -797,7 +797,7 @@ static int ensure_keep(ddx_ctx* ctx, DevBuf& b, size_t bytes, size_t keep_bytes)
     DDX_TRY(ensure(ctx, nb, bytes));
     if (b.p && keep_bytes) {
         hipError_t e = hipMemcpyAsync(nb.p, b.p, keep_bytes, hipMemcpyDeviceToDevice, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess) e = wait_stream(ctx);
         if (e != hipSuccess) {
             release(ctx, nb);
             return set_err(ctx, DDX_E_HIP, "device copy during growth failed: %s", hipGetErrorString(e));
@@ -883,7 +883,7 @@ int stage_upload_counts(ddx_ctx* ctx, int64_t N, int32_t H, const int64_t* indpt
         const int64_t span = nnz > N ? nnz : N;
         k_counts_exact<<<(unsigned)ceil_div(span, 256), 256, 0, ctx->stream>>>(ctx->aug_raw.as<float>(), nnz, ctx->lib32.as<float>(), N, flag);
         DDX_HIP(ctx, hipMemcpyAsync(&exact, flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        DDX_HIP(ctx, wait_stream(ctx));
         ctx->counts_exact = exact != 0 && !ctx->opt.row_sums_sequential;
         if (!ctx->counts_exact)           // fractional / negative / huge counts: scipy's sequential order, replayed
             k_row_sums<<<(unsigned)ceil_div(N, 4), 256, 0, ctx->stream>>>(ctx->aug_indptr.as<int64_t>(), ctx->aug_raw.as<float>(), 0, N,
@@ -900,7 +900,7 @@ int stage_upload_counts(ddx_ctx* ctx, int64_t N, int32_t H, const int64_t* indpt
     } else {
         DDX_TRY(originals_mirror(ctx));
     }
-    DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    DDX_HIP(ctx, wait_stream(ctx));
     ctx->have_counts = true;
     publish_clone_view(ctx);
     return DDX_OK;
@@ -979,7 +979,7 @@ int stage_clone_counts(ddx_ctx* ctx, ddx_ctx* src) {
     ctx->have_synth = ctx->have_lognorm = ctx->scaled = ctx->have_emb = ctx->have_knn = false;
     ctx->rowseg_rows = -1;
     DDX_TRY(bp_clone(ctx, v));
-    DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    DDX_HIP(ctx, wait_stream(ctx));
     ctx->have_counts = true;
     publish_clone_view(ctx);
     return DDX_OK;
@@ -1072,7 +1072,7 @@ int ensure_full_rows(ddx_ctx* ctx) {
     if (!ctx->synth_rows) {
         DDX_TRY(materialise_synthetic(ctx));
         DDX_HIP(ctx, hipMemcpyAsync(&ctx->nnz_aug, ctx->aug_indptr.as<int64_t>() + ctx->M, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
-        DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        DDX_HIP(ctx, wait_stream(ctx));
     }
     if (!ctx->rows_x && ctx->have_lognorm) DDX_TRY(lognorm_rows(ctx));
     // (a matrix scaled on the bit-plane structures: the row-major values follow when somebody asks for them)
@@ -1405,7 +1405,7 @@ int stage_lognormalise(ddx_ctx* ctx, float pseudocount) {
         // exact number of synthetic entries (one 8-byte read-back per iteration; sizes the sorts)
         int64_t nnz_aug = 0;
         DDX_HIP(ctx, hipMemcpyAsync(&nnz_aug, ctx->aug_indptr.as<int64_t>() + M, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
-        DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        DDX_HIP(ctx, wait_stream(ctx));
         ctx->nnz_aug = nnz_aug;
         if (S) {
             ScopedTimer t(ctx, "row_sums");
@@ -1671,7 +1671,7 @@ int bp_scale(ddx_ctx* ctx, float max_value) {
             k_bp_scale_stats<<<(unsigned)ceil_div(H, 256), 256, 0, ctx->stream>>>(stat, bp.restm_colptr, ctx->P_o, bp.restm_s_colptr, ctx->P_s, parts, nparts, ctx->zcol.as<float>(), M, H,
                                                                                   max_value, kBpClipMargin, bp.cmax + 128, ctx->bp_demote.as<uint8_t>(), mean, sd, inv, bsum, want, flags);
             DDX_HIP(ctx, hipMemcpyAsync(hflags, flags, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-            DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            DDX_HIP(ctx, wait_stream(ctx));
         }
         const bool choose = !bp.demote_decided && hflags[1] > 0;
         if (hflags[0] == 0 && !choose) break;
@@ -1680,7 +1680,7 @@ int bp_scale(ddx_ctx* ctx, float max_value) {
         // rest of the fit, then the statistics again on the rebuilt structures (the sums themselves do not depend on the split)
         std::vector<uint8_t> hwant((size_t)H);
         DDX_HIP(ctx, hipMemcpyAsync(hwant.data(), want, (size_t)H, hipMemcpyDeviceToHost, ctx->stream));
-        DDX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        DDX_HIP(ctx, wait_stream(ctx));
         DDX_TRY(bp_rebuild_demoted(ctx, hwant));
     }
     bp.demote_decided = true;
@@ -1724,7 +1724,7 @@ int stage_dense_rows(ddx_ctx* ctx, int64_t row0, int64_t nrows, float* out_host)
     k_dense_rows<<<(unsigned)nrows, 256, 0, ctx->stream>>>(ctx->aug_indptr.as<int64_t>(), ctx->aug_indices.as<int32_t>(), ctx->aug_x.as<float>(),
                                                            ctx->zcol.as<float>(), ctx->H, row0, tmp.as<float>());
     hipError_t e = hipMemcpyAsync(out_host, tmp.p, sizeof(float) * nrows * ctx->H, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = wait_stream(ctx);
     release(ctx, tmp);
     if (e != hipSuccess) return set_err(ctx, DDX_E_HIP, "dense rows copy failed: %s", hipGetErrorString(e));
     return DDX_OK;

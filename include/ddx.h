@@ -75,11 +75,13 @@ int ddx_synchronize(ddx_ctx* ctx);
  *   upload            auto | plain | packed | packed32   transfer form of ddx_upload_raw (auto: 2-byte form once the pinned
  *                                       buffer exists, plain until then; packed / packed32 wait for the buffer)
  *   upload_debug      0 | 1 | 2         timings of the upload on stderr
- *   host_wait         block | spin | yield | auto   how host threads wait for the context's GPU (hipSetDeviceFlags: a property of the
- *                                       device in this process, not of the context).  Default: the runtime's own choice (spinning).
- *                                       block: a waiting thread sleeps instead of keeping a CPU busy -- 0.34 instead of 0.83 s of
- *                                       CPU time per fit, no slower, for hosts whose CPU allowance is smaller than the number of
- *                                       waiting threads; experimental (a long-running process hung at exit with it)
+ *   host_wait         spin | block      how a host thread waits for its context's stream (every wait of the library: read-backs of sizes
+ *                                       and flags, ends of stages).  spin (default): the runtime's hipStreamSynchronize, one busy CPU per
+ *                                       waiting thread.  block: the library polls an event it recorded, sleeping ~20 us between polls after a
+ *                                       short spin -- a waiting thread then costs a few per cent of a CPU; for hosts whose CPU allowance is
+ *                                       smaller than the number of waiting threads (several ranks x several lanes on one node; the Python
+ *                                       host selects it by itself there).  The device's own scheduling flags are never touched (round 5's
+ *                                       hipDeviceScheduleBlockingSync hung a long-running process at exit: profiles/r06_host_wait_hang.txt)
  *   hvg_fold          1 | 0             gene sums folded in while the packed matrix arrives
  *   row_sums          auto | sequential replay scipy's sequential float32 row sums even for exact integer counts
  *   knn_cells         n                 cells of the kNN pruning structure (0 = by size, 1 = first-component windows only)

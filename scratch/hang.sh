@@ -1,21 +1,8 @@
 #!/bin/bash
-# runs the soak with host_wait=block; if the process is still alive 60 s after its loop finished, dumps every thread's stack
-python scratch/soak_block.py block 120 > gpurun_out/hang_soak.log 2>&1 &
-PID=$!
-for i in $(seq 1 400); do
-  kill -0 $PID 2>/dev/null || break
-  if grep -q "loop done" gpurun_out/hang_soak.log 2>/dev/null; then
-    n=$((n+1))
-    if [ "$n" -gt 45 ]; then break; fi
-  fi
-  sleep 1
-done
-if kill -0 $PID 2>/dev/null; then
-  echo "still alive: dumping stacks" >> gpurun_out/hang_soak.log
-  timeout 120 /opt/rocm/bin/rocgdb -p $PID -batch -ex "set pagination off" -ex "thread apply all bt 25" > gpurun_out/hang_bt.txt 2>&1
-  kill -9 $PID
-else
-  echo "exited by itself" >> gpurun_out/hang_soak.log
-fi
-tail -5 gpurun_out/hang_soak.log
-grep -c "^Thread" gpurun_out/hang_bt.txt 2>/dev/null
+# 1. the soak with host_wait=block and ddx_destroy's steps on stderr; 2. the same under rocgdb, interrupted if it hangs
+DDX_OPTIONS="upload_debug=1" timeout 200 python scratch/soak_block.py block 120 > gpurun_out/hang_soak.log 2> gpurun_out/hang_soak.err
+echo "rc=$?" >> gpurun_out/hang_soak.log
+grep -a "ddx_destroy" gpurun_out/hang_soak.err | tail -12 > gpurun_out/hang_steps.txt
+grep -a -c "ddx_destroy.*done" gpurun_out/hang_soak.err >> gpurun_out/hang_steps.txt
+timeout -s INT 240 /opt/rocm/bin/rocgdb -q -batch -ex "set pagination off" -ex "handle SIGSEGV nostop noprint pass" -ex run -ex "thread apply all bt 30" --args python scratch/soak_block.py block 120 > gpurun_out/hang_gdb.txt 2>&1
+tail -5 gpurun_out/hang_soak.log; cat gpurun_out/hang_steps.txt; grep -c "^Thread" gpurun_out/hang_gdb.txt
