@@ -282,9 +282,13 @@ class _HipEngine:
         # superlinear, a digit costs about two steps (profiles/r05_block_lanczos.txt)
         self.lanczos_steps = c.pca_exact_sparse(n_components, start, tol=1e-6, max_steps=48, n_oversamples=over)
         if not getattr(c, "lanczos_converged", True):
-            if small <= 8192:
-                self._pca_exact(n_components)       # still cheap, and exact
-            else:
+            # upstream's eigsh(tol=0) always converges.  Cheap and exact while the smaller side is small (the Gram matrix by ~small / 40
+            # operator round trips + one dense eigh: under a second up to ~3 000); beyond that a second, longer Krylov run before giving up
+            if small <= 3072:
+                self._pca_exact(n_components)
+                return
+            self.lanczos_steps = c.pca_exact_sparse(n_components, start, tol=1e-6, max_steps=96, n_oversamples=over)
+            if not getattr(c, "lanczos_converged", True):
                 warnings.warn("truncated PCA of the sparse operator (pseudocount == 1): the block Lanczos solver stopped before its "
                               f"tolerance after {self.lanczos_steps} steps; trailing components may be off by more than 1e-5",
                               RuntimeWarning, stacklevel=2)

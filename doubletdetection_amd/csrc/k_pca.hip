@@ -270,18 +270,25 @@ constexpr int lds_stage_bytes(int slots, bool pk) { return kLdsWaves * slots * (
 // iteration).  Every block publishes its partial (device-scope release), takes a ticket from `counter`; the holder of the last ticket sees
 // all of them (acquire) and reduces in the FIXED order of k_reduce_partials -- one wave per output, lanes over interleaved blocks, butterfly
 // -- so the result does not depend on which block came last.  It puts the counter back to zero for the next launch on the stream.
-__device__ __forceinline__ bool last_block_ticket(int* counter, int nblocks) {
-    __shared__ int s_last;
+// (s_flag: one int of the block's LDS -- a kernel whose dynamic LDS already fills the CU has no room for a static variable)
+__device__ __forceinline__ bool last_block_ticket(int* counter, int nblocks, int* s_flag) {
     __threadfence();                                     // this block's partials are visible device-wide before its ticket is
     __syncthreads();
     if (threadIdx.x == 0) {
         const int t = atomicAdd(counter, 1);
-        s_last = (t == nblocks - 1) ? 1 : 0;
-        if (s_last) *counter = 0;
+        const int last = (t == nblocks - 1) ? 1 : 0;
+        if (last) *counter = 0;
+        *s_flag = last;
     }
     __syncthreads();
-    if (s_last) __threadfence();                         // (acquire: the other blocks' partials, not this CU's cached lines)
-    return s_last != 0;
+    const bool last = *s_flag != 0;
+    if (last) __threadfence();                           // (acquire: the other blocks' partials, not this CU's cached lines)
+    return last;
+}
+
+__device__ __forceinline__ bool last_block_ticket(int* counter, int nblocks) {
+    __shared__ int s_last;
+    return last_block_ticket(counter, nblocks, &s_last);
 }
 
 __device__ __forceinline__ void reduce_partials_block(const double* __restrict__ partial, int nblocks, int width, double* __restrict__ out) {
@@ -1057,7 +1064,8 @@ __global__ void __launch_bounds__(kLdsThreads) k_spmm_packed(const PackedArgs pa
             for (int g = 0; g < kLdsWaves * 3; ++g) t += cs_s[g * a.L + threadIdx.x];
             a.upart[(int64_t)blockIdx.x * a.L + threadIdx.x] = t;
         }
-        if (last_block_ticket(a.ucount, (int)gridDim.x)) reduce_partials_block(a.upart, (int)gridDim.x, a.L, a.usum);
+        int* s_flag = reinterpret_cast<int*>(cs_s + kLdsWaves * 3 * 64);      // (behind the partials, inside the operand slice's area)
+        if (last_block_ticket(a.ucount, (int)gridDim.x, s_flag)) reduce_partials_block(a.upart, (int)gridDim.x, a.L, a.usum);
     }
 }
 
