@@ -622,7 +622,9 @@ class BoostClassifier:
         if "DDX_UPLOAD_THREADS" not in os.environ:
             # every rank packs its own copy of the matrix for the upload: share the host cores (one node assumed).
             # Passed through the C-ABI (the pool is resized when the figure changes); the environment is not touched.
-            _lib.set_upload_threads(max(4, min(16, (os.cpu_count() or 8) // (2 * world))) if world > 1 else 0)
+            # (a rank's share of the CPU time the node ALLOWS -- the pods show 256 CPUs and allow 16: eight ranks x 16 packing threads
+            # would be throttled, not faster)
+            _lib.set_upload_threads(max(2, min(16, int(_cpu_allowance()) // world)) if world > 1 else 0)
         staged = getattr(self, "_staged", None)
         drawer = ThreadPoolExecutor(max_workers=1)
         draws = None
@@ -752,7 +754,7 @@ class BoostClassifier:
         env = os.environ.get("DDX_HOST_THREADS")
         if env:
             return max(1, int(env))
-        cores = max(1, (os.cpu_count() or 1) // max(1, int(world)))
+        cores = max(1, int(min(os.cpu_count() or 1, _cpu_allowance() if world > 1 else (os.cpu_count() or 1))) // max(1, int(world)))
         if self.n_jobs is None or self.n_jobs <= 0:
             return cores
         if self.n_jobs == 1:

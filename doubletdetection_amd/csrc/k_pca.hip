@@ -266,24 +266,27 @@ constexpr int kLdsOStride = kLdsChunk + 4;    // uint32
 constexpr int lds_value_bytes(bool pk) { return pk ? kLdsOStride * 4 : kLdsDStride * 8; }
 constexpr int lds_stage_bytes(int slots, bool pk) { return kLdsWaves * slots * (lds_value_bytes(pk) + kLdsOStride * 4); }
 
-// The block that finishes LAST adds the blocks' partials (round 6: the separate reduction launch is gone -- 26 launches per boosting
-// iteration).  Every block publishes its partial (device-scope release), takes a ticket from `counter`; the holder of the last ticket sees
-// all of them (acquire) and reduces in the FIXED order of k_reduce_partials -- one wave per output, lanes over interleaved blocks, butterfly
-// -- so the result does not depend on which block came last.  It puts the counter back to zero for the next launch on the stream.
+// The block that finishes LAST adds the blocks' partials (round 6: the separate reduction launches are gone).  Every block writes its partial
+// with device-scope stores (relaxed atomics: they go through to memory, past the writing XCD's L2, without the whole-L2 write-back a release
+// fence costs on this chip -- a fence per block made the Gram kernel three times slower), waits for them to be acknowledged, takes a ticket from
+// `counter`; the holder of the last ticket reads all partials with device-scope loads and reduces in the FIXED order of k_reduce_partials -- one
+// wave per output, lanes over interleaved blocks, butterfly -- so the result does not depend on which block came last.  It puts the counter
+// back to zero for the next launch on the stream.
+__device__ __forceinline__ void partial_store(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double partial_load(const double* p) { return __hip_atomic_load(const_cast<double*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // (s_flag: one int of the block's LDS -- a kernel whose dynamic LDS already fills the CU has no room for a static variable)
 __device__ __forceinline__ bool last_block_ticket(int* counter, int nblocks, int* s_flag) {
-    __threadfence();                                     // this block's partials are visible device-wide before its ticket is
-    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this thread's partial stores have reached memory
+    __syncthreads();                                     // ... and so have everybody's in the block
     if (threadIdx.x == 0) {
-        const int t = atomicAdd(counter, 1);
+        const int t = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int last = (t == nblocks - 1) ? 1 : 0;
-        if (last) *counter = 0;
+        if (last) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         *s_flag = last;
     }
     __syncthreads();
-    const bool last = *s_flag != 0;
-    if (last) __threadfence();                           // (acquire: the other blocks' partials, not this CU's cached lines)
-    return last;
+    return *s_flag != 0;
 }
 
 __device__ __forceinline__ bool last_block_ticket(int* counter, int nblocks) {
@@ -295,7 +298,7 @@ __device__ __forceinline__ void reduce_partials_block(const double* __restrict__
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     for (int c = wave; c < width; c += nwaves) {
         double s = 0.0;
-        for (int b = lane; b < nblocks; b += 64) s += __builtin_nontemporal_load(&partial[(int64_t)b * width + c]);
+        for (int b = lane; b < nblocks; b += 64) s += partial_load(&partial[(int64_t)b * width + c]);
         for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
         if (lane == 0) out[c] = s;
     }
@@ -1062,7 +1065,7 @@ __global__ void __launch_bounds__(kLdsThreads) k_spmm_packed(const PackedArgs pa
         if ((int)threadIdx.x < a.L) {
             double t = 0.0;
             for (int g = 0; g < kLdsWaves * 3; ++g) t += cs_s[g * a.L + threadIdx.x];
-            a.upart[(int64_t)blockIdx.x * a.L + threadIdx.x] = t;
+            partial_store(&a.upart[(int64_t)blockIdx.x * a.L + threadIdx.x], t);
         }
         int* s_flag = reinterpret_cast<int*>(cs_s + kLdsWaves * 3 * 64);      // (behind the partials, inside the operand slice's area)
         if (last_block_ticket(a.ucount, (int)gridDim.x, s_flag)) reduce_partials_block(a.upart, (int)gridDim.x, a.L, a.usum);
@@ -1147,7 +1150,8 @@ __global__ void __launch_bounds__(256) k_wcolsum_partial(const double* __restric
     if (tid < L) {
         double s = 0.0;
         for (int gg = 0; gg < groups; ++gg) s += red[gg * L + tid];
-        partial[(int64_t)blockIdx.x * L + tid] = s;
+        if (counter) partial_store(&partial[(int64_t)blockIdx.x * L + tid], s);
+        else partial[(int64_t)blockIdx.x * L + tid] = s;
     }
     if (counter && last_block_ticket(counter, (int)gridDim.x)) reduce_partials_block(partial, (int)gridDim.x, L, out);
 }
@@ -1271,8 +1275,13 @@ __global__ void __launch_bounds__(256) k_gram_partial(const double* __restrict__
     for (int q = 0; q < MAXP; ++q) {
         if (tid + q * 256 < npairs) {
             double* out = partial + (int64_t)blockIdx.x * L * L;
-            out[pa[q] * L + pb[q]] = acc[q];
-            out[pb[q] * L + pa[q]] = acc[q];
+            if (counter) {
+                partial_store(&out[pa[q] * L + pb[q]], acc[q]);
+                if (pa[q] != pb[q]) partial_store(&out[pb[q] * L + pa[q]], acc[q]);
+            } else {
+                out[pa[q] * L + pb[q]] = acc[q];
+                out[pb[q] * L + pa[q]] = acc[q];
+            }
         }
     }
     if (counter && last_block_ticket(counter, (int)gridDim.x)) {
@@ -1391,7 +1400,7 @@ __global__ void __launch_bounds__(256) k_right_mult(const double* __restrict__ X
         if (tid < L2) {
             double a = 0.0;
             for (int r = 0; r < nr; ++r) a += tw[r0 + r] * y_s[r * L2 + tid];
-            tpart[(int64_t)blockIdx.x * L2 + tid] = a;
+            partial_store(&tpart[(int64_t)blockIdx.x * L2 + tid], a);
         }
     }
     if (cmax) {
@@ -1855,8 +1864,11 @@ static int apply_rows(PcaWork& w, const double* Qcol, double* Yrow) {  // A Q : 
         }
         if (w.bitplane && packed_applies(c, a, slots)) {
             // (the column sums of Y for the A^T Y product that follows: from this kernel's epilogue)
-            a.usum = w.small + 3 * w.L * w.L + w.L; a.upart = w.partial; a.ucount = w.flag + kCounterUsum;
-            w.uvec_of = Yrow;
+            // (not where Yrow is a block buffer that is rewritten before the A^T Y product reads it: fused_ymax says so)
+            if (w.fused_ymax) {
+                a.usum = w.small + 3 * w.L * w.L + w.L; a.upart = w.partial; a.ucount = w.flag + kCounterUsum;
+                w.uvec_of = Yrow;
+            }
             if (c->opt.residual_rows_own == kLdsOwnSparseCols) {
                 a.owners = lds_owners(w.M, slots, a.ld, true);
                 return launch_packed<true, kLdsOwnSparseCols>(c, a, a.nslices, (unsigned)a.owners);

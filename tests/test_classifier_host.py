@@ -407,3 +407,31 @@ def test_contexts_per_gpu_follow_the_iterations_and_the_memory(monkeypatch):
     assert clf._stream_count(10, 1, lead) == 1
     lead.ctx = SizedCtx(11 << 30, 240 << 30, 9 << 30)
     assert clf._stream_count(10, 1, lead) == 7
+
+
+def test_host_wait_follows_the_cpu_allowance_and_the_world(monkeypatch):
+    """How lane threads wait for the GPU (ddx.h: host_wait): spinning while the host has a CPU for every waiting thread of one rank;
+    sleeping polls when several ranks share the node or the allowance is smaller than the lanes; never overriding the caller's choice."""
+    from doubletdetection_amd import _lib, classifier
+
+    class Ctx:
+        def __init__(self):
+            self.opts = {}
+
+        def set_option(self, k, v):
+            self.opts[k] = v
+
+    class Eng:
+        def __init__(self):
+            self.ctx = Ctx()
+
+    monkeypatch.delenv("DDX_OPTIONS", raising=False)
+    monkeypatch.setattr(classifier, "_cpu_allowance", lambda: 16.0)
+    clf = BoostClassifier()
+    assert clf._fit_switches(Eng(), world=1).ctx.opts == {"host_wait": "spin"}
+    assert clf._fit_switches(Eng(), world=8).ctx.opts == {"host_wait": "block"}
+    monkeypatch.setattr(classifier, "_cpu_allowance", lambda: 4.0)
+    assert clf._fit_switches(Eng(), world=1).ctx.opts == {"host_wait": "block"}
+    assert BoostClassifier(streams_per_device=2)._fit_switches(Eng(), world=1).ctx.opts == {"host_wait": "spin"}
+    monkeypatch.setitem(_lib.OPTIONS, "host_wait", "spin")
+    assert clf._fit_switches(Eng(), world=8).ctx.opts == {}

@@ -155,3 +155,29 @@ def test_bench_two_ranks_control_flow(tmp_path):
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["steps"] == 2 and line["value"] > 0 and line["scaling"] == "strong"
     assert line["roofline"] is not None and line["roofline"]["frac"] > 0
+
+
+def test_sleeping_host_waits_give_the_same_fit_for_less_cpu_time(monkeypatch):
+    """Option host_wait=block (the library polls an event with sleeps instead of the runtime's spinning hipStreamSynchronize; what the
+    classifier selects by itself when several ranks share a node): the same arrays, and clearly less CPU time for the waiting lanes."""
+    import time
+
+    from doubletdetection_amd import BoostClassifier, _lib
+    from doubletdetection_amd._synthetic import make_counts
+
+    counts = make_counts(12000, 4000, density=0.08, n_types=6, seed=5)
+    kw = dict(n_iters=8, n_top_var_genes=3000, random_state=2, device=0, streams_per_device=4)
+    out = {}
+    for mode in ("spin", "block"):
+        monkeypatch.setitem(_lib.OPTIONS, "host_wait", mode)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            BoostClassifier(**kw).fit(counts)                      # (warm: contexts, pinned buffers)
+            c0, t0 = time.process_time(), time.perf_counter()
+            clf = BoostClassifier(**kw).fit(counts)
+            out[mode] = (clf, time.process_time() - c0, time.perf_counter() - t0)
+    print({m: (round(c, 3), round(t, 3)) for m, (_, c, t) in out.items()})
+    for name in ("all_log_p_values_", "all_scores_", "communities_", "synth_communities_"):
+        np.testing.assert_array_equal(getattr(out["block"][0], name), getattr(out["spin"][0], name))
+    assert out["block"][1] < 0.75 * out["spin"][1], out
+    assert out["block"][2] < 1.5 * out["spin"][2], out
