@@ -1156,17 +1156,6 @@ __global__ void __launch_bounds__(256) k_wcolsum_partial(const double* __restric
     if (counter && last_block_ticket(counter, (int)gridDim.x)) reduce_partials_block(partial, (int)gridDim.x, L, out);
 }
 
-// out[c] = sum_b partial[b][c]: one wave per output; lanes take interleaved blocks, then a fixed butterfly
-__global__ void __launch_bounds__(256) k_reduce_partials(const double* __restrict__ partial, int nblocks, int width, double* __restrict__ out) {
-    const int lane = threadIdx.x & 63;
-    const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (c >= width) return;
-    double s = 0.0;
-    for (int b = lane; b < nblocks; b += 64) s += partial[(int64_t)b * width + c];
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-    if (lane == 0) out[c] = s;
-}
-
 // The same factorisation and inverse with the matrix in registers (sketch width LT known at compile time, one
 // column per lane, everything unrolled): entries of other columns arrive through v_readlane instead of LDS round
 // trips, which bound the kernel above (68 us at L = 40 against ~25 us here).
@@ -1183,7 +1172,7 @@ __device__ __forceinline__ void chol_inv_reg_wave(const double* __restrict__ G, 
     const int col = lane < LT ? lane : LT - 1;          // idle lanes shadow the last column
     double a[LT];
 #pragma unroll
-    for (int i = 0; i < LT; ++i) a[i] = G[i * LT + col];
+    for (int i = 0; i < LT; ++i) a[i] = partial_load(&G[i * LT + col]);      // (device-scope loads: G may have been written by other workgroups of this launch)
     double maxd = 0.0;
 #pragma unroll
     for (int k = 0; k < LT; ++k) maxd = fmax(maxd, lane_value(a[k], k));
@@ -1225,15 +1214,27 @@ __global__ void __launch_bounds__(64) k_chol_inv_reg(const double* __restrict__ 
     chol_inv_reg_wave<LT>(G, Rinv, flag);
 }
 
+// out[c] = sum_b partial[b][c]: one wave per output; lanes take interleaved blocks, then a fixed butterfly.
+// Rinv != nullptr (a 40 x 40 Gram matrix, the default sketch): the block that finishes last goes on to the Cholesky factor of `out` and its
+// inverse on its first wave (last_block_ticket) -- one launch less in every Cholesky-QR of the power iterations.
+__global__ void __launch_bounds__(256) k_reduce_partials(const double* __restrict__ partial, int nblocks, int width, double* __restrict__ out,
+                                                         int* __restrict__ counter = nullptr, double* __restrict__ Rinv = nullptr, int* __restrict__ flag = nullptr) {
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (c < width) {
+        double s = 0.0;
+        for (int b = lane; b < nblocks; b += 64) s += partial[(int64_t)b * width + c];
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (lane == 0) { if (counter) partial_store(&out[c], s); else out[c] = s; }
+    }
+    if (counter && last_block_ticket(counter, (int)gridDim.x) && threadIdx.x < 64) chol_inv_reg_wave<40>(out, Rinv, flag);
+}
+
 // partial Gram: G_b = X_b^T X_b for a block of rows, staged through LDS in 32-row tiles.  Only the pairs a <= b
 // are accumulated (each thread owns a few of the L(L+1)/2), both triangles are written.
-// counter != nullptr: the block that finishes last adds the partials into Gout (last_block_ticket / reduce_partials_block) and, when Rinv is
-// given (sketch width 40), goes straight on to the Cholesky factor and its inverse on its first wave: Gram partials, their reduction and
-// the factorisation were three launches of the Cholesky-QR chain, one per power iteration.
 template <int MAXP>   // pairs per thread: ceil(L(L+1)/2 / 256)
 __global__ void __launch_bounds__(256) k_gram_partial(const double* __restrict__ X, int64_t R, int L,
-                                                      int64_t rows_per_block, double* __restrict__ partial, int* __restrict__ counter = nullptr,
-                                                      double* __restrict__ Gout = nullptr, double* __restrict__ Rinv = nullptr, int* __restrict__ flag = nullptr) {
+                                                      int64_t rows_per_block, double* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) double tile[];  // [32][L]
     const int tid = threadIdx.x;
     const int npairs = L * (L + 1) / 2;
@@ -1275,21 +1276,8 @@ __global__ void __launch_bounds__(256) k_gram_partial(const double* __restrict__
     for (int q = 0; q < MAXP; ++q) {
         if (tid + q * 256 < npairs) {
             double* out = partial + (int64_t)blockIdx.x * L * L;
-            if (counter) {
-                partial_store(&out[pa[q] * L + pb[q]], acc[q]);
-                if (pa[q] != pb[q]) partial_store(&out[pb[q] * L + pa[q]], acc[q]);
-            } else {
-                out[pa[q] * L + pb[q]] = acc[q];
-                out[pb[q] * L + pa[q]] = acc[q];
-            }
-        }
-    }
-    if (counter && last_block_ticket(counter, (int)gridDim.x)) {
-        reduce_partials_block(partial, (int)gridDim.x, L * L, Gout);
-        if (Rinv) {
-            __threadfence_block();
-            __syncthreads();
-            if (MAXP <= 4 && L == 40 && tid < 64) chol_inv_reg_wave<40>(Gout, Rinv, flag);
+            out[pa[q] * L + pb[q]] = acc[q];
+            out[pb[q] * L + pa[q]] = acc[q];
         }
     }
 }
@@ -1599,13 +1587,16 @@ static int gram(PcaWork& w, const double* X, int64_t R, double* G, double* chol_
         k_reduce_partials<<<(unsigned)ceil_div(w.L * w.L, 4), 256, 0, w.ctx->stream>>>(w.partial, nbw, w.L * w.L, G);
         return DDX_OK;
     }
-    // (128 blocks at most: the block that finishes last adds their partial matrices itself)
-    int nb = (int)std::min<int64_t>(128, ceil_div(R, 128));      // pcaPartial holds 512 partial Gram matrices
+    int nb = (int)std::min<int64_t>(512, ceil_div(R, 128));      // pcaPartial holds 512 partial Gram matrices
     int64_t rpb = ceil_div(R, nb);
     nb = (int)ceil_div(R, rpb);
-    int* counter = w.flag + kCounterGram;
-    if (w.L * (w.L + 1) / 2 <= 4 * 256) k_gram_partial<4><<<nb, 256, sizeof(double) * 32 * w.L, w.ctx->stream>>>(X, R, w.L, rpb, w.partial, counter, G, chol_to, w.flag);
-    else k_gram_partial<(kMaxL * (kMaxL + 1) / 2 + 255) / 256><<<nb, 256, sizeof(double) * 32 * w.L, w.ctx->stream>>>(X, R, w.L, rpb, w.partial, counter, G, nullptr, nullptr);
+    const int LL = w.L * w.L;
+    if (w.L * (w.L + 1) / 2 <= 4 * 256) k_gram_partial<4><<<nb, 256, sizeof(double) * 32 * w.L, w.ctx->stream>>>(X, R, w.L, rpb, w.partial);
+    else k_gram_partial<(kMaxL * (kMaxL + 1) / 2 + 255) / 256><<<nb, 256, sizeof(double) * 32 * w.L, w.ctx->stream>>>(X, R, w.L, rpb, w.partial);
+    if (chol_to && w.L == 40)
+        k_reduce_partials<<<(unsigned)ceil_div(LL, 4), 256, 0, w.ctx->stream>>>(w.partial, nb, LL, G, w.flag + kCounterGram, chol_to, w.flag);
+    else
+        k_reduce_partials<<<(unsigned)ceil_div(LL, 4), 256, 0, w.ctx->stream>>>(w.partial, nb, LL, G);
     return DDX_OK;
 }
 
