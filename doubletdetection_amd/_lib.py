@@ -48,6 +48,7 @@ _SIGNATURES = {
     "ddx_reserve_hint": (C.c_int, [C.c_void_p, C.c_int64]),
     "ddx_trim": (C.c_int, [C.c_void_p, C.c_int64]),
     "ddx_set_upload_threads": (C.c_int, [C.c_int32]),
+    "ddx_set_helper_threads": (C.c_int, [C.c_int32]),
     "ddx_upload_raw": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, c_i64_p, c_i32_p, c_f32_p]),
     "ddx_gene_variances": (C.c_int, [C.c_void_p, c_f32_p]),
     "ddx_select_columns": (C.c_int, [C.c_void_p, c_i64_p, C.c_int32]),
@@ -189,6 +190,11 @@ def pack_rows16(indptr, indices, data, capacity=None):
 def set_upload_threads(n: int) -> None:
     """Host threads that pack the raw matrix for the upload (process-wide; 0 = the library's default)."""
     _check(load().ddx_set_upload_threads(int(n)))
+
+
+def set_helper_threads(n: int) -> None:
+    """Helper threads the restart batches of louvain_best_of may have running in this process at any time (negative: no limit)."""
+    _check(load().ddx_set_helper_threads(int(n)))
 
 
 # ---- context-free host routines --------------------------------------------------------------

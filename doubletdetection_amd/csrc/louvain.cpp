@@ -10,6 +10,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <thread>
 #include <vector>
 
@@ -795,6 +796,36 @@ extern "C" int ddx_louvain(int64_t n_nodes, const int64_t* indptr, const int32_t
     return DDX_OK;
 }
 
+// Helper threads of the restart batches, budgeted per PROCESS: several boosting iterations finish their device part at about the same
+// time and each may run a batch of 20 independent restarts -- 7 jobs x 20 threads on a host that allows 16 CPUs' worth of time (the pods
+// these GPUs come in) throttled the lane threads that feed the GPU.  A job's calling thread always works; helpers beyond it are taken
+// from a budget (ddx_set_helper_threads; negative: unlimited) and handed back when the batch is done, so a job that runs alone (the
+// last iteration of a fit, on the critical path) gets them all and jobs that overlap share them.  The result does not depend on the
+// number of threads (runs are independent and applied in run order).
+static std::atomic<int> g_helper_limit{-1};
+static std::atomic<int> g_helpers_out{0};
+
+extern "C" int ddx_set_helper_threads(int32_t n) {
+    g_helper_limit.store(n < 0 ? -1 : n);
+    return DDX_OK;
+}
+
+static int take_helpers(int want) {
+    if (want <= 0) return 0;
+    const int limit = g_helper_limit.load();
+    if (limit < 0) { g_helpers_out.fetch_add(want); return want; }
+    int cur = g_helpers_out.load();
+    for (;;) {
+        const int take = std::min(want, limit - cur);
+        if (take <= 0) return 0;
+        if (g_helpers_out.compare_exchange_weak(cur, cur + take)) return take;
+    }
+}
+
+static void give_helpers(int n) {
+    if (n > 0) g_helpers_out.fetch_sub(n);
+}
+
 // PhenoGraph's restart rule on top of part B (upstream phenograph.core.runlouvain, reached from dd.py:320-322: the
 // Louvain executable is run again and again, each time from another random node order; a run replaces the best result
 // when its modularity exceeds the best by more than q_tol; the loop ends after `stall` consecutive runs without such a
@@ -826,19 +857,22 @@ extern "C" int ddx_louvain_best_of(int64_t n_nodes, const int64_t* indptr, const
         const int batch = std::min<int32_t>(stall, max_runs - run);
         std::vector<std::vector<int32_t>> memb(batch);
         std::vector<double> q(batch, 0.0);
-        const int nt = std::min(nthreads, batch);
-        auto work = [&](int t) {
-            for (int b = t; b < batch; b += nt) {
+        const int helpers = take_helpers(std::min(nthreads, batch) - 1);
+        std::atomic<int> next{0};
+        auto work = [&]() {
+            for (int b = next.fetch_add(1); b < batch; b = next.fetch_add(1)) {
                 Graph copy = g;                      // sequential_levels consumes its graph
                 sequential_levels(copy, gamma, seed + (uint64_t)(run + b), memb[b], &q[b]);
             }
         };
-        if (nt <= 1) {
-            work(0);
+        if (helpers <= 0) {
+            work();
         } else {
             std::vector<std::thread> pool;
-            for (int t = 0; t < nt; ++t) pool.emplace_back(work, t);
+            for (int t = 0; t < helpers; ++t) pool.emplace_back(work);
+            work();
             for (auto& th : pool) th.join();
+            give_helpers(helpers);
         }
         for (int b = 0; b < batch && run - updated < stall; ++b, ++run) {
             if (!have || q[b] - best_q > q_tol) {

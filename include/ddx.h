@@ -305,6 +305,11 @@ int ddx_leiden_sequential(int64_t n_nodes, const int64_t* indptr, const int32_t*
 int ddx_louvain_best_of(int64_t n_nodes, const int64_t* indptr, const int32_t* indices, const double* weights, double gamma,
                         uint64_t seed, double q_tol, int32_t stall, int32_t max_runs, int32_t threads, int32_t presweeps,
                         int32_t* labels_out /* [n_nodes] */, double* quality_out, int32_t* runs_out);
+/* ddx_set_helper_threads: how many helper threads the restart batches of ddx_louvain_best_of may have running in this PROCESS at any
+ *   time, beyond the calling threads themselves (negative: no limit, the default).  Jobs that overlap share the budget, a job that runs
+ *   alone -- the last iteration of a fit, dd.py:192-198 -- gets all of it; results never depend on it.  The Python host sets it from the
+ *   CPU time the node allows (cgroup quota) minus its lane threads. */
+int ddx_set_helper_threads(int32_t n);
 int ddx_presweep(int64_t n_nodes, const int64_t* indptr, const int32_t* indices, const double* weights, double gamma,
                  int32_t sweeps, int32_t subrounds, int32_t* member_out /* [n_nodes] */, int64_t* n_coarse_out,
                  int64_t* c_indptr_out /* [n_nodes+1] */, int32_t* c_indices_out /* [nnz] */, double* c_weights_out /* [nnz] */);
