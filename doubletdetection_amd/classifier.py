@@ -975,21 +975,22 @@ class BoostClassifier:
         self._host_threads_used = workers
         # host threads one clustering job may use for its batch of restarts (the jobs of different iterations overlap)
         restart_threads = max(1, min(20, workers // max(1, min(workers, len(mine)))))
-        if "DDX_HOST_THREADS" not in os.environ and hasattr(_lib, "set_helper_threads"):
-            # The restart batches of the iterations that finish at about the same time share a process-wide budget of helper threads: what
-            # the node allows (cgroup quota: 16 CPUs on pods that show 256) minus the lane threads that feed the GPU (spinning: one CPU
-            # each) and this rank's share only.  A job may then ask for a full batch of 20: it gets what is free -- all of it when it runs
-            # alone, as the last iteration of a fit does on the critical path.
-            spinning = len(lanes) if "block" != _lib.current_options().get("host_wait", "block" if world > 1 else "spin") else 0
-            budget = int(_cpu_allowance() // max(1, world)) - spinning - 1
-            try:
-                _lib.set_helper_threads(max(0, budget))
+        self._helper_budget = None
+        if hasattr(_lib, "set_helper_threads"):
+            # Several ranks on one node: the restart batches of a rank's iterations share a budget of helper threads -- the rank's share of
+            # the CPU time the node allows (cgroup quota: 16 CPUs on pods that show 256; its lane threads sleep while they wait, host_wait =
+            # block) -- and a job may ask for a full batch of 20: it gets what is free, all of it when it runs alone (the last iteration of a
+            # fit, on the critical path).  One rank: no budget.  Measured at the headline on such a pod (profiles/r06_host_budget.txt): a
+            # budget of 8 helpers beside the seven spinning lanes made the fit 5 ms SLOWER than 7 x 20 oversubscribed threads -- part B of
+            # iteration i has to be back before the lane reaches iteration i + 1's refinement, and throttling costs less than waiting for it.
+            budget = -1
+            if world > 1 and "DDX_HOST_THREADS" not in os.environ:
+                budget = max(0, int(_cpu_allowance() // world) - 1)
                 restart_threads = 20
-                self._helper_budget = max(0, budget)
-            except Exception:               # (a library without the entry point: the static share above)
-                pass
+                self._helper_budget = budget
+            _lib.set_helper_threads(budget)
         # (the most threads one clustering job can have running: its own + the whole budget)
-        self._restart_threads_used = min(restart_threads, getattr(self, "_helper_budget", restart_threads - 1) + 1)
+        self._restart_threads_used = restart_threads if self._helper_budget is None else min(restart_threads, self._helper_budget + 1)
         local = {}
         # Without a process group every iteration runs here: the worker that scores an iteration writes its rows of the
         # fitted attributes itself (behind the GPU's work on the other iterations) instead of leaving 30 MB of copies to the
