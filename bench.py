@@ -400,11 +400,13 @@ def main():
             "host_seconds_last_step": {k2: round(v, 3) for k2, v in getattr(clf, "_host_timings", {}).items()},
             "datagen_s": round(t_gen, 2),
             "notes": "PCA = sklearn's randomized SVD as 16 operator products per iteration (no dense H x H Gram is formed, DESIGN.md "
-                     "section 3).  Round 5: each product = the stored entries equal to 1 as bitmaps against 8-bit digits of the operand on "
+                     "section 3).  Since round 5 each product = the stored entries equal to 1 as bitmaps against 8-bit digits of the operand on "
                      "the int8 matrix cores (bitplane_rows / bitplane_cols: MFMA-bound rows of roofline_top_kernels, exact integer "
                      "arithmetic) + the other entries through the LDS-staged sparse kernel (spmm_rows / spmm_cols); `operator_product` "
-                     "prices a whole product against one pass over all stored entries.  The kNN distance screen runs on the bf16 MFMA "
-                     "(knn_emit / knn_bound)",
+                     "prices a whole product against one pass over all stored entries (an EFFECTIVE bandwidth of several launches: the "
+                     "single-kernel rooflines are roofline_dominant_kernel / roofline_top_kernels).  Round 6: standard_scaling=True takes the same "
+                     "route (1 / sd_j in the operand digits and the A^T Y epilogue; `bitplane.scaled`, `bitplane.demoted_columns`).  The kNN "
+                     "distance screen runs on the bf16 MFMA (knn_emit / knn_bound)",
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(X, args, kw)

@@ -125,6 +125,7 @@ def test_scaled_fit_seven_contexts_equal_one_and_match_the_oracle():
             fits[lanes] = clf
         ref = orc.OracleClassifier(pca="f64", louvain_fn=_native_louvain, **dict(kw, n_iters=2)).fit(data)
     print("scaled fit:", fits[7]._last_bitplane)
+    assert fits[7]._last_bitplane["demoted_columns"] > 0      # (followers copied structures the leader had rebuilt at its first scaling)
     for name in ("all_log_p_values_", "all_scores_", "communities_", "synth_communities_"):
         np.testing.assert_array_equal(getattr(fits[7], name), getattr(fits[1], name), err_msg=name)
     np.testing.assert_array_equal(np.asarray(fits[7].parents_[:2]), np.asarray(ref.parents_))
