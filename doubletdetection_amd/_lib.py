@@ -49,6 +49,7 @@ _SIGNATURES = {
     "ddx_trim": (C.c_int, [C.c_void_p, C.c_int64]),
     "ddx_set_upload_threads": (C.c_int, [C.c_int32]),
     "ddx_set_helper_threads": (C.c_int, [C.c_int32]),
+    "ddx_set_upload_share": (C.c_int, [C.c_char_p, C.c_int32, C.c_int32]),
     "ddx_upload_raw": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, c_i64_p, c_i32_p, c_f32_p]),
     "ddx_gene_variances": (C.c_int, [C.c_void_p, c_f32_p]),
     "ddx_select_columns": (C.c_int, [C.c_void_p, c_i64_p, C.c_int32]),
@@ -190,6 +191,12 @@ def pack_rows16(indptr, indices, data, capacity=None):
 def set_upload_threads(n: int) -> None:
     """Host threads that pack the raw matrix for the upload (process-wide; 0 = the library's default)."""
     _check(load().ddx_set_upload_threads(int(n)))
+
+
+def set_upload_share(name: str, local_rank: int = 0, local_world: int = 1) -> None:
+    """One packing per node for one-process-per-GPU runs: the node's ranks share a POSIX shared-memory image of the packed matrix
+    (include/ddx.h: ddx_set_upload_share).  Empty name / local_world <= 1: off."""
+    _check(load().ddx_set_upload_share((name or "").encode(), int(local_rank), int(local_world)))
 
 
 def set_helper_threads(n: int) -> None:

@@ -83,6 +83,38 @@ def _cpu_allowance() -> float:
         return float(os.cpu_count() or 1)
 
 
+_SHARE_TOKEN = {}
+
+
+def _share_upload(rank, world, backend, one_leader=True):
+    """One packing per node under torch.distributed (dd.py:149-160 x ranks): the ranks agree on a name for the node's shared image once per
+    process group -- rank 0 draws it, everybody receives it -- and tell the library their place on the node.  DDX_UPLOAD_SHARE=0 turns it off."""
+    if not hasattr(_lib, "set_upload_share"):
+        return
+    try:
+        if world <= 1 or backend is None or not one_leader or os.environ.get("DDX_UPLOAD_SHARE", "1") == "0":
+            _lib.set_upload_share("", 0, 1)
+            return
+        import torch.distributed as dist
+
+        key = id(dist.group.WORLD)
+        if key not in _SHARE_TOKEN:
+            import time
+
+            box = [f"{os.getpid()}_{int(time.time() * 1e6) % 10 ** 12}" if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            _SHARE_TOKEN.clear()
+            _SHARE_TOKEN[key] = box[0]
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+        local_rank = int(os.environ.get("LOCAL_RANK", rank)) % max(1, local_world)
+        _lib.set_upload_share(_SHARE_TOKEN[key], local_rank, local_world)
+    except Exception:                      # (sharing is an optimisation: any trouble and every rank packs for itself)
+        try:
+            _lib.set_upload_share("", 0, 1)
+        except Exception:
+            pass
+
+
 def _keep_contexts() -> bool:
     return os.environ.get("DDX_KEEP_CONTEXT", "1") not in ("", "0")
 
@@ -625,6 +657,8 @@ class BoostClassifier:
             # (a rank's share of the CPU time the node ALLOWS -- the pods show 256 CPUs and allow 16: eight ranks x 16 packing threads
             # would be throttled, not faster)
             _lib.set_upload_threads(max(2, min(16, int(_cpu_allowance()) // world)) if world > 1 else 0)
+        self._upload_form_used = None
+        _share_upload(rank, world, backend, one_leader=len(self._device_list(world)) == 1)
         staged = getattr(self, "_staged", None)
         drawer = ThreadPoolExecutor(max_workers=1)
         draws = None
@@ -655,6 +689,9 @@ class BoostClassifier:
                 raise
         self._staged = None
         t_staged = time.perf_counter()
+        lead_ctx = getattr(next(iter(leaders.values())), "ctx", None)
+        if lead_ctx is not None and hasattr(lead_ctx, "upload_form") and restrict:
+            self._upload_form_used = lead_ctx.upload_form()     # 0 plain arrays, 1 packed here, 2 another context's / the node's packed image
         num_cells = csr.shape[0]
         num_genes = self.n_top_var_genes if restrict else csr.shape[1]
         if draws is not None and (int(shape[0]), int(g_early)) != (num_cells, num_genes):      # (cannot happen: the staged matrix has the input's shape)

@@ -3,6 +3,9 @@
 #include <condition_variable>
 #include <functional>
 #include <unistd.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <mutex>
 #include <new>
 #include <chrono>
@@ -689,9 +692,134 @@ __attribute__((target("avx2"))) static void pack16_avx2(const int64_t* indptr, i
     DDX_PACK16_BODY
 }
 
+// ---- one packing per NODE: the packed image in POSIX shared memory (one process per GPU, torchrun) -----------------------------------
+// With one process per GPU every rank used to pack its own copy of the same matrix: 0.1 s of CPU time each, on hosts that allow 16 CPUs'
+// worth of time for 8 ranks (dd.py:149-160 has no counterpart: the reference is one process).  Local rank 0 now packs into a shared
+// segment that every rank of the node registers as pinned memory once; the others follow its progress chunk by chunk -- codes from the
+// segment over their own PCIe link, the listed entries from the segment's side arrays -- exactly as the contexts of ONE process attach to a
+// PackShare.  Generations: a rank's g-th shareable upload is generation g everywhere (the ranks call fit() in lockstep); the owner reuses
+// the buffer for generation g once every follower has reported generation g - 1 finished or abandoned.  Anything unexpected -- a follower
+// that is late, another matrix, a matrix larger than the segment, a timeout -- ends in that rank packing for itself: slower, never wrong.
+constexpr int kShmMaxChunks = 64, kShmMaxRanks = 64;
+constexpr uint32_t kShmMagic = 0x64647836u;
+struct ShmHeader {
+    std::atomic<uint32_t> magic;
+    uint64_t codes_bytes, esc_cap;                       // capacities: bytes of codes, listed entries
+    std::atomic<uint64_t> generation;                    // the job described below (0: none yet)
+    int64_t n_cells, nnz, chunk, nchunks;
+    int32_t n_genes, f16;
+    uint64_t fingerprint;
+    std::atomic<int32_t> bad;                            // the matrix turned out not to be packable (or the owner failed)
+    std::atomic<int64_t> esc_end[kShmMaxChunks];         // -1 until chunk k's codes and listed entries are in place; then the listed entries up to and including it
+    std::atomic<uint64_t> follower_gen[kShmMaxRanks];    // last generation local rank r has finished with (or given up on)
+};
+struct ShmState {
+    std::string name;
+    int local_rank = 0, local_world = 1;
+    uint64_t my_gen = 0;                                 // shareable uploads this process has made
+    ShmHeader* hdr = nullptr;
+    unsigned char* codes = nullptr;
+    int32_t* esc_pos = nullptr; int32_t* esc_col = nullptr; float* esc_val = nullptr;
+    size_t map_bytes = 0;
+    bool registered = false, failed = false, owner_created = false;
+};
+ShmState g_shm;
+std::mutex g_shm_mutex;
+
+static void shm_unlink_at_exit() { if (g_shm.owner_created && !g_shm.name.empty()) (void)shm_unlink(g_shm.name.c_str()); }
+
+static uint64_t upload_fingerprint(int64_t n_cells, int64_t nnz, const int64_t* indptr, const int32_t* indices, const float* data) {
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](uint64_t v) { h ^= v; h *= 1099511628211ull; };
+    const int64_t sr = std::max<int64_t>(1, n_cells / 2048), se = std::max<int64_t>(1, nnz / 4096);
+    for (int64_t r = 0; r <= n_cells; r += sr) mix((uint64_t)indptr[r]);
+    mix((uint64_t)indptr[n_cells]);
+    for (int64_t e = 0; e < nnz; e += se) { uint32_t b; memcpy(&b, &data[e], 4); mix(((uint64_t)(uint32_t)indices[e] << 32) | b); }
+    return h;
+}
+
+// maps (owner: creates) the segment; false: sharing is off for this process from now on
+static bool shm_attach(int device, size_t want_codes, int64_t want_esc) {
+    ShmState& S = g_shm;
+    if (S.failed) return false;
+    if (S.hdr) return true;
+    const bool owner = S.local_rank == 0;
+    int fd = -1;
+    size_t bytes = 0;
+    const size_t hdr_bytes = (sizeof(ShmHeader) + 4095) & ~(size_t)4095;
+    if (owner) {
+        (void)shm_unlink(S.name.c_str());
+        fd = shm_open(S.name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd < 0) { S.failed = true; return false; }
+        const size_t codes = ((want_codes + want_codes / 4 + ((size_t)64 << 20)) + 4095) & ~(size_t)4095;
+        const uint64_t esc = (uint64_t)(want_esc + want_esc / 4 + 4096);
+        bytes = hdr_bytes + codes + 12 * (size_t)esc;
+        if (ftruncate(fd, (off_t)bytes) != 0) { close(fd); (void)shm_unlink(S.name.c_str()); S.failed = true; return false; }
+        void* m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        close(fd);
+        if (m == MAP_FAILED) { (void)shm_unlink(S.name.c_str()); S.failed = true; return false; }
+        ShmHeader* h = new (m) ShmHeader();
+        h->codes_bytes = codes; h->esc_cap = esc;
+        h->generation.store(0);
+        h->bad.store(0);
+        for (auto& e : h->esc_end) e.store(-1);
+        for (auto& f : h->follower_gen) f.store(0);
+        S.hdr = h; S.map_bytes = bytes; S.owner_created = true;
+        static bool hooked = false;
+        if (!hooked) { hooked = true; std::atexit(shm_unlink_at_exit); }
+        h->magic.store(kShmMagic, std::memory_order_release);
+    } else {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            fd = shm_open(S.name.c_str(), O_RDWR, 0600);
+            if (fd >= 0) {
+                struct stat st;
+                if (fstat(fd, &st) == 0 && (size_t)st.st_size > hdr_bytes) { bytes = (size_t)st.st_size; break; }
+                close(fd); fd = -1;
+            }
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(3)) { S.failed = true; return false; }
+            std::this_thread::sleep_for(std::chrono::microseconds(200));
+        }
+        void* m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        close(fd);
+        if (m == MAP_FAILED) { S.failed = true; return false; }
+        S.hdr = static_cast<ShmHeader*>(m); S.map_bytes = bytes;
+        while (S.hdr->magic.load(std::memory_order_acquire) != kShmMagic) {
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(3)) { S.failed = true; S.hdr = nullptr; return false; }
+            std::this_thread::yield();
+        }
+    }
+    unsigned char* base = reinterpret_cast<unsigned char*>(S.hdr);
+    S.codes = base + hdr_bytes;
+    S.esc_pos = reinterpret_cast<int32_t*>(S.codes + S.hdr->codes_bytes);
+    S.esc_col = S.esc_pos + S.hdr->esc_cap;
+    S.esc_val = reinterpret_cast<float*>(S.esc_col + S.hdr->esc_cap);
+    // pinned for THIS process's copies (the copies of a chunk would otherwise be staged through the runtime's own bounce buffers)
+    (void)hipSetDevice(device);
+    S.registered = hipHostRegister(S.codes, S.hdr->codes_bytes, hipHostRegisterPortable) == hipSuccess;
+    if (!S.registered) (void)hipGetLastError();
+    return true;
+}
+
+int ddx_set_upload_share_impl(const char* name, int32_t local_rank, int32_t local_world) {
+    std::lock_guard<std::mutex> lock(g_shm_mutex);
+    ShmState& S = g_shm;
+    const std::string nm = (name && *name && local_world > 1) ? std::string("/ddx_") + name : std::string();
+    if (nm == S.name && local_rank == S.local_rank && local_world == S.local_world) return DDX_OK;
+    if (S.hdr) {
+        if (S.registered) (void)hipHostUnregister(S.codes);
+        (void)munmap(S.hdr, S.map_bytes);
+        if (S.owner_created) (void)shm_unlink(S.name.c_str());
+    }
+    S = ShmState();
+    if (nm.empty() || local_rank < 0 || local_rank >= local_world || local_world > kShmMaxRanks) return DDX_OK;
+    S.name = nm; S.local_rank = local_rank; S.local_world = local_world;
+    return DDX_OK;
+}
+
 // The consumer side of a packed upload: sends the chunks of job `sh` to `ctx` as the packing threads finish them and expands them
 // there.  Run by the context that packs and by every context attached to its job.  DDX_OK / 1 (not packable) / DDX_E_HIP.
-static int send_packed(ddx_ctx* ctx, const PackShare& sh, bool owner, double t_in) {
+static int send_packed(ddx_ctx* ctx, const PackShare& sh, bool owner, double t_in, ShmState* pub = nullptr) {
     const bool f16 = sh.f16;
     const int64_t nnz = sh.nnz, n_cells = sh.n_cells, chunk = sh.chunk, nchunks = sh.nchunks;
     const int32_t n_genes = sh.n_genes;
@@ -741,6 +869,7 @@ static int send_packed(ddx_ctx* ctx, const PackShare& sh, bool owner, double t_i
         if (!f16) {
             k_expand_packed<<<(unsigned)((len + 255) / 256), 256, 0, ctx->stream>>>(reinterpret_cast<const uint32_t*>(dev), len, ctx->raw_indices.as<int32_t>() + c0,
                                                                                     ctx->raw_data.as<float>() + c0);
+            if (pub) pub->hdr->esc_end[k].store(0, std::memory_order_release);
             continue;
         }
         // 2-byte form: the entries this chunk lists go behind those of the earlier chunks (ascending positions), then the rows
@@ -751,6 +880,15 @@ static int send_packed(ddx_ctx* ctx, const PackShare& sh, bool owner, double t_i
             for (const PackEsc& x : listed[(size_t)k * T + w]) { pos.push_back(x.pos); col.push_back(x.col); val.push_back(x.val); }
         const size_t added = pos.size() - before;
         if ((int64_t)pos.size() > esc_cap) { rc = 1; break; }
+        if (pub) {                                            // the other ranks of the node: this chunk's codes are in the segment, its listed entries follow
+            if (pos.size() > pub->hdr->esc_cap) { rc = 1; break; }
+            if (added) {
+                memcpy(pub->esc_pos + before, pos.data() + before, 4 * added);
+                memcpy(pub->esc_col + before, col.data() + before, 4 * added);
+                memcpy(pub->esc_val + before, val.data() + before, 4 * added);
+            }
+            pub->hdr->esc_end[k].store((int64_t)pos.size(), std::memory_order_release);
+        }
         if (added &&
             (hipMemcpyAsync(d_pos + before, pos.data() + before, 4 * added, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
              hipMemcpyAsync(d_col + before, col.data() + before, 4 * added, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
@@ -765,6 +903,7 @@ static int send_packed(ddx_ctx* ctx, const PackShare& sh, bool owner, double t_i
         }
     }
     if (rc != DDX_OK && owner) bad.store(1);               // (stops the packing threads; an attached context's own failure is its own)
+    if (pub && (rc != DDX_OK || bad.load())) pub->hdr->bad.store(1, std::memory_order_release);
     const double t_issued = clk();
     if (ctx->opt.upload_debug > 1) {
         for (int64_t k = 0; k < nchunks; ++k)
@@ -781,6 +920,85 @@ static int send_packed(ddx_ctx* ctx, const PackShare& sh, bool owner, double t_i
                 (int)esz, owner ? "" : " (another context's packing)", T, (long long)nchunks, t_issued - t_in, t_copied - t_in, clk() - t_in);
     for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
     return rc;
+}
+
+// A follower rank's upload from the node's segment (generation `gen`): DDX_OK, 1 (not available / not packable: the caller packs for
+// itself or sends the matrix plain) or DDX_E_HIP.  Mirrors send_packed's consumer loop with the segment as the source.
+static int recv_shared(ddx_ctx* ctx, ShmState& S, uint64_t gen, int64_t n_cells, int64_t nnz, int32_t n_genes, bool f16, const int64_t* indptr, uint64_t fp) {
+    ShmHeader* h = S.hdr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    const auto t0 = now();
+    auto give_up = [&](int rc) { h->follower_gen[S.local_rank].store(gen, std::memory_order_release); return rc; };
+    while (h->generation.load(std::memory_order_acquire) < gen) {
+        if (now() - t0 > std::chrono::milliseconds(1500)) return give_up(1);
+        std::this_thread::yield();
+    }
+    if (h->generation.load(std::memory_order_acquire) != gen || h->n_cells != n_cells || h->nnz != nnz || h->n_genes != n_genes || (h->f16 != 0) != f16 ||
+        h->fingerprint != fp || h->nchunks > kShmMaxChunks)
+        return give_up(1);
+    const int64_t chunk = h->chunk, nchunks = h->nchunks;
+    const size_t esz = f16 ? sizeof(uint16_t) : sizeof(uint32_t);
+    const size_t codes_bytes = (esz * (size_t)nnz + 255) & ~(size_t)255;
+    const int64_t esc_cap = f16 ? nnz / 32 + 1 : 0;
+    unsigned char* side = ctx->raw_packed.as<unsigned char>() + codes_bytes;
+    int32_t* d_pos = reinterpret_cast<int32_t*>(side);
+    int32_t* d_col = d_pos + esc_cap;
+    float* d_val = reinterpret_cast<float*>(d_col + esc_cap);
+    std::vector<hipEvent_t> ev((size_t)nchunks, nullptr);
+    bool fold_ok = f16 && ctx->opt.hvg_fold;
+    int64_t rows_done = 0, fold_max = 1, prev_rows = 0, listed = 0;
+    std::vector<int64_t> rows_done_after((size_t)nchunks, 0);
+    if (f16)
+        for (int64_t k = 0; k < nchunks; ++k) {
+            const int64_t c1 = std::min(nnz, (k + 1) * chunk);
+            const int64_t r1 = (std::upper_bound(indptr, indptr + n_cells + 1, c1) - indptr) - 1;
+            rows_done_after[k] = r1;
+            fold_max = std::max(fold_max, indptr[r1] - indptr[prev_rows]);
+            prev_rows = r1;
+        }
+    int rc = DDX_OK;
+    for (int64_t k = 0; k < nchunks && rc == DDX_OK; ++k) {
+        int64_t end = -1;
+        const auto tk = now();
+        while ((end = h->esc_end[k].load(std::memory_order_acquire)) < 0 && !h->bad.load(std::memory_order_acquire)) {
+            if (h->generation.load(std::memory_order_acquire) != gen || now() - tk > std::chrono::milliseconds(3000)) { rc = 1; break; }
+            std::this_thread::yield();
+        }
+        if (rc != DDX_OK) break;
+        if (end < 0 || h->bad.load()) { rc = 1; break; }
+        const int64_t c0 = k * chunk, len = std::min(nnz, c0 + chunk) - c0;
+        unsigned char* dev = ctx->raw_packed.as<unsigned char>() + esz * c0;
+        if (hipMemcpyAsync(dev, S.codes + esz * c0, esz * len, hipMemcpyHostToDevice, ctx->copy_stream) != hipSuccess ||
+            hipEventCreateWithFlags(&ev[k], hipEventDisableTiming) != hipSuccess || hipEventRecord(ev[k], ctx->copy_stream) != hipSuccess ||
+            hipStreamWaitEvent(ctx->stream, ev[k], 0) != hipSuccess) { rc = DDX_E_HIP; break; }
+        if (!f16) {
+            k_expand_packed<<<(unsigned)((len + 255) / 256), 256, 0, ctx->stream>>>(reinterpret_cast<const uint32_t*>(dev), len, ctx->raw_indices.as<int32_t>() + c0,
+                                                                                    ctx->raw_data.as<float>() + c0);
+            continue;
+        }
+        if (end > esc_cap) { rc = 1; break; }
+        const int64_t added = end - listed;
+        if (added > 0 &&
+            (hipMemcpyAsync(d_pos + listed, S.esc_pos + listed, 4 * (size_t)added, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+             hipMemcpyAsync(d_col + listed, S.esc_col + listed, 4 * (size_t)added, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+             hipMemcpyAsync(d_val + listed, S.esc_val + listed, 4 * (size_t)added, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)) { rc = DDX_E_HIP; break; }
+        listed = end;
+        const int64_t row1 = rows_done_after[k];
+        if (row1 > rows_done) {
+            k_expand_packed16<<<(unsigned)((row1 - rows_done + 3) / 4), 256, 0, ctx->stream>>>(ctx->raw_packed.as<uint16_t>(), ctx->raw_indptr.as<int64_t>(), rows_done, row1, d_pos,
+                                                                                             d_col, d_val, (int32_t)listed, ctx->raw_indices.as<int32_t>(),
+                                                                                             ctx->raw_data.as<float>());
+            if (fold_ok && gene_sums_fold(ctx, n_genes, n_cells, rows_done, row1, indptr[rows_done], indptr[row1], fold_max) != DDX_OK) fold_ok = false;
+            rows_done = row1;
+        }
+    }
+    if (rc != DDX_OK || !fold_ok) ctx->hvg_rows = -1;
+    (void)hipStreamSynchronize(ctx->copy_stream);
+    (void)wait_stream(ctx);                                   // (the segment may be rewritten once this rank has reported)
+    for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
+    if (rc == DDX_OK && (h->bad.load() || h->generation.load() != gen)) rc = 1;
+    if (ctx->opt.upload_debug > 0) fprintf(stderr, "[ddx upload] local rank %d from the node's segment (generation %llu): rc %d\n", S.local_rank, (unsigned long long)gen, rc);
+    return give_up(rc);
 }
 
 // device buffer of the packed form: the codes, then (2-byte form) room for the listed entries: positions | columns | values
@@ -804,6 +1022,48 @@ static int upload_packed(ddx_ctx* ctx, int64_t n_cells, int64_t nnz, int32_t n_g
     const int64_t esc_cap = f16 ? nnz / 32 + 1 : 0;      // listed entries the device buffer has room for
     auto clk = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     ctx->upload_form = 0;
+    // Several ranks on this node (ddx_set_upload_share): this is generation `gen` of the node's segment.  A follower takes the image from
+    // there; the owner (local rank 0) packs into it below.  Whatever goes wrong ends in this rank packing for itself.
+    ShmState* shm = nullptr;
+    uint64_t gen = 0, fp = 0;
+    {
+        std::lock_guard<std::mutex> lock(g_shm_mutex);
+        if (!g_shm.name.empty() && !g_shm.failed && nchunks <= kShmMaxChunks) {
+            gen = ++g_shm.my_gen;
+            if (shm_attach(ctx->device, need, esc_cap)) shm = &g_shm;
+        }
+    }
+    if (shm) fp = upload_fingerprint(n_cells, nnz, indptr, indices, data);
+    if (shm && shm->local_rank != 0) {
+        int rc = packed_device_buffer(ctx, f16, nnz);
+        if (rc == DDX_OK) {
+            (void)wait_stream(ctx);
+            rc = recv_shared(ctx, *shm, gen, n_cells, nnz, n_genes, f16, indptr, fp);
+        }
+        if (rc == DDX_E_HIP) return set_err(ctx, DDX_E_HIP, "packed upload from the node's shared image failed");
+        if (rc < 0) return rc;
+        if (rc == DDX_OK) { ctx->upload_form = 2; return DDX_OK; }
+        shm = nullptr;                                            // not available: this rank packs for itself
+    }
+    // the owner publishes generation `gen` on every path from here on -- as unusable (bad) unless it gets as far as packing into the segment
+    struct ShmPublish {
+        ShmState* s; uint64_t gen; bool done = false;
+        ~ShmPublish() {
+            if (s && !done) { s->hdr->bad.store(1); s->hdr->generation.store(gen, std::memory_order_release); }
+        }
+    } shm_pub{shm, gen};
+    bool shm_serve = false;
+    if (shm) {
+        ShmHeader* h = shm->hdr;
+        shm_serve = need <= h->codes_bytes && (uint64_t)esc_cap <= h->esc_cap;
+        // every follower has finished with (or given up on) the previous generation: the buffer may be rewritten
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int r = 1; r < shm->local_world && shm_serve; ++r)
+            while (h->follower_gen[r].load(std::memory_order_acquire) + 1 < gen) {
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2000)) { shm_serve = false; break; }
+                std::this_thread::yield();
+            }
+    }
     // one packing at a time per process.  A second context staging at the same moment (several GPUs driven by one process) attaches
     // to the running job when it is packing the same host arrays, and sends its copy plain, in parallel, when it is not.
     // (g_share_mutex is held from before the attempt on g_pool_mutex until the job is published: whoever fails to get the pool
@@ -836,7 +1096,7 @@ static int upload_packed(ddx_ctx* ctx, int64_t n_cells, int64_t nnz, int32_t n_g
         else ctx->upload_form = 2;
         return rc;
     }
-    {
+    if (!shm_serve) {
         static pid_t pin_pid = 0;
         if (pin_pid != getpid()) {                               // (a forked child starts over; the parent's helper thread does not exist here)
             pin_pid = getpid(); g_pin_state.store(0); g_pin_buf = nullptr; g_pin_bytes = 0; g_pin_failed = 0;
@@ -866,7 +1126,7 @@ static int upload_packed(ddx_ctx* ctx, int64_t n_cells, int64_t nnz, int32_t n_g
         const int rc = packed_device_buffer(ctx, f16, nnz);
         if (rc != DDX_OK) return rc;
     }
-    unsigned char* pin = static_cast<unsigned char*>(g_pin_buf);
+    unsigned char* pin = shm_serve ? shm->codes : static_cast<unsigned char*>(g_pin_buf);
     WorkerPool* pool = upload_pool();
     const int T = pool->size();
     std::vector<std::atomic<int>> done(nchunks);
@@ -904,9 +1164,17 @@ static int upload_packed(ddx_ctx* ctx, int64_t n_cells, int64_t nnz, int32_t n_g
     g_share = &share;
     share_lock.unlock();
     const double t_in = clk();
+    if (shm_serve) {                      // the node's other ranks may follow from now on
+        ShmHeader* h = shm->hdr;
+        h->n_cells = n_cells; h->nnz = nnz; h->chunk = chunk; h->nchunks = nchunks; h->n_genes = n_genes; h->f16 = f16 ? 1 : 0; h->fingerprint = fp;
+        for (int64_t k = 0; k < nchunks; ++k) h->esc_end[k].store(-1);
+        h->bad.store(0);
+        h->generation.store(gen, std::memory_order_release);
+        shm_pub.done = true;
+    }
     (void)wait_stream(ctx);               // the copies must not overtake whatever the main stream still does with the device buffers
     pool->start(worker);
-    int rc = send_packed(ctx, share, true, t_in);
+    int rc = send_packed(ctx, share, true, t_in, shm_serve ? shm : nullptr);
     pool->wait();
     if (rc == DDX_OK && bad.load()) rc = 1;
     // close the job: nobody attaches any more; the pinned buffer, the lists and the counters stay until the attached contexts are done
@@ -939,6 +1207,10 @@ int ddx_pack_rows16(int64_t n_rows, const int64_t* indptr, const int32_t* indice
         if (listed_val) listed_val[t] = esc[t].val;
     }
     return DDX_OK;
+}
+
+int ddx_set_upload_share(const char* name, int32_t local_rank, int32_t local_world) {
+    return ddx_set_upload_share_impl(name, local_rank, local_world);
 }
 
 int ddx_set_upload_threads(int32_t n) {

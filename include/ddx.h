@@ -115,6 +115,12 @@ int ddx_trim(ddx_ctx* ctx, int64_t keep_bytes);
 /* host threads that pack the raw matrix for the PCIe upload (process-wide; 0 = default min(48, cores/2); several
  * ranks of one node should share the cores) */
 int ddx_set_upload_threads(int32_t n);
+/* one packing per NODE (one process per GPU, dd.py:149-160 x ranks): the ranks of a node name a POSIX shared-memory segment (`name`, the
+ * same string on every rank of the node and new for every job; local_rank 0 creates it, packs into it and unlinks it at exit; the others
+ * register it as pinned memory and send its chunks to their own GPU as local rank 0 finishes them -- ddx_get_upload_form = 2 there).  The
+ * ranks must make their uploads in lockstep (the g-th shareable upload of every rank is the same matrix); a rank that finds the segment
+ * late, busy, too small or holding another matrix packs for itself.  name NULL / "" or local_world <= 1: off (the default). */
+int ddx_set_upload_share(const char* name, int32_t local_rank, int32_t local_world);
 /* The host side of the 2-byte transfer form of ddx_upload_raw (dd.py:149-160: the matrix fit() receives), exposed so that
  * it can be checked without a GPU: codes[i] = step from the previous column of the row (1..255; the first entry of a row
  * steps from column -1) | count << 8 (0..255), or 0 for an entry that does not fit; those are listed whole, in ascending

@@ -182,3 +182,52 @@ def test_sleeping_host_waits_give_the_same_fit_for_less_cpu_time(monkeypatch):
         np.testing.assert_array_equal(getattr(out["block"][0], name), getattr(out["spin"][0], name))
     assert out["block"][1] < 1.15 * out["spin"][1] + 0.02, out
     assert out["block"][2] < 1.5 * out["spin"][2], out
+
+
+def _share_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), LOCAL_WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    sys.path.insert(0, ROOT)
+    import time
+
+    import torch.distributed as dist
+
+    from doubletdetection_amd import BoostClassifier
+    from doubletdetection_amd._synthetic import make_counts
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        counts = make_counts(12000, 3000, density=0.06, n_types=6, seed=31)
+        forms, cpu = [], []
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for _ in range(3):
+                c0 = time.process_time()
+                clf = BoostClassifier(n_iters=4, n_top_var_genes=2000, random_state=1, device=0).fit(counts)
+                cpu.append(time.process_time() - c0)
+                forms.append(clf._upload_form_used)
+        np.savez(os.path.join(out_dir, f"share{rank}.npz"), scores=clf.all_scores_, comm=clf.communities_, forms=np.asarray(forms), cpu=np.asarray(cpu))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ranks_of_a_node_share_one_packing(tmp_path):
+    """One process per GPU (dd.py:149-160 x ranks): local rank 0 packs the matrix once into a POSIX shared-memory image, the other ranks of
+    the node send its chunks to their own GPU (ddx_get_upload_form = 2) -- here two gloo ranks on the one GPU of the test box, three fits
+    in a row (the segment is reused generation by generation).  Results are those of a single process."""
+    import torch.multiprocessing as mp
+
+    from doubletdetection_amd import BoostClassifier
+    from doubletdetection_amd._synthetic import make_counts
+
+    mp.spawn(_share_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "share0.npz"), np.load(tmp_path / "share1.npz")
+    print("upload forms: rank 0", r0["forms"], "rank 1", r1["forms"], " cpu s per fit:", r0["cpu"].round(2), r1["cpu"].round(2))
+    assert list(r0["forms"]) == [1, 1, 1], r0["forms"]
+    assert list(r1["forms"]) == [2, 2, 2], r1["forms"]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        single = BoostClassifier(n_iters=4, n_top_var_genes=2000, random_state=1, device=0).fit(make_counts(12000, 3000, density=0.06, n_types=6, seed=31))
+    for r in (r0, r1):
+        np.testing.assert_array_equal(r["comm"], single.communities_)
+        np.testing.assert_array_equal(r["scores"], single.all_scores_)
