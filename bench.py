@@ -237,13 +237,18 @@ def main():
         one_fit()
     elapsed = 0.0
     clf = None
+    cpu0 = time.process_time()                   # CPU time of this rank's process (all its threads) over the timed steps
     for _ in range(args.steps):
         clf, dt = one_fit()
         elapsed += dt
+    cpu_timed = time.process_time() - cpu0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        t = torch.tensor([cpu_timed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        cpu_timed = float(t.item())
     # ---- everything below is outside the timed region -------------------------------------------------------------------
     resident_elapsed = None
     exclusive = None
@@ -398,6 +403,9 @@ def main():
             "gpu_busy_frac": (round(busy_ms / 1e3 / instr_elapsed, 4) if instr_elapsed and busy_ms else None),
             "gpu_busy_frac_note": "union of the kernel-scope intervals of all streams / wall-clock of the instrumented fits",
             "host_seconds_last_step": {k2: round(v, 3) for k2, v in getattr(clf, "_host_timings", {}).items()},
+            "host_cpu_seconds_per_step": round(cpu_timed / args.steps, 3),
+            "host_cpu_seconds_per_step_note": "process CPU time (all threads) over the timed steps, summed over the ranks; upload form of the last fit: "
+                                              + str(getattr(clf, "_upload_form_used", None)),
             "datagen_s": round(t_gen, 2),
             "notes": "PCA = sklearn's randomized SVD as 16 operator products per iteration (no dense H x H Gram is formed, DESIGN.md "
                      "section 3).  Since round 5 each product = the stored entries equal to 1 as bitmaps against 8-bit digits of the operand on "
