@@ -203,6 +203,7 @@ bool Options::set(const char* key, const char* value) {
     if (k == "residual_rows_own") { if (!num(6, 12, &x) || (x != 6 && x != 12)) return false; residual_rows_own = (int)x; return true; }
     if (k == "synthetic") { if (v == "derived") synthetic_derived = true; else if (v == "merged") synthetic_derived = false; else return false; return true; }
     if (k == "bp_digits") { if (!num(3, 4, &x)) return false; bp_digits = (int)x; return true; }
+    if (k == "bp_digits_early") { if (!num(0, 4, &x) || x == 1) return false; bp_digits_early = (int)x; return true; }
     if (k == "knn_fold") { knn_fold = on(); return true; }
     if (k == "knn_xcd_chunk") { if (!num(0, 4096, &x)) return false; knn_xcd_chunk = (int)x; return true; }
     if (k == "knn_sample_tiles") { if (!num(0, 1 << 24, &x)) return false; knn_sample_tiles = x; return true; }

@@ -48,6 +48,7 @@ struct Options {
     bool pca_debug = false;          // progress of the block Lanczos solver on stderr
     int bitplane = 1;                // entries equal to 1 as bitmaps on the int8 matrix cores (k_bitplane.hip): 0 off, 1 when the matrix is large enough, 2 always
     int bp_digits = 4;               // 8-bit digits of the operand's fixed point in those products (4: 30 bits below the column maximum, 3: 22)
+    int bp_digits_early = 0;         // ... in the power iterations before the last one of the randomized PCA (0: as bp_digits; 2: 14 bits, 3, 4)
     int mirror_mode = 2;             // column-major mirror: 2 counting sort placed by LDS tiles, 1 (DDX_MIRROR=scatter) counting sort with scattered stores, 0 (DDX_MIRROR=sort) radix sort
     bool upload_packed = true;       // DDX_UPLOAD=plain: send the raw matrix as it is (8 bytes per entry) instead of packed
     bool upload_form16 = true;       // DDX_UPLOAD=packed32: column | count << 16 (4 bytes per entry) instead of column step | count << 8 (2 bytes)
@@ -118,6 +119,7 @@ struct BitPlanes {
     double* cmax = nullptr;          // [2][64] column maxima of the operand: Q side, Y side
     const double* ymax_of = nullptr; // the row-side matrix whose maxima (of diag(s) Y) the sparse A Q kernel has just left in cmax[64..]
     const double* qmax_of = nullptr; // the column-side matrix whose (weighted) maxima the Cholesky-QR's right multiplication has just left in cmax[0..63]
+    int nd_now = 0;                  // digits of the products being issued (0: opt.bp_digits); stage_pca lowers it for its early power iterations
     bool qmax_zeroed = false;        // cmax[0..63] are zeros (the last Y-side digit kernel cleared them): maxima may be collected into them
     double* part = nullptr;          // partial blocks of the A^T Y product, one per chunk of the rows
     // standard scaling (sc.pp.scale, dd.py:302-303) on this route: an entry equal to 1 becomes s_i / sd_j as long as it is not clipped, so the

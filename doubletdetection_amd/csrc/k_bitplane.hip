@@ -882,6 +882,7 @@ static int bp_launch_t(ddx_ctx* ctx, const BpProductArgs& a, int chunks) {
 
 template <bool ROWS>
 static int bp_launch(ddx_ctx* ctx, const BpProductArgs& a, int chunks, int ND, int RT) {
+    if (ND == 2) return RT == 1 ? bp_launch_t<1, 3, 2, ROWS>(ctx, a, chunks) : bp_launch_t<2, 3, 2, ROWS>(ctx, a, chunks);
     if (ND == 3) return RT == 1 ? bp_launch_t<1, 4, 3, ROWS>(ctx, a, chunks) : bp_launch_t<2, 4, 3, ROWS>(ctx, a, chunks);
     return RT == 1 ? bp_launch_t<1, 5, 4, ROWS>(ctx, a, chunks) : bp_launch_t<2, 5, 4, ROWS>(ctx, a, chunks);
 }
@@ -899,12 +900,25 @@ static int bp_pick_rt(int64_t ntile, int chunks) {
     return pick;
 }
 
+// digits of the product being issued: the option, or what stage_pca asked for its early power iterations (bp.nd_now)
+static int bp_digits_now(const ddx_ctx* ctx) {
+    const int nd = ctx->bp.nd_now ? ctx->bp.nd_now : ctx->opt.bp_digits;
+    return nd <= 2 ? 2 : nd == 3 ? 3 : 4;
+}
+
+template <bool ROWMAP, typename... Args>
+static void bp_launch_digits(int ND, unsigned grid, hipStream_t st, Args... args) {
+    if (ND == 2) k_bp_digits<2, ROWMAP><<<grid, 256, 0, st>>>(args...);
+    else if (ND == 3) k_bp_digits<3, ROWMAP><<<grid, 256, 0, st>>>(args...);
+    else k_bp_digits<4, ROWMAP><<<grid, 256, 0, st>>>(args...);
+}
+
 // Y[i][:] = s_i (B Q)[i][:] for every row i of the augmented matrix (plain stores: the sparse product that follows adds its part
 // and, through *ymax, collects the column maxima of diag(s) Y that the A^T Y product will cut its digits by)
 int bp_rows_product(ddx_ctx* ctx, const double* Q, int L, double* Y) {
     BitPlanes& bp = ctx->bp;
-    const int ND = ctx->opt.bp_digits == 3 ? 3 : 4;
-    const int NT = ND == 3 ? 4 : 5;
+    const int ND = bp_digits_now(ctx);
+    const int NT = (40 * ND + 31) / 32;                           // 32-wide tiles of the flattened (column, digit) index: 3 / 4 / 5
     v4i* qd = reinterpret_cast<v4i*>(bp.qd);
     double* cmaxQ = bp.cmax;
     double* cmaxY = bp.cmax + 64;
@@ -920,8 +934,7 @@ int bp_rows_product(ddx_ctx* ctx, const double* Q, int L, double* Y) {
         bp.qmax_zeroed = false;
         const int nslot = (NT * 32 + ND - 1) / ND;
         const int64_t nthreads = std::max<int64_t>(64, (int64_t)bp.SKc * kBpSteps * 2 * nslot);
-        if (ND == 3) k_bp_digits<3, false><<<(unsigned)ceil_div(nthreads, 256), 256, 0, ctx->stream>>>(Q, wq, ctx->H, L, NT, nslot, cmaxQ, bp.SKc, 0, 0, qd, cmaxY);
-        else k_bp_digits<4, false><<<(unsigned)ceil_div(nthreads, 256), 256, 0, ctx->stream>>>(Q, wq, ctx->H, L, NT, nslot, cmaxQ, bp.SKc, 0, 0, qd, cmaxY);
+        bp_launch_digits<false>(ND, (unsigned)ceil_div(nthreads, 256), ctx->stream, Q, wq, (int64_t)ctx->H, L, NT, nslot, (const double*)cmaxQ, (int64_t)bp.SKc, (int64_t)0, (int64_t)0, qd, cmaxY);
     }
     bp.ymax_of = nullptr;
     BpProductArgs a{};
@@ -935,8 +948,8 @@ int bp_rows_product(ddx_ctx* ctx, const double* Q, int L, double* Y) {
 // partial blocks of W1[j][:] = sum over the rows i of B[i][j] s_i Y[i][:]: *chunks blocks [H x L] float64 at *part, to be added by k_sum_panels
 int bp_cols_product(ddx_ctx* ctx, const double* Y, int L, const double** part, int* chunks_out) {
     BitPlanes& bp = ctx->bp;
-    const int ND = ctx->opt.bp_digits == 3 ? 3 : 4;
-    const int NT = ND == 3 ? 4 : 5;
+    const int ND = bp_digits_now(ctx);
+    const int NT = (40 * ND + 31) / 32;                           // 32-wide tiles of the flattened (column, digit) index: 3 / 4 / 5
     const int64_t SK = bp.SKr_used;
     int per = 1;
     const int chunks = bp_col_chunks(bp, SK, &per);
@@ -951,8 +964,7 @@ int bp_cols_product(ddx_ctx* ctx, const double* Y, int L, const double** part, i
         }
         const int nslot = (NT * 32 + ND - 1) / ND;
         const int64_t nthreads = std::max<int64_t>(64, SK * kBpSteps * 2 * nslot);
-        if (ND == 3) k_bp_digits<3, true><<<(unsigned)ceil_div(nthreads, 256), 256, 0, ctx->stream>>>(Y, bp.srow, ctx->M, L, NT, nslot, cmaxY, SK, bp.Npad, ctx->N, qd, cmaxQ);
-        else k_bp_digits<4, true><<<(unsigned)ceil_div(nthreads, 256), 256, 0, ctx->stream>>>(Y, bp.srow, ctx->M, L, NT, nslot, cmaxY, SK, bp.Npad, ctx->N, qd, cmaxQ);
+        bp_launch_digits<true>(ND, (unsigned)ceil_div(nthreads, 256), ctx->stream, Y, (const double*)bp.srow, (int64_t)ctx->M, L, NT, nslot, (const double*)cmaxY, (int64_t)SK, (int64_t)bp.Npad, (int64_t)ctx->N, qd, cmaxQ);
     }
     bp.ymax_of = nullptr;
     bp.qmax_zeroed = true;                                        // (zero_me of the digit kernel above)

@@ -2200,6 +2200,14 @@ int stage_pca(ddx_ctx* ctx, int32_t C, int32_t oversample, int32_t n_iter, const
         ctx->q0_rows = q0_rows;
         ctx->q0_cols = L;
     }
+    // Bit-plane products of the power iterations before the last one may carry fewer digits (option bp_digits_early): what such an iteration
+    // loses is a perturbation of the subspace the following iterations start from -- the last iteration and the projection, which
+    // decide the accuracy of the scores, run at full width.
+    struct EarlyDigits {
+        ddx_ctx* c;
+        ~EarlyDigits() { c->bp.nd_now = 0; }
+        void set(bool on) { c->bp.nd_now = (on && c->opt.bp_digits_early) ? c->opt.bp_digits_early : 0; }
+    } early{ctx};
     double* Qfinal;    // orthonormal basis (M x L normal branch, H x L transposed branch)
     double* Bt;        // projection on the other side (H x L normal, M x L transposed)
     int64_t RQ, RB;
@@ -2209,10 +2217,12 @@ int stage_pca(ddx_ctx* ctx, int32_t C, int32_t oversample, int32_t n_iter, const
         // subspace, and in float64 a single step of A^T A (condition (s1/s40)^2) loses nothing measurable
         // (scores agree with the LU-per-half-step evaluation to 1e-12)
         for (int it = 0; it < n_iter; ++it) {
+            early.set(it + 1 < n_iter);
             DDX_TRY(apply_rows(w, colA, rowA));
             DDX_TRY(apply_cols(w, rowA, colB));
             DDX_TRY(cholqr(w, colB, H, colA));
         }
+        early.set(false);
         DDX_TRY(apply_rows(w, colA, rowA));
         DDX_TRY(cholqr(w, rowA, M, rowB));
         DDX_TRY(cholqr(w, rowB, M, rowA));       // second pass: orthonormal to working precision
@@ -2222,10 +2232,12 @@ int stage_pca(ddx_ctx* ctx, int32_t C, int32_t oversample, int32_t n_iter, const
     } else {
         DDX_HIP(ctx, hipMemcpyAsync(rowA, ctx->pcaQ0.p, sizeof(double) * (size_t)M * L, hipMemcpyDeviceToDevice, ctx->stream));
         for (int it = 0; it < n_iter; ++it) {
+            early.set(it + 1 < n_iter);
             DDX_TRY(apply_cols(w, rowA, colA));
             DDX_TRY(apply_rows(w, colA, rowB));
             DDX_TRY(cholqr(w, rowB, M, rowA));
         }
+        early.set(false);
         DDX_TRY(apply_cols(w, rowA, colA));
         DDX_TRY(cholqr(w, colA, H, colB));
         DDX_TRY(cholqr(w, colB, H, colA));
