@@ -163,6 +163,13 @@ def kernel_models(N, G, H, S, nnz_aug, C, k, L=None, knn_window=1.0, bitplane=No
     if bp:
         nd = bp["digits"]
         nt32 = 4 if nd == 3 else 5                                # 32-wide tiles of the flattened (column, digit) index
+        if bp.get("format") == "mx6":
+            nd, nt32 = 6, 8                                       # six base-31 digits in FP6 (priced against the same int8 peak: option bp_format)
+        elif bp.get("digits_early"):
+            # sklearn's 7 power iterations + the projection = 16 products, 12 of them on the early digit count: a launch's average
+            ne = bp["digits_early"]
+            nd = (12 * ne + 4 * nd) / 16.0
+            nt32 = (12 * (4 if ne == 3 else 3 if ne == 2 else 5) + 4 * nt32) / 16.0
         m_pad = -(-N // 256) * 256 + -(-S // 64) * 64             # rows the kernels touch (originals padded to 256, synthetic rows to 64)
         h_pad, k_rows = -(-H // 256) * 256, -(-N // 256) * 256 + -(-S // 256) * 256
         models["bitplane_rows"] = ("mfma", "TOP/s", 2.0 * M * H * L * nd / 1e12, I8_PEAK_TOPS)

@@ -730,7 +730,7 @@ class Context:
         out = np.zeros(8, dtype=np.int64)
         self._c(self._lib.ddx_get_bitplane_stats(self._h, _p(out, c_i64_p)))
         return {"active": bool(out[0]), "rest_original": int(out[1]), "rest_synthetic": int(out[2]), "digits": int(out[3]),
-                "scaled": bool(out[4]), "demoted_columns": int(out[5])}
+                "scaled": bool(out[4]), "demoted_columns": int(out[5]), "format": "mx6" if out[6] else "int8", "digits_early": int(out[7])}
 
     def knn_candidate_counts(self) -> np.ndarray:
         out = np.empty(self._embM, dtype=np.int32)

@@ -203,6 +203,9 @@ bool Options::set(const char* key, const char* value) {
     if (k == "residual_rows_own") { if (!num(6, 12, &x) || (x != 6 && x != 12)) return false; residual_rows_own = (int)x; return true; }
     if (k == "synthetic") { if (v == "derived") synthetic_derived = true; else if (v == "merged") synthetic_derived = false; else return false; return true; }
     if (k == "bp_digits") { if (!num(3, 4, &x)) return false; bp_digits = (int)x; return true; }
+    if (k == "bp_format") { if (v == "mx6") bp_mx = true; else if (v == "int8") bp_mx = false; else return false; return true; }
+    if (k == "bp_dbg_mode") { if (!num(0, 15, &x)) return false; bp_dbg_mode = (int)x; return true; }
+    if (k == "bp_dbg_sk") { if (!num(0, 1 << 20, &x)) return false; bp_dbg_sk = (int)x; return true; }
     if (k == "bp_digits_early") { if (!num(0, 4, &x) || x == 1) return false; bp_digits_early = (int)x; return true; }
     if (k == "knn_fold") { knn_fold = on(); return true; }
     if (k == "knn_xcd_chunk") { if (!num(0, 4096, &x)) return false; knn_xcd_chunk = (int)x; return true; }
@@ -1567,7 +1570,10 @@ int ddx_get_bitplane_stats(ddx_ctx* ctx, int64_t* out) {
     out[3] = ctx->opt.bp_digits == 3 ? 3 : 4;
     out[4] = (on && ctx->bp.scaled) ? 1 : 0;
     out[5] = ctx->bp.ready ? ctx->bp.n_demoted : 0;
-    out[6] = out[7] = 0;
+    out[6] = ctx->opt.bp_mx ? 1 : 0;
+    // digits of the power iterations before the last one (stage_pca's rule; 0: the same as out[3])
+    const int early = ctx->opt.bp_digits_early;
+    out[7] = (early && early < out[3] && !ctx->opt.bp_mx) ? early : 0;
     return DDX_OK;
 }
 

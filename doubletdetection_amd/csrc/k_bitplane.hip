@@ -404,6 +404,7 @@ struct BpProductArgs {
     // COLS (A^T Y): output row = tile * 32 + r < nOut; out[(chunk * nOut + row)][c] = value
     int64_t nOut;
     double* out;
+    int dbg;                  // timing experiments (option bp_dbg_mode; wrong results): 1 no digit copies inside the loop, 2 no bitmap copies, 4 no matrix instructions
 };
 
 // S = B . digits for RT tiles of 32 bitmap rows per wave, over the stages of this workgroup's chunk; see the file header.
@@ -543,12 +544,268 @@ __global__ void __launch_bounds__(64 * kBpWaves) k_bp_product(const BpProductArg
     }
 }
 
+// ---- the same products on the MX matrix instruction of gfx950 (round 6) -----------------------------------------------------------
+// v_mfma_f32_32x32x64_f8f6f4 takes 4-bit and 6-bit floating-point operands at twice the int8 rate on paper and, measured under random digits,
+// at 2.6 x the rate the power-bound int8 kernel reaches (profiles/tools/mfma_fp6_probe.hip: 3.6 against 1.36 P MAC/s).  Its small floats
+// hold small integers EXACTLY:
+//   * the bitmap is the A operand in FP4 (E2M1): bit 0 -> code 0 = 0, bit 1 -> code 1 = 0.5;
+//   * the operand is cut into SIX balanced digits of base 31, d in [-15, 15], the B operand in FP6 (E2M3): the code |d| | sign << 5 is
+//     the value d / 8 (subnormals k / 8 for k < 8, then 1 + m / 8) -- 31^6 / 2 = 2^28.7 levels below the column's largest element
+//     (four int8 digits: 2^30, three: 2^22);
+//   * products 0.5 x d / 8 and their float32 sums are multiples of 1 / 16 below 2^24 / 16 (|sum| <= 15 K / 16, K <= 2^20 per chunk):
+//     exact in any order; the epilogue reads them back as integers and recombines V = sum_d 31^d S_d in float64 (< 2^53), as the int8 form does.
+// Geometry: 40 columns x 6 digits are split into four quarters of 10 columns = 60 of 64 flattened columns = two 32-wide tiles; a wave owns
+// 4 row tiles x the 2 tiles of one quarter (128 accumulator registers, two waves per SIMD) -- every operand fragment read from LDS feeds four
+// matrix instructions (two would leave the LDS as busy as the matrix pipe); a workgroup of 8 waves = 2 row groups x 4 quarters = 256 rows.
+// A stage of 256 k values is four k-steps of 64; its operand fragments (24 bytes per lane and tile: 16 + 8, so that every LDS read is
+// aligned) are 48 KB, three stages 144 KB; the workgroup's 8 KB of bitmap per stage go through LDS as well (a ring of two: 160 KB in all)
+// so that the loop holds no ordinary global load -- the compiler answers one with s_waitcnt vmcnt(0), which would drain the copies in flight.
+// Inside a k-step's 32 values per lane half the order is permuted (kF6Perm): the A operand's nibble pairs are then picked by selectors
+// (w >> 2 j) & 0x03030303 -- three instructions per eight bits.
+typedef int v2i __attribute__((ext_vector_type(2)));
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+constexpr int kF6Digits = 6;
+constexpr int kF6Quarter = 10;                                 // sketch columns per quarter
+constexpr int kF6Steps = 4;                                    // k-steps of 64 per stage
+constexpr int kF6StepBytes = 8 * 1024 + 8 * 512;               // per k-step: eight tiles x (64 lanes x 16 bytes) | eight tiles x (64 lanes x 8 bytes)
+constexpr int kF6StageBytes = kF6Steps * kF6StepBytes;         // 48 KB
+constexpr int kF6StagePieces = kF6StageBytes / 1024;           // wave-wide 1 KB copies per stage
+constexpr int kF6BitsBytes = kBpWaves * 1024;                  // the workgroup's eight (tile, stage) KB of bitmap
+constexpr int kF6Lds = kBpStages * kF6StageBytes + 2 * kF6BitsBytes;
+constexpr double kF6Lim = 443751840.0;                         // (31^6 - 1) / 2: the largest magnitude six balanced digits hold
+constexpr double kF6Scale = kF6Lim * (1.0 - 1.0 / 1048576.0);  // what the column's largest element is scaled to
+// element e of a lane's 32 (nibble e of the A operand, field e of the B operand) is bit kF6Perm(e) of the bitmap word
+__host__ __device__ constexpr int kF6Perm(int e) { return 8 * ((e >> 1) & 3) + 2 * (e >> 3) + (e & 1); }
+
+// operand -> digits in the B-operand layout: lane (h, n) of tile nt holds, for k-step s of stage sk, the 32 six-bit codes of
+// k = sk * 256 + h * 128 + s * 32 + kF6Perm(e) and flattened column nt * 32 + n = quarter * 64 + (column % 10) * 6 + digit.
+// One workgroup per stage: thread (s, h, column) cuts 32 operand values into 6 fragments of 24 bytes inside an LDS image of the stage,
+// which then leaves in full lines.
+template <bool ROWMAP>
+__global__ void __launch_bounds__(320) k_bp_digits6(const double* __restrict__ X, const double* __restrict__ wgt, int64_t R, int L, const double* __restrict__ cmax,
+                                                    int64_t Npad, int64_t N, unsigned char* __restrict__ qd, double* __restrict__ zero_me) {
+    extern __shared__ __align__(16) unsigned char d6_img[];            // [kF6StageBytes]
+    const int64_t sk = blockIdx.x;
+    const int tid = threadIdx.x;
+    if (zero_me && sk == 0 && tid < 64) zero_me[tid] = 0.0;
+    for (int i = tid; i < kF6StageBytes / 16; i += 320) reinterpret_cast<v4i*>(d6_img)[i] = v4i{0, 0, 0, 0};      // (padding columns, columns past L)
+    __syncthreads();
+    const int col = tid % 40, sh = tid / 40, h = sh & 1, s = sh >> 1;
+    if (col < L) {
+        unsigned out[kF6Digits][6] = {};
+        const double cm = cmax[col];
+        const double scale = (cm > 0.0 && cm < 1e300) ? kF6Scale / cm : 0.0;
+#pragma unroll
+        for (int e = 0; e < 32; ++e) {
+            const int64_t k = sk * kBpStageCols + h * 128 + s * 32 + kF6Perm(e);
+            const int64_t row = ROWMAP ? bp_row_of(k, Npad, N, R) : (k < R ? k : -1);
+            unsigned u = (unsigned)kF6Lim;                               // (the digits of zero)
+            if (row >= 0) {
+                const double x = wgt ? wgt[row] * X[row * L + col] : X[row * L + col];
+                const double q = rint(x * scale);
+                // (a column maximum collected by another kernel may differ from |x| here in the last bits: the scale keeps 2^-20 of
+                //  headroom and the end of the range clamps; non-finite operands: zero, caught by the rank check upstream)
+                if (fabs(q) < 1e300) u = (unsigned)((int)fmin(fmax(q, -kF6Lim), kF6Lim) + (int)kF6Lim);
+            }
+            // v + lim = sum_d (digit_d + 15) 31^d: the balanced digits are the base-31 digits of the shifted value, less 15 each
+#pragma unroll
+            for (int d = 0; d < kF6Digits; ++d) {
+                const unsigned qv = u / 31u;
+                const int dg = (int)(u - 31u * qv) - 15;
+                u = qv;
+                const unsigned code = dg < 0 ? (32u | (unsigned)(-dg)) : (unsigned)dg;
+                const int bit0 = 6 * e;
+                out[d][bit0 >> 5] |= code << (bit0 & 31);
+                if ((bit0 & 31) > 26) out[d][(bit0 >> 5) + 1] |= code >> (32 - (bit0 & 31));
+            }
+        }
+        unsigned char* base = d6_img + s * kF6StepBytes;
+        const int quarter = col / kF6Quarter, cl = col - quarter * kF6Quarter;
+#pragma unroll
+        for (int d = 0; d < kF6Digits; ++d) {
+            const int f = cl * kF6Digits + d;
+            const int nt = quarter * 2 + (f >> 5), lane = h * 32 + (f & 31);
+            *reinterpret_cast<v4i*>(base + nt * 1024 + lane * 16) = v4i{(int)out[d][0], (int)out[d][1], (int)out[d][2], (int)out[d][3]};
+            *reinterpret_cast<v2i*>(base + 8 * 1024 + nt * 512 + lane * 8) = v2i{(int)out[d][4], (int)out[d][5]};
+        }
+    }
+    __syncthreads();
+    v4i* dst = reinterpret_cast<v4i*>(qd + sk * (int64_t)kF6StageBytes);
+    for (int i = tid; i < kF6StageBytes / 16; i += 320) dst[i] = reinterpret_cast<const v4i*>(d6_img)[i];
+}
+
+// 32 bits (in the permuted order) -> 32 FP4 codes, 0 or 1 = 0.5: byte m of the selector (w >> 2 j) & 0x03030303 holds the bits of
+// nibbles 2 m and 2 m + 1 of word j and picks the byte 0x00 / 0x01 / 0x10 / 0x11
+__device__ __forceinline__ v8i bp_expand_fp4(unsigned w) {
+    v8i r = {};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[j] = (int)__builtin_amdgcn_perm(0x11100100u, 0x11100100u, (w >> (2 * j)) & 0x03030303u);
+    return r;
+}
+
+template <bool ROWS, int DBG = 0>
+__global__ void __launch_bounds__(64 * kBpWaves) k_bp_product6(const BpProductArgs a) {
+    constexpr int RT = 4, NTW = 2;
+    constexpr int kPer = kF6StagePieces / kBpWaves;               // 1 KB copies of digits per wave and stage (+ one of bitmap)
+    static_assert(kF6StagePieces % kBpWaves == 0, "");
+    extern __shared__ __align__(16) unsigned char bp_smem[];
+    unsigned char* const bits_ring = bp_smem + kBpStages * kF6StageBytes;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, quarter = wave & 3;
+    const int64_t wg_tile0 = (int64_t)blockIdx.x * kBpWaves;      // the workgroup's eight row tiles: two groups of four
+    const int64_t tile0 = wg_tile0 + grp * RT;
+    const int chunk = blockIdx.y;
+    const int sk0 = chunk * a.sk_per_chunk;
+    const int sk1 = sk0 + a.sk_per_chunk < a.SK ? sk0 + a.sk_per_chunk : a.SK;
+    v16f acc[RT][NTW];
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int c = 0; c < NTW; ++c)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][c][i] = 0.f;
+    const unsigned char* qd = reinterpret_cast<const unsigned char*>(a.qd);
+    // this wave copies the bitmap KB of the workgroup's tile number `wave` (a tile past the end re-reads the last one: its rows are not stored)
+    const v4i* my_bm = a.bm + (wg_tile0 + wave < a.ntile ? wg_tile0 + wave : a.ntile - 1) * a.SKstride * 64 + lane;
+    auto stage = [&](int sk, int st) {                           // (a stage past the end re-reads the last one: harmless, same count)
+        const int k = sk < sk1 ? sk : sk1 - 1;
+#pragma unroll
+        for (int u = 0; u < kPer; ++u) {
+            const int piece = u * kBpWaves + wave;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qd + (int64_t)k * kF6StageBytes + piece * 1024 + lane * 16),
+                                             (__attribute__((address_space(3))) void*)(bp_smem + st * kF6StageBytes + piece * 1024), 16, 0, 0);
+        }
+    };
+    auto bits = [&](int sk, int st) {
+        const int k = sk < sk1 ? sk : sk1 - 1;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(my_bm + (int64_t)k * 64),
+                                         (__attribute__((address_space(3))) void*)(bits_ring + st * kF6BitsBytes + wave * 1024), 16, 0, 0);
+    };
+    stage(sk0, 0);
+    bits(sk0, 0);
+    stage(sk0 + 1, 1);
+    const int word_off = ((lane & 31) * 2 + (lane >> 5)) * 16;   // lane (h, r) reads word r * 2 + h of a tile's KB
+#pragma unroll 1
+    for (int sk = sk0; sk < sk1; ++sk) {
+        const int it = sk - sk0;
+        // stage sk's digits and bitmap have landed once only the newest stage's copies are in flight (a wave's copies complete in issue
+        // order); everybody is done with the buffers about to be refilled.  A bare barrier: __syncthreads() would wait for every copy.
+        if constexpr (DBG != 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(kPer) : "memory");
+        if constexpr (!(DBG & 2)) bits(sk + 1, (it + 1) & 1);
+        if constexpr (!(DBG & 1)) stage(sk + 2, (it + 2) % kBpStages);
+        v4i w0[RT];
+#pragma unroll
+        for (int t = 0; t < RT; ++t) w0[t] = *reinterpret_cast<const v4i*>(bits_ring + (it & 1) * kF6BitsBytes + (grp * RT + t) * 1024 + word_off);
+        const unsigned char* cur = bp_smem + (it % kBpStages) * kF6StageBytes + (quarter * NTW) * 1024 + lane * 16;
+        const unsigned char* cur8 = bp_smem + (it % kBpStages) * kF6StageBytes + 8 * 1024 + (quarter * NTW) * 512 + lane * 8;
+        constexpr int PF = 2, NG = kF6Steps * NTW;
+        v4i bq[PF + 1];
+        v2i bq8[PF + 1];
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            bq[p] = *reinterpret_cast<const v4i*>(cur + (p / NTW) * kF6StepBytes + (p % NTW) * 1024);
+            bq8[p] = *reinterpret_cast<const v2i*>(cur8 + (p / NTW) * kF6StepBytes + (p % NTW) * 512);
+        }
+        v8i av[RT], an[RT];
+#pragma unroll
+        for (int t = 0; t < RT; ++t) { av[t] = bp_expand_fp4((unsigned)w0[t][0]); an[t] = v8i{}; }
+        // Every matrix instruction is followed by its share of the NEXT k-step's bit expansion (half a tile: six vector instructions) and the
+        // order is pinned: a wave then keeps the matrix pipe busy by itself -- the 32 cycles an instruction occupies it cover the 24 of the
+        // vector work behind it.  Left to the scheduler the expansions of a step came in one burst of 44 in front of its eight matrix
+        // instructions, the two waves of a SIMD (in step after every barrier) burst together, and vector and matrix time added up
+        // (profiles/tools/mx_ablation.py: 1.8 us per stage for 0.6 + 1.0).
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi) {
+            const int s = gi / NTW, c = gi % NTW;
+            if (gi + PF < NG) {
+                const int g2 = gi + PF;
+                bq[g2 % (PF + 1)] = *reinterpret_cast<const v4i*>(cur + (g2 / NTW) * kF6StepBytes + (g2 % NTW) * 1024);
+                bq8[g2 % (PF + 1)] = *reinterpret_cast<const v2i*>(cur8 + (g2 / NTW) * kF6StepBytes + (g2 % NTW) * 512);
+            }
+            const v4i b4 = bq[gi % (PF + 1)];
+            const v2i b2 = bq8[gi % (PF + 1)];
+            const v8i b = v8i{b4[0], b4[1], b4[2], b4[3], b2[0], b2[1], 0, 0};
+#pragma unroll
+            for (int t = 0; t < RT; ++t) {
+                if constexpr (!(DBG & 4)) acc[t][c] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av[t], b, acc[t][c], 4, 2, 0, 0, 0, 0);
+                else acc[t][c][0] += (float)(av[t][0] ^ av[t][3] ^ b[0] ^ b[5]);
+                if (s + 1 < kF6Steps) {
+                    // half of tile (c * 2 + t / 2)'s next fragment: words 2 (t & 1) and 2 (t & 1) + 1
+                    const int tile = c * (RT / NTW) + (t >> 1), j0 = 2 * (t & 1);
+                    const unsigned w = (unsigned)w0[tile][s + 1];
+                    an[tile][j0] = (int)__builtin_amdgcn_perm(0x11100100u, 0x11100100u, (w >> (2 * j0)) & 0x03030303u);
+                    an[tile][j0 + 1] = (int)__builtin_amdgcn_perm(0x11100100u, 0x11100100u, (w >> (2 * j0 + 2)) & 0x03030303u);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (c == NTW - 1) {
+#pragma unroll
+                for (int t = 0; t < RT; ++t) av[t] = an[t];
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // (the copies issued past the end); the stage buffers become the epilogue's scratch
+    // Epilogue: as k_bp_product's (same C/D layout), per quarter: 8 rows x 10 columns per band, six digits of base 31 each
+    constexpr int F = NTW * 32, FS = F + 4;
+    int32_t* scr = reinterpret_cast<int32_t*>(bp_smem) + wave * (8 * FS);
+    const int n = lane & 31, hh = lane >> 5;
+    constexpr int kOutPerLane = (8 * kF6Quarter + 63) / 64;
+    double myscale[kOutPerLane];
+#pragma unroll
+    for (int i = 0; i < kOutPerLane; ++i) {
+        const int o = lane + 64 * i;
+        const int col = quarter * kF6Quarter + o % kF6Quarter;
+        const double cm = (o < 8 * kF6Quarter && col < a.L) ? a.cmax[col] : 0.0;
+        myscale[i] = (cm > 0.0 && cm < 1e300) ? cm / kF6Scale : 0.0;
+    }
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+        const int64_t tile = tile0 + t;
+        if (tile >= a.ntile) continue;                            // (wave-uniform)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+#pragma unroll
+            for (int c = 0; c < NTW; ++c)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) scr[(hh * 4 + q) * FS + c * 32 + n] = (int32_t)(acc[t][c][b * 4 + q] * 16.f);     // exact: a multiple of 1 / 16
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < kOutPerLane; ++i) {
+                const int o = lane + 64 * i;
+                if (o >= 8 * kF6Quarter) break;
+                const int rr = o / kF6Quarter, cl = o - rr * kF6Quarter;
+                const int col = quarter * kF6Quarter + cl;
+                if (col >= a.L) continue;
+                const int32_t* dp = scr + rr * FS + cl * kF6Digits;
+                double V = (double)dp[kF6Digits - 1];
+#pragma unroll
+                for (int d = kF6Digits - 2; d >= 0; --d) V = V * 31.0 + (double)dp[d];          // exact: integers below 2^53
+                const double val = V * myscale[i];
+                const int64_t pr = tile * 32 + b * 8 + rr;
+                if (ROWS) {
+                    const int64_t row = bp_row_of(pr, a.Npad, a.N, a.M);
+                    if (row >= 0) a.out[row * a.L + col] = a.srow[row] * val;
+                } else if (pr < a.nOut) {
+                    a.out[((int64_t)chunk * a.nOut + pr) * a.L + col] = val;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 static size_t bp_align(size_t v) { return (v + 255) & ~(size_t)255; }
 static int bp_workspace(ddx_ctx* ctx);
-static int bp_col_chunks(const BitPlanes& bp, int64_t SK, int* per_out);
+static int bp_col_chunks(const BitPlanes& bp, int64_t SK, int* per_out, int tiles_per_wg = kBpWaves * 2);
 struct BpProductArgs;
 template <int RT, int NT, int ND, bool ROWS> static int bp_launch_t(ddx_ctx* ctx, const BpProductArgs& a, int chunks);
 
@@ -839,8 +1096,8 @@ int bp_refresh(ddx_ctx* ctx) {
 }
 
 // chunks of the k dimension of the A^T Y product (the padded rows): enough workgroups for a whole round of the GPU
-static int bp_col_chunks(const BitPlanes& bp, int64_t SK, int* per_out) {
-    const int64_t wgcols = ceil_div(bp.ntile_c, kBpWaves * 2);
+static int bp_col_chunks(const BitPlanes& bp, int64_t SK, int* per_out, int tiles_per_wg) {
+    const int64_t wgcols = ceil_div(bp.ntile_c, tiles_per_wg);
     int chunks = (int)std::max<int64_t>(1, std::min<int64_t>(SK, 256 / std::max<int64_t>(1, wgcols)));
     const int per = (int)ceil_div(SK, chunks);
     if (per_out) *per_out = per;
@@ -851,7 +1108,7 @@ static int bp_col_chunks(const BitPlanes& bp, int64_t SK, int* per_out) {
 static int bp_workspace(ddx_ctx* ctx) {
     BitPlanes& bp = ctx->bp;
     const int64_t SKmax = std::max<int64_t>(bp.SKc, bp.SKr_cap);
-    const size_t dig = bp_align(sizeof(v4i) * (size_t)SKmax * kBpSteps * 5 * 64);
+    const size_t dig = bp_align(std::max(sizeof(v4i) * (size_t)SKmax * kBpSteps * 5 * 64, (size_t)SKmax * kF6StageBytes));
     // (the chunk count of a product follows from the stages IN USE, ceil(SK / ceil(SK / c)) <= c with c the bound below -- which the count
     // for the capacity does not bound: 8192 cells x 6000 genes cut 40 used stages into 20 chunks, 49 stages of capacity into 17)
     const int chunks = (int)std::max<int64_t>(1, std::min<int64_t>(bp.SKr_cap, 256 / std::max<int64_t>(1, ceil_div(bp.ntile_c, kBpWaves * 2))));
@@ -871,6 +1128,14 @@ static int bp_workspace(ddx_ctx* ctx) {
     return DDX_OK;
 }
 
+// option bp_dbg_sk (timing only): every chunk stops after that many stages
+static BpProductArgs bp_dbg_args(const ddx_ctx* ctx, const BpProductArgs& a, int chunks) {
+    BpProductArgs b = a;
+    if (ctx->opt.bp_dbg_sk > 0 && ctx->opt.bp_dbg_sk < a.sk_per_chunk) { b.sk_per_chunk = ctx->opt.bp_dbg_sk; b.SK = std::min(a.SK, chunks * b.sk_per_chunk); }
+    b.dbg = ctx->opt.bp_dbg_mode;
+    return b;
+}
+
 template <int RT, int NT, int ND, bool ROWS>
 static int bp_launch_t(ddx_ctx* ctx, const BpProductArgs& a, int chunks) {
     const size_t lds = (size_t)kBpStages * kBpSteps * NT * 64 * 16;
@@ -881,10 +1146,43 @@ static int bp_launch_t(ddx_ctx* ctx, const BpProductArgs& a, int chunks) {
 }
 
 template <bool ROWS>
-static int bp_launch(ddx_ctx* ctx, const BpProductArgs& a, int chunks, int ND, int RT) {
+static int bp_launch(ddx_ctx* ctx, const BpProductArgs& a0, int chunks, int ND, int RT) {
+    const BpProductArgs a = bp_dbg_args(ctx, a0, chunks);
     if (ND == 2) return RT == 1 ? bp_launch_t<1, 3, 2, ROWS>(ctx, a, chunks) : bp_launch_t<2, 3, 2, ROWS>(ctx, a, chunks);
     if (ND == 3) return RT == 1 ? bp_launch_t<1, 4, 3, ROWS>(ctx, a, chunks) : bp_launch_t<2, 4, 3, ROWS>(ctx, a, chunks);
     return RT == 1 ? bp_launch_t<1, 5, 4, ROWS>(ctx, a, chunks) : bp_launch_t<2, 5, 4, ROWS>(ctx, a, chunks);
+}
+
+template <bool ROWS>
+static int bp_launch6(ddx_ctx* ctx, const BpProductArgs& a0, int chunks) {
+    const BpProductArgs a = bp_dbg_args(ctx, a0, chunks);
+    const size_t lds = (size_t)kF6Lds;
+    const dim3 grid((unsigned)ceil_div(a.ntile, kBpWaves), (unsigned)chunks);      // (2 row groups x 4 tiles per workgroup)
+    auto go = [&](auto tag) -> int {
+        constexpr int DBG = decltype(tag)::value;
+        DDX_TRY(allow_dynamic_lds(ctx, reinterpret_cast<const void*>(&k_bp_product6<ROWS, DBG>), (int)lds));
+        k_bp_product6<ROWS, DBG><<<grid, 64 * kBpWaves, lds, ctx->stream>>>(a);
+        return DDX_OK;
+    };
+    switch (a.dbg) {                                              // (timing experiments: profiles/tools/mx_ablation.py)
+        case 1: return go(std::integral_constant<int, 1>());
+        case 2: return go(std::integral_constant<int, 2>());
+        case 3: return go(std::integral_constant<int, 3>());
+        case 4: return go(std::integral_constant<int, 4>());
+        case 7: return go(std::integral_constant<int, 7>());
+        case 8: return go(std::integral_constant<int, 8>());
+        default: return go(std::integral_constant<int, 0>());
+    }
+}
+
+// the products of sketches up to 40 columns wide run on the MX instruction unless option bp_format says int8
+static bool bp_use_mx(const ddx_ctx* ctx, int L) { return ctx->opt.bp_mx && L <= 4 * kF6Quarter; }
+
+template <bool ROWMAP>
+static int bp_launch_digits6(ddx_ctx* ctx, const double* X, const double* wgt, int64_t R, int L, const double* cmax, int64_t SK, int64_t Npad, int64_t N, void* qd, double* zero_me) {
+    DDX_TRY(allow_dynamic_lds(ctx, reinterpret_cast<const void*>(&k_bp_digits6<ROWMAP>), kF6StageBytes));
+    k_bp_digits6<ROWMAP><<<(unsigned)SK, 320, kF6StageBytes, ctx->stream>>>(X, wgt, R, L, cmax, Npad, N, reinterpret_cast<unsigned char*>(qd), zero_me);
+    return DDX_OK;
 }
 
 // tiles per wave: the geometry that fills the GPU's 256 compute units better over whole rounds of workgroups
@@ -917,6 +1215,7 @@ static void bp_launch_digits(int ND, unsigned grid, hipStream_t st, Args... args
 // and, through *ymax, collects the column maxima of diag(s) Y that the A^T Y product will cut its digits by)
 int bp_rows_product(ddx_ctx* ctx, const double* Q, int L, double* Y) {
     BitPlanes& bp = ctx->bp;
+    const bool mx = bp_use_mx(ctx, L);
     const int ND = bp_digits_now(ctx);
     const int NT = (40 * ND + 31) / 32;                           // 32-wide tiles of the flattened (column, digit) index: 3 / 4 / 5
     v4i* qd = reinterpret_cast<v4i*>(bp.qd);
@@ -934,6 +1233,9 @@ int bp_rows_product(ddx_ctx* ctx, const double* Q, int L, double* Y) {
         bp.qmax_zeroed = false;
         const int nslot = (NT * 32 + ND - 1) / ND;
         const int64_t nthreads = std::max<int64_t>(64, (int64_t)bp.SKc * kBpSteps * 2 * nslot);
+        if (mx) {
+            DDX_TRY(bp_launch_digits6<false>(ctx, Q, wq, ctx->H, L, cmaxQ, bp.SKc, 0, 0, bp.qd, cmaxY));
+        } else
         bp_launch_digits<false>(ND, (unsigned)ceil_div(nthreads, 256), ctx->stream, Q, wq, (int64_t)ctx->H, L, NT, nslot, (const double*)cmaxQ, (int64_t)bp.SKc, (int64_t)0, (int64_t)0, qd, cmaxY);
     }
     bp.ymax_of = nullptr;
@@ -942,17 +1244,19 @@ int bp_rows_product(ddx_ctx* ctx, const double* Q, int L, double* Y) {
     a.cmax = cmaxQ;
     a.srow = bp.srow; a.Npad = bp.Npad; a.N = ctx->N; a.M = ctx->M; a.nOut = ctx->M; a.out = Y;
     ScopedTimer t(ctx, "bitplane_rows");
+    if (mx) return bp_launch6<true>(ctx, a, 1);
     return bp_launch<true>(ctx, a, 1, ND, bp_pick_rt(a.ntile, 1));
 }
 
 // partial blocks of W1[j][:] = sum over the rows i of B[i][j] s_i Y[i][:]: *chunks blocks [H x L] float64 at *part, to be added by k_sum_panels
 int bp_cols_product(ddx_ctx* ctx, const double* Y, int L, const double** part, int* chunks_out) {
     BitPlanes& bp = ctx->bp;
+    const bool mx = bp_use_mx(ctx, L);
     const int ND = bp_digits_now(ctx);
     const int NT = (40 * ND + 31) / 32;                           // 32-wide tiles of the flattened (column, digit) index: 3 / 4 / 5
     const int64_t SK = bp.SKr_used;
     int per = 1;
-    const int chunks = bp_col_chunks(bp, SK, &per);
+    const int chunks = bp_col_chunks(bp, SK, &per, mx ? kBpWaves : kBpWaves * 2);
     v4i* qd = reinterpret_cast<v4i*>(bp.qd);
     double* cmaxQ = bp.cmax;
     double* cmaxY = bp.cmax + 64;
@@ -964,6 +1268,9 @@ int bp_cols_product(ddx_ctx* ctx, const double* Y, int L, const double** part, i
         }
         const int nslot = (NT * 32 + ND - 1) / ND;
         const int64_t nthreads = std::max<int64_t>(64, SK * kBpSteps * 2 * nslot);
+        if (mx) {
+            DDX_TRY(bp_launch_digits6<true>(ctx, Y, bp.srow, ctx->M, L, cmaxY, SK, bp.Npad, ctx->N, bp.qd, cmaxQ));
+        } else
         bp_launch_digits<true>(ND, (unsigned)ceil_div(nthreads, 256), ctx->stream, Y, (const double*)bp.srow, (int64_t)ctx->M, L, NT, nslot, (const double*)cmaxY, (int64_t)SK, (int64_t)bp.Npad, (int64_t)ctx->N, qd, cmaxQ);
     }
     bp.ymax_of = nullptr;
@@ -974,7 +1281,8 @@ int bp_cols_product(ddx_ctx* ctx, const double* Y, int L, const double** part, i
     a.cmax = cmaxY; a.nOut = ctx->H; a.out = bp.part;
     // (the bitmap's stage stride is the capacity SKr; the stages in use are [0, SKr_used): the chunks cover only those)
     ScopedTimer t(ctx, "bitplane_cols");
-    DDX_TRY(bp_launch<false>(ctx, a, chunks, ND, 2));
+    if (mx) DDX_TRY(bp_launch6<false>(ctx, a, chunks));
+    else DDX_TRY(bp_launch<false>(ctx, a, chunks, ND, 2));
     *part = bp.part;
     *chunks_out = chunks;
     return DDX_OK;

@@ -71,6 +71,19 @@ int ddx_synchronize(ddx_ctx* ctx);
  *   bp_digits         4 | 3             8-bit digits of the operand's fixed point in the bit-plane products (4: 30 bits below the
  *                                       column's largest element -- default, PCA scores within 4e-7 of the float64 oracle at the
  *                                       BASELINE sizes; 3: 22 bits, a fifth fewer matrix instructions, 4e-6)
+ *   bp_digits_early   0 | 2 | 3 | 4     digits in the power iterations of the randomized PCA BEFORE the last one (the last iteration and the
+ *                                       projection always run on bp_digits).  0 (default): as bp_digits.  3: fits 4 % shorter (-4.5 ms at the
+ *                                       headline) and PCA scores 2.3e-6 instead of 3.7e-7 from the float64 oracle at configs[1] -- inside the
+ *                                       tests' 1e-5 bar there, NOT at configs[4]'s scaled shape (2.8e-5), with a 60-column sketch (1.7e-5), nor
+ *                                       for the whole-fit comparison at 8192 cells (0.65 % of the community labels differ from the float64
+ *                                       oracle's): measured and left off.  2: 8e-4, experiments only
+ *   bp_format         int8 | mx6        int8 (default): 8-bit digits on v_mfma_i32_32x32x32_i8.  mx6: the same products on the MX instruction
+ *                                       v_mfma_f32_32x32x64_f8f6f4 -- bitmap as FP4, six balanced base-31 digits as FP6 (28.7 bits), float32 sums
+ *                                       of exact multiples of 1/16 -- equally exact (4.2e-7), 2.6 x the int8 MAC rate in isolation
+ *                                       (profiles/tools/mfma_fp6_probe.hip), but as a kernel no faster than int8 (bit expansion + operand
+ *                                       traffic, profiles/r06_mx_notes.txt): kept as a tested alternative
+ *   bp_dbg_sk, bp_dbg_mode              TIMING ONLY, wrong results: stages per chunk / parts of the MX kernel's loop taken out
+ *                                       (profiles/tools/mx_stage_sweep.py, mx_ablation.py)
  *   mirror            tiles | scatter | sort   how the column-major mirror is built (default tiles; the others are its references)
  *   upload            auto | plain | packed | packed32   transfer form of ddx_upload_raw (auto: 2-byte form once the pinned
  *                                       buffer exists, plain until then; packed / packed32 wait for the buffer)

@@ -185,7 +185,7 @@ def test_operator_product_variants_agree_at_full_size(data, staged, monkeypatch)
     M, H, C = ctx.M, ctx.H, 30
     q0 = np.random.RandomState(0).normal(size=(H, C + 10)).astype(np.float32).astype(np.float64)
     ctx.pca(C, q0)
-    emb_bp, sing_bp = ctx.embedding_f64()           # the default: bit planes, four digits
+    emb_bp, sing_bp = ctx.embedding_f64()           # the default: bit planes, four int8 digits
 
     def other(env):
         for k, v in env.items():
@@ -237,9 +237,15 @@ def test_operator_product_variants_agree_at_full_size(data, staged, monkeypatch)
     print(f"against the float64-gather run: bit planes 4 digits {d4:.2e}, 3 digits {d3:.2e}, float32 operand copies {d_lds:.2e}")
     np.testing.assert_allclose(sing_bp, sing_f, rtol=1e-8)
     assert d4 < 2e-6 and d3 < 1e-5, (d4, d3)
-    # fewer digits in the power iterations before the last one only (option bp_digits_early): the last iteration and the projection
-    # keep four.  What an early iteration loses perturbs the start of the next ones: the signal components forget it, the
-    # unconverged trailing ones carry it to the end
+    # fewer digits in the power iterations before the last one only (option bp_digits_early, off by default): the last iteration and the
+    # projection keep four.  What an early iteration loses perturbs the start of the next ones: the signal components forget it, the
+    # unconverged trailing ones carry it to the end -- inside the bar here, but not everywhere (include/ddx.h): measured, left off
+    # the same products on the MX matrix instruction (option bp_format=mx6: FP4 bitmap x six base-31 digits in FP6 = 28.7 bits; exact sums)
+    emb_mx, sing_mx = other({"bp_format": "mx6"})
+    d_mx = rel_dev(emb_mx, emb_f)
+    print(f"against the float64-gather run: default (int8, four digits) {d4:.2e}, MX form {d_mx:.2e}; MX against int8 {rel_dev(emb_mx, emb_bp):.2e}")
+    np.testing.assert_allclose(sing_mx, sing_f, rtol=1e-8)
+    assert d_mx < 2e-6
     dev = {}
     for early in ("4", "3", "2"):
         emb_e, sing_e = other({"bp_digits_early": early})

@@ -249,7 +249,7 @@ def test_scaled_matrix(ctx):
 
 
 # ---- a9: randomized PCA (dd.py:305-314 -> sklearn) ----------------------------------------------------
-@pytest.mark.parametrize("gather", ["f32", "f64", "bitplane", "bitplane3"])
+@pytest.mark.parametrize("gather", ["f32", "f64", "bitplane", "bitplane3", "bitplane_mx"])
 @pytest.mark.parametrize("case", ["case_a_hvg_pheno", "case_b_transposed_louvain", "case_c_reftest_scaled",
                                   "case_d_replace_single"])
 def test_pca_scores(case, gather, monkeypatch):
@@ -257,12 +257,15 @@ def test_pca_scores(case, gather, monkeypatch):
     # products and sums); option pca_gather=f64 gathers the float64 iterate itself.  A context takes the process-wide options
     # when it is created: make one for this setting.
     # "bitplane" / "bitplane3": the entries equal to 1 through the int8 matrix cores with four / three digits (k_bitplane.hip;
-    # the automatic rule only takes that route from 4096 cells on: forced here; the scaled case keeps the sparse products)
+    # the automatic rule only takes that route from 4096 cells on: forced here); "bitplane_mx": the same products on the MX matrix
+    # instruction (FP4 bitmap x six base-31 digits in FP6, option bp_format=mx6)
     from doubletdetection_amd import _lib
 
     if gather.startswith("bitplane"):
         monkeypatch.setitem(_lib.OPTIONS, "bitplane", "2")
         monkeypatch.setitem(_lib.OPTIONS, "bp_digits", "3" if gather.endswith("3") else "4")
+        if gather.endswith("_mx"):
+            monkeypatch.setitem(_lib.OPTIONS, "bp_format", "mx6")
     else:
         monkeypatch.setitem(_lib.OPTIONS, "pca_gather", gather)
     with _lib.Context(0) as ctx:
