@@ -169,7 +169,17 @@ int main() {
         const double macs = 256.0 * 8 * iters * macs_per_iter_wave;
         printf("%-58s %8.2f ms  %7.0f T MAC/s  (%.0f TOP/s)\n", name, ms, macs / (ms * 1e-3) / 1e12, 2 * macs / (ms * 1e-3) / 1e12);
     };
+    // does the digits' bit pattern matter to a power-bound kernel?  balanced digits (random sign: the upper bits toggle) against
+    // non-negative 7-bit digits and against 4-bit ones
+    std::vector<uint32_t> Br7(Br8.size()), Br4(Br8.size());
+    for (auto& w : Br7) w = ((uint32_t)rand() ^ ((uint32_t)rand() << 16)) & 0x7f7f7f7fu;
+    for (auto& w : Br4) w = ((uint32_t)rand() ^ ((uint32_t)rand() << 16)) & 0x0f0f0f0fu;
+    v4i *dB7, *dB4;
+    hipMalloc(&dB7, Br7.size() * 4); hipMalloc(&dB4, Br4.size() * 4);
+    hipMemcpy(dB7, Br7.data(), Br7.size() * 4, hipMemcpyHostToDevice); hipMemcpy(dB4, Br4.data(), Br4.size() * 4, hipMemcpyHostToDevice);
     for (int rep = 0; rep < 2; ++rep) {
+        timeit([&](int it) { k_rate_i8<5><<<256, 512>>>(dA8, dB7, it, o8); }, 2.0 * 5 * 2 * 32768.0, "int8 32x32x32, 2 x 5 tiles, non-negative 7-bit digits");
+        timeit([&](int it) { k_rate_i8<5><<<256, 512>>>(dA8, dB4, it, o8); }, 2.0 * 5 * 2 * 32768.0, "int8 32x32x32, 2 x 5 tiles, non-negative 4-bit digits");
         timeit([&](int it) { k_rate_i8<5><<<256, 512>>>(dA8, dB8, it, o8); }, 2.0 * 5 * 2 * 32768.0, "int8 32x32x32, 2 x 5 tiles, random digits (4 digits)");
         timeit([&](int it) { k_rate_i8<4><<<256, 512>>>(dA8, dB8, it, o8); }, 2.0 * 4 * 2 * 32768.0, "int8 32x32x32, 2 x 4 tiles, random digits (3 digits)");
         timeit([&](int it) { k_rate_f6<2, 4><<<256, 512>>>(dA6, dB6, it, o6); }, 2.0 * 4 * 2 * 65536.0, "FP4 x FP6 32x32x64, 2 x 4 tiles, random digits");
