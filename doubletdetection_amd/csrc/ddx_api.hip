@@ -204,8 +204,10 @@ bool Options::set(const char* key, const char* value) {
     if (k == "synthetic") { if (v == "derived") synthetic_derived = true; else if (v == "merged") synthetic_derived = false; else return false; return true; }
     if (k == "bp_digits") { if (!num(3, 4, &x)) return false; bp_digits = (int)x; return true; }
     if (k == "bp_format") { if (v == "mx6") bp_mx = true; else if (v == "int8") bp_mx = false; else return false; return true; }
+#ifdef DDX_ABLATION
     if (k == "bp_dbg_mode") { if (!num(0, 15, &x)) return false; bp_dbg_mode = (int)x; return true; }
     if (k == "bp_dbg_sk") { if (!num(0, 1 << 20, &x)) return false; bp_dbg_sk = (int)x; return true; }
+#endif
     if (k == "bp_digits_early") { if (!num(0, 4, &x) || x == 1) return false; bp_digits_early = (int)x; return true; }
     if (k == "knn_fold") { knn_fold = on(); return true; }
     if (k == "knn_xcd_chunk") { if (!num(0, 4096, &x)) return false; knn_xcd_chunk = (int)x; return true; }

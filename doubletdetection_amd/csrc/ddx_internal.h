@@ -49,8 +49,8 @@ struct Options {
     int bitplane = 1;                // entries equal to 1 as bitmaps on the int8 matrix cores (k_bitplane.hip): 0 off, 1 when the matrix is large enough, 2 always
     int bp_digits = 4;               // 8-bit digits of the operand's fixed point in those products (4: 30 bits below the column maximum, 3: 22)
     bool bp_mx = false;              // those products on the MX matrix instruction (FP4 bitmap x six base-31 digits in FP6, exact: k_bp_product6) instead of int8 digits
-    int bp_dbg_mode = 0;             // TIMING ONLY (wrong results): bits 1 / 2 / 4 take the digit copies / bitmap copies / matrix instructions out of the MX product kernel's loop
-    int bp_dbg_sk = 0;               // TIMING ONLY (wrong results): the matrix-core product kernels stop after this many stages per chunk
+    int bp_dbg_mode = 0;             // only honoured under DDX_ABLATION -- TIMING ONLY (wrong results): bits 1 / 2 / 4 take the digit copies / bitmap copies / matrix instructions out of the MX product kernel's loop
+    int bp_dbg_sk = 0;               // only honoured under DDX_ABLATION -- TIMING ONLY (wrong results): the matrix-core product kernels stop after this many stages per chunk
     int bp_digits_early = 0;         // ... in the power iterations before the last one of the randomized PCA (0 = as bp_digits, the default; 3: 22 bits -- 4 % faster fits, but the whole-fit comparison with the float64 oracle loses labels; 2: experiments)
     int mirror_mode = 2;             // column-major mirror: 2 counting sort placed by LDS tiles, 1 (DDX_MIRROR=scatter) counting sort with scattered stores, 0 (DDX_MIRROR=sort) radix sort
     bool upload_packed = true;       // DDX_UPLOAD=plain: send the raw matrix as it is (8 bytes per entry) instead of packed

@@ -1164,15 +1164,18 @@ static int bp_launch6(ddx_ctx* ctx, const BpProductArgs& a0, int chunks) {
         k_bp_product6<ROWS, DBG><<<grid, 64 * kBpWaves, lds, ctx->stream>>>(a);
         return DDX_OK;
     };
-    switch (a.dbg) {                                              // (timing experiments: profiles/tools/mx_ablation.py)
+#ifdef DDX_ABLATION
+    switch (a.dbg) {                                              // (timing experiments, wrong results: profiles/tools/mx_ablation.py)
         case 1: return go(std::integral_constant<int, 1>());
         case 2: return go(std::integral_constant<int, 2>());
         case 3: return go(std::integral_constant<int, 3>());
         case 4: return go(std::integral_constant<int, 4>());
         case 7: return go(std::integral_constant<int, 7>());
         case 8: return go(std::integral_constant<int, 8>());
-        default: return go(std::integral_constant<int, 0>());
+        default: break;
     }
+#endif
+    return go(std::integral_constant<int, 0>());
 }
 
 // the products of sketches up to 40 columns wide run on the MX instruction unless option bp_format says int8

@@ -82,8 +82,8 @@ int ddx_synchronize(ddx_ctx* ctx);
  *                                       of exact multiples of 1/16 -- equally exact (4.2e-7), 2.6 x the int8 MAC rate in isolation
  *                                       (profiles/tools/mfma_fp6_probe.hip), but as a kernel no faster than int8 (bit expansion + operand
  *                                       traffic, profiles/r06_mx_notes.txt): kept as a tested alternative
- *   bp_dbg_sk, bp_dbg_mode              TIMING ONLY, wrong results: stages per chunk / parts of the MX kernel's loop taken out
- *                                       (profiles/tools/mx_stage_sweep.py, mx_ablation.py)
+ *   bp_dbg_sk, bp_dbg_mode              exist only in -DDDX_ABLATION builds (timing experiments with wrong results: stages per chunk / parts of
+ *                                       the MX kernel's loop taken out; profiles/tools/mx_stage_sweep.py, mx_ablation.py)
  *   mirror            tiles | scatter | sort   how the column-major mirror is built (default tiles; the others are its references)
  *   upload            auto | plain | packed | packed32   transfer form of ddx_upload_raw (auto: 2-byte form once the pinned
  *                                       buffer exists, plain until then; packed / packed32 wait for the buffer)

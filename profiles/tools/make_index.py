@@ -24,6 +24,17 @@ SPECIAL = {
     "pmc_sq.sh": "tool: SQ counter passes",
     "timeline.sh": "tool: busy timeline",
     "HISTORY.md": "analyses behind decisions of rounds 1-5 that DESIGN.md no longer carries (rejected product kernels, kNN history, priced-and-not-built items)",
+    "r06_mx_notes.txt": "round 6: the bit-plane products on the MX matrix instruction (FP4 x FP6): probe, three kernel generations, stage sweep, ablations; the digit schedule bp_digits_early and why it stays off",
+    "r06e_fp6_probe.txt": "round 6: layout check and MAC rates of v_mfma_f32_32x32x64_f8f6f4 against int8 under random digits (profiles/tools/mfma_fp6_probe.hip)",
+    "r06i_probe_digit_patterns.txt": "round 6: the same probe with non-negative 7-bit / 4-bit digits (power-bound int8 kernel: +5 - 12 %)",
+    "r06e_digits_ab.txt": "round 6: fits with bp_digits_early = 0 (A) / 3 (B) / 2 (C), same box, alternating",
+    "r06e_digits_test.txt": "round 6: PCA scores against the float64 run with 4 / 3 / 2 digits in the early power iterations (configs[1])",
+    "r06f_mx_stage_sweep.txt": "round 6: matrix-core product kernels' launch time against the stages per chunk, int8 and MX form (fixed cost per launch vs per stage)",
+    "r06f_mx_ablation.txt": "round 6: compile-time ablations of the MX product kernel v2 (copies / bitmap copies / matrix instructions taken out)",
+    "r06g_mx_ablation.txt": "round 6: the same for v3 (expansion interleaved with the matrix instructions)",
+    "r06g_mx_ab.txt": "round 6: fits with bp_format=int8 (A) / mx6 (B), same box, alternating",
+    "r06_share_times.txt": "round 6: the busiest rank's share of 10 iterations at 2 / 4 / 8 GPUs run on one GPU (DESIGN section 6's projection)",
+    "r06h_gpu_tests_summary.txt": "round 6: last lines of the full `pytest -m gpu` run at HEAD (143 passed)",
     "r05_bitplane_notes.txt": "round 5: bit-plane product kernel (matrix pipe busy 82 %, power-bound), packed residue ablations (section 7 of the file)",
     "r05_block_lanczos.txt": "round 5: pseudocount = 1 block Lanczos schedule, 70 ms per PCA at configs[1]",
     "r04_bitplane_notes.txt": "round 4: first bit-plane version, not faster",

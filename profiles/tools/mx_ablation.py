@@ -1,6 +1,7 @@
 """Round 6: what bounds a stage of the MX product kernel -- option bp_dbg_mode takes parts out of its loop (timing only, wrong results):
 1 no digit copies (global -> LDS), 2 no bitmap copies, 4 no matrix instructions; 8 with mode 0 waits like the ablations (vmcnt(0)).
-python profiles/tools/mx_ablation.py"""
+Needs a library built with -DDDX_ABLATION
+(bash profiles/tools/build_variant.sh ablation -DDDX_ABLATION; DDX_LIB=... python profiles/tools/mx_ablation.py)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import warnings
@@ -10,7 +11,7 @@ from doubletdetection_amd import _lib
 from doubletdetection_amd._synthetic import make_counts
 X = make_counts(100_000, 30_000, density=0.03, device="cuda:0", seed=20250227)
 top = None
-for mode in (0, 1, 3):
+for mode in (0, 8, 1, 2, 3, 4, 7):
     _lib.OPTIONS["bp_format"] = "mx6"
     _lib.OPTIONS["bp_dbg_mode"] = str(mode)
     c = _lib.Context(0)

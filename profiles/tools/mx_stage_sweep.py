@@ -1,5 +1,6 @@
 """Round 6: launch time of the matrix-core product kernels against the number of stages a chunk runs (option bp_dbg_sk: timing only, wrong
-results), for the int8 and the MX (FP4 x FP6) form: separates a launch's fixed cost from its per-stage cost.   python profiles/tools/mx_stage_sweep.py"""
+results), for the int8 and the MX (FP4 x FP6) form: separates a launch's fixed cost from its per-stage cost.   Needs a library built with -DDDX_ABLATION
+(bash profiles/tools/build_variant.sh ablation -DDDX_ABLATION; DDX_LIB=... python profiles/tools/mx_stage_sweep.py)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import warnings
