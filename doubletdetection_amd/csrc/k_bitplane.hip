@@ -471,18 +471,27 @@ __global__ void __launch_bounds__(64 * kBpWaves) k_bp_product(const BpProductArg
         for (int p = 0; p < PF; ++p) bq[p] = cur[p * 64];
         v4i av[RT], an[RT];
 #pragma unroll
-        for (int t = 0; t < RT; ++t) av[t] = bp_expand16((unsigned)w0[t][0] & 0xffffu);
+        for (int t = 0; t < RT; ++t) { av[t] = bp_expand16((unsigned)w0[t][0] & 0xffffu); an[t] = v4i{0, 0, 0, 0}; }
+        // the next k-step's bit expansion (4 RT words of four bytes) is spread over this k-step's NT groups of matrix instructions, order
+        // pinned, instead of one burst in front of the step's first group.  Worth 1 % here (0.159 -> 0.158 ms, profiles/r06j_expand_ab_kernels.txt):
+        // this kernel is power-bound, not issue-bound -- the same change was worth 7 % in the MX kernel, whose two waves per SIMD added
+        // their vector and matrix time (profiles/r06_mx_notes.txt)
+        constexpr int kWordsPerGroup = (4 * RT + NT - 1) / NT;
 #pragma unroll
         for (int gi = 0; gi < NG; ++gi) {
             const int s = gi / NT, c = gi % NT;
             if (gi + PF < NG) bq[(gi + PF) % (PF + 1)] = cur[(gi + PF) * 64];
-            if (c == 0 && s + 1 < kBpSteps) {
-#pragma unroll
-                for (int t = 0; t < RT; ++t) an[t] = bp_expand16(((unsigned)w0[t][(s + 1) >> 1] >> (16 * ((s + 1) & 1))) & 0xffffu);
-            }
             const v4i b = bq[gi % (PF + 1)];
 #pragma unroll
             for (int t = 0; t < RT; ++t) acc[t][c] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[t], b, acc[t][c], 0, 0, 0);
+            if (s + 1 < kBpSteps) {
+#pragma unroll
+                for (int wi = c * kWordsPerGroup; wi < (c + 1) * kWordsPerGroup && wi < 4 * RT; ++wi) {
+                    const int t = wi >> 2, w = wi & 3;
+                    const unsigned bits16 = ((unsigned)w0[t][(s + 1) >> 1] >> (16 * ((s + 1) & 1))) & 0xffffu;
+                    an[t][w] = (int)((((bits16 >> (4 * w)) & 0xfu) * 0x00204081u) & 0x01010101u);
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
             if (c == NT - 1) {
 #pragma unroll
