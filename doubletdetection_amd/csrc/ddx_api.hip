@@ -216,6 +216,7 @@ bool Options::set(const char* key, const char* value) {
     if (k == "knn_cells") { if (!num(0, 1024, &x)) return false; knn_cells = (int)x; return true; }
     if (k == "knn_seg_steps") { if (!num(0, 1 << 20, &x)) return false; knn_seg_steps = (int)x; return true; }
     if (k == "knn_emit_waves") { if (!num(0, 8, &x) || (x != 0 && x != 4 && x != 8)) return false; knn_emit_waves = (int)x; return true; }
+    if (k == "knn_emit_rt") { if (!num(2, 4, &x) || x == 3) return false; knn_emit_rt = (int)x; return true; }
     if (k == "knn_debug") { knn_debug = on(); return true; }
     if (k == "fault") { if (!num(0, 1, &x)) return false; fault = (int)x; return true; }
     if (k == "pca_debug") { pca_debug = on(); return true; }

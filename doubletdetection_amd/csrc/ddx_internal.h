@@ -43,6 +43,7 @@ struct Options {
     int knn_sample_every = 32;       // the bound pass's sample holds every n-th tile of the whole set (0: none)
     int knn_seg_steps = 0;           // steps of a block's tile list per emit work item (0 = default)
     int knn_emit_waves = 0;          // waves per emit block: 4 or 8 (0 = default)
+    int knn_emit_rt = 2;             // query tiles per emit wave: 2 (32 queries), 4 (64 queries, two waves per block; 32-component embeddings)
     bool row_sums_sequential = false;
     bool knn_debug = false;
     bool pca_debug = false;          // progress of the block Lanczos solver on stderr

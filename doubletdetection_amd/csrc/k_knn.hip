@@ -362,13 +362,18 @@ __global__ void __launch_bounds__(64 * kBoundWaves) k_knn_bound_bf(const __bf16*
 // the step size, padded with mask-0 entries); candidates are appended to cbuf[q][*], ccount[q] counts them (beyond `cap`:
 // overflow).  The waves of a block share the staged tiles: the pass is bound by that staging traffic (L2 / Infinity Cache ->
 // LDS), not by the matrix pipe, so a block is as many waves as a workgroup holds (16: 512 queries per staged tile).
-template <int CP, bool FOLD, int kEmitBW>
-__global__ void __launch_bounds__(64 * kEmitBW) __attribute__((amdgpu_waves_per_eu(CP <= 64 ? 4 : 2, CP <= 64 ? 4 : 2)))
+// RTQ: query tiles per wave.  2 (default): a wave screens 32 queries, the block's waves map one to one onto the waves the lists' masks were
+// built for.  4 (option knn_emit_rt, CP = 32): a wave screens 64 queries = two of the lists' waves -- every candidate tile read from LDS and
+// every ballot / branch / log slot serves twice the queries, at half the waves per block.
+template <int CP, bool FOLD, int kEmitBW, int RTQ = kEmitRT>
+__global__ void __launch_bounds__(64 * kEmitBW) __attribute__((amdgpu_waves_per_eu((CP <= 64 && RTQ == kEmitRT) ? 4 : 2, (CP <= 64 && RTQ == kEmitRT) ? 4 : 2)))
 k_knn_emit_bf(const __bf16* __restrict__ Eb, const __bf16* __restrict__ Ebq, const float* __restrict__ nrm, const f4* __restrict__ start4,
               const float* __restrict__ thr, int64_t Mp, int include_self, int32_t* __restrict__ ccount, int32_t* __restrict__ cbuf,
               const int32_t* __restrict__ elist, const int32_t* __restrict__ ecount, int64_t ecap, int dbg,
               int cap, int nseg, int seg_steps, long long* __restrict__ tdbg) {
-    constexpr int RT = kEmitRT, NV = 4 * RT;
+    constexpr int RT = RTQ, NV = 4 * RT;
+    constexpr int WM = RTQ / kEmitRT;                    // waves of the lists' geometry per wave of this kernel
+    static_assert(RTQ % kEmitRT == 0 && NV <= 16, "");
     constexpr int G = chunk_tiles(CP);
     constexpr int tile_vecs = CP * 4;
     __shared__ f4 lds_c[2][G * tile_vecs];
@@ -444,7 +449,7 @@ k_knn_emit_bf(const __bf16* __restrict__ Eb, const __bf16* __restrict__ Ebq, con
         if (step + 1 < nsteps) stage_tiles<CP, kEmitBW, 4>(srcE, srcH, lds_c[buf ^ 1], reinterpret_cast<float*>(lds_h[buf ^ 1]), p1 & 0xffffff, tid, wave, lane);
         if (step + 2 < nsteps) p2 = lst[(step + 2) * G + (lane & (G - 1))];
         // this wave's tiles of the step (wave-uniform mask)
-        unsigned tmask = (unsigned)__ballot(lane < G && ((((unsigned)p0 >> 24) >> wave) & 1u)) & ((1u << G) - 1u);
+        unsigned tmask = (unsigned)__ballot(lane < G && ((((unsigned)p0 >> 24) >> (wave * WM)) & ((1u << WM) - 1u))) & ((1u << G) - 1u);
         const f4* tb = lds_c[buf];
         const f4* th = lds_h[buf];
         static_assert(CP % 32 == 0, "");
@@ -1766,12 +1771,18 @@ int stage_knn(ddx_ctx* ctx, int32_t k, int32_t include_self) {
         if (BW == 8) DDX_EMIT_ONE(CPV, FOLDV, QUERY, 8);        \
         else DDX_EMIT_ONE(CPV, FOLDV, QUERY, 4);                \
     } while (0)
+        // option knn_emit_rt=4: 64 queries per wave, two waves per block, on the lists built for four waves of 32
+#define DDX_EMIT_WIDE(FOLDV, QUERY) k_knn_emit_bf<32, FOLDV, 2, 2 * kEmitRT><<<grid_x, 128, 0, ctx->stream>>>(Eb, QUERY, nrm, start4, thr, Mp, include_self, ccount, cbuf, elist, ecount, ecap, dbg_mode, cap, nseg, seg_steps, tdbg)
+        const bool wide_waves = ctx->opt.knn_emit_rt == 4 && BW == 4 && CP == 32;
         if (fold) {
             k_knn_fold<<<(unsigned)ceil_div(Mp * 8, 256), 256, 0, ctx->stream>>>(nrm, thr, Mp, Eb, Ebq);
-            DDX_EMIT_BF(32, true, Ebq);
-        } else if (CP == 32) DDX_EMIT_BF(32, false, Eb);
+            if (wide_waves) DDX_EMIT_WIDE(true, Ebq);
+            else DDX_EMIT_BF(32, true, Ebq);
+        } else if (CP == 32 && wide_waves) DDX_EMIT_WIDE(false, Eb);
+        else if (CP == 32) DDX_EMIT_BF(32, false, Eb);
         else if (CP == 64) DDX_EMIT_BF(64, false, Eb);
         else DDX_EMIT_BF(128, false, Eb);
+#undef DDX_EMIT_WIDE
 #undef DDX_EMIT_BF
 #undef DDX_EMIT_ONE
         if (tdbg) {

@@ -102,6 +102,10 @@ int ddx_synchronize(ddx_ctx* ctx);
  *   knn_sample_every  n                 the sample holds every n-th tile of the whole set (0 = none; default 32)
  *   knn_seg_steps     n                 steps of a block's tile list per emit work item (0 = default)
  *   knn_emit_waves    4 | 8             waves per emit workgroup (0 = default)
+ *   knn_emit_rt       2 | 4             query tiles per emit wave: 2 (default, 32 queries) or 4 (64 queries, two waves per workgroup on the same
+ *                                       lists; 32-component embeddings).  Exact either way (tests/test_gpu_knn_*.py pass with 4); measured
+ *                                       0.98 -> 1.05 ms at the headline, 3.81 -> 3.83 ms at 625 k points (profiles/r06l_knn_emit_rt.txt): no gain,
+ *                                       kept as the record of the experiment
  *   knn_fold          1 | 0             threshold folded into the screen's operands
  *   fault             0 | 1             fault injection for the error-path tests: 1 = every request for a larger dynamic-LDS limit is refused
  *   knn_xcd_chunk     n                 consecutive query blocks of the bound pass per XCD (0 = launch order)
