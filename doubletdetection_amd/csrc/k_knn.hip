@@ -2023,6 +2023,17 @@ __global__ void __launch_bounds__(256) k_edge_weights_wave(const int32_t* __rest
         }
         return mutual ? w : -w;
     };
+    // HALF: the weight is a function of the shared count (<= K <= 32) and the mutual flag only: lane l evaluates both for l shared
+    // neighbours once, a relation then reads its value from lane `shared` (the two float64 divisions per relation were a third of the
+    // kernel's instructions; the values are the same expression's, bit for bit)
+    const double tabM = HALF ? weight(lane, true) : 0.0, tabN = HALF ? weight(lane, false) : 0.0;
+    auto table = [&](int shared, bool mutual) -> double {           // (both arguments wave-uniform)
+        const double t = mutual ? tabM : tabN;
+        const long long bits = __builtin_bit_cast(long long, t);
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)bits, shared);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(bits >> 32), shared);
+        return __builtin_bit_cast(double, (long long)(((unsigned long long)hi << 32) | lo));
+    };
     for (int t0 = 0; t0 < K; t0 += 4 * PER) {
         int32_t j[4], y[4];
 #pragma unroll
@@ -2050,8 +2061,8 @@ __global__ void __launch_bounds__(256) k_edge_weights_wave(const int32_t* __rest
             const unsigned long long mm = __ballot(valid && y[u] == (int32_t)i);
             if (HALF) {
                 // (the relation's validity is known to its own lane: an invalid relation keeps weight 0)
-                const double w0 = weight(__popc((unsigned)fm), (unsigned)mm != 0u);
-                const double w1 = weight(__popc((unsigned)(fm >> 32)), (unsigned)(mm >> 32) != 0u);
+                const double w0 = table(__popc((unsigned)fm), (unsigned)mm != 0u);
+                const double w1 = table(__popc((unsigned)(fm >> 32)), (unsigned)(mm >> 32) != 0u);
                 const bool mine_ok = myj >= 0 && myj != (int32_t)i;
                 if (lane == t0 + 2 * u) myw = mine_ok ? w0 : 0.0;
                 if (lane == t0 + 2 * u + 1) myw = mine_ok ? w1 : 0.0;
