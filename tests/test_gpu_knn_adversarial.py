@@ -86,10 +86,13 @@ def _embeddings():
     return out
 
 
-@pytest.mark.parametrize("name", ["duplicates", "noise", "line", "outliers", "wide_many"])
-def test_every_query_on_a_hostile_embedding(name):
+@pytest.mark.parametrize("name", ["duplicates", "noise", "line", "outliers", "wide_many", "duplicates-wide_waves", "outliers-wide_waves"])
+def test_every_query_on_a_hostile_embedding(name, monkeypatch):
     from doubletdetection_amd import _lib
 
+    if name.endswith("-wide_waves"):             # the emit pass with 64 queries per wave (option knn_emit_rt=4: built, no faster, kept exact)
+        monkeypatch.setitem(_lib.OPTIONS, "knn_emit_rt", "4")
+        name = name.split("-")[0]
     emb, k, include_self = _embeddings()[name]
     ctx = _lib.Context(0)
     try:
