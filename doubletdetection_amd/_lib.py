@@ -83,6 +83,7 @@ _SIGNATURES = {
     "ddx_get_knn_overflow_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "ddx_get_knn_candidate_counts": (C.c_int, [C.c_void_p, c_i32_p]),
     "ddx_get_bitplane_stats": (C.c_int, [C.c_void_p, c_i64_p]),
+    "ddx_arena_peak": (C.c_int, [C.c_void_p, c_i64_p]),
     "ddx_get_upload_form": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "ddx_build_graph": (C.c_int, [C.c_void_p, C.c_int32]),
     "ddx_graph_relations": (C.c_int, [C.c_void_p, C.c_int32, c_i32_p, c_f64_p]),
@@ -497,6 +498,12 @@ class Context:
         f, t = C.c_int64(0), C.c_int64(0)
         self._c(self._lib.ddx_device_memory(self._h, C.byref(f), C.byref(t)))
         return f.value, t.value
+
+    def arena_peak(self) -> int:
+        """The most this context's buffers have occupied at any one time (bytes)."""
+        out = np.zeros(1, dtype=np.int64)
+        self._c(self._lib.ddx_arena_peak(self._h, _p(out, c_i64_p)))
+        return int(out[0])
 
     def follower_bytes(self) -> int:
         """Device memory a context that clones this one's counts starts with (stage_clone_counts, csrc/k_sparse.hip: its first chunk is

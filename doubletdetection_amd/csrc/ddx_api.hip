@@ -174,6 +174,11 @@ int ensure(ddx_ctx* ctx, DevBuf& b, size_t bytes) {
     b.blk = (int)A.blocks.size();
     A.blocks.push_back({ci, c.off, want, false});
     c.off += want;
+    {
+        size_t used = 0;
+        for (const auto& ch : A.chunks) used += ch.off;
+        if (used > A.peak) A.peak = used;
+    }
     if (ctx->opt.arena_guard)
         (void)hipMemsetAsync(static_cast<char*>(b.p) + b.cap, 0xA5, kArenaPad, ctx->stream);
     return DDX_OK;
@@ -471,6 +476,13 @@ int ddx_device_bytes(const ddx_ctx* ctx, int64_t* bytes) {
     REQUIRE_CTX(ctx);
     if (!bytes) return DDX_E_ARG;
     *bytes = ctx->dev_bytes;
+    return DDX_OK;
+}
+
+int ddx_arena_peak(const ddx_ctx* ctx, int64_t* bytes) {
+    REQUIRE_CTX(ctx);
+    if (!bytes) return DDX_E_ARG;
+    *bytes = (int64_t)ctx->arena.peak;
     return DDX_OK;
 }
 

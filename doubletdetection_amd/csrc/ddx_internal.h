@@ -88,6 +88,7 @@ struct Arena {
     std::vector<Chunk> chunks;
     std::vector<Block> blocks;
     size_t next_chunk = (size_t)256 << 20;     // size of the next chunk to request (ddx reserves a better guess at upload)
+    size_t peak = 0;                            // largest sum of the chunks' bump pointers since the context was created (ddx_arena_peak)
 };
 
 // Bit-plane operator products (k_bitplane.hip): bitmaps of the entries equal to 1 (all rows of the augmented matrix, by rows

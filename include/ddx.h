@@ -119,6 +119,9 @@ int ddx_set_option(ddx_ctx* ctx, const char* key, const char* value);
 int ddx_check_memory(ddx_ctx* ctx);
 /* bytes of device memory currently held by the context */
 int ddx_device_bytes(const ddx_ctx* ctx, int64_t* bytes);
+/* the most the context's buffers have occupied of that memory at any one time since it was created (the chunks are sized from an
+ * estimate made at upload: what a fit really needed decides how many contexts a GPU can hold for the iterations of dd.py:192-198) */
+int ddx_arena_peak(const ddx_ctx* ctx, int64_t* bytes);
 /* free and total memory of the context's GPU as the driver reports them (hipMemGetInfo): what decides how many contexts
  * can run the iterations of dd.py:192-198 side by side on one GPU */
 int ddx_device_memory(ddx_ctx* ctx, int64_t* free_bytes, int64_t* total_bytes);
