@@ -705,7 +705,11 @@ __global__ void __launch_bounds__(64 * kBpWaves) k_bp_product6(const BpProductAr
         if constexpr (DBG != 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(kPer) : "memory");
         if constexpr (!(DBG & 2)) bits(sk + 1, (it + 1) & 1);
-        if constexpr (!(DBG & 1)) stage(sk + 2, (it + 2) % kBpStages);
+        // (the stage's digit copies are issued one at a time between the matrix instructions below: as a block here they and their address
+        //  arithmetic ran while the matrix pipe idled -- 0.25 us of a stage's 1.65)
+        const int k_next = sk + 2 < sk1 ? sk + 2 : sk1 - 1;
+        const unsigned char* const src_next = qd + (int64_t)k_next * kF6StageBytes + wave * 1024 + lane * 16;
+        unsigned char* const dst_next = bp_smem + ((it + 2) % kBpStages) * kF6StageBytes + wave * 1024;
         v4i w0[RT];
 #pragma unroll
         for (int t = 0; t < RT; ++t) w0[t] = *reinterpret_cast<const v4i*>(bits_ring + (it & 1) * kF6BitsBytes + (grp * RT + t) * 1024 + word_off);
@@ -742,6 +746,15 @@ __global__ void __launch_bounds__(64 * kBpWaves) k_bp_product6(const BpProductAr
             for (int t = 0; t < RT; ++t) {
                 if constexpr (!(DBG & 4)) acc[t][c] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av[t], b, acc[t][c], 4, 2, 0, 0, 0, 0);
                 else acc[t][c][0] += (float)(av[t][0] ^ av[t][3] ^ b[0] ^ b[5]);
+                if constexpr (!(DBG & 1)) {
+                    constexpr int kEvery = (NG * RT) / kPer;                      // matrix instructions per copy
+                    const int m = gi * RT + t;
+                    if (m % kEvery == 1 && m / kEvery < kPer) {
+                        const int u = m / kEvery;                                  // piece u * kBpWaves + wave
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_next + u * kBpWaves * 1024),
+                                                         (__attribute__((address_space(3))) void*)(dst_next + u * kBpWaves * 1024), 16, 0, 0);
+                    }
+                }
                 if (s + 1 < kF6Steps) {
                     // half of tile (c * 2 + t / 2)'s next fragment: words 2 (t & 1) and 2 (t & 1) + 1
                     const int tile = c * (RT / NTW) + (t >> 1), j0 = 2 * (t & 1);

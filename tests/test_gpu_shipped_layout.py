@@ -99,6 +99,27 @@ def test_seven_context_fit_matches_the_float64_oracle(data_8k, fit_8k_seven):
         assert np.array_equal(clf.predict(), ref.predict(), equal_nan=True)
 
 
+def test_the_mx_form_of_the_products_gives_the_same_fit(data_8k, fit_8k_seven, monkeypatch):
+    """The products on the MX matrix instruction (option bp_format=mx6: FP4 bitmap x six base-31 digits in FP6, 28.7 bits) against the
+    default int8 form (30 bits) -- which the test above holds to the float64 oracle: the same seven-lane fit, compared attribute by
+    attribute.  (The three-digit schedule bp_digits_early=3 fails exactly this comparison: 0.65 % of the labels.)"""
+    from doubletdetection_amd import _lib
+
+    monkeypatch.setitem(_lib.OPTIONS, "bp_format", "mx6")
+    from doubletdetection_amd import classifier
+
+    classifier.release_device_memory()               # (parked contexts keep the options they were opened with)
+    try:
+        mx = _fit(data_8k, 7, n_iters=7, random_state=0, n_top_var_genes=6000)
+        assert mx._last_bitplane["format"] == "mx6"
+        agree = float(np.mean(mx.communities_ == fit_8k_seven.communities_))
+        print(f"8192 cells, 7 contexts: community labels of the MX form identical to the int8 form's for {agree:.4%} of (iteration, cell) pairs")
+        _same_fit(mx, fit_8k_seven)
+    finally:
+        monkeypatch.delitem(_lib.OPTIONS, "bp_format", raising=False)
+        classifier.release_device_memory()
+
+
 def test_c2_seven_contexts_equal_one_context():
     """(c) BASELINE configs[1]: the shipped layout against the single-context run of the same fit."""
     from doubletdetection_amd._synthetic import make_counts
