@@ -79,7 +79,7 @@ int ddx_synchronize(ddx_ctx* ctx);
  *                                       oracle's): measured and left off.  2: 8e-4, experiments only
  *   bp_format         int8 | mx6        int8 (default): 8-bit digits on v_mfma_i32_32x32x32_i8.  mx6: the same products on the MX instruction
  *                                       v_mfma_f32_32x32x64_f8f6f4 -- bitmap as FP4, six balanced base-31 digits as FP6 (28.7 bits), float32 sums
- *                                       of exact multiples of 1/16 -- equally exact (4.2e-7), 2.6 x the int8 MAC rate in isolation
+ *                                       of exact multiples of 1/16 -- equally exact (4.2e-7; whole fits identical to int8's at 8192 cells), 2.6 x the int8 MAC rate in isolation
  *                                       (profiles/tools/mfma_fp6_probe.hip), but as a kernel no faster than int8 (bit expansion + operand
  *                                       traffic, profiles/r06_mx_notes.txt): kept as a tested alternative
  *   bp_dbg_sk, bp_dbg_mode              exist only in -DDDX_ABLATION builds (timing experiments with wrong results: stages per chunk / parts of
