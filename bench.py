@@ -107,7 +107,7 @@ def parse():
     ap.add_argument("--cpu-full", action="store_true", help="cpu_baseline on ALL cells (two iterations of the oracle at the full size: "
                                                             "minutes and tens of GB of host memory; SURVEY.md section 8 d)")
     ap.add_argument("--instrumented-steps", type=int, default=2, help="extra fits with per-kernel HIP events (N=1) behind the kernel tables")
-    ap.add_argument("--resident-steps", type=int, default=2, help="extra fits on staged counts for value_resident (N=1)")
+    ap.add_argument("--resident-steps", type=int, default=5, help="extra fits on staged counts for value_resident (N=1)")
     ap.add_argument("--no-exclusive", action="store_true", help="skip the extra single-context fits behind roofline_exclusive")
     ap.add_argument("--option", action="append", default=[], metavar="KEY=VALUE", help="ddx_set_option switch for every context (include/ddx.h), repeatable")
     return ap.parse_args()
