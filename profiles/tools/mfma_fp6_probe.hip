@@ -146,7 +146,7 @@ int main() {
     // exactness of long sums: 2048 accumulating instructions of all-ones x 15 / 8 = 64 x 15 / 8 each -> 245 760 exactly
     // ---- rate
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    std::vector<uint32_t> Ar8(4 * 64 * 4), Br8(2 * 5 * 64 * 4), Ar6(4 * 64 * 8, 0u), Br6(2 * 8 * 64 * 8, 0u);
+    std::vector<uint32_t> Ar8(4 * 64 * 4), Br8(2 * 6 * 64 * 4), Ar6(4 * 64 * 8, 0u), Br6(2 * 8 * 64 * 8, 0u);
     for (auto& w : Ar8) { w = 0; for (int b = 0; b < 4; ++b) if (rand() % 100 < 9) w |= 1u << (8 * b); }
     for (auto& w : Br8) w = (uint32_t)rand() ^ ((uint32_t)rand() << 16);
     for (size_t l = 0; l < Ar6.size() / 8; ++l)
@@ -177,6 +177,14 @@ int main() {
     v4i *dB7, *dB4;
     hipMalloc(&dB7, Br7.size() * 4); hipMalloc(&dB4, Br4.size() * 4);
     hipMemcpy(dB7, Br7.data(), Br7.size() * 4, hipMemcpyHostToDevice); hipMemcpy(dB4, Br4.data(), Br4.size() * 4, hipMemcpyHostToDevice);
+    // the int8 rate against the number of column tiles per wave (accumulator registers: 32 per tile pair)
+    timeit([&](int it) { k_rate_i8<2><<<256, 512>>>(dA8, dB8, it, o8); }, 2.0 * 2 * 2 * 32768.0, "int8 32x32x32, 2 x 2 tiles, random digits");
+    timeit([&](int it) { k_rate_i8<3><<<256, 512>>>(dA8, dB8, it, o8); }, 2.0 * 3 * 2 * 32768.0, "int8 32x32x32, 2 x 3 tiles, random digits");
+    timeit([&](int it) { k_rate_i8<4><<<256, 512>>>(dA8, dB8, it, o8); }, 2.0 * 4 * 2 * 32768.0, "int8 32x32x32, 2 x 4 tiles, random digits");
+    timeit([&](int it) { k_rate_i8<5><<<256, 512>>>(dA8, dB8, it, o8); }, 2.0 * 5 * 2 * 32768.0, "int8 32x32x32, 2 x 5 tiles, random digits");
+    timeit([&](int it) { k_rate_i8<6><<<256, 512>>>(dA8, dB8, it, o8); }, 2.0 * 6 * 2 * 32768.0, "int8 32x32x32, 2 x 6 tiles, random digits");
+    timeit([&](int it) { k_rate_i8<5><<<256, 256>>>(dA8, dB8, it, o8); }, 1.0 * 5 * 2 * 32768.0, "int8 32x32x32, 2 x 5 tiles, ONE wave per SIMD");
+    timeit([&](int it) { k_rate_i8<4><<<256, 256>>>(dA8, dB8, it, o8); }, 1.0 * 4 * 2 * 32768.0, "int8 32x32x32, 2 x 4 tiles, ONE wave per SIMD");
     for (int rep = 0; rep < 2; ++rep) {
         timeit([&](int it) { k_rate_i8<5><<<256, 512>>>(dA8, dB7, it, o8); }, 2.0 * 5 * 2 * 32768.0, "int8 32x32x32, 2 x 5 tiles, non-negative 7-bit digits");
         timeit([&](int it) { k_rate_i8<5><<<256, 512>>>(dA8, dB4, it, o8); }, 2.0 * 5 * 2 * 32768.0, "int8 32x32x32, 2 x 5 tiles, non-negative 4-bit digits");
