@@ -158,12 +158,18 @@ __global__ void __launch_bounds__(256) k_lv_sweep(const int64_t* __restrict__ in
         if (!live[i]) continue;                      // (wave-uniform)
         const double kv = (double)kvi[i];
         acc_t W = 0;
-        for (int j = 0; j < deg[i]; ++j) {
-            const int32_t cj = __builtin_amdgcn_readlane(c[i], j);
-            acc_t wj;
-            if (W32) wj = (acc_t)__builtin_amdgcn_readlane((int)w[i], j);
-            else wj = (acc_t)(((int64_t)__builtin_amdgcn_readlane((int)((int64_t)w[i] >> 32), j) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(int64_t)w[i], j));
-            W += (cj == c[i]) ? wj : (acc_t)0;
+        // four neighbours per trip (the loop's own three scalar instructions were a third of a trip of one); lanes past the degree hold
+        // c = -1 and w = 0, so running up to three lanes over changes no sum that is read
+        for (int j0 = 0; j0 < deg[i]; j0 += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = (j0 + u) & 63;
+                const int32_t cj = __builtin_amdgcn_readlane(c[i], j);
+                acc_t wj;
+                if (W32) wj = (acc_t)__builtin_amdgcn_readlane((int)w[i], j);
+                else wj = (acc_t)(((int64_t)__builtin_amdgcn_readlane((int)((int64_t)w[i] >> 32), j) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(int64_t)w[i], j));
+                W += (cj == c[i]) ? wj : (acc_t)0;
+            }
         }
         double best_s = 0.0;
         int32_t best_c = -1;
