@@ -223,7 +223,8 @@ bool Options::set(const char* key, const char* value) {
     if (k == "knn_emit_waves") { if (!num(0, 8, &x) || (x != 0 && x != 4 && x != 8)) return false; knn_emit_waves = (int)x; return true; }
     if (k == "knn_emit_rt") { if (!num(2, 4, &x) || x == 3) return false; knn_emit_rt = (int)x; return true; }
     if (k == "knn_debug") { knn_debug = on(); return true; }
-    if (k == "fault") { if (!num(0, 1, &x)) return false; fault = (int)x; return true; }
+    if (k == "testing") { testing = on(); return true; }
+    if (k == "fault") { if (!testing || !num(0, 1, &x)) return false; fault = (int)x; return true; }      // (fault injection: only after testing=1)
     if (k == "pca_debug") { pca_debug = on(); return true; }
     if (k == "row_sums") { if (v == "auto") row_sums_sequential = false; else if (v == "sequential") row_sums_sequential = true; else return false; return true; }
     if (k == "mirror") { if (v == "tiles") mirror_mode = 2; else if (v == "scatter") mirror_mode = 1; else if (v == "sort") mirror_mode = 0; else return false; return true; }

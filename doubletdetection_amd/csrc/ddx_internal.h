@@ -64,6 +64,7 @@ struct Options {
     int residual_rows_own = 12;      // outputs per lane group of the packed A Q kernel (12: one round of workgroups, each operand slice staged once per CU -- 0.157 ms per launch at the headline; 6: 0.177)
     bool synthetic_derived = true;   // bit-plane route: a doublet's bitmap row and reduced entries from its parents' (k_bp_synth); false: from the merged row
     int fault = 0;                   // fault injection (tests): 1 = allow_dynamic_lds fails
+    bool testing = false;            // option testing=1 (the test suite): unlocks `fault`
     bool hvg_fold = true;            // gene sums folded in while the packed matrix arrives (off: one pass after the upload)
     int host_wait = 0;               // how a host thread waits for its stream (ddx::wait_stream): 0 the runtime's hipStreamSynchronize (spins), 1 "block": an event is polled
                                      // with sleeps in between (a waiting thread costs a few per cent of a CPU instead of a whole one)

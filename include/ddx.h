@@ -112,7 +112,9 @@ int ddx_synchronize(ddx_ctx* ctx);
  *   knn_debug         0 | 1             statistics of the kNN passes on stderr
  *   pca_debug         0 | 1             progress of ddx_pca_exact_sparse on stderr
  *   arena_guard       0 | 1             pattern-filled pad behind every device buffer (see ddx_check_memory)
- *   knn_ablation      n                 timing ablations with wrong results: builds with -DDDX_ABLATION only */
+ *   knn_ablation      n                 timing ablations with wrong results: builds with -DDDX_ABLATION only
+ *   testing, fault    0 | 1             fault = 1 makes every request for a larger dynamic-LDS limit fail (the error-path test of ddx_pca); it is
+ *                                       refused unless testing = 1 was set on the context first -- not for production use */
 int ddx_set_option(ddx_ctx* ctx, const char* key, const char* value);
 /* overflow detector (option arena_guard = 1, set before the first upload): every device buffer is followed by a
  * pattern-filled pad; returns DDX_E_NUMERIC and names the buffer if a kernel wrote past the end of one */

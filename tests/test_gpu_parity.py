@@ -872,6 +872,7 @@ def test_a_failing_stage_inside_the_pca_surfaces_as_an_error():
         c.create_doublets(np.random.default_rng(1).choice(2000, size=(500, 2), replace=False))
         c.lognormalise(0.1)
         q0 = orc.pca_start_matrix(0, 900, 40)
+        c.set_option("testing", "1")             # (fault injection is locked without it)
         c.set_option("fault", "1")
         with pytest.raises(_lib.DdxError) as err:
             c.pca(30, q0)
